@@ -1,0 +1,502 @@
+"""ctypes front-end of the CPU oracle (oracle/libwx_oracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Arrays use the Julia shapes of the reference (column-major); inputs are converted with
+np.asfortranarray, outputs are Fortran-ordered numpy arrays.  `T` is taken from the input dtype
+(float64 / float32); filters are always float64, exactly like the reference.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libwx_oracle.so")
+
+
+def build(force=False):
+    src_newer = (not os.path.exists(_SO)) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
+        for f in ("wx_oracle.c", "wx_oracle_impl.h"))
+    if force or src_newer:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libwx_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+_P, _I, _L, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+
+
+def _suf(dt):
+    return {np.dtype(np.float64): "_f64", np.dtype(np.float32): "_f32"}[np.dtype(dt)]
+
+
+def _f(a, dtype=None):
+    a = np.asarray(a)
+    if dtype is None:
+        dtype = a.dtype if a.dtype in (np.float32, np.float64) else np.float64
+    return np.asfortranarray(a, dtype=dtype)
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _q(qmf):
+    q = np.ascontiguousarray(np.asarray(qmf, dtype=np.float64))
+    return q, _p(q), int(q.size)
+
+
+def _tree(tree):
+    t = np.ascontiguousarray(np.asarray(tree).astype(np.uint8))
+    return t, _p(t), int(t.size)
+
+
+def _call(name, dt, *args, restype=_I):
+    fn = getattr(lib(), name + _suf(dt))
+    fn.restype = restype
+    conv = []
+    for a in args:
+        if isinstance(a, (int, np.integer)):
+            conv.append(_L(int(a)))
+        elif isinstance(a, float):
+            conv.append(_D(a))
+        else:
+            conv.append(a)
+    return fn(*conv)
+
+
+class OracleAssertion(AssertionError):
+    pass
+
+
+def _chk(rc):
+    if rc == -1:
+        raise OracleAssertion("reference @assert would fail")
+    if rc == -2:
+        raise ValueError("reference would throw ArgumentError")
+    if rc == -3:
+        raise IndexError("reference would throw BoundsError")
+    if rc != 0 and rc is not None:
+        raise RuntimeError("oracle status %r" % rc)
+
+
+# ---- filters --------------------------------------------------------------------------------
+def makereverseqmfpair(qmf):
+    q, qp, F = _q(qmf)
+    g, h = np.empty(F), np.empty(F)
+    lib().wxo_makereverseqmfpair(qp, _I(F), _p(g), _p(h))
+    return g, h
+
+
+def make_acreverseqmfpair(qmf):
+    q, qp, F = _q(qmf)
+    P, Q = np.empty(2 * F - 1), np.empty(2 * F - 1)
+    lib().wxo_make_acreverseqmfpair(qp, _I(F), _p(P), _p(Q))
+    return P, Q
+
+
+# ---- integer helpers ------------------------------------------------------------------------
+def maxtransformlevels(n):
+    return lib().wxo_maxtransformlevels(_L(n))
+
+
+def getdepth(i, kind):
+    return lib().wxo_getdepth_binary(_L(i)) if kind == "binary" else lib().wxo_getdepth_quad(_L(i))
+
+
+def gettreelength(*sz):
+    L = lib()
+    L.wxo_gettreelength1d.restype = _L
+    L.wxo_gettreelength2d.restype = _L
+    return L.wxo_gettreelength1d(_L(sz[0])) if len(sz) == 1 else L.wxo_gettreelength2d(_L(sz[0]), _L(sz[1]))
+
+
+def maketree1d(n, L, s="full"):
+    t = np.zeros(max(n - 1, 0), dtype=np.uint8)
+    _chk(lib().wxo_maketree1d(_p(t), _L(n), _I(L), _I(0 if s == "full" else 1)))
+    return t.astype(bool)
+
+
+def maketree2d(n, m, L, s="full"):
+    t = np.zeros(gettreelength(n, m), dtype=np.uint8)
+    _chk(lib().wxo_maketree2d(_p(t), _L(n), _L(m), _I(L), _I(0 if s == "full" else 1)))
+    return t.astype(bool)
+
+
+def isvalidtree1d(n, tree):
+    t, tp, nt = _tree(tree)
+    return bool(lib().wxo_isvalidtree1d(_L(n), tp, _L(nt)))
+
+
+def isvalidtree2d(n, m, tree):
+    t, tp, nt = _tree(tree)
+    return bool(lib().wxo_isvalidtree2d(_L(n), _L(m), tp, _L(nt)))
+
+
+def getleaf(tree, kind):
+    t, tp, nt = _tree(tree)
+    if kind == "binary":
+        res = np.zeros(2 * nt + 1, dtype=np.uint8)
+        _chk(lib().wxo_getleaf_binary(_p(res), tp, _L(nt)))
+    else:
+        res = np.zeros(4 * nt + 1, dtype=np.uint8)
+        _chk(lib().wxo_getleaf_quad(_p(res), tp, _L(nt)))
+    return res.astype(bool)
+
+
+def getrowrange(n, idx):
+    lo, hi = _L(), _L()
+    _chk(lib().wxo_getrowrange(_L(n), _L(idx), ctypes.byref(lo), ctypes.byref(hi)))
+    return lo.value, hi.value
+
+
+def getcolrange(n, idx):
+    lo, hi = _L(), _L()
+    _chk(lib().wxo_getcolrange(_L(n), _L(idx), ctypes.byref(lo), ctypes.byref(hi)))
+    return lo.value, hi.value
+
+
+def main2depthshift(sm, L):
+    sd = np.zeros(L + 1, dtype=np.int64)
+    _chk(lib().wxo_main2depthshift(_L(sm), _I(L), _p(sd)))
+    return sd.tolist()
+
+
+def coarsestscalingrange(n, tree, redundant=False):
+    t, tp, nt = _tree(tree)
+    fn = lib().wxo_coarsestscalingrange
+    fn.restype = _L
+    r = fn(_L(n), tp, _L(nt), _I(int(redundant)))
+    if r < 0:
+        raise OracleAssertion()
+    return r
+
+
+def finestdetailrange(n, tree, redundant=False):
+    t, tp, nt = _tree(tree)
+    fn = lib().wxo_finestdetailrange
+    fn.restype = _L
+    r = fn(_L(n), tp, _L(nt), _I(int(redundant)))
+    if r < 0:
+        raise OracleAssertion()
+    return r
+
+
+# ---- single steps ---------------------------------------------------------------------------
+def dwt_step(v, h, g):
+    v = _f(v); n = v.shape[0]
+    h = np.ascontiguousarray(h, dtype=np.float64); g = np.ascontiguousarray(g, dtype=np.float64)
+    if v.ndim == 1:
+        w1, w2 = np.empty(n // 2, v.dtype), np.empty(n // 2, v.dtype)
+        _call("wxo_dwt_step", v.dtype, _p(w1), _p(w2), _p(v), n, _p(h), _p(g), _I(h.size), restype=None)
+        return w1, w2
+    n2, m2 = v.shape[0] // 2, v.shape[1] // 2
+    ws = [np.empty((n2, m2), v.dtype, order="F") for _ in range(4)]
+    _call("wxo_dwt_step2", v.dtype, *[_p(w) for w in ws], _p(v), n2, m2, _p(h), _p(g), _I(h.size), restype=None)
+    return tuple(ws)
+
+
+def idwt_step(*args):
+    h = np.ascontiguousarray(args[-2], dtype=np.float64); g = np.ascontiguousarray(args[-1], dtype=np.float64)
+    ws = [_f(w) for w in args[:-2]]
+    if len(ws) == 2:
+        n = 2 * ws[0].shape[0]
+        v = np.empty(n, ws[0].dtype)
+        _call("wxo_idwt_step", v.dtype, _p(v), _p(ws[0]), _p(ws[1]), n, _p(h), _p(g), _I(h.size), restype=None)
+        return v
+    n2, m2 = ws[0].shape
+    v = np.empty((2 * n2, 2 * m2), ws[0].dtype, order="F")
+    _call("wxo_idwt_step2", v.dtype, _p(v), *[_p(w) for w in ws], n2, m2, _p(h), _p(g), _I(h.size), restype=None)
+    return v
+
+
+def sdwt_step(v, d, h, g):
+    v = _f(v)
+    h = np.ascontiguousarray(h, dtype=np.float64); g = np.ascontiguousarray(g, dtype=np.float64)
+    if v.ndim == 1:
+        n = v.shape[0]
+        w1, w2 = np.zeros(n, v.dtype), np.zeros(n, v.dtype)
+        _call("wxo_sdwt_step", v.dtype, _p(w1), _p(w2), _p(v), n, _I(d), _p(h), _p(g), _I(h.size), restype=None)
+        return w1, w2
+    n, m = v.shape
+    ws = [np.empty((n, m), v.dtype, order="F") for _ in range(4)]
+    _call("wxo_sdwt_step2", v.dtype, *[_p(w) for w in ws], _p(v), n, m, _I(d), _p(h), _p(g), _I(h.size), restype=None)
+    return tuple(ws)
+
+
+def isdwt_step(*args):
+    """isdwt_step(w1, w2, d, h, g) / (w1, w2, d, sv, sw, h, g) and the 4-child 2-D forms."""
+    # split by position: leading arrays are children, trailing two are filters
+    h = np.ascontiguousarray(args[-2], dtype=np.float64); g = np.ascontiguousarray(args[-1], dtype=np.float64)
+    nchild = 2 if np.asarray(args[0]).ndim == 1 else 4
+    ws = [_f(w) for w in args[:nchild]]
+    rest = args[nchild:-2]
+    d = int(rest[0])
+    shift = len(rest) == 3
+    sv, sw = (int(rest[1]), int(rest[2])) if shift else (0, 0)
+    if nchild == 2:
+        n = ws[0].shape[0]
+        v = np.zeros(n, ws[0].dtype)
+        if shift:
+            _chk(_call("wxo_isdwt_step_shift", v.dtype, _p(v), _p(ws[0]), _p(ws[1]), n, _I(d), sv, sw, _p(h), _p(g), _I(h.size)))
+        else:
+            _call("wxo_isdwt_step_avg", v.dtype, _p(v), _p(ws[0]), _p(ws[1]), n, _I(d), _p(h), _p(g), _I(h.size), restype=None)
+        return v
+    n, m = ws[0].shape
+    v = np.zeros((n, m), ws[0].dtype, order="F")
+    _chk(_call("wxo_isdwt_step2", v.dtype, _p(v), *[_p(w) for w in ws], n, m, _I(d), _I(int(shift)), sv, sw,
+               _p(h), _p(g), _I(h.size)))
+    return v
+
+
+def acdwt_step(v, d, h, g):
+    v = _f(v)
+    h = np.ascontiguousarray(h, dtype=np.float64); g = np.ascontiguousarray(g, dtype=np.float64)
+    if v.ndim == 1:
+        n = v.shape[0]
+        w1, w2 = np.zeros(n, v.dtype), np.zeros(n, v.dtype)
+        _call("wxo_acdwt_step", v.dtype, _p(w1), _p(w2), _p(v), n, _I(d), _p(h), _p(g), _I(h.size), restype=None)
+        return w1, w2
+    n, m = v.shape
+    ws = [np.empty((n, m), v.dtype, order="F") for _ in range(4)]
+    _call("wxo_acdwt_step2", v.dtype, *[_p(w) for w in ws], _p(v), n, m, _I(d), _p(h), _p(g), _I(h.size), restype=None)
+    return tuple(ws)
+
+
+def iacdwt_step(*ws):
+    ws = [_f(w) for w in ws]
+    if len(ws) == 2:
+        v = np.empty_like(ws[0])
+        _call("wxo_iacdwt_step", v.dtype, _p(v), _p(ws[0]), _p(ws[1]), ws[0].shape[0], restype=None)
+        return v
+    n, m = ws[0].shape
+    v = np.empty((n, m), ws[0].dtype, order="F")
+    _call("wxo_iacdwt_step2", v.dtype, _p(v), *[_p(w) for w in ws], n, m, restype=None)
+    return v
+
+
+# ---- decimated packets ----------------------------------------------------------------------
+def wpd(x, qmf, L=None):
+    x = _f(x); q, qp, F = _q(qmf)
+    if x.ndim == 1:
+        n = x.shape[0]
+        L = maxtransformlevels(n) if L is None else L
+        y = np.empty((n, L + 1), x.dtype, order="F")
+        _call("wxo_wpd1d", x.dtype, _p(y), _p(x), n, _I(L), qp, _I(F), restype=None)
+        return y
+    m, n = x.shape
+    L = maxtransformlevels(min(m, n)) if L is None else L
+    y = np.empty((m, n, L + 1), x.dtype, order="F")
+    _call("wxo_wpd2d", x.dtype, _p(y), _p(x), m, n, _I(L), qp, _I(F), restype=None)
+    return y
+
+
+def _tree_for(shape, L_or_tree):
+    if isinstance(L_or_tree, np.ndarray):
+        return L_or_tree
+    if len(shape) == 1:
+        L = maxtransformlevels(shape[0]) if L_or_tree is None else L_or_tree
+        return maketree1d(shape[0], L, "full")
+    L = maxtransformlevels(min(shape)) if L_or_tree is None else L_or_tree
+    return maketree2d(shape[0], shape[1], L, "full")
+
+
+def wpt(x, qmf, L_or_tree=None):
+    x = _f(x); q, qp, F = _q(qmf)
+    t, tp, nt = _tree(_tree_for(x.shape, L_or_tree))
+    y = np.empty(x.shape, x.dtype, order="F")
+    if x.ndim == 1:
+        _chk(_call("wxo_wpt1d_tree", x.dtype, _p(y), _p(x), x.shape[0], tp, nt, qp, _I(F)))
+    else:
+        _chk(_call("wxo_wpt2d_tree", x.dtype, _p(y), _p(x), x.shape[0], x.shape[1], tp, nt, qp, _I(F)))
+    return y
+
+
+def iwpt(xw, qmf, L_or_tree=None):
+    xw = _f(xw); q, qp, F = _q(qmf)
+    t, tp, nt = _tree(_tree_for(xw.shape, L_or_tree))
+    y = np.empty(xw.shape, xw.dtype, order="F")
+    if xw.ndim == 1:
+        _chk(_call("wxo_iwpt1d_tree", xw.dtype, _p(y), _p(xw), xw.shape[0], tp, nt, qp, _I(F)))
+    else:
+        _chk(_call("wxo_iwpt2d_tree", xw.dtype, _p(y), _p(xw), xw.shape[0], xw.shape[1], tp, nt, qp, _I(F)))
+    return y
+
+
+def iwpd(xw, qmf, L_or_tree=None):
+    xw = _f(xw); q, qp, F = _q(qmf)
+    sig = xw.shape[:-1]
+    k = xw.shape[-1]
+    t, tp, nt = _tree(_tree_for(sig, L_or_tree))
+    y = np.empty(sig, xw.dtype, order="F")
+    if len(sig) == 1:
+        _chk(_call("wxo_iwpd1d_tree", xw.dtype, _p(y), _p(xw), sig[0], _I(k), tp, nt, qp, _I(F)))
+    else:
+        _chk(_call("wxo_iwpd2d_tree", xw.dtype, _p(y), _p(xw), sig[0], sig[1], _I(k), tp, nt, qp, _I(F)))
+    return y
+
+
+def getbasiscoef(Xw, tree):
+    Xw = _f(Xw)
+    t, tp, nt = _tree(tree)
+    n, k = Xw.shape
+    out = np.empty(n, Xw.dtype)
+    _chk(_call("wxo_getbasiscoef1d", Xw.dtype, _p(out), _p(Xw), n, _I(k), tp, nt))
+    return out
+
+
+def _all(fn, x, sig_ndim, *args):
+    """`*all` drivers: loop over the last dimension (dwt_all.jl / swt_all.jl / acwt_all.jl)."""
+    x = _f(x)
+    outs = [fn(np.asfortranarray(x[..., i]), *args) for i in range(x.shape[-1])]
+    return np.asfortranarray(np.stack(outs, axis=-1))
+
+
+def wpdall(x, qmf, L=None):
+    return _all(wpd, x, None, qmf, L)
+
+
+def iwpdall(xw, qmf, L_or_tree=None):
+    return _all(iwpd, xw, None, qmf, L_or_tree)
+
+
+def wptall(x, qmf, L_or_tree=None):
+    return _all(wpt, x, None, qmf, L_or_tree)
+
+
+def iwptall(x, qmf, L_or_tree=None):
+    return _all(iwpt, x, None, qmf, L_or_tree)
+
+
+# ---- stationary -----------------------------------------------------------------------------
+def sdwt(x, qmf, L=None):
+    x = _f(x); q, qp, F = _q(qmf); n = x.shape[0]
+    L = maxtransformlevels(n) if L is None else L
+    xw = np.empty((n, L + 1), x.dtype, order="F")
+    _chk(_call("wxo_sdwt1d", x.dtype, _p(xw), _p(x), n, _I(L), qp, _I(F)))
+    return xw
+
+
+def isdwt(xw, qmf, sm=None):
+    xw = _f(xw); q, qp, F = _q(qmf); n, k = xw.shape
+    x = np.empty(n, xw.dtype)
+    _chk(_call("wxo_isdwt1d", xw.dtype, _p(x), _p(xw), n, _I(k - 1), -1 if sm is None else sm, qp, _I(F)))
+    return x
+
+
+def swpt(x, qmf, L=None):
+    x = _f(x); q, qp, F = _q(qmf); n = x.shape[0]
+    L = maxtransformlevels(n) if L is None else L
+    xw = np.empty((n, 1 << L), x.dtype, order="F")
+    _chk(_call("wxo_swpt1d", x.dtype, _p(xw), _p(x), n, _I(L), qp, _I(F)))
+    return xw
+
+
+def iswpt(xw, qmf, sm=None):
+    xw = _f(xw); q, qp, F = _q(qmf); n, m = xw.shape
+    x = np.empty(n, xw.dtype)
+    _chk(_call("wxo_iswpt1d", xw.dtype, _p(x), _p(xw), n, m, -1 if sm is None else sm, qp, _I(F)))
+    return x
+
+
+def swpd(x, qmf, L=None):
+    x = _f(x); q, qp, F = _q(qmf); n = x.shape[0]
+    L = maxtransformlevels(n) if L is None else L
+    xw = np.empty((n, (1 << (L + 1)) - 1), x.dtype, order="F")
+    _chk(_call("wxo_swpd1d", x.dtype, _p(xw), _p(x), n, _I(L), qp, _I(F)))
+    return xw
+
+
+def iswpd(xw, qmf, L_or_tree=None, sm=None):
+    xw = _f(xw); q, qp, F = _q(qmf); n, m = xw.shape
+    t, tp, nt = _tree(_tree_for((n,), L_or_tree))
+    x = np.empty(n, xw.dtype)
+    _chk(_call("wxo_iswpd1d", xw.dtype, _p(x), _p(xw), n, m, tp, nt, -1 if sm is None else sm, qp, _I(F)))
+    return x
+
+
+# ---- autocorrelation ------------------------------------------------------------------------
+def acdwt(x, qmf, L=None):
+    x = _f(x); q, qp, F = _q(qmf); n = x.shape[0]
+    L = maxtransformlevels(n) if L is None else L
+    xw = np.empty((n, L + 1), x.dtype, order="F")
+    _chk(_call("wxo_acdwt1d", x.dtype, _p(xw), _p(x), n, _I(L), qp, _I(F)))
+    return xw
+
+
+def iacdwt(xw):
+    xw = _f(xw); n, k = xw.shape
+    x = np.empty(n, xw.dtype)
+    _call("wxo_iacdwt1d", xw.dtype, _p(x), _p(xw), n, _I(k - 1), restype=None)
+    return x
+
+
+def acwpt(x, qmf, L=None):
+    x = _f(x); q, qp, F = _q(qmf); n = x.shape[0]
+    L = maxtransformlevels(n) if L is None else L
+    xw = np.empty((n, 1 << L), x.dtype, order="F")
+    _chk(_call("wxo_acwpt1d", x.dtype, _p(xw), _p(x), n, _I(L), qp, _I(F)))
+    return xw
+
+
+def iacwpt(xw):
+    xw = _f(xw); n, m = xw.shape
+    x = np.empty(n, xw.dtype)
+    _chk(_call("wxo_iacwpt1d", xw.dtype, _p(x), _p(xw), n, m))
+    return x
+
+
+def acwpd(x, qmf, L=None):
+    x = _f(x); q, qp, F = _q(qmf); n = x.shape[0]
+    L = maxtransformlevels(n) if L is None else L
+    xw = np.empty((n, (1 << (L + 1)) - 1), x.dtype, order="F")
+    _chk(_call("wxo_acwpd1d", x.dtype, _p(xw), _p(x), n, _I(L), qp, _I(F)))
+    return xw
+
+
+def iacwpd(xw, L_or_tree=None):
+    xw = _f(xw); n, m = xw.shape
+    t, tp, nt = _tree(_tree_for((n,), L_or_tree))
+    x = np.empty(n, xw.dtype)
+    _chk(_call("wxo_iacwpd1d", xw.dtype, _p(x), _p(xw), n, m, tp, nt))
+    return x
+
+
+# ---- joint best basis -----------------------------------------------------------------------
+def tree_costs_jbb(X, redundant=False, cost="loglp", p=None):
+    """tree_costs(X::Array{T,3}, JBB(cost, redundant)); X is (n, L, N)."""
+    X = _f(X); n, L, N = X.shape
+    p = (2.0 if cost == "loglp" else 1.0) if p is None else float(p)
+    ncost = L if redundant else (1 << L) - 1
+    costs = np.empty(ncost, X.dtype)
+    _chk(_call("wxo_tree_costs_jbb", X.dtype, _p(costs), _p(X), n, L, N, _I(int(redundant)),
+               _I(0 if cost == "loglp" else 1), _D(p)))
+    return costs
+
+
+def bestbasis_treeselection(costs, n, kind="min"):
+    costs = np.array(costs, copy=True)
+    if costs.dtype not in (np.float32, np.float64):
+        costs = costs.astype(np.float64)
+    tree = np.zeros(n - 1, dtype=np.uint8)
+    _chk(_call("wxo_bestbasis_treeselection", costs.dtype, _p(tree), _p(costs), costs.size, n,
+               _I(0 if kind == "min" else 1)))
+    return tree.astype(bool)
+
+
+def bestbasistree_jbb(X, redundant=False, cost="loglp", p=None):
+    """bestbasistree(X, JBB(...)) BestBasis.jl:194-201 for 1-D signals."""
+    X = _f(X)
+    return bestbasis_treeselection(tree_costs_jbb(X, redundant, cost, p), X.shape[0])

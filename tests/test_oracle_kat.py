@@ -1,0 +1,319 @@
+"""Pins the CPU oracle against every known-answer vector the reference's own tests hold for the
+hot path (tests/golden/reference_kats.json) and against the structural
+identities those tests assert (round trips, swpt == swpd leaves, batch == repeated single)."""
+import numpy as np
+import pytest
+
+
+def _qmf(wx, name):
+    return wx.wavelet(getattr(wx.WT, name)).qmf
+
+
+def _gh(oracle, wx, name):
+    return oracle.makereverseqmfpair(_qmf(wx, name))
+
+
+def test_dwt_step_1d_kat(oracle, wx, kats):
+    k = kats["dwt_step_1d"]
+    g, h = _gh(oracle, wx, k["wavelet"])
+    x = np.array(k["x"])
+    w1, w2 = oracle.dwt_step(x, h, g)
+    assert np.round(np.concatenate([w1, w2]), 3).tolist() == k["w1w2_round3"]
+    # test/transforms.jl:9 feeds the ROUNDED children back
+    assert np.round(oracle.idwt_step(np.round(w1, 3), np.round(w2, 3), h, g), 3).tolist() == k["x"]
+    np.testing.assert_allclose(oracle.idwt_step(w1, w2, h, g), x, rtol=0, atol=1e-13)
+
+
+def test_dwt_step_2d_kat(oracle, wx, kats):
+    k = kats["dwt_step_2d"]
+    g, h = _gh(oracle, wx, k["wavelet"])
+    x = np.array(k["x"])
+    w1, w2, w3, w4 = oracle.dwt_step(x, h, g)
+    got = np.round(np.block([[w1, w2], [w3, w4]]), 3)
+    assert got.tolist() == k["w_round3"]
+    assert np.round(oracle.idwt_step(w1, w2, w3, w4, h, g), 3).tolist() == k["x"]
+
+
+def test_sdwt_step_1d_kat(oracle, wx, kats):
+    k = kats["sdwt_step_1d"]
+    g, h = _gh(oracle, wx, k["wavelet"])
+    x = np.array(k["x"])
+    w1, w2 = oracle.sdwt_step(x, k["d"], h, g)
+    assert np.round(np.stack([w1, w2], axis=1), 3).tolist() == k["w1w2_round3"]
+    r1, r2 = np.round(w1, 3), np.round(w2, 3)
+    assert np.round(oracle.isdwt_step(r1, r2, 0, h, g), 3).tolist() == k["x"]
+    assert np.round(oracle.isdwt_step(r1, r2, 0, 0, 0, h, g), 3).tolist() == k["x"]
+    assert np.round(oracle.isdwt_step(r1, r2, 0, 0, 1, h, g), 3).tolist() == k["x"]
+    for sv, sw in ((-1, 0), (1, 0), (0, 2)):              # test/transforms.jl:63-65
+        with pytest.raises(AssertionError):
+            oracle.isdwt_step(r1, r2, 0, sv, sw, h, g)
+
+
+def test_sdwt_step_2d_kat(oracle, wx, kats):
+    k = kats["sdwt_step_2d"]
+    g, h = _gh(oracle, wx, k["wavelet"])
+    x = np.array(k["x"])
+    ws = oracle.sdwt_step(x, 0, h, g)
+    for w, name in zip(ws, ("w1", "w2", "w3", "w4")):
+        assert (np.round(w, 3) + 0.0).tolist() == k[name]
+    assert np.round(oracle.isdwt_step(*ws, 0, h, g), 3).tolist() == k["x"]
+    assert np.round(oracle.isdwt_step(*ws, 0, 0, 0, h, g), 3).tolist() == k["x"]
+    assert np.round(oracle.isdwt_step(*ws, 0, 0, 1, h, g), 3).tolist() == k["x"]
+    for sv, sw in ((0, 2), (-1, 1), (1, 0)):               # test/transforms.jl:85-87
+        with pytest.raises(AssertionError):
+            oracle.isdwt_step(*ws, 0, sv, sw, h, g)
+
+
+def test_acdwt_step_kat(oracle, wx, kats):
+    k = kats["acdwt_step_1d"]
+    # test/transforms.jl:127: `g, h = make_acreverseqmfpair(wt)`; acdwt_step(x, 0, h, g)
+    g, h = oracle.make_acreverseqmfpair(_qmf(wx, k["wavelet"]))
+    x = np.array(k["x"])
+    w1, w2 = oracle.acdwt_step(x, 0, h, g)
+    assert (np.round(np.stack([w1, w2], axis=1), 3) + 0.0).tolist() == k["w1w2_round3"]
+    assert np.round(oracle.iacdwt_step(np.round(w1, 3), np.round(w2, 3)), 3).tolist() == k["x"]
+    k2 = kats["acdwt_step_2d"]
+    x2 = np.array(k2["x"])
+    ws = oracle.acdwt_step(x2, 0, h, g)
+    for w, name in zip(ws, ("w1", "w2", "w3", "w4")):
+        assert (np.round(w, 3) + 0.0).tolist() == k2[name]
+    assert np.round(oracle.iacdwt_step(*ws), 3).tolist() == k2["x"]
+
+
+def _ns_dwt(oracle, x, g, h):
+    """wavemult/transforms.jl:52-70 restated with the oracle's dwt_step (Haar doctest layout):
+    nxw[ndyad(l, Lmax, false|true)]; ndyad(1,4,false)==17:24 (test/wavemult.jl:16-17)."""
+    n = len(x)
+    Lmax = int(np.log2(n))
+    nxw = np.zeros(2 * n)
+
+    def ndyad(l, s):                      # 0-based slice of the level-l block
+        lo = (1 << (Lmax + 1 - l))
+        blk = 1 << (Lmax - l)
+        start = lo + (blk if s else 0)
+        return slice(start, start + blk)
+    v = np.array(x, dtype=float)
+    for l in range(1, Lmax + 1):
+        w1, w2 = oracle.dwt_step(v, h, g)
+        nxw[ndyad(l, False)] = w1
+        nxw[ndyad(l, True)] = w2
+        v = w1
+    nxw[0:1] = nxw[ndyad(Lmax, False)]
+    return nxw
+
+
+def test_haar_16_digit_doctest(oracle, wx, kats):
+    """The only full-precision vector in the reference: pins dwt_step!/idwt_step! (Haar) to the bit."""
+    k = kats["haar_ns_dwt"]
+    g, h = _gh(oracle, wx, "haar")
+    nxw = _ns_dwt(oracle, k["x"], g, h)
+    # positions 0,1 of the doctest are 0.0 because nxw[1:1] gets the coarsest scaling coef... which
+    # ns_dwt copies to index 1 only (1<<(Lmax-L) = 1); compare the detail/scaling blocks exactly
+    got = nxw.copy()
+    exp = np.array(k["nxw"])
+    np.testing.assert_array_equal(got[2:], exp[2:])
+    # ns_idwt (wavemult/transforms.jl:124-142) on the printed vector
+    n, Lmax = 4, 2
+    x = np.zeros(n)
+    x[0:1] = exp[0:1]
+    for l in range(Lmax, 0, -1):
+        lo = 1 << (Lmax + 1 - l)
+        blk = 1 << (Lmax - l)
+        w1 = exp[lo:lo + blk] + x[0:blk]
+        w2 = exp[lo + blk:lo + 2 * blk]
+        x[0:2 * blk] = oracle.idwt_step(w1, w2, h, g)
+    np.testing.assert_allclose(x, np.array(k["ns_idwt"]), rtol=0, atol=2.3e-16)
+
+
+def test_haar_4digit(oracle, wx, kats):
+    k = kats["haar_ns_dwt_4digit"]
+    g, h = _gh(oracle, wx, "haar")
+    nxw = _ns_dwt(oracle, k["x"], g, h)
+    assert (np.round(nxw, 4) + 0.0).tolist()[2:] == k["nxw_round4"][2:]
+
+
+def test_integer_helpers_match_reference_literals(oracle, wx, kats):
+    k = kats
+    Xw = np.arange(1, 13, dtype=float).reshape((4, 3), order="F")
+    assert oracle.getbasiscoef(Xw, oracle.maketree1d(4, 2, "dwt")).tolist() == k["getbasiscoef"]["dwt_tree_L2"]
+    assert oracle.getbasiscoef(Xw, oracle.maketree1d(4, 2, "full")).tolist() == k["getbasiscoef"]["full_tree_L2"]
+    for bad in ([0, 1, 0], [1, 1, 1, 1]):                   # test/utils.jl:9-10
+        with pytest.raises(AssertionError):
+            oracle.getbasiscoef(Xw, np.array(bad, dtype=bool))
+    with pytest.raises(AssertionError):                      # :11
+        oracle.getbasiscoef(Xw, oracle.maketree1d(8, 2, "dwt"))
+    with pytest.raises(AssertionError):                      # :12  k-1 <= L
+        oracle.getbasiscoef(np.zeros((4, 4)), oracle.maketree1d(4, 2, "dwt"))
+    with pytest.raises(ValueError):                          # :13  ArgumentError
+        oracle.getbasiscoef(np.zeros((4, 2)), oracle.maketree1d(4, 2, "dwt"))
+    for sm, L, exp in k["main2depthshift"]["cases"]:
+        assert oracle.main2depthshift(sm, L) == exp
+        assert wx.main2depthshift(sm, L) == exp
+    for sm, L in k["main2depthshift"]["assert_fail"]:
+        with pytest.raises(AssertionError):
+            oracle.main2depthshift(sm, L)
+        with pytest.raises(AssertionError):
+            wx.main2depthshift(sm, L)
+    for idx in ("2", "3", "4", "5"):
+        assert list(oracle.getrowrange(8, int(idx))) == k["rowrange_n8"][idx]
+        assert list(oracle.getcolrange(8, int(idx))) == k["colrange_n8"][idx]
+        r = wx.getrowrange(8, int(idx)); c = wx.getcolrange(8, int(idx))
+        assert [r[0], r[-1]] == k["rowrange_n8"][idx] and [c[0], c[-1]] == k["colrange_n8"][idx]
+    with pytest.raises(AssertionError):
+        oracle.getrowrange(8, 86)
+    with pytest.raises(AssertionError):
+        wx.getcolrange(8, 86)
+    for name, val in k["childindex_of_3"].items():
+        if name != "src":
+            assert wx.getchildindex(3, name) == val
+    with pytest.raises(AssertionError):
+        wx.getchildindex(3, "fail")
+    for i, p in k["parentindex"]["binary"]:
+        assert wx.getparentindex(i, "binary") == p
+    for i, p in k["parentindex"]["quad"]:
+        assert wx.getparentindex(i, "quad") == p
+    gl = k["getleaf"]
+    assert oracle.getleaf(oracle.maketree1d(4, 2, "dwt"), "binary").astype(int).tolist() == gl["binary_dwt_4_2"]
+    assert wx.getleaf(wx.maketree(4, 2, "dwt"), "binary").astype(int).tolist() == gl["binary_dwt_4_2"]
+    ql = oracle.getleaf(oracle.maketree2d(4, 4, 2, "dwt"), "quad")
+    assert len(ql) == gl["quad_len"] and (np.flatnonzero(ql) + 1).tolist() == gl["quad_dwt_4_4_2_true_idx_1based"]
+    ql2 = wx.getleaf(wx.maketree(4, 4, 2, "dwt"), "quad")
+    assert (ql2 == ql).all()
+    for bad_tree, kind in (([0, 1, 0], "binary"), ([0, 1], "binary"), ([0, 1, 1, 1, 1], "quad"), ([0, 1], "quad")):
+        with pytest.raises(AssertionError):
+            oracle.getleaf(np.array(bad_tree, dtype=bool), kind)
+        with pytest.raises(AssertionError):
+            wx.getleaf(np.array(bad_tree, dtype=bool), kind)
+    mt = k["maketree2d"]
+    assert oracle.maketree2d(4, 4, 2, "full").astype(int).tolist() == mt["full_4_4_2"]
+    assert oracle.maketree2d(4, 4, 2, "dwt").astype(int).tolist() == mt["dwt_4_4_2"]
+    assert wx.maketree(4, 4, 2).astype(int).tolist() == mt["full_4_4_2"]
+    assert wx.maketree(np.zeros((4, 4)), "dwt").astype(int).tolist() == mt["dwt_4_4_2"]
+    with pytest.raises(AssertionError):
+        oracle.maketree2d(4, 4, 3, "dwt")
+    with pytest.raises(AssertionError):
+        wx.maketree(4, 4, 3, "dwt")
+    with pytest.raises(AssertionError):
+        wx.maketree(4, 4, 2, "fail")
+    assert oracle.getdepth(5, "binary") == 2 and oracle.getdepth(5, "quad") == 1
+    assert wx.getdepth(5, "binary") == 2 and wx.getdepth(5, "quad") == 1
+    with pytest.raises(AssertionError):
+        wx.getdepth(0, "binary")
+    assert oracle.gettreelength(8) == 7 and oracle.gettreelength(8, 8) == 21 and oracle.gettreelength(8, 16) == 21
+    assert wx.gettreelength(8) == 7 and wx.gettreelength(8, 8) == 21 and wx.gettreelength(8, 16) == 21
+    tree = oracle.maketree1d(4, 1, "dwt")
+    assert oracle.coarsestscalingrange(4, tree) == 2 and oracle.coarsestscalingrange(4, tree, True) == 2
+    assert oracle.finestdetailrange(4, tree) == 3 and oracle.finestdetailrange(4, tree, True) == 3
+    r = wx.coarsestscalingrange(np.zeros(4), tree)
+    assert [r[0], r[-1]] == k["scalingranges"]["coarsest"]
+    assert wx.coarsestscalingrange(4, tree, True)[1] == 2 and wx.finestdetailrange(np.zeros((4, 3)), tree, True)[1] == 3
+    r = wx.finestdetailrange(4, tree)
+    assert [r[0], r[-1]] == k["scalingranges"]["finest"]
+    for n_bad in (5,):
+        with pytest.raises(AssertionError):
+            oracle.coarsestscalingrange(n_bad, tree, True)
+        with pytest.raises(AssertionError):
+            wx.finestdetailrange(n_bad, tree, False)
+    assert oracle.isvalidtree2d(4, 4, oracle.maketree2d(4, 4, 2, "full"))
+    assert oracle.isvalidtree2d(4, 4, oracle.maketree2d(4, 4, 2, "dwt"))
+    for bad in k["isvalidtree2d"]["invalid"]:
+        assert not oracle.isvalidtree2d(4, 4, np.array(bad, dtype=bool))
+        assert not wx.isvalidtree(np.zeros((4, 4)), np.array(bad, dtype=bool))
+    assert wx.maxtransformlevels(np.zeros((4, 2)), 1) == 2 and wx.maxtransformlevels(np.zeros((4, 2)), 2) == 1
+    with pytest.raises(AssertionError):
+        wx.maxtransformlevels(np.zeros((4, 2)), 3)
+    assert wx.nodelength(8, 2) == 2
+
+
+@pytest.mark.parametrize("wname", ["haar", "db4", "db8", "coif6"])
+def test_structural_identities_1d(oracle, wx, wname):
+    """test/transforms.jl:25-33, 93-105, 151-165 as identities on the oracle."""
+    rng = np.random.default_rng(7)
+    q = _qmf(wx, wname)
+    x = rng.standard_normal(16)
+    y = [oracle.wpt(x, q, L) for L in (1, 2, 3, 4)]
+    np.testing.assert_allclose(oracle.wpd(x, q), np.stack([x] + y, axis=1), rtol=0, atol=1e-14)
+    tree = oracle.maketree1d(16, 4, "dwt")
+    for arg in (None, 2, tree):
+        np.testing.assert_allclose(oracle.iwpd(oracle.wpd(x, q), q, arg), x, atol=1e-12)
+        np.testing.assert_allclose(oracle.iwpt(oracle.wpt(x, q, arg), q, arg), x, atol=1e-12)
+    sm = 3
+    np.testing.assert_allclose(oracle.isdwt(oracle.sdwt(x, q, 3), q), x, atol=1e-12)
+    np.testing.assert_allclose(oracle.isdwt(oracle.sdwt(x, q), q, sm), x, atol=1e-12)
+    assert (oracle.swpt(x, q) == oracle.swpd(x, q)[:, 15:31]).all()
+    assert (oracle.swpt(x, q, 3) == oracle.swpd(x, q)[:, 7:15]).all()
+    np.testing.assert_allclose(oracle.iswpt(oracle.swpt(x, q), q), x, atol=1e-12)
+    np.testing.assert_allclose(oracle.iswpt(oracle.swpt(x, q), q, sm), x, atol=1e-12)
+    for arg in (None, 2, tree):
+        np.testing.assert_allclose(oracle.iswpd(oracle.swpd(x, q), q, arg), x, atol=1e-12)
+        np.testing.assert_allclose(oracle.iswpd(oracle.swpd(x, q), q, arg, sm), x, atol=1e-12)
+    np.testing.assert_allclose(oracle.iacdwt(oracle.acdwt(x, q)), x, atol=1e-12)
+    np.testing.assert_allclose(oracle.iacdwt(oracle.acdwt(x, q, 2)), x, atol=1e-12)
+    assert (oracle.acwpt(x, q) == oracle.acwpd(x, q)[:, 15:31]).all()
+    assert (oracle.acwpt(x, q, 2) == oracle.acwpd(x, q)[:, 3:7]).all()
+    np.testing.assert_allclose(oracle.iacwpt(oracle.acwpt(x, q)), x, atol=1e-12)
+    for arg in (None, 2, tree):
+        np.testing.assert_allclose(oracle.iacwpd(oracle.acwpd(x, q), arg), x, atol=1e-12)
+    with pytest.raises(AssertionError):                    # test/transforms.jl:162
+        oracle.iacwpd(oracle.acwpd(x, q)[:8], tree)
+
+
+def test_structural_identities_2d(oracle, wx):
+    """test/transforms.jl:36-49"""
+    rng = np.random.default_rng(8)
+    q = _qmf(wx, "db4")
+    x = rng.standard_normal((8, 8))
+    z = [oracle.wpt(x, q, L) for L in (1, 2, 3)]
+    np.testing.assert_allclose(oracle.wpd(x, q), np.stack([x] + z, axis=2), rtol=0, atol=1e-13)
+    tree = oracle.maketree2d(8, 8, 3, "dwt")
+    for arg in (None, 2, tree):
+        np.testing.assert_allclose(oracle.iwpd(oracle.wpd(x, q), q, arg), x, atol=1e-12)
+        np.testing.assert_allclose(oracle.iwpt(oracle.wpt(x, q, arg), q, arg), x, atol=1e-12)
+    # one 2-D level == separable 1-D steps (dwt_one_level.jl:319-354): LL block equals row/col lowpass
+    g, h = oracle.makereverseqmfpair(q)
+    w1, w2, w3, w4 = oracle.dwt_step(x, h, g)
+    np.testing.assert_allclose(z[0], np.block([[w1, w2], [w3, w4]]), atol=1e-14)
+
+
+def test_batch_equals_repeated_single(oracle, wx):
+    """test/transforms.jl:270-364: `*all` of a repeated signal == the single-signal result."""
+    rng = np.random.default_rng(9)
+    q = _qmf(wx, "db4")
+    x = rng.standard_normal(8)
+    X = np.stack([x, x, x], axis=1)
+    W = oracle.wpdall(X, q)
+    assert W.shape == (8, 4, 3)
+    for i in range(3):
+        assert (W[:, :, i] == oracle.wpd(x, q)).all()
+    np.testing.assert_allclose(oracle.iwpdall(W, q), X, atol=1e-12)
+    assert (oracle.wptall(X, q, 2)[:, 1] == oracle.wpt(x, q, 2)).all()
+
+
+def test_float32_rounding_rule(oracle, wx):
+    """Float32 data x Float64 taps, rounded to Float32 at every accumulate."""
+    rng = np.random.default_rng(10)
+    q = _qmf(wx, "db4")
+    x = rng.standard_normal(32).astype(np.float32)
+    y32 = oracle.wpd(x, q, 3)
+    assert y32.dtype == np.float32
+    y64 = oracle.wpd(x.astype(np.float64), q, 3)
+    err = np.abs(y32 - y64).max() / np.abs(y64).max()
+    assert 0 < err < 1e-5
+
+
+def test_jbb_tree_is_valid_and_costs_shape(oracle, wx):
+    """test/bestbasis.jl:25-32 only asserts isvalidtree (tree parity is unpinned by the reference)."""
+    rng = np.random.default_rng(11)
+    q = _qmf(wx, "haar")
+    X = rng.standard_normal((16, 5))
+    xw = oracle.wpdall(X, q)
+    costs = oracle.tree_costs_jbb(xw)
+    assert costs.shape == (31,)
+    assert oracle.isvalidtree1d(16, oracle.bestbasistree_jbb(xw))
+    assert oracle.isvalidtree1d(16, oracle.bestbasistree_jbb(xw, cost="norm"))
+    xsw = np.asfortranarray(np.stack([oracle.swpd(X[:, i], q) for i in range(5)], axis=-1))
+    assert oracle.isvalidtree1d(16, oracle.bestbasistree_jbb(xsw, redundant=True))
+    xacw = np.asfortranarray(np.stack([oracle.acwpd(X[:, i], q) for i in range(5)], axis=-1))
+    assert oracle.isvalidtree1d(16, oracle.bestbasistree_jbb(xacw, redundant=True))
+    with pytest.raises(AssertionError):                    # test/bestbasis.jl:44 (n=3 -> k too long)
+        oracle.bestbasis_treeselection(rng.standard_normal(7), 3)

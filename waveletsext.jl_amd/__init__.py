@@ -1,0 +1,18 @@
+"""waveletsext.jl_amd -- MI355X-native drop-in for the batched wavelet-packet hot path of
+WaveletsExt.jl (wpt/iwpt, wpd/iwpd, swpt/swpd, acwpt/acwpd, their `*all` batch drivers and the
+JBB best-basis reduction).  Host side: this package mirrors the reference's function names and
+argument conventions; compute: hand-written HIP kernels for gfx950 behind the C ABI declared in
+include/waveletsext_hip.h (csrc/libwaveletsext_hip.so).  There is no CPU fallback.
+
+The directory name contains a dot, so import it through the `waveletsext_jl_amd` shim at the
+repository root (`import waveletsext_jl_amd as wx`).
+"""
+from .filters import WT, OrthoFilter, ArgumentError, wavelet, daubechies            # noqa: F401
+from .util import (maxtransformlevels, isdyadic, ndyadicscales, nodelength, getchildindex,   # noqa: F401
+                   getparentindex, getdepth, gettreelength, maketree, isvalidtree, getleaf,
+                   getrowrange, getcolrange, main2depthshift, coarsestscalingrange,
+                   finestdetailrange, delete_subtree)
+from ._arrays import jl_empty, to_device, to_numpy, to_colmajor                     # noqa: F401
+from ._lib import WxError, device_count, set_force_generic, LIB_PATH                # noqa: F401
+from .dwt import (wpd, wpd_, wpdall, iwpd, iwpd_, iwpdall, wpt, wpt_, iwpt, iwpt_,   # noqa: F401
+                  wptall, iwptall, getbasiscoef, getbasiscoefall)

@@ -1,0 +1,118 @@
+"""ctypes binding of libwaveletsext_hip.so (the C ABI in include/waveletsext_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing this module raises on
+import of the symbol table, and every compute entry point fails with WxError(WX_EHIP) when no
+HIP device is visible.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwaveletsext_hip.so")
+
+WX_OK, WX_EASSERT, WX_EARG, WX_EBOUNDS, WX_EHIP, WX_EUNSUPPORTED = 0, -1, -2, -3, -10, -11
+
+
+class WxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libwaveletsext_hip status %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load the library once (RTLD_GLOBAL is not needed; HIP runtime comes in as a dependency)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libwaveletsext_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C waveletsext.jl_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+_P, _I, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+
+
+def _declare(L):
+    L.wx_version.restype = _I
+    L.wx_last_error.restype = ctypes.c_char_p
+    L.wx_device_count.restype = _I
+    L.wx_set_force_generic.argtypes = [_I]
+    L.wx_set_force_generic.restype = None
+    sigs = {
+        # name: argtypes (without the _f64/_f32 suffix)
+        "wx_wpd1d": [_P, _P, _L, _I, _L, _P, _I, _P],
+        "wx_wpt1d": [_P, _P, _L, _I, _P, _L, _L, _P, _I, _P],
+        "wx_iwpt1d": [_P, _P, _L, _I, _P, _L, _L, _P, _I, _P],
+        "wx_iwpd1d": [_P, _P, _L, _I, _I, _P, _L, _L, _P, _I, _P],
+        "wx_getbasiscoef1d": [_P, _P, _L, _I, _P, _L, _L, _P],
+    }
+    sigs.update(_EXTRA_SIGS)
+    for name, args in sigs.items():
+        for suf in ("_f64", "_f32"):
+            if hasattr(L, name + suf):
+                fn = getattr(L, name + suf)
+                fn.argtypes = args
+                fn.restype = _I
+    for name, args in _PLAIN_SIGS.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _I
+
+
+# filled in by the other host modules' families (SWT / ACWT / 2-D / JBB)
+_EXTRA_SIGS = {
+    "wx_wpd2d": [_P, _P, _L, _L, _I, _L, _P, _I, _P],
+    "wx_wpt2d": [_P, _P, _L, _L, _I, _P, _L, _L, _P, _I, _P],
+    "wx_iwpt2d": [_P, _P, _L, _L, _I, _P, _L, _L, _P, _I, _P],
+    "wx_iwpd2d": [_P, _P, _L, _L, _I, _I, _P, _L, _L, _P, _I, _P],
+    "wx_sdwt1d": [_P, _P, _L, _I, _L, _P, _I, _P],
+    "wx_isdwt1d": [_P, _P, _L, _I, _L, _L, _P, _I, _P],
+    "wx_swpt1d": [_P, _P, _L, _I, _L, _P, _I, _P],
+    "wx_iswpt1d": [_P, _P, _L, _I, _L, _L, _P, _I, _P],
+    "wx_swpd1d": [_P, _P, _L, _I, _L, _P, _I, _P],
+    "wx_iswpd1d": [_P, _P, _L, _I, _P, _L, _L, _L, _P, _I, _P],
+    "wx_acdwt1d": [_P, _P, _L, _I, _L, _P, _I, _P],
+    "wx_iacdwt1d": [_P, _P, _L, _I, _L, _P],
+    "wx_acwpt1d": [_P, _P, _L, _I, _L, _P, _I, _P],
+    "wx_iacwpt1d": [_P, _P, _L, _I, _L, _P],
+    "wx_acwpd1d": [_P, _P, _L, _I, _L, _P, _I, _P],
+    "wx_iacwpd1d": [_P, _P, _L, _I, _P, _L, _L, _P],
+    "wx_jbb_moments": [_P, _P, _P, _L, _L, _I, _P],
+    "wx_jbb_costs": [_P, _P, _L, _L, _L, _I, _I, ctypes.c_double, _P, _P],
+    "wx_acwpd_jbb_moments": [_P, _P, _P, _L, _I, _L, _P, _I, _I, _P],
+    "wx_wpd_jbb_moments": [_P, _P, _P, _L, _I, _L, _P, _I, _I, _P],
+    "wx_swpd_jbb_moments": [_P, _P, _P, _L, _I, _L, _P, _I, _I, _P],
+}
+_PLAIN_SIGS = {
+    "wx_treeselect_f64": [_P, _L, _L, _I, _P],
+    "wx_treeselect_f32": [_P, _L, _L, _I, _P],
+}
+
+
+def check(rc):
+    if rc == WX_OK:
+        return
+    msg = lib().wx_last_error().decode("utf-8", "replace")
+    if rc == WX_EASSERT:
+        raise AssertionError(msg)
+    if rc == WX_EARG:
+        from .filters import ArgumentError
+        raise ArgumentError(msg)
+    if rc == WX_EBOUNDS:
+        raise IndexError(msg)
+    raise WxError(rc, msg)
+
+
+def device_count():
+    return lib().wx_device_count()
+
+
+def set_force_generic(on):
+    lib().wx_set_force_generic(1 if on else 0)

@@ -1,0 +1,235 @@
+// wx_api.hip -- C ABI (include/waveletsext_hip.h): library entry points and the 1-D decimated
+// wavelet-packet family.  Argument checks mirror the reference's @assert / throw sites.
+#include "../../include/waveletsext_hip.h"
+#include "wx_host.h"
+#include "wx_kernels.h"
+#include <atomic>
+
+const char *wx_err_cstr();
+static std::atomic<int> g_force_generic{0};
+int wx_force_generic() { return g_force_generic.load(); }
+
+extern "C" {
+
+int wx_version(void) { return 100; /* 0.1.0 */ }
+const char *wx_last_error(void) { return wx_err_cstr(); }
+int wx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+void wx_set_force_generic(int on) { g_force_generic.store(on ? 1 : 0); }
+
+}  // extern "C"
+
+#define WX_REQUIRE(cond, code, msg) \
+    do { if (!(cond)) return wx_set_error(code, msg); } while (0)
+
+static int wx_need_device()
+{
+    if (wx_device_count() < 1) return wx_set_error(WX_EHIP, "no HIP device visible: the MI355X kernels cannot run");
+    return WX_OK;
+}
+
+// ---- wpd ----------------------------------------------------------------------------------
+template <typename T>
+static int api_wpd1d(const T *x, T *y, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream)
+{
+    WxFilt filt;
+    int rc = wx_pack_filter(qmf, F, &filt);
+    if (rc) return rc;
+    WX_REQUIRE(n >= 1 && batch >= 0, WX_EARG, "wpd: bad dimensions");
+    WX_REQUIRE(0 <= L && L <= wx_maxtransformlevels(n), WX_EASSERT, "wpd!: 0 <= L <= maxtransformlevels(x) (DWT.jl:137)");
+    WX_REQUIRE(n < ((int64_t)1 << 30), WX_EUNSUPPORTED, "wpd: signal length >= 2^30 not supported");
+    if ((rc = wx_need_device())) return rc;
+    hipStream_t st = wx_stream(stream);
+    WxIO io(st);
+    const T *dx = (const T *)io.in(x, sizeof(T) * n * batch);
+    T *dy = (T *)io.out(y, sizeof(T) * n * (L + 1) * batch);
+    if ((batch && n) && (!dx || !dy)) return io.finish(WX_EHIP);
+    rc = wx_dev_wpd1d<T>(dx, dy, n, L, batch, filt, st, wx_force_generic());
+    return io.finish(rc);
+}
+
+// resolves (L | tree) into the device-side description shared by wpt / iwpt / iwpd
+struct WxTree1d {
+    int Leff = 0;
+    const uint8_t *dstatus = nullptr;   // device copy of the tree (nullptr = full tree)
+    int64_t nstatus = 0;
+    bool full = true;
+};
+
+static int wx_resolve_tree1d(int64_t n, int L, const uint8_t *tree, int64_t ntree, WxScratch &scr, WxTree1d *out,
+                             const char *who)
+{
+    (void)who;
+    WX_REQUIRE(wx_isdyadic(n), WX_EASSERT, "maketree/isvalidtree: signal length must be dyadic (Wavelets.jl)");
+    if (!tree) {
+        WX_REQUIRE(0 <= L && L <= wx_maxtransformlevels(n), WX_EASSERT, "maketree: 0 <= L <= maxtransformlevels(n)");
+        out->Leff = L;
+        out->full = true;
+        return WX_OK;
+    }
+    WX_REQUIRE(wx_isvalidtree1d(n, tree, ntree), WX_EASSERT, "@assert isvalidtree(x, tree)");
+    out->Leff = wx_tree_depth1d(tree, ntree);
+    // a full tree of depth Leff needs no status bytes
+    bool full = true;
+    for (int64_t i = 1; i <= ((int64_t)1 << out->Leff) - 1 && full; ++i) full = tree[i - 1] != 0;
+    out->full = full;
+    if (!full) {
+        out->dstatus = (const uint8_t *)scr.upload(tree, (size_t)ntree);
+        if (!out->dstatus) return WX_EHIP;
+        out->nstatus = ntree;
+    }
+    return WX_OK;
+}
+
+// ---- wpt / iwpt ---------------------------------------------------------------------------
+template <typename T, bool INVERSE>
+static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
+                     const double *qmf, int F, void *stream)
+{
+    WxFilt filt;
+    int rc = wx_pack_filter(qmf, F, &filt);
+    if (rc) return rc;
+    WX_REQUIRE(n >= 1 && batch >= 0, WX_EARG, "wpt: bad dimensions");
+    WX_REQUIRE(n < ((int64_t)1 << 30), WX_EUNSUPPORTED, "wpt: signal length >= 2^30 not supported");
+    hipStream_t st = wx_stream(stream);
+    WxScratch scr(st);
+    WxTree1d tr;
+    // argument errors are reported before any device is needed
+    if (tree) WX_REQUIRE(wx_isdyadic(n) && wx_isvalidtree1d(n, tree, ntree), WX_EASSERT, "@assert isvalidtree(x, tree)");
+    else WX_REQUIRE(wx_isdyadic(n) && 0 <= L && L <= wx_maxtransformlevels(n), WX_EASSERT,
+                    "maketree: isdyadic(n) and 0 <= L <= maxtransformlevels(n)");
+    if ((rc = wx_need_device())) return rc;
+    if ((rc = wx_resolve_tree1d(n, L, tree, ntree, scr, &tr, "wpt"))) return rc;
+    WxIO io(st);
+    const T *dx = (const T *)io.in(x, sizeof(T) * n * batch);
+    T *dy = (T *)io.out(y, sizeof(T) * n * batch);
+    if ((batch && n) && (!dx || !dy)) return io.finish(WX_EHIP);
+    const int force = wx_force_generic();
+    T *s1 = nullptr;
+    const bool fused = !force && wx_fused1d_ok<T>(n, F);
+    if (!fused && tr.Leff > 1 && batch) {
+        s1 = (T *)scr.alloc(sizeof(T) * n * batch);
+        if (!s1) return io.finish(WX_EHIP);
+    }
+    if (INVERSE)
+        rc = wx_dev_iwpt1d<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, nullptr, 0, n, s1, nullptr, st, force);
+    else
+        rc = wx_dev_wpt1d<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, s1, st, force);
+    return io.finish(rc);
+}
+
+// ---- iwpd ---------------------------------------------------------------------------------
+template <typename T>
+static int api_iwpd1d(const T *xw, T *xh, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
+                      const double *qmf, int F, void *stream)
+{
+    WxFilt filt;
+    int rc = wx_pack_filter(qmf, F, &filt);
+    if (rc) return rc;
+    WX_REQUIRE(n >= 1 && batch >= 0 && k >= 1, WX_EARG, "iwpd: bad dimensions");
+    WX_REQUIRE(n < ((int64_t)1 << 30), WX_EUNSUPPORTED, "iwpd: signal length >= 2^30 not supported");
+    if (tree) WX_REQUIRE(wx_isdyadic(n) && wx_isvalidtree1d(n, tree, ntree), WX_EASSERT, "@assert isvalidtree(x̂, tree) (DWT.jl:346)");
+    else WX_REQUIRE(wx_isdyadic(n) && 0 <= L && L <= wx_maxtransformlevels(n), WX_EASSERT,
+                    "maketree: isdyadic(n) and 0 <= L <= maxtransformlevels(n)");
+    WX_REQUIRE(k - 1 <= wx_maxtransformlevels(n), WX_EASSERT, "getbasiscoef: @assert k-1 <= L (Utils.jl:110)");
+    const int Leff = tree ? wx_tree_depth1d(tree, ntree) : L;
+    WX_REQUIRE(Leff < k, WX_EARG, "getbasiscoef: Not enough decomposition levels in Xw (Utils.jl:120)");
+    if ((rc = wx_need_device())) return rc;
+    hipStream_t st = wx_stream(stream);
+    WxScratch scr(st);
+    WxTree1d tr;
+    if ((rc = wx_resolve_tree1d(n, L, tree, ntree, scr, &tr, "iwpd"))) return rc;
+    WxIO io(st);
+    const T *dxw = (const T *)io.in(xw, sizeof(T) * n * k * batch);
+    T *dxh = (T *)io.out(xh, sizeof(T) * n * batch);
+    if ((batch && n) && (!dxw || !dxh)) return io.finish(WX_EHIP);
+    const int force = wx_force_generic();
+    const bool fused = !force && wx_fused1d_ok<T>(n, F);
+    const int *dcol = nullptr;
+    int log2blk = 0;
+    if (!tr.full) {
+        std::vector<int> col;
+        wx_leaf_colmap1d(tree, ntree, tr.Leff, col);
+        for (int64_t v = n >> tr.Leff; v > 1; v >>= 1) ++log2blk;
+        dcol = (const int *)scr.upload(col.data(), col.size() * sizeof(int));
+        if (!dcol) return io.finish(WX_EHIP);
+    }
+    T *s1 = nullptr, *s2 = nullptr;
+    if (!fused && batch) {
+        if (dcol) s2 = (T *)scr.alloc(sizeof(T) * n * batch);
+        if (tr.Leff > 1) s1 = (T *)scr.alloc(sizeof(T) * n * batch);
+        if ((dcol && !s2) || (tr.Leff > 1 && !s1)) return io.finish(WX_EHIP);
+    }
+    // full tree: every leaf sits in column Leff -> shift the base pointer, keep the table stride
+    const T *base = tr.full ? dxw + (int64_t)tr.Leff * n : dxw;
+    rc = wx_dev_iwpt1d<T>(base, dxh, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, dcol, log2blk, n * (int64_t)k,
+                          s1, s2, st, force);
+    return io.finish(rc);
+}
+
+template <typename T>
+static int api_getbasiscoef1d(const T *Xw, T *out, int64_t n, int k, const uint8_t *tree, int64_t ntree, int64_t batch,
+                              void *stream)
+{
+    WX_REQUIRE(n >= 1 && batch >= 0 && k >= 1, WX_EARG, "getbasiscoef: bad dimensions");
+    WX_REQUIRE(wx_isvalidtree1d(n, tree, ntree), WX_EASSERT, "@assert isvalidtree(x, tree) (Utils.jl:109)");
+    WX_REQUIRE(k - 1 <= wx_maxtransformlevels(n), WX_EASSERT, "@assert k-1 <= L (Utils.jl:110)");
+    WX_REQUIRE(wx_isdyadic(n), WX_EASSERT, "@assert leaf_len == length(leaf) (Utils.jl:113)");
+    const int Leff = wx_tree_depth1d(tree, ntree);
+    WX_REQUIRE(Leff < k, WX_EARG, "Not enough decomposition levels in Xw (Utils.jl:120)");
+    int rc;
+    if ((rc = wx_need_device())) return rc;
+    hipStream_t st = wx_stream(stream);
+    WxScratch scr(st);
+    std::vector<int> col;
+    wx_leaf_colmap1d(tree, ntree, Leff, col);
+    const int *dcol = (const int *)scr.upload(col.data(), col.size() * sizeof(int));
+    if (!dcol) return WX_EHIP;
+    WxIO io(st);
+    const T *dX = (const T *)io.in(Xw, sizeof(T) * n * k * batch);
+    T *dout = (T *)io.out(out, sizeof(T) * n * batch);
+    if ((batch && n) && (!dX || !dout)) return io.finish(WX_EHIP);
+    rc = wx_dev_getbasiscoef1d<T>(dX, dout, n, k, batch, dcol, (int)(n >> Leff), st);
+    return io.finish(rc);
+}
+
+extern "C" {
+
+int wx_wpd1d_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream)
+{ return api_wpd1d<double>(x, y, n, L, batch, qmf, F, stream); }
+int wx_wpd1d_f32(const float *x, float *y, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream)
+{ return api_wpd1d<float>(x, y, n, L, batch, qmf, F, stream); }
+
+int wx_wpt1d_f64(const double *x, double *y, int64_t n, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
+                 const double *qmf, int F, void *stream)
+{ return api_wpt1d<double, false>(x, y, n, L, tree, ntree, batch, qmf, F, stream); }
+int wx_wpt1d_f32(const float *x, float *y, int64_t n, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
+                 const double *qmf, int F, void *stream)
+{ return api_wpt1d<float, false>(x, y, n, L, tree, ntree, batch, qmf, F, stream); }
+
+int wx_iwpt1d_f64(const double *xw, double *xhat, int64_t n, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream)
+{ return api_wpt1d<double, true>(xw, xhat, n, L, tree, ntree, batch, qmf, F, stream); }
+int wx_iwpt1d_f32(const float *xw, float *xhat, int64_t n, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream)
+{ return api_wpt1d<float, true>(xw, xhat, n, L, tree, ntree, batch, qmf, F, stream); }
+
+int wx_iwpd1d_f64(const double *xw, double *xhat, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream)
+{ return api_iwpd1d<double>(xw, xhat, n, k, L, tree, ntree, batch, qmf, F, stream); }
+int wx_iwpd1d_f32(const float *xw, float *xhat, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream)
+{ return api_iwpd1d<float>(xw, xhat, n, k, L, tree, ntree, batch, qmf, F, stream); }
+
+int wx_getbasiscoef1d_f64(const double *Xw, double *out, int64_t n, int k, const uint8_t *tree, int64_t ntree,
+                          int64_t batch, void *stream)
+{ return api_getbasiscoef1d<double>(Xw, out, n, k, tree, ntree, batch, stream); }
+int wx_getbasiscoef1d_f32(const float *Xw, float *out, int64_t n, int k, const uint8_t *tree, int64_t ntree,
+                          int64_t batch, void *stream)
+{ return api_getbasiscoef1d<float>(Xw, out, n, k, tree, ntree, batch, stream); }
+
+}  // extern "C"

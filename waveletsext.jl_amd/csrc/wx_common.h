@@ -1,0 +1,56 @@
+// wx_common.h -- shared declarations of the MI355X (gfx950) wavelet-packet kernels.
+// CDNA4 only: wave64, 160 KiB LDS per CU, no MFMA (bandwidth-bound stencils).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WX_MAXF 64            // longest supported QMF (even length)
+#define WX_WAVE 64
+
+// status codes of the C ABI (include/waveletsext_hip.h)
+#define WX_OK 0
+#define WX_EASSERT (-1)       // the reference would fail an @assert (AssertionError)
+#define WX_EARG (-2)          // the reference would throw ArgumentError
+#define WX_EBOUNDS (-3)       // the reference would throw BoundsError
+#define WX_EHIP (-10)         // HIP runtime failure (see wx_last_error)
+#define WX_EUNSUPPORTED (-11) // valid for the reference, not implemented by this library
+
+// QMF passed by value as a kernel argument: lands in SGPRs via s_load, so every tap is a
+// scalar operand of v_fma_f64 / v_fma_f32.
+struct WxFilt {
+    double q[WX_MAXF];
+    int F;
+};
+
+// autocorrelation-shell half filter a_l/(2*sqrt(2)), l = 1..F-1 (acwt_utils.jl:7-48)
+struct WxAcFilt {
+    double b[WX_MAXF];        // b[l-1] = c2 * a_l
+    double c1;                // 1/sqrt(2)
+    int F;                    // length of the generating QMF; AC filter has 2F-1 taps
+};
+
+struct WxStreamScratch;       // opaque
+
+template <typename T> struct WxVec2;
+template <> struct WxVec2<double> { typedef double2 type; };
+template <> struct WxVec2<float> { typedef float2 type; };
+
+static __device__ __forceinline__ int wx_modn(int x, int n)
+{
+    int r = x % n;
+    return r < 0 ? r + n : r;
+}
+static __device__ __forceinline__ int64_t wx_modn64(int64_t x, int64_t n)
+{
+    int64_t r = x % n;
+    return r < 0 ? r + n : r;
+}
+
+#define WX_HIP_CHECK(expr)                                   \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return wx_set_hip_error(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+int wx_set_hip_error(hipError_t e, const char *what, const char *file, int line);
+int wx_set_error(int code, const char *msg);

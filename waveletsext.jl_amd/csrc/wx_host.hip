@@ -1,0 +1,186 @@
+// wx_host.hip -- host-side plumbing of libwaveletsext_hip.so (no kernels here).
+#include "wx_host.h"
+#include <mutex>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+static thread_local std::string g_wx_err;
+
+int wx_set_hip_error(hipError_t e, const char *what, const char *file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_wx_err = buf;
+    (void)hipGetLastError();
+    return WX_EHIP;
+}
+int wx_set_error(int code, const char *msg)
+{
+    g_wx_err = msg ? msg : "";
+    return code;
+}
+const char *wx_err_cstr() { return g_wx_err.c_str(); }
+
+hipStream_t wx_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+bool wx_is_device_ptr(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+int wx_pack_filter(const double *qmf, int F, WxFilt *out)
+{
+    if (!qmf) return wx_set_error(WX_EARG, "qmf is NULL");
+    if (F < 2 || (F & 1) || F > WX_MAXF) return wx_set_error(WX_EARG, "filter length must be even, 2..64");
+    memset(out, 0, sizeof *out);
+    for (int i = 0; i < F; ++i) out->q[i] = qmf[i];
+    out->F = F;
+    return WX_OK;
+}
+
+int wx_maxtransformlevels(int64_t n)
+{
+    if (n < 2) return 0;
+    int tl = 0;
+    while ((n & 1) == 0) { n >>= 1; ++tl; }
+    return tl;
+}
+bool wx_isdyadic(int64_t n) { return n >= 1 && (n & (n - 1)) == 0; }
+int wx_getdepth_binary(int64_t idx) { int d = 0; while (idx > 1) { idx >>= 1; ++d; } return d; }
+int wx_getdepth_quad(int64_t idx)
+{
+    int64_t t = 3 * idx - 2; int d = 0;
+    while (t >= 4) { t >>= 2; ++d; }
+    return d;
+}
+int64_t wx_gettreelength2d(int64_t m, int64_t n)
+{
+    const int L = wx_maxtransformlevels(m < n ? m : n);
+    return (((int64_t)1 << (2 * L)) - 1) / 3;
+}
+bool wx_isvalidtree1d(int64_t n, const uint8_t *tree, int64_t ntree)
+{
+    if (ntree != n - 1) return false;
+    if (ntree == 0) return true;
+    if (!tree) return false;
+    for (int64_t i = 1; 2 * i + 1 <= ntree; ++i)
+        if (!tree[i - 1] && (tree[2 * i - 1] || tree[2 * i])) return false;
+    return true;
+}
+bool wx_isvalidtree2d(int64_t m, int64_t n, const uint8_t *tree, int64_t ntree)
+{
+    if (wx_gettreelength2d(m, n) != ntree) return false;
+    if (ntree == 0) return true;
+    if (!tree) return false;
+    const int L0 = ntree > 0 ? wx_getdepth_quad(ntree) : 0;
+    const int64_t ns = (((int64_t)1 << (2 * L0)) - 1) / 3;
+    for (int64_t i = 1; i <= ns; ++i) {
+        const bool haschild = tree[4 * i - 3] || tree[4 * i - 2] || tree[4 * i - 1] || tree[4 * i];
+        if (!tree[i - 1] && haschild) return false;
+    }
+    return true;
+}
+int wx_tree_depth1d(const uint8_t *tree, int64_t ntree)
+{
+    int L = 0;
+    for (int64_t i = ntree; i >= 1; --i)
+        if (tree[i - 1]) { L = wx_getdepth_binary(i) + 1; break; }
+    return L;
+}
+int wx_tree_depth2d(const uint8_t *tree, int64_t ntree)
+{
+    int L = 0;
+    for (int64_t i = ntree; i >= 1; --i)
+        if (tree[i - 1]) { L = wx_getdepth_quad(i) + 1; break; }
+    return L;
+}
+static void wx_colmap_rec(const uint8_t *tree, int64_t ntree, int64_t node, int d, int64_t j, int Leff,
+                          std::vector<int> &col)
+{
+    if (node <= ntree && tree[node - 1]) {
+        wx_colmap_rec(tree, ntree, 2 * node, d + 1, 2 * j, Leff, col);
+        wx_colmap_rec(tree, ntree, 2 * node + 1, d + 1, 2 * j + 1, Leff, col);
+    } else {
+        const int64_t w = (int64_t)1 << (Leff - d);
+        for (int64_t k = j * w; k < (j + 1) * w; ++k) col[(size_t)k] = d;
+    }
+}
+void wx_leaf_colmap1d(const uint8_t *tree, int64_t ntree, int Leff, std::vector<int> &col)
+{
+    col.assign((size_t)1 << Leff, 0);
+    wx_colmap_rec(tree, ntree, 1, 0, 0, Leff, col);
+}
+
+// ---- scratch ------------------------------------------------------------------------------
+WxScratch::~WxScratch()
+{
+    for (void *p : ptrs)
+        if (p && hipFreeAsync(p, st) != hipSuccess) (void)hipGetLastError();
+}
+void *WxScratch::alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMallocAsync(&p, bytes, st);
+    if (e != hipSuccess) { wx_set_hip_error(e, "hipMallocAsync(scratch)", __FILE__, __LINE__); return nullptr; }
+    ptrs.push_back(p);
+    return p;
+}
+void *WxScratch::upload(const void *host, size_t bytes)
+{
+    void *p = alloc(bytes);
+    if (!p) return nullptr;
+    hipError_t e = hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { wx_set_hip_error(e, "upload(tree)", __FILE__, __LINE__); return nullptr; }
+    return p;
+}
+
+// ---- staged IO ----------------------------------------------------------------------------
+WxIO::~WxIO()
+{
+    for (auto &it : items)
+        if (it.staged && it.dev && hipFree(it.dev) != hipSuccess) (void)hipGetLastError();
+}
+const void *WxIO::in(const void *p, size_t bytes)
+{
+    if (bytes == 0 || wx_is_device_ptr(p)) return p;
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e != hipSuccess) { wx_set_hip_error(e, "hipMalloc(stage in)", __FILE__, __LINE__); return nullptr; }
+    items.push_back({const_cast<void *>(p), d, bytes, true, false});
+    any_staged = true;
+    e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { wx_set_hip_error(e, "hipMemcpyAsync(H2D)", __FILE__, __LINE__); return nullptr; }
+    return d;
+}
+void *WxIO::out(void *p, size_t bytes)
+{
+    if (bytes == 0 || wx_is_device_ptr(p)) return p;
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e != hipSuccess) { wx_set_hip_error(e, "hipMalloc(stage out)", __FILE__, __LINE__); return nullptr; }
+    items.push_back({p, d, bytes, true, true});
+    any_staged = true;
+    return d;
+}
+int WxIO::finish(int rc)
+{
+    if (!any_staged) return rc;
+    if (rc == WX_OK) {
+        for (auto &it : items)
+            if (it.copy_out) {
+                hipError_t e = hipMemcpyAsync(it.user, it.dev, it.bytes, hipMemcpyDeviceToHost, st);
+                if (e != hipSuccess) rc = wx_set_hip_error(e, "hipMemcpyAsync(D2H)", __FILE__, __LINE__);
+            }
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess && rc == WX_OK) rc = wx_set_hip_error(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    return rc;
+}
