@@ -1,0 +1,161 @@
+"""GPU parity: 1-D decimated wavelet packets (wpd / wpt / iwpt / iwpd / getbasiscoef) through the
+C ABI vs the CPU oracle on identical seeded inputs.  Tolerance: 1e-10 relative for Float64
+(BASELINE.json north_star), 1e-5 for Float32; asserted as max|gpu-oracle|/max|oracle|."""
+import numpy as np
+import pytest
+
+from helpers import TOL, random_tree_1d, relerr
+
+pytestmark = pytest.mark.gpu
+
+WAVELETS = ["haar", "db2", "db3", "db4", "db8", "coif6", "db10"]
+
+
+def _wt(wx, name):
+    return wx.wavelet(getattr(wx.WT, name))
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.mark.parametrize("force_generic", [0, 1])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("wname", WAVELETS)
+def test_wpd_matches_oracle(wx, oracle, wname, dtype, force_generic):
+    rng = np.random.default_rng(1002)
+    wt = _wt(wx, wname)
+    wx.set_force_generic(force_generic)
+    try:
+        for n, B in ((2, 3), (4, 5), (8, 1), (64, 7), (256, 3), (1024, 2)):
+            x = np.asfortranarray(rng.standard_normal((n, B)).astype(dtype))
+            for L in sorted({0, 1, wx.maxtransformlevels(n)}):
+                got = wx.wpdall(x, wt, L)
+                exp = oracle.wpdall(x, wt.qmf, L)
+                assert got.shape == (n, L + 1, B) and got.dtype == dtype
+                assert relerr(got, exp) <= TOL[np.dtype(dtype)], (n, B, L)
+    finally:
+        wx.set_force_generic(0)
+
+
+def test_wpd_non_dyadic_lengths(wx, oracle):
+    """wpd!/wpdall accept n = odd * 2^k with L <= k (DWT.jl:137; only `wpd` asserts isdyadic)."""
+    rng = np.random.default_rng(5)
+    wt = _wt(wx, "db4")
+    for n, L in ((12, 2), (24, 3), (96, 5), (6, 1), (10, 1)):
+        x = np.asfortranarray(rng.standard_normal((n, 4)))
+        assert relerr(wx.wpdall(x, wt, L), oracle.wpdall(x, wt.qmf, L)) <= 1e-10
+    with pytest.raises(AssertionError):
+        wx.wpd(rng.standard_normal(12), wt, 2)                 # DWT.jl:64 isdyadic
+
+
+@pytest.mark.parametrize("force_generic", [0, 1])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("wname", ["haar", "db4", "db8", "coif6"])
+def test_wpt_iwpt_by_level_and_tree(wx, oracle, wname, dtype, force_generic):
+    rng = np.random.default_rng(77)
+    wt = _wt(wx, wname)
+    tol = TOL[np.dtype(dtype)]
+    wx.set_force_generic(force_generic)
+    try:
+        for n, B in ((2, 2), (8, 3), (64, 5), (512, 2)):
+            x = np.asfortranarray(rng.standard_normal((n, B)).astype(dtype))
+            Lmax = wx.maxtransformlevels(n)
+            trees = [wx.maketree(n, Lmax, "dwt"), random_tree_1d(n, rng), random_tree_1d(n, rng, 0.5),
+                     np.zeros(n - 1, dtype=bool)]
+            for arg in [None, 0, 1, Lmax] + trees:
+                got = wx.wptall(x, wt, arg)
+                exp = oracle.wptall(x, wt.qmf, arg)
+                assert relerr(got, exp) <= tol, (n, arg)
+                back = wx.iwptall(exp, wt, arg)
+                assert relerr(back, oracle.iwptall(exp, wt.qmf, arg)) <= tol
+                assert relerr(back, x) <= 10 * tol
+            # single-signal methods
+            assert relerr(wx.wpt(x[:, 0], wt, trees[1]), oracle.wpt(x[:, 0], wt.qmf, trees[1])) <= tol
+            y = np.empty(n, dtype=dtype)
+            assert wx.wpt_(y, x[:, 0], wt, 1) is y
+            assert relerr(y, oracle.wpt(x[:, 0], wt.qmf, 1)) <= tol
+    finally:
+        wx.set_force_generic(0)
+
+
+@pytest.mark.parametrize("force_generic", [0, 1])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_iwpd_and_getbasiscoef(wx, oracle, dtype, force_generic):
+    rng = np.random.default_rng(31)
+    wt = _wt(wx, "db4")
+    tol = TOL[np.dtype(dtype)]
+    wx.set_force_generic(force_generic)
+    try:
+        for n, B in ((8, 3), (64, 4), (256, 2)):
+            x = np.asfortranarray(rng.standard_normal((n, B)).astype(dtype))
+            Lmax = wx.maxtransformlevels(n)
+            xw = oracle.wpdall(x, wt.qmf)
+            for arg in [None, 2, wx.maketree(n, Lmax, "dwt"), random_tree_1d(n, rng), random_tree_1d(n, rng, 0.4)]:
+                got = wx.iwpdall(xw, wt, arg)
+                assert relerr(got, oracle.iwpdall(xw, wt.qmf, arg)) <= tol
+                assert relerr(got, x) <= 10 * tol
+            assert relerr(wx.iwpd(xw[:, :, 0], wt), x[:, 0]) <= 10 * tol
+            tree = random_tree_1d(n, rng)
+            gb = wx.getbasiscoefall(xw, tree)
+            for i in range(B):
+                assert (gb[:, i] == oracle.getbasiscoef(xw[:, :, i], tree)).all()
+            assert (wx.getbasiscoef(xw[:, :, 0], tree) == gb[:, 0]).all()
+            # wpt by tree == getbasiscoef(wpd) (test/transforms.jl:25-30 generalised)
+            assert relerr(wx.wptall(x, wt, tree), gb) <= tol
+    finally:
+        wx.set_force_generic(0)
+
+
+def test_device_pointer_path_is_async_and_matches(wx, oracle, torch_mod):
+    torch = torch_mod
+    rng = np.random.default_rng(3)
+    wt = _wt(wx, "db8")
+    x = np.asfortranarray(rng.standard_normal((4096, 6)))
+    xd = wx.to_device(x)
+    yd = wx.wpdall(xd, wt)
+    assert isinstance(yd, torch.Tensor) and yd.is_cuda and tuple(yd.shape) == (4096, 13, 6)
+    y = wx.to_numpy(yd)
+    assert relerr(y, oracle.wpdall(x, wt.qmf)) <= 1e-10
+    back = wx.iwpdall(yd, wt)
+    assert relerr(wx.to_numpy(back), x) <= 1e-10
+    leaves = wx.wptall(xd, wt, 10)
+    assert relerr(wx.to_numpy(leaves), y[:, 10, :]) <= 1e-12
+    # a side stream: results must be ordered on torch's current stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y2 = wx.wpdall(xd, wt)
+    s.synchronize()
+    assert torch.equal(y2, yd)
+
+
+def test_full_size_config2_properties(wx, torch_mod):
+    """BASELINE config 2 at full size (65536 x 4096 Float64, db8, L=12): size-independent
+    properties -- every level of an orthogonal packet table carries the signal energy, wpt(L) is
+    column L of wpd, and iwpd(wpd(x)) == x."""
+    torch = torch_mod
+    n, B, L = 4096, 65536, 12
+    free, _ = torch.cuda.mem_get_info()
+    need = 8 * n * B * (L + 1 + 3)
+    if free < need * 1.05:
+        pytest.skip("not enough free HBM for the full-size check")
+    wt = _wt(wx, "db8")
+    g = torch.Generator(device="cuda").manual_seed(1002)
+    x = wx.jl_empty((n, B), torch.float64, "cuda")
+    x.normal_(generator=g)
+    y = wx.wpdall(x, wt, L)
+    assert tuple(y.shape) == (n, L + 1, B)
+    e0 = (x * x).sum(dim=0)
+    for d in (1, 5, L):
+        ed = (y[:, d, :] * y[:, d, :]).sum(dim=0)
+        assert float(((ed - e0).abs() / e0).max()) < 1e-11
+    assert torch.equal(y[:, 0, :], x)
+    leaves = wx.wptall(x, wt, L)
+    assert float((leaves - y[:, L, :]).abs().max()) < 1e-12
+    back = wx.iwpdall(y, wt, L)
+    assert float((back - x).abs().max() / x.abs().max()) < 1e-10
+    back2 = wx.iwptall(leaves, wt, L)
+    assert float((back2 - x).abs().max() / x.abs().max()) < 1e-10
