@@ -119,7 +119,7 @@ def main():
         inv = lambda: wx.dwt._iwpd_batched(wx.dwt.Arg(y), wx.dwt.Arg(xh), 1, wt, L, None)
         fwd_bytes = 8.0 * n * B * (1 + L + 1)            # x read once + (L+1) columns written once
         inv_bytes = 8.0 * n * B * 2                      # leaf column read + x written
-        kernel = "k_fwd1d_fused<double,16,256,WRITE_ALL>"
+        kernel = "k_fwd1d_fused<double, 16, 256, true>"
     else:
         y = wx.jl_empty((n, B), torch.float64, dev)
         xh = wx.jl_empty((n, B), torch.float64, dev)
@@ -127,7 +127,7 @@ def main():
         inv = lambda: wx.dwt._wpt_batched("wx_iwpt", wx.dwt.Arg(y), wx.dwt.Arg(xh), 1, wt, L, None)
         fwd_bytes = 8.0 * n * B * 2
         inv_bytes = 8.0 * n * B * 2
-        kernel = "k_fwd1d_fused<double,8,256,wpt>"
+        kernel = "k_fwd1d_fused<double, 8, 256, false>"
 
     def step():
         fwd()
@@ -178,6 +178,15 @@ def main():
 
     out = None
     if rank == 0:
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
+        # command (profiles/traffic.json, written by tools/summarize_prof.py); null if not profiled.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if not a.batch:
+                traffic = tj.get(a.workload, {}).get(kernel, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
         achieved = fwd_bytes / (fwd_avg * 1e-3) / 1e9
         out = {
             "metric": "Msamples/s (fwd+inv wavelet packets)",
@@ -190,7 +199,7 @@ def main():
             "config": {"workload": w["desc"], "n": n, "batch_per_gpu": B, "wavelet": w["wavelet"], "L": L,
                        "sharding": "batch split across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": fwd_bytes, "avg_launch_ms": fwd_avg,
                          "median_launch_ms": fwd_ms[len(fwd_ms) // 2]},
             "inverse": {"avg_launch_ms": inv_avg, "algorithmic_bytes_per_launch": inv_bytes,
