@@ -86,6 +86,75 @@ int wx_getbasiscoef1d_f64(const double *Xw, double *out, int64_t n, int k, const
 int wx_getbasiscoef1d_f32(const float *Xw, float *out, int64_t n, int k, const uint8_t *tree, int64_t ntree,
                           int64_t batch, void *stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * 1-D stationary (undecimated) transforms -- SWT.jl, swt/swt_all.jl
+ * `sm` is the shift of the shift-based inverse (SWT.jl:259-284, 613-646, 1063-1093);
+ * sm < 0 selects the average-based inverse (SWT.jl:313-330, 685-712, 1137-1160).
+ * ------------------------------------------------------------------------------------------ */
+
+/* sdwt!(xw, x, wt, L) SWT.jl:109-130 / sdwtall swt_all.jl:33.  x (n,batch) -> xw (n, L+1, batch) = [s_L d_L .. d_1] */
+int wx_sdwt1d_f64(const double *x, double *xw, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_sdwt1d_f32(const float *x, float *xw, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+/* isdwt!(x, xw, wt[, sm]) SWT.jl:259-330 / isdwtall swt_all.jl:89,107 */
+int wx_isdwt1d_f64(const double *xw, double *x, int64_t n, int L, int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+int wx_isdwt1d_f32(const float *xw, float *x, int64_t n, int L, int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+/* swpt!(xw, x, wt, L) SWT.jl:439-472 / swptall swt_all.jl:156-176.  xw (n, 2^L, batch), natural order */
+int wx_swpt1d_f64(const double *x, double *xw, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_swpt1d_f32(const float *x, float *xw, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+/* iswpt!(x, xw, wt[, sm]) SWT.jl:613-712 / iswptall swt_all.jl:212,230; xw has 2^L columns */
+int wx_iswpt1d_f64(const double *xw, double *x, int64_t n, int L, int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+int wx_iswpt1d_f32(const float *xw, float *x, int64_t n, int L, int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+/* swpd!(xw, x, wt, L) SWT.jl:840-868 / swpdall swt_all.jl:279-299.  xw (n, 2^(L+1)-1, batch), heap order */
+int wx_swpd1d_f64(const double *x, double *xw, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_swpd1d_f32(const float *x, float *xw, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+/* iswpd!(x, xw, wt, L | tree[, sm]) SWT.jl:1035-1160 / iswpdall swt_all.jl:343-392; xw has ncols columns */
+int wx_iswpd1d_f64(const double *xw, double *x, int64_t n, int64_t ncols, int L, const uint8_t *tree, int64_t ntree,
+                   int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+int wx_iswpd1d_f32(const float *xw, float *x, int64_t n, int64_t ncols, int L, const uint8_t *tree, int64_t ntree,
+                   int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 1-D autocorrelation wavelet transforms -- ACWT.jl, acwt/acwt_all.jl (Float64 only: the
+ * reference's acdwt_step! requires eltype(filter) == eltype(data), acwt_one_level.jl:101-106)
+ * ------------------------------------------------------------------------------------------ */
+/* acdwt! ACWT.jl:109-129 / acdwtall acwt_all.jl:33 */
+int wx_acdwt1d_f64(const double *x, double *xw, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+/* iacdwt! ACWT.jl:287-304 / iacdwtall */
+int wx_iacdwt1d_f64(const double *xw, double *x, int64_t n, int L, int64_t batch, void *stream);
+/* acwpt! ACWT.jl:427-460 / acwptall acwt_all.jl:136 */
+int wx_acwpt1d_f64(const double *x, double *xw, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+/* iacwpt! ACWT.jl:581-610 / iacwptall */
+int wx_iacwpt1d_f64(const double *xw, double *x, int64_t n, int L, int64_t batch, void *stream);
+/* acwpd! ACWT.jl:733-759 / acwpdall acwt_all.jl:239 */
+int wx_acwpd1d_f64(const double *x, double *xw, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+/* iacwpd!(x, xw, L | tree) ACWT.jl:917-968 / iacwpdall acwt_all.jl:300-333 */
+int wx_iacwpd1d_f64(const double *xw, double *x, int64_t n, int64_t ncols, int L, const uint8_t *tree, int64_t ntree,
+                    int64_t batch, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Joint best basis (JBB) -- bestbasis/bestbasis_tree.jl:150-180, BestBasis.jl:59-83,194-201
+ * ------------------------------------------------------------------------------------------ */
+/* sum[e] = sum_b X[e,b], sumsq[e] = sum_b X[e,b]^2 over the last (signal) axis; X is (nk, batch)
+ * with nk = n*k the flattened (coef, column) index.  accumulate != 0 adds to the existing
+ * contents (batch shards / RCCL all-reduce partials). */
+int wx_jbb_moments_f64(const double *X, double *sum, double *sumsq, int64_t nk, int64_t batch, int accumulate, void *stream);
+int wx_jbb_moments_f32(const float *X, float *sum, float *sumsq, int64_t nk, int64_t batch, int accumulate, void *stream);
+/* tree_costs(X, JBB(cost, redundant)) from the moments of Ntot signals.  cost_kind 0 = LoglpCost(p),
+ * 1 = NormCost(p).  costs has k entries (redundant) or 2^k - 1 (wpd table with k columns). */
+int wx_jbb_costs_f64(const double *sum, const double *sumsq, int64_t Ntot, int64_t n, int64_t k, int redundant,
+                     int cost_kind, double p, double *costs, void *stream);
+int wx_jbb_costs_f32(const float *sum, const float *sumsq, int64_t Ntot, int64_t n, int64_t k, int redundant,
+                     int cost_kind, double p, float *costs, void *stream);
+/* bestbasis_treeselection(costs, n, :min | :max) BestBasis.jl:59-83.  HOST pointers only; costs
+ * (k entries) is mutated like the reference; tree receives n-1 bytes. */
+int wx_treeselect_f64(double *costs, int64_t k, int64_t n, int type_max, uint8_t *tree);
+int wx_treeselect_f32(float *costs, int64_t k, int64_t n, int type_max, uint8_t *tree);
+/* acwpdall + the JBB moments of its output without materialising the (n, 2^(L+1)-1, batch)
+ * table (BASELINE config 5): sum / sumsq are (n, 2^(L+1)-1). */
+int wx_acwpd_jbb_moments_f64(const double *x, double *sum, double *sumsq, int64_t n, int L, int64_t batch,
+                             const double *qmf, int F, int accumulate, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,3 +55,35 @@ def test_no_cpu_fallback_without_gpu(wx):
     with pytest.raises(wx.WxError) as ei:
         wx.wpdall(np.zeros((8, 2)), wx.wavelet(wx.WT.haar))
     assert ei.value.code == -10
+
+
+def test_treeselect_host_routine_matches_oracle(wx, oracle):
+    """wx_treeselect_* is pure host code (BestBasis.jl:59-83): bit-exact vs the oracle on CPU."""
+    rng = np.random.default_rng(4)
+    for n in (4, 16, 64):
+        for k in ((2 * n - 1), n - 1, 3):
+            for kind in ("min", "max"):
+                costs = rng.standard_normal(k) ** 2
+                assert (wx.bestbasis_treeselection(costs, n, kind) == oracle.bestbasis_treeselection(costs, n, kind)).all()
+        ties = np.ones(2 * n - 1)
+        ties[1:] = 0.5                      # children sum == parent at the root: strict < keeps the parent
+        assert not wx.bestbasis_treeselection(ties, n)[0]
+    with pytest.raises(wx.ArgumentError):
+        wx.bestbasis_treeselection(rng.standard_normal(15), 8, "fail")          # test/bestbasis.jl:43
+    with pytest.raises(AssertionError):
+        wx.bestbasis_treeselection(rng.standard_normal(7), 3)                   # test/bestbasis.jl:44
+
+
+def test_redundant_argument_errors(wx):
+    wt = wx.wavelet(wx.WT.db4)
+    with pytest.raises(wx.ArgumentError):
+        wx.swpt(np.zeros(8), wt, 4)                                             # SWT.jl:64
+    with pytest.raises(wx.ArgumentError):
+        wx.acwpd(np.zeros(8), wt, 0)                                            # L >= 1
+    with pytest.raises(wx.ArgumentError):
+        wx.iswpt(np.zeros((8, 3)), wt)                                          # columns not dyadic
+    with pytest.raises(AssertionError):
+        wx.iswpd(np.zeros((8, 15)), wt, np.array([0, 1, 0, 0, 0, 0, 0], dtype=bool))
+    p, q = wx.make_acreverseqmfpair(wx.wavelet(wx.WT.haar))
+    np.testing.assert_allclose(p, [0.35355339, 0.70710678, 0.35355339], atol=1e-8)
+    np.testing.assert_allclose(q, [-0.35355339, 0.70710678, -0.35355339], atol=1e-8)

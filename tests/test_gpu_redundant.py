@@ -1,0 +1,163 @@
+"""GPU parity: stationary (SWT) and autocorrelation (ACWT) families and the JBB reduction vs the
+CPU oracle.  Float64 tolerance 1e-10 relative, Float32 1e-5; tree bits compared with ==."""
+import numpy as np
+import pytest
+
+from helpers import TOL, random_tree_1d, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _wt(wx, name):
+    return wx.wavelet(getattr(wx.WT, name))
+
+
+def _stack(fn, X, *a):
+    return np.asfortranarray(np.stack([fn(np.asfortranarray(X[..., i]), *a) for i in range(X.shape[-1])], axis=-1))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "coif6"])
+def test_swt_forward_families(wx, oracle, wname, dtype):
+    rng = np.random.default_rng(2003)
+    wt = _wt(wx, wname)
+    tol = TOL[np.dtype(dtype)]
+    for n, B in ((4, 2), (16, 3), (64, 5), (24, 2), (512, 2)):
+        x = np.asfortranarray(rng.standard_normal((n, B)).astype(dtype))
+        Lmax = wx.maxtransformlevels(n)
+        for L in sorted({1, Lmax}):
+            assert relerr(wx.sdwtall(x, wt, L), _stack(oracle.sdwt, x, wt.qmf, L)) <= tol
+            assert relerr(wx.swptall(x, wt, L), _stack(oracle.swpt, x, wt.qmf, L)) <= tol
+            assert relerr(wx.swpdall(x, wt, L), _stack(oracle.swpd, x, wt.qmf, L)) <= tol
+        # swpt == leaves of swpd (test/transforms.jl:95-96), exactly
+        L = Lmax
+        assert (wx.swpt(x[:, 0], wt) == wx.swpd(x[:, 0], wt)[:, (1 << L) - 1:]).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("wname", ["haar", "db4", "db8"])
+def test_swt_inverse_families(wx, oracle, wname, dtype):
+    rng = np.random.default_rng(2004)
+    wt = _wt(wx, wname)
+    tol = TOL[np.dtype(dtype)]
+    for n, B in ((8, 3), (64, 4), (256, 2)):
+        x = np.asfortranarray(rng.standard_normal((n, B)).astype(dtype))
+        Lmax = wx.maxtransformlevels(n)
+        for L in sorted({1, 3, Lmax}):
+            sd = _stack(oracle.sdwt, x, wt.qmf, L)
+            sp = _stack(oracle.swpt, x, wt.qmf, L)
+            for sm in [None, 1, (1 << L) - 1] + ([5] if L >= 3 else []):
+                got = wx.isdwtall(sd, wt, sm)
+                assert relerr(got, _stack(oracle.isdwt, sd, wt.qmf, sm)) <= tol, (n, L, sm)
+                assert relerr(got, x) <= 20 * tol
+            for sm in [None, 0, 1, (1 << L) - 1]:
+                got = wx.iswptall(sp, wt, sm)
+                assert relerr(got, _stack(oracle.iswpt, sp, wt.qmf, sm)) <= tol, (n, L, sm)
+                assert relerr(got, x) <= 20 * tol
+        sw = _stack(oracle.swpd, x, wt.qmf, Lmax)
+        trees = [None, 2, wx.maketree(n, Lmax, "dwt"), random_tree_1d(n, rng), random_tree_1d(n, rng, 0.5)]
+        for arg in trees:
+            for sm in (None, 0, 3):
+                got = wx.iswpdall(sw, wt, arg, sm)
+                exp = np.asfortranarray(np.stack([oracle.iswpd(sw[:, :, i], wt.qmf, arg, sm) for i in range(B)], axis=-1))
+                assert relerr(got, exp) <= tol, (n, arg if not isinstance(arg, np.ndarray) else "tree", sm)
+                assert relerr(got, x) <= 20 * tol
+        assert relerr(wx.iswpd(sw[:, :, 0], wt, trees[3], 3), x[:, 0]) <= 20 * tol
+    with pytest.raises(AssertionError):
+        wx.isdwt(np.zeros((8, 4)), wt, 0)                    # SWT.jl:266: log2(0) = -Inf
+    with pytest.raises(AssertionError):
+        wx.isdwt(np.zeros((8, 4)), wt, 8)
+    with pytest.raises(AssertionError):
+        wx.iswpt(np.zeros((8, 8)), wt, 8)                    # main2depthshift assert
+
+
+@pytest.mark.parametrize("wname", ["haar", "db4", "coif6"])
+def test_acwt_families(wx, oracle, wname):
+    rng = np.random.default_rng(2005)
+    wt = _wt(wx, wname)
+    for n, B in ((8, 3), (64, 4), (24, 2), (256, 2)):
+        x = np.asfortranarray(rng.standard_normal((n, B)))
+        Lmax = wx.maxtransformlevels(n)
+        for L in sorted({1, 2, Lmax}):
+            ad = wx.acdwtall(x, wt, L)
+            ap = wx.acwptall(x, wt, L)
+            aw = wx.acwpdall(x, wt, L)
+            assert relerr(ad, _stack(oracle.acdwt, x, wt.qmf, L)) <= 1e-10
+            assert relerr(ap, _stack(oracle.acwpt, x, wt.qmf, L)) <= 1e-10
+            assert relerr(aw, _stack(oracle.acwpd, x, wt.qmf, L)) <= 1e-10
+            assert (ap == aw[:, (1 << L) - 1:(1 << (L + 1)) - 1, :]).all()       # test/transforms.jl:153-154
+            assert relerr(wx.iacdwtall(ad), x) <= 1e-10
+            assert relerr(wx.iacwptall(ap), x) <= 1e-10
+            if wx.isdyadic(n):
+                assert relerr(wx.iacwpdall(aw, L), x) <= 1e-10
+                assert relerr(wx.iacwpdall(aw, wt, L), x) <= 1e-10
+            else:                                   # maketree(n, L, :full) asserts isdyadic(n) (Wavelets.jl)
+                with pytest.raises(AssertionError):
+                    wx.iacwpdall(aw, L)
+            # inverses are bit-compatible with the oracle (same pairwise order)
+            assert (wx.iacdwtall(ad) == _stack(oracle.iacdwt, ad)).all()
+            assert (wx.iacwptall(ap) == _stack(oracle.iacwpt, ap)).all()
+        if wx.isdyadic(n):
+            aw = wx.acwpdall(x, wt)
+            for tree in (wx.maketree(n, Lmax, "dwt"), random_tree_1d(n, rng), random_tree_1d(n, rng, 0.5)):
+                got = wx.iacwpdall(aw, tree)
+                exp = np.asfortranarray(np.stack([oracle.iacwpd(aw[:, :, i], tree) for i in range(B)], axis=-1))
+                assert (got == exp).all()
+                assert relerr(got, x) <= 1e-10
+            y = np.empty(n)
+            assert wx.iacwpd_(y, aw[:, :, 0], wt, tree) is y
+            with pytest.raises(AssertionError):                                   # test/transforms.jl:162
+                wx.iacwpd_(np.zeros(n // 2), aw[:, :, 0], wt, tree)
+    with pytest.raises(TypeError):
+        wx.acwpt(np.zeros(8, dtype=np.float32), wt)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_jbb_costs_and_trees(wx, oracle, dtype):
+    rng = np.random.default_rng(2006)
+    wt = _wt(wx, "db4")
+    n, N = 64, 48
+    t = np.arange(n) / n
+    base = np.sin(2 * np.pi * 5 * t) + 0.5 * np.sign(np.sin(2 * np.pi * 2 * t))
+    X = np.asfortranarray((base[:, None] * (1 + 0.3 * rng.standard_normal((1, N))) + 0.2 * rng.standard_normal((n, N))).astype(dtype))
+    xw = oracle.wpdall(X, wt.qmf)
+    ctol = 1e-9 if dtype == np.float64 else 2e-3
+    for method, okw in ((wx.JBB(), dict()), (wx.JBB(wx.NormCost(1), False), dict(cost="norm")),
+                        (wx.JBB(wx.LoglpCost(1)), dict(cost="loglp", p=1.0))):
+        got = wx.tree_costs(xw, method)
+        exp = oracle.tree_costs_jbb(xw, **okw)
+        assert relerr(got, exp) <= ctol
+        tree = wx.bestbasistree(xw, method)
+        assert wx.isvalidtree(np.zeros(n), tree)
+        if dtype == np.float64:
+            assert (tree == oracle.bestbasistree_jbb(xw, **okw)).all()           # bit-exact tree indices
+    if dtype == np.float64:
+        xsw = _stack(oracle.swpd, X, wt.qmf, 4)
+        got = wx.tree_costs(xsw, wx.JBB(redundant=True))
+        assert relerr(got, oracle.tree_costs_jbb(xsw, redundant=True)) <= ctol
+        assert (wx.bestbasistree(xsw, wx.JBB(redundant=True)) == oracle.bestbasistree_jbb(xsw, redundant=True)).all()
+        xacw = _stack(oracle.acwpd, X, wt.qmf, 5)
+        assert (wx.bestbasistree(xacw, wx.JBB(redundant=True)) == oracle.bestbasistree_jbb(xacw, redundant=True)).all()
+        # moments are exact sequential sums -> identical to the oracle's accumulation order
+        s, q = wx.jbb_moments(xacw)
+        assert (s == xacw.sum(axis=2, dtype=np.float64)).all() or relerr(s, xacw.sum(axis=2)) < 1e-14
+        # fused acwpd + moments (config 5 path) and shard accumulation (multi-GPU partials)
+        s2, q2 = wx.acwpd_jbb_moments(X, wt, 5)
+        assert relerr(s2, s) <= 1e-12 and relerr(q2, q) <= 1e-12
+        sa, qa = wx.acwpd_jbb_moments(X[:, :20], wt, 5)
+        sa, qa = wx.acwpd_jbb_moments(X[:, 20:], wt, 5, accumulate_into=(sa, qa))
+        assert relerr(sa, s) <= 1e-12 and relerr(qa, q) <= 1e-12
+        costs = wx.costs_from_moments(sa, qa, N, wx.JBB(redundant=True))
+        assert (wx.bestbasis_treeselection(costs, n) == oracle.bestbasistree_jbb(xacw, redundant=True)).all()
+
+
+def test_jbb_many_signals_chunked_reduction(wx, oracle):
+    """few coefficients, many signals: the split-axis moments path must agree with the oracle"""
+    rng = np.random.default_rng(2007)
+    wt = _wt(wx, "haar")
+    X = np.asfortranarray(rng.standard_normal((16, 4096)) * (1 + np.arange(16))[:, None])
+    xw = wx.wpdall(X, wt)
+    got = wx.tree_costs(xw)
+    exp = oracle.tree_costs_jbb(oracle.wpdall(X, wt.qmf))
+    assert relerr(got, exp) <= 1e-10
+    assert (wx.bestbasistree(xw) == oracle.bestbasistree_jbb(oracle.wpdall(X, wt.qmf))).all()

@@ -16,3 +16,10 @@ from ._arrays import jl_empty, to_device, to_numpy, to_colmajor                 
 from ._lib import WxError, device_count, set_force_generic, LIB_PATH                # noqa: F401
 from .dwt import (wpd, wpd_, wpdall, iwpd, iwpd_, iwpdall, wpt, wpt_, iwpt, iwpt_,   # noqa: F401
                   wptall, iwptall, getbasiscoef, getbasiscoefall)
+from .swt import (sdwt, sdwt_, sdwtall, isdwt, isdwt_, isdwtall, swpt, swpt_, swptall, iswpt, iswpt_,   # noqa: F401
+                  iswptall, swpd, swpd_, swpdall, iswpd, iswpd_, iswpdall)
+from .acwt import (acdwt, acdwt_, acdwtall, iacdwt, iacdwt_, iacdwtall, acwpt, acwpt_, acwptall,       # noqa: F401
+                   iacwpt, iacwpt_, iacwptall, acwpd, acwpd_, acwpdall, iacwpd, iacwpd_, iacwpdall,
+                   autocorr, pfilter, qfilter, make_acqmfpair, make_acreverseqmfpair)
+from .bestbasis import (JBB, LoglpCost, NormCost, tree_costs, bestbasistree, bestbasis_treeselection,   # noqa: F401
+                        jbb_moments, costs_from_moments, acwpd_jbb_moments)

@@ -77,13 +77,13 @@ _EXTRA_SIGS = {
     "wx_swpt1d": [_P, _P, _L, _I, _L, _P, _I, _P],
     "wx_iswpt1d": [_P, _P, _L, _I, _L, _L, _P, _I, _P],
     "wx_swpd1d": [_P, _P, _L, _I, _L, _P, _I, _P],
-    "wx_iswpd1d": [_P, _P, _L, _I, _P, _L, _L, _L, _P, _I, _P],
+    "wx_iswpd1d": [_P, _P, _L, _L, _I, _P, _L, _L, _L, _P, _I, _P],
     "wx_acdwt1d": [_P, _P, _L, _I, _L, _P, _I, _P],
     "wx_iacdwt1d": [_P, _P, _L, _I, _L, _P],
     "wx_acwpt1d": [_P, _P, _L, _I, _L, _P, _I, _P],
     "wx_iacwpt1d": [_P, _P, _L, _I, _L, _P],
     "wx_acwpd1d": [_P, _P, _L, _I, _L, _P, _I, _P],
-    "wx_iacwpd1d": [_P, _P, _L, _I, _P, _L, _L, _P],
+    "wx_iacwpd1d": [_P, _P, _L, _L, _I, _P, _L, _L, _P],
     "wx_jbb_moments": [_P, _P, _P, _L, _L, _I, _P],
     "wx_jbb_costs": [_P, _P, _L, _L, _L, _I, _I, ctypes.c_double, _P, _P],
     "wx_acwpd_jbb_moments": [_P, _P, _P, _L, _I, _L, _P, _I, _I, _P],

@@ -19,3 +19,25 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
 template <typename T>
 int wx_dev_getbasiscoef1d(const T *Xw, T *out, int64_t n, int k, int64_t batch, const int *colmap, int blk,
                           hipStream_t st);
+
+// ---- 1-D redundant: SWT / ACWT (wx_swt1d.hip); layout 0 = dwt (n,L+1), 1 = wpt (n,2^L), 2 = wpd heap ----
+template <typename T>
+int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batch, const WxFilt &filt,
+                   const WxAcFilt *ac, hipStream_t st);
+template <typename T>
+int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, int64_t batch, int64_t sm,
+                   const uint8_t *dtree, int64_t ntree, const WxFilt &filt, T *scratch0, T *scratch1,
+                   hipStream_t st);
+template <typename T> int wx_dev_iacdwt(const T *xw, T *x, int64_t n, int L, int64_t batch, hipStream_t st);
+template <typename T> int wx_dev_iacwpt(const T *xw, T *x, int64_t n, int L, int64_t batch, hipStream_t st);
+template <typename T>
+int wx_dev_iacwpd(const T *xw, T *x, int64_t n, int ncols, int64_t batch, const uint8_t *dtree, int64_t ntree,
+                  int Lfull, hipStream_t st);
+
+// ---- JBB (wx_jbb.hip) ----
+template <typename T>
+int wx_dev_jbb_moments(const T *X, T *sum, T *sumsq, int64_t nk, int64_t batch, int accumulate, T *scratch,
+                       int nchunks, hipStream_t st);
+template <typename T>
+int wx_dev_jbb_costs(const T *sum, const T *sumsq, int64_t Ntot, int64_t n, int64_t k, int redundant,
+                     int cost_kind, double p, T *costs, hipStream_t st);

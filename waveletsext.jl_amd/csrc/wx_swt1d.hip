@@ -1,0 +1,383 @@
+// wx_swt1d.hip -- batched 1-D redundant (undecimated) transforms for gfx950: the stationary
+// family (sdwt / swpt / swpd and inverses) and the autocorrelation family (acdwt / acwpt / acwpd
+// and inverses).
+//
+// Reference semantics (paths relative to /root/reference/src/mod), 0-based, s = 2^d:
+//   sdwt_step!   swt/swt_one_level.jl:99-127   a[i] = sum_j q[j] v[(i+(j-1)s) mod n]
+//                                              d[i] = sum_j (-1)^j q[j] v[(i-j s) mod n]
+//   isdwt_step!  swt/swt_one_level.jl:279-318  shift (sv, sw): the parent samples of residue class
+//                sv (mod s) are an ordinary idwt_step of the child samples of class sw (mod 2s);
+//                stored one parent-sample earlier when sw == sv.   :257-277 average: both child
+//                classes sw = sv and sw = sv + s for every sv, then / 2.
+//   acdwt_step!  acwt/acwt_one_level.jl:101-128  w1 = v/sqrt2 + S, w2 = v/sqrt2 - S,
+//                S[k] = sum_{l odd} a_l/(2 sqrt2) (v[k-ls] + v[k+ls])   (acwt_utils.jl:7-72; the
+//                even-lag autocorrelations vanish by QMF orthogonality)
+//   iacdwt_step! acwt/acwt_one_level.jl:217-224  v = (w1 + w2)/sqrt2
+// Containers: SWT.jl:109-130 (sdwt (n,L+1) = [s_L d_L .. d_1]), :439-472 (swpt (n,2^L), children
+// overwrite the parent column), :840-868 (swpd (n,2^(L+1)-1), heap order); ACWT.jl:109-129,
+// 427-460, 733-759 use the same three layouts.
+//
+// Forward: one workgroup owns one (signal, parent node): the parent column is staged in LDS
+// (which also resolves the reference's parent/child column aliasing), both children are written
+// coalesced.  For a fixed tap all lanes read consecutive LDS words, so the dilation stride never
+// causes bank conflicts.
+#include "wx_common.h"
+#include "wx_kernels.h"
+
+enum { WX_LAYOUT_DWT = 0, WX_LAYOUT_WPT = 1, WX_LAYOUT_WPD = 2 };
+
+static __device__ __forceinline__ void wx_fwd_cols(int layout, int L, int d, int b, int &pcol, int &lcol, int &hcol)
+{
+    if (layout == WX_LAYOUT_DWT) { pcol = L - d; lcol = L - d - 1; hcol = L - d; }
+    else if (layout == WX_LAYOUT_WPT) { const int w = 1 << (L - d); pcol = b * w; lcol = pcol; hcol = pcol + (w >> 1); }
+    else { pcol = (1 << d) - 1 + b; lcol = (1 << (d + 1)) - 1 + 2 * b; hcol = lcol + 1; }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward level: blockIdx.x = node, blockIdx.y = signal (grid-strided)
+// ------------------------------------------------------------------------------------------
+template <typename T, bool AC>
+__global__ __launch_bounds__(256) void k_swt_fwd_level(const T *__restrict__ x, T *__restrict__ xw, int n,
+                                                       int ncols, int64_t batch, int L, int d, int layout,
+                                                       WxFilt filt, WxAcFilt ac)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    T *v = reinterpret_cast<T *>(wx_smem);
+    const int b = blockIdx.x;
+    int pcol, lcol, hcol;
+    wx_fwd_cols(layout, L, d, b, pcol, lcol, hcol);
+    const int s = (1 << d) % n;                      // dilation (s < n whenever L <= maxtransformlevels(n))
+    for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
+        T *base = xw + sig * (int64_t)n * ncols;
+        const T *src = (d == 0) ? x + sig * (int64_t)n : base + (int64_t)pcol * n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const T t = src[i];
+            v[i] = t;
+            if (d == 0 && layout == WX_LAYOUT_WPD) base[i] = t;      // root column of the packet table
+        }
+        __syncthreads();
+        T *lo = base + (int64_t)lcol * n, *hi = base + (int64_t)hcol * n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            if (!AC) {
+                double a = 0.0, dd = 0.0;
+                int k1 = i - s; if (k1 < 0) k1 += n;                 // (i + (0-1)s) mod n
+                int k2 = i;
+                for (int j = 0; j < filt.F; ++j) {
+                    a = fma(filt.q[j], (double)v[k1], a);
+                    dd = fma((j & 1) ? -filt.q[j] : filt.q[j], (double)v[k2], dd);
+                    k1 += s; if (k1 >= n) k1 -= n;
+                    k2 -= s; if (k2 < 0) k2 += n;
+                }
+                lo[i] = (T)a;
+                hi[i] = (T)dd;
+            } else {
+                double S = 0.0;
+                int km = i, kp = i;
+                const int s2 = (2 * s) % n;
+                km -= s; if (km < 0) km += n;
+                kp += s; if (kp >= n) kp -= n;
+                for (int l = 1; l < ac.F; l += 2) {                  // odd lags only
+                    S = fma(ac.b[l - 1], (double)v[km] + (double)v[kp], S);
+                    km -= s2; if (km < 0) km += n;
+                    kp += s2; if (kp >= n) kp -= n;
+                }
+                const double c = ac.c1 * (double)v[i];
+                lo[i] = (T)(c + S);
+                hi[i] = (T)(c - S);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SWT inverse level.  Children/parents are addressed through a small descriptor so that the same
+// kernel serves isdwt / iswpt / iswpd (tree-driven).  One thread per parent sample it owns.
+//   sm_mode 0: average based (all n positions); 1: shift based (only class sv, n/s positions)
+// ------------------------------------------------------------------------------------------
+struct WxInvDesc {
+    const void *in;        // caller's coefficient array (read only), column stride n, signal stride n*ncols
+    void *cur;             // scratch holding computed nodes of depth d+1 (column = node index in level)
+    void *out;             // destination for depth d (scratch, or the final x when d == 0)
+    int64_t cur_cols;      // columns per signal in cur
+    int64_t out_cols;      // columns per signal in out
+    int ncols;             // columns per signal in `in`
+    int layout, L, d;
+    const uint8_t *tree;   // heap-ordered tree bytes (WPD layout only; nullptr = full tree of depth L)
+    int64_t ntree;
+};
+
+template <typename T>
+static __device__ __forceinline__ const T *wx_inv_child(const WxInvDesc &D, int64_t sig, int n, int b, int which,
+                                                        bool &valid)
+{
+    // child `which` (0 low / 1 high) of node b at depth d; returns its column base for signal sig
+    const T *in = reinterpret_cast<const T *>(D.in) + sig * (int64_t)n * D.ncols;
+    const T *cur = reinterpret_cast<const T *>(D.cur) + sig * (int64_t)n * D.cur_cols;
+    valid = true;
+    if (D.layout == WX_LAYOUT_DWT) {
+        // w1 = running reconstruction (cur column 0, or in[:,0] at the first step), w2 = in[:, L-d]
+        if (which == 0) return (D.d == D.L - 1) ? in : cur;
+        return in + (int64_t)(D.L - D.d) * n;
+    }
+    const int cb = 2 * b + which;                        // child index within depth d+1
+    if (D.layout == WX_LAYOUT_WPT)
+        return (D.d == D.L - 1) ? in + (int64_t)cb * n : cur + (int64_t)cb * n;
+    const int64_t heap = ((int64_t)1 << (D.d + 1)) + cb; // 1-based heap index of the child
+    const bool computed = D.tree ? (heap <= D.ntree && D.tree[heap - 1]) : (D.d + 1 < D.L);
+    if (computed) return cur + (int64_t)cb * n;
+    if (heap > D.ncols) { valid = false; return in; }
+    return in + (heap - 1) * (int64_t)n;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_swt_inv_level(WxInvDesc D, int n, int64_t batch, int sm_mode, int sv,
+                                                       int sw, WxFilt filt)
+{
+    const int d = D.d;
+    const int s = 1 << d;                // parent stride
+    const int np = n >> d;               // parent samples per residue class
+    const int nc = np >> 1;              // child samples per residue class
+    const int nodes = (D.layout == WX_LAYOUT_DWT) ? 1 : (1 << d);
+    const int per_node = sm_mode ? np : n;
+    const int64_t total = (int64_t)batch * nodes * per_node;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(g % per_node);
+        const int64_t t2 = g / per_node;
+        const int b = (int)(t2 % nodes);
+        const int64_t sig = t2 / nodes;
+        if (D.layout == WX_LAYOUT_WPD && D.tree) {
+            const int64_t heap = ((int64_t)1 << d) + b;
+            if (!(heap <= D.ntree && D.tree[heap - 1])) continue;        // node has no children: nothing to do
+        }
+        bool ok1, ok2;
+        const T *w1 = wx_inv_child<T>(D, sig, n, b, 0, ok1);
+        const T *w2 = wx_inv_child<T>(D, sig, n, b, 1, ok2);
+        T *out = reinterpret_cast<T *>(D.out) + sig * (int64_t)n * D.out_cols +
+                 (int64_t)((D.layout == WX_LAYOUT_DWT || d == 0) ? 0 : b) * n;
+        int p, cls;
+        if (sm_mode) { cls = sv; p = -1; } else { p = r; cls = p & (s - 1); }
+        double acc = 0.0;
+        const int nvar = sm_mode ? 1 : 2;
+        int pos_out = 0;
+        for (int var = 0; var < nvar; ++var) {
+            // variant A: sw == sv (parent sample t0 stored at class position t0-1); B: sw == sv + s
+            const bool shifted = sm_mode ? (sw != sv) : (var == 1);
+            const int swc = shifted ? cls + s : cls;
+            int t0;
+            if (sm_mode) {
+                t0 = r;                                   // parent sample index inside the class
+                const int u = shifted ? t0 : (t0 == 0 ? np - 1 : t0 - 1);
+                pos_out = cls + u * s;
+            } else {
+                const int u = p >> d;
+                t0 = shifted ? u : (u + 1 == np ? 0 : u + 1);
+                pos_out = p;
+            }
+            const int tau = t0 >> 1;
+            const bool odd = t0 & 1;
+            int k1 = tau, k2 = tau;
+            double v = 0.0;
+            for (int m = 0; m < filt.F / 2; ++m) {
+                const double a = (double)w1[swc + (int64_t)k1 * 2 * s];
+                const double c = (double)w2[swc + (int64_t)k2 * 2 * s];
+                if (!odd) { v = fma(filt.q[2 * m], a, v); v = fma(-filt.q[2 * m + 1], c, v); }
+                else { v = fma(filt.q[2 * m + 1], a, v); v = fma(filt.q[2 * m], c, v); }
+                k1 = k1 == 0 ? nc - 1 : k1 - 1;
+                k2 = k2 + 1 == nc ? 0 : k2 + 1;
+            }
+            acc += v;
+        }
+        out[pos_out] = (T)(sm_mode ? acc : acc * 0.5);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ACWT inverses: pure pairwise sums (acwt_one_level.jl:217-224), bit-compatible evaluation order
+// ------------------------------------------------------------------------------------------
+// iacdwt! ACWT.jl:287-304: x = xw[:,0]; for d = L-1..0: x = (x + xw[:, L-d]) / sqrt2
+template <typename T>
+__global__ __launch_bounds__(256) void k_iacdwt(const T *__restrict__ xw, T *__restrict__ x, int n, int L,
+                                                int64_t batch)
+{
+    const double sqrt2 = 1.4142135623730951;
+    const int64_t total = (int64_t)batch * n;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t sig = g / n;
+        const int i = (int)(g - sig * n);
+        const T *c = xw + sig * (int64_t)n * (L + 1) + i;
+        T v = c[0];
+        for (int d = L - 1; d >= 0; --d) v = (T)(((double)v + (double)c[(int64_t)(L - d) * n]) / sqrt2);
+        x[g] = v;
+    }
+}
+
+// iacwpt! ACWT.jl:581-610: binary tree of (low + high)/sqrt2 over the 2^L leaf columns
+template <typename T>
+__global__ __launch_bounds__(256) void k_iacwpt(const T *__restrict__ xw, T *__restrict__ x, int n, int L,
+                                                int64_t batch)
+{
+    const double sqrt2 = 1.4142135623730951;
+    const int64_t total = (int64_t)batch * n;
+    const int m = 1 << L;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t sig = g / n;
+        const int i = (int)(g - sig * n);
+        const T *c = xw + sig * (int64_t)n * m + i;
+        T st[32];
+        for (int b = 0; b < m; ++b) {
+            T val = c[(int64_t)b * n];
+            int k = b, lvl = 0;
+            while (k & 1) { val = (T)(((double)st[lvl] + (double)val) / sqrt2); k >>= 1; ++lvl; }
+            st[lvl] = val;
+        }
+        x[g] = st[L];
+    }
+}
+
+// iacwpd! ACWT.jl:944-968: value(node) = leaf column, or (value(2i) + value(2i+1))/sqrt2 when
+// tree[i]; iterative post-order walk, identical for every thread (uniform control flow)
+template <typename T>
+__global__ __launch_bounds__(256) void k_iacwpd(const T *__restrict__ xw, T *__restrict__ x, int n, int ncols,
+                                                int64_t batch, const uint8_t *__restrict__ tree, int64_t ntree,
+                                                int Lfull)
+{
+    const double sqrt2 = 1.4142135623730951;
+    const int64_t total = (int64_t)batch * n;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t sig = g / n;
+        const int i = (int)(g - sig * n);
+        const T *c = xw + sig * (int64_t)n * ncols + i;
+        T val[34];
+        int64_t node = 1;
+        int depth = 0;
+        // state machine: descend left while the node has children; at a leaf load it, then climb
+        // while we are a right child, combining with the stored left value
+        while (true) {
+            const bool haskids = tree ? (node <= ntree && tree[node - 1]) : (depth < Lfull);
+            if (haskids) { node = 2 * node; ++depth; continue; }
+            T v = c[(node - 1) * (int64_t)n];
+            while (node > 1 && (node & 1)) {                     // right child: combine with left sibling
+                v = (T)(((double)val[depth] + (double)v) / sqrt2);
+                node >>= 1; --depth;
+            }
+            if (node == 1) { x[g] = v; break; }
+            val[depth] = v;                                       // left child done: go to the sibling
+            node = node + 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------
+static int wx_grid1(int64_t total)
+{
+    int64_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <typename T>
+int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batch, const WxFilt &filt,
+                   const WxAcFilt *ac, hipStream_t st)
+{
+    if (batch == 0 || n == 0) return WX_OK;
+    const size_t lds = (size_t)n * sizeof(T);
+    if (lds > 160 * 1024)
+        return wx_set_error(WX_EUNSUPPORTED, "redundant transforms: signal does not fit the 160 KiB LDS of one CU");
+    const int ncols = layout == WX_LAYOUT_DWT ? L + 1 : (layout == WX_LAYOUT_WPT ? (1 << L) : (1 << (L + 1)) - 1);
+    WxAcFilt acz;
+    if (ac) acz = *ac; else { acz.F = 0; acz.c1 = 0; }
+    auto kern = ac ? k_swt_fwd_level<T, true> : k_swt_fwd_level<T, false>;
+    if (lds > 64 * 1024)
+        WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int d = 0; d < L; ++d) {
+        const int nodes = layout == WX_LAYOUT_DWT ? 1 : (1 << d);
+        int64_t gy = batch;
+        const int64_t cap = (int64_t)65535;
+        if (gy > cap) gy = cap;
+        hipLaunchKernelGGL(kern, dim3(nodes, (unsigned)gy), dim3(256), lds, st, x, xw, (int)n, ncols, batch, L, d,
+                           layout, filt, acz);
+    }
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
+// scratch: two level buffers (see wx_swt_inv_scratch_elems); sm < 0 = average based
+template <typename T>
+int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, int64_t batch, int64_t sm,
+                   const uint8_t *dtree, int64_t ntree, const WxFilt &filt, T *scratch0, T *scratch1,
+                   hipStream_t st)
+{
+    if (batch == 0 || n == 0) return WX_OK;
+    if (L == 0) {
+        WX_HIP_CHECK(hipMemcpy2DAsync(x, n * sizeof(T), xw, (size_t)n * ncols * sizeof(T), n * sizeof(T), batch,
+                                      hipMemcpyDeviceToDevice, st));
+        return WX_OK;
+    }
+    // main2depthshift (Utils.jl:297-305)
+    int64_t sd[64];
+    sd[0] = 0;
+    if (sm >= 0) { int64_t acc = 0; for (int d = 0; d < L; ++d) { acc += ((sm >> d) & 1) << d; sd[d + 1] = acc; } }
+    for (int d = L - 1; d >= 0; --d) {
+        WxInvDesc D;
+        D.in = xw; D.ncols = ncols; D.layout = layout; D.L = L; D.d = d; D.tree = dtree; D.ntree = ntree;
+        T *bufs[2] = {scratch0, scratch1};
+        const int nodes_d = layout == WX_LAYOUT_DWT ? 1 : (1 << d);
+        const int nodes_c = layout == WX_LAYOUT_DWT ? 1 : (1 << (d + 1));
+        D.cur = bufs[(d + 1) & 1]; D.cur_cols = nodes_c;
+        if (d == 0) { D.out = x; D.out_cols = 1; } else { D.out = bufs[d & 1]; D.out_cols = nodes_d; }
+        const int sm_mode = sm >= 0 ? 1 : 0;
+        const int64_t per_node = sm_mode ? (n >> d) : n;
+        const int64_t total = batch * nodes_d * per_node;
+        hipLaunchKernelGGL(k_swt_inv_level<T>, dim3(wx_grid1(total)), dim3(256), 0, st, D, (int)n, batch, sm_mode,
+                           sm >= 0 ? (int)sd[d] : 0, sm >= 0 ? (int)sd[d + 1] : 0, filt);
+    }
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
+template <typename T>
+int wx_dev_iacdwt(const T *xw, T *x, int64_t n, int L, int64_t batch, hipStream_t st)
+{
+    if (batch == 0 || n == 0) return WX_OK;
+    hipLaunchKernelGGL(k_iacdwt<T>, dim3(wx_grid1(batch * n)), dim3(256), 0, st, xw, x, (int)n, L, batch);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+template <typename T>
+int wx_dev_iacwpt(const T *xw, T *x, int64_t n, int L, int64_t batch, hipStream_t st)
+{
+    if (batch == 0 || n == 0) return WX_OK;
+    hipLaunchKernelGGL(k_iacwpt<T>, dim3(wx_grid1(batch * n)), dim3(256), 0, st, xw, x, (int)n, L, batch);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+template <typename T>
+int wx_dev_iacwpd(const T *xw, T *x, int64_t n, int ncols, int64_t batch, const uint8_t *dtree, int64_t ntree,
+                  int Lfull, hipStream_t st)
+{
+    if (batch == 0 || n == 0) return WX_OK;
+    hipLaunchKernelGGL(k_iacwpd<T>, dim3(wx_grid1(batch * n)), dim3(256), 0, st, xw, x, (int)n, ncols, batch, dtree,
+                       ntree, Lfull);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
+#define WX_INST(T)                                                                                              \
+    template int wx_dev_swt_fwd<T>(const T *, T *, int64_t, int, int, int64_t, const WxFilt &, const WxAcFilt *, \
+                                   hipStream_t);                                                                \
+    template int wx_dev_swt_inv<T>(const T *, T *, int64_t, int, int, int, int64_t, int64_t, const uint8_t *,    \
+                                   int64_t, const WxFilt &, T *, T *, hipStream_t);                             \
+    template int wx_dev_iacdwt<T>(const T *, T *, int64_t, int, int64_t, hipStream_t);                          \
+    template int wx_dev_iacwpt<T>(const T *, T *, int64_t, int, int64_t, hipStream_t);                          \
+    template int wx_dev_iacwpd<T>(const T *, T *, int64_t, int, int64_t, const uint8_t *, int64_t, int, hipStream_t);
+WX_INST(double)
+WX_INST(float)
