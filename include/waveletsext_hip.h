@@ -88,6 +88,30 @@ int wx_getbasiscoef1d_f32(const float *Xw, float *out, int64_t n, int k, const u
 
 
 /* ------------------------------------------------------------------------------------------
+ * 2-D decimated wavelet packets (quad trees, heap order, children 4i-2..4i+1 =
+ * top-left, top-right, bottom-left, bottom-right; utils/utils_tree.jl:57-75)
+ * Images are (m, n) column-major; batch is the last dimension.
+ * ------------------------------------------------------------------------------------------ */
+/* wpd!(y, x, wt, L) DWT.jl:164-209 / wpdall dwt/dwt_all.jl:260-282.  x (m,n,batch) -> y (m,n,L+1,batch) */
+int wx_wpd2d_f64(const double *x, double *y, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_wpd2d_f32(const float *x, float *y, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+/* wpt!(y, x, wt, L | tree) DWT.jl:493-548 / wptall dwt/dwt_all.jl:152-166 */
+int wx_wpt2d_f64(const double *x, double *y, int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
+                 const double *qmf, int F, void *stream);
+int wx_wpt2d_f32(const float *x, float *y, int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
+                 const double *qmf, int F, void *stream);
+/* iwpt!(xhat, xw, wt, L | tree) DWT.jl:655-710 / iwptall dwt/dwt_all.jl:210-225 */
+int wx_iwpt2d_f64(const double *xw, double *xhat, int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream);
+int wx_iwpt2d_f32(const float *xw, float *xhat, int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream);
+/* iwpd!(xhat, xw, wt, L | tree) DWT.jl:331-337,354-401 / iwpdall; xw (m,n,k,batch) */
+int wx_iwpd2d_f64(const double *xw, double *xhat, int64_t m, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream);
+int wx_iwpd2d_f32(const float *xw, float *xhat, int64_t m, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * 1-D stationary (undecimated) transforms -- SWT.jl, swt/swt_all.jl
  * `sm` is the shift of the shift-based inverse (SWT.jl:259-284, 613-646, 1063-1093);
  * sm < 0 selects the average-based inverse (SWT.jl:313-330, 685-712, 1137-1160).

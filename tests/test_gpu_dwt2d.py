@@ -1,0 +1,77 @@
+"""GPU parity: 2-D decimated wavelet packets (quad trees) vs the CPU oracle.  Float64 1e-10,
+Float32 1e-5 (config 4 is Float32)."""
+import numpy as np
+import pytest
+
+from helpers import TOL, random_tree_2d, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _wt(wx, name):
+    return wx.wavelet(getattr(wx.WT, name))
+
+
+def _stack(fn, X, *a):
+    return np.asfortranarray(np.stack([fn(np.asfortranarray(X[..., i]), *a) for i in range(X.shape[-1])], axis=-1))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("wname", ["haar", "db4", "coif6"])
+def test_wpd2d_and_wpt2d(wx, oracle, wname, dtype):
+    rng = np.random.default_rng(3001)
+    wt = _wt(wx, wname)
+    tol = TOL[np.dtype(dtype)]
+    for (m, n), B in (((2, 2), 2), ((8, 8), 3), ((16, 32), 2), ((24, 8), 2), ((64, 64), 2)):
+        x = np.asfortranarray(rng.standard_normal((m, n, B)).astype(dtype))
+        Lmax = wx.maxtransformlevels(min(m, n))
+        for L in sorted({0, 1, Lmax}):
+            got = wx.wpdall(x, wt, L)
+            assert got.shape == (m, n, L + 1, B)
+            assert relerr(got, _stack(oracle.wpd, x, wt.qmf, L)) <= tol, (m, n, L)
+        trees = [None, 1, wx.maketree(m, n, Lmax, "dwt"), random_tree_2d(m, n, rng), random_tree_2d(m, n, rng, 0.85)]
+        for arg in trees:
+            exp = _stack(oracle.wpt, x, wt.qmf, arg)
+            got = wx.wptall(x, wt, arg)
+            assert relerr(got, exp) <= tol, (m, n)
+            back = wx.iwptall(exp, wt, arg)
+            assert relerr(back, _stack(oracle.iwpt, exp, wt.qmf, arg)) <= tol
+            assert relerr(back, x) <= 20 * tol
+        # single-image methods, and wpd slices == wpt by level (test/transforms.jl:36-43)
+        z = wx.wpt(x[:, :, 0], wt, 1)
+        assert relerr(z, wx.wpd(x[:, :, 0], wt)[:, :, 1] if Lmax >= 1 else x[:, :, 0]) <= tol
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_iwpd2d(wx, oracle, dtype):
+    rng = np.random.default_rng(3002)
+    wt = _wt(wx, "db4")
+    tol = TOL[np.dtype(dtype)]
+    for (m, n), B in (((8, 8), 3), ((32, 16), 2)):
+        x = np.asfortranarray(rng.standard_normal((m, n, B)).astype(dtype))
+        Lmax = wx.maxtransformlevels(min(m, n))
+        xw = _stack(oracle.wpd, x, wt.qmf, Lmax)
+        for arg in [None, 2, wx.maketree(m, n, Lmax, "dwt"), random_tree_2d(m, n, rng), random_tree_2d(m, n, rng, 0.85)]:
+            got = wx.iwpdall(xw, wt, arg)
+            assert relerr(got, _stack(oracle.iwpd, xw, wt.qmf, arg)) <= tol
+            assert relerr(got, x) <= 20 * tol
+        assert relerr(wx.iwpd(xw[..., 0], wt), x[..., 0]) <= 20 * tol
+        with pytest.raises(IndexError):
+            wx.iwpdall(xw[:, :, :2, :], wt, Lmax)          # needs slice L+1: BoundsError in the reference
+
+
+def test_config4_shape_float32_properties(wx):
+    """BASELINE config 4 geometry (512x512 Float32, db4, L=6) on a reduced batch: energy is
+    preserved by the orthogonal transform and iwpt(wpt(x)) == x within Float32 tolerance."""
+    import torch
+    wt = _wt(wx, "db4")
+    B = 64
+    g = torch.Generator(device="cuda").manual_seed(1004)
+    x = wx.jl_empty((512, 512, B), torch.float32, "cuda")
+    x.normal_(generator=g)
+    y = wx.wptall(x, wt, 6)
+    e0 = (x.double() ** 2).sum(dim=(0, 1))
+    e1 = (y.double() ** 2).sum(dim=(0, 1))
+    assert float(((e1 - e0).abs() / e0).max()) < 1e-5
+    back = wx.iwptall(y, wt, 6)
+    assert float((back - x).abs().max() / x.abs().max()) < 1e-5

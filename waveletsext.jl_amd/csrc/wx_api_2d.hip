@@ -1,0 +1,185 @@
+// wx_api_2d.hip -- C ABI for the 2-D decimated wavelet-packet family (quad trees).
+#include "../../include/waveletsext_hip.h"
+#include "wx_host.h"
+#include "wx_kernels.h"
+
+#define WX_REQUIRE(cond, code, msg) \
+    do { if (!(cond)) return wx_set_error(code, msg); } while (0)
+
+static int wx_need_device3()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        return wx_set_error(WX_EHIP, "no HIP device visible: the MI355X kernels cannot run");
+    }
+    return WX_OK;
+}
+
+// leaf depth of every (2^Leff x 2^Leff) block, quad-tree traversal of getbasiscoef (Utils.jl:117-131)
+static void wx_colmap2d_rec(const uint8_t *tree, int64_t ntree, int64_t node, int d, int j, int k, int Leff,
+                            std::vector<int> &col)
+{
+    const int nblk = 1 << Leff;
+    if (node <= ntree && tree[node - 1]) {
+        for (int c = 0; c < 4; ++c)
+            wx_colmap2d_rec(tree, ntree, 4 * node - 2 + c, d + 1, 2 * j + (c >> 1), 2 * k + (c & 1), Leff, col);
+    } else {
+        const int w = 1 << (Leff - d);
+        for (int r = j * w; r < (j + 1) * w; ++r)
+            for (int c = k * w; c < (k + 1) * w; ++c) col[(size_t)r * nblk + c] = d;
+    }
+}
+
+struct WxTree2d {
+    int Leff = 0;
+    bool full = true;
+    const uint8_t *dstatus = nullptr;
+    int64_t nstatus = 0;
+};
+
+static int wx_check_tree2d(int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree)
+{
+    const int L0 = wx_maxtransformlevels(m < n ? m : n);
+    if (!tree) {
+        WX_REQUIRE(0 <= L && L <= L0, WX_EASSERT, "maketree(n, m, L): @assert 0 <= L <= L0 (utils_tree.jl:196)");
+        return WX_OK;
+    }
+    WX_REQUIRE(wx_isvalidtree2d(m, n, tree, ntree), WX_EASSERT, "@assert isvalidtree(x, tree) (DWT.jl:504,666)");
+    return WX_OK;
+}
+
+static int wx_resolve_tree2d(int L, const uint8_t *tree, int64_t ntree, WxScratch &scr, WxTree2d *out)
+{
+    if (!tree) { out->Leff = L; out->full = true; return WX_OK; }
+    out->Leff = wx_tree_depth2d(tree, ntree);
+    int64_t nfull = 0, p = 1;
+    for (int i = 0; i < out->Leff; ++i) { nfull += p; p *= 4; }
+    bool full = true;
+    for (int64_t i = 1; i <= nfull && full; ++i) full = tree[i - 1] != 0;
+    out->full = full;
+    if (!full) {
+        out->dstatus = (const uint8_t *)scr.upload(tree, (size_t)ntree);
+        if (!out->dstatus) return WX_EHIP;
+        out->nstatus = ntree;
+    }
+    return WX_OK;
+}
+
+template <typename T>
+static int api_wpd2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream)
+{
+    WxFilt filt;
+    int rc = wx_pack_filter(qmf, F, &filt);
+    if (rc) return rc;
+    WX_REQUIRE(m >= 1 && n >= 1 && batch >= 0, WX_EARG, "wpd: bad dimensions");
+    WX_REQUIRE(0 <= L && L <= wx_maxtransformlevels(m < n ? m : n), WX_EASSERT,
+               "wpd!: @assert 0 <= L <= maxtransformlevels(x) (DWT.jl:169)");
+    WX_REQUIRE(m < ((int64_t)1 << 30) && n < ((int64_t)1 << 30), WX_EUNSUPPORTED, "image side >= 2^30");
+    if ((rc = wx_need_device3())) return rc;
+    hipStream_t st = wx_stream(stream);
+    WxScratch scr(st);
+    WxIO io(st);
+    const T *dx = (const T *)io.in(x, sizeof(T) * m * n * batch);
+    T *dy = (T *)io.out(y, sizeof(T) * m * n * (L + 1) * batch);
+    if (batch && (!dx || !dy)) return io.finish(WX_EHIP);
+    T *tmp = nullptr;
+    if (batch && L > 0) { tmp = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!tmp) return io.finish(WX_EHIP); }
+    rc = wx_dev_wpd2d<T>(dx, dy, m, n, L, batch, filt, tmp, st);
+    return io.finish(rc);
+}
+
+template <typename T, bool INVERSE>
+static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree,
+                     int64_t batch, const double *qmf, int F, void *stream)
+{
+    WxFilt filt;
+    int rc = wx_pack_filter(qmf, F, &filt);
+    if (rc) return rc;
+    WX_REQUIRE(m >= 1 && n >= 1 && batch >= 0, WX_EARG, "wpt: bad dimensions");
+    WX_REQUIRE(m < ((int64_t)1 << 30) && n < ((int64_t)1 << 30), WX_EUNSUPPORTED, "image side >= 2^30");
+    if ((rc = wx_check_tree2d(m, n, L, tree, ntree))) return rc;
+    if ((rc = wx_need_device3())) return rc;
+    hipStream_t st = wx_stream(stream);
+    WxScratch scr(st);
+    WxTree2d tr;
+    if ((rc = wx_resolve_tree2d(L, tree, ntree, scr, &tr))) return rc;
+    WxIO io(st);
+    const T *dx = (const T *)io.in(x, sizeof(T) * m * n * batch);
+    T *dy = (T *)io.out(y, sizeof(T) * m * n * batch);
+    if (batch && (!dx || !dy)) return io.finish(WX_EHIP);
+    T *tmp = nullptr, *pong = nullptr;
+    if (batch && tr.Leff > 0) { tmp = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!tmp) return io.finish(WX_EHIP); }
+    if (batch && tr.Leff > 1) { pong = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!pong) return io.finish(WX_EHIP); }
+    rc = wx_dev_wpt2d<T>(dx, dy, m, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, tmp, pong, INVERSE, m * n, st);
+    return io.finish(rc);
+}
+
+template <typename T>
+static int api_iwpd2d(const T *xw, T *xh, int64_t m, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree,
+                      int64_t batch, const double *qmf, int F, void *stream)
+{
+    WxFilt filt;
+    int rc = wx_pack_filter(qmf, F, &filt);
+    if (rc) return rc;
+    WX_REQUIRE(m >= 1 && n >= 1 && batch >= 0 && k >= 1, WX_EARG, "iwpd: bad dimensions");
+    WX_REQUIRE(m < ((int64_t)1 << 30) && n < ((int64_t)1 << 30), WX_EUNSUPPORTED, "image side >= 2^30");
+    if ((rc = wx_check_tree2d(m, n, L, tree, ntree))) return rc;
+    const int Leff = tree ? wx_tree_depth2d(tree, ntree) : L;
+    WX_REQUIRE(Leff < k, WX_EBOUNDS, "iwpd!: the tree needs slice d+2 beyond size(xw,3) (DWT.jl:383-386)");
+    if ((rc = wx_need_device3())) return rc;
+    hipStream_t st = wx_stream(stream);
+    WxScratch scr(st);
+    WxTree2d tr;
+    if ((rc = wx_resolve_tree2d(L, tree, ntree, scr, &tr))) return rc;
+    WxIO io(st);
+    const int64_t mn = m * n;
+    const T *dxw = (const T *)io.in(xw, sizeof(T) * mn * k * batch);
+    T *dxh = (T *)io.out(xh, sizeof(T) * mn * batch);
+    if (batch && (!dxw || !dxh)) return io.finish(WX_EHIP);
+    T *tmp = nullptr, *pong = nullptr, *leaves = nullptr;
+    if (batch && tr.Leff > 0) { tmp = (T *)scr.alloc(sizeof(T) * mn * batch); if (!tmp) return io.finish(WX_EHIP); }
+    if (batch && tr.Leff > 1) { pong = (T *)scr.alloc(sizeof(T) * mn * batch); if (!pong) return io.finish(WX_EHIP); }
+    const T *src = dxw + (int64_t)tr.Leff * mn;      // full tree: every leaf is in slice Leff
+    int64_t in_img = mn * k;
+    if (!tr.full) {
+        std::vector<int> col((size_t)1 << (2 * tr.Leff), 0);
+        wx_colmap2d_rec(tree, ntree, 1, 0, 0, 0, tr.Leff, col);
+        const int *dcol = (const int *)scr.upload(col.data(), col.size() * sizeof(int));
+        if (!dcol) return io.finish(WX_EHIP);
+        if (batch) { leaves = (T *)scr.alloc(sizeof(T) * mn * batch); if (!leaves) return io.finish(WX_EHIP); }
+        rc = wx_dev_gather_leaves2d<T>(dxw, leaves, m, n, k, batch, dcol, 1 << tr.Leff, st);
+        if (rc) return io.finish(rc);
+        src = leaves;
+        in_img = mn;
+    }
+    rc = wx_dev_wpt2d<T>(src, dxh, m, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, tmp, pong, true, in_img, st);
+    return io.finish(rc);
+}
+
+extern "C" {
+
+int wx_wpd2d_f64(const double *x, double *y, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream)
+{ return api_wpd2d<double>(x, y, m, n, L, batch, qmf, F, stream); }
+int wx_wpd2d_f32(const float *x, float *y, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream)
+{ return api_wpd2d<float>(x, y, m, n, L, batch, qmf, F, stream); }
+int wx_wpt2d_f64(const double *x, double *y, int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
+                 const double *qmf, int F, void *stream)
+{ return api_wpt2d<double, false>(x, y, m, n, L, tree, ntree, batch, qmf, F, stream); }
+int wx_wpt2d_f32(const float *x, float *y, int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
+                 const double *qmf, int F, void *stream)
+{ return api_wpt2d<float, false>(x, y, m, n, L, tree, ntree, batch, qmf, F, stream); }
+int wx_iwpt2d_f64(const double *xw, double *xhat, int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream)
+{ return api_wpt2d<double, true>(xw, xhat, m, n, L, tree, ntree, batch, qmf, F, stream); }
+int wx_iwpt2d_f32(const float *xw, float *xhat, int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream)
+{ return api_wpt2d<float, true>(xw, xhat, m, n, L, tree, ntree, batch, qmf, F, stream); }
+int wx_iwpd2d_f64(const double *xw, double *xhat, int64_t m, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream)
+{ return api_iwpd2d<double>(xw, xhat, m, n, k, L, tree, ntree, batch, qmf, F, stream); }
+int wx_iwpd2d_f32(const float *xw, float *xhat, int64_t m, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree,
+                  int64_t batch, const double *qmf, int F, void *stream)
+{ return api_iwpd2d<float>(xw, xhat, m, n, k, L, tree, ntree, batch, qmf, F, stream); }
+
+}  // extern "C"

@@ -1,0 +1,254 @@
+// wx_dwt2d.hip -- batched 2-D decimated wavelet-packet kernels (quad trees) for gfx950.
+//
+// Reference semantics (paths relative to /root/reference/src/mod):
+//   dwt_step! 2-D   dwt/dwt_one_level.jl:319-354  1-D step down every column (dim 1) into temp
+//                   (low rows on top), then along every row (dim 2):  w1 = top-left (low,low),
+//                   w2 = top-right (low dim1, high dim2), w3 = bottom-left, w4 = bottom-right
+//   idwt_step! 2-D  dwt/dwt_one_level.jl:401-436  rows first, then columns
+//   wpd! 2-D        DWT.jl:164-209   slice d+1 holds all 4^d nodes of depth d
+//   wpt!/iwpt! 2-D  DWT.jl:500-548, 662-710 (quad tree in heap order, children 4i-2..4i+1)
+//   iwpd! 2-D       DWT.jl:354-401
+// Quad-tree geometry (Utils.jl:465-542, utils_tree.jl:57-99): the node at depth d whose path has
+// child codes c_1..c_d (0 TL, 1 TR, 2 BL, 3 BR) covers row block sum (c_t>>1) 2^(d-t) and column
+// block sum (c_t&1) 2^(d-t); its heap index is (4^d-1)/3 + 1 + morton(rowblock, colblock).
+//
+// Images are column-major (m rows contiguous).  Consecutive lanes always walk dim 1 so every
+// global access is coalesced; a level is two passes (columns, rows) through a scratch image.
+#include "wx_common.h"
+#include "wx_kernels.h"
+
+static __device__ __forceinline__ int64_t wx_quad_heap(int d, int j, int k)
+{
+    int64_t start = 1, mort = 0;
+    for (int t = d - 1; t >= 0; --t) {
+        mort = (mort << 2) | ((int64_t)((j >> t) & 1) << 1) | (int64_t)((k >> t) & 1);
+        start = 4 * start - 2;
+    }
+    return start + mort;
+}
+
+static __device__ __forceinline__ bool wx_quad_active(const uint8_t *status, int64_t nstatus, int d, int j, int k)
+{
+    if (!status) return true;
+    const int64_t h = wx_quad_heap(d, j, k);
+    return h <= nstatus && status[h - 1];
+}
+
+// pass along dim 1 (columns).  INVERSE = false: analysis (src node -> [low; high] rows);
+// INVERSE = true: synthesis ([low; high] rows -> node).  One thread per output pair.
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void k_dwt2d_dim1(const T *__restrict__ src, T *__restrict__ dst,
+                                                    int64_t src_img, int64_t dst_img, int m, int n, int d,
+                                                    int64_t batch, WxFilt filt, const uint8_t *__restrict__ status,
+                                                    int64_t nstatus)
+{
+    const int mp = m >> d, np = n >> d, h = mp >> 1, mh = m >> 1;
+    const int64_t total = (int64_t)batch * n * mh;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(g % mh);
+        const int64_t g2 = g / mh;
+        const int c = (int)(g2 % n);
+        const int64_t b = g2 / n;
+        const int j = i / h, t = i - j * h;
+        const T *v = src + b * src_img + (int64_t)c * m + (int64_t)j * mp;
+        T *o = dst + b * dst_img + (int64_t)c * m + (int64_t)j * mp;
+        if (!wx_quad_active(status, nstatus, d, j, c / np)) {
+            o[2 * t] = v[2 * t];
+            o[2 * t + 1] = v[2 * t + 1];
+            continue;
+        }
+        if (!INVERSE) {
+            double a = 0.0, dd = 0.0;
+            int k1 = 2 * t, k2 = 2 * t + 1;
+            if (k1 >= mp) k1 -= mp;
+            if (k2 >= mp) k2 -= mp;
+            for (int k = 0; k < filt.F; ++k) {
+                a = fma(filt.q[k], (double)v[k1], a);
+                dd = fma((k & 1) ? -filt.q[k] : filt.q[k], (double)v[k2], dd);
+                k1 = k1 + 1 == mp ? 0 : k1 + 1;
+                k2 = k2 == 0 ? mp - 1 : k2 - 1;
+            }
+            o[t] = (T)a;
+            o[h + t] = (T)dd;
+        } else {
+            double v0 = 0.0, v1 = 0.0;
+            int k1 = t, k2 = t;
+            for (int mm = 0; mm < filt.F / 2; ++mm) {
+                const double av = (double)v[k1], dv = (double)v[h + k2];
+                v0 = fma(filt.q[2 * mm], av, v0);
+                v0 = fma(-filt.q[2 * mm + 1], dv, v0);
+                v1 = fma(filt.q[2 * mm + 1], av, v1);
+                v1 = fma(filt.q[2 * mm], dv, v1);
+                k1 = k1 == 0 ? h - 1 : k1 - 1;
+                k2 = k2 + 1 == h ? 0 : k2 + 1;
+            }
+            o[2 * t] = (T)v0;
+            o[2 * t + 1] = (T)v1;
+        }
+    }
+}
+
+// pass along dim 2 (rows): lanes run over rows r, each thread owns one output pair of one row
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void k_dwt2d_dim2(const T *__restrict__ src, T *__restrict__ dst,
+                                                    int64_t src_img, int64_t dst_img, int m, int n, int d,
+                                                    int64_t batch, WxFilt filt, const uint8_t *__restrict__ status,
+                                                    int64_t nstatus)
+{
+    const int mp = m >> d, np = n >> d, h = np >> 1, nh = n >> 1;
+    const int64_t total = (int64_t)batch * nh * m;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(g % m);
+        const int64_t g2 = g / m;
+        const int jj = (int)(g2 % nh);
+        const int64_t b = g2 / nh;
+        const int k = jj / h, t = jj - k * h;
+        const T *v = src + b * src_img + r + (int64_t)k * np * m;   // column 0 of the node block
+        T *o = dst + b * dst_img + r + (int64_t)k * np * m;
+        if (!wx_quad_active(status, nstatus, d, r / mp, k)) {
+            o[(int64_t)(2 * t) * m] = v[(int64_t)(2 * t) * m];
+            o[(int64_t)(2 * t + 1) * m] = v[(int64_t)(2 * t + 1) * m];
+            continue;
+        }
+        if (!INVERSE) {
+            double a = 0.0, dd = 0.0;
+            int k1 = 2 * t, k2 = 2 * t + 1;
+            if (k1 >= np) k1 -= np;
+            if (k2 >= np) k2 -= np;
+            for (int kk = 0; kk < filt.F; ++kk) {
+                a = fma(filt.q[kk], (double)v[(int64_t)k1 * m], a);
+                dd = fma((kk & 1) ? -filt.q[kk] : filt.q[kk], (double)v[(int64_t)k2 * m], dd);
+                k1 = k1 + 1 == np ? 0 : k1 + 1;
+                k2 = k2 == 0 ? np - 1 : k2 - 1;
+            }
+            o[(int64_t)t * m] = (T)a;
+            o[(int64_t)(h + t) * m] = (T)dd;
+        } else {
+            double v0 = 0.0, v1 = 0.0;
+            int k1 = t, k2 = t;
+            for (int mm = 0; mm < filt.F / 2; ++mm) {
+                const double av = (double)v[(int64_t)k1 * m], dv = (double)v[(int64_t)(h + k2) * m];
+                v0 = fma(filt.q[2 * mm], av, v0);
+                v0 = fma(-filt.q[2 * mm + 1], dv, v0);
+                v1 = fma(filt.q[2 * mm + 1], av, v1);
+                v1 = fma(filt.q[2 * mm], dv, v1);
+                k1 = k1 == 0 ? h - 1 : k1 - 1;
+                k2 = k2 + 1 == h ? 0 : k2 + 1;
+            }
+            o[(int64_t)(2 * t) * m] = (T)v0;
+            o[(int64_t)(2 * t + 1) * m] = (T)v1;
+        }
+    }
+}
+
+// getbasiscoef 2-D (Utils.jl:127-130): out[r,c] = Xw[r, c, depth of the leaf that owns (r,c)]
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_leaves2d(const T *__restrict__ Xw, T *__restrict__ out, int m,
+                                                         int n, int k, int64_t batch,
+                                                         const int *__restrict__ colmap, int nblk, int blk_r,
+                                                         int blk_c)
+{
+    const int64_t mn = (int64_t)m * n, total = batch * mn;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = g / mn;
+        const int64_t e = g - b * mn;
+        const int r = (int)(e % m), c = (int)(e / m);
+        const int dsl = colmap[(r / blk_r) * nblk + (c / blk_c)];
+        out[g] = Xw[(b * k + dsl) * mn + e];
+    }
+}
+
+static int wx_grid2(int64_t total)
+{
+    int64_t g = (total + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <typename T, bool INVERSE>
+static void wx_launch_level2d(const T *src, T *tmp, T *dst, int64_t src_img, int64_t dst_img, int m, int n, int d,
+                              int64_t batch, const WxFilt &filt, const uint8_t *status, int64_t nstatus,
+                              hipStream_t st)
+{
+    const int64_t mn = (int64_t)m * n;
+    const int g = wx_grid2(batch * mn / 2);
+    if (!INVERSE) {
+        hipLaunchKernelGGL((k_dwt2d_dim1<T, false>), dim3(g), dim3(256), 0, st, src, tmp, src_img, mn, m, n, d, batch,
+                           filt, status, nstatus);
+        hipLaunchKernelGGL((k_dwt2d_dim2<T, false>), dim3(g), dim3(256), 0, st, (const T *)tmp, dst, mn, dst_img, m, n,
+                           d, batch, filt, status, nstatus);
+    } else {
+        hipLaunchKernelGGL((k_dwt2d_dim2<T, true>), dim3(g), dim3(256), 0, st, src, tmp, src_img, mn, m, n, d, batch,
+                           filt, status, nstatus);
+        hipLaunchKernelGGL((k_dwt2d_dim1<T, true>), dim3(g), dim3(256), 0, st, (const T *)tmp, dst, mn, dst_img, m, n,
+                           d, batch, filt, status, nstatus);
+    }
+}
+
+// wpd 2-D: y is (m, n, L+1, batch); tmp holds m*n*batch elements
+template <typename T>
+int wx_dev_wpd2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const WxFilt &filt, T *tmp,
+                 hipStream_t st)
+{
+    if (batch == 0 || m * n == 0) return WX_OK;
+    const int64_t mn = m * n, yimg = mn * (L + 1);
+    WX_HIP_CHECK(hipMemcpy2DAsync(y, yimg * sizeof(T), x, mn * sizeof(T), mn * sizeof(T), batch,
+                                  hipMemcpyDeviceToDevice, st));
+    for (int d = 0; d < L; ++d)
+        wx_launch_level2d<T, false>(y + d * mn, tmp, y + (d + 1) * mn, yimg, yimg, (int)m, (int)n, d, batch, filt,
+                                    nullptr, 0, st);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
+// wpt / iwpt 2-D on (m, n, batch); tmp and pong hold m*n*batch elements each (pong only if L > 1)
+template <typename T>
+int wx_dev_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const WxFilt &filt,
+                 const uint8_t *status, int64_t nstatus, T *tmp, T *pong, bool inverse, int64_t in_img,
+                 hipStream_t st)
+{
+    if (batch == 0 || m * n == 0) return WX_OK;
+    const int64_t mn = m * n;
+    if (L == 0) {
+        WX_HIP_CHECK(hipMemcpy2DAsync(y, mn * sizeof(T), x, in_img * sizeof(T), mn * sizeof(T), batch,
+                                      hipMemcpyDeviceToDevice, st));
+        return WX_OK;
+    }
+    const T *src = x;
+    int64_t src_img = in_img;
+    for (int s = 0; s < L; ++s) {
+        const int d = inverse ? L - 1 - s : s;
+        T *dst = ((L - 1 - s) & 1) ? pong : y;                 // last step lands in y
+        if (inverse)
+            wx_launch_level2d<T, true>(src, tmp, dst, src_img, mn, (int)m, (int)n, d, batch, filt, status, nstatus, st);
+        else
+            wx_launch_level2d<T, false>(src, tmp, dst, src_img, mn, (int)m, (int)n, d, batch, filt, status, nstatus, st);
+        src = dst;
+        src_img = mn;
+    }
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
+template <typename T>
+int wx_dev_gather_leaves2d(const T *Xw, T *out, int64_t m, int64_t n, int k, int64_t batch, const int *colmap,
+                           int nblk, hipStream_t st)
+{
+    if (batch == 0 || m * n == 0) return WX_OK;
+    hipLaunchKernelGGL(k_gather_leaves2d<T>, dim3(wx_grid2(batch * m * n)), dim3(256), 0, st, Xw, out, (int)m, (int)n,
+                       k, batch, colmap, nblk, (int)(m / nblk), (int)(n / nblk));
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
+#define WX_INST(T)                                                                                            \
+    template int wx_dev_wpd2d<T>(const T *, T *, int64_t, int64_t, int, int64_t, const WxFilt &, T *, hipStream_t); \
+    template int wx_dev_wpt2d<T>(const T *, T *, int64_t, int64_t, int, int64_t, const WxFilt &, const uint8_t *,  \
+                                 int64_t, T *, T *, bool, int64_t, hipStream_t);                              \
+    template int wx_dev_gather_leaves2d<T>(const T *, T *, int64_t, int64_t, int, int64_t, const int *, int, hipStream_t);
+WX_INST(double)
+WX_INST(float)

@@ -41,3 +41,15 @@ int wx_dev_jbb_moments(const T *X, T *sum, T *sumsq, int64_t nk, int64_t batch, 
 template <typename T>
 int wx_dev_jbb_costs(const T *sum, const T *sumsq, int64_t Ntot, int64_t n, int64_t k, int redundant,
                      int cost_kind, double p, T *costs, hipStream_t st);
+
+// ---- 2-D decimated (wx_dwt2d.hip) ----
+template <typename T>
+int wx_dev_wpd2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const WxFilt &filt, T *tmp,
+                 hipStream_t st);
+template <typename T>
+int wx_dev_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const WxFilt &filt,
+                 const uint8_t *status, int64_t nstatus, T *tmp, T *pong, bool inverse, int64_t in_img,
+                 hipStream_t st);
+template <typename T>
+int wx_dev_gather_leaves2d(const T *Xw, T *out, int64_t m, int64_t n, int k, int64_t batch, const int *colmap,
+                           int nblk, hipStream_t st);
