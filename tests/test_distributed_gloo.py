@@ -1,0 +1,92 @@
+"""N > 1 path on CPU: world_size-2 `gloo` processes exercise the batch sharding, the C1 all-gather
+of reconstructed output and the C2 all-reduce of JBB moments (the per-rank compute stand-in is the
+oracle, since there is no GPU here; on the MI355X node the same functions run over RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, B, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import waveletsext_jl_amd as wx
+    from waveletsext_jl_amd import distributed as wd   # noqa
+    import wx_oracle as wo
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(99)                       # same full batch on every rank
+        n = 32
+        X = np.asfortranarray(rng.standard_normal((n, B)))
+        q = wx.wavelet(wx.WT.db4).qmf
+        lo, hi = wd.shard_range(B, world, rank)
+        xl = np.asfortranarray(X[:, lo:hi])
+        # transforms are per-signal: shard -> local wpdall -> local iwpdall, no collective
+        yl = wo.wpdall(xl, q)
+        xr = wo.iwpdall(yl, q)
+        t_local = torch.from_numpy(np.ascontiguousarray(xr.T)).T       # column-major (n, B_r)
+        full = wd.allgather_batch(t_local, B)
+        assert tuple(full.shape) == (n, B)
+        np.testing.assert_allclose(full.numpy(), X, atol=1e-12)
+        # 3-D shards gather too (packet tables)
+        t3 = torch.from_numpy(np.ascontiguousarray(yl.transpose(2, 1, 0))).permute(2, 1, 0)
+        full3 = wd.allgather_batch(t3, B)
+        np.testing.assert_array_equal(full3.numpy(), wo.wpdall(X, q))
+        # C2: JBB moments of the local shard, all-reduced == moments of the whole batch
+        s = torch.from_numpy(np.ascontiguousarray(yl.sum(axis=2).T)).T
+        qq = torch.from_numpy(np.ascontiguousarray((yl ** 2).sum(axis=2).T)).T
+        s, qq = wd.allreduce_moments(s, qq)
+        Y = wo.wpdall(X, q)
+        np.testing.assert_allclose(s.numpy(), Y.sum(axis=2), rtol=0, atol=1e-11)
+        np.testing.assert_allclose(qq.numpy(), (Y ** 2).sum(axis=2), rtol=0, atol=1e-10)
+        # the tree every rank derives from the reduced moments == the oracle's tree on the full batch
+        N = B
+        ex, ex2 = s.numpy() / N, qq.numpy() / N
+        sig = np.sqrt(ex2 - ex ** 2)
+        costs = []
+        for lvl in range(Y.shape[1]):
+            n0 = n >> lvl
+            for node in range(1 << lvl):
+                costs.append(2 * np.log(np.abs(sig[node * n0:(node + 1) * n0, lvl])).sum())
+        tree = wx.bestbasis_treeselection(np.array(costs), n)
+        assert (tree == wo.bestbasistree_jbb(Y)).all()
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [8, 7])
+def test_world2_gloo_shard_gather_reduce(tmp_path, B):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_shard_ranges_cover_and_are_contiguous():
+    sys.path.insert(0, ROOT)
+    import waveletsext_jl_amd  # noqa
+    from waveletsext_jl_amd import distributed as wd
+    for B in (0, 1, 7, 8, 65536, 262144 + 3):
+        for world in (1, 2, 4, 8):
+            edges = [wd.shard_range(B, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == B
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = wd.shard_sizes(B, world)
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,95 @@
+"""Multi-GPU layer: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on
+the MI355X node, "gloo" in the CPU tests).
+
+Every transform of the hot path is independent per signal (`*all` drivers loop over the last
+dimension: dwt/dwt_all.jl:277-279, swt/swt_all.jl:171-173, acwt/acwt_all.jl:254-256), so the batch
+shards contiguously across ranks -- in Julia's column-major layout a shard is one contiguous
+block -- and the transforms need NO data-path collective.  Two exchange steps exist:
+
+  C1  all-gather of the reconstructed output, only when every rank needs the whole (n, B) array;
+  C2  all-reduce(sum) of the JBB moments [sum | sumsq] (bestbasis_tree.jl:153-154 sums over the
+      signal axis), after which every rank derives the same costs and the same tree.
+"""
+import numpy as np
+
+try:
+    import torch
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    torch = None
+    dist = None
+
+
+def shard_range(B, world, rank):
+    """Contiguous batch shard [lo, hi) of rank `rank`; sizes differ by at most one signal."""
+    base, rem = divmod(int(B), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(B, world):
+    return [shard_range(B, world, r)[1] - shard_range(B, world, r)[0] for r in range(world)]
+
+
+def local_shard(x, world, rank):
+    """View of this rank's signals (last dimension) of a full-batch array."""
+    lo, hi = shard_range(x.shape[-1], world, rank)
+    return x[..., lo:hi]
+
+
+def _as_batch_major(t):
+    """(sig..., B) column-major tensor -> contiguous (B, reversed sig...) view of the same memory."""
+    return t.permute(*reversed(range(t.dim()))) if t.dim() > 1 else t
+
+
+def allgather_batch(local, B_total, group=None):
+    """C1: gather per-rank shards (sig..., B_r) into the full (sig..., B_total) array on every
+    rank.  Shards may be ragged (B_total not divisible by the world size)."""
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(B_total, world)
+    sig = tuple(local.shape[:-1])
+    rev = tuple(reversed(sig))
+    src = _as_batch_major(local).contiguous()
+    if len(set(sizes)) == 1:
+        full = torch.empty((B_total,) + rev, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(full, src, group=group)
+    else:
+        # ragged shards: pad to the largest shard (collectives need equal counts), then trim
+        smax = max(sizes)
+        padded = torch.zeros((smax,) + rev, dtype=local.dtype, device=local.device)
+        padded[: src.shape[0]] = src
+        buf = torch.empty((world * smax,) + rev, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(buf, padded, group=group)
+        full = torch.cat([buf[r * smax: r * smax + sizes[r]] for r in range(world)], dim=0)
+    return _as_batch_major(full) if full.dim() > 1 else full
+
+
+def allreduce_moments(s, q, group=None):
+    """C2: in-place all-reduce(sum) of the JBB moment arrays (one fused buffer, one collective)."""
+    fused = torch.stack([_as_batch_major(s).contiguous().reshape(-1), _as_batch_major(q).contiguous().reshape(-1)])
+    dist.all_reduce(fused, op=dist.ReduceOp.SUM, group=group)
+    shp = tuple(reversed(tuple(s.shape)))
+    s_out = _as_batch_major(fused[0].reshape(shp))
+    q_out = _as_batch_major(fused[1].reshape(shp))
+    return s_out, q_out
+
+
+def bestbasistree_sharded(X_local, N_total, method=None, group=None):
+    """bestbasistree(X, JBB(...)) (BestBasis.jl:194-201) over a batch that is sharded across
+    ranks: local moments on the GPU, one all-reduce, costs + tree selection on every rank."""
+    from . import bestbasis as bb
+    s, q = bb.jbb_moments(X_local)
+    s, q = allreduce_moments(s, q, group)
+    costs = bb.costs_from_moments(s, q, N_total, method)
+    return bb.bestbasis_treeselection(costs, X_local.shape[0])
+
+
+def acwpd_bestbasistree_sharded(x_local, wt, L, N_total, method=None, group=None):
+    """BASELINE config 5: acwpdall + JBB tree over a sharded batch without materialising the
+    decomposition; returns the BitVector on every rank."""
+    from . import bestbasis as bb
+    method = bb.JBB(redundant=True) if method is None else method
+    s, q = bb.acwpd_jbb_moments(x_local, wt, L)
+    s, q = allreduce_moments(s, q, group)
+    costs = bb.costs_from_moments(s, q, N_total, method)
+    return bb.bestbasis_treeselection(costs, x_local.shape[0])
