@@ -1,0 +1,226 @@
+# WaveletsExtHIP.jl -- reference-side binding for libwaveletsext_hip.so (delivered as source: there is no
+# Julia in the build image or on the GPU box, so this file is NOT exercised by the test suite; every
+# entry point it calls is exercised through the same C ABI by tests/ via ctypes).
+#
+# It adds methods to the generic functions of Wavelets.jl / WaveletsExt.jl for a marker wrapper type
+# `HIP(x)`, so existing user code switches the hot path by wrapping its input:
+#
+#     using Wavelets, WaveletsExt, WaveletsExtHIP
+#     xw = wpdall(HIP(x), wt, L)            # MI355X kernels instead of dwt/dwt_all.jl:260-282
+#     x̂  = iwpdall(HIP(xw), wt, tree)
+#     tr = bestbasistree(HIP(acwpdall(HIP(x), wt)), JBB(redundant=true))
+#
+# Plain `Array`s are passed as host pointers (the library stages H2D/D2H); AMDGPU.jl `ROCArray`s can be
+# passed unchanged (device pointers, asynchronous on `stream`).
+module WaveletsExtHIP
+
+using Wavelets, WaveletsExt
+import Wavelets.Transforms: wpt, wpt!, iwpt, iwpt!
+import Wavelets.Threshold: bestbasistree
+import WaveletsExt.DWT: wpd, wpd!, iwpd, iwpd!, wpdall, iwpdall, wptall, iwptall
+import WaveletsExt.SWT: sdwtall, isdwtall, swptall, iswptall, swpdall, iswpdall
+import WaveletsExt.ACWT: acdwtall, iacdwtall, acwptall, iacwptall, acwpdall, iacwpdall
+import WaveletsExt.BestBasis: tree_costs, JBB, LoglpCost, NormCost, bestbasis_treeselection
+
+export HIP
+
+const LIB = get(ENV, "WAVELETSEXT_HIP_LIB", "libwaveletsext_hip.so")
+
+"Marker wrapper: dispatches the hot path to the HIP library."
+struct HIP{T,N,A<:AbstractArray{T,N}} <: AbstractArray{T,N}
+    a::A
+end
+Base.size(x::HIP) = size(x.a)
+Base.getindex(x::HIP, i...) = getindex(x.a, i...)
+Base.parent(x::HIP) = x.a
+
+const WX_EASSERT, WX_EARG, WX_EBOUNDS = Cint(-1), Cint(-2), Cint(-3)
+
+function check(rc::Cint)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:wx_last_error, LIB), Cstring, ()))
+    rc == WX_EASSERT && throw(AssertionError(msg))
+    rc == WX_EARG && throw(ArgumentError(msg))
+    rc == WX_EBOUNDS && throw(BoundsError())
+    error("libwaveletsext_hip status $rc: $msg")
+end
+
+sfx(::Type{Float64}) = "_f64"
+sfx(::Type{Float32}) = "_f32"
+treebytes(tree::BitVector) = Vector{UInt8}(tree)
+qmfvec(wt::OrthoFilter) = Vector{Float64}(WT.qmf(wt))
+batchof(x, nsig) = prod(size(x)[(nsig+1):end])
+
+# one @eval per element type keeps the ccall symbol a compile-time constant
+for (T, S) in ((Float64, "_f64"), (Float32, "_f32"))
+    @eval begin
+        # ---- wpdall / wpd (dwt/dwt_all.jl:260-282, DWT.jl:131-209) -------------------------------------------
+        function wpdall(x::HIP{$T}, wt::OrthoFilter, L::Integer = maxtransformlevels(minimum(size(x)[1:end-1])))
+            @assert ndims(x) > 1
+            sz = size(x)[1:end-1]; N = size(x)[end]
+            y = Array{$T}(undef, (sz..., L + 1, N)); q = qmfvec(wt)
+            if length(sz) == 1
+                check(ccall(($("wx_wpd1d" * S), LIB), Cint,
+                            (Ptr{$T}, Ptr{$T}, Int64, Cint, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                            parent(x), y, sz[1], L, N, q, length(q), C_NULL))
+            else
+                check(ccall(($("wx_wpd2d" * S), LIB), Cint,
+                            (Ptr{$T}, Ptr{$T}, Int64, Int64, Cint, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                            parent(x), y, sz[1], sz[2], L, N, q, length(q), C_NULL))
+            end
+            return y
+        end
+
+        # ---- iwpdall (dwt/dwt_all.jl:324-342), by level or by tree --------------------------------------------
+        function iwpdall(xw::HIP{$T}, wt::OrthoFilter, arg = maxtransformlevels(minimum(size(xw)[1:end-2])))
+            @assert ndims(xw) > 2
+            sz = size(xw)[1:end-2]; k = size(xw)[end-1]; N = size(xw)[end]
+            x̂ = Array{$T}(undef, (sz..., N)); q = qmfvec(wt)
+            L, tree = arg isa BitVector ? (0, treebytes(arg)) : (Int(arg), UInt8[])
+            tp = isempty(tree) ? Ptr{UInt8}(C_NULL) : pointer(tree)
+            GC.@preserve tree begin
+                if length(sz) == 1
+                    check(ccall(($("wx_iwpd1d" * S), LIB), Cint,
+                                (Ptr{$T}, Ptr{$T}, Int64, Cint, Cint, Ptr{UInt8}, Int64, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                                parent(xw), x̂, sz[1], k, L, tp, length(tree), N, q, length(q), C_NULL))
+                else
+                    check(ccall(($("wx_iwpd2d" * S), LIB), Cint,
+                                (Ptr{$T}, Ptr{$T}, Int64, Int64, Cint, Cint, Ptr{UInt8}, Int64, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                                parent(xw), x̂, sz[1], sz[2], k, L, tp, length(tree), N, q, length(q), C_NULL))
+                end
+            end
+            return x̂
+        end
+
+        # ---- wptall / iwptall (dwt/dwt_all.jl:152-166, 210-225) -----------------------------------------------
+        function _wptall(sym1::Symbol, x::HIP{$T}, wt::OrthoFilter, arg)
+            @assert ndims(x) > 1
+            sz = size(x)[1:end-1]; N = size(x)[end]
+            y = similar(parent(x)); q = qmfvec(wt)
+            L, tree = arg isa BitVector ? (0, treebytes(arg)) : (Int(arg), UInt8[])
+            tp = isempty(tree) ? Ptr{UInt8}(C_NULL) : pointer(tree)
+            GC.@preserve tree begin
+                if length(sz) == 1
+                    f = sym1 === :fwd ? $("wx_wpt1d" * S) : $("wx_iwpt1d" * S)
+                    check(ccall((f, LIB), Cint,
+                                (Ptr{$T}, Ptr{$T}, Int64, Cint, Ptr{UInt8}, Int64, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                                parent(x), y, sz[1], L, tp, length(tree), N, q, length(q), C_NULL))
+                else
+                    f = sym1 === :fwd ? $("wx_wpt2d" * S) : $("wx_iwpt2d" * S)
+                    check(ccall((f, LIB), Cint,
+                                (Ptr{$T}, Ptr{$T}, Int64, Int64, Cint, Ptr{UInt8}, Int64, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                                parent(x), y, sz[1], sz[2], L, tp, length(tree), N, q, length(q), C_NULL))
+                end
+            end
+            return y
+        end
+        wptall(x::HIP{$T}, wt::OrthoFilter, arg = maxtransformlevels(minimum(size(x)[1:end-1]))) = _wptall(:fwd, x, wt, arg)
+        iwptall(x::HIP{$T}, wt::OrthoFilter, arg = maxtransformlevels(minimum(size(x)[1:end-1]))) = _wptall(:inv, x, wt, arg)
+        # single-signal methods are the batch-1 case of the same entry points
+        wpt(x::HIP{$T}, wt::OrthoFilter, arg = maxtransformlevels(parent(x))) =
+            dropdims(wptall(HIP(reshape(parent(x), size(x)..., 1)), wt, arg), dims = ndims(x) + 1)
+        iwpt(x::HIP{$T}, wt::OrthoFilter, arg = maxtransformlevels(parent(x))) =
+            dropdims(iwptall(HIP(reshape(parent(x), size(x)..., 1)), wt, arg), dims = ndims(x) + 1)
+        wpd(x::HIP{$T}, wt::OrthoFilter, L::Integer = maxtransformlevels(parent(x))) =
+            dropdims(wpdall(HIP(reshape(parent(x), size(x)..., 1)), wt, L), dims = ndims(x) + 2)
+        iwpd(xw::HIP{$T}, wt::OrthoFilter, arg = maxtransformlevels(minimum(size(xw)[1:end-1]))) =
+            dropdims(iwpdall(HIP(reshape(parent(xw), size(xw)..., 1)), wt, arg), dims = ndims(xw))
+
+        # ---- stationary family (swt/swt_all.jl) ----------------------------------------------------------------
+        function _swt_fwd(f, ncols, x::HIP{$T}, wt::OrthoFilter, L::Integer)
+            @assert ndims(x) == 2
+            n, N = size(x); q = qmfvec(wt)
+            xw = Array{$T}(undef, (n, ncols, N))
+            check(ccall((f, LIB), Cint, (Ptr{$T}, Ptr{$T}, Int64, Cint, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                        parent(x), xw, n, L, N, q, length(q), C_NULL))
+            return xw
+        end
+        sdwtall(x::HIP{$T}, wt::OrthoFilter, L::Integer = maxtransformlevels(size(x, 1))) = _swt_fwd($("wx_sdwt1d" * S), L + 1, x, wt, L)
+        swptall(x::HIP{$T}, wt::OrthoFilter, L::Integer = maxtransformlevels(size(x, 1))) = _swt_fwd($("wx_swpt1d" * S), 1 << L, x, wt, L)
+        swpdall(x::HIP{$T}, wt::OrthoFilter, L::Integer = maxtransformlevels(size(x, 1))) = _swt_fwd($("wx_swpd1d" * S), 1 << (L + 1) - 1, x, wt, L)
+
+        function isdwtall(xw::HIP{$T}, wt::OrthoFilter, sm::Integer = -1)     # sm < 0: average-based (swt_all.jl:89)
+            n, k, N = size(xw); x = Array{$T}(undef, (n, N)); q = qmfvec(wt)
+            check(ccall(($("wx_isdwt1d" * S), LIB), Cint, (Ptr{$T}, Ptr{$T}, Int64, Cint, Int64, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                        parent(xw), x, n, k - 1, sm, N, q, length(q), C_NULL))
+            return x
+        end
+        function iswptall(xw::HIP{$T}, wt::OrthoFilter, sm::Integer = -1)
+            n, m, N = size(xw); x = Array{$T}(undef, (n, N)); q = qmfvec(wt)
+            isdyadic(m) || throw(ArgumentError("Number of columns of xw is not dyadic."))
+            check(ccall(($("wx_iswpt1d" * S), LIB), Cint, (Ptr{$T}, Ptr{$T}, Int64, Cint, Int64, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                        parent(xw), x, n, ndyadicscales(m), sm, N, q, length(q), C_NULL))
+            return x
+        end
+        function iswpdall(xw::HIP{$T}, wt::OrthoFilter, arg = maxtransformlevels(size(xw, 1)), sm::Integer = -1)
+            n, m, N = size(xw); x = Array{$T}(undef, (n, N)); q = qmfvec(wt)
+            L, tree = arg isa BitVector ? (0, treebytes(arg)) : (Int(arg), UInt8[])
+            tp = isempty(tree) ? Ptr{UInt8}(C_NULL) : pointer(tree)
+            GC.@preserve tree check(ccall(($("wx_iswpd1d" * S), LIB), Cint,
+                (Ptr{$T}, Ptr{$T}, Int64, Int64, Cint, Ptr{UInt8}, Int64, Int64, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                parent(xw), x, n, m, L, tp, length(tree), sm, N, q, length(q), C_NULL))
+            return x
+        end
+    end
+end
+
+# ---- autocorrelation family (Float64 only, acwt/acwt_all.jl) ---------------------------------------------------
+function _ac_fwd(f, ncols, x::HIP{Float64}, wt::OrthoFilter, L::Integer)
+    n, N = size(x); q = qmfvec(wt)
+    xw = Array{Float64}(undef, (n, ncols, N))
+    check(ccall((f, LIB), Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Cint, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                parent(x), xw, n, L, N, q, length(q), C_NULL))
+    return xw
+end
+acdwtall(x::HIP{Float64}, wt::OrthoFilter, L::Integer = maxtransformlevels(size(x, 1))) = _ac_fwd(:wx_acdwt1d_f64, L + 1, x, wt, L)
+acwptall(x::HIP{Float64}, wt::OrthoFilter, L::Integer = maxtransformlevels(size(x, 1))) = _ac_fwd(:wx_acwpt1d_f64, 1 << L, x, wt, L)
+acwpdall(x::HIP{Float64}, wt::OrthoFilter, L::Integer = maxtransformlevels(size(x, 1))) = _ac_fwd(:wx_acwpd1d_f64, 1 << (L + 1) - 1, x, wt, L)
+
+function iacdwtall(xw::HIP{Float64}, wt = nothing)
+    n, k, N = size(xw); x = Array{Float64}(undef, (n, N))
+    check(ccall((:wx_iacdwt1d_f64, LIB), Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Cint, Int64, Ptr{Cvoid}), parent(xw), x, n, k - 1, N, C_NULL))
+    return x
+end
+function iacwptall(xw::HIP{Float64}, wt = nothing)
+    n, m, N = size(xw); x = Array{Float64}(undef, (n, N))
+    check(ccall((:wx_iacwpt1d_f64, LIB), Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Cint, Int64, Ptr{Cvoid}), parent(xw), x, n, ndyadicscales(m), N, C_NULL))
+    return x
+end
+function iacwpdall(xw::HIP{Float64}, arg = maxtransformlevels(size(xw, 1)))
+    n, m, N = size(xw); x = Array{Float64}(undef, (n, N))
+    L, tree = arg isa BitVector ? (0, treebytes(arg)) : (Int(arg), UInt8[])
+    tp = isempty(tree) ? Ptr{UInt8}(C_NULL) : pointer(tree)
+    GC.@preserve tree check(ccall((:wx_iacwpd1d_f64, LIB), Cint,
+        (Ptr{Float64}, Ptr{Float64}, Int64, Int64, Cint, Ptr{UInt8}, Int64, Int64, Ptr{Cvoid}),
+        parent(xw), x, n, m, L, tp, length(tree), N, C_NULL))
+    return x
+end
+iacwpdall(xw::HIP{Float64}, wt::Union{OrthoFilter,Nothing}, arg) = iacwpdall(xw, arg)
+
+# ---- JBB (bestbasis/bestbasis_tree.jl:150-180, BestBasis.jl:194-201) -------------------------------------------
+costkind(c::LoglpCost) = (Cint(0), Float64(c.p))
+costkind(c::NormCost) = (Cint(1), Float64(c.p))
+
+function tree_costs(X::HIP{Float64,3}, method::JBB)
+    n, k, N = size(X)
+    s = Array{Float64}(undef, (n, k)); q = similar(s)
+    check(ccall((:wx_jbb_moments_f64, LIB), Cint, (Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Cint, Ptr{Cvoid}),
+                parent(X), s, q, n * k, N, 0, C_NULL))
+    kind, p = costkind(method.cost)
+    costs = Vector{Float64}(undef, method.redundant ? k : 1 << k - 1)
+    check(ccall((:wx_jbb_costs_f64, LIB), Cint,
+                (Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Cint, Cint, Float64, Ptr{Float64}, Ptr{Cvoid}),
+                s, q, N, n, k, method.redundant, kind, p, costs, C_NULL))
+    @assert !any(isnan, costs)        # the reference's `@assert all(σ .>= 0)` (bestbasis_tree.jl:158)
+    return costs
+end
+
+function bestbasistree(X::HIP{Float64,3}, method::JBB = JBB())
+    costs = tree_costs(X, method)
+    n = size(X, 1)
+    tree = Vector{UInt8}(undef, n - 1)
+    check(ccall((:wx_treeselect_f64, LIB), Cint, (Ptr{Float64}, Int64, Int64, Cint, Ptr{UInt8}), costs, length(costs), n, 0, tree))
+    return BitVector(tree .!= 0)
+end
+
+end # module
