@@ -19,6 +19,7 @@
 //     n = odd * 2^k, signals that do not fit LDS, and filters without a fused instantiation.
 #include "wx_common.h"
 #include "wx_kernels.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------
 // generic (one level per launch)
@@ -376,14 +377,32 @@ template <typename T> bool wx_fused1d_ok(int64_t n, int F)
 template bool wx_fused1d_ok<double>(int64_t, int);
 template bool wx_fused1d_ok<float>(int64_t, int);
 
-static int wx_fused_grid(size_t lds, int64_t batch)
+static int wx_fused_grid(size_t lds, int64_t batch, int nt)
 {
     int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+    const int by_waves = 2048 / nt;                 // 32 waves per CU
+    if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > 16) per_cu = 16;
     int64_t g = (int64_t)256 * per_cu;
     if (g > batch) g = batch;
     return (int)g;
+}
+
+// threads per workgroup of the fused kernels: one lane per 4-output item of a level, capped by
+// WX_FUSED_NT (tuning knob, default 512: measured best on MI355X)
+static int wx_fused_nt(int64_t n)
+{
+    static int cap = 0;
+    if (!cap) {
+        const char *e = getenv("WX_FUSED_NT");
+        cap = e ? atoi(e) : 512;
+        if (cap != 64 && cap != 128 && cap != 256 && cap != 512 && cap != 1024) cap = 512;
+    }
+    int64_t want = n / 4;
+    int nt = 64;
+    while (nt < cap && nt < want) nt <<= 1;
+    return nt;
 }
 
 template <typename K> static hipError_t wx_allow_lds(K kernel, size_t lds)
@@ -393,18 +412,29 @@ template <typename K> static hipError_t wx_allow_lds(K kernel, size_t lds)
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
+template <typename T, int F, bool WRITE_ALL, int NT>
+static int launch_fwd_fused_FN(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
+                               const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
+{
+    const size_t lds = wx_fused_lds_bytes<T>(n);
+    auto kern = k_fwd1d_fused<T, F, NT, WRITE_ALL>;
+    WX_HIP_CHECK(wx_allow_lds(kern, lds));
+    hipLaunchKernelGGL(kern, dim3(wx_fused_grid(lds, batch, NT)), dim3(NT), lds, st, x, y, wx_log2(n), L, batch,
+                       xs, ys, filt, status, nstatus);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
 template <typename T, int F, bool WRITE_ALL>
 static int launch_fwd_fused_F(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
                               const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
 {
-    constexpr int NT = 256;
-    const size_t lds = wx_fused_lds_bytes<T>(n);
-    auto kern = k_fwd1d_fused<T, F, NT, WRITE_ALL>;
-    WX_HIP_CHECK(wx_allow_lds(kern, lds));
-    hipLaunchKernelGGL(kern, dim3(wx_fused_grid(lds, batch)), dim3(NT), lds, st, x, y, wx_log2(n), L, batch,
-                       xs, ys, filt, status, nstatus);
-    WX_HIP_CHECK(hipGetLastError());
-    return WX_OK;
+    switch (wx_fused_nt(n)) {
+    case 64: return launch_fwd_fused_FN<T, F, WRITE_ALL, 64>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    case 128: return launch_fwd_fused_FN<T, F, WRITE_ALL, 128>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    case 256: return launch_fwd_fused_FN<T, F, WRITE_ALL, 256>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    case 512: return launch_fwd_fused_FN<T, F, WRITE_ALL, 512>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    default: return launch_fwd_fused_FN<T, F, WRITE_ALL, 1024>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    }
 }
 
 template <typename T, bool WRITE_ALL>
@@ -419,19 +449,31 @@ static int launch_fwd_fused(const T *x, T *y, int64_t n, int L, int64_t batch, i
     return wx_set_error(WX_EUNSUPPORTED, "no fused instantiation for this filter length");
 }
 
+template <typename T, int F, int NT>
+static int launch_inv_fused_FN(const T *xw, T *xh, int64_t n, int L, int64_t batch, int64_t is, int64_t os,
+                               const WxFilt &filt, const uint8_t *status, int64_t nstatus, const int *colmap,
+                               int log2blk, hipStream_t st)
+{
+    const size_t lds = wx_fused_lds_bytes<T>(n);
+    auto kern = k_inv1d_fused<T, F, NT>;
+    WX_HIP_CHECK(wx_allow_lds(kern, lds));
+    hipLaunchKernelGGL(kern, dim3(wx_fused_grid(lds, batch, NT)), dim3(NT), lds, st, xw, xh, wx_log2(n), L, batch,
+                       is, os, filt, status, nstatus, colmap, log2blk);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
 template <typename T, int F>
 static int launch_inv_fused_F(const T *xw, T *xh, int64_t n, int L, int64_t batch, int64_t is, int64_t os,
                               const WxFilt &filt, const uint8_t *status, int64_t nstatus, const int *colmap,
                               int log2blk, hipStream_t st)
 {
-    constexpr int NT = 256;
-    const size_t lds = wx_fused_lds_bytes<T>(n);
-    auto kern = k_inv1d_fused<T, F, NT>;
-    WX_HIP_CHECK(wx_allow_lds(kern, lds));
-    hipLaunchKernelGGL(kern, dim3(wx_fused_grid(lds, batch)), dim3(NT), lds, st, xw, xh, wx_log2(n), L, batch,
-                       is, os, filt, status, nstatus, colmap, log2blk);
-    WX_HIP_CHECK(hipGetLastError());
-    return WX_OK;
+    switch (wx_fused_nt(n)) {
+    case 64: return launch_inv_fused_FN<T, F, 64>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
+    case 128: return launch_inv_fused_FN<T, F, 128>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
+    case 256: return launch_inv_fused_FN<T, F, 256>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
+    case 512: return launch_inv_fused_FN<T, F, 512>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
+    default: return launch_inv_fused_FN<T, F, 1024>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
+    }
 }
 
 template <typename T>
