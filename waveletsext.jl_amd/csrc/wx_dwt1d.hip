@@ -20,6 +20,7 @@
 #include "wx_common.h"
 #include "wx_kernels.h"
 #include <stdlib.h>
+#include <string.h>
 
 // ------------------------------------------------------------------------------------------
 // generic (one level per launch)
@@ -122,231 +123,518 @@ __global__ __launch_bounds__(256) void k_gather_leaves1d(const T *__restrict__ X
 
 // ------------------------------------------------------------------------------------------
 // fused forward: wpd (WRITE_ALL) / wpt
+//
+// LDS layout of one level ("4 planes"): natural position x of the level maps to
+//   eo = x & 1 (even/odd phase), pair P = x >> 2, w = (x >> 1) & 1, plane parity pp = P & 1,
+//   idx = P >> 1;  element = plane(eo, pp)[2*idx + w].
+// i.e. plane E<pp> holds the pairs (v[4P], v[4P+2]) and O<pp> the pairs (v[4P+1], v[4P+3]) of the
+// pairs with parity pp.  With the even/odd phases separated both QMF branches are unit-stride
+// convolutions; with the pair-parity split a lane that owns FOUR adjacent outputs of each branch
+// reads its tap window as 16-byte pairs at a lane stride of exactly 16 bytes in every plane
+// (conflict-free ds_read_b128), and consecutive planes are offset by 128 B so accesses that
+// alternate planes between neighbouring lanes stay conflict-free too.
+// Levels whose nodes are shorter than 16 samples are done one node per lane with the filter
+// periodised to the node length (WxFold), which also removes the redundant wrapped taps.
 // ------------------------------------------------------------------------------------------
-template <typename T, int F, int NT, bool WRITE_ALL>
-__global__ __launch_bounds__(NT) void k_fwd1d_fused(const T *__restrict__ x, T *__restrict__ y,
+#ifdef WX_STAMPS
+// diagnostic build only (never shipped): per-phase shader-clock shares of the fused forward kernel
+__device__ unsigned long long wx_stamp_buf[8];
+#define WX_T(var) const unsigned long long var = clock64()
+#else
+#define WX_T(var)
+#endif
+
+struct WxFold {                 // periodised analysis filters: a[i] = sum_u qaN[u] v[(2i+u) mod N]
+    double qa8[8], qd8[8], qa4[4], qd4[4], qa2[2], qd2[2];
+};
+
+template <typename T> struct WxVec4;
+template <> struct WxVec4<double> { typedef double4 type; };
+template <> struct WxVec4<float> { typedef float4 type; };
+
+static constexpr int wx_floor_half(int s) { return s >= 0 ? s / 2 : -((-s + 1) / 2); }
+
+// WX_PF = 4-element groups a lane stages per signal (n/4 <= WX_PF * NT): 2 up to n = 8*NT, else 4
+template <typename T, int F, int NT, bool WRITE_ALL, int WX_PF>
+__global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, T *__restrict__ y,
                                                     int log2n, int L, int64_t batch, int64_t x_stride,
-                                                    int64_t y_stride, WxFilt filt,
+                                                    int64_t y_stride, WxFilt filt, WxFold fold,
                                                     const uint8_t *__restrict__ status, int64_t nstatus)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     typedef typename WxVec2<T>::type V2;
+    typedef typename WxVec4<T>::type V4;
     constexpr int HF = F / 2;
     constexpr int BACK = (HF & 1) ? HF - 1 : HF;
-    constexpr int NP = BACK + 1;                 // 16-byte (f64) / 8-byte (f32) pairs per window
+    constexpr int NP4 = BACK + 2;                // 16-byte pairs per plane-pair window (4 outputs)
+    constexpr int PAD = 128 / (int)sizeof(T);
     const int n = 1 << log2n;
-    const int half = n >> 1;
+    const int Q = n >> 2;                        // elements per plane
+    const int PS = Q + PAD;                      // plane stride (elements)
     T *buf0 = reinterpret_cast<T *>(wx_smem);
-    T *buf1 = buf0 + n;
+    T *buf1 = buf0 + 4 * PS;
+    T *fl = buf1 + 4 * PS;                       // periodised filters (28 values), read as LDS broadcasts
+    const int tid = threadIdx.x;
+    if (tid < 28) fl[tid] = (T)reinterpret_cast<const double *>(&fold)[tid];
+    const T *qa8 = fl, *qd8 = fl + 8, *qa4 = fl + 16, *qd4 = fl + 20, *qa2 = fl + 24, *qd2 = fl + 26;
 
     T q[F];
 #pragma unroll
     for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
 
-    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
-        const T *xs = x + b * x_stride;
+    // prefetch the first signal
+    V4 pre[WX_PF];
+    int64_t b = blockIdx.x;
+    if (b < batch) {
+#pragma unroll
+        for (int k = 0; k < WX_PF; ++k) {
+            const int u = tid + k * NT;
+            if (u < Q) pre[k] = reinterpret_cast<const V4 *>(x + b * x_stride)[u];
+        }
+    }
+#ifdef WX_STAMPS
+    unsigned long long st_stage = 0, st_comp = 0, st_bar = 0, st_final = 0, st_total = 0;
+#endif
+    for (; b < batch; b += gridDim.x) {
+        WX_T(t_begin);
         T *ys = y + b * y_stride;
         T *cur = buf0, *nxt = buf1;
-        for (int p = threadIdx.x; p < half; p += NT) {
-            const V2 v = reinterpret_cast<const V2 *>(xs)[p];
-            cur[p] = v.x;
-            cur[half + p] = v.y;
-            if (WRITE_ALL) reinterpret_cast<V2 *>(ys)[p] = v;
+        // registers -> planes (and column 0 of the packet table)
+#pragma unroll
+        for (int k = 0; k < WX_PF; ++k) {
+            const int u = tid + k * NT;
+            if (u < Q) {
+                const V4 v = pre[k];
+                V2 ev; ev.x = v.x; ev.y = v.z;
+                V2 ov; ov.x = v.y; ov.y = v.w;
+                const int pp = u & 1, idx = u >> 1;
+                reinterpret_cast<V2 *>(cur + (0 + pp) * PS)[idx] = ev;
+                reinterpret_cast<V2 *>(cur + (2 + pp) * PS)[idx] = ov;
+                if (WRITE_ALL) reinterpret_cast<V4 *>(ys)[u] = v;
+            }
         }
         __syncthreads();
+        // next signal's loads fly while this one is transformed
+        if (b + gridDim.x < batch) {
+#pragma unroll
+            for (int k = 0; k < WX_PF; ++k) {
+                const int u = tid + k * NT;
+                if (u < Q) pre[k] = reinterpret_cast<const V4 *>(x + (b + gridDim.x) * x_stride)[u];
+            }
+        }
+        bool direct = false;
+        WX_T(t_staged);
+#ifdef WX_STAMPS
+        st_stage += t_staged - t_begin;
+#endif
         for (int d = 0; d < L; ++d) {
-            const int lh = log2n - d - 1;        // log2(child length)
-            const T *E = cur, *O = cur + half;
-            T *En = nxt, *On = nxt + half;
-            V2 *yl = reinterpret_cast<V2 *>(WRITE_ALL ? ys + (int64_t)(d + 1) * n : ys);
-            if (lh >= 1) {
-                const int hq = 1 << (lh - 1);
-                for (int w = threadIdx.x; w < (n >> 2); w += NT) {
-                    const int j = w >> (lh - 1);
-                    const int t = w & (hq - 1);
-                    const int B = j << lh;
+            WX_T(t_l0);
+            const int lh = log2n - d - 1;        // log2(child length h); node length np = 2h
+            const V2 *E0 = reinterpret_cast<const V2 *>(cur), *E1 = reinterpret_cast<const V2 *>(cur + PS);
+            const V2 *O0 = reinterpret_cast<const V2 *>(cur + 2 * PS), *O1 = reinterpret_cast<const V2 *>(cur + 3 * PS);
+            V2 *En0 = reinterpret_cast<V2 *>(nxt), *En1 = reinterpret_cast<V2 *>(nxt + PS);
+            V2 *On0 = reinterpret_cast<V2 *>(nxt + 2 * PS), *On1 = reinterpret_cast<V2 *>(nxt + 3 * PS);
+            const bool last = (d == L - 1);
+            direct = !WRITE_ALL && last && status == nullptr;     // leaves go straight to HBM
+            const bool to_global = WRITE_ALL || direct;
+            const bool to_lds = !direct && !(WRITE_ALL && last);
+            V4 *yl = reinterpret_cast<V4 *>(WRITE_ALL ? ys + (int64_t)(d + 1) * n : ys);
+            if (lh >= 3) {
+                // ---- four outputs per branch per lane ----
+                const int hq4 = 1 << (lh - 2);
+                for (int w = tid; w < (n >> 3); w += NT) {
+                    const int j = w >> (lh - 2);
+                    const int t = w & (hq4 - 1);
+                    const int IB = j << (lh - 2);
                     if (status) {
                         const int64_t node = ((int64_t)1 << d) + j;
                         if (!(node <= nstatus && status[node - 1])) {
-                            reinterpret_cast<V2 *>(En + B)[t] = reinterpret_cast<const V2 *>(E + B)[t];
-                            reinterpret_cast<V2 *>(On + B)[t] = reinterpret_cast<const V2 *>(O + B)[t];
+                            En0[IB + t] = E0[IB + t]; En1[IB + t] = E1[IB + t];
+                            On0[IB + t] = O0[IB + t]; On1[IB + t] = O1[IB + t];
                             continue;
                         }
                     }
-                    T e[2 * NP], o[2 * NP];
+                    T e[2 * NP4], o[2 * NP4];
 #pragma unroll
-                    for (int r = 0; r < NP; ++r) {
-                        const int u = (t - BACK / 2 + r) & (hq - 1);
-                        const V2 ve = reinterpret_cast<const V2 *>(E + B)[u];
-                        const V2 vo = reinterpret_cast<const V2 *>(O + B)[u];
+                    for (int r = 0; r < NP4; ++r) {
+                        const int pr = (BACK / 2 + r) & 1;
+                        const int kr = wx_floor_half(r - BACK / 2);
+                        const int idx = IB + ((t + kr) & (hq4 - 1));
+                        const V2 ve = pr ? E1[idx] : E0[idx];
+                        const V2 vo = pr ? O1[idx] : O0[idx];
                         e[2 * r] = ve.x; e[2 * r + 1] = ve.y;
                         o[2 * r] = vo.x; o[2 * r + 1] = vo.y;
                     }
-                    T a0 = 0, a1 = 0, d0 = 0, d1 = 0;
+                    T a[4], dd[4];
 #pragma unroll
-                    for (int m = 0; m < HF; ++m) {
-                        a0 = fma(q[2 * m], e[BACK + m], a0);
-                        a0 = fma(q[2 * m + 1], o[BACK + m], a0);
-                        a1 = fma(q[2 * m], e[BACK + 1 + m], a1);
-                        a1 = fma(q[2 * m + 1], o[BACK + 1 + m], a1);
-                        d0 = fma(q[2 * m], o[BACK - m], d0);
-                        d0 = fma(-q[2 * m + 1], e[BACK - m], d0);
-                        d1 = fma(q[2 * m], o[BACK + 1 - m], d1);
-                        d1 = fma(-q[2 * m + 1], e[BACK + 1 - m], d1);
+                    for (int s = 0; s < 4; ++s) {
+                        T as = 0, ds = 0;
+#pragma unroll
+                        for (int m = 0; m < HF; ++m) {
+                            as = fma(q[2 * m], e[s + m + BACK], as);
+                            as = fma(q[2 * m + 1], o[s + m + BACK], as);
+                            ds = fma(q[2 * m], o[s - m + BACK], ds);
+                            ds = fma(-q[2 * m + 1], e[s - m + BACK], ds);
+                        }
+                        a[s] = as; dd[s] = ds;
                     }
-                    En[B + t] = a0; On[B + t] = a1;
-                    En[B + hq + t] = d0; On[B + hq + t] = d1;
-                    if (WRITE_ALL) {
-                        V2 va; va.x = a0; va.y = a1;
-                        V2 vd; vd.x = d0; vd.y = d1;
-                        yl[B + t] = va;
-                        yl[B + hq + t] = vd;
+                    if (to_lds) {
+                        const int io = IB + (t >> 1);
+                        V2 v;
+                        if (t & 1) {
+                            v.x = a[0]; v.y = a[2]; En1[io] = v;
+                            v.x = a[1]; v.y = a[3]; On1[io] = v;
+                            v.x = dd[0]; v.y = dd[2]; En1[io + (hq4 >> 1)] = v;
+                            v.x = dd[1]; v.y = dd[3]; On1[io + (hq4 >> 1)] = v;
+                        } else {
+                            v.x = a[0]; v.y = a[2]; En0[io] = v;
+                            v.x = a[1]; v.y = a[3]; On0[io] = v;
+                            v.x = dd[0]; v.y = dd[2]; En0[io + (hq4 >> 1)] = v;
+                            v.x = dd[1]; v.y = dd[3]; On0[io + (hq4 >> 1)] = v;
+                        }
+                    }
+                    if (to_global) {
+                        V4 va; va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3];
+                        V4 vd; vd.x = dd[0]; vd.y = dd[1]; vd.z = dd[2]; vd.w = dd[3];
+                        const int g0 = (j << (lh - 1)) + t;           // (j*np + 4t) / 4
+                        yl[g0] = va;
+                        yl[g0 + hq4] = vd;
                     }
                 }
-            } else {                             // parent nodes of length 2
-                for (int w = threadIdx.x; w < half; w += NT) {
-                    const T ev = E[w], ov = O[w];
+            } else if (lh == 2) {
+                // ---- nodes of 8 samples: one node per lane, filter periodised to length 8 ----
+                for (int j = tid; j < (n >> 3); j += NT) {
+                    const V2 e0 = E0[j], e1 = E1[j], o0 = O0[j], o1 = O1[j];
                     if (status) {
-                        const int64_t node = ((int64_t)1 << d) + w;
-                        if (!(node <= nstatus && status[node - 1])) { En[w] = ev; On[w] = ov; continue; }
+                        const int64_t node = ((int64_t)1 << d) + j;
+                        if (!(node <= nstatus && status[node - 1])) { En0[j] = e0; En1[j] = e1; On0[j] = o0; On1[j] = o1; continue; }
                     }
-                    T a = 0, dd = 0;
+                    const T v[8] = {e0.x, o0.x, e0.y, o0.y, e1.x, o1.x, e1.y, o1.y};
+                    T a[4], dd[4];
 #pragma unroll
-                    for (int k = 0; k < F; ++k) {
-                        a = fma(q[k], (k & 1) ? ov : ev, a);
-                        dd = fma((k & 1) ? -q[k] : q[k], (k & 1) ? ev : ov, dd);
+                    for (int i = 0; i < 4; ++i) {
+                        T as = 0, ds = 0;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            as = fma(qa8[u], v[(2 * i + u) & 7], as);
+                            ds = fma(qd8[u], v[(2 * i + u) & 7], ds);
+                        }
+                        a[i] = as; dd[i] = ds;
                     }
-                    En[w] = a; On[w] = dd;
-                    if (WRITE_ALL) { V2 v; v.x = a; v.y = dd; yl[w] = v; }
+                    if (to_lds) {
+                        V2 t0; t0.x = a[0]; t0.y = a[2]; En0[j] = t0;
+                        t0.x = a[1]; t0.y = a[3]; On0[j] = t0;
+                        t0.x = dd[0]; t0.y = dd[2]; En1[j] = t0;
+                        t0.x = dd[1]; t0.y = dd[3]; On1[j] = t0;
+                    }
+                    if (to_global) {
+                        V4 va; va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3];
+                        V4 vd; vd.x = dd[0]; vd.y = dd[1]; vd.z = dd[2]; vd.w = dd[3];
+                        yl[2 * j] = va; yl[2 * j + 1] = vd;
+                    }
+                }
+            } else if (lh == 1) {
+                // ---- nodes of 4 samples ----
+                for (int jj = tid; jj < (n >> 3); jj += NT)
+                for (int j = 2 * jj; j < 2 * jj + 2; ++j) {
+                    const int pp = j & 1, idx = j >> 1;
+                    const V2 ev = pp ? E1[idx] : E0[idx];
+                    const V2 ov = pp ? O1[idx] : O0[idx];
+                    V2 eo_ = ev, oo_ = ov;
+                    bool act = true;
+                    if (status) {
+                        const int64_t node = ((int64_t)1 << d) + j;
+                        act = node <= nstatus && status[node - 1];
+                    }
+                    T a0 = ev.x, a1 = ov.x, d0 = ev.y, d1 = ov.y;    // pass-through values (natural order kept)
+                    if (act) {
+                        const T v[4] = {ev.x, ov.x, ev.y, ov.y};
+                        a0 = a1 = d0 = d1 = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            a0 = fma(qa4[u], v[u & 3], a0);
+                            a1 = fma(qa4[u], v[(2 + u) & 3], a1);
+                            d0 = fma(qd4[u], v[u & 3], d0);
+                            d1 = fma(qd4[u], v[(2 + u) & 3], d1);
+                        }
+                        eo_.x = a0; eo_.y = d0; oo_.x = a1; oo_.y = d1;
+                    }
+                    if (to_lds) {
+                        if (pp) { En1[idx] = eo_; On1[idx] = oo_; } else { En0[idx] = eo_; On0[idx] = oo_; }
+                    }
+                    if (to_global) {
+                        V4 vv;
+                        if (act) { vv.x = a0; vv.y = a1; vv.z = d0; vv.w = d1; }
+                        else { vv.x = ev.x; vv.y = ov.x; vv.z = ev.y; vv.w = ov.y; }
+                        yl[j] = vv;
+                    }
+                }
+            } else {
+                // ---- nodes of 2 samples: two nodes per lane ----
+                for (int uu = tid; uu < (n >> 3); uu += NT)
+                for (int u = 2 * uu; u < 2 * uu + 2; ++u) {
+                    const int pp = u & 1, idx = u >> 1;
+                    const V2 ev = pp ? E1[idx] : E0[idx];
+                    const V2 ov = pp ? O1[idx] : O0[idx];
+                    V2 en = ev, on = ov;
+                    bool act0 = true, act1 = true;
+                    if (status) {
+                        const int64_t node = ((int64_t)1 << d) + 2 * u;
+                        act0 = node <= nstatus && status[node - 1];
+                        act1 = node + 1 <= nstatus && status[node];
+                    }
+                    if (act0) {
+                        en.x = fma(qa2[1], ov.x, qa2[0] * ev.x);
+                        on.x = fma(qd2[1], ov.x, qd2[0] * ev.x);
+                    }
+                    if (act1) {
+                        en.y = fma(qa2[1], ov.y, qa2[0] * ev.y);
+                        on.y = fma(qd2[1], ov.y, qd2[0] * ev.y);
+                    }
+                    if (to_lds) {
+                        if (pp) { En1[idx] = en; On1[idx] = on; } else { En0[idx] = en; On0[idx] = on; }
+                    }
+                    if (to_global) { V4 vv; vv.x = en.x; vv.y = on.x; vv.z = en.y; vv.w = on.y; yl[u] = vv; }
                 }
             }
-            __syncthreads();
+            WX_T(t_l1);
+            // a level whose nodes fit one wave's 512-sample region (64 items x 8 samples) only
+            // exchanges data inside that wave: no workgroup barrier, the wave runs on down the tree
+            if (lh <= 8) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else {
+                __syncthreads();
+            }
+            WX_T(t_l2);
+#ifdef WX_STAMPS
+            st_comp += t_l1 - t_l0; st_bar += t_l2 - t_l1;
+#endif
             T *tmp = cur; cur = nxt; nxt = tmp;
         }
-        if (!WRITE_ALL) {
-            for (int p = threadIdx.x; p < half; p += NT) {
-                V2 v; v.x = cur[p]; v.y = cur[half + p];
-                reinterpret_cast<V2 *>(ys)[p] = v;
+        WX_T(t_lev);
+        if (!WRITE_ALL && !direct) {
+            __syncthreads();                       // the copy-out crosses the waves' regions
+            for (int u = tid; u < Q; u += NT) {
+                const int pp = u & 1, idx = u >> 1;
+                const V2 ev = reinterpret_cast<const V2 *>(cur + (0 + pp) * PS)[idx];
+                const V2 ov = reinterpret_cast<const V2 *>(cur + (2 + pp) * PS)[idx];
+                V4 v; v.x = ev.x; v.y = ov.x; v.z = ev.y; v.w = ov.y;
+                reinterpret_cast<V4 *>(ys)[u] = v;
             }
-            __syncthreads();
         }
+        __syncthreads();                           // all waves are done with this signal's LDS image
+#ifdef WX_STAMPS
+        { const unsigned long long t_end = clock64(); st_final += t_end - t_lev; st_total += t_end - t_begin; }
+#endif
     }
+#ifdef WX_STAMPS
+    if ((tid & 63) == 0) {
+        atomicAdd(&wx_stamp_buf[0], st_stage); atomicAdd(&wx_stamp_buf[1], st_comp); atomicAdd(&wx_stamp_buf[2], st_bar);
+        atomicAdd(&wx_stamp_buf[3], st_final); atomicAdd(&wx_stamp_buf[4], st_total); atomicAdd(&wx_stamp_buf[5], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
 // fused inverse: iwpt / iwpd (leaf gather on load)
+//
+// LDS layout of one level ("2 planes"): natural position x -> pair P = x >> 1, w = x & 1,
+// plane pp = P & 1, idx = P >> 1; element = plane(pp)[2*idx + w]; plane 1 is offset by 128 B.
+// A lane owns EIGHT adjacent parent samples (k = 4t..4t+3): both child windows are runs of
+// 16-byte pairs read at a lane stride of 16 B per plane (conflict-free).  Nodes of 4 and 2
+// samples use the synthesis step folded into a small matrix (WxFoldInv).  Levels whose nodes fit
+// a wave's 512-sample region run without workgroup barriers.
 // ------------------------------------------------------------------------------------------
-template <typename T, int F, int NT>
-__global__ __launch_bounds__(NT) void k_inv1d_fused(const T *__restrict__ xw, T *__restrict__ xh,
-                                                    int log2n, int L, int64_t batch, int64_t in_stride,
-                                                    int64_t out_stride, WxFilt filt,
-                                                    const uint8_t *__restrict__ status, int64_t nstatus,
-                                                    const int *__restrict__ colmap, int log2blk)
+struct WxFoldInv {               // v = M x over one node in natural order [a | d]
+    double m4[16], m2[4];
+};
+
+template <typename T, int F, int NT, int WX_PF>
+__global__ __launch_bounds__(NT, 4) void k_inv1d_fused(const T *__restrict__ xw, T *__restrict__ xh,
+                                                       int log2n, int L, int64_t batch, int64_t in_stride,
+                                                       int64_t out_stride, WxFilt filt, WxFoldInv fold,
+                                                       const uint8_t *__restrict__ status, int64_t nstatus,
+                                                       const int *__restrict__ colmap, int log2blk)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     typedef typename WxVec2<T>::type V2;
+    typedef typename WxVec4<T>::type V4;
     constexpr int HF = F / 2;
     constexpr int BACK = (HF & 1) ? HF - 1 : HF;
-    constexpr int NPI = BACK / 2 + 1;            // pairs per child window
+    constexpr int NPA = BACK / 2 + 2;            // 16-byte pairs per child window (8 parent samples)
+    constexpr int PAD = 128 / (int)sizeof(T);
     const int n = 1 << log2n;
-    const int half = n >> 1;
+    const int Q = n >> 2;
+    const int PS = (n >> 1) + PAD;               // plane stride (elements)
     T *buf0 = reinterpret_cast<T *>(wx_smem);
-    T *buf1 = buf0 + n;
+    T *buf1 = buf0 + 2 * PS;
+    T *fl = buf1 + 2 * PS;
+    const int tid = threadIdx.x;
+    if (tid < 20) fl[tid] = (T)reinterpret_cast<const double *>(&fold)[tid];
+    const T *m4 = fl, *m2 = fl + 16;
 
     T q[F];
 #pragma unroll
     for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
 
-    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
-        const T *xs = xw + b * in_stride;
+    V2 pre[2 * WX_PF];
+    auto prefetch = [&](int64_t sig) {
+        const T *xs = xw + sig * in_stride;
+#pragma unroll
+        for (int k = 0; k < WX_PF; ++k) {
+            const int u = tid + k * NT;
+            if (u < Q) {
+                if (colmap) {                    // packet table: the leaf of depth c lives in column c
+                    const int c0 = colmap[(4 * u) >> log2blk], c1 = colmap[(4 * u + 2) >> log2blk];
+                    pre[2 * k] = reinterpret_cast<const V2 *>(xs + (int64_t)c0 * n)[2 * u];
+                    pre[2 * k + 1] = reinterpret_cast<const V2 *>(xs + (int64_t)c1 * n)[2 * u + 1];
+                } else {
+                    const V4 v = reinterpret_cast<const V4 *>(xs)[u];
+                    pre[2 * k].x = v.x; pre[2 * k].y = v.y; pre[2 * k + 1].x = v.z; pre[2 * k + 1].y = v.w;
+                }
+            }
+        }
+    };
+    int64_t b = blockIdx.x;
+    if (b < batch) prefetch(b);
+    for (; b < batch; b += gridDim.x) {
         T *os = xh + b * out_stride;
         T *cur = buf0, *nxt = buf1;
-        if (colmap) {                            // packet table (n, k): leaf of depth c lives in column c
-            for (int p = threadIdx.x; p < half; p += NT) {
-                const int c = colmap[(2 * p) >> log2blk];
-                reinterpret_cast<V2 *>(cur)[p] = reinterpret_cast<const V2 *>(xs + (int64_t)c * n)[p];
+#pragma unroll
+        for (int k = 0; k < WX_PF; ++k) {
+            const int u = tid + k * NT;
+            if (u < Q) {
+                reinterpret_cast<V2 *>(cur)[u] = pre[2 * k];
+                reinterpret_cast<V2 *>(cur + PS)[u] = pre[2 * k + 1];
             }
-        } else {
-            for (int p = threadIdx.x; p < half; p += NT)
-                reinterpret_cast<V2 *>(cur)[p] = reinterpret_cast<const V2 *>(xs)[p];
         }
         __syncthreads();
-        bool direct = false;
+        if (b + gridDim.x < batch) prefetch(b + gridDim.x);
         for (int d = L - 1; d >= 0; --d) {
-            const int lh = log2n - d - 1;
-            if (lh >= 1) {
-                const int hq = 1 << (lh - 1);
-                direct = (d == 0);
-                for (int w = threadIdx.x; w < (n >> 2); w += NT) {
-                    const int j = w >> (lh - 1);
-                    const int t = w & (hq - 1);
-                    const int base = j << (lh + 1);
-                    V2 *dst = direct ? reinterpret_cast<V2 *>(os) : reinterpret_cast<V2 *>(nxt);
+            const int lh = log2n - d - 1;        // log2(child length h); parent node length np = 2h
+            const V2 *C0 = reinterpret_cast<const V2 *>(cur), *C1 = reinterpret_cast<const V2 *>(cur + PS);
+            V2 *N0 = reinterpret_cast<V2 *>(nxt), *N1 = reinterpret_cast<V2 *>(nxt + PS);
+            const bool root = (d == 0);
+            if (lh >= 2) {
+                const int hq4 = 1 << (lh - 2);                       // items per node = h/4
+                for (int w = tid; w < (n >> 3); w += NT) {
+                    const int j = w >> (lh - 2);
+                    const int t = w & (hq4 - 1);
+                    const int IA = j << (lh - 1);                    // idx base of child a: j*h/2
+                    const int ID = IA + hq4;                         // idx base of child d
+                    const int io = IA + 2 * t;                       // idx of the parent's first output pair
                     if (status) {
                         const int64_t node = ((int64_t)1 << d) + j;
                         if (!(node <= nstatus && status[node - 1])) {
-                            const int i0 = (base >> 1) + 2 * t;
-                            dst[i0] = reinterpret_cast<const V2 *>(cur)[i0];
-                            dst[i0 + 1] = reinterpret_cast<const V2 *>(cur)[i0 + 1];
+                            N0[io] = C0[io]; N1[io] = C1[io]; N0[io + 1] = C0[io + 1]; N1[io + 1] = C1[io + 1];
                             continue;
                         }
                     }
-                    const V2 *A = reinterpret_cast<const V2 *>(cur + base);
-                    const V2 *D = reinterpret_cast<const V2 *>(cur + base + (1 << lh));
-                    T aw[2 * NPI], dw[2 * NPI];
+                    T aw[2 * NPA], dw[2 * NPA];
 #pragma unroll
-                    for (int r = 0; r < NPI; ++r) {
-                        const V2 va = A[(t - BACK / 2 + r) & (hq - 1)];
-                        const V2 vd = D[(t + r) & (hq - 1)];
+                    for (int r = 0; r < NPA; ++r) {
+                        const int pa = (BACK / 2 + r) & 1;
+                        const int ka = wx_floor_half(r - BACK / 2);
+                        const int ia = IA + ((t + ka) & (hq4 - 1));
+                        const V2 va = pa ? C1[ia] : C0[ia];
+                        const int pd = r & 1;
+                        const int id = ID + ((t + (r >> 1)) & (hq4 - 1));
+                        const V2 vd = pd ? C1[id] : C0[id];
                         aw[2 * r] = va.x; aw[2 * r + 1] = va.y;
                         dw[2 * r] = vd.x; dw[2 * r + 1] = vd.y;
                     }
-                    T v0 = 0, v1 = 0, v2 = 0, v3 = 0;   // v[4t..4t+3]
+                    T v[8];
 #pragma unroll
-                    for (int m = 0; m < HF; ++m) {
-                        v0 = fma(q[2 * m], aw[BACK - m], v0);
-                        v0 = fma(-q[2 * m + 1], dw[m], v0);
-                        v1 = fma(q[2 * m + 1], aw[BACK - m], v1);
-                        v1 = fma(q[2 * m], dw[m], v1);
-                        v2 = fma(q[2 * m], aw[BACK + 1 - m], v2);
-                        v2 = fma(-q[2 * m + 1], dw[1 + m], v2);
-                        v3 = fma(q[2 * m + 1], aw[BACK + 1 - m], v3);
-                        v3 = fma(q[2 * m], dw[1 + m], v3);
+                    for (int s = 0; s < 4; ++s) {
+                        T ve = 0, vo = 0;
+#pragma unroll
+                        for (int m = 0; m < HF; ++m) {
+                            ve = fma(q[2 * m], aw[BACK + s - m], ve);
+                            ve = fma(-q[2 * m + 1], dw[s + m], ve);
+                            vo = fma(q[2 * m + 1], aw[BACK + s - m], vo);
+                            vo = fma(q[2 * m], dw[s + m], vo);
+                        }
+                        v[2 * s] = ve; v[2 * s + 1] = vo;
                     }
-                    V2 lo; lo.x = v0; lo.y = v1;
-                    V2 hi; hi.x = v2; hi.y = v3;
-                    const int i0 = (base >> 1) + 2 * t;
-                    dst[i0] = lo;
-                    dst[i0 + 1] = hi;
+                    if (root) {
+                        V4 lo; lo.x = v[0]; lo.y = v[1]; lo.z = v[2]; lo.w = v[3];
+                        V4 hi; hi.x = v[4]; hi.y = v[5]; hi.z = v[6]; hi.w = v[7];
+                        reinterpret_cast<V4 *>(os)[2 * w] = lo;
+                        reinterpret_cast<V4 *>(os)[2 * w + 1] = hi;
+                    } else {
+                        V2 p;
+                        p.x = v[0]; p.y = v[1]; N0[io] = p;
+                        p.x = v[2]; p.y = v[3]; N1[io] = p;
+                        p.x = v[4]; p.y = v[5]; N0[io + 1] = p;
+                        p.x = v[6]; p.y = v[7]; N1[io + 1] = p;
+                    }
                 }
-            } else {                             // children of length 1
-                direct = false;
-                for (int w = threadIdx.x; w < half; w += NT) {
-                    const V2 c = reinterpret_cast<const V2 *>(cur)[w];
-                    if (status) {
-                        const int64_t node = ((int64_t)1 << d) + w;
-                        if (!(node <= nstatus && status[node - 1])) { reinterpret_cast<V2 *>(nxt)[w] = c; continue; }
-                    }
-                    T v0 = 0, v1 = 0;
+            } else if (lh == 1) {
+                // parent nodes of 4 samples [a0 a1 d0 d1]: two nodes (8 positions) per item
+                for (int w = tid; w < (n >> 3); w += NT) {
 #pragma unroll
-                    for (int m = 0; m < HF; ++m) {
-                        v0 = fma(q[2 * m], c.x, v0);
-                        v0 = fma(-q[2 * m + 1], c.y, v0);
-                        v1 = fma(q[2 * m + 1], c.x, v1);
-                        v1 = fma(q[2 * m], c.y, v1);
+                    for (int c = 0; c < 2; ++c) {
+                        const int j = 2 * w + c;
+                        const int io = 2 * w + c;                    // pairs 2j (plane 0) and 2j+1 (plane 1) share idx j
+                        const V2 ap = C0[io], dp = C1[io];
+                        bool act = true;
+                        if (status) {
+                            const int64_t node = ((int64_t)1 << d) + j;
+                            act = node <= nstatus && status[node - 1];
+                        }
+                        V2 lo = ap, hi = dp;
+                        if (act) {
+                            const T xx[4] = {ap.x, ap.y, dp.x, dp.y};
+                            T o[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                T acc = 0;
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) acc = fma(m4[4 * i + u], xx[u], acc);
+                                o[i] = acc;
+                            }
+                            lo.x = o[0]; lo.y = o[1]; hi.x = o[2]; hi.y = o[3];
+                        }
+                        N0[io] = lo; N1[io] = hi;
                     }
-                    V2 v; v.x = v0; v.y = v1;
-                    reinterpret_cast<V2 *>(nxt)[w] = v;
+                }
+            } else {
+                // parent nodes of 2 samples [a d]: four nodes (8 positions) per item
+                for (int w = tid; w < (n >> 3); w += NT) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int j = 4 * w + c;                     // node j = pair j
+                        const int io = j >> 1;
+                        const V2 p = (j & 1) ? C1[io] : C0[io];
+                        bool act = true;
+                        if (status) {
+                            const int64_t node = ((int64_t)1 << d) + j;
+                            act = node <= nstatus && status[node - 1];
+                        }
+                        V2 o = p;
+                        if (act) {
+                            o.x = fma(m2[1], p.y, m2[0] * p.x);
+                            o.y = fma(m2[3], p.y, m2[2] * p.x);
+                        }
+                        if (j & 1) N1[io] = o; else N0[io] = o;
+                    }
                 }
             }
-            __syncthreads();
+            // the next level to run is d-1 (node length 4h): wave-local once 4h <= 512
+            if (d > 0) {
+                if (lh + 2 <= 9) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                } else {
+                    __syncthreads();
+                }
+            }
             T *tmp = cur; cur = nxt; nxt = tmp;
         }
-        if (!direct) {
-            for (int p = threadIdx.x; p < half; p += NT)
-                reinterpret_cast<V2 *>(os)[p] = reinterpret_cast<const V2 *>(cur)[p];
-            __syncthreads();
-        }
+        __syncthreads();                           // all waves are done with this signal's LDS image
     }
 }
 
@@ -365,11 +653,11 @@ static int wx_grid_for(int64_t total, int block)
 static bool wx_is_pow2(int64_t n) { return n >= 1 && (n & (n - 1)) == 0; }
 static int wx_log2(int64_t n) { int l = 0; while (((int64_t)1 << (l + 1)) <= n) ++l; return l; }
 
-template <typename T> static size_t wx_fused_lds_bytes(int64_t n) { return (size_t)2 * n * sizeof(T); }
+template <typename T> static size_t wx_fused_lds_bytes(int64_t n) { return (size_t)2 * n * sizeof(T) + 1024 + 256; }
 
 template <typename T> bool wx_fused1d_ok(int64_t n, int F)
 {
-    if (!wx_is_pow2(n) || n < 2) return false;
+    if (!wx_is_pow2(n) || n < 8) return false;
     if (wx_fused_lds_bytes<T>(n) > 160 * 1024) return false;
     switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 16: case 18: case 20: return true; }
     return false;
@@ -399,10 +687,47 @@ static int wx_fused_nt(int64_t n)
         cap = e ? atoi(e) : 512;
         if (cap != 64 && cap != 128 && cap != 256 && cap != 512 && cap != 1024) cap = 512;
     }
-    int64_t want = n / 4;
+    int64_t want = n / 8;
     int nt = 64;
     while (nt < cap && nt < want) nt <<= 1;
+    while (nt < 1024 && n / 4 > 4 * (int64_t)nt) nt <<= 1;     // staging registers: n/4 <= 4*NT
     return nt;
+}
+
+// periodise the analysis pair to node lengths 8, 4, 2:  a[i] = sum_k q[k] v[(2i+k) mod N],
+// d[i] = sum_k (-1)^k q[k] v[(2i+1-k) mod N]  ->  both as sum_u c[u] v[(2i+u) mod N]
+static WxFold wx_make_fold(const WxFilt &f)
+{
+    WxFold o;
+    memset(&o, 0, sizeof o);
+    for (int k = 0; k < f.F; ++k) {
+        const double qa = f.q[k], qd = (k & 1) ? -f.q[k] : f.q[k];
+        o.qa8[k & 7] += qa; o.qa4[k & 3] += qa; o.qa2[k & 1] += qa;
+        o.qd8[((1 - k) % 8 + 8) & 7] += qd; o.qd4[((1 - k) % 4 + 4) & 3] += qd; o.qd2[((1 - k) % 2 + 2) & 1] += qd;
+    }
+    return o;
+}
+
+// synthesis step (idwt_step!, dwt_one_level.jl:192-223) of a whole node of length N = 4 or 2 as a
+// matrix over the node in natural order x = [a | d]:  v[2k] = sum_m q[2m] a[k-m] - q[2m+1] d[k+m],
+// v[2k+1] = sum_m q[2m+1] a[k-m] + q[2m] d[k+m]  (indices mod N/2)
+static WxFoldInv wx_make_fold_inv(const WxFilt &f)
+{
+    WxFoldInv o;
+    memset(&o, 0, sizeof o);
+    for (int N = 2; N <= 4; N += 2) {
+        const int h = N / 2;
+        double *M = N == 4 ? o.m4 : o.m2;
+        for (int k = 0; k < h; ++k)
+            for (int m = 0; m < f.F / 2; ++m) {
+                const int ia = ((k - m) % h + h) % h, id = h + (k + m) % h;
+                M[(2 * k) * N + ia] += f.q[2 * m];
+                M[(2 * k) * N + id] -= f.q[2 * m + 1];
+                M[(2 * k + 1) * N + ia] += f.q[2 * m + 1];
+                M[(2 * k + 1) * N + id] += f.q[2 * m];
+            }
+    }
+    return o;
 }
 
 template <typename K> static hipError_t wx_allow_lds(K kernel, size_t lds)
@@ -412,17 +737,27 @@ template <typename K> static hipError_t wx_allow_lds(K kernel, size_t lds)
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
+template <typename T, int F, bool WRITE_ALL, int NT, int PF>
+static int launch_fwd_fused_FNP(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
+                                const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
+{
+    const size_t lds = wx_fused_lds_bytes<T>(n);
+    auto kern = k_fwd1d_fused<T, F, NT, WRITE_ALL, PF>;
+    WX_HIP_CHECK(wx_allow_lds(kern, lds));
+    const WxFold fold = wx_make_fold(filt);
+    hipLaunchKernelGGL(kern, dim3(wx_fused_grid(lds, batch, NT)), dim3(NT), lds, st, x, y, wx_log2(n), L, batch,
+                       xs, ys, filt, fold, status, nstatus);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
 template <typename T, int F, bool WRITE_ALL, int NT>
 static int launch_fwd_fused_FN(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
                                const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
 {
-    const size_t lds = wx_fused_lds_bytes<T>(n);
-    auto kern = k_fwd1d_fused<T, F, NT, WRITE_ALL>;
-    WX_HIP_CHECK(wx_allow_lds(kern, lds));
-    hipLaunchKernelGGL(kern, dim3(wx_fused_grid(lds, batch, NT)), dim3(NT), lds, st, x, y, wx_log2(n), L, batch,
-                       xs, ys, filt, status, nstatus);
-    WX_HIP_CHECK(hipGetLastError());
-    return WX_OK;
+    if (n / 4 <= 2 * NT) return launch_fwd_fused_FNP<T, F, WRITE_ALL, NT, 2>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    if (NT >= 512 && n / 4 <= 4 * NT)
+        return launch_fwd_fused_FNP<T, F, WRITE_ALL, (NT >= 512 ? NT : 512), 4>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    return wx_set_error(WX_EUNSUPPORTED, "fused forward: signal too long for the staging registers");
 }
 template <typename T, int F, bool WRITE_ALL>
 static int launch_fwd_fused_F(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
@@ -449,18 +784,29 @@ static int launch_fwd_fused(const T *x, T *y, int64_t n, int L, int64_t batch, i
     return wx_set_error(WX_EUNSUPPORTED, "no fused instantiation for this filter length");
 }
 
+template <typename T, int F, int NT, int PF>
+static int launch_inv_fused_FNP(const T *xw, T *xh, int64_t n, int L, int64_t batch, int64_t is, int64_t os,
+                                const WxFilt &filt, const uint8_t *status, int64_t nstatus, const int *colmap,
+                                int log2blk, hipStream_t st)
+{
+    const size_t lds = wx_fused_lds_bytes<T>(n);
+    auto kern = k_inv1d_fused<T, F, NT, PF>;
+    WX_HIP_CHECK(wx_allow_lds(kern, lds));
+    const WxFoldInv fold = wx_make_fold_inv(filt);
+    hipLaunchKernelGGL(kern, dim3(wx_fused_grid(lds, batch, NT)), dim3(NT), lds, st, xw, xh, wx_log2(n), L, batch,
+                       is, os, filt, fold, status, nstatus, colmap, log2blk);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
 template <typename T, int F, int NT>
 static int launch_inv_fused_FN(const T *xw, T *xh, int64_t n, int L, int64_t batch, int64_t is, int64_t os,
                                const WxFilt &filt, const uint8_t *status, int64_t nstatus, const int *colmap,
                                int log2blk, hipStream_t st)
 {
-    const size_t lds = wx_fused_lds_bytes<T>(n);
-    auto kern = k_inv1d_fused<T, F, NT>;
-    WX_HIP_CHECK(wx_allow_lds(kern, lds));
-    hipLaunchKernelGGL(kern, dim3(wx_fused_grid(lds, batch, NT)), dim3(NT), lds, st, xw, xh, wx_log2(n), L, batch,
-                       is, os, filt, status, nstatus, colmap, log2blk);
-    WX_HIP_CHECK(hipGetLastError());
-    return WX_OK;
+    if (n / 4 <= 2 * NT) return launch_inv_fused_FNP<T, F, NT, 2>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
+    if (NT >= 512 && n / 4 <= 4 * NT)
+        return launch_inv_fused_FNP<T, F, (NT >= 512 ? NT : 512), 4>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
+    return wx_set_error(WX_EUNSUPPORTED, "fused inverse: signal too long for the staging registers");
 }
 template <typename T, int F>
 static int launch_inv_fused_F(const T *xw, T *xh, int64_t n, int L, int64_t batch, int64_t is, int64_t os,
@@ -596,3 +942,12 @@ int wx_dev_getbasiscoef1d(const T *Xw, T *out, int64_t n, int k, int64_t batch, 
     template int wx_dev_getbasiscoef1d<T>(const T *, T *, int64_t, int, int64_t, const int *, int, hipStream_t);
 WX_INST(double)
 WX_INST(float)
+
+#ifdef WX_STAMPS
+extern "C" int wx_debug_read_stamps(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(wx_stamp_buf), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(wx_stamp_buf), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
