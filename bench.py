@@ -119,7 +119,7 @@ def main():
         inv = lambda: wx.dwt._iwpd_batched(wx.dwt.Arg(y), wx.dwt.Arg(xh), 1, wt, L, None)
         fwd_bytes = 8.0 * n * B * (1 + L + 1)            # x read once + (L+1) columns written once
         inv_bytes = 8.0 * n * B * 2                      # leaf column read + x written
-        kernel = "k_fwd1d_fused<double, 16, 256, true>"
+        kernel = "k_fwd1d_fused<double, 16, 512, true, 2>"
     else:
         y = wx.jl_empty((n, B), torch.float64, dev)
         xh = wx.jl_empty((n, B), torch.float64, dev)
@@ -127,7 +127,7 @@ def main():
         inv = lambda: wx.dwt._wpt_batched("wx_iwpt", wx.dwt.Arg(y), wx.dwt.Arg(xh), 1, wt, L, None)
         fwd_bytes = 8.0 * n * B * 2
         inv_bytes = 8.0 * n * B * 2
-        kernel = "k_fwd1d_fused<double, 8, 256, false>"
+        kernel = "k_fwd1d_inplace<double, 8, 256, false>"
 
     def step():
         fwd()

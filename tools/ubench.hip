@@ -51,6 +51,45 @@ __global__ void k_fill(double4 *__restrict__ out, size_t n)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = v;
 }
 
+__global__ void k_fill16(float4 *__restrict__ out, size_t n)
+{
+    float4 v = {1, 2, 3, 4};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = v;
+}
+__global__ void k_fill16_nt(float4 *__restrict__ out, size_t n)
+{
+    float4 v = {1, 2, 3, 4};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    { typedef float v4f __attribute__((ext_vector_type(4))); v4f vv = {1, 2, 3, 4}; __builtin_nontemporal_store(vv, (v4f *)&out[i]); }
+}
+// each block writes a contiguous 416 KiB region (like one packet table), 16 B per lane
+__global__ void k_fill_chunks(float4 *__restrict__ out, size_t chunk16, size_t nchunks)
+{
+    float4 v = {1, 2, 3, 4};
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x)
+        for (size_t i = threadIdx.x; i < chunk16; i += blockDim.x) out[c * chunk16 + i] = v;
+}
+// 32 bytes per lane as two 16-byte stores (lane stride 32 B), like the wpd kernel's V4 stores
+__global__ void k_fill_chunks32(float4 *__restrict__ out, size_t chunk16, size_t nchunks)
+{
+    float4 v = {1, 2, 3, 4};
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x)
+        for (size_t i = threadIdx.x; 2 * i + 1 < chunk16; i += blockDim.x) { out[c * chunk16 + 2 * i] = v; out[c * chunk16 + 2 * i + 1] = v; }
+}
+// same bytes, but every store instruction covers a contiguous 1 KiB per wave
+__global__ void k_fill_chunks16x2(float4 *__restrict__ out, size_t chunk16, size_t nchunks)
+{
+    float4 v = {1, 2, 3, 4};
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x)
+        for (size_t i = threadIdx.x; i + blockDim.x < chunk16; i += 2 * blockDim.x) { out[c * chunk16 + i] = v; out[c * chunk16 + i + blockDim.x] = v; }
+}
+__global__ void k_read16(const float4 *__restrict__ in, float *out, size_t n)
+{
+    float acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { float4 v = in[i]; acc += v.x + v.y + v.z + v.w; }
+    if (acc == 123.456f) out[0] = acc;
+}
+
 template <typename F> float time_ms(F f, int reps)
 {
     hipEvent_t a, b;
@@ -91,5 +130,28 @@ int main()
     printf("copy 4 GiB -> 4 GiB: %.3f ms  %.2f TB/s (read+write)\n", ms, 2.0 * n * 32 / ms / 1e9);
     ms = time_ms([&] { hipLaunchKernelGGL(k_fill, dim3(256 * 16), dim3(256), 0, 0, b, n); }, 5);
     printf("fill 4 GiB: %.3f ms  %.2f TB/s (write only)\n", ms, 1.0 * n * 32 / ms / 1e9);
+    size_t n16 = n * 2;
+    for (int bl : {1024, 2048, 4096, 8192, 16384}) {
+        ms = time_ms([&] { hipLaunchKernelGGL(k_fill16, dim3(bl), dim3(256), 0, 0, (float4 *)b, n16); }, 5);
+        printf("fill16 %5d blocks: %.3f ms %.2f TB/s\n", bl, ms, n16 * 16.0 / ms / 1e9);
+    }
+    ms = time_ms([&] { hipLaunchKernelGGL(k_fill16_nt, dim3(4096), dim3(256), 0, 0, (float4 *)b, n16); }, 5);
+    printf("fill16 nontemporal 4096 blocks: %.3f ms %.2f TB/s\n", ms, n16 * 16.0 / ms / 1e9);
+    for (int bl : {512, 1024, 2048}) {
+        size_t chunk16 = 425984 / 16, nch = n16 / chunk16;
+        ms = time_ms([&] { hipLaunchKernelGGL(k_fill_chunks, dim3(bl), dim3(512), 0, 0, (float4 *)b, chunk16, nch); }, 5);
+        printf("fill 416KiB chunks %4d blocks x512: %.3f ms %.2f TB/s\n", bl, ms, nch * chunk16 * 16.0 / ms / 1e9);
+    }
+    for (int bl : {512, 1024}) {
+        size_t chunk16 = 425984 / 16, nch = n16 / chunk16;
+        ms = time_ms([&] { hipLaunchKernelGGL(k_fill_chunks32, dim3(bl), dim3(512), 0, 0, (float4 *)b, chunk16, nch); }, 5);
+        printf("fill chunks 2x16B/lane stride32 %4d blocks: %.3f ms %.2f TB/s\n", bl, ms, nch * chunk16 * 16.0 / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_fill_chunks16x2, dim3(bl), dim3(512), 0, 0, (float4 *)b, chunk16, nch); }, 5);
+        printf("fill chunks 2x16B/lane contiguous %4d blocks: %.3f ms %.2f TB/s\n", bl, ms, nch * chunk16 * 16.0 / ms / 1e9);
+    }
+    for (int bl : {2048, 8192}) {
+        ms = time_ms([&] { hipLaunchKernelGGL(k_read16, dim3(bl), dim3(256), 0, 0, (const float4 *)a, (float *)d, n16); }, 5);
+        printf("read16 %5d blocks: %.3f ms %.2f TB/s\n", bl, ms, n16 * 16.0 / ms / 1e9);
+    }
     return 0;
 }

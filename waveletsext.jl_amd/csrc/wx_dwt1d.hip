@@ -438,6 +438,241 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
 }
 
 // ------------------------------------------------------------------------------------------
+// fused forward, in-place variant: ONE level buffer per signal (the 4-plane layout is a function of
+// the natural position only, so children overwrite their parent).  Half the LDS of the ping-pong
+// kernel -> twice as many signals resident per CU (4 at n = 4096 Float64), i.e. more independent
+// load / compute / store phases in flight.  Levels whose nodes fit a wave's 512-sample region run
+// with wave-level ordering only; the wider top levels use a read | barrier | write | barrier
+// split with the (at most two) items of a lane held in registers.
+// ------------------------------------------------------------------------------------------
+template <typename T, int F, int NT, bool WRITE_ALL>
+__global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x, T *__restrict__ y,
+                                                      int log2n, int L, int64_t batch, int64_t x_stride,
+                                                      int64_t y_stride, WxFilt filt, WxFold fold,
+                                                      const uint8_t *__restrict__ status, int64_t nstatus)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    typedef typename WxVec2<T>::type V2;
+    typedef typename WxVec4<T>::type V4;
+    constexpr int HF = F / 2;
+    constexpr int BACK = (HF & 1) ? HF - 1 : HF;
+    constexpr int NP4 = BACK + 2;
+    constexpr int PAD = 128 / (int)sizeof(T);
+    constexpr int KI = 2;                        // items per lane and level (n/8 <= KI*NT)
+    const int n = 1 << log2n;
+    const int Q = n >> 2;
+    const int PS = Q + PAD;
+    T *buf = reinterpret_cast<T *>(wx_smem);
+    T *fl = buf + 4 * PS;
+    const int tid = threadIdx.x;
+    if (tid < 28) fl[tid] = (T)reinterpret_cast<const double *>(&fold)[tid];
+    const T *qa8 = fl, *qd8 = fl + 8, *qa4 = fl + 16, *qd4 = fl + 20, *qa2 = fl + 24, *qd2 = fl + 26;
+    V2 *E0 = reinterpret_cast<V2 *>(buf), *E1 = reinterpret_cast<V2 *>(buf + PS);
+    V2 *O0 = reinterpret_cast<V2 *>(buf + 2 * PS), *O1 = reinterpret_cast<V2 *>(buf + 3 * PS);
+
+    T q[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
+
+    // one 8-output item: window reads + FMAs
+    auto compute_item = [&](int lh, int w, T (&a)[4], T (&dd)[4]) {
+        const int hq4 = 1 << (lh - 2);
+        const int j = w >> (lh - 2);
+        const int t = w & (hq4 - 1);
+        const int IB = j << (lh - 2);
+        T e[2 * NP4], o[2 * NP4];
+#pragma unroll
+        for (int r = 0; r < NP4; ++r) {
+            const int pr = (BACK / 2 + r) & 1;
+            const int kr = wx_floor_half(r - BACK / 2);
+            const int idx = IB + ((t + kr) & (hq4 - 1));
+            const V2 ve = pr ? E1[idx] : E0[idx];
+            const V2 vo = pr ? O1[idx] : O0[idx];
+            e[2 * r] = ve.x; e[2 * r + 1] = ve.y;
+            o[2 * r] = vo.x; o[2 * r + 1] = vo.y;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            T as = 0, ds = 0;
+#pragma unroll
+            for (int m = 0; m < HF; ++m) {
+                as = fma(q[2 * m], e[s + m + BACK], as);
+                as = fma(q[2 * m + 1], o[s + m + BACK], as);
+                ds = fma(q[2 * m], o[s - m + BACK], ds);
+                ds = fma(-q[2 * m + 1], e[s - m + BACK], ds);
+            }
+            a[s] = as; dd[s] = ds;
+        }
+    };
+    auto write_item = [&](int lh, int w, const T (&a)[4], const T (&dd)[4], bool to_lds, bool to_global, V4 *yl) {
+        const int hq4 = 1 << (lh - 2);
+        const int j = w >> (lh - 2);
+        const int t = w & (hq4 - 1);
+        const int IB = j << (lh - 2);
+        if (to_lds) {
+            const int io = IB + (t >> 1);
+            V2 *Ea = (t & 1) ? E1 : E0, *Oa = (t & 1) ? O1 : O0;
+            V2 v;
+            v.x = a[0]; v.y = a[2]; Ea[io] = v;
+            v.x = a[1]; v.y = a[3]; Oa[io] = v;
+            v.x = dd[0]; v.y = dd[2]; Ea[io + (hq4 >> 1)] = v;
+            v.x = dd[1]; v.y = dd[3]; Oa[io + (hq4 >> 1)] = v;
+        }
+        if (to_global) {
+            V4 va; va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3];
+            V4 vd; vd.x = dd[0]; vd.y = dd[1]; vd.z = dd[2]; vd.w = dd[3];
+            const int g0 = (j << (lh - 1)) + t;
+            yl[g0] = va;
+            yl[g0 + hq4] = vd;
+        }
+    };
+    auto node_active = [&](int d, int j) -> bool {
+        if (!status) return true;
+        const int64_t node = ((int64_t)1 << d) + j;
+        return node <= nstatus && status[node - 1];
+    };
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
+        const T *xs = x + b * x_stride;
+        T *ys = y + b * y_stride;
+        for (int u = tid; u < Q; u += NT) {
+            const V4 v = reinterpret_cast<const V4 *>(xs)[u];
+            V2 ev; ev.x = v.x; ev.y = v.z;
+            V2 ov; ov.x = v.y; ov.y = v.w;
+            if (u & 1) { E1[u >> 1] = ev; O1[u >> 1] = ov; } else { E0[u >> 1] = ev; O0[u >> 1] = ov; }
+            if (WRITE_ALL) reinterpret_cast<V4 *>(ys)[u] = v;
+        }
+        __syncthreads();
+        bool direct = false;
+        for (int d = 0; d < L; ++d) {
+            const int lh = log2n - d - 1;
+            const bool last = (d == L - 1);
+            direct = !WRITE_ALL && last && status == nullptr;
+            const bool to_global = WRITE_ALL || direct;
+            const bool to_lds = !direct && !(WRITE_ALL && last);
+            V4 *yl = reinterpret_cast<V4 *>(WRITE_ALL ? ys + (int64_t)(d + 1) * n : ys);
+            if (lh >= 3) {
+                if (lh <= 8) {
+                    // wave-local: read | wave order | write, item by item
+                    for (int w = tid; w < (n >> 3); w += NT) {
+                        if (!node_active(d, w >> (lh - 2))) continue;         // in place: nothing to copy
+                        T a[4], dd[4];
+                        compute_item(lh, w, a, dd);
+                        wave_sync();
+                        write_item(lh, w, a, dd, to_lds, to_global, yl);
+                    }
+                } else {
+                    T a[KI][4], dd[KI][4];
+#pragma unroll
+                    for (int k = 0; k < KI; ++k) {
+                        const int w = tid + k * NT;
+                        if (w < (n >> 3) && node_active(d, w >> (lh - 2))) compute_item(lh, w, a[k], dd[k]);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < KI; ++k) {
+                        const int w = tid + k * NT;
+                        if (w < (n >> 3) && node_active(d, w >> (lh - 2))) write_item(lh, w, a[k], dd[k], to_lds, to_global, yl);
+                    }
+                }
+            } else if (lh == 2) {
+                for (int j = tid; j < (n >> 3); j += NT) {
+                    if (!node_active(d, j)) continue;
+                    const V2 e0 = E0[j], e1 = E1[j], o0 = O0[j], o1 = O1[j];
+                    const T v[8] = {e0.x, o0.x, e0.y, o0.y, e1.x, o1.x, e1.y, o1.y};
+                    T a[4], dd[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        T as = 0, ds = 0;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            as = fma(qa8[u], v[(2 * i + u) & 7], as);
+                            ds = fma(qd8[u], v[(2 * i + u) & 7], ds);
+                        }
+                        a[i] = as; dd[i] = ds;
+                    }
+                    if (to_lds) {
+                        V2 t0; t0.x = a[0]; t0.y = a[2]; E0[j] = t0;
+                        t0.x = a[1]; t0.y = a[3]; O0[j] = t0;
+                        t0.x = dd[0]; t0.y = dd[2]; E1[j] = t0;
+                        t0.x = dd[1]; t0.y = dd[3]; O1[j] = t0;
+                    }
+                    if (to_global) {
+                        V4 va; va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3];
+                        V4 vd; vd.x = dd[0]; vd.y = dd[1]; vd.z = dd[2]; vd.w = dd[3];
+                        yl[2 * j] = va; yl[2 * j + 1] = vd;
+                    }
+                }
+            } else if (lh == 1) {
+                for (int jj = tid; jj < (n >> 3); jj += NT)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int j = 2 * jj + c;
+                    const int pp = j & 1, idx = j >> 1;
+                    const V2 ev = pp ? E1[idx] : E0[idx];
+                    const V2 ov = pp ? O1[idx] : O0[idx];
+                    V4 vv; vv.x = ev.x; vv.y = ov.x; vv.z = ev.y; vv.w = ov.y;
+                    if (node_active(d, j)) {
+                        const T v[4] = {ev.x, ov.x, ev.y, ov.y};
+                        T a0 = 0, a1 = 0, d0 = 0, d1 = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            a0 = fma(qa4[u], v[u & 3], a0);
+                            a1 = fma(qa4[u], v[(2 + u) & 3], a1);
+                            d0 = fma(qd4[u], v[u & 3], d0);
+                            d1 = fma(qd4[u], v[(2 + u) & 3], d1);
+                        }
+                        vv.x = a0; vv.y = a1; vv.z = d0; vv.w = d1;
+                        if (to_lds) {
+                            V2 en; en.x = a0; en.y = d0;
+                            V2 on; on.x = a1; on.y = d1;
+                            if (pp) { E1[idx] = en; O1[idx] = on; } else { E0[idx] = en; O0[idx] = on; }
+                        }
+                    }
+                    if (to_global) yl[j] = vv;
+                }
+            } else {
+                for (int uu = tid; uu < (n >> 3); uu += NT)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int u = 2 * uu + c;
+                    const int pp = u & 1, idx = u >> 1;
+                    const V2 ev = pp ? E1[idx] : E0[idx];
+                    const V2 ov = pp ? O1[idx] : O0[idx];
+                    V2 en = ev, on = ov;
+                    if (node_active(d, 2 * u)) {
+                        en.x = fma(qa2[1], ov.x, qa2[0] * ev.x);
+                        on.x = fma(qd2[1], ov.x, qd2[0] * ev.x);
+                    }
+                    if (node_active(d, 2 * u + 1)) {
+                        en.y = fma(qa2[1], ov.y, qa2[0] * ev.y);
+                        on.y = fma(qd2[1], ov.y, qd2[0] * ev.y);
+                    }
+                    if (to_lds) { if (pp) { E1[idx] = en; O1[idx] = on; } else { E0[idx] = en; O0[idx] = on; } }
+                    if (to_global) { V4 vv; vv.x = en.x; vv.y = on.x; vv.z = en.y; vv.w = on.y; yl[u] = vv; }
+                }
+            }
+            if (lh <= 8) wave_sync(); else __syncthreads();
+        }
+        if (!WRITE_ALL && !direct) {
+            __syncthreads();
+            for (int u = tid; u < Q; u += NT) {
+                const V2 ev = (u & 1) ? E1[u >> 1] : E0[u >> 1];
+                const V2 ov = (u & 1) ? O1[u >> 1] : O0[u >> 1];
+                V4 v; v.x = ev.x; v.y = ov.x; v.z = ev.y; v.w = ov.y;
+                reinterpret_cast<V4 *>(ys)[u] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // fused inverse: iwpt / iwpd (leaf gather on load)
 //
 // LDS layout of one level ("2 planes"): natural position x -> pair P = x >> 1, w = x & 1,
@@ -759,10 +994,54 @@ static int launch_fwd_fused_FN(const T *x, T *y, int64_t n, int L, int64_t batch
         return launch_fwd_fused_FNP<T, F, WRITE_ALL, (NT >= 512 ? NT : 512), 4>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
     return wx_set_error(WX_EUNSUPPORTED, "fused forward: signal too long for the staging registers");
 }
+static int wx_fwd_mode()
+{
+    static int mode = -1;
+    if (mode < 0) { const char *e = getenv("WX_FWD_MODE"); mode = e ? atoi(e) : 1; }
+    return mode;                                   // 0 = ping-pong + prefetch, 1 = in-place
+}
+template <typename T> static size_t wx_inplace_lds_bytes(int64_t n) { return (size_t)n * sizeof(T) + 512 + 256; }
+
+template <typename T, int F, bool WRITE_ALL, int NT>
+static int launch_fwd_inplace_FN(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
+                                 const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
+{
+    const size_t lds = wx_inplace_lds_bytes<T>(n);
+    auto kern = k_fwd1d_inplace<T, F, NT, WRITE_ALL>;
+    WX_HIP_CHECK(wx_allow_lds(kern, lds));
+    const WxFold fold = wx_make_fold(filt);
+    hipLaunchKernelGGL(kern, dim3(wx_fused_grid(lds, batch, NT)), dim3(NT), lds, st, x, y, wx_log2(n), L, batch,
+                       xs, ys, filt, fold, status, nstatus);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+template <typename T, int F, bool WRITE_ALL>
+static int launch_fwd_inplace_F(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
+                                const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
+{
+    // two items per lane: NT = n/16 (64..1024)
+    int nt = 64;
+    while (nt < 1024 && nt * 16 < n) nt <<= 1;
+    switch (nt) {
+    case 64: return launch_fwd_inplace_FN<T, F, WRITE_ALL, 64>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    case 128: return launch_fwd_inplace_FN<T, F, WRITE_ALL, 128>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    case 256: return launch_fwd_inplace_FN<T, F, WRITE_ALL, 256>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    case 512: return launch_fwd_inplace_FN<T, F, WRITE_ALL, 512>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    default: return launch_fwd_inplace_FN<T, F, WRITE_ALL, 1024>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    }
+}
+
 template <typename T, int F, bool WRITE_ALL>
 static int launch_fwd_fused_F(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
                               const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
 {
+    // measured on MI355X (tools/ktime.py): the in-place kernel wins for short filters when only the
+    // leaves are written (wpt); long filters run out of registers with two items per lane, and wpd is
+    // bound by its store stream either way
+    if constexpr (F <= 8 && !WRITE_ALL) {
+        if (wx_fwd_mode() == 1 && n <= 16384)
+            return launch_fwd_inplace_F<T, F, WRITE_ALL>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    }
     switch (wx_fused_nt(n)) {
     case 64: return launch_fwd_fused_FN<T, F, WRITE_ALL, 64>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
     case 128: return launch_fwd_fused_FN<T, F, WRITE_ALL, 128>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
