@@ -6,13 +6,17 @@ kernel's achieved HBM bandwidth against the 8 TB/s roofline, next to the CPU pat
 
 A step = one forward pass + one inverse pass over one batch of synthetic signals that are already
 resident in HBM.  Default workload = BASELINE config 2 (`wpdall` 65536 x 4096 Float64, db8, full
-packet tree L=12, then `iwpdall`).  `--workload target` runs the north-star target configuration
-(`wptall`/`iwptall`, db4, L=10).  N > 1: one process per GPU (torchrun), each rank owns a
-fixed-size shard of the batch (weak scaling); the transforms need no data-path collective.
+packet tree L=12, then `iwpdall`).  Other workloads (`--workload`): `target` (north-star target
+wptall/iwptall db4 L=10), `cfg3` (swptall/iswptall 16384-sample signals, haar, L=12, one resident
+chunk of the 8192-signal batch per step), `cfg4` (2-D wptall/iwptall 512x512 Float32 db4 L=6, the
+per-GPU shard of 512 images), `cfg5` (acwpd + JBB moments/costs/tree, coif6, L=11, a 2048-signal
+slice of the per-GPU shard).  N > 1: one process per GPU (torchrun), each rank owns a fixed-size
+shard of the batch (weak scaling); the transforms need no data-path collective.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -22,13 +26,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290
+FP64_PEAK_TFLOPS = 78.6        # FP64 vector spec; tools/ubench.hip measures 55-61 on this part
 
 WORKLOADS = {
-    # name: (n, per-GPU batch, wavelet, L, kind)
-    "cfg2": dict(n=4096, batch=65536, wavelet="db8", L=12, kind="wpd",
+    "cfg2": dict(kind="wpd", n=4096, batch=65536, wavelet="db8", L=12, dtype="f64",
+                 kernel="k_fwd1d_fused<double, 16, 512, true, 2>",
                  desc="BASELINE config 2: wpdall+iwpdall 65536x4096 f64 db8 full tree L=12"),
-    "target": dict(n=4096, batch=65536, wavelet="db4", L=10, kind="wpt",
+    "target": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=10, dtype="f64",
+                   kernel="k_fwd1d_inplace<double, 8, 256, false>",
                    desc="north-star target: wptall+iwptall 65536x4096 f64 db4 L=10"),
+    "cfg3": dict(kind="swpt", n=16384, batch=64, wavelet="haar", L=12, dtype="f64",
+                 kernel="k_swt_fwd_level<double, false>",
+                 desc="BASELINE config 3: swptall+iswptall (average-based) 16384-sample f64 haar L=12; one resident "
+                      "chunk of 64 signals (32 GiB of leaves) of the 8192-signal batch per step"),
+    "cfg4": dict(kind="wpt2d", m=512, n=512, batch=512, wavelet="db4", L=6, dtype="f32",
+                 kernel="k_dwt2d_dim2<float, false>",
+                 desc="BASELINE config 4: 2-D wptall+iwptall 512x512 f32 db4 L=6, 512 images per GPU (4096 / 8)"),
+    "cfg5": dict(kind="acwpd_jbb", n=2048, batch=2048, wavelet="coif6", L=11, dtype="f64",
+                 kernel="k_swt_fwd_level<double, true>",
+                 desc="BASELINE config 5: acwpd + JBB moments/costs/tree 2048-sample f64 coif6 L=11; 2048-signal slice "
+                      "of the 32768-signal per-GPU shard per step (no inverse: output is the tree)"),
 }
 
 
@@ -46,43 +63,153 @@ def parse():
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle ("port": scalar restatement of the reference's loops, one thread, like the
+# reference) timed on this host on a bounded sample of the same workload
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline(w, seconds):
-    """The oracle ("port": scalar restatement of wpdall -> wpd! -> dwt_step!, one thread, like the
-    reference) timed on this host on a bounded sample of the same workload."""
-    import ctypes
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import wx_oracle as wo
     import waveletsext_jl_amd as wx
     lib = wo.lib()
-    n, L = w["n"], w["L"]
     q = np.ascontiguousarray(wx.wavelet(getattr(wx.WT, w["wavelet"])).qmf)
-    tree = wo.maketree1d(n, L, "full").astype(np.uint8)
     rng = np.random.default_rng(1002)
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)
+    I, L64 = ctypes.c_int, ctypes.c_int64
+    kind, L = w["kind"], w["L"]
 
     def run(B):
-        x = np.asfortranarray(rng.standard_normal((n, B)))
-        xh = np.empty_like(x)
-        P = lambda a: ctypes.c_void_p(a.ctypes.data)
-        I, L64 = ctypes.c_int, ctypes.c_int64
-        t0 = time.perf_counter()
-        if w["kind"] == "wpd":
-            y = np.empty((n, L + 1, B), order="F")
-            lib.wxo_wpdall1d_f64(P(y), P(x), L64(n), I(L), L64(B), P(q), I(q.size))
-            lib.wxo_iwpdall1d_f64(P(xh), P(y), L64(n), I(L + 1), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
+        if kind in ("wpd", "wpt"):
+            n = w["n"]
+            tree = wo.maketree1d(n, L, "full").astype(np.uint8)
+            x = np.asfortranarray(rng.standard_normal((n, B)))
+            xh = np.empty_like(x)
+            t0 = time.perf_counter()
+            if kind == "wpd":
+                y = np.empty((n, L + 1, B), order="F")
+                lib.wxo_wpdall1d_f64(P(y), P(x), L64(n), I(L), L64(B), P(q), I(q.size))
+                lib.wxo_iwpdall1d_f64(P(xh), P(y), L64(n), I(L + 1), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
+            else:
+                y = np.empty_like(x)
+                lib.wxo_wptall1d_f64(P(y), P(x), L64(n), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
+                lib.wxo_iwptall1d_f64(P(xh), P(y), L64(n), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
+            dt = time.perf_counter() - t0
+            assert np.abs(xh - x).max() < 1e-9
+            return dt, B * n
+        if kind == "swpt":
+            n = w["n"]
+            x = rng.standard_normal((n, B))
+            t0 = time.perf_counter()
+            for i in range(B):
+                xw = wo.swpt(x[:, i], q, L)
+                xr = wo.iswpt(xw, q)
+            dt = time.perf_counter() - t0
+            assert np.abs(xr - x[:, B - 1]).max() < 1e-9
+            return dt, B * n
+        if kind == "wpt2d":
+            m, n = w["m"], w["n"]
+            x = rng.standard_normal((m, n, B)).astype(np.float32)
+            t0 = time.perf_counter()
+            for i in range(B):
+                y = wo.wpt(np.asfortranarray(x[:, :, i]), q, L)
+                xr = wo.iwpt(y, q, L)
+            dt = time.perf_counter() - t0
+            assert np.abs(xr - x[:, :, B - 1]).max() < 1e-3
+            return dt, B * m * n
+        if kind == "acwpd_jbb":
+            n = w["n"]
+            x = rng.standard_normal((n, B))
+            t0 = time.perf_counter()
+            X = np.asfortranarray(np.stack([wo.acwpd(x[:, i], q, L) for i in range(B)], axis=-1))
+            tree = wo.bestbasistree_jbb(X, redundant=True)
+            dt = time.perf_counter() - t0
+            assert tree.size == n - 1
+            return dt, B * n
+        raise ValueError(kind)
+
+    probe = 16 if kind in ("wpd", "wpt") else 2
+    t_probe, _ = run(probe)
+    cap = 8192 if kind in ("wpd", "wpt") else (64 if kind == "wpt2d" else 32)
+    B = int(max(probe, min(cap, seconds / (t_probe / probe))))
+    dt, samples = run(B)
+    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d of the %d signals per step, same transform pair, oracle C -O2 single thread, %.1f s"
+                      % (B, w["batch"], dt)}
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU workloads: each returns (fwd, inv, check, info)
+# ------------------------------------------------------------------------------------------------
+def make_workload(w, wx, torch, dev, rank):
+    from waveletsext_jl_amd import dwt as D
+    from waveletsext_jl_amd._arrays import qmf_arg
+    kind, L, B = w["kind"], w["L"], w["batch"]
+    wt = wx.wavelet(getattr(wx.WT, w["wavelet"]))
+    F = len(wt.qmf)
+    td = torch.float64 if w["dtype"] == "f64" else torch.float32
+    es = 8 if w["dtype"] == "f64" else 4
+    gen = torch.Generator(device=dev).manual_seed(1002 + rank)
+    A = D.Arg
+    if kind in ("wpd", "wpt"):
+        n = w["n"]
+        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
+        xh = wx.jl_empty((n, B), td, dev)
+        if kind == "wpd":
+            y = wx.jl_empty((n, L + 1, B), td, dev)
+            fwd = lambda: D._wpd_batched(A(x), A(y), 1, wt, L)
+            inv = lambda: D._iwpd_batched(A(y), A(xh), 1, wt, L, None)
+            fb = es * n * B * (L + 2)                # x read once + (L+1) columns written once
         else:
-            y = np.empty_like(x)
-            lib.wxo_wptall1d_f64(P(y), P(x), L64(n), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
-            lib.wxo_iwptall1d_f64(P(xh), P(y), L64(n), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
-        dt = time.perf_counter() - t0
-        assert np.abs(xh - x).max() < 1e-9
-        return dt
-    t_probe = run(16)
-    B = int(max(16, min(8192, seconds / (t_probe / 16))))
-    dt = run(B)
-    return {"value": B * n / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "%d of the %d signals (n=%d), fwd+inv, oracle C -O2 single thread, %.1f s"
-                      % (B, w["batch"], n, dt)}
+            y = wx.jl_empty((n, B), td, dev)
+            fwd = lambda: D._wpt_batched("wx_wpt", A(x), A(y), 1, wt, L, None)
+            inv = lambda: D._wpt_batched("wx_iwpt", A(y), A(xh), 1, wt, L, None)
+            fb = es * n * B * 2
+        check = lambda: float((xh - x).abs().max() / x.abs().max())
+        return fwd, inv, check, dict(fwd_bytes=fb, inv_bytes=es * n * B * 2, fwd_flops=2.0 * F * n * L * B,
+                                     samples=n * B, bound="hbm", keep=(x, y, xh))
+    if kind == "swpt":
+        n = w["n"]
+        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
+        xw = wx.jl_empty((n, 1 << L, B), td, dev)
+        xh = wx.jl_empty((n, B), td, dev)
+        q, qp, Fq = qmf_arg(wt)
+        fwd = lambda: D._call("wx_swpt1d", "_f64", A(x).ptr, A(xw).ptr, n, L, B, qp, Fq, A(x).stream())
+        inv = lambda: D._call("wx_iswpt1d", "_f64", A(xw).ptr, A(xh).ptr, n, L, -1, B, qp, Fq, A(x).stream())
+        fb = es * n * B * (1 + (1 << L))
+        check = lambda: float((xh - x).abs().max() / x.abs().max())
+        return fwd, inv, check, dict(fwd_bytes=fb, inv_bytes=fb, fwd_flops=((1 << L) - 1) * 4.0 * F * n * B,
+                                     samples=n * B, bound="hbm", keep=(x, xw, xh, q))
+    if kind == "wpt2d":
+        m, n = w["m"], w["n"]
+        x = wx.jl_empty((m, n, B), td, dev); x.normal_(generator=gen)
+        y = wx.jl_empty((m, n, B), td, dev)
+        xh = wx.jl_empty((m, n, B), td, dev)
+        fwd = lambda: D._wpt_batched("wx_wpt", A(x), A(y), 2, wt, L, None)
+        inv = lambda: D._wpt_batched("wx_iwpt", A(y), A(xh), 2, wt, L, None)
+        fb = es * m * n * B * 2
+        check = lambda: float((xh - x).abs().max() / x.abs().max())
+        return fwd, inv, check, dict(fwd_bytes=fb, inv_bytes=fb, fwd_flops=L * 2.0 * (2 * F * m * n) * B,
+                                     samples=m * n * B, bound="hbm", keep=(x, y, xh))
+    if kind == "acwpd_jbb":
+        n = w["n"]
+        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
+        ncols = (1 << (L + 1)) - 1
+        state = {}
+
+        def fwd():
+            state["s"], state["q"] = wx.acwpd_jbb_moments(x, wt, L)
+
+        def inv():      # second leg of config 5 = costs + tree selection from the moments
+            costs = wx.costs_from_moments(state["s"], state["q"], B, wx.JBB(redundant=True))
+            state["tree"] = wx.bestbasis_treeselection(costs, n)
+
+        check = lambda: 0.0 if wx.isvalidtree(torch.empty(n), state["tree"]) else 1.0
+        # structure exploited by the kernel: odd lags only, S shared by both children
+        flops = (ncols - (1 << L)) * n * (2.0 * (F // 2) * 2 + 4) * B
+        return fwd, inv, check, dict(fwd_bytes=es * (n * B + 2 * n * ncols), inv_bytes=es * 2 * n * ncols,
+                                     fwd_flops=flops, samples=n * B, bound="fp64", keep=(x,))
+    raise ValueError(kind)
 
 
 def main():
@@ -105,33 +232,7 @@ def main():
     w = dict(WORKLOADS[a.workload])
     if a.batch:
         w["batch"] = a.batch
-    n, B, L = w["n"], w["batch"], w["L"]
-    wt = wx.wavelet(getattr(wx.WT, w["wavelet"]))
-
-    gen = torch.Generator(device=dev).manual_seed(1002 + rank)
-    x = wx.jl_empty((n, B), torch.float64, dev)
-    x.normal_(generator=gen)
-
-    if w["kind"] == "wpd":
-        y = wx.jl_empty((n, L + 1, B), torch.float64, dev)
-        xh = wx.jl_empty((n, B), torch.float64, dev)
-        fwd = lambda: wx.dwt._wpd_batched(wx.dwt.Arg(x), wx.dwt.Arg(y), 1, wt, L)
-        inv = lambda: wx.dwt._iwpd_batched(wx.dwt.Arg(y), wx.dwt.Arg(xh), 1, wt, L, None)
-        fwd_bytes = 8.0 * n * B * (1 + L + 1)            # x read once + (L+1) columns written once
-        inv_bytes = 8.0 * n * B * 2                      # leaf column read + x written
-        kernel = "k_fwd1d_fused<double, 16, 512, true, 2>"
-    else:
-        y = wx.jl_empty((n, B), torch.float64, dev)
-        xh = wx.jl_empty((n, B), torch.float64, dev)
-        fwd = lambda: wx.dwt._wpt_batched("wx_wpt", wx.dwt.Arg(x), wx.dwt.Arg(y), 1, wt, L, None)
-        inv = lambda: wx.dwt._wpt_batched("wx_iwpt", wx.dwt.Arg(y), wx.dwt.Arg(xh), 1, wt, L, None)
-        fwd_bytes = 8.0 * n * B * 2
-        inv_bytes = 8.0 * n * B * 2
-        kernel = "k_fwd1d_inplace<double, 8, 256, false>"
-
-    def step():
-        fwd()
-        inv()
+    fwd, inv, check, info = make_workload(w, wx, torch, dev, rank)
 
     def sync():
         if world > 1:
@@ -139,10 +240,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(a.warmup):
-        step()
+        fwd()
+        inv()
     sync()
-    err = float((xh - x).abs().max() / x.abs().max())
-    assert err < 1e-10, "round trip broken: %g" % err
+    err = check()
+    tol = 1e-10 if w["dtype"] == "f64" else 1e-5
+    assert err < tol, "round trip broken: %g" % err
 
     # HIP events on the launch stream (torch's current stream == the stream passed to the C ABI)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
@@ -166,13 +269,13 @@ def main():
     inv_avg = sum(inv_ms) / len(inv_ms)
 
     gather_ms = None
-    if a.gather and world > 1:
-        full = torch.empty((world * B, n), dtype=torch.float64, device=dev)
-        src = xh.T if xh.dim() > 1 else xh
-        dist.all_gather_into_tensor(full, src.contiguous())
+    if a.gather and world > 1 and w["kind"] in ("wpd", "wpt"):
+        from waveletsext_jl_amd import distributed as wd
+        xh = info["keep"][2]
+        wd.allgather_batch(xh, world * w["batch"])
         sync()
         t1 = time.perf_counter()
-        dist.all_gather_into_tensor(full, src.contiguous())
+        wd.allgather_batch(xh, world * w["batch"])
         sync()
         gather_ms = (time.perf_counter() - t1) * 1e3
 
@@ -184,26 +287,36 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if not a.batch:
-                traffic = tj.get(a.workload, {}).get(kernel, {}).get("hbm_bytes_per_launch")
+                traffic = tj.get(a.workload, {}).get(w["kernel"], {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-        achieved = fwd_bytes / (fwd_avg * 1e-3) / 1e9
+        fb = float(info["fwd_bytes"])
+        if info["bound"] == "hbm":
+            achieved = fb / (fwd_avg * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": w["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": fb}
+        else:
+            achieved = info["fwd_flops"] / (fwd_avg * 1e-3) / 1e12
+            roof = {"bound": "fp64-valu (no MFMA on this path)", "kernel": w["kernel"], "achieved": achieved,
+                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+                    "algorithmic_flops_per_step": info["fwd_flops"], "hbm_GBs": fb / (fwd_avg * 1e-3) / 1e9}
+        roof.update({"avg_launch_ms": fwd_avg, "median_launch_ms": fwd_ms[len(fwd_ms) // 2],
+                     "fwd_TFLOPs": info["fwd_flops"] / (fwd_avg * 1e-3) / 1e12})
+        cfg = {"workload": w["desc"], "batch_per_gpu": w["batch"], "wavelet": w["wavelet"], "L": w["L"],
+               "sharding": "batch split across ranks, no data-path collective"}
+        cfg.update({k: w[k] for k in ("n", "m") if k in w})
         out = {
             "metric": "Msamples/s (fwd+inv wavelet packets)",
-            "value": world * B * n * a.steps / elapsed / 1e6,
+            "value": world * info["samples"] * a.steps / elapsed / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic N(0,1), seed 1002+rank, resident in HBM",
-            "config": {"workload": w["desc"], "n": n, "batch_per_gpu": B, "wavelet": w["wavelet"], "L": L,
-                       "sharding": "batch split across ranks, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": fwd_bytes, "avg_launch_ms": fwd_avg,
-                         "median_launch_ms": fwd_ms[len(fwd_ms) // 2]},
-            "inverse": {"avg_launch_ms": inv_avg, "algorithmic_bytes_per_launch": inv_bytes,
-                        "achieved_GBs": inv_bytes / (inv_avg * 1e-3) / 1e9},
+            "dtype": w["dtype"], "data": "synthetic N(0,1), seed 1002+rank, resident in HBM",
+            "config": cfg,
+            "roofline": roof,
+            "inverse": {"avg_launch_ms": inv_avg, "algorithmic_bytes_per_launch": float(info["inv_bytes"]),
+                        "achieved_GBs": info["inv_bytes"] / (inv_avg * 1e-3) / 1e9},
             "roundtrip_rel_err": err,
         }
         if gather_ms is not None:

@@ -123,10 +123,28 @@ WxScratch::~WxScratch()
     for (void *p : ptrs)
         if (p && hipFreeAsync(p, st) != hipSuccess) (void)hipGetLastError();
 }
+// keep freed scratch cached in the device's default memory pool (the default release threshold of 0
+// would hand it back to the driver at every synchronisation and make each call re-map gigabytes)
+static void wx_retain_pool()
+{
+    static std::mutex mu;
+    static bool done[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[dev]) return;
+    done[dev] = true;
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    uint64_t thr = UINT64_MAX;
+    if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr) != hipSuccess) (void)hipGetLastError();
+}
+
 void *WxScratch::alloc(size_t bytes)
 {
     void *p = nullptr;
     if (bytes == 0) bytes = 16;
+    wx_retain_pool();
     hipError_t e = hipMallocAsync(&p, bytes, st);
     if (e != hipSuccess) { wx_set_hip_error(e, "hipMallocAsync(scratch)", __FILE__, __LINE__); return nullptr; }
     ptrs.push_back(p);

@@ -37,7 +37,7 @@ static __device__ __forceinline__ void wx_fwd_cols(int layout, int L, int d, int
 // forward level: blockIdx.x = node, blockIdx.y = signal (grid-strided)
 // ------------------------------------------------------------------------------------------
 template <typename T, bool AC>
-__global__ __launch_bounds__(256) void k_swt_fwd_level(const T *__restrict__ x, T *__restrict__ xw, int n,
+__global__ __launch_bounds__(1024) void k_swt_fwd_level(const T *__restrict__ x, T *__restrict__ xw, int n,
                                                        int ncols, int64_t batch, int L, int d, int layout,
                                                        WxFilt filt, WxAcFilt ac)
 {
@@ -303,7 +303,9 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         int64_t gy = batch;
         const int64_t cap = (int64_t)65535;
         if (gy > cap) gy = cap;
-        hipLaunchKernelGGL(kern, dim3(nodes, (unsigned)gy), dim3(256), lds, st, x, xw, (int)n, ncols, batch, L, d,
+        // long signals occupy most of a CU's LDS (one workgroup per CU): give that workgroup 16 waves
+        const int nt = n >= 8192 ? 1024 : (n >= 2048 ? 512 : 256);
+        hipLaunchKernelGGL(kern, dim3(nodes, (unsigned)gy), dim3(nt), lds, st, x, xw, (int)n, ncols, batch, L, d,
                            layout, filt, acz);
     }
     WX_HIP_CHECK(hipGetLastError());
