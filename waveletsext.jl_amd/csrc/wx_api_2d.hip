@@ -3,6 +3,8 @@
 #include "wx_host.h"
 #include "wx_kernels.h"
 
+int wx_force_generic();
+
 #define WX_REQUIRE(cond, code, msg) \
     do { if (!(cond)) return wx_set_error(code, msg); } while (0)
 
@@ -110,6 +112,10 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
     if (batch && (!dx || !dy)) return io.finish(WX_EHIP);
     T *tmp = nullptr, *pong = nullptr;
     if (batch && tr.Leff > 0) { tmp = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!tmp) return io.finish(WX_EHIP); }
+    if (tr.full && tr.Leff > 0 && !wx_force_generic() && wx_wpt2d_fast_ok<T>(m, n, F)) {
+        rc = wx_dev_wpt2d_fast<T>(dx, dy, m, n, tr.Leff, batch, filt, tmp, INVERSE, m * n, st);
+        return io.finish(rc);
+    }
     if (batch && tr.Leff > 1) { pong = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!pong) return io.finish(WX_EHIP); }
     rc = wx_dev_wpt2d<T>(dx, dy, m, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, tmp, pong, INVERSE, m * n, st);
     return io.finish(rc);
@@ -139,6 +145,10 @@ static int api_iwpd2d(const T *xw, T *xh, int64_t m, int64_t n, int k, int L, co
     if (batch && (!dxw || !dxh)) return io.finish(WX_EHIP);
     T *tmp = nullptr, *pong = nullptr, *leaves = nullptr;
     if (batch && tr.Leff > 0) { tmp = (T *)scr.alloc(sizeof(T) * mn * batch); if (!tmp) return io.finish(WX_EHIP); }
+    if (tr.full && tr.Leff > 0 && !wx_force_generic() && wx_wpt2d_fast_ok<T>(m, n, F)) {
+        rc = wx_dev_wpt2d_fast<T>(dxw + (int64_t)tr.Leff * mn, dxh, m, n, tr.Leff, batch, filt, tmp, true, mn * k, st);
+        return io.finish(rc);
+    }
     if (batch && tr.Leff > 1) { pong = (T *)scr.alloc(sizeof(T) * mn * batch); if (!pong) return io.finish(WX_EHIP); }
     const T *src = dxw + (int64_t)tr.Leff * mn;      // full tree: every leaf is in slice Leff
     int64_t in_img = mn * k;

@@ -161,6 +161,188 @@ __global__ __launch_bounds__(256) void k_gather_leaves2d(const T *__restrict__ X
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Full-tree fast path.  The column steps C_d (dim 1) and the row steps R_d (dim 2) act on different
+// axes of a product structure, so C_0 R_0 C_1 R_1 ... = (C_{L-1}..C_0)(R_{L-1}..R_0): a full 2-D
+// packet transform of depth L is the batched 1-D transform of depth L down every column (the fused
+// 1-D kernels, columns are contiguous) followed by the 1-D transform along every row.  The row
+// transform runs on strips of R rows staged in LDS as [column][row-in-strip]; lanes run over the
+// rows of the strip, so every LDS access of a wave is a run of consecutive words whatever the tap,
+// and the HBM side moves R contiguous elements per column.  4 image passes in total instead of 4
+// per level.  (Rounding differs from the per-level order by O(eps); inside the 1e-5 / 1e-10 budget.)
+// ------------------------------------------------------------------------------------------
+template <typename T, int F, bool INVERSE>
+__global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, T *__restrict__ dst,
+                                                     int64_t src_img, int64_t dst_img, int m, int log2n, int L,
+                                                     int64_t nimg, WxFilt filt, int log2R, int S)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    const int n = 1 << log2n;
+    const int R = 1 << log2R;
+    T *cur = reinterpret_cast<T *>(wx_smem);
+    T *nxt = cur + (size_t)n * S;
+    const int strips_per_img = (m + R - 1) >> log2R;
+    const int64_t nstrips = nimg * strips_per_img;
+    T q[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
+    const int r = threadIdx.x & (R - 1);             // row of the strip owned by this lane
+    const int g0 = threadIdx.x >> log2R;             // first item (column pair group) of this lane
+    const int gstep = blockDim.x >> log2R;
+    for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+        const int64_t img = sidx / strips_per_img;
+        const int r0 = (int)(sidx - img * strips_per_img) << log2R;
+        const T *sp = src + img * src_img + r0 + r;
+        T *dp = dst + img * dst_img + r0 + r;
+        T *a = cur + r, *b = nxt + r;
+        const bool row_ok = r0 + r < m;
+        if (row_ok)
+            for (int c = g0; c < n; c += gstep) a[c * S] = sp[(int64_t)c * m];
+        __syncthreads();
+        for (int s = 0; s < L; ++s) {
+            const int d = INVERSE ? L - 1 - s : s;
+            const int lnp = log2n - d;               // log2(node length)
+            const int np = 1 << lnp, h = np >> 1;
+            if (h >= 2) {
+                // two output pairs per item: 2F-tap window held in registers
+                for (int it = g0; it < (n >> 2); it += gstep) {
+                    const int j = it >> (lnp - 2), t = it & ((h >> 1) - 1);
+                    const T *v = a + (size_t)(j << lnp) * S;
+                    T *o = b + (size_t)(j << lnp) * S;
+                    if (!INVERSE) {
+                        // outputs i = 2t, 2t+1: a[i] needs v[2i..2i+F-1], d[i] needs v[2i+2-F..2i+1]
+                        T w[2 * F];
+#pragma unroll
+                        for (int k = 0; k < 2 * F; ++k) w[k] = v[((4 * t + 2 - F + k) & (np - 1)) * S];
+                        T a0 = 0, a1 = 0, d0 = 0, d1 = 0;
+#pragma unroll
+                        for (int k = 0; k < F; ++k) {
+                            a0 = fma(q[k], w[F - 2 + k], a0);
+                            a1 = fma(q[k], w[F + k], a1);
+                            d0 = fma((k & 1) ? -q[k] : q[k], w[F - 1 - k], d0);
+                            d1 = fma((k & 1) ? -q[k] : q[k], w[F + 1 - k], d1);
+                        }
+                        o[(2 * t) * S] = a0; o[(2 * t + 1) * S] = a1;
+                        o[(h + 2 * t) * S] = d0; o[(h + 2 * t + 1) * S] = d1;
+                    } else {
+                        // parent samples 4t..4t+3 (k = 2t, 2t+1) from a[k-m], d[k+m]
+                        constexpr int HF = F / 2;
+                        T aw[HF + 1], dw[HF + 1];
+#pragma unroll
+                        for (int k = 0; k < HF + 1; ++k) {
+                            aw[k] = v[((2 * t + 1 - HF + k) & (h - 1)) * S];        // a[2t+1-HF .. 2t+1]
+                            dw[k] = v[(h + ((2 * t + k) & (h - 1))) * S];           // d[2t .. 2t+HF]
+                        }
+                        T v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+#pragma unroll
+                        for (int mm = 0; mm < HF; ++mm) {
+                            v0 = fma(q[2 * mm], aw[HF - 1 - mm], v0);
+                            v0 = fma(-q[2 * mm + 1], dw[mm], v0);
+                            v1 = fma(q[2 * mm + 1], aw[HF - 1 - mm], v1);
+                            v1 = fma(q[2 * mm], dw[mm], v1);
+                            v2 = fma(q[2 * mm], aw[HF - mm], v2);
+                            v2 = fma(-q[2 * mm + 1], dw[1 + mm], v2);
+                            v3 = fma(q[2 * mm + 1], aw[HF - mm], v3);
+                            v3 = fma(q[2 * mm], dw[1 + mm], v3);
+                        }
+                        o[(4 * t) * S] = v0; o[(4 * t + 1) * S] = v1;
+                        o[(4 * t + 2) * S] = v2; o[(4 * t + 3) * S] = v3;
+                    }
+                }
+            } else {
+                // nodes of two samples: a = v0 sum(q even) + v1 sum(q odd), ... (wrapped taps)
+                for (int j = g0; j < (n >> 1); j += gstep) {
+                    const T x0 = a[(2 * j) * S], x1 = a[(2 * j + 1) * S];
+                    T y0 = 0, y1 = 0;
+                    if (!INVERSE) {
+#pragma unroll
+                        for (int k = 0; k < F; ++k) {
+                            y0 = fma(q[k], (k & 1) ? x1 : x0, y0);
+                            y1 = fma((k & 1) ? -q[k] : q[k], (k & 1) ? x0 : x1, y1);
+                        }
+                    } else {
+#pragma unroll
+                        for (int mm = 0; mm < F / 2; ++mm) {
+                            y0 = fma(q[2 * mm], x0, y0); y0 = fma(-q[2 * mm + 1], x1, y0);
+                            y1 = fma(q[2 * mm + 1], x0, y1); y1 = fma(q[2 * mm], x1, y1);
+                        }
+                    }
+                    b[(2 * j) * S] = y0; b[(2 * j + 1) * S] = y1;
+                }
+            }
+            __syncthreads();
+            T *tmp = a; a = b; b = tmp;
+        }
+        if (row_ok)
+            for (int c = g0; c < n; c += gstep) dp[(int64_t)c * m] = a[c * S];
+        __syncthreads();
+    }
+}
+
+template <typename T> static void wx_rows_geometry(int &R, int &S)
+{
+    if (sizeof(T) == 4) { R = 32; S = 32; } else { R = 16; S = 24; }
+}
+
+template <typename T> bool wx_wpt2d_fast_ok(int64_t m, int64_t n, int F)
+{
+    int R, S;
+    wx_rows_geometry<T>(R, S);
+    const bool pow2 = n >= 2 && (n & (n - 1)) == 0;
+    return pow2 && wx_fused1d_ok<T>(m, F) && (size_t)2 * n * S * sizeof(T) <= 160 * 1024 && n * m < ((int64_t)1 << 31);
+}
+
+template <typename T, bool INVERSE>
+static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img, int64_t m, int64_t n, int L,
+                          int64_t batch, const WxFilt &filt, hipStream_t st)
+{
+    int R, S;
+    wx_rows_geometry<T>(R, S);
+    const size_t lds = (size_t)2 * n * S * sizeof(T);
+    void (*kern)(const T *, T *, int64_t, int64_t, int, int, int, int64_t, WxFilt, int, int) = nullptr;
+    switch (filt.F) {
+#define WX_CASE(FF) case FF: kern = k_rows_fused<T, FF, INVERSE>; break;
+        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+#undef WX_CASE
+    default: return wx_set_error(WX_EUNSUPPORTED, "no fused row kernel for this filter length");
+    }
+    if (lds > 64 * 1024)
+        WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int log2n = 0;
+    while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
+    const int64_t nstrips = batch * ((m + R - 1) / R);
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    const int nt = per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024);
+    int64_t grid = (int64_t)256 * per_cu;
+    if (grid > nstrips) grid = nstrips;
+    int log2R = 0;
+    while ((1 << (log2R + 1)) <= R) ++log2R;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), lds, st, src, dst, src_img, dst_img, (int)m, log2n, L, batch,
+                       filt, log2R, S);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
+// full tree of depth L on (m, n, batch): tmp holds m*n*batch elements
+template <typename T>
+int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const WxFilt &filt, T *tmp,
+                      bool inverse, int64_t in_img, hipStream_t st)
+{
+    if (batch == 0 || m * n == 0) return WX_OK;
+    const int64_t mn = m * n;
+    int rc;
+    if (!inverse) {
+        // columns: the images' columns are m-sample signals, contiguous: (m, n*batch)
+        if (in_img != mn) return wx_set_error(WX_EUNSUPPORTED, "fast 2-D forward needs a dense input");
+        if ((rc = wx_dev_wpt1d<T>(x, tmp, m, L, n * batch, filt, nullptr, 0, nullptr, st, 0))) return rc;
+        return wx_launch_rows<T, false>(tmp, y, mn, mn, m, n, L, batch, filt, st);
+    }
+    if ((rc = wx_launch_rows<T, true>(x, tmp, in_img, mn, m, n, L, batch, filt, st))) return rc;
+    return wx_dev_iwpt1d<T>(tmp, y, m, L, n * batch, filt, nullptr, 0, nullptr, 0, m, nullptr, nullptr, st, 0);
+}
+
 static int wx_grid2(int64_t total)
 {
     int64_t g = (total + 255) / 256;
@@ -249,6 +431,8 @@ int wx_dev_gather_leaves2d(const T *Xw, T *out, int64_t m, int64_t n, int k, int
     template int wx_dev_wpd2d<T>(const T *, T *, int64_t, int64_t, int, int64_t, const WxFilt &, T *, hipStream_t); \
     template int wx_dev_wpt2d<T>(const T *, T *, int64_t, int64_t, int, int64_t, const WxFilt &, const uint8_t *,  \
                                  int64_t, T *, T *, bool, int64_t, hipStream_t);                              \
-    template int wx_dev_gather_leaves2d<T>(const T *, T *, int64_t, int64_t, int, int64_t, const int *, int, hipStream_t);
+    template int wx_dev_gather_leaves2d<T>(const T *, T *, int64_t, int64_t, int, int64_t, const int *, int, hipStream_t); \
+    template bool wx_wpt2d_fast_ok<T>(int64_t, int64_t, int);                                                  \
+    template int wx_dev_wpt2d_fast<T>(const T *, T *, int64_t, int64_t, int, int64_t, const WxFilt &, T *, bool, int64_t, hipStream_t);
 WX_INST(double)
 WX_INST(float)

@@ -53,3 +53,7 @@ int wx_dev_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, c
 template <typename T>
 int wx_dev_gather_leaves2d(const T *Xw, T *out, int64_t m, int64_t n, int k, int64_t batch, const int *colmap,
                            int nblk, hipStream_t st);
+template <typename T> bool wx_wpt2d_fast_ok(int64_t m, int64_t n, int F);
+template <typename T>
+int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const WxFilt &filt, T *tmp,
+                      bool inverse, int64_t in_img, hipStream_t st);
