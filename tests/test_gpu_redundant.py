@@ -161,3 +161,25 @@ def test_jbb_many_signals_chunked_reduction(wx, oracle):
     exp = oracle.tree_costs_jbb(oracle.wpdall(X, wt.qmf))
     assert relerr(got, exp) <= 1e-10
     assert (wx.bestbasistree(xw) == oracle.bestbasistree_jbb(oracle.wpdall(X, wt.qmf))).all()
+
+
+@pytest.mark.parametrize("n,L,wname", [(256, 8, "coif6"), (128, 7, "db4"), (512, 5, "haar")])
+def test_fused_acwpd_moments_deep_trees(wx, oracle, n, L, wname):
+    """config-5 path: residue-class subtree kernel (several top-table depths) and the materialising
+    fallback must both reproduce the oracle's moments, costs and tree."""
+    rng = np.random.default_rng(2008)
+    wt = _wt(wx, wname)
+    N = 21
+    t = np.arange(n) / n
+    X = np.asfortranarray(np.sin(2 * np.pi * 7 * t)[:, None] * (1 + 0.4 * rng.standard_normal((1, N))) + 0.3 * rng.standard_normal((n, N)))
+    xacw = _stack(oracle.acwpd, X, wt.qmf, L)
+    s_ref, q_ref = xacw.sum(axis=2), (xacw ** 2).sum(axis=2)
+    for force in (0, 1):
+        wx.set_force_generic(force)
+        try:
+            s, q = wx.acwpd_jbb_moments(X, wt, L)
+            assert relerr(s, s_ref) <= 1e-12 and relerr(q, q_ref) <= 1e-12, force
+            costs = wx.costs_from_moments(s, q, N, wx.JBB(redundant=True))
+            assert (wx.bestbasis_treeselection(costs, n) == oracle.bestbasistree_jbb(xacw, redundant=True)).all()
+        finally:
+            wx.set_force_generic(0)

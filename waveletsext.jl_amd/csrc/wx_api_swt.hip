@@ -296,18 +296,38 @@ static int api_acwpd_jbb_moments(const double *x, double *sum, double *sumsq, in
         dsq = (double *)io.out(sumsq, sizeof(double) * nk);
     }
     if (!dsum || !dsq || (batch && !dx)) return io.finish(WX_EHIP);
-    // chunk so that the scratch table stays <= 8 GiB
-    int64_t chunk = ((int64_t)8 << 30) / (int64_t)(sizeof(double) * nk);
-    if (chunk < 1) chunk = 1;
-    if (chunk > batch) chunk = batch;
-    double *tab = batch ? (double *)scr.alloc(sizeof(double) * nk * chunk) : nullptr;
-    if (batch && !tab) return io.finish(WX_EHIP);
     WxAcFilt acf;
     wx_pack_acfilter(filt, &acf);
     if (batch == 0 && !accumulate) {
         WX_HIP_CHECK(hipMemsetAsync(dsum, 0, sizeof(double) * nk, st));
         WX_HIP_CHECK(hipMemsetAsync(dsq, 0, sizeof(double) * nk, st));
     }
+    const int D0 = wx_force_generic() ? -1 : wx_acwpd_fused_depth(n, L, F);
+    if (D0 >= 0 && D0 < L) {
+        // fused: only the shallow top table (depth <= D0) goes through HBM
+        const int64_t ncols_top = ((int64_t)1 << (D0 + 1)) - 1;
+        const int64_t nk_top = n * ncols_top;
+        int64_t chunk = ((int64_t)8 << 30) / (int64_t)(sizeof(double) * nk_top);
+        if (chunk < 1) chunk = 1;
+        if (chunk > batch) chunk = batch;
+        double *tab = batch ? (double *)scr.alloc(sizeof(double) * nk_top * chunk) : nullptr;
+        if (batch && !tab) return io.finish(WX_EHIP);
+        for (int64_t b0 = 0; b0 < batch && rc == WX_OK; b0 += chunk) {
+            const int64_t bc = (batch - b0 < chunk) ? batch - b0 : chunk;
+            const int acc = (accumulate || b0 > 0) ? 1 : 0;
+            if (D0 > 0) rc = wx_dev_swt_fwd<double>(dx + b0 * n, tab, n, D0, LAYOUT_WPD, bc, filt, &acf, st);
+            else WX_HIP_CHECK(hipMemcpyAsync(tab, dx + b0 * n, sizeof(double) * n * bc, hipMemcpyDeviceToDevice, st));
+            if (rc == WX_OK) rc = wx_dev_jbb_moments<double>(tab, dsum, dsq, nk_top, bc, acc, nullptr, 1, st);
+            if (rc == WX_OK) rc = wx_dev_acwpd_subtree_moments(tab, dsum, dsq, n, L, D0, bc, acf, acc, st);
+        }
+        return io.finish(rc);
+    }
+    // fallback: materialise the table in chunks of <= 8 GiB
+    int64_t chunk = ((int64_t)8 << 30) / (int64_t)(sizeof(double) * nk);
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    double *tab = batch ? (double *)scr.alloc(sizeof(double) * nk * chunk) : nullptr;
+    if (batch && !tab) return io.finish(WX_EHIP);
     for (int64_t b0 = 0; b0 < batch && rc == WX_OK; b0 += chunk) {
         const int64_t bc = (batch - b0 < chunk) ? batch - b0 : chunk;
         rc = wx_dev_swt_fwd<double>(dx + b0 * n, tab, n, L, LAYOUT_WPD, bc, filt, &acf, st);

@@ -88,6 +88,183 @@ __global__ __launch_bounds__(256) void k_jbb_costs(const T *__restrict__ sum, co
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// acwpd + JBB moments without the packet table (BASELINE config 5).
+// Below depth D0 the dilated autocorrelation steps (stride 2^d >= 2^D0) never mix samples of
+// different residue classes mod 2^D0, so the subtree under (node q of depth D0, class r) is an
+// independent undecimated packet decomposition of a signal of n' = n / 2^D0 samples.  One workgroup
+// owns one (q, r): it walks the signals in order, G at a time, keeps the G sub-signals' levels in
+// LDS and accumulates sum / sum-of-squares of every (node, sample) of its subtree in registers --
+// sequentially over the signals, i.e. in the order of Julia's sum(X, dims=3).  HBM sees only the
+// shallow top table (depth <= D0) instead of the full (n, 2^(L+1)-1) table per signal.
+// ------------------------------------------------------------------------------------------
+template <int LP, int G, int NL>
+__global__ __launch_bounds__(512) void k_acwpd_subtree_moments(const double *__restrict__ top, double *__restrict__ sum,
+                                                               double *__restrict__ sumsq, int log2n, int D0,
+                                                               int ncols_top, int64_t batch, WxAcFilt ac,
+                                                               int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    constexpr int NT = 512;
+    constexpr int GC = 4;                         // signals per inner chunk (register window)
+    const int n = 1 << log2n;
+    const int lnp = log2n - D0;                   // log2 of the sub-signal length n'
+    const int np = 1 << lnp;
+    const int q = blockIdx.x >> D0;               // node of depth D0
+    const int r = blockIdx.x & ((1 << D0) - 1);   // residue class
+    const int tid = threadIdx.x;
+    // level buffers: even levels in bufA, odd in bufB; per signal slot sizes szA / szB doubles
+    int szA = np, szB = 0;
+    for (int j = 1; j < LP; ++j) { const int c = np << j; if (j & 1) { if (c > szB) szB = c; } else if (c > szA) szA = c; }
+    double *bufA = reinterpret_cast<double *>(wx_smem);
+    double *bufB = bufA + (size_t)G * szA;
+    // odd-lag taps b_1, b_3, ... as LDS broadcasts (the lag loop stays rolled: unrolling it lets the
+    // scheduler hoist every window load and spill)
+    double *bl = bufB + (size_t)G * szB;
+    if (tid < NL) bl[tid] = ac.b[2 * tid];
+    const double c1 = ac.c1;
+    const int64_t colq = ((int64_t)1 << D0) - 1 + q;                // heap column (0-based) of the subtree root
+    const int64_t sig_stride = (int64_t)n * ncols_top;
+
+    // level j: item = tid mod cnt_j, the 512/cnt_j lane subsets share the G signals of a group
+    double s_lo[LP], q_lo[LP], s_hi[LP], q_hi[LP];
+#pragma unroll
+    for (int j = 0; j < LP; ++j) { s_lo[j] = q_lo[j] = s_hi[j] = q_hi[j] = 0.0; }
+
+    for (int64_t sig0 = 0; sig0 < batch; sig0 += G) {
+        const int gcount = (batch - sig0 < G) ? (int)(batch - sig0) : G;
+        for (int e = tid; e < G * np; e += NT) {
+            const int g = e >> lnp, i = e & (np - 1);
+            bufA[(size_t)g * szA + i] = g < gcount ? top[(sig0 + g) * sig_stride + colq * n + r + ((int64_t)i << D0)] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < LP; ++j) {
+            const double *cur = (j & 1) ? bufB : bufA;
+            double *nxt = (j & 1) ? bufA : bufB;
+            const int scur = (j & 1) ? szB : szA, snxt = (j & 1) ? szA : szB;
+            const int lcnt = lnp + j;                                 // log2(items of this level)
+            const int item = tid & ((1 << lcnt) - 1);
+            const int sub = tid >> lcnt;                              // lane subset
+            const int nsub = NT >> lcnt;
+            const int p = item >> lnp, i = item & (np - 1);
+            const int st = 1 << j;
+            const double *v = cur + ((size_t)p << lnp);
+            for (int g0 = sub; g0 < gcount; g0 += nsub * GC) {
+                double S[GC];
+#pragma unroll
+                for (int c = 0; c < GC; ++c) S[c] = 0.0;
+                int km = (i - st) & (np - 1), kp = (i + st) & (np - 1);
+#pragma unroll 1
+                for (int l = 0; l < NL; ++l) {
+                    const double bt = bl[l];
+#pragma unroll
+                    for (int c = 0; c < GC; ++c) {
+                        const int g = g0 + c * nsub;                  // g >= G reads stay inside the buffer pair
+                        const size_t off = (size_t)(g < G ? g : g0) * scur;
+                        S[c] = fma(bt, v[off + km] + v[off + kp], S[c]);
+                    }
+                    km = (km - 2 * st) & (np - 1);
+                    kp = (kp + 2 * st) & (np - 1);
+                }
+#pragma unroll
+                for (int c = 0; c < GC; ++c) {
+                    const int g = g0 + c * nsub;
+                    if (g < gcount) {
+                        const double cc = c1 * v[(size_t)g * scur + i];
+                        const double lo = cc + S[c], hi = cc - S[c];
+                        s_lo[j] += lo; q_lo[j] += lo * lo;
+                        s_hi[j] += hi; q_hi[j] += hi * hi;
+                        if (j + 1 < LP) {
+                            double *o = nxt + (size_t)g * snxt;
+                            o[((size_t)(2 * p) << lnp) + i] = lo;
+                            o[((size_t)(2 * p + 1) << lnp) + i] = hi;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // combine the lane subsets (in subset order) and add to the heap columns of the subtree
+    const int64_t H = ((int64_t)1 << D0) + q;                         // 1-based heap index of the subtree root
+    double *red = bufA;                                               // 4 * NT doubles
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+        const int lcnt = lnp + j;
+        const int nsub = NT >> lcnt;
+        __syncthreads();
+        red[tid] = s_lo[j]; red[NT + tid] = q_lo[j]; red[2 * NT + tid] = s_hi[j]; red[3 * NT + tid] = q_hi[j];
+        __syncthreads();
+        if (tid < (1 << lcnt)) {
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int sidx = 0; sidx < nsub; ++sidx) {
+                const int t = tid + (sidx << lcnt);
+                a0 += red[t]; a1 += red[NT + t]; a2 += red[2 * NT + t]; a3 += red[3 * NT + t];
+            }
+            const int p = tid >> lnp, i = tid & (np - 1);
+            const int64_t hl = (H << (j + 1)) + 2 * p;               // low child, 1-based
+            const int64_t row = r + ((int64_t)i << D0);
+            const int64_t el = (hl - 1) * n + row, eh = hl * n + row;
+            if (accumulate) { sum[el] += a0; sumsq[el] += a1; sum[eh] += a2; sumsq[eh] += a3; }
+            else { sum[el] = a0; sumsq[el] = a1; sum[eh] = a2; sumsq[eh] = a3; }
+        }
+    }
+}
+
+// D0 for which the deepest subtree level has at most 512 (parent, sample) items; < 0 if the fused
+// path does not apply
+int wx_acwpd_fused_depth(int64_t n, int L, int F)
+{
+    const int NL = F / 2;
+    if (!(NL >= 1 && NL <= 10 && NL != 7)) return -1;
+    if (n < 2 || (n & (n - 1))) return -1;
+    int log2n = 0;
+    while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
+    for (int D0 = 0; D0 < L; ++D0) {
+        const int LP = L - D0;
+        if (LP > 6 || D0 > log2n) continue;
+        const int64_t cnt = (n >> D0) << (LP - 1);
+        if (cnt <= 512 && (n >> D0) >= 1) return D0;
+    }
+    return -1;
+}
+
+int wx_dev_acwpd_subtree_moments(const double *top, double *sum, double *sumsq, int64_t n, int L, int D0,
+                                 int64_t batch, const WxAcFilt &ac, int accumulate, hipStream_t st)
+{
+    constexpr int G = 8;
+    int log2n = 0;
+    while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
+    const int LP = L - D0;
+    const int np = (int)(n >> D0);
+    int szA = np, szB = 0;
+    for (int j = 1; j < LP; ++j) { const int c = np << j; if (j & 1) { if (c > szB) szB = c; } else if (c > szA) szA = c; }
+    size_t lds = ((size_t)G * (szA + szB) + 16) * sizeof(double);
+    if (lds < (size_t)4 * 512 * sizeof(double)) lds = (size_t)4 * 512 * sizeof(double);   // final reduction
+    const int ncols_top = (1 << (D0 + 1)) - 1;
+    const unsigned grid = 1u << (2 * D0);
+    typedef void (*kern_t)(const double *, double *, double *, int, int, int, int64_t, WxAcFilt, int);
+    kern_t kern = nullptr;
+    const int NL = ac.F / 2;
+#define WX_LP(NLV) \
+    switch (LP) { case 1: kern = k_acwpd_subtree_moments<1, G, NLV>; break; case 2: kern = k_acwpd_subtree_moments<2, G, NLV>; break; \
+                  case 3: kern = k_acwpd_subtree_moments<3, G, NLV>; break; case 4: kern = k_acwpd_subtree_moments<4, G, NLV>; break; \
+                  case 5: kern = k_acwpd_subtree_moments<5, G, NLV>; break; case 6: kern = k_acwpd_subtree_moments<6, G, NLV>; break; }
+    switch (NL) {
+    case 1: WX_LP(1) break; case 2: WX_LP(2) break; case 3: WX_LP(3) break; case 4: WX_LP(4) break; case 5: WX_LP(5) break;
+    case 6: WX_LP(6) break; case 8: WX_LP(8) break; case 9: WX_LP(9) break; case 10: WX_LP(10) break;
+    }
+#undef WX_LP
+    if (!kern) return wx_set_error(WX_EUNSUPPORTED, "fused acwpd moments: unsupported filter length / subtree depth");
+    if (lds > 64 * 1024)
+        WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, top, sum, sumsq, log2n, D0, ncols_top, batch, ac, accumulate);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
 template <typename T>
 int wx_dev_jbb_moments(const T *X, T *sum, T *sumsq, int64_t nk, int64_t batch, int accumulate, T *scratch,
                        int nchunks, hipStream_t st)

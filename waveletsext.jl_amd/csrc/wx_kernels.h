@@ -57,3 +57,8 @@ template <typename T> bool wx_wpt2d_fast_ok(int64_t m, int64_t n, int F);
 template <typename T>
 int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const WxFilt &filt, T *tmp,
                       bool inverse, int64_t in_img, hipStream_t st);
+
+// ---- fused acwpd + JBB moments (wx_jbb.hip) ----
+int wx_acwpd_fused_depth(int64_t n, int L, int F);
+int wx_dev_acwpd_subtree_moments(const double *top, double *sum, double *sumsq, int64_t n, int L, int D0,
+                                 int64_t batch, const WxAcFilt &ac, int accumulate, hipStream_t st);
