@@ -40,10 +40,10 @@ WORKLOADS = {
                  desc="BASELINE config 3: swptall+iswptall (average-based) 16384-sample f64 haar L=12; one resident "
                       "chunk of 64 signals (32 GiB of leaves) of the 8192-signal batch per step"),
     "cfg4": dict(kind="wpt2d", m=512, n=512, batch=512, wavelet="db4", L=6, dtype="f32",
-                 kernel="k_dwt2d_dim2<float, false>",
+                 kernel="k_rows_fused<float, 8, false>",
                  desc="BASELINE config 4: 2-D wptall+iwptall 512x512 f32 db4 L=6, 512 images per GPU (4096 / 8)"),
     "cfg5": dict(kind="acwpd_jbb", n=2048, batch=2048, wavelet="coif6", L=11, dtype="f64",
-                 kernel="k_swt_fwd_level<double, true>",
+                 kernel="k_acwpd_subtree_moments<5, 8, 9>",
                  desc="BASELINE config 5: acwpd + JBB moments/costs/tree 2048-sample f64 coif6 L=11; 2048-signal slice "
                       "of the 32768-signal per-GPU shard per step (no inverse: output is the tree)"),
 }
@@ -128,14 +128,38 @@ def cpu_baseline(w, seconds):
             return dt, B * n
         raise ValueError(kind)
 
+    def run_omp(B):
+        """all host cores: OpenMP over the batch (1-D decimated workloads only)"""
+        n = w["n"]
+        tree = wo.maketree1d(n, L, "full").astype(np.uint8)
+        x = np.asfortranarray(rng.standard_normal((n, B)))
+        xh = np.empty_like(x)
+        y = np.empty((n, L + 1, B) if kind == "wpd" else (n, B), order="F")
+        t0 = time.perf_counter()
+        if kind == "wpd":
+            lib.wxo_wpd_iwpd_roundtrip_omp_f64(P(xh), P(y), P(x), L64(n), I(L), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
+        else:
+            lib.wxo_wpt_iwpt_roundtrip_omp_f64(P(xh), P(y), P(x), L64(n), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
+        dt = time.perf_counter() - t0
+        assert np.abs(xh - x).max() < 1e-9
+        return dt, B * n
+
     probe = 16 if kind in ("wpd", "wpt") else 2
     t_probe, _ = run(probe)
     cap = 8192 if kind in ("wpd", "wpt") else (64 if kind == "wpt2d" else 32)
     B = int(max(probe, min(cap, seconds / (t_probe / probe))))
     dt, samples = run(B)
-    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "%d of the %d signals per step, same transform pair, oracle C -O2 single thread, %.1f s"
-                      % (B, w["batch"], dt)}
+    out = {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": "%d of the %d signals per step, same transform pair, oracle C -O2 single thread, %.1f s"
+                     % (B, w["batch"], dt)}
+    if kind in ("wpd", "wpt"):
+        nthr = int(lib.wxo_omp_max_threads())
+        Bo = int(min(16384, max(256, B * max(1, nthr // 4))))
+        run_omp(min(Bo, 1024))
+        dto, so = run_omp(Bo)
+        out["all_cores"] = {"value": so / dto / 1e6, "unit": "Msamples/s", "cores": nthr, "kind": "port",
+                            "sample": "%d signals, OpenMP over the batch, %.1f s" % (Bo, dto)}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

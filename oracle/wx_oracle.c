@@ -300,3 +300,30 @@ int wxo_iwptall1d_f64(double *y, const double *x, int64_t n, int64_t B, const ui
     for (int64_t b = 0; b < B && rc == 0; b++) rc = wxo_iwpt1d_tree_f64(y + b * n, x + b * n, n, tree, ntree, qmf, F);
     return rc;
 }
+
+/* "generous" CPU baseline: the same per-signal restatement with OpenMP over the
+ * batch on all host cores.  The reference itself has no threading anywhere. */
+#ifdef _OPENMP
+#include <omp.h>
+int wxo_omp_max_threads(void) { return omp_get_max_threads(); }
+#else
+int wxo_omp_max_threads(void) { return 1; }
+#endif
+void wxo_wpd_iwpd_roundtrip_omp_f64(double *xh, double *y, const double *x, int64_t n, int L, int64_t B,
+                                    const uint8_t *tree, int64_t ntree, const double *qmf, int F)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; b++) {
+        wxo_wpd1d_f64(y + b * n * (L + 1), x + b * n, n, L, qmf, F);
+        wxo_iwpd1d_tree_f64(xh + b * n, y + b * n * (L + 1), n, L + 1, tree, ntree, qmf, F);
+    }
+}
+void wxo_wpt_iwpt_roundtrip_omp_f64(double *xh, double *y, const double *x, int64_t n, int64_t B,
+                                    const uint8_t *tree, int64_t ntree, const double *qmf, int F)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; b++) {
+        wxo_wpt1d_tree_f64(y + b * n, x + b * n, n, tree, ntree, qmf, F);
+        wxo_iwpt1d_tree_f64(xh + b * n, y + b * n, n, tree, ntree, qmf, F);
+    }
+}
