@@ -179,6 +179,50 @@ int wx_treeselect_f32(float *costs, int64_t k, int64_t n, int type_max, uint8_t 
 int wx_acwpd_jbb_moments_f64(const double *x, double *sum, double *sumsq, int64_t n, int L, int64_t batch,
                              const double *qmf, int F, int accumulate, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 2-D redundant transforms.  Images (m, n) column-major, batch last.  Slices per image:
+ * sdwt/acdwt 3L+1 (SWT.jl:132-158), swpt/acwpt 4^L natural order (SWT.jl:474-513), swpd/acwpd
+ * (4^(L+1)-1)/3 in quad-heap order (SWT.jl:870-902).  sm as in the 1-D entry points.
+ * ------------------------------------------------------------------------------------------ */
+int wx_sdwt2d_f64(const double *x, double *xw, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_sdwt2d_f32(const float *x, float *xw, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_swpt2d_f64(const double *x, double *xw, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_swpt2d_f32(const float *x, float *xw, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_swpd2d_f64(const double *x, double *xw, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_swpd2d_f32(const float *x, float *xw, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+/* isdwt! 2-D SWT.jl:286-358; iswpt! 2-D :648-758; iswpd! 2-D :1095-1199 */
+int wx_isdwt2d_f64(const double *xw, double *x, int64_t m, int64_t n, int L, int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+int wx_isdwt2d_f32(const float *xw, float *x, int64_t m, int64_t n, int L, int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+int wx_iswpt2d_f64(const double *xw, double *x, int64_t m, int64_t n, int L, int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+int wx_iswpt2d_f32(const float *xw, float *x, int64_t m, int64_t n, int L, int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+int wx_iswpd2d_f64(const double *xw, double *x, int64_t m, int64_t n, int64_t ncols, int L, const uint8_t *tree, int64_t ntree,
+                   int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+int wx_iswpd2d_f32(const float *xw, float *x, int64_t m, int64_t n, int64_t ncols, int L, const uint8_t *tree, int64_t ntree,
+                   int64_t sm, int64_t batch, const double *qmf, int F, void *stream);
+/* acdwt!/acwpt!/acwpd! 2-D ACWT.jl:131-157, 462-501, 761-793 and inverses :306-329, 612-648, 970-1000 (Float64) */
+int wx_acdwt2d_f64(const double *x, double *xw, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_acwpt2d_f64(const double *x, double *xw, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_acwpd2d_f64(const double *x, double *xw, int64_t m, int64_t n, int L, int64_t batch, const double *qmf, int F, void *stream);
+int wx_iacdwt2d_f64(const double *xw, double *x, int64_t m, int64_t n, int L, int64_t batch, void *stream);
+int wx_iacwpt2d_f64(const double *xw, double *x, int64_t m, int64_t n, int L, int64_t batch, void *stream);
+int wx_iacwpd2d_f64(const double *xw, double *x, int64_t m, int64_t n, int64_t ncols, int L, const uint8_t *tree, int64_t ntree,
+                    int64_t batch, void *stream);
+
+/* tree_costs(X::Array{T,4}, ::JBB) bestbasis_tree.jl:182-207 from moments (wx_jbb_moments_* with nk = m*n*k);
+ * costs has k entries (redundant) or (4^k - 1)/3 (wpd table with k slices) */
+int wx_jbb_costs2d_f64(const double *sum, const double *sumsq, int64_t Ntot, int64_t m, int64_t n, int64_t k, int redundant,
+                       int cost_kind, double p, double *costs, void *stream);
+int wx_jbb_costs2d_f32(const float *sum, const float *sumsq, int64_t Ntot, int64_t m, int64_t n, int64_t k, int redundant,
+                       int cost_kind, double p, float *costs, void *stream);
+/* bestbasis_treeselection(costs, n, m, type) BestBasis.jl:85-110 (HOST pointers; tree gets gettreelength(m,n) bytes) */
+int wx_treeselect2d_f64(double *costs, int64_t k, int64_t m, int64_t n, int type_max, uint8_t *tree);
+int wx_treeselect2d_f32(float *costs, int64_t k, int64_t m, int64_t n, int type_max, uint8_t *tree);
+/* getbasiscoef / getbasiscoefall for 2-D signals Utils.jl:127-130, 192-195.  Xw (m,n,k,batch) -> out (m,n,batch) */
+int wx_getbasiscoef2d_f64(const double *Xw, double *out, int64_t m, int64_t n, int k, const uint8_t *tree, int64_t ntree,
+                          int64_t batch, void *stream);
+int wx_getbasiscoef2d_f32(const float *Xw, float *out, int64_t m, int64_t n, int k, const uint8_t *tree, int64_t ntree,
+                          int64_t batch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -500,3 +500,66 @@ def bestbasistree_jbb(X, redundant=False, cost="loglp", p=None):
     """bestbasistree(X, JBB(...)) BestBasis.jl:194-201 for 1-D signals."""
     X = _f(X)
     return bestbasis_treeselection(tree_costs_jbb(X, redundant, cost, p), X.shape[0])
+
+
+# ---- 2-D redundant families, 2-D JBB, 2-D getbasiscoef --------------------------------------------
+def _ncols2d(kind, L):
+    return {"dwt": 3 * L + 1, "wpt": 1 << (2 * L), "wpd": ((1 << (2 * (L + 1))) - 1) // 3}[kind]
+
+
+def red2d_fwd(kind, x, qmf, L=None, ac=False):
+    """sdwt/swpt/swpd (ac=False) or acdwt/acwpt/acwpd (ac=True) of an (n, m) image"""
+    x = _f(x); q, qp, F = _q(qmf); n, m = x.shape
+    L = maxtransformlevels(min(n, m)) if L is None else L
+    xw = np.empty((n, m, _ncols2d(kind, L)), x.dtype, order="F")
+    _chk(_call("wxo_red_%s2d" % kind, x.dtype, _p(xw), _p(x), n, m, _I(L), _I(int(ac)), qp, _I(F)))
+    return xw
+
+
+def red2d_inv(kind, xw, qmf=None, L_or_tree=None, sm=None, ac=False):
+    xw = _f(xw); n, m, k = xw.shape
+    q, qp, F = _q(qmf if qmf is not None else [1.0, 1.0])
+    x = np.empty((n, m), xw.dtype, order="F")
+    smv = -1 if sm is None else sm
+    if kind == "dwt":
+        _chk(_call("wxo_ired_dwt2d", xw.dtype, _p(x), _p(xw), n, m, _I(k), _I(int(ac)), smv, qp, _I(F)))
+    elif kind == "wpt":
+        _chk(_call("wxo_ired_wpt2d", xw.dtype, _p(x), _p(xw), n, m, k, _I(int(ac)), smv, qp, _I(F)))
+    else:
+        t, tp, nt = _tree(_tree_for((n, m), L_or_tree))
+        _chk(_call("wxo_ired_wpd2d", xw.dtype, _p(x), _p(xw), n, m, k, tp, nt, _I(int(ac)), smv, qp, _I(F)))
+    return x
+
+
+def getbasiscoef2d(Xw, tree):
+    Xw = _f(Xw); n, m, k = Xw.shape
+    t, tp, nt = _tree(tree)
+    out = np.empty((n, m), Xw.dtype, order="F")
+    _chk(_call("wxo_getbasiscoef2d", Xw.dtype, _p(out), _p(Xw), n, m, _I(k), tp, nt))
+    return out
+
+
+def tree_costs_jbb2d(X, redundant=False, cost="loglp", p=None):
+    """tree_costs(X::Array{T,4}, JBB(cost, redundant)); X is (n, m, L, N)."""
+    X = _f(X); n, m, L, N = X.shape
+    p = (2.0 if cost == "loglp" else 1.0) if p is None else float(p)
+    ncost = L if redundant else ((1 << (2 * L)) - 1) // 3
+    costs = np.empty(ncost, X.dtype)
+    _chk(_call("wxo_tree_costs_jbb2d", X.dtype, _p(costs), _p(X), n, m, L, N, _I(int(redundant)),
+               _I(0 if cost == "loglp" else 1), _D(p)))
+    return costs
+
+
+def bestbasis_treeselection2d(costs, n, m, kind="min"):
+    costs = np.array(costs, copy=True)
+    if costs.dtype not in (np.float32, np.float64):
+        costs = costs.astype(np.float64)
+    tree = np.zeros(gettreelength(n, m), dtype=np.uint8)
+    _chk(_call("wxo_bestbasis_treeselection2d", costs.dtype, _p(tree), _p(costs), costs.size, n, m,
+               _I(0 if kind == "min" else 1)))
+    return tree.astype(bool)
+
+
+def bestbasistree_jbb2d(X, redundant=False, cost="loglp", p=None):
+    X = _f(X)
+    return bestbasis_treeselection2d(tree_costs_jbb2d(X, redundant, cost, p), X.shape[0], X.shape[1])

@@ -817,12 +817,6 @@ int FN(wxo_iacwpd1d)(T *x, const T *xw, int64_t n, int64_t m, const uint8_t *tre
     return rc;
 }
 
-/* ------------------------------------------------------------------------- */
-/* bestbasis/bestbasis_tree.jl:150-180  tree_costs(X::Array{T,3}, ::JBB)      */
-/* X is (n, L, N).  cost_kind 0 = LoglpCost(p), 1 = NormCost(p)               */
-/* (bestbasis_costs.jl:127-132).  costs must hold L (redundant) or 2^L-1      */
-/* entries.  Returns -1 if the @assert all(sigma .>= 0) fails (NaN sigma).    */
-/* ------------------------------------------------------------------------- */
 /* bestbasis_costs.jl:127-132  coefcost(x, ::LoglpCost) = p*sum(log.(abs.(x)));
  * coefcost(x, ::NormCost) = norm(x,p)^p.  Plain left-to-right sums (Julia's own sum is a
  * pairwise/SIMD reassociation with no fixed order; agreement ~1e-13 relative). */
@@ -838,6 +832,306 @@ static T FN(wxo_coefcost_jbb)(const T *x, int64_t n, int cost_kind, double p)
     return (T)s;
 }
 
+/* ------------------------------------------------------------------------- */
+/* 2-D redundant drivers.  All images are (n, m) dense column-major, slices are */
+/* n*m apart.  AC variants use acdwt_step!/iacdwt_step! 2-D.                    */
+/* ------------------------------------------------------------------------- */
+static void FN(acdwt_step2)(T *w1, T *w2, T *w3, T *w4, const T *v, int64_t n, int64_t m, int d,
+                            const double *h, const double *g, int AL, T *temp)
+{
+    T *t1 = temp, *t2 = temp + n * m;
+    for (int64_t j = 1; j <= m; j++)
+        FN(acdwt_step_s)(&M2(t1, n, 1, j), 1, &M2(t2, n, 1, j), 1, &M2(v, n, 1, j), 1, n, d, h, g, AL);
+    for (int64_t i = 1; i <= n; i++) {
+        FN(acdwt_step_s)(&M2(w1, n, i, 1), n, &M2(w2, n, i, 1), n, &M2(t1, n, i, 1), n, m, d, h, g, AL);
+        FN(acdwt_step_s)(&M2(w3, n, i, 1), n, &M2(w4, n, i, 1), n, &M2(t2, n, i, 1), n, m, d, h, g, AL);
+    }
+}
+static void FN(iacdwt_step2)(T *v, const T *w1, const T *w2, const T *w3, const T *w4, int64_t n, int64_t m, T *temp)
+{
+    T *t1 = temp, *t2 = temp + n * m;
+    for (int64_t i = 1; i <= n; i++) {
+        FN(iacdwt_step_s)(&M2(t1, n, i, 1), n, &M2(w1, n, i, 1), n, &M2(w2, n, i, 1), n, m);
+        FN(iacdwt_step_s)(&M2(t2, n, i, 1), n, &M2(w3, n, i, 1), n, &M2(w4, n, i, 1), n, m);
+    }
+    for (int64_t j = 1; j <= m; j++)
+        FN(iacdwt_step_s)(&M2(v, n, 1, j), 1, &M2(t1, n, 1, j), 1, &M2(t2, n, 1, j), 1, n);
+}
+
+/* one forward step on slices: ac selects acdwt_step! (filters P,Q) instead of sdwt_step! (g,h) */
+static void FN(red_fwd2)(T *w1, T *w2, T *w3, T *w4, const T *v, int64_t n, int64_t m, int d, int ac,
+                         const double *f1, const double *f2, int flen, T *temp)
+{
+    if (ac) FN(acdwt_step2)(w1, w2, w3, w4, v, n, m, d, f1, f2, flen, temp);     /* (h=Q, g=P) */
+    else FN(sdwt_step2)(w1, w2, w3, w4, v, n, m, d, f1, f2, flen, temp);         /* (h, g) */
+}
+
+/* SWT.jl:132-158 sdwt! 2-D / ACWT.jl:131-157 acdwt! 2-D; xw is (n, m, 3L+1) */
+int FN(wxo_red_dwt2d)(T *xw, const T *x, int64_t n, int64_t m, int L, int ac, const double *qmf, int F)
+{
+    int Lmax = wxo_maxtransformlevels(n < m ? n : m);
+    if (!(L <= Lmax) || !(L >= 1)) return -2;
+    int flen = ac ? 2 * F - 1 : F;
+    double *f1 = (double *)malloc(sizeof(double) * flen), *f2 = (double *)malloc(sizeof(double) * flen);
+    if (ac) { double *P = f2, *Q = f1; wxo_make_acreverseqmfpair(qmf, F, P, Q); }   /* g=P -> f2, h=Q -> f1 */
+    else { double *g = f2, *h = f1; wxo_makereverseqmfpair(qmf, F, g, h); }
+    int64_t nm = n * m;
+    T *temp = (T *)malloc(sizeof(T) * 2 * nm), *v = (T *)malloc(sizeof(T) * nm);
+    for (int64_t i = 0; i < nm; i++) xw[(int64_t)(3 * L) * nm + i] = x[i];          /* xw[:,:,end] = x */
+    for (int d = 0; d <= L - 1; d++) {
+        for (int64_t i = 0; i < nm; i++) v[i] = xw[(int64_t)(3 * (L - d)) * nm + i]; /* slice 3(L-d)+1 */
+        FN(red_fwd2)(xw + (int64_t)(3 * (L - d) - 3) * nm, xw + (int64_t)(3 * (L - d) - 2) * nm,
+                     xw + (int64_t)(3 * (L - d) - 1) * nm, xw + (int64_t)(3 * (L - d)) * nm, v, n, m, d, ac,
+                     f1, f2, flen, temp);
+    }
+    free(temp); free(v); free(f1); free(f2);
+    return 0;
+}
+
+/* SWT.jl:286-311 (sm >= 0), :332-358 (sm < 0) isdwt! 2-D; ACWT.jl:306-329 iacdwt! 2-D (ac) */
+int FN(wxo_ired_dwt2d)(T *x, const T *xw, int64_t n, int64_t m, int k, int ac, int64_t sm, const double *qmf, int F)
+{
+    int L = (k - 1) / 3;
+    int64_t nm = n * m;
+    int64_t *sd = NULL;
+    double *g = NULL, *h = NULL;
+    if (!ac) {
+        if (sm >= 0) {
+            /* @assert 0 <= log2(sm) <= L (:293) then main2depthshift asserts sm < 2^L */
+            if (!(sm >= 1 && sm <= ((int64_t)1 << L))) return -1;
+            if (!(sm < ((int64_t)1 << L))) return -1;
+            sd = (int64_t *)malloc(sizeof(int64_t) * (L + 1));
+            wxo_main2depthshift(sm, L, sd);
+        }
+        g = (double *)malloc(sizeof(double) * F); h = (double *)malloc(sizeof(double) * F);
+        wxo_makereverseqmfpair(qmf, F, g, h);
+    }
+    T *temp = (T *)calloc(2 * nm, sizeof(T)), *w1 = (T *)malloc(sizeof(T) * nm);
+    int rc = 0;
+    for (int64_t i = 0; i < nm; i++) x[i] = xw[i];
+    for (int d = L - 1; d >= 0; d--) {
+        for (int64_t i = 0; i < nm; i++) w1[i] = x[i];
+        const T *w2 = xw + (int64_t)(3 * (L - d) - 2) * nm, *w3 = xw + (int64_t)(3 * (L - d) - 1) * nm,
+                *w4 = xw + (int64_t)(3 * (L - d)) * nm;
+        if (ac) FN(iacdwt_step2)(x, w1, w2, w3, w4, n, m, temp);
+        else rc |= FN(isdwt_step2)(x, w1, w2, w3, w4, n, m, d, sm >= 0, sm >= 0 ? sd[d] : 0, sm >= 0 ? sd[d + 1] : 0, h, g, F, temp);
+    }
+    free(temp); free(w1); free(sd); free(g); free(h);
+    return rc ? -1 : 0;
+}
+
+/* SWT.jl:474-513 swpt! 2-D / ACWT.jl:462-501 acwpt! 2-D; xw is (n, m, 4^L) */
+int FN(wxo_red_wpt2d)(T *xw, const T *x, int64_t n, int64_t m, int L, int ac, const double *qmf, int F)
+{
+    int Lmax = wxo_maxtransformlevels(n < m ? n : m);
+    if (!(L <= Lmax) || !(L >= 1)) return -2;
+    int flen = ac ? 2 * F - 1 : F;
+    double *f1 = (double *)malloc(sizeof(double) * flen), *f2 = (double *)malloc(sizeof(double) * flen);
+    if (ac) wxo_make_acreverseqmfpair(qmf, F, f2, f1); else wxo_makereverseqmfpair(qmf, F, f2, f1);
+    int64_t nm = n * m;
+    T *temp = (T *)malloc(sizeof(T) * 2 * nm), *v = (T *)malloc(sizeof(T) * nm);
+    for (int64_t i = 0; i < nm; i++) xw[i] = x[i];
+    int64_t tot = (int64_t)1 << (2 * L);
+    for (int d = 0; d <= L - 1; d++) {
+        int64_t nn = (int64_t)1 << (2 * d);
+        for (int64_t b = 0; b <= nn - 1; b++) {
+            int64_t np = tot / nn, nc = np / 4;
+            int64_t j1 = (4 * b) * nc, j2 = (4 * b + 1) * nc, j3 = (4 * b + 2) * nc, j4 = (4 * b + 3) * nc;   /* 0-based */
+            for (int64_t i = 0; i < nm; i++) v[i] = xw[j1 * nm + i];
+            FN(red_fwd2)(xw + j1 * nm, xw + j2 * nm, xw + j3 * nm, xw + j4 * nm, v, n, m, d, ac, f1, f2, flen, temp);
+        }
+    }
+    free(temp); free(v); free(f1); free(f2);
+    return 0;
+}
+
+/* SWT.jl:648-683 (shift), :714-758 (average) iswpt! 2-D; ACWT.jl:612-648 iacwpt! 2-D; xw (n, m, k = 4^L) */
+int FN(wxo_ired_wpt2d)(T *x, const T *xw, int64_t n, int64_t m, int64_t k, int ac, int64_t sm, const double *qmf, int F)
+{
+    int L = 0;
+    while (((int64_t)1 << (2 * (L + 1))) <= k) L++;
+    if (((int64_t)1 << (2 * L)) != k) return -2;                          /* not a power of 4 */
+    if (!(L <= wxo_maxtransformlevels(n < m ? n : m))) return -1;
+    int64_t nm = n * m;
+    int64_t *sd = NULL;
+    double *g = NULL, *h = NULL;
+    if (!ac) {
+        if (sm >= 0) {
+            if (!(sm < ((int64_t)1 << L))) return -1;
+            sd = (int64_t *)malloc(sizeof(int64_t) * (L + 1));
+            wxo_main2depthshift(sm, L, sd);
+        }
+        g = (double *)malloc(sizeof(double) * F); h = (double *)malloc(sizeof(double) * F);
+        wxo_makereverseqmfpair(qmf, F, g, h);
+    }
+    T *xwt = (T *)malloc(sizeof(T) * nm * k), *temp = (T *)calloc(2 * nm, sizeof(T)), *w1 = (T *)malloc(sizeof(T) * nm);
+    for (int64_t i = 0; i < nm * k; i++) xwt[i] = xw[i];
+    int rc = 0;
+    if (L == 0) for (int64_t i = 0; i < nm; i++) x[i] = xw[i];
+    for (int d = L - 1; d >= 0; d--) {
+        int64_t nn = (int64_t)1 << (2 * d);
+        for (int64_t b = 0; b <= nn - 1; b++) {
+            int64_t np = k / nn, nc = np / 4;
+            int64_t j1 = (4 * b) * nc, j2 = (4 * b + 1) * nc, j3 = (4 * b + 2) * nc, j4 = (4 * b + 3) * nc;
+            T *v = d == 0 ? x : xwt + j1 * nm;
+            for (int64_t i = 0; i < nm; i++) w1[i] = xwt[j1 * nm + i];
+            if (ac) FN(iacdwt_step2)(v, w1, xwt + j2 * nm, xwt + j3 * nm, xwt + j4 * nm, n, m, temp);
+            else rc |= FN(isdwt_step2)(v, w1, xwt + j2 * nm, xwt + j3 * nm, xwt + j4 * nm, n, m, d, sm >= 0,
+                                       sm >= 0 ? sd[d] : 0, sm >= 0 ? sd[d + 1] : 0, h, g, F, temp);
+        }
+    }
+    free(xwt); free(temp); free(w1); free(sd); free(g); free(h);
+    return rc ? -1 : 0;
+}
+
+/* SWT.jl:870-902 swpd! 2-D / ACWT.jl:761-793 acwpd! 2-D; xw is (n, m, (4^(L+1)-1)/3), quad heap order */
+int FN(wxo_red_wpd2d)(T *xw, const T *x, int64_t n, int64_t m, int L, int ac, const double *qmf, int F)
+{
+    int flen = ac ? 2 * F - 1 : F;
+    double *f1 = (double *)malloc(sizeof(double) * flen), *f2 = (double *)malloc(sizeof(double) * flen);
+    if (ac) wxo_make_acreverseqmfpair(qmf, F, f2, f1); else wxo_makereverseqmfpair(qmf, F, f2, f1);
+    int64_t nm = n * m;
+    int64_t k = ((((int64_t)1 << (2 * (L + 1))) - 1) / 3);
+    int64_t n1 = k - ((int64_t)1 << (2 * L));
+    T *temp = (T *)malloc(sizeof(T) * 2 * nm);
+    for (int64_t i = 0; i < nm; i++) xw[i] = x[i];
+    for (int64_t i = 1; i <= n1; i++) {
+        int d = wxo_getdepth_quad(i);
+        FN(red_fwd2)(xw + (4 * i - 2 - 1) * nm, xw + (4 * i - 1 - 1) * nm, xw + (4 * i - 1) * nm, xw + (4 * i + 1 - 1) * nm,
+                     xw + (i - 1) * nm, n, m, d, ac, f1, f2, flen, temp);
+    }
+    free(temp); free(f1); free(f2);
+    return 0;
+}
+
+/* SWT.jl:1095-1129 (shift), :1162-1199 (average) iswpd! 2-D; ACWT.jl:970-1000 iacwpd! 2-D */
+int FN(wxo_ired_wpd2d)(T *x, const T *xw, int64_t n, int64_t m, int64_t k, const uint8_t *tree, int64_t ntree,
+                       int ac, int64_t sm, const double *qmf, int F)
+{
+    if (!wxo_isvalidtree2d(n, m, tree, ntree)) return -1;
+    int64_t nm = n * m;
+    int L = wxo_getdepth_quad(k);
+    int64_t *sd = NULL;
+    double *g = NULL, *h = NULL;
+    if (!ac) {
+        if (sm >= 0) {
+            if (!(sm < ((int64_t)1 << L))) return -1;
+            sd = (int64_t *)malloc(sizeof(int64_t) * (L + 1));
+            wxo_main2depthshift(sm, L, sd);
+        }
+        g = (double *)malloc(sizeof(double) * F); h = (double *)malloc(sizeof(double) * F);
+        wxo_makereverseqmfpair(qmf, F, g, h);
+    }
+    T *xwt = (T *)malloc(sizeof(T) * nm * k), *temp = (T *)calloc(2 * nm, sizeof(T));
+    for (int64_t i = 0; i < nm * k; i++) xwt[i] = xw[i];
+    int rc = 0;
+    for (int64_t i = ntree; i >= 1; i--) {
+        if (!tree[i - 1]) continue;
+        int d = wxo_getdepth_quad(i);
+        if (4 * i + 1 > k) { rc = -3; break; }
+        T *v = i == 1 ? x : xwt + (i - 1) * nm;
+        const T *c1 = xwt + (4 * i - 2 - 1) * nm, *c2 = xwt + (4 * i - 1 - 1) * nm, *c3 = xwt + (4 * i - 1) * nm,
+                *c4 = xwt + (4 * i + 1 - 1) * nm;
+        if (ac) FN(iacdwt_step2)(v, c1, c2, c3, c4, n, m, temp);
+        else rc |= FN(isdwt_step2)(v, c1, c2, c3, c4, n, m, d, sm >= 0, sm >= 0 ? sd[d] : 0, sm >= 0 ? sd[d + 1] : 0,
+                                   h, g, F, temp);
+    }
+    if (!(ntree >= 1 && tree[0])) for (int64_t i = 0; i < nm; i++) x[i] = xw[i];
+    free(xwt); free(temp); free(sd); free(g); free(h);
+    return rc < 0 ? rc : (rc ? -1 : 0);
+}
+
+/* Utils.jl:101-134  getbasiscoef(Xw, tree), N==3 branch (2-D signals); Xw is (n, m, k) */
+int FN(wxo_getbasiscoef2d)(T *xw, const T *Xw, int64_t n, int64_t m, int k, const uint8_t *tree, int64_t ntree)
+{
+    int L = wxo_maxtransformlevels(n < m ? n : m);
+    if (!wxo_isvalidtree2d(n, m, tree, ntree)) return -1;
+    if (!(k - 1 <= L)) return -1;
+    int64_t nleaf = 4 * ntree + 1;
+    uint8_t *leaf = (uint8_t *)calloc(nleaf, 1);
+    if (wxo_getleaf_quad(leaf, tree, ntree) != 0) { free(leaf); return -1; }
+    int64_t leaf_len = ((((int64_t)1 << (2 * (L + 1))) - 1) / 3);               /* gettreelength(2^(L+1), 2^(L+1)) */
+    if (leaf_len != nleaf) { free(leaf); return -1; }
+    for (int64_t i = 1; i <= nleaf; i++) {
+        if (!leaf[i - 1]) continue;
+        int d = wxo_getdepth_quad(i);
+        if (!(d < k)) { free(leaf); return -2; }
+        int64_t r0, r1, c0, c1;
+        wxo_getrowrange(n, i, &r0, &r1); wxo_getcolrange(m, i, &c0, &c1);
+        for (int64_t c = c0; c <= c1; c++)
+            for (int64_t r = r0; r <= r1; r++) M2(xw, n, r, c) = M2(Xw + (int64_t)d * n * m, n, r, c);
+    }
+    free(leaf);
+    return 0;
+}
+
+/* bestbasis/bestbasis_tree.jl:182-207  tree_costs(X::Array{T,4}, ::JBB); X is (n, m, L, N) */
+int FN(wxo_tree_costs_jbb2d)(T *costs, const T *X, int64_t n, int64_t m, int64_t L, int64_t N, int redundant,
+                             int cost_kind, double p)
+{
+    int64_t nl = n * m * L;
+    T *EX = (T *)calloc(nl, sizeof(T)), *EX2 = (T *)calloc(nl, sizeof(T)), *sig = (T *)malloc(sizeof(T) * nl);
+    for (int64_t s = 0; s < N; s++)
+        for (int64_t e = 0; e < nl; e++) {
+            T xv = X[s * nl + e];
+            EX[e] = (T)(EX[e] + xv);
+            EX2[e] = (T)(EX2[e] + (T)(xv * xv));
+        }
+    int bad = 0;
+    for (int64_t e = 0; e < nl; e++) {
+        T ex = (T)(EX[e] / (T)N), ex2 = (T)(EX2[e] / (T)N);
+        sig[e] = (T)sqrt((double)(T)(ex2 - (T)(ex * ex)));
+        if (!(sig[e] >= 0)) bad = 1;
+    }
+    if (bad) { free(EX); free(EX2); free(sig); return -1; }
+    if (redundant) {
+        for (int64_t i = 1; i <= L; i++) {
+            int d = wxo_getdepth_quad(i);
+            costs[i - 1] = (T)(FN(wxo_coefcost_jbb)(sig + (i - 1) * n * m, n * m, cost_kind, p) / (T)((int64_t)1 << (2 * d)));
+        }
+    } else {
+        int64_t nc = ((((int64_t)1 << (2 * L)) - 1) / 3);                       /* gettreelength(1<<L, 1<<L) */
+        T *blk = (T *)malloc(sizeof(T) * n * m);
+        for (int64_t i = 1; i <= nc; i++) {
+            int d = wxo_getdepth_quad(i);
+            int64_t r0, r1, c0, c1;
+            wxo_getrowrange(n, i, &r0, &r1); wxo_getcolrange(m, i, &c0, &c1);
+            int64_t cnt = 0;
+            for (int64_t c = c0; c <= c1; c++)
+                for (int64_t r = r0; r <= r1; r++) blk[cnt++] = M2(sig + (int64_t)d * n * m, n, r, c);
+            costs[i - 1] = FN(wxo_coefcost_jbb)(blk, cnt, cost_kind, p);
+        }
+        free(blk);
+    }
+    free(EX); free(EX2); free(sig);
+    return 0;
+}
+
+/* BestBasis.jl:85-110  bestbasis_treeselection(costs, n, m, type) (quad tree) */
+int FN(wxo_bestbasis_treeselection2d)(uint8_t *tree, T *costs, int64_t k, int64_t n, int64_t m, int type_max)
+{
+    if (!(k <= wxo_gettreelength2d(2 * n, 2 * m))) return -1;
+    int L = wxo_getdepth_quad(k);
+    int64_t ntree = wxo_gettreelength2d(n, m);
+    if (wxo_maketree2d(tree, n, m, L, 0) != 0) return -1;
+    for (int64_t i = ntree; i >= 1; i--) {
+        if (tree[i - 1]) {
+            T pc = costs[i - 1];
+            T cc = (T)((T)((T)(costs[4 * i - 2 - 1] + costs[4 * i - 1 - 1]) + costs[4 * i - 1]) + costs[4 * i + 1 - 1]);
+            if (!type_max && cc < pc) costs[i - 1] = cc;
+            else if (type_max && cc > pc) costs[i - 1] = cc;
+            else wxo_delete_subtree(tree, ntree, i, 1);
+        }
+    }
+    return wxo_isvalidtree2d(n, m, tree, ntree) ? 0 : -1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* bestbasis/bestbasis_tree.jl:150-180  tree_costs(X::Array{T,3}, ::JBB)      */
+/* X is (n, L, N).  cost_kind 0 = LoglpCost(p), 1 = NormCost(p)               */
+/* (bestbasis_costs.jl:127-132).  costs must hold L (redundant) or 2^L-1      */
+/* entries.  Returns -1 if the @assert all(sigma .>= 0) fails (NaN sigma).    */
+/* ------------------------------------------------------------------------- */
 int FN(wxo_tree_costs_jbb)(T *costs, const T *X, int64_t n, int64_t L, int64_t N, int redundant,
                            int cost_kind, double p)
 {

@@ -84,6 +84,20 @@ _EXTRA_SIGS = {
     "wx_iacwpt1d": [_P, _P, _L, _I, _L, _P],
     "wx_acwpd1d": [_P, _P, _L, _I, _L, _P, _I, _P],
     "wx_iacwpd1d": [_P, _P, _L, _L, _I, _P, _L, _L, _P],
+    "wx_sdwt2d": [_P, _P, _L, _L, _I, _L, _P, _I, _P],
+    "wx_swpt2d": [_P, _P, _L, _L, _I, _L, _P, _I, _P],
+    "wx_swpd2d": [_P, _P, _L, _L, _I, _L, _P, _I, _P],
+    "wx_isdwt2d": [_P, _P, _L, _L, _I, _L, _L, _P, _I, _P],
+    "wx_iswpt2d": [_P, _P, _L, _L, _I, _L, _L, _P, _I, _P],
+    "wx_iswpd2d": [_P, _P, _L, _L, _L, _I, _P, _L, _L, _L, _P, _I, _P],
+    "wx_acdwt2d": [_P, _P, _L, _L, _I, _L, _P, _I, _P],
+    "wx_acwpt2d": [_P, _P, _L, _L, _I, _L, _P, _I, _P],
+    "wx_acwpd2d": [_P, _P, _L, _L, _I, _L, _P, _I, _P],
+    "wx_iacdwt2d": [_P, _P, _L, _L, _I, _L, _P],
+    "wx_iacwpt2d": [_P, _P, _L, _L, _I, _L, _P],
+    "wx_iacwpd2d": [_P, _P, _L, _L, _L, _I, _P, _L, _L, _P],
+    "wx_jbb_costs2d": [_P, _P, _L, _L, _L, _L, _I, _I, ctypes.c_double, _P, _P],
+    "wx_getbasiscoef2d": [_P, _P, _L, _L, _I, _P, _L, _L, _P],
     "wx_jbb_moments": [_P, _P, _P, _L, _L, _I, _P],
     "wx_jbb_costs": [_P, _P, _L, _L, _L, _I, _I, ctypes.c_double, _P, _P],
     "wx_acwpd_jbb_moments": [_P, _P, _P, _L, _I, _L, _P, _I, _I, _P],
@@ -93,6 +107,8 @@ _EXTRA_SIGS = {
 _PLAIN_SIGS = {
     "wx_treeselect_f64": [_P, _L, _L, _I, _P],
     "wx_treeselect_f32": [_P, _L, _L, _I, _P],
+    "wx_treeselect2d_f64": [_P, _L, _L, _L, _I, _P],
+    "wx_treeselect2d_f32": [_P, _L, _L, _L, _I, _P],
 }
 
 

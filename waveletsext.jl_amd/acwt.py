@@ -58,50 +58,53 @@ def _f64(x):
 
 def acdwt(x, wt, L=None):
     """ACWT.jl:60-74"""
-    return _fwd("wx_acdwt1d", lambda L: L + 1, _f64(x).arr, wt, L, False)
+    return _fwd("wx_acdwt1d", "dwt", _f64(x).arr, wt, L, False)
 
 
 def acdwt_(xw, x, wt, L=None):
-    return _fwd("wx_acdwt1d", lambda L: L + 1, _f64(x).arr, wt, L, False, xw)
+    return _fwd("wx_acdwt1d", "dwt", _f64(x).arr, wt, L, False, xw)
 
 
 def acdwtall(x, wt, L=None):
     """acwt_all.jl:33"""
-    return _fwd("wx_acdwt1d", lambda L: L + 1, _f64(x).arr, wt, L, True)
+    return _fwd("wx_acdwt1d", "dwt", _f64(x).arr, wt, L, True)
 
 
 def acwpt(x, wt, L=None):
     """ACWT.jl:379-395"""
-    return _fwd("wx_acwpt1d", lambda L: 1 << L, _f64(x).arr, wt, L, False)
+    return _fwd("wx_acwpt1d", "wpt", _f64(x).arr, wt, L, False)
 
 
 def acwpt_(xw, x, wt, L=None):
-    return _fwd("wx_acwpt1d", lambda L: 1 << L, _f64(x).arr, wt, L, False, xw)
+    return _fwd("wx_acwpt1d", "wpt", _f64(x).arr, wt, L, False, xw)
 
 
 def acwptall(x, wt, L=None):
     """acwt_all.jl:136"""
-    return _fwd("wx_acwpt1d", lambda L: 1 << L, _f64(x).arr, wt, L, True)
+    return _fwd("wx_acwpt1d", "wpt", _f64(x).arr, wt, L, True)
 
 
 def acwpd(x, wt, L=None):
     """ACWT.jl:683-699"""
-    return _fwd("wx_acwpd1d", lambda L: (1 << (L + 1)) - 1, _f64(x).arr, wt, L, False)
+    return _fwd("wx_acwpd1d", "wpd", _f64(x).arr, wt, L, False)
 
 
 def acwpd_(xw, x, wt, L=None):
-    return _fwd("wx_acwpd1d", lambda L: (1 << (L + 1)) - 1, _f64(x).arr, wt, L, False, xw)
+    return _fwd("wx_acwpd1d", "wpd", _f64(x).arr, wt, L, False, xw)
 
 
 def acwpdall(x, wt, L=None):
     """acwt_all.jl:239"""
-    return _fwd("wx_acwpd1d", lambda L: (1 << (L + 1)) - 1, _f64(x).arr, wt, L, True)
+    return _fwd("wx_acwpd1d", "wpd", _f64(x).arr, wt, L, True)
 
 
 def _iacdwt(xw, batched, x=None):
     xw, sig, k, N = _inv_common(_f64(xw).arr, batched)
     out = xw.new(sig + ((N,) if batched else ())) if x is None else out_arg(x, xw)
-    _call("wx_iacdwt1d", "_f64", xw.ptr, out.ptr, sig[0], k - 1, 1 if N is None else N, xw.stream())
+    if len(sig) == 1:
+        _call("wx_iacdwt1d", "_f64", xw.ptr, out.ptr, sig[0], k - 1, 1 if N is None else N, xw.stream())
+    else:
+        _call("wx_iacdwt2d", "_f64", xw.ptr, out.ptr, sig[0], sig[1], (k - 1) // 3, 1 if N is None else N, xw.stream())
     return out.arr if x is None else x
 
 
@@ -120,6 +123,16 @@ def iacdwtall(xw, wt=None):
 
 def _iacwpt(xw, batched, x=None):
     xw, sig, m, N = _inv_common(_f64(xw).arr, batched)
+    if len(sig) == 2:
+        L = 0
+        while (1 << (2 * (L + 1))) <= m:
+            L += 1
+        if (1 << (2 * L)) != m:
+            raise ArgumentError("Size of dimension 3 is not a power of 4.")       # ACWT.jl:617
+        assert L <= maxtransformlevels(int(min(sig)))                              # ACWT.jl:620
+        out = xw.new(sig + ((N,) if batched else ())) if x is None else out_arg(x, xw)
+        _call("wx_iacwpt2d", "_f64", xw.ptr, out.ptr, sig[0], sig[1], L, 1 if N is None else N, xw.stream())
+        return out.arr if x is None else x
     if not isdyadic(m):
         raise ArgumentError("Number of columns of xw is not dyadic.")             # ACWT.jl:586
     L = ndyadicscales(m)
@@ -154,7 +167,7 @@ def _iacwpd(xw, L_or_tree, batched, x=None):
     xw, sig, m, N = _inv_common(_f64(xw).arr, batched)
     L, tree = _split_Ltree(L_or_tree, maxtransformlevels(int(sig[0])))
     if tree is None:
-        if not L <= maxtransformlevels(int(sig[0])):
+        if not L <= maxtransformlevels(int(min(sig))):
             raise ArgumentError("Too many transform levels (length(x) < 2^L)")     # ACWT.jl:853-855
         if not L >= 1:
             raise ArgumentError("L must be >= 1")
@@ -163,7 +176,10 @@ def _iacwpd(xw, L_or_tree, batched, x=None):
         assert tuple(x.shape) == sig + ((N,) if batched else ())
     out = xw.new(sig + ((N,) if batched else ())) if x is None else out_arg(x, xw)
     tk, tp, nt = tree_arg(tree)
-    _call("wx_iacwpd1d", "_f64", xw.ptr, out.ptr, sig[0], m, L, tp, nt, 1 if N is None else N, xw.stream())
+    if len(sig) == 1:
+        _call("wx_iacwpd1d", "_f64", xw.ptr, out.ptr, sig[0], m, L, tp, nt, 1 if N is None else N, xw.stream())
+    else:
+        _call("wx_iacwpd2d", "_f64", xw.ptr, out.ptr, sig[0], sig[1], m, L, tp, nt, 1 if N is None else N, xw.stream())
     return out.arr if x is None else x
 
 

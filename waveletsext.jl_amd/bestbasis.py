@@ -42,25 +42,32 @@ def _cost_kind(cost):
 
 
 def jbb_moments(X, accumulate_into=None):
-    """(sum, sumsq) over the signal (last) axis of a decomposition X (n, k, N)."""
+    """(sum, sumsq) over the signal (last) axis of a decomposition X (n, k, N) or (n, m, k, N)."""
     X = Arg(X)
-    assert X.arr.ndim == 3
-    n, k, N = X.shape
+    assert 3 <= X.arr.ndim <= 4
+    shp, N = X.shape[:-1], X.shape[-1]
     if accumulate_into is None:
-        s, q = X.new((n, k)), X.new((n, k))
+        s, q = X.new(shp), X.new(shp)
         acc = 0
     else:
         s, q = Arg(accumulate_into[0]), Arg(accumulate_into[1])
         acc = 1
-    _call("wx_jbb_moments", X.suffix, X.ptr, s.ptr, q.ptr, n * k, N, acc, X.stream())
+    _call("wx_jbb_moments", X.suffix, X.ptr, s.ptr, q.ptr, int(np.prod(shp, dtype=np.int64)), N, acc, X.stream())
     return s.arr, q.arr
 
 
 def costs_from_moments(s, q, Ntot, method=None):
     method = JBB() if method is None else method
     s, q = Arg(s), Arg(q)
-    n, k = s.shape
     kind, p = _cost_kind(method.cost)
+    if s.arr.ndim == 3:                                               # 2-D signals: (n, m, k)
+        n, m, k = s.shape
+        ncost = k if method.redundant else gettreelength(1 << k, 1 << k)
+        costs = s.new((ncost,))
+        _call("wx_jbb_costs2d", s.suffix, s.ptr, q.ptr, int(Ntot), n, m, k, int(method.redundant), kind, p, costs.ptr,
+              s.stream())
+        return costs.arr
+    n, k = s.shape
     ncost = k if method.redundant else gettreelength(1 << k)
     costs = s.new((ncost,))
     _call("wx_jbb_costs", s.suffix, s.ptr, q.ptr, int(Ntot), n, k, int(method.redundant), kind, p, costs.ptr,
@@ -74,23 +81,33 @@ def tree_costs(X, method=None):
     if not isinstance(method, JBB):
         raise _lib.WxError(_lib.WX_EUNSUPPORTED, "only the JBB best-basis type is on the device path")
     Xa = Arg(X)
-    if Xa.arr.ndim != 3:
-        raise _lib.WxError(_lib.WX_EUNSUPPORTED, "JBB tree costs of 2-D signals are not implemented yet")
+    assert 3 <= Xa.arr.ndim <= 4
     s, q = jbb_moments(Xa.arr)
-    costs = costs_from_moments(s, q, Xa.shape[2], method)
+    costs = costs_from_moments(s, q, Xa.shape[-1], method)
     c = to_numpy(costs)
     assert not np.isnan(c).any()                                      # @assert all(sigma .>= 0) (:158)
     return costs
 
 
-def bestbasis_treeselection(costs, n, kind="min"):
-    """BestBasis.jl:59-83; `costs` (host copy) is mutated like the reference, returns the BitVector."""
+def bestbasis_treeselection(costs, n, *args):
+    """bestbasis_treeselection(costs, n[, type]) BestBasis.jl:59-83 and (costs, n, m[, type]) :85-110; `costs`
+    (host copy) is mutated like the reference, returns the BitVector."""
+    args = list(args)
+    kind = args.pop() if args and isinstance(args[-1], str) else "min"
     if kind not in ("min", "max"):
         raise ArgumentError("Unsupported type %s." % kind)
     c = np.array(to_numpy(costs), copy=True)
     if c.dtype not in (np.float32, np.float64):
         c = c.astype(np.float64)
     k = c.size
+    if args:                                                          # quad tree
+        m = int(args[0])
+        assert k <= gettreelength(2 * n, 2 * m)                       # BestBasis.jl:90
+        tree = np.zeros(gettreelength(n, m), dtype=np.uint8)
+        fn = getattr(_lib.lib(), "wx_treeselect2d_f64" if c.dtype == np.float64 else "wx_treeselect2d_f32")
+        _lib.check(fn(ctypes.c_void_p(c.ctypes.data), k, n, m, 0 if kind == "min" else 1,
+                      ctypes.c_void_p(tree.ctypes.data)))
+        return tree.astype(bool)
     assert k <= gettreelength(2 * n)                                  # BestBasis.jl:63
     tree = np.zeros(max(n - 1, 0), dtype=np.uint8)
     fn = getattr(_lib.lib(), "wx_treeselect_f64" if c.dtype == np.float64 else "wx_treeselect_f32")
@@ -104,7 +121,7 @@ def bestbasistree(X, method=None):
     Xa = Arg(X)
     assert 3 <= Xa.arr.ndim <= 4
     costs = tree_costs(Xa.arr, method)
-    return bestbasis_treeselection(costs, Xa.shape[0])
+    return bestbasis_treeselection(costs, *Xa.shape[:-2])
 
 
 def acwpd_jbb_moments(x, wt, L=None, accumulate_into=None):

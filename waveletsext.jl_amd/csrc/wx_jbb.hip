@@ -88,6 +88,64 @@ __global__ __launch_bounds__(256) void k_jbb_costs(const T *__restrict__ sum, co
     }
 }
 
+// tree_costs(X::Array{T,4}, ::JBB) bestbasis/bestbasis_tree.jl:182-207: one block per quad node.
+// redundant: cost[i] = coefcost(sigma[:,:,i]) / 4^depth(i); otherwise the node's (rows, cols) block of
+// slice depth+1 (Utils.jl:465-542 geometry through the morton code of the heap index)
+template <typename T>
+__global__ __launch_bounds__(256) void k_jbb_costs2d(const T *__restrict__ sum, const T *__restrict__ sumsq,
+                                                     int64_t Ntot, int m, int n, int k, int redundant, int cost_kind,
+                                                     double p, T *__restrict__ costs)
+{
+    __shared__ double red[256];
+    const int64_t idx = blockIdx.x;               // 0-based heap index
+    int depth = 0;
+    { int64_t t = 3 * (idx + 1) - 2; while (t >= 4) { t >>= 2; ++depth; } }
+    int64_t start = 1;
+    for (int t = 0; t < depth; ++t) start = 4 * start - 2;
+    const int64_t mort = idx + 1 - start;
+    int jr = 0, jc = 0;
+    for (int t = 0; t < depth; ++t) { jr |= (int)((mort >> (2 * t + 1)) & 1) << t; jc |= (int)((mort >> (2 * t)) & 1) << t; }
+    int r0, c0, nr, ncl;
+    int64_t slice;
+    if (redundant) { slice = idx; r0 = 0; c0 = 0; nr = m; ncl = n; }
+    else { slice = depth; nr = m >> depth; ncl = n >> depth; r0 = jr * nr; c0 = jc * ncl; }
+    double acc = 0.0;
+    const int cnt = nr * ncl;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const int r = r0 + i % nr, c = c0 + i / nr;
+        const int64_t e = slice * (int64_t)m * n + (int64_t)c * m + r;
+        const T ex = (T)(sum[e] / (T)Ntot), ex2 = (T)(sumsq[e] / (T)Ntot);
+        const T sg = (T)sqrt((double)(T)(ex2 - (T)(ex * ex)));
+        if (cost_kind == 0) acc += (double)(T)log((double)(T)fabs((double)sg));
+        else acc += pow(fabs((double)sg), p);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double c = cost_kind == 0 ? p * red[0] : red[0];
+        if (redundant) c /= (double)((int64_t)1 << (2 * depth));
+        costs[idx] = (T)c;
+    }
+}
+
+template <typename T>
+int wx_dev_jbb_costs2d(const T *sum, const T *sumsq, int64_t Ntot, int64_t m, int64_t n, int64_t k, int redundant,
+                       int cost_kind, double p, T *costs, hipStream_t st)
+{
+    const int64_t ncost = redundant ? k : ((((int64_t)1 << (2 * k)) - 1) / 3);
+    if (ncost == 0) return WX_OK;
+    hipLaunchKernelGGL(k_jbb_costs2d<T>, dim3((unsigned)ncost), dim3(256), 0, st, sum, sumsq, Ntot, (int)m, (int)n, (int)k,
+                       redundant, cost_kind, p, costs);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+template int wx_dev_jbb_costs2d<double>(const double *, const double *, int64_t, int64_t, int64_t, int64_t, int, int, double, double *, hipStream_t);
+template int wx_dev_jbb_costs2d<float>(const float *, const float *, int64_t, int64_t, int64_t, int64_t, int, int, double, float *, hipStream_t);
+
 // ------------------------------------------------------------------------------------------
 // acwpd + JBB moments without the packet table (BASELINE config 5).
 // Below depth D0 the dilated autocorrelation steps (stride 2^d >= 2^D0) never mix samples of

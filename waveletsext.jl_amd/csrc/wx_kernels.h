@@ -62,3 +62,15 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
 int wx_acwpd_fused_depth(int64_t n, int L, int F);
 int wx_dev_acwpd_subtree_moments(const double *top, double *sum, double *sumsq, int64_t n, int L, int D0,
                                  int64_t batch, const WxAcFilt &ac, int accumulate, hipStream_t st);
+
+// ---- 2-D redundant: SWT / ACWT (wx_swt2d.hip); layout 0 = dwt (m,n,3L+1), 1 = wpt (m,n,4^L), 2 = wpd quad heap ----
+template <typename T>
+int wx_dev_red2d_fwd(const T *x, T *xw, int64_t m, int64_t n, int L, int layout, int64_t batch, const WxFilt &filt,
+                     const WxAcFilt *ac, T *tmp, hipStream_t st);
+template <typename T>
+int wx_dev_red2d_inv(const T *xw, T *x, int64_t m, int64_t n, int L, int layout, int64_t ncols, int64_t batch, int64_t sm,
+                     bool ac, const uint8_t *dtree, int64_t ntree, const WxFilt &filt, T *s0, T *s1, T *tmp,
+                     hipStream_t st);
+template <typename T>
+int wx_dev_jbb_costs2d(const T *sum, const T *sumsq, int64_t Ntot, int64_t m, int64_t n, int64_t k, int redundant,
+                       int cost_kind, double p, T *costs, hipStream_t st);

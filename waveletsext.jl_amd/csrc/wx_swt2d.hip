@@ -1,0 +1,378 @@
+// wx_swt2d.hip -- batched 2-D redundant (undecimated) transforms for gfx950: stationary family
+// (sdwt / swpt / swpd 2-D and inverses) and autocorrelation family (acdwt / acwpt / acwpd 2-D).
+//
+// Reference semantics (paths relative to /root/reference/src/mod):
+//   sdwt_step! 2-D   swt/swt_one_level.jl:334-370   1-D step down every column into temp[:,:,1|2], then
+//                    along every row: w1,w2 <- temp1 (low,high along dim 2), w3,w4 <- temp2
+//   isdwt_step! 2-D  swt/swt_one_level.jl:395-431 (average), :433-469 (shift): rows first, then columns
+//   acdwt_step! 2-D  acwt/acwt_one_level.jl:240-276;  iacdwt_step! 2-D :288-322
+//   containers       SWT.jl:132-158 (sdwt (n,m,3L+1)), :474-513 (swpt (n,m,4^L)), :870-902 (swpd, quad heap),
+//                    inverses :286-358, :648-758, :1095-1199; ACWT.jl:131-157, 306-329, 462-501, 612-648,
+//                    761-793, 970-1000
+// Images are (m rows, n cols) column-major; every pass has consecutive lanes on consecutive rows
+// (coalesced).  A forward level is one pass along dim 1 into scratch and one along dim 2; the
+// parent slice is fully consumed by the first pass, which resolves the reference's aliasing of
+// the parent with child 1.
+#include "wx_common.h"
+#include "wx_kernels.h"
+
+enum { WX2_DWT = 0, WX2_WPT = 1, WX2_WPD = 2 };
+
+struct WxRed2d {
+    int layout, L, d;
+    int m, n;               // rows, columns
+    int64_t ncols;          // slices per image in the coefficient array
+    int64_t batch;
+};
+
+static __device__ __forceinline__ int64_t wx_quad_start(int d)   // 1-based heap index of the first node of depth d
+{
+    int64_t s = 1;
+    for (int t = 0; t < d; ++t) s = 4 * s - 2;
+    return s;
+}
+
+// 0-based slice indices of the parent (pv) and of the four children of node b at depth d
+static __device__ __forceinline__ void wx_red2d_slices(const WxRed2d &D, int b, int64_t &pv, int64_t (&pc)[4])
+{
+    if (D.layout == WX2_DWT) {
+        pv = 3 * (D.L - D.d);
+        pc[0] = pv - 3; pc[1] = pv - 2; pc[2] = pv - 1; pc[3] = pv;
+    } else if (D.layout == WX2_WPT) {
+        const int64_t nc = (int64_t)1 << (2 * (D.L - D.d - 1));
+        pv = 4 * (int64_t)b * nc;
+        for (int c = 0; c < 4; ++c) pc[c] = (4 * (int64_t)b + c) * nc;
+    } else {
+        const int64_t i = wx_quad_start(D.d) + b;
+        pv = i - 1;
+        for (int c = 0; c < 4; ++c) pc[c] = 4 * i - 2 + c - 1;
+    }
+}
+
+// undecimated analysis pair at index i along a line of `len` samples with element stride `es`
+template <typename T, bool AC>
+static __device__ __forceinline__ void wx_red_point(const T *line, int64_t es, int len, int i, int s,
+                                                    const WxFilt &filt, const WxAcFilt &ac, T &lo, T &hi)
+{
+    if (!AC) {
+        double a = 0.0, dd = 0.0;
+        int k1 = i - s; if (k1 < 0) k1 += len;
+        int k2 = i;
+        for (int j = 0; j < filt.F; ++j) {
+            a = fma(filt.q[j], (double)line[k1 * es], a);
+            dd = fma((j & 1) ? -filt.q[j] : filt.q[j], (double)line[k2 * es], dd);
+            k1 += s; if (k1 >= len) k1 -= len;
+            k2 -= s; if (k2 < 0) k2 += len;
+        }
+        lo = (T)a; hi = (T)dd;
+    } else {
+        double S = 0.0;
+        const int s2 = (2 * s) % len;
+        int km = i - s; if (km < 0) km += len;
+        int kp = i + s; if (kp >= len) kp -= len;
+        for (int l = 1; l < ac.F; l += 2) {
+            S = fma(ac.b[l - 1], (double)line[km * es] + (double)line[kp * es], S);
+            km -= s2; if (km < 0) km += len;
+            kp += s2; if (kp >= len) kp -= len;
+        }
+        const double c = ac.c1 * (double)line[i * es];
+        lo = (T)(c + S); hi = (T)(c - S);
+    }
+}
+
+// pass 1 (dim 1): parent slice -> scratch t[job][0|1]
+template <typename T, bool AC>
+__global__ __launch_bounds__(256) void k_red2d_fwd_dim1(const T *__restrict__ x, T *__restrict__ xw, T *__restrict__ tmp,
+                                                        WxRed2d D, int nodes, WxFilt filt, WxAcFilt ac)
+{
+    const int64_t mn = (int64_t)D.m * D.n;
+    const int64_t total = D.batch * nodes * mn;
+    const int s = (1 << D.d) % D.m;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t job = g / mn;
+        const int64_t e = g - job * mn;
+        const int r = (int)(e % D.m);
+        const int64_t c = e / D.m;
+        const int b = (int)(job % nodes);
+        const int64_t sig = job / nodes;
+        int64_t pv, pc[4];
+        wx_red2d_slices(D, b, pv, pc);
+        const T *src = (D.d == 0) ? x + sig * mn : xw + (sig * D.ncols + pv) * mn;
+        if (D.d == 0 && D.layout == WX2_WPD) xw[(sig * D.ncols) * mn + e] = src[e];
+        T lo, hi;
+        wx_red_point<T, AC>(src + c * D.m, 1, D.m, r, s, filt, ac, lo, hi);
+        tmp[(job * 2) * mn + e] = lo;
+        tmp[(job * 2 + 1) * mn + e] = hi;
+    }
+}
+
+// pass 2 (dim 2): t[job][which] -> children (2*which, 2*which+1)
+template <typename T, bool AC>
+__global__ __launch_bounds__(256) void k_red2d_fwd_dim2(T *__restrict__ xw, const T *__restrict__ tmp, WxRed2d D,
+                                                        int nodes, WxFilt filt, WxAcFilt ac)
+{
+    const int64_t mn = (int64_t)D.m * D.n;
+    const int64_t total = D.batch * nodes * 2 * mn;
+    const int s = (1 << D.d) % D.n;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t jw = g / mn;                         // job*2 + which
+        const int64_t e = g - jw * mn;
+        const int r = (int)(e % D.m);
+        const int c = (int)(e / D.m);
+        const int which = (int)(jw & 1);
+        const int64_t job = jw >> 1;
+        const int b = (int)(job % nodes);
+        const int64_t sig = job / nodes;
+        int64_t pv, pc[4];
+        wx_red2d_slices(D, b, pv, pc);
+        T lo, hi;
+        wx_red_point<T, AC>(tmp + jw * mn + r, D.m, D.n, c, s, filt, ac, lo, hi);
+        xw[(sig * D.ncols + pc[2 * which]) * mn + e] = lo;
+        xw[(sig * D.ncols + pc[2 * which + 1]) * mn + e] = hi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// inverse
+// ------------------------------------------------------------------------------------------
+struct WxInv2d {
+    WxRed2d R;
+    const void *in;          // caller's coefficients (read only)
+    void *cur;               // computed nodes of depth d+1 (slice = node index in level)
+    void *out;               // destination for depth d (or final x)
+    int64_t cur_cols, out_cols;
+    const uint8_t *tree;     // WPD only
+    int64_t ntree;
+};
+
+// base pointer of child c (0..3) of node b; DWT: child 0 is the running reconstruction
+template <typename T>
+static __device__ __forceinline__ const T *wx_inv2d_child(const WxInv2d &D, int64_t sig, int b, int c)
+{
+    const int64_t mn = (int64_t)D.R.m * D.R.n;
+    const T *in = reinterpret_cast<const T *>(D.in) + sig * D.R.ncols * mn;
+    const T *cur = reinterpret_cast<const T *>(D.cur) + sig * D.cur_cols * mn;
+    if (D.R.layout == WX2_DWT) {
+        if (c == 0) return (D.R.d == D.R.L - 1) ? in : cur;
+        return in + (int64_t)(3 * (D.R.L - D.R.d) - 3 + c) * mn;
+    }
+    const int64_t cb = 4 * (int64_t)b + c;
+    if (D.R.layout == WX2_WPT) return (D.R.d == D.R.L - 1) ? in + cb * mn : cur + cb * mn;
+    const int64_t heap = wx_quad_start(D.R.d + 1) + cb;
+    const bool computed = D.tree ? (heap <= D.ntree && D.tree[heap - 1]) : (D.R.d + 1 < D.R.L);
+    return computed ? cur + cb * mn : in + (heap - 1) * mn;
+}
+
+// one parent sample of isdwt_step! along a line: slot u of residue class cls (position cls + u*s)
+template <typename T>
+static __device__ __forceinline__ double wx_isdwt_point(const T *w1, const T *w2, int64_t es, int len, int d, int cls,
+                                                        int u, bool shifted, const WxFilt &filt)
+{
+    const int s = 1 << d;
+    const int np = len >> d, nc = np >> 1;
+    const int t0 = shifted ? u : (u + 1 == np ? 0 : u + 1);
+    const int swc = shifted ? cls + s : cls;
+    const int tau = t0 >> 1;
+    const bool odd = t0 & 1;
+    int k1 = tau, k2 = tau;
+    double v = 0.0;
+    for (int m = 0; m < filt.F / 2; ++m) {
+        const double a = (double)w1[(swc + (int64_t)k1 * 2 * s) * es];
+        const double c = (double)w2[(swc + (int64_t)k2 * 2 * s) * es];
+        if (!odd) { v = fma(filt.q[2 * m], a, v); v = fma(-filt.q[2 * m + 1], c, v); }
+        else { v = fma(filt.q[2 * m + 1], a, v); v = fma(filt.q[2 * m], c, v); }
+        k1 = k1 == 0 ? nc - 1 : k1 - 1;
+        k2 = k2 + 1 == nc ? 0 : k2 + 1;
+    }
+    return v;
+}
+
+// rows pass (dim 2): children (2*which, 2*which+1) -> tmp[job][which]
+//   shift mode: only rows of class sw (mod 2s) and columns of class sv (mod s) are produced
+template <typename T>
+__global__ __launch_bounds__(256) void k_red2d_inv_dim2(WxInv2d D, T *__restrict__ tmp, int nodes, int sm_mode,
+                                                        int sv, int sw, WxFilt filt)
+{
+    const int m = D.R.m, n = D.R.n, d = D.R.d, s = 1 << d;
+    const int64_t mn = (int64_t)m * n;
+    const int nr = sm_mode ? (m >> (d + 1)) : m;          // rows handled per job
+    const int ncl = sm_mode ? (n >> d) : n;               // columns handled per job
+    const int64_t per = (int64_t)nr * ncl;
+    const int64_t total = D.R.batch * nodes * 2 * per;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t jw = g / per;
+        const int64_t e = g - jw * per;
+        const int ri = (int)(e % nr), ci = (int)(e / nr);
+        const int which = (int)(jw & 1);
+        const int64_t job = jw >> 1;
+        const int b = (int)(job % nodes);
+        const int64_t sig = job / nodes;
+        if (D.R.layout == WX2_WPD && D.tree) {
+            const int64_t heap = wx_quad_start(d) + b;
+            if (!(heap <= D.ntree && D.tree[heap - 1])) continue;
+        }
+        const T *w1 = wx_inv2d_child<T>(D, sig, b, 2 * which);
+        const T *w2 = wx_inv2d_child<T>(D, sig, b, 2 * which + 1);
+        int r, c, cls, u;
+        bool single, shifted = false;
+        if (sm_mode) { r = sw + ri * 2 * s; cls = sv; u = ci; c = cls + u * s; single = true; shifted = (sw != sv); }
+        else { r = ri; c = ci; cls = c & (s - 1); u = c >> d; single = false; }
+        double v;
+        if (single) v = wx_isdwt_point<T>(w1 + r, w2 + r, m, n, d, cls, u, shifted, filt);
+        else v = 0.5 * (wx_isdwt_point<T>(w1 + r, w2 + r, m, n, d, cls, u, false, filt) +
+                        wx_isdwt_point<T>(w1 + r, w2 + r, m, n, d, cls, u, true, filt));
+        tmp[jw * mn + r + (int64_t)c * m] = (T)v;
+    }
+}
+
+// columns pass (dim 1): tmp[job][0], tmp[job][1] -> parent
+template <typename T>
+__global__ __launch_bounds__(256) void k_red2d_inv_dim1(WxInv2d D, const T *__restrict__ tmp, int nodes, int sm_mode,
+                                                        int sv, int sw, WxFilt filt)
+{
+    const int m = D.R.m, n = D.R.n, d = D.R.d, s = 1 << d;
+    const int64_t mn = (int64_t)m * n;
+    const int nr = sm_mode ? (m >> d) : m;
+    const int ncl = sm_mode ? (n >> d) : n;
+    const int64_t per = (int64_t)nr * ncl;
+    const int64_t total = D.R.batch * nodes * per;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t job = g / per;
+        const int64_t e = g - job * per;
+        const int ri = (int)(e % nr), ci = (int)(e / nr);
+        const int b = (int)(job % nodes);
+        const int64_t sig = job / nodes;
+        if (D.R.layout == WX2_WPD && D.tree) {
+            const int64_t heap = wx_quad_start(d) + b;
+            if (!(heap <= D.ntree && D.tree[heap - 1])) continue;
+        }
+        const T *t1 = tmp + (job * 2) * mn, *t2 = tmp + (job * 2 + 1) * mn;
+        int r, c, cls, u;
+        double v;
+        if (sm_mode) {
+            cls = sv; u = ri; r = cls + u * s; c = sv + ci * s;
+            v = wx_isdwt_point<T>(t1 + (int64_t)c * m, t2 + (int64_t)c * m, 1, m, d, cls, u, sw != sv, filt);
+        } else {
+            r = ri; c = ci; cls = r & (s - 1); u = r >> d;
+            v = 0.5 * (wx_isdwt_point<T>(t1 + (int64_t)c * m, t2 + (int64_t)c * m, 1, m, d, cls, u, false, filt) +
+                       wx_isdwt_point<T>(t1 + (int64_t)c * m, t2 + (int64_t)c * m, 1, m, d, cls, u, true, filt));
+        }
+        T *out = reinterpret_cast<T *>(D.out) + (sig * D.out_cols + ((D.R.layout == WX2_DWT || d == 0) ? 0 : b)) * mn;
+        out[r + (int64_t)c * m] = (T)v;
+    }
+}
+
+// iacdwt_step! 2-D: v = ((w1+w2)/sqrt2 + (w3+w4)/sqrt2)/sqrt2, same operation order as the reference
+template <typename T>
+__global__ __launch_bounds__(256) void k_red2d_iac(WxInv2d D, int nodes)
+{
+    const double sqrt2 = 1.4142135623730951;
+    const int64_t mn = (int64_t)D.R.m * D.R.n;
+    const int64_t total = D.R.batch * nodes * mn;
+    const int d = D.R.d;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t job = g / mn;
+        const int64_t e = g - job * mn;
+        const int b = (int)(job % nodes);
+        const int64_t sig = job / nodes;
+        if (D.R.layout == WX2_WPD && D.tree) {
+            const int64_t heap = wx_quad_start(d) + b;
+            if (!(heap <= D.ntree && D.tree[heap - 1])) continue;
+        }
+        const T *w1 = wx_inv2d_child<T>(D, sig, b, 0), *w2 = wx_inv2d_child<T>(D, sig, b, 1);
+        const T *w3 = wx_inv2d_child<T>(D, sig, b, 2), *w4 = wx_inv2d_child<T>(D, sig, b, 3);
+        const T t1 = (T)(((double)w1[e] + (double)w2[e]) / sqrt2);
+        const T t2 = (T)(((double)w3[e] + (double)w4[e]) / sqrt2);
+        T *out = reinterpret_cast<T *>(D.out) + (sig * D.out_cols + ((D.R.layout == WX2_DWT || d == 0) ? 0 : b)) * mn;
+        out[e] = (T)(((double)t1 + (double)t2) / sqrt2);
+    }
+}
+
+static int wx_grid2r(int64_t total)
+{
+    int64_t g = (total + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static int64_t wx_red2d_ncols(int layout, int L)
+{
+    if (layout == WX2_DWT) return 3 * L + 1;
+    if (layout == WX2_WPT) return (int64_t)1 << (2 * L);
+    return ((((int64_t)1 << (2 * (L + 1))) - 1) / 3);
+}
+
+// tmp: 2 * 4^(L-1) * batch * m*n elements (1 node per level for the dwt layout)
+template <typename T>
+int wx_dev_red2d_fwd(const T *x, T *xw, int64_t m, int64_t n, int L, int layout, int64_t batch, const WxFilt &filt,
+                     const WxAcFilt *ac, T *tmp, hipStream_t st)
+{
+    if (batch == 0 || m * n == 0) return WX_OK;
+    WxAcFilt acz;
+    if (ac) acz = *ac; else { acz.F = 0; acz.c1 = 0; }
+    for (int d = 0; d < L; ++d) {
+        WxRed2d D;
+        D.layout = layout; D.L = L; D.d = d; D.m = (int)m; D.n = (int)n; D.ncols = wx_red2d_ncols(layout, L); D.batch = batch;
+        const int nodes = layout == WX2_DWT ? 1 : (1 << (2 * d));
+        const int64_t tot = batch * nodes * m * n;
+        if (ac) {
+            hipLaunchKernelGGL((k_red2d_fwd_dim1<T, true>), dim3(wx_grid2r(tot)), dim3(256), 0, st, x, xw, tmp, D, nodes, filt, acz);
+            hipLaunchKernelGGL((k_red2d_fwd_dim2<T, true>), dim3(wx_grid2r(2 * tot)), dim3(256), 0, st, xw, (const T *)tmp, D, nodes, filt, acz);
+        } else {
+            hipLaunchKernelGGL((k_red2d_fwd_dim1<T, false>), dim3(wx_grid2r(tot)), dim3(256), 0, st, x, xw, tmp, D, nodes, filt, acz);
+            hipLaunchKernelGGL((k_red2d_fwd_dim2<T, false>), dim3(wx_grid2r(2 * tot)), dim3(256), 0, st, xw, (const T *)tmp, D, nodes, filt, acz);
+        }
+    }
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
+// sm < 0: average based.  ac: autocorrelation inverse (no filter).  s0/s1: level buffers, tmp: 2 slices per job
+template <typename T>
+int wx_dev_red2d_inv(const T *xw, T *x, int64_t m, int64_t n, int L, int layout, int64_t ncols, int64_t batch, int64_t sm,
+                     bool ac, const uint8_t *dtree, int64_t ntree, const WxFilt &filt, T *s0, T *s1, T *tmp,
+                     hipStream_t st)
+{
+    if (batch == 0 || m * n == 0) return WX_OK;
+    const int64_t mn = m * n;
+    if (L == 0) {
+        WX_HIP_CHECK(hipMemcpy2DAsync(x, mn * sizeof(T), xw, (size_t)mn * ncols * sizeof(T), mn * sizeof(T), batch,
+                                      hipMemcpyDeviceToDevice, st));
+        return WX_OK;
+    }
+    int64_t sd[40];
+    sd[0] = 0;
+    if (sm >= 0) { int64_t acc = 0; for (int d = 0; d < L; ++d) { acc += ((sm >> d) & 1) << d; sd[d + 1] = acc; } }
+    T *bufs[2] = {s0, s1};
+    for (int d = L - 1; d >= 0; --d) {
+        WxInv2d D;
+        D.R.layout = layout; D.R.L = L; D.R.d = d; D.R.m = (int)m; D.R.n = (int)n; D.R.ncols = ncols; D.R.batch = batch;
+        D.in = xw; D.tree = dtree; D.ntree = ntree;
+        const int nodes_d = layout == WX2_DWT ? 1 : (1 << (2 * d));
+        const int64_t nodes_c = layout == WX2_DWT ? 1 : ((int64_t)1 << (2 * (d + 1)));
+        D.cur = bufs[(d + 1) & 1]; D.cur_cols = nodes_c;
+        if (d == 0) { D.out = x; D.out_cols = 1; } else { D.out = bufs[d & 1]; D.out_cols = nodes_d; }
+        const int64_t jobs = batch * nodes_d;
+        if (ac) {
+            hipLaunchKernelGGL(k_red2d_iac<T>, dim3(wx_grid2r(jobs * mn)), dim3(256), 0, st, D, nodes_d);
+        } else {
+            const int sm_mode = sm >= 0 ? 1 : 0;
+            const int sv = sm >= 0 ? (int)sd[d] : 0, sw = sm >= 0 ? (int)sd[d + 1] : 0;
+            const int64_t per2 = sm_mode ? (m >> (d + 1)) * (n >> d) : mn;
+            const int64_t per1 = sm_mode ? (m >> d) * (n >> d) : mn;
+            hipLaunchKernelGGL(k_red2d_inv_dim2<T>, dim3(wx_grid2r(jobs * 2 * per2)), dim3(256), 0, st, D, tmp, nodes_d, sm_mode, sv, sw, filt);
+            hipLaunchKernelGGL(k_red2d_inv_dim1<T>, dim3(wx_grid2r(jobs * per1)), dim3(256), 0, st, D, (const T *)tmp, nodes_d, sm_mode, sv, sw, filt);
+        }
+    }
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
+#define WX_INST(T)                                                                                                    \
+    template int wx_dev_red2d_fwd<T>(const T *, T *, int64_t, int64_t, int, int, int64_t, const WxFilt &, const WxAcFilt *, \
+                                     T *, hipStream_t);                                                               \
+    template int wx_dev_red2d_inv<T>(const T *, T *, int64_t, int64_t, int, int, int64_t, int64_t, int64_t, bool,      \
+                                     const uint8_t *, int64_t, const WxFilt &, T *, T *, T *, hipStream_t);
+WX_INST(double)
+WX_INST(float)

@@ -198,9 +198,12 @@ def iwptall(xw, wt, L_or_tree=None):
 def getbasiscoef(Xw, tree):
     Xw = Arg(Xw)
     assert 2 <= Xw.arr.ndim <= 3                                      # Utils.jl:103
-    if Xw.arr.ndim == 3:
-        raise _lib.WxError(_lib.WX_EUNSUPPORTED, "getbasiscoef for 2-D signals is not implemented yet")
     tk, tp, nt = tree_arg(np.asarray(tree, dtype=bool))
+    if Xw.arr.ndim == 3:
+        m, n, k = Xw.shape
+        out = Xw.new((m, n))
+        _call("wx_getbasiscoef2d", Xw.suffix, Xw.ptr, out.ptr, m, n, k, tp, nt, 1, Xw.stream())
+        return out.arr
     n, k = Xw.shape
     out = Xw.new((n,))
     _call("wx_getbasiscoef1d", Xw.suffix, Xw.ptr, out.ptr, n, k, tp, nt, 1, Xw.stream())
@@ -210,9 +213,23 @@ def getbasiscoef(Xw, tree):
 def getbasiscoefall(Xw, tree):
     Xw = Arg(Xw)
     assert 3 <= Xw.arr.ndim <= 4                                      # Utils.jl:175
-    if Xw.arr.ndim == 4:
-        raise _lib.WxError(_lib.WX_EUNSUPPORTED, "getbasiscoefall for 2-D signals is not implemented yet")
     tree = np.asarray(tree, dtype=bool)
+    if Xw.arr.ndim == 4:
+        mm, nn, k, N = Xw.shape
+        import ctypes
+        out = Xw.new((mm, nn, N))
+        if tree.ndim == 2:
+            assert N == tree.shape[1]
+            esz = Xw.dtype.itemsize
+            for i in range(N):
+                tk, tp, ntl = tree_arg(tree[:, i])
+                src = ctypes.c_void_p(Xw.ptr.value + i * mm * nn * k * esz)
+                dst = ctypes.c_void_p(out.ptr.value + i * mm * nn * esz)
+                _call("wx_getbasiscoef2d", Xw.suffix, src, dst, mm, nn, k, tp, ntl, 1, Xw.stream())
+        else:
+            tk, tp, nt = tree_arg(tree)
+            _call("wx_getbasiscoef2d", Xw.suffix, Xw.ptr, out.ptr, mm, nn, k, tp, nt, N, Xw.stream())
+        return out.arr
     n, k, m = Xw.shape
     if tree.ndim == 2:                                                # Utils.jl:199-225: one tree per signal
         nt, mt = tree.shape
