@@ -159,3 +159,24 @@ def test_full_size_config2_properties(wx, torch_mod):
     assert float((back - x).abs().max() / x.abs().max()) < 1e-10
     back2 = wx.iwptall(leaves, wt, L)
     assert float((back2 - x).abs().max() / x.abs().max()) < 1e-10
+
+
+def test_dwtall_is_the_dwt_tree_packet_transform(wx, oracle):
+    """dwt/dwt_all.jl:39-110 through the packet kernels"""
+    rng = np.random.default_rng(55)
+    wt = _wt(wx, "db4")
+    x = np.asfortranarray(rng.standard_normal((64, 5)))
+    for L in (None, 0, 1, 3):
+        Lv = 6 if L is None else L
+        tree = wx.maketree(64, Lv, "dwt")
+        y = wx.dwtall(x, wt, L)
+        assert relerr(y, oracle.wptall(x, wt.qmf, tree)) <= 1e-10
+        assert relerr(wx.idwtall(y, wt, L), x) <= 1e-10
+    # pyramid layout: [s_L | d_L | ... | d_1]; one level == one dwt_step
+    g, h = oracle.makereverseqmfpair(wt.qmf)
+    w1, w2 = oracle.dwt_step(x[:, 0], h, g)
+    assert relerr(wx.dwt(x[:, 0], wt, 1), np.concatenate([w1, w2])) <= 1e-12
+    img = np.asfortranarray(rng.standard_normal((16, 16, 3)))
+    yi = wx.dwtall(img, wt)
+    assert relerr(yi[..., 1], oracle.wpt(img[..., 1], wt.qmf, oracle.maketree2d(16, 16, 4, "dwt"))) <= 1e-10
+    assert relerr(wx.idwtall(yi, wt), img) <= 1e-10

@@ -193,7 +193,47 @@ def iwptall(xw, wt, L_or_tree=None):
 
 
 # ---------------------------------------------------------------------------------------------
-# getbasiscoef / getbasiscoefall (Utils.jl:101-225), 1-D signals on device
+# dwt / idwt / dwtall / idwtall: the non-packet pyramid transform is the packet
+# transform along the :dwt tree (test/transforms.jl:42: `dwt(x, wt) ≈ wpt(x, wt, maketree(x,:dwt))`;
+# 1-D Wavelets.jl pyramid order [s_L d_L .. d_1] == the leaves of that tree in natural order).
+# Batch drivers: dwt/dwt_all.jl:39-54, 95-110.  1-D and 2-D (the reference also admits 3-D).
+# ---------------------------------------------------------------------------------------------
+def _dwt_like(name, x, wt, L, batched):
+    xa = Arg(x)
+    sig = xa.shape[:-1] if batched else xa.shape
+    assert len(sig) in (1, 2)
+    if batched:
+        assert xa.arr.ndim > 1                                        # dwt_all.jl:40,96
+    Lmax = maxtransformlevels(int(min(sig)))
+    Lv = Lmax if L is None else int(L)
+    assert 0 <= Lv <= Lmax
+    if Lv == 0:
+        return (_wptall_like if batched else _wpt_like)(name, x, wt, 0)
+    from .util import maketree
+    tree = maketree(*sig, Lv, "dwt")
+    return (_wptall_like if batched else _wpt_like)(name, x, wt, tree)
+
+
+def dwt(x, wt, L=None):
+    return _dwt_like("wx_wpt", x, wt, L, False)
+
+
+def idwt(xw, wt, L=None):
+    return _dwt_like("wx_iwpt", xw, wt, L, False)
+
+
+def dwtall(x, wt, L=None):
+    """dwt/dwt_all.jl:39-54"""
+    return _dwt_like("wx_wpt", x, wt, L, True)
+
+
+def idwtall(xw, wt, L=None):
+    """dwt/dwt_all.jl:95-110"""
+    return _dwt_like("wx_iwpt", xw, wt, L, True)
+
+
+# ---------------------------------------------------------------------------------------------
+# getbasiscoef / getbasiscoefall (Utils.jl:101-225), 1-D and 2-D tables on device
 # ---------------------------------------------------------------------------------------------
 def getbasiscoef(Xw, tree):
     Xw = Arg(Xw)
