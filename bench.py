@@ -166,7 +166,7 @@ def cpu_baseline(w, seconds):
 # GPU workloads: each returns (fwd, inv, check, info)
 # ------------------------------------------------------------------------------------------------
 def make_workload(w, wx, torch, dev, rank):
-    from waveletsext_jl_amd import dwt as D
+    D = sys.modules["waveletsext_jl_amd.dwt"]        # the submodule (the package attribute `dwt` is the function)
     from waveletsext_jl_amd._arrays import qmf_arg
     kind, L, B = w["kind"], w["L"], w["batch"]
     wt = wx.wavelet(getattr(wx.WT, w["wavelet"]))
