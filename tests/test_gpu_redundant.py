@@ -29,9 +29,16 @@ def test_swt_forward_families(wx, oracle, wname, dtype):
             assert relerr(wx.sdwtall(x, wt, L), _stack(oracle.sdwt, x, wt.qmf, L)) <= tol
             assert relerr(wx.swptall(x, wt, L), _stack(oracle.swpt, x, wt.qmf, L)) <= tol
             assert relerr(wx.swpdall(x, wt, L), _stack(oracle.swpd, x, wt.qmf, L)) <= tol
-        # swpt == leaves of swpd (test/transforms.jl:95-96), exactly
+        # swpt == leaves of swpd (test/transforms.jl:95-96).  The reference gets bit equality because both
+        # run the same per-level loop; here swpt fuses levels with composite taps, so the identity holds to
+        # rounding (and both match the oracle within the parity tolerance above)
         L = Lmax
-        assert (wx.swpt(x[:, 0], wt) == wx.swpd(x[:, 0], wt)[:, (1 << L) - 1:]).all()
+        assert relerr(wx.swpt(x[:, 0], wt), wx.swpd(x[:, 0], wt)[:, (1 << L) - 1:]) <= (1e-13 if dtype == np.float64 else 1e-5)
+        wx.set_force_generic(1)
+        try:                                    # the per-level path keeps the identity exact
+            assert (wx.swpt(x[:, 0], wt) == wx.swpd(x[:, 0], wt)[:, (1 << L) - 1:]).all()
+        finally:
+            wx.set_force_generic(0)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

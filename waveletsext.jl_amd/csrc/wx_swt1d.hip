@@ -24,6 +24,9 @@
 #include "wx_common.h"
 #include "wx_kernels.h"
 
+int wx_force_generic();
+static int wx_force_generic_swt() { return wx_force_generic(); }
+
 enum { WX_LAYOUT_DWT = 0, WX_LAYOUT_WPT = 1, WX_LAYOUT_WPD = 2 };
 
 static __device__ __forceinline__ void wx_fwd_cols(int layout, int L, int d, int b, int &pcol, int &lcol, int &hcol)
@@ -85,6 +88,46 @@ __global__ __launch_bounds__(1024) void k_swt_fwd_level(const T *__restrict__ x,
                 lo[i] = (T)(c + S);
                 hi[i] = (T)(c - S);
             }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K levels per pass (swpt only): the 2^K descendants of depth d+K are computed straight from the
+// LDS-resident parent with composite taps (products of the K per-level taps, merged per offset on
+// the host).  The intermediate levels never touch HBM: a pass reads 2^d*n and writes 2^(d+K)*n.
+//   table layout: coef[c * U + t] multiplies v[(i + shift[t]) mod n], c = descendant (natural
+//   order), t = index into the union of offsets
+// ------------------------------------------------------------------------------------------
+template <typename T, int NC>
+__global__ __launch_bounds__(1024) void k_swt_fwd_multi(const T *__restrict__ x, T *__restrict__ xw, int n,
+                                                        int ncols, int64_t batch, int L, int d, int K,
+                                                        const double *__restrict__ coef,
+                                                        const int *__restrict__ shift, int U)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    T *v = reinterpret_cast<T *>(wx_smem);
+    const int b = blockIdx.x;
+    const int wp = 1 << (L - d);                   // column pitch of depth-d nodes
+    const int wc = 1 << (L - d - K);               // column pitch of the descendants
+    for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
+        T *base = xw + sig * (int64_t)n * ncols;
+        const T *src = (d == 0) ? x + sig * (int64_t)n : base + (int64_t)(b * wp) * n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) v[i] = src[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            double acc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+            for (int t = 0; t < U; ++t) {
+                int k = i + shift[t]; if (k >= n) k -= n;
+                const double vv = (double)v[k];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = fma(coef[c * U + t], vv, acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) base[(int64_t)((b * NC + c) * wc) * n + i] = (T)acc[c];
         }
         __syncthreads();
     }
@@ -283,6 +326,39 @@ static int wx_grid1(int64_t total)
     return (int)g;
 }
 
+// composite taps of K consecutive stationary levels starting at dilation s (units of s):
+// level k (0-based) has taps lo: offset (j-1)*2^k, hi: offset -j*2^k
+#include <map>
+#include <vector>
+static void wx_swt_composite(const WxFilt &f, int K, std::vector<double> &coef, std::vector<int> &offs)
+{
+    const int NC = 1 << K;
+    std::vector<std::map<int, double>> filt(NC);
+    for (int c = 0; c < NC; ++c) {
+        std::map<int, double> cur;
+        cur[0] = 1.0;
+        for (int k = 0; k < K; ++k) {
+            const int hi = (c >> (K - 1 - k)) & 1;              // first level's choice is the MSB
+            std::map<int, double> nxt;
+            for (auto &e : cur)
+                for (int j = 0; j < f.F; ++j) {
+                    const int o = hi ? -j * (1 << k) : (j - 1) * (1 << k);
+                    const double q = hi ? ((j & 1) ? -f.q[j] : f.q[j]) : f.q[j];
+                    nxt[e.first + o] += e.second * q;
+                }
+            cur.swap(nxt);
+        }
+        filt[c] = cur;
+    }
+    std::map<int, int> uni;
+    for (auto &m : filt) for (auto &e : m) uni[e.first] = 0;
+    int U = 0;
+    offs.clear();
+    for (auto &e : uni) { e.second = U++; offs.push_back(e.first); }
+    coef.assign((size_t)NC * U, 0.0);
+    for (int c = 0; c < NC; ++c) for (auto &e : filt[c]) coef[(size_t)c * U + uni[e.first]] = e.second;
+}
+
 template <typename T>
 int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batch, const WxFilt &filt,
                    const WxAcFilt *ac, hipStream_t st)
@@ -298,16 +374,54 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
     if (lds > 64 * 1024)
         WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int d = 0; d < L; ++d) {
-        const int nodes = layout == WX_LAYOUT_DWT ? 1 : (1 << d);
+    const int nt = n >= 8192 ? 1024 : (n >= 2048 ? 512 : 256);
+    // swpt: fuse K levels per pass (K = 3 for very short filters, else 2); the tables live in a
+    // stream-ordered scratch buffer
+    const int KF = (!ac && layout == WX_LAYOUT_WPT && !wx_force_generic_swt()) ? (filt.F <= 4 ? 3 : (filt.F <= 16 ? 2 : 1)) : 1;
+    double *dcoef = nullptr;
+    int *dshift = nullptr;
+    std::vector<void *> frees;
+    int d = 0;
+    while (d < L) {
+        const int K = (KF > 1 && L - d >= 2) ? (L - d >= KF ? KF : L - d) : 1;
         int64_t gy = batch;
-        const int64_t cap = (int64_t)65535;
-        if (gy > cap) gy = cap;
-        // long signals occupy most of a CU's LDS (one workgroup per CU): give that workgroup 16 waves
-        const int nt = n >= 8192 ? 1024 : (n >= 2048 ? 512 : 256);
-        hipLaunchKernelGGL(kern, dim3(nodes, (unsigned)gy), dim3(nt), lds, st, x, xw, (int)n, ncols, batch, L, d,
-                           layout, filt, acz);
+        if (gy > 65535) gy = 65535;
+        if (K == 1) {
+            const int nodes = layout == WX_LAYOUT_DWT ? 1 : (1 << d);
+            // long signals occupy most of a CU's LDS (one workgroup per CU): give that workgroup 16 waves
+            hipLaunchKernelGGL(kern, dim3(nodes, (unsigned)gy), dim3(nt), lds, st, x, xw, (int)n, ncols, batch, L, d,
+                               layout, filt, acz);
+            d += 1;
+            continue;
+        }
+        std::vector<double> coef;
+        std::vector<int> offs;
+        wx_swt_composite(filt, K, coef, offs);
+        const int U = (int)offs.size();
+        std::vector<int> shift(U);
+        const int64_t sdil = (int64_t)1 << d;
+        for (int t = 0; t < U; ++t) {
+            int64_t sh = ((int64_t)offs[t] * sdil) % n;
+            if (sh < 0) sh += n;
+            shift[t] = (int)sh;
+        }
+        void *p1 = nullptr, *p2 = nullptr;
+        WX_HIP_CHECK(hipMallocAsync(&p1, coef.size() * sizeof(double), st));
+        WX_HIP_CHECK(hipMallocAsync(&p2, shift.size() * sizeof(int), st));
+        frees.push_back(p1); frees.push_back(p2);
+        WX_HIP_CHECK(hipMemcpyAsync(p1, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        WX_HIP_CHECK(hipMemcpyAsync(p2, shift.data(), shift.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        WX_HIP_CHECK(hipStreamSynchronize(st));                  // host tables go out of scope
+        dcoef = (double *)p1; dshift = (int *)p2;
+        auto km = K == 2 ? k_swt_fwd_multi<T, 4> : k_swt_fwd_multi<T, 8>;
+        if (lds > 64 * 1024)
+            WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(km),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(km, dim3(1 << d, (unsigned)gy), dim3(nt), lds, st, x, xw, (int)n, ncols, batch, L, d, K,
+                           (const double *)dcoef, (const int *)dshift, U);
+        d += K;
     }
+    for (void *p : frees) if (hipFreeAsync(p, st) != hipSuccess) (void)hipGetLastError();
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
