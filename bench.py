@@ -36,7 +36,7 @@ WORKLOADS = {
                    kernel="k_fwd1d_inplace<double, 8, 256, false>",
                    desc="north-star target: wptall+iwptall 65536x4096 f64 db4 L=10"),
     "cfg3": dict(kind="swpt", n=16384, batch=64, wavelet="haar", L=12, dtype="f64",
-                 kernel="k_swt_fwd_level<double, false>",
+                 kernel="k_swt_fwd_multi<double, 8>",
                  desc="BASELINE config 3: swptall+iswptall (average-based) 16384-sample f64 haar L=12; one resident "
                       "chunk of 64 signals (32 GiB of leaves) of the 8192-signal batch per step"),
     "cfg4": dict(kind="wpt2d", m=512, n=512, batch=512, wavelet="db4", L=6, dtype="f32",

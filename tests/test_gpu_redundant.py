@@ -78,6 +78,27 @@ def test_swt_inverse_families(wx, oracle, wname, dtype):
         wx.iswpt(np.zeros((8, 8)), wt, 8)                    # main2depthshift assert
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("wname", ["haar", "db4", "db8"])
+def test_iswpt_fused_passes(wx, oracle, wname, dtype):
+    """average-based iswpt runs two (three for F <= 4) levels per pass where the residue-class tiles fit the
+    LDS: arbitrary (non-transform) coefficient tables, non-dyadic lengths, mixed fused/per-level schedules vs
+    the oracle and vs the per-level device path"""
+    rng = np.random.default_rng(2010)
+    wt = _wt(wx, wname)
+    tol = TOL[np.dtype(dtype)]
+    for n, L, B in ((384, 7, 2), (1024, 10, 2), (2048, 6, 3), (640, 5, 2)):
+        sp = np.asfortranarray(rng.standard_normal((n, 1 << L, B)).astype(dtype))
+        got = wx.iswptall(sp, wt)
+        assert relerr(got, _stack(oracle.iswpt, sp, wt.qmf, None)) <= tol, (n, L)
+        wx.set_force_generic(1)
+        try:
+            ref = wx.iswptall(sp, wt)
+        finally:
+            wx.set_force_generic(0)
+        assert relerr(got, ref) <= (1e-13 if dtype == np.float64 else 1e-5)
+
+
 @pytest.mark.parametrize("wname", ["haar", "db4", "coif6"])
 def test_acwt_families(wx, oracle, wname):
     rng = np.random.default_rng(2005)

@@ -118,17 +118,14 @@ static int api_swt_inv(const T *xw, T *x, int64_t n, int64_t ncols, int L, int l
     const T *dxw = (const T *)io.in(xw, sizeof(T) * n * ncols * batch);
     T *dx = (T *)io.out(x, sizeof(T) * n * batch);
     if ((batch && n) && (!dxw || !dx)) return io.finish(WX_EHIP);
-    // level buffers: depth d (1 <= d <= Leff-1) lives in bufs[d & 1] with 2^d (or 1) columns
-    int64_t need[2] = {0, 0};
-    for (int d = 1; d <= Leff - 1; ++d) {
-        const int64_t cols = layout == LAYOUT_DWT ? 1 : ((int64_t)1 << d);
-        if (cols > need[d & 1]) need[d & 1] = cols;
-    }
+    // level buffers follow the inverse schedule (fused iswpt passes skip every other depth)
+    WxSwtInvPlan plan;
+    wx_swt_inv_plan(layout, Leff, F, sm, n, sizeof(T), dtree != nullptr, &plan);
     T *s0 = nullptr, *s1 = nullptr;
-    if (batch && need[0]) { s0 = (T *)scr.alloc(sizeof(T) * n * need[0] * batch); if (!s0) return io.finish(WX_EHIP); }
-    if (batch && need[1]) { s1 = (T *)scr.alloc(sizeof(T) * n * need[1] * batch); if (!s1) return io.finish(WX_EHIP); }
+    if (batch && plan.need_cols[0]) { s0 = (T *)scr.alloc(sizeof(T) * n * plan.need_cols[0] * batch); if (!s0) return io.finish(WX_EHIP); }
+    if (batch && plan.need_cols[1]) { s1 = (T *)scr.alloc(sizeof(T) * n * plan.need_cols[1] * batch); if (!s1) return io.finish(WX_EHIP); }
     // with a sparse tree the shifts still follow the table depth (sd has Lshift+1 entries)
-    rc = wx_dev_swt_inv<T>(dxw, dx, n, Leff, layout, (int)ncols, batch, sm, dtree, ntree, filt, s0, s1, st);
+    rc = wx_dev_swt_inv<T>(dxw, dx, n, Leff, layout, (int)ncols, batch, sm, dtree, ntree, filt, plan, s0, s1, st);
     return io.finish(rc);
 }
 

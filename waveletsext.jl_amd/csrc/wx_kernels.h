@@ -24,10 +24,19 @@ int wx_dev_getbasiscoef1d(const T *Xw, T *out, int64_t n, int k, int64_t batch, 
 template <typename T>
 int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batch, const WxFilt &filt,
                    const WxAcFilt *ac, hipStream_t st);
+// inverse schedule: pass i reconstructs depth to[i] from depth from[i] (from - to = 1, or 2 for a fused
+// average-based iswpt pass working on R[i] residue classes per workgroup); its output lives in scratch
+// buffer buf[i] (-1 = the caller's x).  need_cols[] = columns per signal each scratch buffer must hold.
+struct WxSwtInvPlan {
+    int npass;
+    int from[32], to[32], buf[32], R[32];
+    int64_t need_cols[2];
+};
+void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz, bool has_tree, WxSwtInvPlan *P);
 template <typename T>
 int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, int64_t batch, int64_t sm,
-                   const uint8_t *dtree, int64_t ntree, const WxFilt &filt, T *scratch0, T *scratch1,
-                   hipStream_t st);
+                   const uint8_t *dtree, int64_t ntree, const WxFilt &filt, const WxSwtInvPlan &plan, T *scratch0,
+                   T *scratch1, hipStream_t st);
 template <typename T> int wx_dev_iacdwt(const T *xw, T *x, int64_t n, int L, int64_t batch, hipStream_t st);
 template <typename T> int wx_dev_iacwpt(const T *xw, T *x, int64_t n, int L, int64_t batch, hipStream_t st);
 template <typename T>

@@ -236,6 +236,79 @@ __global__ __launch_bounds__(256) void k_swt_inv_level(WxInvDesc D, int n, int64
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Fused average-based iswpt pass: depth d+K -> d in one kernel.  The average of the two shift
+// variants of a stationary synthesis step is the shift-invariant filter
+//   parent[p] = 1/2 * sum_j q[j] lo[p + (1-j) s] + (-1)^j q[j] hi[p + j s],      s = 2^d
+// (the adjoint of the analysis step), so K steps compose into one set of taps per descendant,
+// all at multiples of s: a workgroup that owns R residue classes mod s of one node needs only
+// those classes of the 2^K descendants.  LDS tile v[c][u][r] = desc_c[r0 + r + u s].
+// ------------------------------------------------------------------------------------------
+template <typename T, int NC, int OPT>
+__global__ __launch_bounds__(512) void k_swt_inv_multi(const T *__restrict__ src, int64_t src_cols,
+                                                       T *__restrict__ dst, int64_t dst_cols, int n, int64_t batch,
+                                                       int d, int R, const double *__restrict__ coef,
+                                                       const int *__restrict__ uoff, int U)
+{
+    // one descendant column tile at a time through a double-buffered LDS tile, accumulators in
+    // registers; the next column's tile is fetched into registers while the current one is used
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    T *v = reinterpret_cast<T *>(wx_smem);
+    const int s = 1 << d;
+    const int nu = n >> d;
+    const int nblk = s / R;
+    const int b = blockIdx.x / nblk;
+    const int r0 = (blockIdx.x - b * nblk) * R;
+    const int tile = nu * R;
+    const int lgR = __ffs(R) - 1;
+    const int NT = blockDim.x;
+    int64_t goff[OPT];
+    int lo[OPT];
+#pragma unroll
+    for (int j = 0; j < OPT; ++j) {
+        const int o = threadIdx.x + j * NT;
+        lo[j] = o;
+        goff[j] = (o & (R - 1)) + (int64_t)(o >> lgR) * s;
+    }
+    for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
+        const T *sp = src + (sig * src_cols + (int64_t)b * NC) * n + r0;
+        T pre[OPT];
+        double acc[OPT];
+#pragma unroll
+        for (int j = 0; j < OPT; ++j) { acc[j] = 0.0; if (lo[j] < tile) v[lo[j]] = sp[goff[j]]; }
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < NC; ++c) {
+            const T *vb = v + (c & 1) * tile;
+            if (c + 1 < NC) {
+#pragma unroll
+                for (int j = 0; j < OPT; ++j) if (lo[j] < tile) pre[j] = sp[(int64_t)(c + 1) * n + goff[j]];
+            }
+            for (int t = 0; t < U; ++t) {
+                const double cf = coef[c * U + t];
+                const int sh = uoff[t];
+#pragma unroll
+                for (int j = 0; j < OPT; ++j) {
+                    if (lo[j] < tile) {
+                        int k = (lo[j] >> lgR) + sh; if (k >= nu) k -= nu;
+                        acc[j] = fma(cf, (double)vb[(k << lgR) + (lo[j] & (R - 1))], acc[j]);
+                    }
+                }
+            }
+            if (c + 1 < NC) {
+                T *vn = v + ((c + 1) & 1) * tile;
+#pragma unroll
+                for (int j = 0; j < OPT; ++j) if (lo[j] < tile) vn[lo[j]] = pre[j];
+            }
+            __syncthreads();
+        }
+        T *dp = dst + (sig * dst_cols + b) * n + r0;
+#pragma unroll
+        for (int j = 0; j < OPT; ++j) if (lo[j] < tile) dp[goff[j]] = (T)acc[j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // ACWT inverses: pure pairwise sums (acwt_one_level.jl:217-224), bit-compatible evaluation order
 // ------------------------------------------------------------------------------------------
@@ -328,6 +401,7 @@ static int wx_grid1(int64_t total)
 
 // composite taps of K consecutive stationary levels starting at dilation s (units of s):
 // level k (0-based) has taps lo: offset (j-1)*2^k, hi: offset -j*2^k
+#include <cstdlib>
 #include <map>
 #include <vector>
 static void wx_swt_composite(const WxFilt &f, int K, std::vector<double> &coef, std::vector<int> &offs)
@@ -426,11 +500,58 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
     return WX_OK;
 }
 
-// scratch: two level buffers (see wx_swt_inv_scratch_elems); sm < 0 = average based
+static int64_t wx_swtinv_lds_bytes()
+{
+    static int64_t v = -1;
+    if (v < 0) { const char *e = getenv("WX_SWTINV_LDS_KIB"); v = (e && atoi(e) > 0 && atoi(e) <= 64 ? atoi(e) : 16) * 1024; }
+    return v;
+}
+static int wx_swtinv_threads()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("WX_SWTINV_NT"); v = (e && (atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256)) ? atoi(e) : 512; }
+    return v;
+}
+// inverse schedule (see WxSwtInvPlan): fused two-level (three for F <= 4) passes for the average-based full iswpt while the
+// 2^K descendant tiles of >= 64-byte runs fit in 128 KiB of LDS, single levels otherwise
+void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz, bool has_tree, WxSwtInvPlan *P)
+{
+    P->npass = 0;
+    P->need_cols[0] = P->need_cols[1] = 0;
+    const bool fuse = layout == WX_LAYOUT_WPT && sm < 0 && !has_tree && F <= 16 && !wx_force_generic_swt();
+    const int64_t budget = wx_swtinv_lds_bytes();
+    int d = L, pp = 0;
+    while (d > 0) {
+        int K = 1, R = 0;
+        for (int Kt = (F <= 4 ? 3 : 2); fuse && Kt >= 2 && K == 1; --Kt) {
+            if (d < Kt) continue;
+            const int dp = d - Kt;
+            const int64_t s = (int64_t)1 << dp, nu = n >> dp;
+            int64_t r = (int64_t)(budget / esz) / nu;                  // one column tile = nu * R elements
+            int64_t rp = 1; while (rp * 2 <= r) rp *= 2;
+            if (r < 1) rp = 0;
+            if (rp > s) rp = s;
+            if (rp > 128) rp = 128;
+            if (rp * (int64_t)esz >= 64) { K = Kt; R = (int)rp; }
+        }
+        const int i = P->npass++;
+        P->from[i] = d; P->to[i] = d - K; P->R[i] = R;
+        if (d - K == 0) P->buf[i] = -1;
+        else {
+            P->buf[i] = pp;
+            const int64_t cols = layout == WX_LAYOUT_DWT ? 1 : ((int64_t)1 << (d - K));
+            if (cols > P->need_cols[pp]) P->need_cols[pp] = cols;
+            pp ^= 1;
+        }
+        d -= K;
+    }
+}
+
+// scratch: two level buffers sized by the plan; sm < 0 = average based
 template <typename T>
 int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, int64_t batch, int64_t sm,
-                   const uint8_t *dtree, int64_t ntree, const WxFilt &filt, T *scratch0, T *scratch1,
-                   hipStream_t st)
+                   const uint8_t *dtree, int64_t ntree, const WxFilt &filt, const WxSwtInvPlan &plan, T *scratch0,
+                   T *scratch1, hipStream_t st)
 {
     if (batch == 0 || n == 0) return WX_OK;
     if (L == 0) {
@@ -442,20 +563,87 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
     int64_t sd[64];
     sd[0] = 0;
     if (sm >= 0) { int64_t acc = 0; for (int d = 0; d < L; ++d) { acc += ((sm >> d) & 1) << d; sd[d + 1] = acc; } }
-    for (int d = L - 1; d >= 0; --d) {
-        WxInvDesc D;
-        D.in = xw; D.ncols = ncols; D.layout = layout; D.L = L; D.d = d; D.tree = dtree; D.ntree = ntree;
-        T *bufs[2] = {scratch0, scratch1};
+    T *bufs[2] = {scratch0, scratch1};
+    std::vector<void *> frees;
+    double *dcoef[4] = {nullptr, nullptr, nullptr, nullptr};
+    int *duoff[4] = {nullptr, nullptr, nullptr, nullptr};
+    int Utab[4] = {0, 0, 0, 0};
+    T *prev = nullptr;                                   // buffer holding depth plan.from[i] (nullptr = xw)
+    int64_t prev_cols = 0;
+    for (int i = 0; i < plan.npass; ++i) {
+        const int d = plan.to[i];
+        const int K = plan.from[i] - d;
         const int nodes_d = layout == WX_LAYOUT_DWT ? 1 : (1 << d);
-        const int nodes_c = layout == WX_LAYOUT_DWT ? 1 : (1 << (d + 1));
-        D.cur = bufs[(d + 1) & 1]; D.cur_cols = nodes_c;
-        if (d == 0) { D.out = x; D.out_cols = 1; } else { D.out = bufs[d & 1]; D.out_cols = nodes_d; }
-        const int sm_mode = sm >= 0 ? 1 : 0;
-        const int64_t per_node = sm_mode ? (n >> d) : n;
-        const int64_t total = batch * nodes_d * per_node;
-        hipLaunchKernelGGL(k_swt_inv_level<T>, dim3(wx_grid1(total)), dim3(256), 0, st, D, (int)n, batch, sm_mode,
-                           sm >= 0 ? (int)sd[d] : 0, sm >= 0 ? (int)sd[d + 1] : 0, filt);
+        T *outp = plan.buf[i] < 0 ? x : bufs[plan.buf[i]];
+        const int64_t out_cols = plan.buf[i] < 0 ? 1 : nodes_d;
+        if (K >= 2) {
+            if (!dcoef[K]) {
+                // adjoint of the forward composite: negated offsets, (1/2)^K gain
+                std::vector<double> coef;
+                std::vector<int> offs;
+                wx_swt_composite(filt, K, coef, offs);
+                const int U = Utab[K] = (int)offs.size();
+                for (auto &c : coef) c *= (K == 2 ? 0.25 : 0.125);
+                for (auto &o : offs) o = -o;
+                void *p1 = nullptr, *p2 = nullptr;
+                WX_HIP_CHECK(hipMallocAsync(&p1, coef.size() * sizeof(double), st));
+                WX_HIP_CHECK(hipMallocAsync(&p2, (size_t)U * sizeof(int) * 32, st));
+                frees.push_back(p1); frees.push_back(p2);
+                // one reduced offset table per depth (offsets are taken mod nu = n >> d)
+                std::vector<int> tab((size_t)U * 32, 0);
+                for (int dd = 0; dd < 32 && dd <= L; ++dd) {
+                    const int64_t nu = n >> dd;
+                    if (nu < 1) break;
+                    for (int t = 0; t < U; ++t) {
+                        int64_t o = (int64_t)offs[t] % nu;
+                        if (o < 0) o += nu;
+                        tab[(size_t)dd * U + t] = (int)o;
+                    }
+                }
+                WX_HIP_CHECK(hipMemcpyAsync(p1, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, st));
+                WX_HIP_CHECK(hipMemcpyAsync(p2, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
+                WX_HIP_CHECK(hipStreamSynchronize(st));      // host tables go out of scope
+                dcoef[K] = (double *)p1; duoff[K] = (int *)p2;
+            }
+            const int R = plan.R[i];
+            const int64_t nu = n >> d;
+            const int64_t tile = nu * R;
+            const size_t lds = (size_t)2 * tile * sizeof(T);
+            int NT = wx_swtinv_threads();
+            while (NT > 64 && NT >= 2 * tile) NT >>= 1;
+            const int64_t opt = (tile + NT - 1) / NT;
+            typedef void (*KM)(const T *, int64_t, T *, int64_t, int, int64_t, int, int, const double *, const int *, int);
+            KM km = nullptr;
+            if (K == 2) km = opt <= 2 ? k_swt_inv_multi<T, 4, 2> : opt <= 4 ? k_swt_inv_multi<T, 4, 4> : opt <= 8 ? k_swt_inv_multi<T, 4, 8> : k_swt_inv_multi<T, 4, 16>;
+            else km = opt <= 2 ? k_swt_inv_multi<T, 8, 2> : opt <= 4 ? k_swt_inv_multi<T, 8, 4> : opt <= 8 ? k_swt_inv_multi<T, 8, 8> : k_swt_inv_multi<T, 8, 16>;
+            if (opt > 16) return wx_set_error(WX_EHIP, "iswpt: inconsistent fused-pass plan");
+            if (lds > 64 * 1024)
+                WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(km),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int64_t gy = batch;
+            if (gy > 65535) gy = 65535;
+            const T *srcp = prev ? prev : xw;
+            const int64_t src_cols = prev ? prev_cols : ncols;
+            hipLaunchKernelGGL(km, dim3((unsigned)(nodes_d * (((int64_t)1 << d) / R)), (unsigned)gy), dim3(NT), lds, st,
+                               srcp, src_cols, outp, out_cols, (int)n, batch, d, R, (const double *)dcoef[K],
+                               (const int *)(duoff[K] + (size_t)d * Utab[K]), Utab[K]);
+        } else {
+            WxInvDesc D;
+            D.in = xw; D.ncols = ncols; D.layout = layout; D.L = L; D.d = d; D.tree = dtree; D.ntree = ntree;
+            // the first pass reads the caller's table; wx_inv_child picks `in` when d == L-1, and for the
+            // wpt layout after a fused pass the source is always a scratch buffer
+            D.cur = prev; D.cur_cols = prev_cols;
+            D.out = outp; D.out_cols = out_cols;
+            const int sm_mode = sm >= 0 ? 1 : 0;
+            const int64_t per_node = sm_mode ? (n >> d) : n;
+            const int64_t total = batch * nodes_d * per_node;
+            hipLaunchKernelGGL(k_swt_inv_level<T>, dim3(wx_grid1(total)), dim3(256), 0, st, D, (int)n, batch, sm_mode,
+                               sm >= 0 ? (int)sd[d] : 0, sm >= 0 ? (int)sd[d + 1] : 0, filt);
+        }
+        prev = plan.buf[i] < 0 ? nullptr : outp;
+        prev_cols = out_cols;
     }
+    for (void *p : frees) if (hipFreeAsync(p, st) != hipSuccess) (void)hipGetLastError();
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
@@ -491,7 +679,7 @@ int wx_dev_iacwpd(const T *xw, T *x, int64_t n, int ncols, int64_t batch, const 
     template int wx_dev_swt_fwd<T>(const T *, T *, int64_t, int, int, int64_t, const WxFilt &, const WxAcFilt *, \
                                    hipStream_t);                                                                \
     template int wx_dev_swt_inv<T>(const T *, T *, int64_t, int, int, int, int64_t, int64_t, const uint8_t *,    \
-                                   int64_t, const WxFilt &, T *, T *, hipStream_t);                             \
+                                   int64_t, const WxFilt &, const WxSwtInvPlan &, T *, T *, hipStream_t);        \
     template int wx_dev_iacdwt<T>(const T *, T *, int64_t, int, int64_t, hipStream_t);                          \
     template int wx_dev_iacwpt<T>(const T *, T *, int64_t, int, int64_t, hipStream_t);                          \
     template int wx_dev_iacwpd<T>(const T *, T *, int64_t, int, int64_t, const uint8_t *, int64_t, int, hipStream_t);
