@@ -25,11 +25,11 @@ template <typename T>
 int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batch, const WxFilt &filt,
                    const WxAcFilt *ac, hipStream_t st);
 // inverse schedule: pass i reconstructs depth to[i] from depth from[i] (from - to = 1, or 2 for a fused
-// average-based iswpt pass working on R[i] residue classes per workgroup); its output lives in scratch
+// average-based iswpt pass working on R[i] residue classes per workgroup, OPT[i] rows per thread); its output lives in scratch
 // buffer buf[i] (-1 = the caller's x).  need_cols[] = columns per signal each scratch buffer must hold.
 struct WxSwtInvPlan {
     int npass;
-    int from[32], to[32], buf[32], R[32];
+    int from[32], to[32], buf[32], R[32], OPT[32];
     int64_t need_cols[2];
 };
 void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz, bool has_tree, WxSwtInvPlan *P);

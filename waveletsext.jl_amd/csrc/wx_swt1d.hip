@@ -23,6 +23,9 @@
 // causes bank conflicts.
 #include "wx_common.h"
 #include "wx_kernels.h"
+#include <cstdlib>
+#include <map>
+#include <vector>
 
 int wx_force_generic();
 static int wx_force_generic_swt() { return wx_force_generic(); }
@@ -128,6 +131,60 @@ __global__ __launch_bounds__(1024) void k_swt_fwd_multi(const T *__restrict__ x,
             }
 #pragma unroll
             for (int c = 0; c < NC; ++c) base[(int64_t)((b * NC + c) * wc) * n + i] = (T)acc[c];
+        }
+        __syncthreads();
+    }
+}
+
+
+// Residue-class variant for deep passes (s = 2^d large): descendant samples of class r (mod s)
+// depend only on the parent's samples of class r, so a workgroup stages an (n/s) x R tile of the
+// parent (runs of R consecutive samples every s) instead of the whole column: small LDS footprint,
+// several workgroups per CU.  uoff[t] = composite offset in units of s, reduced mod n/s.
+template <typename T, int NC, int OPT>
+__global__ __launch_bounds__(512) void k_swt_fwd_multi_rc(const T *__restrict__ x, T *__restrict__ xw, int n,
+                                                          int ncols, int64_t batch, int L, int d, int K, int R,
+                                                          const double *__restrict__ coef,
+                                                          const int *__restrict__ uoff, int U)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    T *v = reinterpret_cast<T *>(wx_smem);
+    const int s = 1 << d;
+    const int nu = n >> d;
+    const int nblk = s / R;
+    const int b = blockIdx.x / nblk;
+    const int r0 = (blockIdx.x - b * nblk) * R;
+    const int tile = nu * R;
+    const int lgR = __ffs(R) - 1;
+    const int NT = blockDim.x;
+    const int wp = 1 << (L - d);
+    const int wc = 1 << (L - d - K);
+    for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
+        T *base = xw + sig * (int64_t)n * ncols;
+        const T *src = ((d == 0) ? x + sig * (int64_t)n : base + (int64_t)(b * wp) * n) + r0;
+#pragma unroll
+        for (int j = 0; j < OPT; ++j) {
+            const int o = threadIdx.x + j * NT;
+            if (o < tile) v[o] = src[(o & (R - 1)) + (int64_t)(o >> lgR) * s];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < OPT; ++j) {
+            const int o = threadIdx.x + j * NT;
+            if (o >= tile) break;
+            const int r = o & (R - 1), u = o >> lgR;
+            double acc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+            for (int t = 0; t < U; ++t) {
+                int k = u + uoff[t]; if (k >= nu) k -= nu;
+                const double vv = (double)v[(k << lgR) + r];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = fma(coef[c * U + t], vv, acc[c]);
+            }
+            T *dp = base + r0 + r + (int64_t)u * s;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dp[(int64_t)((b * NC + c) * wc) * n] = (T)acc[c];
         }
         __syncthreads();
     }
@@ -248,11 +305,14 @@ __global__ __launch_bounds__(256) void k_swt_inv_level(WxInvDesc D, int n, int64
 template <typename T, int NC, int OPT>
 __global__ __launch_bounds__(512) void k_swt_inv_multi(const T *__restrict__ src, int64_t src_cols,
                                                        T *__restrict__ dst, int64_t dst_cols, int n, int64_t batch,
-                                                       int d, int R, const double *__restrict__ coef,
-                                                       const int *__restrict__ uoff, int U)
+                                                       int d, int R, const double *__restrict__ coefp, int ustart,
+                                                       int U)
 {
-    // one descendant column tile at a time through a double-buffered LDS tile, accumulators in
-    // registers; the next column's tile is fetched into registers while the current one is used
+    // One descendant column tile at a time through a double-buffered LDS tile, accumulators in
+    // registers; the next column's tile is fetched into registers while the current one is used.
+    // A thread owns OPT consecutive rows u0..u0+OPT-1 of one residue r, so the U contiguous taps
+    // slide over a window of OPT+U-1 LDS values (not OPT*U): coefp[c][w - j + OPT-1] is the tap
+    // table zero-padded by OPT-1 on both sides, ustart = first tap offset reduced mod nu.
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     T *v = reinterpret_cast<T *>(wx_smem);
     const int s = 1 << d;
@@ -262,50 +322,43 @@ __global__ __launch_bounds__(512) void k_swt_inv_multi(const T *__restrict__ src
     const int r0 = (blockIdx.x - b * nblk) * R;
     const int tile = nu * R;
     const int lgR = __ffs(R) - 1;
-    const int NT = blockDim.x;
-    int64_t goff[OPT];
-    int lo[OPT];
-#pragma unroll
-    for (int j = 0; j < OPT; ++j) {
-        const int o = threadIdx.x + j * NT;
-        lo[j] = o;
-        goff[j] = (o & (R - 1)) + (int64_t)(o >> lgR) * s;
-    }
+    const int r = threadIdx.x & (R - 1);
+    const int u0 = (threadIdx.x >> lgR) * OPT;
+    const int UP = U + 2 * (OPT - 1);
+    const int64_t g0 = r + (int64_t)u0 * s;
+    int kstart = u0 + ustart; if (kstart >= nu) kstart -= nu;
     for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
-        const T *sp = src + (sig * src_cols + (int64_t)b * NC) * n + r0;
+        const T *sp = src + (sig * src_cols + (int64_t)b * NC) * n + r0 + g0;
         T pre[OPT];
         double acc[OPT];
 #pragma unroll
-        for (int j = 0; j < OPT; ++j) { acc[j] = 0.0; if (lo[j] < tile) v[lo[j]] = sp[goff[j]]; }
+        for (int j = 0; j < OPT; ++j) { acc[j] = 0.0; v[((u0 + j) << lgR) + r] = sp[(int64_t)j * s]; }
         __syncthreads();
 #pragma unroll 1
         for (int c = 0; c < NC; ++c) {
-            const T *vb = v + (c & 1) * tile;
+            const T *vb = v + (c & 1) * tile + r;
             if (c + 1 < NC) {
 #pragma unroll
-                for (int j = 0; j < OPT; ++j) if (lo[j] < tile) pre[j] = sp[(int64_t)(c + 1) * n + goff[j]];
+                for (int j = 0; j < OPT; ++j) pre[j] = sp[(int64_t)(c + 1) * n + (int64_t)j * s];
             }
-            for (int t = 0; t < U; ++t) {
-                const double cf = coef[c * U + t];
-                const int sh = uoff[t];
+            const double *cp = coefp + c * UP + (OPT - 1);
+            int k = kstart;
+            for (int w = 0; w < U + OPT - 1; ++w) {
+                const double val = (double)vb[k << lgR];
+                k = (k + 1 == nu) ? 0 : k + 1;
 #pragma unroll
-                for (int j = 0; j < OPT; ++j) {
-                    if (lo[j] < tile) {
-                        int k = (lo[j] >> lgR) + sh; if (k >= nu) k -= nu;
-                        acc[j] = fma(cf, (double)vb[(k << lgR) + (lo[j] & (R - 1))], acc[j]);
-                    }
-                }
+                for (int j = 0; j < OPT; ++j) acc[j] = fma(cp[w - j], val, acc[j]);
             }
             if (c + 1 < NC) {
                 T *vn = v + ((c + 1) & 1) * tile;
 #pragma unroll
-                for (int j = 0; j < OPT; ++j) if (lo[j] < tile) vn[lo[j]] = pre[j];
+                for (int j = 0; j < OPT; ++j) vn[((u0 + j) << lgR) + r] = pre[j];
             }
             __syncthreads();
         }
-        T *dp = dst + (sig * dst_cols + b) * n + r0;
+        T *dp = dst + (sig * dst_cols + b) * n + r0 + g0;
 #pragma unroll
-        for (int j = 0; j < OPT; ++j) if (lo[j] < tile) dp[goff[j]] = (T)acc[j];
+        for (int j = 0; j < OPT; ++j) dp[(int64_t)j * s] = (T)acc[j];
     }
 }
 
@@ -391,6 +444,12 @@ __global__ __launch_bounds__(256) void k_iacwpd(const T *__restrict__ xw, T *__r
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
+static int64_t wx_swtfwd_lds_bytes()
+{
+    static int64_t v = -1;
+    if (v < 0) { const char *e = getenv("WX_SWTFWD_LDS_KIB"); v = (e && atoi(e) > 0 && atoi(e) <= 64 ? atoi(e) : 32) * 1024; }
+    return v;
+}
 static int wx_grid1(int64_t total)
 {
     int64_t g = (total + 255) / 256;
@@ -401,9 +460,6 @@ static int wx_grid1(int64_t total)
 
 // composite taps of K consecutive stationary levels starting at dilation s (units of s):
 // level k (0-based) has taps lo: offset (j-1)*2^k, hi: offset -j*2^k
-#include <cstdlib>
-#include <map>
-#include <vector>
 static void wx_swt_composite(const WxFilt &f, int K, std::vector<double> &coef, std::vector<int> &offs)
 {
     const int NC = 1 << K;
@@ -479,6 +535,22 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
             if (sh < 0) sh += n;
             shift[t] = (int)sh;
         }
+        // residue-class tiles when runs of >= 64 bytes fit the per-workgroup tile budget
+        int Rrc = 0;
+        {
+            const int64_t nu = n >> d;
+            int64_t r = (int64_t)(wx_swtfwd_lds_bytes() / sizeof(T)) / nu, rp = 1;
+            while (rp * 2 <= r) rp *= 2;
+            if (r < 1) rp = 0;
+            if (rp > sdil) rp = sdil;
+            if (rp > 128) rp = 128;
+            if (rp * (int64_t)sizeof(T) >= 64) Rrc = (int)rp;
+            if (Rrc) for (int t = 0; t < U; ++t) {
+                int64_t o = (int64_t)offs[t] % nu;
+                if (o < 0) o += nu;
+                shift[t] = (int)o;
+            }
+        }
         void *p1 = nullptr, *p2 = nullptr;
         WX_HIP_CHECK(hipMallocAsync(&p1, coef.size() * sizeof(double), st));
         WX_HIP_CHECK(hipMallocAsync(&p2, shift.size() * sizeof(int), st));
@@ -487,6 +559,22 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         WX_HIP_CHECK(hipMemcpyAsync(p2, shift.data(), shift.size() * sizeof(int), hipMemcpyHostToDevice, st));
         WX_HIP_CHECK(hipStreamSynchronize(st));                  // host tables go out of scope
         dcoef = (double *)p1; dshift = (int *)p2;
+        if (Rrc) {
+            const int64_t tile = (n >> d) * Rrc;
+            int NT = 512;
+            while (NT > 64 && NT >= 2 * tile) NT >>= 1;
+            const int64_t opt = (tile + NT - 1) / NT;
+            if (opt > 16) return wx_set_error(WX_EHIP, "swpt: inconsistent fused-pass plan");
+            typedef void (*KM)(const T *, T *, int, int, int64_t, int, int, int, int, const double *, const int *, int);
+            KM kr = nullptr;
+            if (K == 2) kr = opt <= 2 ? k_swt_fwd_multi_rc<T, 4, 2> : opt <= 4 ? k_swt_fwd_multi_rc<T, 4, 4> : opt <= 8 ? k_swt_fwd_multi_rc<T, 4, 8> : k_swt_fwd_multi_rc<T, 4, 16>;
+            else kr = opt <= 2 ? k_swt_fwd_multi_rc<T, 8, 2> : opt <= 4 ? k_swt_fwd_multi_rc<T, 8, 4> : opt <= 8 ? k_swt_fwd_multi_rc<T, 8, 8> : k_swt_fwd_multi_rc<T, 8, 16>;
+            hipLaunchKernelGGL(kr, dim3((unsigned)(((int64_t)1 << d) * (sdil / Rrc)), (unsigned)gy), dim3(NT),
+                               (size_t)tile * sizeof(T), st, x, xw, (int)n, ncols, batch, L, d, K, Rrc,
+                               (const double *)dcoef, (const int *)dshift, U);
+            d += K;
+            continue;
+        }
         auto km = K == 2 ? k_swt_fwd_multi<T, 4> : k_swt_fwd_multi<T, 8>;
         if (lds > 64 * 1024)
             WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(km),
@@ -503,7 +591,7 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
 static int64_t wx_swtinv_lds_bytes()
 {
     static int64_t v = -1;
-    if (v < 0) { const char *e = getenv("WX_SWTINV_LDS_KIB"); v = (e && atoi(e) > 0 && atoi(e) <= 64 ? atoi(e) : 16) * 1024; }
+    if (v < 0) { const char *e = getenv("WX_SWTINV_LDS_KIB"); v = (e && atoi(e) > 0 && atoi(e) <= 64 ? atoi(e) : 32) * 1024; }
     return v;
 }
 static int wx_swtinv_threads()
@@ -522,7 +610,7 @@ void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz
     const int64_t budget = wx_swtinv_lds_bytes();
     int d = L, pp = 0;
     while (d > 0) {
-        int K = 1, R = 0;
+        int K = 1, R = 0, OPT = 1;
         for (int Kt = (F <= 4 ? 3 : 2); fuse && Kt >= 2 && K == 1; --Kt) {
             if (d < Kt) continue;
             const int dp = d - Kt;
@@ -532,10 +620,19 @@ void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz
             if (r < 1) rp = 0;
             if (rp > s) rp = s;
             if (rp > 128) rp = 128;
-            if (rp * (int64_t)esz >= 64) { K = Kt; R = (int)rp; }
+            // rows per thread: the largest of 8/4/2/1 dividing nu that keeps >= 64 threads; at most 512 threads
+            int o = 1;
+            for (;; rp >>= 1) {
+                if (rp * (int64_t)esz < 64) { rp = 0; break; }
+                o = 1;
+                for (int oo = 8; oo >= 2; oo >>= 1) if (nu % oo == 0 && nu * rp / oo >= 64) { o = oo; break; }
+                while (nu * rp / o > 512 && o < 8 && nu % (o * 2) == 0) o *= 2;
+                if (nu * rp / o <= 512) break;
+            }
+            if (rp) { K = Kt; R = (int)rp; OPT = o; }
         }
         const int i = P->npass++;
-        P->from[i] = d; P->to[i] = d - K; P->R[i] = R;
+        P->from[i] = d; P->to[i] = d - K; P->R[i] = R; P->OPT[i] = OPT;
         if (d - K == 0) P->buf[i] = -1;
         else {
             P->buf[i] = pp;
@@ -565,9 +662,9 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
     if (sm >= 0) { int64_t acc = 0; for (int d = 0; d < L; ++d) { acc += ((sm >> d) & 1) << d; sd[d + 1] = acc; } }
     T *bufs[2] = {scratch0, scratch1};
     std::vector<void *> frees;
-    double *dcoef[4] = {nullptr, nullptr, nullptr, nullptr};
-    int *duoff[4] = {nullptr, nullptr, nullptr, nullptr};
-    int Utab[4] = {0, 0, 0, 0};
+    double *dcoef[16] = {nullptr};                       // padded tap tables per (K, rows-per-thread)
+    int Utab[16] = {0};
+    int omin[16] = {0};
     T *prev = nullptr;                                   // buffer holding depth plan.from[i] (nullptr = xw)
     int64_t prev_cols = 0;
     for (int i = 0; i < plan.npass; ++i) {
@@ -577,46 +674,42 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
         T *outp = plan.buf[i] < 0 ? x : bufs[plan.buf[i]];
         const int64_t out_cols = plan.buf[i] < 0 ? 1 : nodes_d;
         if (K >= 2) {
-            if (!dcoef[K]) {
-                // adjoint of the forward composite: negated offsets, (1/2)^K gain
-                std::vector<double> coef;
-                std::vector<int> offs;
-                wx_swt_composite(filt, K, coef, offs);
-                const int U = Utab[K] = (int)offs.size();
-                for (auto &c : coef) c *= (K == 2 ? 0.25 : 0.125);
-                for (auto &o : offs) o = -o;
-                void *p1 = nullptr, *p2 = nullptr;
-                WX_HIP_CHECK(hipMallocAsync(&p1, coef.size() * sizeof(double), st));
-                WX_HIP_CHECK(hipMallocAsync(&p2, (size_t)U * sizeof(int) * 32, st));
-                frees.push_back(p1); frees.push_back(p2);
-                // one reduced offset table per depth (offsets are taken mod nu = n >> d)
-                std::vector<int> tab((size_t)U * 32, 0);
-                for (int dd = 0; dd < 32 && dd <= L; ++dd) {
-                    const int64_t nu = n >> dd;
-                    if (nu < 1) break;
-                    for (int t = 0; t < U; ++t) {
-                        int64_t o = (int64_t)offs[t] % nu;
-                        if (o < 0) o += nu;
-                        tab[(size_t)dd * U + t] = (int)o;
-                    }
-                }
-                WX_HIP_CHECK(hipMemcpyAsync(p1, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, st));
-                WX_HIP_CHECK(hipMemcpyAsync(p2, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
-                WX_HIP_CHECK(hipStreamSynchronize(st));      // host tables go out of scope
-                dcoef[K] = (double *)p1; duoff[K] = (int *)p2;
-            }
             const int R = plan.R[i];
             const int64_t nu = n >> d;
             const int64_t tile = nu * R;
+            const int OPT = plan.OPT[i];
+            const int NT = (int)(tile / OPT);
+            const int slot = K * 4 + (OPT == 8 ? 3 : OPT == 4 ? 2 : OPT == 2 ? 1 : 0);
+            if (!dcoef[slot]) {
+                // adjoint of the forward composite: negated offsets (so reversed tap order), (1/2)^K gain,
+                // zero padded by OPT-1 on both sides for the sliding window
+                std::vector<double> coef;
+                std::vector<int> offs;
+                wx_swt_composite(filt, K, coef, offs);
+                const int U = (int)offs.size();
+                for (int t = 1; t < U; ++t)
+                    if (offs[t] != offs[0] + t) return wx_set_error(WX_EHIP, "iswpt: composite taps are not contiguous");
+                const int UP = U + 2 * (OPT - 1), NCk = 1 << K;
+                std::vector<double> pad((size_t)NCk * UP, 0.0);
+                for (int c = 0; c < NCk; ++c)
+                    for (int t = 0; t < U; ++t)
+                        pad[(size_t)c * UP + (OPT - 1) + t] = coef[(size_t)c * U + (U - 1 - t)] * (K == 2 ? 0.25 : 0.125);
+                void *p1 = nullptr;
+                WX_HIP_CHECK(hipMallocAsync(&p1, pad.size() * sizeof(double), st));
+                frees.push_back(p1);
+                WX_HIP_CHECK(hipMemcpyAsync(p1, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice, st));
+                WX_HIP_CHECK(hipStreamSynchronize(st));      // host table goes out of scope
+                dcoef[slot] = (double *)p1;
+                Utab[slot] = U;
+                omin[slot] = -offs[U - 1];                   // smallest offset of the adjoint taps
+            }
+            int64_t ustart = omin[slot] % nu;
+            if (ustart < 0) ustart += nu;
             const size_t lds = (size_t)2 * tile * sizeof(T);
-            int NT = wx_swtinv_threads();
-            while (NT > 64 && NT >= 2 * tile) NT >>= 1;
-            const int64_t opt = (tile + NT - 1) / NT;
-            typedef void (*KM)(const T *, int64_t, T *, int64_t, int, int64_t, int, int, const double *, const int *, int);
+            typedef void (*KM)(const T *, int64_t, T *, int64_t, int, int64_t, int, int, const double *, int, int);
             KM km = nullptr;
-            if (K == 2) km = opt <= 2 ? k_swt_inv_multi<T, 4, 2> : opt <= 4 ? k_swt_inv_multi<T, 4, 4> : opt <= 8 ? k_swt_inv_multi<T, 4, 8> : k_swt_inv_multi<T, 4, 16>;
-            else km = opt <= 2 ? k_swt_inv_multi<T, 8, 2> : opt <= 4 ? k_swt_inv_multi<T, 8, 4> : opt <= 8 ? k_swt_inv_multi<T, 8, 8> : k_swt_inv_multi<T, 8, 16>;
-            if (opt > 16) return wx_set_error(WX_EHIP, "iswpt: inconsistent fused-pass plan");
+            if (K == 2) km = OPT == 8 ? k_swt_inv_multi<T, 4, 8> : OPT == 4 ? k_swt_inv_multi<T, 4, 4> : OPT == 2 ? k_swt_inv_multi<T, 4, 2> : k_swt_inv_multi<T, 4, 1>;
+            else km = OPT == 8 ? k_swt_inv_multi<T, 8, 8> : OPT == 4 ? k_swt_inv_multi<T, 8, 4> : OPT == 2 ? k_swt_inv_multi<T, 8, 2> : k_swt_inv_multi<T, 8, 1>;
             if (lds > 64 * 1024)
                 WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(km),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -625,8 +718,8 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
             const T *srcp = prev ? prev : xw;
             const int64_t src_cols = prev ? prev_cols : ncols;
             hipLaunchKernelGGL(km, dim3((unsigned)(nodes_d * (((int64_t)1 << d) / R)), (unsigned)gy), dim3(NT), lds, st,
-                               srcp, src_cols, outp, out_cols, (int)n, batch, d, R, (const double *)dcoef[K],
-                               (const int *)(duoff[K] + (size_t)d * Utab[K]), Utab[K]);
+                               srcp, src_cols, outp, out_cols, (int)n, batch, d, R, (const double *)dcoef[slot],
+                               (int)ustart, Utab[slot]);
         } else {
             WxInvDesc D;
             D.in = xw; D.ncols = ncols; D.layout = layout; D.L = L; D.d = d; D.tree = dtree; D.ntree = ntree;
