@@ -46,6 +46,8 @@ extern "C" {
 int wx_version(void);                       /* 10000*major + 100*minor + patch */
 const char *wx_last_error(void);            /* message of the last failing call on this thread */
 int wx_device_count(void);                  /* number of visible HIP devices (0 if none) */
+/* releases the library's only state, the cached stream-ordered scratch of the current device */
+int wx_shutdown(void);
 /* test hook: nonzero forces the one-level-per-launch kernels instead of the fused LDS kernels */
 void wx_set_force_generic(int on);
 
@@ -222,6 +224,26 @@ int wx_getbasiscoef2d_f64(const double *Xw, double *out, int64_t m, int64_t n, i
                           int64_t batch, void *stream);
 int wx_getbasiscoef2d_f32(const float *Xw, float *out, int64_t m, int64_t n, int k, const uint8_t *tree, int64_t ntree,
                           int64_t batch, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU exchange (one process per GPU, RCCL over xGMI; bound lazily, single-GPU callers never
+ * load RCCL).  Transforms shard over the batch (last) dimension with no collective: the loops
+ * dwt/dwt_all.jl:277-279, swt/swt_all.jl:171-173, acwt/acwt_all.jl:254-256 are independent per
+ * signal.  The only exchange steps are
+ *   C1 all-gather of the reconstructed output shards (iwpdall / iwptall ... results), and
+ *   C2 all-reduce (sum) of the JBB moments [sum | sumsq] before wx_jbb_costs_* -- the means over
+ *      all signals of bestbasis/bestbasis_tree.jl:153-154.
+ * id128: 128-byte RCCL unique id made by rank 0 (wx_comm_unique_id) and broadcast by the launcher
+ * (MPI.jl / Distributed.jl / torch.distributed).  Buffers are device pointers; `count` elements per
+ * rank (equal on every rank: pad ragged shards), recv holds nranks*count; asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------------ */
+int wx_comm_unique_id(void *id128);
+int wx_comm_init(int nranks, int rank, const void *id128, void **comm);
+int wx_comm_destroy(void *comm);
+int wx_allgather_out_f64(const double *send, double *recv, int64_t count, void *comm, void *stream);
+int wx_allgather_out_f32(const float *send, float *recv, int64_t count, void *comm, void *stream);
+int wx_allreduce_moments_f64(double *buf, int64_t count, void *comm, void *stream);
+int wx_allreduce_moments_f32(float *buf, int64_t count, void *comm, void *stream);
 
 #ifdef __cplusplus
 }

@@ -180,3 +180,33 @@ def test_dwtall_is_the_dwt_tree_packet_transform(wx, oracle):
     yi = wx.dwtall(img, wt)
     assert relerr(yi[..., 1], oracle.wpt(img[..., 1], wt.qmf, oracle.maketree2d(16, 16, 4, "dwt"))) <= 1e-10
     assert relerr(wx.idwtall(yi, wt), img) <= 1e-10
+
+
+def test_native_rccl_exchange_single_rank(wx):
+    """the library's own RCCL entry points (C1 all-gather, C2 all-reduce) with a one-rank communicator:
+    plumbing, dtype dispatch and stream ordering; multi-rank behaviour is RCCL's"""
+    import torch
+    from waveletsext_jl_amd import distributed as D
+    uid = D.NativeComm.unique_id()
+    assert len(uid) == 128
+    comm = D.NativeComm(1, 0, uid)
+    try:
+        for dt in (torch.float64, torch.float32):
+            x = wx.jl_empty((64, 5), dt, "cuda")
+            x.normal_()
+            full = comm.allgather_batch(x, 5)
+            torch.cuda.synchronize()
+            assert full.shape == x.shape and torch.equal(full, x)
+            s = wx.jl_empty((64, 3), dt, "cuda"); s.normal_()
+            q = wx.jl_empty((64, 3), dt, "cuda"); q.normal_()
+            s2, q2 = comm.allreduce_moments(s, q)
+            torch.cuda.synchronize()
+            assert torch.equal(s2, s) and torch.equal(q2, q)
+        with pytest.raises(wx.ArgumentError):
+            import ctypes
+            from waveletsext_jl_amd import _lib
+            host = np.zeros(4)
+            _lib.check(_lib.lib().wx_allreduce_moments_f64(host.ctypes.data, 4, comm.handle, None))
+    finally:
+        comm.close()
+    wx.shutdown()

@@ -109,6 +109,14 @@ _PLAIN_SIGS = {
     "wx_treeselect_f32": [_P, _L, _L, _I, _P],
     "wx_treeselect2d_f64": [_P, _L, _L, _L, _I, _P],
     "wx_treeselect2d_f32": [_P, _L, _L, _L, _I, _P],
+    "wx_shutdown": [],
+    "wx_comm_unique_id": [_P],
+    "wx_comm_init": [_I, _I, _P, ctypes.POINTER(ctypes.c_void_p)],
+    "wx_comm_destroy": [_P],
+    "wx_allgather_out_f64": [_P, _P, _L, _P, _P],
+    "wx_allgather_out_f32": [_P, _P, _L, _P, _P],
+    "wx_allreduce_moments_f64": [_P, _L, _P, _P],
+    "wx_allreduce_moments_f32": [_P, _L, _P, _P],
 }
 
 
@@ -128,6 +136,11 @@ def check(rc):
 
 def device_count():
     return lib().wx_device_count()
+
+
+def shutdown():
+    """release the library's cached device scratch (wx_shutdown)"""
+    check(lib().wx_shutdown())
 
 
 def set_force_generic(on):

@@ -140,6 +140,19 @@ static void wx_retain_pool()
     if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr) != hipSuccess) (void)hipGetLastError();
 }
 
+// hand the cached scratch of the current device back to the driver (the only state the library owns)
+extern "C" int wx_shutdown(void)
+{
+    int dev = 0, n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void)hipGetLastError(); return WX_OK; }
+    WX_HIP_CHECK(hipGetDevice(&dev));
+    WX_HIP_CHECK(hipDeviceSynchronize());
+    hipMemPool_t pool;
+    WX_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, dev));
+    WX_HIP_CHECK(hipMemPoolTrimTo(pool, 0));
+    return WX_OK;
+}
+
 void *WxScratch::alloc(size_t bytes)
 {
     void *p = nullptr;

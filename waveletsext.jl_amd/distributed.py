@@ -93,3 +93,54 @@ def acwpd_bestbasistree_sharded(x_local, wt, L, N_total, method=None, group=None
     s, q = allreduce_moments(s, q, group)
     costs = bb.costs_from_moments(s, q, N_total, method)
     return bb.bestbasis_treeselection(costs, x_local.shape[0])
+
+
+# ---- the same two exchange steps through the library's own RCCL entry points ---------------------
+# (what a host without torch.distributed -- the Julia shim -- calls; include/waveletsext_hip.h "Multi-GPU
+# exchange").  The launcher only has to broadcast the 128-byte id from rank 0.
+class NativeComm:
+    """RCCL communicator owned by libwaveletsext_hip.so (wx_comm_init / wx_comm_destroy)."""
+
+    def __init__(self, nranks, rank, unique_id):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        self.nranks, self.rank = int(nranks), int(rank)
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().wx_comm_init(self.nranks, self.rank, ctypes.cast(buf, ctypes.c_void_p), ctypes.byref(h)))
+        self.handle = h
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+        from . import _lib
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.lib().wx_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return buf.raw
+
+    def _fn(self, stem, t):
+        return getattr(self._lib.lib(), stem + ("_f64" if t.dtype == torch.float64 else "_f32"))
+
+    def allgather_batch(self, local, B_total):
+        """C1 with equal shards (pad ragged shards before calling): (sig..., B_r) -> (sig..., nranks*B_r)"""
+        assert local.is_cuda and local.dtype in (torch.float32, torch.float64)
+        assert B_total == local.shape[-1] * self.nranks, "equal shards only: pad ragged shards"
+        src = _as_batch_major(local).contiguous()
+        full = torch.empty((B_total,) + tuple(src.shape[1:]), dtype=local.dtype, device=local.device)
+        st = torch.cuda.current_stream(local.device).cuda_stream
+        self._lib.check(self._fn("wx_allgather_out", local)(src.data_ptr(), full.data_ptr(), src.numel(), self.handle, st))
+        return _as_batch_major(full) if full.dim() > 1 else full
+
+    def allreduce_moments(self, s, q):
+        """C2: one in-place sum over the fused [sum | sumsq] buffer"""
+        fused = torch.stack([_as_batch_major(s).contiguous().reshape(-1), _as_batch_major(q).contiguous().reshape(-1)])
+        st = torch.cuda.current_stream(s.device).cuda_stream
+        self._lib.check(self._fn("wx_allreduce_moments", fused)(fused.data_ptr(), fused.numel(), self.handle, st))
+        shp = tuple(reversed(tuple(s.shape)))
+        return _as_batch_major(fused[0].reshape(shp)), _as_batch_major(fused[1].reshape(shp))
+
+    def close(self):
+        if self.handle:
+            self._lib.check(self._lib.lib().wx_comm_destroy(self.handle))
+            self.handle = None

@@ -223,4 +223,30 @@ function bestbasistree(X::HIP{Float64,3}, method::JBB = JBB())
     return BitVector(tree .!= 0)
 end
 
+# ---- multi-GPU (one process per GPU; include/waveletsext_hip.h "Multi-GPU exchange") ----------------------------
+# The launcher (MPI.jl, Distributed.jl) broadcasts the 128-byte id made on rank 0.  Transforms need no
+# collective: each process runs the methods above on its contiguous shard `x[:, lo:hi]`.  `buf` arguments of the
+# two exchange steps are device pointers (e.g. `pointer(::ROCArray)`), `count` elements per rank.
+struct Comm; handle::Ptr{Cvoid}; nranks::Int; rank::Int; end
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:wx_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+    return id
+end
+function Comm(nranks::Integer, rank::Integer, id::Vector{UInt8})
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:wx_comm_init, LIB), Cint, (Cint, Cint, Ptr{UInt8}, Ref{Ptr{Cvoid}}), nranks, rank, id, h))
+    return Comm(h[], nranks, rank)
+end
+Base.close(c::Comm) = check(ccall((:wx_comm_destroy, LIB), Cint, (Ptr{Cvoid},), c.handle))
+# C1: reconstructed output shards -> full batch on every rank (recv holds nranks*count elements)
+allgather_out!(recv::Ptr{Float64}, send::Ptr{Float64}, count::Integer, c::Comm, stream = C_NULL) =
+    check(ccall((:wx_allgather_out_f64, LIB), Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                send, recv, count, c.handle, stream))
+# C2: JBB moments [sum | sumsq] summed over ranks in place, then wx_jbb_costs_* / wx_treeselect_* on every rank
+allreduce_moments!(buf::Ptr{Float64}, count::Integer, c::Comm, stream = C_NULL) =
+    check(ccall((:wx_allreduce_moments_f64, LIB), Cint, (Ptr{Float64}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                buf, count, c.handle, stream))
+shutdown() = check(ccall((:wx_shutdown, LIB), Cint, ()))
+
 end # module
