@@ -176,10 +176,36 @@ __global__ __launch_bounds__(512) void k_acwpd_subtree_moments(const double *__r
     for (int j = 1; j < LP; ++j) { const int c = np << j; if (j & 1) { if (c > szB) szB = c; } else if (c > szA) szA = c; }
     double *bufA = reinterpret_cast<double *>(wx_smem);
     double *bufB = bufA + (size_t)G * szA;
-    // odd-lag taps b_1, b_3, ... as LDS broadcasts (the lag loop stays rolled: unrolling it lets the
-    // scheduler hoist every window load and spill)
-    double *bl = bufB + (size_t)G * szB;
-    if (tid < NL) bl[tid] = ac.b[2 * tid];
+    // Tap table per level as LDS broadcasts (the tap loop stays rolled: unrolling it lets the scheduler
+    // hoist every window load and spill).  At level j the sub-signal splits into classes of M = n' >> j
+    // samples and only odd lags are non-zero, so when M/2 <= 2 NL the +-lags alias onto the M/2 odd
+    // residues mod M and the periodised filter has M/2 taps (sums of the b_l that alias) instead of 2 NL.
+    struct FoldTap { double B; int off; int pad; };
+    FoldTap *ft = reinterpret_cast<FoldTap *>(bufB + (size_t)G * szB);
+    int *fT = reinterpret_cast<int *>(ft + LP * 2 * NL);
+    if (tid < LP * 2 * NL) {
+        const int j = tid / (2 * NL), k = tid - j * (2 * NL);
+        const int M = np >> j;
+        double B = 0.0;
+        int rho = 0;
+        if (M / 2 <= 2 * NL) {
+            rho = 2 * k + 1;
+            if (k < M / 2)
+                for (int l = 0; l < NL; ++l) {
+                    const int lag = (2 * l + 1) % M;
+                    if (lag == rho) B += ac.b[2 * l];
+                    if ((M - lag) % M == rho) B += ac.b[2 * l];
+                }
+            if (k == 0) fT[j] = M / 2;
+        } else {
+            if (k < NL) { rho = 2 * k + 1; B = ac.b[2 * k]; }
+            else { rho = M - (2 * (k - NL) + 1); B = ac.b[2 * (k - NL)]; }
+            if (k == 0) fT[j] = 2 * NL;
+        }
+        ft[tid].B = B;
+        ft[tid].off = (rho << j) & (np - 1);
+        ft[tid].pad = 0;
+    }
     const double c1 = ac.c1;
     const int64_t colq = ((int64_t)1 << D0) - 1 + q;                // heap column (0-based) of the subtree root
     const int64_t sig_stride = (int64_t)n * ncols_top;
@@ -206,24 +232,23 @@ __global__ __launch_bounds__(512) void k_acwpd_subtree_moments(const double *__r
             const int sub = tid >> lcnt;                              // lane subset
             const int nsub = NT >> lcnt;
             const int p = item >> lnp, i = item & (np - 1);
-            const int st = 1 << j;
             const double *v = cur + ((size_t)p << lnp);
             for (int g0 = sub; g0 < gcount; g0 += nsub * GC) {
                 double S[GC];
 #pragma unroll
                 for (int c = 0; c < GC; ++c) S[c] = 0.0;
-                int km = (i - st) & (np - 1), kp = (i + st) & (np - 1);
+                const FoldTap *tp = ft + j * 2 * NL;
+                const int T = fT[j];
 #pragma unroll 1
-                for (int l = 0; l < NL; ++l) {
-                    const double bt = bl[l];
+                for (int l = 0; l < T; ++l) {
+                    const double bt = tp[l].B;
+                    const int kk = (i + tp[l].off) & (np - 1);
 #pragma unroll
                     for (int c = 0; c < GC; ++c) {
                         const int g = g0 + c * nsub;                  // g >= G reads stay inside the buffer pair
                         const size_t off = (size_t)(g < G ? g : g0) * scur;
-                        S[c] = fma(bt, v[off + km] + v[off + kp], S[c]);
+                        S[c] = fma(bt, v[off + kk], S[c]);
                     }
-                    km = (km - 2 * st) & (np - 1);
-                    kp = (kp + 2 * st) & (np - 1);
                 }
 #pragma unroll
                 for (int c = 0; c < GC; ++c) {
@@ -298,7 +323,7 @@ int wx_dev_acwpd_subtree_moments(const double *top, double *sum, double *sumsq, 
     const int np = (int)(n >> D0);
     int szA = np, szB = 0;
     for (int j = 1; j < LP; ++j) { const int c = np << j; if (j & 1) { if (c > szB) szB = c; } else if (c > szA) szA = c; }
-    size_t lds = ((size_t)G * (szA + szB) + 16) * sizeof(double);
+    size_t lds = ((size_t)G * (szA + szB) + 2 * 6 * 2 * 10 + 8) * sizeof(double);   // + tap table
     if (lds < (size_t)4 * 512 * sizeof(double)) lds = (size_t)4 * 512 * sizeof(double);   // final reduction
     const int ncols_top = (1 << (D0 + 1)) - 1;
     const unsigned grid = 1u << (2 * D0);
