@@ -156,22 +156,26 @@ template int wx_dev_jbb_costs2d<float>(const float *, const float *, int64_t, in
 // sequentially over the signals, i.e. in the order of Julia's sum(X, dims=3).  HBM sees only the
 // shallow top table (depth <= D0) instead of the full (n, 2^(L+1)-1) table per signal.
 // ------------------------------------------------------------------------------------------
+struct WxFoldTap { double B; int off; int pad; };
+
 template <int LP, int G, int NL>
-__global__ __launch_bounds__(512) void k_acwpd_subtree_moments(const double *__restrict__ top, double *__restrict__ sum,
+__global__ __launch_bounds__(256) void k_acwpd_subtree_moments(const double *__restrict__ top, double *__restrict__ sum,
                                                                double *__restrict__ sumsq, int log2n, int D0,
                                                                int ncols_top, int64_t batch, WxAcFilt ac,
                                                                int accumulate)
 {
+    static_assert(G == 4, "the LDS layout interleaves 4 signals (two 16-byte reads per position)");
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
-    constexpr int NT = 512;
-    constexpr int GC = 4;                         // signals per inner chunk (register window)
+    constexpr int NT = 256;
     const int n = 1 << log2n;
     const int lnp = log2n - D0;                   // log2 of the sub-signal length n'
     const int np = 1 << lnp;
     const int q = blockIdx.x >> D0;               // node of depth D0
     const int r = blockIdx.x & ((1 << D0) - 1);   // residue class
     const int tid = threadIdx.x;
-    // level buffers: even levels in bufA, odd in bufB; per signal slot sizes szA / szB doubles
+    // level buffers: even levels in bufA, odd in bufB; element (position e of the level, signal g of the
+    // group) lives at [e * G + g]: a thread reads the G signals of a position as 2 x 16 bytes with one
+    // address, consecutive items read consecutive 32-byte chunks (conflict free)
     int szA = np, szB = 0;
     for (int j = 1; j < LP; ++j) { const int c = np << j; if (j & 1) { if (c > szB) szB = c; } else if (c > szA) szA = c; }
     double *bufA = reinterpret_cast<double *>(wx_smem);
@@ -180,8 +184,7 @@ __global__ __launch_bounds__(512) void k_acwpd_subtree_moments(const double *__r
     // hoist every window load and spill).  At level j the sub-signal splits into classes of M = n' >> j
     // samples and only odd lags are non-zero, so when M/2 <= 2 NL the +-lags alias onto the M/2 odd
     // residues mod M and the periodised filter has M/2 taps (sums of the b_l that alias) instead of 2 NL.
-    struct FoldTap { double B; int off; int pad; };
-    FoldTap *ft = reinterpret_cast<FoldTap *>(bufB + (size_t)G * szB);
+    WxFoldTap *ft = reinterpret_cast<WxFoldTap *>(bufB + (size_t)G * szB);
     int *fT = reinterpret_cast<int *>(ft + LP * 2 * NL);
     if (tid < LP * 2 * NL) {
         const int j = tid / (2 * NL), k = tid - j * (2 * NL);
@@ -203,94 +206,96 @@ __global__ __launch_bounds__(512) void k_acwpd_subtree_moments(const double *__r
             if (k == 0) fT[j] = 2 * NL;
         }
         ft[tid].B = B;
-        ft[tid].off = (rho << j) & (np - 1);
+        ft[tid].off = ((rho << j) & (np - 1)) * G;                   // in doubles of the interleaved layout
         ft[tid].pad = 0;
     }
     const double c1 = ac.c1;
     const int64_t colq = ((int64_t)1 << D0) - 1 + q;                // heap column (0-based) of the subtree root
     const int64_t sig_stride = (int64_t)n * ncols_top;
 
-    // level j: item = tid mod cnt_j, the 512/cnt_j lane subsets share the G signals of a group
-    double s_lo[LP], q_lo[LP], s_hi[LP], q_hi[LP];
+    // thread tid owns items tid and tid + 256 (the deepest level may have 512) of every level and sums its
+    // signals in order, group after group: exactly the order of Julia's sum(X, dims=3)
+    double acc[LP + 1][4];                                           // [LP] = second item of the deepest level
 #pragma unroll
-    for (int j = 0; j < LP; ++j) { s_lo[j] = q_lo[j] = s_hi[j] = q_hi[j] = 0.0; }
+    for (int j = 0; j <= LP; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[j][k] = 0.0;
 
+    // sub-signal fetch: element e = (g, i); missing signals of the last group are zeros, which add
+    // exact zeros to every moment below
+    const int fe_g = tid >> lnp, fe_i = tid & (np - 1);
+    const bool fetcher = tid < G * np;                               // G * np <= 256 (see wx_acwpd_fused_depth)
+    const double *fsrc = top + colq * n + r + ((int64_t)fe_i << D0);
+    double pre = (fetcher && fe_g < batch) ? fsrc[fe_g * sig_stride] : 0.0;
+    const int posmask = (np - 1) * G;                                // wraps the position, keeps the signal lane
     for (int64_t sig0 = 0; sig0 < batch; sig0 += G) {
-        const int gcount = (batch - sig0 < G) ? (int)(batch - sig0) : G;
-        for (int e = tid; e < G * np; e += NT) {
-            const int g = e >> lnp, i = e & (np - 1);
-            bufA[(size_t)g * szA + i] = g < gcount ? top[(sig0 + g) * sig_stride + colq * n + r + ((int64_t)i << D0)] : 0.0;
-        }
+        if (fetcher) bufA[(size_t)fe_i * G + fe_g] = pre;
         __syncthreads();
+        {   // next group's samples travel while this group is processed
+            const int64_t gn = sig0 + G + fe_g;
+            pre = (fetcher && gn < batch) ? fsrc[gn * sig_stride] : 0.0;
+        }
 #pragma unroll
         for (int j = 0; j < LP; ++j) {
             const double *cur = (j & 1) ? bufB : bufA;
             double *nxt = (j & 1) ? bufA : bufB;
-            const int scur = (j & 1) ? szB : szA, snxt = (j & 1) ? szA : szB;
-            const int lcnt = lnp + j;                                 // log2(items of this level)
-            const int item = tid & ((1 << lcnt) - 1);
-            const int sub = tid >> lcnt;                              // lane subset
-            const int nsub = NT >> lcnt;
-            const int p = item >> lnp, i = item & (np - 1);
-            const double *v = cur + ((size_t)p << lnp);
-            for (int g0 = sub; g0 < gcount; g0 += nsub * GC) {
-                double S[GC];
+            const int cnt = np << j;                                  // items of this level
+            const WxFoldTap *tp = ft + j * 2 * NL;
+            const int T = __builtin_amdgcn_readfirstlane(fT[j]);
 #pragma unroll
-                for (int c = 0; c < GC; ++c) S[c] = 0.0;
-                const FoldTap *tp = ft + j * 2 * NL;
-                const int T = fT[j];
+            for (int h = 0; h < (j == LP - 1 ? 2 : 1); ++h) {         // only the deepest level can have 512 items
+                const int item = tid + h * NT;
+                const int aj = j + h;
+                if (item < cnt) {
+                    const int p = item >> lnp, iG = (item & (np - 1)) * G;
+                    const double *v = cur + ((size_t)p << lnp) * G;
+                    double S[G];
+#pragma unroll
+                    for (int c = 0; c < G; ++c) S[c] = 0.0;
 #pragma unroll 1
-                for (int l = 0; l < T; ++l) {
-                    const double bt = tp[l].B;
-                    const int kk = (i + tp[l].off) & (np - 1);
+                    for (int l = 0; l < T; ++l) {
+                        const double bt = tp[l].B;
+                        const double *xv = v + ((iG + tp[l].off) & posmask);
 #pragma unroll
-                    for (int c = 0; c < GC; ++c) {
-                        const int g = g0 + c * nsub;                  // g >= G reads stay inside the buffer pair
-                        const size_t off = (size_t)(g < G ? g : g0) * scur;
-                        S[c] = fma(bt, v[off + kk], S[c]);
+                        for (int c = 0; c < G; ++c) S[c] = fma(bt, xv[c], S[c]);
                     }
-                }
+                    const double *xc = v + iG;
+                    double *olo = nxt + (((size_t)(2 * p)) << lnp) * G + iG;
+                    double *ohi = olo + ((size_t)G << lnp);
+                    double a0 = acc[aj][0], a1 = acc[aj][1], a2 = acc[aj][2], a3 = acc[aj][3];
 #pragma unroll
-                for (int c = 0; c < GC; ++c) {
-                    const int g = g0 + c * nsub;
-                    if (g < gcount) {
-                        const double cc = c1 * v[(size_t)g * scur + i];
+                    for (int c = 0; c < G; ++c) {
+                        const double cc = c1 * xc[c];
                         const double lo = cc + S[c], hi = cc - S[c];
-                        s_lo[j] += lo; q_lo[j] += lo * lo;
-                        s_hi[j] += hi; q_hi[j] += hi * hi;
-                        if (j + 1 < LP) {
-                            double *o = nxt + (size_t)g * snxt;
-                            o[((size_t)(2 * p) << lnp) + i] = lo;
-                            o[((size_t)(2 * p + 1) << lnp) + i] = hi;
-                        }
+                        a0 += lo; a1 = fma(lo, lo, a1);
+                        a2 += hi; a3 = fma(hi, hi, a3);
+                        if (j + 1 < LP) { olo[c] = lo; ohi[c] = hi; }
                     }
+                    acc[aj][0] = a0; acc[aj][1] = a1; acc[aj][2] = a2; acc[aj][3] = a3;
                 }
             }
             __syncthreads();
         }
     }
-    // combine the lane subsets (in subset order) and add to the heap columns of the subtree
+    // add to the heap columns of the subtree
     const int64_t H = ((int64_t)1 << D0) + q;                         // 1-based heap index of the subtree root
-    double *red = bufA;                                               // 4 * NT doubles
 #pragma unroll
     for (int j = 0; j < LP; ++j) {
-        const int lcnt = lnp + j;
-        const int nsub = NT >> lcnt;
-        __syncthreads();
-        red[tid] = s_lo[j]; red[NT + tid] = q_lo[j]; red[2 * NT + tid] = s_hi[j]; red[3 * NT + tid] = q_hi[j];
-        __syncthreads();
-        if (tid < (1 << lcnt)) {
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            for (int sidx = 0; sidx < nsub; ++sidx) {
-                const int t = tid + (sidx << lcnt);
-                a0 += red[t]; a1 += red[NT + t]; a2 += red[2 * NT + t]; a3 += red[3 * NT + t];
+#pragma unroll
+        for (int h = 0; h < (j == LP - 1 ? 2 : 1); ++h) {
+            const int item = tid + h * NT;
+            const int aj = j + h;
+            if (item < (np << j)) {
+                const int p = item >> lnp, i = item & (np - 1);
+                const int64_t hl = (H << (j + 1)) + 2 * p;           // low child, 1-based
+                const int64_t row = r + ((int64_t)i << D0);
+                const int64_t el = (hl - 1) * n + row, eh = hl * n + row;
+                if (accumulate) {
+                    sum[el] += acc[aj][0]; sumsq[el] += acc[aj][1]; sum[eh] += acc[aj][2]; sumsq[eh] += acc[aj][3];
+                } else {
+                    sum[el] = acc[aj][0]; sumsq[el] = acc[aj][1]; sum[eh] = acc[aj][2]; sumsq[eh] = acc[aj][3];
+                }
             }
-            const int p = tid >> lnp, i = tid & (np - 1);
-            const int64_t hl = (H << (j + 1)) + 2 * p;               // low child, 1-based
-            const int64_t row = r + ((int64_t)i << D0);
-            const int64_t el = (hl - 1) * n + row, eh = hl * n + row;
-            if (accumulate) { sum[el] += a0; sumsq[el] += a1; sum[eh] += a2; sumsq[eh] += a3; }
-            else { sum[el] = a0; sumsq[el] = a1; sum[eh] = a2; sumsq[eh] = a3; }
         }
     }
 }
@@ -308,7 +313,7 @@ int wx_acwpd_fused_depth(int64_t n, int L, int F)
         const int LP = L - D0;
         if (LP > 6 || D0 > log2n) continue;
         const int64_t cnt = (n >> D0) << (LP - 1);
-        if (cnt <= 512 && (n >> D0) >= 1) return D0;
+        if (cnt <= 512 && (n >> D0) >= 1 && (n >> D0) * 4 <= 256) return D0;   // 4 signals x n' fetched by 256 threads
     }
     return -1;
 }
@@ -316,7 +321,7 @@ int wx_acwpd_fused_depth(int64_t n, int L, int F)
 int wx_dev_acwpd_subtree_moments(const double *top, double *sum, double *sumsq, int64_t n, int L, int D0,
                                  int64_t batch, const WxAcFilt &ac, int accumulate, hipStream_t st)
 {
-    constexpr int G = 8;
+    constexpr int G = 4;
     int log2n = 0;
     while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
     const int LP = L - D0;
@@ -324,7 +329,6 @@ int wx_dev_acwpd_subtree_moments(const double *top, double *sum, double *sumsq, 
     int szA = np, szB = 0;
     for (int j = 1; j < LP; ++j) { const int c = np << j; if (j & 1) { if (c > szB) szB = c; } else if (c > szA) szA = c; }
     size_t lds = ((size_t)G * (szA + szB) + 2 * 6 * 2 * 10 + 8) * sizeof(double);   // + tap table
-    if (lds < (size_t)4 * 512 * sizeof(double)) lds = (size_t)4 * 512 * sizeof(double);   // final reduction
     const int ncols_top = (1 << (D0 + 1)) - 1;
     const unsigned grid = 1u << (2 * D0);
     typedef void (*kern_t)(const double *, double *, double *, int, int, int, int64_t, WxAcFilt, int);
@@ -343,7 +347,7 @@ int wx_dev_acwpd_subtree_moments(const double *top, double *sum, double *sumsq, 
     if (lds > 64 * 1024)
         WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, top, sum, sumsq, log2n, D0, ncols_top, batch, ac, accumulate);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, top, sum, sumsq, log2n, D0, ncols_top, batch, ac, accumulate);
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
