@@ -158,13 +158,15 @@ template int wx_dev_jbb_costs2d<float>(const float *, const float *, int64_t, in
 // ------------------------------------------------------------------------------------------
 struct WxFoldTap { double B; int off; int pad; };
 
+constexpr int WX_AC_PLANE = 768;      // positions per signal-pair plane: the two largest levels, 512 + 256
+
 template <int LP, int G, int NL>
 __global__ __launch_bounds__(256) void k_acwpd_subtree_moments(const double *__restrict__ top, double *__restrict__ sum,
                                                                double *__restrict__ sumsq, int log2n, int D0,
                                                                int ncols_top, int64_t batch, WxAcFilt ac,
                                                                int accumulate)
 {
-    static_assert(G == 4, "the LDS layout interleaves 4 signals (two 16-byte reads per position)");
+    static_assert(G == 4, "the LDS layout holds two planes of signal pairs");
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     constexpr int NT = 256;
     const int n = 1 << log2n;
@@ -173,18 +175,19 @@ __global__ __launch_bounds__(256) void k_acwpd_subtree_moments(const double *__r
     const int q = blockIdx.x >> D0;               // node of depth D0
     const int r = blockIdx.x & ((1 << D0) - 1);   // residue class
     const int tid = threadIdx.x;
-    // level buffers: even levels in bufA, odd in bufB; element (position e of the level, signal g of the
-    // group) lives at [e * G + g]: a thread reads the G signals of a position as 2 x 16 bytes with one
-    // address, consecutive items read consecutive 32-byte chunks (conflict free)
+    // LDS: plane 0 holds signals (0,1) of the group as one double2 per position, plane 1 signals (2,3) at the
+    // fixed distance WX_AC_PLANE, so a thread reads the 4 signals of a position with one address (16-byte
+    // reads, the second through the immediate offset) and consecutive items read consecutive 16 bytes:
+    // conflict free.  Within a plane, even levels live at [0, szA), odd levels at [szA, szA + szB).
     int szA = np, szB = 0;
     for (int j = 1; j < LP; ++j) { const int c = np << j; if (j & 1) { if (c > szB) szB = c; } else if (c > szA) szA = c; }
-    double *bufA = reinterpret_cast<double *>(wx_smem);
-    double *bufB = bufA + (size_t)G * szA;
+    double2 *bufA = reinterpret_cast<double2 *>(wx_smem);
+    double2 *bufB = bufA + szA;
     // Tap table per level as LDS broadcasts (the tap loop stays rolled: unrolling it lets the scheduler
     // hoist every window load and spill).  At level j the sub-signal splits into classes of M = n' >> j
     // samples and only odd lags are non-zero, so when M/2 <= 2 NL the +-lags alias onto the M/2 odd
     // residues mod M and the periodised filter has M/2 taps (sums of the b_l that alias) instead of 2 NL.
-    WxFoldTap *ft = reinterpret_cast<WxFoldTap *>(bufB + (size_t)G * szB);
+    WxFoldTap *ft = reinterpret_cast<WxFoldTap *>(bufA + 2 * WX_AC_PLANE);
     int *fT = reinterpret_cast<int *>(ft + LP * 2 * NL);
     if (tid < LP * 2 * NL) {
         const int j = tid / (2 * NL), k = tid - j * (2 * NL);
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void k_acwpd_subtree_moments(const double *__r
             if (k == 0) fT[j] = 2 * NL;
         }
         ft[tid].B = B;
-        ft[tid].off = ((rho << j) & (np - 1)) * G;                   // in doubles of the interleaved layout
+        ft[tid].off = (rho << j) & (np - 1);
         ft[tid].pad = 0;
     }
     const double c1 = ac.c1;
@@ -226,10 +229,10 @@ __global__ __launch_bounds__(256) void k_acwpd_subtree_moments(const double *__r
     const int fe_g = tid >> lnp, fe_i = tid & (np - 1);
     const bool fetcher = tid < G * np;                               // G * np <= 256 (see wx_acwpd_fused_depth)
     const double *fsrc = top + colq * n + r + ((int64_t)fe_i << D0);
+    double *fdst = reinterpret_cast<double *>(bufA + (fe_g >> 1) * WX_AC_PLANE + fe_i) + (fe_g & 1);
     double pre = (fetcher && fe_g < batch) ? fsrc[fe_g * sig_stride] : 0.0;
-    const int posmask = (np - 1) * G;                                // wraps the position, keeps the signal lane
     for (int64_t sig0 = 0; sig0 < batch; sig0 += G) {
-        if (fetcher) bufA[(size_t)fe_i * G + fe_g] = pre;
+        if (fetcher) *fdst = pre;
         __syncthreads();
         {   // next group's samples travel while this group is processed
             const int64_t gn = sig0 + G + fe_g;
@@ -237,8 +240,8 @@ __global__ __launch_bounds__(256) void k_acwpd_subtree_moments(const double *__r
         }
 #pragma unroll
         for (int j = 0; j < LP; ++j) {
-            const double *cur = (j & 1) ? bufB : bufA;
-            double *nxt = (j & 1) ? bufA : bufB;
+            const double2 *cur = (j & 1) ? bufB : bufA;
+            double2 *nxt = (j & 1) ? bufA : bufB;
             const int cnt = np << j;                                  // items of this level
             const WxFoldTap *tp = ft + j * 2 * NL;
             const int T = __builtin_amdgcn_readfirstlane(fT[j]);
@@ -247,31 +250,35 @@ __global__ __launch_bounds__(256) void k_acwpd_subtree_moments(const double *__r
                 const int item = tid + h * NT;
                 const int aj = j + h;
                 if (item < cnt) {
-                    const int p = item >> lnp, iG = (item & (np - 1)) * G;
-                    const double *v = cur + ((size_t)p << lnp) * G;
-                    double S[G];
-#pragma unroll
-                    for (int c = 0; c < G; ++c) S[c] = 0.0;
+                    const int p = item >> lnp, i = item & (np - 1);
+                    const double2 *v = cur + ((size_t)p << lnp);
+                    double S0 = 0.0, S1 = 0.0, S2 = 0.0, S3 = 0.0;
 #pragma unroll 1
                     for (int l = 0; l < T; ++l) {
                         const double bt = tp[l].B;
-                        const double *xv = v + ((iG + tp[l].off) & posmask);
-#pragma unroll
-                        for (int c = 0; c < G; ++c) S[c] = fma(bt, xv[c], S[c]);
+                        const double2 *xv = v + ((i + tp[l].off) & (np - 1));
+                        const double2 x01 = xv[0], x23 = xv[WX_AC_PLANE];
+                        S0 = fma(bt, x01.x, S0); S1 = fma(bt, x01.y, S1);
+                        S2 = fma(bt, x23.x, S2); S3 = fma(bt, x23.y, S3);
                     }
-                    const double *xc = v + iG;
-                    double *olo = nxt + (((size_t)(2 * p)) << lnp) * G + iG;
-                    double *ohi = olo + ((size_t)G << lnp);
+                    const double2 c01 = v[i], c23 = v[i + WX_AC_PLANE];
                     double a0 = acc[aj][0], a1 = acc[aj][1], a2 = acc[aj][2], a3 = acc[aj][3];
+                    double lo[4], hi[4];
+                    const double cc[4] = {c1 * c01.x, c1 * c01.y, c1 * c23.x, c1 * c23.y};
+                    const double SS[4] = {S0, S1, S2, S3};
 #pragma unroll
-                    for (int c = 0; c < G; ++c) {
-                        const double cc = c1 * xc[c];
-                        const double lo = cc + S[c], hi = cc - S[c];
-                        a0 += lo; a1 = fma(lo, lo, a1);
-                        a2 += hi; a3 = fma(hi, hi, a3);
-                        if (j + 1 < LP) { olo[c] = lo; ohi[c] = hi; }
+                    for (int c = 0; c < 4; ++c) {
+                        lo[c] = cc[c] + SS[c]; hi[c] = cc[c] - SS[c];
+                        a0 += lo[c]; a1 = fma(lo[c], lo[c], a1);
+                        a2 += hi[c]; a3 = fma(hi[c], hi[c], a3);
                     }
                     acc[aj][0] = a0; acc[aj][1] = a1; acc[aj][2] = a2; acc[aj][3] = a3;
+                    if (j + 1 < LP) {
+                        double2 *olo = nxt + (((size_t)(2 * p)) << lnp) + i;
+                        double2 *ohi = olo + np;
+                        olo[0] = make_double2(lo[0], lo[1]); olo[WX_AC_PLANE] = make_double2(lo[2], lo[3]);
+                        ohi[0] = make_double2(hi[0], hi[1]); ohi[WX_AC_PLANE] = make_double2(hi[2], hi[3]);
+                    }
                 }
             }
             __syncthreads();
@@ -328,7 +335,7 @@ int wx_dev_acwpd_subtree_moments(const double *top, double *sum, double *sumsq, 
     const int np = (int)(n >> D0);
     int szA = np, szB = 0;
     for (int j = 1; j < LP; ++j) { const int c = np << j; if (j & 1) { if (c > szB) szB = c; } else if (c > szA) szA = c; }
-    size_t lds = ((size_t)G * (szA + szB) + 2 * 6 * 2 * 10 + 8) * sizeof(double);   // + tap table
+    size_t lds = ((size_t)2 * 768 * 2 + 2 * 6 * 2 * 10 + 8) * sizeof(double);   // two signal-pair planes + tap table
     const int ncols_top = (1 << (D0 + 1)) - 1;
     const unsigned grid = 1u << (2 * D0);
     typedef void (*kern_t)(const double *, double *, double *, int, int, int, int64_t, WxAcFilt, int);
