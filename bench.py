@@ -31,19 +31,25 @@ FP64_PEAK_TFLOPS = 78.6        # FP64 vector spec; tools/ubench.hip 
 WORKLOADS = {
     "cfg2": dict(kind="wpd", n=4096, batch=65536, wavelet="db8", L=12, dtype="f64",
                  kernel="k_fwd1d_fused<double, 16, 512, true, 2>",
+                 fwd_kernels=[("k_fwd1d_fused<double, 16, 512, true, 2>", 1)],
                  desc="BASELINE config 2: wpdall+iwpdall 65536x4096 f64 db8 full tree L=12"),
     "target": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=10, dtype="f64",
                    kernel="k_fwd1d_inplace<double, 8, 256, false>",
+                   fwd_kernels=[("k_fwd1d_inplace<double, 8, 256, false>", 1)],
                    desc="north-star target: wptall+iwptall 65536x4096 f64 db4 L=10"),
     "cfg3": dict(kind="swpt", n=16384, batch=64, wavelet="haar", L=12, dtype="f64",
-                 kernel="k_swt_fwd_multi<double, 8>",
+                 kernel="k_swt_fwd_multi_rc<double, 8, 8>",
+                 fwd_kernels=[("k_swt_fwd_multi<double, 8>", 2), ("k_swt_fwd_multi_rc<double, 8, 8>", 2)],
                  desc="BASELINE config 3: swptall+iswptall (average-based) 16384-sample f64 haar L=12; one resident "
                       "chunk of 64 signals (32 GiB of leaves) of the 8192-signal batch per step"),
     "cfg4": dict(kind="wpt2d", m=512, n=512, batch=512, wavelet="db4", L=6, dtype="f32",
                  kernel="k_rows_fused<float, 8, false>",
+                 fwd_kernels=[("k_fwd1d_inplace<float, 8, 64, false>", 1), ("k_rows_fused<float, 8, false>", 1)],
                  desc="BASELINE config 4: 2-D wptall+iwptall 512x512 f32 db4 L=6, 512 images per GPU (4096 / 8)"),
     "cfg5": dict(kind="acwpd_jbb", n=2048, batch=2048, wavelet="coif6", L=11, dtype="f64",
-                 kernel="k_acwpd_subtree_moments<5, 8, 9>",
+                 kernel="k_acwpd_subtree_moments<5, 4, 9>",
+                 fwd_kernels=[("k_swt_fwd_level<double, true>", 6), ("k_jbb_moments<double>", 1),
+                              ("k_acwpd_subtree_moments<5, 4, 9>", 1), ("k_jbb_costs<double>", 1)],
                  desc="BASELINE config 5: acwpd + JBB moments/costs/tree 2048-sample f64 coif6 L=11; 2048-signal slice "
                       "of the 32768-signal per-GPU shard per step (no inverse: output is the tree)"),
 }
@@ -305,13 +311,14 @@ def main():
 
     out = None
     if rank == 0:
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
-        # command (profiles/traffic.json, written by tools/summarize_prof.py); null if not profiled.
+        # HBM traffic of one forward pass = sum over its kernels (launches per pass x PMC bytes per launch)
+        # from separate rocprofv3 --pmc passes of this same command (profiles/traffic.json, written by
+        # tools/collect_evidence.py); null if not profiled.  `kernel` names the dominant one.
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(a.workload, {})
             if not a.batch:
-                traffic = tj.get(a.workload, {}).get(w["kernel"], {}).get("hbm_bytes_per_launch")
+                traffic = sum(cnt * tj[name]["hbm_bytes_per_launch"] for name, cnt in w["fwd_kernels"])
         except Exception:
             traffic = None
         fb = float(info["fwd_bytes"])

@@ -25,6 +25,10 @@ int wx_tree_depth2d(const uint8_t *tree, int64_t ntree);
 // leaf depth of each block of n>>Leff positions (getbasiscoef traversal, Utils.jl:117-131)
 void wx_leaf_colmap1d(const uint8_t *tree, int64_t ntree, int Leff, std::vector<int> &col);
 
+// Small immutable tables (composite taps, ...) live in a per-device cache keyed by their content: uploaded
+// once with a blocking copy, reused by every later call, released by wx_shutdown().  nullptr on failure.
+const void *wx_const_upload(const void *host, size_t bytes);
+
 // Stream-ordered device scratch that frees itself on the same stream.
 struct WxScratch {
     hipStream_t st;

@@ -140,13 +140,60 @@ static void wx_retain_pool()
     if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr) != hipSuccess) (void)hipGetLastError();
 }
 
-// hand the cached scratch of the current device back to the driver (the only state the library owns)
+// ---- per-device cache of small constant tables -------------------------------------------------
+#include <map>
+#include <string>
+namespace {
+std::mutex g_const_mu;
+std::map<std::pair<int, std::string>, void *> g_const;
+std::vector<void *> g_const_old;                                    // previous generation, freed at the next flush
+}
+const void *wx_const_upload(const void *host, size_t bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::pair<int, std::string> key(dev, std::string(reinterpret_cast<const char *>(host), bytes));
+    std::lock_guard<std::mutex> lk(g_const_mu);
+    auto it = g_const.find(key);
+    if (it != g_const.end()) return it->second;
+    if (g_const.size() >= 1024) {
+        // bounded: start over.  Pointers handed out during the current API call must stay valid, so the
+        // retired generation is only freed at the following flush (no call uploads 1024 tables).
+        if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+        for (void *q : g_const_old) if (hipFree(q) != hipSuccess) (void)hipGetLastError();
+        g_const_old.clear();
+        for (auto &e : g_const) g_const_old.push_back(e.second);
+        g_const.clear();
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) { wx_set_hip_error(e, "hipMalloc(constant table)", __FILE__, __LINE__); return nullptr; }
+    e = hipMemcpy(p, host, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { wx_set_hip_error(e, "hipMemcpy(constant table)", __FILE__, __LINE__); (void)hipFree(p); return nullptr; }
+    g_const.emplace(std::move(key), p);
+    return p;
+}
+
+// hand the cached scratch and constant tables of the current device back to the driver (the only state
+// the library owns)
 extern "C" int wx_shutdown(void)
 {
     int dev = 0, n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void)hipGetLastError(); return WX_OK; }
     WX_HIP_CHECK(hipGetDevice(&dev));
     WX_HIP_CHECK(hipDeviceSynchronize());
+    {
+        std::lock_guard<std::mutex> lk(g_const_mu);
+        for (auto it = g_const.begin(); it != g_const.end();) {
+            if (it->first.first == dev) { if (hipFree(it->second) != hipSuccess) (void)hipGetLastError(); it = g_const.erase(it); }
+            else ++it;
+        }
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev == 1) {   // retired tables carry no device tag
+            for (void *q : g_const_old) if (hipFree(q) != hipSuccess) (void)hipGetLastError();
+            g_const_old.clear();
+        }
+    }
     hipMemPool_t pool;
     WX_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, dev));
     WX_HIP_CHECK(hipMemPoolTrimTo(pool, 0));
@@ -165,6 +212,9 @@ void *WxScratch::alloc(size_t bytes)
 }
 void *WxScratch::upload(const void *host, size_t bytes)
 {
+    // trees and column maps are small and repeat from call to call: the content-keyed cache makes the
+    // upload a lookup (no allocation, no stream synchronisation)
+    if (bytes > 0 && bytes <= 64 * 1024) return const_cast<void *>(wx_const_upload(host, bytes));
     void *p = alloc(bytes);
     if (!p) return nullptr;
     hipError_t e = hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, st);

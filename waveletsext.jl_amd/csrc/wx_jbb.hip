@@ -172,8 +172,13 @@ __global__ __launch_bounds__(256) void k_acwpd_subtree_moments(const double *__r
     const int n = 1 << log2n;
     const int lnp = log2n - D0;                   // log2 of the sub-signal length n'
     const int np = 1 << lnp;
-    const int q = blockIdx.x >> D0;               // node of depth D0
-    const int r = blockIdx.x & ((1 << D0) - 1);   // residue class
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, and the 2^D0 residue classes of one
+    // node read the same cache lines of the top table (8 bytes out of every 2^D0 * 8), so consecutive logical
+    // ids (same node) are mapped to the same XCD / L2 instead of being spread over all eight
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int q = bid >> D0;                      // node of depth D0
+    const int r = bid & ((1 << D0) - 1);          // residue class
     const int tid = threadIdx.x;
     // LDS: plane 0 holds signals (0,1) of the group as one double2 per position, plane 1 signals (2,3) at the
     // fixed distance WX_AC_PLANE, so a thread reads the 4 signals of a position with one address (16-byte

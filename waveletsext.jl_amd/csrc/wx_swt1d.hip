@@ -23,6 +23,7 @@
 // causes bank conflicts.
 #include "wx_common.h"
 #include "wx_kernels.h"
+#include "wx_host.h"
 #include <cstdlib>
 #include <map>
 #include <vector>
@@ -510,7 +511,6 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
     const int KF = (!ac && layout == WX_LAYOUT_WPT && !wx_force_generic_swt()) ? (filt.F <= 4 ? 3 : (filt.F <= 16 ? 2 : 1)) : 1;
     double *dcoef = nullptr;
     int *dshift = nullptr;
-    std::vector<void *> frees;
     int d = 0;
     while (d < L) {
         const int K = (KF > 1 && L - d >= 2) ? (L - d >= KF ? KF : L - d) : 1;
@@ -551,14 +551,9 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
                 shift[t] = (int)o;
             }
         }
-        void *p1 = nullptr, *p2 = nullptr;
-        WX_HIP_CHECK(hipMallocAsync(&p1, coef.size() * sizeof(double), st));
-        WX_HIP_CHECK(hipMallocAsync(&p2, shift.size() * sizeof(int), st));
-        frees.push_back(p1); frees.push_back(p2);
-        WX_HIP_CHECK(hipMemcpyAsync(p1, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, st));
-        WX_HIP_CHECK(hipMemcpyAsync(p2, shift.data(), shift.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        WX_HIP_CHECK(hipStreamSynchronize(st));                  // host tables go out of scope
-        dcoef = (double *)p1; dshift = (int *)p2;
+        dcoef = (double *)wx_const_upload(coef.data(), coef.size() * sizeof(double));
+        dshift = (int *)wx_const_upload(shift.data(), shift.size() * sizeof(int));
+        if (!dcoef || !dshift) return WX_EHIP;
         if (Rrc) {
             const int64_t tile = (n >> d) * Rrc;
             int NT = 512;
@@ -583,7 +578,6 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
                            (const double *)dcoef, (const int *)dshift, U);
         d += K;
     }
-    for (void *p : frees) if (hipFreeAsync(p, st) != hipSuccess) (void)hipGetLastError();
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
@@ -661,7 +655,6 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
     sd[0] = 0;
     if (sm >= 0) { int64_t acc = 0; for (int d = 0; d < L; ++d) { acc += ((sm >> d) & 1) << d; sd[d + 1] = acc; } }
     T *bufs[2] = {scratch0, scratch1};
-    std::vector<void *> frees;
     double *dcoef[16] = {nullptr};                       // padded tap tables per (K, rows-per-thread)
     int Utab[16] = {0};
     int omin[16] = {0};
@@ -694,12 +687,8 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
                 for (int c = 0; c < NCk; ++c)
                     for (int t = 0; t < U; ++t)
                         pad[(size_t)c * UP + (OPT - 1) + t] = coef[(size_t)c * U + (U - 1 - t)] * (K == 2 ? 0.25 : 0.125);
-                void *p1 = nullptr;
-                WX_HIP_CHECK(hipMallocAsync(&p1, pad.size() * sizeof(double), st));
-                frees.push_back(p1);
-                WX_HIP_CHECK(hipMemcpyAsync(p1, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice, st));
-                WX_HIP_CHECK(hipStreamSynchronize(st));      // host table goes out of scope
-                dcoef[slot] = (double *)p1;
+                dcoef[slot] = (double *)wx_const_upload(pad.data(), pad.size() * sizeof(double));
+                if (!dcoef[slot]) return WX_EHIP;
                 Utab[slot] = U;
                 omin[slot] = -offs[U - 1];                   // smallest offset of the adjoint taps
             }
@@ -736,7 +725,6 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
         prev = plan.buf[i] < 0 ? nullptr : outp;
         prev_cols = out_cols;
     }
-    for (void *p : frees) if (hipFreeAsync(p, st) != hipSuccess) (void)hipGetLastError();
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
