@@ -52,6 +52,11 @@ WORKLOADS = {
                               ("k_acwpd_subtree_moments<5, 4, 9>", 1), ("k_jbb_costs<double>", 1)],
                  desc="BASELINE config 5: acwpd + JBB moments/costs/tree 2048-sample f64 coif6 L=11; 2048-signal slice "
                       "of the 32768-signal per-GPU shard per step (no inverse: output is the tree)"),
+    "bb": dict(kind="wpd_bb", n=4096, batch=16384, wavelet="db8", L=12, dtype="f64",
+               kernel="k_bb_costs1d<double>",
+               fwd_kernels=[("k_bb_norms<double>", 1), ("k_bb_costs1d<double>", 1), ("k_bb_treeselect<double, 2>", 1)],
+               desc="SURVEY 8(f) row 3: per-signal best basis, bestbasistreeall(wpdall(x), BB()) 16384x4096 f64 db8 L=12; "
+                    "timed leg = Shannon costs + tree selection over the resident 6.5 GiB table (wpdall is the other leg)"),
 }
 
 
@@ -123,6 +128,15 @@ def cpu_baseline(w, seconds):
             dt = time.perf_counter() - t0
             assert np.abs(xr - x[:, :, B - 1]).max() < 1e-3
             return dt, B * m * n
+        if kind == "wpd_bb":
+            n = w["n"]
+            x = rng.standard_normal((n, B))
+            t0 = time.perf_counter()
+            X = np.asfortranarray(np.stack([wo.wpd(x[:, i], q, L) for i in range(B)], axis=-1))
+            trees = wo.bestbasistreeall_bb(X)
+            dt = time.perf_counter() - t0
+            assert trees.shape == (n - 1, B)
+            return dt, B * n
         if kind == "acwpd_jbb":
             n = w["n"]
             x = rng.standard_normal((n, B))
@@ -221,6 +235,30 @@ def make_workload(w, wx, torch, dev, rank):
         check = lambda: float((xh - x).abs().max() / x.abs().max())
         return fwd, inv, check, dict(fwd_bytes=fb, inv_bytes=fb, fwd_flops=L * 2.0 * (2 * F * m * n) * B,
                                      samples=m * n * B, bound="hbm", keep=(x, y, xh))
+    if kind == "wpd_bb":
+        from waveletsext_jl_amd import bestbasis as bbm
+        n = w["n"]
+        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
+        xw = wx.jl_empty((n, L + 1, B), td, dev)
+        qq, qp, Fq = qmf_arg(wt)
+        state = {}
+        method = wx.BB()
+
+        def inv():      # the transform leg (named inv only because the harness times two legs)
+            D._call("wx_wpd1d", "_f64", A(x).ptr, A(xw).ptr, n, L, B, qp, Fq, A(x).stream())
+
+        def fwd():      # the best-basis leg: costs of every node of every signal + all trees, on the device
+            costs = bbm._bb_costs(A(xw), method, True)
+            state["trees"] = bbm._bb_trees(costs, (n,), B)
+
+        inv()
+
+        def check():
+            t = state["trees"][:4].cpu().numpy().astype(bool)
+            return 0.0 if all(wx.isvalidtree(torch.empty(n), t[i]) for i in range(4)) else 1.0
+        ncost = (1 << (L + 1)) - 1
+        return fwd, inv, check, dict(fwd_bytes=es * (n * (L + 1) + ncost) * B + (n - 1) * B, inv_bytes=es * n * (L + 2) * B,
+                                     fwd_flops=4.0 * n * (L + 1) * B, samples=n * B, bound="hbm", keep=(x, xw))
     if kind == "acwpd_jbb":
         n = w["n"]
         x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)

@@ -226,6 +226,31 @@ int wx_getbasiscoef2d_f32(const float *Xw, float *out, int64_t m, int64_t n, int
                           int64_t batch, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Standard (per-signal) best basis, BB -- SURVEY 8(f) row 3, widened after the 8(a) rows.
+ * tree_costs(X, BB(cost, redundant)) bestbasis/bestbasis_tree.jl:210-258 with coefcost(x, cost, nrm)
+ * bestbasis/bestbasis_costs.jl:104-125: cost_kind 0 = ShannonEntropyCost, 1 = LogEnergyEntropyCost;
+ * nrm = norm of the signal (first column / slice); the non-redundant 2-D branch normalises every block by
+ * its own norm like the reference (:252).  X (n, k, batch) -> costs (ncost, batch), ncost = k (redundant)
+ * or 2^k - 1; 2-D X (m, n, k, batch), ncost = k or (4^k - 1)/3.
+ * wx_treeselect_batch_*: bestbasis_treeselection (BestBasis.jl:59-110) for every signal at once, i.e. the
+ * loop of bestbasistreeall(X, BB()) (BestBasis.jl:253-262): costs (ncost, batch) are mutated like the
+ * reference, trees (n - 1 | gettreelength(m, n), batch) one byte per node; n = 0 selects the 1-D (binary)
+ * tree of an m-sample signal.  Pointers may be host or device.
+ * ------------------------------------------------------------------------------------------ */
+int wx_bb_costs_f64(const double *X, double *costs, int64_t n, int64_t k, int64_t batch, int redundant, int cost_kind,
+                    void *stream);
+int wx_bb_costs_f32(const float *X, float *costs, int64_t n, int64_t k, int64_t batch, int redundant, int cost_kind,
+                    void *stream);
+int wx_bb_costs2d_f64(const double *X, double *costs, int64_t m, int64_t n, int64_t k, int64_t batch, int redundant,
+                      int cost_kind, void *stream);
+int wx_bb_costs2d_f32(const float *X, float *costs, int64_t m, int64_t n, int64_t k, int64_t batch, int redundant,
+                      int cost_kind, void *stream);
+int wx_treeselect_batch_f64(double *costs, int64_t ncost, int64_t m, int64_t n, int type_max, int64_t batch,
+                            uint8_t *trees, void *stream);
+int wx_treeselect_batch_f32(float *costs, int64_t ncost, int64_t m, int64_t n, int type_max, int64_t batch,
+                            uint8_t *trees, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Multi-GPU exchange (one process per GPU, RCCL over xGMI; bound lazily, single-GPU callers never
  * load RCCL).  Transforms shard over the batch (last) dimension with no collective: the loops
  * dwt/dwt_all.jl:277-279, swt/swt_all.jl:171-173, acwt/acwt_all.jl:254-256 are independent per

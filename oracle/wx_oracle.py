@@ -563,3 +563,34 @@ def bestbasis_treeselection2d(costs, n, m, kind="min"):
 def bestbasistree_jbb2d(X, redundant=False, cost="loglp", p=None):
     X = _f(X)
     return bestbasis_treeselection2d(tree_costs_jbb2d(X, redundant, cost, p), X.shape[0], X.shape[1])
+
+
+# ---- standard (per-signal) best basis, BB -----------------------------------------------------------
+def tree_costs_bb(X, redundant=False, cost="shannon"):
+    """tree_costs(X, BB(cost, redundant)) bestbasis_tree.jl:209-258; X is (n, L) or (n, m, L)."""
+    X = _f(X)
+    kind = _I(0 if cost == "shannon" else 1)
+    if X.ndim == 2:
+        n, L = X.shape
+        costs = np.empty(L if redundant else (1 << L) - 1, X.dtype)
+        _chk(_call("wxo_tree_costs_bb", X.dtype, _p(costs), _p(X), n, L, _I(int(redundant)), kind))
+    else:
+        n, m, L = X.shape
+        costs = np.empty(L if redundant else ((1 << (2 * L)) - 1) // 3, X.dtype)
+        _chk(_call("wxo_tree_costs_bb2d", X.dtype, _p(costs), _p(X), n, m, L, _I(int(redundant)), kind))
+    return costs
+
+
+def bestbasistree_bb(X, redundant=False, cost="shannon"):
+    """bestbasistree(X, BB(...)) BestBasis.jl:203-210"""
+    X = _f(X)
+    c = tree_costs_bb(X, redundant, cost)
+    if X.ndim == 2:
+        return bestbasis_treeselection(c, X.shape[0])
+    return bestbasis_treeselection2d(c, X.shape[0], X.shape[1])
+
+
+def bestbasistreeall_bb(X, redundant=False, cost="shannon"):
+    """bestbasistreeall(X, BB(...)) BestBasis.jl:253-262: (tree length, k) BitMatrix"""
+    X = _f(X)
+    return np.stack([bestbasistree_bb(np.asfortranarray(X[..., i]), redundant, cost) for i in range(X.shape[-1])], axis=1)

@@ -1191,6 +1191,85 @@ int FN(wxo_bestbasis_treeselection)(uint8_t *tree, T *costs, int64_t k, int64_t 
     return wxo_isvalidtree1d(n, tree, ntree) ? 0 : -1;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Standard (per-signal) best basis, BB: bestbasis/bestbasis_costs.jl:94-121  */
+/* coefcost(x, ::ShannonEntropyCost | ::LogEnergyEntropyCost, nrm) and        */
+/* bestbasis/bestbasis_tree.jl:209-258 tree_costs(X, ::BB).                   */
+/* cost_kind 0 = ShannonEntropyCost, 1 = LogEnergyEntropyCost.                */
+/* norm(x) is restated as sqrt(sum x^2) accumulated in T (Julia dispatches    */
+/* to BLAS nrm2 / generic_norm2: rounding-level differences, parity unpinned).*/
+/* ------------------------------------------------------------------------- */
+static T FN(wxo_norm2)(const T *x, int64_t n)
+{
+    T acc = 0;
+    for (int64_t i = 0; i < n; i++) acc = (T)(acc + (T)(x[i] * x[i]));
+    return (T)sqrt((double)acc);
+}
+static T FN(wxo_coefcost_bb)(const T *x, int64_t n, int cost_kind, T nrm)
+{
+    T sum = 0;
+    if (nrm == sum) return sum;                                 /* bestbasis_costs.jl:115 */
+    for (int64_t i = 0; i < n; i++) {
+        T r = (T)(x[i] / nrm);
+        T s = (T)(r * r);
+        T c;
+        if (s == 0) c = (T)(-0.0);
+        else if (cost_kind == 0) c = (T)(-(T)(s * (T)log((double)s)));
+        else c = (T)(-(T)log((double)s));
+        sum = (T)(sum + c);
+    }
+    return sum;
+}
+
+/* tree_costs(X::Array{T,2}, ::BB) bestbasis_tree.jl:209-233; X is (n, L) */
+int FN(wxo_tree_costs_bb)(T *costs, const T *X, int64_t n, int64_t L, int redundant, int cost_kind)
+{
+    T nrm = FN(wxo_norm2)(X, n);
+    if (redundant) {
+        for (int64_t i = 1; i <= L; i++) {
+            int j = wxo_getdepth_binary(i);
+            costs[i - 1] = (T)(FN(wxo_coefcost_bb)(X + (i - 1) * n, n, cost_kind, nrm) / (T)((int64_t)1 << j));
+        }
+    } else {
+        int64_t i = 1;
+        for (int64_t lvl = 0; lvl <= L - 1; lvl++) {
+            int64_t n0 = n >> lvl;
+            for (int64_t node = 0; node <= ((int64_t)1 << lvl) - 1; node++) {
+                costs[i - 1] = FN(wxo_coefcost_bb)(X + lvl * n + node * n0, n0, cost_kind, nrm);
+                i++;
+            }
+        }
+    }
+    return 0;
+}
+
+/* tree_costs(X::Array{T,3}, ::BB) bestbasis_tree.jl:235-258; X is (n, m, L).  The non-redundant branch
+ * calls coefcost without nrm (:253), so every block is normalised by its own norm. */
+int FN(wxo_tree_costs_bb2d)(T *costs, const T *X, int64_t n, int64_t m, int64_t L, int redundant, int cost_kind)
+{
+    if (redundant) {
+        T nrm = FN(wxo_norm2)(X, n * m);
+        for (int64_t i = 1; i <= L; i++) {
+            int d = wxo_getdepth_quad(i);
+            costs[i - 1] = (T)(FN(wxo_coefcost_bb)(X + (i - 1) * n * m, n * m, cost_kind, nrm) / (T)((int64_t)1 << (2 * d)));
+        }
+    } else {
+        int64_t nc = ((((int64_t)1 << (2 * L)) - 1) / 3);
+        T *blk = (T *)malloc(sizeof(T) * n * m);
+        for (int64_t i = 1; i <= nc; i++) {
+            int d = wxo_getdepth_quad(i);
+            int64_t r0, r1, c0, c1;
+            wxo_getrowrange(n, i, &r0, &r1); wxo_getcolrange(m, i, &c0, &c1);
+            int64_t cnt = 0;
+            for (int64_t c = c0; c <= c1; c++)
+                for (int64_t r = r0; r <= r1; r++) blk[cnt++] = M2(X + (int64_t)d * n * m, n, r, c);
+            costs[i - 1] = FN(wxo_coefcost_bb)(blk, cnt, cost_kind, FN(wxo_norm2)(blk, cnt));
+        }
+        free(blk);
+    }
+    return 0;
+}
+
 #undef T
 #undef FN
 #undef V1

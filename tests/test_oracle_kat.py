@@ -317,3 +317,46 @@ def test_jbb_tree_is_valid_and_costs_shape(oracle, wx):
     assert oracle.isvalidtree1d(16, oracle.bestbasistree_jbb(xacw, redundant=True))
     with pytest.raises(AssertionError):                    # test/bestbasis.jl:44 (n=3 -> k too long)
         oracle.bestbasis_treeselection(rng.standard_normal(7), 3)
+
+
+def test_bb_costs_and_trees_oracle(oracle):
+    """standard best basis (bestbasis_tree.jl:210-258, bestbasis_costs.jl:104-125): closed forms.  The
+    reference's own tests only assert isvalidtree (test/bestbasis.jl:13-19) -> parity of the BB trees is
+    pinned by this restatement, like JBB."""
+    import numpy as np
+    q = np.array([1.0, 1.0]) / np.sqrt(2.0)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(16)
+    X = oracle.wpd(x, q, 4)
+    c = oracle.tree_costs_bb(X)
+    nrm = np.linalg.norm(x)
+    i = 0
+    for lvl in range(5):
+        n0 = 16 >> lvl
+        for node in range(1 << lvl):
+            s = (X[node * n0:(node + 1) * n0, lvl] / nrm) ** 2
+            assert abs(c[i] - (-(s * np.log(s)).sum())) <= 1e-12
+            i += 1
+    cl = oracle.tree_costs_bb(X, cost="logenergy")
+    assert abs(cl[0] - (-np.log((x / nrm) ** 2).sum())) <= 1e-10
+    # a unit impulse is sparsest at the root: entropy 0 there, > 0 after a Haar step -> the tree is empty
+    e = np.zeros(8); e[3] = 1.0
+    assert not oracle.bestbasistree_bb(oracle.wpd(e, q, 3)).any()
+    # a zero signal has nrm == 0 -> all costs 0 (bestbasis_costs.jl:119), nothing beats the parent
+    assert (oracle.tree_costs_bb(np.zeros((8, 4))) == 0).all()
+    # redundant: node i divided by 2^depth
+    Xs = oracle.swpd(x, q, 2)
+    cr = oracle.tree_costs_bb(Xs, True)
+    s3 = (Xs[:, 2] / nrm) ** 2
+    assert abs(cr[2] - (-(s3 * np.log(s3)).sum()) / 2) <= 1e-12
+    # 2-D non-redundant: every block normalised by its own norm (bestbasis_tree.jl:252)
+    img = rng.standard_normal((4, 4))
+    Xi = np.asfortranarray(np.stack([img, img], axis=2))
+    c2 = oracle.tree_costs_bb(Xi)
+    s = (img / np.linalg.norm(img)) ** 2
+    assert abs(c2[0] - (-(s * np.log(s)).sum())) <= 1e-12
+    blk = img[:2, 2:]                                   # node 3 = top-right
+    s = (blk / np.linalg.norm(blk)) ** 2
+    assert abs(c2[2] - (-(s * np.log(s)).sum())) <= 1e-12
+    trees = oracle.bestbasistreeall_bb(np.asfortranarray(np.stack([X, X], axis=2)))
+    assert trees.shape == (15, 2) and (trees[:, 0] == trees[:, 1]).all()

@@ -7,7 +7,7 @@ TAG=$1
 mkdir -p $R/gpurun_out/bench_$TAG
 cd $R
 timeout 900 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu_$TAG.log 2>&1; tail -2 gpurun_out/pytest_gpu_$TAG.log
-for w in cfg2 target cfg3 cfg4 cfg5; do
+for w in cfg2 target cfg3 cfg4 cfg5 bb; do
   timeout 600 python bench.py --workload $w > gpurun_out/bench_$TAG/$w.json 2> gpurun_out/bench_$TAG/$w.err
   tail -c 300 gpurun_out/bench_$TAG/$w.json; echo
   bash tools/profile.sh $TAG $w pmc > /dev/null 2>&1

@@ -16,6 +16,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     return name.replace("void ", "")[:90]
 

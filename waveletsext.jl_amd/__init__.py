@@ -22,4 +22,5 @@ from .acwt import (acdwt, acdwt_, acdwtall, iacdwt, iacdwt_, iacdwtall, acwpt, a
                    iacwpt, iacwpt_, iacwptall, acwpd, acwpd_, acwpdall, iacwpd, iacwpd_, iacwpdall,
                    autocorr, pfilter, qfilter, make_acqmfpair, make_acreverseqmfpair)
 from .bestbasis import (JBB, LoglpCost, NormCost, tree_costs, bestbasistree, bestbasis_treeselection,   # noqa: F401
-                        jbb_moments, costs_from_moments, acwpd_jbb_moments)
+                        jbb_moments, costs_from_moments, acwpd_jbb_moments,
+                        BB, ShannonEntropyCost, LogEnergyEntropyCost, bestbasistreeall)

@@ -110,6 +110,12 @@ _PLAIN_SIGS = {
     "wx_treeselect2d_f64": [_P, _L, _L, _L, _I, _P],
     "wx_treeselect2d_f32": [_P, _L, _L, _L, _I, _P],
     "wx_shutdown": [],
+    "wx_bb_costs_f64": [_P, _P, _L, _L, _L, _I, _I, _P],
+    "wx_bb_costs_f32": [_P, _P, _L, _L, _L, _I, _I, _P],
+    "wx_bb_costs2d_f64": [_P, _P, _L, _L, _L, _L, _I, _I, _P],
+    "wx_bb_costs2d_f32": [_P, _P, _L, _L, _L, _L, _I, _I, _P],
+    "wx_treeselect_batch_f64": [_P, _L, _L, _L, _I, _L, _P, _P],
+    "wx_treeselect_batch_f32": [_P, _L, _L, _L, _I, _L, _P, _P],
     "wx_comm_unique_id": [_P],
     "wx_comm_init": [_I, _I, _P, ctypes.POINTER(ctypes.c_void_p)],
     "wx_comm_destroy": [_P],

@@ -27,6 +27,24 @@ class NormCost:
         self.p = p
 
 
+class ShannonEntropyCost:
+    """bestbasis_costs.jl:76"""
+
+
+class LogEnergyEntropyCost:
+    """bestbasis_costs.jl:86"""
+
+
+class BB:
+    """Standard (per-signal) best basis, bestbasis_tree.jl:60-63"""
+
+    def __init__(self, cost=None, redundant=False):
+        self.cost = ShannonEntropyCost() if cost is None else cost
+        if not isinstance(self.cost, (ShannonEntropyCost, LogEnergyEntropyCost)):
+            raise TypeError("BB cost must be ShannonEntropyCost or LogEnergyEntropyCost")
+        self.redundant = bool(redundant)
+
+
 class JBB:
     """bestbasis_tree.jl:43-46"""
 
@@ -75,9 +93,63 @@ def costs_from_moments(s, q, Ntot, method=None):
     return costs.arr
 
 
+def _bb_costs(Xa, method, batched):
+    """(ncost[, N]) costs of one signal (n, k) / (n, m, k) or of a batch (..., N) for BB"""
+    nd = Xa.arr.ndim - (1 if batched else 0)
+    assert 2 <= nd <= 3
+    N = Xa.shape[-1] if batched else 1
+    kind = 0 if isinstance(method.cost, ShannonEntropyCost) else 1
+    if nd == 2:
+        n, k = Xa.shape[:2]
+        ncost = k if method.redundant else (1 << k) - 1
+        costs = Xa.new((ncost, N) if batched else (ncost,))
+        _call("wx_bb_costs", Xa.suffix, Xa.ptr, costs.ptr, n, k, N, int(method.redundant), kind, Xa.stream())
+    else:
+        n, m, k = Xa.shape[:3]
+        ncost = k if method.redundant else gettreelength(1 << k, 1 << k)
+        costs = Xa.new((ncost, N) if batched else (ncost,))
+        _call("wx_bb_costs2d", Xa.suffix, Xa.ptr, costs.ptr, n, m, k, N, int(method.redundant), kind, Xa.stream())
+    return costs
+
+
+def _bb_trees(costs, sig, N, kind="min"):
+    """bestbasis_treeselection for every column of costs (ncost, N) on the device -> uint8 (ntree, N)"""
+    ncost = costs.shape[0]
+    ntree = sig[0] - 1 if len(sig) == 1 else gettreelength(*sig)
+    if costs.kind == "torch":
+        import torch
+        trees = torch.empty((N, ntree), dtype=torch.uint8, device=costs.device)
+        tp, st = ctypes.c_void_p(trees.data_ptr()), costs.stream()
+    else:
+        trees = np.empty((N, ntree), dtype=np.uint8)
+        tp, st = ctypes.c_void_p(trees.ctypes.data), ctypes.c_void_p(0)
+    fn = getattr(_lib.lib(), "wx_treeselect_batch" + costs.suffix)
+    _lib.check(fn(costs.ptr, ncost, sig[0], sig[1] if len(sig) == 2 else 0, 0 if kind == "min" else 1, N, tp, st))
+    return trees
+
+
+def bestbasistreeall(X, method=None):
+    """bestbasistreeall(X, BB(...)) BestBasis.jl:253-262: X (n, k, N) or (n, m, k, N) -> BitMatrix (tree length, N);
+    costs and the selection of all N trees run on the device."""
+    method = BB() if method is None else method
+    if not isinstance(method, BB):
+        raise TypeError("bestbasistreeall takes a BB method (BestBasis.jl:253)")
+    Xa = Arg(X)
+    assert 3 <= Xa.arr.ndim <= 4                                      # BestBasis.jl:254
+    sig = Xa.shape[:-2]
+    costs = _bb_costs(Xa, method, True)
+    trees = _bb_trees(costs, sig, Xa.shape[-1])
+    t = trees.cpu().numpy() if costs.kind == "torch" else trees
+    return np.asfortranarray(t.T.astype(bool))
+
+
 def tree_costs(X, method=None):
-    """tree_costs(X::Array{T,3}, method::JBB) bestbasis_tree.jl:150-180"""
+    """tree_costs(X::Array{T,3}, method::JBB) bestbasis_tree.jl:150-180; tree_costs(X, ::BB) :210-258 (one signal)"""
     method = JBB() if method is None else method
+    if isinstance(method, BB):
+        Xa = Arg(X)
+        assert 2 <= Xa.arr.ndim <= 3
+        return _bb_costs(Xa, method, False).arr
     if not isinstance(method, JBB):
         raise _lib.WxError(_lib.WX_EUNSUPPORTED, "only the JBB best-basis type is on the device path")
     Xa = Arg(X)
@@ -116,9 +188,16 @@ def bestbasis_treeselection(costs, n, *args):
 
 
 def bestbasistree(X, method=None):
-    """bestbasistree(X, JBB(...)) BestBasis.jl:194-201 (X is (n, k, N))"""
+    """bestbasistree(X, JBB(...)) BestBasis.jl:194-201 (X is (n, k, N)); bestbasistree(X, BB(...)) :203-210 (one
+    signal, X is (n, k) or (n, m, k))"""
     method = JBB() if method is None else method
     Xa = Arg(X)
+    if isinstance(method, BB):
+        assert 2 <= Xa.arr.ndim <= 3                                  # BestBasis.jl:205
+        costs = _bb_costs(Xa, method, False)
+        trees = _bb_trees(costs, Xa.shape[:-1], 1)
+        t = trees.cpu().numpy() if costs.kind == "torch" else trees
+        return t[0].astype(bool)
     assert 3 <= Xa.arr.ndim <= 4
     costs = tree_costs(Xa.arr, method)
     return bestbasis_treeselection(costs, *Xa.shape[:-2])

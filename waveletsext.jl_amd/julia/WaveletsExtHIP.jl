@@ -20,7 +20,8 @@ import Wavelets.Threshold: bestbasistree
 import WaveletsExt.DWT: wpd, wpd!, iwpd, iwpd!, wpdall, iwpdall, wptall, iwptall
 import WaveletsExt.SWT: sdwtall, isdwtall, swptall, iswptall, swpdall, iswpdall
 import WaveletsExt.ACWT: acdwtall, iacdwtall, acwptall, iacwptall, acwpdall, iacwpdall
-import WaveletsExt.BestBasis: tree_costs, JBB, LoglpCost, NormCost, bestbasis_treeselection
+import WaveletsExt.BestBasis: tree_costs, JBB, LoglpCost, NormCost, bestbasis_treeselection, BB, ShannonEntropyCost,
+                             LogEnergyEntropyCost, bestbasistreeall
 
 export HIP
 
@@ -221,6 +222,21 @@ function bestbasistree(X::HIP{Float64,3}, method::JBB = JBB())
     tree = Vector{UInt8}(undef, n - 1)
     check(ccall((:wx_treeselect_f64, LIB), Cint, (Ptr{Float64}, Int64, Int64, Cint, Ptr{UInt8}), costs, length(costs), n, 0, tree))
     return BitVector(tree .!= 0)
+end
+
+# ---- standard best basis for a whole batch (BestBasis.jl:253-262): costs + all trees on the device -------------
+bbkind(::ShannonEntropyCost) = Cint(0)
+bbkind(::LogEnergyEntropyCost) = Cint(1)
+function bestbasistreeall(X::HIP{Float64,3}, method::BB)
+    n, k, N = size(X)
+    ncost = method.redundant ? k : 1 << k - 1
+    costs = Matrix{Float64}(undef, ncost, N)
+    check(ccall((:wx_bb_costs_f64, LIB), Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Cint, Cint, Ptr{Cvoid}),
+                parent(X), costs, n, k, N, method.redundant, bbkind(method.cost), C_NULL))
+    trees = Matrix{UInt8}(undef, n - 1, N)
+    check(ccall((:wx_treeselect_batch_f64, LIB), Cint,
+                (Ptr{Float64}, Int64, Int64, Int64, Cint, Int64, Ptr{UInt8}, Ptr{Cvoid}), costs, ncost, n, 0, 0, N, trees, C_NULL))
+    return BitMatrix(trees .!= 0)
 end
 
 # ---- multi-GPU (one process per GPU; include/waveletsext_hip.h "Multi-GPU exchange") ----------------------------
