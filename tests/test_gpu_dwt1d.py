@@ -210,3 +210,17 @@ def test_native_rccl_exchange_single_rank(wx):
     finally:
         comm.close()
     wx.shutdown()
+
+
+def test_null_pointer_is_an_argument_error(wx):
+    """a NULL array with non-zero extent is rejected with WX_EARG before anything touches the device"""
+    import ctypes
+    from waveletsext_jl_amd import _lib
+    q = np.array([1.0, 1.0]) / np.sqrt(2.0)
+    y = np.zeros((8, 4, 2), order="F")
+    rc = _lib.lib().wx_wpd1d_f64(None, y.ctypes.data, 8, 3, 2, q.ctypes.data, 2, None)
+    assert rc == _lib.WX_EARG and b"NULL" in _lib.lib().wx_last_error()
+    x = np.zeros((8, 2), order="F")
+    rc = _lib.lib().wx_wpd1d_f64(x.ctypes.data, None, 8, 3, 2, q.ctypes.data, 2, None)
+    assert rc == _lib.WX_EARG
+    assert _lib.lib().wx_wpd1d_f64(None, None, 8, 3, 0, q.ctypes.data, 2, None) == 0      # empty batch: nothing to read

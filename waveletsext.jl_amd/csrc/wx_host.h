@@ -46,6 +46,7 @@ struct WxIO {
     struct Item { void *user; void *dev; size_t bytes; bool staged; bool copy_out; };
     std::vector<Item> items;
     bool any_staged = false;
+    int err = 0;                                    // WX_EARG when a NULL pointer was passed for a non-empty array
     explicit WxIO(hipStream_t s) : st(s) {}
     ~WxIO();
     const void *in(const void *p, size_t bytes);    // staged H2D if p is host memory

@@ -231,6 +231,7 @@ WxIO::~WxIO()
 }
 const void *WxIO::in(const void *p, size_t bytes)
 {
+    if (bytes != 0 && p == nullptr) { err = wx_set_error(WX_EARG, "NULL data pointer for a non-empty array"); return nullptr; }
     if (bytes == 0 || wx_is_device_ptr(p)) return p;
     void *d = nullptr;
     hipError_t e = hipMalloc(&d, bytes);
@@ -243,6 +244,7 @@ const void *WxIO::in(const void *p, size_t bytes)
 }
 void *WxIO::out(void *p, size_t bytes)
 {
+    if (bytes != 0 && p == nullptr) { err = wx_set_error(WX_EARG, "NULL data pointer for a non-empty array"); return nullptr; }
     if (bytes == 0 || wx_is_device_ptr(p)) return p;
     void *d = nullptr;
     hipError_t e = hipMalloc(&d, bytes);
@@ -253,6 +255,7 @@ void *WxIO::out(void *p, size_t bytes)
 }
 int WxIO::finish(int rc)
 {
+    if (err != WX_OK) rc = err;                    // an argument error outranks the caller's generic code
     if (!any_staged) return rc;
     if (rc == WX_OK) {
         for (auto &it : items)
