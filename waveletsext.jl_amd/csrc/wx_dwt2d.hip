@@ -16,6 +16,7 @@
 // global access is coalesced; a level is two passes (columns, rows) through a scratch image.
 #include "wx_common.h"
 #include "wx_kernels.h"
+#include <cstdlib>
 
 static __device__ __forceinline__ int64_t wx_quad_heap(int d, int j, int k)
 {
@@ -171,33 +172,40 @@ __global__ __launch_bounds__(256) void k_gather_leaves2d(const T *__restrict__ X
 // and the HBM side moves R contiguous elements per column.  4 image passes in total instead of 4
 // per level.  (Rounding differs from the per-level order by O(eps); inside the 1e-5 / 1e-10 budget.)
 // ------------------------------------------------------------------------------------------
-template <typename T, int F, bool INVERSE>
+template <typename T, int V> struct alignas(sizeof(T) * V) WxRowVec { T e[V]; };
+
+// V = rows per lane (16-byte LDS / HBM accesses when V * sizeof(T) = 16): the filter work per LDS
+// instruction grows V-fold, which is what bounds this kernel (LDS instruction issue, not bytes).
+template <typename T, int F, bool INVERSE, int V>
 __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, T *__restrict__ dst,
                                                      int64_t src_img, int64_t dst_img, int m, int log2n, int L,
                                                      int64_t nimg, WxFilt filt, int log2R, int S)
 {
+    typedef WxRowVec<T, V> TV;
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     const int n = 1 << log2n;
-    const int R = 1 << log2R;
-    T *cur = reinterpret_cast<T *>(wx_smem);
-    T *nxt = cur + (size_t)n * S;
+    const int R = 1 << log2R;                         // rows per strip
+    const int RV = R / V, log2RV = log2R - (V == 4 ? 2 : (V == 2 ? 1 : 0));
+    const int SV = S / V;                             // LDS column pitch in vectors
+    TV *cur = reinterpret_cast<TV *>(wx_smem);
+    TV *nxt = cur + (size_t)n * SV;
     const int strips_per_img = (m + R - 1) >> log2R;
     const int64_t nstrips = nimg * strips_per_img;
     T q[F];
 #pragma unroll
     for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
-    const int r = threadIdx.x & (R - 1);             // row of the strip owned by this lane
-    const int g0 = threadIdx.x >> log2R;             // first item (column pair group) of this lane
-    const int gstep = blockDim.x >> log2R;
+    const int r = threadIdx.x & (RV - 1);            // row group of the strip owned by this lane
+    const int g0 = threadIdx.x >> log2RV;            // first item (column pair group) of this lane
+    const int gstep = blockDim.x >> log2RV;
     for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
         const int64_t img = sidx / strips_per_img;
         const int r0 = (int)(sidx - img * strips_per_img) << log2R;
-        const T *sp = src + img * src_img + r0 + r;
-        T *dp = dst + img * dst_img + r0 + r;
-        T *a = cur + r, *b = nxt + r;
-        const bool row_ok = r0 + r < m;
+        const T *sp = src + img * src_img + r0 + r * V;
+        T *dp = dst + img * dst_img + r0 + r * V;
+        TV *a = cur + r, *b = nxt + r;
+        const bool row_ok = r0 + r * V < m;          // m is a multiple of V (checked by the launcher)
         if (row_ok)
-            for (int c = g0; c < n; c += gstep) a[c * S] = sp[(int64_t)c * m];
+            for (int c = g0; c < n; c += gstep) a[c * SV] = *reinterpret_cast<const TV *>(sp + (int64_t)c * m);
         __syncthreads();
         for (int s = 0; s < L; ++s) {
             const int d = INVERSE ? L - 1 - s : s;
@@ -207,74 +215,90 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
                 // two output pairs per item: 2F-tap window held in registers
                 for (int it = g0; it < (n >> 2); it += gstep) {
                     const int j = it >> (lnp - 2), t = it & ((h >> 1) - 1);
-                    const T *v = a + (size_t)(j << lnp) * S;
-                    T *o = b + (size_t)(j << lnp) * S;
+                    const TV *v = a + (size_t)(j << lnp) * SV;
+                    TV *o = b + (size_t)(j << lnp) * SV;
                     if (!INVERSE) {
                         // outputs i = 2t, 2t+1: a[i] needs v[2i..2i+F-1], d[i] needs v[2i+2-F..2i+1]
-                        T w[2 * F];
+                        TV w[2 * F];
 #pragma unroll
-                        for (int k = 0; k < 2 * F; ++k) w[k] = v[((4 * t + 2 - F + k) & (np - 1)) * S];
-                        T a0 = 0, a1 = 0, d0 = 0, d1 = 0;
+                        for (int k = 0; k < 2 * F; ++k) w[k] = v[((4 * t + 2 - F + k) & (np - 1)) * SV];
+                        TV a0, a1, d0, d1;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) { a0.e[e] = 0; a1.e[e] = 0; d0.e[e] = 0; d1.e[e] = 0; }
 #pragma unroll
                         for (int k = 0; k < F; ++k) {
-                            a0 = fma(q[k], w[F - 2 + k], a0);
-                            a1 = fma(q[k], w[F + k], a1);
-                            d0 = fma((k & 1) ? -q[k] : q[k], w[F - 1 - k], d0);
-                            d1 = fma((k & 1) ? -q[k] : q[k], w[F + 1 - k], d1);
+                            const T qd = (k & 1) ? -q[k] : q[k];
+#pragma unroll
+                            for (int e = 0; e < V; ++e) {
+                                a0.e[e] = fma(q[k], w[F - 2 + k].e[e], a0.e[e]);
+                                a1.e[e] = fma(q[k], w[F + k].e[e], a1.e[e]);
+                                d0.e[e] = fma(qd, w[F - 1 - k].e[e], d0.e[e]);
+                                d1.e[e] = fma(qd, w[F + 1 - k].e[e], d1.e[e]);
+                            }
                         }
-                        o[(2 * t) * S] = a0; o[(2 * t + 1) * S] = a1;
-                        o[(h + 2 * t) * S] = d0; o[(h + 2 * t + 1) * S] = d1;
+                        o[(2 * t) * SV] = a0; o[(2 * t + 1) * SV] = a1;
+                        o[(h + 2 * t) * SV] = d0; o[(h + 2 * t + 1) * SV] = d1;
                     } else {
                         // parent samples 4t..4t+3 (k = 2t, 2t+1) from a[k-m], d[k+m]
                         constexpr int HF = F / 2;
-                        T aw[HF + 1], dw[HF + 1];
+                        TV aw[HF + 1], dw[HF + 1];
 #pragma unroll
                         for (int k = 0; k < HF + 1; ++k) {
-                            aw[k] = v[((2 * t + 1 - HF + k) & (h - 1)) * S];        // a[2t+1-HF .. 2t+1]
-                            dw[k] = v[(h + ((2 * t + k) & (h - 1))) * S];           // d[2t .. 2t+HF]
+                            aw[k] = v[((2 * t + 1 - HF + k) & (h - 1)) * SV];        // a[2t+1-HF .. 2t+1]
+                            dw[k] = v[(h + ((2 * t + k) & (h - 1))) * SV];           // d[2t .. 2t+HF]
                         }
-                        T v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                        TV v0, v1, v2, v3;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) { v0.e[e] = 0; v1.e[e] = 0; v2.e[e] = 0; v3.e[e] = 0; }
 #pragma unroll
                         for (int mm = 0; mm < HF; ++mm) {
-                            v0 = fma(q[2 * mm], aw[HF - 1 - mm], v0);
-                            v0 = fma(-q[2 * mm + 1], dw[mm], v0);
-                            v1 = fma(q[2 * mm + 1], aw[HF - 1 - mm], v1);
-                            v1 = fma(q[2 * mm], dw[mm], v1);
-                            v2 = fma(q[2 * mm], aw[HF - mm], v2);
-                            v2 = fma(-q[2 * mm + 1], dw[1 + mm], v2);
-                            v3 = fma(q[2 * mm + 1], aw[HF - mm], v3);
-                            v3 = fma(q[2 * mm], dw[1 + mm], v3);
+#pragma unroll
+                            for (int e = 0; e < V; ++e) {
+                                v0.e[e] = fma(q[2 * mm], aw[HF - 1 - mm].e[e], v0.e[e]);
+                                v0.e[e] = fma(-q[2 * mm + 1], dw[mm].e[e], v0.e[e]);
+                                v1.e[e] = fma(q[2 * mm + 1], aw[HF - 1 - mm].e[e], v1.e[e]);
+                                v1.e[e] = fma(q[2 * mm], dw[mm].e[e], v1.e[e]);
+                                v2.e[e] = fma(q[2 * mm], aw[HF - mm].e[e], v2.e[e]);
+                                v2.e[e] = fma(-q[2 * mm + 1], dw[1 + mm].e[e], v2.e[e]);
+                                v3.e[e] = fma(q[2 * mm + 1], aw[HF - mm].e[e], v3.e[e]);
+                                v3.e[e] = fma(q[2 * mm], dw[1 + mm].e[e], v3.e[e]);
+                            }
                         }
-                        o[(4 * t) * S] = v0; o[(4 * t + 1) * S] = v1;
-                        o[(4 * t + 2) * S] = v2; o[(4 * t + 3) * S] = v3;
+                        o[(4 * t) * SV] = v0; o[(4 * t + 1) * SV] = v1;
+                        o[(4 * t + 2) * SV] = v2; o[(4 * t + 3) * SV] = v3;
                     }
                 }
             } else {
                 // nodes of two samples: a = v0 sum(q even) + v1 sum(q odd), ... (wrapped taps)
                 for (int j = g0; j < (n >> 1); j += gstep) {
-                    const T x0 = a[(2 * j) * S], x1 = a[(2 * j + 1) * S];
-                    T y0 = 0, y1 = 0;
-                    if (!INVERSE) {
+                    const TV x0 = a[(2 * j) * SV], x1 = a[(2 * j + 1) * SV];
+                    TV y0, y1;
 #pragma unroll
-                        for (int k = 0; k < F; ++k) {
-                            y0 = fma(q[k], (k & 1) ? x1 : x0, y0);
-                            y1 = fma((k & 1) ? -q[k] : q[k], (k & 1) ? x0 : x1, y1);
-                        }
-                    } else {
+                    for (int e = 0; e < V; ++e) {
+                        T s0 = 0, s1 = 0;
+                        if (!INVERSE) {
 #pragma unroll
-                        for (int mm = 0; mm < F / 2; ++mm) {
-                            y0 = fma(q[2 * mm], x0, y0); y0 = fma(-q[2 * mm + 1], x1, y0);
-                            y1 = fma(q[2 * mm + 1], x0, y1); y1 = fma(q[2 * mm], x1, y1);
+                            for (int k = 0; k < F; ++k) {
+                                s0 = fma(q[k], (k & 1) ? x1.e[e] : x0.e[e], s0);
+                                s1 = fma((k & 1) ? -q[k] : q[k], (k & 1) ? x0.e[e] : x1.e[e], s1);
+                            }
+                        } else {
+#pragma unroll
+                            for (int mm = 0; mm < F / 2; ++mm) {
+                                s0 = fma(q[2 * mm], x0.e[e], s0); s0 = fma(-q[2 * mm + 1], x1.e[e], s0);
+                                s1 = fma(q[2 * mm + 1], x0.e[e], s1); s1 = fma(q[2 * mm], x1.e[e], s1);
+                            }
                         }
+                        y0.e[e] = s0; y1.e[e] = s1;
                     }
-                    b[(2 * j) * S] = y0; b[(2 * j + 1) * S] = y1;
+                    b[(2 * j) * SV] = y0; b[(2 * j + 1) * SV] = y1;
                 }
             }
             __syncthreads();
-            T *tmp = a; a = b; b = tmp;
+            TV *tmp = a; a = b; b = tmp;
         }
         if (row_ok)
-            for (int c = g0; c < n; c += gstep) dp[(int64_t)c * m] = a[c * S];
+            for (int c = g0; c < n; c += gstep) *reinterpret_cast<TV *>(dp + (int64_t)c * m) = a[c * SV];
         __syncthreads();
     }
 }
@@ -282,6 +306,12 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
 template <typename T> static void wx_rows_geometry(int &R, int &S)
 {
     if (sizeof(T) == 4) { R = 32; S = 32; } else { R = 16; S = 24; }
+    // tuning knobs (strip height, a power of two, and LDS column pitch >= R)
+    const char *er = getenv("WX_ROWS_R"), *es = getenv("WX_ROWS_S");
+    if (er && es) {
+        const int r = atoi(er), s2 = atoi(es);
+        if (r >= 4 && r <= 64 && (r & (r - 1)) == 0 && s2 >= r && s2 <= 128) { R = r; S = s2; }
+    }
 }
 
 template <typename T> bool wx_wpt2d_fast_ok(int64_t m, int64_t n, int F)
@@ -299,9 +329,14 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
     int R, S;
     wx_rows_geometry<T>(R, S);
     const size_t lds = (size_t)2 * n * S * sizeof(T);
+    // 16-byte row vectors when the geometry and the pointers allow it
+    constexpr int VW = 16 / (int)sizeof(T);
+    const bool vec = m % VW == 0 && R % VW == 0 && S % VW == 0 && src_img % VW == 0 && dst_img % VW == 0 &&
+                     ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) && filt.F <= 12 &&   // 2F-tap window of vectors in registers
+                     !getenv("WX_ROWS_SCALAR");
     void (*kern)(const T *, T *, int64_t, int64_t, int, int, int, int64_t, WxFilt, int, int) = nullptr;
     switch (filt.F) {
-#define WX_CASE(FF) case FF: kern = k_rows_fused<T, FF, INVERSE>; break;
+#define WX_CASE(FF) case FF: kern = vec ? k_rows_fused<T, FF, INVERSE, VW> : k_rows_fused<T, FF, INVERSE, 1>; break;
         WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
     default: return wx_set_error(WX_EUNSUPPORTED, "no fused row kernel for this filter length");
