@@ -1,0 +1,83 @@
+"""GPU parity, randomized differential sweep: seeded random geometry (lengths incl. non-dyadic multiples of
+2^L, depths incl. 0, batches incl. 1, every filter in the table, both element types, random trees, host and
+device pointers) for every 1-D family against the CPU oracle.  Complements the hand-picked cases of the other
+test files; tolerances as everywhere (1e-10 Float64 / 1e-5 Float32, trees and gathers exact)."""
+import numpy as np
+import pytest
+
+from helpers import TOL, random_tree_1d, relerr
+
+pytestmark = pytest.mark.gpu
+
+FILTERS = ["haar", "db2", "db3", "db4", "db5", "db6", "db8", "db10", "coif2", "coif4", "coif6"]
+
+
+def _stack(fn, X, *a):
+    return np.asfortranarray(np.stack([fn(np.asfortranarray(X[..., i]), *a) for i in range(X.shape[-1])], axis=-1))
+
+
+def _cases(seed, count):
+    rng = np.random.default_rng(seed)
+    for _ in range(count):
+        L = int(rng.integers(0, 8))
+        odd = int(rng.choice([1, 1, 1, 3, 5]))
+        n = odd << int(rng.integers(L, 11)) if odd == 1 else odd << L << int(rng.integers(0, 3))
+        n = max(n, 2)
+        while L > 0 and (n % (1 << L) != 0):
+            L -= 1
+        yield dict(n=n, L=L, B=int(rng.choice([1, 2, 3, 7])), wname=str(rng.choice(FILTERS)),
+                   dtype=np.dtype(rng.choice([np.float64, np.float32])), dev=bool(rng.random() < 0.3), rng=rng)
+
+
+def _put(wx, x, dev):
+    return wx.to_device(x) if dev else x
+
+
+def test_fuzz_decimated(wx, oracle):
+    for c in _cases(4001, 60):
+        n, L, B, dt, rng = c["n"], c["L"], c["B"], c["dtype"], c["rng"]
+        wt = wx.wavelet(getattr(wx.WT, c["wname"]))
+        tol = TOL[dt]
+        x = np.asfortranarray(rng.standard_normal((n, B)).astype(dt))
+        tag = (n, L, B, c["wname"], str(dt), c["dev"])
+        xw = wx.to_numpy(wx.wpdall(_put(wx, x, c["dev"]), wt, L))
+        assert relerr(xw, _stack(oracle.wpd, x, wt.qmf, L)) <= tol, tag
+        if n & (n - 1) == 0:                                            # maketree (iwpd by level, trees) needs dyadic lengths
+            assert relerr(wx.to_numpy(wx.iwpdall(_put(wx, xw, c["dev"]), wt, L)), x) <= 50 * tol, tag
+            tl = wx.to_numpy(wx.wptall(_put(wx, x, c["dev"]), wt, L))
+            assert relerr(tl, _stack(oracle.wpt, x, wt.qmf, L)) <= tol, tag
+            assert relerr(wx.to_numpy(wx.iwptall(_put(wx, tl, c["dev"]), wt, L)), x) <= 50 * tol, tag
+            if n >= 4:
+                tree = random_tree_1d(n, rng)
+                tt = wx.to_numpy(wx.wptall(_put(wx, x, c["dev"]), wt, tree))
+                assert relerr(tt, _stack(oracle.wpt, x, wt.qmf, tree)) <= tol, tag
+                assert relerr(wx.to_numpy(wx.iwptall(_put(wx, tt, c["dev"]), wt, tree)), x) <= 50 * tol, tag
+                full = wx.to_numpy(wx.wpdall(x, wt))
+                assert (wx.to_numpy(wx.getbasiscoefall(_put(wx, full, c["dev"]), tree)) ==
+                        _stack(oracle.getbasiscoef, full, tree)).all(), tag
+
+
+def test_fuzz_redundant(wx, oracle):
+    for c in _cases(4002, 40):
+        n, L, B, dt, rng = c["n"], min(c["L"], 5), c["B"], c["dtype"], c["rng"]
+        if L == 0:
+            continue
+        wt = wx.wavelet(getattr(wx.WT, c["wname"]))
+        tol = TOL[dt]
+        x = np.asfortranarray(rng.standard_normal((n, B)).astype(dt))
+        tag = (n, L, B, c["wname"], str(dt), c["dev"])
+        sp = wx.to_numpy(wx.swptall(_put(wx, x, c["dev"]), wt, L))
+        assert relerr(sp, _stack(oracle.swpt, x, wt.qmf, L)) <= tol, tag
+        sm = [None, int(rng.integers(0, 1 << L))][int(rng.integers(0, 2))]
+        got = wx.to_numpy(wx.iswptall(_put(wx, sp, c["dev"]), wt, sm))
+        assert relerr(got, _stack(oracle.iswpt, sp, wt.qmf, sm)) <= tol, tag
+        assert relerr(got, x) <= 50 * tol, tag
+        sd = wx.to_numpy(wx.sdwtall(_put(wx, x, c["dev"]), wt, L))
+        assert relerr(sd, _stack(oracle.sdwt, x, wt.qmf, L)) <= tol, tag
+        assert relerr(wx.to_numpy(wx.isdwtall(_put(wx, sd, c["dev"]), wt)), x) <= 50 * tol, tag
+        if n & (n - 1) == 0 and dt == np.float64:
+            aw = wx.to_numpy(wx.acwpdall(_put(wx, x, c["dev"]), wt, L))
+            assert relerr(aw, _stack(oracle.acwpd, x, wt.qmf, L)) <= tol, tag
+            assert relerr(wx.to_numpy(wx.iacwpdall(_put(wx, aw, c["dev"]), L)), x) <= 50 * tol, tag
+            tree = wx.bestbasistree(_put(wx, aw, c["dev"]), wx.JBB(redundant=True))
+            assert (tree == oracle.bestbasistree_jbb(aw, redundant=True)).all(), tag

@@ -211,3 +211,33 @@ def test_fused_acwpd_moments_deep_trees(wx, oracle, n, L, wname):
             assert (wx.bestbasis_treeselection(costs, n) == oracle.bestbasistree_jbb(xacw, redundant=True)).all()
         finally:
             wx.set_force_generic(0)
+
+
+def test_jbb_identical_signals_give_zero_sigma(wx, oracle):
+    """a batch of identical signals: x^2 and the sums are rounded separately in the reference
+    (bestbasis_tree.jl:153-156), so for B = 1, 2, 4 the variance is exactly 0 (sigma = 0, costs -Inf: not NaN, not
+    log(1 ulp)); for other B the mean is inexact and the reference's own `@assert all(sigma .>= 0)` / sqrt may
+    fail -- whatever the oracle does, the device path must do the same, through the table and the fused path"""
+    rng = np.random.default_rng(2011)
+    wt = _wt(wx, "db4")
+    x1 = rng.standard_normal(64)
+    for B in (1, 2, 3, 4, 6):
+        x = np.asfortranarray(np.stack([x1] * B, axis=1))
+        for X, red in ((wx.wpdall(x, wt), False), (wx.acwpdall(x, wt), True)):
+            try:
+                exp = oracle.tree_costs_jbb(X, red)
+            except Exception:
+                exp = None
+            if exp is None or np.isnan(exp).any():
+                with pytest.raises(AssertionError):
+                    wx.tree_costs(X, wx.JBB(redundant=red))
+                continue
+            c = wx.to_numpy(wx.tree_costs(X, wx.JBB(redundant=red)))
+            assert (np.isneginf(c) == np.isneginf(exp)).all(), (B, red)
+            if B in (1, 2, 4):
+                assert np.isneginf(c).all(), (B, red)
+            assert (wx.bestbasistree(X, wx.JBB(redundant=red)) == oracle.bestbasistree_jbb(X, redundant=red)).all()
+        if B in (1, 2, 4):
+            s_, q_ = wx.acwpd_jbb_moments(x, wt)
+            cf = wx.to_numpy(wx.costs_from_moments(s_, q_, B, wx.JBB(redundant=True)))
+            assert np.isneginf(cf).all(), B

@@ -13,6 +13,17 @@
 #include "wx_kernels.h"
 
 // sum[e] (+)= sum_b X[e, b];  sumsq[e] (+)= sum_b X[e, b]^2      (e in [0, nk), b in chunk)
+// x*x rounded on its own, as the reference's X.^2 (bestbasis_tree.jl:154): folding the square into the
+// running sum (one rounding) would give a batch of identical signals a variance of +-1 ulp instead of the exact
+// 0 (sigma = 0, cost -Inf) of the reference.  This file is compiled with -ffp-contract=on (see the Makefile):
+// products are only fused inside one expression or through an explicit fma(), never across statements
+// (-ffp-contract=fast fuses in the backend whatever the source says).
+template <typename T> static __device__ __forceinline__ T wx_sq_unfused(T v)
+{
+    const T sq = v * v;
+    return sq;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_jbb_moments(const T *__restrict__ X, T *__restrict__ sum,
                                                      T *__restrict__ sumsq, int64_t nk, int64_t batch,
@@ -29,7 +40,8 @@ __global__ __launch_bounds__(256) void k_jbb_moments(const T *__restrict__ X, T 
         for (int64_t b = b0; b < b1; ++b) {
             const T v = p[b * nk];
             s = (T)(s + v);
-            q = (T)(q + (T)(v * v));
+            const T vq = wx_sq_unfused<T>(v);
+            q = (T)(q + vq);
         }
         sum[c * out_stride + e] = s;
         sumsq[c * out_stride + e] = q;
@@ -50,6 +62,15 @@ __global__ __launch_bounds__(256) void k_jbb_combine(T *__restrict__ sum, T *__r
 }
 
 // one block per cost entry; block-wide tree reduction
+// E[x^2] - E[x]^2 exactly as the reference rounds it (separate multiply and subtract): with a fused
+// multiply-add a batch of identical signals would give a tiny negative variance (NaN sigma, the reference's
+// @assert all(sigma .>= 0)) instead of the exact 0 the reference gets.
+template <typename T> static __device__ __forceinline__ T wx_var_unfused(T ex2, T ex)
+{
+    const T sq = ex * ex;                 // separate statements: not contracted under -ffp-contract=on
+    return ex2 - sq;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_jbb_costs(const T *__restrict__ sum, const T *__restrict__ sumsq,
                                                    int64_t Ntot, int n, int k, int redundant, int cost_kind,
@@ -70,7 +91,7 @@ __global__ __launch_bounds__(256) void k_jbb_costs(const T *__restrict__ sum, co
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
         const int64_t e = (int64_t)col * n + off + i;
         const T ex = (T)(sum[e] / (T)Ntot), ex2 = (T)(sumsq[e] / (T)Ntot);
-        const T var = (T)(ex2 - (T)(ex * ex));
+        const T var = wx_var_unfused<T>(ex2, ex);
         const T sg = (T)sqrt((double)var);                           // NaN if cancellation made var < 0
         if (cost_kind == 0) acc += (double)(T)log((double)(T)fabs((double)sg));
         else acc += pow(fabs((double)sg), p);
@@ -115,7 +136,7 @@ __global__ __launch_bounds__(256) void k_jbb_costs2d(const T *__restrict__ sum, 
         const int r = r0 + i % nr, c = c0 + i / nr;
         const int64_t e = slice * (int64_t)m * n + (int64_t)c * m + r;
         const T ex = (T)(sum[e] / (T)Ntot), ex2 = (T)(sumsq[e] / (T)Ntot);
-        const T sg = (T)sqrt((double)(T)(ex2 - (T)(ex * ex)));
+        const T sg = (T)sqrt((double)wx_var_unfused<T>(ex2, ex));
         if (cost_kind == 0) acc += (double)(T)log((double)(T)fabs((double)sg));
         else acc += pow(fabs((double)sg), p);
     }
@@ -269,13 +290,14 @@ __global__ __launch_bounds__(256) void k_acwpd_subtree_moments(const double *__r
                     const double2 c01 = v[i], c23 = v[i + WX_AC_PLANE];
                     double a0 = acc[aj][0], a1 = acc[aj][1], a2 = acc[aj][2], a3 = acc[aj][3];
                     double lo[4], hi[4];
-                    const double cc[4] = {c1 * c01.x, c1 * c01.y, c1 * c23.x, c1 * c23.y};
+                    const double xc[4] = {c01.x, c01.y, c23.x, c23.y};
                     const double SS[4] = {S0, S1, S2, S3};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        lo[c] = cc[c] + SS[c]; hi[c] = cc[c] - SS[c];
-                        a0 += lo[c]; a1 = fma(lo[c], lo[c], a1);
-                        a2 += hi[c]; a3 = fma(hi[c], hi[c], a3);
+                        lo[c] = fma(c1, xc[c], SS[c]); hi[c] = fma(c1, xc[c], -SS[c]);   // v/sqrt2 +- S (transform: tolerance)
+                        const double lq = wx_sq_unfused<double>(lo[c]), hq = wx_sq_unfused<double>(hi[c]);
+                        a0 += lo[c]; a1 += lq;
+                        a2 += hi[c]; a3 += hq;
                     }
                     acc[aj][0] = a0; acc[aj][1] = a1; acc[aj][2] = a2; acc[aj][3] = a3;
                     if (j + 1 < LP) {
