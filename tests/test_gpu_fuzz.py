@@ -81,3 +81,79 @@ def test_fuzz_redundant(wx, oracle):
             assert relerr(wx.to_numpy(wx.iacwpdall(_put(wx, aw, c["dev"]), L)), x) <= 50 * tol, tag
             tree = wx.bestbasistree(_put(wx, aw, c["dev"]), wx.JBB(redundant=True))
             assert (tree == oracle.bestbasistree_jbb(aw, redundant=True)).all(), tag
+
+
+def _cases2d(seed, count):
+    rng = np.random.default_rng(seed)
+    for _ in range(count):
+        L = int(rng.integers(0, 5))
+        m = int(rng.choice([1, 1, 3])) << L << int(rng.integers(0, 3))
+        n = int(rng.choice([1, 1, 5])) << L << int(rng.integers(0, 3))
+        m, n = max(m, 2), max(n, 2)
+        while L > 0 and (m % (1 << L) or n % (1 << L)):
+            L -= 1
+        yield dict(m=m, n=n, L=L, B=int(rng.choice([1, 2, 5])), wname=str(rng.choice(FILTERS[:8])),
+                   dtype=np.dtype(rng.choice([np.float64, np.float32])), dev=bool(rng.random() < 0.3), rng=rng)
+
+
+def test_fuzz_2d(wx, oracle):
+    from helpers import random_tree_2d
+    for c in _cases2d(4003, 40):
+        m, n, L, B, dt, rng = c["m"], c["n"], c["L"], c["B"], c["dtype"], c["rng"]
+        wt = wx.wavelet(getattr(wx.WT, c["wname"]))
+        tol = TOL[dt]
+        x = np.asfortranarray(rng.standard_normal((m, n, B)).astype(dt))
+        tag = (m, n, L, B, c["wname"], str(dt), c["dev"])
+        xw = wx.to_numpy(wx.wpdall(_put(wx, x, c["dev"]), wt, L))
+        assert relerr(xw, _stack(oracle.wpd, x, wt.qmf, L)) <= tol, tag
+        y = wx.to_numpy(wx.wptall(_put(wx, x, c["dev"]), wt, L))
+        assert relerr(y, _stack(oracle.wpt, x, wt.qmf, L)) <= tol, tag
+        assert relerr(wx.to_numpy(wx.iwptall(_put(wx, y, c["dev"]), wt, L)), x) <= 50 * tol, tag
+        assert relerr(wx.to_numpy(wx.iwpdall(_put(wx, xw, c["dev"]), wt, L)), x) <= 50 * tol, tag
+        if wx.maxtransformlevels(min(m, n)) >= 1:
+            tree = random_tree_2d(m, n, rng)
+            Lside = min(wx.maxtransformlevels(m), wx.maxtransformlevels(n))
+            if wx.maxtransformlevels(min(m, n)) > Lside and tree[(4 ** Lside - 1) // 3:].any():
+                with pytest.raises(AssertionError):                      # a side not divisible by 2^depth
+                    wx.wptall(x, wt, tree)
+                tree[(4 ** Lside - 1) // 3:] = False
+            yt = wx.to_numpy(wx.wptall(_put(wx, x, c["dev"]), wt, tree))
+            assert relerr(yt, _stack(oracle.wpt, x, wt.qmf, tree)) <= tol, tag
+            assert relerr(wx.to_numpy(wx.iwptall(_put(wx, yt, c["dev"]), wt, tree)), x) <= 50 * tol, tag
+        if L >= 1 and m * n <= 4096:
+            Lr = min(L, 2)
+            sp = wx.to_numpy(wx.swptall(_put(wx, x, c["dev"]), wt, Lr))
+            assert relerr(sp, np.asfortranarray(np.stack([oracle.red2d_fwd("wpt", x[:, :, i], wt.qmf, Lr) for i in range(B)], axis=-1))) <= tol, tag
+            assert relerr(wx.to_numpy(wx.iswptall(_put(wx, sp, c["dev"]), wt)), x) <= 50 * tol, tag
+
+
+def test_fuzz_best_basis_degenerate_inputs(wx, oracle):
+    """zeros, constants, impulses, identical and single signals through JBB and BB: whatever the oracle does
+    (including failing the reference's asserts) the device path does too"""
+    rng = np.random.default_rng(4004)
+    wt = wx.wavelet(wx.WT.db2)
+    n = 32
+    base = {
+        "zeros": np.zeros(n), "const": np.full(n, 3.25), "impulse": np.eye(1, n, 5).ravel(),
+        "ramp": np.arange(n, dtype=float), "noise": rng.standard_normal(n),
+    }
+    for name, v in base.items():
+        for B in (1, 2, 5):
+            x = np.asfortranarray(np.stack([v] * B, axis=1))
+            if name == "noise":
+                x = np.asfortranarray(x + 1e-3 * rng.standard_normal(x.shape))
+            X = wx.wpdall(x, wt)
+            # BB: one tree per signal
+            assert (wx.bestbasistreeall(X, wx.BB()) == oracle.bestbasistreeall_bb(X)).all(), (name, B)
+            assert (wx.bestbasistreeall(X, wx.BB(cost=wx.LogEnergyEntropyCost())) ==
+                    oracle.bestbasistreeall_bb(X, cost="logenergy")).all(), (name, B)
+            # JBB
+            try:
+                exp = oracle.bestbasistree_jbb(X)
+            except Exception:
+                exp = None
+            if exp is None:
+                with pytest.raises(AssertionError):
+                    wx.bestbasistree(X, wx.JBB())
+            else:
+                assert (wx.bestbasistree(X, wx.JBB()) == exp).all(), (name, B)

@@ -43,11 +43,18 @@ struct WxTree2d {
 static int wx_check_tree2d(int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree)
 {
     const int L0 = wx_maxtransformlevels(m < n ? m : n);
+    // the reference bounds L by maxtransformlevels(min(m, n)) only; a side that is not divisible by 2^depth
+    // then trips the size asserts of its 2-D dwt_step! (dwt_one_level.jl:319-354) -- rejected here up front
+    const int Lm = wx_maxtransformlevels(m), Ln = wx_maxtransformlevels(n);
+    const int Lside = Lm < Ln ? Lm : Ln;
     if (!tree) {
         WX_REQUIRE(0 <= L && L <= L0, WX_EASSERT, "maketree(n, m, L): @assert 0 <= L <= L0 (utils_tree.jl:196)");
+        WX_REQUIRE(L <= Lside, WX_EASSERT, "both sides must be divisible by 2^L (dwt_step! size asserts)");
         return WX_OK;
     }
     WX_REQUIRE(wx_isvalidtree2d(m, n, tree, ntree), WX_EASSERT, "@assert isvalidtree(x, tree) (DWT.jl:504,666)");
+    WX_REQUIRE(wx_tree_depth2d(tree, ntree) <= Lside, WX_EASSERT,
+               "both sides must be divisible by 2^depth(tree) (dwt_step! size asserts)");
     return WX_OK;
 }
 
