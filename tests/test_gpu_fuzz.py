@@ -157,3 +157,49 @@ def test_fuzz_best_basis_degenerate_inputs(wx, oracle):
                     wx.bestbasistree(X, wx.JBB())
             else:
                 assert (wx.bestbasistree(X, wx.JBB()) == exp).all(), (name, B)
+
+
+def test_fuzz_redundant_trees_and_2d_ac(wx, oracle):
+    from helpers import random_tree_2d
+    rng = np.random.default_rng(4005)
+    for it in range(24):
+        wt = wx.wavelet(getattr(wx.WT, str(rng.choice(FILTERS[:6]))))
+        dt = np.dtype(rng.choice([np.float64, np.float32]))
+        tol = TOL[dt]
+        n = 1 << int(rng.integers(2, 8))
+        B = int(rng.choice([1, 3]))
+        x = np.asfortranarray(rng.standard_normal((n, B)).astype(dt))
+        Lmax = wx.maxtransformlevels(n)
+        L = int(rng.integers(1, min(Lmax, 5) + 1))
+        # swpd + iswpd by random tree and random shift
+        sw = wx.swpdall(x, wt, L)
+        assert relerr(sw, _stack(oracle.swpd, x, wt.qmf, L)) <= tol, (n, L)
+        tree = random_tree_1d(n, rng)
+        tree[(1 << L) - 1:] = False                                   # the table only holds depth <= L
+        sm = None if rng.random() < 0.5 else int(rng.integers(0, 1 << L))
+        got = wx.iswpdall(sw, wt, tree, sm)
+        exp = np.asfortranarray(np.stack([oracle.iswpd(sw[:, :, i], wt.qmf, tree, sm) for i in range(B)], axis=-1))
+        assert relerr(got, exp) <= tol, (n, L, sm)
+        assert relerr(got, x) <= 50 * tol, (n, L, sm)
+        # isdwt with a random shift
+        sd = wx.sdwtall(x, wt, L)
+        s2 = int(rng.integers(1, 1 << L)) if L >= 1 else None
+        assert relerr(wx.isdwtall(sd, wt, s2), _stack(oracle.isdwt, sd, wt.qmf, s2)) <= tol, (n, L, s2)
+        if dt == np.float64:
+            # ACWT by tree (1-D) and the 2-D autocorrelation families
+            aw = wx.acwpdall(x, wt, L)
+            got = wx.iacwpdall(aw, tree)
+            exp = np.asfortranarray(np.stack([oracle.iacwpd(aw[:, :, i], tree) for i in range(B)], axis=-1))
+            assert (got == exp).all(), (n, L)                        # pairwise sums: bit exact
+            m2, n2 = 1 << int(rng.integers(2, 5)), 1 << int(rng.integers(2, 5))
+            img = np.asfortranarray(rng.standard_normal((m2, n2, B)))
+            L2 = int(rng.integers(1, min(wx.maxtransformlevels(min(m2, n2)), 2) + 1))
+            a2 = wx.acwpdall(img, wt, L2)
+            e2 = np.asfortranarray(np.stack([oracle.red2d_fwd("wpd", img[:, :, i], wt.qmf, L2, ac=True) for i in range(B)], axis=-1))
+            assert relerr(a2, e2) <= tol, (m2, n2, L2)
+            assert relerr(wx.iacwpdall(a2, L2), img) <= 50 * tol, (m2, n2, L2)
+            t2 = random_tree_2d(m2, n2, rng)
+            t2[(4 ** L2 - 1) // 3:] = False
+            g2 = wx.iacwpdall(a2, t2)
+            x2 = np.asfortranarray(np.stack([oracle.red2d_inv("wpd", a2[:, :, :, i], None, t2, ac=True) for i in range(B)], axis=-1))
+            assert relerr(g2, x2) <= tol, (m2, n2, L2)
