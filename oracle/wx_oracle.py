@@ -594,3 +594,74 @@ def bestbasistreeall_bb(X, redundant=False, cost="shannon"):
     """bestbasistreeall(X, BB(...)) BestBasis.jl:253-262: (tree length, k) BitMatrix"""
     X = _f(X)
     return np.stack([bestbasistree_bb(np.asfortranarray(X[..., i]), redundant, cost) for i in range(X.shape[-1])], axis=1)
+
+
+# ---- denoising core (Denoising.jl:214-232, 483-599; Wavelets.jl Threshold) ---------------------------
+TH_KINDS = {"hard": 0, "soft": 1, "semisoft": 2, "stein": 3}
+
+
+def noisest_range(v):
+    """mad!(v)/0.6745 of a 1-D array"""
+    v = np.ascontiguousarray(_f(v).ravel())
+    fn = getattr(lib(), "wxo_noisest_range" + _suf(v.dtype))
+    fn.restype = ctypes.c_double if v.dtype == np.float64 else ctypes.c_float
+    return float(fn(_p(v), _L(v.size)))
+
+
+def threshold(x, th, t):
+    x = np.array(_f(x), copy=True, order="F")
+    fn = getattr(lib(), "wxo_threshold" + _suf(x.dtype))
+    fn.restype = None
+    fn(_p(x), _L(x.size), _I(TH_KINDS[th]), (ctypes.c_double if x.dtype == np.float64 else ctypes.c_float)(t))
+    return x
+
+
+def noisest(x, redundant, tree=None):
+    """Denoising.jl:214-232"""
+    x = _f(x)
+    n = x.shape[0]
+    if not redundant and tree is None:
+        return noisest_range(x[n // 2:])
+    if not redundant:
+        return noisest_range(x[finestdetailrange(n, tree) - 1:])
+    if tree is None:
+        return noisest_range(x[:, -1])
+    return noisest_range(x[:, finestdetailrange(n, tree, True) - 1])
+
+
+def denoise(x, inputtype, qmf, L=None, tree=None, th="hard", t=None, estnoise=None, smooth="regular"):
+    """Denoising.jl:483-599 for dnt = VisuShrink-like (th, t); estnoise None -> noisest, or a number"""
+    x = _f(x)
+    n = x.shape[0]
+    L = maxtransformlevels(n) if L is None else L
+    tree = maketree1d(n, L, "dwt") if tree is None else np.asarray(tree, dtype=bool)
+    t = np.sqrt(2 * np.log(n)) if t is None else t
+    dwt_tree = maketree1d(n, L, "dwt")
+    if inputtype == "sig":
+        x = wpt(x, qmf, dwt_tree)                                     # dwt(x, wt, L)
+        inputtype = "dwt"
+    red = inputtype in ("sdwt", "swpd", "acdwt", "acwpd")
+    tr = None if inputtype in ("dwt", "sdwt", "acdwt") else tree
+    sigma = noisest(x, red, tr) if estnoise is None else float(estnoise)
+    xt = np.array(x, copy=True, order="F")
+    if inputtype == "dwt":
+        lo = (n >> L) if smooth == "undersmooth" else 0
+        xt[lo:] = threshold(xt[lo:], th, sigma * t)
+        return xt if qmf is None else iwpt(xt, qmf, dwt_tree)         # idwt(x, wt, L)
+    if inputtype == "wpt":
+        lo = coarsestscalingrange(n, tree) if smooth == "undersmooth" else 0
+        xt[lo:] = threshold(xt[lo:], th, sigma * t)
+        return xt if qmf is None else iwpt(xt, qmf, tree)
+    if inputtype in ("sdwt", "acdwt"):
+        c0 = 1 if smooth == "undersmooth" else 0
+        xt[:, c0:] = threshold(xt[:, c0:], th, sigma * t)
+        if inputtype == "sdwt":
+            return xt if qmf is None else isdwt(xt, qmf)
+        return iacdwt(xt)
+    leaves = np.flatnonzero(getleaf(tree, "binary"))
+    if smooth == "undersmooth":
+        leaves = leaves[leaves != coarsestscalingrange(n, tree, True) - 1]
+    xt[:, leaves] = threshold(xt[:, leaves], th, sigma * t)
+    if inputtype == "swpd":
+        return xt if qmf is None else iswpd(xt, qmf, tree)
+    return iacwpd(xt, tree)

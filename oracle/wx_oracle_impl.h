@@ -1270,6 +1270,56 @@ int FN(wxo_tree_costs_bb2d)(T *costs, const T *X, int64_t n, int64_t m, int64_t 
     return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Denoising core: noise estimate and thresholding.         */
+/* Denoising.jl:214-232 noisest(x, redundant, tree) = mad!(dr)/0.6745 with    */
+/* Wavelets.jl Threshold.mad!  (m = median!(y); y .= abs.(y .- m);            */
+/* median!(y)) and Statistics.median! (even length: middle(a,b) = a/2 + b/2); */
+/* Wavelets.jl Threshold.threshold!(x, TH, t) for HardTH / SoftTH /           */
+/* SemiSoftTH / SteinTH.  Wavelets.jl is not vendored: these four loops and   */
+/* mad! are restated from its published source -- parity unpinned.            */
+/* ------------------------------------------------------------------------- */
+static int FN(wxo_cmp)(const void *a, const void *b)
+{
+    T x = *(const T *)a, y = *(const T *)b;
+    return (x > y) - (x < y);
+}
+static T FN(wxo_median_inplace)(T *y, int64_t n)
+{
+    qsort(y, (size_t)n, sizeof(T), FN(wxo_cmp));
+    if (n & 1) return y[n / 2];
+    return (T)((T)(y[n / 2 - 1] / 2) + (T)(y[n / 2] / 2));
+}
+/* mad!(y)/0.6745 of `cnt` values taken with stride 1 from p */
+T FN(wxo_noisest_range)(const T *p, int64_t cnt)
+{
+    T *y = (T *)malloc(sizeof(T) * (size_t)(cnt > 0 ? cnt : 1));
+    for (int64_t i = 0; i < cnt; i++) y[i] = p[i];
+    T m = FN(wxo_median_inplace)(y, cnt);
+    for (int64_t i = 0; i < cnt; i++) y[i] = (T)fabs((double)(T)(y[i] - m));
+    T r = FN(wxo_median_inplace)(y, cnt);
+    free(y);
+    return (T)(r / (T)0.6745);
+}
+/* threshold!(x, TH, t): th_kind 0 Hard, 1 Soft, 2 SemiSoft, 3 Stein */
+void FN(wxo_threshold)(T *x, int64_t cnt, int th_kind, T t)
+{
+    for (int64_t i = 0; i < cnt; i++) {
+        T v = x[i];
+        if (th_kind == 0) { if ((T)fabs((double)v) <= t) x[i] = 0; }
+        else if (th_kind == 1) {
+            T sh = (T)((T)fabs((double)v) - t);
+            x[i] = sh < 0 ? (T)0 : (T)((v > 0 ? (T)1 : (v < 0 ? (T)-1 : v)) * sh);
+        } else if (th_kind == 2) {
+            T sh = (T)((T)(v * v) - (T)(t * t));
+            x[i] = sh < 0 ? (T)0 : (T)((v > 0 ? (T)1 : (v < 0 ? (T)-1 : v)) * (T)sqrt((double)sh));
+        } else {
+            T sh = (T)((T)1 - (T)((T)(t * t) / (T)(v * v)));
+            x[i] = sh < 0 ? (T)0 : (T)(v * sh);
+        }
+    }
+}
+
 #undef T
 #undef FN
 #undef V1

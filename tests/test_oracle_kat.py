@@ -360,3 +360,26 @@ def test_bb_costs_and_trees_oracle(oracle):
     assert abs(c2[2] - (-(s * np.log(s)).sum())) <= 1e-12
     trees = oracle.bestbasistreeall_bb(np.asfortranarray(np.stack([X, X], axis=2)))
     assert trees.shape == (15, 2) and (trees[:, 0] == trees[:, 1]).all()
+
+
+def test_denoise_core_oracle(oracle):
+    """noisest = MAD/0.6745 and the four threshold functions: closed forms; the range helpers they rely on are the
+    KAT-pinned coarsestscalingrange / finestdetailrange (test/utils.jl:44-54)"""
+    import numpy as np
+    assert oracle.noisest_range(np.array([1.0, 2, 3, 4, 100])) == 1 / 0.6745          # median 3, deviations 2 1 0 1 97
+    assert oracle.noisest_range(np.array([1.0, 2, 3, 4])) == 1 / 0.6745               # median 2.5, deviations 1.5 .5 .5 1.5
+    v = np.array([-3.0, -1.0, 0.0, 0.5, 2.0])
+    assert (oracle.threshold(v, "hard", 1.0) == [-3, 0, 0, 0, 2]).all()
+    assert (oracle.threshold(v, "soft", 1.0) == [-2, 0, 0, 0, 1]).all()
+    assert np.allclose(oracle.threshold(v, "semisoft", 1.0), [-np.sqrt(8), 0, 0, 0, np.sqrt(3)])
+    assert np.allclose(oracle.threshold(np.array([-3.0, 0.5, 2.0]), "stein", 1.0), [-3 * (1 - 1 / 9), 0, 2 * 0.75])
+    x = np.arange(8, dtype=float)
+    assert oracle.noisest(x, False) == oracle.noisest_range(x[4:])                    # dwt: upper half
+    tree = oracle.maketree1d(8, 2, "full")                                            # finest detail = last quarter
+    assert oracle.noisest(x, False, tree) == oracle.noisest_range(x[6:])
+    X = np.asfortranarray(np.arange(24, dtype=float).reshape(8, 3, order="F"))
+    assert oracle.noisest(X, True) == oracle.noisest_range(X[:, 2])                   # sdwt: last column = d_1
+    # a constant signal has no detail: sigma 0, nothing changes
+    c = np.full(16, 2.0)
+    q = np.array([1.0, 1.0]) / np.sqrt(2.0)
+    assert np.allclose(oracle.denoise(c, "sig", q), c)

@@ -24,3 +24,5 @@ from .acwt import (acdwt, acdwt_, acdwtall, iacdwt, iacdwt_, iacdwtall, acwpt, a
 from .bestbasis import (JBB, LoglpCost, NormCost, tree_costs, bestbasistree, bestbasis_treeselection,   # noqa: F401
                         jbb_moments, costs_from_moments, acwpd_jbb_moments,
                         BB, ShannonEntropyCost, LogEnergyEntropyCost, bestbasistreeall)
+from .denoising import (HardTH, SoftTH, SemiSoftTH, SteinTH, VisuShrink, noisest, threshold, denoise,   # noqa: F401,E402
+                        denoiseall)

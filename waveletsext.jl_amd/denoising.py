@@ -1,0 +1,189 @@
+"""Denoising: host-side mirror of the reference's `Denoising` module (src/mod/Denoising.jl:214-232, 483-712) for
+the VisuShrink family.  The two data-parallel steps -- the MAD noise estimate of every signal and the thresholding
+of the coefficient table -- run on the device between the batch transforms; `denoiseall` is one pipeline for the
+whole batch instead of the reference's loop over signals.  SURVEY section 8(f) row 1.
+
+Wavelets.jl (`Threshold.HardTH/SoftTH/SemiSoftTH/SteinTH`, `VisuShrink`, `mad!`) is not vendored in the reference
+tree; those pieces are restated from its published source.  RelErrorShrink / SureShrink are not on the device
+path (they raise)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._arrays import Arg, to_numpy
+from .dwt import dwt, dwtall, idwt, idwtall, iwpt, iwptall
+from .swt import isdwt, isdwtall, iswpd, iswpdall
+from .acwt import iacdwt, iacdwtall, iacwpd, iacwpdall
+from .util import (coarsestscalingrange, finestdetailrange, getleaf, isdyadic, maketree, maxtransformlevels,
+                   nodelength)
+
+
+class HardTH:
+    kind = 0
+
+
+class SoftTH:
+    kind = 1
+
+
+class SemiSoftTH:
+    kind = 2
+
+
+class SteinTH:
+    kind = 3
+
+
+class VisuShrink:
+    """VisuShrink(n) / VisuShrink(n, th) (Denoising.jl:124-126: t = sqrt(2 log n)) or VisuShrink(th, t)"""
+
+    def __init__(self, a, b=None):
+        if isinstance(a, (int, np.integer)):
+            self.th = HardTH() if b is None else b
+            self.t = float(np.sqrt(2 * np.log(int(a))))
+        else:
+            self.th, self.t = a, float(b)
+
+
+INPUTTYPES = ("sig", "dwt", "wpt", "sdwt", "swpd", "acdwt", "acwpd")
+
+
+def _detail_range(n, k, inputtype, tree):
+    """(row_lo, col) 0-based of the finest detail coefficients, as noisest picks them (Denoising.jl:221-230)"""
+    if inputtype == "dwt":
+        return n // 2, 0
+    if inputtype == "wpt":
+        return finestdetailrange(n, tree)[0] - 1, 0
+    if inputtype in ("sdwt", "acdwt"):
+        return 0, k - 1
+    return 0, finestdetailrange(n, tree, True)[1] - 1
+
+
+def _noisest(xa, batched, inputtype, tree):
+    n = xa.shape[0]
+    assert isdyadic(n)                                                 # Denoising.jl:218
+    N = xa.shape[-1] if batched else 1
+    k = 1 if inputtype in ("dwt", "wpt") else xa.shape[1]
+    lo, col = _detail_range(n, k, inputtype, tree)
+    sig = np.empty(N, dtype=xa.dtype)
+    fn = getattr(_lib.lib(), "wx_noisest" + xa.suffix)
+    _lib.check(fn(xa.ptr, n, k, N, lo, col, ctypes.c_void_p(sig.ctypes.data), xa.stream()))
+    return sig
+
+
+def noisest(x, redundant, tree=None):
+    """noisest(x, redundant[, tree]) Denoising.jl:214-232 for one decomposed signal"""
+    xa = Arg(x)
+    it = ("sdwt" if tree is None else "swpd") if redundant else ("dwt" if tree is None else "wpt")
+    return float(_noisest(xa, False, it, None if tree is None else np.asarray(tree, dtype=bool))[0])
+
+
+def _threshold_inplace(xa, batched, th, t, row_lo=0, colmask=None):
+    n = xa.shape[0]
+    N = xa.shape[-1] if batched else 1
+    k = 1 if xa.arr.ndim - (1 if batched else 0) == 1 else xa.shape[1]
+    tv = np.ascontiguousarray(np.atleast_1d(np.asarray(t, dtype=xa.dtype)))
+    cm = None if colmask is None else np.ascontiguousarray(np.asarray(colmask, dtype=np.uint8))
+    fn = getattr(_lib.lib(), "wx_threshold" + xa.suffix)
+    _lib.check(fn(xa.ptr, n, k, N, th.kind, ctypes.c_void_p(tv.ctypes.data), tv.size, int(row_lo),
+                  ctypes.c_void_p(cm.ctypes.data) if cm is not None else ctypes.c_void_p(0), xa.stream()))
+
+
+def threshold(x, th, t):
+    """Wavelets.Threshold.threshold(x, TH, t): thresholded copy"""
+    xa = Arg(x)
+    out = xa.new(xa.shape)
+    if xa.kind == "torch":
+        out.arr.copy_(xa.arr)
+    else:
+        out.arr[...] = xa.arr
+    _threshold_inplace(out, False, th, t)
+    return out.arr
+
+
+def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
+    assert smooth in ("undersmooth", "regular")                       # Denoising.jl:493
+    assert inputtype in INPUTTYPES                                     # Denoising.jl:494
+    if not isinstance(dnt, VisuShrink):
+        raise _lib.WxError(_lib.WX_EUNSUPPORTED, "only VisuShrink thresholds are on the device path")
+    xa = Arg(x)
+    n = xa.shape[0]
+    L = maxtransformlevels(n) if L is None else int(L)
+    tree = maketree(n, L, "dwt") if tree is None else np.asarray(tree, dtype=bool)
+    if inputtype == "sig":
+        if wt is None:
+            raise ValueError("inputtype=:sig not supported with wt=nothing")    # Denoising.jl:498
+        xa = Arg(dwtall(xa.arr, wt, L) if batched else dwt(xa.arr, wt, L))
+        inputtype = "dwt"
+    if inputtype not in ("dwt", "wpt"):
+        assert xa.arr.ndim > (2 if batched else 1)                     # @assert ndims(x) > 1
+    N = xa.shape[-1] if batched else 1
+    # working copy (the reference thresholds a copy and leaves x alone)
+    xt = xa.new(xa.shape)
+    if xt.kind == "torch":
+        xt.arr.copy_(xa.arr)
+    else:
+        xt.arr[...] = xa.arr
+    # noise estimation
+    tr = None if inputtype in ("dwt", "sdwt", "acdwt") else tree
+    if estnoise is None or callable(estnoise):
+        if estnoise is not None and estnoise is not noisest:
+            raise _lib.WxError(_lib.WX_EUNSUPPORTED, "only noisest (or precomputed values) estimates noise on the device path")
+        sigma = _noisest(xt, batched, inputtype, tr)
+    else:
+        sigma = np.broadcast_to(np.asarray(estnoise, dtype=np.float64), (N,)).astype(xa.dtype)
+    if bestTH is not None:
+        sigma = np.full(N, bestTH(sigma.astype(np.float64)), dtype=xa.dtype)     # Denoising.jl:697-700
+    t = (sigma.astype(np.float64) * dnt.t).astype(xa.dtype)            # σ*dnt.t
+    # thresholding + reconstruction
+    if inputtype == "dwt":
+        lo = nodelength(n, L) if smooth == "undersmooth" else 0
+        _threshold_inplace(xt, batched, dnt.th, t, lo)
+        if wt is None:
+            return xt.arr
+        return idwtall(xt.arr, wt, L) if batched else idwt(xt.arr, wt, L)
+    if inputtype == "wpt":
+        lo = coarsestscalingrange(n, tree)[-1] if smooth == "undersmooth" else 0
+        _threshold_inplace(xt, batched, dnt.th, t, lo)
+        if wt is None:
+            return xt.arr
+        return iwptall(xt.arr, wt, tree) if batched else iwpt(xt.arr, wt, tree)
+    k = xt.shape[1]
+    if inputtype in ("sdwt", "acdwt"):
+        mask = np.ones(k, dtype=np.uint8)
+        if smooth == "undersmooth":
+            mask[0] = 0
+        _threshold_inplace(xt, batched, dnt.th, t, 0, mask)
+        if inputtype == "sdwt":
+            if wt is None:
+                return xt.arr
+            return isdwtall(xt.arr, wt) if batched else isdwt(xt.arr, wt)
+        return iacdwtall(xt.arr) if batched else iacdwt(xt.arr)
+    leaves = np.asarray(getleaf(tree, "binary"), dtype=bool)
+    assert not leaves[k:].any(), "tree has leaves below the last column of the table"
+    mask = leaves[:k].astype(np.uint8)
+    if smooth == "undersmooth":
+        mask[coarsestscalingrange(n, tree, True)[1] - 1] = 0
+    _threshold_inplace(xt, batched, dnt.th, t, 0, mask)
+    if inputtype == "swpd":
+        if wt is None:
+            return xt.arr
+        return iswpdall(xt.arr, wt, tree) if batched else iswpd(xt.arr, wt, tree)
+    return iacwpdall(xt.arr, tree) if batched else iacwpd(xt.arr, tree)
+
+
+def denoise(x, inputtype, wt, L=None, tree=None, dnt=None, estnoise=None, smooth="regular"):
+    """denoise(x, inputtype, wt; L, tree, dnt, estnoise, smooth) Denoising.jl:483-599 (one signal)"""
+    xa = Arg(x)
+    dnt = VisuShrink(xa.shape[0]) if dnt is None else dnt
+    return _denoise(xa.arr, inputtype, wt, L, tree, dnt, estnoise, None, smooth, False)
+
+
+def denoiseall(x, inputtype, wt, L=None, tree=None, dnt=None, estnoise=None, bestTH=None, smooth="regular"):
+    """denoiseall(x, inputtype, wt; L, tree, dnt, estnoise, bestTH, smooth) Denoising.jl:651-712: the whole batch
+    in one pipeline (transform, per-signal MAD, threshold, inverse) on the device"""
+    xa = Arg(x)
+    assert xa.arr.ndim > 1                                             # Denoising.jl:663
+    dnt = VisuShrink(xa.shape[0]) if dnt is None else dnt
+    return _denoise(xa.arr, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, True)
