@@ -57,6 +57,12 @@ WORKLOADS = {
                fwd_kernels=[("k_bb_norms<double>", 1), ("k_bb_costs1d<double>", 1), ("k_bb_treeselect<double, 2>", 1)],
                desc="SURVEY 8(f) row 3: per-signal best basis, bestbasistreeall(wpdall(x), BB()) 16384x4096 f64 db8 L=12; "
                     "timed leg = Shannon costs + tree selection over the resident 6.5 GiB table (wpdall is the other leg)"),
+    "ldb": dict(kind="wpd_ldb", n=4096, batch=16384, wavelet="db8", L=12, dtype="f64",
+                kernel="k_ldb_class_partial<double>",
+                fwd_kernels=[("k_ldb_root_norm2<double>", 1), ("k_ldb_class_sum<double>", 1),
+                             ("k_ldb_class_partial<double>", 1), ("k_ldb_class_combine<double>", 1)],
+                desc="SURVEY 8(f) row 2: LDB time-frequency energy maps of 4 classes over wpdall(x) 16384x4096 f64 db8 "
+                     "L=12; timed leg = energy_map over the resident 6.5 GiB table (wpdall is the other leg)"),
 }
 
 
@@ -136,6 +142,16 @@ def cpu_baseline(w, seconds):
             trees = wo.bestbasistreeall_bb(X)
             dt = time.perf_counter() - t0
             assert trees.shape == (n - 1, B)
+            return dt, B * n
+        if kind == "wpd_ldb":
+            n = w["n"]
+            x = rng.standard_normal((n, B))
+            y = [i % 4 for i in range(B)]
+            t0 = time.perf_counter()
+            X = np.asfortranarray(np.stack([wo.wpd(x[:, i], q, L) for i in range(B)], axis=-1))
+            G = wo.ldb_energy_map(X, y)
+            dt = time.perf_counter() - t0
+            assert G.shape == (n, L + 1, 4)
             return dt, B * n
         if kind == "acwpd_jbb":
             n = w["n"]
@@ -259,6 +275,28 @@ def make_workload(w, wx, torch, dev, rank):
         ncost = (1 << (L + 1)) - 1
         return fwd, inv, check, dict(fwd_bytes=es * (n * (L + 1) + ncost) * B + (n - 1) * B, inv_bytes=es * n * (L + 2) * B,
                                      fwd_flops=4.0 * n * (L + 1) * B, samples=n * B, bound="hbm", keep=(x, xw))
+    if kind == "wpd_ldb":
+        n = w["n"]
+        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
+        xw = wx.jl_empty((n, L + 1, B), td, dev)
+        qq, qp, Fq = qmf_arg(wt)
+        labels = [i % 4 for i in range(B)]
+        state = {}
+
+        def inv():      # the transform leg
+            D._call("wx_wpd1d", "_f64", A(x).ptr, A(xw).ptr, n, L, B, qp, Fq, A(x).stream())
+
+        def fwd():      # class energy maps of the whole table
+            state["G"] = wx.energy_map(xw, labels)
+
+        inv()
+
+        def check():
+            g = state["G"]
+            s = float(g[:, 0, :].sum().item())                       # root column: energies sum to 1 per class
+            return abs(s - 4.0) / 4.0
+        return fwd, inv, check, dict(fwd_bytes=es * (n * (L + 1)) * (B + 4), inv_bytes=es * n * (L + 2) * B,
+                                     fwd_flops=2.0 * n * (L + 1) * B, samples=n * B, bound="hbm", keep=(x, xw))
     if kind == "acwpd_jbb":
         n = w["n"]
         x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)

@@ -272,6 +272,30 @@ int wx_threshold_f32(float *X, int64_t n, int64_t k, int64_t batch, int th_kind,
                      int64_t row_lo, const uint8_t *colmask, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Local Discriminant Basis, the batch-sized steps -- SURVEY 8(f) row 2.
+ * wx_energy_map_*: energy_map(Xw, y, TimeFrequency()) ldb/ldb_energymap.jl:109-141.  Xw is a packet table
+ * (n, k, N) or (m, n, k, N) passed flat: nk = elements per signal, nroot = elements of the root column/slice
+ * (n or m*n), cls[i] in [0, nc) = index of signal i's class in unique(y) order.  Gamma (nk, nc):
+ * Gamma[e, c] = sum_{i in c} Xw[e, i]^2 / sum_{i in c} norm(x_i)^2.
+ * wx_class_mean_* / wx_class_var_*: per-class mean and variance (two passes, n-1 denominator, like Julia's
+ * mean / var over the signal axis) of X (nk, N) for FishersClassSeparability, ldb/ldb_measures.jl:441-479.
+ * The rest of fitdec! (LDB.jl:186-251: discriminant measure on the small class maps, node costs with top_k,
+ * wx_treeselect_* with type max, ordering) is host logic on small arrays; the feature gather of transform
+ * (LDB.jl:300-305) is wx_wpt*_ / wx_getbasiscoef* plus an index selection.  Pointers may be host or device,
+ * cls is a host array.
+ * ------------------------------------------------------------------------------------------ */
+int wx_energy_map_f64(const double *Xw, int64_t nk, int64_t nroot, int64_t N, const int32_t *cls, int nc, double *Gamma,
+                      void *stream);
+int wx_energy_map_f32(const float *Xw, int64_t nk, int64_t nroot, int64_t N, const int32_t *cls, int nc, float *Gamma,
+                      void *stream);
+int wx_class_mean_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *mean, void *stream);
+int wx_class_mean_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, float *mean, void *stream);
+int wx_class_var_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, const double *mean, double *var,
+                     void *stream);
+int wx_class_var_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, const float *mean, float *var,
+                     void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Multi-GPU exchange (one process per GPU, RCCL over xGMI; bound lazily, single-GPU callers never
  * load RCCL).  Transforms shard over the batch (last) dimension with no collective: the loops
  * dwt/dwt_all.jl:277-279, swt/swt_all.jl:171-173, acwt/acwt_all.jl:254-256 are independent per

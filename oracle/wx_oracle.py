@@ -665,3 +665,115 @@ def denoise(x, inputtype, qmf, L=None, tree=None, th="hard", t=None, estnoise=No
     if inputtype == "swpd":
         return xt if qmf is None else iswpd(xt, qmf, tree)
     return iacwpd(xt, tree)
+
+
+# ---- Local Discriminant Basis, TimeFrequency energy map (LDB.jl:186-251, ldb/ldb_energymap.jl:109-141,
+# ---- ldb/ldb_measures.jl:139-183, 302-325, 427-479): plain loops in the reference's order ------------
+def _unique(y):
+    out = []
+    for v in list(np.asarray(y).tolist()):
+        if v not in out:
+            out.append(v)
+    return out
+
+
+def ldb_energy_map(Xw, y):
+    Xw = _f(Xw)
+    N = Xw.ndim
+    classes = _unique(y)
+    sz, L = Xw.shape[:N - 2], Xw.shape[N - 2]
+    G = np.empty(tuple(sz) + (L, len(classes)), dtype=Xw.dtype, order="F")
+    yl = list(np.asarray(y).tolist())
+    for ci, c in enumerate(classes):
+        idx = [i for i, v in enumerate(yl) if v == c]
+        norm_sum = Xw.dtype.type(0)
+        en = np.zeros(tuple(sz) + (L,), dtype=Xw.dtype, order="F")
+        for i in idx:
+            root = Xw[..., 0, i]
+            acc = Xw.dtype.type(0)
+            for v in root.ravel(order="F"):
+                acc = Xw.dtype.type(acc + v * v)
+            nrm = Xw.dtype.type(np.sqrt(acc))
+            norm_sum = Xw.dtype.type(norm_sum + nrm * nrm)
+            en = (en + Xw[..., i] * Xw[..., i]).astype(Xw.dtype)
+        G[..., ci] = en / norm_sum
+    return G
+
+
+def _ldb_pair(p, q, dm, lp=2):
+    if dm == "are":
+        return 0.0 if (p == 0 or q == 0) else p * np.log(p / q)
+    if dm == "sre":
+        return _ldb_pair(p, q, "are") + _ldb_pair(q, p, "are")
+    if dm == "hellinger":
+        return (np.sqrt(p) - np.sqrt(q)) ** 2
+    return (p - q) ** lp
+
+
+def ldb_discriminant_measure(G, dm="are", lp=2):
+    G = _f(G)
+    nc = G.shape[-1]
+    D = np.zeros(G.shape[:-1], dtype=G.dtype, order="F")
+    flat = D.reshape(-1, order="F")
+    for i in range(nc):
+        for j in range(i + 1, nc):
+            gi, gj = G[..., i].reshape(-1, order="F"), G[..., j].reshape(-1, order="F")
+            for e in range(flat.size):
+                flat[e] = G.dtype.type(flat[e] + G.dtype.type(_ldb_pair(gi[e], gj[e], dm, lp)))
+    return np.asfortranarray(flat.reshape(D.shape, order="F"))
+
+
+def ldb_fitdec(Xw, y, dm="are", lp=2, top_k=None, dp="basis"):
+    """fitdec! -> dict(G, DM, cost, tree, DP, order) with 1-based `order`"""
+    Xw = _f(Xw)
+    sz, L = Xw.shape[:-2], Xw.shape[-2]
+    nelem = int(np.prod(sz))
+    top_k = nelem if top_k is None else top_k
+    G = ldb_energy_map(Xw, y)
+    DM = ldb_discriminant_measure(G, dm, lp)
+    one_d = len(sz) == 1
+    ncost = (1 << L) - 1 if one_d else ((1 << (2 * L)) - 1) // 3
+    cost = np.empty(ncost, dtype=Xw.dtype)
+    for i in range(1, ncost + 1):
+        d = getdepth(i, "binary" if one_d else "quad")
+        if one_d:
+            th, nth = i - (1 << d), sz[0] >> d
+            v = list(DM[th * nth:(th + 1) * nth, d])
+        else:
+            r0, r1 = getrowrange(sz[0], i)
+            c0, c1 = getcolrange(sz[1], i)
+            v = list(DM[r0 - 1:r1, c0 - 1:c1, d].ravel(order="F"))
+        if top_k < len(v):
+            v = sorted(v, reverse=True)[:top_k]
+        s = Xw.dtype.type(0)
+        for x in v:
+            s = Xw.dtype.type(s + x)
+        cost[i - 1] = s
+    tree = bestbasis_treeselection(cost, sz[0], "max") if one_d else bestbasis_treeselection2d(cost, sz[0], sz[1], "max")
+    if dp == "basis":
+        power = getbasiscoef(DM, tree) if one_d else getbasiscoef2d(DM, tree)
+    else:
+        Xc = np.asfortranarray(np.stack([(getbasiscoef if one_d else getbasiscoef2d)(np.asfortranarray(Xw[..., i]), tree)
+                                         for i in range(Xw.shape[-1])], axis=-1))
+        power = ldb_fisher_power(Xc, y)
+    order = np.argsort(-power.ravel(order="F"), kind="stable") + 1
+    return dict(G=G, DM=DM, cost=cost, tree=tree, DP=power, order=order)
+
+
+def ldb_fisher_power(coefs, y):
+    coefs = _f(coefs)
+    classes = _unique(y)
+    yl = list(np.asarray(y).tolist())
+    sz = coefs.shape[:-1]
+    E = np.empty(tuple(sz) + (len(classes),), dtype=coefs.dtype)
+    V = np.empty_like(E)
+    Ni = np.empty(len(classes), dtype=coefs.dtype)
+    for ci, c in enumerate(classes):
+        idx = [i for i, v in enumerate(yl) if v == c]
+        Ni[ci] = len(idx)
+        sub = coefs[..., idx]
+        E[..., ci] = sub.mean(axis=-1)
+        V[..., ci] = sub.var(axis=-1, ddof=1)
+    Ea = E.mean(axis=-1, keepdims=True)
+    p = Ni / Ni.sum()
+    return np.asfortranarray((((E - Ea * E) ** 2) * p).sum(axis=-1) / (V * p).sum(axis=-1))

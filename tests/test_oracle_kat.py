@@ -383,3 +383,26 @@ def test_denoise_core_oracle(oracle):
     c = np.full(16, 2.0)
     q = np.array([1.0, 1.0]) / np.sqrt(2.0)
     assert np.allclose(oracle.denoise(c, "sig", q), c)
+
+
+def test_ldb_oracle_closed_forms(oracle):
+    """LDB with the TimeFrequency energy map (ldb_energymap.jl:109-141, ldb_measures.jl:302-325): hand values"""
+    import numpy as np
+    # two classes, two signals each, n = 2, packet table with a single extra level (Haar)
+    X = np.asfortranarray(np.array([[1.0, 1.0, 2.0, 0.0], [1.0, 1.0, 0.0, 2.0]]))          # (n, N)
+    y = ["p", "p", "q", "q"]
+    q = np.array([1.0, 1.0]) / np.sqrt(2.0)
+    Xw = oracle.wpdall(X, q, 1)                                                          # (2, 2, 4)
+    G = oracle.ldb_energy_map(Xw, y)
+    # class p: signals (1,1),(1,1): energy per coefficient 2, norm sum 4 -> 0.5; level 1: (sqrt2, 0) -> (1, 0)
+    assert np.allclose(G[:, :, 0], [[0.5, 1.0], [0.5, 0.0]])
+    # class q: (2,0),(0,2): level 0 energies (4,4)/8; level 1: (sqrt2, sqrt2) and (sqrt2,-sqrt2) -> (4, 4)/8
+    assert np.allclose(G[:, :, 1], [[0.5, 0.5], [0.5, 0.5]])
+    D = oracle.ldb_discriminant_measure(G, "are")
+    assert np.allclose(D, [[0.0, np.log(2.0)], [0.0, 0.0]])                               # p log(p/q), 0 when p or q is 0
+    assert np.allclose(oracle.ldb_discriminant_measure(G, "hellinger"),
+                       [[0.0, (1 - np.sqrt(0.5)) ** 2], [0.0, 0.5]])
+    r = oracle.ldb_fitdec(Xw, y)
+    assert np.allclose(r["cost"], [0.0, np.log(2.0), 0.0])
+    assert r["tree"].tolist() == [True]                                                  # children (log 2) beat the root (0)
+    assert r["order"][0] == 1                                                            # the scaling coefficient discriminates

@@ -26,3 +26,7 @@ from .bestbasis import (JBB, LoglpCost, NormCost, tree_costs, bestbasistree, bes
                         BB, ShannonEntropyCost, LogEnergyEntropyCost, bestbasistreeall)
 from .denoising import (HardTH, SoftTH, SemiSoftTH, SteinTH, VisuShrink, noisest, threshold, denoise,   # noqa: F401,E402
                         denoiseall)
+from .ldb import (TimeFrequency, AsymmetricRelativeEntropy, SymmetricRelativeEntropy, LpDistance,        # noqa: F401,E402
+                  HellingerDistance, BasisDiscriminantMeasure, FishersClassSeparability, energy_map,
+                  discriminant_measure, discriminant_power, LocalDiscriminantBasis, fit_, fitdec_, transform,
+                  fit_transform, inverse_transform, change_nfeatures)

@@ -101,8 +101,6 @@ _EXTRA_SIGS = {
     "wx_jbb_moments": [_P, _P, _P, _L, _L, _I, _P],
     "wx_jbb_costs": [_P, _P, _L, _L, _L, _I, _I, ctypes.c_double, _P, _P],
     "wx_acwpd_jbb_moments": [_P, _P, _P, _L, _I, _L, _P, _I, _I, _P],
-    "wx_wpd_jbb_moments": [_P, _P, _P, _L, _I, _L, _P, _I, _I, _P],
-    "wx_swpd_jbb_moments": [_P, _P, _P, _L, _I, _L, _P, _I, _I, _P],
 }
 _PLAIN_SIGS = {
     "wx_treeselect_f64": [_P, _L, _L, _I, _P],
@@ -110,6 +108,12 @@ _PLAIN_SIGS = {
     "wx_treeselect2d_f64": [_P, _L, _L, _L, _I, _P],
     "wx_treeselect2d_f32": [_P, _L, _L, _L, _I, _P],
     "wx_shutdown": [],
+    "wx_energy_map_f64": [_P, _L, _L, _L, _P, _I, _P, _P],
+    "wx_energy_map_f32": [_P, _L, _L, _L, _P, _I, _P, _P],
+    "wx_class_mean_f64": [_P, _L, _L, _P, _I, _P, _P],
+    "wx_class_mean_f32": [_P, _L, _L, _P, _I, _P, _P],
+    "wx_class_var_f64": [_P, _L, _L, _P, _I, _P, _P, _P],
+    "wx_class_var_f32": [_P, _L, _L, _P, _I, _P, _P, _P],
     "wx_noisest_f64": [_P, _L, _L, _L, _L, _L, _P, _P],
     "wx_noisest_f32": [_P, _L, _L, _L, _L, _L, _P, _P],
     "wx_threshold_f64": [_P, _L, _L, _L, _I, _P, _L, _L, _P, _P],

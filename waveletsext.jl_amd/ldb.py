@@ -1,0 +1,279 @@
+"""Local Discriminant Basis: host-side mirror of the reference's `LDB` module (src/mod/LDB.jl,
+ldb/ldb_energymap.jl, ldb/ldb_measures.jl) for the TimeFrequency energy map.  SURVEY section 8(f) row 2.
+
+The batch-sized steps run on the device: the packet decomposition (`wpdall`), the class energy maps
+(`wx_energy_map_*`), the class means / variances for Fisher's separability (`wx_class_mean_*`, `wx_class_var_*`),
+the basis gather (`getbasiscoefall` / `wptall`) and the inverse (`iwptall`).  The discriminant measure, the node
+costs with top_k, the (host) tree selection and the ordering work on the small (n, levels, classes) maps.
+ProbabilityDensity / Signatures energy maps (kernel density estimates), EarthMoverDistance and
+RobustFishersClassSeparability (medians over the signal axis) are not on the device path and raise."""
+import ctypes
+import itertools
+
+import numpy as np
+
+from . import _lib
+from ._arrays import Arg, to_numpy
+from .bestbasis import bestbasis_treeselection
+from .dwt import getbasiscoef, getbasiscoefall, iwptall, wpdall, wptall
+from .filters import ArgumentError, WT, wavelet
+from .util import getdepth, gettreelength, isvalidtree, maxtransformlevels, nodelength, getrowrange, getcolrange
+
+
+class TimeFrequency:
+    """ldb_energymap.jl:21"""
+
+
+class AsymmetricRelativeEntropy:
+    """ldb_measures.jl:43"""
+
+
+class SymmetricRelativeEntropy:
+    """ldb_measures.jl:62"""
+
+
+class LpDistance:
+    """ldb_measures.jl:74-76"""
+
+    def __init__(self, p=2):
+        self.p = p
+
+
+class HellingerDistance:
+    """ldb_measures.jl:88"""
+
+
+class BasisDiscriminantMeasure:
+    """ldb_measures.jl:378"""
+
+
+class FishersClassSeparability:
+    """ldb_measures.jl:389"""
+
+
+def _classes(y):
+    """unique(y) in first-occurrence order (Julia's unique) -> (classes, int32 class index per signal)"""
+    y = list(np.asarray(y).tolist())
+    classes, idx = [], np.empty(len(y), dtype=np.int32)
+    for i, v in enumerate(y):
+        if v not in classes:
+            classes.append(v)
+        idx[i] = classes.index(v)
+    return classes, idx
+
+
+def energy_map(Xw, y, method=None):
+    """energy_map(Xw, y, TimeFrequency()) ldb_energymap.jl:109-141 -> Gamma (sz..., L, nc)"""
+    method = TimeFrequency() if method is None else method
+    if not isinstance(method, TimeFrequency):
+        raise _lib.WxError(_lib.WX_EUNSUPPORTED, "only the TimeFrequency energy map is on the device path")
+    Xa = Arg(Xw)
+    N = Xa.arr.ndim
+    assert 3 <= N <= 4
+    classes, idx = _classes(y)
+    nc = len(classes)
+    sz, L, Nx = Xa.shape[:N - 2], Xa.shape[N - 2], Xa.shape[N - 1]
+    assert Nx == idx.size
+    assert nc > 1
+    assert 1 <= L - 1 <= maxtransformlevels(int(min(sz)))
+    nroot = int(np.prod(sz, dtype=np.int64))
+    G = Xa.new(tuple(sz) + (L, nc))
+    fn = getattr(_lib.lib(), "wx_energy_map" + Xa.suffix)
+    _lib.check(fn(Xa.ptr, nroot * L, nroot, Nx, ctypes.c_void_p(idx.ctypes.data), nc, G.ptr, Xa.stream()))
+    return G.arr
+
+
+def _pair(p, q, dm):
+    """pairwise_discriminant_measure(p, q, dm) elementwise, ldb_measures.jl:302-325"""
+    if isinstance(dm, AsymmetricRelativeEntropy):
+        assert (p >= 0).all() and (q >= 0).all()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r = p * np.log(p / q)
+        return np.where((p == 0) | (q == 0), 0.0, r).astype(p.dtype)
+    if isinstance(dm, SymmetricRelativeEntropy):
+        return _pair(p, q, AsymmetricRelativeEntropy()) + _pair(q, p, AsymmetricRelativeEntropy())
+    if isinstance(dm, HellingerDistance):
+        return (np.sqrt(p) - np.sqrt(q)) ** 2
+    if isinstance(dm, LpDistance):
+        return (p - q) ** dm.p
+    raise _lib.WxError(_lib.WX_EUNSUPPORTED, "discriminant measure not supported on this path")
+
+
+def discriminant_measure(G, dm=None):
+    """discriminant_measure(Gamma, dm) ldb_measures.jl:139-183 for time-frequency maps: sum over class pairs"""
+    dm = AsymmetricRelativeEntropy() if dm is None else dm
+    G = to_numpy(G)
+    nc = G.shape[-1]
+    assert 3 <= G.ndim <= 4 and nc > 1
+    D = np.zeros(G.shape[:-1], dtype=G.dtype, order="F")
+    for i, j in itertools.combinations(range(nc), 2):
+        D = D + _pair(G[..., i], G[..., j], dm)
+    return np.asfortranarray(D)
+
+
+def _node_costs(DM, sz, L, top_k):
+    """LDB.jl:218-240"""
+    one_d = len(sz) == 1
+    ncost = gettreelength(1 << L) if one_d else gettreelength(1 << L, 1 << L)
+    cost = np.empty(ncost, dtype=DM.dtype)
+    for i in range(1, ncost + 1):
+        d = getdepth(i, "binary" if one_d else "quad")
+        if one_d:
+            th = i - (1 << d)
+            nth = nodelength(sz[0], d)
+            v = DM[th * nth:(th + 1) * nth, d]
+        else:
+            r, c = getrowrange(sz[0], i), getcolrange(sz[1], i)
+            v = DM[r[0] - 1:r[-1], c[0] - 1:c[-1], d].ravel(order="F")
+        if top_k < v.size:
+            v = np.sort(v)[::-1][:top_k]
+        s = DM.dtype.type(0)
+        for x in v:                                  # sum(...) in element order
+            s = DM.dtype.type(s + x)
+        cost[i - 1] = s
+    return cost
+
+
+def discriminant_power(a, b, dp=None):
+    """discriminant_power(D, tree, BasisDiscriminantMeasure()) ldb_measures.jl:427-438, or
+    discriminant_power(coefs, y, FishersClassSeparability()) :441-479 -> (power, order) with 1-based order"""
+    dp = BasisDiscriminantMeasure() if dp is None else dp
+    if isinstance(dp, BasisDiscriminantMeasure):
+        D, tree = to_numpy(a), np.asarray(b, dtype=bool)
+        assert 2 <= D.ndim <= 3
+        assert isvalidtree(np.empty(D.shape[:-1]), tree)
+        power = to_numpy(getbasiscoef(D, tree))
+    elif isinstance(dp, FishersClassSeparability):
+        Xa = Arg(a)
+        assert 2 <= Xa.arr.ndim <= 3
+        classes, idx = _classes(b)
+        nc = len(classes)
+        sz, N = Xa.shape[:-1], Xa.shape[-1]
+        ne = int(np.prod(sz, dtype=np.int64))
+        mean = Xa.new(tuple(sz) + (nc,))
+        var = Xa.new(tuple(sz) + (nc,))
+        cp = ctypes.c_void_p(idx.ctypes.data)
+        _lib.check(getattr(_lib.lib(), "wx_class_mean" + Xa.suffix)(Xa.ptr, ne, N, cp, nc, mean.ptr, Xa.stream()))
+        _lib.check(getattr(_lib.lib(), "wx_class_var" + Xa.suffix)(Xa.ptr, ne, N, cp, nc, mean.ptr, var.ptr, Xa.stream()))
+        E, V = to_numpy(mean.arr), to_numpy(var.arr)
+        Ni = np.array([(idx == c).sum() for c in range(nc)], dtype=E.dtype)
+        Ea = E.mean(axis=-1, keepdims=True)
+        p = Ni / Ni.sum()
+        power = (((E - Ea * E) ** 2) * p).sum(axis=-1) / (V * p).sum(axis=-1)        # :472-477
+    else:
+        raise _lib.WxError(_lib.WX_EUNSUPPORTED, "RobustFishersClassSeparability is not on the device path")
+    order = np.argsort(-power.ravel(order="F"), kind="stable") + 1                 # sortperm(vec(power), rev=true)
+    return np.asfortranarray(power), order
+
+
+class LocalDiscriminantBasis:
+    """LocalDiscriminantBasis LDB.jl:92-111 (TimeFrequency energy map)"""
+
+    def __init__(self, wt=None, max_dec_level=None, dm=None, en=None, dp=None, top_k=None, n_features=None):
+        self.wt = wavelet(WT.haar) if wt is None else wt
+        self.max_dec_level = max_dec_level
+        self.dm = AsymmetricRelativeEntropy() if dm is None else dm
+        self.en = TimeFrequency() if en is None else en
+        self.dp = BasisDiscriminantMeasure() if dp is None else dp
+        self.top_k = top_k
+        self.n_features = n_features
+        self.sz = self.G = self.DM = self.cost = self.tree = self.DP = self.order = None
+
+
+def fitdec_(f, Xw, y):
+    """fitdec!(f, Xw, y) LDB.jl:186-251"""
+    Xa = Arg(Xw)
+    assert 3 <= Xa.arr.ndim <= 4
+    classes, _ = _classes(y)
+    nc = len(classes)
+    f.sz = tuple(Xa.shape[:-2])
+    L, Nx = Xa.shape[-2], Xa.shape[-1]
+    nelem = int(np.prod(f.sz, dtype=np.int64))
+    f.top_k = nelem if f.top_k is None else f.top_k
+    f.n_features = nelem if f.n_features is None else f.n_features
+    f.max_dec_level = L - 1 if f.max_dec_level is None else f.max_dec_level
+    assert Nx == len(y)
+    assert 1 <= f.top_k <= nelem
+    assert 1 <= f.n_features <= nelem
+    assert f.max_dec_level + 1 == L
+    assert 1 <= f.max_dec_level <= maxtransformlevels(int(min(f.sz)))
+    assert nc > 1
+    f.G = energy_map(Xa.arr, y, f.en)
+    f.DM = discriminant_measure(f.G, f.dm)
+    f.cost = _node_costs(f.DM, f.sz, L, f.top_k)
+    f.tree = bestbasis_treeselection(f.cost, *f.sz, "max")
+    if isinstance(f.dp, BasisDiscriminantMeasure):
+        f.DP, f.order = discriminant_power(f.DM, f.tree, f.dp)
+    else:
+        f.DP, f.order = discriminant_power(getbasiscoefall(Xa.arr, f.tree), y, f.dp)
+    return None
+
+
+def fit_(f, X, y):
+    """fit!(f, X, y) LDB.jl:139-156"""
+    Xa = Arg(X)
+    assert 2 <= Xa.arr.ndim <= 3
+    L = maxtransformlevels(int(min(Xa.shape[:-1])))
+    f.max_dec_level = L if f.max_dec_level is None else f.max_dec_level
+    assert 1 <= f.max_dec_level <= L
+    fitdec_(f, wpdall(Xa.arr, f.wt, f.max_dec_level), y)
+    return None
+
+
+def _select(Xb, order, nfeat):
+    """rows order[0:nfeat] (1-based, column-major linear index into a signal) of every signal -> (nfeat, N)"""
+    flat = Xb.reshape((-1, Xb.shape[-1]), order="F") if isinstance(Xb, np.ndarray) else None
+    if flat is not None:
+        return np.asfortranarray(flat[order[:nfeat] - 1, :])
+    import torch
+    N = Xb.shape[-1]
+    t = Xb.permute(*reversed(range(Xb.dim()))).reshape(N, -1)          # (N, elements) view of the column-major data
+    sel = torch.as_tensor(order[:nfeat] - 1, device=Xb.device, dtype=torch.long)
+    return t.index_select(1, sel).t()                                  # (nfeat, N), column-major strides
+
+
+def transform(f, X):
+    """transform(f, X) LDB.jl:277-306"""
+    Xa = Arg(X)
+    assert 2 <= Xa.arr.ndim <= 3
+    for v in (f.max_dec_level, f.top_k, f.n_features, f.sz, f.G, f.DM, f.cost, f.tree, f.DP, f.order):
+        assert v is not None
+    assert tuple(Xa.shape[:-1]) == tuple(f.sz)
+    return _select(wptall(Xa.arr, f.wt, f.tree), f.order, f.n_features)
+
+
+def fit_transform(f, X, y):
+    """fit_transform(f, X, y) LDB.jl:339-358"""
+    Xa = Arg(X)
+    assert 2 <= Xa.arr.ndim <= 3
+    sz = Xa.shape[:-1]
+    f.max_dec_level = maxtransformlevels(int(min(sz))) if f.max_dec_level is None else f.max_dec_level
+    assert 1 <= f.max_dec_level <= maxtransformlevels(int(min(sz)))
+    Xw = wpdall(Xa.arr, f.wt, f.max_dec_level)
+    fitdec_(f, Xw, y)
+    return _select(getbasiscoefall(Xw, f.tree), f.order, f.n_features)
+
+
+def inverse_transform(f, X):
+    """inverse_transform(f, X) LDB.jl:388-401"""
+    Xn = to_numpy(X)
+    assert Xn.shape[0] == f.n_features
+    N = Xn.shape[1]
+    Xc = np.zeros((int(np.prod(f.sz, dtype=np.int64)), N), dtype=Xn.dtype, order="F")
+    Xc[f.order[:f.n_features] - 1, :] = Xn
+    return iwptall(np.asfortranarray(Xc.reshape(tuple(f.sz) + (N,), order="F")), f.wt, f.tree)
+
+
+def change_nfeatures(f, x, n_features):
+    """change_nfeatures(f, x, n_features) LDB.jl:433-448"""
+    assert f.n_features is not None
+    xn = to_numpy(x)
+    if xn.shape[0] != f.n_features:
+        raise ArgumentError("f.n_features and number of rows of x do not match!")
+    assert 1 <= n_features <= int(np.prod(f.sz, dtype=np.int64))
+    if f.n_features >= n_features:
+        f.n_features = n_features
+        return np.asfortranarray(xn[:n_features, :])
+    X = inverse_transform(f, xn)
+    f.n_features = n_features
+    return transform(f, X)
