@@ -276,7 +276,9 @@ int wx_threshold_f32(float *X, int64_t n, int64_t k, int64_t batch, int th_kind,
  * wx_energy_map_*: energy_map(Xw, y, TimeFrequency()) ldb/ldb_energymap.jl:109-141.  Xw is a packet table
  * (n, k, N) or (m, n, k, N) passed flat: nk = elements per signal, nroot = elements of the root column/slice
  * (n or m*n), cls[i] in [0, nc) = index of signal i's class in unique(y) order.  Gamma (nk, nc):
- * Gamma[e, c] = sum_{i in c} Xw[e, i]^2 / sum_{i in c} norm(x_i)^2.
+ * Gamma[e, c] = sum_{i in c} Xw[e, i]^2 / sum_{i in c} norm(x_i)^2.  norm_sum (nc entries, may be NULL) returns the
+ * denominators: a batch sharded over GPUs combines its shards as sum_r Gamma_r * norm_sum_r / sum_r norm_sum_r
+ * (two all-reduces of small arrays); with norm_sum given a class may be empty on this shard (its Gamma is NaN).
  * wx_class_mean_* / wx_class_var_*: per-class mean and variance (two passes, n-1 denominator, like Julia's
  * mean / var over the signal axis) of X (nk, N) for FishersClassSeparability, ldb/ldb_measures.jl:441-479.
  * The rest of fitdec! (LDB.jl:186-251: discriminant measure on the small class maps, node costs with top_k,
@@ -285,9 +287,9 @@ int wx_threshold_f32(float *X, int64_t n, int64_t k, int64_t batch, int th_kind,
  * cls is a host array.
  * ------------------------------------------------------------------------------------------ */
 int wx_energy_map_f64(const double *Xw, int64_t nk, int64_t nroot, int64_t N, const int32_t *cls, int nc, double *Gamma,
-                      void *stream);
+                      double *norm_sum, void *stream);
 int wx_energy_map_f32(const float *Xw, int64_t nk, int64_t nroot, int64_t N, const int32_t *cls, int nc, float *Gamma,
-                      void *stream);
+                      float *norm_sum, void *stream);
 int wx_class_mean_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *mean, void *stream);
 int wx_class_mean_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, float *mean, void *stream);
 int wx_class_var_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, const double *mean, double *var,

@@ -66,6 +66,19 @@ def _worker(rank, world, port, B, out_dir):
                 costs.append(2 * np.log(np.abs(sig[node * n0:(node + 1) * n0, lvl])).sum())
         tree = wx.bestbasis_treeselection(np.array(costs), n)
         assert (tree == wo.bestbasistree_jbb(Y)).all()
+        # LDB energy maps of a sharded batch: per-shard maps + norm sums, two small all-reduces
+        labels = [("u", "v", "w")[i % 3] if i > 0 else "w" for i in range(B)]      # rank-dependent class mix
+        classes = wo._unique(labels)
+        yl_lab = labels[lo:hi]
+        Gr = np.full((n, Y.shape[1], len(classes)), np.nan)
+        nsr = np.zeros(len(classes))
+        for ci, c in enumerate(classes):
+            idx = [i for i, v in enumerate(yl_lab) if v == c]
+            if idx:
+                nsr[ci] = sum(float(np.sqrt((xl[:, i] ** 2).sum())) ** 2 for i in idx)
+                Gr[:, :, ci] = (yl[:, :, idx] ** 2).sum(axis=2) / nsr[ci]
+        Gfull = wd.combine_energy_maps(np.asfortranarray(Gr), nsr)
+        np.testing.assert_allclose(Gfull, wo.ldb_energy_map(Y, labels), rtol=1e-12, atol=1e-14)
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()

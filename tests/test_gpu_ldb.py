@@ -91,3 +91,20 @@ def test_ldb_2d(wx, oracle):
     assert relerr(f.cost, exp["cost"]) <= 1e-9
     assert (f.tree == exp["tree"]).all() and (f.order[:12] == exp["order"][:12]).all()
     assert Xc.shape == (12, X.shape[-1])
+
+
+def test_energy_map_shards_combine(wx, oracle):
+    """the multi-GPU formula on one GPU: maps + norm sums of two shards (one of them missing a class) combine to the
+    map of the whole batch"""
+    rng = np.random.default_rng(6004)
+    X, y = _classdata(rng, 32, 4, np.float64)
+    order = np.argsort([{"a": 0, "b": 1, "c": 2}[v] for v in y], kind="stable")    # shard 0 = classes a, b only
+    X, y = np.asfortranarray(X[:, order]), [y[i] for i in order]
+    Xw = wx.wpdall(X, wx.wavelet(wx.WT.db2))
+    classes = ["a", "b", "c"]
+    cut = 8
+    G0, n0 = wx.energy_map(Xw[:, :, :cut], y[:cut], classes=classes, return_norm_sum=True)
+    G1, n1 = wx.energy_map(Xw[:, :, cut:], y[cut:], classes=classes, return_norm_sum=True)
+    assert n0[2] == 0 and np.isnan(G0[:, :, 2]).all()
+    comb = (np.nan_to_num(G0) * n0 + np.nan_to_num(G1) * n1) / (n0 + n1)
+    assert relerr(comb, wx.energy_map(Xw, y)) <= 1e-12

@@ -108,8 +108,8 @@ _PLAIN_SIGS = {
     "wx_treeselect2d_f64": [_P, _L, _L, _L, _I, _P],
     "wx_treeselect2d_f32": [_P, _L, _L, _L, _I, _P],
     "wx_shutdown": [],
-    "wx_energy_map_f64": [_P, _L, _L, _L, _P, _I, _P, _P],
-    "wx_energy_map_f32": [_P, _L, _L, _L, _P, _I, _P, _P],
+    "wx_energy_map_f64": [_P, _L, _L, _L, _P, _I, _P, _P, _P],
+    "wx_energy_map_f32": [_P, _L, _L, _L, _P, _I, _P, _P, _P],
     "wx_class_mean_f64": [_P, _L, _L, _P, _I, _P, _P],
     "wx_class_mean_f32": [_P, _L, _L, _P, _I, _P, _P],
     "wx_class_var_f64": [_P, _L, _L, _P, _I, _P, _P, _P],

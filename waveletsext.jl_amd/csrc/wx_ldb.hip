@@ -104,7 +104,7 @@ int need_device()
     return WX_OK;
 }
 
-int check_labels(const int32_t *cls, int64_t N, int nc)
+int check_labels(const int32_t *cls, int64_t N, int nc, bool allow_empty)
 {
     WX_REQUIRE(cls != nullptr, WX_EARG, "class labels are NULL");
     WX_REQUIRE(nc > 1, WX_EASSERT, "@assert nc > 1 (ldb_energymap.jl:122)");
@@ -114,7 +114,7 @@ int check_labels(const int32_t *cls, int64_t N, int nc)
         WX_REQUIRE(cls[i] >= 0 && cls[i] < nc, WX_EARG, "class index outside [0, nc)");
         seen[(size_t)cls[i]] = 1;
     }
-    for (int c = 0; c < nc; ++c) WX_REQUIRE(seen[(size_t)c], WX_EARG, "a class has no signal");
+    if (!allow_empty) for (int c = 0; c < nc; ++c) WX_REQUIRE(seen[(size_t)c], WX_EARG, "a class has no signal");
     return WX_OK;
 }
 
@@ -133,10 +133,10 @@ int pick_chunks(int64_t nk, int64_t N)
 // mode 0: energy map (needs nroot), mode 1: class means, mode 2: class variances (needs mean)
 template <typename T>
 int api_class_reduce(const T *X, int64_t nk, int64_t nroot, int64_t N, const int32_t *cls, int nc, int mode,
-                     const T *mean, T *out, void *stream)
+                     const T *mean, T *out, T *den_out, void *stream)
 {
     WX_REQUIRE(nk >= 1 && N >= 1, WX_EARG, "bad dimensions");
-    int rc = check_labels(cls, N, nc);
+    int rc = check_labels(cls, N, nc, den_out != nullptr);      // a shard of a multi-GPU batch may miss a class
     if (rc) return rc;
     if ((rc = need_device())) return rc;
     hipStream_t st = wx_stream(stream);
@@ -145,7 +145,8 @@ int api_class_reduce(const T *X, int64_t nk, int64_t nroot, int64_t N, const int
     const T *dX = (const T *)io.in(X, sizeof(T) * nk * N);
     T *dout = (T *)io.out(out, sizeof(T) * nk * nc);
     const T *dmean = mode == 2 ? (const T *)io.in(mean, sizeof(T) * nk * nc) : nullptr;
-    if (!dX || !dout || (mode == 2 && !dmean)) return io.finish(WX_EHIP);
+    T *dden = den_out ? (T *)io.out(den_out, sizeof(T) * nc) : nullptr;
+    if (!dX || !dout || (mode == 2 && !dmean) || (den_out && !dden)) return io.finish(WX_EHIP);
     const int *dcls = (const int *)scr.upload(cls, sizeof(int32_t) * (size_t)N);
     if (!dcls) return io.finish(WX_EHIP);
     const int nchunks = pick_chunks(nk, N);
@@ -166,6 +167,8 @@ int api_class_reduce(const T *X, int64_t nk, int64_t nroot, int64_t N, const int
                        N, dcls, nc, chunk, mode, dmean, partial);
     hipLaunchKernelGGL(k_ldb_class_combine<T>, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const T *)partial, nk, nc,
                        nchunks, (const T *)(mode == 0 ? den : count), mode == 2 ? 1 : 0, dout);
+    if (dden && hipMemcpyAsync(dden, mode == 0 ? den : count, sizeof(T) * nc, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return io.finish(wx_set_error(WX_EHIP, "copy of the class denominators"));
     if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "LDB reduction kernels failed to launch"));
     return io.finish(WX_OK);
 }
@@ -173,16 +176,18 @@ int api_class_reduce(const T *X, int64_t nk, int64_t nroot, int64_t N, const int
 }  // namespace
 
 extern "C" {
-int wx_energy_map_f64(const double *Xw, int64_t nk, int64_t nroot, int64_t N, const int32_t *cls, int nc, double *Gamma, void *stream)
-{ return api_class_reduce<double>(Xw, nk, nroot, N, cls, nc, 0, nullptr, Gamma, stream); }
-int wx_energy_map_f32(const float *Xw, int64_t nk, int64_t nroot, int64_t N, const int32_t *cls, int nc, float *Gamma, void *stream)
-{ return api_class_reduce<float>(Xw, nk, nroot, N, cls, nc, 0, nullptr, Gamma, stream); }
+int wx_energy_map_f64(const double *Xw, int64_t nk, int64_t nroot, int64_t N, const int32_t *cls, int nc, double *Gamma,
+                      double *norm_sum, void *stream)
+{ return api_class_reduce<double>(Xw, nk, nroot, N, cls, nc, 0, nullptr, Gamma, norm_sum, stream); }
+int wx_energy_map_f32(const float *Xw, int64_t nk, int64_t nroot, int64_t N, const int32_t *cls, int nc, float *Gamma,
+                      float *norm_sum, void *stream)
+{ return api_class_reduce<float>(Xw, nk, nroot, N, cls, nc, 0, nullptr, Gamma, norm_sum, stream); }
 int wx_class_mean_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *mean, void *stream)
-{ return api_class_reduce<double>(X, nk, 0, N, cls, nc, 1, nullptr, mean, stream); }
+{ return api_class_reduce<double>(X, nk, 0, N, cls, nc, 1, nullptr, mean, nullptr, stream); }
 int wx_class_mean_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, float *mean, void *stream)
-{ return api_class_reduce<float>(X, nk, 0, N, cls, nc, 1, nullptr, mean, stream); }
+{ return api_class_reduce<float>(X, nk, 0, N, cls, nc, 1, nullptr, mean, nullptr, stream); }
 int wx_class_var_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, const double *mean, double *var, void *stream)
-{ return api_class_reduce<double>(X, nk, 0, N, cls, nc, 2, mean, var, stream); }
+{ return api_class_reduce<double>(X, nk, 0, N, cls, nc, 2, mean, var, nullptr, stream); }
 int wx_class_var_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, const float *mean, float *var, void *stream)
-{ return api_class_reduce<float>(X, nk, 0, N, cls, nc, 2, mean, var, stream); }
+{ return api_class_reduce<float>(X, nk, 0, N, cls, nc, 2, mean, var, nullptr, stream); }
 }

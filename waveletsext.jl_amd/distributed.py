@@ -95,6 +95,29 @@ def acwpd_bestbasistree_sharded(x_local, wt, L, N_total, method=None, group=None
     return bb.bestbasis_treeselection(costs, x_local.shape[0])
 
 
+
+def combine_energy_maps(G_local, ns_local, group=None):
+    """LDB energy maps of a sharded batch (ldb_energymap.jl:109-141): Gamma = sum_r Gamma_r * ns_r / sum_r ns_r, where
+    ns_r are the shard's per-class norm sums (a class absent from a shard has ns_r = 0 and a NaN map, which counts
+    as zero).  Two small all-reduces; every rank gets the same maps."""
+    is_t = torch is not None and isinstance(G_local, torch.Tensor)
+    G = G_local if is_t else torch.from_numpy(np.ascontiguousarray(np.asarray(G_local)))
+    ns = torch.as_tensor(np.asarray(ns_local), dtype=G.dtype, device=G.device)
+    W = torch.nan_to_num(G, nan=0.0) * ns                              # classes are the last axis: broadcasts
+    W = W.contiguous()
+    dist.all_reduce(W, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(ns, op=dist.ReduceOp.SUM, group=group)
+    out = W / ns
+    return out if is_t else np.asfortranarray(out.numpy())
+
+
+def energy_map_sharded(Xw_local, y_local, classes, group=None):
+    """energy_map over a batch sharded across ranks: local class sums on the GPU, then combine_energy_maps"""
+    from . import ldb
+    G, ns = ldb.energy_map(Xw_local, y_local, classes=classes, return_norm_sum=True)
+    return combine_energy_maps(G, ns, group)
+
+
 # ---- the same two exchange steps through the library's own RCCL entry points ---------------------
 # (what a host without torch.distributed -- the Julia shim -- calls; include/waveletsext_hip.h "Multi-GPU
 # exchange").  The launcher only has to broadcast the 128-byte id from rank 0.

@@ -62,15 +62,21 @@ def _classes(y):
     return classes, idx
 
 
-def energy_map(Xw, y, method=None):
-    """energy_map(Xw, y, TimeFrequency()) ldb_energymap.jl:109-141 -> Gamma (sz..., L, nc)"""
+def energy_map(Xw, y, method=None, classes=None, return_norm_sum=False):
+    """energy_map(Xw, y, TimeFrequency()) ldb_energymap.jl:109-141 -> Gamma (sz..., L, nc).  `classes` fixes the class
+    order (a shard of a multi-GPU batch passes the global unique(y)); `return_norm_sum` also returns the per-class
+    denominators so that shards can be combined (distributed.energy_map_sharded)."""
     method = TimeFrequency() if method is None else method
     if not isinstance(method, TimeFrequency):
         raise _lib.WxError(_lib.WX_EUNSUPPORTED, "only the TimeFrequency energy map is on the device path")
     Xa = Arg(Xw)
     N = Xa.arr.ndim
     assert 3 <= N <= 4
-    classes, idx = _classes(y)
+    if classes is None:
+        classes, idx = _classes(y)
+    else:
+        classes = list(classes)
+        idx = np.array([classes.index(v) for v in list(np.asarray(y).tolist())], dtype=np.int32)
     nc = len(classes)
     sz, L, Nx = Xa.shape[:N - 2], Xa.shape[N - 2], Xa.shape[N - 1]
     assert Nx == idx.size
@@ -78,9 +84,11 @@ def energy_map(Xw, y, method=None):
     assert 1 <= L - 1 <= maxtransformlevels(int(min(sz)))
     nroot = int(np.prod(sz, dtype=np.int64))
     G = Xa.new(tuple(sz) + (L, nc))
+    ns = np.empty(nc, dtype=Xa.dtype) if return_norm_sum else None
     fn = getattr(_lib.lib(), "wx_energy_map" + Xa.suffix)
-    _lib.check(fn(Xa.ptr, nroot * L, nroot, Nx, ctypes.c_void_p(idx.ctypes.data), nc, G.ptr, Xa.stream()))
-    return G.arr
+    _lib.check(fn(Xa.ptr, nroot * L, nroot, Nx, ctypes.c_void_p(idx.ctypes.data), nc, G.ptr,
+                  ctypes.c_void_p(ns.ctypes.data) if ns is not None else ctypes.c_void_p(0), Xa.stream()))
+    return (G.arr, ns) if return_norm_sum else G.arr
 
 
 def _pair(p, q, dm):
