@@ -55,6 +55,21 @@ def test_no_cpu_fallback_without_gpu(wx):
     with pytest.raises(wx.WxError) as ei:
         wx.wpdall(np.zeros((8, 2)), wx.wavelet(wx.WT.haar))
     assert ei.value.code == -10
+    # every family fails the same way: there is no host implementation behind the API
+    wt = wx.wavelet(wx.WT.haar)
+    X3 = np.zeros((8, 4, 2))
+    calls = [
+        lambda: wx.wptall(np.zeros((8, 2)), wt), lambda: wx.iwptall(np.zeros((8, 2)), wt),
+        lambda: wx.swptall(np.zeros((8, 2)), wt, 2), lambda: wx.iswptall(np.zeros((8, 4, 2)), wt),
+        lambda: wx.acwpdall(np.zeros((8, 2)), wt, 2), lambda: wx.wptall(np.zeros((8, 8, 2)), wt, 1),
+        lambda: wx.bestbasistree(X3, wx.JBB()), lambda: wx.bestbasistreeall(X3, wx.BB()),
+        lambda: wx.denoiseall(np.zeros((8, 2)), "sig", wt), lambda: wx.noisest(np.zeros(8), False),
+        lambda: wx.energy_map(X3, [0, 1]), lambda: wx.acwpd_jbb_moments(np.zeros((8, 2)), wt),
+    ]
+    for c in calls:
+        with pytest.raises(wx.WxError) as ei:
+            c()
+        assert ei.value.code == -10
 
 
 def test_treeselect_host_routine_matches_oracle(wx, oracle):
