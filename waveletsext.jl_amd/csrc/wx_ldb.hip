@@ -56,30 +56,41 @@ __global__ __launch_bounds__(256) void k_ldb_class_sum(const T *__restrict__ v, 
     if (threadIdx.x == 0) { out[c] = (T)red[0]; count[c] = (T)redn[0]; }
 }
 
-// mode 0: partial[chunk][c][e] = sum over the chunk's signals of class c of X[e, i]^2
-// mode 1:                                                                     X[e, i]
-// mode 2:                                                                    (X[e, i] - mean[c][e])^2
+// `order` lists the signals class by class (stable), `offs[c]..offs[c+1]` is class c's range; workgroup
+// (blockIdx.y = c * nch + ch) sums chunk ch of class c:
+// mode 0: partial[c][ch][e] = sum of X[e, i]^2,  mode 1: of X[e, i],  mode 2: of (X[e, i] - mean[c][e])^2
 template <typename T>
-__global__ __launch_bounds__(256) void k_ldb_class_partial(const T *__restrict__ X, int64_t nk, int64_t N,
-                                                           const int *__restrict__ cls, int nc, int64_t chunk,
-                                                           int mode, const T *__restrict__ mean,
+__global__ __launch_bounds__(256) void k_ldb_class_partial(const T *__restrict__ X, int64_t nk,
+                                                           const int *__restrict__ order, const int *__restrict__ offs,
+                                                           int nch, int mode, const T *__restrict__ mean,
                                                            T *__restrict__ partial)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nk) return;
-    const int64_t i0 = (int64_t)blockIdx.y * chunk;
-    int64_t i1 = i0 + chunk; if (i1 > N) i1 = N;
-    for (int c = 0; c < nc; ++c) {
-        T acc = 0;
-        const T mu = mode == 2 ? mean[(int64_t)c * nk + e] : (T)0;
-        for (int64_t i = i0; i < i1; ++i) {
-            if (cls[i] != c) continue;                      // uniform: every lane sees the same label
-            const T x = X[i * nk + e];
-            if (mode == 1) acc = (T)(acc + x);
-            else { const T d = (T)(x - mu); const T sq = (T)(d * d); acc = (T)(acc + sq); }
+    const int c = blockIdx.y / nch, ch = blockIdx.y - c * nch;
+    const int j0 = offs[c], cnt = offs[c + 1] - j0;
+    const int per = (cnt + nch - 1) / nch;
+    int a = j0 + ch * per, b = a + per;
+    if (b > j0 + cnt) b = j0 + cnt;
+    const T mu = mode == 2 ? mean[(int64_t)c * nk + e] : (T)0;
+    T acc = 0;
+    int j = a;
+    for (; j + 4 <= b; j += 4) {                              // four independent loads in flight
+        const T x0 = X[(int64_t)order[j] * nk + e], x1 = X[(int64_t)order[j + 1] * nk + e];
+        const T x2 = X[(int64_t)order[j + 2] * nk + e], x3 = X[(int64_t)order[j + 3] * nk + e];
+        if (mode == 1) { acc = (T)(acc + x0); acc = (T)(acc + x1); acc = (T)(acc + x2); acc = (T)(acc + x3); }
+        else {
+            const T d0 = (T)(x0 - mu), d1 = (T)(x1 - mu), d2 = (T)(x2 - mu), d3 = (T)(x3 - mu);
+            acc = (T)(acc + (T)(d0 * d0)); acc = (T)(acc + (T)(d1 * d1));
+            acc = (T)(acc + (T)(d2 * d2)); acc = (T)(acc + (T)(d3 * d3));
         }
-        partial[((int64_t)blockIdx.y * nc + c) * nk + e] = acc;
     }
+    for (; j < b; ++j) {
+        const T x = X[(int64_t)order[j] * nk + e];
+        if (mode == 1) acc = (T)(acc + x);
+        else { const T d = (T)(x - mu); acc = (T)(acc + (T)(d * d)); }
+    }
+    partial[((int64_t)c * nch + ch) * nk + e] = acc;
 }
 
 // out[c][e] = (sum of the chunk partials in order) * scale, scale = 1/den[c] or 1/(den[c]-1) (variance)
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(256) void k_ldb_class_combine(const T *__restrict__
     if (e >= nk) return;
     for (int c = 0; c < nc; ++c) {
         T acc = 0;
-        for (int j = 0; j < nchunks; ++j) acc = (T)(acc + partial[((int64_t)j * nc + c) * nk + e]);
+        for (int j = 0; j < nchunks; ++j) acc = (T)(acc + partial[((int64_t)c * nchunks + j) * nk + e]);
         const T d = minus_one ? (T)(den[c] - (T)1) : den[c];
         out[(int64_t)c * nk + e] = (T)(acc / d);
     }
@@ -147,10 +158,25 @@ int api_class_reduce(const T *X, int64_t nk, int64_t nroot, int64_t N, const int
     const T *dmean = mode == 2 ? (const T *)io.in(mean, sizeof(T) * nk * nc) : nullptr;
     T *dden = den_out ? (T *)io.out(den_out, sizeof(T) * nc) : nullptr;
     if (!dX || !dout || (mode == 2 && !dmean) || (den_out && !dden)) return io.finish(WX_EHIP);
-    const int *dcls = (const int *)scr.upload(cls, sizeof(int32_t) * (size_t)N);
-    if (!dcls) return io.finish(WX_EHIP);
-    const int nchunks = pick_chunks(nk, N);
-    const int64_t chunk = (N + nchunks - 1) / nchunks;
+    // signals class by class in index order (the order the reference sums them in) + class offsets
+    std::vector<int> order((size_t)N), offs((size_t)nc + 1, 0);
+    for (int64_t i = 0; i < N; ++i) offs[(size_t)cls[i] + 1]++;
+    for (int c = 0; c < nc; ++c) offs[(size_t)c + 1] += offs[(size_t)c];
+    {
+        std::vector<int> pos(offs.begin(), offs.end() - 1);
+        for (int64_t i = 0; i < N; ++i) order[(size_t)pos[(size_t)cls[i]]++] = (int)i;
+    }
+    WX_REQUIRE(N < ((int64_t)1 << 31), WX_EUNSUPPORTED, "too many signals");
+    const int *dcls = (const int *)scr.alloc(sizeof(int32_t) * (size_t)N);
+    int *dorder = (int *)scr.alloc(sizeof(int) * (size_t)N);
+    int *doffs = (int *)scr.alloc(sizeof(int) * ((size_t)nc + 1));
+    if (!dcls || !dorder || !doffs) return io.finish(WX_EHIP);
+    if (hipMemcpyAsync((void *)dcls, cls, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(dorder, order.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(doffs, offs.data(), sizeof(int) * ((size_t)nc + 1), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)                    // the host vectors go out of scope
+        return io.finish(wx_set_error(WX_EHIP, "upload of the class index tables"));
+    const int nchunks = pick_chunks(nk, (N + nc - 1) / nc);
     T *partial = (T *)scr.alloc(sizeof(T) * (size_t)nchunks * nc * nk);
     T *per_sig = (T *)scr.alloc(sizeof(T) * (size_t)N);
     T *den = (T *)scr.alloc(sizeof(T) * 2 * (size_t)nc);
@@ -163,8 +189,8 @@ int api_class_reduce(const T *X, int64_t nk, int64_t nroot, int64_t N, const int
         if (hipMemsetAsync(per_sig, 0, sizeof(T) * (size_t)N, st) != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "memset"));
     }
     hipLaunchKernelGGL(k_ldb_class_sum<T>, dim3((unsigned)nc), dim3(256), 0, st, (const T *)per_sig, dcls, N, nc, den, count);
-    hipLaunchKernelGGL(k_ldb_class_partial<T>, dim3((unsigned)((nk + 255) / 256), (unsigned)nchunks), dim3(256), 0, st, dX, nk,
-                       N, dcls, nc, chunk, mode, dmean, partial);
+    hipLaunchKernelGGL(k_ldb_class_partial<T>, dim3((unsigned)((nk + 255) / 256), (unsigned)(nchunks * nc)), dim3(256), 0, st, dX,
+                       nk, (const int *)dorder, (const int *)doffs, nchunks, mode, dmean, partial);
     hipLaunchKernelGGL(k_ldb_class_combine<T>, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const T *)partial, nk, nc,
                        nchunks, (const T *)(mode == 0 ? den : count), mode == 2 ? 1 : 0, dout);
     if (dden && hipMemcpyAsync(dden, mode == 0 ? den : count, sizeof(T) * nc, hipMemcpyDeviceToDevice, st) != hipSuccess)
