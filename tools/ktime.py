@@ -17,7 +17,7 @@ def t(fn, reps=10):
 n, B = 4096, 65536
 x = wx.jl_empty((n, B), torch.float64, "cuda"); x.normal_()
 y1 = wx.jl_empty((n, B), torch.float64, "cuda")
-for name, L in (("db8", 12), ("db8", 10), ("db4", 12), ("db4", 10), ("haar", 12), ("db2", 12)):
+for name, L in (("db8", 12), ("db8", 10), ("db4", 12), ("db4", 10), ("db2", 12), ("db2", 10), ("haar", 12), ("haar", 10)):
     wt = wx.wavelet(getattr(wx.WT, name))
     yt = wx.jl_empty((n, L + 1, B), torch.float64, "cuda")
     f_wpt = t(lambda: _wpt_batched("wx_wpt", Arg(x), Arg(y1), 1, wt, L, None))
