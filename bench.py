@@ -320,6 +320,17 @@ def make_workload(w, wx, torch, dev, rank):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # started by hand as `python bench.py --gpus N`: run the same command under the launcher as a child
+        # process (nothing has touched the GPU yet) and hand back its exit code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
     import torch
     import torch.distributed as dist
     import waveletsext_jl_amd as wx
