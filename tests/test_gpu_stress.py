@@ -1,0 +1,67 @@
+"""GPU stress: geometry limits rather than values -- batches beyond the 65535 grid limit, the longest signals
+of the fused and of the per-level paths, big images, many trees at once.  Checked through size-independent
+properties (round trip, energy conservation, batch == repeated single) so that nothing has to run on the CPU."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    import torch
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def test_batches_beyond_the_grid_limit(wx, torch_mod=None):
+    import torch
+    wt = wx.wavelet(wx.WT.db2)
+    B = 70001                                                         # > 65535 (gridDim.y) and odd
+    x = wx.jl_empty((64, B), torch.float64, "cuda"); x.normal_()
+    assert _rel(wx.iwpdall(wx.wpdall(x, wt), wt), x) <= 1e-12
+    assert _rel(wx.iwptall(wx.wptall(x, wt), wt), x) <= 1e-12
+    assert _rel(wx.iswptall(wx.swptall(x, wt, 3), wt), x) <= 1e-12
+    assert _rel(wx.isdwtall(wx.sdwtall(x, wt, 3), wt, 5), x) <= 1e-12
+    assert _rel(wx.iacwpdall(wx.acwpdall(x, wt, 3), 3), x) <= 1e-12
+    xw = wx.wpdall(x, wt)
+    trees = wx.bestbasistreeall(xw, wx.BB())
+    assert trees.shape == (63, B)
+    one = wx.bestbasistree(xw[:, :, B - 1], wx.BB())
+    assert (trees[:, B - 1] == one).all()
+    y = wx.denoiseall(x, "sig", wt)
+    assert tuple(y.shape) == (64, B) and bool(torch.isfinite(y).all())
+    img = wx.jl_empty((8, 8, B), torch.float32, "cuda"); img.normal_()
+    assert _rel(wx.iwptall(wx.wptall(img, wt, 2), wt, 2), img) <= 1e-5
+
+
+@pytest.mark.parametrize("n,dtype", [(8192, "f64"), (16384, "f64"), (32768, "f32"), (65536, "f32")])
+def test_long_signals(wx, n, dtype):
+    import torch
+    td = torch.float64 if dtype == "f64" else torch.float32
+    tol = 1e-12 if dtype == "f64" else 2e-5
+    wt = wx.wavelet(wx.WT.db4)
+    x = wx.jl_empty((n, 9), td, "cuda"); x.normal_()
+    L = 10
+    xw = wx.wpdall(x, wt, L)
+    e0 = (x.double() ** 2).sum(0)
+    for lvl in (1, L):
+        assert float(((xw[:, lvl, :].double() ** 2).sum(0) / e0 - 1).abs().max()) <= 100 * tol     # orthogonality per level
+    assert _rel(wx.iwpdall(xw, wt, L), x) <= 10 * tol
+    assert _rel(wx.wptall(x, wt, L), xw[:, L, :]) <= tol
+    if n <= 16384:
+        sp = wx.swptall(x, wt, 4)
+        assert _rel(wx.iswptall(sp, wt), x) <= 10 * tol
+
+
+def test_large_images_and_deep_quadtrees(wx):
+    import torch
+    wt = wx.wavelet(wx.WT.db2)
+    img = wx.jl_empty((1024, 2048, 3), torch.float32, "cuda"); img.normal_()
+    y = wx.wptall(img, wt, 7)
+    e = float((y.double() ** 2).sum() / (img.double() ** 2).sum())
+    assert abs(e - 1) <= 1e-4
+    assert _rel(wx.iwptall(y, wt, 7), img) <= 1e-4
+    small = wx.jl_empty((256, 256, 5), torch.float64, "cuda"); small.normal_()
+    xw = wx.wpdall(small, wt, 5)
+    assert _rel(wx.iwpdall(xw, wt, 5), small) <= 1e-11
+    trees = wx.bestbasistreeall(xw, wx.BB())
+    assert trees.shape[1] == 5 and all(wx.isvalidtree(np.empty((256, 256)), trees[:, i]) for i in range(5))
