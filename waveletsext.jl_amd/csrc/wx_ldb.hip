@@ -176,7 +176,8 @@ int api_class_reduce(const T *X, int64_t nk, int64_t nroot, int64_t N, const int
         hipMemcpyAsync(doffs, offs.data(), sizeof(int) * ((size_t)nc + 1), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)                    // the host vectors go out of scope
         return io.finish(wx_set_error(WX_EHIP, "upload of the class index tables"));
-    const int nchunks = pick_chunks(nk, (N + nc - 1) / nc);
+    int nchunks = pick_chunks(nk, (N + nc - 1) / nc);
+    if ((int64_t)nchunks * nc > 65535) nchunks = 65535 / nc;       // gridDim.y
     T *partial = (T *)scr.alloc(sizeof(T) * (size_t)nchunks * nc * nk);
     T *per_sig = (T *)scr.alloc(sizeof(T) * (size_t)N);
     T *den = (T *)scr.alloc(sizeof(T) * 2 * (size_t)nc);
