@@ -65,3 +65,42 @@ def test_large_images_and_deep_quadtrees(wx):
     assert _rel(wx.iwpdall(xw, wt, 5), small) <= 1e-11
     trees = wx.bestbasistreeall(xw, wx.BB())
     assert trees.shape[1] == 5 and all(wx.isvalidtree(np.empty((256, 256)), trees[:, i]) for i in range(5))
+
+
+def test_concurrent_host_threads_on_their_own_streams(wx):
+    """the C ABI is re-entrant: four host threads, each on its own HIP stream, run different families at the same
+    time (ctypes drops the GIL inside the calls) and get the same results as a serial run"""
+    import threading
+    import torch
+    wt = wx.wavelet(wx.WT.db4)
+    rng = torch.Generator(device="cuda"); rng.manual_seed(7)
+    xs = []
+    for i in range(4):
+        x = wx.jl_empty((1024, 257 + i), torch.float64, "cuda"); x.normal_(generator=rng); xs.append(x)
+
+    def work(i, out):
+        x = xs[i]
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            res = []
+            for _ in range(3):
+                res = [wx.iwpdall(wx.wpdall(x, wt), wt), wx.wptall(x, wt, 7), wx.iswptall(wx.swptall(x, wt, 4), wt),
+                       wx.bestbasistree(wx.wpdall(x, wt), wx.JBB()), wx.bestbasistreeall(wx.wpdall(x, wt), wx.BB()),
+                       wx.denoiseall(x, "sig", wt)]
+            s.synchronize()
+        out[i] = res
+
+    serial, par = {}, {}
+    for i in range(4):
+        work(i, serial)
+    ts = [threading.Thread(target=work, args=(i, par)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(4):
+        for a, b in zip(serial[i], par[i]):
+            if isinstance(a, np.ndarray):
+                assert (a == b).all()
+            else:
+                assert torch.equal(a, b)
