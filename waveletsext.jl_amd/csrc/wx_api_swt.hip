@@ -118,6 +118,12 @@ static int api_swt_inv(const T *xw, T *x, int64_t n, int64_t ncols, int L, int l
     const T *dxw = (const T *)io.in(xw, sizeof(T) * n * ncols * batch);
     T *dx = (T *)io.out(x, sizeof(T) * n * batch);
     if ((batch && n) && (!dxw || !dx)) return io.finish(WX_EHIP);
+    // a full tree only reads its leaves, the last 2^Leff columns of the heap-ordered table: that is the iswpt
+    // layout at a column offset (signal stride stays ncols), so it takes the fused iswpt passes
+    if (layout == LAYOUT_WPD && !dtree && Leff >= 1 && (sm < 0 || Lshift == Leff)) {
+        layout = LAYOUT_WPT;
+        dxw += (((int64_t)1 << Leff) - 1) * n;
+    }
     // level buffers follow the inverse schedule (fused iswpt passes skip every other depth)
     WxSwtInvPlan plan;
     wx_swt_inv_plan(layout, Leff, F, sm, n, sizeof(T), dtree != nullptr, &plan);
