@@ -54,12 +54,10 @@ class FishersClassSeparability:
 def _classes(y):
     """unique(y) in first-occurrence order (Julia's unique) -> (classes, int32 class index per signal)"""
     y = list(np.asarray(y).tolist())
-    classes, idx = [], np.empty(len(y), dtype=np.int32)
+    pos, idx = {}, np.empty(len(y), dtype=np.int32)
     for i, v in enumerate(y):
-        if v not in classes:
-            classes.append(v)
-        idx[i] = classes.index(v)
-    return classes, idx
+        idx[i] = pos.setdefault(v, len(pos))
+    return list(pos), idx
 
 
 def energy_map(Xw, y, method=None, classes=None, return_norm_sum=False):
@@ -76,7 +74,8 @@ def energy_map(Xw, y, method=None, classes=None, return_norm_sum=False):
         classes, idx = _classes(y)
     else:
         classes = list(classes)
-        idx = np.array([classes.index(v) for v in list(np.asarray(y).tolist())], dtype=np.int32)
+        pos = {v: i for i, v in enumerate(classes)}
+        idx = np.array([pos[v] for v in list(np.asarray(y).tolist())], dtype=np.int32)
     nc = len(classes)
     sz, L, Nx = Xa.shape[:N - 2], Xa.shape[N - 2], Xa.shape[N - 1]
     assert Nx == idx.size
@@ -135,10 +134,7 @@ def _node_costs(DM, sz, L, top_k):
             v = DM[r[0] - 1:r[-1], c[0] - 1:c[-1], d].ravel(order="F")
         if top_k < v.size:
             v = np.sort(v)[::-1][:top_k]
-        s = DM.dtype.type(0)
-        for x in v:                                  # sum(...) in element order
-            s = DM.dtype.type(s + x)
-        cost[i - 1] = s
+        cost[i - 1] = np.cumsum(v, dtype=DM.dtype)[-1] if v.size else 0      # sequential sum in element order
     return cost
 
 
