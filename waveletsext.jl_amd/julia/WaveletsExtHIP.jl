@@ -16,7 +16,7 @@ module WaveletsExtHIP
 
 using Wavelets, WaveletsExt
 import Wavelets.Transforms: wpt, wpt!, iwpt, iwpt!
-import Wavelets.Threshold: bestbasistree
+import Wavelets.Threshold: bestbasistree, HardTH, SoftTH, SemiSoftTH, SteinTH
 import WaveletsExt.DWT: wpd, wpd!, iwpd, iwpd!, wpdall, iwpdall, wptall, iwptall
 import WaveletsExt.SWT: sdwtall, isdwtall, swptall, iswptall, swpdall, iswpdall
 import WaveletsExt.ACWT: acdwtall, iacdwtall, acwptall, iacwptall, acwpdall, iacwpdall
@@ -237,6 +237,26 @@ function bestbasistreeall(X::HIP{Float64,3}, method::BB)
     check(ccall((:wx_treeselect_batch_f64, LIB), Cint,
                 (Ptr{Float64}, Int64, Int64, Int64, Cint, Int64, Ptr{UInt8}, Ptr{Cvoid}), costs, ncost, n, 0, 0, N, trees, C_NULL))
     return BitMatrix(trees .!= 0)
+end
+
+# ---- denoising core (Denoising.jl:214-232, 651-712) for a batch of dwt-decomposed signals ------------------------
+# sigma_i = mad!(finest details of signal i)/0.6745 and the threshold step on the device; the transforms are the
+# batch methods above (`dwtall`/`idwtall` of WaveletsExt dispatch on HIP like `wptall`).  Other input types differ
+# only in (row_lo, col, colmask), see waveletsext.jl_amd/denoising.py.
+thkind(::HardTH) = Cint(0); thkind(::SoftTH) = Cint(1); thkind(::SemiSoftTH) = Cint(2); thkind(::SteinTH) = Cint(3)
+function noisestall(xw::HIP{Float64,2})
+    n, N = size(xw)
+    sigma = Vector{Float64}(undef, N)
+    check(ccall((:wx_noisest_f64, LIB), Cint, (Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Ptr{Float64}, Ptr{Cvoid}),
+                parent(xw), n, 1, N, n >> 1, 0, sigma, C_NULL))
+    return sigma
+end
+function thresholdall!(xw::HIP{Float64,2}, th, t::Vector{Float64}; row_lo::Integer = 0)
+    n, N = size(xw)
+    check(ccall((:wx_threshold_f64, LIB), Cint,
+                (Ptr{Float64}, Int64, Int64, Int64, Cint, Ptr{Float64}, Int64, Int64, Ptr{UInt8}, Ptr{Cvoid}),
+                parent(xw), n, 1, N, thkind(th), t, length(t), row_lo, C_NULL, C_NULL))
+    return xw
 end
 
 # ---- multi-GPU (one process per GPU; include/waveletsext_hip.h "Multi-GPU exchange") ----------------------------
