@@ -34,6 +34,18 @@ bool wx_is_device_ptr(const void *p)
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// device memory must belong to the current device: the kernels are launched there (one process per GPU is the
+// intended deployment; a caller driving several GPUs from one process selects the device before each call)
+static bool wx_on_other_device(const void *p)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice && a.device != cur;
+}
+
 int wx_pack_filter(const double *qmf, int F, WxFilt *out)
 {
     if (!qmf) return wx_set_error(WX_EARG, "qmf is NULL");
@@ -232,6 +244,7 @@ WxIO::~WxIO()
 const void *WxIO::in(const void *p, size_t bytes)
 {
     if (bytes != 0 && p == nullptr) { err = wx_set_error(WX_EARG, "NULL data pointer for a non-empty array"); return nullptr; }
+    if (bytes != 0 && wx_on_other_device(p)) { err = wx_set_error(WX_EARG, "array lives on another device than the current one"); return nullptr; }
     if (bytes == 0 || wx_is_device_ptr(p)) return p;
     void *d = nullptr;
     hipError_t e = hipMalloc(&d, bytes);
@@ -245,6 +258,7 @@ const void *WxIO::in(const void *p, size_t bytes)
 void *WxIO::out(void *p, size_t bytes)
 {
     if (bytes != 0 && p == nullptr) { err = wx_set_error(WX_EARG, "NULL data pointer for a non-empty array"); return nullptr; }
+    if (bytes != 0 && wx_on_other_device(p)) { err = wx_set_error(WX_EARG, "array lives on another device than the current one"); return nullptr; }
     if (bytes == 0 || wx_is_device_ptr(p)) return p;
     void *d = nullptr;
     hipError_t e = hipMalloc(&d, bytes);
