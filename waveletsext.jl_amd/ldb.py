@@ -53,11 +53,12 @@ class FishersClassSeparability:
 
 def _classes(y):
     """unique(y) in first-occurrence order (Julia's unique) -> (classes, int32 class index per signal)"""
-    y = list(np.asarray(y).tolist())
-    pos, idx = {}, np.empty(len(y), dtype=np.int32)
-    for i, v in enumerate(y):
-        idx[i] = pos.setdefault(v, len(pos))
-    return list(pos), idx
+    arr = np.asarray(y)
+    u, first, inv = np.unique(arr, return_index=True, return_inverse=True)
+    rank = np.empty(u.size, dtype=np.int32)
+    rank[np.argsort(first, kind="stable")] = np.arange(u.size, dtype=np.int32)
+    classes = [u[i].item() if hasattr(u[i], "item") else u[i] for i in np.argsort(first, kind="stable")]
+    return classes, np.ascontiguousarray(rank[inv.ravel()].astype(np.int32))
 
 
 def energy_map(Xw, y, method=None, classes=None, return_norm_sum=False):
@@ -74,8 +75,9 @@ def energy_map(Xw, y, method=None, classes=None, return_norm_sum=False):
         classes, idx = _classes(y)
     else:
         classes = list(classes)
+        own, loc = _classes(y)
         pos = {v: i for i, v in enumerate(classes)}
-        idx = np.array([pos[v] for v in list(np.asarray(y).tolist())], dtype=np.int32)
+        idx = np.ascontiguousarray(np.array([pos[v] for v in own], dtype=np.int32)[loc])
     nc = len(classes)
     sz, L, Nx = Xa.shape[:N - 2], Xa.shape[N - 2], Xa.shape[N - 1]
     assert Nx == idx.size
