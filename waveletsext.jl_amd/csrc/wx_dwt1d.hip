@@ -925,7 +925,9 @@ static int wx_fused_nt(int64_t n)
     int64_t want = n / 8;
     int nt = 64;
     while (nt < cap && nt < want) nt <<= 1;
-    while (nt < 1024 && n / 4 > 4 * (int64_t)nt) nt <<= 1;     // staging registers: n/4 <= 4*NT
+    // staging registers: n/4 <= 2*NT below 512 threads (a knob value that is too small is raised), n/4 <= 4*NT above
+    while (nt < 512 && n / 4 > 2 * (int64_t)nt) nt <<= 1;
+    while (nt < 1024 && n / 4 > 4 * (int64_t)nt) nt <<= 1;
     return nt;
 }
 
