@@ -108,3 +108,28 @@ def test_energy_map_shards_combine(wx, oracle):
     assert n0[2] == 0 and np.isnan(G0[:, :, 2]).all()
     comb = (np.nan_to_num(G0) * n0 + np.nan_to_num(G1) * n1) / (n0 + n1)
     assert relerr(comb, wx.energy_map(Xw, y)) <= 1e-12
+
+
+def test_ldb_reference_test_expectations(wx):
+    """the behaviours test/ldb.jl asserts: shapes of fit_transform / transform / inverse_transform and
+    change_nfeatures (:83-87: shrinking works, growing goes through inverse + transform, after which the old
+    feature matrix no longer matches f.n_features -> ArgumentError)"""
+    rng = np.random.default_rng(6005)
+    X, y = _classdata(rng, 32, 5, np.float64)                     # (32, 15), three classes like the reference's set
+    for dm in (wx.AsymmetricRelativeEntropy(), wx.SymmetricRelativeEntropy(), wx.LpDistance(2), wx.HellingerDistance()):
+        f = wx.LocalDiscriminantBasis(wt=wx.wavelet(wx.WT.coif6), max_dec_level=3, dm=dm, top_k=5, n_features=5)
+        Xc = wx.fit_transform(f, X, y)
+        assert Xc.shape == (5, 15)
+        wx.fit_(f, X, y)
+        assert wx.transform(f, X).shape == (5, 15)
+        assert wx.inverse_transform(f, Xc).shape == (32, 15)
+    x = wx.change_nfeatures(f, Xc, 5)
+    assert x.shape == (5, 15)
+    grown = wx.change_nfeatures(f, Xc, 10)
+    assert grown.shape == (10, 15) and f.n_features == 10
+    with pytest.raises(wx.ArgumentError):
+        wx.change_nfeatures(f, Xc, 10)
+    X2, y2 = _classdata(rng, 8, 5, np.float64, two_d=True)       # (8, 8, 15)
+    f = wx.LocalDiscriminantBasis(max_dec_level=2, n_features=5)
+    Xc = wx.fit_transform(f, X2, y2)
+    assert Xc.shape == (5, 15) and wx.inverse_transform(f, Xc).shape == (8, 8, 15)
