@@ -94,3 +94,39 @@ def test_denoise_and_denoiseall(wx, oracle, inputtype, dtype):
         err0 = np.mean([np.linalg.norm(x[:, i] - x0) for i in range(B)])
         err1 = np.mean([np.linalg.norm(Y[:, i] - x0) for i in range(B)])
         assert err1 <= err0
+
+
+def test_denoise_reference_test_expectations(wx):
+    """the bounds test/denoising.jl:14-97 asserts on a noisy heavisine (n = 2^8, Haar, VisuShrink(2, HardTH())):
+    denoising never makes the relative error worse than (twice) the noise level, for single signals and groups"""
+    rng = np.random.default_rng(5003)
+    n = 256
+    t = np.linspace(0, 1, n)
+    x0 = 4 * np.sin(4 * np.pi * t) - np.sign(t - 0.3) - np.sign(0.72 - t)
+    x = x0 + 0.5 * rng.standard_normal(n)
+    wt = wx.wavelet(wx.WT.haar)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    err = rel(x, x0)
+    dnt = wx.VisuShrink(2, wx.HardTH())
+    assert rel(wx.denoise(x, "sig", wt, dnt=dnt), x0) <= err
+    assert rel(wx.denoise(wx.dwt(x, wt, 4), "dwt", wt, L=4, dnt=dnt, smooth="undersmooth"), x0) <= 2 * err
+    assert rel(wx.denoise(wx.dwt(x, wt), "dwt", wt, dnt=dnt, smooth="undersmooth"), x0) <= 2 * err
+    full = wx.maketree(n, 8, "full")
+    assert rel(wx.denoise(wx.wpt(x, wt), "wpt", wt, tree=full, dnt=dnt, smooth="undersmooth"), x0) <= 2 * err
+    assert rel(wx.denoise(wx.sdwt(x, wt), "sdwt", wt, dnt=dnt, smooth="undersmooth"), x0) <= 2 * err
+    assert rel(wx.denoise(wx.swpd(x, wt), "swpd", wt, smooth="undersmooth"), x0) <= 2 * err
+    assert rel(wx.denoise(wx.acdwt(x, wt), "acdwt", wt, dnt=dnt, smooth="undersmooth"), x0) <= 2 * err
+    assert rel(wx.denoise(wx.acwpd(x, wt), "acwpd", wt, smooth="undersmooth"), x0) <= 2 * err
+    # group denoising
+    X0 = np.asfortranarray(np.stack([np.roll(x0, 2 * i) for i in range(5)], axis=1))
+    X = np.asfortranarray(X0 + 0.5 * rng.standard_normal(X0.shape))
+    max_err = max(rel(X[:, i], X0[:, i]) for i in range(5))
+    mean_err = lambda Y: np.mean([rel(Y[:, i], X0[:, i]) for i in range(5)])
+    assert mean_err(wx.denoiseall(X, "sig", wt, dnt=dnt, bestTH=np.mean)) <= max_err
+    assert mean_err(wx.denoiseall(wx.dwtall(X, wt), "dwt", wt, dnt=dnt)) <= max_err
+    assert mean_err(wx.denoiseall(wx.sdwtall(X, wt), "sdwt", wt)) <= max_err
+    assert mean_err(wx.denoiseall(wx.acdwtall(X, wt), "acdwt", wt)) <= max_err
+    with pytest.raises(AssertionError):
+        wx.denoise(x, "nope", wt)
+    with pytest.raises(AssertionError):
+        wx.denoise(x, "sig", wt, smooth="oversmooth")
