@@ -38,6 +38,7 @@ struct WxTree2d {
     bool full = true;
     const uint8_t *dstatus = nullptr;
     int64_t nstatus = 0;
+    const uint8_t *htree = nullptr;           // host copy (the caller's), for the per-depth lists of decomposed nodes
 };
 
 static int wx_check_tree2d(int64_t m, int64_t n, int L, const uint8_t *tree, int64_t ntree)
@@ -71,6 +72,7 @@ static int wx_resolve_tree2d(int L, const uint8_t *tree, int64_t ntree, WxScratc
         out->dstatus = (const uint8_t *)scr.upload(tree, (size_t)ntree);
         if (!out->dstatus) return WX_EHIP;
         out->nstatus = ntree;
+        out->htree = tree;
     }
     return WX_OK;
 }
@@ -124,7 +126,7 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
         return io.finish(rc);
     }
     if (batch && tr.Leff > 1) { pong = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!pong) return io.finish(WX_EHIP); }
-    rc = wx_dev_wpt2d<T>(dx, dy, m, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, tmp, pong, INVERSE, m * n, st);
+    rc = wx_dev_wpt2d<T>(dx, dy, m, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, tmp, pong, INVERSE, m * n, st, tr.htree);
     return io.finish(rc);
 }
 
@@ -170,7 +172,7 @@ static int api_iwpd2d(const T *xw, T *xh, int64_t m, int64_t n, int k, int L, co
         src = leaves;
         in_img = mn;
     }
-    rc = wx_dev_wpt2d<T>(src, dxh, m, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, tmp, pong, true, in_img, st);
+    rc = wx_dev_wpt2d<T>(src, dxh, m, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, tmp, pong, true, in_img, st, tr.htree);
     return io.finish(rc);
 }
 

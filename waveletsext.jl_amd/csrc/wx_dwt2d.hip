@@ -16,6 +16,7 @@
 // global access is coalesced; a level is two passes (columns, rows) through a scratch image.
 #include "wx_common.h"
 #include "wx_kernels.h"
+#include "wx_host.h"
 #include <cstdlib>
 
 static __device__ __forceinline__ int64_t wx_quad_heap(int d, int j, int k)
@@ -41,23 +42,37 @@ template <typename T, bool INVERSE>
 __global__ __launch_bounds__(256) void k_dwt2d_dim1(const T *__restrict__ src, T *__restrict__ dst,
                                                     int64_t src_img, int64_t dst_img, int m, int n, int d,
                                                     int64_t batch, WxFilt filt, const uint8_t *__restrict__ status,
-                                                    int64_t nstatus)
+                                                    int64_t nstatus, int copy_inactive,
+                                                    const int *__restrict__ act, int nact)
 {
     const int mp = m >> d, np = n >> d, h = mp >> 1, mh = m >> 1;
-    const int64_t total = (int64_t)batch * n * mh;
+    // act = (block-row, block-column) of the nodes this level decomposes: the grid then covers those blocks only
+    const int64_t per_img = act ? (int64_t)nact * np * h : (int64_t)n * mh;
+    const int64_t total = (int64_t)batch * per_img;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
          g += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(g % mh);
-        const int64_t g2 = g / mh;
-        const int c = (int)(g2 % n);
-        const int64_t b = g2 / n;
-        const int j = i / h, t = i - j * h;
+        int j, t, c;
+        int64_t b;
+        if (act) {
+            b = g / per_img;
+            const int64_t li = g - b * per_img;
+            const int a = (int)(li / ((int64_t)np * h));
+            const int lj = (int)(li - (int64_t)a * np * h);
+            t = lj % h;
+            j = act[2 * a];
+            c = act[2 * a + 1] * np + lj / h;
+        } else {
+            const int i = (int)(g % mh);
+            const int64_t g2 = g / mh;
+            c = (int)(g2 % n);
+            b = g2 / n;
+            j = i / h; t = i - j * h;
+        }
         const T *v = src + b * src_img + (int64_t)c * m + (int64_t)j * mp;
         T *o = dst + b * dst_img + (int64_t)c * m + (int64_t)j * mp;
-        if (!wx_quad_active(status, nstatus, d, j, c / np)) {
-            o[2 * t] = v[2 * t];
-            o[2 * t + 1] = v[2 * t + 1];
-            continue;
+        if (!act && !wx_quad_active(status, nstatus, d, j, c / np)) {
+            if (copy_inactive) { o[2 * t] = v[2 * t]; o[2 * t + 1] = v[2 * t + 1]; }
+            continue;                                   // in-place levels leave undecomposed blocks alone
         }
         if (!INVERSE) {
             double a = 0.0, dd = 0.0;
@@ -95,22 +110,38 @@ template <typename T, bool INVERSE>
 __global__ __launch_bounds__(256) void k_dwt2d_dim2(const T *__restrict__ src, T *__restrict__ dst,
                                                     int64_t src_img, int64_t dst_img, int m, int n, int d,
                                                     int64_t batch, WxFilt filt, const uint8_t *__restrict__ status,
-                                                    int64_t nstatus)
+                                                    int64_t nstatus, int copy_inactive,
+                                                    const int *__restrict__ act, int nact)
 {
     const int mp = m >> d, np = n >> d, h = np >> 1, nh = n >> 1;
-    const int64_t total = (int64_t)batch * nh * m;
+    const int64_t per_img = act ? (int64_t)nact * mp * h : (int64_t)nh * m;
+    const int64_t total = (int64_t)batch * per_img;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
          g += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(g % m);
-        const int64_t g2 = g / m;
-        const int jj = (int)(g2 % nh);
-        const int64_t b = g2 / nh;
-        const int k = jj / h, t = jj - k * h;
+        int r, k, t;
+        int64_t b;
+        if (act) {
+            b = g / per_img;
+            const int64_t li = g - b * per_img;
+            const int a = (int)(li / ((int64_t)mp * h));
+            const int lj = (int)(li - (int64_t)a * mp * h);
+            r = act[2 * a] * mp + lj % mp;
+            t = lj / mp;
+            k = act[2 * a + 1];
+        } else {
+            r = (int)(g % m);
+            const int64_t g2 = g / m;
+            const int jj = (int)(g2 % nh);
+            b = g2 / nh;
+            k = jj / h; t = jj - k * h;
+        }
         const T *v = src + b * src_img + r + (int64_t)k * np * m;   // column 0 of the node block
         T *o = dst + b * dst_img + r + (int64_t)k * np * m;
-        if (!wx_quad_active(status, nstatus, d, r / mp, k)) {
-            o[(int64_t)(2 * t) * m] = v[(int64_t)(2 * t) * m];
-            o[(int64_t)(2 * t + 1) * m] = v[(int64_t)(2 * t + 1) * m];
+        if (!act && !wx_quad_active(status, nstatus, d, r / mp, k)) {
+            if (copy_inactive) {
+                o[(int64_t)(2 * t) * m] = v[(int64_t)(2 * t) * m];
+                o[(int64_t)(2 * t + 1) * m] = v[(int64_t)(2 * t + 1) * m];
+            }
             continue;
         }
         if (!INVERSE) {
@@ -389,20 +420,20 @@ static int wx_grid2(int64_t total)
 template <typename T, bool INVERSE>
 static void wx_launch_level2d(const T *src, T *tmp, T *dst, int64_t src_img, int64_t dst_img, int m, int n, int d,
                               int64_t batch, const WxFilt &filt, const uint8_t *status, int64_t nstatus,
-                              hipStream_t st)
+                              hipStream_t st, int copy_inactive = 1, const int *act = nullptr, int nact = 0)
 {
     const int64_t mn = (int64_t)m * n;
-    const int g = wx_grid2(batch * mn / 2);
+    const int g = wx_grid2(act ? batch * nact * ((int64_t)(m >> d) * (n >> d)) / 2 : batch * mn / 2);
     if (!INVERSE) {
         hipLaunchKernelGGL((k_dwt2d_dim1<T, false>), dim3(g), dim3(256), 0, st, src, tmp, src_img, mn, m, n, d, batch,
-                           filt, status, nstatus);
+                           filt, status, nstatus, copy_inactive, act, nact);
         hipLaunchKernelGGL((k_dwt2d_dim2<T, false>), dim3(g), dim3(256), 0, st, (const T *)tmp, dst, mn, dst_img, m, n,
-                           d, batch, filt, status, nstatus);
+                           d, batch, filt, status, nstatus, copy_inactive, act, nact);
     } else {
         hipLaunchKernelGGL((k_dwt2d_dim2<T, true>), dim3(g), dim3(256), 0, st, src, tmp, src_img, mn, m, n, d, batch,
-                           filt, status, nstatus);
+                           filt, status, nstatus, copy_inactive, act, nact);
         hipLaunchKernelGGL((k_dwt2d_dim1<T, true>), dim3(g), dim3(256), 0, st, (const T *)tmp, dst, mn, dst_img, m, n,
-                           d, batch, filt, status, nstatus);
+                           d, batch, filt, status, nstatus, copy_inactive, act, nact);
     }
 }
 
@@ -426,13 +457,58 @@ int wx_dev_wpd2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, c
 template <typename T>
 int wx_dev_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const WxFilt &filt,
                  const uint8_t *status, int64_t nstatus, T *tmp, T *pong, bool inverse, int64_t in_img,
-                 hipStream_t st)
+                 hipStream_t st, const uint8_t *htree)
 {
     if (batch == 0 || m * n == 0) return WX_OK;
     const int64_t mn = m * n;
     if (L == 0) {
         WX_HIP_CHECK(hipMemcpy2DAsync(y, mn * sizeof(T), x, in_img * sizeof(T), mn * sizeof(T), batch,
                                       hipMemcpyDeviceToDevice, st));
+        return WX_OK;
+    }
+    if (status) {
+        // Tree-driven: a level rewrites exactly the blocks of the nodes it decomposes (children live where the
+        // parent was), so all levels run in place on y through tmp and skip every other block -- the work is
+        // proportional to the decomposed area (a dwt tree touches 1 + 1/4 + 1/16 + ... images, not L).
+        // (block-row, block-column) of the decomposed nodes of every depth, from the host copy of the tree
+        std::vector<const int *> dact((size_t)L, nullptr);
+        std::vector<int> nact((size_t)L, 0);
+        if (htree) {
+            for (int d = 0; d < L; ++d) {
+                std::vector<int> lst;
+                int64_t start = 1;
+                for (int t = 0; t < d; ++t) start = 4 * start - 2;
+                const int64_t cnt = (int64_t)1 << (2 * d);
+                for (int64_t mo = 0; mo < cnt; ++mo) {
+                    const int64_t hp = start + mo;
+                    if (!(hp <= nstatus && htree[hp - 1])) continue;
+                    int jr = 0, jc = 0;
+                    for (int t = 0; t < d; ++t) { jr |= (int)((mo >> (2 * t + 1)) & 1) << t; jc |= (int)((mo >> (2 * t)) & 1) << t; }
+                    lst.push_back(jr); lst.push_back(jc);
+                }
+                nact[(size_t)d] = (int)(lst.size() / 2);
+                if (!lst.empty()) {
+                    dact[(size_t)d] = (const int *)wx_const_upload(lst.data(), lst.size() * sizeof(int));
+                    if (!dact[(size_t)d]) return WX_EHIP;
+                }
+            }
+        }
+        auto level = [&](const T *src, int64_t simg, int d, bool inv, int copy) {
+            if (htree && nact[(size_t)d] == 0) return;                     // nothing decomposed at this depth
+            if (inv) wx_launch_level2d<T, true>(src, tmp, y, simg, mn, (int)m, (int)n, d, batch, filt, status, nstatus, st, copy,
+                                                htree ? dact[(size_t)d] : nullptr, nact[(size_t)d]);
+            else wx_launch_level2d<T, false>(src, tmp, y, simg, mn, (int)m, (int)n, d, batch, filt, status, nstatus, st, copy,
+                                             htree ? dact[(size_t)d] : nullptr, nact[(size_t)d]);
+        };
+        if (!inverse) {
+            level(x, in_img, 0, false, 1);                                 // the root: every block is written
+            for (int d = 1; d < L; ++d) level(y, mn, d, false, 0);
+        } else {
+            WX_HIP_CHECK(hipMemcpy2DAsync(y, mn * sizeof(T), x, in_img * sizeof(T), mn * sizeof(T), batch,
+                                          hipMemcpyDeviceToDevice, st));
+            for (int d = L - 1; d >= 0; --d) level(y, mn, d, true, 0);
+        }
+        WX_HIP_CHECK(hipGetLastError());
         return WX_OK;
     }
     const T *src = x;
@@ -465,7 +541,7 @@ int wx_dev_gather_leaves2d(const T *Xw, T *out, int64_t m, int64_t n, int k, int
 #define WX_INST(T)                                                                                            \
     template int wx_dev_wpd2d<T>(const T *, T *, int64_t, int64_t, int, int64_t, const WxFilt &, T *, hipStream_t); \
     template int wx_dev_wpt2d<T>(const T *, T *, int64_t, int64_t, int, int64_t, const WxFilt &, const uint8_t *,  \
-                                 int64_t, T *, T *, bool, int64_t, hipStream_t);                              \
+                                 int64_t, T *, T *, bool, int64_t, hipStream_t, const uint8_t *);             \
     template int wx_dev_gather_leaves2d<T>(const T *, T *, int64_t, int64_t, int, int64_t, const int *, int, hipStream_t); \
     template bool wx_wpt2d_fast_ok<T>(int64_t, int64_t, int);                                                  \
     template int wx_dev_wpt2d_fast<T>(const T *, T *, int64_t, int64_t, int, int64_t, const WxFilt &, T *, bool, int64_t, hipStream_t);

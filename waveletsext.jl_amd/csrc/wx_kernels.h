@@ -58,7 +58,7 @@ int wx_dev_wpd2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, c
 template <typename T>
 int wx_dev_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const WxFilt &filt,
                  const uint8_t *status, int64_t nstatus, T *tmp, T *pong, bool inverse, int64_t in_img,
-                 hipStream_t st);
+                 hipStream_t st, const uint8_t *htree = nullptr);
 template <typename T>
 int wx_dev_gather_leaves2d(const T *Xw, T *out, int64_t m, int64_t n, int k, int64_t batch, const int *colmap,
                            int nblk, hipStream_t st);
