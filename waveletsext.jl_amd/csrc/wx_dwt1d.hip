@@ -159,7 +159,7 @@ template <typename T, int F, int NT, bool WRITE_ALL, int WX_PF>
 __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, T *__restrict__ y,
                                                     int log2n, int L, int64_t batch, int64_t x_stride,
                                                     int64_t y_stride, WxFilt filt, WxFold fold,
-                                                    const uint8_t *__restrict__ status, int64_t nstatus)
+                                                    const uint8_t *__restrict__ status_g, int64_t nstatus)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     typedef typename WxVec2<T>::type V2;
@@ -175,6 +175,11 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
     T *buf1 = buf0 + 4 * PS;
     T *fl = buf1 + 4 * PS;                       // periodised filters (28 values), read as LDS broadcasts
     const int tid = threadIdx.x;
+    // the tree (one byte per node, the same for every signal) is kept in LDS: the per-item node tests of every
+    // level would otherwise each wait for a global load
+    uint8_t *sst = reinterpret_cast<uint8_t *>(fl + 32);
+    const uint8_t *status = status_g ? sst : nullptr;
+    if (status_g) for (int i = tid; i < n && i < nstatus; i += NT) sst[i] = status_g[i];
     if (tid < 28) fl[tid] = (T)reinterpret_cast<const double *>(&fold)[tid];
     const T *qa8 = fl, *qd8 = fl + 8, *qa4 = fl + 16, *qd4 = fl + 20, *qa2 = fl + 24, *qd2 = fl + 26;
 
@@ -449,7 +454,7 @@ template <typename T, int F, int NT, bool WRITE_ALL>
 __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x, T *__restrict__ y,
                                                       int log2n, int L, int64_t batch, int64_t x_stride,
                                                       int64_t y_stride, WxFilt filt, WxFold fold,
-                                                      const uint8_t *__restrict__ status, int64_t nstatus)
+                                                      const uint8_t *__restrict__ status_g, int64_t nstatus)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     typedef typename WxVec2<T>::type V2;
@@ -465,6 +470,9 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x
     T *buf = reinterpret_cast<T *>(wx_smem);
     T *fl = buf + 4 * PS;
     const int tid = threadIdx.x;
+    uint8_t *sst = reinterpret_cast<uint8_t *>(fl + 32);            // the tree in LDS (see k_fwd1d_fused)
+    const uint8_t *status = status_g ? sst : nullptr;
+    if (status_g) for (int i = tid; i < n && i < nstatus; i += NT) sst[i] = status_g[i];
     if (tid < 28) fl[tid] = (T)reinterpret_cast<const double *>(&fold)[tid];
     const T *qa8 = fl, *qd8 = fl + 8, *qa4 = fl + 16, *qd4 = fl + 20, *qa2 = fl + 24, *qd2 = fl + 26;
     V2 *E0 = reinterpret_cast<V2 *>(buf), *E1 = reinterpret_cast<V2 *>(buf + PS);
@@ -690,7 +698,7 @@ template <typename T, int F, int NT, int WX_PF>
 __global__ __launch_bounds__(NT, 4) void k_inv1d_fused(const T *__restrict__ xw, T *__restrict__ xh,
                                                        int log2n, int L, int64_t batch, int64_t in_stride,
                                                        int64_t out_stride, WxFilt filt, WxFoldInv fold,
-                                                       const uint8_t *__restrict__ status, int64_t nstatus,
+                                                       const uint8_t *__restrict__ status_g, int64_t nstatus,
                                                        const int *__restrict__ colmap, int log2blk)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
@@ -707,6 +715,9 @@ __global__ __launch_bounds__(NT, 4) void k_inv1d_fused(const T *__restrict__ xw,
     T *buf1 = buf0 + 2 * PS;
     T *fl = buf1 + 2 * PS;
     const int tid = threadIdx.x;
+    uint8_t *sst = reinterpret_cast<uint8_t *>(fl + 32);            // the tree in LDS (see k_fwd1d_fused)
+    const uint8_t *status = status_g ? sst : nullptr;
+    if (status_g) for (int i = tid; i < n && i < nstatus; i += NT) sst[i] = status_g[i];
     if (tid < 20) fl[tid] = (T)reinterpret_cast<const double *>(&fold)[tid];
     const T *m4 = fl, *m2 = fl + 16;
 
@@ -978,7 +989,7 @@ template <typename T, int F, bool WRITE_ALL, int NT, int PF>
 static int launch_fwd_fused_FNP(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
                                 const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
 {
-    const size_t lds = wx_fused_lds_bytes<T>(n);
+    const size_t lds = wx_fused_lds_bytes<T>(n) + (status ? (size_t)n : 0);     // + the tree bytes
     auto kern = k_fwd1d_fused<T, F, NT, WRITE_ALL, PF>;
     WX_HIP_CHECK(wx_allow_lds(kern, lds));
     const WxFold fold = wx_make_fold(filt);
@@ -1008,7 +1019,7 @@ template <typename T, int F, bool WRITE_ALL, int NT>
 static int launch_fwd_inplace_FN(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
                                  const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
 {
-    const size_t lds = wx_inplace_lds_bytes<T>(n);
+    const size_t lds = wx_inplace_lds_bytes<T>(n) + (status ? (size_t)n : 0);   // + the tree bytes
     auto kern = k_fwd1d_inplace<T, F, NT, WRITE_ALL>;
     WX_HIP_CHECK(wx_allow_lds(kern, lds));
     const WxFold fold = wx_make_fold(filt);
@@ -1070,7 +1081,7 @@ static int launch_inv_fused_FNP(const T *xw, T *xh, int64_t n, int L, int64_t ba
                                 const WxFilt &filt, const uint8_t *status, int64_t nstatus, const int *colmap,
                                 int log2blk, hipStream_t st)
 {
-    const size_t lds = wx_fused_lds_bytes<T>(n);
+    const size_t lds = wx_fused_lds_bytes<T>(n) + (status ? (size_t)n : 0);     // + the tree bytes
     auto kern = k_inv1d_fused<T, F, NT, PF>;
     WX_HIP_CHECK(wx_allow_lds(kern, lds));
     const WxFoldInv fold = wx_make_fold_inv(filt);
