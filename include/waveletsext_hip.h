@@ -256,9 +256,10 @@ int wx_treeselect_batch_f32(float *costs, int64_t ncost, int64_t m, int64_t n, i
  * k = 1 for dwt / wpt leaves, L+1 for sdwt / acdwt, 2^(L+1)-1 for swpd / acwpd.
  * wx_noisest_*: noisest(x, redundant, tree) Denoising.jl:214-232 = Wavelets.Threshold.mad!(dr)/0.6745 for every
  * signal, dr = rows [row_lo, n) of column `col` (the caller resolves finestdetailrange, Utils.jl:416-436);
- * exact order statistics (LDS bitonic sort), sigma has `batch` entries.
- * wx_threshold_*: Wavelets.Threshold.threshold!(x, TH, t) in place on rows [row_lo, n) of the columns with
- * colmask != 0 (NULL = all): th_kind 0 HardTH, 1 SoftTH, 2 SemiSoftTH, 3 SteinTH; t holds nt = 1 or `batch`
+ * exact order statistics (radix select in LDS), sigma has `batch` entries.
+ * wx_threshold_*: Y = Wavelets.Threshold.threshold(X, TH, t) on rows [row_lo, n) of the columns with
+ * colmask != 0 (NULL = all), everything else copied; Y == X thresholds in place (threshold!) and touches only the
+ * selected elements: th_kind 0 HardTH, 1 SoftTH, 2 SemiSoftTH, 3 SteinTH; t holds nt = 1 or `batch`
  * thresholds (sigma_i * dnt.t).  Wavelets.jl is not vendored: mad! and the threshold loops are restated from
  * its source.  Pointers may be host or device.
  * ------------------------------------------------------------------------------------------ */
@@ -266,10 +267,10 @@ int wx_noisest_f64(const double *X, int64_t n, int64_t k, int64_t batch, int64_t
                    void *stream);
 int wx_noisest_f32(const float *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo, int64_t col, float *sigma,
                    void *stream);
-int wx_threshold_f64(double *X, int64_t n, int64_t k, int64_t batch, int th_kind, const double *t, int64_t nt,
-                     int64_t row_lo, const uint8_t *colmask, void *stream);
-int wx_threshold_f32(float *X, int64_t n, int64_t k, int64_t batch, int th_kind, const float *t, int64_t nt,
-                     int64_t row_lo, const uint8_t *colmask, void *stream);
+int wx_threshold_f64(const double *X, double *Y, int64_t n, int64_t k, int64_t batch, int th_kind, const double *t,
+                     int64_t nt, int64_t row_lo, const uint8_t *colmask, void *stream);
+int wx_threshold_f32(const float *X, float *Y, int64_t n, int64_t k, int64_t batch, int th_kind, const float *t,
+                     int64_t nt, int64_t row_lo, const uint8_t *colmask, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Local Discriminant Basis, the batch-sized steps -- SURVEY 8(f) row 2.

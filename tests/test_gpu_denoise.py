@@ -130,3 +130,27 @@ def test_denoise_reference_test_expectations(wx):
         wx.denoise(x, "nope", wt)
     with pytest.raises(AssertionError):
         wx.denoise(x, "sig", wt, smooth="oversmooth")
+
+
+def test_noisest_degenerate_distributions(wx, oracle):
+    """the bucketed selection behind noisest must stay exact when the values do not spread: constants, two values,
+    heavy ties, one huge outlier (everything else in one bucket -> the narrowing loop), tiny and odd/even counts"""
+    rng = np.random.default_rng(5004)
+    cases = []
+    for n in (4, 8, 64, 1024, 4096):
+        half = n // 2
+        cases += [
+            np.zeros(n), np.full(n, -3.5),
+            np.where(np.arange(n) % 2 == 0, 1.0, -1.0),
+            np.round(rng.standard_normal(n) * 2) / 2,                       # heavy ties
+            np.concatenate([rng.standard_normal(n - 1) * 1e-6, [1e12]]),    # one outlier stretches the range
+            np.concatenate([np.full(half, 1.0), 1.0 + np.arange(half) * 2.0 ** -40]),   # near-equal cluster
+            rng.standard_normal(n) * 10.0 ** rng.integers(-200, 200),
+        ]
+    for v in cases:
+        v = np.ascontiguousarray(rng.permutation(v))
+        assert wx.noisest(v, False) == oracle.noisest(v, False), v[:4]
+        with np.errstate(over="ignore"):
+            v32 = v.astype(np.float32)
+        if np.isfinite(v32).all():
+            assert wx.noisest(v32, False) == oracle.noisest(v32, False)

@@ -17,6 +17,38 @@ extern "C" int wx_device_count(void);
 
 namespace {
 
+template <typename T> __device__ __forceinline__ T wx_thresh(T v, T tt, int th_kind)
+{
+    if (th_kind == 0) return (T)fabs((double)v) <= tt ? (T)0 : v;
+    const T sg = v > (T)0 ? (T)1 : (v < (T)0 ? (T)-1 : v);
+    if (th_kind == 1) { const T sh = (T)((T)fabs((double)v) - tt); return sh < (T)0 ? (T)0 : (T)(sg * sh); }
+    if (th_kind == 2) {
+        const T sh = (T)((T)(v * v) - (T)(tt * tt));
+        return sh < (T)0 ? (T)0 : (T)(sg * (T)sqrt((double)sh));
+    }
+    const T sh = (T)((T)1 - (T)((T)(tt * tt) / (T)(v * v)));
+    return sh < (T)0 ? (T)0 : (T)(v * sh);
+}
+
+// out of place: Y = X with the selected rows / columns thresholded (one read + one write of the table instead
+// of a copy followed by an in-place pass); colflag[c] != 0 selects column c (nullptr = all)
+template <typename T>
+__global__ __launch_bounds__(256) void k_threshold_copy(const T *__restrict__ X, T *__restrict__ Y, int n, int k,
+                                                        int64_t batch, int th_kind, const T *__restrict__ t,
+                                                        int per_signal, int row_lo, const uint8_t *__restrict__ colflag)
+{
+    const int64_t per_sig = (int64_t)n * k;
+    const int64_t total = per_sig * batch;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t sig = g / per_sig;
+        const int64_t rem = g - sig * per_sig;
+        const int c = (int)(rem / n), r = (int)(rem - (int64_t)c * n);
+        const T v = X[g];
+        const bool sel = r >= row_lo && (!colflag || colflag[c]);
+        Y[g] = sel ? wx_thresh<T>(v, per_signal ? t[sig] : t[0], th_kind) : v;
+    }
+}
+
 // X (n, k, batch): rows [row_lo, n) of the selected columns of every signal, in place
 template <typename T>
 __global__ __launch_bounds__(256) void k_threshold(T *__restrict__ X, int n, int k, int64_t batch, int th_kind,
@@ -32,59 +64,160 @@ __global__ __launch_bounds__(256) void k_threshold(T *__restrict__ X, int n, int
         const int c = (int)(rem / rows), r = (int)(rem - (int64_t)c * rows) + row_lo;
         T *p = X + (sig * k + (cols ? cols[c] : c)) * (int64_t)n + r;
         const T v = *p, tt = per_signal ? t[sig] : t[0];
-        T out;
-        if (th_kind == 0) out = (T)fabs((double)v) <= tt ? (T)0 : v;
-        else {
-            const T sg = v > (T)0 ? (T)1 : (v < (T)0 ? (T)-1 : v);
-            if (th_kind == 1) { const T sh = (T)((T)fabs((double)v) - tt); out = sh < (T)0 ? (T)0 : (T)(sg * sh); }
-            else if (th_kind == 2) {
-                const T sh = (T)((T)(v * v) - (T)(tt * tt));
-                out = sh < (T)0 ? (T)0 : (T)(sg * (T)sqrt((double)sh));
-            } else {
-                const T sh = (T)((T)1 - (T)((T)(tt * tt) / (T)(v * v)));
-                out = sh < (T)0 ? (T)0 : (T)(v * sh);
-            }
-        }
+        const T out = wx_thresh<T>(v, tt, th_kind);
         if (out != v || th_kind != 0) *p = out;
     }
 }
 
-template <typename T> __device__ __forceinline__ void bitonic_sort_lds(T *v, int P)
+// ---- exact order statistics in LDS (256 threads) -------------------------------------------------
+// Value bucketing instead of a sort: with the exact min / max of the candidates, bucket(x) = floor((x - lo) * scale)
+// is monotone, so the k-th smallest lies in the bucket where the running count crosses k.  One histogram pass
+// (1024 buckets: coefficients spread over them, so the LDS atomics do not pile up on one word) leaves a handful
+// of candidates, which are ranked directly.  Degenerate data (everything in one bucket) narrows [lo, hi] to that
+// bucket's own min / max and repeats; equal candidates end the search.  No arithmetic on the result: exact.
+constexpr int WX_NB = 1024;       // buckets
+constexpr int WX_LST = 256;       // candidates ranked directly
+
+template <typename T> __device__ __forceinline__ T wx_wave_min(T v)
 {
-    for (int size = 2; size <= P; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < (P >> 1); i += blockDim.x) {
-                const int lo = 2 * i - (i & (stride - 1));         // index with the `stride` bit clear
-                const int hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const T a = v[lo], b = v[hi];
-                if ((a > b) == up) { v[lo] = b; v[hi] = a; }
+    for (int o = 32; o > 0; o >>= 1) { const T u = __shfl_xor(v, o, 64); v = u < v ? u : v; }
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wx_wave_max(T v)
+{
+    for (int o = 32; o > 0; o >>= 1) { const T u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
+    return v;
+}
+struct WxSelScratch {
+    unsigned int hist[WX_NB];
+    double lst[WX_LST];
+    double red[16];
+    int ired[8];
+};
+
+// block-wide min and max of f(i) over i in [0, cnt) restricted by pred; every thread gets the result
+template <typename T, typename P>
+__device__ void wx_block_minmax(const T *v, int cnt, P pred, WxSelScratch *S, T &mn, T &mx)
+{
+    T a = (T)INFINITY, b = (T)-INFINITY;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) { const T x = v[i]; if (pred(x)) { a = x < a ? x : a; b = x > b ? x : b; } }
+    a = wx_wave_min(a); b = wx_wave_max(b);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { S->red[w] = (double)a; S->red[4 + w] = (double)b; }
+    __syncthreads();
+    double m0 = S->red[0], m1 = S->red[4];
+    for (int j = 1; j < (int)(blockDim.x >> 6); ++j) { m0 = S->red[j] < m0 ? S->red[j] : m0; m1 = S->red[4 + j] > m1 ? S->red[4 + j] : m1; }
+    mn = (T)m0; mx = (T)m1;
+}
+
+// k-th smallest (0-based) of v[0..cnt); all threads return the same value
+template <typename T>
+__device__ T wx_select_kth(const T *v, int cnt, int k, WxSelScratch *S)
+{
+    T lo, hi;
+    wx_block_minmax(v, cnt, [](T) { return true; }, S, lo, hi);
+    int kk = k;                                       // rank among the candidates lo <= x <= hi
+    for (;;) {
+        if (!(lo < hi)) return lo;                    // all candidates equal (or NaN-degenerate)
+        const double scale = (double)WX_NB / ((double)hi - (double)lo);
+        auto bucket = [&](T x) { int b = (int)(((double)x - (double)lo) * scale); return b < WX_NB ? b : WX_NB - 1; };
+        for (int i = threadIdx.x; i < WX_NB; i += blockDim.x) S->hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const T x = v[i];
+            if (x >= lo && x <= hi) atomicAdd(&S->hist[bucket(x)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) S->ired[2] = -1;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            // lane l owns buckets 16l .. 16l+15: wave-wide scan of the lane sums, then the crossing bucket
+            unsigned sum = 0;
+            for (int j = 0; j < WX_NB / 64; ++j) sum += S->hist[(WX_NB / 64) * threadIdx.x + j];
+            unsigned incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += up; }
+            const unsigned excl = incl - sum;
+            if ((unsigned)kk >= excl && (unsigned)kk < incl) {
+                unsigned c = excl;
+                int b = (WX_NB / 64) * threadIdx.x;
+                const int bend = b + WX_NB / 64 - 1;
+                while (b < bend && (unsigned)kk >= c + S->hist[b]) { c += S->hist[b]; ++b; }
+                S->ired[0] = b; S->ired[1] = (int)c; S->ired[2] = (int)S->hist[b];
             }
         }
+        __syncthreads();
+        const int bsel = S->ired[0], before = S->ired[1], cb = S->ired[2];
+        if (cb < 0) return (T)NAN;                     // rank beyond the comparable elements (NaNs in the data)
+        if (cb <= WX_LST) {
+            // gather the bucket's candidates and rank them (ties by slot): the (kk - before)-th is the answer
+            if (threadIdx.x == 0) S->ired[3] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+                const T x = v[i];
+                if (x >= lo && x <= hi && bucket(x) == bsel) S->lst[atomicAdd(&S->ired[3], 1)] = (double)x;
+            }
+            __syncthreads();
+            const int want = kk - before;
+            if ((int)threadIdx.x < cb) {
+                const double x = S->lst[threadIdx.x];
+                int rank = 0;
+                for (int j = 0; j < cb; ++j) { const double y = S->lst[j]; rank += (y < x) || (y == x && j < (int)threadIdx.x); }
+                if (rank == want) S->red[8] = x;
+            }
+            __syncthreads();
+            const T r = (T)S->red[8];
+            __syncthreads();
+            return r;
+        }
+        // too many candidates in one bucket: narrow to that bucket's own range and repeat
+        T nlo, nhi;
+        const T clo = lo, chi = hi;
+        wx_block_minmax(v, cnt, [&](T x) { return x >= clo && x <= chi && bucket(x) == bsel; }, S, nlo, nhi);
+        lo = nlo; hi = nhi; kk -= before;
+    }
+}
+
+// median as Statistics.median!: middle element, or middle(a, b) = a/2 + b/2 of the two middle ones
+template <typename T> __device__ T wx_median_lds(const T *v, int cnt, WxSelScratch *S)
+{
+    const T a = wx_select_kth<T>(v, cnt, (cnt - 1) / 2, S);
+    if (cnt & 1) return a;
+    // the next order statistic: a again if at least (cnt/2 + 1) elements are <= a, else the smallest element > a
+    int le = 0;
+    T nx = (T)INFINITY;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) { const T x = v[i]; le += x <= a; if (x > a && x < nx) nx = x; }
+    nx = wx_wave_min(nx);
+    for (int o = 32; o > 0; o >>= 1) le += __shfl_xor(le, o, 64);
+    const int w = threadIdx.x >> 6;
     __syncthreads();
+    if ((threadIdx.x & 63) == 0) { S->red[w] = (double)nx; S->ired[4 + w] = le; }
+    __syncthreads();
+    double m = S->red[0];
+    int tot = S->ired[4];
+    for (int j = 1; j < (int)(blockDim.x >> 6); ++j) { m = S->red[j] < m ? S->red[j] : m; tot += S->ired[4 + j]; }
+    __syncthreads();
+    const T b = tot >= cnt / 2 + 1 ? a : (T)m;
+    return (T)((T)(a / (T)2) + (T)(b / (T)2));
 }
 
 // one workgroup per signal: median, absolute deviations, median again -- exact order statistics, so the result
 // equals the reference's partial sorts bit for bit
 template <typename T>
-__global__ __launch_bounds__(1024) void k_mad(const T *__restrict__ X, int64_t sig_stride, int64_t off, int cnt, int P,
-                                              T *__restrict__ sigma)
+__global__ __launch_bounds__(256) void k_mad(const T *__restrict__ X, int64_t sig_stride, int64_t off, int cnt,
+                                             T *__restrict__ sigma)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     T *v = reinterpret_cast<T *>(wx_smem);
+    __shared__ WxSelScratch S;
     const T *x = X + (int64_t)blockIdx.x * sig_stride + off;
-    const T inf = (T)INFINITY;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) v[i] = i < cnt ? x[i] : inf;
-    bitonic_sort_lds<T>(v, P);
-    const T m = (cnt & 1) ? v[cnt / 2] : (T)((T)(v[cnt / 2 - 1] / (T)2) + (T)(v[cnt / 2] / (T)2));
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) v[i] = x[i];
     __syncthreads();
+    const T m = wx_median_lds<T>(v, cnt, &S);
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) v[i] = (T)fabs((double)(T)(v[i] - m));
-    bitonic_sort_lds<T>(v, P);
-    if (threadIdx.x == 0) {
-        const T r = (cnt & 1) ? v[cnt / 2] : (T)((T)(v[cnt / 2 - 1] / (T)2) + (T)(v[cnt / 2] / (T)2));
-        sigma[blockIdx.x] = (T)(r / (T)0.6745);
-    }
+    __syncthreads();
+    const T r = wx_median_lds<T>(v, cnt, &S);
+    if (threadIdx.x == 0) sigma[blockIdx.x] = (T)(r / (T)0.6745);
 }
 
 int need_device()
@@ -100,9 +233,7 @@ int api_noisest(const T *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo,
     WX_REQUIRE(wx_isdyadic(n), WX_EASSERT, "@assert isdyadic(size(x,1)) (Denoising.jl:218)");
     WX_REQUIRE(0 <= row_lo && row_lo < n && 0 <= col && col < k, WX_EBOUNDS, "detail range outside the array");
     const int64_t cnt = n - row_lo;
-    int64_t P = 2;
-    while (P < cnt) P <<= 1;
-    WX_REQUIRE((size_t)P * sizeof(T) <= 128 * 1024, WX_EUNSUPPORTED, "noisest: more detail coefficients than fit the LDS of one CU");
+    WX_REQUIRE((size_t)cnt * sizeof(T) <= 128 * 1024, WX_EUNSUPPORTED, "noisest: more detail coefficients than fit the LDS of one CU");
     int rc;
     if ((rc = need_device())) return rc;
     if (batch == 0) return WX_OK;
@@ -111,21 +242,21 @@ int api_noisest(const T *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo,
     const T *dX = (const T *)io.in(X, sizeof(T) * n * k * batch);
     T *ds = (T *)io.out(sigma, sizeof(T) * batch);
     if (!dX || !ds) return io.finish(WX_EHIP);
-    const size_t lds = (size_t)P * sizeof(T);
-    if (lds > 64 * 1024) {
+    const size_t lds = (size_t)cnt * sizeof(T);
+    if (lds > 60 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "hipFuncSetAttribute(LDS)"));
     }
-    const int nt = P >= 2048 ? 1024 : (P >= 512 ? 256 : 64);
-    hipLaunchKernelGGL(k_mad<T>, dim3((unsigned)batch), dim3(nt), lds, st, dX, n * k, col * n + row_lo, (int)cnt, (int)P, ds);
+    hipLaunchKernelGGL(k_mad<T>, dim3((unsigned)batch), dim3(256), lds, st, dX, n * k, col * n + row_lo, (int)cnt, ds);
     if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "noisest kernel failed to launch"));
     return io.finish(WX_OK);
 }
 
 template <typename T>
-int api_threshold(T *X, int64_t n, int64_t k, int64_t batch, int th_kind, const T *t, int64_t nt, int64_t row_lo,
-                  const uint8_t *colmask, void *stream)
+int api_threshold(const T *X, T *Y, int64_t n, int64_t k, int64_t batch, int th_kind, const T *t, int64_t nt,
+                  int64_t row_lo, const uint8_t *colmask, void *stream)
 {
+    WX_REQUIRE(X != nullptr && Y != nullptr, WX_EARG, "NULL array");
     WX_REQUIRE(n >= 1 && k >= 1 && batch >= 0, WX_EARG, "bad dimensions");
     WX_REQUIRE(th_kind >= 0 && th_kind <= 3, WX_EARG, "th_kind: 0 HardTH, 1 SoftTH, 2 SemiSoftTH, 3 SteinTH");
     WX_REQUIRE(t != nullptr && (nt == 1 || nt == batch), WX_EARG, "one threshold, or one per signal");
@@ -133,27 +264,46 @@ int api_threshold(T *X, int64_t n, int64_t k, int64_t batch, int th_kind, const 
     WX_REQUIRE(n < ((int64_t)1 << 31) && k < ((int64_t)1 << 31), WX_EUNSUPPORTED, "array too large");
     int rc;
     if ((rc = need_device())) return rc;
+    const bool inplace = (const T *)Y == X;
     std::vector<int> cols;
     if (colmask) for (int64_t c = 0; c < k; ++c) if (colmask[c]) cols.push_back((int)c);
     const int ncols = colmask ? (int)cols.size() : (int)k;
-    if (batch == 0 || ncols == 0 || row_lo == n) return WX_OK;
+    if (batch == 0) return WX_OK;
+    if (inplace && (ncols == 0 || row_lo == n)) return WX_OK;
     hipStream_t st = wx_stream(stream);
     WxScratch scr(st);
     WxIO io(st);
-    T *dX = (T *)io.in(X, sizeof(T) * n * k * batch);
-    for (auto &it : io.items) if (it.user == X) it.copy_out = true;
     const T *dt = (const T *)io.in(t, sizeof(T) * nt);
-    if (!dX || !dt) return io.finish(WX_EHIP);
-    const int *dcols = nullptr;
-    if (colmask) {
-        dcols = (const int *)scr.upload(cols.data(), cols.size() * sizeof(int));
-        if (!dcols) return io.finish(WX_EHIP);
+    const int per_signal = nt == batch ? 1 : 0;
+    if (inplace) {
+        T *dX = (T *)io.in(X, sizeof(T) * n * k * batch);
+        for (auto &it : io.items) if (it.user == X) it.copy_out = true;
+        if (!dX || !dt) return io.finish(WX_EHIP);
+        const int *dcols = nullptr;
+        if (colmask) {
+            dcols = (const int *)scr.upload(cols.data(), cols.size() * sizeof(int));
+            if (!dcols) return io.finish(WX_EHIP);
+        }
+        const int64_t total = (n - row_lo) * ncols * batch;
+        int64_t grid = (total + 255) / 256;
+        if (grid > 256 * 32) grid = 256 * 32;
+        hipLaunchKernelGGL(k_threshold<T>, dim3((unsigned)grid), dim3(256), 0, st, dX, (int)n, (int)k, batch, th_kind, dt,
+                           per_signal, (int)row_lo, dcols, ncols);
+    } else {
+        const T *dX = (const T *)io.in(X, sizeof(T) * n * k * batch);
+        T *dY = (T *)io.out(Y, sizeof(T) * n * k * batch);
+        if (!dX || !dY || !dt) return io.finish(WX_EHIP);
+        const uint8_t *dflag = nullptr;
+        if (colmask) {
+            dflag = (const uint8_t *)scr.upload(colmask, (size_t)k);
+            if (!dflag) return io.finish(WX_EHIP);
+        }
+        const int64_t total = n * k * batch;
+        int64_t grid = (total + 255) / 256;
+        if (grid > 256 * 32) grid = 256 * 32;
+        hipLaunchKernelGGL(k_threshold_copy<T>, dim3((unsigned)grid), dim3(256), 0, st, dX, dY, (int)n, (int)k, batch, th_kind,
+                           dt, per_signal, (int)row_lo, dflag);
     }
-    const int64_t total = (n - row_lo) * ncols * batch;
-    int64_t grid = (total + 255) / 256;
-    if (grid > 256 * 32) grid = 256 * 32;
-    hipLaunchKernelGGL(k_threshold<T>, dim3((unsigned)grid), dim3(256), 0, st, dX, (int)n, (int)k, batch, th_kind, dt,
-                       nt == batch && batch > 1 ? 1 : (nt == batch ? 1 : 0), (int)row_lo, dcols, ncols);
     if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "threshold kernel failed to launch"));
     return io.finish(WX_OK);
 }
@@ -165,10 +315,10 @@ int wx_noisest_f64(const double *X, int64_t n, int64_t k, int64_t batch, int64_t
 { return api_noisest<double>(X, n, k, batch, row_lo, col, sigma, stream); }
 int wx_noisest_f32(const float *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo, int64_t col, float *sigma, void *stream)
 { return api_noisest<float>(X, n, k, batch, row_lo, col, sigma, stream); }
-int wx_threshold_f64(double *X, int64_t n, int64_t k, int64_t batch, int th_kind, const double *t, int64_t nt, int64_t row_lo,
-                     const uint8_t *colmask, void *stream)
-{ return api_threshold<double>(X, n, k, batch, th_kind, t, nt, row_lo, colmask, stream); }
-int wx_threshold_f32(float *X, int64_t n, int64_t k, int64_t batch, int th_kind, const float *t, int64_t nt, int64_t row_lo,
-                     const uint8_t *colmask, void *stream)
-{ return api_threshold<float>(X, n, k, batch, th_kind, t, nt, row_lo, colmask, stream); }
+int wx_threshold_f64(const double *X, double *Y, int64_t n, int64_t k, int64_t batch, int th_kind, const double *t, int64_t nt,
+                     int64_t row_lo, const uint8_t *colmask, void *stream)
+{ return api_threshold<double>(X, Y, n, k, batch, th_kind, t, nt, row_lo, colmask, stream); }
+int wx_threshold_f32(const float *X, float *Y, int64_t n, int64_t k, int64_t batch, int th_kind, const float *t, int64_t nt,
+                     int64_t row_lo, const uint8_t *colmask, void *stream)
+{ return api_threshold<float>(X, Y, n, k, batch, th_kind, t, nt, row_lo, colmask, stream); }
 }

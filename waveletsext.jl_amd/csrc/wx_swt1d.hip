@@ -97,6 +97,108 @@ __global__ __launch_bounds__(1024) void k_swt_fwd_level(const T *__restrict__ x,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// sdwt / acdwt with every level in one kernel: the running approximation stays in LDS (ping-pong), each
+// level writes only its detail column, the last approximation goes to column 0.  HBM sees the signal once
+// and every output column once ((L+2) n per signal instead of 3 L n one level at a time).
+// ------------------------------------------------------------------------------------------
+template <typename T, bool AC>
+__global__ __launch_bounds__(1024) void k_sdwt_fused(const T *__restrict__ x, T *__restrict__ xw, int n, int64_t batch,
+                                                    int L, WxFilt filt, WxAcFilt ac)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    T *a = reinterpret_cast<T *>(wx_smem);
+    T *b = a + n;
+    for (int64_t sig = blockIdx.x; sig < batch; sig += gridDim.x) {
+        T *base = xw + sig * (int64_t)n * (L + 1);
+        const T *src = x + sig * (int64_t)n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) a[i] = src[i];
+        __syncthreads();
+        T *v = a, *w = b;
+        for (int d = 0; d < L; ++d) {
+            const int s = (1 << d) % n;
+            T *hi = base + (int64_t)(L - d) * n;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                if (!AC) {
+                    double lo = 0.0, dd = 0.0;
+                    int k1 = i - s; if (k1 < 0) k1 += n;
+                    int k2 = i;
+                    for (int j = 0; j < filt.F; ++j) {
+                        lo = fma(filt.q[j], (double)v[k1], lo);
+                        dd = fma((j & 1) ? -filt.q[j] : filt.q[j], (double)v[k2], dd);
+                        k1 += s; if (k1 >= n) k1 -= n;
+                        k2 -= s; if (k2 < 0) k2 += n;
+                    }
+                    w[i] = (T)lo;
+                    hi[i] = (T)dd;
+                } else {
+                    double S = 0.0;
+                    int km = i, kp = i;
+                    const int s2 = (2 * s) % n;
+                    km -= s; if (km < 0) km += n;
+                    kp += s; if (kp >= n) kp -= n;
+                    for (int l = 1; l < ac.F; l += 2) {
+                        S = fma(ac.b[l - 1], (double)v[km] + (double)v[kp], S);
+                        km -= s2; if (km < 0) km += n;
+                        kp += s2; if (kp >= n) kp -= n;
+                    }
+                    const double c = ac.c1 * (double)v[i];
+                    w[i] = (T)(c + S);
+                    hi[i] = (T)(c - S);
+                }
+            }
+            __syncthreads();
+            T *t = v; v = w; w = t;
+        }
+        for (int i = threadIdx.x; i < n; i += blockDim.x) base[i] = v[i];
+        __syncthreads();
+    }
+}
+
+// Average-based isdwt, every level in one kernel.  The mean of the two shift variants of a synthesis step is
+// the shift-invariant adjoint filter (see k_swt_inv_multi):
+//   r_d[p] = 1/2 sum_j q[j] r_{d+1}[p + (1-j) s] + (-1)^j q[j] w_d[p + j s],   s = 2^d,
+// r_L = column 0, w_d = detail column L-d.  r ping-pongs in LDS, the detail column of the level is staged next
+// to it; HBM sees every input column once and the signal once.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_isdwt_avg_fused(const T *__restrict__ xw, T *__restrict__ x, int n,
+                                                         int64_t batch, int L, WxFilt filt)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    T *a = reinterpret_cast<T *>(wx_smem);
+    T *b = a + n;
+    T *wd = b + n;
+    for (int64_t sig = blockIdx.x; sig < batch; sig += gridDim.x) {
+        const T *base = xw + sig * (int64_t)n * (L + 1);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) a[i] = base[i];
+        T *r = a, *rn = b;
+        for (int d = L - 1; d >= 0; --d) {
+            const T *wcol = base + (int64_t)(L - d) * n;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) wd[i] = wcol[i];
+            __syncthreads();
+            const int s = (1 << d) % n;
+            for (int p = threadIdx.x; p < n; p += blockDim.x) {
+                double acc = 0.0;
+                int k1 = p + s; if (k1 >= n) k1 -= n;          // p + (1 - 0) s
+                int k2 = p;                                    // p + 0 s
+                for (int j = 0; j < filt.F; ++j) {
+                    acc = fma(filt.q[j], (double)r[k1], acc);
+                    acc = fma((j & 1) ? -filt.q[j] : filt.q[j], (double)wd[k2], acc);
+                    k1 -= s; if (k1 < 0) k1 += n;
+                    k2 += s; if (k2 >= n) k2 -= n;
+                }
+                rn[p] = (T)(0.5 * acc);
+            }
+            __syncthreads();
+            T *t = r; r = rn; rn = t;
+        }
+        T *dst = x + sig * (int64_t)n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = r[i];
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K levels per pass (swpt only): the 2^K descendants of depth d+K are computed straight from the
 // LDS-resident parent with composite taps (products of the K per-level taps, merged per offset on
@@ -506,6 +608,20 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nt = n >= 8192 ? 1024 : (n >= 2048 ? 512 : 256);
+    if (layout == WX_LAYOUT_DWT && L >= 2 && 2 * lds <= 160 * 1024 && !wx_force_generic_swt()) {
+        // sdwt / acdwt: every level in one kernel, approximation resident in LDS
+        auto kf = ac ? k_sdwt_fused<T, true> : k_sdwt_fused<T, false>;
+        if (2 * lds > 64 * 1024)
+            WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
+        int per_cu = (int)((160 * 1024) / (2 * lds));
+        if (per_cu > 8) per_cu = 8;
+        int64_t grid = (int64_t)256 * per_cu;
+        if (grid > batch) grid = batch;
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(nt), 2 * lds, st, x, xw, (int)n, batch, L, filt, acz);
+        WX_HIP_CHECK(hipGetLastError());
+        return WX_OK;
+    }
     // swpt: fuse K levels per pass (K = 3 for very short filters, else 2); the tables live in a
     // stream-ordered scratch buffer
     const int KF = (!ac && layout == WX_LAYOUT_WPT && !wx_force_generic_swt()) ? (filt.F <= 4 ? 3 : (filt.F <= 16 ? 2 : 1)) : 1;
@@ -648,6 +764,21 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
     if (L == 0) {
         WX_HIP_CHECK(hipMemcpy2DAsync(x, n * sizeof(T), xw, (size_t)n * ncols * sizeof(T), n * sizeof(T), batch,
                                       hipMemcpyDeviceToDevice, st));
+        return WX_OK;
+    }
+    if (layout == WX_LAYOUT_DWT && sm < 0 && L >= 2 && (size_t)3 * n * sizeof(T) <= 160 * 1024 && !wx_force_generic_swt()) {
+        // average-based isdwt: every level in one kernel
+        const size_t lds3 = (size_t)3 * n * sizeof(T);
+        if (lds3 > 64 * 1024)
+            WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_isdwt_avg_fused<T>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        int per_cu = (int)((160 * 1024) / lds3);
+        if (per_cu > 8) per_cu = 8;
+        int64_t grid = (int64_t)256 * per_cu;
+        if (grid > batch) grid = batch;
+        const int nt = n >= 4096 ? 1024 : (n >= 1024 ? 512 : 256);
+        hipLaunchKernelGGL(k_isdwt_avg_fused<T>, dim3((unsigned)grid), dim3(nt), lds3, st, xw, x, (int)n, batch, L, filt);
+        WX_HIP_CHECK(hipGetLastError());
         return WX_OK;
     }
     // main2depthshift (Utils.jl:297-305)

@@ -79,14 +79,15 @@ def noisest(x, redundant, tree=None):
     return float(_noisest(xa, False, it, None if tree is None else np.asarray(tree, dtype=bool))[0])
 
 
-def _threshold_inplace(xa, batched, th, t, row_lo=0, colmask=None):
+def _threshold(xa, out, batched, th, t, row_lo=0, colmask=None):
+    """out = threshold(xa) on the selected rows / columns (out is xa: in place)"""
     n = xa.shape[0]
     N = xa.shape[-1] if batched else 1
     k = 1 if xa.arr.ndim - (1 if batched else 0) == 1 else xa.shape[1]
     tv = np.ascontiguousarray(np.atleast_1d(np.asarray(t, dtype=xa.dtype)))
     cm = None if colmask is None else np.ascontiguousarray(np.asarray(colmask, dtype=np.uint8))
     fn = getattr(_lib.lib(), "wx_threshold" + xa.suffix)
-    _lib.check(fn(xa.ptr, n, k, N, th.kind, ctypes.c_void_p(tv.ctypes.data), tv.size, int(row_lo),
+    _lib.check(fn(xa.ptr, out.ptr, n, k, N, th.kind, ctypes.c_void_p(tv.ctypes.data), tv.size, int(row_lo),
                   ctypes.c_void_p(cm.ctypes.data) if cm is not None else ctypes.c_void_p(0), xa.stream()))
 
 
@@ -94,11 +95,7 @@ def threshold(x, th, t):
     """Wavelets.Threshold.threshold(x, TH, t): thresholded copy"""
     xa = Arg(x)
     out = xa.new(xa.shape)
-    if xa.kind == "torch":
-        out.arr.copy_(xa.arr)
-    else:
-        out.arr[...] = xa.arr
-    _threshold_inplace(out, False, th, t)
+    _threshold(xa, out, False, th, t)
     return out.arr
 
 
@@ -119,18 +116,13 @@ def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
     if inputtype not in ("dwt", "wpt"):
         assert xa.arr.ndim > (2 if batched else 1)                     # @assert ndims(x) > 1
     N = xa.shape[-1] if batched else 1
-    # working copy (the reference thresholds a copy and leaves x alone)
-    xt = xa.new(xa.shape)
-    if xt.kind == "torch":
-        xt.arr.copy_(xa.arr)
-    else:
-        xt.arr[...] = xa.arr
+    xt = xa.new(xa.shape)              # thresholded copy (the reference leaves x alone): written by _threshold
     # noise estimation
     tr = None if inputtype in ("dwt", "sdwt", "acdwt") else tree
     if estnoise is None or callable(estnoise):
         if estnoise is not None and estnoise is not noisest:
             raise _lib.WxError(_lib.WX_EUNSUPPORTED, "only noisest (or precomputed values) estimates noise on the device path")
-        sigma = _noisest(xt, batched, inputtype, tr)
+        sigma = _noisest(xa, batched, inputtype, tr)
     else:
         sigma = np.broadcast_to(np.asarray(estnoise, dtype=np.float64), (N,)).astype(xa.dtype)
     if bestTH is not None:
@@ -139,13 +131,13 @@ def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
     # thresholding + reconstruction
     if inputtype == "dwt":
         lo = nodelength(n, L) if smooth == "undersmooth" else 0
-        _threshold_inplace(xt, batched, dnt.th, t, lo)
+        _threshold(xa, xt, batched, dnt.th, t, lo)
         if wt is None:
             return xt.arr
         return idwtall(xt.arr, wt, L) if batched else idwt(xt.arr, wt, L)
     if inputtype == "wpt":
         lo = coarsestscalingrange(n, tree)[-1] if smooth == "undersmooth" else 0
-        _threshold_inplace(xt, batched, dnt.th, t, lo)
+        _threshold(xa, xt, batched, dnt.th, t, lo)
         if wt is None:
             return xt.arr
         return iwptall(xt.arr, wt, tree) if batched else iwpt(xt.arr, wt, tree)
@@ -154,7 +146,7 @@ def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
         mask = np.ones(k, dtype=np.uint8)
         if smooth == "undersmooth":
             mask[0] = 0
-        _threshold_inplace(xt, batched, dnt.th, t, 0, mask)
+        _threshold(xa, xt, batched, dnt.th, t, 0, mask)
         if inputtype == "sdwt":
             if wt is None:
                 return xt.arr
@@ -165,7 +157,7 @@ def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
     mask = leaves[:k].astype(np.uint8)
     if smooth == "undersmooth":
         mask[coarsestscalingrange(n, tree, True)[1] - 1] = 0
-    _threshold_inplace(xt, batched, dnt.th, t, 0, mask)
+    _threshold(xa, xt, batched, dnt.th, t, 0, mask)
     if inputtype == "swpd":
         if wt is None:
             return xt.arr

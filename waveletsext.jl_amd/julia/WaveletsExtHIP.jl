@@ -254,8 +254,8 @@ end
 function thresholdall!(xw::HIP{Float64,2}, th, t::Vector{Float64}; row_lo::Integer = 0)
     n, N = size(xw)
     check(ccall((:wx_threshold_f64, LIB), Cint,
-                (Ptr{Float64}, Int64, Int64, Int64, Cint, Ptr{Float64}, Int64, Int64, Ptr{UInt8}, Ptr{Cvoid}),
-                parent(xw), n, 1, N, thkind(th), t, length(t), row_lo, C_NULL, C_NULL))
+                (Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Cint, Ptr{Float64}, Int64, Int64, Ptr{UInt8}, Ptr{Cvoid}),
+                parent(xw), parent(xw), n, 1, N, thkind(th), t, length(t), row_lo, C_NULL, C_NULL))
     return xw
 end
 
