@@ -203,3 +203,30 @@ def test_fuzz_redundant_trees_and_2d_ac(wx, oracle):
             g2 = wx.iacwpdall(a2, t2)
             x2 = np.asfortranarray(np.stack([oracle.red2d_inv("wpd", a2[:, :, :, i], None, t2, ac=True) for i in range(B)], axis=-1))
             assert relerr(g2, x2) <= tol, (m2, n2, L2)
+
+
+def test_fuzz_denoise_random_trees(wx, oracle):
+    """denoise through random best-basis-like trees (wpt leaves, swpd / acwpd heap columns), both smoothing modes,
+    every threshold function, random noise estimates"""
+    rng = np.random.default_rng(4006)
+    ths = {"hard": wx.HardTH, "soft": wx.SoftTH, "semisoft": wx.SemiSoftTH, "stein": wx.SteinTH}
+    for it in range(18):
+        n = 1 << int(rng.integers(4, 9))
+        wt = wx.wavelet(getattr(wx.WT, str(rng.choice(FILTERS[:6]))))
+        x = np.asfortranarray(rng.standard_normal((n, 3)) + np.sin(np.arange(n) / 5.0)[:, None])
+        Lmax = wx.maxtransformlevels(n)
+        tree = random_tree_1d(n, rng, 0.8)
+        tree[0] = True
+        thname = str(rng.choice(list(ths)))
+        smooth = str(rng.choice(["regular", "undersmooth"]))
+        dnt = wx.VisuShrink(ths[thname](), float(rng.uniform(0.5, 3.0)))
+        est = None if rng.random() < 0.6 else float(rng.uniform(0.1, 1.0))
+        kw = dict(L=Lmax, tree=tree, dnt=dnt, smooth=smooth, estnoise=est)
+        inputs = {"wpt": wx.to_numpy(wx.wptall(x, wt, tree)), "swpd": wx.to_numpy(wx.swpdall(x, wt, Lmax)),
+                  "acwpd": wx.to_numpy(wx.acwpdall(x, wt, Lmax))}
+        for inputtype, X in inputs.items():
+            Y = wx.to_numpy(wx.denoiseall(X, inputtype, wt, **kw))
+            for i in range(3):
+                exp = oracle.denoise(np.asfortranarray(X[..., i]), inputtype, wt.qmf, L=Lmax, tree=tree, th=thname,
+                                     t=dnt.t, estnoise=est, smooth=smooth)
+                assert relerr(Y[:, i], exp) <= 1e-9, (n, inputtype, thname, smooth, est)
