@@ -9,6 +9,10 @@ from helpers import TOL, random_tree_1d, relerr
 
 pytestmark = pytest.mark.gpu
 
+import os
+
+SCALE = int(os.environ.get("WX_FUZZ_SCALE", "1"))      # soak runs: WX_FUZZ_SCALE=10 multiplies the case counts
+
 FILTERS = ["haar", "db2", "db3", "db4", "db5", "db6", "db8", "db10", "coif2", "coif4", "coif6"]
 
 
@@ -34,7 +38,7 @@ def _put(wx, x, dev):
 
 
 def test_fuzz_decimated(wx, oracle):
-    for c in _cases(4001, 60):
+    for c in _cases(4001, 60 * SCALE):
         n, L, B, dt, rng = c["n"], c["L"], c["B"], c["dtype"], c["rng"]
         wt = wx.wavelet(getattr(wx.WT, c["wname"]))
         tol = TOL[dt]
@@ -58,7 +62,7 @@ def test_fuzz_decimated(wx, oracle):
 
 
 def test_fuzz_redundant(wx, oracle):
-    for c in _cases(4002, 40):
+    for c in _cases(4002, 40 * SCALE):
         n, L, B, dt, rng = c["n"], min(c["L"], 5), c["B"], c["dtype"], c["rng"]
         if L == 0:
             continue
@@ -98,7 +102,7 @@ def _cases2d(seed, count):
 
 def test_fuzz_2d(wx, oracle):
     from helpers import random_tree_2d
-    for c in _cases2d(4003, 40):
+    for c in _cases2d(4003, 40 * SCALE):
         m, n, L, B, dt, rng = c["m"], c["n"], c["L"], c["B"], c["dtype"], c["rng"]
         wt = wx.wavelet(getattr(wx.WT, c["wname"]))
         tol = TOL[dt]
@@ -162,7 +166,7 @@ def test_fuzz_best_basis_degenerate_inputs(wx, oracle):
 def test_fuzz_redundant_trees_and_2d_ac(wx, oracle):
     from helpers import random_tree_2d
     rng = np.random.default_rng(4005)
-    for it in range(24):
+    for it in range(24 * SCALE):
         wt = wx.wavelet(getattr(wx.WT, str(rng.choice(FILTERS[:6]))))
         dt = np.dtype(rng.choice([np.float64, np.float32]))
         tol = TOL[dt]
@@ -210,7 +214,7 @@ def test_fuzz_denoise_random_trees(wx, oracle):
     every threshold function, random noise estimates"""
     rng = np.random.default_rng(4006)
     ths = {"hard": wx.HardTH, "soft": wx.SoftTH, "semisoft": wx.SemiSoftTH, "stein": wx.SteinTH}
-    for it in range(18):
+    for it in range(18 * SCALE):
         n = 1 << int(rng.integers(4, 9))
         wt = wx.wavelet(getattr(wx.WT, str(rng.choice(FILTERS[:6]))))
         x = np.asfortranarray(rng.standard_normal((n, 3)) + np.sin(np.arange(n) / 5.0)[:, None])
