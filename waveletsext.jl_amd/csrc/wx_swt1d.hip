@@ -103,10 +103,14 @@ __global__ __launch_bounds__(1024) void k_swt_fwd_level(const T *__restrict__ x,
 // level writes only its detail column, the last approximation goes to column 0.  HBM sees the signal once
 // and every output column once ((L+2) n per signal instead of 3 L n one level at a time).
 // ------------------------------------------------------------------------------------------
-template <typename T, bool AC>
+// FT > 0 (orthogonal filters): for dilations s >= 16 a lane owns R = 4 consecutive samples of one residue class
+// mod s, so the F taps of both branches slide over a window of R + 2F - 3 class samples held in registers
+// (22 LDS reads instead of 64 for F = 8); lanes run over consecutive residues, i.e. consecutive LDS words.
+template <typename T, bool AC, int FT>
 __global__ __launch_bounds__(1024) void k_sdwt_fused(const T *__restrict__ x, T *__restrict__ xw, int n, int64_t batch,
                                                     int L, WxFilt filt, WxAcFilt ac)
 {
+    constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     T *a = reinterpret_cast<T *>(wx_smem);
     T *b = a + n;
@@ -119,6 +123,30 @@ __global__ __launch_bounds__(1024) void k_sdwt_fused(const T *__restrict__ x, T 
         for (int d = 0; d < L; ++d) {
             const int s = (1 << d) % n;
             T *hi = base + (int64_t)(L - d) * n;
+            const int M = s > 0 ? n / s : 0;
+            if (!AC && FT > 0 && s >= 16 && M >= R && M % R == 0 && (int64_t)M * s == n) {
+                constexpr int FW = FT > 0 ? FT : 2;
+                constexpr int WN = R + 2 * FW - 3;
+                for (int qi = threadIdx.x; qi < n / R; qi += blockDim.x) {
+                    const int c = qi % s, u0 = (qi / s) * R;
+                    double W[WN];
+                    int u = (u0 - (FW - 1)) % M; if (u < 0) u += M;
+#pragma unroll
+                    for (int k = 0; k < WN; ++k) { W[k] = (double)v[c + u * s]; u = u + 1 == M ? 0 : u + 1; }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        double lo = 0.0, dd = 0.0;
+#pragma unroll
+                        for (int j = 0; j < FW; ++j) {
+                            lo = fma(filt.q[j], W[FW - 2 + r + j], lo);
+                            dd = fma((j & 1) ? -filt.q[j] : filt.q[j], W[FW - 1 + r - j], dd);
+                        }
+                        const int i = c + (u0 + r) * s;
+                        w[i] = (T)lo;
+                        hi[i] = (T)dd;
+                    }
+                }
+            } else
             for (int i = threadIdx.x; i < n; i += blockDim.x) {
                 if (!AC) {
                     double lo = 0.0, dd = 0.0;
@@ -161,10 +189,11 @@ __global__ __launch_bounds__(1024) void k_sdwt_fused(const T *__restrict__ x, T 
 //   r_d[p] = 1/2 sum_j q[j] r_{d+1}[p + (1-j) s] + (-1)^j q[j] w_d[p + j s],   s = 2^d,
 // r_L = column 0, w_d = detail column L-d.  r ping-pongs in LDS, the detail column of the level is staged next
 // to it; HBM sees every input column once and the signal once.
-template <typename T>
+template <typename T, int FT>
 __global__ __launch_bounds__(1024) void k_isdwt_avg_fused(const T *__restrict__ xw, T *__restrict__ x, int n,
                                                          int64_t batch, int L, WxFilt filt)
 {
+    constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     T *a = reinterpret_cast<T *>(wx_smem);
     T *b = a + n;
@@ -178,6 +207,33 @@ __global__ __launch_bounds__(1024) void k_isdwt_avg_fused(const T *__restrict__ 
             for (int i = threadIdx.x; i < n; i += blockDim.x) wd[i] = wcol[i];
             __syncthreads();
             const int s = (1 << d) % n;
+            const int M = s > 0 ? n / s : 0;
+            if (FT > 0 && s >= 16 && M >= R && M % R == 0 && (int64_t)M * s == n) {
+                // R samples of one residue class per lane: r_c[u + 1 - j] and w_c[u + j] slide over R + F - 1 values each
+                constexpr int FW = FT > 0 ? FT : 2;
+                constexpr int WN = R + FW - 1;
+                for (int qi = threadIdx.x; qi < n / R; qi += blockDim.x) {
+                    const int c = qi % s, u0 = (qi / s) * R;
+                    double Wr[WN], Ww[WN];
+                    int ur = (u0 + 1 - (FW - 1)) % M; if (ur < 0) ur += M;      // r_c[u0 + 2 - F .. u0 + R]
+                    int uw = u0;                                               // w_c[u0 .. u0 + R + F - 2]
+#pragma unroll
+                    for (int k = 0; k < WN; ++k) {
+                        Wr[k] = (double)r[c + ur * s]; ur = ur + 1 == M ? 0 : ur + 1;
+                        Ww[k] = (double)wd[c + uw * s]; uw = uw + 1 == M ? 0 : uw + 1;
+                    }
+#pragma unroll
+                    for (int t = 0; t < R; ++t) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int j = 0; j < FW; ++j) {
+                            acc = fma(filt.q[j], Wr[t + (FW - 1) - j], acc);     // r_c[u0 + t + 1 - j]
+                            acc = fma((j & 1) ? -filt.q[j] : filt.q[j], Ww[t + j], acc);
+                        }
+                        rn[c + (u0 + t) * s] = (T)(0.5 * acc);
+                    }
+                }
+            } else
             for (int p = threadIdx.x; p < n; p += blockDim.x) {
                 double acc = 0.0;
                 int k1 = p + s; if (k1 >= n) k1 -= n;          // p + (1 - 0) s
@@ -610,7 +666,14 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
     const int nt = n >= 8192 ? 1024 : (n >= 2048 ? 512 : 256);
     if (layout == WX_LAYOUT_DWT && L >= 2 && 2 * lds <= 160 * 1024 && !wx_force_generic_swt()) {
         // sdwt / acdwt: every level in one kernel, approximation resident in LDS
-        auto kf = ac ? k_sdwt_fused<T, true> : k_sdwt_fused<T, false>;
+        typedef void (*KF)(const T *, T *, int, int64_t, int, WxFilt, WxAcFilt);
+        KF kf = ac ? k_sdwt_fused<T, true, 0> : k_sdwt_fused<T, false, 0>;
+        if (!ac) switch (filt.F) {
+#define WX_CASE(FF) case FF: kf = k_sdwt_fused<T, false, FF>; break;
+            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12)
+#undef WX_CASE
+            default: break;                              // longer filters: runtime tap loop (register budget)
+        }
         if (2 * lds > 64 * 1024)
             WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
@@ -769,15 +832,23 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
     if (layout == WX_LAYOUT_DWT && sm < 0 && L >= 2 && (size_t)3 * n * sizeof(T) <= 160 * 1024 && !wx_force_generic_swt()) {
         // average-based isdwt: every level in one kernel
         const size_t lds3 = (size_t)3 * n * sizeof(T);
+        typedef void (*KI)(const T *, T *, int, int64_t, int, WxFilt);
+        KI ki = k_isdwt_avg_fused<T, 0>;
+        switch (filt.F) {
+#define WX_CASE(FF) case FF: ki = k_isdwt_avg_fused<T, FF>; break;
+            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12)
+#undef WX_CASE
+            default: break;
+        }
         if (lds3 > 64 * 1024)
-            WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_isdwt_avg_fused<T>),
+            WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
         int per_cu = (int)((160 * 1024) / lds3);
         if (per_cu > 8) per_cu = 8;
         int64_t grid = (int64_t)256 * per_cu;
         if (grid > batch) grid = batch;
         const int nt = n >= 4096 ? 1024 : (n >= 1024 ? 512 : 256);
-        hipLaunchKernelGGL(k_isdwt_avg_fused<T>, dim3((unsigned)grid), dim3(nt), lds3, st, xw, x, (int)n, batch, L, filt);
+        hipLaunchKernelGGL(ki, dim3((unsigned)grid), dim3(nt), lds3, st, xw, x, (int)n, batch, L, filt);
         WX_HIP_CHECK(hipGetLastError());
         return WX_OK;
     }
