@@ -1311,8 +1311,12 @@ void FN(wxo_threshold)(T *x, int64_t cnt, int th_kind, T t)
             T sh = (T)((T)fabs((double)v) - t);
             x[i] = sh < 0 ? (T)0 : (T)((v > 0 ? (T)1 : (v < 0 ? (T)-1 : v)) * sh);
         } else if (th_kind == 2) {
-            T sh = (T)((T)(v * v) - (T)(t * t));
-            x[i] = sh < 0 ? (T)0 : (T)((v > 0 ? (T)1 : (v < 0 ? (T)-1 : v)) * (T)sqrt((double)sh));
+            /* semisoft, upper knee at 2t: 0 below t, sign(x) (2|x| - 2t) up to 2t, x above */
+            T av = (T)fabs((double)v);
+            if (!(av > (T)((T)2 * t))) {
+                T tmp = (T)((T)((T)2 * av) - (T)((T)2 * t));
+                x[i] = tmp < 0 ? (T)0 : (T)((v > 0 ? (T)1 : (v < 0 ? (T)-1 : v)) * tmp);
+            }
         } else {
             T sh = (T)((T)1 - (T)((T)(t * t) / (T)(v * v)));
             x[i] = sh < 0 ? (T)0 : (T)(v * sh);

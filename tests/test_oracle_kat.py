@@ -371,7 +371,8 @@ def test_denoise_core_oracle(oracle):
     v = np.array([-3.0, -1.0, 0.0, 0.5, 2.0])
     assert (oracle.threshold(v, "hard", 1.0) == [-3, 0, 0, 0, 2]).all()
     assert (oracle.threshold(v, "soft", 1.0) == [-2, 0, 0, 0, 1]).all()
-    assert np.allclose(oracle.threshold(v, "semisoft", 1.0), [-np.sqrt(8), 0, 0, 0, np.sqrt(3)])
+    assert (oracle.threshold(np.array([-3.0, -1.5, -1.0, 0.0, 0.5, 1.25, 2.0, 2.5]), "semisoft", 1.0) ==
+            [-3.0, -1.0, 0.0, 0.0, 0.0, 0.5, 2.0, 2.5]).all()          # 0 below t, 2(|x| - t) up to 2t, x above
     assert np.allclose(oracle.threshold(np.array([-3.0, 0.5, 2.0]), "stein", 1.0), [-3 * (1 - 1 / 9), 0, 2 * 0.75])
     x = np.arange(8, dtype=float)
     assert oracle.noisest(x, False) == oracle.noisest_range(x[4:])                    # dwt: upper half

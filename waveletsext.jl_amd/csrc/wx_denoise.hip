@@ -1,7 +1,8 @@
 // wx_denoise.hip -- denoising core on the device: SURVEY section 8(f) row 1 (threshold between the forward and
 // the inverse transform; both transforms are the batch entry points of the other translation units).
 //   noisest(x, redundant, tree)      Denoising.jl:214-232  = Wavelets.Threshold.mad!(dr) / 0.6745
-//   threshold!(x, TH, t)             Wavelets.jl Threshold (HardTH / SoftTH / SemiSoftTH / SteinTH), applied as
+//   threshold!(x, TH, t)             Wavelets.jl Threshold (HardTH / SoftTH / SemiSoftTH / SteinTH; SemiSoftTH is the
+//                                    piecewise-linear rule with the upper knee at 2t), applied as
 //                                    in denoise(), Denoising.jl:483-599, to the rows / columns it selects
 // Wavelets.jl is not vendored in the reference tree: mad! and the four threshold loops are restated from its
 // published source (parity unpinned, like the filter tables).
@@ -23,8 +24,11 @@ template <typename T> __device__ __forceinline__ T wx_thresh(T v, T tt, int th_k
     const T sg = v > (T)0 ? (T)1 : (v < (T)0 ? (T)-1 : v);
     if (th_kind == 1) { const T sh = (T)((T)fabs((double)v) - tt); return sh < (T)0 ? (T)0 : (T)(sg * sh); }
     if (th_kind == 2) {
-        const T sh = (T)((T)(v * v) - (T)(tt * tt));
-        return sh < (T)0 ? (T)0 : (T)(sg * (T)sqrt((double)sh));
+        // semisoft (Gao-Bruce, upper knee at 2t): 0 below t, sign(x) * 2(|x| - t) up to 2t, x above
+        const T av = (T)fabs((double)v);
+        if (av > (T)((T)2 * tt)) return v;
+        const T tmp = (T)((T)((T)2 * av) - (T)((T)2 * tt));
+        return tmp < (T)0 ? (T)0 : (T)(sg * tmp);
     }
     const T sh = (T)((T)1 - (T)((T)(tt * tt) / (T)(v * v)));
     return sh < (T)0 ? (T)0 : (T)(v * sh);
