@@ -18,13 +18,15 @@
  *    derives the (g, h) pair of WT.makereverseqmfpair(wt, true) and the autocorrelation filters
  *    itself.  `tree` is a host pointer, one byte per node in heap order (a Julia BitVector
  *    converted with Vector{UInt8}); tree == NULL selects the full tree of depth L.
- *    Tree-driven calls synchronise `stream` once while uploading the tree.
+ *    Trees and other small tables are uploaded once per distinct content with a blocking copy and then cached
+ *    on the device (released by wx_shutdown), so repeated calls with the same tree stay asynchronous.
  *  - `stream` is a hipStream_t (NULL = default stream).
  *  - Return value: WX_OK, or a negative status.  WX_EASSERT / WX_EARG / WX_EBOUNDS mean the
  *    reference would have thrown AssertionError / ArgumentError / BoundsError for these
  *    arguments; wx_last_error() gives the message.  Nothing throws across the boundary.
- *  - In/out buffers must not alias unless stated.  The library is re-entrant; the only global
- *    state is the per-thread last-error string.
+ *  - In/out buffers must not alias unless stated.  The library is re-entrant (callable from several host
+ *    threads on their own streams); its only state is the per-thread last-error string, the cached scratch
+ *    pool and the cache of small constant tables.  examples/roundtrip.c drives it from plain C.
  */
 #ifndef WAVELETSEXT_HIP_H
 #define WAVELETSEXT_HIP_H

@@ -102,3 +102,22 @@ def test_redundant_argument_errors(wx):
     p, q = wx.make_acreverseqmfpair(wx.wavelet(wx.WT.haar))
     np.testing.assert_allclose(p, [0.35355339, 0.70710678, 0.35355339], atol=1e-8)
     np.testing.assert_allclose(q, [-0.35355339, 0.70710678, -0.35355339], atol=1e-8)
+
+
+def test_header_compiles_as_c_and_example_links(tmp_path):
+    """include/waveletsext_hip.h is a C header: examples/roundtrip.c builds with gcc -std=c99 against the .so
+    (and, without a GPU, fails loudly with the library's status instead of computing on the CPU)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "waveletsext.jl_amd", "csrc")
+    exe = str(tmp_path / "roundtrip")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "roundtrip.c"), "-o", exe, "-L" + lib, "-lwaveletsext_hip", "-lm",
+                    "-Wl,-rpath," + lib], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    import waveletsext_jl_amd as wx
+    if wx.device_count() == 0:
+        assert r.returncode == 1 and "no HIP device" in r.stderr
+    else:
+        assert r.returncode == 0, r.stderr

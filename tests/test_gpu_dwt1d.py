@@ -224,3 +224,17 @@ def test_null_pointer_is_an_argument_error(wx):
     rc = _lib.lib().wx_wpd1d_f64(x.ctypes.data, None, 8, 3, 2, q.ctypes.data, 2, None)
     assert rc == _lib.WX_EARG
     assert _lib.lib().wx_wpd1d_f64(None, None, 8, 3, 0, q.ctypes.data, 2, None) == 0      # empty batch: nothing to read
+
+
+def test_c_host_example_runs(tmp_path):
+    """examples/roundtrip.c: a plain C host drives wpdall -> JBB tree -> iwpdall through the C ABI"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "waveletsext.jl_amd", "csrc")
+    exe = str(tmp_path / "roundtrip")
+    subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "roundtrip.c"),
+                    "-o", exe, "-L" + lib, "-lwaveletsext_hip", "-lm", "-Wl,-rpath," + lib], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "round trip max error" in r.stdout
