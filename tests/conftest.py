@@ -23,6 +23,10 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def wx():
+    import subprocess
+    lib = os.path.join(ROOT, "waveletsext.jl_amd", "csrc", "libwaveletsext_hip.so")
+    if not os.path.exists(lib):                       # fresh checkout: the .so is not in the history
+        subprocess.run(["make", "-C", os.path.dirname(lib), "-j4"], check=True)
     import waveletsext_jl_amd
     return waveletsext_jl_amd
 

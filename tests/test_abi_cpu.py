@@ -104,7 +104,7 @@ def test_redundant_argument_errors(wx):
     np.testing.assert_allclose(q, [-0.35355339, 0.70710678, -0.35355339], atol=1e-8)
 
 
-def test_header_compiles_as_c_and_example_links(tmp_path):
+def test_header_compiles_as_c_and_example_links(tmp_path, wx):
     """include/waveletsext_hip.h is a C header: examples/roundtrip.c builds with gcc -std=c99 against the .so
     (and, without a GPU, fails loudly with the library's status instead of computing on the CPU)"""
     import os

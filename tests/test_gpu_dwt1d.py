@@ -226,7 +226,7 @@ def test_null_pointer_is_an_argument_error(wx):
     assert _lib.lib().wx_wpd1d_f64(None, None, 8, 3, 0, q.ctypes.data, 2, None) == 0      # empty batch: nothing to read
 
 
-def test_c_host_example_runs(tmp_path):
+def test_c_host_example_runs(tmp_path, wx):
     """examples/roundtrip.c: a plain C host drives wpdall -> JBB tree -> iwpdall through the C ABI"""
     import os
     import subprocess
