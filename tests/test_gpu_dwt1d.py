@@ -238,3 +238,22 @@ def test_c_host_example_runs(tmp_path, wx):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "round trip max error" in r.stdout
+
+
+@pytest.mark.parametrize("dtype,n", [(np.float64, 16384), (np.float64, 32768), (np.float32, 32768), (np.float32, 131072)])
+@pytest.mark.parametrize("wname", ["haar", "db4", "db10"])
+def test_long_signals_split_path_matches_oracle(wx, oracle, wname, dtype, n):
+    """Signals beyond the LDS of one CU: per-level launches down to the first depth whose nodes fit, then the
+    fused kernel on the nodes (wx_dev_wpt1d / wx_dev_wpd1d / wx_dev_iwpt1d).  Same oracle, same tolerance."""
+    rng = np.random.default_rng(n + 3)
+    wt = _wt(wx, wname)
+    tol = TOL[np.dtype(dtype)]
+    x = np.asfortranarray(rng.standard_normal((n, 3)).astype(dtype))
+    for L in (wx.maxtransformlevels(n) - 4, 2, 1):
+        exp = oracle.wpdall(x, wt.qmf, L)
+        got = wx.wpdall(x, wt, L)
+        assert relerr(got, exp) <= tol, ("wpd", L)
+        leaves = np.asfortranarray(exp[:, L, :])
+        assert relerr(wx.wptall(x, wt, L), leaves) <= tol, ("wpt", L)
+        assert relerr(wx.iwptall(leaves, wt, L), x) <= 10 * tol, ("iwpt", L)
+        assert relerr(wx.iwpdall(exp, wt, L), x) <= 10 * tol, ("iwpd", L)

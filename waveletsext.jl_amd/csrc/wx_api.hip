@@ -160,9 +160,10 @@ static int api_iwpd1d(const T *xw, T *xh, int64_t n, int k, int L, const uint8_t
     }
     T *s1 = nullptr, *s2 = nullptr;
     if (!fused && batch) {
-        if (dcol) s2 = (T *)scr.alloc(sizeof(T) * n * batch);
+        const bool want_s2 = dcol || (tr.full && tr.Leff > 1);      // gathered leaves, or the densified leaf column
+        if (want_s2) s2 = (T *)scr.alloc(sizeof(T) * n * batch);
         if (tr.Leff > 1) s1 = (T *)scr.alloc(sizeof(T) * n * batch);
-        if ((dcol && !s2) || (tr.Leff > 1 && !s1)) return io.finish(WX_EHIP);
+        if ((want_s2 && !s2) || (tr.Leff > 1 && !s1)) return io.finish(WX_EHIP);
     }
     // full tree: every leaf sits in column Leff -> shift the base pointer, keep the table stride
     const T *base = tr.full ? dxw + (int64_t)tr.Leff * n : dxw;

@@ -152,6 +152,13 @@ template <typename T> struct WxVec4;
 template <> struct WxVec4<double> { typedef double4 type; };
 template <> struct WxVec4<float> { typedef float4 type; };
 
+// Element offset of work item q when every signal is split into 2^sub contiguous nodes of n samples: signal
+// q >> sub (stride apart), node q & (2^sub - 1).  sub == 0: plain q * stride.
+__device__ __forceinline__ int64_t wx_sub_base(int64_t q, int64_t stride, int sub, int n)
+{
+    return (q >> sub) * stride + (q & (((int64_t)1 << sub) - 1)) * n;
+}
+
 static constexpr int wx_floor_half(int s) { return s >= 0 ? s / 2 : -((-s + 1) / 2); }
 
 // WX_PF = 4-element groups a lane stages per signal (n/4 <= WX_PF * NT): 2 up to n = 8*NT, else 4
@@ -159,7 +166,8 @@ template <typename T, int F, int NT, bool WRITE_ALL, int WX_PF>
 __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, T *__restrict__ y,
                                                     int log2n, int L, int64_t batch, int64_t x_stride,
                                                     int64_t y_stride, WxFilt filt, WxFold fold,
-                                                    const uint8_t *__restrict__ status_g, int64_t nstatus)
+                                                    const uint8_t *__restrict__ status_g, int64_t nstatus,
+                                                    int sub_log2, int64_t lvl_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     typedef typename WxVec2<T>::type V2;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
 #pragma unroll
         for (int k = 0; k < WX_PF; ++k) {
             const int u = tid + k * NT;
-            if (u < Q) pre[k] = reinterpret_cast<const V4 *>(x + b * x_stride)[u];
+            if (u < Q) pre[k] = reinterpret_cast<const V4 *>(x + wx_sub_base(b, x_stride, sub_log2, n))[u];
         }
     }
 #ifdef WX_STAMPS
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
 #endif
     for (; b < batch; b += gridDim.x) {
         WX_T(t_begin);
-        T *ys = y + b * y_stride;
+        T *ys = y + wx_sub_base(b, y_stride, sub_log2, n);
         T *cur = buf0, *nxt = buf1;
         // registers -> planes (and column 0 of the packet table)
 #pragma unroll
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
                 const int pp = u & 1, idx = u >> 1;
                 reinterpret_cast<V2 *>(cur + (0 + pp) * PS)[idx] = ev;
                 reinterpret_cast<V2 *>(cur + (2 + pp) * PS)[idx] = ov;
-                if (WRITE_ALL) reinterpret_cast<V4 *>(ys)[u] = v;
+                if (WRITE_ALL && sub_log2 == 0) reinterpret_cast<V4 *>(ys)[u] = v;
             }
         }
         __syncthreads();
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
 #pragma unroll
             for (int k = 0; k < WX_PF; ++k) {
                 const int u = tid + k * NT;
-                if (u < Q) pre[k] = reinterpret_cast<const V4 *>(x + (b + gridDim.x) * x_stride)[u];
+                if (u < Q) pre[k] = reinterpret_cast<const V4 *>(x + wx_sub_base(b + gridDim.x, x_stride, sub_log2, n))[u];
             }
         }
         bool direct = false;
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
             direct = !WRITE_ALL && last && status == nullptr;     // leaves go straight to HBM
             const bool to_global = WRITE_ALL || direct;
             const bool to_lds = !direct && !(WRITE_ALL && last);
-            V4 *yl = reinterpret_cast<V4 *>(WRITE_ALL ? ys + (int64_t)(d + 1) * n : ys);
+            V4 *yl = reinterpret_cast<V4 *>(WRITE_ALL ? ys + (int64_t)(d + 1) * lvl_stride : ys);
             if (lh >= 3) {
                 // ---- four outputs per branch per lane ----
                 const int hq4 = 1 << (lh - 2);
@@ -985,26 +993,30 @@ template <typename K> static hipError_t wx_allow_lds(K kernel, size_t lds)
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
+// wpd of long signals: the fused kernel starts at depth sub.log2 of the packet table (2^log2 nodes per signal,
+// levels sub.lvl elements apart)
+struct WxSub { int log2 = 0; int64_t lvl = 0; };
+
 template <typename T, int F, bool WRITE_ALL, int NT, int PF>
 static int launch_fwd_fused_FNP(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
-                                const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
+                                const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st, WxSub sub = WxSub())
 {
     const size_t lds = wx_fused_lds_bytes<T>(n) + (status ? (size_t)n : 0);     // + the tree bytes
     auto kern = k_fwd1d_fused<T, F, NT, WRITE_ALL, PF>;
     WX_HIP_CHECK(wx_allow_lds(kern, lds));
     const WxFold fold = wx_make_fold(filt);
     hipLaunchKernelGGL(kern, dim3(wx_fused_grid(lds, batch, NT)), dim3(NT), lds, st, x, y, wx_log2(n), L, batch,
-                       xs, ys, filt, fold, status, nstatus);
+                       xs, ys, filt, fold, status, nstatus, sub.log2, sub.lvl ? sub.lvl : n);
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
 template <typename T, int F, bool WRITE_ALL, int NT>
 static int launch_fwd_fused_FN(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
-                               const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
+                               const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st, WxSub sub = WxSub())
 {
-    if (n / 4 <= 2 * NT) return launch_fwd_fused_FNP<T, F, WRITE_ALL, NT, 2>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    if (n / 4 <= 2 * NT) return launch_fwd_fused_FNP<T, F, WRITE_ALL, NT, 2>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st, sub);
     if (NT >= 512 && n / 4 <= 4 * NT)
-        return launch_fwd_fused_FNP<T, F, WRITE_ALL, (NT >= 512 ? NT : 512), 4>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+        return launch_fwd_fused_FNP<T, F, WRITE_ALL, (NT >= 512 ? NT : 512), 4>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st, sub);
     return wx_set_error(WX_EUNSUPPORTED, "fused forward: signal too long for the staging registers");
 }
 static int wx_fwd_mode()
@@ -1046,7 +1058,7 @@ static int launch_fwd_inplace_F(const T *x, T *y, int64_t n, int L, int64_t batc
 
 template <typename T, int F, bool WRITE_ALL>
 static int launch_fwd_fused_F(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
-                              const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
+                              const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st, WxSub sub = WxSub())
 {
     // measured on MI355X (tools/ktime.py): the in-place kernel wins for short filters when only the
     // leaves are written (wpt); long filters run out of registers with two items per lane, and wpd is
@@ -1056,20 +1068,20 @@ static int launch_fwd_fused_F(const T *x, T *y, int64_t n, int L, int64_t batch,
             return launch_fwd_inplace_F<T, F, WRITE_ALL>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
     }
     switch (wx_fused_nt(n)) {
-    case 64: return launch_fwd_fused_FN<T, F, WRITE_ALL, 64>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
-    case 128: return launch_fwd_fused_FN<T, F, WRITE_ALL, 128>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
-    case 256: return launch_fwd_fused_FN<T, F, WRITE_ALL, 256>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
-    case 512: return launch_fwd_fused_FN<T, F, WRITE_ALL, 512>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
-    default: return launch_fwd_fused_FN<T, F, WRITE_ALL, 1024>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+    case 64: return launch_fwd_fused_FN<T, F, WRITE_ALL, 64>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st, sub);
+    case 128: return launch_fwd_fused_FN<T, F, WRITE_ALL, 128>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st, sub);
+    case 256: return launch_fwd_fused_FN<T, F, WRITE_ALL, 256>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st, sub);
+    case 512: return launch_fwd_fused_FN<T, F, WRITE_ALL, 512>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st, sub);
+    default: return launch_fwd_fused_FN<T, F, WRITE_ALL, 1024>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st, sub);
     }
 }
 
 template <typename T, bool WRITE_ALL>
 static int launch_fwd_fused(const T *x, T *y, int64_t n, int L, int64_t batch, int64_t xs, int64_t ys,
-                            const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st)
+                            const WxFilt &filt, const uint8_t *status, int64_t nstatus, hipStream_t st, WxSub sub = WxSub())
 {
     switch (filt.F) {
-#define WX_CASE(FF) case FF: return launch_fwd_fused_F<T, FF, WRITE_ALL>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st);
+#define WX_CASE(FF) case FF: return launch_fwd_fused_F<T, FF, WRITE_ALL>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st, sub);
         WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
     }
@@ -1139,13 +1151,26 @@ int wx_dev_wpd1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
     // column 0 = x (strided 2-D copy), then level by level inside the table
     WX_HIP_CHECK(hipMemcpy2DAsync(y, ys * sizeof(T), x, n * sizeof(T), n * sizeof(T), batch,
                                   hipMemcpyDeviceToDevice, st));
-    for (int d = 0; d < L; ++d) {
+    // long signals: from the first depth d0 whose nodes fit the LDS of a CU on, the fused kernel finishes each
+    // node's subtree on chip, reading column d0 and writing columns d0+1..L of the same table
+    int d0 = L;
+    if (!force_generic && wx_is_pow2(n)) {
+        d0 = 0;
+        while (d0 < L && !wx_fused1d_ok<T>(n >> d0, filt.F)) ++d0;
+        if (d0 < L && (!wx_fused1d_ok<T>(n >> d0, filt.F) || (batch << d0) > ((int64_t)1 << 40))) d0 = L;
+    }
+    for (int d = 0; d < (d0 < L ? d0 : L); ++d) {
         const int64_t total = batch * (n / 2);
         hipLaunchKernelGGL(k_fwd1d_level<T>, dim3(wx_grid_for(total, 256)), dim3(256), 0, st, y + d * n,
                            y + (d + 1) * n, ys, ys, (int)n, (int)(n >> d), d, batch, filt,
                            (const uint8_t *)nullptr, (int64_t)0);
     }
     WX_HIP_CHECK(hipGetLastError());
+    if (d0 < L) {
+        WxSub sub; sub.log2 = d0; sub.lvl = n;
+        return launch_fwd_fused<T, true>(y + d0 * n, y + d0 * n, n >> d0, L - d0, batch << d0, ys, ys, filt, nullptr,
+                                         0, st, sub);
+    }
     return WX_OK;
 }
 
@@ -1162,6 +1187,27 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
     }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))
         return launch_fwd_fused<T, false>(x, y, n, L, batch, n, n, filt, status, nstatus, st);
+    // Signals too long for the LDS of one CU (full tree): the first d0 levels run one level per launch; from
+    // depth d0 on every node is an independent signal of n >> d0 samples -- contiguous, (n >> d0, batch << d0)
+    // in Julia layout -- and the fused kernel finishes them on chip.
+    int d0 = 0;
+    if (!force_generic && !status && wx_is_pow2(n)) {
+        while (d0 < L && !wx_fused1d_ok<T>(n >> d0, filt.F)) ++d0;
+        if (d0 >= L || !wx_fused1d_ok<T>(n >> d0, filt.F) || (batch << d0) > ((int64_t)1 << 40)) d0 = 0;
+    }
+    if (d0 > 0) {
+        const T *src = x;
+        for (int d = 0; d < d0; ++d) {
+            T *dst = ((d0 - 1 - d) & 1) ? y : scratch;                 // depth d0 lands in scratch
+            const int64_t total = batch * (n / 2);
+            hipLaunchKernelGGL(k_fwd1d_level<T>, dim3(wx_grid_for(total, 256)), dim3(256), 0, st, src, dst, n, n,
+                               (int)n, (int)(n >> d), d, batch, filt, (const uint8_t *)nullptr, (int64_t)0);
+            src = dst;
+        }
+        WX_HIP_CHECK(hipGetLastError());
+        const int64_t n2 = n >> d0;
+        return launch_fwd_fused<T, false>(scratch, y, n2, L - d0, batch << d0, n2, n2, filt, nullptr, 0, st);
+    }
     // ping-pong so that the last level lands in y
     const T *src = x;
     for (int d = 0; d < L; ++d) {
@@ -1192,6 +1238,35 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
     }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))
         return launch_inv_fused<T>(xw, xh, n, L, batch, is, n, filt, status, nstatus, colmap, log2blk, st);
+    // long signals, full tree, dense leaves: depths L-1 .. d0 on chip as (n >> d0, batch << d0) sub-signals,
+    // the remaining d0 levels one per launch (mirror of wx_dev_wpt1d)
+    int d0 = 0;
+    if (!force_generic && !status && !colmap && (is == n || scratch2) && wx_is_pow2(n)) {
+        while (d0 < L && !wx_fused1d_ok<T>(n >> d0, filt.F)) ++d0;
+        if (d0 >= L || !wx_fused1d_ok<T>(n >> d0, filt.F) || (batch << d0) > ((int64_t)1 << 40)) d0 = 0;
+    }
+    if (d0 > 0 && is != n) {
+        // leaves of a packet table (one column per signal, signals n*k apart): densify once
+        WX_HIP_CHECK(hipMemcpy2DAsync(scratch2, n * sizeof(T), xw, is * sizeof(T), n * sizeof(T), batch,
+                                      hipMemcpyDeviceToDevice, st));
+        xw = scratch2;
+    }
+    if (d0 > 0) {
+        T *fbuf = (d0 & 1) ? scratch : xh;                              // as if depth d0 were one more generic level
+        const int64_t n2 = n >> d0;
+        int rc = launch_inv_fused<T>(xw, fbuf, n2, L - d0, batch << d0, n2, n2, filt, nullptr, 0, nullptr, 0, st);
+        if (rc) return rc;
+        const T *src2 = fbuf;
+        for (int d = d0 - 1; d >= 0; --d) {
+            T *dst = (d & 1) ? scratch : xh;
+            const int64_t total = batch * (n / 2);
+            hipLaunchKernelGGL(k_inv1d_level<T>, dim3(wx_grid_for(total, 256)), dim3(256), 0, st, src2, dst, n, n, (int)n,
+                               (int)(n >> d), d, batch, filt, (const uint8_t *)nullptr, (int64_t)0);
+            src2 = dst;
+        }
+        WX_HIP_CHECK(hipGetLastError());
+        return WX_OK;
+    }
     const T *src = xw;
     int64_t src_stride = is;
     if (colmap) {
