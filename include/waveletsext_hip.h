@@ -301,6 +301,36 @@ int wx_class_var_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, 
                      void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Shift-invariant wavelet packet decomposition (Cohen, Raz & Malah) -- SURVEY 8(f) row 4.
+ * The reference's ShiftInvariantWaveletTransformObject (siwt/siwt_utls.jl:75-90, a Dict of node objects per
+ * signal) is a flat table here: W is (n, NS, batch), NS = wx_siwt_ncols(L, d) = sum_j 2^min(j,d).  Depth j owns
+ * the 2^min(j,d) columns that start at sum_{i<j} 2^min(i,d); column `slot` of depth j is TransformShift
+ * t = slot << max(0, j-d) (the only shifts siwpd_subtree! creates, SIWT.jl:104-131), and the node (j, i, t) is
+ * rows [i*(n>>j), (i+1)*(n>>j)) of that column.  Costs / status use one entry per node: index
+ * sum_{i<j} 2^i 2^min(i,d) + (slot << j) + i, NN = wx_siwt_nnodes(L, d) per signal.
+ * wx_siwpd_*          siwpd(x, wt, L, d) SIWT.jl:57-69 for every signal of x (n, batch); costs (NN, batch, may be
+ *                     NULL) = Nodes[index].Cost: coefcost(Value, ShannonEntropyCost(), norm(x)) (siwt_utls.jl:118-126).
+ * wx_siwt_bestbasis_* bestbasistree!(siwtObj) siwt/siwt_bestbasis.jl:28-102 per signal: costs are updated in place
+ *                     (Nodes[index].Cost, MinCost = costs[0]); status (NN, batch): 0 = node deleted, 1 = leaf of the
+ *                     best tree, 2 = kept with its non-shifted children, 3 = kept with its shifted children.
+ * wx_isiwpd_*         isiwpd(siwtObj) SIWT.jl:166-229: merges children into parents bottom-up along `status`,
+ *                     overwriting the parents' rows of W like the reference overwrites Nodes[index].Value; xh (n, batch).
+ * Errors: WX_EASSERT for 0 <= L <= maxtransformlevels(n), 1 <= d <= L (SIWT.jl:62-63).
+ * ------------------------------------------------------------------------------------------ */
+int64_t wx_siwt_ncols(int L, int d);
+int64_t wx_siwt_nnodes(int L, int d);
+int wx_siwpd_f64(const double *x, double *W, double *costs, int64_t n, int L, int d, int64_t batch, const double *qmf,
+                 int F, void *stream);
+int wx_siwpd_f32(const float *x, float *W, float *costs, int64_t n, int L, int d, int64_t batch, const double *qmf,
+                 int F, void *stream);
+int wx_siwt_bestbasis_f64(double *costs, uint8_t *status, int L, int d, int64_t batch, void *stream);
+int wx_siwt_bestbasis_f32(float *costs, uint8_t *status, int L, int d, int64_t batch, void *stream);
+int wx_isiwpd_f64(double *W, const uint8_t *status, double *xh, int64_t n, int L, int d, int64_t batch, const double *qmf,
+                  int F, void *stream);
+int wx_isiwpd_f32(float *W, const uint8_t *status, float *xh, int64_t n, int L, int d, int64_t batch, const double *qmf,
+                  int F, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Multi-GPU exchange (one process per GPU, RCCL over xGMI; bound lazily, single-GPU callers never
  * load RCCL).  Transforms shard over the batch (last) dimension with no collective: the loops
  * dwt/dwt_all.jl:277-279, swt/swt_all.jl:171-173, acwt/acwt_all.jl:254-256 are independent per

@@ -1324,6 +1324,57 @@ void FN(wxo_threshold)(T *x, int64_t cnt, int th_kind, T t)
     }
 }
 
+/* ------------------------------------------------------------------------- */
+/* Shift-invariant WPD: siwt/siwt_one_level.jl:71-98       */
+/* sidwt_step!(w1, w2, v, h, g, s) and :154-185 isidwt_step!(v, w1, w2, h,   */
+/* g, s); node cost = coefcost(Value, ShannonEntropyCost(), signalNorm)      */
+/* (siwt_utls.jl:118-126 via bestbasis_costs.jl:104-124).                    */
+/* ------------------------------------------------------------------------- */
+void FN(wxo_sidwt_step)(T *w1, T *w2, const T *v, int64_t n, const double *h, const double *g, int filtlen, int s)
+{
+    int64_t n1 = n / 2;
+    for (int64_t i = 1; i <= n1; i++) {
+        int64_t k1 = wxo_mod1(2 * i - 1 - s, n);
+        int64_t k2 = 2 * i - s;
+        V1(w1, 1, i) = (T)(g[filtlen - 1] * (double)V1(v, 1, k1));
+        V1(w2, 1, i) = (T)(h[0] * (double)V1(v, 1, k2));
+        for (int j = 2; j <= filtlen; j++) {
+            k1 = k1 + 1; if (k1 > n) k1 = wxo_mod1(k1, n);
+            k2 = k2 - 1; if (k2 <= 0) k2 = wxo_mod1(k2, n);
+            V1(w1, 1, i) = (T)((double)V1(w1, 1, i) + g[filtlen - j] * (double)V1(v, 1, k1));
+            V1(w2, 1, i) = (T)((double)V1(w2, 1, i) + h[j - 1] * (double)V1(v, 1, k2));
+        }
+    }
+}
+void FN(wxo_isidwt_step)(T *v, const T *w1, const T *w2, int64_t n, const double *h, const double *g, int filtlen,
+                         int s)
+{
+    int64_t n1 = n / 2;
+    for (int64_t i = 1; i <= n; i++) {
+        int64_t l = wxo_mod1(i - s, n);
+        int j0 = (int)wxo_mod1(i, 2);
+        int j1 = filtlen - j0 + 1;
+        int j2 = (int)wxo_mod1(i + 1, 2);
+        int64_t k1 = (i + 1) >> 1;
+        int64_t k2 = (i + 1) >> 1;
+        V1(v, 1, l) = (T)(g[j1 - 1] * (double)V1(w1, 1, k1) + h[j2 - 1] * (double)V1(w2, 1, k2));
+        for (int j = j0 + 2; j <= filtlen; j += 2) {
+            j1 = filtlen - j + 1;
+            j2 = j + (j & 1) - ((j & 1) ? 0 : 1);
+            k1 = k1 - 1; if (k1 <= 0) k1 = wxo_mod1(k1, n1);
+            k2 = k2 + 1; if (k2 > n1) k2 = wxo_mod1(k2, n1);
+            V1(v, 1, l) = (T)((double)V1(v, 1, l) + (g[j1 - 1] * (double)V1(w1, 1, k1) + h[j2 - 1] * (double)V1(w2, 1, k2)));
+        }
+    }
+}
+/* coefcost(x, ShannonEntropyCost(), nrm); nrm < 0 -> norm(x) */
+T FN(wxo_siwt_nodecost)(const T *x, int64_t n, T nrm)
+{
+    if (nrm < 0) nrm = FN(wxo_norm2)(x, n);
+    return FN(wxo_coefcost_bb)(x, n, 0, nrm);
+}
+T FN(wxo_siwt_norm)(const T *x, int64_t n) { return FN(wxo_norm2)(x, n); }
+
 #undef T
 #undef FN
 #undef V1

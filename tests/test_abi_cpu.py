@@ -65,6 +65,8 @@ def test_no_cpu_fallback_without_gpu(wx):
         lambda: wx.bestbasistree(X3, wx.JBB()), lambda: wx.bestbasistreeall(X3, wx.BB()),
         lambda: wx.denoiseall(np.zeros((8, 2)), "sig", wt), lambda: wx.noisest(np.zeros(8), False),
         lambda: wx.energy_map(X3, [0, 1]), lambda: wx.acwpd_jbb_moments(np.zeros((8, 2)), wt),
+        lambda: wx.siwpd(np.ones(8), wt), lambda: wx.siwpdall(np.ones((8, 2)), wt, 2, 1),
+        lambda: wx.ShiftInvariantWaveletTransformObject(np.ones(8), wt),
     ]
     for c in calls:
         with pytest.raises(wx.WxError) as ei:

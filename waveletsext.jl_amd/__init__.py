@@ -30,3 +30,15 @@ from .ldb import (TimeFrequency, AsymmetricRelativeEntropy, SymmetricRelativeEnt
                   HellingerDistance, BasisDiscriminantMeasure, FishersClassSeparability, energy_map,
                   discriminant_measure, discriminant_power, LocalDiscriminantBasis, fit_, fitdec_, transform,
                   fit_transform, inverse_transform, change_nfeatures)
+from .siwt import (ShiftInvariantWaveletTransformNode, ShiftInvariantWaveletTransformObject,               # noqa: F401,E402
+                   ShiftInvariantWaveletTransformBatch, siwpd, siwpdall, isiwpd, isiwpdall, bestbasistree_,
+                   bestbasistreeall_, delete_node_)
+from . import siwt as _siwt                                                                                # noqa: E402
+_isvalidtree_arrays = isvalidtree                                                                          # noqa: F405
+
+
+def isvalidtree(*args):                                                                                    # noqa: F811
+    """isvalidtree(x, tree) (Wavelets.jl) or isvalidtree(siwtObj) (siwt/siwt_utls.jl:185-207)"""
+    if len(args) == 1 and isinstance(args[0], ShiftInvariantWaveletTransformObject):
+        return _siwt.isvalidtree(args[0])
+    return _isvalidtree_arrays(*args)

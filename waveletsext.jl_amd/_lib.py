@@ -64,6 +64,10 @@ def _declare(L):
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = _I
+    for name in ("wx_siwt_ncols", "wx_siwt_nnodes"):
+        if hasattr(L, name):
+            getattr(L, name).argtypes = [_I, _I]
+            getattr(L, name).restype = _L
 
 
 # filled in by the other host modules' families (SWT / ACWT / 2-D / JBB)
@@ -101,6 +105,9 @@ _EXTRA_SIGS = {
     "wx_jbb_moments": [_P, _P, _P, _L, _L, _I, _P],
     "wx_jbb_costs": [_P, _P, _L, _L, _L, _I, _I, ctypes.c_double, _P, _P],
     "wx_acwpd_jbb_moments": [_P, _P, _P, _L, _I, _L, _P, _I, _I, _P],
+    "wx_siwpd": [_P, _P, _P, _L, _I, _I, _L, _P, _I, _P],
+    "wx_siwt_bestbasis": [_P, _P, _I, _I, _L, _P],
+    "wx_isiwpd": [_P, _P, _P, _L, _I, _I, _L, _P, _I, _P],
 }
 _PLAIN_SIGS = {
     "wx_treeselect_f64": [_P, _L, _L, _I, _P],
