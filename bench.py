@@ -63,6 +63,11 @@ WORKLOADS = {
                              ("k_ldb_class_partial<double>", 1), ("k_ldb_class_combine<double>", 1)],
                 desc="SURVEY 8(f) row 2: LDB time-frequency energy maps of 4 classes over wpdall(x) 16384x4096 f64 db8 "
                      "L=12; timed leg = energy_map over the resident 6.5 GiB table (wpdall is the other leg)"),
+    "siwt": dict(kind="siwt", n=1024, batch=4096, wavelet="db4", L=10, d=3, dtype="f64",
+                 kernel="k_siwt_costs<double>",
+                 fwd_kernels=[("k_siwt_fwd_level<double>", 10), ("k_siwt_norms<double>", 1), ("k_siwt_costs<double>", 1)],
+                 desc="SURVEY 8(f) row 4: shift-invariant packet decomposition siwpd(x, wt, 10, 3) + node costs of 4096 "
+                      "1024-sample f64 signals (71-column table, 2.4 GB); second leg = bestbasistree! + isiwpd of all signals"),
 }
 
 
@@ -153,6 +158,17 @@ def cpu_baseline(w, seconds):
             dt = time.perf_counter() - t0
             assert G.shape[:2] == (n, L + 1)
             return dt, B * n
+        if kind == "siwt":
+            n = w["n"]
+            x = rng.standard_normal((n, B))
+            t0 = time.perf_counter()
+            for i in range(B):
+                obj = wo.siwpd(x[:, i], q, L, w["d"])
+                wo.siwt_bestbasistree(obj)
+                xr = wo.isiwpd(obj)
+            dt = time.perf_counter() - t0
+            assert np.abs(xr - x[:, B - 1]).max() < 1e-9
+            return dt, B * n
         if kind == "acwpd_jbb":
             n = w["n"]
             x = rng.standard_normal((n, B))
@@ -186,8 +202,9 @@ def cpu_baseline(w, seconds):
     B = int(max(probe, min(cap, seconds / (t_probe / probe))))
     dt, samples = run(B)
     out = {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-           "sample": "%d of the %d signals per step, same transform pair, oracle C -O2 single thread, %.1f s"
-                     % (B, w["batch"], dt)}
+           "sample": "%d of the %d signals per step, same transform pair, %s, %.1f s"
+                     % (B, w["batch"], "oracle: C -O2 steps under the reference's Dict-and-recursion object model in Python, one thread"
+                        if kind == "siwt" else "oracle C -O2 single thread", dt)}
     if kind in ("wpd", "wpt"):
         nthr = int(lib.wxo_omp_max_threads())
         Bo = int(min(16384, max(256, B * max(1, nthr // 4))))
@@ -297,6 +314,25 @@ def make_workload(w, wx, torch, dev, rank):
             return abs(s - 4.0) / 4.0
         return fwd, inv, check, dict(fwd_bytes=es * (n * (L + 1)) * (B + 4), inv_bytes=es * n * (L + 2) * B,
                                      fwd_flops=2.0 * n * (L + 1) * B, samples=n * B, bound="hbm", keep=(x, xw))
+    if kind == "siwt":
+        n, d = w["n"], w["d"]
+        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
+        state = {}
+
+        def fwd():      # decomposition + the cost of every node
+            state["b"] = wx.siwpdall(x, wt, L, d)
+
+        def inv():      # best basis of every signal, then the inverse along it
+            state["b"]._b.bestbasis()                  # bestbasistreeall_ without the copy of the status bytes to the host
+            state["xh"] = wx.isiwpdall(state["b"])
+
+        check = lambda: float((state["xh"] - x).abs().max() / x.abs().max())
+        NS = sum(1 << min(j, d) for j in range(L + 1))
+        NN = sum((1 << min(j, d)) << j for j in range(L + 1))
+        # parents read once per child pair, every column written once, the table read once more for the costs
+        fb = es * B * (n * (NS - (1 << min(L, d))) + 2 * n * NS + NN)
+        return fwd, inv, check, dict(fwd_bytes=fb, inv_bytes=es * B * (2 * NN + 3 * n * L) + 2 * NN * B,
+                                     fwd_flops=4.0 * F * (n / 2) * (NS - 1) * B, samples=n * B, bound="hbm", keep=(x,))
     if kind == "acwpd_jbb":
         n = w["n"]
         x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)

@@ -259,6 +259,46 @@ function thresholdall!(xw::HIP{Float64,2}, th, t::Vector{Float64}; row_lo::Integ
     return xw
 end
 
+# ---- shift-invariant packet decomposition for a whole batch (SIWT.jl:57-229 per signal) --------------------------
+# The flat table of include/waveletsext_hip.h instead of one Dict of node objects per signal: W (n, NS, N), node
+# (j, i, t) = W[i*(n>>j)+1 : (i+1)*(n>>j), coloff(j) + (t >> max(0, j-d)) + 1, signal].  `siwt_node` rebuilds the
+# reference's ShiftInvariantWaveletTransformNode for callers that want the object model back.
+struct SIWTBatch
+    W::Array{Float64,3}; costs::Matrix{Float64}; status::Matrix{UInt8}; wt::OrthoFilter; L::Int; d::Int
+end
+siwt_coloff(j, d) = sum(1 << min(i, d) for i in 0:j-1; init = 0)
+siwt_nodeoff(j, d) = sum((1 << min(i, d)) << i for i in 0:j-1; init = 0)
+function siwpdall(x::HIP{Float64,2}, wt::OrthoFilter, L::Integer = maxtransformlevels(size(x, 1)), d::Integer = L)
+    n, N = size(x)
+    NS = ccall((:wx_siwt_ncols, LIB), Int64, (Cint, Cint), L, d)
+    NN = ccall((:wx_siwt_nnodes, LIB), Int64, (Cint, Cint), L, d)
+    W = Array{Float64,3}(undef, n, NS, N); costs = Matrix{Float64}(undef, NN, N)
+    q = qmfvec(wt)
+    check(ccall((:wx_siwpd_f64, LIB), Cint,
+                (Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Cint, Cint, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                parent(x), W, costs, n, L, d, N, q, length(q), C_NULL))
+    return SIWTBatch(W, costs, fill(0x01, NN, N), wt, L, d)
+end
+function bestbasistreeall!(b::SIWTBatch)
+    check(ccall((:wx_siwt_bestbasis_f64, LIB), Cint, (Ptr{Float64}, Ptr{UInt8}, Cint, Cint, Int64, Ptr{Cvoid}),
+                b.costs, b.status, b.L, b.d, size(b.W, 3), C_NULL))
+    return b.status
+end
+function isiwpdall(b::SIWTBatch)
+    n, _, N = size(b.W)
+    xh = Matrix{Float64}(undef, n, N); q = qmfvec(b.wt)
+    check(ccall((:wx_isiwpd_f64, LIB), Cint,
+                (Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, Int64, Cint, Cint, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                b.W, b.status, xh, n, b.L, b.d, N, q, length(q), C_NULL))
+    return xh
+end
+function siwt_node(b::SIWTBatch, sig::Integer, j::Integer, i::Integer, t::Integer)
+    n = size(b.W, 1); m = max(0, j - b.d); slot = t >> m; len = n >> j
+    v = b.W[i*len+1:(i+1)*len, siwt_coloff(j, b.d) + slot + 1, sig]
+    return WaveletsExt.SIWT.ShiftInvariantWaveletTransformNode{1,Int,Float64}(j, i, t,
+        b.costs[siwt_nodeoff(j, b.d) + (slot << j) + i + 1, sig], v)
+end
+
 # ---- multi-GPU (one process per GPU; include/waveletsext_hip.h "Multi-GPU exchange") ----------------------------
 # The launcher (MPI.jl, Distributed.jl) broadcasts the 128-byte id made on rank 0.  Transforms need no
 # collective: each process runs the methods above on its contiguous shard `x[:, lo:hi]`.  `buf` arguments of the

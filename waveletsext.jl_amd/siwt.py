@@ -268,9 +268,13 @@ class _Batch:
         fn = getattr(_lib.lib(), "wx_isiwpd" + self.suffix)
         _lib.check(fn(self._wa.ptr, self._status_ptr(), out.ptr, self.n, self.L, self.d, self.B, qp, F, self._wa.stream()))
         # the children were merged into their parents and deleted (SIWT.jl:223-226): only the roots are left
-        st = np.zeros((self.NN, self.B), dtype=np.uint8)
-        st[0, :] = 1
-        self._set_status(st)
+        if self.kind == "torch":
+            self.status.zero_()
+            self.status[:, 0] = 1
+        else:
+            self.status[:] = 0
+            self.status[0, :] = 1
+        self._sh = None
         return out.arr
 
 
