@@ -75,3 +75,20 @@ def test_config4_shape_float32_properties(wx):
     assert float(((e1 - e0).abs() / e0).max()) < 1e-5
     back = wx.iwptall(y, wt, 6)
     assert float((back - x).abs().max() / x.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db8", "db10"])
+def test_wpd2d_tile_level_matches_oracle(wx, oracle, wname, dtype):
+    """images whose sides are multiples of the 64 x 64 (Float32) / 64 x 32 (Float64) tile take the one-pass level
+    (k_dwt2d_level_tile): nodes larger than the tile (halo + wrap), equal to it, and smaller (wrap inside LDS),
+    square and not; the last levels (nodes below 8 samples) fall back to the two-pass level."""
+    rng = np.random.default_rng(64)
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    for (m, n, L, B) in ((64, 64, 6, 3), (128, 64, 5, 2), (64, 256, 4, 2), (256, 128, 3, 1)):
+        x = np.asfortranarray(rng.standard_normal((m, n, B)).astype(dtype))
+        got = wx.wpdall(x, wt, L)
+        exp = oracle.wpdall(x, wt.qmf, L)
+        assert got.shape == (m, n, L + 1, B)
+        assert relerr(got, exp) <= TOL[np.dtype(dtype)], (m, n, L)
+        assert relerr(wx.iwpdall(got, wt, L), x) <= 10 * TOL[np.dtype(dtype)]
