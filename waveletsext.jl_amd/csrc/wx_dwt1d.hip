@@ -556,12 +556,22 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x
     for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
         const T *xs = x + b * x_stride;
         T *ys = y + b * y_stride;
-        for (int u = tid; u < Q; u += NT) {
-            const V4 v = reinterpret_cast<const V4 *>(xs)[u];
+        auto stage = [&](int u, const V4 &v) {
             V2 ev; ev.x = v.x; ev.y = v.z;
             V2 ov; ov.x = v.y; ov.y = v.w;
             if (u & 1) { E1[u >> 1] = ev; O1[u >> 1] = ov; } else { E0[u >> 1] = ev; O0[u >> 1] = ov; }
             if (WRITE_ALL) reinterpret_cast<V4 *>(ys)[u] = v;
+        };
+        if (Q == 2 * NT) {
+            // both 16-byte groups of a lane in flight together (a loop would wait for the first before the second)
+            const V4 v0 = reinterpret_cast<const V4 *>(xs)[tid], v1 = reinterpret_cast<const V4 *>(xs)[tid + NT];
+            stage(tid, v0); stage(tid + NT, v1);
+        } else if (Q == 4 * NT) {
+            const V4 v0 = reinterpret_cast<const V4 *>(xs)[tid], v1 = reinterpret_cast<const V4 *>(xs)[tid + NT];
+            const V4 v2 = reinterpret_cast<const V4 *>(xs)[tid + 2 * NT], v3 = reinterpret_cast<const V4 *>(xs)[tid + 3 * NT];
+            stage(tid, v0); stage(tid + NT, v1); stage(tid + 2 * NT, v2); stage(tid + 3 * NT, v3);
+        } else {
+            for (int u = tid; u < Q; u += NT) stage(u, reinterpret_cast<const V4 *>(xs)[u]);
         }
         __syncthreads();
         bool direct = false;

@@ -235,8 +235,18 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
         T *dp = dst + img * dst_img + r0 + r * V;
         TV *a = cur + r, *b = nxt + r;
         const bool row_ok = r0 + r * V < m;          // m is a multiple of V (checked by the launcher)
-        if (row_ok)
-            for (int c = g0; c < n; c += gstep) a[c * SV] = *reinterpret_cast<const TV *>(sp + (int64_t)c * m);
+        if (row_ok) {
+            // four columns of a lane in flight together (a plain loop waits for each load before the next)
+            int c = g0;
+            for (; c + 3 * gstep < n; c += 4 * gstep) {
+                const TV t0 = *reinterpret_cast<const TV *>(sp + (int64_t)c * m);
+                const TV t1 = *reinterpret_cast<const TV *>(sp + (int64_t)(c + gstep) * m);
+                const TV t2 = *reinterpret_cast<const TV *>(sp + (int64_t)(c + 2 * gstep) * m);
+                const TV t3 = *reinterpret_cast<const TV *>(sp + (int64_t)(c + 3 * gstep) * m);
+                a[c * SV] = t0; a[(c + gstep) * SV] = t1; a[(c + 2 * gstep) * SV] = t2; a[(c + 3 * gstep) * SV] = t3;
+            }
+            for (; c < n; c += gstep) a[c * SV] = *reinterpret_cast<const TV *>(sp + (int64_t)c * m);
+        }
         __syncthreads();
         for (int s = 0; s < L; ++s) {
             const int d = INVERSE ? L - 1 - s : s;
