@@ -63,8 +63,19 @@ __global__ __launch_bounds__(256) void k_bb_costs1d(const T *__restrict__ X, con
     if (cnt >= 256) {
         for (int node = 0; node < nodes; ++node) {
             double acc = 0.0;
-            if (nr != (T)0)
-                for (int i = threadIdx.x; i < cnt; i += blockDim.x) acc += bb_term<T>(x[(int64_t)node * cnt + i], nr, cost_kind);
+            if (nr != (T)0) {
+                // eight loads in flight per lane, then the (long) cost terms
+                const T *xn = x + (int64_t)node * cnt;
+                int i = threadIdx.x;
+                for (; i + 7 * 256 < cnt; i += 8 * 256) {
+                    T v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = xn[i + u * 256];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += bb_term<T>(v[u], nr, cost_kind);
+                }
+                for (; i < cnt; i += 256) acc += bb_term<T>(xn[i], nr, cost_kind);
+            }
             const double tot = bb_block_sum(acc, red);
             if (threadIdx.x == 0) o[node] = (T)(nr == (T)0 ? 0.0 : tot);
         }
@@ -72,8 +83,11 @@ __global__ __launch_bounds__(256) void k_bb_costs1d(const T *__restrict__ X, con
         // coalesced chunks of 256 consecutive coefficients = 256/cnt whole nodes: segmented reduction with
         // wavefront shuffles (groups of cnt <= 64 lanes), one more LDS step for 128-sample nodes
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        T nextv = x[threadIdx.x];                              // the next chunk's load flies under this chunk's terms
         for (int base = 0; base < n; base += 256) {
-            double v = nr != (T)0 ? bb_term<T>(x[base + threadIdx.x], nr, cost_kind) : 0.0;
+            const T cur = nextv;
+            if (base + 256 < n) nextv = x[base + 256 + threadIdx.x];
+            double v = nr != (T)0 ? bb_term<T>(cur, nr, cost_kind) : 0.0;
             const int w0 = cnt < 64 ? cnt : 64;
             for (int w = w0 >> 1; w > 0; w >>= 1) v += __shfl_xor(v, w, 64);
             if (cnt <= 64) {
