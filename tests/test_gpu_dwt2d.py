@@ -92,3 +92,32 @@ def test_wpd2d_tile_level_matches_oracle(wx, oracle, wname, dtype):
         assert got.shape == (m, n, L + 1, B)
         assert relerr(got, exp) <= TOL[np.dtype(dtype)], (m, n, L)
         assert relerr(wx.iwpdall(got, wt, L), x) <= 10 * TOL[np.dtype(dtype)]
+
+
+def _truncate_tree2d(tree, depth):
+    """drop every node of the quad tree at depth >= `depth` (heap order, depth d starts at (4^d - 1) / 3)"""
+    t = np.array(tree, dtype=bool)
+    t[(4 ** depth - 1) // 3:] = False
+    return t
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("wname", ["haar", "db4", "db8"])
+def test_wpt2d_tree_driven_tile_levels(wx, oracle, wname, dtype):
+    """trees on images whose sides are multiples of the tile: the one-pass tree-driven levels (decomposed nodes
+    only; children that are decomposed further go through the scratch images, leaves straight to the output) --
+    nodes larger than, equal to and smaller than a tile, dwt trees, sparse and dense random trees."""
+    rng = np.random.default_rng(3010)
+    wt = _wt(wx, wname)
+    tol = TOL[np.dtype(dtype)]
+    for (m, n, depth, B) in ((64, 64, 4, 3), (128, 64, 3, 2), (64, 256, 4, 2), (256, 256, 5, 1)):
+        x = np.asfortranarray(rng.standard_normal((m, n, B)).astype(dtype))
+        full = wx.maketree(m, n, wx.maxtransformlevels(min(m, n)), "dwt")
+        trees = [_truncate_tree2d(full, depth), _truncate_tree2d(full, 1),
+                 _truncate_tree2d(random_tree_2d(m, n, rng, 0.5), depth),
+                 _truncate_tree2d(random_tree_2d(m, n, rng, 0.9), depth)]
+        for tree in trees:
+            exp = _stack(oracle.wpt, x, wt.qmf, tree)
+            got = wx.wptall(x, wt, tree)
+            assert relerr(got, exp) <= tol, (m, n, int(tree.sum()))
+            assert relerr(wx.iwptall(got, wt, tree), x) <= 20 * tol

@@ -432,8 +432,13 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
 template <typename T, int F, int CR, int CC>
 __global__ __launch_bounds__(256) void k_dwt2d_level_tile(const T *__restrict__ src, T *__restrict__ dst,
                                                           int64_t src_img, int64_t dst_img, int m, int n, int d,
-                                                          WxFilt filt)
+                                                          WxFilt filt, T *__restrict__ dst_int, int64_t int_img,
+                                                          const uint8_t *__restrict__ status, int64_t nstatus,
+                                                          const int *__restrict__ act)
 {
+    // Tree-driven levels (status != nullptr): only the nodes the tree decomposes are transformed; a child that is
+    // decomposed further goes to dst_int (the scratch image the next level reads), a leaf straight to dst.  act
+    // (nodes at least as large as a tile) lists the decomposed nodes so that the grid covers nothing else.
     constexpr int OPT = 4, H = F - 2, W = 2 * F + 2 * OPT - 4;
     constexpr int PIN = (CR + 2 * H) | 1;                // pitch of a staged column (odd)
     constexpr int PT = CR | 1;                           // pitch of a column of the intermediate
@@ -445,11 +450,30 @@ __global__ __launch_bounds__(256) void k_dwt2d_level_tile(const T *__restrict__ 
     const bool bigR = mp > CR, bigC = np > CC;
     const int HR = bigR ? H : 0, HC = bigC ? H : 0;
     const int NR = CR + 2 * HR, NC = CC + 2 * HC;
-    const int tiles_r = m / CR;
-    const int R0 = (int)(blockIdx.x % tiles_r) * CR, C0 = (int)(blockIdx.x / tiles_r) * CC;
+    const int lmp = 31 - __clz(mp), lnp = 31 - __clz(np);
+    int R0, C0;
+    if (act) {
+        const int tpr = mp / CR, tpn = tpr * (np / CC);
+        const int a = (int)blockIdx.x / tpn, t = (int)blockIdx.x - a * tpn;
+        R0 = act[2 * a] * mp + (t % tpr) * CR;
+        C0 = act[2 * a + 1] * np + (t / tpr) * CC;
+    } else {
+        const int tiles_r = m / CR;
+        R0 = (int)(blockIdx.x % tiles_r) * CR;
+        C0 = (int)(blockIdx.x / tiles_r) * CC;
+    }
+    if (status && !act) {
+        // several small nodes per tile: nothing to do unless the tree decomposes one of them
+        const int nnr = bigR ? 1 : CR >> lmp, nnc = bigC ? 1 : CC >> lnp;
+        int any = 0;
+        for (int e = tid; e < nnr * nnc; e += 256)
+            any |= wx_quad_active(status, nstatus, d, (R0 >> lmp) + e % nnr, (C0 >> lnp) + e / nnr) ? 1 : 0;
+        if (!__syncthreads_or(any)) return;
+    }
     const int nbR = R0 & ~(mp - 1), nbC = C0 & ~(np - 1);          // node of the tile (big nodes)
     const T *simg = src + (int64_t)blockIdx.y * src_img;
     T *dimg = dst + (int64_t)blockIdx.y * dst_img;
+    T *iimg = dst_int ? dst_int + (int64_t)blockIdx.y * int_img : dimg;
     T q[F];
 #pragma unroll
     for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
@@ -524,6 +548,14 @@ __global__ __launch_bounds__(256) void k_dwt2d_level_tile(const T *__restrict__ 
         const int hi = tr >= CR / 2, i = tr - hi * (CR / 2);
         const int rs = R0 + 2 * i, nr = rs & ~(mp - 1);
         const int grow = nr + hi * (mp >> 1) + ((rs - nr) >> 1);
+        T *olo = dimg, *ohi = dimg;                      // destinations of the low / high column subbands
+        if (status) {
+            const int64_t h = wx_quad_heap(d, rs >> lmp, (C0 + 2 * j0) >> lnp);     // all OPT pairs lie in one node
+            if (!(h <= nstatus && status[h - 1])) continue;
+            const int64_t c0 = 4 * h - 2 + 2 * hi;
+            if (c0 <= nstatus && status[c0 - 1]) olo = iimg;
+            if (c0 + 1 <= nstatus && status[c0]) ohi = iimg;
+        }
 #pragma unroll
         for (int s2 = 0; s2 < OPT; ++s2) {
             T a = 0, dd = 0;
@@ -534,15 +566,27 @@ __global__ __launch_bounds__(256) void k_dwt2d_level_tile(const T *__restrict__ 
             }
             const int cs = C0 + 2 * (j0 + s2), nc = cs & ~(np - 1);
             const int gcol = nc + ((cs - nc) >> 1);
-            dimg[(int64_t)gcol * m + grow] = a;
-            dimg[(int64_t)(gcol + (np >> 1)) * m + grow] = dd;
+            olo[(int64_t)gcol * m + grow] = a;
+            ohi[(int64_t)(gcol + (np >> 1)) * m + grow] = dd;
         }
     }
 }
 
+struct WxTileTree {                       // tree-driven level: see k_dwt2d_level_tile
+    void *dst_int = nullptr;
+    int64_t int_img = 0;
+    const uint8_t *status = nullptr;
+    int64_t nstatus = 0;
+    const int *act = nullptr;             // used when the nodes are at least as large as a tile
+    int nact = 0;
+};
+
+template <typename T> static constexpr int wx_tile_cc() { return sizeof(T) == 4 ? 64 : 32; }
+static constexpr int WX_TILE_CR = 64;
+
 template <typename T, int F, int CR, int CC>
 static bool wx_launch_level_tile_F(const T *src, T *dst, int64_t src_img, int64_t dst_img, int m, int n, int d,
-                                   int64_t batch, const WxFilt &filt, hipStream_t st)
+                                   int64_t batch, const WxFilt &filt, hipStream_t st, const WxTileTree &tt)
 {
     constexpr int H = F - 2;
     const size_t lds = sizeof(T) * ((size_t)(CC + 2 * H) * ((CR + 2 * H) | 1) + (size_t)(CC + 2 * H) * (CR | 1));
@@ -550,28 +594,39 @@ static bool wx_launch_level_tile_F(const T *src, T *dst, int64_t src_img, int64_
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return false;
-    const unsigned tiles = (unsigned)((m / CR) * (n / CC));
+    const int mp = m >> d, np = n >> d;
+    const bool by_node = tt.status && tt.act && mp >= CR && np >= CC;
+    const unsigned tiles = by_node ? (unsigned)(tt.nact * (mp / CR) * (np / CC)) : (unsigned)((m / CR) * (n / CC));
+    if (tiles == 0) return true;
+    T *di = (T *)tt.dst_int;
     for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
         const unsigned bc = (unsigned)(batch - b0 < 65535 ? batch - b0 : 65535);
         hipLaunchKernelGGL(kern, dim3(tiles, bc), dim3(256), lds, st, src + b0 * src_img, dst + b0 * dst_img, src_img,
-                           dst_img, m, n, d, filt);
+                           dst_img, m, n, d, filt, di ? di + b0 * tt.int_img : (T *)nullptr, tt.int_img, tt.status,
+                           tt.nstatus, by_node ? tt.act : (const int *)nullptr);
     }
     return true;
 }
 
 // true when the level ran as one tile pass; false = not applicable (the caller takes the two-pass level)
-template <typename T>
-static bool wx_launch_level_tile(const T *src, T *dst, int64_t src_img, int64_t dst_img, int m, int n, int d,
-                                 int64_t batch, const WxFilt &filt, hipStream_t st)
+template <typename T> static bool wx_level_tile_ok(int m, int n, int d, int F)
 {
     static const bool off = getenv("WX_LEVEL2D_TILE") && atoi(getenv("WX_LEVEL2D_TILE")) == 0;
     if (off) return false;
     const int mp = m >> d, np = n >> d;
     if ((m & (m - 1)) || (n & (n - 1)) || mp < 8 || np < 8) return false;
-    constexpr int CR = 64, CC = sizeof(T) == 4 ? 64 : 32;
-    if (m % CR || n % CC) return false;
+    if (m % WX_TILE_CR || n % wx_tile_cc<T>()) return false;
+    return F == 2 || F == 4 || F == 6 || F == 8 || F == 10 || F == 12 || F == 16 || F == 20;
+}
+
+template <typename T>
+static bool wx_launch_level_tile(const T *src, T *dst, int64_t src_img, int64_t dst_img, int m, int n, int d,
+                                 int64_t batch, const WxFilt &filt, hipStream_t st, const WxTileTree &tt = WxTileTree())
+{
+    if (!wx_level_tile_ok<T>(m, n, d, filt.F)) return false;
+    constexpr int CR = WX_TILE_CR, CC = wx_tile_cc<T>();
     switch (filt.F) {
-#define WX_CASE(FF) case FF: return wx_launch_level_tile_F<T, FF, CR, CC>(src, dst, src_img, dst_img, m, n, d, batch, filt, st);
+#define WX_CASE(FF) case FF: return wx_launch_level_tile_F<T, FF, CR, CC>(src, dst, src_img, dst_img, m, n, d, batch, filt, st, tt);
         WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(20)
 #undef WX_CASE
     }
@@ -671,6 +726,23 @@ int wx_dev_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, c
             else wx_launch_level2d<T, false>(src, tmp, y, simg, mn, (int)m, (int)n, d, batch, filt, status, nstatus, st, copy,
                                              htree ? dact[(size_t)d] : nullptr, nact[(size_t)d]);
         };
+        if (!inverse && htree && (L == 1 || pong) && wx_level_tile_ok<T>((int)m, (int)n, L - 1, filt.F)) {
+            // one pass per level: a level reads its nodes from the scratch image of its parity (the root from x),
+            // sends the children that are decomposed further to the other scratch image and the leaves to y
+            T *sc[2] = {tmp, pong};
+            for (int d = 0; d < L; ++d) {
+                if (nact[(size_t)d] == 0) continue;
+                WxTileTree tt;
+                tt.dst_int = sc[(d + 1) & 1]; tt.int_img = mn;
+                tt.status = status; tt.nstatus = nstatus;
+                tt.act = dact[(size_t)d]; tt.nact = nact[(size_t)d];
+                if (!wx_launch_level_tile<T>(d ? (const T *)sc[d & 1] : x, y, d ? mn : in_img, mn, (int)m, (int)n, d, batch,
+                                             filt, st, tt))
+                    return wx_set_error(WX_EHIP, "2-D tile level failed to launch");
+            }
+            WX_HIP_CHECK(hipGetLastError());
+            return WX_OK;
+        }
         if (!inverse) {
             level(x, in_img, 0, false, 1);                                 // the root: every block is written
             for (int d = 1; d < L; ++d) level(y, mn, d, false, 0);
