@@ -120,4 +120,9 @@ def test_wpt2d_tree_driven_tile_levels(wx, oracle, wname, dtype):
             exp = _stack(oracle.wpt, x, wt.qmf, tree)
             got = wx.wptall(x, wt, tree)
             assert relerr(got, exp) <= tol, (m, n, int(tree.sum()))
-            assert relerr(wx.iwptall(got, wt, tree), x) <= 20 * tol
+            back = wx.iwptall(exp, wt, tree)
+            assert relerr(back, _stack(oracle.iwpt, exp, wt.qmf, tree)) <= tol, (m, n, int(tree.sum()))
+            assert relerr(back, x) <= 20 * tol
+        xw = wx.wpdall(x, wt, depth)                      # iwpd gathers the leaves of the tree from the table first
+        for tree in trees[2:]:
+            assert relerr(wx.iwpdall(xw, wt, tree), x) <= 20 * tol

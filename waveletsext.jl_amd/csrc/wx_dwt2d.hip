@@ -633,6 +633,204 @@ static bool wx_launch_level_tile(const T *src, T *dst, int64_t src_img, int64_t 
     return false;
 }
 
+// ---- tree-driven inverse level in one pass ---------------------------------------------------------------
+// The mirror of k_dwt2d_level_tile for idwt_step! 2-D (dwt/dwt_one_level.jl:401-436: along the rows first, then
+// down the columns).  A workgroup rebuilds a CR x CC tile of every decomposed node of depth d: the four child
+// tiles (F/2 - 1 halo pairs on both sides for nodes larger than the tile, whole nodes wrapping in LDS otherwise)
+// are staged from the image that holds them -- a child that was itself rebuilt one level earlier comes from the
+// scratch image src_int, a leaf from the caller's coefficients src_leaf -- synthesised along dim 2 into a second
+// LDS array ([low; high] rows), along dim 1 into an LDS copy of the output tile (lanes across columns of odd
+// pitch: conflict-free) and stored with lanes down the rows.  One read of the children and one write of the
+// parent per level instead of two of each.
+template <typename T, int F, int CR, int CC>
+__global__ __launch_bounds__(256) void k_idwt2d_level_tile(const T *__restrict__ src_leaf, int64_t leaf_img,
+                                                           const T *__restrict__ src_int, int64_t int_img,
+                                                           T *__restrict__ dst, int64_t dst_img, int m, int n, int d,
+                                                           WxFilt filt, const uint8_t *__restrict__ status,
+                                                           int64_t nstatus, const int *__restrict__ act)
+{
+    constexpr int OPT = 4, HF = F / 2, G = HF - 1, WN = G + OPT;
+    constexpr int HRm = CR / 2 + 2 * G, HCm = CC / 2 + 2 * G;
+    constexpr int PCH = HRm | 1;                         // pitch of a staged child column
+    constexpr int PTP = (2 * HRm) | 1;                   // pitch of a column of the intermediate ([low; high] rows)
+    constexpr int POUT = CR | 1;                         // pitch of a column of the output tile (aliases the children)
+    static_assert(CC * POUT <= 4 * HCm * PCH, "output tile must fit the staged children");
+    extern __shared__ __attribute__((aligned(16))) char wx_smem3[];
+    T *ch = reinterpret_cast<T *>(wx_smem3);
+    T *tmp = ch + 4 * HCm * PCH;
+    uint8_t *fl = reinterpret_cast<uint8_t *>(tmp + CC * PTP);       // per (node of the tile, child): 0 skip, 1 leaf, 2 scratch
+    T *out = ch;
+    const int tid = threadIdx.x;
+    const int mp = m >> d, np = n >> d, hr = mp >> 1, hc = np >> 1;
+    const int lmp = 31 - __clz(mp), lnp = 31 - __clz(np);
+    const bool bigR = mp > CR, bigC = np > CC;
+    const int GR = bigR ? G : 0, GC = bigC ? G : 0;
+    const int NRc = CR / 2 + 2 * GR, NCc = CC / 2 + 2 * GC;          // staged rows / columns of a child
+    int R0, C0;
+    if (act) {
+        const int tpr = mp / CR, tpn = tpr * (np / CC);
+        const int a = (int)blockIdx.x / tpn, t = (int)blockIdx.x - a * tpn;
+        R0 = act[2 * a] * mp + (t % tpr) * CR;
+        C0 = act[2 * a + 1] * np + (t / tpr) * CC;
+    } else {
+        const int tiles_r = m / CR;
+        R0 = (int)(blockIdx.x % tiles_r) * CR;
+        C0 = (int)(blockIdx.x / tiles_r) * CC;
+    }
+    const int nnr = bigR ? 1 : CR >> lmp, nnc = bigC ? 1 : CC >> lnp;
+    int any = 0;
+    for (int e = tid; e < nnr * nnc * 4; e += 256) {
+        const int c = e & 3, nd = e >> 2;
+        const int64_t h = wx_quad_heap(d, (R0 >> lmp) + nd % nnr, (C0 >> lnp) + nd / nnr);
+        uint8_t f = 0;
+        if (h <= nstatus && status[h - 1]) {
+            const int64_t hch = 4 * h - 2 + c;
+            f = (hch <= nstatus && status[hch - 1]) ? 2 : 1;
+        }
+        fl[e] = f;
+        any |= f;
+    }
+    if (!__syncthreads_or(any)) return;
+    const int nbR = R0 & ~(mp - 1), nbC = C0 & ~(np - 1);
+    const T *limg = src_leaf + (int64_t)blockIdx.y * leaf_img;
+    const T *iimg = src_int ? src_int + (int64_t)blockIdx.y * int_img : limg;
+    T *dimg = dst + (int64_t)blockIdx.y * dst_img;
+    T q[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
+
+    // stage the four children (batches of independent loads, see k_dwt2d_level_tile)
+    {
+        const int per = NRc * NCc, tot = 4 * per;
+        constexpr int NBMAX = (4 * HRm * HCm + 255) / 256;
+        constexpr int NB = NBMAX < 24 ? NBMAX : 24;
+        for (int e0 = tid; e0 < tot; e0 += NB * 256) {
+            T v[NB];
+            int at[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int e = e0 + u * 256;
+                at[u] = -1;
+                if (e < tot) {
+                    const int c = e / per, r2 = e - c * per;
+                    const int lc = r2 / NRc, lr = r2 - lc * NRc;
+                    int grow, gcol, jn = 0, kn = 0;
+                    if (bigR) grow = nbR + (c >> 1) * hr + ((((R0 - nbR) >> 1) + lr - G) & (hr - 1));
+                    else { jn = lr >> (lmp - 1); grow = R0 + jn * mp + (c >> 1) * hr + (lr & (hr - 1)); }
+                    if (bigC) gcol = nbC + (c & 1) * hc + ((((C0 - nbC) >> 1) + lc - G) & (hc - 1));
+                    else { kn = lc >> (lnp - 1); gcol = C0 + kn * np + (c & 1) * hc + (lc & (hc - 1)); }
+                    const uint8_t f = fl[(kn * nnr + jn) * 4 + c];
+                    v[u] = f ? (f == 2 ? iimg : limg)[(int64_t)gcol * m + grow] : (T)0;
+                    at[u] = (c * HCm + lc) * PCH + lr;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) if (at[u] >= 0) ch[at[u]] = v[u];
+        }
+    }
+    __syncthreads();
+    // dim 2: item = (row half, staged child row, group of OPT column pairs); lanes down the rows
+    for (int e = tid; e < 2 * NRc * (CC / 2 / OPT); e += 256) {
+        const int g = e / (2 * NRc), r2 = e - g * (2 * NRc);
+        const int rh = r2 / NRc, lr = r2 - rh * NRc;
+        const T *ca = ch + (rh * 2) * HCm * PCH + lr, *cd = ch + (rh * 2 + 1) * HCm * PCH + lr;
+        T aw[WN], dw[WN];
+        if (bigC) {
+#pragma unroll
+            for (int t = 0; t < WN; ++t) { aw[t] = ca[(g * OPT + t) * PCH]; dw[t] = cd[(g * OPT + t + G) * PCH]; }
+        } else {
+            const int base = (g * OPT) & ~(hc - 1), p = g * OPT - base;
+#pragma unroll
+            for (int t = 0; t < WN; ++t) {
+                aw[t] = ca[(base + ((p - G + t) & (hc - 1))) * PCH];
+                dw[t] = cd[(base + ((p + t) & (hc - 1))) * PCH];
+            }
+        }
+        T *to = tmp + rh * HRm + lr;
+#pragma unroll
+        for (int s2 = 0; s2 < OPT; ++s2) {
+            T v0 = 0, v1 = 0;
+#pragma unroll
+            for (int mm = 0; mm < HF; ++mm) {
+                v0 = fma(q[2 * mm], aw[s2 + G - mm], v0); v0 = fma(-q[2 * mm + 1], dw[s2 + mm], v0);
+                v1 = fma(q[2 * mm + 1], aw[s2 + G - mm], v1); v1 = fma(q[2 * mm], dw[s2 + mm], v1);
+            }
+            to[(2 * (g * OPT + s2)) * PTP] = v0;
+            to[(2 * (g * OPT + s2) + 1) * PTP] = v1;
+        }
+    }
+    __syncthreads();
+    // dim 1: item = (column, group of OPT row pairs); lanes across the columns
+    for (int e = tid; e < CC * (CR / 2 / OPT); e += 256) {
+        const int g = e / CC, c = e - g * CC;
+        const T *lo = tmp + c * PTP, *hi = lo + HRm;
+        T aw[WN], dw[WN];
+        if (bigR) {
+#pragma unroll
+            for (int t = 0; t < WN; ++t) { aw[t] = lo[g * OPT + t]; dw[t] = hi[g * OPT + t + G]; }
+        } else {
+            const int base = (g * OPT) & ~(hr - 1), p = g * OPT - base;
+#pragma unroll
+            for (int t = 0; t < WN; ++t) { aw[t] = lo[base + ((p - G + t) & (hr - 1))]; dw[t] = hi[base + ((p + t) & (hr - 1))]; }
+        }
+        T *to = out + c * POUT;
+#pragma unroll
+        for (int s2 = 0; s2 < OPT; ++s2) {
+            T v0 = 0, v1 = 0;
+#pragma unroll
+            for (int mm = 0; mm < HF; ++mm) {
+                v0 = fma(q[2 * mm], aw[s2 + G - mm], v0); v0 = fma(-q[2 * mm + 1], dw[s2 + mm], v0);
+                v1 = fma(q[2 * mm + 1], aw[s2 + G - mm], v1); v1 = fma(q[2 * mm], dw[s2 + mm], v1);
+            }
+            to[2 * (g * OPT + s2)] = v0;
+            to[2 * (g * OPT + s2) + 1] = v1;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < CR * CC; e += 256) {
+        const int c = e / CR, r = e - c * CR;
+        const int jn = bigR ? 0 : r >> lmp, kn = bigC ? 0 : c >> lnp;
+        if (fl[(kn * nnr + jn) * 4]) dimg[(int64_t)(C0 + c) * m + R0 + r] = out[c * POUT + r];
+    }
+}
+
+template <typename T, int F, int CR, int CC>
+static bool wx_launch_ilevel_tile_F(const T *src_leaf, int64_t leaf_img, const T *src_int, T *dst, int64_t dst_img, int m,
+                                    int n, int d, int64_t batch, const WxFilt &filt, hipStream_t st, const WxTileTree &tt)
+{
+    constexpr int G = F / 2 - 1, HRm = CR / 2 + 2 * G, HCm = CC / 2 + 2 * G;
+    const size_t lds = sizeof(T) * ((size_t)4 * HCm * (HRm | 1) + (size_t)CC * ((2 * HRm) | 1)) + 256;
+    auto kern = k_idwt2d_level_tile<T, F, CR, CC>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return false;
+    const int mp = m >> d, np = n >> d;
+    const bool by_node = tt.act && mp >= CR && np >= CC;
+    const unsigned tiles = by_node ? (unsigned)(tt.nact * (mp / CR) * (np / CC)) : (unsigned)((m / CR) * (n / CC));
+    if (tiles == 0) return true;
+    for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+        const unsigned bc = (unsigned)(batch - b0 < 65535 ? batch - b0 : 65535);
+        hipLaunchKernelGGL(kern, dim3(tiles, bc), dim3(256), lds, st, src_leaf + b0 * leaf_img, leaf_img,
+                           src_int ? src_int + b0 * tt.int_img : (const T *)nullptr, tt.int_img, dst + b0 * dst_img, dst_img,
+                           m, n, d, filt, tt.status, tt.nstatus, by_node ? tt.act : (const int *)nullptr);
+    }
+    return true;
+}
+
+template <typename T>
+static bool wx_launch_ilevel_tile(const T *src_leaf, int64_t leaf_img, const T *src_int, T *dst, int64_t dst_img, int m,
+                                  int n, int d, int64_t batch, const WxFilt &filt, hipStream_t st, const WxTileTree &tt)
+{
+    if (!wx_level_tile_ok<T>(m, n, d, filt.F) || !tt.status) return false;
+    constexpr int CR = WX_TILE_CR, CC = wx_tile_cc<T>();
+    switch (filt.F) {
+#define WX_CASE(FF) case FF: return wx_launch_ilevel_tile_F<T, FF, CR, CC>(src_leaf, leaf_img, src_int, dst, dst_img, m, n, d, batch, filt, st, tt);
+        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(20)
+#undef WX_CASE
+    }
+    return false;
+}
+
 static int wx_grid2(int64_t total)
 {
     int64_t g = (total + 255) / 256;
@@ -739,6 +937,24 @@ int wx_dev_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, c
                 if (!wx_launch_level_tile<T>(d ? (const T *)sc[d & 1] : x, y, d ? mn : in_img, mn, (int)m, (int)n, d, batch,
                                              filt, st, tt))
                     return wx_set_error(WX_EHIP, "2-D tile level failed to launch");
+            }
+            WX_HIP_CHECK(hipGetLastError());
+            return WX_OK;
+        }
+        if (inverse && htree && (L == 1 || pong) && wx_level_tile_ok<T>((int)m, (int)n, L - 1, filt.F)) {
+            // the mirror image: a level takes the children that were rebuilt one level earlier from the scratch
+            // image of their parity and the leaves from x, and writes the parents into the other scratch image (the
+            // root into y)
+            T *sc[2] = {tmp, pong};
+            for (int d = L - 1; d >= 0; --d) {
+                if (nact[(size_t)d] == 0) continue;
+                WxTileTree tt;
+                tt.int_img = mn;
+                tt.status = status; tt.nstatus = nstatus;
+                tt.act = dact[(size_t)d]; tt.nact = nact[(size_t)d];
+                if (!wx_launch_ilevel_tile<T>(x, in_img, (const T *)sc[(d + 1) & 1], d ? sc[d & 1] : y, mn, (int)m, (int)n, d,
+                                              batch, filt, st, tt))
+                    return wx_set_error(WX_EHIP, "2-D inverse tile level failed to launch");
             }
             WX_HIP_CHECK(hipGetLastError());
             return WX_OK;
