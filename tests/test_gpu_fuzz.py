@@ -234,3 +234,65 @@ def test_fuzz_denoise_random_trees(wx, oracle):
                 exp = oracle.denoise(np.asfortranarray(X[..., i]), inputtype, wt.qmf, L=Lmax, tree=tree, th=thname,
                                      t=dnt.t, estnoise=est, smooth=smooth)
                 assert relerr(Y[:, i], exp) <= 1e-9, (n, inputtype, thname, smooth, est)
+
+
+def test_fuzz_long_signals_tiles_and_siwt(wx, oracle):
+    """the paths added after the first fuzz rounds: 1-D signals beyond the LDS of a CU (per-level launches, then the
+    fused kernel on the nodes), 2-D images made of whole tiles (one-pass levels, full and tree-driven, forward and
+    inverse), and the shift-invariant decomposition"""
+    from helpers import random_tree_2d
+    rng = np.random.default_rng(4010)
+    for it in range(6 * SCALE):
+        dt = np.dtype(rng.choice([np.float64, np.float32]))
+        wt = wx.wavelet(getattr(wx.WT, str(rng.choice(FILTERS[:8]))))
+        n = 1 << int(rng.integers(13, 17))
+        B = int(rng.choice([1, 2, 5]))
+        L = int(rng.integers(1, wx.maxtransformlevels(n) - 2))
+        x = np.asfortranarray(rng.standard_normal((n, B)).astype(dt))
+        tag = ("1d", n, L, B, wt.name, str(dt))
+        exp = _stack(oracle.wpd, x, wt.qmf, L)
+        assert relerr(wx.wpdall(x, wt, L), exp) <= TOL[dt], tag
+        leaves = np.asfortranarray(exp[:, L, :])
+        assert relerr(wx.wptall(x, wt, L), leaves) <= TOL[dt], tag
+        assert relerr(wx.iwptall(leaves, wt, L), x) <= 50 * TOL[dt], tag
+        assert relerr(wx.iwpdall(exp, wt, L), x) <= 50 * TOL[dt], tag
+    for it in range(8 * SCALE):
+        dt = np.dtype(rng.choice([np.float64, np.float32]))
+        wt = wx.wavelet(getattr(wx.WT, str(rng.choice(["haar", "db2", "db3", "db4", "db5", "db6", "db8", "db10"]))))
+        m, n = 64 << int(rng.integers(0, 3)), 64 << int(rng.integers(0, 3))
+        B = int(rng.choice([1, 3]))
+        depth = int(rng.integers(1, wx.maxtransformlevels(min(m, n)) - 1))           # nodes of >= 8 samples... or fewer
+        x = np.asfortranarray(rng.standard_normal((m, n, B)).astype(dt))
+        tag = ("2d", m, n, depth, B, wt.name, str(dt))
+        xw = wx.wpdall(x, wt, depth)
+        assert relerr(xw, _stack(oracle.wpd, x, wt.qmf, depth)) <= TOL[dt], tag
+        tree = random_tree_2d(m, n, rng, float(rng.choice([0.4, 0.7, 0.95])))
+        tree[(4 ** depth - 1) // 3:] = False
+        yt = wx.wptall(x, wt, tree)
+        assert relerr(yt, _stack(oracle.wpt, x, wt.qmf, tree)) <= TOL[dt], tag
+        assert relerr(wx.iwptall(yt, wt, tree), x) <= 50 * TOL[dt], tag
+        assert relerr(wx.iwpdall(xw, wt, tree), x) <= 50 * TOL[dt], tag
+    for it in range(10 * SCALE):
+        dt = np.dtype(rng.choice([np.float64, np.float32]))
+        wt = wx.wavelet(getattr(wx.WT, str(rng.choice(FILTERS[:8]))))
+        k = int(rng.integers(2, 8))
+        n = int(rng.choice([1, 1, 3])) << k
+        L = int(rng.integers(1, k + 1))
+        d = int(rng.integers(1, L + 1))
+        B = int(rng.choice([1, 4]))
+        X = np.asfortranarray(rng.standard_normal((n, B)).astype(dt))
+        tag = ("siwt", n, L, d, B, wt.name, str(dt))
+        batch = wx.siwpdall(X, wt, L, d)
+        ref = oracle.siwpd(X[:, B - 1], wt.qmf, L, d)
+        obj = batch[B - 1]
+        assert obj.BestTree == ref.BestTree, tag
+        for key in list(ref.Nodes)[:: max(1, len(ref.Nodes) // 40)]:
+            v = np.asarray(obj.Nodes[key].Value)
+            scale = max(1.0, float(np.abs(ref.Nodes[key]["Value"]).max()))
+            assert float(np.abs(v - ref.Nodes[key]["Value"]).max()) <= (0.0 if dt == np.float64 else 1e-6) * scale, (tag, key)
+            assert abs(obj.Nodes[key].Cost - ref.Nodes[key]["Cost"]) <= (1e-9 if dt == np.float64 else 2e-4) * max(1.0, abs(ref.Nodes[key]["Cost"])), (tag, key)
+        wx.bestbasistreeall_(batch)
+        oracle.siwt_bestbasistree(ref)
+        assert wx.isvalidtree(obj), tag
+        assert abs(obj.MinCost - ref.MinCost) <= (1e-9 if dt == np.float64 else 2e-4) * max(1.0, abs(ref.MinCost)), tag
+        assert relerr(wx.isiwpdall(batch), X) <= 50 * TOL[dt], tag
