@@ -126,3 +126,17 @@ def test_wpt2d_tree_driven_tile_levels(wx, oracle, wname, dtype):
         xw = wx.wpdall(x, wt, depth)                      # iwpd gathers the leaves of the tree from the table first
         for tree in trees[2:]:
             assert relerr(wx.iwpdall(xw, wt, tree), x) <= 20 * tol
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4"])
+def test_full_tree_rows_in_place_kernel(wx, oracle, wname):
+    """row counts that select the one-LDS-image row kernel of the full-tree fast path (512 columns Float32, 256
+    columns Float64): forward and inverse against the oracle"""
+    rng = np.random.default_rng(3020)
+    wt = _wt(wx, wname)
+    for (m, n, dtype, L) in ((64, 512, np.float32, 6), (32, 512, np.float32, 3), (64, 256, np.float64, 5), (16, 256, np.float64, 4)):
+        x = np.asfortranarray(rng.standard_normal((m, n, 2)).astype(dtype))
+        exp = _stack(oracle.wpt, x, wt.qmf, L)
+        got = wx.wptall(x, wt, L)
+        assert relerr(got, exp) <= TOL[np.dtype(dtype)], (m, n, L)
+        assert relerr(wx.iwptall(exp, wt, L), x) <= 20 * TOL[np.dtype(dtype)], (m, n, L)

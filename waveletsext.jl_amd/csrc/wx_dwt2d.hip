@@ -207,11 +207,16 @@ template <typename T, int V> struct alignas(sizeof(T) * V) WxRowVec { T e[V]; };
 
 // V = rows per lane (16-byte LDS / HBM accesses when V * sizeof(T) = 16): the filter work per LDS
 // instruction grows V-fold, which is what bounds this kernel (LDS instruction issue, not bytes).
-template <typename T, int F, bool INVERSE, int V>
+template <typename T, int F, bool INVERSE, int V, int KI = 0>
 __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, T *__restrict__ dst,
                                                      int64_t src_img, int64_t dst_img, int m, int log2n, int L,
                                                      int64_t nimg, WxFilt filt, int log2R, int S)
 {
+    // KI == 0: two LDS images, a level reads one and writes the other.  KI > 0: one LDS image, every lane keeps the
+    // results of its (at most KI) items in registers across a barrier and writes them back in place -- half the
+    // LDS, so two workgroups share a CU and one loads / stores its strip while the other computes.
+    constexpr bool INPLACE = KI > 0;
+    constexpr int KM = INPLACE ? KI : 1;
     typedef WxRowVec<T, V> TV;
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     const int n = 1 << log2n;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
     const int RV = R / V, log2RV = log2R - (V == 4 ? 2 : (V == 2 ? 1 : 0));
     const int SV = S / V;                             // LDS column pitch in vectors
     TV *cur = reinterpret_cast<TV *>(wx_smem);
-    TV *nxt = cur + (size_t)n * SV;
+    TV *nxt = INPLACE ? cur : cur + (size_t)n * SV;
     const int strips_per_img = (m + R - 1) >> log2R;
     const int64_t nstrips = nimg * strips_per_img;
     T q[F];
@@ -228,6 +233,70 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
     const int r = threadIdx.x & (RV - 1);            // row group of the strip owned by this lane
     const int g0 = threadIdx.x >> log2RV;            // first item (column pair group) of this lane
     const int gstep = blockDim.x >> log2RV;
+
+    // one item = two output pairs of one node: 2F-tap window (forward) / F/2+1 pairs of children (inverse)
+    auto compute = [&](const TV *a, int lnp, int it, TV (&res)[4]) {
+        const int np = 1 << lnp, h = np >> 1;
+        const int j = it >> (lnp - 2), t = it & ((h >> 1) - 1);
+        const TV *v = a + (size_t)(j << lnp) * SV;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < V; ++e) res[u].e[e] = 0;
+        if (!INVERSE) {
+            // outputs i = 2t, 2t+1: a[i] needs v[2i..2i+F-1], d[i] needs v[2i+2-F..2i+1]
+            TV w[2 * F];
+#pragma unroll
+            for (int k = 0; k < 2 * F; ++k) w[k] = v[((4 * t + 2 - F + k) & (np - 1)) * SV];
+#pragma unroll
+            for (int k = 0; k < F; ++k) {
+                const T qd = (k & 1) ? -q[k] : q[k];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    res[0].e[e] = fma(q[k], w[F - 2 + k].e[e], res[0].e[e]);
+                    res[1].e[e] = fma(q[k], w[F + k].e[e], res[1].e[e]);
+                    res[2].e[e] = fma(qd, w[F - 1 - k].e[e], res[2].e[e]);
+                    res[3].e[e] = fma(qd, w[F + 1 - k].e[e], res[3].e[e]);
+                }
+            }
+        } else {
+            // parent samples 4t..4t+3 (k = 2t, 2t+1) from a[k-m], d[k+m]
+            constexpr int HF = F / 2;
+            TV aw[HF + 1], dw[HF + 1];
+#pragma unroll
+            for (int k = 0; k < HF + 1; ++k) {
+                aw[k] = v[((2 * t + 1 - HF + k) & (h - 1)) * SV];        // a[2t+1-HF .. 2t+1]
+                dw[k] = v[(h + ((2 * t + k) & (h - 1))) * SV];           // d[2t .. 2t+HF]
+            }
+#pragma unroll
+            for (int mm = 0; mm < HF; ++mm) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    res[0].e[e] = fma(q[2 * mm], aw[HF - 1 - mm].e[e], res[0].e[e]);
+                    res[0].e[e] = fma(-q[2 * mm + 1], dw[mm].e[e], res[0].e[e]);
+                    res[1].e[e] = fma(q[2 * mm + 1], aw[HF - 1 - mm].e[e], res[1].e[e]);
+                    res[1].e[e] = fma(q[2 * mm], dw[mm].e[e], res[1].e[e]);
+                    res[2].e[e] = fma(q[2 * mm], aw[HF - mm].e[e], res[2].e[e]);
+                    res[2].e[e] = fma(-q[2 * mm + 1], dw[1 + mm].e[e], res[2].e[e]);
+                    res[3].e[e] = fma(q[2 * mm + 1], aw[HF - mm].e[e], res[3].e[e]);
+                    res[3].e[e] = fma(q[2 * mm], dw[1 + mm].e[e], res[3].e[e]);
+                }
+            }
+        }
+    };
+    auto store = [&](TV *b, int lnp, int it, const TV (&res)[4]) {
+        const int np = 1 << lnp, h = np >> 1;
+        const int j = it >> (lnp - 2), t = it & ((h >> 1) - 1);
+        TV *o = b + (size_t)(j << lnp) * SV;
+        if (!INVERSE) {
+            o[(2 * t) * SV] = res[0]; o[(2 * t + 1) * SV] = res[1];
+            o[(h + 2 * t) * SV] = res[2]; o[(h + 2 * t + 1) * SV] = res[3];
+        } else {
+            o[(4 * t) * SV] = res[0]; o[(4 * t + 1) * SV] = res[1];
+            o[(4 * t + 2) * SV] = res[2]; o[(4 * t + 3) * SV] = res[3];
+        }
+    };
+
     for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
         const int64_t img = sidx / strips_per_img;
         const int r0 = (int)(sidx - img * strips_per_img) << log2R;
@@ -253,64 +322,29 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
             const int lnp = log2n - d;               // log2(node length)
             const int np = 1 << lnp, h = np >> 1;
             if (h >= 2) {
-                // two output pairs per item: 2F-tap window held in registers
-                for (int it = g0; it < (n >> 2); it += gstep) {
-                    const int j = it >> (lnp - 2), t = it & ((h >> 1) - 1);
-                    const TV *v = a + (size_t)(j << lnp) * SV;
-                    TV *o = b + (size_t)(j << lnp) * SV;
-                    if (!INVERSE) {
-                        // outputs i = 2t, 2t+1: a[i] needs v[2i..2i+F-1], d[i] needs v[2i+2-F..2i+1]
-                        TV w[2 * F];
+                if (INPLACE) {
+                    TV res[KM][4];
 #pragma unroll
-                        for (int k = 0; k < 2 * F; ++k) w[k] = v[((4 * t + 2 - F + k) & (np - 1)) * SV];
-                        TV a0, a1, d0, d1;
+                    for (int ki = 0; ki < KM; ++ki) {
+                        const int it = g0 + ki * gstep;
+                        if (it < (n >> 2)) compute(a, lnp, it, res[ki]);
+                    }
+                    __syncthreads();
 #pragma unroll
-                        for (int e = 0; e < V; ++e) { a0.e[e] = 0; a1.e[e] = 0; d0.e[e] = 0; d1.e[e] = 0; }
-#pragma unroll
-                        for (int k = 0; k < F; ++k) {
-                            const T qd = (k & 1) ? -q[k] : q[k];
-#pragma unroll
-                            for (int e = 0; e < V; ++e) {
-                                a0.e[e] = fma(q[k], w[F - 2 + k].e[e], a0.e[e]);
-                                a1.e[e] = fma(q[k], w[F + k].e[e], a1.e[e]);
-                                d0.e[e] = fma(qd, w[F - 1 - k].e[e], d0.e[e]);
-                                d1.e[e] = fma(qd, w[F + 1 - k].e[e], d1.e[e]);
-                            }
-                        }
-                        o[(2 * t) * SV] = a0; o[(2 * t + 1) * SV] = a1;
-                        o[(h + 2 * t) * SV] = d0; o[(h + 2 * t + 1) * SV] = d1;
-                    } else {
-                        // parent samples 4t..4t+3 (k = 2t, 2t+1) from a[k-m], d[k+m]
-                        constexpr int HF = F / 2;
-                        TV aw[HF + 1], dw[HF + 1];
-#pragma unroll
-                        for (int k = 0; k < HF + 1; ++k) {
-                            aw[k] = v[((2 * t + 1 - HF + k) & (h - 1)) * SV];        // a[2t+1-HF .. 2t+1]
-                            dw[k] = v[(h + ((2 * t + k) & (h - 1))) * SV];           // d[2t .. 2t+HF]
-                        }
-                        TV v0, v1, v2, v3;
-#pragma unroll
-                        for (int e = 0; e < V; ++e) { v0.e[e] = 0; v1.e[e] = 0; v2.e[e] = 0; v3.e[e] = 0; }
-#pragma unroll
-                        for (int mm = 0; mm < HF; ++mm) {
-#pragma unroll
-                            for (int e = 0; e < V; ++e) {
-                                v0.e[e] = fma(q[2 * mm], aw[HF - 1 - mm].e[e], v0.e[e]);
-                                v0.e[e] = fma(-q[2 * mm + 1], dw[mm].e[e], v0.e[e]);
-                                v1.e[e] = fma(q[2 * mm + 1], aw[HF - 1 - mm].e[e], v1.e[e]);
-                                v1.e[e] = fma(q[2 * mm], dw[mm].e[e], v1.e[e]);
-                                v2.e[e] = fma(q[2 * mm], aw[HF - mm].e[e], v2.e[e]);
-                                v2.e[e] = fma(-q[2 * mm + 1], dw[1 + mm].e[e], v2.e[e]);
-                                v3.e[e] = fma(q[2 * mm + 1], aw[HF - mm].e[e], v3.e[e]);
-                                v3.e[e] = fma(q[2 * mm], dw[1 + mm].e[e], v3.e[e]);
-                            }
-                        }
-                        o[(4 * t) * SV] = v0; o[(4 * t + 1) * SV] = v1;
-                        o[(4 * t + 2) * SV] = v2; o[(4 * t + 3) * SV] = v3;
+                    for (int ki = 0; ki < KM; ++ki) {
+                        const int it = g0 + ki * gstep;
+                        if (it < (n >> 2)) store(b, lnp, it, res[ki]);
+                    }
+                } else {
+                    for (int it = g0; it < (n >> 2); it += gstep) {
+                        TV res[4];
+                        compute(a, lnp, it, res);
+                        store(b, lnp, it, res);
                     }
                 }
             } else {
-                // nodes of two samples: a = v0 sum(q even) + v1 sum(q odd), ... (wrapped taps)
+                // nodes of two samples: a = v0 sum(q even) + v1 sum(q odd), ... (wrapped taps); an item only
+                // touches its own pair, so this step is in place as it stands
                 for (int j = g0; j < (n >> 1); j += gstep) {
                     const TV x0 = a[(2 * j) * SV], x1 = a[(2 * j + 1) * SV];
                     TV y0, y1;
@@ -336,7 +370,7 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
                 }
             }
             __syncthreads();
-            TV *tmp = a; a = b; b = tmp;
+            if (!INPLACE) { TV *tmp = a; a = b; b = tmp; }
         }
         if (row_ok)
             for (int c = g0; c < n; c += gstep) *reinterpret_cast<TV *>(dp + (int64_t)c * m) = a[c * SV];
@@ -369,16 +403,30 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
 {
     int R, S;
     wx_rows_geometry<T>(R, S);
-    const size_t lds = (size_t)2 * n * S * sizeof(T);
+    size_t lds = (size_t)2 * n * S * sizeof(T);
     // 16-byte row vectors when the geometry and the pointers allow it
     constexpr int VW = 16 / (int)sizeof(T);
     const bool vec = m % VW == 0 && R % VW == 0 && S % VW == 0 && src_img % VW == 0 && dst_img % VW == 0 &&
                      ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) && filt.F <= 12 &&   // 2F-tap window of vectors in registers
                      !getenv("WX_ROWS_SCALAR");
     void (*kern)(const T *, T *, int64_t, int64_t, int, int, int, int64_t, WxFilt, int, int) = nullptr;
+    // in place (one LDS image, two workgroups of 1024 lanes per CU) when a lane has at most two items per level
+    static const int inplace_env = getenv("WX_ROWS_INPLACE") ? atoi(getenv("WX_ROWS_INPLACE")) : 1;
+    // (two workgroups of 512 lanes: the same 16 wavefronts per CU as one workgroup of 1024 with two LDS images,
+    // but their load / compute / store phases interleave)
+    const int nt_ip = 512;
+    const int lanes_per_col = vec ? R / VW : R;
+    const int items_per_lane = (int)((n / 4 + (nt_ip / lanes_per_col) - 1) / (nt_ip / lanes_per_col));
+    const bool inplace = inplace_env && vec && filt.F <= 8 && lanes_per_col <= nt_ip && items_per_lane <= 2 &&
+                         (size_t)n * S * sizeof(T) <= 80 * 1024 && (size_t)n * S * sizeof(T) > 40 * 1024;
+    if (inplace) lds = (size_t)n * S * sizeof(T);
     switch (filt.F) {
 #define WX_CASE(FF) case FF: kern = vec ? k_rows_fused<T, FF, INVERSE, VW> : k_rows_fused<T, FF, INVERSE, 1>; break;
-        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+        WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+#undef WX_CASE
+#define WX_CASE(FF) case FF: kern = inplace ? (items_per_lane <= 1 ? k_rows_fused<T, FF, INVERSE, VW, 1> : k_rows_fused<T, FF, INVERSE, VW, 2>) \
+                                   : (vec ? k_rows_fused<T, FF, INVERSE, VW> : k_rows_fused<T, FF, INVERSE, 1>); break;
+        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8)
 #undef WX_CASE
     default: return wx_set_error(WX_EUNSUPPORTED, "no fused row kernel for this filter length");
     }
@@ -390,7 +438,7 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
     const int64_t nstrips = batch * ((m + R - 1) / R);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
-    const int nt = per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024);
+    const int nt = inplace ? nt_ip : (per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024));
     int64_t grid = (int64_t)256 * per_cu;
     if (grid > nstrips) grid = nstrips;
     int log2R = 0;
