@@ -43,8 +43,8 @@ WORKLOADS = {
                  desc="BASELINE config 3: swptall+iswptall (average-based) 16384-sample f64 haar L=12; one resident "
                       "chunk of 64 signals (32 GiB of leaves) of the 8192-signal batch per step"),
     "cfg4": dict(kind="wpt2d", m=512, n=512, batch=512, wavelet="db4", L=6, dtype="f32",
-                 kernel="k_rows_fused<float, 8, false, 4>",
-                 fwd_kernels=[("k_fwd1d_inplace<float, 8, 64, false>", 1), ("k_rows_fused<float, 8, false, 4>", 1)],
+                 kernel="k_rows_fused<float, 8, false, 4, 2>",
+                 fwd_kernels=[("k_fwd1d_inplace<float, 8, 64, false>", 1), ("k_rows_fused<float, 8, false, 4, 2>", 1)],
                  desc="BASELINE config 4: 2-D wptall+iwptall 512x512 f32 db4 L=6, 512 images per GPU (4096 / 8)"),
     "cfg5": dict(kind="acwpd_jbb", n=2048, batch=2048, wavelet="coif6", L=11, dtype="f64",
                  kernel="k_acwpd_subtree_moments<5, 4, 9>",
