@@ -64,8 +64,9 @@ WORKLOADS = {
                 desc="SURVEY 8(f) row 2: LDB time-frequency energy maps of 4 classes over wpdall(x) 16384x4096 f64 db8 "
                      "L=12; timed leg = energy_map over the resident 6.5 GiB table (wpdall is the other leg)"),
     "siwt": dict(kind="siwt", n=1024, batch=4096, wavelet="db4", L=10, d=3, dtype="f64",
-                 kernel="k_siwt_costs<double>",
-                 fwd_kernels=[("k_siwt_fwd_level<double>", 10), ("k_siwt_norms<double>", 1), ("k_siwt_costs<double>", 1)],
+                 kernel="k_siwt_fwd_level<double, true, 8>",
+                 fwd_kernels=[("k_siwt_fwd_level<double, false, 8>", 1), ("k_siwt_fwd_level<double, true, 8>", 9), ("k_siwt_norms<double>", 1),
+                              ("k_siwt_costs<double>", 1)],
                  desc="SURVEY 8(f) row 4: shift-invariant packet decomposition siwpd(x, wt, 10, 3) + node costs of 4096 "
                       "1024-sample f64 signals (71-column table, 2.4 GB); second leg = bestbasistree! + isiwpd of all signals"),
 }
@@ -329,8 +330,9 @@ def make_workload(w, wx, torch, dev, rank):
         check = lambda: float((state["xh"] - x).abs().max() / x.abs().max())
         NS = sum(1 << min(j, d) for j in range(L + 1))
         NN = sum((1 << min(j, d)) << j for j in range(L + 1))
-        # parents read once per child pair, every column written once, the table read once more for the costs
-        fb = es * B * (n * (NS - (1 << min(L, d))) + 2 * n * NS + NN)
+        # parents read once, every column written once, one cost per node (the costs of nodes of <= 256 samples
+        # come out of the level that creates them; only the top depths are read a second time)
+        fb = es * B * (n * (NS - (1 << min(L, d))) + n * NS + NN)
         return fwd, inv, check, dict(fwd_bytes=fb, inv_bytes=es * B * (2 * NN + 3 * n * L) + 2 * NN * B,
                                      fwd_flops=4.0 * F * (n / 2) * (NS - 1) * B, samples=n * B, bound="hbm", keep=(x,))
     if kind == "acwpd_jbb":

@@ -50,12 +50,21 @@ template <typename T> __device__ __forceinline__ T siwt_mac(T acc, double q, T v
 
 // ---- forward: depth j -> j + 1 -------------------------------------------------------------------------
 // item = (child slot, node, i0): a = sum_t q[t] v[(2 i0 - s + t) mod np], d = sum_t (-1)^t q[t] v[(2 i0 + 1 - s - t) mod np]
-template <typename T>
+// FUSE: the Shannon cost of the two child nodes is reduced in the same launch (children of at most 256 samples,
+// dyadic n: a child is a run of h2 consecutive lanes -- wavefront shuffles, then one LDS step across the
+// wavefronts of a 128 / 256-sample child), so the table is not read a second time for the costs of these depths.
+// FT: filter length known at compile time (taps in scalar registers, all loads of a lane in flight), 0 = any length
+template <typename T, bool FUSE, int FT>
 __global__ __launch_bounds__(256) void k_siwt_fwd_level(T *__restrict__ W, int n, int64_t NS, int j, int d,
-                                                        int64_t col_j, int64_t col_j1, int64_t items, WxFilt filt)
+                                                        int64_t col_j, int64_t col_j1, int64_t items, WxFilt filt,
+                                                        const T *__restrict__ nrm, T *__restrict__ costs, int64_t NN,
+                                                        int64_t node_j1)
 {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= items) return;
+    __shared__ double red[2][4];
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = e < items;
+    if (!FUSE && !valid) return;
+    if (!valid) e = items - 1;                                      // keeps the lane in the reductions; adds nothing
     const int half = n >> 1;
     const int64_t slot1 = e / half;
     const int r = (int)(e - slot1 * half);
@@ -68,24 +77,79 @@ __global__ __launch_bounds__(256) void k_siwt_fwd_level(T *__restrict__ W, int n
     T *sig = W + (int64_t)blockIdx.y * NS * n;
     const T *v = sig + (col_j + slot0) * n + (int64_t)node * np;
     T *o = sig + (col_j1 + slot1) * n + (int64_t)node * np;
-    const int F = filt.F;
+    const int F = FT ? FT : filt.F;
     int k1 = 2 * i0 - s; if (k1 < 0) k1 += np;
     int k2 = 2 * i0 + 1 - s;
-    T a = (T)(filt.q[0] * (double)v[k1]);
-    T dd = (T)(filt.q[0] * (double)v[k2]);
-    for (int t = 1; t < F; ++t) {
-        if (++k1 == np) k1 = 0;
-        if (--k2 < 0) k2 = np - 1;
-        a = siwt_mac<T>(a, filt.q[t], v[k1]);
-        dd = siwt_mac<T>(dd, (t & 1) ? -filt.q[t] : filt.q[t], v[k2]);
+    T a, dd;
+    if (FT) {
+        T xa[FT ? FT : 1], xd[FT ? FT : 1];
+#pragma unroll
+        for (int t = 0; t < FT; ++t) {
+            if (t) { if (++k1 == np) k1 = 0; if (--k2 < 0) k2 = np - 1; }
+            xa[t] = v[k1]; xd[t] = v[k2];
+        }
+        a = (T)(filt.q[0] * (double)xa[0]);
+        dd = (T)(filt.q[0] * (double)xd[0]);
+#pragma unroll
+        for (int t = 1; t < FT; ++t) {
+            a = siwt_mac<T>(a, filt.q[t], xa[t]);
+            dd = siwt_mac<T>(dd, (t & 1) ? -filt.q[t] : filt.q[t], xd[t]);
+        }
+    } else {
+    a = (T)(filt.q[0] * (double)v[k1]);
+    dd = (T)(filt.q[0] * (double)v[k2]);
+    // taps in blocks of eight: the sixteen loads of a block are in flight together (a tap-by-tap loop waits for
+    // every pair of loads: measured 0.27 ms per level against 0.11 ms of HBM time); the sums keep their order
+    for (int t0 = 1; t0 < F; t0 += 8) {
+        T xa[8], xd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (t0 + u < F) {
+                if (++k1 == np) k1 = 0;
+                if (--k2 < 0) k2 = np - 1;
+                xa[u] = v[k1]; xd[u] = v[k2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (t0 + u < F) {
+                const int t = t0 + u;
+                a = siwt_mac<T>(a, filt.q[t], xa[u]);
+                dd = siwt_mac<T>(dd, (t & 1) ? -filt.q[t] : filt.q[t], xd[u]);
+            }
+        }
     }
-    o[i0] = a;
-    o[h2 + i0] = dd;
+    }
+    if (valid) {
+        o[i0] = a;
+        o[h2 + i0] = dd;
+    }
+    if (FUSE) {
+        const T nr = nrm[blockIdx.y];
+        double ca = (valid && nr != (T)0) ? bb_term<T>(a, nr, 0) : 0.0;
+        double cd = (valid && nr != (T)0) ? bb_term<T>(dd, nr, 0) : 0.0;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int w0 = h2 < 64 ? h2 : 64;
+        for (int w = w0 >> 1; w > 0; w >>= 1) { ca += __shfl_xor(ca, w, 64); cd += __shfl_xor(cd, w, 64); }
+        T *c = costs + (int64_t)blockIdx.y * NN + node_j1 + (slot1 << (j + 1)) + 2 * node;
+        if (h2 <= 64) {
+            if (valid && (lane & (h2 - 1)) == 0) { c[0] = (T)ca; c[1] = (T)cd; }
+        } else {                                                   // 128 or 256 samples: 2 or 4 wavefronts per child
+            if (lane == 0) { red[0][wave] = ca; red[1][wave] = cd; }
+            __syncthreads();
+            const int wpn = h2 >> 6;
+            if (valid && lane == 0 && (wave & (wpn - 1)) == 0) {
+                double sa = 0.0, sd = 0.0;
+                for (int u = 0; u < wpn; ++u) { sa += red[0][wave + u]; sd += red[1][wave + u]; }
+                c[0] = (T)sa; c[1] = (T)sd;
+            }
+        }
+    }
 }
 
 // ---- inverse: children of depth j + 1 -> the nodes of depth j that kept children ------------------------
 // status: 0 not in the tree, 1 leaf, 2 non-shifted children, 3 shifted children
-template <typename T>
+template <typename T, int FT>
 __global__ __launch_bounds__(256) void k_siwt_inv_level(T *__restrict__ W, const uint8_t *__restrict__ status, int n,
                                                         int64_t NS, int64_t NN, int j, int d, int64_t col_j,
                                                         int64_t col_j1, int64_t node_j, int64_t items, WxFilt filt)
@@ -106,16 +170,47 @@ __global__ __launch_bounds__(256) void k_siwt_inv_level(T *__restrict__ W, const
     const T *a = sig + (col_j1 + slot1) * n + (int64_t)node * np;
     const T *dd = a + h2;
     T *v = sig + (col_j + slot0) * n + (int64_t)node * np;
-    const int F = filt.F;
+    const int F = FT ? FT : filt.F;
     // isidwt_step!: v[l] = g*w1 + h*w2, then v[l] += (g*w1 + h*w2) per further tap pair
     int ka = k, kd = k;
-    T ev = (T)(filt.q[0] * (double)a[ka] + (-filt.q[1]) * (double)dd[kd]);
-    T od = (T)(filt.q[1] * (double)a[ka] + filt.q[0] * (double)dd[kd]);
-    for (int m = 1; 2 * m < F; ++m) {
-        if (--ka < 0) ka = h2 - 1;
-        if (++kd == h2) kd = 0;
-        ev = (T)((double)ev + (filt.q[2 * m] * (double)a[ka] + (-filt.q[2 * m + 1]) * (double)dd[kd]));
-        od = (T)((double)od + (filt.q[2 * m + 1] * (double)a[ka] + filt.q[2 * m] * (double)dd[kd]));
+    T ev, od;
+    if (FT) {
+        constexpr int HT = FT ? FT / 2 : 1;
+        T xa[HT], xd[HT];
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            if (m) { if (--ka < 0) ka = h2 - 1; if (++kd == h2) kd = 0; }
+            xa[m] = a[ka]; xd[m] = dd[kd];
+        }
+        ev = (T)(filt.q[0] * (double)xa[0] + (-filt.q[1]) * (double)xd[0]);
+        od = (T)(filt.q[1] * (double)xa[0] + filt.q[0] * (double)xd[0]);
+#pragma unroll
+        for (int m = 1; m < HT; ++m) {
+            ev = (T)((double)ev + (filt.q[2 * m] * (double)xa[m] + (-filt.q[2 * m + 1]) * (double)xd[m]));
+            od = (T)((double)od + (filt.q[2 * m + 1] * (double)xa[m] + filt.q[2 * m] * (double)xd[m]));
+        }
+    } else {
+    ev = (T)(filt.q[0] * (double)a[ka] + (-filt.q[1]) * (double)dd[kd]);
+    od = (T)(filt.q[1] * (double)a[ka] + filt.q[0] * (double)dd[kd]);
+    for (int m0 = 1; 2 * m0 < F; m0 += 8) {
+        T xa[8], xd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (2 * (m0 + u) < F) {
+                if (--ka < 0) ka = h2 - 1;
+                if (++kd == h2) kd = 0;
+                xa[u] = a[ka]; xd[u] = dd[kd];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (2 * (m0 + u) < F) {
+                const int m = m0 + u;
+                ev = (T)((double)ev + (filt.q[2 * m] * (double)xa[u] + (-filt.q[2 * m + 1]) * (double)xd[u]));
+                od = (T)((double)od + (filt.q[2 * m + 1] * (double)xa[u] + filt.q[2 * m] * (double)xd[u]));
+            }
+        }
+    }
     }
     int p0 = 2 * k - s; if (p0 < 0) p0 += np;
     v[p0] = ev;
@@ -279,16 +374,28 @@ int api_siwpd(const T *x, T *W, T *costs, int64_t n, int L, int d, int64_t batch
     for (int64_t b0 = 0; b0 < batch; b0 += 65535) {                   // gridDim.y limit
         const unsigned bc = (unsigned)(batch - b0 < 65535 ? batch - b0 : 65535);
         T *Wb = dW + b0 * NS * n;
+        if (dc) hipLaunchKernelGGL(k_siwt_norms<T>, dim3(bc), dim3(256), 0, st, (const T *)Wb, (int)n, NS * n, dn + b0);
+        // costs of the depths whose nodes have at most 256 samples come out of the level that creates them
+        const bool dyadic = (n & (n - 1)) == 0;
+        int jc = 0;                                                 // depths 0 .. jc keep the separate cost kernel
         for (int j = 0; j < L; ++j) {
             const int64_t items = (n / 2) * (g.coloff[j + 2] - g.coloff[j + 1]);
-            hipLaunchKernelGGL(k_siwt_fwd_level<T>, dim3(blocks_for(items), bc), dim3(256), 0, st, Wb, (int)n, NS, j, d,
-                               g.coloff[j], g.coloff[j + 1], items, filt);
+            const bool fuse = dc && dyadic && (n >> (j + 1)) <= 256 && (n >> (j + 1)) >= 1;
+            void (*kf)(T *, int, int64_t, int, int, int64_t, int64_t, int64_t, WxFilt, const T *, T *, int64_t, int64_t);
+            switch (filt.F) {
+#define WX_CASE(FF) case FF: kf = fuse ? k_siwt_fwd_level<T, true, FF> : k_siwt_fwd_level<T, false, FF>; break;
+                WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+#undef WX_CASE
+            default: kf = fuse ? k_siwt_fwd_level<T, true, 0> : k_siwt_fwd_level<T, false, 0>;
+            }
+            hipLaunchKernelGGL(kf, dim3(blocks_for(items), bc), dim3(256), 0, st, Wb, (int)n, NS, j, d, g.coloff[j],
+                               g.coloff[j + 1], items, filt, fuse ? (const T *)(dn + b0) : (const T *)nullptr,
+                               fuse ? dc + b0 * NN : (T *)nullptr, NN, g.nodeoff[j + 1]);
+            if (!fuse) jc = j + 1;
         }
-        if (dc) {
-            hipLaunchKernelGGL(k_siwt_norms<T>, dim3(bc), dim3(256), 0, st, (const T *)Wb, (int)n, NS * n, dn + b0);
-            hipLaunchKernelGGL(k_siwt_costs<T>, dim3((unsigned)NS, bc), dim3(256), 0, st, (const T *)Wb, (const T *)(dn + b0),
-                               (int)n, NS, NN, g, dc + b0 * NN);
-        }
+        if (dc)
+            hipLaunchKernelGGL(k_siwt_costs<T>, dim3((unsigned)g.coloff[jc + 1], bc), dim3(256), 0, st, (const T *)Wb,
+                               (const T *)(dn + b0), (int)n, NS, NN, g, dc + b0 * NN);
     }
     if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "siwpd kernels failed to launch"));
     return io.finish(WX_OK);
@@ -354,7 +461,14 @@ int api_isiwpd(T *W, const uint8_t *status, T *xh, int64_t n, int L, int d, int6
         const unsigned bc = (unsigned)(batch - b0 < 65535 ? batch - b0 : 65535);
         for (int j = L - 1; j >= 0; --j) {
             const int64_t items = (n / 2) * (g.coloff[j + 1] - g.coloff[j]);
-            hipLaunchKernelGGL(k_siwt_inv_level<T>, dim3(blocks_for(items), bc), dim3(256), 0, st, dW + b0 * NS * n, ds + b0 * NN,
+            void (*ki)(T *, const uint8_t *, int, int64_t, int64_t, int, int, int64_t, int64_t, int64_t, int64_t, WxFilt);
+            switch (filt.F) {
+#define WX_CASE(FF) case FF: ki = k_siwt_inv_level<T, FF>; break;
+                WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+#undef WX_CASE
+            default: ki = k_siwt_inv_level<T, 0>;
+            }
+            hipLaunchKernelGGL(ki, dim3(blocks_for(items), bc), dim3(256), 0, st, dW + b0 * NS * n, ds + b0 * NN,
                                (int)n, NS, NN, j, d, g.coloff[j], g.coloff[j + 1], g.nodeoff[j], items, filt);
         }
     }
