@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_bb_costs1d(const T *__restrict__ X, con
     __shared__ double red[256];
     const int64_t sig = blockIdx.y;
     const T nr = nrm[sig];
+    const WxNorm<T> nrw(nr);
     T *out = costs + sig * ncost;
     if (redundant) {
         const int64_t idx = blockIdx.x;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void k_bb_costs1d(const T *__restrict__ X, con
         const T *x = X + (sig * k + idx) * (int64_t)n;
         double acc = 0.0;
         if (nr != (T)0)
-            for (int i = threadIdx.x; i < n; i += blockDim.x) acc += bb_term<T>(x[i], nr, cost_kind);
+            for (int i = threadIdx.x; i < n; i += blockDim.x) acc += bb_term<T>(x[i], nrw, cost_kind);
         const double tot = bb_block_sum(acc, red);
         if (threadIdx.x == 0) out[idx] = (T)((T)(nr == (T)0 ? 0.0 : tot) / (T)((int64_t)1 << depth));
         return;
@@ -72,9 +73,9 @@ __global__ __launch_bounds__(256) void k_bb_costs1d(const T *__restrict__ X, con
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] = xn[i + u * 256];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) acc += bb_term<T>(v[u], nr, cost_kind);
+                    for (int u = 0; u < 8; ++u) acc += bb_term<T>(v[u], nrw, cost_kind);
                 }
-                for (; i < cnt; i += 256) acc += bb_term<T>(xn[i], nr, cost_kind);
+                for (; i < cnt; i += 256) acc += bb_term<T>(xn[i], nrw, cost_kind);
             }
             const double tot = bb_block_sum(acc, red);
             if (threadIdx.x == 0) o[node] = (T)(nr == (T)0 ? 0.0 : tot);
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void k_bb_costs1d(const T *__restrict__ X, con
         for (int base = 0; base < n; base += 256) {
             const T cur = nextv;
             if (base + 256 < n) nextv = x[base + 256 + threadIdx.x];
-            double v = nr != (T)0 ? bb_term<T>(cur, nr, cost_kind) : 0.0;
+            double v = nr != (T)0 ? bb_term<T>(cur, nrw, cost_kind) : 0.0;
             const int w0 = cnt < 64 ? cnt : 64;
             for (int w = w0 >> 1; w > 0; w >>= 1) v += __shfl_xor(v, w, 64);
             if (cnt <= 64) {
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void k_bb_costs1d(const T *__restrict__ X, con
         for (int node = threadIdx.x; node < nodes; node += blockDim.x) {
             double acc = 0.0;
             if (nr != (T)0)
-                for (int i = 0; i < cnt; ++i) acc += bb_term<T>(x[(int64_t)node * cnt + i], nr, cost_kind);
+                for (int i = 0; i < cnt; ++i) acc += bb_term<T>(x[(int64_t)node * cnt + i], nrw, cost_kind);
             o[node] = (T)(nr == (T)0 ? 0.0 : acc);
         }
     }
@@ -126,10 +127,11 @@ __global__ __launch_bounds__(256) void k_bb_costs2d(const T *__restrict__ X, con
         { int64_t t = 3 * (idx + 1) - 2; while (t >= 4) { t >>= 2; ++depth; } }
         const T *x = X + (sig * k + idx) * (int64_t)m * n;
         const T nv = nrm[sig];
+        const WxNorm<T> nvw(nv);
         const int cnt = m * n;
         double acc = 0.0;
         if (nv != (T)0)
-            for (int i = threadIdx.x; i < cnt; i += blockDim.x) acc += bb_term<T>(x[i], nv, cost_kind);
+            for (int i = threadIdx.x; i < cnt; i += blockDim.x) acc += bb_term<T>(x[i], nvw, cost_kind);
         const double tot = bb_block_sum(acc, red);
         if (threadIdx.x == 0) out[idx] = (T)((T)(nv == (T)0 ? 0.0 : tot) / (T)((int64_t)1 << (2 * depth)));
         return;
@@ -155,10 +157,11 @@ __global__ __launch_bounds__(256) void k_bb_costs2d(const T *__restrict__ X, con
                 a2 = fma(v, v, a2);
             }
             const T nv = (T)sqrt(bb_block_sum(a2, red));
+            const WxNorm<T> nvw(nv);
             double acc = 0.0;
             if (nv != (T)0)
                 for (int i = threadIdx.x; i < cnt; i += blockDim.x)
-                    acc += bb_term<T>(x[(int64_t)(c0 + i / nr_) * m + r0 + i % nr_], nv, cost_kind);
+                    acc += bb_term<T>(x[(int64_t)(c0 + i / nr_) * m + r0 + i % nr_], nvw, cost_kind);
             const double tot = bb_block_sum(acc, red);
             if (threadIdx.x == 0) o[node] = (T)(nv == (T)0 ? 0.0 : tot);
         }
@@ -170,10 +173,11 @@ __global__ __launch_bounds__(256) void k_bb_costs2d(const T *__restrict__ X, con
             for (int c = 0; c < ncl; ++c)
                 for (int r = 0; r < nr_; ++r) { const double v = (double)x[(int64_t)(c0 + c) * m + r0 + r]; a2 = fma(v, v, a2); }
             const T nv = (T)sqrt(a2);
+            const WxNorm<T> nvw(nv);
             double acc = 0.0;
             if (nv != (T)0)
                 for (int c = 0; c < ncl; ++c)
-                    for (int r = 0; r < nr_; ++r) acc += bb_term<T>(x[(int64_t)(c0 + c) * m + r0 + r], nv, cost_kind);
+                    for (int r = 0; r < nr_; ++r) acc += bb_term<T>(x[(int64_t)(c0 + c) * m + r0 + r], nvw, cost_kind);
             o[node] = (T)(nv == (T)0 ? 0.0 : acc);
         }
     }

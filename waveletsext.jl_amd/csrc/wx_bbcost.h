@@ -15,7 +15,14 @@ __device__ __forceinline__ double wx_log_pos(double s)
     int e;
     double m = frexp(s, &e);                       // [0.5, 1)
     if (m < 0.70710678118654752) { m += m; e -= 1; }
-    const double z = (m - 1.0) / (m + 1.0);
+    // (m - 1) / (m + 1), divisor in [1.7, 2.42]: reciprocal estimate + two Newton steps + one correction of the
+    // quotient, without the scaling / fix-up instructions of the general division
+    const double dv = m + 1.0, nu = m - 1.0;
+    double rc = __builtin_amdgcn_rcp(dv);
+    rc = fma(fma(-dv, rc, 1.0), rc, rc);
+    rc = fma(fma(-dv, rc, 1.0), rc, rc);
+    double z = nu * rc;
+    z = fma(fma(-dv, z, nu), rc, z);
     const double w = z * z;
     double p = 1.0 / 19.0;
     p = fma(p, w, 1.0 / 17.0);
@@ -32,10 +39,24 @@ __device__ __forceinline__ double wx_log_pos(double s)
     return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
 }
 
-template <typename T> __device__ __forceinline__ double bb_term(T x, T nrm, int cost_kind)
+// x / nrm for many x and one nrm: rn = RN(1 / nrm) is formed once per signal, then q = RN(x rn),
+// q' = RN(q + RN(x - q nrm) rn) -- the residual is exact (fma), so q' is the correctly rounded quotient (Markstein)
+// except for a divisor whose significand is all ones; three full-rate instructions instead of the division
+// sequence with its reciprocal.
+template <typename T> struct WxNorm {
+    T nrm, rn;
+    __device__ __forceinline__ explicit WxNorm(T n) : nrm(n), rn((T)1 / n) {}
+    __device__ __forceinline__ T div(T x) const
+    {
+        const T q = x * rn;
+        return fma(fma(-q, nrm, x), rn, q);
+    }
+};
+
+template <typename T> __device__ __forceinline__ double bb_term(T x, const WxNorm<T> &nr, int cost_kind)
 {
     // coefcost(x::T, et, nrm): s = (x/nrm)^2 in T; Shannon -s log s, log-energy -log s, -0 when s == 0
-    const T r = (T)(x / nrm);
+    const T r = nr.div(x);
     const T s = (T)(r * r);
     if (s == (T)0) return -0.0;
     const T lg = (T)wx_log_pos((double)s);

@@ -126,8 +126,9 @@ __global__ __launch_bounds__(256) void k_siwt_fwd_level(T *__restrict__ W, int n
     }
     if (FUSE) {
         const T nr = nrm[blockIdx.y];
-        double ca = (valid && nr != (T)0) ? bb_term<T>(a, nr, 0) : 0.0;
-        double cd = (valid && nr != (T)0) ? bb_term<T>(dd, nr, 0) : 0.0;
+        const WxNorm<T> nrw(nr);
+        double ca = (valid && nr != (T)0) ? bb_term<T>(a, nrw, 0) : 0.0;
+        double cd = (valid && nr != (T)0) ? bb_term<T>(dd, nrw, 0) : 0.0;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int w0 = h2 < 64 ? h2 : 64;
         for (int w = w0 >> 1; w > 0; w >>= 1) { ca += __shfl_xor(ca, w, 64); cd += __shfl_xor(cd, w, 64); }
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256) void k_siwt_costs(const T *__restrict__ W, con
     while (j < g.L && col >= g.coloff[j + 1]) ++j;
     const int64_t slot = col - g.coloff[j];
     const T nr = nrm[sig];
+    const WxNorm<T> nrw(nr);
     const int cnt = n >> j, nodes = 1 << j;
     const T *x = W + (sig * NS + col) * (int64_t)n;
     T *o = costs + sig * NN + g.nodeoff[j] + (slot << j);
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void k_siwt_costs(const T *__restrict__ W, con
         for (int node = 0; node < nodes; ++node) {
             double acc = 0.0;
             if (nr != (T)0)
-                for (int i = threadIdx.x; i < cnt; i += 256) acc += bb_term<T>(x[(int64_t)node * cnt + i], nr, 0);
+                for (int i = threadIdx.x; i < cnt; i += 256) acc += bb_term<T>(x[(int64_t)node * cnt + i], nrw, 0);
             const double tot = bb_block_sum(acc, red);
             if (threadIdx.x == 0) o[node] = (T)(nr == (T)0 ? 0.0 : tot);
         }
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void k_siwt_costs(const T *__restrict__ W, con
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int base = 0; base < n; base += 256) {
             const bool in = base + (int)threadIdx.x < n;
-            double v = (in && nr != (T)0) ? bb_term<T>(x[base + threadIdx.x], nr, 0) : 0.0;
+            double v = (in && nr != (T)0) ? bb_term<T>(x[base + threadIdx.x], nrw, 0) : 0.0;
             const int w0 = cnt < 64 ? cnt : 64;
             for (int w = w0 >> 1; w > 0; w >>= 1) v += __shfl_xor(v, w, 64);
             if (cnt <= 64) {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void k_siwt_costs(const T *__restrict__ W, con
         for (int node = threadIdx.x; node < nodes; node += 256) {
             double acc = 0.0;
             if (nr != (T)0)
-                for (int i = 0; i < cnt; ++i) acc += bb_term<T>(x[(int64_t)node * cnt + i], nr, 0);
+                for (int i = 0; i < cnt; ++i) acc += bb_term<T>(x[(int64_t)node * cnt + i], nrw, 0);
             o[node] = (T)(nr == (T)0 ? 0.0 : acc);
         }
     }
