@@ -197,7 +197,18 @@ __global__ __launch_bounds__(256) void k_bb_treeselect(T *__restrict__ costs, in
     uint8_t *flag = reinterpret_cast<uint8_t *>(c + ncost);       // 1 = pruned, later reused as the tree bit
     const int64_t sig = blockIdx.x;
     T *gc = costs + sig * ncost;
-    for (int64_t i = threadIdx.x; i < ncost; i += blockDim.x) c[i] = gc[i];
+    {
+        // eight loads of a lane in flight together
+        int64_t i = threadIdx.x;
+        for (; i + 7 * 256 < ncost; i += 8 * 256) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = gc[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[i + u * 256] = v[u];
+        }
+        for (; i < ncost; i += 256) c[i] = gc[i];
+    }
     __syncthreads();
     // first 1-based index of depth d: binary 2^d, quad (4^d - 1)/3 + 1
     auto first = [](int d) -> int64_t { return ARITY == 2 ? ((int64_t)1 << d) : ((((int64_t)1 << (2 * d)) - 1) / 3 + 1); };
