@@ -46,6 +46,24 @@ static __device__ __forceinline__ int64_t wx_modn64(int64_t x, int64_t n)
     return r < 0 ? r + n : r;
 }
 
+// global -> LDS (or register-staged global -> global) copy of n elements by the whole workgroup with NB loads of a
+// lane in flight: a plain `dst[i] = src[i]` loop waits for every load before issuing the next (measured: tree
+// selection 1.0 -> 0.5 ms, 2-D tile levels 3.0 -> 2.3 ms from this alone)
+template <typename T, int NB = 8>
+static __device__ __forceinline__ void wx_stage(T *__restrict__ dst, const T *__restrict__ src, int n)
+{
+    const int st = blockDim.x;
+    int i = threadIdx.x;
+    for (; i + (NB - 1) * st < n; i += NB * st) {
+        T v[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) v[u] = src[i + u * st];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) dst[i + u * st] = v[u];
+    }
+    for (; i < n; i += st) dst[i] = src[i];
+}
+
 #define WX_HIP_CHECK(expr)                                   \
     do {                                                     \
         hipError_t _e = (expr);                              \

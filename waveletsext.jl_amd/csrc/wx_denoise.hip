@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_mad(const T *__restrict__ X, int64_t si
     T *v = reinterpret_cast<T *>(wx_smem);
     __shared__ WxSelScratch S;
     const T *x = X + (int64_t)blockIdx.x * sig_stride + off;
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) v[i] = x[i];
+    wx_stage<T>(v, x, cnt);
     __syncthreads();
     const T m = wx_median_lds<T>(v, cnt, &S);
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) v[i] = (T)fabs((double)(T)(v[i] - m));

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(1024) void k_sdwt_fused(const T *__restrict__ x, T 
     for (int64_t sig = blockIdx.x; sig < batch; sig += gridDim.x) {
         T *base = xw + sig * (int64_t)n * (L + 1);
         const T *src = x + sig * (int64_t)n;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) a[i] = src[i];
+        wx_stage<T>(a, src, n);
         __syncthreads();
         T *v = a, *w = b;
         for (int d = 0; d < L; ++d) {
@@ -200,11 +200,11 @@ __global__ __launch_bounds__(1024) void k_isdwt_avg_fused(const T *__restrict__ 
     T *wd = b + n;
     for (int64_t sig = blockIdx.x; sig < batch; sig += gridDim.x) {
         const T *base = xw + sig * (int64_t)n * (L + 1);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) a[i] = base[i];
+        wx_stage<T>(a, base, n);
         T *r = a, *rn = b;
         for (int d = L - 1; d >= 0; --d) {
             const T *wcol = base + (int64_t)(L - d) * n;
-            for (int i = threadIdx.x; i < n; i += blockDim.x) wd[i] = wcol[i];
+            wx_stage<T>(wd, wcol, n);
             __syncthreads();
             const int s = (1 << d) % n;
             const int M = s > 0 ? n / s : 0;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(1024) void k_swt_fwd_multi(const T *__restrict__ x,
     for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
         T *base = xw + sig * (int64_t)n * ncols;
         const T *src = (d == 0) ? x + sig * (int64_t)n : base + (int64_t)(b * wp) * n;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) v[i] = src[i];
+        wx_stage<T>(v, src, n);
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             double acc[NC];
