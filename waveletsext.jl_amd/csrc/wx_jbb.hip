@@ -37,7 +37,20 @@ __global__ __launch_bounds__(256) void k_jbb_moments(const T *__restrict__ X, T 
         T s = 0, q = 0;
         if (accumulate && c == 0) { s = sum[e]; q = sumsq[e]; }
         const T *p = X + e;
-        for (int64_t b = b0; b < b1; ++b) {
+        // eight signals' loads in flight, summed in the same order as one by one
+        int64_t b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(b + u) * nk];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s = (T)(s + v[u]);
+                const T vq = wx_sq_unfused<T>(v[u]);
+                q = (T)(q + vq);
+            }
+        }
+        for (; b < b1; ++b) {
             const T v = p[b * nk];
             s = (T)(s + v);
             const T vq = wx_sq_unfused<T>(v);
