@@ -85,24 +85,26 @@ template <typename T, bool AC>
 __global__ __launch_bounds__(256) void k_red2d_fwd_dim1(const T *__restrict__ x, T *__restrict__ xw, T *__restrict__ tmp,
                                                         WxRed2d D, int nodes, WxFilt filt, WxAcFilt ac)
 {
+    // grid.y walks the jobs (node x signal), grid.x the elements of one image: the per-element index arithmetic is
+    // one 32-bit division; with a flat 64-bit index the four 64-bit divisions per element cost more than the filter
     const int64_t mn = (int64_t)D.m * D.n;
-    const int64_t total = D.batch * nodes * mn;
+    const int64_t njobs = D.batch * nodes;
     const int s = (1 << D.d) % D.m;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t job = g / mn;
-        const int64_t e = g - job * mn;
-        const int r = (int)(e % D.m);
-        const int64_t c = e / D.m;
-        const int b = (int)(job % nodes);
-        const int64_t sig = job / nodes;
-        int64_t pv, pc[4];
-        wx_red2d_slices(D, b, pv, pc);
-        const T *src = (D.d == 0) ? x + sig * mn : xw + (sig * D.ncols + pv) * mn;
+    for (int64_t job = blockIdx.y; job < njobs; job += gridDim.y) {
+      const int b = (int)(job % nodes);
+      const int64_t sig = job / nodes;
+      int64_t pv, pc[4];
+      wx_red2d_slices(D, b, pv, pc);
+      const T *src = (D.d == 0) ? x + sig * mn : xw + (sig * D.ncols + pv) * mn;
+      for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < (unsigned)mn; e += gridDim.x * 256u) {
+        const unsigned c = e / (unsigned)D.m;
+        const int r = (int)(e - c * (unsigned)D.m);
         if (D.d == 0 && D.layout == WX2_WPD) xw[(sig * D.ncols) * mn + e] = src[e];
         T lo, hi;
-        wx_red_point<T, AC>(src + c * D.m, 1, D.m, r, s, filt, ac, lo, hi);
+        wx_red_point<T, AC>(src + (int64_t)c * D.m, 1, D.m, r, s, filt, ac, lo, hi);
         tmp[(job * 2) * mn + e] = lo;
         tmp[(job * 2 + 1) * mn + e] = hi;
+      }
     }
 }
 
@@ -112,23 +114,23 @@ __global__ __launch_bounds__(256) void k_red2d_fwd_dim2(T *__restrict__ xw, cons
                                                         int nodes, WxFilt filt, WxAcFilt ac)
 {
     const int64_t mn = (int64_t)D.m * D.n;
-    const int64_t total = D.batch * nodes * 2 * mn;
+    const int64_t njobs = D.batch * nodes * 2;
     const int s = (1 << D.d) % D.n;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t jw = g / mn;                         // job*2 + which
-        const int64_t e = g - jw * mn;
-        const int r = (int)(e % D.m);
-        const int c = (int)(e / D.m);
-        const int which = (int)(jw & 1);
-        const int64_t job = jw >> 1;
-        const int b = (int)(job % nodes);
-        const int64_t sig = job / nodes;
-        int64_t pv, pc[4];
-        wx_red2d_slices(D, b, pv, pc);
+    for (int64_t jw = blockIdx.y; jw < njobs; jw += gridDim.y) {       // job*2 + which
+      const int which = (int)(jw & 1);
+      const int64_t job = jw >> 1;
+      const int b = (int)(job % nodes);
+      const int64_t sig = job / nodes;
+      int64_t pv, pc[4];
+      wx_red2d_slices(D, b, pv, pc);
+      for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < (unsigned)mn; e += gridDim.x * 256u) {
+        const int c = (int)(e / (unsigned)D.m);
+        const int r = (int)(e - (unsigned)c * (unsigned)D.m);
         T lo, hi;
         wx_red_point<T, AC>(tmp + jw * mn + r, D.m, D.n, c, s, filt, ac, lo, hi);
         xw[(sig * D.ncols + pc[2 * which]) * mn + e] = lo;
         xw[(sig * D.ncols + pc[2 * which + 1]) * mn + e] = hi;
+      }
     }
 }
 
@@ -198,21 +200,20 @@ __global__ __launch_bounds__(256) void k_red2d_inv_dim2(WxInv2d D, T *__restrict
     const int nr = sm_mode ? (m >> (d + 1)) : m;          // rows handled per job
     const int ncl = sm_mode ? (n >> d) : n;               // columns handled per job
     const int64_t per = (int64_t)nr * ncl;
-    const int64_t total = D.R.batch * nodes * 2 * per;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t jw = g / per;
-        const int64_t e = g - jw * per;
-        const int ri = (int)(e % nr), ci = (int)(e / nr);
-        const int which = (int)(jw & 1);
-        const int64_t job = jw >> 1;
-        const int b = (int)(job % nodes);
-        const int64_t sig = job / nodes;
-        if (D.R.layout == WX2_WPD && D.tree) {
-            const int64_t heap = wx_quad_start(d) + b;
-            if (!(heap <= D.ntree && D.tree[heap - 1])) continue;
-        }
-        const T *w1 = wx_inv2d_child<T>(D, sig, b, 2 * which);
-        const T *w2 = wx_inv2d_child<T>(D, sig, b, 2 * which + 1);
+    const int64_t njobs = D.R.batch * nodes * 2;
+    for (int64_t jw = blockIdx.y; jw < njobs; jw += gridDim.y) {
+      const int which = (int)(jw & 1);
+      const int64_t job = jw >> 1;
+      const int b = (int)(job % nodes);
+      const int64_t sig = job / nodes;
+      if (D.R.layout == WX2_WPD && D.tree) {
+          const int64_t heap = wx_quad_start(d) + b;
+          if (!(heap <= D.ntree && D.tree[heap - 1])) continue;
+      }
+      const T *w1 = wx_inv2d_child<T>(D, sig, b, 2 * which);
+      const T *w2 = wx_inv2d_child<T>(D, sig, b, 2 * which + 1);
+      for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < (unsigned)per; e += gridDim.x * 256u) {
+        const int ci = (int)(e / (unsigned)nr), ri = (int)(e - (unsigned)ci * (unsigned)nr);
         int r, c, cls, u;
         bool single, shifted = false;
         if (sm_mode) { r = sw + ri * 2 * s; cls = sv; u = ci; c = cls + u * s; single = true; shifted = (sw != sv); }
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256) void k_red2d_inv_dim2(WxInv2d D, T *__restrict
         else v = 0.5 * (wx_isdwt_point<T>(w1 + r, w2 + r, m, n, d, cls, u, false, filt) +
                         wx_isdwt_point<T>(w1 + r, w2 + r, m, n, d, cls, u, true, filt));
         tmp[jw * mn + r + (int64_t)c * m] = (T)v;
+      }
     }
 }
 
@@ -235,18 +237,18 @@ __global__ __launch_bounds__(256) void k_red2d_inv_dim1(WxInv2d D, const T *__re
     const int nr = sm_mode ? (m >> d) : m;
     const int ncl = sm_mode ? (n >> d) : n;
     const int64_t per = (int64_t)nr * ncl;
-    const int64_t total = D.R.batch * nodes * per;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t job = g / per;
-        const int64_t e = g - job * per;
-        const int ri = (int)(e % nr), ci = (int)(e / nr);
-        const int b = (int)(job % nodes);
-        const int64_t sig = job / nodes;
-        if (D.R.layout == WX2_WPD && D.tree) {
-            const int64_t heap = wx_quad_start(d) + b;
-            if (!(heap <= D.ntree && D.tree[heap - 1])) continue;
-        }
-        const T *t1 = tmp + (job * 2) * mn, *t2 = tmp + (job * 2 + 1) * mn;
+    const int64_t njobs = D.R.batch * nodes;
+    for (int64_t job = blockIdx.y; job < njobs; job += gridDim.y) {
+      const int b = (int)(job % nodes);
+      const int64_t sig = job / nodes;
+      if (D.R.layout == WX2_WPD && D.tree) {
+          const int64_t heap = wx_quad_start(d) + b;
+          if (!(heap <= D.ntree && D.tree[heap - 1])) continue;
+      }
+      const T *t1 = tmp + (job * 2) * mn, *t2 = tmp + (job * 2 + 1) * mn;
+      T *out = reinterpret_cast<T *>(D.out) + (sig * D.out_cols + ((D.R.layout == WX2_DWT || d == 0) ? 0 : b)) * mn;
+      for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < (unsigned)per; e += gridDim.x * 256u) {
+        const int ci = (int)(e / (unsigned)nr), ri = (int)(e - (unsigned)ci * (unsigned)nr);
         int r, c, cls, u;
         double v;
         if (sm_mode) {
@@ -257,8 +259,8 @@ __global__ __launch_bounds__(256) void k_red2d_inv_dim1(WxInv2d D, const T *__re
             v = 0.5 * (wx_isdwt_point<T>(t1 + (int64_t)c * m, t2 + (int64_t)c * m, 1, m, d, cls, u, false, filt) +
                        wx_isdwt_point<T>(t1 + (int64_t)c * m, t2 + (int64_t)c * m, 1, m, d, cls, u, true, filt));
         }
-        T *out = reinterpret_cast<T *>(D.out) + (sig * D.out_cols + ((D.R.layout == WX2_DWT || d == 0) ? 0 : b)) * mn;
         out[r + (int64_t)c * m] = (T)v;
+      }
     }
 }
 
@@ -268,32 +270,35 @@ __global__ __launch_bounds__(256) void k_red2d_iac(WxInv2d D, int nodes)
 {
     const double sqrt2 = 1.4142135623730951;
     const int64_t mn = (int64_t)D.R.m * D.R.n;
-    const int64_t total = D.R.batch * nodes * mn;
+    const int64_t njobs = D.R.batch * nodes;
     const int d = D.R.d;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t job = g / mn;
-        const int64_t e = g - job * mn;
-        const int b = (int)(job % nodes);
-        const int64_t sig = job / nodes;
-        if (D.R.layout == WX2_WPD && D.tree) {
-            const int64_t heap = wx_quad_start(d) + b;
-            if (!(heap <= D.ntree && D.tree[heap - 1])) continue;
-        }
-        const T *w1 = wx_inv2d_child<T>(D, sig, b, 0), *w2 = wx_inv2d_child<T>(D, sig, b, 1);
-        const T *w3 = wx_inv2d_child<T>(D, sig, b, 2), *w4 = wx_inv2d_child<T>(D, sig, b, 3);
+    for (int64_t job = blockIdx.y; job < njobs; job += gridDim.y) {
+      const int b = (int)(job % nodes);
+      const int64_t sig = job / nodes;
+      if (D.R.layout == WX2_WPD && D.tree) {
+          const int64_t heap = wx_quad_start(d) + b;
+          if (!(heap <= D.ntree && D.tree[heap - 1])) continue;
+      }
+      const T *w1 = wx_inv2d_child<T>(D, sig, b, 0), *w2 = wx_inv2d_child<T>(D, sig, b, 1);
+      const T *w3 = wx_inv2d_child<T>(D, sig, b, 2), *w4 = wx_inv2d_child<T>(D, sig, b, 3);
+      T *out = reinterpret_cast<T *>(D.out) + (sig * D.out_cols + ((D.R.layout == WX2_DWT || d == 0) ? 0 : b)) * mn;
+      for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < (unsigned)mn; e += gridDim.x * 256u) {
         const T t1 = (T)(((double)w1[e] + (double)w2[e]) / sqrt2);
         const T t2 = (T)(((double)w3[e] + (double)w4[e]) / sqrt2);
-        T *out = reinterpret_cast<T *>(D.out) + (sig * D.out_cols + ((D.R.layout == WX2_DWT || d == 0) ? 0 : b)) * mn;
         out[e] = (T)(((double)t1 + (double)t2) / sqrt2);
+      }
     }
 }
 
-static int wx_grid2r(int64_t total)
+// grid.x over the elements of one job, grid.y over the jobs
+static dim3 wx_grid2r(int64_t per, int64_t njobs)
 {
-    int64_t g = (total + 255) / 256;
-    if (g > 256 * 32) g = 256 * 32;
-    if (g < 1) g = 1;
-    return (int)g;
+    int64_t gx = (per + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
+    int64_t gy = njobs < 65535 ? njobs : 65535;
+    if (gy < 1) gy = 1;
+    return dim3((unsigned)gx, (unsigned)gy);
 }
 
 static int64_t wx_red2d_ncols(int layout, int L)
@@ -315,13 +320,12 @@ int wx_dev_red2d_fwd(const T *x, T *xw, int64_t m, int64_t n, int L, int layout,
         WxRed2d D;
         D.layout = layout; D.L = L; D.d = d; D.m = (int)m; D.n = (int)n; D.ncols = wx_red2d_ncols(layout, L); D.batch = batch;
         const int nodes = layout == WX2_DWT ? 1 : (1 << (2 * d));
-        const int64_t tot = batch * nodes * m * n;
         if (ac) {
-            hipLaunchKernelGGL((k_red2d_fwd_dim1<T, true>), dim3(wx_grid2r(tot)), dim3(256), 0, st, x, xw, tmp, D, nodes, filt, acz);
-            hipLaunchKernelGGL((k_red2d_fwd_dim2<T, true>), dim3(wx_grid2r(2 * tot)), dim3(256), 0, st, xw, (const T *)tmp, D, nodes, filt, acz);
+            hipLaunchKernelGGL((k_red2d_fwd_dim1<T, true>), wx_grid2r(m * n, batch * nodes), dim3(256), 0, st, x, xw, tmp, D, nodes, filt, acz);
+            hipLaunchKernelGGL((k_red2d_fwd_dim2<T, true>), wx_grid2r(m * n, 2 * batch * nodes), dim3(256), 0, st, xw, (const T *)tmp, D, nodes, filt, acz);
         } else {
-            hipLaunchKernelGGL((k_red2d_fwd_dim1<T, false>), dim3(wx_grid2r(tot)), dim3(256), 0, st, x, xw, tmp, D, nodes, filt, acz);
-            hipLaunchKernelGGL((k_red2d_fwd_dim2<T, false>), dim3(wx_grid2r(2 * tot)), dim3(256), 0, st, xw, (const T *)tmp, D, nodes, filt, acz);
+            hipLaunchKernelGGL((k_red2d_fwd_dim1<T, false>), wx_grid2r(m * n, batch * nodes), dim3(256), 0, st, x, xw, tmp, D, nodes, filt, acz);
+            hipLaunchKernelGGL((k_red2d_fwd_dim2<T, false>), wx_grid2r(m * n, 2 * batch * nodes), dim3(256), 0, st, xw, (const T *)tmp, D, nodes, filt, acz);
         }
     }
     WX_HIP_CHECK(hipGetLastError());
@@ -355,14 +359,14 @@ int wx_dev_red2d_inv(const T *xw, T *x, int64_t m, int64_t n, int L, int layout,
         if (d == 0) { D.out = x; D.out_cols = 1; } else { D.out = bufs[d & 1]; D.out_cols = nodes_d; }
         const int64_t jobs = batch * nodes_d;
         if (ac) {
-            hipLaunchKernelGGL(k_red2d_iac<T>, dim3(wx_grid2r(jobs * mn)), dim3(256), 0, st, D, nodes_d);
+            hipLaunchKernelGGL(k_red2d_iac<T>, wx_grid2r(mn, jobs), dim3(256), 0, st, D, nodes_d);
         } else {
             const int sm_mode = sm >= 0 ? 1 : 0;
             const int sv = sm >= 0 ? (int)sd[d] : 0, sw = sm >= 0 ? (int)sd[d + 1] : 0;
             const int64_t per2 = sm_mode ? (m >> (d + 1)) * (n >> d) : mn;
             const int64_t per1 = sm_mode ? (m >> d) * (n >> d) : mn;
-            hipLaunchKernelGGL(k_red2d_inv_dim2<T>, dim3(wx_grid2r(jobs * 2 * per2)), dim3(256), 0, st, D, tmp, nodes_d, sm_mode, sv, sw, filt);
-            hipLaunchKernelGGL(k_red2d_inv_dim1<T>, dim3(wx_grid2r(jobs * per1)), dim3(256), 0, st, D, (const T *)tmp, nodes_d, sm_mode, sv, sw, filt);
+            hipLaunchKernelGGL(k_red2d_inv_dim2<T>, wx_grid2r(per2, jobs * 2), dim3(256), 0, st, D, tmp, nodes_d, sm_mode, sv, sw, filt);
+            hipLaunchKernelGGL(k_red2d_inv_dim1<T>, wx_grid2r(per1, jobs), dim3(256), 0, st, D, (const T *)tmp, nodes_d, sm_mode, sv, sw, filt);
         }
     }
     WX_HIP_CHECK(hipGetLastError());
