@@ -24,8 +24,7 @@ __global__ __launch_bounds__(256) void k_bb_norms(const T *__restrict__ X, int64
 {
     __shared__ double red[256];
     const T *x = X + (int64_t)blockIdx.x * sig_stride;
-    double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) { const double v = (double)x[i]; acc = fma(v, v, acc); }
+    const double acc = wx_sumsq_strided<T>(x, cnt);
     const double tot = bb_block_sum(acc, red);
     if (threadIdx.x == 0) nrm[blockIdx.x] = (T)sqrt(tot);
 }

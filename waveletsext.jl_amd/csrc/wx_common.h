@@ -64,6 +64,23 @@ static __device__ __forceinline__ void wx_stage(T *__restrict__ dst, const T *__
     for (; i < n; i += st) dst[i] = src[i];
 }
 
+// per-lane partial of sum x^2 over x[tid], x[tid + 256], ...: eight loads in flight, same order of additions
+template <typename T>
+static __device__ __forceinline__ double wx_sumsq_strided(const T *__restrict__ x, int64_t cnt)
+{
+    double acc = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 256 < cnt; i += 8 * 256) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const double d = (double)v[u]; acc = fma(d, d, acc); }
+    }
+    for (; i < cnt; i += 256) { const double d = (double)x[i]; acc = fma(d, d, acc); }
+    return acc;
+}
+
 #define WX_HIP_CHECK(expr)                                   \
     do {                                                     \
         hipError_t _e = (expr);                              \

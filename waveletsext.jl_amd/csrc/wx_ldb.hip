@@ -26,8 +26,7 @@ __global__ __launch_bounds__(256) void k_ldb_root_norm2(const T *__restrict__ X,
 {
     __shared__ double red[256];
     const T *x = X + (int64_t)blockIdx.x * sig_stride;
-    double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) { const double v = (double)x[i]; acc = fma(v, v, acc); }
+    const double acc = wx_sumsq_strided<T>(x, cnt);
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
