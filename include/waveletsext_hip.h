@@ -315,6 +315,9 @@ int wx_class_var_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, 
  *                     best tree, 2 = kept with its non-shifted children, 3 = kept with its shifted children.
  * wx_isiwpd_*         isiwpd(siwtObj) SIWT.jl:166-229: merges children into parents bottom-up along `status`,
  *                     overwriting the parents' rows of W like the reference overwrites Nodes[index].Value; xh (n, batch).
+ *                     literal = 0: the inverse step is told `shifted` exactly when the children came from the shifted
+ *                     step (the reading under which the reference's test isiwpd(siwtObj) ~ signal holds); literal = 1:
+ *                     the flag as siwt/siwt_one_level.jl:126 spells it (true for the NON-shifted children).
  * Errors: WX_EASSERT for 0 <= L <= maxtransformlevels(n), 1 <= d <= L (SIWT.jl:62-63).
  * ------------------------------------------------------------------------------------------ */
 int64_t wx_siwt_ncols(int L, int d);
@@ -326,9 +329,9 @@ int wx_siwpd_f32(const float *x, float *W, float *costs, int64_t n, int L, int d
 int wx_siwt_bestbasis_f64(double *costs, uint8_t *status, int L, int d, int64_t batch, void *stream);
 int wx_siwt_bestbasis_f32(float *costs, uint8_t *status, int L, int d, int64_t batch, void *stream);
 int wx_isiwpd_f64(double *W, const uint8_t *status, double *xh, int64_t n, int L, int d, int64_t batch, const double *qmf,
-                  int F, void *stream);
+                  int F, int literal, void *stream);
 int wx_isiwpd_f32(float *W, const uint8_t *status, float *xh, int64_t n, int L, int d, int64_t batch, const double *qmf,
-                  int F, void *stream);
+                  int F, int literal, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU exchange (one process per GPU, RCCL over xGMI; bound lazily, single-GPU callers never

@@ -949,8 +949,9 @@ def siwt_bestbasistree(obj):
     return obj.BestTree
 
 
-def isiwpd(obj):
-    """isiwpd(siwtObj) SIWT.jl:166-173 + isiwpd_subtree! :190-229 (children are deleted as they are merged)"""
+def isiwpd(obj, literal=False):
+    """isiwpd(siwtObj) SIWT.jl:166-173 + isiwpd_subtree! :190-229 (children are deleted as they are merged).
+    literal=True hands the numeric step the flag exactly as siwt_one_level.jl:126 spells it."""
     g, h = makereverseqmfpair(obj.qmf)
     tree = lambda: set(obj.BestTree)
 
@@ -971,7 +972,7 @@ def isiwpd(obj):
         # `isiwpd(siwtObj) ≈ signal`) cannot hold under that reading.  The oracle is pinned to the test: `s` is
         # true exactly when the children were produced by the shifted step (sidwt_step!(..., true)), the only
         # choice that inverts siwt_one_level.jl:71-98.  Julia cannot be run here to settle it; noted in DESIGN.md.
-        s = cs != shift
+        s = (cs == shift) if literal else (cs != shift)
         obj.Nodes[index]["Value"] = isidwt_step(obj.Nodes[c1]["Value"], obj.Nodes[c2]["Value"], h, g, s)
         siwt_delete_node(obj, c1); siwt_delete_node(obj, c2)
 

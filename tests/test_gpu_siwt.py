@@ -130,3 +130,25 @@ def test_batch_on_device_matches_single_signals(wx, oracle):
     bs = wx.siwpdall(wx.to_device(Xs), wt, L, L)
     wx.bestbasistreeall_(bs)
     assert float(np.ptp(bs.MinCost)) <= 1e-9
+
+
+def test_literal_readings(wx, oracle):
+    """literal=True reproduces the reference's code where it disagrees with its own tests"""
+    wt = _wt(wx, "haar")
+    signal = np.array([2, 3, -4, 5.0])
+    obj = wx.siwpd(signal, wt)
+    wx.bestbasistree_(obj)
+    assert np.allclose(wx.isiwpd(obj, literal=True), np.roll(signal, -1), atol=1e-12)
+    rng = np.random.default_rng(9)
+    wt = _wt(wx, "db4")
+    X = np.asfortranarray(rng.standard_normal((64, 3)))
+    batch = wx.siwpdall(X, wt, 4, 4)
+    wx.bestbasistreeall_(batch)
+    refs = []
+    for b in range(3):
+        ref = oracle.siwpd(X[:, b], wt.qmf, 4, 4)
+        oracle.siwt_bestbasistree(ref)
+        assert wx.isvalidtree(batch[b]) and wx.isvalidtree(batch[b], literal=True) == oracle.siwt_isvalidtree(ref, literal=True)
+        refs.append(oracle.isiwpd(ref, literal=True))
+    got = wx.isiwpdall(batch, literal=True)
+    assert relerr(got, np.asfortranarray(np.stack(refs, axis=1))) <= 1e-10

@@ -458,3 +458,21 @@ def test_siwt_nodes_are_packets_of_the_rotated_signal(oracle):
         oracle.siwt_bestbasistree(obj)
         assert oracle.siwt_isvalidtree(obj)
         assert np.allclose(oracle.isiwpd(obj), x, atol=1e-12)
+
+
+def test_siwt_literal_readings_of_the_reference(oracle):
+    """the two places where SIWT's code and its tests disagree, as written: the inverse flag of
+    siwt_one_level.jl:126 returns the known-answer signal rotated by one sample, and isvalidtree (siwt_utls.jl:195)
+    rejects every tree that uses a shifted pair"""
+    from waveletsext_jl_amd import WT, wavelet
+    q = wavelet(WT.haar).qmf
+    signal = np.array([2, 3, -4, 5.0])
+    obj = oracle.siwpd(signal, q)
+    oracle.siwt_bestbasistree(obj)
+    assert np.allclose(oracle.isiwpd(obj, literal=True), np.roll(signal, -1), rtol=1e-12)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(4)
+    obj = oracle.siwpd(x, q, 2, 2)
+    tree = oracle.siwt_bestbasistree(obj)
+    assert any(t for (j, i, t) in tree)                                # this signal's best basis uses a shift
+    assert oracle.siwt_isvalidtree(obj) and not oracle.siwt_isvalidtree(obj, literal=True)

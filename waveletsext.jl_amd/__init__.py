@@ -37,8 +37,8 @@ from . import siwt as _siwt                                                     
 _isvalidtree_arrays = isvalidtree                                                                          # noqa: F405
 
 
-def isvalidtree(*args):                                                                                    # noqa: F811
-    """isvalidtree(x, tree) (Wavelets.jl) or isvalidtree(siwtObj) (siwt/siwt_utls.jl:185-207)"""
+def isvalidtree(*args, **kw):                                                                              # noqa: F811
+    """isvalidtree(x, tree) (Wavelets.jl) or isvalidtree(siwtObj[, literal=False]) (siwt/siwt_utls.jl:185-207)"""
     if len(args) == 1 and isinstance(args[0], ShiftInvariantWaveletTransformObject):
-        return _siwt.isvalidtree(args[0])
-    return _isvalidtree_arrays(*args)
+        return _siwt.isvalidtree(args[0], **kw)
+    return _isvalidtree_arrays(*args, **kw)

@@ -107,7 +107,7 @@ _EXTRA_SIGS = {
     "wx_acwpd_jbb_moments": [_P, _P, _P, _L, _I, _L, _P, _I, _I, _P],
     "wx_siwpd": [_P, _P, _P, _L, _I, _I, _L, _P, _I, _P],
     "wx_siwt_bestbasis": [_P, _P, _I, _I, _L, _P],
-    "wx_isiwpd": [_P, _P, _P, _L, _I, _I, _L, _P, _I, _P],
+    "wx_isiwpd": [_P, _P, _P, _L, _I, _I, _L, _P, _I, _I, _P],
 }
 _PLAIN_SIGS = {
     "wx_treeselect_f64": [_P, _L, _L, _I, _P],

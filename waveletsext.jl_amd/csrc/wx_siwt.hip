@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void k_siwt_fwd_level(T *__restrict__ W, int n
 template <typename T, int FT>
 __global__ __launch_bounds__(256) void k_siwt_inv_level(T *__restrict__ W, const uint8_t *__restrict__ status, int n,
                                                         int64_t NS, int64_t NN, int j, int d, int64_t col_j,
-                                                        int64_t col_j1, int64_t node_j, int64_t items, WxFilt filt)
+                                                        int64_t col_j1, int64_t node_j, int64_t items, WxFilt filt,
+                                                        int literal)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= items) return;
@@ -164,9 +165,11 @@ __global__ __launch_bounds__(256) void k_siwt_inv_level(T *__restrict__ W, const
     const int node = r / h2, k = r - node * h2;
     const uint8_t stt = status[(int64_t)blockIdx.y * NN + node_j + (slot0 << j) + node];
     if (stt < 2) return;
-    const int s = stt == 3;
+    const int shifted = stt == 3;
+    // literal: the flag as siwt_one_level.jl:126 spells it (true for the non-shifted children), see DESIGN.md 4.13
+    const int s = literal ? !shifted : shifted;
     const int m1 = j + 1 > d ? j + 1 - d : 0, m0 = j > d ? j - d : 0;
-    const int64_t slot1 = ((slot0 << m0) + (s ? ((int64_t)1 << j) : 0)) >> m1;
+    const int64_t slot1 = ((slot0 << m0) + (shifted ? ((int64_t)1 << j) : 0)) >> m1;
     T *sig = W + (int64_t)blockIdx.y * NS * n;
     const T *a = sig + (col_j1 + slot1) * n + (int64_t)node * np;
     const T *dd = a + h2;
@@ -441,7 +444,7 @@ int api_siwt_bestbasis(T *costs, uint8_t *status, int L, int d, int64_t batch, v
 
 template <typename T>
 int api_isiwpd(T *W, const uint8_t *status, T *xh, int64_t n, int L, int d, int64_t batch, const double *qmf, int F,
-               void *stream)
+               int literal, void *stream)
 {
     WxFilt filt;
     int rc = wx_pack_filter(qmf, F, &filt);
@@ -463,7 +466,7 @@ int api_isiwpd(T *W, const uint8_t *status, T *xh, int64_t n, int L, int d, int6
         const unsigned bc = (unsigned)(batch - b0 < 65535 ? batch - b0 : 65535);
         for (int j = L - 1; j >= 0; --j) {
             const int64_t items = (n / 2) * (g.coloff[j + 1] - g.coloff[j]);
-            void (*ki)(T *, const uint8_t *, int, int64_t, int64_t, int, int, int64_t, int64_t, int64_t, int64_t, WxFilt);
+            void (*ki)(T *, const uint8_t *, int, int64_t, int64_t, int, int, int64_t, int64_t, int64_t, int64_t, WxFilt, int);
             switch (filt.F) {
 #define WX_CASE(FF) case FF: ki = k_siwt_inv_level<T, FF>; break;
                 WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
@@ -471,7 +474,7 @@ int api_isiwpd(T *W, const uint8_t *status, T *xh, int64_t n, int L, int d, int6
             default: ki = k_siwt_inv_level<T, 0>;
             }
             hipLaunchKernelGGL(ki, dim3(blocks_for(items), bc), dim3(256), 0, st, dW + b0 * NS * n, ds + b0 * NN,
-                               (int)n, NS, NN, j, d, g.coloff[j], g.coloff[j + 1], g.nodeoff[j], items, filt);
+                               (int)n, NS, NN, j, d, g.coloff[j], g.coloff[j + 1], g.nodeoff[j], items, filt, literal ? 1 : 0);
         }
     }
     if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "isiwpd kernels failed to launch"));
@@ -505,10 +508,10 @@ int wx_siwt_bestbasis_f64(double *costs, uint8_t *status, int L, int d, int64_t 
 int wx_siwt_bestbasis_f32(float *costs, uint8_t *status, int L, int d, int64_t batch, void *stream)
 { return api_siwt_bestbasis<float>(costs, status, L, d, batch, stream); }
 int wx_isiwpd_f64(double *W, const uint8_t *status, double *xh, int64_t n, int L, int d, int64_t batch, const double *qmf,
-                  int F, void *stream)
-{ return api_isiwpd<double>(W, status, xh, n, L, d, batch, qmf, F, stream); }
+                  int F, int literal, void *stream)
+{ return api_isiwpd<double>(W, status, xh, n, L, d, batch, qmf, F, literal, stream); }
 int wx_isiwpd_f32(float *W, const uint8_t *status, float *xh, int64_t n, int L, int d, int64_t batch, const double *qmf, int F,
-                  void *stream)
-{ return api_isiwpd<float>(W, status, xh, n, L, d, batch, qmf, F, stream); }
+                  int literal, void *stream)
+{ return api_isiwpd<float>(W, status, xh, n, L, d, batch, qmf, F, literal, stream); }
 
 }  // extern "C"

@@ -284,12 +284,12 @@ function bestbasistreeall!(b::SIWTBatch)
                 b.costs, b.status, b.L, b.d, size(b.W, 3), C_NULL))
     return b.status
 end
-function isiwpdall(b::SIWTBatch)
+function isiwpdall(b::SIWTBatch; literal::Bool = false)   # literal: the flag as siwt_one_level.jl:126 spells it
     n, _, N = size(b.W)
     xh = Matrix{Float64}(undef, n, N); q = qmfvec(b.wt)
     check(ccall((:wx_isiwpd_f64, LIB), Cint,
-                (Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, Int64, Cint, Cint, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
-                b.W, b.status, xh, n, b.L, b.d, N, q, length(q), C_NULL))
+                (Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, Int64, Cint, Cint, Int64, Ptr{Float64}, Cint, Cint, Ptr{Cvoid}),
+                b.W, b.status, xh, n, b.L, b.d, N, q, length(q), literal, C_NULL))
     return xh
 end
 function siwt_node(b::SIWTBatch, sig::Integer, j::Integer, i::Integer, t::Integer)

@@ -262,11 +262,12 @@ class _Batch:
         _lib.check(fn(self._ca.ptr, self._status_ptr(), self.L, self.d, self.B, self._wa.stream()))
         self._ch = self._sh = None
 
-    def inverse(self):
+    def inverse(self, literal=False):
         out = self._wa.new((self.n, self.B))
         q, qp, F = qmf_arg(self.wt)
         fn = getattr(_lib.lib(), "wx_isiwpd" + self.suffix)
-        _lib.check(fn(self._wa.ptr, self._status_ptr(), out.ptr, self.n, self.L, self.d, self.B, qp, F, self._wa.stream()))
+        _lib.check(fn(self._wa.ptr, self._status_ptr(), out.ptr, self.n, self.L, self.d, self.B, qp, F, int(bool(literal)),
+                      self._wa.stream()))
         # the children were merged into their parents and deleted (SIWT.jl:223-226): only the roots are left
         if self.kind == "torch":
             self.status.zero_()
@@ -350,22 +351,23 @@ def bestbasistree_(siwtObj):
     return siwtObj.BestTree
 
 
-def isiwpdall(batch):
-    """isiwpd of every signal; (n, batch)"""
+def isiwpdall(batch, literal=False):
+    """isiwpd of every signal; (n, batch).  literal=True passes the inverse step the flag exactly as
+    siwt/siwt_one_level.jl:126 spells it (see the module docstring)"""
     b = batch._b
     if b.status is None:
         assert b.L == 0, "hasNonShiftedChildren xor hasShiftedChildren (SIWT.jl:210): run bestbasistreeall_ first"
         return b.W[:, 0, :]
-    return b.inverse()
+    return b.inverse(literal)
 
 
-def isiwpd(siwtObj):
+def isiwpd(siwtObj, literal=False):
     """isiwpd(siwtObj) SIWT.jl:166-173: the children are merged bottom-up and deleted; returns the root's Value"""
     b = siwtObj._b
     if b.status is None:
         assert b.L == 0, "hasNonShiftedChildren xor hasShiftedChildren (SIWT.jl:210): run bestbasistree_ first"
     else:
-        b.inverse()
+        b.inverse(literal)
     return siwtObj.Nodes[(0, 0, 0)].Value
 
 
@@ -388,14 +390,15 @@ def delete_node_(siwtObj, index):
     b._set_status(st)
 
 
-def isvalidtree(siwtObj):
+def isvalidtree(siwtObj, literal=False):
     """Wavelets.Util.isvalidtree(siwtObj) siwt_utls.jl:185-207: every node but the root has its parent, and every
-    node has no children, its non-shifted pair, or its shifted pair -- never both"""
+    node has no children, its non-shifted pair, or its shifted pair -- never both.  literal=True looks the parent
+    up under the child's TransformShift, as :195 is written (false for every tree that uses a shift)"""
     nodes = set(siwtObj.BestTree)
     for (j, i, t) in nodes:
         is_root = (j, i, t) == (0, 0, 0)
         has_parent = (j - 1, i >> 1, t) in nodes
-        if j >= 1 and (t >> (j - 1)) & 1:
+        if not literal and j >= 1 and (t >> (j - 1)) & 1:
             has_parent = has_parent or (j - 1, i >> 1, t - (1 << (j - 1))) in nodes
         has_c = (j + 1, 2 * i, t) in nodes and (j + 1, 2 * i + 1, t) in nodes
         has_s = (j + 1, 2 * i, t + (1 << j)) in nodes and (j + 1, 2 * i + 1, t + (1 << j)) in nodes
