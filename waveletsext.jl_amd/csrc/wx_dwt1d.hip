@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
     constexpr int HF = F / 2;
     constexpr int BACK = (HF & 1) ? HF - 1 : HF;
     constexpr int NP4 = BACK + 2;                // 16-byte pairs per plane-pair window (4 outputs)
-    constexpr int PAD = 128 / (int)sizeof(T);
+    constexpr int PAD = 64 / (int)sizeof(T);
     const int n = 1 << log2n;
     const int Q = n >> 2;                        // elements per plane
     const int PS = Q + PAD;                      // plane stride (elements)
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x
     constexpr int HF = F / 2;
     constexpr int BACK = (HF & 1) ? HF - 1 : HF;
     constexpr int NP4 = BACK + 2;
-    constexpr int PAD = 128 / (int)sizeof(T);
+    constexpr int PAD = 64 / (int)sizeof(T);
     constexpr int KI = 2;                        // items per lane and level (n/8 <= KI*NT)
     const int n = 1 << log2n;
     const int Q = n >> 2;
