@@ -149,23 +149,37 @@ __global__ __launch_bounds__(256) void k_siwt_fwd_level(T *__restrict__ W, int n
 }
 
 // ---- inverse: children of depth j + 1 -> the nodes of depth j that kept children ------------------------
-// status: 0 not in the tree, 1 leaf, 2 non-shifted children, 3 shifted children
-template <typename T, int FT>
-__global__ __launch_bounds__(256) void k_siwt_inv_level(T *__restrict__ W, const uint8_t *__restrict__ status, int n,
-                                                        int64_t NS, int64_t NN, int j, int d, int64_t col_j,
-                                                        int64_t col_j1, int64_t node_j, int64_t items, WxFilt filt,
-                                                        int literal)
+// status: 0 not in the tree, 1 leaf, 2 non-shifted children, 3 shifted children.
+// A valid tree keeps at most one shift per (depth, IndexAtDepth) -- the path from the root fixes it -- so the
+// nodes of the tree are found through a per-signal map (depth, index) -> slot * 4 + status built in one pass over
+// the status bytes; every level then runs n / 2 lanes per signal instead of one lane per pair of every column.
+__global__ __launch_bounds__(256) void k_siwt_build_map(const uint8_t *__restrict__ status, int64_t NN, WxSiwtGeom g,
+                                                        int *__restrict__ map, int mapn)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= items) return;
-    const int half = n >> 1;
-    const int64_t slot0 = e / half;
-    const int r = (int)(e - slot0 * half);
+    if (e >= NN) return;
+    const uint8_t stt = status[(int64_t)blockIdx.y * NN + e];
+    if (!stt) return;
+    int j = 0;
+    while (j < g.L && e >= g.nodeoff[j + 1]) ++j;
+    const int64_t rel = e - g.nodeoff[j];
+    const int slot = (int)(rel >> j), idx = (int)(rel & (((int64_t)1 << j) - 1));
+    atomicMax(&map[(int64_t)blockIdx.y * mapn + ((1 << j) - 1) + idx], slot * 4 + stt);   // (max: defined even for an invalid tree)
+}
+
+template <typename T, int FT>
+__global__ __launch_bounds__(256) void k_siwt_inv_level(T *__restrict__ W, const int *__restrict__ map, int mapn, int n,
+                                                        int64_t NS, int j, int d, int64_t col_j, int64_t col_j1,
+                                                        WxFilt filt, int literal)
+{
+    const int r = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (r >= (n >> 1)) return;
     const int np = n >> j, h2 = np >> 1;
     const int node = r / h2, k = r - node * h2;
-    const uint8_t stt = status[(int64_t)blockIdx.y * NN + node_j + (slot0 << j) + node];
-    if (stt < 2) return;
-    const int shifted = stt == 3;
+    const int mv = map[(int64_t)blockIdx.y * mapn + ((1 << j) - 1) + node];
+    if (mv < 0 || (mv & 3) < 2) return;
+    const int64_t slot0 = mv >> 2;
+    const int shifted = (mv & 3) == 3;
     // literal: the flag as siwt_one_level.jl:126 spells it (true for the non-shifted children), see DESIGN.md 4.13
     const int s = literal ? !shifted : shifted;
     const int m1 = j + 1 > d ? j + 1 - d : 0, m0 = j > d ? j - d : 0;
@@ -462,19 +476,27 @@ int api_isiwpd(T *W, const uint8_t *status, T *xh, int64_t n, int L, int d, int6
     const uint8_t *ds = (const uint8_t *)io.in(status, (size_t)NN * batch);
     T *dx = (T *)io.out(xh, sizeof(T) * n * batch);
     if (!dW || !ds || !dx) return io.finish(WX_EHIP);
+    WxScratch scr(st);
+    const int mapn = (1 << (L + 1)) - 1;                              // one entry per (depth, IndexAtDepth)
+    int *dmap = (int *)scr.alloc(sizeof(int) * (size_t)mapn * batch);
+    if (!dmap) return io.finish(WX_EHIP);
+    if (hipMemsetAsync(dmap, 0xFF, sizeof(int) * (size_t)mapn * batch, st) != hipSuccess)
+        return io.finish(wx_set_error(WX_EHIP, "isiwpd: memset"));
     for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
         const unsigned bc = (unsigned)(batch - b0 < 65535 ? batch - b0 : 65535);
+        hipLaunchKernelGGL(k_siwt_build_map, dim3(blocks_for(NN), bc), dim3(256), 0, st, ds + b0 * NN, NN, g,
+                           dmap + b0 * mapn, mapn);
         for (int j = L - 1; j >= 0; --j) {
-            const int64_t items = (n / 2) * (g.coloff[j + 1] - g.coloff[j]);
-            void (*ki)(T *, const uint8_t *, int, int64_t, int64_t, int, int, int64_t, int64_t, int64_t, int64_t, WxFilt, int);
+            void (*ki)(T *, const int *, int, int, int64_t, int, int, int64_t, int64_t, WxFilt, int);
             switch (filt.F) {
 #define WX_CASE(FF) case FF: ki = k_siwt_inv_level<T, FF>; break;
                 WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
             default: ki = k_siwt_inv_level<T, 0>;
             }
-            hipLaunchKernelGGL(ki, dim3(blocks_for(items), bc), dim3(256), 0, st, dW + b0 * NS * n, ds + b0 * NN,
-                               (int)n, NS, NN, j, d, g.coloff[j], g.coloff[j + 1], g.nodeoff[j], items, filt, literal ? 1 : 0);
+            hipLaunchKernelGGL(ki, dim3(blocks_for(n / 2), bc), dim3(256), 0, st, dW + b0 * NS * n,
+                               (const int *)(dmap + b0 * mapn), mapn, (int)n, NS, j, d, g.coloff[j], g.coloff[j + 1], filt,
+                               literal ? 1 : 0);
         }
     }
     if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "isiwpd kernels failed to launch"));
