@@ -199,7 +199,7 @@ def cpu_baseline(w, seconds):
 
     probe = 16 if kind in ("wpd", "wpt") else 2
     t_probe, _ = run(probe)
-    cap = 8192 if kind in ("wpd", "wpt") else (64 if kind == "wpt2d" else 32)
+    cap = 16384 if kind in ("wpd", "wpt") else (64 if kind == "wpt2d" else 32)
     B = int(max(probe, min(cap, seconds / (t_probe / probe))))
     dt, samples = run(B)
     out = {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
