@@ -24,15 +24,19 @@ __device__ __forceinline__ double wx_log_pos(double s)
     double z = nu * rc;
     z = fma(fma(-dv, z, nu), rc, z);
     const double w = z * z;
+    // Horner with the coefficients as scalar operands of v_fma_f64: written as plain fma() the compiler picks
+    // v_fmac_f64, whose addend is the destination, and spends a v_mov_b64 per step to put the constant there
     double p = 1.0 / 19.0;
-    p = fma(p, w, 1.0 / 17.0);
-    p = fma(p, w, 1.0 / 15.0);
-    p = fma(p, w, 1.0 / 13.0);
-    p = fma(p, w, 1.0 / 11.0);
-    p = fma(p, w, 1.0 / 9.0);
-    p = fma(p, w, 1.0 / 7.0);
-    p = fma(p, w, 1.0 / 5.0);
-    p = fma(p, w, 1.0 / 3.0);
+#define WX_HORNER(c) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(w), "s"((double)(c)))
+    WX_HORNER(1.0 / 17.0);
+    WX_HORNER(1.0 / 15.0);
+    WX_HORNER(1.0 / 13.0);
+    WX_HORNER(1.0 / 11.0);
+    WX_HORNER(1.0 / 9.0);
+    WX_HORNER(1.0 / 7.0);
+    WX_HORNER(1.0 / 5.0);
+    WX_HORNER(1.0 / 3.0);
+#undef WX_HORNER
     const double zz = z + z;
     const double lm = fma(zz * w, p, zz);
     const double ed = (double)e;
