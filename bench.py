@@ -198,8 +198,9 @@ def cpu_baseline(w, seconds):
         return dt, B * n
 
     probe = 16 if kind in ("wpd", "wpt") else 2
+    run(probe)                                   # first call: library load, page faults
     t_probe, _ = run(probe)
-    cap = 16384 if kind in ("wpd", "wpt") else (64 if kind == "wpt2d" else 32)
+    cap = {"wpd": 16384, "wpt": 16384, "wpt2d": 320, "wpd_bb": 4096, "wpd_ldb": 2048}.get(kind, 32)
     B = int(max(probe, min(cap, seconds / (t_probe / probe))))
     dt, samples = run(B)
     out = {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
