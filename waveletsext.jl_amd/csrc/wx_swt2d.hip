@@ -15,6 +15,7 @@
 // the parent with child 1.
 #include "wx_common.h"
 #include "wx_kernels.h"
+#include <cstdlib>
 
 enum { WX2_DWT = 0, WX2_WPT = 1, WX2_WPD = 2 };
 
@@ -58,11 +59,25 @@ static __device__ __forceinline__ void wx_red_point(const T *line, int64_t es, i
         double a = 0.0, dd = 0.0;
         int k1 = i - s; if (k1 < 0) k1 += len;
         int k2 = i;
-        for (int j = 0; j < filt.F; ++j) {
-            a = fma(filt.q[j], (double)line[k1 * es], a);
-            dd = fma((j & 1) ? -filt.q[j] : filt.q[j], (double)line[k2 * es], dd);
-            k1 += s; if (k1 >= len) k1 -= len;
-            k2 -= s; if (k2 < 0) k2 += len;
+        // taps in blocks of four: eight loads in flight before the first multiply-add; same order of the sums
+        for (int j0 = 0; j0 < filt.F; j0 += 4) {
+            T xa[4], xd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j0 + u < filt.F) {
+                    xa[u] = line[k1 * es]; xd[u] = line[k2 * es];
+                    k1 += s; if (k1 >= len) k1 -= len;
+                    k2 -= s; if (k2 < 0) k2 += len;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j0 + u < filt.F) {
+                    const int j = j0 + u;
+                    a = fma(filt.q[j], (double)xa[u], a);
+                    dd = fma((j & 1) ? -filt.q[j] : filt.q[j], (double)xd[u], dd);
+                }
+            }
         }
         lo = (T)a; hi = (T)dd;
     } else {
@@ -70,10 +85,19 @@ static __device__ __forceinline__ void wx_red_point(const T *line, int64_t es, i
         const int s2 = (2 * s) % len;
         int km = i - s; if (km < 0) km += len;
         int kp = i + s; if (kp >= len) kp -= len;
-        for (int l = 1; l < ac.F; l += 2) {
-            S = fma(ac.b[l - 1], (double)line[km * es] + (double)line[kp * es], S);
-            km -= s2; if (km < 0) km += len;
-            kp += s2; if (kp >= len) kp -= len;
+        for (int l0 = 1; l0 < ac.F; l0 += 8) {                 // four odd lags per block: eight loads in flight
+            T xm[4], xp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (l0 + 2 * u < ac.F) {
+                    xm[u] = line[km * es]; xp[u] = line[kp * es];
+                    km -= s2; if (km < 0) km += len;
+                    kp += s2; if (kp >= len) kp -= len;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (l0 + 2 * u < ac.F) S = fma(ac.b[l0 + 2 * u - 1], (double)xm[u] + (double)xp[u], S);
         }
         const double c = ac.c1 * (double)line[i * es];
         lo = (T)(c + S); hi = (T)(c - S);
@@ -290,6 +314,84 @@ __global__ __launch_bounds__(256) void k_red2d_iac(WxInv2d D, int nodes)
     }
 }
 
+// ---- forward level in one pass ----------------------------------------------------------------------------------
+// The two-pass level moves 9 images per node (parent read, 2 written + 2 read through scratch, 4 children written).
+// Here a workgroup owns a strip of R rows of one node over ALL columns: the dim-1 step of the strip is computed
+// straight from the parent (taps along the contiguous dimension: coalesced, neighbouring rows hit in cache) into two
+// LDS images [column][row-in-strip]; the dim-2 step then runs out of LDS (whole rows resident: the periodic wrap and
+// the 2^d dilation are plain index arithmetic) and stores the four children: 5 images per node.  The reference's
+// in-place containers alias a child with its parent (swpt: child 0, sdwt: the next approximation), which a fused
+// level cannot write while other workgroups still read the parent -- so a child that is decomposed again travels
+// through a scratch image of its depth's parity (src_s / dst_s) and only final coefficients are written to xw.
+template <typename T, bool AC>
+__global__ __launch_bounds__(256) void k_red2d_fwd_fused(const T *__restrict__ x, T *__restrict__ xw,
+                                                         const T *__restrict__ src_s, T *__restrict__ dst_s, WxRed2d D,
+                                                         int nodes, int R, WxFilt filt, WxAcFilt ac)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem4[];
+    const int m = D.m, n = D.n, d = D.d;
+    const int64_t mn = (int64_t)m * n;
+    T *lo1 = reinterpret_cast<T *>(wx_smem4), *hi1 = lo1 + (size_t)n * R;
+    const int strips = m / R;
+    const int s1 = (1 << d) % m, s2 = (1 << d) % n;
+    const bool last = d + 1 == D.L;
+    const int64_t total = D.batch * nodes * strips;
+    for (int64_t bs = blockIdx.x; bs < total; bs += gridDim.x) {
+        const int64_t job = bs / strips;
+        const int r0 = (int)(bs - job * strips) * R;
+        const int b = (int)(job % nodes);
+        const int64_t sig = job / nodes;
+        int64_t pv, pc[4];
+        wx_red2d_slices(D, b, pv, pc);
+        const T *src;
+        T *dst[4];
+        if (D.layout == WX2_WPD) {
+            src = d == 0 ? x + sig * mn : xw + (sig * D.ncols + pv) * mn;
+            for (int c = 0; c < 4; ++c) dst[c] = xw + (sig * D.ncols + pc[c]) * mn;
+        } else if (D.layout == WX2_WPT) {
+            src = d == 0 ? x + sig * mn : src_s + job * mn;
+            for (int c = 0; c < 4; ++c)
+                dst[c] = last ? xw + (sig * D.ncols + pc[c]) * mn : dst_s + (job * 4 + c) * mn;
+        } else {                                          // DWT: child 0 is the next level's parent
+            src = d == 0 ? x + sig * mn : src_s + sig * mn;
+            dst[0] = last ? xw + (sig * D.ncols + pc[0]) * mn : dst_s + sig * mn;
+            for (int c = 1; c < 4; ++c) dst[c] = xw + (sig * D.ncols + pc[c]) * mn;
+        }
+        for (int e = threadIdx.x; e < R * n; e += 256) {
+            const int c = e / R, r = e - c * R;
+            T lo, hi;
+            wx_red_point<T, AC>(src + (int64_t)c * m, 1, m, r0 + r, s1, filt, ac, lo, hi);
+            lo1[e] = lo; hi1[e] = hi;
+            if (d == 0 && D.layout == WX2_WPD) xw[(sig * D.ncols) * mn + (int64_t)c * m + r0 + r] = src[(int64_t)c * m + r0 + r];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < R * n; e += 256) {
+            const int c = e / R, r = e - c * R;
+            const int64_t o = (int64_t)c * m + r0 + r;
+            T lo, hi;
+            wx_red_point<T, AC>(lo1 + r, R, n, c, s2, filt, ac, lo, hi);
+            dst[0][o] = lo; dst[1][o] = hi;
+            wx_red_point<T, AC>(hi1 + r, R, n, c, s2, filt, ac, lo, hi);
+            dst[2][o] = lo; dst[3][o] = hi;
+        }
+        __syncthreads();
+    }
+}
+
+// rows per strip of the fused level (0: not applicable)
+template <typename T> static int wx_red2d_fused_rows(int64_t m, int64_t n)
+{
+    static const bool off = getenv("WX_RED2D_FUSED") && atoi(getenv("WX_RED2D_FUSED")) == 0;
+    if (off) return 0;
+    // LDS budget of a strip: 32 KiB (4 workgroups per CU hide the tap loads' latency; measured 64 / 32 / 16 KiB:
+    // sdwt 2.11 / 1.65 / 2.47 ms, swpt 10.5 / 8.2 / 16.5 ms); the autocorrelation step has half the taps and is
+    // indifferent (6.6 / 6.9 ms)
+    static const size_t kib = getenv("WX_RED2D_LDS_KIB") ? (size_t)atoi(getenv("WX_RED2D_LDS_KIB")) : 32;
+    int R = 32;
+    while (R >= 4 && ((size_t)2 * n * R * sizeof(T) > kib * 1024 || m % R)) R >>= 1;
+    return R >= 4 ? R : 0;
+}
+
 // grid.x over the elements of one job, grid.y over the jobs
 static dim3 wx_grid2r(int64_t per, int64_t njobs)
 {
@@ -316,6 +418,29 @@ int wx_dev_red2d_fwd(const T *x, T *xw, int64_t m, int64_t n, int L, int layout,
     if (batch == 0 || m * n == 0) return WX_OK;
     WxAcFilt acz;
     if (ac) acz = *ac; else { acz.F = 0; acz.c1 = 0; }
+    const int R = wx_red2d_fused_rows<T>(m, n);
+    if (R) {
+        // scratch images of the nodes that are decomposed again: depth d in buf[d & 1] (each half of tmp holds the
+        // 4^(L-1) nodes of the deepest intermediate depth)
+        const int64_t half = (layout == WX2_DWT ? 1 : ((int64_t)1 << (2 * (L > 1 ? L - 1 : 0)))) * batch * m * n;
+        T *buf[2] = {tmp, tmp + half};
+        const size_t lds = (size_t)2 * n * R * sizeof(T);
+        for (int d = 0; d < L; ++d) {
+            WxRed2d D;
+            D.layout = layout; D.L = L; D.d = d; D.m = (int)m; D.n = (int)n; D.ncols = wx_red2d_ncols(layout, L); D.batch = batch;
+            const int nodes = layout == WX2_DWT ? 1 : (1 << (2 * d));
+            int64_t g = batch * nodes * (m / R);
+            if (g > 256 * 8) g = 256 * 8;
+            if (ac)
+                hipLaunchKernelGGL((k_red2d_fwd_fused<T, true>), dim3((unsigned)g), dim3(256), lds, st, x, xw, (const T *)buf[d & 1],
+                                   buf[(d + 1) & 1], D, nodes, R, filt, acz);
+            else
+                hipLaunchKernelGGL((k_red2d_fwd_fused<T, false>), dim3((unsigned)g), dim3(256), lds, st, x, xw, (const T *)buf[d & 1],
+                                   buf[(d + 1) & 1], D, nodes, R, filt, acz);
+        }
+        WX_HIP_CHECK(hipGetLastError());
+        return WX_OK;
+    }
     for (int d = 0; d < L; ++d) {
         WxRed2d D;
         D.layout = layout; D.L = L; D.d = d; D.m = (int)m; D.n = (int)n; D.ncols = wx_red2d_ncols(layout, L); D.batch = batch;
