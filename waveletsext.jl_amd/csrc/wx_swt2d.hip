@@ -389,7 +389,9 @@ template <typename T> static int wx_red2d_fused_rows(int64_t m, int64_t n)
     static const size_t kib = getenv("WX_RED2D_LDS_KIB") ? (size_t)atoi(getenv("WX_RED2D_LDS_KIB")) : 32;
     int R = 32;
     while (R >= 4 && ((size_t)2 * n * R * sizeof(T) > kib * 1024 || m % R)) R >>= 1;
-    return R >= 4 ? R : 0;
+    // store runs of a strip are R rows: below 64 bytes the one-pass level loses to the two passes (512 columns of
+    // Float64, R = 4: swpt 16.5 ms against 12.1), so wide images keep the two-pass levels
+    return R >= 4 && (size_t)R * sizeof(T) >= 64 ? R : 0;
 }
 
 // grid.x over the elements of one job, grid.y over the jobs
