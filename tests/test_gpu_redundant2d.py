@@ -107,3 +107,25 @@ def test_jbb2d_and_getbasiscoef2d(wx, oracle):
         assert (gb[..., i] == oracle.getbasiscoef2d(yw[..., i], t2)).all()
     assert (wx.getbasiscoef(yw[..., 0], t2) == gb[..., 0]).all()
     assert relerr(wx.wptall(Y, wt, t2), gb) <= 1e-10                  # wpt by tree == gathered leaves
+
+
+@pytest.mark.parametrize("wname", ["haar", "db4", "db8"])
+def test_one_pass_forward_levels_whole_rows_and_column_tiles(wx, oracle, wname):
+    """the one-pass forward level (k_red2d_fwd_fused): strips holding whole rows (up to 256 columns), column tiles
+    with halo for wider images, rows not divisible by the preferred strip height, all three containers, both
+    families, Float64 and Float32 -- against the oracle (same arithmetic as the two-pass level: exact order of sums)"""
+    rng = np.random.default_rng(4100)
+    wt = _wt(wx, wname)
+    for (m, n, L, dtype) in ((64, 256, 3, np.float64), (32, 512, 2, np.float64), (16, 1024, 3, np.float32),
+                             (48, 640, 2, np.float64), (128, 128, 3, np.float32)):
+        tol = TOL[np.dtype(dtype)]
+        x = np.asfortranarray(rng.standard_normal((m, n)).astype(dtype))
+        for kind, fn in (("dwt", wx.sdwt), ("wpt", wx.swpt), ("wpd", wx.swpd)):
+            assert relerr(fn(x, wt, L), oracle.red2d_fwd(kind, x, wt.qmf, L)) <= tol, (m, n, L, kind)
+        if dtype == np.float64:
+            for kind, fn in (("dwt", wx.acdwt), ("wpt", wx.acwpt), ("wpd", wx.acwpd)):
+                assert relerr(fn(x, wt, L), oracle.red2d_fwd(kind, x, wt.qmf, L, ac=True)) <= tol, (m, n, L, kind, "ac")
+        xb = np.asfortranarray(rng.standard_normal((m, n, 3)).astype(dtype))
+        got = wx.swptall(xb, wt, L)
+        assert relerr(got[..., 2], oracle.red2d_fwd("wpt", np.asfortranarray(xb[..., 2]), wt.qmf, L)) <= tol
+        assert relerr(wx.iswptall(got, wt), xb) <= 50 * tol

@@ -326,17 +326,22 @@ __global__ __launch_bounds__(256) void k_red2d_iac(WxInv2d D, int nodes)
 template <typename T, bool AC>
 __global__ __launch_bounds__(256) void k_red2d_fwd_fused(const T *__restrict__ x, T *__restrict__ xw,
                                                          const T *__restrict__ src_s, T *__restrict__ dst_s, WxRed2d D,
-                                                         int nodes, int R, WxFilt filt, WxAcFilt ac)
+                                                         int nodes, int R, int CT, int hb, int W, WxFilt filt, WxAcFilt ac)
 {
+    // CT = n, hb = 0, W = n: the strip holds whole rows (wrap in LDS).  Wider images: tiles of CT columns with the
+    // taps' reach as halo (hb before, W - CT - hb after), fetched with wrap from the parent; no wrap in LDS then.
     extern __shared__ __attribute__((aligned(16))) char wx_smem4[];
     const int m = D.m, n = D.n, d = D.d;
     const int64_t mn = (int64_t)m * n;
-    T *lo1 = reinterpret_cast<T *>(wx_smem4), *hi1 = lo1 + (size_t)n * R;
-    const int strips = m / R;
+    T *lo1 = reinterpret_cast<T *>(wx_smem4), *hi1 = lo1 + (size_t)W * R;
+    const int strips = m / R, ctiles = (n + CT - 1) / CT;
     const int s1 = (1 << d) % m, s2 = (1 << d) % n;
     const bool last = d + 1 == D.L;
-    const int64_t total = D.batch * nodes * strips;
-    for (int64_t bs = blockIdx.x; bs < total; bs += gridDim.x) {
+    const int64_t total = D.batch * nodes * strips * ctiles;
+    for (int64_t bs0 = blockIdx.x; bs0 < total; bs0 += gridDim.x) {
+        const int64_t bs = bs0 / ctiles;
+        const int c0 = (int)(bs0 - bs * ctiles) * CT;
+        const int cw = n - c0 < CT ? n - c0 : CT;             // columns of this tile
         const int64_t job = bs / strips;
         const int r0 = (int)(bs - job * strips) * R;
         const int b = (int)(job % nodes);
@@ -357,41 +362,60 @@ __global__ __launch_bounds__(256) void k_red2d_fwd_fused(const T *__restrict__ x
             dst[0] = last ? xw + (sig * D.ncols + pc[0]) * mn : dst_s + sig * mn;
             for (int c = 1; c < 4; ++c) dst[c] = xw + (sig * D.ncols + pc[c]) * mn;
         }
-        for (int e = threadIdx.x; e < R * n; e += 256) {
-            const int c = e / R, r = e - c * R;
+        const int wl = CT == n ? n : cw + (W - CT);           // staged columns of this tile
+        for (int e = threadIdx.x; e < R * wl; e += 256) {
+            const int lc = e / R, r = e - lc * R;
+            int c = c0 - hb + lc;
+            if (c < 0) c += n; else if (c >= n) c -= n;
             T lo, hi;
             wx_red_point<T, AC>(src + (int64_t)c * m, 1, m, r0 + r, s1, filt, ac, lo, hi);
             lo1[e] = lo; hi1[e] = hi;
-            if (d == 0 && D.layout == WX2_WPD) xw[(sig * D.ncols) * mn + (int64_t)c * m + r0 + r] = src[(int64_t)c * m + r0 + r];
+            if (d == 0 && D.layout == WX2_WPD && lc >= hb && lc < hb + cw)
+                xw[(sig * D.ncols) * mn + (int64_t)c * m + r0 + r] = src[(int64_t)c * m + r0 + r];
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < R * n; e += 256) {
-            const int c = e / R, r = e - c * R;
-            const int64_t o = (int64_t)c * m + r0 + r;
+        for (int e = threadIdx.x; e < R * cw; e += 256) {
+            const int cl = e / R, r = e - cl * R;
+            const int64_t o = (int64_t)(c0 + cl) * m + r0 + r;
             T lo, hi;
-            wx_red_point<T, AC>(lo1 + r, R, n, c, s2, filt, ac, lo, hi);
+            wx_red_point<T, AC>(lo1 + r, R, wl, cl + hb, s2, filt, ac, lo, hi);
             dst[0][o] = lo; dst[1][o] = hi;
-            wx_red_point<T, AC>(hi1 + r, R, n, c, s2, filt, ac, lo, hi);
+            wx_red_point<T, AC>(hi1 + r, R, wl, cl + hb, s2, filt, ac, lo, hi);
             dst[2][o] = lo; dst[3][o] = hi;
         }
         __syncthreads();
     }
 }
 
-// rows per strip of the fused level (0: not applicable)
-template <typename T> static int wx_red2d_fused_rows(int64_t m, int64_t n)
+// geometry of the one-pass level at dilation s: R rows per strip, tiles of CT columns with hb halo columns before and
+// W - CT - hb after (CT = n: whole rows).  R = 0: not applicable (the caller takes the two passes).
+struct WxRedTile { int R, CT, hb, W; };
+template <typename T> static WxRedTile wx_red2d_fused_geom(int64_t m, int64_t n, int s, int F, bool ac)
 {
     static const bool off = getenv("WX_RED2D_FUSED") && atoi(getenv("WX_RED2D_FUSED")) == 0;
-    if (off) return 0;
     // LDS budget of a strip: 32 KiB (4 workgroups per CU hide the tap loads' latency; measured 64 / 32 / 16 KiB:
     // sdwt 2.11 / 1.65 / 2.47 ms, swpt 10.5 / 8.2 / 16.5 ms); the autocorrelation step has half the taps and is
     // indifferent (6.6 / 6.9 ms)
     static const size_t kib = getenv("WX_RED2D_LDS_KIB") ? (size_t)atoi(getenv("WX_RED2D_LDS_KIB")) : 32;
-    int R = 32;
-    while (R >= 4 && ((size_t)2 * n * R * sizeof(T) > kib * 1024 || m % R)) R >>= 1;
-    // store runs of a strip are R rows: below 64 bytes the one-pass level loses to the two passes (512 columns of
-    // Float64, R = 4: swpt 16.5 ms against 12.1), so wide images keep the two-pass levels
-    return R >= 4 && (size_t)R * sizeof(T) >= 64 ? R : 0;
+    WxRedTile g = {0, 0, 0, 0};
+    if (off || s >= n) return g;
+    // store runs of a strip are R rows: below 64 bytes the one-pass level loses to the two passes
+    // whole rows first (no redundant dim-1 work): 256 images of 256 x 256 Float64, swpt: 7.6 ms against 9.0 tiled
+    for (int R = 128 / (int)sizeof(T); R * (int)sizeof(T) >= 64; R >>= 1) {
+        if (m % R) continue;
+        const int wmax = (int)(kib * 1024 / ((size_t)2 * R * sizeof(T)));
+        if (n <= wmax) { g.R = R; g.CT = (int)n; g.hb = 0; g.W = (int)n; return g; }
+    }
+    // column tiles for wider Float64 images (Float32 tiles lose to the two passes: 1024 x 1024, swpt 13.7 ms against 11.8)
+    if (sizeof(T) != 8) return g;
+    for (int R = 128 / (int)sizeof(T); R * (int)sizeof(T) >= 64; R >>= 1) {
+        if (m % R) continue;
+        const int wmax = (int)(kib * 1024 / ((size_t)2 * R * sizeof(T)));
+        const int hb = (F - 1) * s, ha = ac ? (F - 1) * s : (F - 2) * s;
+        const int ct = wmax - hb - ha;
+        if (ct >= hb + ha && ct >= 16) { g.R = R; g.CT = ct; g.hb = hb; g.W = wmax; return g; }   // at most 2x the dim-1 work
+    }
+    return g;
 }
 
 // grid.x over the elements of one job, grid.y over the jobs
@@ -420,25 +444,27 @@ int wx_dev_red2d_fwd(const T *x, T *xw, int64_t m, int64_t n, int L, int layout,
     if (batch == 0 || m * n == 0) return WX_OK;
     WxAcFilt acz;
     if (ac) acz = *ac; else { acz.F = 0; acz.c1 = 0; }
-    const int R = wx_red2d_fused_rows<T>(m, n);
-    if (R) {
+    bool all_fused = L > 0;
+    for (int d = 0; d < L; ++d) all_fused = all_fused && wx_red2d_fused_geom<T>(m, n, 1 << d, filt.F, ac != nullptr).R > 0;
+    if (all_fused) {
         // scratch images of the nodes that are decomposed again: depth d in buf[d & 1] (each half of tmp holds the
         // 4^(L-1) nodes of the deepest intermediate depth)
         const int64_t half = (layout == WX2_DWT ? 1 : ((int64_t)1 << (2 * (L > 1 ? L - 1 : 0)))) * batch * m * n;
         T *buf[2] = {tmp, tmp + half};
-        const size_t lds = (size_t)2 * n * R * sizeof(T);
         for (int d = 0; d < L; ++d) {
             WxRed2d D;
             D.layout = layout; D.L = L; D.d = d; D.m = (int)m; D.n = (int)n; D.ncols = wx_red2d_ncols(layout, L); D.batch = batch;
             const int nodes = layout == WX2_DWT ? 1 : (1 << (2 * d));
-            int64_t g = batch * nodes * (m / R);
+            const WxRedTile t = wx_red2d_fused_geom<T>(m, n, 1 << d, filt.F, ac != nullptr);
+            const size_t lds = (size_t)2 * t.W * t.R * sizeof(T);
+            int64_t g = batch * nodes * (m / t.R) * ((n + t.CT - 1) / t.CT);
             if (g > 256 * 8) g = 256 * 8;
             if (ac)
                 hipLaunchKernelGGL((k_red2d_fwd_fused<T, true>), dim3((unsigned)g), dim3(256), lds, st, x, xw, (const T *)buf[d & 1],
-                                   buf[(d + 1) & 1], D, nodes, R, filt, acz);
+                                   buf[(d + 1) & 1], D, nodes, t.R, t.CT, t.hb, t.W, filt, acz);
             else
                 hipLaunchKernelGGL((k_red2d_fwd_fused<T, false>), dim3((unsigned)g), dim3(256), lds, st, x, xw, (const T *)buf[d & 1],
-                                   buf[(d + 1) & 1], D, nodes, R, filt, acz);
+                                   buf[(d + 1) & 1], D, nodes, t.R, t.CT, t.hb, t.W, filt, acz);
         }
         WX_HIP_CHECK(hipGetLastError());
         return WX_OK;
