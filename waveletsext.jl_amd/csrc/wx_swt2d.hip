@@ -202,13 +202,27 @@ static __device__ __forceinline__ double wx_isdwt_point(const T *w1, const T *w2
     const bool odd = t0 & 1;
     int k1 = tau, k2 = tau;
     double v = 0.0;
-    for (int m = 0; m < filt.F / 2; ++m) {
-        const double a = (double)w1[(swc + (int64_t)k1 * 2 * s) * es];
-        const double c = (double)w2[(swc + (int64_t)k2 * 2 * s) * es];
-        if (!odd) { v = fma(filt.q[2 * m], a, v); v = fma(-filt.q[2 * m + 1], c, v); }
-        else { v = fma(filt.q[2 * m + 1], a, v); v = fma(filt.q[2 * m], c, v); }
-        k1 = k1 == 0 ? nc - 1 : k1 - 1;
-        k2 = k2 + 1 == nc ? 0 : k2 + 1;
+    // tap pairs in blocks of four: eight loads in flight before the first multiply-add, same order of the sum
+    for (int m0 = 0; m0 < filt.F / 2; m0 += 4) {
+        T xa[4], xc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (m0 + q < filt.F / 2) {
+                xa[q] = w1[(swc + (int64_t)k1 * 2 * s) * es];
+                xc[q] = w2[(swc + (int64_t)k2 * 2 * s) * es];
+                k1 = k1 == 0 ? nc - 1 : k1 - 1;
+                k2 = k2 + 1 == nc ? 0 : k2 + 1;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (m0 + q < filt.F / 2) {
+                const int m = m0 + q;
+                const double a = (double)xa[q], c = (double)xc[q];
+                if (!odd) { v = fma(filt.q[2 * m], a, v); v = fma(-filt.q[2 * m + 1], c, v); }
+                else { v = fma(filt.q[2 * m + 1], a, v); v = fma(filt.q[2 * m], c, v); }
+            }
+        }
     }
     return v;
 }
@@ -429,6 +443,54 @@ static dim3 wx_grid2r(int64_t per, int64_t njobs)
     return dim3((unsigned)gx, (unsigned)gy);
 }
 
+// ---- average-based inverse level in one pass ---------------------------------------------------------------------
+// The mirror of k_red2d_fwd_fused for isdwt_step! 2-D (average of the two shifts in each dimension).  The two 1-D
+// synthesis steps act on different axes and commute, so the strip first merges along dim 1 -- (w1, w3) and (w2, w4),
+// taps along the contiguous dimension, straight from the children -- into two LDS images over all columns, then
+// merges those along dim 2 out of LDS.  (The reference goes rows first; the results agree to rounding.)  5 images
+// per node instead of 9.  Whole-row strips only; the shift-based variants and wider images keep the two passes.
+template <typename T>
+__global__ __launch_bounds__(256) void k_red2d_inv_fused(WxInv2d D, int nodes, int R, WxFilt filt)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem5[];
+    const int m = D.R.m, n = D.R.n, d = D.R.d, s = 1 << d;
+    const int64_t mn = (int64_t)m * n;
+    T *ulo = reinterpret_cast<T *>(wx_smem5), *uhi = ulo + (size_t)n * R;
+    const int strips = m / R;
+    const int64_t total = D.R.batch * nodes * strips;
+    for (int64_t bs = blockIdx.x; bs < total; bs += gridDim.x) {
+        const int64_t job = bs / strips;
+        const int r0 = (int)(bs - job * strips) * R;
+        const int b = (int)(job % nodes);
+        const int64_t sig = job / nodes;
+        if (D.R.layout == WX2_WPD && D.tree) {
+            const int64_t heap = wx_quad_start(d) + b;
+            if (!(heap <= D.ntree && D.tree[heap - 1])) continue;      // (uniform for the workgroup)
+        }
+        const T *w1 = wx_inv2d_child<T>(D, sig, b, 0), *w2 = wx_inv2d_child<T>(D, sig, b, 1);
+        const T *w3 = wx_inv2d_child<T>(D, sig, b, 2), *w4 = wx_inv2d_child<T>(D, sig, b, 3);
+        T *out = reinterpret_cast<T *>(D.out) + (sig * D.out_cols + ((D.R.layout == WX2_DWT || d == 0) ? 0 : b)) * mn;
+        for (int e = threadIdx.x; e < R * n; e += 256) {
+            const int c = e / R, r = r0 + (e - c * R);
+            const int cls = r & (s - 1), u = r >> d;
+            const int64_t co = (int64_t)c * m;
+            ulo[e] = (T)(0.5 * (wx_isdwt_point<T>(w1 + co, w3 + co, 1, m, d, cls, u, false, filt) +
+                                wx_isdwt_point<T>(w1 + co, w3 + co, 1, m, d, cls, u, true, filt)));
+            uhi[e] = (T)(0.5 * (wx_isdwt_point<T>(w2 + co, w4 + co, 1, m, d, cls, u, false, filt) +
+                                wx_isdwt_point<T>(w2 + co, w4 + co, 1, m, d, cls, u, true, filt)));
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < R * n; e += 256) {
+            const int c = e / R, rl = e - c * R;
+            const int cls = c & (s - 1), u = c >> d;
+            const double v = 0.5 * (wx_isdwt_point<T>(ulo + rl, uhi + rl, R, n, d, cls, u, false, filt) +
+                                    wx_isdwt_point<T>(ulo + rl, uhi + rl, R, n, d, cls, u, true, filt));
+            out[(int64_t)c * m + r0 + rl] = (T)v;
+        }
+        __syncthreads();
+    }
+}
+
 static int64_t wx_red2d_ncols(int layout, int L)
 {
     if (layout == WX2_DWT) return 3 * L + 1;
@@ -516,6 +578,18 @@ int wx_dev_red2d_inv(const T *xw, T *x, int64_t m, int64_t n, int L, int layout,
         } else {
             const int sm_mode = sm >= 0 ? 1 : 0;
             const int sv = sm >= 0 ? (int)sd[d] : 0, sw = sm >= 0 ? (int)sd[d + 1] : 0;
+            if (!sm_mode && (m & (m - 1)) == 0 && (n & (n - 1)) == 0) {
+                const WxRedTile t = wx_red2d_fused_geom<T>(m, n, 1 << d, filt.F, false);
+                // whole-row strips; measured against the two passes (256 images, L = 3 iswpt): 128 x 128 Float64
+                // 9.4 ms vs 12.3, 256 x 256 Float32 8.6 vs 9.8, but 256 x 256 Float64 (strips of 8 rows) 12.7 vs 11.3
+                if (t.R && t.CT == (int)n && (size_t)n * sizeof(T) <= 1024) {
+                    int64_t g = jobs * (m / t.R);
+                    if (g > 256 * 8) g = 256 * 8;
+                    hipLaunchKernelGGL(k_red2d_inv_fused<T>, dim3((unsigned)g), dim3(256), (size_t)2 * n * t.R * sizeof(T), st, D,
+                                       nodes_d, t.R, filt);
+                    continue;
+                }
+            }
             const int64_t per2 = sm_mode ? (m >> (d + 1)) * (n >> d) : mn;
             const int64_t per1 = sm_mode ? (m >> d) * (n >> d) : mn;
             hipLaunchKernelGGL(k_red2d_inv_dim2<T>, wx_grid2r(per2, jobs * 2), dim3(256), 0, st, D, tmp, nodes_d, sm_mode, sv, sw, filt);
