@@ -410,7 +410,8 @@ template <typename T> static WxRedTile wx_red2d_fused_geom(int64_t m, int64_t n,
     // LDS budget of a strip: 32 KiB (4 workgroups per CU hide the tap loads' latency; measured 64 / 32 / 16 KiB:
     // sdwt 2.11 / 1.65 / 2.47 ms, swpt 10.5 / 8.2 / 16.5 ms); the autocorrelation step has half the taps and is
     // indifferent (6.6 / 6.9 ms)
-    static const size_t kib = getenv("WX_RED2D_LDS_KIB") ? (size_t)atoi(getenv("WX_RED2D_LDS_KIB")) : 32;
+    static const size_t kib_env = getenv("WX_RED2D_LDS_KIB") ? (size_t)atoi(getenv("WX_RED2D_LDS_KIB")) : 0;
+    const size_t kib = kib_env ? kib_env : 32;
     WxRedTile g = {0, 0, 0, 0};
     if (off || s >= n) return g;
     // store runs of a strip are R rows: below 64 bytes the one-pass level loses to the two passes
