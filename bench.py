@@ -37,6 +37,11 @@ WORKLOADS = {
                    kernel="k_fwd1d_inplace<double, 8, 256, false>",
                    fwd_kernels=[("k_fwd1d_inplace<double, 8, 256, false>", 1)],
                    desc="north-star target: wptall+iwptall 65536x4096 f64 db4 L=10"),
+    "target_haar": dict(kind="wpt", n=4096, batch=65536, wavelet="haar", L=10, dtype="f64",
+                        kernel="k_haar_wpt_f64<256>",
+                        fwd_kernels=[("k_haar_wpt_f64<256>", 1)],
+                        desc="north-star target with the Haar filter: wptall+iwptall 65536x4096 f64 haar L=10 "
+                             "(Walsh-Hadamard kernels, wx_haar.hip)"),
     "cfg3": dict(kind="swpt", n=16384, batch=64, wavelet="haar", L=12, dtype="f64",
                  kernel="k_swt_fwd_multi_rc<double, 8, 8>",
                  fwd_kernels=[("k_swt_fwd_multi<double, 8>", 2), ("k_swt_fwd_multi_rc<double, 8, 8>", 2)],

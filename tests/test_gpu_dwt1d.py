@@ -257,3 +257,36 @@ def test_long_signals_split_path_matches_oracle(wx, oracle, wname, dtype, n):
         assert relerr(wx.wptall(x, wt, L), leaves) <= tol, ("wpt", L)
         assert relerr(wx.iwptall(leaves, wt, L), x) <= 10 * tol, ("iwpt", L)
         assert relerr(wx.iwpdall(exp, wt, L), x) <= 10 * tol, ("iwpd", L)
+
+
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192])
+def test_haar_walsh_hadamard_path(wx, oracle, n):
+    """Haar, full tree, Float64, 1024 <= n <= 8192, L <= 10: the Walsh-Hadamard kernels of wx_haar.hip (registers +
+    cross-lane butterflies, one pass through LDS for the bit-reversed packet order) against the oracle, for every
+    depth, host and device arrays; a two-tap filter with unequal taps and the forced generic path give the same
+    coefficients through the general kernels."""
+    rng = np.random.default_rng(n)
+    wt = _wt(wx, "haar")
+    x = np.asfortranarray(rng.standard_normal((n, 5)))
+    for L in range(1, min(10, wx.maxtransformlevels(n)) + 1):
+        exp = _stack_cols(oracle, x, wt.qmf, L)
+        got = wx.wptall(x, wt, L)
+        assert relerr(got, exp) <= 1e-13, (n, L)
+        assert relerr(wx.iwptall(exp, wt, L), x) <= 1e-13, (n, L)
+    L = 7
+    exp = _stack_cols(oracle, x, wt.qmf, L)
+    gd = wx.wptall(wx.to_device(x), wt, L)
+    assert relerr(wx.to_numpy(gd), exp) <= 1e-13
+    assert relerr(wx.to_numpy(wx.iwptall(gd, wt, L)), x) <= 1e-13
+    wx.set_force_generic(1)
+    try:
+        assert relerr(wx.wptall(x, wt, L), exp) <= 1e-13
+    finally:
+        wx.set_force_generic(0)
+    skew = wx.OrthoFilter([0.6, 0.8], "skew2")                          # q0 != q1: not a Walsh-Hadamard butterfly
+    e2 = _stack_cols(oracle, x, skew.qmf, 3)
+    assert relerr(wx.wptall(x, skew, 3), e2) <= 1e-13
+
+
+def _stack_cols(oracle, x, qmf, L):
+    return np.asfortranarray(np.stack([oracle.wpt(np.ascontiguousarray(x[:, i]), qmf, L) for i in range(x.shape[1])], axis=1))

@@ -16,7 +16,7 @@ import summarize_prof  # noqa: E402
 
 def main(tag, prefix):
     traffic = {}
-    for w in ("cfg2", "target", "cfg3", "cfg4", "cfg5", "bb", "ldb", "siwt"):
+    for w in ("cfg2", "target", "target_haar", "cfg3", "cfg4", "cfg5", "bb", "ldb", "siwt"):
         src = os.path.join(ROOT, "gpurun_out", "prof_" + tag, w)
         if os.path.isdir(src):
             dst = os.path.join(ROOT, "profiles", "%s_%s" % (prefix, w))

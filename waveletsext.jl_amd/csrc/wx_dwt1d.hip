@@ -1195,6 +1195,10 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
         WX_HIP_CHECK(hipMemcpyAsync(y, x, sizeof(T) * n * batch, hipMemcpyDeviceToDevice, st));
         return WX_OK;
     }
+    if constexpr (sizeof(T) == 8) {
+        // Haar, full tree: Walsh-Hadamard formulation (wx_haar.hip)
+        if (!force_generic && !status && wx_haar_wpt_f64((const double *)x, (double *)y, n, L, batch, filt, st)) return WX_OK;
+    }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))
         return launch_fwd_fused<T, false>(x, y, n, L, batch, n, n, filt, status, nstatus, st);
     // Signals too long for the LDS of one CU (full tree): the first d0 levels run one level per launch; from
@@ -1245,6 +1249,12 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
         WX_HIP_CHECK(hipMemcpy2DAsync(xh, n * sizeof(T), xw, is * sizeof(T), n * sizeof(T), batch,
                                       hipMemcpyDeviceToDevice, st));
         return WX_OK;
+    }
+    if constexpr (sizeof(T) == 8) {
+        // Haar, full tree, dense leaves: inverse Walsh-Hadamard formulation (wx_haar.hip)
+        if (!force_generic && !status && !colmap && is == n &&
+            wx_haar_iwpt_f64((const double *)xw, (double *)xh, n, L, batch, filt, st))
+            return WX_OK;
     }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))
         return launch_inv_fused<T>(xw, xh, n, L, batch, is, n, filt, status, nstatus, colmap, log2blk, st);

@@ -83,3 +83,7 @@ int wx_dev_red2d_inv(const T *xw, T *x, int64_t m, int64_t n, int L, int layout,
 template <typename T>
 int wx_dev_jbb_costs2d(const T *sum, const T *sumsq, int64_t Ntot, int64_t m, int64_t n, int64_t k, int redundant,
                        int cost_kind, double p, T *costs, hipStream_t st);
+
+// Haar packets as Walsh-Hadamard transforms (wx_haar.hip); false = not applicable
+bool wx_haar_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+bool wx_haar_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
