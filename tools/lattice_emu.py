@@ -1,0 +1,237 @@
+"""Lane-and-register level emulation (numpy) of csrc/wx_lattice.hip: the same layouts, LDS slots and cross-lane moves
+as the kernel, one Python statement per kernel statement.  Used to debug the kernel's data movement on the CPU and
+as an executable specification of the layouts (python tools/lattice_emu.py compares with the oracle)."""
+import os, sys
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from tools.lattice_proto import lattice_factor
+
+LANES = np.arange(64)
+
+
+def rev6(v):
+    r = np.zeros_like(v)
+    for k in range(6):
+        r |= ((v >> k) & 1) << (5 - k)
+    return r
+
+
+def nbr(v, H, d):
+    """value held by lane (i + d) within groups of 2^H lanes (what lat_nbr<H, d> returns in lane i)"""
+    if H == 0:
+        return v.copy()
+    g = 1 << H
+    src = (LANES & ~(g - 1)) | ((LANES + d) & (g - 1))
+    return v[src]
+
+
+def shear_coefs(t):
+    """the rotation c [[1, t], [-t, 1]] as two in-place shears on (u, w = sigma v): u += p w; w -= kap u
+    (sigma_0 = 1, sigma_{j+1} = sigma_j / (1 + t_j^2)); returns (p, kap)"""
+    t = np.asarray(t, dtype=np.longdouble)
+    sig = np.longdouble(1)
+    p, kap = [], []
+    for tj in t:
+        p.append(tj / sig)
+        kap.append(sig * tj / (1 + tj * tj))
+        sig = sig / (1 + tj * tj)
+    return np.array(p, dtype=np.float64), np.array(kap, dtype=np.float64)
+
+
+def level(x, K, H, t, inv):
+    """x: (64 regs, 64 lanes); t = (p, kap)"""
+    NSEQ, M, S = 1 << K, 32 >> K, 1 << K
+    U = lambda s, m: s + ((2 * m) << K)
+    pc, kc = t
+    NS = len(pc)
+
+    def advance():
+        for s in range(NSEQ):
+            first = x[U(s, 0) + S].copy()
+            for m in range(M - 1):
+                x[U(s, m) + S] = x[U(s, m + 1) + S]
+            x[U(s, M - 1) + S] = nbr(first, H, +1)
+
+    def delay():
+        for s in range(NSEQ):
+            last = x[U(s, M - 1) + S].copy()
+            for m in range(M - 1, 0, -1):
+                x[U(s, m) + S] = x[U(s, m - 1) + S]
+            x[U(s, 0) + S] = nbr(last, H, -1)
+
+    if not inv:
+        for j in range(NS):
+            for s in range(NSEQ):
+                for m in range(M):
+                    x[U(s, m)] = x[U(s, m)] + pc[j] * x[U(s, m) + S]
+                    x[U(s, m) + S] = x[U(s, m) + S] - kc[j] * x[U(s, m)]
+            if j + 1 < NS:
+                advance()
+        for j in range(NS - 1):
+            delay()
+    else:
+        for j in range(NS - 1):
+            advance()
+        for j in range(NS - 1, -1, -1):
+            for s in range(NSEQ):
+                for m in range(M):
+                    x[U(s, m) + S] = x[U(s, m) + S] + kc[j] * x[U(s, m)]
+                    x[U(s, m)] = x[U(s, m)] - pc[j] * x[U(s, m) + S]
+            if j > 0:
+                delay()
+
+
+def lat_pi(L, r):
+    e = 0
+    for k in range(12 - L):
+        e |= ((r >> (L - 6 + k)) & 1) << k
+    for j in range(L - 6):
+        e |= ((r >> (L - 7 - j)) & 1) << (12 - L + j)
+    return e
+
+
+def lat_pi_inv(L, e):
+    for r in range(64):
+        if lat_pi(L, r) == e:
+            return r
+    raise ValueError
+
+
+def wpt_emu(xsig, t, gain1, L):
+    lane = LANES
+    lds = np.full(1104, np.nan)
+    # L0 loads
+    r = np.empty((16, 4, 64))
+    for blk in range(16):
+        for e in range(4):
+            r[blk, e] = xsig[256 * blk + 4 * lane + e]
+    a = np.empty((64, 64))
+    wa, ra = lane + (lane >> 4), 17 * lane
+    for e in range(4):
+        for blk in range(16):
+            lds[wa + 68 * blk] = r[blk, e]
+        for m in range(16):
+            a[4 * m + e] = lds[ra + m]
+    level(a, 0, 6, t, False)
+    level(a, 1, 6, t, False)
+    bb = np.empty((64, 64))
+    sw = lane ^ ((lane >> 5) << 1)
+    wa0, wa1 = sw, sw ^ 1
+    H, p10 = lane & 15, lane >> 4
+    lam0 = 4 * H
+    sg = (p10 & 1) | ((lam0 >> 5) << 1)
+    rah = [64 * p10 + ((lam0 + h) ^ sg) for h in range(4)]
+    for f in range(4):
+        for j in range(16):
+            lds[(wa1 if j & 1 else wa0) + 64 * j] = a[16 * f + j]
+        for h in range(4):
+            for g in range(4):
+                bb[16 * h + 4 * f + g] = lds[rah[h] + 256 * g]
+    for K in range(4):
+        level(bb, K, 4, t, False)
+    c = np.empty((64, 64))
+    wa = lane + (lane >> 5)
+    ra = 66 * (lane >> 2) + 16 * (lane & 1) + 33 * ((lane >> 1) & 1)
+    for f in range(4):
+        for j in range(16):
+            lds[wa + 66 * j] = bb[16 * f + j]
+        for Hh in range(16):
+            c[4 * Hh + f] = lds[ra + Hh]
+    for K in range(6):
+        if L > 6 + K:
+            level(c, K, 0, t, False)
+    # store
+    y = np.full(4096, np.nan)
+    ch = rev6(lane)
+    c0, c1, c2 = ch & 1, (ch >> 1) & 1, (ch >> 2) & 1
+    wrow = (c0 ^ c2) | ((ch >> 3) << 1) | (c1 << 4) | (c2 << 5)
+    wa = 17 * wrow
+    q = lane >> 3
+    q0, q1, q2 = q & 1, (q >> 1) & 1, q >> 2
+    ra = 17 * ((q0 ^ q2) + 16 * q1 + 32 * q2) + 2 * (lane & 7)
+    yo = 64 * q + 2 * (lane & 7)
+    pcl = np.array([bin(v).count("1") for v in lane])
+    base = gain1 ** L * (gain1 ** -2.0) ** pcl                       # per lane: g^(L - 2 popcount(lane))
+    mask = (1 << (L - 6)) - 1
+    for k in range(4):
+        for e4 in range(16):
+            rr = lat_pi_inv(L, 16 * k + e4)
+            lds[wa + e4] = c[rr] * (base * (gain1 ** -2.0) ** bin(rr & mask).count("1"))
+        for i in range(8):
+            y[512 * i + 16 * k + yo] = lds[ra + 34 * i]
+            y[512 * i + 16 * k + yo + 1] = lds[ra + 34 * i + 1]
+    return y
+
+
+def iwpt_emu(w, t, gain1, L):
+    lane = LANES
+    lds = np.full(1104, np.nan)
+    pcl = np.array([bin(v).count("1") for v in lane])
+    base = gain1 ** -L * (gain1 ** 2.0) ** pcl
+    mask = (1 << (L - 6)) - 1
+    ch = rev6(lane)
+    rrow = (((ch >> 1) ^ ch) & 1) | ((ch >> 2) << 1) | ((ch & 1) << 5)
+    ra = 17 * rrow
+    lanepart = (((lane >> 4) ^ (lane >> 3)) & 1) | (((lane >> 5) & 1) << 1) | (((lane >> 3) & 1) << 5)
+    wa = 17 * lanepart + 2 * (lane & 7)
+    xo = 64 * (lane >> 3) + 2 * (lane & 7)
+    c = np.empty((64, 64))
+    for k in range(4):
+        for i in range(8):
+            lds[wa + 68 * i] = w[512 * i + 16 * k + xo]
+            lds[wa + 68 * i + 1] = w[512 * i + 16 * k + xo + 1]
+        for e4 in range(16):
+            rr = lat_pi_inv(L, 16 * k + e4)
+            c[rr] = lds[ra + e4] * (base * (gain1 ** 2.0) ** bin(rr & mask).count("1"))
+    for K in range(5, -1, -1):
+        if L > 6 + K:
+            level(c, K, 0, t, True)
+    bb = np.empty((64, 64))
+    wa = 34 * (lane >> 1) + (lane & 1)
+    H, p0, p1 = lane & 15, (lane >> 4) & 1, lane >> 5
+    ra = 34 * p1 + 2 * H + p0
+    for f in range(4):
+        for Hh in range(16):
+            lds[wa + 2 * Hh] = c[4 * Hh + f]
+        for j in range(16):
+            bb[16 * f + j] = lds[ra + 68 * j]
+    for K in range(3, -1, -1):
+        level(bb, K, 4, t, True)
+    a = np.empty((64, 64))
+    H, p10 = lane & 15, lane >> 4
+    wah = [((h ^ (H >> 2)) | ((H & 3) << 2) | (((H >> 2) & 1) << 4) | ((H >> 3) << 5)) + 64 * p10 for h in range(4)]
+    Ha, ha = lane >> 2, lane & 3
+    ra = (ha ^ (Ha >> 2)) | ((Ha & 3) << 2) | (((Ha >> 2) & 1) << 4) | ((Ha >> 3) << 5)
+    for f in range(4):
+        for h in range(4):
+            for g in range(4):
+                lds[wah[h] + 256 * g] = bb[16 * h + 4 * f + g]
+        for j in range(16):
+            a[16 * f + j] = lds[ra + 64 * j]
+    level(a, 1, 6, t, True)
+    level(a, 0, 6, t, True)
+    wa, ra = 17 * lane, 2 * (lane & 15) + 17 * (lane >> 4)
+    y = np.full(4096, np.nan)
+    for e in range(4):
+        for m in range(16):
+            lds[wa + 2 * m] = a[4 * m + e]
+        for blk in range(16):
+            y[256 * blk + 4 * lane + e] = lds[ra + 68 * blk]
+    return y
+
+
+if __name__ == "__main__":
+    from oracle import wx_oracle as O
+    from waveletsext_jl_amd import filters as Fm
+    rng = np.random.default_rng(1)
+    for name in ("db2", "db4", "db8"):
+        q = np.asarray(Fm.wavelet(name).qmf, dtype=np.float64)
+        t, g1 = lattice_factor(q)
+        t = shear_coefs(t)
+        for L in (6, 7, 9, 10, 12):
+            x = rng.standard_normal(4096)
+            ref = O.wpt(x, q, L)
+            got = wpt_emu(x, t, g1, L)
+            back = iwpt_emu(ref, t, g1, L)
+            print(name, L, "fwd", np.abs(got - ref).max() / np.abs(ref).max(), "inv", np.abs(back - x).max() / np.abs(x).max())

@@ -1,0 +1,202 @@
+"""LDS exchange maps of csrc/wx_lattice.hip, checked against the gfx950 bank rules.
+
+The lattice kernels keep a 4096-sample Float64 signal in the registers of ONE wavefront (64 per lane) and change
+which six index bits are register-resident four times per transform (layouts L0 -> A -> B -> C -> S).  Every
+exchange moves 16 registers per lane per round through a 8.6 KiB LDS window with ds_write_b64 / ds_read_b64.
+Bank rules (MI355X_MICROARCH.md, LDS table): ds_write_b64 is serviced in 4 groups of 16 contiguous lanes over 32
+banks (element address mod 16 must differ inside a group), ds_read_b64 in 2 groups of 32 lanes over 64 banks (element
+address mod 32 must differ).  This script enumerates every instruction of every round of the eight exchanges and
+asserts: the element -> LDS slot map is injective inside a round, both sides are conflict-free, and the write map
+and the read map agree element by element.  `python tools/lattice_lds_maps.py` prints the window sizes.
+
+p = sample index (12 bits).  Layouts (reg index, lane):
+  L0: reg (blk = p[11:8], e = p[1:0]), lane p[7:2]                 -- 32 contiguous bytes per lane and block
+  A : reg p[5:0],  lane p[11:6]                                     -- wave-cyclic neighbours
+  B : reg p[7:2],  lane p[11:8] | p[1:0] << 4                       -- row-cyclic (16 lanes) neighbours
+  C : reg p[11:6], lane p[5:0]                                      -- whole dilated sequences in registers
+  S : store order: round k, instruction i, lane l: chunk c = 8i + (l >> 3), e = 16k + 2 (l & 7) + {0, 1};
+      in C a lane nu holds chunk c = bitreverse6(nu) and register r is element e = pi_L(r) of the chunk
+"""
+import itertools
+
+
+def rev6(v):
+    return int(f"{v:06b}"[::-1], 2)
+
+
+def check(name, writes, reads, size_limit=1104):
+    """writes / reads: list of instructions, each a list of 64 (element_id, slot) per lane"""
+    w = {}
+    for ins in writes:
+        assert len(ins) == 64
+        for g in range(4):
+            banks = [ins[l][1] % 16 for l in range(16 * g, 16 * g + 16)]
+            assert len(set(banks)) == 16, (name, "write conflict", g, banks)
+        for el, slot in ins:
+            assert el not in w, (name, "element written twice", el)
+            w[el] = slot
+    assert len(set(w.values())) == len(w), (name, "slots collide")
+    seen = set()
+    for ins in reads:
+        for g in range(2):
+            banks = [ins[l][1] % 32 for l in range(32 * g, 32 * g + 32)]
+            assert len(set(banks)) == 32, (name, "read conflict", g, sorted(banks))
+        for el, slot in ins:
+            assert w[el] == slot, (name, "read/write disagree", el)
+            seen.add(el)
+    assert seen == set(w), (name, "not every element read")
+    mx = max(w.values()) + 1
+    assert mx <= size_limit, (name, mx)
+    return mx
+
+
+def t1(e):       # L0 -> A, round e = p[1:0]
+    wr = [[(256 * blk + 4 * l + e, 68 * blk + l + (l >> 4)) for l in range(64)] for blk in range(16)]
+    rd = [[(64 * lam + 4 * m + e, 17 * lam + m) for lam in range(64)] for m in range(16)]
+    return wr, rd
+
+
+def t2(f):       # A -> B, round f = p[5:4]
+    wr = []
+    for j in range(16):                                  # A reg 16 f + j, j = p[3:0]
+        ins = []
+        for lam in range(64):                            # lam = p[11:6]
+            p = (lam << 6) | (f << 4) | j
+            slot = 64 * j + (lam ^ ((j & 1) | ((lam >> 5) << 1)))
+            ins.append((p, slot))
+        wr.append(ins)
+    rd = []
+    for h in range(4):
+        for g in range(4):                               # B reg 16 h + 4 f + g
+            ins = []
+            for mu in range(64):
+                H, p10 = mu & 15, mu >> 4
+                p = (H << 8) | (h << 6) | (f << 4) | (g << 2) | p10
+                lam = 4 * H + h
+                j = 4 * g + p10
+                slot = 64 * j + (lam ^ ((j & 1) | ((lam >> 5) << 1)))
+                ins.append((p, slot))
+            rd.append(ins)
+    return wr, rd
+
+
+def t3(f):       # B -> C, round f = p[7:6]
+    wr = []
+    for j in range(16):                                  # B reg 16 f + j, j = p[5:2]
+        ins = []
+        for mu in range(64):
+            H, p10 = mu & 15, mu >> 4
+            p = (H << 8) | (f << 6) | (j << 2) | p10
+            ins.append((p, 66 * j + mu + (mu >> 5)))
+        wr.append(ins)
+    rd = []
+    for H in range(16):                                  # C reg 4 H + f
+        ins = []
+        for nu in range(64):
+            p = (H << 8) | (f << 6) | nu
+            base = 66 * (nu >> 2) + 16 * (nu & 1) + 33 * ((nu >> 1) & 1)
+            ins.append((p, base + H))
+        rd.append(ins)
+    return wr, rd
+
+
+def w4(c):       # LDS row of chunk c in the C -> S exchange
+    c0, c1, c2 = c & 1, (c >> 1) & 1, (c >> 2) & 1
+    return (c0 ^ c2) | ((c >> 3) << 1) | (c1 << 4) | (c2 << 5)
+
+
+def t4(k):       # C -> S, round k = e[5:4]; element id = (c, e4)
+    wr = [[((rev6(nu), e4), 17 * w4(rev6(nu)) + e4) for nu in range(64)] for e4 in range(16)]
+    rd = []
+    for i in range(8):
+        for hf in range(2):
+            ins = []
+            for l in range(64):
+                c = 8 * i + (l >> 3)
+                c0, c1, c2 = c & 1, (c >> 1) & 1, (c >> 2) & 1
+                base = 17 * ((c0 ^ c2) + 16 * c1 + 32 * c2) + 2 * (l & 7)
+                ins.append(((c, 2 * (l & 7) + hf), base + 34 * i + hf))
+            rd.append(ins)
+    return wr, rd
+
+
+def w4i(c):      # LDS row of chunk c in the S -> C exchange
+    c0, c1 = c & 1, (c >> 1) & 1
+    return (c1 ^ c0) | ((c >> 2) << 1) | (c0 << 5)
+
+
+def t4i(k):      # S -> C
+    wr = []
+    for i in range(8):
+        for hf in range(2):
+            ins = []
+            for l in range(64):
+                c = 8 * i + (l >> 3)
+                lanepart = (((l >> 4) ^ (l >> 3)) & 1) | (((l >> 5) & 1) << 1) | (((l >> 3) & 1) << 5)
+                assert w4i(c) == lanepart + 4 * i
+                ins.append(((c, 2 * (l & 7) + hf), 17 * lanepart + 2 * (l & 7) + 68 * i + hf))
+            wr.append(ins)
+    rd = [[((rev6(nu), e4), 17 * w4i(rev6(nu)) + e4) for nu in range(64)] for e4 in range(16)]
+    return wr, rd
+
+
+def t3i(f):      # C -> B
+    wr = []
+    for H in range(16):
+        ins = []
+        for nu in range(64):
+            p = (H << 8) | (f << 6) | nu
+            ins.append((p, 34 * (nu >> 1) + (nu & 1) + 2 * H))
+        wr.append(ins)
+    rd = []
+    for j in range(16):
+        ins = []
+        for mu in range(64):
+            H, p0, p1 = mu & 15, (mu >> 4) & 1, mu >> 5
+            p = (H << 8) | (f << 6) | (j << 2) | (p1 << 1) | p0
+            ins.append((p, 34 * p1 + 2 * H + p0 + 68 * j))
+        rd.append(ins)
+    return wr, rd
+
+
+def rho(lam):    # slot of lane lam (A layout) inside a 64-slot row of the B -> A exchange
+    H, h = lam >> 2, lam & 3
+    return (h ^ (H >> 2)) | ((H & 3) << 2) | (((H >> 2) & 1) << 4) | ((H >> 3) << 5)
+
+
+def t2i(f):      # B -> A
+    wr = []
+    for h in range(4):
+        for g in range(4):
+            ins = []
+            for mu in range(64):
+                H, p10 = mu & 15, mu >> 4
+                p = (H << 8) | (h << 6) | (f << 4) | (g << 2) | p10
+                base_h = (h ^ (H >> 2)) | ((H & 3) << 2) | (((H >> 2) & 1) << 4) | ((H >> 3) << 5)
+                assert base_h == rho(4 * H + h)
+                ins.append((p, base_h + 64 * p10 + 256 * g))
+            wr.append(ins)
+    rd = []
+    for j in range(16):
+        ins = []
+        for lam in range(64):
+            p = (lam << 6) | (f << 4) | j
+            ins.append((p, rho(lam) + 64 * j))
+        rd.append(ins)
+    return wr, rd
+
+
+def t1i(e):      # A -> L0
+    wr = [[(64 * lam + 4 * m + e, 17 * lam + 2 * m) for lam in range(64)] for m in range(16)]
+    rd = [[(256 * blk + 4 * l + e, 2 * (l & 15) + 17 * (l >> 4) + 68 * blk) for l in range(64)] for blk in range(16)]
+    return wr, rd
+
+
+if __name__ == "__main__":
+    worst = 0
+    for name, fn in [("T1", t1), ("T2", t2), ("T3", t3), ("T4", t4), ("T4i", t4i), ("T3i", t3i), ("T2i", t2i),
+                     ("T1i", t1i)]:
+        sizes = {check(name, *fn(r)) for r in range(4)}
+        print(name, "window (elements):", sorted(sizes))
+        worst = max(worst, max(sizes))
+    print("LDS window per wavefront:", worst, "elements =", worst * 8, "bytes")

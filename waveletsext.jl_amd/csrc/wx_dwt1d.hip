@@ -1198,6 +1198,11 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
     if constexpr (sizeof(T) == 8) {
         // Haar, full tree: Walsh-Hadamard formulation (wx_haar.hip)
         if (!force_generic && !status && wx_haar_wpt_f64((const double *)x, (double *)y, n, L, batch, filt, st)) return WX_OK;
+        // longer filters, full tree: rotations in registers (wx_lattice.hip)
+        if (!force_generic && !status) {
+            const int r = wx_lattice_wpt_f64((const double *)x, (double *)y, n, L, batch, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
     }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))
         return launch_fwd_fused<T, false>(x, y, n, L, batch, n, n, filt, status, nstatus, st);
@@ -1255,6 +1260,10 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
         if (!force_generic && !status && !colmap && is == n &&
             wx_haar_iwpt_f64((const double *)xw, (double *)xh, n, L, batch, filt, st))
             return WX_OK;
+        if (!force_generic && !status && !colmap) {
+            const int r = wx_lattice_iwpt_f64((const double *)xw, (double *)xh, n, L, batch, is, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
     }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))
         return launch_inv_fused<T>(xw, xh, n, L, batch, is, n, filt, status, nstatus, colmap, log2blk, st);

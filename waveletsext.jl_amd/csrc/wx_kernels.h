@@ -87,3 +87,9 @@ int wx_dev_jbb_costs2d(const T *sum, const T *sumsq, int64_t Ntot, int64_t m, in
 // Haar packets as Walsh-Hadamard transforms (wx_haar.hip); false = not applicable
 bool wx_haar_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
 bool wx_haar_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+
+// full-tree Float64 packets as a lattice of plane rotations in the registers of one wavefront per signal
+// (wx_lattice.hip); 0 = not applicable, 1 = launched, < 0 = error
+int wx_lattice_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
+                        const WxFilt &filt, hipStream_t st);

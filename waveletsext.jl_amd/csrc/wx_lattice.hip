@@ -1,0 +1,674 @@
+// wx_lattice.hip -- full-tree 1-D wavelet packets (wpt / iwpt by level, Float64, n = 4096, L >= 6) as a lattice of
+// plane rotations held in the registers of ONE wavefront per signal.
+//
+// Reference semantics: dwt/dwt_one_level.jl:79-107 (analysis step) and :192-223 (synthesis step), driven level by
+// level by Wavelets.jl's wpt / iwpt (call sites dwt/dwt_all.jl:152-166, 210-225).
+//
+// Why: the direct form costs 2F multiply-adds per output pair; at F = 8, L = 10 that is 4.3e10 Float64 flops per
+// 65536 x 4096 batch = the whole FP64 budget of the 60 %-of-HBM target (0.89 ms).  The 2x2 polyphase matrix of an
+// orthonormal QMF is paraunitary:
+//     [a]   [ Qe(w)      Qo(w)   ] [v_even]      Qe(w) = sum q[2m] w^m, Qo(w) = sum q[2m+1] w^m, w = advance one pair
+//     [d] = [-Qo(1/w)    Qe(1/w) ] [v_odd ]
+// and factors into F/2 rotations c_j [[1, t_j], [-t_j, 1]] separated by "advance the odd channel by one pair"
+// (Vaidyanathan's lattice; factorisation on the host in long double, wx_lattice_factor): F multiply-adds per pair,
+// half the direct form, and the common gain (prod c_j)^L is applied once at the end.
+//
+// Layout: level l acts on index bit b = l - 1 of the natural sample index p with dilation 2^b and period n (the
+// a-children stay on the slots with bit b = 0, the d-children on bit b = 1), so the depth-L transform is L in-place
+// stencils followed by a bit reversal of the low L index bits (Wavelets.jl's packet order).  A wavefront holds the
+// 4096 samples as 64 registers per lane and changes which six index bits are register-resident four times:
+//     L0 (32 contiguous bytes per lane, as loaded)  ->  A: reg p[5:0]   levels 1-2,  halo = wave rotate (DPP)
+//                                                   ->  B: reg p[7:2]   levels 3-6,  halo = row rotate (DPP)
+//                                                   ->  C: reg p[11:6]  levels 7-12, whole sequences in registers
+//                                                   ->  S: full 128-byte lines per 8 lanes for the stores
+// Each exchange moves 16 registers per round through an 8.6 KiB LDS window with conflict-free ds_write_b64 /
+// ds_read_b64 (maps derived and checked in tools/lattice_lds_maps.py).  No workgroup barrier anywhere: one wavefront
+// = one workgroup, ordering is wave-level.  Per signal and lane: F/2 * 64 * L FMAs (2560 for db4, L = 10), ~110
+// DPP moves for the halos, 256 LDS writes + 256 LDS reads, one 32 KiB read and one 32 KiB write of HBM.
+//
+// Rounding: the rotations reassociate the reference's tap sums; measured difference from the oracle <= 3e-15
+// relative for every filter of the table at L = 12 (tools/lattice_proto.py), far inside the 1e-10 bar.
+#include "wx_common.h"
+#include "wx_kernels.h"
+#include <cmath>
+#include <cstdlib>
+#include <utility>
+
+#define WX_LAT_MAXS 10        // rotations per level = F / 2 (F <= 20)
+#define WX_LAT_LDS 1104       // elements of the LDS window (max over the eight exchanges: 1102)
+
+// Rotation j (c_j [[1, t_j], [-t_j, 1]]) is applied as two in-place shears on (u, w = sigma_j v):
+//     u += p_j w,  w -= kap_j u      p_j = t_j / sigma_j,  kap_j = sigma_j t_j c_j^2,  sigma_{j+1} = sigma_j c_j^2
+// (no temporary: the 128 data registers of a lane leave room for 3 wavefronts per SIMD).  After a level the a-slot
+// holds a / g and the d-slot d * g (g = prod c_j), so a leaf whose path took k detail branches carries g^(2k - L):
+// one multiply per element at the end (analysis) or at the start (synthesis).
+struct WxLat {
+    double p[WX_LAT_MAXS];
+    double kap[WX_LAT_MAXS];
+    double g0;                // analysis: g^L, synthesis: g^-L      (leaf with k = 0)
+    double g2;                // analysis: g^-2, synthesis: g^2      (per detail branch on the path)
+};
+
+namespace {
+
+__device__ __forceinline__ void lat_sync()
+{
+    // wave-level ordering of LDS traffic: the hardware executes a wavefront's DS operations in order; this only
+    // stops the compiler from moving a lane's loads above another lane's stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// keeps a wave-uniform pointer in scalar registers and opaque to address reassociation, so that the accesses below use
+// the "scalar base + 32-bit lane offset + immediate" form (one address VGPR instead of a 64-bit pair per access)
+typedef double lat_d2 __attribute__((ext_vector_type(2)));
+typedef double lat_d4 __attribute__((ext_vector_type(4)));
+typedef const double __attribute__((address_space(1))) *lat_gc;
+typedef double __attribute__((address_space(1))) *lat_gm;
+__device__ __forceinline__ lat_gc lat_sbase(const double *p)
+{
+    lat_gc g = (lat_gc)p;
+    asm("" : "+s"(g));
+    return g;
+}
+__device__ __forceinline__ lat_gm lat_sbase(double *p)
+{
+    lat_gm g = (lat_gm)p;
+    asm("" : "+s"(g));
+    return g;
+}
+
+// LDS traffic as explicit single ds_write_b64 / ds_read_b64 (byte address VGPR + 16-bit immediate).  The compiler would
+// pair them into ds_write2_b64 / ds_read2_b64: half the read rate (MI355X_MICROARCH.md, LDS table) and, worse, pairs of
+// destination registers that must be adjacent -- with the depth-dependent register order of the C layout that costs
+// hundreds of copies and spills.  volatile asm statements keep their program order, the hardware executes a
+// wavefront's DS operations in order, and lat_wait() is the only wait the reads need.
+template <int OFF> __device__ __forceinline__ void lds_wr(unsigned addr, double v)
+{
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ double lds_rd(unsigned addr)
+{
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// all outstanding DS reads have landed; the operands tie the values to the wait so that no use is scheduled above it
+__device__ __forceinline__ void lat_wait8(double &a, double &b, double &c, double &d, double &e, double &f, double &g, double &h)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "memory");
+}
+
+template <int CTRL> __device__ __forceinline__ double lat_dpp(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    // rotations: every lane has a source, so with bound_ctrl the old value is dead and no initialising move is emitted
+    const int plo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    const int phi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(phi, plo);
+}
+
+// value held by the lane that owns the next (DIR = +1) / previous (DIR = -1) chunk of the same dilated sequence;
+// H = number of cyclic lane bits (they are the low bits of the lane id): 6 wave, 4 row of 16, 0 = sequence in-lane
+template <int H, int DIR> __device__ __forceinline__ double lat_nbr(double v)
+{
+    if constexpr (H == 6) return lat_dpp<(DIR > 0 ? 0x134 : 0x13C)>(v);      // wave_rol:1 / wave_ror:1
+    else if constexpr (H == 4) return lat_dpp<(DIR > 0 ? 0x12F : 0x121)>(v); // row_ror:15 / row_ror:1
+    else return v;
+}
+
+// one packet level on register-index bit K (2^K interleaved sequences of 32 >> K pairs per lane)
+template <int K, int H, int NS, bool INV> __device__ __forceinline__ void lat_level(double (&x)[64], const WxLat &cf)
+{
+    constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
+    auto U = [](int s, int m) { return s + ((2 * m) << K); };
+    auto advance = [&]() {           // odd channel: pair m takes the value of pair m + 1
+#pragma unroll
+        for (int s = 0; s < NSEQ; ++s) {
+            const double first = x[U(s, 0) + S];
+#pragma unroll
+            for (int m = 0; m + 1 < M; ++m) x[U(s, m) + S] = x[U(s, m + 1) + S];
+            x[U(s, M - 1) + S] = lat_nbr<H, +1>(first);
+        }
+    };
+    auto delay = [&]() {             // pair m takes the value of pair m - 1
+#pragma unroll
+        for (int s = 0; s < NSEQ; ++s) {
+            const double last = x[U(s, M - 1) + S];
+#pragma unroll
+            for (int m = M - 1; m > 0; --m) x[U(s, m) + S] = x[U(s, m - 1) + S];
+            x[U(s, 0) + S] = lat_nbr<H, -1>(last);
+        }
+    };
+    if constexpr (!INV) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const double pj = cf.p[j], kj = cf.kap[j];
+#pragma unroll
+            for (int s = 0; s < NSEQ; ++s)
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    x[U(s, m)] = fma(pj, x[U(s, m) + S], x[U(s, m)]);
+                    x[U(s, m) + S] = fma(-kj, x[U(s, m)], x[U(s, m) + S]);
+                }
+            if (j + 1 < NS) advance();
+        }
+#pragma unroll
+        for (int j = 0; j + 1 < NS; ++j) delay();
+    } else {
+#pragma unroll
+        for (int j = 0; j + 1 < NS; ++j) advance();
+#pragma unroll
+        for (int j = NS - 1; j >= 0; --j) {
+            const double pj = cf.p[j], kj = cf.kap[j];
+#pragma unroll
+            for (int s = 0; s < NSEQ; ++s)
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    x[U(s, m) + S] = fma(kj, x[U(s, m)], x[U(s, m) + S]);
+                    x[U(s, m)] = fma(-pj, x[U(s, m) + S], x[U(s, m)]);
+                }
+            if (j > 0) delay();
+        }
+    }
+}
+
+__device__ __forceinline__ int lat_rev6(int v) { return (int)(__builtin_bitreverse32((unsigned)v) >> 26); }
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <int... I, typename F> __device__ __forceinline__ void lat_for_impl(std::integer_sequence<int, I...>, F &&f)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void lat_for(F &&f)
+{
+    lat_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+template <int B0, typename A> __device__ __forceinline__ void lat_wait16(A &x)
+{
+    // x[B0 .. B0+15] are the destinations of the 16 reads just issued
+    lat_wait8(x[B0], x[B0 + 1], x[B0 + 2], x[B0 + 3], x[B0 + 4], x[B0 + 5], x[B0 + 6], x[B0 + 7]);
+    lat_wait8(x[B0 + 8], x[B0 + 9], x[B0 + 10], x[B0 + 11], x[B0 + 12], x[B0 + 13], x[B0 + 14], x[B0 + 15]);
+}
+
+// element e of a lane's 64-sample output chunk held by C register r, depth L (6 <= L <= 12):
+// e[k] = r[L-6+k] for k < 12-L, e[12-L+j] = r[L-7-j] for j <= L-7
+constexpr int lat_pi(int L, int r)
+{
+    int e = 0;
+    for (int k = 0; k < 12 - L; ++k) e |= ((r >> (L - 6 + k)) & 1) << k;
+    for (int j = 0; j <= L - 7; ++j) e |= ((r >> (L - 7 - j)) & 1) << (12 - L + j);
+    return e;
+}
+constexpr int lat_pi_inv(int L, int e)
+{
+    for (int r = 0; r < 64; ++r)
+        if (lat_pi(L, r) == e) return r;
+    return -1;
+}
+
+// f[m] = g0 * g2^(popcount(lane) + m): the gain of a leaf whose path has popcount(lane) detail branches in the lane bits
+// (levels 1-6) and m in the register bits (levels 7-L)
+__device__ __forceinline__ void lat_gains(double (&f)[7], int lane, const WxLat &cf)
+{
+    double b = cf.g0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b = ((lane >> k) & 1) ? b * cf.g2 : b;
+    f[0] = b;
+#pragma unroll
+    for (int m = 1; m < 7; ++m) f[m] = f[m - 1] * cf.g2;
+}
+constexpr int lat_pc(int v)
+{
+    int c = 0;
+    for (; v; v >>= 1) c += v & 1;
+    return c;
+}
+
+// C -> S exchange + stores for a compile-time depth (exchange T4 of tools/lattice_lds_maps.py)
+template <int L> __device__ __forceinline__ void lat_store_c(double (&c)[64], unsigned lds0, double *__restrict__ ys,
+                                                             int lane, const WxLat &cf)
+{
+    double gf[7];
+    lat_gains(gf, lane, cf);
+    const int ch = lat_rev6(lane);
+    const int c0 = ch & 1, c1 = (ch >> 1) & 1, c2 = (ch >> 2) & 1;
+    const int wrow = (c0 ^ c2) | ((ch >> 3) << 1) | (c1 << 4) | (c2 << 5);
+    const unsigned wa = lds0 + 8u * 17u * wrow;
+    const int q = lane >> 3;                              // chunk within the instruction's group of 8
+    const int q0 = q & 1, q1 = (q >> 1) & 1, q2 = q >> 2;
+    const unsigned ra = lds0 + 8u * (17u * ((q0 ^ q2) + 16 * q1 + 32 * q2) + 2u * (lane & 7));
+    const unsigned yo = 64u * q + 2u * (lane & 7);       // lane part of the store address (elements)
+    lat_for<4>([&](auto K) {
+        constexpr int k = K;
+        lat_for<16>([&](auto E) {
+            constexpr int e4 = E;
+            constexpr int rr = lat_pi_inv(L, 16 * k + e4);
+            lds_wr<8 * e4>(wa, c[rr] * gf[lat_pc(rr & ((1 << (L - 6)) - 1))]);
+        });
+        lat_for<2>([&](auto HH) {
+            constexpr int hh = HH;
+            double v[8];
+            lat_for<4>([&](auto I) {
+                constexpr int i = 4 * hh + I;
+                v[2 * I] = lds_rd<8 * (34 * i)>(ra);
+                v[2 * I + 1] = lds_rd<8 * (34 * i + 1)>(ra);
+            });
+            lat_wait8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            lat_for<4>([&](auto I) {
+                constexpr int i = 4 * hh + I;
+                lat_d2 o;
+                o.x = v[2 * I];
+                o.y = v[2 * I + 1];
+                *(lat_d2 __attribute__((address_space(1))) *)(lat_sbase(ys + 512 * i + 16 * k) + yo) = o;
+            });
+        });
+    });
+}
+
+// loads + S -> C exchange (T4i)
+template <int L> __device__ __forceinline__ void lat_load_c(double (&c)[64], unsigned lds0, const double *__restrict__ xs,
+                                                            int lane, const WxLat &cf)
+{
+    double gf[7];
+    lat_gains(gf, lane, cf);
+    const int ch = lat_rev6(lane);
+    const int rrow = (((ch >> 1) ^ ch) & 1) | ((ch >> 2) << 1) | ((ch & 1) << 5);
+    const unsigned ra = lds0 + 8u * 17u * rrow;
+    const int lanepart = (((lane >> 4) ^ (lane >> 3)) & 1) | (((lane >> 5) & 1) << 1) | (((lane >> 3) & 1) << 5);
+    const unsigned wa = lds0 + 8u * (17u * lanepart + 2u * (lane & 7));
+    const unsigned xo = 64u * (lane >> 3) + 2u * (lane & 7);
+    lat_d2 v[8];
+    lat_for<8>([&](auto I) {
+        constexpr int i = I;
+        v[i] = *(const lat_d2 __attribute__((address_space(1))) *)(lat_sbase(xs + 512 * i) + xo);
+    });
+    lat_for<4>([&](auto K) {
+        constexpr int k = K;
+        lat_for<8>([&](auto I) {
+            constexpr int i = I;
+            lds_wr<8 * (68 * i)>(wa, v[i].x);
+            lds_wr<8 * (68 * i + 1)>(wa, v[i].y);
+        });
+        // the next round's loads go out as soon as their registers are free (the asm statements are memory barriers
+        // for the compiler, so this order is kept)
+        if constexpr (k < 3)
+            lat_for<8>([&](auto I) {
+                constexpr int i = I;
+                v[i] = *(const lat_d2 __attribute__((address_space(1))) *)(lat_sbase(xs + 512 * i + 16 * (k + 1)) + xo);
+            });
+        lat_for<16>([&](auto E) {
+            constexpr int e4 = E;
+            c[lat_pi_inv(L, 16 * k + e4)] = lds_rd<8 * e4>(ra);
+        });
+        lat_for<2>([&](auto G) {
+            constexpr int g = G;
+            lat_wait8(c[lat_pi_inv(L, 16 * k + 8 * g)], c[lat_pi_inv(L, 16 * k + 8 * g + 1)], c[lat_pi_inv(L, 16 * k + 8 * g + 2)],
+                      c[lat_pi_inv(L, 16 * k + 8 * g + 3)], c[lat_pi_inv(L, 16 * k + 8 * g + 4)], c[lat_pi_inv(L, 16 * k + 8 * g + 5)],
+                      c[lat_pi_inv(L, 16 * k + 8 * g + 6)], c[lat_pi_inv(L, 16 * k + 8 * g + 7)]);
+        });
+        lat_for<16>([&](auto E) {
+            constexpr int rr = lat_pi_inv(L, 16 * k + E);
+            c[rr] *= gf[lat_pc(rr & ((1 << (L - 6)) - 1))];
+        });
+    });
+}
+
+// ---------------------------------------------------------------- forward
+template <int NS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lat_wpt_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, int64_t batch, WxLat cf)
+{
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int64_t sig = blockIdx.x;
+    const double *xs = x + sig * 4096;
+    double a[64];
+    {
+        // L0: lane holds samples 256 blk + 4 lane + e;  T1: L0 -> A (reg p[5:0], lane p[11:6])
+        lat_d4 r[16];
+        lat_for<16>([&](auto B) {
+            constexpr int blk = B;
+            r[blk] = *(const lat_d4 __attribute__((address_space(1))) *)(lat_sbase(xs + 256 * blk) + 4u * lane);
+        });
+        const unsigned wa = lds0 + 8u * (lane + (lane >> 4)), ra = lds0 + 8u * 17u * lane;
+        lat_for<4>([&](auto E) {
+            constexpr int e = E;
+            lat_for<16>([&](auto B) {
+                constexpr int blk = B;
+                lds_wr<8 * 68 * blk>(wa, r[blk][e]);
+            });
+            double t[16];
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                t[m] = lds_rd<8 * m>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                a[4 * m + e] = t[m];
+            });
+        });
+    }
+    lat_level<0, 6, NS, false>(a, cf);
+    lat_level<1, 6, NS, false>(a, cf);
+    // T2: A -> B (reg p[7:2], lane mu = p[11:8] | p[1:0] << 4)
+    double bb[64];
+    {
+        const int sw = lane ^ ((lane >> 5) << 1);
+        const unsigned wa0 = lds0 + 8u * sw, wa1 = lds0 + 8u * (sw ^ 1);
+        const int H = lane & 15, p10 = lane >> 4;
+        const int lam0 = 4 * H, sg = (p10 & 1) | ((lam0 >> 5) << 1);
+        unsigned ra[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ra[h] = lds0 + 8u * (64 * p10 + ((lam0 + h) ^ sg));
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                lds_wr<8 * 64 * j>((j & 1) ? wa1 : wa0, a[16 * f + j]);
+            });
+            double t[16];
+            lat_for<16>([&](auto Q) {
+                constexpr int h = Q / 4, g = Q % 4;
+                t[Q] = lds_rd<8 * 256 * g>(ra[h]);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto Q) {
+                constexpr int h = Q / 4, g = Q % 4;
+                bb[16 * h + 4 * f + g] = t[Q];
+            });
+        });
+    }
+    lat_level<0, 4, NS, false>(bb, cf);
+    lat_level<1, 4, NS, false>(bb, cf);
+    lat_level<2, 4, NS, false>(bb, cf);
+    lat_level<3, 4, NS, false>(bb, cf);
+    // T3: B -> C (reg p[11:6], lane nu = p[5:0])
+    double c[64];
+    {
+        const unsigned wa = lds0 + 8u * (lane + (lane >> 5));
+        const unsigned ra = lds0 + 8u * (66 * (lane >> 2) + 16 * (lane & 1) + 33 * ((lane >> 1) & 1));
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                lds_wr<8 * 66 * j>(wa, bb[16 * f + j]);
+            });
+            double t[16];
+            lat_for<16>([&](auto Hq) {
+                constexpr int H = Hq;
+                t[H] = lds_rd<8 * H>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto Hq) {
+                constexpr int H = Hq;
+                c[4 * H + f] = t[H];
+            });
+        });
+    }
+    if (L > 6) lat_level<0, 0, NS, false>(c, cf);
+    if (L > 7) lat_level<1, 0, NS, false>(c, cf);
+    if (L > 8) lat_level<2, 0, NS, false>(c, cf);
+    if (L > 9) lat_level<3, 0, NS, false>(c, cf);
+    if (L > 10) lat_level<4, 0, NS, false>(c, cf);
+    if (L > 11) lat_level<5, 0, NS, false>(c, cf);
+    double *ys = y + sig * 4096;
+    switch (L) {
+    case 6: lat_store_c<6>(c, lds0, ys, lane, cf); break;
+    case 7: lat_store_c<7>(c, lds0, ys, lane, cf); break;
+    case 8: lat_store_c<8>(c, lds0, ys, lane, cf); break;
+    case 9: lat_store_c<9>(c, lds0, ys, lane, cf); break;
+    case 10: lat_store_c<10>(c, lds0, ys, lane, cf); break;
+    case 11: lat_store_c<11>(c, lds0, ys, lane, cf); break;
+    default: lat_store_c<12>(c, lds0, ys, lane, cf); break;
+    }
+}
+
+// ---------------------------------------------------------------- inverse
+template <int NS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lat_iwpt_f64(
+    const double *__restrict__ xw, double *__restrict__ y, int L, int64_t batch, int64_t in_stride, WxLat cf)
+{
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int64_t sig = blockIdx.x;
+    const double *xs = xw + sig * in_stride;
+    double c[64];
+    switch (L) {
+    case 6: lat_load_c<6>(c, lds0, xs, lane, cf); break;
+    case 7: lat_load_c<7>(c, lds0, xs, lane, cf); break;
+    case 8: lat_load_c<8>(c, lds0, xs, lane, cf); break;
+    case 9: lat_load_c<9>(c, lds0, xs, lane, cf); break;
+    case 10: lat_load_c<10>(c, lds0, xs, lane, cf); break;
+    case 11: lat_load_c<11>(c, lds0, xs, lane, cf); break;
+    default: lat_load_c<12>(c, lds0, xs, lane, cf); break;
+    }
+    if (L > 11) lat_level<5, 0, NS, true>(c, cf);
+    if (L > 10) lat_level<4, 0, NS, true>(c, cf);
+    if (L > 9) lat_level<3, 0, NS, true>(c, cf);
+    if (L > 8) lat_level<2, 0, NS, true>(c, cf);
+    if (L > 7) lat_level<1, 0, NS, true>(c, cf);
+    if (L > 6) lat_level<0, 0, NS, true>(c, cf);
+    // T3i: C -> B
+    double bb[64];
+    {
+        const unsigned wa = lds0 + 8u * (34 * (lane >> 1) + (lane & 1));
+        const int H = lane & 15, p0 = (lane >> 4) & 1, p1 = lane >> 5;
+        const unsigned ra = lds0 + 8u * (34 * p1 + 2 * H + p0);
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<16>([&](auto Hq) {
+                constexpr int Hh = Hq;
+                lds_wr<8 * 2 * Hh>(wa, c[4 * Hh + f]);
+            });
+            double t[16];
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                t[j] = lds_rd<8 * 68 * j>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                bb[16 * f + j] = t[j];
+            });
+        });
+    }
+    lat_level<3, 4, NS, true>(bb, cf);
+    lat_level<2, 4, NS, true>(bb, cf);
+    lat_level<1, 4, NS, true>(bb, cf);
+    lat_level<0, 4, NS, true>(bb, cf);
+    // T2i: B -> A
+    double a[64];
+    {
+        const int H = lane & 15, p10 = lane >> 4;
+        unsigned wa[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            wa[h] = lds0 + 8u * (((h ^ (H >> 2)) | ((H & 3) << 2) | (((H >> 2) & 1) << 4) | ((H >> 3) << 5)) + 64 * p10);
+        const int Ha = lane >> 2, ha = lane & 3;
+        const unsigned ra = lds0 + 8u * ((ha ^ (Ha >> 2)) | ((Ha & 3) << 2) | (((Ha >> 2) & 1) << 4) | ((Ha >> 3) << 5));
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<16>([&](auto Q) {
+                constexpr int h = Q / 4, g = Q % 4;
+                lds_wr<8 * 256 * g>(wa[h], bb[16 * h + 4 * f + g]);
+            });
+            double t[16];
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                t[j] = lds_rd<8 * 64 * j>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                a[16 * f + j] = t[j];
+            });
+        });
+    }
+    lat_level<1, 6, NS, true>(a, cf);
+    lat_level<0, 6, NS, true>(a, cf);
+    // T1i: A -> L0 and the stores (32 contiguous bytes per lane)
+    {
+        const unsigned wa = lds0 + 8u * 17u * lane, ra = lds0 + 8u * (2 * (lane & 15) + 17 * (lane >> 4));
+        lat_d4 r[16];
+        lat_for<4>([&](auto E) {
+            constexpr int e = E;
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                lds_wr<8 * 2 * m>(wa, a[4 * m + e]);
+            });
+            double t[16];
+            lat_for<16>([&](auto B) {
+                constexpr int blk = B;
+                t[blk] = lds_rd<8 * 68 * blk>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto B) {
+                constexpr int blk = B;
+                r[blk][e] = t[blk];
+            });
+        });
+        double *ys = y + sig * 4096;
+        lat_for<16>([&](auto B) {
+            constexpr int blk = B;
+            *(lat_d4 __attribute__((address_space(1))) *)(lat_sbase(ys + 256 * blk) + 4u * lane) = r[blk];
+        });
+    }
+}
+
+}  // namespace
+
+// Lattice factorisation of the polyphase matrix (long double): G(w) = [[Qe, Qo], [-w^J Qo(1/w), w^J Qe(1/w)]]
+// = R_J Lambda(w) R_{J-1} ... Lambda(w) R_0 with R_j = c_j [[1, t_j], [-t_j, 1]], Lambda = diag(1, w).
+// Returns false when a rotation is too close to a quarter turn (|t| huge) or the rebuilt filter misses q.
+static bool wx_lattice_factor(const WxFilt &filt, int L, bool inverse, WxLat *out)
+{
+    const int F = filt.F;
+    if (F < 2 || (F & 1) || F / 2 > WX_LAT_MAXS) return false;
+    const int J = F / 2 - 1;
+    long double G[WX_LAT_MAXS][2][2] = {};
+    for (int m = 0; m <= J; ++m) {
+        G[m][0][0] = filt.q[2 * m];
+        G[m][0][1] = filt.q[2 * m + 1];
+        G[J - m][1][0] = -(long double)filt.q[2 * m + 1];
+        G[J - m][1][1] = filt.q[2 * m];
+    }
+    long double t[WX_LAT_MAXS], cs[WX_LAT_MAXS];
+    for (int deg = J; deg >= 1; --deg) {
+        const int k = (fabsl(G[deg][0][0]) + fabsl(G[deg][1][0]) >= fabsl(G[deg][0][1]) + fabsl(G[deg][1][1])) ? 0 : 1;
+        const long double a0 = G[deg][0][k], a1 = G[deg][1][k], r = hypotl(a0, a1);
+        if (!(r > 0)) return false;
+        const long double c = a1 / r, s = a0 / r;
+        long double Hm[WX_LAT_MAXS][2][2];
+        for (int m = 0; m <= deg; ++m)
+            for (int col = 0; col < 2; ++col) {
+                Hm[m][0][col] = c * G[m][0][col] - s * G[m][1][col];
+                Hm[m][1][col] = s * G[m][0][col] + c * G[m][1][col];
+            }
+        for (int col = 0; col < 2; ++col)
+            if (fabsl(Hm[deg][0][col]) > 1e-13L || fabsl(Hm[0][1][col]) > 1e-13L) return false;   // not paraunitary
+        for (int m = 0; m < deg; ++m)
+            for (int col = 0; col < 2; ++col) {
+                G[m][0][col] = Hm[m][0][col];
+                G[m][1][col] = Hm[m + 1][1][col];
+            }
+        if (fabsl(c) < 1e-3L) return false;
+        t[deg] = s / c;
+        cs[deg] = c;
+    }
+    {
+        const long double c = G[0][0][0], s = G[0][0][1];
+        if (fabsl(G[0][1][0] + s) > 1e-13L || fabsl(G[0][1][1] - c) > 1e-13L || fabsl(c) < 1e-3L) return false;
+        t[0] = s / c;
+        cs[0] = c;
+    }
+    long double gain1 = 1;
+    double tr[WX_LAT_MAXS];
+    for (int j = 0; j <= J; ++j) {
+        tr[j] = (double)t[j];
+        gain1 *= cs[j];
+    }
+    // rebuild the filter from the rounded tangents: row 0 of the product must be (Qe, Qo)
+    long double P[WX_LAT_MAXS][2][2] = {};
+    P[0][0][0] = 1; P[0][0][1] = tr[0]; P[0][1][0] = -(long double)tr[0]; P[0][1][1] = 1;
+    for (int j = 1; j <= J; ++j) {
+        long double Q[WX_LAT_MAXS][2][2] = {};
+        const long double tj = tr[j];
+        for (int m = 0; m < j; ++m)
+            for (int col = 0; col < 2; ++col) {
+                // Lambda: row 1 advances (w^1), then the rotation
+                Q[m][0][col] += P[m][0][col];
+                Q[m + 1][0][col] += tj * P[m][1][col];
+                Q[m][1][col] += -tj * P[m][0][col];
+                Q[m + 1][1][col] += P[m][1][col];
+            }
+        for (int m = 0; m <= j; ++m)
+            for (int r2 = 0; r2 < 2; ++r2)
+                for (int col = 0; col < 2; ++col) P[m][r2][col] = Q[m][r2][col];
+    }
+    for (int m = 0; m <= J; ++m)
+        if (fabsl(gain1 * P[m][0][0] - filt.q[2 * m]) > 1e-14L || fabsl(gain1 * P[m][0][1] - filt.q[2 * m + 1]) > 1e-14L)
+            return false;
+    // shear form
+    long double sig = 1;
+    for (int j = 0; j < WX_LAT_MAXS; ++j) {
+        if (j <= J) {
+            const long double c2 = 1 / (1 + t[j] * t[j]);
+            out->p[j] = (double)(t[j] / sig);
+            out->kap[j] = (double)(sig * t[j] * c2);
+            sig *= c2;
+        } else {
+            out->p[j] = out->kap[j] = 0.0;
+        }
+    }
+    const long double gL = powl(gain1, L);
+    out->g0 = (double)(inverse ? 1 / gL : gL);
+    out->g2 = (double)(inverse ? gain1 * gain1 : 1 / (gain1 * gain1));
+    // the intermediate values range over g^(+-L): keep them far from the limits of Float64
+    return std::isfinite(out->g0) && fabsl(gL) > 1e-60L && fabsl(gL) < 1e60L;
+}
+
+// 0 = not applicable (the caller takes the general kernels), 1 = launched, < 0 = HIP error code of the C ABI
+static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
+                             const WxFilt &filt, hipStream_t st)
+{
+    static const bool off = getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0;
+    if (off || n != 4096 || L < 6 || L > 12 || filt.F < 4 || batch <= 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
+    if (inverse && (in_stride & 3)) return 0;
+    WxLat cf;
+    if (!wx_lattice_factor(filt, L, inverse, &cf)) return 0;
+    static const int wg_per_cu = getenv("WX_LATTICE_WG") ? atoi(getenv("WX_LATTICE_WG")) : 0;
+    int64_t grid = batch;
+    if (wg_per_cu > 0 && grid > (int64_t)256 * wg_per_cu) grid = (int64_t)256 * wg_per_cu;
+    if (grid > 0x7fffffff) grid = 0x7fffffff;
+#define WX_GO(NSS)                                                                                                  \
+    case NSS:                                                                                                       \
+        if (inverse)                                                                                                \
+            hipLaunchKernelGGL(k_lat_iwpt_f64<NSS>, dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, in_stride, cf); \
+        else                                                                                                        \
+            hipLaunchKernelGGL(k_lat_wpt_f64<NSS>, dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, cf);       \
+        break;
+    switch (filt.F / 2) {
+        WX_GO(2) WX_GO(3) WX_GO(4) WX_GO(5) WX_GO(6) WX_GO(8) WX_GO(9) WX_GO(10)
+    default: return 0;
+    }
+#undef WX_GO
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wx_set_hip_error(e, "lattice wpt launch", __FILE__, __LINE__);
+    return 1;
+}
+
+int wx_lattice_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
+{
+    return wx_lattice_launch(false, x, y, n, L, batch, n, filt, st);
+}
+int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt,
+                        hipStream_t st)
+{
+    return wx_lattice_launch(true, xw, y, n, L, batch, in_stride, filt, st);
+}
