@@ -50,7 +50,8 @@ const char *wx_last_error(void);            /* message of the last failing call 
 int wx_device_count(void);                  /* number of visible HIP devices (0 if none) */
 /* releases the library's only state, the cached stream-ordered scratch of the current device */
 int wx_shutdown(void);
-/* test hook: nonzero forces the one-level-per-launch kernels instead of the fused LDS kernels */
+/* test hook: 1 forces the one-level-per-launch kernels instead of the fused kernels; 2 keeps the fused LDS kernels
+ * but skips the register-resident ones (Haar Walsh-Hadamard, lattice) so that both families can be checked */
 void wx_set_force_generic(int on);
 
 /* ------------------------------------------------------------------------------------------

@@ -89,6 +89,23 @@ def test_treeselect_host_routine_matches_oracle(wx, oracle):
         wx.bestbasis_treeselection(rng.standard_normal(15), 8, "fail")          # test/bestbasis.jl:43
     with pytest.raises(AssertionError):
         wx.bestbasis_treeselection(rng.standard_normal(7), 3)                   # test/bestbasis.jl:44
+    for k in (5, 6, 2):                                                         # not 2^(L+1)-1: the children of depth
+        with pytest.raises(IndexError):                                         # L-1 would be read past the vector
+            wx.bestbasis_treeselection(rng.standard_normal(k), 16)
+    with pytest.raises(IndexError):
+        wx.bestbasis_treeselection(rng.standard_normal(7), 4, 4)                # quad tree: 5 costs of depth 1 needed
+
+
+def test_acwpd_jbb_moments_is_float64_only(wx):
+    """ACWT is Float64-only like the reference (acwt_one_level.jl:101-106): Float32 data must be refused, never
+    reinterpreted (there is no wx_acwpd_jbb_moments_f32)"""
+    wt = wx.wavelet(wx.WT.db4)
+    with pytest.raises(wx.WxError) as ei:
+        wx.acwpd_jbb_moments(np.zeros((16, 4), dtype=np.float32), wt, 2)
+    assert ei.value.code == -11
+    with pytest.raises(TypeError):
+        wx.acwpd_jbb_moments(np.zeros((16, 4)), wt, 2, accumulate_into=(np.zeros((16, 7), dtype=np.float32),
+                                                                         np.zeros((16, 7), dtype=np.float32)))
 
 
 def test_redundant_argument_errors(wx):

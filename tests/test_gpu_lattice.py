@@ -1,0 +1,125 @@
+"""GPU parity of the register-resident 1-D packet kernels (csrc/wx_lattice.hip, csrc/wx_haar.hip) against the CPU oracle
+at the geometries the bench times: n = 4096 Float64, full trees of depth 6..12.  Tolerance 1e-10 relative
+(BASELINE.json north_star); the lattice reassociates the reference's tap sums, observed difference <= 4e-15."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _wt(wx, name):
+    return wx.wavelet(getattr(wx.WT, name))
+
+
+@pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db5", "db6", "db8", "coif6", "db10"])
+def test_lattice_every_depth_matches_oracle(wx, oracle, wname):
+    """dwt/dwt_all.jl:152-166, 210-225 over Wavelets.jl's wpt / iwpt by level, every depth the lattice kernels take"""
+    rng = np.random.default_rng(4096)
+    wt = _wt(wx, wname)
+    n, B = 4096, 3
+    for L in range(6, 13):
+        x = np.asfortranarray(rng.standard_normal((n, B)))
+        exp = oracle.wptall(x, wt.qmf, L)
+        got = wx.wptall(x, wt, L)
+        assert relerr(got, exp) <= 1e-12, (wname, L)
+        back = wx.iwptall(exp, wt, L)
+        assert relerr(back, x) <= 1e-12, (wname, L)
+
+
+@pytest.mark.parametrize("mode", [0, 2, 1])
+def test_target_geometry_every_kernel_family(wx, oracle, mode):
+    """BASELINE row T: wptall / iwptall, n = 4096, db4, L = 10 -- through the lattice kernels (mode 0), the fused LDS
+    kernels (mode 2) and the one-level-per-launch kernels (mode 1)"""
+    rng = np.random.default_rng(1010)
+    wt = _wt(wx, "db4")
+    x = np.asfortranarray(rng.standard_normal((4096, 5)))
+    exp = oracle.wptall(x, wt.qmf, 10)
+    wx.set_force_generic(mode)
+    try:
+        assert relerr(wx.wptall(x, wt, 10), exp) <= 1e-10
+        assert relerr(wx.iwptall(exp, wt, 10), x) <= 1e-10
+    finally:
+        wx.set_force_generic(0)
+
+
+@pytest.mark.parametrize("fwd_mode", ["0", "1"])
+def test_target_geometry_fused_forward_modes(fwd_mode):
+    """the two variants of the fused LDS forward kernel (WX_FWD_MODE is read once per process) at the target geometry"""
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import waveletsext_jl_amd as wx, wx_oracle as O\n"
+        "wt = wx.wavelet(wx.WT.db4); rng = np.random.default_rng(3)\n"
+        "x = np.asfortranarray(rng.standard_normal((4096, 5)))\n"
+        "exp = O.wptall(x, wt.qmf, 10)\n"
+        "wx.set_force_generic(2)\n"
+        "e1 = np.abs(wx.wptall(x, wt, 10) - exp).max() / np.abs(exp).max()\n"
+        "e2 = np.abs(wx.iwptall(exp, wt, 10) - x).max() / np.abs(x).max()\n"
+        "assert e1 <= 1e-10 and e2 <= 1e-10, (e1, e2)\n" % (ROOT, os.path.join(ROOT, "oracle")))
+    env = dict(os.environ, WX_FWD_MODE=fwd_mode)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_config2_inverse_reads_the_packet_table(wx, oracle):
+    """BASELINE config 2, second leg: iwpdall of the full tree = the lattice inverse reading column L of the
+    (n, L+1, B) table in place (DWT.jl:340-401, dwt/dwt_all.jl:323-342)"""
+    rng = np.random.default_rng(2)
+    wt = _wt(wx, "db8")
+    n, L, B = 4096, 12, 3
+    x = np.asfortranarray(rng.standard_normal((n, B)))
+    tab = oracle.wpdall(x, wt.qmf, L)
+    assert relerr(wx.wpdall(x, wt, L), tab) <= 1e-10
+    assert relerr(wx.iwpdall(tab, wt, L), x) <= 1e-10
+    assert relerr(wx.iwpdall(tab, wt), x) <= 1e-10
+    for Lp in (6, 9):                                     # shallower full trees of the same table
+        exp = oracle.iwpdall(tab, wt.qmf, Lp)
+        assert relerr(wx.iwpdall(tab, wt, Lp), exp) <= 1e-10
+
+
+def test_lattice_batches_larger_than_one_wave_of_workgroups(wx, oracle):
+    """one workgroup per signal: more signals than resident workgroups, and an odd count"""
+    import torch
+    rng = np.random.default_rng(8)
+    wt = _wt(wx, "db4")
+    n, B, L = 4096, 3 * 256 * 12 + 5, 10
+    x = wx.to_device(np.asfortranarray(rng.standard_normal((n, B))))
+    y = wx.wptall(x, wt, L)
+    xr = wx.iwptall(y, wt, L)
+    assert float((xr - x).abs().max()) <= 1e-11
+    idx = [0, 1, 255, 256, 3071, 3072, B - 2, B - 1]
+    xs = np.asfortranarray(x[:, idx].cpu().numpy())
+    assert relerr(y[:, idx].cpu().numpy(), oracle.wptall(xs, wt.qmf, L)) <= 1e-12
+    # energy: orthonormal transform
+    assert abs(float((y * y).sum() / (x * x).sum()) - 1.0) <= 1e-12
+    del x, y, xr
+    torch.cuda.empty_cache()
+
+
+def test_haar_register_path_batches_larger_than_the_grid(wx, oracle):
+    """the Walsh-Hadamard kernels are persistent (grid <= 5 workgroups per CU): every signal of a longer batch against
+    the oracle, odd and even depths (the gain of a pair of levels is the exact 1/2)"""
+    rng = np.random.default_rng(11)
+    wt = _wt(wx, "haar")
+    for n, L, B in ((1024, 10, 256 * 8 * 2 + 3), (4096, 9, 256 * 5 + 7)):
+        x = np.asfortranarray(rng.standard_normal((n, B)))
+        exp = oracle.wptall(x, wt.qmf, L)
+        assert relerr(wx.wptall(x, wt, L), exp) <= 1e-13
+        assert relerr(wx.iwptall(exp, wt, L), x) <= 1e-13
+
+
+def test_filter_without_a_lattice_falls_back(wx, oracle):
+    """a QMF that is not orthonormal has no rotation lattice: the call must take the general kernels and still match
+    the direct-form oracle"""
+    rng = np.random.default_rng(5)
+    q = np.array([0.5, 0.9, 0.3, -0.1, 0.05, 0.02, 0.0, 0.01])
+    wt = wx.OrthoFilter(q)
+    x = np.asfortranarray(rng.standard_normal((4096, 2)))
+    assert relerr(wx.wptall(x, wt, 8), oracle.wptall(x, q, 8)) <= 1e-10

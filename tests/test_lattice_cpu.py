@@ -1,0 +1,47 @@
+"""CPU checks of the lattice formulation used by csrc/wx_lattice.hip: the rotation factorisation against the oracle,
+the LDS exchange maps against the bank rules, and the lane-level emulation of the kernel's data movement."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def test_lds_exchange_maps_are_conflict_free_bijections():
+    from tools import lattice_lds_maps as M
+    for name, fn in (("T1", M.t1), ("T2", M.t2), ("T3", M.t3), ("T4", M.t4), ("T4i", M.t4i), ("T3i", M.t3i),
+                     ("T2i", M.t2i), ("T1i", M.t1i)):
+        for r in range(4):
+            assert M.check(name, *fn(r)) <= 1104
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db8", "coif6", "db10"])
+def test_rotation_lattice_equals_the_direct_form(wx, oracle, wname):
+    from tools.lattice_proto import wpt_lattice, iwpt_lattice
+    q = np.asarray(wx.wavelet(getattr(wx.WT, wname)).qmf, dtype=np.float64)
+    rng = np.random.default_rng(3)
+    for n, L in ((64, 6), (256, 5), (1024, 10)):
+        x = rng.standard_normal(n)
+        ref = oracle.wpt(x, q, L)
+        assert np.abs(wpt_lattice(x, q, L) - ref).max() <= 1e-13 * np.abs(ref).max()
+        assert np.abs(iwpt_lattice(ref, q, L) - x).max() <= 1e-13 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("wname,L", [("db2", 6), ("db4", 10), ("db8", 12), ("db4", 7)])
+def test_kernel_emulation_matches_oracle(wx, oracle, wname, L):
+    """tools/lattice_emu.py follows the kernel statement by statement (layouts, LDS slots, cross-lane rotations, shear
+    form of the rotations, path-dependent gain)"""
+    from tools.lattice_emu import wpt_emu, iwpt_emu, shear_coefs
+    from tools.lattice_proto import lattice_factor
+    q = np.asarray(wx.wavelet(getattr(wx.WT, wname)).qmf, dtype=np.float64)
+    t, g1 = lattice_factor(q)
+    sh = shear_coefs(t)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(4096)
+    ref = oracle.wpt(x, q, L)
+    assert np.abs(wpt_emu(x, sh, g1, L) - ref).max() <= 1e-13 * np.abs(ref).max()
+    assert np.abs(iwpt_emu(ref, sh, g1, L) - x).max() <= 1e-13 * np.abs(x).max()

@@ -165,4 +165,4 @@ def shutdown():
 
 
 def set_force_generic(on):
-    lib().wx_set_force_generic(1 if on else 0)
+    lib().wx_set_force_generic(2 if on == 2 else (1 if on else 0))

@@ -217,6 +217,14 @@ def acwpd_jbb_moments(x, wt, L=None, accumulate_into=None):
     else:
         s, q = Arg(accumulate_into[0]), Arg(accumulate_into[1])
         acc = 1
+        for a in (s, q):
+            if a.shape != (n, ncols) or a.kind != x.kind:
+                raise TypeError("accumulate_into must be two (n, 2^(L+1)-1) arrays of the same kind as x")
+    # ACWT is Float64-only like the reference (acwt_one_level.jl:101-106): the suffix of every array selects the entry
+    # point, so Float32 data raises WX_EUNSUPPORTED instead of being reinterpreted
+    for a in (s, q):
+        if a.suffix != x.suffix:
+            raise TypeError("accumulate_into element type differs from x's")
     qq, qp, F = qmf_arg(wt)
-    _call("wx_acwpd_jbb_moments", "_f64", x.ptr, s.ptr, q.ptr, n, L, N, qp, F, acc, x.stream())
+    _call("wx_acwpd_jbb_moments", x.suffix, x.ptr, s.ptr, q.ptr, n, L, N, qp, F, acc, x.stream())
     return s.arr, q.arr

@@ -7,7 +7,8 @@
 
 const char *wx_err_cstr();
 static std::atomic<int> g_force_generic{0};
-int wx_force_generic() { return g_force_generic.load(); }
+int wx_force_generic() { return g_force_generic.load() == 1; }
+int wx_skip_register_kernels() { return g_force_generic.load() == 2; }
 
 extern "C" {
 
@@ -19,7 +20,7 @@ int wx_device_count(void)
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
-void wx_set_force_generic(int on) { g_force_generic.store(on ? 1 : 0); }
+void wx_set_force_generic(int on) { g_force_generic.store(on == 2 ? 2 : (on ? 1 : 0)); }
 
 }  // extern "C"
 

@@ -256,6 +256,9 @@ static int api_treeselect(T *costs, int64_t k, int64_t n, int type_max, uint8_t 
     WX_REQUIRE(k <= tl, WX_EASSERT, "@assert k <= gettreelength(2*n) (BestBasis.jl:63)");
     const int L = wx_getdepth_binary(k);
     WX_REQUIRE(wx_isdyadic(n) && L <= wx_maxtransformlevels(n), WX_EASSERT, "maketree(n, L, :full)");
+    // the loop below reads the children of every node of depth < L: costs[2^(L+1)-2] (the reference would throw a
+    // BoundsError for a shorter vector)
+    WX_REQUIRE(L == 0 || k >= ((int64_t)1 << (L + 1)) - 1, WX_EBOUNDS, "costs do not cover the children of depth L-1");
     const int64_t ntree = n - 1;
     memset(tree, 0, (size_t)ntree);
     for (int64_t i = 1; i <= ((int64_t)1 << L) - 1; ++i) tree[i - 1] = 1;

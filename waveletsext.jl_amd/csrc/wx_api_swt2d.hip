@@ -168,6 +168,8 @@ static int api_treeselect2d(T *costs, int64_t k, int64_t m, int64_t n, int type_
     WX_REQUIRE(k <= wx_gettreelength2d(2 * m, 2 * n), WX_EASSERT, "@assert k <= gettreelength(2*n,2*m) (BestBasis.jl:90)");
     const int L = wx_getdepth_quad(k);
     WX_REQUIRE(L <= wx_maxtransformlevels(m < n ? m : n), WX_EASSERT, "maketree(n, m, L, :full)");
+    WX_REQUIRE(L == 0 || k >= ((((int64_t)1 << (2 * (L + 1))) - 1) / 3), WX_EBOUNDS,
+               "costs do not cover the children of depth L-1");
     const int64_t ntree = wx_gettreelength2d(m, n);
     memset(tree, 0, (size_t)ntree);
     int64_t nfull = 0, pw = 1;

@@ -1195,11 +1195,15 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
         WX_HIP_CHECK(hipMemcpyAsync(y, x, sizeof(T) * n * batch, hipMemcpyDeviceToDevice, st));
         return WX_OK;
     }
+    const bool noreg = wx_skip_register_kernels();      // test hook: fused LDS kernels only
     if constexpr (sizeof(T) == 8) {
         // Haar, full tree: Walsh-Hadamard formulation (wx_haar.hip)
-        if (!force_generic && !status && wx_haar_wpt_f64((const double *)x, (double *)y, n, L, batch, filt, st)) return WX_OK;
+        if (!force_generic && !noreg && !status) {
+            const int r = wx_haar_wpt_f64((const double *)x, (double *)y, n, L, batch, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
         // longer filters, full tree: rotations in registers (wx_lattice.hip)
-        if (!force_generic && !status) {
+        if (!force_generic && !noreg && !status) {
             const int r = wx_lattice_wpt_f64((const double *)x, (double *)y, n, L, batch, filt, st);
             if (r) return r < 0 ? r : WX_OK;
         }
@@ -1255,12 +1259,14 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
                                       hipMemcpyDeviceToDevice, st));
         return WX_OK;
     }
+    const bool noreg = wx_skip_register_kernels();
     if constexpr (sizeof(T) == 8) {
         // Haar, full tree, dense leaves: inverse Walsh-Hadamard formulation (wx_haar.hip)
-        if (!force_generic && !status && !colmap && is == n &&
-            wx_haar_iwpt_f64((const double *)xw, (double *)xh, n, L, batch, filt, st))
-            return WX_OK;
-        if (!force_generic && !status && !colmap) {
+        if (!force_generic && !noreg && !status && !colmap && is == n) {
+            const int r = wx_haar_iwpt_f64((const double *)xw, (double *)xh, n, L, batch, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
+        if (!force_generic && !noreg && !status && !colmap) {
             const int r = wx_lattice_iwpt_f64((const double *)xw, (double *)xh, n, L, batch, is, filt, st);
             if (r) return r < 0 ? r : WX_OK;
         }

@@ -960,7 +960,7 @@ int wx_dev_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, c
                 }
                 nact[(size_t)d] = (int)(lst.size() / 2);
                 if (!lst.empty()) {
-                    dact[(size_t)d] = (const int *)wx_const_upload(lst.data(), lst.size() * sizeof(int));
+                    dact[(size_t)d] = (const int *)wx_const_upload(lst.data(), lst.size() * sizeof(int), st, true);
                     if (!dact[(size_t)d]) return WX_EHIP;
                 }
             }

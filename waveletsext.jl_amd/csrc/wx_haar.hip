@@ -12,6 +12,7 @@
 // HBM peak on this transform; this is the route to the 60 % north star for the Haar filter.
 #include "wx_common.h"
 #include "wx_kernels.h"
+#include <cmath>
 #include <cstdlib>
 
 namespace {
@@ -209,17 +210,25 @@ __global__ __launch_bounds__(NT) void k_haar_iwpt_f64(const double *__restrict__
 
 }  // namespace
 
-// true when the transform ran here; false = not applicable (the caller takes the general kernels)
-static bool wx_haar_launch(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt,
-                           hipStream_t st)
+// 1 = the transform was launched here, 0 = not applicable (the caller takes the general kernels; decided before
+// anything is queued), < 0 = HIP failure reported through wx_set_hip_error
+static int wx_haar_launch(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt,
+                          hipStream_t st)
 {
     static const bool off = getenv("WX_HAAR_WHT") && atoi(getenv("WX_HAAR_WHT")) == 0;
-    if (off || filt.F != 2 || filt.q[0] != filt.q[1]) return false;
-    if ((n & (n - 1)) || n < 1024 || n > 8192 || L < 1 || L > 10) return false;
+    if (off || filt.F != 2 || filt.q[0] != filt.q[1]) return 0;
+    if ((n & (n - 1)) || n < 1024 || n > 8192 || L < 1 || L > 10) return 0;
     int log2n = 0;
     while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
-    double scale = 1.0;
-    for (int l = 0; l < L; ++l) scale *= filt.q[0];
+    // the butterflies add unscaled values and the gain q0^L is applied once (the reference rounds q0 (a +- b) at every
+    // level: results differ from it by a few ulp, inside the 1e-10 bar).  q0^2 is exactly 1/2 for the Haar
+    // filter up to its own rounding, so pairs of levels contribute an exact power of two.
+    double scale = (L & 1) ? filt.q[0] : 1.0;
+    {
+        const double q2 = filt.q[0] * filt.q[0];
+        const double half = (fabs(q2 - 0.5) < 1e-15) ? 0.5 : q2;
+        for (int l = 0; l < L / 2; ++l) scale *= half;
+    }
     const size_t lds = (size_t)n * sizeof(double);
     const int nt = (int)(n / 16);
     int per_cu = (int)((160 * 1024) / lds);
@@ -229,9 +238,11 @@ static bool wx_haar_launch(bool inverse, const double *x, double *y, int64_t n, 
 #define WX_GO(NTT)                                                                                              \
     {                                                                                                           \
         auto kern = inverse ? k_haar_iwpt_f64<NTT> : k_haar_wpt_f64<NTT>;                                       \
-        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                        \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-            return false;                                                                                       \
+        if (lds > 64 * 1024) {                                                                                  \
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                     \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+            if (ea != hipSuccess) return wx_set_hip_error(ea, "hipFuncSetAttribute", __FILE__, __LINE__);       \
+        }                                                                                                       \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTT), lds, st, x, y, log2n, L, batch, scale);        \
     }
     switch (nt) {
@@ -239,17 +250,19 @@ static bool wx_haar_launch(bool inverse, const double *x, double *y, int64_t n, 
     case 128: WX_GO(128) break;
     case 256: WX_GO(256) break;
     case 512: WX_GO(512) break;
-    default: return false;
+    default: return 0;
     }
 #undef WX_GO
-    return hipGetLastError() == hipSuccess;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wx_set_hip_error(e, "haar wpt launch", __FILE__, __LINE__);
+    return 1;
 }
 
-bool wx_haar_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
+int wx_haar_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
 {
     return wx_haar_launch(false, x, y, n, L, batch, filt, st);
 }
-bool wx_haar_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
+int wx_haar_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
 {
     return wx_haar_launch(true, xw, y, n, L, batch, filt, st);
 }

@@ -27,7 +27,8 @@ void wx_leaf_colmap1d(const uint8_t *tree, int64_t ntree, int Leff, std::vector<
 
 // Small immutable tables (composite taps, ...) live in a per-device cache keyed by their content: uploaded
 // once with a blocking copy, reused by every later call, released by wx_shutdown().  nullptr on failure.
-const void *wx_const_upload(const void *host, size_t bytes);
+const void *wx_const_upload(const void *host, size_t bytes);                                  // waits on the host
+const void *wx_const_upload(const void *host, size_t bytes, hipStream_t st, bool have_stream);  // ordered on st
 
 // Stream-ordered device scratch that frees itself on the same stream.
 struct WxScratch {

@@ -153,38 +153,107 @@ static void wx_retain_pool()
 }
 
 // ---- per-device cache of small constant tables -------------------------------------------------
+// Keyed on (device, 64-bit hash, size) and verified against a pinned host copy of the content, which is also the
+// source of the asynchronous upload: no std::string copy per call, no NULL-stream hipMemcpy (that would serialise
+// against every blocking stream of the host program).  An entry carries the event of its upload; a later user on
+// another stream waits for that event on the device, a caller without a stream waits for it on the host.  Bounded at
+// 1024 entries: a flush retires the whole generation, tagged with its device, and frees the generation retired by the
+// previous flush under that device (so a table handed out during a running API call outlives it by a full generation).
 #include <map>
-#include <string>
+#include <tuple>
 namespace {
+struct WxConstEnt {
+    void *dev;
+    void *pin;
+    size_t bytes;
+    hipEvent_t ev;
+    bool ready;
+    int device;
+};
 std::mutex g_const_mu;
-std::map<std::pair<int, std::string>, void *> g_const;
-std::vector<void *> g_const_old;                                    // previous generation, freed at the next flush
+std::multimap<std::tuple<int, uint64_t, size_t>, WxConstEnt> g_const;
+std::vector<WxConstEnt> g_const_old;                                // previous generation, freed at the next flush
+uint64_t wx_fnv1a(const void *p, size_t n)
+{
+    const unsigned char *c = static_cast<const unsigned char *>(p);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
 }
-const void *wx_const_upload(const void *host, size_t bytes)
+void wx_const_release(WxConstEnt &e)
+{
+    if (e.ev && hipEventDestroy(e.ev) != hipSuccess) (void)hipGetLastError();
+    if (e.dev && hipFree(e.dev) != hipSuccess) (void)hipGetLastError();
+    if (e.pin && hipHostFree(e.pin) != hipSuccess) (void)hipGetLastError();
+    e.ev = nullptr; e.dev = e.pin = nullptr;
+}
+void wx_const_free_retired(int only_dev)
+{
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::vector<WxConstEnt> keep;
+    for (auto &e : g_const_old) {
+        if (only_dev >= 0 && e.device != only_dev) { keep.push_back(e); continue; }
+        if (hipSetDevice(e.device) != hipSuccess) { (void)hipGetLastError(); keep.push_back(e); continue; }
+        if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+        wx_const_release(e);
+    }
+    g_const_old.swap(keep);
+    if (hipSetDevice(cur) != hipSuccess) (void)hipGetLastError();
+}
+}
+const void *wx_const_upload(const void *host, size_t bytes, hipStream_t st, bool have_stream)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    std::pair<int, std::string> key(dev, std::string(reinterpret_cast<const char *>(host), bytes));
+    const auto key = std::make_tuple(dev, wx_fnv1a(host, bytes), bytes);
     std::lock_guard<std::mutex> lk(g_const_mu);
-    auto it = g_const.find(key);
-    if (it != g_const.end()) return it->second;
+    auto range = g_const.equal_range(key);
+    for (auto it = range.first; it != range.second; ++it) {
+        WxConstEnt &e = it->second;
+        if (bytes && memcmp(e.pin, host, bytes) != 0) continue;       // hash collision
+        if (!e.ready) {
+            hipError_t q = hipEventQuery(e.ev);
+            if (q == hipSuccess) e.ready = true;
+            else {
+                (void)hipGetLastError();
+                q = have_stream ? hipStreamWaitEvent(st, e.ev, 0) : hipEventSynchronize(e.ev);
+                if (q != hipSuccess) { wx_set_hip_error(q, "wait for a constant table", __FILE__, __LINE__); return nullptr; }
+                if (!have_stream) e.ready = true;
+            }
+        }
+        return e.dev;
+    }
     if (g_const.size() >= 1024) {
-        // bounded: start over.  Pointers handed out during the current API call must stay valid, so the
-        // retired generation is only freed at the following flush (no call uploads 1024 tables).
-        if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
-        for (void *q : g_const_old) if (hipFree(q) != hipSuccess) (void)hipGetLastError();
-        g_const_old.clear();
-        for (auto &e : g_const) g_const_old.push_back(e.second);
+        wx_const_free_retired(-1);
+        for (auto &kv : g_const) g_const_old.push_back(kv.second);
         g_const.clear();
     }
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-    if (e != hipSuccess) { wx_set_hip_error(e, "hipMalloc(constant table)", __FILE__, __LINE__); return nullptr; }
-    e = hipMemcpy(p, host, bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { wx_set_hip_error(e, "hipMemcpy(constant table)", __FILE__, __LINE__); (void)hipFree(p); return nullptr; }
-    g_const.emplace(std::move(key), p);
-    return p;
+    WxConstEnt e = {nullptr, nullptr, bytes, nullptr, false, dev};
+    hipError_t rc = hipMalloc(&e.dev, bytes ? bytes : 16);
+    if (rc == hipSuccess) rc = hipHostMalloc(&e.pin, bytes ? bytes : 16, hipHostMallocDefault);
+    if (rc == hipSuccess) rc = hipEventCreateWithFlags(&e.ev, hipEventDisableTiming);
+    if (rc == hipSuccess) {
+        if (bytes) memcpy(e.pin, host, bytes);
+        static thread_local hipStream_t own[64] = {nullptr};          // uploads of callers that pass no stream
+        hipStream_t up = st;
+        if (!have_stream) {
+            if (dev < 64 && !own[dev]) rc = hipStreamCreateWithFlags(&own[dev], hipStreamNonBlocking);
+            up = dev < 64 ? own[dev] : nullptr;
+        }
+        if (rc == hipSuccess && bytes) rc = hipMemcpyAsync(e.dev, e.pin, bytes, hipMemcpyHostToDevice, up);
+        if (rc == hipSuccess) rc = hipEventRecord(e.ev, up);
+        if (rc == hipSuccess && !have_stream) { rc = hipEventSynchronize(e.ev); e.ready = true; }
+    }
+    if (rc != hipSuccess) {
+        wx_set_hip_error(rc, "upload of a constant table", __FILE__, __LINE__);
+        wx_const_release(e);
+        return nullptr;
+    }
+    g_const.emplace(key, e);
+    return e.dev;
 }
+const void *wx_const_upload(const void *host, size_t bytes) { return wx_const_upload(host, bytes, nullptr, false); }
 
 // hand the cached scratch and constant tables of the current device back to the driver (the only state
 // the library owns)
@@ -197,14 +266,10 @@ extern "C" int wx_shutdown(void)
     {
         std::lock_guard<std::mutex> lk(g_const_mu);
         for (auto it = g_const.begin(); it != g_const.end();) {
-            if (it->first.first == dev) { if (hipFree(it->second) != hipSuccess) (void)hipGetLastError(); it = g_const.erase(it); }
+            if (std::get<0>(it->first) == dev) { wx_const_release(it->second); it = g_const.erase(it); }
             else ++it;
         }
-        int ndev = 0;
-        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev == 1) {   // retired tables carry no device tag
-            for (void *q : g_const_old) if (hipFree(q) != hipSuccess) (void)hipGetLastError();
-            g_const_old.clear();
-        }
+        wx_const_free_retired(dev);
     }
     hipMemPool_t pool;
     WX_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, dev));
@@ -226,7 +291,7 @@ void *WxScratch::upload(const void *host, size_t bytes)
 {
     // trees and column maps are small and repeat from call to call: the content-keyed cache makes the
     // upload a lookup (no allocation, no stream synchronisation)
-    if (bytes > 0 && bytes <= 64 * 1024) return const_cast<void *>(wx_const_upload(host, bytes));
+    if (bytes > 0 && bytes <= 64 * 1024) return const_cast<void *>(wx_const_upload(host, bytes, st, true));
     void *p = alloc(bytes);
     if (!p) return nullptr;
     hipError_t e = hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, st);

@@ -4,6 +4,7 @@
 #include "wx_common.h"
 
 template <typename T> bool wx_fused1d_ok(int64_t n, int F);
+int wx_skip_register_kernels();   // test hook (wx_set_force_generic(2)): skip the Haar / lattice register kernels
 
 // ---- 1-D decimated (wx_dwt1d.hip) ----
 template <typename T>
@@ -84,9 +85,9 @@ template <typename T>
 int wx_dev_jbb_costs2d(const T *sum, const T *sumsq, int64_t Ntot, int64_t m, int64_t n, int64_t k, int redundant,
                        int cost_kind, double p, T *costs, hipStream_t st);
 
-// Haar packets as Walsh-Hadamard transforms (wx_haar.hip); false = not applicable
-bool wx_haar_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
-bool wx_haar_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+// Haar packets as Walsh-Hadamard transforms (wx_haar.hip); 0 = not applicable, 1 = launched, < 0 = error
+int wx_haar_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+int wx_haar_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
 
 // full-tree Float64 packets as a lattice of plane rotations in the registers of one wavefront per signal
 // (wx_lattice.hip); 0 = not applicable, 1 = launched, < 0 = error

@@ -730,8 +730,8 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
                 shift[t] = (int)o;
             }
         }
-        dcoef = (double *)wx_const_upload(coef.data(), coef.size() * sizeof(double));
-        dshift = (int *)wx_const_upload(shift.data(), shift.size() * sizeof(int));
+        dcoef = (double *)wx_const_upload(coef.data(), coef.size() * sizeof(double), st, true);
+        dshift = (int *)wx_const_upload(shift.data(), shift.size() * sizeof(int), st, true);
         if (!dcoef || !dshift) return WX_EHIP;
         if (Rrc) {
             const int64_t tile = (n >> d) * Rrc;
@@ -889,7 +889,7 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
                 for (int c = 0; c < NCk; ++c)
                     for (int t = 0; t < U; ++t)
                         pad[(size_t)c * UP + (OPT - 1) + t] = coef[(size_t)c * U + (U - 1 - t)] * (K == 2 ? 0.25 : 0.125);
-                dcoef[slot] = (double *)wx_const_upload(pad.data(), pad.size() * sizeof(double));
+                dcoef[slot] = (double *)wx_const_upload(pad.data(), pad.size() * sizeof(double), st, true);
                 if (!dcoef[slot]) return WX_EHIP;
                 Utab[slot] = U;
                 omin[slot] = -offs[U - 1];                   // smallest offset of the adjoint taps
