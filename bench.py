@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the batched wavelet-packet hot path on MI355X.
 
-Metric (BASELINE.json): Msamples/s for forward + inverse wavelet packets, with the dominant
-kernel's achieved HBM bandwidth against the 8 TB/s roofline, next to the CPU path.
+Metric (BASELINE.json): Msamples/s for forward + inverse wavelet packets, with the dominant kernel's achieved HBM
+bandwidth against the 8 TB/s roofline, next to the CPU path timed on this host.
 
-A step = one forward pass + one inverse pass over one batch of synthetic signals that are already
-resident in HBM.  Default workload = BASELINE config 2 (`wpdall` 65536 x 4096 Float64, db8, full
-packet tree L=12, then `iwpdall`).  Other workloads (`--workload`): `target` (north-star target
-wptall/iwptall db4 L=10), `cfg3` (swptall/iswptall 16384-sample signals, haar, L=12, one resident
-chunk of the 8192-signal batch per step), `cfg4` (2-D wptall/iwptall 512x512 Float32 db4 L=6, the
-per-GPU shard of 512 images), `cfg5` (acwpd + JBB moments/costs/tree, coif6, L=11, a 2048-signal
-slice of the per-GPU shard).  N > 1: one process per GPU (torchrun), each rank owns a fixed-size
-shard of the batch (weak scaling); the transforms need no data-path collective.
+A step = one forward pass + one inverse pass over the whole batch of the configuration, synthetic signals already
+resident in HBM.  Default workload = BASELINE config 2 (`wpdall` 65536 x 4096 Float64, db8, full packet tree L = 12, then
+`iwpdall`).  Other workloads (`--workload`): `target` (north-star target: wptall / iwptall db4 L = 10), `cfg3` (swptall /
+iswptall 8192 signals of 16384 samples, haar, L = 12: the 4 TiB of leaves exist 64 signals at a time, a step loops over
+all chunks of the rank's shard), `cfg4` (2-D wptall / iwptall 4096 images 512 x 512 Float32 db4 L = 6), `cfg5` (acwpd + JBB
+moments / costs / tree, 262144 signals of 2048 samples, coif6, L = 11: moments accumulate over chunks of 2048 signals, one
+all-reduce of the moments when N > 1, costs and tree on every rank), plus the widened rows `bb`, `ldb`, `siwt`.
+
+N > 1: one process per GPU (torchrun).  `--scaling strong` (default): the configuration's batch is split contiguously
+over the ranks (distributed.shard_range) -- "the sharded batch" of the north star; `--scaling weak`: every rank gets the
+whole configuration batch.  The transforms need no data-path collective; `value` is the sharded compute.  The one
+exchange the path has for these workloads -- the all-gather of the reconstructed output -- is timed as a second loop
+with the exchange INSIDE the step (the inverse runs in >= 4 chunks, each chunk's all-gather on a side stream overlaps the
+next chunk's inverse) and reported next to it (`with_allgather`); for cfg5 the all-reduce of the moments is part of the
+algorithm and always inside the step.
 
 Prints ONE JSON line (rank 0).
 """
@@ -30,33 +37,33 @@ FP64_PEAK_TFLOPS = 78.6        # FP64 vector spec; tools/ubench.hip 
 
 WORKLOADS = {
     "cfg2": dict(kind="wpd", n=4096, batch=65536, wavelet="db8", L=12, dtype="f64",
-                 kernel="k_fwd1d_fused<double, 16, 512, true, 2>",
+                 kernel="k_fwd1d_fused<double, 16, 512, true, 2>", inv_kernel="k_lat_iwpt_f64<8>",
                  fwd_kernels=[("k_fwd1d_fused<double, 16, 512, true, 2>", 1)],
                  desc="BASELINE config 2: wpdall+iwpdall 65536x4096 f64 db8 full tree L=12"),
     "target": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=10, dtype="f64",
-                   kernel="k_fwd1d_inplace<double, 8, 256, false>",
-                   fwd_kernels=[("k_fwd1d_inplace<double, 8, 256, false>", 1)],
+                   kernel="k_lat_wpt_f64<4>", inv_kernel="k_lat_iwpt_f64<4>",
+                   fwd_kernels=[("k_lat_wpt_f64<4>", 1)],
                    desc="north-star target: wptall+iwptall 65536x4096 f64 db4 L=10"),
     "target_haar": dict(kind="wpt", n=4096, batch=65536, wavelet="haar", L=10, dtype="f64",
                         kernel="k_haar_wpt_f64<256>",
                         fwd_kernels=[("k_haar_wpt_f64<256>", 1)],
                         desc="north-star target with the Haar filter: wptall+iwptall 65536x4096 f64 haar L=10 "
                              "(Walsh-Hadamard kernels, wx_haar.hip)"),
-    "cfg3": dict(kind="swpt", n=16384, batch=64, wavelet="haar", L=12, dtype="f64",
+    "cfg3": dict(kind="swpt", n=16384, batch=8192, chunk=64, wavelet="haar", L=12, dtype="f64",
                  kernel="k_swt_fwd_multi_rc<double, 8, 8>",
                  fwd_kernels=[("k_swt_fwd_multi<double, 8>", 2), ("k_swt_fwd_multi_rc<double, 8, 8>", 2)],
-                 desc="BASELINE config 3: swptall+iswptall (average-based) 16384-sample f64 haar L=12; one resident "
-                      "chunk of 64 signals (32 GiB of leaves) of the 8192-signal batch per step"),
-    "cfg4": dict(kind="wpt2d", m=512, n=512, batch=512, wavelet="db4", L=6, dtype="f32",
+                 desc="BASELINE config 3: swptall+iswptall (average-based) 8192x16384 f64 haar L=12; the leaves exist one "
+                      "resident chunk of 64 signals (32 GiB) at a time, a step loops over every chunk of the shard"),
+    "cfg4": dict(kind="wpt2d", m=512, n=512, batch=4096, wavelet="db4", L=6, dtype="f32",
                  kernel="k_rows_fused<float, 8, false, 4, 2>",
                  fwd_kernels=[("k_fwd1d_inplace<float, 8, 64, false>", 1), ("k_rows_fused<float, 8, false, 4, 2>", 1)],
-                 desc="BASELINE config 4: 2-D wptall+iwptall 512x512 f32 db4 L=6, 512 images per GPU (4096 / 8)"),
-    "cfg5": dict(kind="acwpd_jbb", n=2048, batch=2048, wavelet="coif6", L=11, dtype="f64",
+                 desc="BASELINE config 4: 2-D wptall+iwptall 4096 images 512x512 f32 db4 L=6"),
+    "cfg5": dict(kind="acwpd_jbb", n=2048, batch=262144, chunk=2048, wavelet="coif6", L=11, dtype="f64",
                  kernel="k_acwpd_subtree_moments<5, 4, 9>",
                  fwd_kernels=[("k_swt_fwd_level<double, true>", 6), ("k_jbb_moments<double>", 1),
                               ("k_acwpd_subtree_moments<5, 4, 9>", 1), ("k_jbb_costs<double>", 1)],
-                 desc="BASELINE config 5: acwpd + JBB moments/costs/tree 2048-sample f64 coif6 L=11; 2048-signal slice "
-                      "of the 32768-signal per-GPU shard per step (no inverse: output is the tree)"),
+                 desc="BASELINE config 5: acwpd + JBB moments/costs/tree 262144x2048 f64 coif6 L=11; moments accumulate over "
+                      "chunks of 2048 signals, all-reduce of the moments when N > 1 (no inverse: the output is the tree)"),
     "bb": dict(kind="wpd_bb", n=4096, batch=16384, wavelet="db8", L=12, dtype="f64",
                kernel="k_bb_costs1d<double>",
                fwd_kernels=[("k_bb_norms<double>", 1), ("k_bb_costs1d<double>", 1), ("k_bb_treeselect<double, 2>", 1)],
@@ -83,11 +90,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (debug)")
+    ap.add_argument("--batch", type=int, default=0, help="override the configuration's total batch (debug / validation)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the configuration's batch split over the ranks, weak = the whole batch per rank")
+    ap.add_argument("--chunks", type=int, default=4, help="pieces of the overlapped all-gather of the reconstructed output")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the second loop with the all-gather in the step")
+    ap.add_argument("--dump", default="", help="validation: rank 0 saves the (gathered) reconstructed output as .npy")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--gather", action="store_true",
-                    help="also time an RCCL all-gather of the reconstructed output (reported, not in value)")
+    ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the all-gather loop is on by default)")
     return ap.parse_args()
 
 
@@ -223,62 +234,225 @@ def cpu_baseline(w, seconds):
 
 
 # ------------------------------------------------------------------------------------------------
-# GPU workloads: each returns (fwd, inv, check, info)
+# GPU workloads
 # ------------------------------------------------------------------------------------------------
-def make_workload(w, wx, torch, dev, rank):
+class Legs:
+    """HIP events on the launch stream (torch's current stream == the stream passed to the C ABI) around every
+    forward / inverse launch of the timed steps"""
+
+    def __init__(self, torch):
+        self.torch, self.ev = torch, {"fwd": [], "inv": []}
+
+    def run(self, leg, fn):
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.ev[leg].append((e0, e1))
+
+    def ms(self, leg):
+        return sorted(a.elapsed_time(b) for a, b in self.ev[leg])
+
+
+class Workload:
+    gatherable = False
+
+    def step(self, legs):
+        raise NotImplementedError
+
+    def step_gather(self, legs):
+        raise NotImplementedError
+
+    def output(self, gathered):
+        return None
+
+
+def make_workload(w, wx, torch, dev, rank, world, a, dist):
     D = sys.modules["waveletsext_jl_amd.dwt"]        # the submodule (the package attribute `dwt` is the function)
     from waveletsext_jl_amd._arrays import qmf_arg
-    kind, L, B = w["kind"], w["L"], w["batch"]
+    from waveletsext_jl_amd import distributed as wd
+    kind, L, Bt = w["kind"], w["L"], w["batch"]
     wt = wx.wavelet(getattr(wx.WT, w["wavelet"]))
     F = len(wt.qmf)
     td = torch.float64 if w["dtype"] == "f64" else torch.float32
     es = 8 if w["dtype"] == "f64" else 4
-    gen = torch.Generator(device=dev).manual_seed(1002 + rank)
     A = D.Arg
-    if kind in ("wpd", "wpt"):
-        n = w["n"]
-        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
-        xh = wx.jl_empty((n, B), td, dev)
+    strong = world > 1 and a.scaling == "strong"
+    lo, hi = wd.shard_range(Bt, world, rank) if strong else (0, Bt)
+    Bl = hi - lo
+    B_all = Bt if (strong or world == 1) else world * Bt          # signals the whole job processes per step
+    want_gather = world > 1 and not a.no_gather
+
+    def signals(sig):
+        """this rank's signals: strong scaling slices one batch generated from one seed (so that N ranks compute what
+        one rank computes), weak scaling draws an own batch per rank"""
+        gen = torch.Generator(device=dev).manual_seed(1002 if (strong or world == 1) else 1002 + rank)
+        if strong:
+            full = wx.jl_empty(tuple(sig) + (Bt,), td, dev)
+            full.normal_(generator=gen)
+            x = wx.jl_empty(tuple(sig) + (Bl,), td, dev)
+            x.copy_(full[..., lo:hi])
+            del full
+            torch.cuda.empty_cache()
+            return x
+        x = wx.jl_empty(tuple(sig) + (Bl,), td, dev)
+        x.normal_(generator=gen)
+        return x
+
+    W = Workload()
+    W.lo, W.hi, W.B_all = lo, hi, B_all
+
+    if kind in ("wpd", "wpt", "wpt2d"):
+        sig = (w["n"],) if kind != "wpt2d" else (w["m"], w["n"])
+        npts = 1
+        for v in sig:
+            npts *= v
+        x = signals(sig)
+        B_out = (Bt if strong else world * Bt) if want_gather else Bl
+        out_lo = (lo if strong else rank * Bt) if want_gather else 0
+        full = wx.jl_empty(sig + (B_out,), td, dev)              # reconstructed output of every rank (or just ours)
+        xh = full[..., out_lo: out_lo + Bl]
         if kind == "wpd":
-            y = wx.jl_empty((n, L + 1, B), td, dev)
+            y = wx.jl_empty(sig + (L + 1, Bl), td, dev)
             fwd = lambda: D._wpd_batched(A(x), A(y), 1, wt, L)
-            inv = lambda: D._iwpd_batched(A(y), A(xh), 1, wt, L, None)
-            fb = es * n * B * (L + 2)                # x read once + (L+1) columns written once
+            inv_to = lambda c0, c1, dst: D._iwpd_batched(A(y[..., c0:c1]), A(dst), 1, wt, L, None)
+            fb = es * npts * Bl * (L + 2)                # x read once + (L+1) columns written once
+            flops = 2.0 * F * npts * L * Bl
         else:
-            y = wx.jl_empty((n, B), td, dev)
-            fwd = lambda: D._wpt_batched("wx_wpt", A(x), A(y), 1, wt, L, None)
-            inv = lambda: D._wpt_batched("wx_iwpt", A(y), A(xh), 1, wt, L, None)
-            fb = es * n * B * 2
-        check = lambda: float((xh - x).abs().max() / x.abs().max())
-        return fwd, inv, check, dict(fwd_bytes=fb, inv_bytes=es * n * B * 2, fwd_flops=2.0 * F * n * L * B,
-                                     samples=n * B, bound="hbm", keep=(x, y, xh))
+            y = wx.jl_empty(sig + (Bl,), td, dev)
+            nd = len(sig)
+            fwd = lambda: D._wpt_batched("wx_wpt", A(x), A(y), nd, wt, L, None)
+            inv_to = lambda c0, c1, dst: D._wpt_batched("wx_iwpt", A(y[..., c0:c1]), A(dst), nd, wt, L, None)
+            fb = es * npts * Bl * 2
+            flops = (2.0 * F * npts * L * Bl) if nd == 1 else L * 2.0 * (2 * F * npts) * Bl
+        W.gatherable = want_gather
+        g = None
+        if want_gather:
+            # strong: the shards of one batch; weak: every rank's own batch, concatenated
+            g = wd.OverlappedAllGather(full, B_out, nchunks=a.chunks)
+            assert (g.lo, g.hi) == (out_lo, out_lo + Bl), "shards of the gather and of the bench disagree"
+            nposts = max(len(wd.chunk_ranges(n_r, a.chunks)) for n_r in wd.shard_sizes(B_out, world))
+
+        def step(legs):
+            legs.run("fwd", fwd)
+            legs.run("inv", lambda: inv_to(0, Bl, xh))
+
+        def step_gather(legs):
+            legs.run("fwd", fwd)
+            for c in range(nposts):
+                if c < len(g.chunks):
+                    c0, c1 = g.chunks[c]
+                    legs.run("inv", lambda: inv_to(c0, c1, g.local_chunk(c)))
+                g.post(c)
+            g.finish()
+
+        W.step, W.step_gather = step, step_gather
+        W.check = lambda: float((xh - x).abs().max() / x.abs().max())
+        W.output = lambda gathered: full if gathered else xh
+        W.info = dict(fwd_bytes=fb, inv_bytes=es * npts * Bl * 2, fwd_flops=flops, samples=npts * Bl, bound="hbm",
+                      gather_bytes=es * npts * (B_out - Bl))
+        W.keep = (x, y, full)
+        return W
+
     if kind == "swpt":
-        n = w["n"]
-        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
-        xw = wx.jl_empty((n, 1 << L, B), td, dev)
-        xh = wx.jl_empty((n, B), td, dev)
+        n, CH = w["n"], min(w["chunk"], max(Bl, 1))
+        x = signals((n,))
+        B_out = (Bt if strong else world * Bt) if want_gather else Bl
+        out_lo = (lo if strong else rank * Bt) if want_gather else 0
+        full = wx.jl_empty((n, B_out), td, dev)
+        xh = full[:, out_lo: out_lo + Bl]
+        xw = wx.jl_empty((n, 1 << L, CH), td, dev)
         q, qp, Fq = qmf_arg(wt)
-        fwd = lambda: D._call("wx_swpt1d", "_f64", A(x).ptr, A(xw).ptr, n, L, B, qp, Fq, A(x).stream())
-        inv = lambda: D._call("wx_iswpt1d", "_f64", A(xw).ptr, A(xh).ptr, n, L, -1, B, qp, Fq, A(x).stream())
-        fb = es * n * B * (1 + (1 << L))
-        check = lambda: float((xh - x).abs().max() / x.abs().max())
-        return fwd, inv, check, dict(fwd_bytes=fb, inv_bytes=fb, fwd_flops=((1 << L) - 1) * 4.0 * F * n * B,
-                                     samples=n * B, bound="hbm", keep=(x, xw, xh, q))
-    if kind == "wpt2d":
-        m, n = w["m"], w["n"]
-        x = wx.jl_empty((m, n, B), td, dev); x.normal_(generator=gen)
-        y = wx.jl_empty((m, n, B), td, dev)
-        xh = wx.jl_empty((m, n, B), td, dev)
-        fwd = lambda: D._wpt_batched("wx_wpt", A(x), A(y), 2, wt, L, None)
-        inv = lambda: D._wpt_batched("wx_iwpt", A(y), A(xh), 2, wt, L, None)
-        fb = es * m * n * B * 2
-        check = lambda: float((xh - x).abs().max() / x.abs().max())
-        return fwd, inv, check, dict(fwd_bytes=fb, inv_bytes=fb, fwd_flops=L * 2.0 * (2 * F * m * n) * B,
-                                     samples=m * n * B, bound="hbm", keep=(x, y, xh))
+        chunks = [(c0, min(c0 + CH, Bl)) for c0 in range(0, Bl, CH)]
+
+        def fwd(c0, c1):
+            D._call("wx_swpt1d", "_f64", A(x[:, c0:c1]).ptr, A(xw).ptr, n, L, c1 - c0, qp, Fq, A(x).stream())
+
+        def inv(c0, c1, dst):
+            D._call("wx_iswpt1d", "_f64", A(xw).ptr, A(dst).ptr, n, L, -1, c1 - c0, qp, Fq, A(x).stream())
+
+        W.gatherable = want_gather
+        if want_gather:
+            g = wd.OverlappedAllGather(full, B_out, nchunks=a.chunks)
+            nposts = max(len(wd.chunk_ranges(n_r, a.chunks)) for n_r in wd.shard_sizes(B_out, world))
+
+        def step(legs):
+            for c0, c1 in chunks:
+                legs.run("fwd", lambda: fwd(c0, c1))
+                legs.run("inv", lambda: inv(c0, c1, xh[:, c0:c1]))
+
+        def step_gather(legs):
+            # the gather's pieces are groups of whole resident chunks
+            for c in range(nposts):
+                if c < len(g.chunks):
+                    g0, g1 = g.chunks[c]
+                    for c0 in range(g0, g1, CH):
+                        c1 = min(c0 + CH, g1)
+                        legs.run("fwd", lambda: fwd(c0, c1))
+                        legs.run("inv", lambda: inv(c0, c1, xh[:, c0:c1]))
+                g.post(c)
+            g.finish()
+
+        W.step, W.step_gather = step, step_gather
+        W.check = lambda: float((xh - x).abs().max() / x.abs().max())
+        W.output = lambda gathered: full if gathered else xh
+        fb = es * n * CH * (1 + (1 << L))
+        W.info = dict(fwd_bytes=fb, inv_bytes=fb, fwd_flops=((1 << L) - 1) * 4.0 * F * n * CH, samples=n * Bl, bound="hbm",
+                      launch_unit="one resident chunk of %d signals" % CH, gather_bytes=es * n * (B_out - Bl))
+        W.keep = (x, xw, full, q)
+        return W
+
+    if kind == "acwpd_jbb":
+        n, CH = w["n"], min(w["chunk"], max(Bl, 1))
+        x = signals((n,))
+        ncols = (1 << (L + 1)) - 1
+        chunks = [(c0, min(c0 + CH, Bl)) for c0 in range(0, Bl, CH)]
+        state = {}
+        N_total = B_all
+        method = wx.JBB(redundant=True)
+        backend_nccl = world > 1 and dist.get_backend() == "nccl"
+
+        def moments():
+            s = q = None
+            for c0, c1 in chunks:
+                if s is None:
+                    s, q = wx.acwpd_jbb_moments(x[:, c0:c1], wt, L)
+                else:
+                    wx.acwpd_jbb_moments(x[:, c0:c1], wt, L, accumulate_into=(s, q))
+            state["s"], state["q"] = s, q
+
+        def tree():
+            s, q = state["s"], state["q"]
+            if world > 1:                               # C2: the moments of the whole batch on every rank
+                if backend_nccl:
+                    s, q = wd.allreduce_moments(s, q)
+                else:                                   # validation mode: gloo on host copies
+                    sc, qc = wd.allreduce_moments(s.cpu(), q.cpu())
+                    s, q = wx.to_colmajor(sc.to(dev)), wx.to_colmajor(qc.to(dev))
+            costs = wx.costs_from_moments(s, q, N_total, method)
+            state["tree"] = wx.bestbasis_treeselection(costs, n)
+
+        def step(legs):
+            legs.run("fwd", moments)
+            legs.run("inv", tree)
+
+        W.step = step
+        W.check = lambda: 0.0 if wx.isvalidtree(torch.empty(n), state["tree"]) else 1.0
+        W.output = lambda gathered: torch.from_numpy(state["tree"].astype("float64"))
+        # structure exploited by the kernel: odd lags only, S shared by both children
+        flops = (ncols - (1 << L)) * n * (2.0 * (F // 2) * 2 + 4) * Bl
+        W.info = dict(fwd_bytes=es * (n * Bl + 2 * n * ncols), inv_bytes=es * 2 * n * ncols, fwd_flops=flops, samples=n * Bl,
+                      bound="fp64", launch_unit="the rank's whole shard: %d chunks of <= %d signals" % (len(chunks), CH),
+                      collective="all-reduce of 2 x %d moments inside the second leg" % (n * ncols) if world > 1 else None)
+        W.keep = (x,)
+        return W
+
+    # ---- widened rows (SURVEY 8f): sharded like the rest, no exchange step timed -----------------------------------
+    n = w["n"]
+    x = signals((n,))
+    B = Bl
     if kind == "wpd_bb":
         from waveletsext_jl_amd import bestbasis as bbm
-        n = w["n"]
-        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
         xw = wx.jl_empty((n, L + 1, B), td, dev)
         qq, qp, Fq = qmf_arg(wt)
         state = {}
@@ -297,11 +471,10 @@ def make_workload(w, wx, torch, dev, rank):
             t = state["trees"][:4].cpu().numpy().astype(bool)
             return 0.0 if all(wx.isvalidtree(torch.empty(n), t[i]) for i in range(4)) else 1.0
         ncost = (1 << (L + 1)) - 1
-        return fwd, inv, check, dict(fwd_bytes=es * (n * (L + 1) + ncost) * B + (n - 1) * B, inv_bytes=es * n * (L + 2) * B,
-                                     fwd_flops=4.0 * n * (L + 1) * B, samples=n * B, bound="hbm", keep=(x, xw))
-    if kind == "wpd_ldb":
-        n = w["n"]
-        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
+        W.info = dict(fwd_bytes=es * (n * (L + 1) + ncost) * B + (n - 1) * B, inv_bytes=es * n * (L + 2) * B,
+                      fwd_flops=4.0 * n * (L + 1) * B, samples=n * B, bound="hbm")
+        W.keep = (x, xw)
+    elif kind == "wpd_ldb":
         xw = wx.jl_empty((n, L + 1, B), td, dev)
         qq, qp, Fq = qmf_arg(wt)
         labels = [i % 4 for i in range(B)]
@@ -319,11 +492,11 @@ def make_workload(w, wx, torch, dev, rank):
             g = state["G"]
             s = float(g[:, 0, :].sum().item())                       # root column: energies sum to 1 per class
             return abs(s - 4.0) / 4.0
-        return fwd, inv, check, dict(fwd_bytes=es * (n * (L + 1)) * (B + 4), inv_bytes=es * n * (L + 2) * B,
-                                     fwd_flops=2.0 * n * (L + 1) * B, samples=n * B, bound="hbm", keep=(x, xw))
-    if kind == "siwt":
-        n, d = w["n"], w["d"]
-        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
+        W.info = dict(fwd_bytes=es * (n * (L + 1)) * (B + 4), inv_bytes=es * n * (L + 2) * B,
+                      fwd_flops=2.0 * n * (L + 1) * B, samples=n * B, bound="hbm")
+        W.keep = (x, xw)
+    elif kind == "siwt":
+        d = w["d"]
         state = {}
 
         def fwd():      # decomposition + the cost of every node
@@ -339,27 +512,18 @@ def make_workload(w, wx, torch, dev, rank):
         # parents read once, every column written once, one cost per node (the costs of nodes of <= 256 samples
         # come out of the level that creates them; only the top depths are read a second time)
         fb = es * B * (n * (NS - (1 << min(L, d))) + n * NS + NN)
-        return fwd, inv, check, dict(fwd_bytes=fb, inv_bytes=es * B * (2 * NN + 3 * n * L) + 2 * NN * B,
-                                     fwd_flops=4.0 * F * (n / 2) * (NS - 1) * B, samples=n * B, bound="hbm", keep=(x,))
-    if kind == "acwpd_jbb":
-        n = w["n"]
-        x = wx.jl_empty((n, B), td, dev); x.normal_(generator=gen)
-        ncols = (1 << (L + 1)) - 1
-        state = {}
+        W.info = dict(fwd_bytes=fb, inv_bytes=es * B * (2 * NN + 3 * n * L) + 2 * NN * B,
+                      fwd_flops=4.0 * F * (n / 2) * (NS - 1) * B, samples=n * B, bound="hbm")
+        W.keep = (x,)
+    else:
+        raise ValueError(kind)
 
-        def fwd():
-            state["s"], state["q"] = wx.acwpd_jbb_moments(x, wt, L)
+    def step(legs):
+        legs.run("fwd", fwd)
+        legs.run("inv", inv)
 
-        def inv():      # second leg of config 5 = costs + tree selection from the moments
-            costs = wx.costs_from_moments(state["s"], state["q"], B, wx.JBB(redundant=True))
-            state["tree"] = wx.bestbasis_treeselection(costs, n)
-
-        check = lambda: 0.0 if wx.isvalidtree(torch.empty(n), state["tree"]) else 1.0
-        # structure exploited by the kernel: odd lags only, S shared by both children
-        flops = (ncols - (1 << L)) * n * (2.0 * (F // 2) * 2 + 4) * B
-        return fwd, inv, check, dict(fwd_bytes=es * (n * B + 2 * n * ncols), inv_bytes=es * 2 * n * ncols,
-                                     fwd_flops=flops, samples=n * B, bound="fp64", keep=(x,))
-    raise ValueError(kind)
+    W.step, W.check = step, check
+    return W
 
 
 def main():
@@ -385,8 +549,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # WX_BENCH_BACKEND=gloo lets several ranks share one GPU (a validation mode for 1-GPU boxes: same
-    # sharding, barriers, max-over-ranks timing and aggregation, no RCCL); the real run is nccl, one GPU per rank
+    # WX_BENCH_BACKEND=gloo lets several ranks share one GPU (a validation mode for 1-GPU boxes: same sharding,
+    # barriers, exchange schedule, max-over-ranks timing and aggregation, no RCCL); the real run is nccl, one GPU per rank
     backend = os.environ.get("WX_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
@@ -401,52 +565,81 @@ def main():
     w = dict(WORKLOADS[a.workload])
     if a.batch:
         w["batch"] = a.batch
-    fwd, inv, check, info = make_workload(w, wx, torch, dev, rank)
+    W = make_workload(w, wx, torch, dev, rank, world, a, dist)
+    info = W.info
+    red_dev = dev if backend == "nccl" else "cpu"
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(step_fn):
+        legs = Legs(torch)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step_fn(legs)
+        sync()
+        mine = time.perf_counter() - t0
+        per_rank = [mine]
+        if world > 1:
+            t = torch.zeros(world, dtype=torch.float64, device=red_dev)
+            t[rank] = mine
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            per_rank = [float(v) for v in t.tolist()]
+        return max(per_rank), per_rank, legs
+
+    warm = Legs(torch)
     for _ in range(a.warmup):
-        fwd()
-        inv()
+        W.step(warm)
     sync()
-    err = check()
+    err = W.check()
     tol = 1e-10 if w["dtype"] == "f64" else 1e-5
     assert err < tol, "round trip broken: %g" % err
 
-    # HIP events on the launch stream (torch's current stream == the stream passed to the C ABI)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        ev[i][0].record()
-        fwd()
-        ev[i][1].record()
-        inv()
-        ev[i][2].record()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    fwd_ms = sorted(e[0].elapsed_time(e[1]) for e in ev)
-    inv_ms = sorted(e[1].elapsed_time(e[2]) for e in ev)
+    elapsed, per_rank, legs = timed(W.step)
+    fwd_ms, inv_ms = legs.ms("fwd"), legs.ms("inv")
     fwd_avg = sum(fwd_ms) / len(fwd_ms)
     inv_avg = sum(inv_ms) / len(inv_ms)
+    samples_all = W.B_all * (info["samples"] // max(W.hi - W.lo, 1))
 
-    gather_ms = None
-    if a.gather and world > 1 and w["kind"] in ("wpd", "wpt"):
+    gather = None
+    if W.gatherable:
+        # second loop: the all-gather of the reconstructed output inside the step, overlapped with the inverse
+        for _ in range(max(1, min(a.warmup, 2))):
+            W.step_gather(Legs(torch))
+        sync()
+        g_elapsed, g_per_rank, _ = timed(W.step_gather)
+        # the exchange alone (nothing to overlap with), for the budget: one step's worth of posts
         from waveletsext_jl_amd import distributed as wd
-        xh = info["keep"][2]
-        wd.allgather_batch(xh, world * w["batch"])
+        full = W.output(True)
         sync()
         t1 = time.perf_counter()
-        wd.allgather_batch(xh, world * w["batch"])
+        gg = wd.OverlappedAllGather(full, full.shape[-1], nchunks=a.chunks)
+        nposts = max(len(wd.chunk_ranges(n_r, a.chunks)) for n_r in wd.shard_sizes(full.shape[-1], world))
+        for c in range(nposts):
+            gg.post(c)
+        gg.finish()
         sync()
-        gather_ms = (time.perf_counter() - t1) * 1e3
+        alone_ms = (time.perf_counter() - t1) * 1e3
+        gather = {"ms_per_step": g_elapsed / a.steps * 1e3,
+                  "value": samples_all * a.steps / g_elapsed / 1e6,
+                  "allgather_alone_ms": alone_ms,
+                  "exposed_ms": (g_elapsed - elapsed) / a.steps * 1e3,
+                  "overlap_ms": max(0.0, alone_ms - (g_elapsed - elapsed) / a.steps * 1e3),
+                  "chunks": a.chunks, "bytes_received_per_rank": float(info.get("gather_bytes", 0)),
+                  "per_rank_ms": [v / a.steps * 1e3 for v in g_per_rank],
+                  "schedule": "inverse in %d chunks; chunk c's exchange (grouped point-to-point, every piece lands in "
+                              "place) on a side stream while chunk c+1 is transformed" % a.chunks}
+        gerr = float((full[..., W.lo:W.hi] - W.keep[0]).abs().max() / W.keep[0].abs().max()) if a.scaling == "strong" else None
+        if gerr is not None:
+            assert gerr < tol, "gathered output broken: %g" % gerr
+    if a.dump:
+        import numpy as np
+        outp = W.output(W.gatherable)
+        if rank == 0 and outp is not None:
+            np.save(a.dump, outp.detach().cpu().numpy())
 
     out = None
     if rank == 0:
@@ -456,7 +649,7 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(a.workload, {})
-            if not a.batch:
+            if not a.batch and world == 1:
                 traffic = sum(cnt * tj[name]["hbm_bytes_per_launch"] for name, cnt in w["fwd_kernels"])
         except Exception:
             traffic = None
@@ -471,30 +664,44 @@ def main():
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                     "algorithmic_flops_per_step": info["fwd_flops"], "hbm_GBs": fb / (fwd_avg * 1e-3) / 1e9}
         roof.update({"avg_launch_ms": fwd_avg, "median_launch_ms": fwd_ms[len(fwd_ms) // 2],
-                     "fwd_TFLOPs": info["fwd_flops"] / (fwd_avg * 1e-3) / 1e12})
-        cfg = {"workload": w["desc"], "batch_per_gpu": w["batch"], "wavelet": w["wavelet"], "L": w["L"],
-               "sharding": "batch split across ranks, no data-path collective"}
-        cfg.update({k: w[k] for k in ("n", "m") if k in w})
+                     "launches_per_step": len(fwd_ms) // a.steps,
+                     "fwd_TFLOPs_direct_form": info["fwd_flops"] / (fwd_avg * 1e-3) / 1e12})
+        if "launch_unit" in info:
+            roof["launch_unit"] = info["launch_unit"]
+        cfg = {"workload": w["desc"], "batch": w["batch"], "batch_this_rank": W.hi - W.lo, "wavelet": w["wavelet"], "L": w["L"],
+               "sharding": ("contiguous batch shards (distributed.shard_range), no data-path collective in `value`"
+                            if world > 1 else "one GPU")}
+        cfg.update({k: w[k] for k in ("n", "m", "chunk") if k in w})
+        if info.get("collective"):
+            cfg["collective"] = info["collective"]
         out = {
             "metric": "Msamples/s (fwd+inv wavelet packets)",
-            "value": world * info["samples"] * a.steps / elapsed / 1e6,
+            "value": samples_all * a.steps / elapsed / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": w["dtype"], "data": "synthetic N(0,1), seed 1002+rank, resident in HBM",
+            "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None,
+            "dtype": w["dtype"],
+            "data": "synthetic N(0,1), seed 1002 (one batch, sliced per rank; weak scaling: 1002 + rank), resident in HBM",
             "config": cfg,
             "roofline": roof,
-            "inverse": {"avg_launch_ms": inv_avg, "algorithmic_bytes_per_launch": float(info["inv_bytes"]),
-                        "achieved_GBs": info["inv_bytes"] / (inv_avg * 1e-3) / 1e9},
+            "inverse": {"kernel": w.get("inv_kernel"), "avg_launch_ms": inv_avg,
+                        "algorithmic_bytes_per_launch": float(info["inv_bytes"]),
+                        "achieved_GBs": info["inv_bytes"] / (inv_avg * 1e-3) / 1e9,
+                        "frac": info["inv_bytes"] / (inv_avg * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "roundtrip_rel_err": err,
+            "ranks": {"nranks": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
+                      "per_rank_ms": [v / a.steps * 1e3 for v in per_rank],
+                      "min_ms": min(per_rank) / a.steps * 1e3, "max_ms": max(per_rank) / a.steps * 1e3},
         }
-        if gather_ms is not None:
-            out["allgather_reconstructed_ms"] = gather_ms
-        if not a.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w, a.cpu_seconds)
-        elif not a.no_cpu:
-            out["cpu_baseline"] = None
+        if gather is not None:
+            out["with_allgather"] = gather
+        if not a.no_cpu:
+            cb = cpu_baseline(w, a.cpu_seconds)
+            allc = cb.pop("all_cores", None)
+            out["cpu_baseline"] = cb
+            if allc is not None:
+                out["cpu_baseline_all_cores"] = allc
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -79,6 +79,20 @@ def _worker(rank, world, port, B, out_dir):
                 Gr[:, :, ci] = (yl[:, :, idx] ** 2).sum(axis=2) / nsr[ci]
         Gfull = wd.combine_energy_maps(np.asfortranarray(Gr), nsr)
         np.testing.assert_allclose(Gfull, wo.ldb_energy_map(Y, labels), rtol=1e-12, atol=1e-14)
+        # C1 in pieces (the bench's overlapped schedule): every rank fills the chunks of its own shard of `full` in
+        # place and posts them; afterwards every rank holds the whole array.  Ragged shards, more pieces than signals.
+        for nchunks in (1, 3, 4, 16):
+            fullt = torch.full((B, n), float("nan"), dtype=torch.float64).T          # column-major (n, B)
+            g = wd.OverlappedAllGather(fullt, B, nchunks=nchunks)
+            assert (g.lo, g.hi) == (lo, hi)
+            nposts = max(len(wd.chunk_ranges(sz, nchunks)) for sz in wd.shard_sizes(B, world))
+            for c in range(nposts):
+                if c < len(g.chunks):
+                    c0, c1 = g.chunks[c]
+                    g.local_chunk(c).copy_(torch.from_numpy(np.ascontiguousarray(xr[:, c0:c1].T)).T)
+                g.post(c)
+            g.finish()
+            np.testing.assert_allclose(fullt.numpy(), X, atol=1e-12)
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -90,6 +104,17 @@ def test_world2_gloo_shard_gather_reduce(tmp_path, B):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_chunk_ranges():
+    sys.path.insert(0, ROOT)
+    from waveletsext_jl_amd import distributed as wd
+    for Bl in (0, 1, 3, 4, 5, 8192):
+        for k in (1, 4, 7):
+            ch = wd.chunk_ranges(Bl, k)
+            assert len(ch) == (min(k, Bl) if Bl else 0)
+            assert not ch or (ch[0][0] == 0 and ch[-1][1] == Bl and all(a[1] == b[0] for a, b in zip(ch, ch[1:])))
+            assert all(c1 > c0 for c0, c1 in ch)
 
 
 def test_shard_ranges_cover_and_are_contiguous():

@@ -104,3 +104,50 @@ def test_concurrent_host_threads_on_their_own_streams(wx):
                 assert (a == b).all()
             else:
                 assert torch.equal(a, b)
+
+
+def _run_bench(args, env_extra, timeout=900):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    import json
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("workload,batch", [("cfg2", 37), ("target", 64), ("cfg4", 6)])
+def test_bench_two_ranks_gather_equals_one_rank(tmp_path, workload, batch):
+    """bench.py's N > 1 path in its validation mode (two fresh child processes share this GPU, gloo instead of RCCL):
+    strong scaling of a small batch, the all-gather of the reconstructed output inside the step, and the gathered array
+    of two ranks equal to what one rank reconstructs (dwt/dwt_all.jl:277-279 shards over the signal axis)"""
+    import numpy as np
+    one = str(tmp_path / "one.npy")
+    two = str(tmp_path / "two.npy")
+    common = ["--workload", workload, "--batch", str(batch), "--steps", "2", "--warmup", "1", "--no-cpu"]
+    j1 = _run_bench(common + ["--dump", one], {})
+    j2 = _run_bench(common + ["--gpus", "2", "--scaling", "strong", "--chunks", "4", "--dump", two],
+                    {"WX_BENCH_BACKEND": "gloo"})
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    assert j2["ranks"]["nranks"] == 2 and len(j2["ranks"]["per_rank_ms"]) == 2
+    ga = j2["with_allgather"]
+    assert ga["chunks"] == 4 and ga["ms_per_step"] > 0 and "allgather_alone_ms" in ga and "overlap_ms" in ga
+    a, b = np.load(one), np.load(two)
+    assert a.shape == b.shape and a.shape[-1] == batch
+    assert np.array_equal(a, b)
+
+
+def test_bench_config5_two_ranks_same_tree(tmp_path):
+    """config 5 sharded: moments per shard (accumulated over chunks), the all-reduce inside the step, the same tree on
+    two ranks as on one (bestbasis/bestbasis_tree.jl:153-154 sums over the signal axis)"""
+    import numpy as np
+    one = str(tmp_path / "one.npy")
+    two = str(tmp_path / "two.npy")
+    common = ["--workload", "cfg5", "--batch", "5000", "--steps", "1", "--warmup", "1", "--no-cpu"]
+    _run_bench(common + ["--dump", one], {})
+    j2 = _run_bench(common + ["--gpus", "2", "--dump", two], {"WX_BENCH_BACKEND": "gloo"})
+    assert j2["roofline"]["launches_per_step"] == 1 and "all-reduce" in j2["config"]["collective"]
+    assert np.array_equal(np.load(one), np.load(two))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): bash tools/refresh_evidence.sh <tag>
+# usage (GPU box, repo root): bash tools/refresh_evidence.sh <tag> [round-prefix, default r02]
 # full GPU test log, the three rocprofv3 passes per workload, then one bench line per workload (with the CPU
 # baseline) reading the traffic table just measured; everything lands under gpurun_out/ and
 # tools/collect_evidence.py files it under profiles/
@@ -11,7 +11,7 @@ timeout 900 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu_$TAG.log 2>
 for w in cfg2 target target_haar cfg3 cfg4 cfg5 bb ldb siwt; do
   bash tools/profile.sh $TAG $w pmc > /dev/null 2>&1
 done
-python tools/collect_evidence.py $TAG r01 > /dev/null 2>&1      # profiles/traffic.json of this build, read by bench.py
+python tools/collect_evidence.py $TAG ${2:-r02} > /dev/null 2>&1      # profiles/traffic.json of this build, read by bench.py
 for w in cfg2 target target_haar cfg3 cfg4 cfg5 bb ldb siwt; do
   timeout 600 python bench.py --workload $w > gpurun_out/bench_$TAG/$w.json 2> gpurun_out/bench_$TAG/$w.err
   tail -c 200 gpurun_out/bench_$TAG/$w.json; echo

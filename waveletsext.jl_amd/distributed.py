@@ -64,6 +64,96 @@ def allgather_batch(local, B_total, group=None):
     return _as_batch_major(full) if full.dim() > 1 else full
 
 
+def chunk_ranges(B_local, nchunks):
+    """[c0, c1) pieces of a shard of B_local signals: at most nchunks, sizes differ by at most one, none empty"""
+    k = max(1, min(int(nchunks), int(B_local)))
+    return [shard_range(B_local, k, c) for c in range(k)] if B_local else []
+
+
+class OverlappedAllGather:
+    """C1 in pieces, overlapped with the compute that produces the pieces.
+
+    `full` is the (sig..., B_total) column-major result on every rank.  A rank's transform writes chunk c of its own
+    shard straight into `full[..., lo + c0 : lo + c1]` (no staging copy) and then calls `post(c)`: the chunk goes to the
+    other ranks, and their chunk c lands in this rank's `full`, on a side stream, while the caller's stream computes
+    chunk c + 1.  The exchange is a grouped point-to-point pattern (send to every peer, receive from every peer): xGMI is
+    a full mesh of point-to-point links, so every link carries exactly one pair's traffic, and every piece lands in its
+    final place (a ring all-gather wants a rank-major receive buffer, which a chunk of every shard is not).
+    `finish()` makes the caller's stream wait for all pieces.  With the gloo backend (CPU validation, or several ranks on
+    one GPU) device tensors are staged through the host.
+    """
+
+    def __init__(self, full, B_total, nchunks=4, group=None):
+        self.full, self.group = full, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.B_total = int(B_total)
+        self.lo, self.hi = shard_range(B_total, self.world, self.rank)
+        self.nchunks = max(1, int(nchunks))
+        self.chunks = chunk_ranges(self.hi - self.lo, self.nchunks)
+        self.cuda = bool(full.is_cuda)
+        self.host_staged = self.cuda and dist.get_backend(group) != "nccl"
+        self.side = torch.cuda.Stream(full.device) if self.cuda else None
+        self.work = []
+
+    def local_chunk(self, c):
+        """the slice of `full` this rank's compute must fill for chunk c"""
+        c0, c1 = self.chunks[c]
+        return self.full[..., self.lo + c0: self.lo + c1]
+
+    def _peer_chunk(self, r, c):
+        rlo, rhi = shard_range(self.B_total, self.world, r)
+        ch = chunk_ranges(rhi - rlo, self.nchunks)
+        if c >= len(ch):
+            return None
+        return self.full[..., rlo + ch[c][0]: rlo + ch[c][1]]
+
+    def post(self, c):
+        if self.world == 1:
+            return
+        mine = _as_batch_major(self.local_chunk(c)) if c < len(self.chunks) else None
+        ops, recvs = [], []
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            peer = dist.get_global_rank(self.group, r) if self.group is not None else r
+            dst = self._peer_chunk(r, c)
+            if dst is not None:
+                dbm = _as_batch_major(dst)
+                if self.host_staged:
+                    buf = torch.empty(dbm.shape, dtype=dbm.dtype, device="cpu")
+                    recvs.append((dbm, buf))
+                    ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
+                else:
+                    ops.append(dist.P2POp(dist.irecv, dbm, peer, self.group))
+            if mine is not None:
+                ops.append(dist.P2POp(dist.isend, mine.cpu() if self.host_staged else mine, peer, self.group))
+        if not ops:
+            return
+        if self.cuda and not self.host_staged:
+            ev = torch.cuda.Event()
+            ev.record()                                   # chunk c is complete on the caller's stream
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self.work.extend(dist.batch_isend_irecv(ops))
+        else:
+            if self.cuda:
+                torch.cuda.current_stream(self.full.device).synchronize()
+            for wk in dist.batch_isend_irecv(ops):
+                wk.wait()
+            for dbm, buf in recvs:
+                dbm.copy_(buf)
+
+    def finish(self):
+        if self.world == 1:
+            return
+        if self.cuda and not self.host_staged:
+            with torch.cuda.stream(self.side):
+                for wk in self.work:
+                    wk.wait()
+            torch.cuda.current_stream(self.full.device).wait_stream(self.side)
+        self.work = []
+
+
 def allreduce_moments(s, q, group=None):
     """C2: in-place all-reduce(sum) of the JBB moment arrays (one fused buffer, one collective)."""
     fused = torch.stack([_as_batch_major(s).contiguous().reshape(-1), _as_batch_major(q).contiguous().reshape(-1)])
