@@ -101,18 +101,21 @@ def lat_pi_inv(L, e):
 def wpt_emu(xsig, t, gain1, L):
     lane = LANES
     lds = np.full(1104, np.nan)
-    # L0 loads
-    r = np.empty((16, 4, 64))
-    for blk in range(16):
-        for e in range(4):
-            r[blk, e] = xsig[256 * blk + 4 * lane + e]
+    # L0 loads: instruction (hi3, f) = eight complete 128-byte lines
+    xo = 64 * (lane >> 3) + 2 * (lane & 7)
+    r = np.empty((32, 2, 64))
+    for hi3 in range(8):
+        for f in range(4):
+            for e in range(2):
+                r[4 * hi3 + f, e] = xsig[512 * hi3 + 16 * f + xo + e]
     a = np.empty((64, 64))
-    wa, ra = lane + (lane >> 4), 17 * lane
-    for e in range(4):
-        for blk in range(16):
-            lds[wa + 68 * blk] = r[blk, e]
+    wa, ra = 17 * (lane >> 3) + 2 * (lane & 7), 17 * lane
+    for f in range(4):
+        for hi3 in range(8):
+            for e in range(2):
+                lds[wa + 136 * hi3 + e] = r[4 * hi3 + f, e]
         for m in range(16):
-            a[4 * m + e] = lds[ra + m]
+            a[16 * f + m] = lds[ra + m]
     level(a, 0, 6, t, False)
     level(a, 1, 6, t, False)
     bb = np.empty((64, 64))
@@ -211,13 +214,15 @@ def iwpt_emu(w, t, gain1, L):
             a[16 * f + j] = lds[ra + 64 * j]
     level(a, 1, 6, t, True)
     level(a, 0, 6, t, True)
-    wa, ra = 17 * lane, 2 * (lane & 15) + 17 * (lane >> 4)
+    wa, ra = 17 * lane, 17 * (lane >> 3) + 4 * (lane & 7)
+    yo = 64 * (lane >> 3) + 2 * (lane & 7)
     y = np.full(4096, np.nan)
-    for e in range(4):
+    for f in range(4):
         for m in range(16):
-            lds[wa + 2 * m] = a[4 * m + e]
-        for blk in range(16):
-            y[256 * blk + 4 * lane + e] = lds[ra + 68 * blk]
+            lds[wa + 4 * (m >> 1) + 2 * (m & 1)] = a[16 * f + m]
+        for hi3 in range(8):
+            for e in range(2):
+                y[512 * hi3 + 16 * f + yo + e] = lds[ra + 136 * hi3 + 2 * e]
     return y
 
 

@@ -10,7 +10,7 @@ asserts: the element -> LDS slot map is injective inside a round, both sides are
 and the read map agree element by element.  `python tools/lattice_lds_maps.py` prints the window sizes.
 
 p = sample index (12 bits).  Layouts (reg index, lane):
-  L0: reg (blk = p[11:8], e = p[1:0]), lane p[7:2]                 -- 32 contiguous bytes per lane and block
+  L0: reg (p[11:9], p[5:4], p[0]), lane p[8:6] << 3 | p[3:1]       -- eight complete 128-byte lines per instruction
   A : reg p[5:0],  lane p[11:6]                                     -- wave-cyclic neighbours
   B : reg p[7:2],  lane p[11:8] | p[1:0] << 4                       -- row-cyclic (16 lanes) neighbours
   C : reg p[11:6], lane p[5:0]                                      -- whole dilated sequences in registers
@@ -50,9 +50,14 @@ def check(name, writes, reads, size_limit=1104):
     return mx
 
 
-def t1(e):       # L0 -> A, round e = p[1:0]
-    wr = [[(256 * blk + 4 * l + e, 68 * blk + l + (l >> 4)) for l in range(64)] for blk in range(16)]
-    rd = [[(64 * lam + 4 * m + e, 17 * lam + m) for lam in range(64)] for m in range(16)]
+def t1(f):       # L0 -> A, round f = p[5:4]; L0: instruction (hi3 = p[11:9], f), lane l: p[8:6] = l >> 3, p[3:1] = l & 7,
+    # register e = p[0] -- eight complete 128-byte lines per load instruction
+    wr = []
+    for hi3 in range(8):
+        for e in range(2):
+            wr.append([(512 * hi3 + 64 * (l >> 3) + 16 * f + 2 * (l & 7) + e,
+                        17 * (l >> 3) + 2 * (l & 7) + 136 * hi3 + e) for l in range(64)])
+    rd = [[(64 * lam + 16 * f + 2 * j + e, 17 * lam + 2 * j + e) for lam in range(64)] for j in range(8) for e in range(2)]
     return wr, rd
 
 
@@ -186,9 +191,13 @@ def t2i(f):      # B -> A
     return wr, rd
 
 
-def t1i(e):      # A -> L0
-    wr = [[(64 * lam + 4 * m + e, 17 * lam + 2 * m) for lam in range(64)] for m in range(16)]
-    rd = [[(256 * blk + 4 * l + e, 2 * (l & 15) + 17 * (l >> 4) + 68 * blk) for l in range(64)] for blk in range(16)]
+def t1i(f):      # A -> L0 (same L0 as t1: full lines per store instruction)
+    wr = [[(64 * lam + 16 * f + 2 * j + e, 17 * lam + 4 * j + 2 * e) for lam in range(64)] for j in range(8) for e in range(2)]
+    rd = []
+    for hi3 in range(8):
+        for e in range(2):
+            rd.append([(512 * hi3 + 64 * (l >> 3) + 16 * f + 2 * (l & 7) + e,
+                        17 * (l >> 3) + 4 * (l & 7) + 136 * hi3 + 2 * e) for l in range(64)])
     return wr, rd
 
 

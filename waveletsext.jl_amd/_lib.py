@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwaveletsext_hip.so")
+# WX_HIP_LIB: another build of the same library (kernel experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("WX_HIP_LIB") or os.path.join(_HERE, "csrc", "libwaveletsext_hip.so")
 
 WX_OK, WX_EASSERT, WX_EARG, WX_EBOUNDS, WX_EHIP, WX_EUNSUPPORTED = 0, -1, -2, -3, -10, -11
 

@@ -17,7 +17,7 @@
 // a-children stay on the slots with bit b = 0, the d-children on bit b = 1), so the depth-L transform is L in-place
 // stencils followed by a bit reversal of the low L index bits (Wavelets.jl's packet order).  A wavefront holds the
 // 4096 samples as 64 registers per lane and changes which six index bits are register-resident four times:
-//     L0 (32 contiguous bytes per lane, as loaded)  ->  A: reg p[5:0]   levels 1-2,  halo = wave rotate (DPP)
+//     L0 (eight full 128-byte lines per load)       ->  A: reg p[5:0]   levels 1-2,  halo = wave rotate (DPP)
 //                                                   ->  B: reg p[7:2]   levels 3-6,  halo = row rotate (DPP)
 //                                                   ->  C: reg p[11:6]  levels 7-12, whole sequences in registers
 //                                                   ->  S: full 128-byte lines per 8 lanes for the stores
@@ -66,6 +66,28 @@ typedef double lat_d2 __attribute__((ext_vector_type(2)));
 typedef double lat_d4 __attribute__((ext_vector_type(4)));
 typedef const double __attribute__((address_space(1))) *lat_gc;
 typedef double __attribute__((address_space(1))) *lat_gm;
+// global accesses of the kernels: 16 bytes per lane, streamed once (WX_LAT_NT: non-temporal hint)
+#ifndef WX_LAT_NT
+#define WX_LAT_NT 3     // measured (db4, L = 10, 65536 signals): forward 0.82 -> 0.79 ms, inverse 0.88 -> 0.80 ms
+#endif
+__device__ __forceinline__ lat_d2 lat_ld2(const double __attribute__((address_space(1))) *p)
+{
+    typedef const lat_d2 __attribute__((address_space(1))) *P;
+#if WX_LAT_NT & 1
+    return __builtin_nontemporal_load((P)p);
+#else
+    return *(P)p;
+#endif
+}
+__device__ __forceinline__ void lat_st2(double __attribute__((address_space(1))) *p, lat_d2 v)
+{
+    typedef lat_d2 __attribute__((address_space(1))) *P;
+#if WX_LAT_NT & 2
+    __builtin_nontemporal_store(v, (P)p);
+#else
+    *(P)p = v;
+#endif
+}
 __device__ __forceinline__ lat_gc lat_sbase(const double *p)
 {
     lat_gc g = (lat_gc)p;
@@ -109,13 +131,28 @@ template <int CTRL> __device__ __forceinline__ double lat_dpp(double v)
     return __hiloint2double(phi, plo);
 }
 
-// value held by the lane that owns the next (DIR = +1) / previous (DIR = -1) chunk of the same dilated sequence;
-// H = number of cyclic lane bits (they are the low bits of the lane id): 6 wave, 4 row of 16, 0 = sequence in-lane
-template <int H, int DIR> __device__ __forceinline__ double lat_nbr(double v)
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <int... I, typename F> __device__ __forceinline__ void lat_for_impl(std::integer_sequence<int, I...>, F &&f)
 {
-    if constexpr (H == 6) return lat_dpp<(DIR > 0 ? 0x134 : 0x13C)>(v);      // wave_rol:1 / wave_ror:1
-    else if constexpr (H == 4) return lat_dpp<(DIR > 0 ? 0x12F : 0x121)>(v); // row_ror:15 / row_ror:1
-    else return v;
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void lat_for(F &&f)
+{
+    lat_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+// value held by the lane that owns the chunk D places further along the same dilated sequence (D < 0: back);
+// H = number of cyclic lane bits (they are the low bits of the lane id): 6 wave (|D| <= 1), 4 row of 16, 0 = the whole
+// sequence is in this lane
+template <int H, int D> __device__ __forceinline__ double lat_nbr(double v)
+{
+    if constexpr (H == 0 || D == 0) return v;
+    else if constexpr (H == 6) {
+        static_assert(D == 1 || D == -1, "wave rotations move one lane");
+        return lat_dpp<(D > 0 ? 0x134 : 0x13C)>(v);                           // wave_rol:1 / wave_ror:1
+    } else {
+        static_assert(H == 4 && D > -16 && D < 16, "row rotations");
+        return lat_dpp<0x120 + ((16 - D) & 15)>(v);                           // row_ror:n: lane i takes lane i - n (mod 16)
+    }
 }
 
 // one packet level on register-index bit K (2^K interleaved sequences of 32 >> K pairs per lane)
@@ -123,24 +160,27 @@ template <int K, int H, int NS, bool INV> __device__ __forceinline__ void lat_le
 {
     constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
     auto U = [](int s, int m) { return s + ((2 * m) << K); };
-    auto advance = [&]() {           // odd channel: pair m takes the value of pair m + 1
+    // odd channel: pair m takes the value of pair m + SH of the periodic sequence (SH < 0: delay); the pairs that come
+    // from another lane's chunk are one DPP move each, all independent
+    auto shift = [&](auto SHc) {
+        constexpr int SH = decltype(SHc)::value;
+        if constexpr (SH != 0) {
 #pragma unroll
-        for (int s = 0; s < NSEQ; ++s) {
-            const double first = x[U(s, 0) + S];
+            for (int s = 0; s < NSEQ; ++s) {
+                double old[M];
 #pragma unroll
-            for (int m = 0; m + 1 < M; ++m) x[U(s, m) + S] = x[U(s, m + 1) + S];
-            x[U(s, M - 1) + S] = lat_nbr<H, +1>(first);
+                for (int m = 0; m < M; ++m) old[m] = x[U(s, m) + S];
+                lat_for<M>([&](auto Mc) {
+                    constexpr int m = Mc;
+                    constexpr int g = m + SH;                                  // source pair in sequence order
+                    constexpr int d = (g >= 0) ? g / M : -((-g + M - 1) / M);   // floor(g / M): chunks away
+                    constexpr int src = g - d * M;
+                    x[U(s, m) + S] = lat_nbr<H, d>(old[src]);
+                });
+            }
         }
     };
-    auto delay = [&]() {             // pair m takes the value of pair m - 1
-#pragma unroll
-        for (int s = 0; s < NSEQ; ++s) {
-            const double last = x[U(s, M - 1) + S];
-#pragma unroll
-            for (int m = M - 1; m > 0; --m) x[U(s, m) + S] = x[U(s, m - 1) + S];
-            x[U(s, 0) + S] = lat_nbr<H, -1>(last);
-        }
-    };
+    constexpr bool one_shot = (H != 6) || (NS - 1 <= M);                       // wave rotations reach one lane only
     if constexpr (!INV) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -152,13 +192,19 @@ template <int K, int H, int NS, bool INV> __device__ __forceinline__ void lat_le
                     x[U(s, m)] = fma(pj, x[U(s, m) + S], x[U(s, m)]);
                     x[U(s, m) + S] = fma(-kj, x[U(s, m)], x[U(s, m) + S]);
                 }
-            if (j + 1 < NS) advance();
+            if (j + 1 < NS) shift(std::integral_constant<int, 1>{});
         }
+        if constexpr (one_shot) shift(std::integral_constant<int, -(NS - 1)>{});
+        else {
 #pragma unroll
-        for (int j = 0; j + 1 < NS; ++j) delay();
+            for (int j = 0; j + 1 < NS; ++j) shift(std::integral_constant<int, -1>{});
+        }
     } else {
+        if constexpr (one_shot) shift(std::integral_constant<int, NS - 1>{});
+        else {
 #pragma unroll
-        for (int j = 0; j + 1 < NS; ++j) advance();
+            for (int j = 0; j + 1 < NS; ++j) shift(std::integral_constant<int, 1>{});
+        }
 #pragma unroll
         for (int j = NS - 1; j >= 0; --j) {
             const double pj = cf.p[j], kj = cf.kap[j];
@@ -169,22 +215,13 @@ template <int K, int H, int NS, bool INV> __device__ __forceinline__ void lat_le
                     x[U(s, m) + S] = fma(kj, x[U(s, m)], x[U(s, m) + S]);
                     x[U(s, m)] = fma(-pj, x[U(s, m) + S], x[U(s, m)]);
                 }
-            if (j > 0) delay();
+            if (j > 0) shift(std::integral_constant<int, -1>{});
         }
     }
 }
 
 __device__ __forceinline__ int lat_rev6(int v) { return (int)(__builtin_bitreverse32((unsigned)v) >> 26); }
 
-// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
-template <int... I, typename F> __device__ __forceinline__ void lat_for_impl(std::integer_sequence<int, I...>, F &&f)
-{
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F> __device__ __forceinline__ void lat_for(F &&f)
-{
-    lat_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
 template <int B0, typename A> __device__ __forceinline__ void lat_wait16(A &x)
 {
     // x[B0 .. B0+15] are the destinations of the 16 reads just issued
@@ -261,7 +298,7 @@ template <int L> __device__ __forceinline__ void lat_store_c(double (&c)[64], un
                 lat_d2 o;
                 o.x = v[2 * I];
                 o.y = v[2 * I + 1];
-                *(lat_d2 __attribute__((address_space(1))) *)(lat_sbase(ys + 512 * i + 16 * k) + yo) = o;
+                lat_st2(lat_sbase(ys + 512 * i + 16 * k) + yo, o);
             });
         });
     });
@@ -282,7 +319,7 @@ template <int L> __device__ __forceinline__ void lat_load_c(double (&c)[64], uns
     lat_d2 v[8];
     lat_for<8>([&](auto I) {
         constexpr int i = I;
-        v[i] = *(const lat_d2 __attribute__((address_space(1))) *)(lat_sbase(xs + 512 * i) + xo);
+        v[i] = lat_ld2(lat_sbase(xs + 512 * i) + xo);
     });
     lat_for<4>([&](auto K) {
         constexpr int k = K;
@@ -296,7 +333,7 @@ template <int L> __device__ __forceinline__ void lat_load_c(double (&c)[64], uns
         if constexpr (k < 3)
             lat_for<8>([&](auto I) {
                 constexpr int i = I;
-                v[i] = *(const lat_d2 __attribute__((address_space(1))) *)(lat_sbase(xs + 512 * i + 16 * (k + 1)) + xo);
+                v[i] = lat_ld2(lat_sbase(xs + 512 * i + 16 * (k + 1)) + xo);
             });
         lat_for<16>([&](auto E) {
             constexpr int e4 = E;
@@ -316,8 +353,8 @@ template <int L> __device__ __forceinline__ void lat_load_c(double (&c)[64], uns
 }
 
 // ---------------------------------------------------------------- forward
-template <int NS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lat_wpt_f64(
+template <int NS, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_f64(
     const double *__restrict__ x, double *__restrict__ y, int L, int64_t batch, WxLat cf)
 {
     __shared__ double lds[WX_LAT_LDS];
@@ -327,18 +364,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const double *xs = x + sig * 4096;
     double a[64];
     {
-        // L0: lane holds samples 256 blk + 4 lane + e;  T1: L0 -> A (reg p[5:0], lane p[11:6])
-        lat_d4 r[16];
-        lat_for<16>([&](auto B) {
-            constexpr int blk = B;
-            r[blk] = *(const lat_d4 __attribute__((address_space(1))) *)(lat_sbase(xs + 256 * blk) + 4u * lane);
+        // L0: instruction (hi3 = p[11:9], f = p[5:4]) loads eight complete 128-byte lines: lane holds p[8:6] = lane >> 3,
+        // p[3:1] = lane & 7, register e = p[0].  T1: L0 -> A (reg p[5:0], lane p[11:6]), round f
+        lat_d2 r[32];
+        const unsigned xo = 64u * (lane >> 3) + 2u * (lane & 7);
+        lat_for<32>([&](auto Q) {
+            constexpr int hi3 = Q / 4, f = Q % 4;
+            r[Q] = lat_ld2(lat_sbase(xs + 512 * hi3 + 16 * f) + xo);
         });
-        const unsigned wa = lds0 + 8u * (lane + (lane >> 4)), ra = lds0 + 8u * 17u * lane;
-        lat_for<4>([&](auto E) {
-            constexpr int e = E;
-            lat_for<16>([&](auto B) {
-                constexpr int blk = B;
-                lds_wr<8 * 68 * blk>(wa, r[blk][e]);
+        const unsigned wa = lds0 + 8u * (17u * (lane >> 3) + 2u * (lane & 7)), ra = lds0 + 8u * 17u * lane;
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<8>([&](auto Hq) {
+                constexpr int hi3 = Hq;
+                lds_wr<8 * (136 * hi3)>(wa, r[4 * hi3 + f].x);
+                lds_wr<8 * (136 * hi3 + 1)>(wa, r[4 * hi3 + f].y);
             });
             double t[16];
             lat_for<16>([&](auto M) {
@@ -348,7 +388,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             lat_wait16<0>(t);
             lat_for<16>([&](auto M) {
                 constexpr int m = M;
-                a[4 * m + e] = t[m];
+                a[16 * f + m] = t[m];
             });
         });
     }
@@ -428,8 +468,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 }
 
 // ---------------------------------------------------------------- inverse
-template <int NS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lat_iwpt_f64(
+template <int NS, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_f64(
     const double *__restrict__ xw, double *__restrict__ y, int L, int64_t batch, int64_t in_stride, WxLat cf)
 {
     __shared__ double lds[WX_LAT_LDS];
@@ -511,31 +551,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
     lat_level<1, 6, NS, true>(a, cf);
     lat_level<0, 6, NS, true>(a, cf);
-    // T1i: A -> L0 and the stores (32 contiguous bytes per lane)
+    // T1i: A -> L0 and the stores (eight complete 128-byte lines per instruction), round f = p[5:4]
     {
-        const unsigned wa = lds0 + 8u * 17u * lane, ra = lds0 + 8u * (2 * (lane & 15) + 17 * (lane >> 4));
-        lat_d4 r[16];
-        lat_for<4>([&](auto E) {
-            constexpr int e = E;
+        const unsigned wa = lds0 + 8u * 17u * lane, ra = lds0 + 8u * (17u * (lane >> 3) + 4u * (lane & 7));
+        const unsigned yo = 64u * (lane >> 3) + 2u * (lane & 7);
+        double *ys = y + sig * 4096;
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
             lat_for<16>([&](auto M) {
-                constexpr int m = M;
-                lds_wr<8 * 2 * m>(wa, a[4 * m + e]);
+                constexpr int m = M;                     // m = 2 j + e
+                lds_wr<8 * (4 * (m >> 1) + 2 * (m & 1))>(wa, a[16 * f + m]);
             });
             double t[16];
-            lat_for<16>([&](auto B) {
-                constexpr int blk = B;
-                t[blk] = lds_rd<8 * 68 * blk>(ra);
+            lat_for<16>([&](auto M) {
+                constexpr int hi3 = M / 2, e = M % 2;
+                t[M] = lds_rd<8 * (136 * hi3 + 2 * e)>(ra);
             });
             lat_wait16<0>(t);
-            lat_for<16>([&](auto B) {
-                constexpr int blk = B;
-                r[blk][e] = t[blk];
+            lat_for<8>([&](auto Hq) {
+                constexpr int hi3 = Hq;
+                lat_d2 o;
+                o.x = t[2 * hi3];
+                o.y = t[2 * hi3 + 1];
+                lat_st2(lat_sbase(ys + 512 * hi3 + 16 * f) + yo, o);
             });
-        });
-        double *ys = y + sig * 4096;
-        lat_for<16>([&](auto B) {
-            constexpr int blk = B;
-            *(lat_d4 __attribute__((address_space(1))) *)(lat_sbase(ys + 256 * blk) + 4u * lane) = r[blk];
         });
     }
 }
@@ -646,12 +685,19 @@ static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n
     int64_t grid = batch;
     if (wg_per_cu > 0 && grid > (int64_t)256 * wg_per_cu) grid = (int64_t)256 * wg_per_cu;
     if (grid > 0x7fffffff) grid = 0x7fffffff;
+    // wavefronts per SIMD the kernels are compiled for (amdgpu_waves_per_eu): the forward fits 3 (166 registers); the
+    // inverse needs 194 registers without spills, and its spills at 3 cost 15 % extra HBM traffic (scratch) and 6 % time
+    // (db4 L = 10: 0.84 ms at 3, 0.78 ms at 2; the forward built for 2 is 2 % slower than for 3).  WX_LATTICE_INV_WPE = 3
+    // selects the other build of the inverse.
+    static const int inv_wpe = getenv("WX_LATTICE_INV_WPE") ? atoi(getenv("WX_LATTICE_INV_WPE")) : 2;
 #define WX_GO(NSS)                                                                                                  \
     case NSS:                                                                                                       \
-        if (inverse)                                                                                                \
-            hipLaunchKernelGGL(k_lat_iwpt_f64<NSS>, dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, in_stride, cf); \
+        if (inverse && inv_wpe == 3)                                                                                \
+            hipLaunchKernelGGL((k_lat_iwpt_f64<NSS, 3>), dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, in_stride, cf); \
+        else if (inverse)                                                                                           \
+            hipLaunchKernelGGL((k_lat_iwpt_f64<NSS, 2>), dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, in_stride, cf); \
         else                                                                                                        \
-            hipLaunchKernelGGL(k_lat_wpt_f64<NSS>, dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, cf);       \
+            hipLaunchKernelGGL((k_lat_wpt_f64<NSS, 3>), dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, cf);  \
         break;
     switch (filt.F / 2) {
         WX_GO(2) WX_GO(3) WX_GO(4) WX_GO(5) WX_GO(6) WX_GO(8) WX_GO(9) WX_GO(10)
