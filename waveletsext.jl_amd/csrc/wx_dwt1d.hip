@@ -151,6 +151,24 @@ struct WxFold {                 // periodised analysis filters: a[i] = sum_u qaN
 template <typename T> struct WxVec4;
 template <> struct WxVec4<double> { typedef double4 type; };
 template <> struct WxVec4<float> { typedef float4 type; };
+// store of a lane's 4 consecutive elements (two 16-byte instructions at a lane stride of 32 bytes) to the packet table /
+// the output.  Plain stores: each instruction covers half of every 32 bytes and the L2 merges the halves into full
+// lines; with the non-temporal hint (WX_WPD_NT=1) the halves reach HBM separately -- measured on config 2:
+// 6.4 ms -> 19.6 ms.  (The lattice kernels write whole 128-byte lines per instruction and gain from the hint.)
+#ifndef WX_WPD_NT
+#define WX_WPD_NT 0
+#endif
+template <typename V4> __device__ __forceinline__ void wx_gst(V4 *p, const V4 &v)
+{
+#if WX_WPD_NT
+    typedef decltype(v.x) T;
+    typedef T EV __attribute__((ext_vector_type(4)));
+    EV e = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(e, reinterpret_cast<EV *>(p));
+#else
+    *p = v;
+#endif
+}
 
 // Element offset of work item q when every signal is split into 2^sub contiguous nodes of n samples: signal
 // q >> sub (stride apart), node q & (2^sub - 1).  sub == 0: plain q * stride.
@@ -223,7 +241,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
                 const int pp = u & 1, idx = u >> 1;
                 reinterpret_cast<V2 *>(cur + (0 + pp) * PS)[idx] = ev;
                 reinterpret_cast<V2 *>(cur + (2 + pp) * PS)[idx] = ov;
-                if (WRITE_ALL && sub_log2 == 0) reinterpret_cast<V4 *>(ys)[u] = v;
+                if (WRITE_ALL && sub_log2 == 0) wx_gst(reinterpret_cast<V4 *>(ys) + u, v);
             }
         }
         __syncthreads();
@@ -310,8 +328,8 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
                         V4 va; va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3];
                         V4 vd; vd.x = dd[0]; vd.y = dd[1]; vd.z = dd[2]; vd.w = dd[3];
                         const int g0 = (j << (lh - 1)) + t;           // (j*np + 4t) / 4
-                        yl[g0] = va;
-                        yl[g0 + hq4] = vd;
+                        wx_gst(yl + (g0), va);
+                        wx_gst(yl + (g0 + hq4), vd);
                     }
                 }
             } else if (lh == 2) {
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
                     if (to_global) {
                         V4 va; va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3];
                         V4 vd; vd.x = dd[0]; vd.y = dd[1]; vd.z = dd[2]; vd.w = dd[3];
-                        yl[2 * j] = va; yl[2 * j + 1] = vd;
+                        wx_gst(yl + (2 * j), va); wx_gst(yl + (2 * j + 1), vd);
                     }
                 }
             } else if (lh == 1) {
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
                         V4 vv;
                         if (act) { vv.x = a0; vv.y = a1; vv.z = d0; vv.w = d1; }
                         else { vv.x = ev.x; vv.y = ov.x; vv.z = ev.y; vv.w = ov.y; }
-                        yl[j] = vv;
+                        wx_gst(yl + (j), vv);
                     }
                 }
             } else {
@@ -407,7 +425,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
                     if (to_lds) {
                         if (pp) { En1[idx] = en; On1[idx] = on; } else { En0[idx] = en; On0[idx] = on; }
                     }
-                    if (to_global) { V4 vv; vv.x = en.x; vv.y = on.x; vv.z = en.y; vv.w = on.y; yl[u] = vv; }
+                    if (to_global) { V4 vv; vv.x = en.x; vv.y = on.x; vv.z = en.y; vv.w = on.y; wx_gst(yl + (u), vv); }
                 }
             }
             WX_T(t_l1);
@@ -434,7 +452,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_fused(const T *__restrict__ x, 
                 const V2 ev = reinterpret_cast<const V2 *>(cur + (0 + pp) * PS)[idx];
                 const V2 ov = reinterpret_cast<const V2 *>(cur + (2 + pp) * PS)[idx];
                 V4 v; v.x = ev.x; v.y = ov.x; v.z = ev.y; v.w = ov.y;
-                reinterpret_cast<V4 *>(ys)[u] = v;
+                wx_gst(reinterpret_cast<V4 *>(ys) + u, v);
             }
         }
         __syncthreads();                           // all waves are done with this signal's LDS image
@@ -538,8 +556,8 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x
             V4 va; va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3];
             V4 vd; vd.x = dd[0]; vd.y = dd[1]; vd.z = dd[2]; vd.w = dd[3];
             const int g0 = (j << (lh - 1)) + t;
-            yl[g0] = va;
-            yl[g0 + hq4] = vd;
+            wx_gst(yl + (g0), va);
+            wx_gst(yl + (g0 + hq4), vd);
         }
     };
     auto node_active = [&](int d, int j) -> bool {
@@ -560,7 +578,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x
             V2 ev; ev.x = v.x; ev.y = v.z;
             V2 ov; ov.x = v.y; ov.y = v.w;
             if (u & 1) { E1[u >> 1] = ev; O1[u >> 1] = ov; } else { E0[u >> 1] = ev; O0[u >> 1] = ov; }
-            if (WRITE_ALL) reinterpret_cast<V4 *>(ys)[u] = v;
+            if (WRITE_ALL) wx_gst(reinterpret_cast<V4 *>(ys) + u, v);
         };
         if (Q == 2 * NT) {
             // both 16-byte groups of a lane in flight together (a loop would wait for the first before the second)
@@ -631,7 +649,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x
                     if (to_global) {
                         V4 va; va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3];
                         V4 vd; vd.x = dd[0]; vd.y = dd[1]; vd.z = dd[2]; vd.w = dd[3];
-                        yl[2 * j] = va; yl[2 * j + 1] = vd;
+                        wx_gst(yl + (2 * j), va); wx_gst(yl + (2 * j + 1), vd);
                     }
                 }
             } else if (lh == 1) {
@@ -660,7 +678,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x
                             if (pp) { E1[idx] = en; O1[idx] = on; } else { E0[idx] = en; O0[idx] = on; }
                         }
                     }
-                    if (to_global) yl[j] = vv;
+                    if (to_global) wx_gst(yl + (j), vv);
                 }
             } else {
                 for (int uu = tid; uu < (n >> 3); uu += NT)
@@ -680,7 +698,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x
                         on.y = fma(qd2[1], ov.y, qd2[0] * ev.y);
                     }
                     if (to_lds) { if (pp) { E1[idx] = en; O1[idx] = on; } else { E0[idx] = en; O0[idx] = on; } }
-                    if (to_global) { V4 vv; vv.x = en.x; vv.y = on.x; vv.z = en.y; vv.w = on.y; yl[u] = vv; }
+                    if (to_global) { V4 vv; vv.x = en.x; vv.y = on.x; vv.z = en.y; vv.w = on.y; wx_gst(yl + (u), vv); }
                 }
             }
             if (lh <= 8) wave_sync(); else __syncthreads();
@@ -691,7 +709,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x
                 const V2 ev = (u & 1) ? E1[u >> 1] : E0[u >> 1];
                 const V2 ov = (u & 1) ? O1[u >> 1] : O0[u >> 1];
                 V4 v; v.x = ev.x; v.y = ov.x; v.z = ev.y; v.w = ov.y;
-                reinterpret_cast<V4 *>(ys)[u] = v;
+                wx_gst(reinterpret_cast<V4 *>(ys) + u, v);
             }
         }
         __syncthreads();
