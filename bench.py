@@ -234,6 +234,34 @@ def cpu_baseline(w, seconds):
 
 
 # ------------------------------------------------------------------------------------------------
+# PCIe-inclusive rate: host (numpy) arrays handed to the C ABI, the library stages H2D / D2H itself.  Reported next to
+# the headline, never as `value` (the timed region of `value` starts with the inputs resident in HBM).
+# ------------------------------------------------------------------------------------------------
+def pcie_inclusive(w, wx):
+    import numpy as np
+    if w["kind"] not in ("wpd", "wpt"):
+        return None
+    n, L, B = w["n"], w["L"], min(w["batch"], 8192)
+    wt = wx.wavelet(getattr(wx.WT, w["wavelet"]))
+    rng = np.random.default_rng(7)
+    x = np.asfortranarray(rng.standard_normal((n, B)))
+    fwd = (lambda a: wx.wpdall(a, wt, L)) if w["kind"] == "wpd" else (lambda a: wx.wptall(a, wt, L))
+    inv = (lambda a: wx.iwpdall(a, wt, L)) if w["kind"] == "wpd" else (lambda a: wx.iwptall(a, wt, L))
+    y = fwd(x)                                  # first call: pinned ring, host threads, page cache of the allocator
+    t0 = time.perf_counter()
+    y = fwd(x)                                  # the result is a freshly allocated pageable array every time
+    t1 = time.perf_counter()
+    xr = inv(y)
+    t2 = time.perf_counter()
+    assert np.abs(xr - x).max() < 1e-9
+    return {"signals": B, "forward_ms": (t1 - t0) * 1e3, "inverse_ms": (t2 - t1) * 1e3,
+            "forward_host_GBs": (x.nbytes + y.nbytes) / (t1 - t0) / 1e9, "inverse_host_GBs": (x.nbytes + y.nbytes) / (t2 - t1) / 1e9,
+            "value": 2.0 * B * n / (t2 - t0) / 1e6, "unit": "Msamples/s",
+            "note": "numpy arrays in pageable host memory -> C ABI -> numpy arrays; D2H through the pinned ring + host "
+                    "thread pool of wx_host.hip; not the headline"}
+
+
+# ------------------------------------------------------------------------------------------------
 # GPU workloads
 # ------------------------------------------------------------------------------------------------
 class Legs:
@@ -696,6 +724,13 @@ def main():
         }
         if gather is not None:
             out["with_allgather"] = gather
+        if not a.no_cpu and world == 1:
+            try:
+                pc = pcie_inclusive(w, wx)
+            except Exception as e:  # pragma: no cover
+                pc = {"error": str(e)}
+            if pc is not None:
+                out["pcie_inclusive"] = pc
         if not a.no_cpu:
             cb = cpu_baseline(w, a.cpu_seconds)
             allc = cb.pop("all_cores", None)

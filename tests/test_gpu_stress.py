@@ -151,3 +151,26 @@ def test_bench_config5_two_ranks_same_tree(tmp_path):
     j2 = _run_bench(common + ["--gpus", "2", "--dump", two], {"WX_BENCH_BACKEND": "gloo"})
     assert j2["roofline"]["launches_per_step"] == 1 and "all-reduce" in j2["config"]["collective"]
     assert np.array_equal(np.load(one), np.load(two))
+
+
+def test_host_arrays_through_the_pinned_staging_ring(wx):
+    """numpy in / numpy out: the D2H of a result larger than the staging threshold runs through the pinned ring and the
+    host thread pool (wx_host.hip), in chunks of 32 MiB with a ragged tail -- the same numbers as the device-tensor
+    path, bit for bit"""
+    import torch
+    wt = wx.wavelet(wx.WT.db4)
+    rng = np.random.default_rng(21)
+    n, B, L = 4096, 333, 9                       # (n, L+1, B) Float64 = 109 MB: three full chunks and a tail
+    x = np.asfortranarray(rng.standard_normal((n, B)))
+    y_host = wx.wpdall(x, wt, L)
+    y_dev = wx.wpdall(wx.to_device(x), wt, L)
+    assert isinstance(y_host, np.ndarray) and y_host.flags.f_contiguous
+    assert np.array_equal(y_host, y_dev.cpu().numpy())
+    xr = wx.iwpdall(y_host, wt, L)
+    assert np.abs(xr - x).max() <= 1e-12
+    for _ in range(3):                           # the ring and the pool are reused from call to call
+        assert np.array_equal(wx.wpdall(x, wt, L), y_host)
+    wx.shutdown()                                # releases the ring and the pool; the next call rebuilds them
+    assert np.array_equal(wx.wpdall(x, wt, L), y_host)
+    del y_dev
+    torch.cuda.empty_cache()
