@@ -126,7 +126,8 @@ static int api_swt_inv(const T *xw, T *x, int64_t n, int64_t ncols, int L, int l
     }
     // level buffers follow the inverse schedule (fused iswpt passes skip every other depth)
     WxSwtInvPlan plan;
-    wx_swt_inv_plan(layout, Leff, F, sm, n, sizeof(T), dtree != nullptr, &plan);
+    wx_swt_inv_plan(layout, Leff, F, sm, n, sizeof(T), dtree != nullptr, &plan,
+                    layout == LAYOUT_WPT && sm < 0 && !dtree && wx_haar_swpt6_ok(n, Leff, filt, sizeof(T)));
     T *s0 = nullptr, *s1 = nullptr;
     if (batch && plan.need_cols[0]) { s0 = (T *)scr.alloc(sizeof(T) * n * plan.need_cols[0] * batch); if (!s0) return io.finish(WX_EHIP); }
     if (batch && plan.need_cols[1]) { s1 = (T *)scr.alloc(sizeof(T) * n * plan.need_cols[1] * batch); if (!s1) return io.finish(WX_EHIP); }

@@ -33,7 +33,14 @@ struct WxSwtInvPlan {
     int from[32], to[32], buf[32], R[32], OPT[32];
     int64_t need_cols[2];
 };
-void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz, bool has_tree, WxSwtInvPlan *P);
+void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz, bool has_tree, WxSwtInvPlan *P,
+                     bool haar6 = false);
+// last six levels of the Haar swpt / average-based iswpt as sliding Walsh-Hadamard transforms (wx_haarswt.hip)
+bool wx_haar_swpt6_ok(int64_t n, int L, const WxFilt &filt, size_t esz);
+int wx_haar_swpt6_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+int wx_haar_iswpt_levels();
+int wx_haar_iswpt6(const double *src, int64_t src_cols, double *dst, int64_t dst_cols, int64_t n, int L, int64_t batch,
+                   const WxFilt &filt, hipStream_t st);
 template <typename T>
 int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, int64_t batch, int64_t sm,
                    const uint8_t *dtree, int64_t ntree, const WxFilt &filt, const WxSwtInvPlan &plan, T *scratch0,

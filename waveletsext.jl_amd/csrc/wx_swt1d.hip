@@ -691,8 +691,11 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
     double *dcoef = nullptr;
     int *dshift = nullptr;
     int d = 0;
-    while (d < L) {
-        const int K = (KF > 1 && L - d >= 2) ? (L - d >= KF ? KF : L - d) : 1;
+    // Haar, deep trees: the last six levels are one register pass (wx_haarswt.hip); the passes here stop at depth L - 6
+    const bool haar6 = !ac && layout == WX_LAYOUT_WPT && !wx_force_generic_swt() && wx_haar_swpt6_ok(n, L, filt, sizeof(T));
+    const int dstop = haar6 ? L - 6 : L;
+    while (d < dstop) {
+        const int K = (KF > 1 && dstop - d >= 2) ? (dstop - d >= KF ? KF : dstop - d) : 1;
         int64_t gy = batch;
         if (gy > 65535) gy = 65535;
         if (K == 1) {
@@ -758,6 +761,9 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         d += K;
     }
     WX_HIP_CHECK(hipGetLastError());
+    if constexpr (sizeof(T) == 8) {
+        if (haar6) return wx_haar_swpt6_fwd((double *)xw, n, L, batch, filt, st);
+    }
     return WX_OK;
 }
 
@@ -775,7 +781,8 @@ static int wx_swtinv_threads()
 }
 // inverse schedule (see WxSwtInvPlan): fused two-level (three for F <= 4) passes for the average-based full iswpt while the
 // 2^K descendant tiles of >= 64-byte runs fit in 128 KiB of LDS, single levels otherwise
-void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz, bool has_tree, WxSwtInvPlan *P)
+void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz, bool has_tree, WxSwtInvPlan *P,
+                     bool haar6)
 {
     P->npass = 0;
     P->need_cols[0] = P->need_cols[1] = 0;
@@ -784,6 +791,7 @@ void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz
     int d = L, pp = 0;
     while (d > 0) {
         int K = 1, R = 0, OPT = 1;
+        if (fuse && haar6 && d == L) { K = wx_haar_iswpt_levels(); R = 64; OPT = 0; }   // register pass of wx_haarswt.hip (OPT = 0 marks it)
         for (int Kt = (F <= 4 ? 3 : 2); fuse && Kt >= 2 && K == 1; --Kt) {
             if (d < Kt) continue;
             const int dp = d - Kt;
@@ -868,7 +876,16 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
         const int nodes_d = layout == WX_LAYOUT_DWT ? 1 : (1 << d);
         T *outp = plan.buf[i] < 0 ? x : bufs[plan.buf[i]];
         const int64_t out_cols = plan.buf[i] < 0 ? 1 : nodes_d;
-        if (K >= 2) {
+        if (K >= 5 && plan.OPT[i] == 0) {
+            if constexpr (sizeof(T) == 8) {
+                const T *srcp6 = prev ? prev : xw;
+                const int rc6 = wx_haar_iswpt6((const double *)srcp6, prev ? prev_cols : ncols, (double *)outp, out_cols, n,
+                                               plan.from[i], batch, filt, st);
+                if (rc6) return rc6;
+            } else {
+                return wx_set_error(WX_EHIP, "iswpt: the Haar register pass is Float64 only");
+            }
+        } else if (K >= 2) {
             const int R = plan.R[i];
             const int64_t nu = n >> d;
             const int64_t tile = nu * R;
