@@ -37,8 +37,8 @@ FP64_PEAK_TFLOPS = 78.6        # FP64 vector spec; tools/ubench.hip 
 
 WORKLOADS = {
     "cfg2": dict(kind="wpd", n=4096, batch=65536, wavelet="db8", L=12, dtype="f64",
-                 kernel="k_fwd1d_fused<double, 16, 512, true, 2>", inv_kernel="k_lat_iwpt_f64<8, 2>",
-                 fwd_kernels=[("k_fwd1d_fused<double, 16, 512, true, 2>", 1)],
+                 kernel="k_lat_wpd_f64<8, 2>", inv_kernel="k_lat_iwpt_f64<8, 2>",
+                 fwd_kernels=[("k_lat_wpd_f64<8, 2>", 1)],
                  desc="BASELINE config 2: wpdall+iwpdall 65536x4096 f64 db8 full tree L=12"),
     "target": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=10, dtype="f64",
                    kernel="k_lat_wpt_f64<4, 3>", inv_kernel="k_lat_iwpt_f64<4, 2>",

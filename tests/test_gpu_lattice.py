@@ -123,3 +123,24 @@ def test_filter_without_a_lattice_falls_back(wx, oracle):
     wt = wx.OrthoFilter(q)
     x = np.asfortranarray(rng.standard_normal((4096, 2)))
     assert relerr(wx.wptall(x, wt, 8), oracle.wptall(x, q, 8)) <= 1e-10
+
+
+@pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db8", "coif6", "db10"])
+def test_lattice_wpd_every_depth_matches_oracle(wx, oracle, wname):
+    """wpdall of 4096-sample Float64 signals (DWT.jl:131-161, dwt/dwt_all.jl:260-282) through k_lat_wpd_f64: every level
+    leaves the registers through its own LDS transposition; every depth 1..12, every column of the table"""
+    rng = np.random.default_rng(12)
+    wt = _wt(wx, wname)
+    for L in range(1, 13):
+        x = np.asfortranarray(rng.standard_normal((4096, 2)))
+        exp = oracle.wpdall(x, wt.qmf, L)
+        got = wx.wpdall(x, wt, L)
+        assert got.shape == (4096, L + 1, 2)
+        assert np.array_equal(got[:, 0, :], x)                       # column 0 is the signal itself
+        assert relerr(got, exp) <= 1e-12, (wname, L)
+    # and the kernels it replaces still agree (mode 2: fused LDS kernel)
+    wx.set_force_generic(2)
+    try:
+        assert relerr(wx.wpdall(x, wt, 12), exp) <= 1e-10
+    finally:
+        wx.set_force_generic(0)

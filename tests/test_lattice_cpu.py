@@ -45,3 +45,32 @@ def test_kernel_emulation_matches_oracle(wx, oracle, wname, L):
     ref = oracle.wpt(x, q, L)
     assert np.abs(wpt_emu(x, sh, g1, L) - ref).max() <= 1e-13 * np.abs(ref).max()
     assert np.abs(iwpt_emu(ref, sh, g1, L) - x).max() <= 1e-13 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("wname,L", [("db4", 12), ("db8", 5), ("db2", 9)])
+def test_wpd_emission_emulation_matches_oracle(wx, oracle, wname, L):
+    """the per-level output routing of k_lat_wpd_f64 (emit_plan: round bits, line-address order, gains) in numpy"""
+    from tools.lattice_emu import wpd_emu, shear_coefs, emit_plan, LANES
+    from tools.lattice_proto import lattice_factor
+    q = np.asarray(wx.wavelet(getattr(wx.WT, wname)).qmf, dtype=np.float64)
+    t, g1 = lattice_factor(q)
+    x = np.random.default_rng(4).standard_normal(4096)
+    ref = oracle.wpd(x, q, L)
+    got = wpd_emu(x, shear_coefs(t), g1, L)
+    assert not np.isnan(got).any()
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    # every level's LDS writes are conflict-free: the 16 lanes of a ds_write_b64 group land on 16 different bank pairs
+    for lay, levels in ((0, (1, 2)), (2, (3, 4, 5, 6)), (6, (7, 8, 9, 10, 11, 12))):
+        for l in levels:
+            P = emit_plan(lay, l)
+            hi = np.zeros(64, dtype=np.int64)
+            pos = np.zeros(64, dtype=np.int64)
+            for k in range(6):
+                if P["lane_o"][k][0] < 4:
+                    pos += ((LANES >> k) & 1) << P["lane_o"][k][0]
+            for qq, (kind, b, ob) in enumerate(P["line"]):
+                if kind == "lane":
+                    hi += ((LANES >> b) & 1) << qq
+            slot = 17 * hi + pos
+            for g in range(4):
+                assert len(set(slot[16 * g:16 * g + 16] % 16)) == 16, (lay, l)

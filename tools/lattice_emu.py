@@ -240,3 +240,161 @@ if __name__ == "__main__":
             got = wpt_emu(x, t, g1, L)
             back = iwpt_emu(ref, t, g1, L)
             print(name, L, "fwd", np.abs(got - ref).max() / np.abs(ref).max(), "inv", np.abs(back - x).max() / np.abs(x).max())
+
+
+# ---- wpd: every level leaves the registers through an LDS transposition (k_lat_wpd_f64) ---------------------------------
+def src_of_pbit(lay, t):
+    """('reg' | 'lane', bit index) that holds sample-index bit t in layout lay (0 = A, 2 = B, 6 = C)"""
+    if lay == 0:
+        return ("reg", t) if t < 6 else ("lane", t - 6)
+    if lay == 2:
+        if 2 <= t < 8:
+            return ("reg", t - 2)
+        return ("lane", t - 8) if t >= 8 else ("lane", 4 + t)
+    return ("reg", t - 6) if t >= 6 else ("lane", t)
+
+
+def obit_of_pbit(l, t):
+    """where sample-index bit t lands in the position inside column l of the packet table"""
+    return 11 - t if t < l else t - l
+
+
+def emit_plan(lay, l):
+    """routing of one level's output: round bits, order of the line-id bits, per-bit weights"""
+    reg_o = {}
+    lane_o = {}
+    for t in range(12):
+        kind, i = src_of_pbit(lay, t)
+        (reg_o if kind == "reg" else lane_o)[i] = (obit_of_pbit(l, t), t)
+    round_regbits = [i for i in range(6) if reg_o[i][0] >= 4][:2]
+    assert len(round_regbits) == 2
+    vbits = [i for i in range(6) if i not in round_regbits]
+    line = []                                        # (kind, bit, obit) in compress order
+    for k in range(4):
+        if lane_o[k][0] >= 4:
+            line.append(("lane", k, lane_o[k][0]))
+    for k in (4, 5):
+        if lane_o[k][0] >= 4:
+            line.append(("lane", k, lane_o[k][0]))
+    for i in vbits:
+        if reg_o[i][0] >= 4:
+            line.append(("reg", i, reg_o[i][0]))
+    assert len(line) == 6, (lay, l, line)
+    return dict(reg_o=reg_o, lane_o=lane_o, round_regbits=round_regbits, vbits=vbits, line=line)
+
+
+def emit_level(x, lay, l, g, lds, ycol):
+    """x: (64 regs, 64 lanes) after level l in layout lay -> column l (4096 values) of the packet table"""
+    P = emit_plan(lay, l)
+    lane = LANES
+    low = (1 << l) - 1
+    # lane parts
+    hi_lane = np.zeros(64, dtype=np.int64)
+    pos_lane = np.zeros(64, dtype=np.int64)
+    pc_lane = np.zeros(64, dtype=np.int64)
+    for k in range(6):
+        ob, t = P["lane_o"][k]
+        bit = (lane >> k) & 1
+        if ob < 4:
+            pos_lane += bit << ob
+        if t < l:
+            pc_lane += bit
+    for q, (kind, b, ob) in enumerate(P["line"]):
+        if kind == "lane":
+            hi_lane += ((lane >> b) & 1) << q
+    base = g ** l * (g ** -2.0) ** pc_lane
+    for rho in range(4):
+        # registers of the round: the two round bits fixed
+        regs = []
+        for v in range(16):
+            r = 0
+            for j, i in enumerate(P["vbits"]):
+                r |= ((v >> j) & 1) << i
+            for j, i in enumerate(P["round_regbits"]):
+                r |= ((rho >> j) & 1) << i
+            regs.append(r)
+        o_round = 0
+        for j, i in enumerate(P["round_regbits"]):
+            o_round |= ((rho >> j) & 1) << P["reg_o"][i][0]
+        for r in regs:
+            hi_reg = pos_reg = pc_reg = 0
+            for i in range(6):
+                ob, t = P["reg_o"][i]
+                bit = (r >> i) & 1
+                if ob < 4:
+                    pos_reg |= bit << ob
+                if t < l:
+                    pc_reg += bit
+            for q, (kind, b, ob) in enumerate(P["line"]):
+                if kind == "reg":
+                    hi_reg |= ((r >> b) & 1) << q
+            slot = 17 * (hi_lane + hi_reg) + pos_lane + pos_reg
+            lds[slot] = x[r] * (base * (g ** -2.0) ** pc_reg)
+        for i in range(8):
+            for e in range(2):
+                hi = 8 * i + (lane >> 3)
+                pos = 2 * (lane & 7) + e
+                o = np.full(64, o_round | 0, dtype=np.int64) + pos
+                for q, (kind, b, ob) in enumerate(P["line"]):
+                    o += ((hi >> q) & 1) << ob
+                ycol[o] = lds[17 * hi + pos]
+
+
+def wpd_emu(xsig, t, gain1, L):
+    """(4096, L+1) packet table through the kernel's layouts; column 0 = the signal"""
+    lane = LANES
+    lds = np.full(1104, np.nan)
+    y = np.full((4096, L + 1), np.nan)
+    y[:, 0] = xsig
+    xo = 64 * (lane >> 3) + 2 * (lane & 7)
+    r = np.empty((32, 2, 64))
+    for hi3 in range(8):
+        for f in range(4):
+            for e in range(2):
+                r[4 * hi3 + f, e] = xsig[512 * hi3 + 16 * f + xo + e]
+    a = np.empty((64, 64))
+    wa, ra = 17 * (lane >> 3) + 2 * (lane & 7), 17 * lane
+    for f in range(4):
+        for hi3 in range(8):
+            for e in range(2):
+                lds[wa + 136 * hi3 + e] = r[4 * hi3 + f, e]
+        for m in range(16):
+            a[16 * f + m] = lds[ra + m]
+    for K in range(2):
+        if L > K:
+            level(a, K, 6, t, False)
+            emit_level(a, 0, K + 1, gain1, lds, y[:, K + 1])
+    if L <= 2:
+        return y
+    bb = np.empty((64, 64))
+    sw = lane ^ ((lane >> 5) << 1)
+    wa0, wa1 = sw, sw ^ 1
+    H, p10 = lane & 15, lane >> 4
+    lam0 = 4 * H
+    sg = (p10 & 1) | ((lam0 >> 5) << 1)
+    rah = [64 * p10 + ((lam0 + h) ^ sg) for h in range(4)]
+    for f in range(4):
+        for j in range(16):
+            lds[(wa1 if j & 1 else wa0) + 64 * j] = a[16 * f + j]
+        for h in range(4):
+            for g in range(4):
+                bb[16 * h + 4 * f + g] = lds[rah[h] + 256 * g]
+    for K in range(4):
+        if L > 2 + K:
+            level(bb, K, 4, t, False)
+            emit_level(bb, 2, 3 + K, gain1, lds, y[:, 3 + K])
+    if L <= 6:
+        return y
+    c = np.empty((64, 64))
+    wa = lane + (lane >> 5)
+    ra = 66 * (lane >> 2) + 16 * (lane & 1) + 33 * ((lane >> 1) & 1)
+    for f in range(4):
+        for j in range(16):
+            lds[wa + 66 * j] = bb[16 * f + j]
+        for Hh in range(16):
+            c[4 * Hh + f] = lds[ra + Hh]
+    for K in range(6):
+        if L > 6 + K:
+            level(c, K, 0, t, False)
+            emit_level(c, 6, 7 + K, gain1, lds, y[:, 7 + K])
+    return y

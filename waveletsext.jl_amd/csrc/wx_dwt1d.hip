@@ -1174,6 +1174,13 @@ int wx_dev_wpd1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
 {
     if (batch == 0 || n == 0) return WX_OK;
     const int64_t ys = n * (L + 1);
+    if constexpr (sizeof(T) == 8) {
+        // 4096-sample signals: rotations in registers, every level leaves through an LDS transposition (wx_lattice.hip)
+        if (!force_generic && !wx_skip_register_kernels()) {
+            const int r = wx_lattice_wpd_f64((const double *)x, (double *)y, n, L, batch, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
+    }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))
         return launch_fwd_fused<T, true>(x, y, n, L, batch, n, ys, filt, nullptr, 0, st);
     // column 0 = x (strided 2-D copy), then level by level inside the table

@@ -98,6 +98,7 @@ int wx_haar_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batc
 
 // full-tree Float64 packets as a lattice of plane rotations in the registers of one wavefront per signal
 // (wx_lattice.hip); 0 = not applicable, 1 = launched, < 0 = error
+int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
 int wx_lattice_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
 int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                         const WxFilt &filt, hipStream_t st);

@@ -88,6 +88,19 @@ __device__ __forceinline__ void lat_st2(double __attribute__((address_space(1)))
     *(P)p = v;
 #endif
 }
+// stores of the wpd kernel (28 of the 30 GiB it moves): WX_LAT_WPD_NT selects the hint separately
+#ifndef WX_LAT_WPD_NT
+#define WX_LAT_WPD_NT 0     // measured on config 2 (same box): plain stores 5.95 ms, non-temporal 6.20 ms
+#endif
+__device__ __forceinline__ void lat_st2w(double __attribute__((address_space(1))) *p, lat_d2 v)
+{
+    typedef lat_d2 __attribute__((address_space(1))) *P;
+#if WX_LAT_WPD_NT
+    __builtin_nontemporal_store(v, (P)p);
+#else
+    *(P)p = v;
+#endif
+}
 __device__ __forceinline__ lat_gc lat_sbase(const double *p)
 {
     lat_gc g = (lat_gc)p;
@@ -467,6 +480,296 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     }
 }
 
+// ---------------------------------------------------------------- wpd: every level leaves through an LDS transposition
+// After level l the registers hold level l of the packet table in the in-place order: the coefficient at sample index p
+// belongs at position  o = bitreverse_l(p[l-1:0]) << (12 - l) | p >> l  of column l (DWT.jl:145-158: node j of depth l =
+// rows [j n/2^l, (j+1) n/2^l)), scaled by g^(l - 2 popcount(p[l-1:0])).  o is a bit permutation of p, so "which register
+// of which lane" -> "which byte of which 128-byte line" is static routing: p bit t sits in a register or lane bit that
+// depends on the layout (A, B, C) and lands on o bit (t < l ? 11 - t : t - l).  An exchange round moves 16 registers per
+// lane (two register bits that land on line-address bits are fixed per round): slot = 17 * line + position, where the six
+// line-address bits of the round are ordered with the low lane bits first (conflict-free ds_write_b64 for every
+// layout and level, 2-way ds_read_b64; enumerated in tools/lattice_emu.py::emit_plan and checked against the oracle's
+// wpd there); the read side hands every group of 8 lanes one complete line for a 16-byte-per-lane store.
+struct LatSrc { int reg; int bit; };                       // reg = 1: register-index bit, 0: lane-id bit
+constexpr LatSrc lat_src(int lay, int t)
+{
+    if (lay == 0) return t < 6 ? LatSrc{1, t} : LatSrc{0, t - 6};
+    if (lay == 2) return (t >= 2 && t < 8) ? LatSrc{1, t - 2} : (t >= 8 ? LatSrc{0, t - 8} : LatSrc{0, 4 + t});
+    return t >= 6 ? LatSrc{1, t - 6} : LatSrc{0, t};
+}
+constexpr int lat_pbit(int lay, int reg, int bit)           // sample-index bit held by that register / lane bit
+{
+    for (int t = 0; t < 12; ++t)
+        if (lat_src(lay, t).reg == reg && lat_src(lay, t).bit == bit) return t;
+    return -1;
+}
+constexpr int lat_obit(int l, int t) { return t < l ? 11 - t : t - l; }
+constexpr int lat_reg_o(int lay, int l, int i) { return lat_obit(l, lat_pbit(lay, 1, i)); }
+constexpr int lat_lane_o(int lay, int l, int k) { return lat_obit(l, lat_pbit(lay, 0, k)); }
+// the j-th (j = 0, 1) register bit fixed per round: the lowest register bits that land on a line-address bit
+constexpr int lat_round_bit(int lay, int l, int j)
+{
+    int c = 0;
+    for (int i = 0; i < 6; ++i)
+        if (lat_reg_o(lay, l, i) >= 4) { if (c == j) return i; ++c; }
+    return -1;
+}
+constexpr bool lat_is_round_bit(int lay, int l, int i) { return i == lat_round_bit(lay, l, 0) || i == lat_round_bit(lay, l, 1); }
+constexpr int lat_vbit(int lay, int l, int j)               // j-th of the four register bits that vary inside a round
+{
+    int c = 0;
+    for (int i = 0; i < 6; ++i)
+        if (!lat_is_round_bit(lay, l, i)) { if (c == j) return i; ++c; }
+    return -1;
+}
+// the q-th line-address bit of a round: {is_reg, source bit, o bit}; low lane bits first, then lane bits 4, 5, then registers
+struct LatLine { int reg; int bit; int ob; };
+constexpr LatLine lat_line(int lay, int l, int q)
+{
+    int c = 0;
+    for (int k = 0; k < 6; ++k)
+        if (lat_lane_o(lay, l, k) >= 4) { if (c == q) return LatLine{0, k, lat_lane_o(lay, l, k)}; ++c; }
+    for (int j = 0; j < 4; ++j) {
+        const int i = lat_vbit(lay, l, j);
+        if (lat_reg_o(lay, l, i) >= 4) { if (c == q) return LatLine{1, i, lat_reg_o(lay, l, i)}; ++c; }
+    }
+    return LatLine{-1, -1, -1};
+}
+constexpr int lat_emit_reg(int lay, int l, int rho, int v)  // register of round rho, v = 0..15
+{
+    int r = 0;
+    for (int j = 0; j < 4; ++j) r |= ((v >> j) & 1) << lat_vbit(lay, l, j);
+    for (int j = 0; j < 2; ++j) r |= ((rho >> j) & 1) << lat_round_bit(lay, l, j);
+    return r;
+}
+constexpr int lat_emit_slot_reg(int lay, int l, int r)      // register part of the LDS slot (elements)
+{
+    int hi = 0, pos = 0;
+    for (int i = 0; i < 6; ++i)
+        if (lat_reg_o(lay, l, i) < 4) pos |= ((r >> i) & 1) << lat_reg_o(lay, l, i);
+    for (int q = 0; q < 6; ++q)
+        if (lat_line(lay, l, q).reg == 1) hi |= ((r >> lat_line(lay, l, q).bit) & 1) << q;
+    return 17 * hi + pos;
+}
+constexpr int lat_emit_pc_reg(int lay, int l, int r)        // detail branches on the path held in register bits
+{
+    int c = 0;
+    for (int i = 0; i < 6; ++i)
+        if (lat_pbit(lay, 1, i) < l) c += (r >> i) & 1;
+    return c;
+}
+constexpr int lat_emit_o_round(int lay, int l, int rho)
+{
+    int o = 0;
+    for (int j = 0; j < 2; ++j) o |= ((rho >> j) & 1) << lat_reg_o(lay, l, lat_round_bit(lay, l, j));
+    return o;
+}
+constexpr int lat_emit_o_instr(int lay, int l, int i)       // line-address bits 3..5 of the round come from the store index
+{
+    int o = 0;
+    for (int q = 3; q < 6; ++q) o |= ((i >> (q - 3)) & 1) << lat_line(lay, l, q).ob;
+    return o;
+}
+
+struct WxLatW {
+    WxLat c;
+    double gl[13];            // g^l
+};
+
+template <int LAY, int LVL>
+__device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double *__restrict__ ycol, int lane, const WxLatW &cw)
+{
+    // lane parts: line-address bits, in-line position bits, detail branches of the path
+    int hi_lane = 0, pos_lane = 0;
+    double b = cw.gl[LVL];
+    lat_for<6>([&](auto Kc) {
+        constexpr int k = Kc;
+        constexpr int ob = lat_lane_o(LAY, LVL, k);
+        if constexpr (ob < 4) pos_lane |= ((lane >> k) & 1) << ob;
+        if constexpr (lat_pbit(LAY, 0, k) < LVL) b = ((lane >> k) & 1) ? b * cw.c.g2 : b;
+    });
+    lat_for<6>([&](auto Qc) {
+        constexpr int q = Qc;
+        constexpr LatLine ln = lat_line(LAY, LVL, q);
+        if constexpr (ln.reg == 0) hi_lane |= ((lane >> ln.bit) & 1) << q;
+    });
+    double gf[7];
+    gf[0] = b;
+#pragma unroll
+    for (int m = 1; m < 7; ++m) gf[m] = gf[m - 1] * cw.c.g2;
+    const unsigned wa = lds0 + 8u * (unsigned)(17 * hi_lane + pos_lane);
+    // read side: store instruction i of a round covers lines 8 i + (lane >> 3), a lane takes elements 2 (lane & 7), +1
+    const int qq = lane >> 3;
+    int o_lane = 2 * (lane & 7);
+    lat_for<3>([&](auto Qc) {
+        constexpr int q = Qc;
+        o_lane |= ((qq >> q) & 1) << lat_line(LAY, LVL, q).ob;
+    });
+    const unsigned ra = lds0 + 8u * (unsigned)(17 * qq + 2 * (lane & 7));
+    const unsigned yo = (unsigned)o_lane;
+    lat_for<4>([&](auto Rc) {
+        constexpr int rho = Rc;
+        lat_for<16>([&](auto Vc) {
+            constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
+            lds_wr<8 * lat_emit_slot_reg(LAY, LVL, r)>(wa, x[r] * gf[lat_emit_pc_reg(LAY, LVL, r)]);
+        });
+        lat_for<2>([&](auto HH) {
+            constexpr int hh = HH;
+            double v[8];
+            lat_for<4>([&](auto I) {
+                constexpr int i = 4 * hh + I;
+                v[2 * I] = lds_rd<8 * (17 * 8 * i)>(ra);
+                v[2 * I + 1] = lds_rd<8 * (17 * 8 * i + 1)>(ra);
+            });
+            lat_wait8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            lat_for<4>([&](auto I) {
+                constexpr int i = 4 * hh + I;
+                lat_d2 o;
+                o.x = v[2 * I];
+                o.y = v[2 * I + 1];
+                lat_st2w(lat_sbase(ycol + lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i)) + yo, o);
+            });
+        });
+    });
+}
+
+// the three layout changes of the forward direction, shared by wpt and wpd
+__device__ __forceinline__ void lat_t2(double (&a)[64], double (&bb)[64], unsigned lds0, int lane)
+{
+    const int sw = lane ^ ((lane >> 5) << 1);
+    const unsigned wa0 = lds0 + 8u * sw, wa1 = lds0 + 8u * (sw ^ 1);
+    const int H = lane & 15, p10 = lane >> 4;
+    const int lam0 = 4 * H, sg = (p10 & 1) | ((lam0 >> 5) << 1);
+    unsigned ra[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) ra[h] = lds0 + 8u * (64 * p10 + ((lam0 + h) ^ sg));
+    lat_for<4>([&](auto Fq) {
+        constexpr int f = Fq;
+        lat_for<16>([&](auto Jq) {
+            constexpr int j = Jq;
+            lds_wr<8 * 64 * j>((j & 1) ? wa1 : wa0, a[16 * f + j]);
+        });
+        double t[16];
+        lat_for<16>([&](auto Q) {
+            constexpr int h = Q / 4, g = Q % 4;
+            t[Q] = lds_rd<8 * 256 * g>(ra[h]);
+        });
+        lat_wait16<0>(t);
+        lat_for<16>([&](auto Q) {
+            constexpr int h = Q / 4, g = Q % 4;
+            bb[16 * h + 4 * f + g] = t[Q];
+        });
+    });
+}
+__device__ __forceinline__ void lat_t3(double (&bb)[64], double (&c)[64], unsigned lds0, int lane)
+{
+    const unsigned wa = lds0 + 8u * (lane + (lane >> 5));
+    const unsigned ra = lds0 + 8u * (66 * (lane >> 2) + 16 * (lane & 1) + 33 * ((lane >> 1) & 1));
+    lat_for<4>([&](auto Fq) {
+        constexpr int f = Fq;
+        lat_for<16>([&](auto Jq) {
+            constexpr int j = Jq;
+            lds_wr<8 * 66 * j>(wa, bb[16 * f + j]);
+        });
+        double t[16];
+        lat_for<16>([&](auto Hq) {
+            constexpr int H = Hq;
+            t[H] = lds_rd<8 * H>(ra);
+        });
+        lat_wait16<0>(t);
+        lat_for<16>([&](auto Hq) {
+            constexpr int H = Hq;
+            c[4 * H + f] = t[H];
+        });
+    });
+}
+
+// wpd!(y, x, wt, L) DWT.jl:131-161 / wpdall dwt/dwt_all.jl:260-282 for 4096-sample Float64 signals: y is (4096, L+1, batch)
+template <int NS, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpd_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, int64_t batch, WxLatW cw)
+{
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int64_t sig = blockIdx.x;
+    const double *xs = x + sig * 4096;
+    double *ys = y + sig * 4096 * (int64_t)(L + 1);
+    const WxLat &cf = cw.c;
+    double a[64];
+    {
+        lat_d2 r[32];
+        const unsigned xo = 64u * (lane >> 3) + 2u * (lane & 7);
+        lat_for<32>([&](auto Q) {
+            constexpr int hi3 = Q / 4, f = Q % 4;
+            r[Q] = lat_ld2(lat_sbase(xs + 512 * hi3 + 16 * f) + xo);
+        });
+        // column 0 of the table is the signal (DWT.jl:145)
+        lat_for<32>([&](auto Q) {
+            constexpr int hi3 = Q / 4, f = Q % 4;
+            lat_st2w(lat_sbase(ys + 512 * hi3 + 16 * f) + xo, r[Q]);
+        });
+        const unsigned wa = lds0 + 8u * (17u * (lane >> 3) + 2u * (lane & 7)), ra = lds0 + 8u * 17u * lane;
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<8>([&](auto Hq) {
+                constexpr int hi3 = Hq;
+                lds_wr<8 * (136 * hi3)>(wa, r[4 * hi3 + f].x);
+                lds_wr<8 * (136 * hi3 + 1)>(wa, r[4 * hi3 + f].y);
+            });
+            double t[16];
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                t[m] = lds_rd<8 * m>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                a[16 * f + m] = t[m];
+            });
+        });
+    }
+    lat_level<0, 6, NS, false>(a, cf);
+    lat_emit<0, 1>(a, lds0, ys + 4096 * 1, lane, cw);
+    if (L < 2) return;
+    lat_level<1, 6, NS, false>(a, cf);
+    lat_emit<0, 2>(a, lds0, ys + 4096 * 2, lane, cw);
+    if (L < 3) return;
+    double bb[64];
+    lat_t2(a, bb, lds0, lane);
+    lat_level<0, 4, NS, false>(bb, cf);
+    lat_emit<2, 3>(bb, lds0, ys + 4096 * 3, lane, cw);
+    if (L < 4) return;
+    lat_level<1, 4, NS, false>(bb, cf);
+    lat_emit<2, 4>(bb, lds0, ys + 4096 * 4, lane, cw);
+    if (L < 5) return;
+    lat_level<2, 4, NS, false>(bb, cf);
+    lat_emit<2, 5>(bb, lds0, ys + 4096 * 5, lane, cw);
+    if (L < 6) return;
+    lat_level<3, 4, NS, false>(bb, cf);
+    lat_emit<2, 6>(bb, lds0, ys + 4096 * 6, lane, cw);
+    if (L < 7) return;
+    double c[64];
+    lat_t3(bb, c, lds0, lane);
+    lat_level<0, 0, NS, false>(c, cf);
+    lat_emit<6, 7>(c, lds0, ys + 4096 * 7, lane, cw);
+    if (L < 8) return;
+    lat_level<1, 0, NS, false>(c, cf);
+    lat_emit<6, 8>(c, lds0, ys + 4096 * 8, lane, cw);
+    if (L < 9) return;
+    lat_level<2, 0, NS, false>(c, cf);
+    lat_emit<6, 9>(c, lds0, ys + 4096 * 9, lane, cw);
+    if (L < 10) return;
+    lat_level<3, 0, NS, false>(c, cf);
+    lat_emit<6, 10>(c, lds0, ys + 4096 * 10, lane, cw);
+    if (L < 11) return;
+    lat_level<4, 0, NS, false>(c, cf);
+    lat_emit<6, 11>(c, lds0, ys + 4096 * 11, lane, cw);
+    if (L < 12) return;
+    lat_level<5, 0, NS, false>(c, cf);
+    lat_emit<6, 12>(c, lds0, ys + 4096 * 12, lane, cw);
+}
+
 // ---------------------------------------------------------------- inverse
 template <int NS, int WPE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_f64(
@@ -706,6 +1009,41 @@ static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n
 #undef WX_GO
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wx_set_hip_error(e, "lattice wpt launch", __FILE__, __LINE__);
+    return 1;
+}
+
+// wpd: 0 = not applicable, 1 = launched, < 0 = error
+int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
+{
+    static const bool off = (getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0) ||
+                            (getenv("WX_LATTICE_WPD") && atoi(getenv("WX_LATTICE_WPD")) == 0);
+    if (off || n != 4096 || L < 1 || L > 12 || filt.F < 4 || batch <= 0 || batch > 0x7fffffff) return 0;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
+    WxLatW cw;
+    if (!wx_lattice_factor(filt, L, false, &cw.c)) return 0;
+    // g^l for every level (g0 = g^L, g2 = g^-2): g = (g2)^(-1/2) with the sign of g0's L-th root
+    {
+        const long double g2 = cw.c.g2;
+        long double g = 1 / sqrtl(g2);
+        // the sign of g: recompute the product of the cosines
+        WxLat tmp;
+        if (!wx_lattice_factor(filt, 1, false, &tmp)) return 0;
+        g = tmp.g0;
+        long double acc = 1;
+        for (int l = 0; l <= 12; ++l) { cw.gl[l] = (double)acc; acc *= g; }
+    }
+    // built for 2 wavefronts per SIMD (174-178 registers, no spills; the 3-wavefront build spills and is 1.5 % slower)
+#define WX_GOW(NSS)                                                                                                 \
+    case NSS:                                                                                                       \
+        hipLaunchKernelGGL((k_lat_wpd_f64<NSS, 2>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L, batch, cw);     \
+        break;
+    switch (filt.F / 2) {
+        WX_GOW(2) WX_GOW(3) WX_GOW(4) WX_GOW(5) WX_GOW(6) WX_GOW(8) WX_GOW(9) WX_GOW(10)
+    default: return 0;
+    }
+#undef WX_GOW
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wx_set_hip_error(e, "lattice wpd launch", __FILE__, __LINE__);
     return 1;
 }
 
