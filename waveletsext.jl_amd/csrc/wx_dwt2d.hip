@@ -466,6 +466,21 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
     int64_t S = sub_env;
     if (S <= 0 || S >= batch) S = batch;
     if (!inverse && in_img != mn) return wx_set_error(WX_EUNSUPPORTED, "fast 2-D forward needs a dense input");
+    if constexpr (sizeof(T) == 4) {
+        // 512 x 512 Float32, depth 6: the transposing lattice kernel applied twice (wx_lattice2d.hip)
+        if (wx_lattice2d_ok(m, n, L, filt, sizeof(T)) && in_img == mn) {
+            if (getenv("WX_LATTICE2D_DEBUG")) {                  // diagnostics: one pass only, straight into y
+                const int rd = wx_lattice2d_colT_f32((const float *)x, (float *)y, batch, filt, inverse, st);
+                return rd == 1 ? WX_OK : WX_EHIP;
+            }
+            const int r1 = wx_lattice2d_colT_f32((const float *)x, (float *)tmp, batch, filt, inverse, st);
+            if (r1 < 0) return r1;
+            if (r1 == 1) {
+                const int r2 = wx_lattice2d_colT_f32((const float *)tmp, (float *)y, batch, filt, inverse, st);
+                return r2 == 1 ? WX_OK : (r2 < 0 ? r2 : wx_set_error(WX_EHIP, "lattice2d: second pass refused"));
+            }
+        }
+    }
     for (int64_t b0 = 0, k = 0; b0 < batch; b0 += S, ++k) {
         const int64_t nb = (batch - b0 < S) ? batch - b0 : S;
         T *ring = (S == batch) ? tmp : tmp + (k & 1) * S * mn;

@@ -974,6 +974,17 @@ static bool wx_lattice_factor(const WxFilt &filt, int L, bool inverse, WxLat *ou
     return std::isfinite(out->g0) && fabsl(gL) > 1e-60L && fabsl(gL) < 1e60L;
 }
 
+// the factorisation for other translation units (wx_lattice2d.hip): p[j], kap[j] (j < F/2), g0 = g^(+-L), g2 = g^(-+2)
+bool wx_lattice_coeffs(const WxFilt &filt, int L, bool inverse, double *p, double *kap, double *g0, double *g2)
+{
+    WxLat c;
+    if (!wx_lattice_factor(filt, L, inverse, &c)) return false;
+    for (int j = 0; j < WX_LAT_MAXS; ++j) { p[j] = c.p[j]; kap[j] = c.kap[j]; }
+    *g0 = c.g0;
+    *g2 = c.g2;
+    return true;
+}
+
 // 0 = not applicable (the caller takes the general kernels), 1 = launched, < 0 = HIP error code of the C ABI
 static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                              const WxFilt &filt, hipStream_t st)

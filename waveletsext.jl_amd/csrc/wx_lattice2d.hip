@@ -1,0 +1,351 @@
+// wx_lattice2d.hip -- 2-D full-tree packets of 512 x 512 Float32 images (depth 6) as two applications of ONE kernel: a
+// lattice transform down 32 contiguous columns in registers whose result is stored TRANSPOSED.
+//
+// Reference semantics: 2-D wpt / iwpt by level (DWT.jl:500-548, 662-710 over dwt/dwt_one_level.jl:319-354, 401-436); a
+// full tree of depth L is separable: the 1-D packet transform down every column, then along every row (§4.5 of DESIGN.md).
+// The round-1 path runs the row pass out of LDS strips (LDS-issue bound, 2.5 TB/s) and the column pass one wavefront per
+// column (latency bound).  Here both passes are the same contiguous-signal kernel: it reads the columns of the image
+// (contiguous), transforms them with the rotation lattice of wx_lattice.hip -- v_pk_fma_f32 on pairs of adjacent columns,
+// 16 columns = 4096 Float32 pairs per wavefront, the same register layouts A and B and the same intra-wavefront LDS
+// exchanges as the Float64 kernel -- and writes Z[j + 512 o(i)]: position o(i) of the packet order becomes the column,
+// the column index j the contiguous dimension.  The second application transforms the former rows and restores the
+// orientation.  A workgroup of two wavefronts covers 32 columns = one 128-byte line of the transposed image per row;
+// the transposition goes through LDS in four rounds of 128 rows (two register bits fixed per round).
+//
+// Halo: the columns of a wavefront are independent periodic sequences of 512 samples: in layout A (reg i[5:0]) the
+// neighbouring chunk is the next of 8 lanes (cyclic: two DPP moves and a select), in layout B (reg i[7:2]) the other of 2
+// lanes (quad_perm).  Depth 6 needs levels on index bits 0..5 only: A takes 0-1, B takes 2-5.
+#include "wx_common.h"
+#include "wx_kernels.h"
+#include <cstdlib>
+#include <utility>
+
+bool wx_lattice_coeffs(const WxFilt &filt, int L, bool inverse, double *p, double *kap, double *g0, double *g2);
+
+#define WX_L2_MAXS 10
+#define WX_L2_WIN 1104        // 8-byte slots of one wavefront's exchange window
+
+struct WxLat2 {
+    float p[WX_L2_MAXS];
+    float kap[WX_L2_MAXS];
+    float g0, g2;
+};
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const float __attribute__((address_space(1))) *l2_gc;
+typedef float __attribute__((address_space(1))) *l2_gm;
+
+__device__ __forceinline__ l2_gc l2_sbase(const float *p)
+{
+    l2_gc g = (l2_gc)p;
+    asm("" : "+s"(g));
+    return g;
+}
+__device__ __forceinline__ l2_gm l2_sbase(float *p)
+{
+    l2_gm g = (l2_gm)p;
+    asm("" : "+s"(g));
+    return g;
+}
+template <int... I, typename F> __device__ __forceinline__ void l2_for_impl(std::integer_sequence<int, I...>, F &&f)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void l2_for(F &&f)
+{
+    l2_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+template <int OFF> __device__ __forceinline__ void l2_wr32(unsigned addr, float v)
+{
+    asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void l2_wr64(unsigned addr, f2 v)
+{
+    const double d = __builtin_bit_cast(double, v);
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(d), "n"(OFF) : "memory");
+}
+// the value of a pending LDS read stays an untouched 64-bit register pair until the wait: turning it into a float2 first
+// lets the compiler move its halves (it does not know the data has not landed) -- only l2_wait16 hands out float2
+template <int OFF> __device__ __forceinline__ double l2_rd64(unsigned addr)
+{
+    double d;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+    return d;
+}
+__device__ __forceinline__ void l2_wait8(double &a, double &b, double &c, double &d, double &e, double &f, double &g, double &h)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "memory");
+}
+__device__ __forceinline__ void l2_wait16(double (&x)[16])
+{
+    l2_wait8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
+    l2_wait8(x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15]);
+}
+// keeps a coefficient pair in vector registers (see the note at l2_level)
+__device__ __forceinline__ void l2_vgpr(f2 &v)
+{
+    double d = __builtin_bit_cast(double, v);
+    asm volatile("" : "+v"(d));
+    v = __builtin_bit_cast(f2, d);
+}
+template <int CTRL> __device__ __forceinline__ int l2_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+
+// value held by the lane that owns the chunk D places further along the same column; HALO 3: the chunks of a column are
+// the 8 lanes that share lane >> 3 (cyclic); HALO 1: the 2 lanes lane, lane ^ 1
+template <int HALO, int D> __device__ __forceinline__ f2 l2_nbr(f2 v, bool edge_hi, bool edge_lo)
+{
+    if constexpr (D == 0) return v;
+    else {
+        // the element travels as one 64-bit register pair (two 32-bit DPP moves), exactly like the Float64 kernel's halo:
+        // per-component code on the float2 was merged by the compiler into one move for both halves
+        const double dv = __builtin_bit_cast(double, v);
+        const int lo = __double2loint(dv), hi = __double2hiint(dv);
+        int rlo, rhi;
+        if constexpr (HALO == 1) {
+            if constexpr ((D & 1) == 0) return v;
+            rlo = l2_dpp<0xB1>(lo);                                   // quad_perm [1,0,3,2]
+            rhi = l2_dpp<0xB1>(hi);
+        } else {
+            static_assert(D == 1 || D == -1, "layout A moves one chunk");
+            if constexpr (D > 0) {
+                // lanes 0..6 of a group of 8 take lane + 1 (row_shl:1), lane 7 takes lane - 7 (row_shr:7)
+                const int alo = l2_dpp<0x101>(lo), ahi = l2_dpp<0x101>(hi);
+                const int blo = l2_dpp<0x117>(lo), bhi = l2_dpp<0x117>(hi);
+                rlo = edge_hi ? blo : alo;
+                rhi = edge_hi ? bhi : ahi;
+            } else {
+                const int alo = l2_dpp<0x111>(lo), ahi = l2_dpp<0x111>(hi);
+                const int blo = l2_dpp<0x107>(lo), bhi = l2_dpp<0x107>(hi);
+                rlo = edge_lo ? blo : alo;
+                rhi = edge_lo ? bhi : ahi;
+            }
+        }
+        return __builtin_bit_cast(f2, __hiloint2double(rhi, rlo));
+    }
+}
+
+// one packet level on register-index bit K (see lat_level of wx_lattice.hip); both halves of an element (two adjacent
+// columns) take the same rotation: v_pk_fma_f32
+template <int K, int HALO, int NS, bool INV> __device__ __forceinline__ void l2_level(f2 (&x)[64], const WxLat2 &cf, int lane)
+{
+    constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
+    auto U = [](int s, int m) { return s + ((2 * m) << K); };
+    const bool edge_hi = (lane & 7) == 7, edge_lo = (lane & 7) == 0;
+    auto shift = [&](auto SHc) {
+        constexpr int SH = decltype(SHc)::value;
+        if constexpr (SH != 0) {
+#pragma unroll
+            for (int s = 0; s < NSEQ; ++s) {
+                f2 old[M];
+#pragma unroll
+                for (int m = 0; m < M; ++m) old[m] = x[U(s, m) + S];
+                l2_for<M>([&](auto Mc) {
+                    constexpr int m = Mc;
+                    constexpr int g = m + SH;
+                    constexpr int d = (g >= 0) ? g / M : -((-g + M - 1) / M);
+                    constexpr int src = g - d * M;
+                    x[U(s, m) + S] = l2_nbr<HALO, d>(old[src], edge_hi, edge_lo);
+                });
+            }
+        }
+    };
+    constexpr bool one_shot = (HALO == 1) || (NS - 1 <= M);
+    if constexpr (!INV) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            f2 pj = {cf.p[j], cf.p[j]}, kj = {-cf.kap[j], -cf.kap[j]};
+            l2_vgpr(pj);
+            l2_vgpr(kj);
+#pragma unroll
+            for (int s = 0; s < NSEQ; ++s)
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    x[U(s, m)] = __builtin_elementwise_fma(pj, x[U(s, m) + S], x[U(s, m)]);
+                    x[U(s, m) + S] = __builtin_elementwise_fma(kj, x[U(s, m)], x[U(s, m) + S]);
+                }
+            if (j + 1 < NS) shift(std::integral_constant<int, 1>{});
+        }
+        if constexpr (one_shot) shift(std::integral_constant<int, -(NS - 1)>{});
+        else {
+#pragma unroll
+            for (int j = 0; j + 1 < NS; ++j) shift(std::integral_constant<int, -1>{});
+        }
+    } else {
+        if constexpr (one_shot) shift(std::integral_constant<int, NS - 1>{});
+        else {
+#pragma unroll
+            for (int j = 0; j + 1 < NS; ++j) shift(std::integral_constant<int, 1>{});
+        }
+#pragma unroll
+        for (int j = NS - 1; j >= 0; --j) {
+            f2 pj = {-cf.p[j], -cf.p[j]}, kj = {cf.kap[j], cf.kap[j]};
+            l2_vgpr(pj);
+            l2_vgpr(kj);
+#pragma unroll
+            for (int s = 0; s < NSEQ; ++s)
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    x[U(s, m) + S] = __builtin_elementwise_fma(kj, x[U(s, m)], x[U(s, m) + S]);
+                    x[U(s, m)] = __builtin_elementwise_fma(pj, x[U(s, m) + S], x[U(s, m)]);
+                }
+            if (j > 0) shift(std::integral_constant<int, -1>{});
+        }
+    }
+}
+
+// A (reg i[5:0], lane i[8:6] | cp << 3)  ->  B (reg i[7:2], lane (i8 | cp << 1) | i[1:0] << 4): exchange T2 of
+// tools/lattice_lds_maps.py (the lane numbers are those of the Float64 kernel with p[11:9] = cp)
+__device__ __forceinline__ void l2_t2(f2 (&a)[64], f2 (&bb)[64], unsigned lds0, int lane)
+{
+    const int sw = lane ^ ((lane >> 5) << 1);
+    const unsigned wa0 = lds0 + 8u * sw, wa1 = lds0 + 8u * (sw ^ 1);
+    const int H = lane & 15, p10 = lane >> 4;
+    const int lam0 = 4 * H, sg = (p10 & 1) | ((lam0 >> 5) << 1);
+    unsigned ra[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) ra[h] = lds0 + 8u * (64 * p10 + ((lam0 + h) ^ sg));
+    l2_for<4>([&](auto Fq) {
+        constexpr int f = Fq;
+        l2_for<16>([&](auto Jq) {
+            constexpr int j = Jq;
+            l2_wr64<8 * 64 * j>((j & 1) ? wa1 : wa0, a[16 * f + j]);
+        });
+        double t[16];
+        l2_for<16>([&](auto Q) {
+            constexpr int h = Q / 4, g = Q % 4;
+            t[Q] = l2_rd64<8 * 256 * g>(ra[h]);
+        });
+        l2_wait16(t);
+        l2_for<16>([&](auto Q) {
+            constexpr int h = Q / 4, g = Q % 4;
+            bb[16 * h + 4 * f + g] = __builtin_bit_cast(f2, t[Q]);
+        });
+    });
+}
+
+// forward: src image (column j = 512 contiguous samples at src + 512 j) -> dst image transposed and in packet order:
+// dst[j + 512 o(i)], o(i) = bitreverse6(i[5:0]) << 3 | i[8:6].  grid (16, images), 128 threads.
+template <int NS>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lat2d_colT_f32(
+    const float *__restrict__ src, float *__restrict__ dst, int64_t img, WxLat2 cf)
+{
+    __shared__ double lds[2 * WX_L2_WIN];
+    const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
+    const float *simg = src + img * blockIdx.y;
+    float *dimg = dst + img * blockIdx.y;
+    const int j0 = 32 * blockIdx.x + 16 * wave;
+    f2 a[64];
+    {
+        // loads: instruction (cp, i7, i8) covers 8 complete lines: lane = sub | h << 3 | i5 << 4 | i6 << 5 holds samples
+        // i = 256 i8 + 128 i7 + 64 i6 + 32 i5 + 4 sub + {0..3} of column 2 cp + h
+        const int sub = lane & 7, h = (lane >> 3) & 1, i5 = (lane >> 4) & 1, i6 = lane >> 5;
+        const unsigned lo = 512u * h + 64u * i6 + 32u * i5 + 4u * sub;
+        f4 r[32];
+        l2_for<32>([&](auto Q) {
+            constexpr int cp = Q >> 2, i7 = Q & 1, i8 = (Q >> 1) & 1;
+            r[Q] = *(const f4 __attribute__((address_space(1))) *)(l2_sbase(simg + (int64_t)(j0 + 2 * cp) * 512 + 256 * i8 + 128 * i7) + lo);
+        });
+        // T1: the two columns of a pair meet in one 8-byte slot (two ds_write_b32): slot = 17 lam + m, lam = i[8:6] | cp << 3,
+        // m = i[5:2]; round rho = i[1:0]
+        const unsigned wa = lds0 + 4u * (34u * i6 + 2u * sub + 16u * i5 + h), ra = lds0 + 8u * 17u * lane;
+        l2_for<4>([&](auto Rq) {
+            constexpr int rho = Rq;
+            l2_for<32>([&](auto Q) {
+                constexpr int cp = Q >> 2, i7 = Q & 1, i8 = (Q >> 1) & 1;
+                l2_wr32<4 * 34 * (2 * i7 + 4 * i8 + 8 * cp)>(wa, r[Q][rho]);
+            });
+            double t[16];
+            l2_for<16>([&](auto M) {
+                constexpr int m = M;
+                t[m] = l2_rd64<8 * m>(ra);
+            });
+            l2_wait16(t);
+            l2_for<16>([&](auto M) {
+                constexpr int m = M;
+                a[4 * m + rho] = __builtin_bit_cast(f2, t[m]);
+            });
+        });
+    }
+    l2_level<0, 3, NS, false>(a, cf, lane);
+    l2_level<1, 3, NS, false>(a, cf, lane);
+    f2 bb[64];
+    l2_t2(a, bb, lds0, lane);
+    l2_level<0, 1, NS, false>(bb, cf, lane);
+    l2_level<1, 1, NS, false>(bb, cf, lane);
+    l2_level<2, 1, NS, false>(bb, cf, lane);
+    l2_level<3, 1, NS, false>(bb, cf, lane);
+    // gains: a leaf whose path took k detail branches carries g^(2k - 6); path bits i[1:0] sit in the lane, i[5:2] in the
+    // register index
+    float gf[5];
+    {
+        float b = cf.g0;
+        b = (lane & 16) ? b * cf.g2 : b;
+        b = (lane & 32) ? b * cf.g2 : b;
+        gf[0] = b;
+#pragma unroll
+        for (int m = 1; m < 5; ++m) gf[m] = gf[m - 1] * cf.g2;
+    }
+    // transposed store: round rho fixes (i2, i3) = register bits 0, 1 -> 128 of the 512 rows o(i); a row of the
+    // workgroup is 16 column pairs = 128 bytes.  slot = 16 row + (pair ^ 8 i8)
+    const int i8 = lane & 1, cp = (lane >> 1) & 7, i0 = (lane >> 4) & 1, i1 = lane >> 5;
+    const unsigned wa = ldsb + 8u * (16u * ((i8 << 2) | (i1 << 5) | (i0 << 6)) + (unsigned)((8 * wave + cp) ^ (8 * i8)));
+    __syncthreads();                                      // the exchange windows are reused as the row buffer
+    l2_for<4>([&](auto Rq) {
+        constexpr int rho = Rq;
+        l2_for<16>([&](auto Vq) {
+            constexpr int v = Vq;                         // v bits: i4, i5, i6, i7
+            constexpr int r = rho + 4 * v;
+            constexpr int rowreg = ((v & 1) << 4) | (((v >> 1) & 1) << 3) | (((v >> 3) & 1) << 1) | ((v >> 2) & 1);
+            constexpr int pc = (rho & 1) + (rho >> 1) + (v & 1) + ((v >> 1) & 1);
+            f2 val = bb[r];
+            val.x *= gf[pc];
+            val.y *= gf[pc];
+            l2_wr64<8 * 16 * rowreg>(wa, val);
+        });
+        __syncthreads();
+        l2_for<8>([&](auto Kq) {
+            constexpr int k = Kq;
+            const int rr = 16 * k + (tid >> 3), u = tid & 7;
+            const int o2 = (rr >> 2) & 1;
+            const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * (16u * rr + (unsigned)((2 * u) ^ (8 * o2))));
+            const int o = (rr & 31) | ((rho >> 1) << 5) | ((rho & 1) << 6) | ((rr >> 5) << 7);
+            *(f4 __attribute__((address_space(1))) *)(l2_sbase(dimg + 32 * blockIdx.x) + (unsigned)(512 * o + 4 * u)) = val;
+        });
+        __syncthreads();
+    });
+}
+
+}  // namespace
+
+bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz)
+{
+    static const bool off = getenv("WX_LATTICE2D") && atoi(getenv("WX_LATTICE2D")) == 0;
+    return !off && esz == 4 && m == 512 && n == 512 && L == 6 && filt.F >= 4 && filt.F / 2 <= WX_L2_MAXS;
+}
+
+// one transposing pass over `batch` images: 0 = not applicable, 1 = launched, < 0 = error
+int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t batch, const WxFilt &filt, bool inverse, hipStream_t st)
+{
+    if (inverse) return 0;
+    double p[WX_L2_MAXS], kap[WX_L2_MAXS], g0, g2;
+    if (!wx_lattice_coeffs(filt, 6, false, p, kap, &g0, &g2)) return 0;
+    WxLat2 cf;
+    for (int j = 0; j < WX_L2_MAXS; ++j) { cf.p[j] = (float)p[j]; cf.kap[j] = (float)kap[j]; }
+    cf.g0 = (float)g0;
+    cf.g2 = (float)g2;
+    if (batch > 65535 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return 0;
+#define WX_GO2(NSS) case NSS: hipLaunchKernelGGL(k_lat2d_colT_f32<NSS>, dim3(16, (unsigned)batch), dim3(128), 0, st, src, dst, (int64_t)512 * 512, cf); break;
+    switch (filt.F / 2) {
+        WX_GO2(2) WX_GO2(4)
+    default: return 0;
+    }
+#undef WX_GO2
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wx_set_hip_error(e, "lattice2d launch", __FILE__, __LINE__);
+    return 1;
+}
