@@ -468,7 +468,7 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
     if (!inverse && in_img != mn) return wx_set_error(WX_EUNSUPPORTED, "fast 2-D forward needs a dense input");
     if constexpr (sizeof(T) == 4) {
         // 512 x 512 Float32, depth 6: the transposing lattice kernel applied twice (wx_lattice2d.hip)
-        if (wx_lattice2d_ok(m, n, L, filt, sizeof(T)) && in_img == mn) {
+        if (wx_lattice2d_ok(m, n, L, filt, sizeof(T)) && in_img == mn && !(inverse && getenv("WX_LATTICE2D_NOINV"))) {
             if (getenv("WX_LATTICE2D_DEBUG")) {                  // diagnostics: one pass only, straight into y
                 const int rd = wx_lattice2d_colT_f32((const float *)x, (float *)y, batch, filt, inverse, st);
                 return rd == 1 ? WX_OK : WX_EHIP;

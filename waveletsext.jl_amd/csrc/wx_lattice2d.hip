@@ -91,6 +91,13 @@ __device__ __forceinline__ void l2_vgpr(f2 &v)
     asm volatile("" : "+v"(d));
     v = __builtin_bit_cast(f2, d);
 }
+// workgroup barrier after inline-asm LDS stores: the compiler does not count them, so the wait that makes them visible to
+// the other wavefront is explicit (without it the transposed store raced: one image in a few hundred came out wrong)
+__device__ __forceinline__ void l2_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+    __syncthreads();
+}
 template <int CTRL> __device__ __forceinline__ int l2_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 
 // value held by the lane that owns the chunk D places further along the same column; HALO 3: the chunks of a column are
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // workgroup is 16 column pairs = 128 bytes.  slot = 16 row + (pair ^ 8 i8)
     const int i8 = lane & 1, cp = (lane >> 1) & 7, i0 = (lane >> 4) & 1, i1 = lane >> 5;
     const unsigned wa = ldsb + 8u * (16u * ((i8 << 2) | (i1 << 5) | (i0 << 6)) + (unsigned)((8 * wave + cp) ^ (8 * i8)));
-    __syncthreads();                                      // the exchange windows are reused as the row buffer
+    l2_barrier();                                      // the exchange windows are reused as the row buffer
     l2_for<4>([&](auto Rq) {
         constexpr int rho = Rq;
         l2_for<16>([&](auto Vq) {
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             val.y *= gf[pc];
             l2_wr64<8 * 16 * rowreg>(wa, val);
         });
-        __syncthreads();
+        l2_barrier();
         l2_for<8>([&](auto Kq) {
             constexpr int k = Kq;
             const int rr = 16 * k + (tid >> 3), u = tid & 7;
@@ -316,7 +323,128 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const int o = (rr & 31) | ((rho >> 1) << 5) | ((rho & 1) << 6) | ((rr >> 5) << 7);
             *(f4 __attribute__((address_space(1))) *)(l2_sbase(dimg + 32 * blockIdx.x) + (unsigned)(512 * o + 4 * u)) = val;
         });
-        __syncthreads();
+        l2_barrier();
+    });
+}
+
+// B -> A (exchange T2i of tools/lattice_lds_maps.py)
+__device__ __forceinline__ void l2_t2i(f2 (&bb)[64], f2 (&a)[64], unsigned lds0, int lane)
+{
+    const int H = lane & 15, p10 = lane >> 4;
+    unsigned wa[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+        wa[h] = lds0 + 8u * (((h ^ (H >> 2)) | ((H & 3) << 2) | (((H >> 2) & 1) << 4) | ((H >> 3) << 5)) + 64 * p10);
+    const int Ha = lane >> 2, ha = lane & 3;
+    const unsigned ra = lds0 + 8u * ((ha ^ (Ha >> 2)) | ((Ha & 3) << 2) | (((Ha >> 2) & 1) << 4) | ((Ha >> 3) << 5));
+    l2_for<4>([&](auto Fq) {
+        constexpr int f = Fq;
+        l2_for<16>([&](auto Q) {
+            constexpr int h = Q / 4, g = Q % 4;
+            l2_wr64<8 * 256 * g>(wa[h], bb[16 * h + 4 * f + g]);
+        });
+        double t[16];
+        l2_for<16>([&](auto Jq) {
+            constexpr int j = Jq;
+            t[j] = l2_rd64<8 * 64 * j>(ra);
+        });
+        l2_wait16(t);
+        l2_for<16>([&](auto Jq) {
+            constexpr int j = Jq;
+            a[16 * f + j] = __builtin_bit_cast(f2, t[j]);
+        });
+    });
+}
+
+// inverse: src image (column j = 512 contiguous packet coefficients, position o(i) = bitreverse6(i[5:0]) << 3 | i[8:6]) ->
+// dst image transposed, natural order: dst[j + 512 i].  grid (16, images), 128 threads.
+template <int NS>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lat2d_icolT_f32(
+    const float *__restrict__ src, float *__restrict__ dst, int64_t img, WxLat2 cf)
+{
+    __shared__ double lds[2 * WX_L2_WIN];
+    const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
+    const float *simg = src + img * blockIdx.y;
+    float *dimg = dst + img * blockIdx.y;
+    const int j0 = 32 * blockIdx.x + 16 * wave;
+    f2 bb[64];
+    {
+        // loads as in the forward kernel, in packet order: lane = sub | h << 3 | o5 << 4 | o6 << 5, instruction (cp, o7, o8);
+        // o8 = i0, o7 = i1, o6 = i2, o5 = i3, o4 = i4, o3 = i5, o2 = i8, o1 = i7, o0 = i6
+        const int sub = lane & 7, h = (lane >> 3) & 1, o5 = (lane >> 4) & 1, o6 = lane >> 5;
+        const unsigned lo = 512u * h + 64u * o6 + 32u * o5 + 4u * sub;
+        f4 r[32];
+        l2_for<32>([&](auto Q) {
+            constexpr int cp = Q >> 2, o7 = Q & 1, o8 = (Q >> 1) & 1;
+            r[Q] = *(const f4 __attribute__((address_space(1))) *)(l2_sbase(simg + (int64_t)(j0 + 2 * cp) * 512 + 256 * o8 + 128 * o7) + lo);
+        });
+        // into layout B (reg i[7:2], lane mu = i8 | cp << 1 | i0 << 4 | i1 << 5): round rho = o[1:0] = (i6, i7 << 1) fixes
+        // register bits 4, 5; slot = 17 mu + v, v = i2 | i3 << 1 | i4 << 2 | i5 << 3
+        const int i8 = sub & 1, i5 = (sub >> 1) & 1, i4 = sub >> 2;
+        const unsigned wa = lds0 + 4u * (34u * i8 + 2u * (o6 + 2u * o5 + 4u * i4 + 8u * i5) + h), ra = lds0 + 8u * 17u * lane;
+        // gains: the coefficient of a leaf whose path took k detail branches enters as coef * g^(2k - 6)
+        float gf[5];
+        {
+            float b = cf.g0;
+            b = (lane & 16) ? b * cf.g2 : b;
+            b = (lane & 32) ? b * cf.g2 : b;
+            gf[0] = b;
+#pragma unroll
+            for (int m = 1; m < 5; ++m) gf[m] = gf[m - 1] * cf.g2;
+        }
+        l2_for<4>([&](auto Rq) {
+            constexpr int rho = Rq;                       // rho bit 0 = o0 = i6, bit 1 = o1 = i7
+            l2_for<32>([&](auto Q) {
+                constexpr int cp = Q >> 2, i1 = Q & 1, i0 = (Q >> 1) & 1;
+                l2_wr32<4 * 34 * (2 * cp + 16 * i0 + 32 * i1)>(wa, r[Q][rho]);
+            });
+            double t[16];
+            l2_for<16>([&](auto V) {
+                constexpr int v = V;
+                t[v] = l2_rd64<8 * v>(ra);
+            });
+            l2_wait16(t);
+            l2_for<16>([&](auto V) {
+                constexpr int v = V;
+                constexpr int pc = (v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1) + ((v >> 3) & 1);
+                f2 e = __builtin_bit_cast(f2, t[v]);
+                e.x *= gf[pc];
+                e.y *= gf[pc];
+                bb[v + 16 * rho] = e;                     // register index i[7:2] = v | i6 << 4 | i7 << 5
+            });
+        });
+    }
+    l2_level<3, 1, NS, true>(bb, cf, lane);
+    l2_level<2, 1, NS, true>(bb, cf, lane);
+    l2_level<1, 1, NS, true>(bb, cf, lane);
+    l2_level<0, 1, NS, true>(bb, cf, lane);
+    f2 a[64];
+    l2_t2i(bb, a, lds0, lane);
+    l2_level<1, 3, NS, true>(a, cf, lane);
+    l2_level<0, 3, NS, true>(a, cf, lane);
+    // transposed store, natural row order: layout A (reg i[5:0], lane i[8:6] | cp << 3); round rho = i[5:4];
+    // row of the round rr = i[3:0] | i[8:6] << 4, slot = 16 rr + (pair ^ i[8:6] << 1)
+    const int i86 = lane & 7, cp = lane >> 3;
+    const unsigned wa = ldsb + 8u * (16u * (unsigned)(i86 << 4) + (unsigned)((8 * wave + cp) ^ (i86 << 1)));
+    l2_barrier();
+    l2_for<4>([&](auto Rq) {
+        constexpr int rho = Rq;
+        l2_for<16>([&](auto Vq) {
+            constexpr int v = Vq;                         // i[3:0]
+            l2_wr64<8 * 16 * v>(wa, a[v + 16 * rho]);
+        });
+        l2_barrier();
+        l2_for<8>([&](auto Kq) {
+            constexpr int k = Kq;
+            const int rr = 16 * k + (tid >> 3), u = tid & 7;
+            const int s86 = rr >> 4;
+            const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * (16u * rr + (unsigned)((2 * u) ^ (s86 << 1))));
+            const int i = (rr & 15) | (rho << 4) | (s86 << 6);
+            *(f4 __attribute__((address_space(1))) *)(l2_sbase(dimg + 32 * blockIdx.x) + (unsigned)(512 * i + 4 * u)) = val;
+        });
+        l2_barrier();
     });
 }
 
@@ -331,15 +459,20 @@ bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz
 // one transposing pass over `batch` images: 0 = not applicable, 1 = launched, < 0 = error
 int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t batch, const WxFilt &filt, bool inverse, hipStream_t st)
 {
-    if (inverse) return 0;
     double p[WX_L2_MAXS], kap[WX_L2_MAXS], g0, g2;
-    if (!wx_lattice_coeffs(filt, 6, false, p, kap, &g0, &g2)) return 0;
+    if (!wx_lattice_coeffs(filt, 6, inverse, p, kap, &g0, &g2)) return 0;
     WxLat2 cf;
     for (int j = 0; j < WX_L2_MAXS; ++j) { cf.p[j] = (float)p[j]; cf.kap[j] = (float)kap[j]; }
     cf.g0 = (float)g0;
     cf.g2 = (float)g2;
     if (batch > 65535 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return 0;
-#define WX_GO2(NSS) case NSS: hipLaunchKernelGGL(k_lat2d_colT_f32<NSS>, dim3(16, (unsigned)batch), dim3(128), 0, st, src, dst, (int64_t)512 * 512, cf); break;
+#define WX_GO2(NSS)                                                                                                       \
+    case NSS:                                                                                                            \
+        if (inverse)                                                                                                     \
+            hipLaunchKernelGGL(k_lat2d_icolT_f32<NSS>, dim3(16, (unsigned)batch), dim3(128), 0, st, src, dst, (int64_t)512 * 512, cf); \
+        else                                                                                                             \
+            hipLaunchKernelGGL(k_lat2d_colT_f32<NSS>, dim3(16, (unsigned)batch), dim3(128), 0, st, src, dst, (int64_t)512 * 512, cf); \
+        break;
     switch (filt.F / 2) {
         WX_GO2(2) WX_GO2(4)
     default: return 0;
