@@ -50,13 +50,13 @@ WORKLOADS = {
                         desc="north-star target with the Haar filter: wptall+iwptall 65536x4096 f64 haar L=10 "
                              "(Walsh-Hadamard kernels, wx_haar.hip)"),
     "cfg3": dict(kind="swpt", n=16384, batch=8192, chunk=64, wavelet="haar", L=12, dtype="f64",
-                 kernel="k_swt_fwd_multi_rc<double, 8, 8>",
-                 fwd_kernels=[("k_swt_fwd_multi<double, 8>", 2), ("k_swt_fwd_multi_rc<double, 8, 8>", 2)],
+                 kernel="k_haar_swpt6_fwd<1>", inv_kernel="k_haar_iswpt<5, 1>",
+                 fwd_kernels=[("k_swt_fwd_multi<double, 8>", 2), ("k_haar_swpt6_fwd<1>", 1)],
                  desc="BASELINE config 3: swptall+iswptall (average-based) 8192x16384 f64 haar L=12; the leaves exist one "
                       "resident chunk of 64 signals (32 GiB) at a time, a step loops over every chunk of the shard"),
     "cfg4": dict(kind="wpt2d", m=512, n=512, batch=4096, wavelet="db4", L=6, dtype="f32",
-                 kernel="k_rows_fused<float, 8, false, 4, 2>",
-                 fwd_kernels=[("k_fwd1d_inplace<float, 8, 64, false>", 1), ("k_rows_fused<float, 8, false, 4, 2>", 1)],
+                 kernel="k_lat2d_colT_f32<4>", inv_kernel="k_lat2d_icolT_f32<4>",
+                 fwd_kernels=[("k_lat2d_colT_f32<4>", 2)],
                  desc="BASELINE config 4: 2-D wptall+iwptall 4096 images 512x512 f32 db4 L=6"),
     "cfg5": dict(kind="acwpd_jbb", n=2048, batch=262144, chunk=2048, wavelet="coif6", L=11, dtype="f64",
                  kernel="k_acwpd_subtree_moments<5, 4, 9>",

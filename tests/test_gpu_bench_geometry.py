@@ -1,12 +1,17 @@
 """GPU parity at the EXACT signal geometry of the benchmarked configurations (size-dependent kernel dispatch: K-level
 fused passes, residue-class tiles, the D0 = 6 subtree kernel, chunk accumulation), batch reduced so that the oracle
 finishes in seconds.  Tolerances: 1e-10 relative (north_star), JBB trees bit-exact."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
 from helpers import relerr
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_config3_geometry_swpt_iswpt(wx, oracle):
@@ -90,3 +95,64 @@ def test_config5_geometry_moments_and_tree(wx, oracle, mode):
         assert (wx.bestbasis_treeselection(costs2, n) == tree_ref).all()
     finally:
         wx.set_force_generic(0)
+
+
+@pytest.mark.parametrize("wname", ["db2", "db4"])
+def test_config4_geometry_2d_lattice_matches_oracle(wx, oracle, wname):
+    """BASELINE config 4: 2-D wptall / iwptall of 512 x 512 Float32 images, L = 6 (dwt/dwt_all.jl:152-166, 210-225 over
+    Wavelets.jl's 2-D wpt by level) through the transposing lattice column kernels (csrc/wx_lattice2d.hip).  Float32:
+    tolerance 2e-6 x the largest coefficient (observed 5e-7; the reference's own Float32 rounding is of that size)."""
+    rng = np.random.default_rng(512)
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    x = np.asfortranarray(rng.standard_normal((512, 512, 3)).astype(np.float32))
+    exp = oracle.wptall(x.astype(np.float64), wt.qmf, 6)
+    got = wx.wptall(x, wt, 6)
+    assert got.dtype == np.float32
+    assert relerr(got.astype(np.float64), exp) <= 2e-6, wname
+    back = wx.iwptall(exp.astype(np.float32), wt, 6)
+    assert relerr(back.astype(np.float64), x.astype(np.float64)) <= 2e-6, wname
+
+
+def test_config4_every_image_of_a_large_batch_round_trips(wx):
+    """the two wavefronts of a 2-D lattice workgroup exchange columns through LDS; a missing wait before the workgroup
+    barrier once corrupted one image in a few hundred, so every image of several large batches is checked, repeatedly,
+    and the forward result must be identical from run to run"""
+    import torch
+    wt = wx.wavelet(wx.WT.db4)
+    for B in (256, 1024):
+        x = wx.jl_empty((512, 512, B), torch.float32, "cuda")
+        x.normal_(generator=torch.Generator(device="cuda").manual_seed(B))
+        y0 = wx.wptall(x, wt, 6)
+        for _ in range(4):
+            y = wx.wptall(x, wt, 6)
+            assert torch.equal(y, y0)
+            xr = wx.iwptall(y, wt, 6)
+            err = (xr - x).abs().amax(dim=(0, 1)) / x.abs().max()
+            assert float(err.max()) <= 2e-6, (B, int(err.argmax()), float(err.max()))
+        # orthonormal transform: the energy of every image is preserved
+        e0 = (x.double() ** 2).sum(dim=(0, 1))
+        e1 = (y0.double() ** 2).sum(dim=(0, 1))
+        assert float(((e1 - e0).abs() / e0).max()) <= 1e-5
+        del x, y, y0, xr
+
+
+def test_config4_lattice_and_lds_kernels_agree():
+    """the 2-D lattice path against the previous fused LDS kernels (WX_LATTICE2D=0, read once per process)"""
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path[:0] = [%r]\n"
+        "import waveletsext_jl_amd as wx\n"
+        "wt = wx.wavelet(wx.WT.db4); rng = np.random.default_rng(7)\n"
+        "x = np.asfortranarray(rng.standard_normal((512, 512, 4)).astype(np.float32))\n"
+        "y = wx.wptall(x, wt, 6); np.save(sys.argv[1], y); np.save(sys.argv[2], wx.iwptall(y, wt, 6))\n" % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        outs = []
+        for flag in ("1", "0"):
+            f1, f2 = os.path.join(d, "y%s.npy" % flag), os.path.join(d, "x%s.npy" % flag)
+            r = subprocess.run([sys.executable, "-c", code, f1, f2], env=dict(os.environ, WX_LATTICE2D=flag),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append((np.load(f1), np.load(f2)))
+        assert relerr(outs[0][0], outs[1][0]) <= 2e-6
+        assert relerr(outs[0][1], outs[1][1]) <= 2e-6
