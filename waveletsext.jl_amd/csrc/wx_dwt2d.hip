@@ -462,6 +462,9 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
     // the 256 MiB Infinity Cache between its write and its read.  Measured on config 4 (4096 images 512 x 512 Float32):
     // no gain at any S (forward 6.9 ms whole batch, 6.8 ms at S = 128, 7.7 ms at S = 32) -- the two passes are bound by
     // latency and LDS issue, not by HBM bandwidth, so halving the HBM traffic does not show; kept as a knob.
+    // Measured again with the lattice column kernels (each pass at ~61 % of HBM peak): step 6.79 ms whole batch, 7.18 ms at
+    // S = 96, 7.74 ms at S = 128, 8.7 ms at S = 64, 11.3 ms at S = 32 -- short launches lose more in ramp-up and tail than
+    // the cache saves.
     static const int64_t sub_env = getenv("WX_2D_SUB") ? atoll(getenv("WX_2D_SUB")) : 0;
     int64_t S = sub_env;
     if (S <= 0 || S >= batch) S = batch;
@@ -473,12 +476,16 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
                 const int rd = wx_lattice2d_colT_f32((const float *)x, (float *)y, batch, filt, inverse, st);
                 return rd == 1 ? WX_OK : WX_EHIP;
             }
-            const int r1 = wx_lattice2d_colT_f32((const float *)x, (float *)tmp, batch, filt, inverse, st);
-            if (r1 < 0) return r1;
-            if (r1 == 1) {
-                const int r2 = wx_lattice2d_colT_f32((const float *)tmp, (float *)y, batch, filt, inverse, st);
-                return r2 == 1 ? WX_OK : (r2 < 0 ? r2 : wx_set_error(WX_EHIP, "lattice2d: second pass refused"));
+            bool took = true;
+            for (int64_t b0 = 0; b0 < batch && took; b0 += S) {
+                const int64_t nb = (batch - b0 < S) ? batch - b0 : S;
+                const int r1 = wx_lattice2d_colT_f32((const float *)x + b0 * mn, (float *)tmp, nb, filt, inverse, st);
+                if (r1 < 0) return r1;
+                if (r1 == 0) { if (b0) return wx_set_error(WX_EHIP, "lattice2d: pass refused"); took = false; break; }
+                const int r2 = wx_lattice2d_colT_f32((const float *)tmp, (float *)y + b0 * mn, nb, filt, inverse, st);
+                if (r2 != 1) return r2 < 0 ? r2 : wx_set_error(WX_EHIP, "lattice2d: second pass refused");
             }
+            if (took) return WX_OK;
         }
     }
     for (int64_t b0 = 0, k = 0; b0 < batch; b0 += S, ++k) {
