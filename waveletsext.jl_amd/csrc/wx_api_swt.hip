@@ -325,7 +325,9 @@ static int api_acwpd_jbb_moments(const double *x, double *sum, double *sumsq, in
             if (D0 > 0) rc = wx_dev_swt_fwd<double>(dx + b0 * n, tab, n, D0, LAYOUT_WPD, bc, filt, &acf, st);
             else WX_HIP_CHECK(hipMemcpyAsync(tab, dx + b0 * n, sizeof(double) * n * bc, hipMemcpyDeviceToDevice, st));
             if (rc == WX_OK) rc = wx_dev_jbb_moments<double>(tab, dsum, dsq, nk_top, bc, acc, nullptr, 1, st);
-            if (rc == WX_OK) rc = wx_dev_acwpd_subtree_moments(tab, dsum, dsq, n, L, D0, bc, acf, acc, st);
+            if (rc == WX_OK)
+                rc = wx_acwpd_mfma_ok(n, L, D0) ? wx_dev_acwpd_subtree_mfma(tab, dsum, dsq, n, L, D0, bc, acf, acc, st)
+                                                : wx_dev_acwpd_subtree_moments(tab, dsum, dsq, n, L, D0, bc, acf, acc, st);
         }
         return io.finish(rc);
     }

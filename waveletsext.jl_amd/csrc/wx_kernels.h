@@ -77,6 +77,9 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
 
 // ---- fused acwpd + JBB moments (wx_jbb.hip) ----
 int wx_acwpd_fused_depth(int64_t n, int L, int F);
+bool wx_acwpd_mfma_ok(int64_t n, int L, int D0);                    // wx_acsubtree.hip: one wavefront per subtree, matrix pipe
+int wx_dev_acwpd_subtree_mfma(const double *top, double *sum, double *sumsq, int64_t n, int L, int D0, int64_t batch,
+                              const WxAcFilt &ac, int accumulate, hipStream_t st);
 int wx_dev_acwpd_subtree_moments(const double *top, double *sum, double *sumsq, int64_t n, int L, int D0,
                                  int64_t batch, const WxAcFilt &ac, int accumulate, hipStream_t st);
 
