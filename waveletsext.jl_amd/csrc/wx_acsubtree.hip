@@ -32,6 +32,18 @@
 #include "wx_host.h"
 
 typedef double wx_d4 __attribute__((ext_vector_type(4)));
+// a wave-uniform pointer kept in scalar registers: loads take the "scalar base + 32-bit lane byte offset" form
+typedef const char __attribute__((address_space(1))) *acs_gc;
+static __device__ __forceinline__ acs_gc acs_sbase(const double *p)
+{
+    acs_gc g = (acs_gc)p;
+    asm("" : "+s"(g));
+    return g;
+}
+static __device__ __forceinline__ double acs_ld(acs_gc base, unsigned boff)
+{
+    return *(const double __attribute__((address_space(1))) *)(base + boff);
+}
 
 static __device__ __forceinline__ double acs_sq(double v)
 {
@@ -104,14 +116,15 @@ void k_acwpd_subtree_mfma(const double *__restrict__ top, double *__restrict__ s
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int i = 2 * (g + 4 * t) + par;
-        offP[t] = (unsigned)(s * sig_stride) + (unsigned)(i << D0);
-        offS[t] = (unsigned)(s * sig_stride) + (unsigned)(((i + 1) & 31) << D0);
+        offP[t] = 8u * ((unsigned)(s * sig_stride) + (unsigned)(i << D0));               // bytes; < 2^32: 8 signals of the top table
+        offS[t] = 8u * ((unsigned)(s * sig_stride) + (unsigned)(((i + 1) & 31) << D0));
     }
     double P[4], S[4];
     {
         const bool ok = s < batch;
+        const acs_gc p = acs_sbase(src);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { P[t] = ok ? src[offP[t]] : 0.0; S[t] = ok ? src[offS[t]] : 0.0; }
+        for (int t = 0; t < 4; ++t) { P[t] = ok ? acs_ld(p, offP[t]) : 0.0; S[t] = ok ? acs_ld(p, offS[t]) : 0.0; }
     }
     const int w = 2 * g + par;
     const int wb0 = acs_wbase(w, s, 0), wb1 = acs_wbase(w, s, 1);
@@ -126,13 +139,7 @@ void k_acwpd_subtree_mfma(const double *__restrict__ top, double *__restrict__ s
     //   level 2 (node p2): owner = (2 p2 + (i >> 4)) * 8 + (i & 7), e = (i >> 3) & 1, slot = 64 + 64 e + owner
     //   level 3 (node p3): owner = 8 p3 + (i & 7), m = i >> 3, slot = 64 m + owner
     for (int64_t sig0 = 0; sig0 < batch; sig0 += 8) {
-        wx_d4 X0 = {P[0], P[1], P[2], P[3]}, XS = {S[0], S[1], S[2], S[3]};
-        {   // next block's samples travel while this one is processed
-            const bool ok = sig0 + 8 + s < batch;
-            const double *p = src + (sig0 + 8) * sig_stride;                  // uniform
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { P[t] = ok ? p[offP[t]] : 0.0; S[t] = ok ? p[offS[t]] : 0.0; }
-        }
+        const wx_d4 X0 = {P[0], P[1], P[2], P[3]}, XS = {S[0], S[1], S[2], S[3]};
         // ---- level 0 -> the two depth-1 nodes
         wx_d4 acc = {0, 0, 0, 0};
 #pragma unroll
@@ -158,7 +165,19 @@ void k_acwpd_subtree_mfma(const double *__restrict__ top, double *__restrict__ s
         for (int p2 = 0; p2 < 4; ++p2)
 #pragma unroll
             for (int t = 0; t < 4; ++t) ACS_W(64 + 64 * (t & 1) + (2 * p2 + (t >> 1)) * 8) = L2[p2][t];
-        // ---- owners of the depth-1 and depth-2 coefficients add the 8 signals in order
+        // ---- level 2 -> the eight depth-3 nodes: four independent product chains, interleaved; while the matrix pipe works
+        // the owners of the depth-1 and depth-2 coefficients add the 8 signals in order
+        wx_d4 a3[2];
+        auto level2_pair = [&](int pp) {
+            a3[0] = a3[1] = wx_d4{0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double At = ACS_A(2, t);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) a3[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(At, L2[2 * pp + k][t], a3[k], 0, 0, 0);
+            }
+        };
+        level2_pair(0);
         {
             double2 v1[4], v2[2][4];
 #pragma unroll
@@ -177,17 +196,30 @@ void k_acwpd_subtree_mfma(const double *__restrict__ top, double *__restrict__ s
                 for (int e = 0; e < 2; ++e) { a2s[e] += v2[e][c].y; a2q[e] += acs_sq(v2[e][c].y); }
             }
         }
-        // ---- level 2 -> the eight depth-3 nodes (their LDS slots overlay the two regions above: same wavefront, in order)
+        // the depth-3 slots overlay the two regions just read: same wavefront, LDS operations complete in order
+        auto level3_write = [&](int pp) {
 #pragma unroll
-        for (int p2 = 0; p2 < 4; ++p2) {
-            wx_d4 a = {0, 0, 0, 0};
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a = __builtin_amdgcn_mfma_f64_16x16x4f64(ACS_A(2, t), L2[p2][t], a, 0, 0, 0);
+                for (int t = 0; t < 4; ++t) {
+                    const int p2 = 2 * pp + k;
+                    ACS_W(64 * t + (2 * p2) * 8) = fma(c1, L2[p2][t], a3[k][t]);
+                    ACS_W(64 * t + (2 * p2 + 1) * 8) = fma(c1, L2[p2][t], -a3[k][t]);
+                }
+        };
+        level3_write(0);
+        level2_pair(1);
+        level3_write(1);
+        // next block's samples travel during the lane-local phase (most of the block's time)
+        if (sig0 + 16 <= batch) {
+            const acs_gc p = acs_sbase(src + (sig0 + 8) * sig_stride);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                ACS_W(64 * t + (2 * p2) * 8) = fma(c1, L2[p2][t], a[t]);
-                ACS_W(64 * t + (2 * p2 + 1) * 8) = fma(c1, L2[p2][t], -a[t]);
-            }
+            for (int t = 0; t < 4; ++t) { P[t] = acs_ld(p, offP[t]); S[t] = acs_ld(p, offS[t]); }
+        } else {
+            const bool ok = sig0 + 8 + s < batch;
+            const acs_gc p = acs_sbase(src + (sig0 + 8) * sig_stride);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { P[t] = ok ? acs_ld(p, offP[t]) : 0.0; S[t] = ok ? acs_ld(p, offS[t]) : 0.0; }
         }
         // ---- levels 3 and 4 inside the lane: x[m] = depth-3 node p3 at i = c3 + 8 m
 #pragma unroll
