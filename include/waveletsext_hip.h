@@ -275,6 +275,23 @@ int wx_threshold_f64(const double *X, double *Y, int64_t n, int64_t k, int64_t b
 int wx_threshold_f32(const float *X, float *Y, int64_t n, int64_t k, int64_t batch, int th_kind, const float *t,
                      int64_t nt, int64_t row_lo, const uint8_t *colmask, void *stream);
 
+/* Threshold selection of SureShrink and RelErrorShrink for every signal of the batch (they are what
+ * denoiseall(...; estnoise = relerrorthreshold) and the SureShrink(xw, redundant, tree) constructor evaluate):
+ * wx_surethreshold_*:     surethreshold(coef, redundant, tree)             Denoising.jl:146-166
+ * wx_relerrorthreshold_*: relerrorthreshold(coef, redundant, tree, elbows) Denoising.jl:285-327 (orth2relerror
+ *                         :344-349, findelbow :367-381; the plot of makeplot = true is not part of the path)
+ * over all n rows of the columns with colmask != 0 (NULL = all k columns: the caller resolves getleaf(tree) for
+ * swpd / acwpd tables); t has `batch` entries.  One workgroup per signal: bitonic sort of the magnitudes, workgroup
+ * scan, first-index argmin / argmax.  Pointers may be host or device. */
+int wx_surethreshold_f64(const double *X, int64_t n, int64_t k, int64_t batch, const uint8_t *colmask, double *t,
+                         void *stream);
+int wx_surethreshold_f32(const float *X, int64_t n, int64_t k, int64_t batch, const uint8_t *colmask, float *t,
+                         void *stream);
+int wx_relerrorthreshold_f64(const double *X, int64_t n, int64_t k, int64_t batch, const uint8_t *colmask, int elbows,
+                             double *t, void *stream);
+int wx_relerrorthreshold_f32(const float *X, int64_t n, int64_t k, int64_t batch, const uint8_t *colmask, int elbows,
+                             float *t, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Local Discriminant Basis, the batch-sized steps -- SURVEY 8(f) row 2.
  * wx_energy_map_*: energy_map(Xw, y, TimeFrequency()) ldb/ldb_energymap.jl:109-141.  Xw is a packet table

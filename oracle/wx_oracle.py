@@ -667,6 +667,67 @@ def denoise(x, inputtype, qmf, L=None, tree=None, th="hard", t=None, estnoise=No
     return iacwpd(xt, tree)
 
 
+# ---- threshold selection of SureShrink / RelErrorShrink (Denoising.jl:146-166, 285-381) ----------------
+# numpy restatement statement by statement; "parity unpinned": the reference's own tests only check the return type
+# (test/denoising.jl:92-103) and there is no Julia here.  np.cumsum adds sequentially like Julia's cumsum; np.sum is
+# pairwise like Julia's sum (different block size: last-bit differences in `sum(orth)`).
+def _shrink_coefs(coef, redundant, tree):
+    coef = _f(coef)
+    if not redundant:
+        return coef.reshape(-1, order="F")
+    if tree is None:
+        return coef.reshape(-1, order="F")
+    leaves = getleaf(np.asarray(tree, dtype=bool), "binary")
+    return coef[:, leaves].reshape(-1, order="F")
+
+
+def surethreshold(coef, redundant, tree=None):
+    """Denoising.jl:146-166"""
+    y = _shrink_coefs(coef, redundant, tree)
+    a = np.sort(np.abs(y)) ** 2
+    b = np.cumsum(a)
+    n = y.size
+    c = np.arange(n - 1, -1, -1).astype(y.dtype)
+    s = b + c * a
+    risk = ((n - 2 * np.arange(1, n + 1)) + s) / n
+    return float(np.sqrt(a[int(np.argmin(risk))]))
+
+
+def orth2relerror(orth):
+    """Denoising.jl:344-349"""
+    orth = np.sort(_f(orth) ** 2)[::-1]
+    tot = np.sum(orth)
+    return np.abs(tot - np.cumsum(orth)) ** 0.5 / tot ** 0.5
+
+
+def findelbow(x, y):
+    """Denoising.jl:367-381; returns the 0-based index of the elbow"""
+    v = np.array([x[-1] - x[0], y[-1] - y[0]])
+    v = v / np.linalg.norm(v, 2)
+    xy = np.stack([x - x[0], y - y[0]], axis=1)
+    H = np.sum(xy ** 2, axis=1) ** 0.5
+    A = xy @ v
+    O = np.abs(H ** 2 - A ** 2) ** 0.5
+    return int(np.argmax(O))
+
+
+def relerrorthreshold(coef, redundant=False, tree=None, elbows=2):
+    """Denoising.jl:285-327 (makeplot = false)"""
+    assert elbows >= 1
+    c = _shrink_coefs(coef, redundant, tree)
+    x = np.sort(np.abs(c))[::-1]
+    r = orth2relerror(c)
+    x = np.append(x, 0)
+    r = np.insert(r, 0, r[0])
+    xmax, ymax = np.max(x), np.max(r)
+    x = x[::-1] / xmax
+    y = r[::-1] / ymax
+    ix = findelbow(x, y)
+    for _ in range(1, elbows):
+        ix = findelbow(x[:ix + 1], y[:ix + 1])
+    return float(x[ix] * xmax)
+
+
 # ---- Local Discriminant Basis, TimeFrequency energy map (LDB.jl:186-251, ldb/ldb_energymap.jl:109-141,
 # ---- ldb/ldb_measures.jl:139-183, 302-325, 427-479): plain loops in the reference's order ------------
 def _unique(y):

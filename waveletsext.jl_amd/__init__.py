@@ -24,8 +24,9 @@ from .acwt import (acdwt, acdwt_, acdwtall, iacdwt, iacdwt_, iacdwtall, acwpt, a
 from .bestbasis import (JBB, LoglpCost, NormCost, tree_costs, bestbasistree, bestbasis_treeselection,   # noqa: F401
                         jbb_moments, costs_from_moments, acwpd_jbb_moments,
                         BB, ShannonEntropyCost, LogEnergyEntropyCost, bestbasistreeall)
-from .denoising import (HardTH, SoftTH, SemiSoftTH, SteinTH, VisuShrink, noisest, threshold, denoise,   # noqa: F401,E402
-                        denoiseall)
+from .denoising import (HardTH, SoftTH, SemiSoftTH, SteinTH, VisuShrink, SureShrink, RelErrorShrink,   # noqa: F401,E402
+                        noisest, threshold, denoise, denoiseall, surethreshold, relerrorthreshold,
+                        surethresholdall, relerrorthresholdall)
 from .ldb import (TimeFrequency, AsymmetricRelativeEntropy, SymmetricRelativeEntropy, LpDistance,        # noqa: F401,E402
                   HellingerDistance, BasisDiscriminantMeasure, FishersClassSeparability, energy_map,
                   discriminant_measure, discriminant_power, LocalDiscriminantBasis, fit_, fitdec_, transform,

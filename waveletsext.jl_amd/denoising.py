@@ -4,8 +4,9 @@ of the coefficient table -- run on the device between the batch transforms; `den
 whole batch instead of the reference's loop over signals.  SURVEY section 8(f) row 1.
 
 Wavelets.jl (`Threshold.HardTH/SoftTH/SemiSoftTH/SteinTH`, `VisuShrink`, `mad!`) is not vendored in the reference
-tree; those pieces are restated from its published source.  RelErrorShrink / SureShrink are not on the device
-path (they raise)."""
+tree; those pieces are restated from its published source.  The threshold selection of SureShrink and
+RelErrorShrink (Denoising.jl:146-166, 285-381) is one workgroup per signal on the device (csrc/wx_shrink.hip), so
+`denoiseall(...; estnoise = relerrorthreshold)` (test/denoising.jl:59-83) is one pipeline as well."""
 import ctypes
 
 import numpy as np
@@ -46,7 +47,73 @@ class VisuShrink:
             self.th, self.t = a, float(b)
 
 
+class RelErrorShrink:
+    """RelErrorShrink(th = HardTH(), t = 1.0) Denoising.jl:41-48"""
+
+    def __init__(self, th=None, t=1.0):
+        self.th = HardTH() if th is None else th
+        self.t = float(t)
+
+
+class SureShrink:
+    """SureShrink(th, t) Denoising.jl:60-66, or SureShrink(xw[, redundant, tree, th]) Denoising.jl:97-103: the
+    threshold is surethreshold(xw, redundant, tree)"""
+
+    def __init__(self, a, b=False, tree=None, th=None):
+        if isinstance(a, (HardTH, SoftTH, SemiSoftTH, SteinTH)):
+            self.th, self.t = a, float(b)
+        else:
+            self.th = HardTH() if th is None else th
+            self.t = surethreshold(a, bool(b), tree)
+
+
 INPUTTYPES = ("sig", "dwt", "wpt", "sdwt", "swpd", "acdwt", "acwpd")
+
+
+def _select(xa, batched, redundant, tree, kind, elbows=2):
+    """surethreshold (kind 0) / relerrorthreshold (kind 1) of every signal: the selected coefficients are all of them,
+    or the leaf columns of a redundant packet table (Denoising.jl:150-157, 293-300)"""
+    n = xa.shape[0]
+    N = xa.shape[-1] if batched else 1
+    nd = xa.arr.ndim - (1 if batched else 0)
+    k = 1 if nd == 1 else xa.shape[1]
+    cm = None
+    if redundant and tree is not None:
+        leaves = np.asarray(getleaf(np.asarray(tree, dtype=bool), "binary"), dtype=bool)
+        assert not leaves[k:].any(), "tree has leaves below the last column of the table"
+        cm = np.ascontiguousarray(leaves[:k].astype(np.uint8))
+    out = np.empty(N, dtype=xa.dtype)
+    cmp = ctypes.c_void_p(cm.ctypes.data) if cm is not None else ctypes.c_void_p(0)
+    if kind == 0:
+        fn = getattr(_lib.lib(), "wx_surethreshold" + xa.suffix)
+        _lib.check(fn(xa.ptr, n, k, N, cmp, ctypes.c_void_p(out.ctypes.data), xa.stream()))
+    else:
+        assert elbows >= 1                                             # Denoising.jl:291
+        fn = getattr(_lib.lib(), "wx_relerrorthreshold" + xa.suffix)
+        _lib.check(fn(xa.ptr, n, k, N, cmp, int(elbows), ctypes.c_void_p(out.ctypes.data), xa.stream()))
+    return out
+
+
+def surethreshold(coef, redundant, tree=None):
+    """surethreshold(coef, redundant[, tree]) Denoising.jl:146-166 for one decomposed signal"""
+    return float(_select(Arg(coef), False, redundant, tree, 0)[0])
+
+
+def relerrorthreshold(coef, redundant=False, tree=None, elbows=2):
+    """relerrorthreshold(coef[, redundant, tree, elbows]) Denoising.jl:285-327 for one decomposed signal (the plot of
+    makeplot = true belongs to the reference's Visualizations, out of scope)"""
+    return float(_select(Arg(coef), False, redundant, tree, 1, elbows)[0])
+
+
+def surethresholdall(coef, redundant, tree=None):
+    """surethreshold of every signal of a batch (last axis), one launch"""
+    return _select(Arg(coef), True, redundant, tree, 0)
+
+
+def relerrorthresholdall(coef, redundant=False, tree=None, elbows=2):
+    """relerrorthreshold of every signal of a batch (last axis), one launch: what denoiseall evaluates signal by
+    signal when estnoise = relerrorthreshold (Denoising.jl:676-680)"""
+    return _select(Arg(coef), True, redundant, tree, 1, elbows)
 
 
 def _detail_range(n, k, inputtype, tree):
@@ -102,8 +169,8 @@ def threshold(x, th, t):
 def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
     assert smooth in ("undersmooth", "regular")                       # Denoising.jl:493
     assert inputtype in INPUTTYPES                                     # Denoising.jl:494
-    if not isinstance(dnt, VisuShrink):
-        raise _lib.WxError(_lib.WX_EUNSUPPORTED, "only VisuShrink thresholds are on the device path")
+    if not isinstance(dnt, (VisuShrink, SureShrink, RelErrorShrink)):
+        raise _lib.WxError(_lib.WX_EARG, "dnt must be a VisuShrink, SureShrink or RelErrorShrink")
     xa = Arg(x)
     n = xa.shape[0]
     L = maxtransformlevels(n) if L is None else int(L)
@@ -120,9 +187,16 @@ def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
     # noise estimation
     tr = None if inputtype in ("dwt", "sdwt", "acdwt") else tree
     if estnoise is None or callable(estnoise):
-        if estnoise is not None and estnoise is not noisest:
-            raise _lib.WxError(_lib.WX_EUNSUPPORTED, "only noisest (or precomputed values) estimates noise on the device path")
-        sigma = _noisest(xa, batched, inputtype, tr)
+        red = inputtype in ("sdwt", "swpd", "acdwt", "acwpd")
+        if estnoise is None or estnoise is noisest:
+            sigma = _noisest(xa, batched, inputtype, tr)
+        elif estnoise is relerrorthreshold:                            # estnoise(x, redundant, tree), Denoising.jl:503-571
+            sigma = _select(xa, batched, red, tr, 1)
+        elif estnoise is surethreshold:
+            sigma = _select(xa, batched, red, tr, 0)
+        else:
+            raise _lib.WxError(_lib.WX_EUNSUPPORTED,
+                               "noise estimates on the device path: noisest, relerrorthreshold, surethreshold or precomputed values")
     else:
         sigma = np.broadcast_to(np.asarray(estnoise, dtype=np.float64), (N,)).astype(xa.dtype)
     if bestTH is not None:
