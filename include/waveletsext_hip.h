@@ -275,6 +275,19 @@ int wx_threshold_f64(const double *X, double *Y, int64_t n, int64_t k, int64_t b
 int wx_threshold_f32(const float *X, float *Y, int64_t n, int64_t k, int64_t batch, int th_kind, const float *t,
                      int64_t nt, int64_t row_lo, const uint8_t *colmask, void *stream);
 
+/* 3-D discrete wavelet transform of a batch of cubes: dwtall / idwtall on 4-D arrays (dwt/dwt_all.jl:39-54, 95-110 over
+ * Wavelets.jl's 3-D dwt! / idwt!, which is not vendored: the separable pyramid -- one analysis step along dimension 1,
+ * 2, 3 of the low-pass sub-cube per level -- is restated from its published source).  x, y: (n1, n2, n3, batch)
+ * column-major, n1 == n2 == n3 dyadic, 0 <= L <= maxtransformlevels(n1); y may be x.  Pointers may be host or device. */
+int wx_dwt3d_f64(const double *x, double *y, int64_t n1, int64_t n2, int64_t n3, int L, int64_t batch, const double *qmf,
+                 int F, void *stream);
+int wx_dwt3d_f32(const float *x, float *y, int64_t n1, int64_t n2, int64_t n3, int L, int64_t batch, const double *qmf,
+                 int F, void *stream);
+int wx_idwt3d_f64(const double *x, double *y, int64_t n1, int64_t n2, int64_t n3, int L, int64_t batch, const double *qmf,
+                  int F, void *stream);
+int wx_idwt3d_f32(const float *x, float *y, int64_t n1, int64_t n2, int64_t n3, int L, int64_t batch, const double *qmf,
+                  int F, void *stream);
+
 /* Threshold selection of SureShrink and RelErrorShrink for every signal of the batch (they are what
  * denoiseall(...; estnoise = relerrorthreshold) and the SureShrink(xw, redundant, tree) constructor evaluate):
  * wx_surethreshold_*:     surethreshold(coef, redundant, tree)             Denoising.jl:146-166

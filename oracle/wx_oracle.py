@@ -380,6 +380,45 @@ def iwptall(x, qmf, L_or_tree=None):
     return _all(iwpt, x, None, qmf, L_or_tree)
 
 
+# ---- 3-D dwt of a cube (dwt_all.jl:8-9; Wavelets.jl's 3-D transform is not vendored: the separable pyramid out of the
+# ---- same one-level step as 1-D, parity unpinned) -------------------------------------------------------------
+def dwt3d(x, qmf, L=None):
+    x = _f(x)
+    n = x.shape[0]
+    assert x.ndim == 3 and x.shape == (n, n, n)
+    L = maxtransformlevels(n) if L is None else L
+    g, h = makereverseqmfpair(qmf)
+    y = np.array(x, copy=True, order="F")
+    for l in range(L):
+        ns = n >> l
+        for axis in range(3):
+            sub = np.moveaxis(y[:ns, :ns, :ns], axis, 0)
+            for i in range(ns):
+                for j in range(ns):
+                    a, d = dwt_step(np.ascontiguousarray(sub[:, i, j]), h, g)
+                    sub[:ns // 2, i, j] = a
+                    sub[ns // 2:, i, j] = d
+    return y
+
+
+def idwt3d(xw, qmf, L=None):
+    xw = _f(xw)
+    n = xw.shape[0]
+    assert xw.ndim == 3 and xw.shape == (n, n, n)
+    L = maxtransformlevels(n) if L is None else L
+    g, h = makereverseqmfpair(qmf)
+    y = np.array(xw, copy=True, order="F")
+    for l in range(L - 1, -1, -1):
+        ns = n >> l
+        for axis in (2, 1, 0):
+            sub = np.moveaxis(y[:ns, :ns, :ns], axis, 0)
+            for i in range(ns):
+                for j in range(ns):
+                    sub[:, i, j] = idwt_step(np.ascontiguousarray(sub[:ns // 2, i, j]),
+                                             np.ascontiguousarray(sub[ns // 2:, i, j]), h, g)
+    return y
+
+
 # ---- stationary -----------------------------------------------------------------------------
 def sdwt(x, qmf, L=None):
     x = _f(x); q, qp, F = _q(qmf); n = x.shape[0]

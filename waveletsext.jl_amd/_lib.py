@@ -126,6 +126,10 @@ _PLAIN_SIGS = {
     "wx_noisest_f32": [_P, _L, _L, _L, _L, _L, _P, _P],
     "wx_threshold_f64": [_P, _P, _L, _L, _L, _I, _P, _L, _L, _P, _P],
     "wx_threshold_f32": [_P, _P, _L, _L, _L, _I, _P, _L, _L, _P, _P],
+    "wx_dwt3d_f64": [_P, _P, _L, _L, _L, _I, _L, _P, _I, _P],
+    "wx_dwt3d_f32": [_P, _P, _L, _L, _L, _I, _L, _P, _I, _P],
+    "wx_idwt3d_f64": [_P, _P, _L, _L, _L, _I, _L, _P, _I, _P],
+    "wx_idwt3d_f32": [_P, _P, _L, _L, _L, _I, _L, _P, _I, _P],
     "wx_surethreshold_f64": [_P, _L, _L, _L, _P, _P, _P],
     "wx_surethreshold_f32": [_P, _L, _L, _L, _P, _P, _P],
     "wx_relerrorthreshold_f64": [_P, _L, _L, _L, _P, _I, _P, _P],

@@ -198,10 +198,27 @@ def iwptall(xw, wt, L_or_tree=None):
 # 1-D Wavelets.jl pyramid order [s_L d_L .. d_1] == the leaves of that tree in natural order).
 # Batch drivers: dwt/dwt_all.jl:39-54, 95-110.  1-D and 2-D (the reference also admits 3-D).
 # ---------------------------------------------------------------------------------------------
+def _dwt3d(name, xa, wt, L, batched):
+    """3-D signals (dwt_all.jl:8-9 "1-D, 2-D, and 3-D"): Wavelets.jl's separable pyramid on cubes, csrc/wx_dwt3d.hip"""
+    import ctypes
+    sig = xa.shape[:-1] if batched else xa.shape
+    N = xa.shape[-1] if batched else 1
+    Lmax = maxtransformlevels(int(min(sig)))
+    Lv = Lmax if L is None else int(L)
+    assert 0 <= Lv <= Lmax
+    out = xa.new(xa.shape)
+    q = np.ascontiguousarray(wt.qmf, dtype=np.float64)
+    fn = getattr(_lib.lib(), ("wx_dwt3d" if name == "wx_wpt" else "wx_idwt3d") + xa.suffix)
+    _lib.check(fn(xa.ptr, out.ptr, sig[0], sig[1], sig[2], Lv, N, ctypes.c_void_p(q.ctypes.data), q.size, xa.stream()))
+    return out.arr
+
+
 def _dwt_like(name, x, wt, L, batched):
     xa = Arg(x)
     sig = xa.shape[:-1] if batched else xa.shape
-    assert len(sig) in (1, 2)
+    assert len(sig) in (1, 2, 3)
+    if len(sig) == 3:
+        return _dwt3d(name, xa, wt, L, batched)
     if batched:
         assert xa.arr.ndim > 1                                        # dwt_all.jl:40,96
     Lmax = maxtransformlevels(int(min(sig)))
