@@ -1,43 +1,64 @@
 #!/usr/bin/env python3
-"""Rewrite the rows of DESIGN.md section 6's table from profiles/r01_bench_*.json (the committed bench lines)."""
+"""Rewrite the rows of DESIGN.md section 6's table from profiles/<prefix>_bench_*.json (the committed bench lines).
+usage: python tools/update_design_table.py [r02]"""
 import json
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PFX = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def B(w):
-    return json.loads(open(os.path.join(ROOT, "profiles", "r01_bench_%s.json" % w)).read())
+    return json.loads(open(os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (PFX, w))).read())
 
 
 def main():
     p = os.path.join(ROOT, "DESIGN.md")
     s = open(p).read()
     rows = {}
-    d = B('cfg2'); r = d['roofline']
-    rows['cfg2'] = f"| cfg2 `wpdall`+`iwpdall` 65536x4096 f64 db8 L=12 | **{d['value']:.0f}** | {r['avg_launch_ms']:.2f} ms, {r['achieved']/1000:.2f} TB/s | **{100*r['frac']:.1f} % of HBM peak** | {d['inverse']['avg_launch_ms']:.2f} ms | {d['cpu_baseline']['value']:.1f} |"
-    d = B('target'); r = d['roofline']
-    rows['target'] = f"| target `wptall`+`iwptall` 65536x4096 f64 db4 L=10 | {d['value']:.0f} | {r['avg_launch_ms']:.2f} ms, {r['achieved']/1000:.2f} TB/s | {100*r['frac']:.0f} % HBM (FP64-bound) | {d['inverse']['avg_launch_ms']:.2f} ms | {d['cpu_baseline']['value']:.1f} |"
-    d = B('target_haar'); r = d['roofline']
-    rows['target_haar'] = f"| target_haar `wptall`+`iwptall` 65536x4096 f64 haar L=10 | **{d['value']:.0f}** | {r['avg_launch_ms']:.2f} ms, {r['achieved']/1000:.2f} TB/s | **{100*r['frac']:.1f} % of HBM peak** | {d['inverse']['avg_launch_ms']:.2f} ms ({d['inverse']['achieved_GBs']/80:.0f} %) | {d['cpu_baseline']['value']:.1f} |"
-    d = B('cfg3'); r = d['roofline']
-    rows['cfg3'] = f"| cfg3 `swptall`+`iswptall` 64x16384 f64 haar L=12 | {d['value']:.1f} | {r['avg_launch_ms']:.2f} ms, {r['achieved']/1000:.2f} TB/s | {100*r['frac']:.0f} % HBM | {d['inverse']['avg_launch_ms']:.2f} ms | {d['cpu_baseline']['value']:.4f} |"
-    d = B('cfg4'); r = d['roofline']
-    rows['cfg4'] = f"| cfg4 2-D `wptall`+`iwptall` 512x(512x512) f32 db4 L=6 | {d['value']:.0f} | {r['avg_launch_ms']:.2f} ms | {100*r['frac']:.1f} % HBM (2 passes, LDS/FP bound) | {d['inverse']['avg_launch_ms']:.2f} ms | {d['cpu_baseline']['value']:.1f} |"
-    d = B('cfg5'); r = d['roofline']
-    rows['cfg5'] = f"| cfg5 acwpd+JBB 2048x2048 f64 coif6 L=11 | {d['value']:.0f} | {r['avg_launch_ms']:.1f} ms, {r['achieved']:.0f} TFLOP/s-equiv. | {100*r['frac']:.0f} % FP64 peak (LDS-issue bound) | {d['inverse']['avg_launch_ms']:.2f} ms (costs+tree) | {d['cpu_baseline']['value']:.4f} |"
-    d = B('bb'); r = d['roofline']
-    rows['bb'] = f"| bb `bestbasistreeall(·, BB())` 16384x4096 f64 (+`wpdall`) | {d['value']:.0f} | {r['avg_launch_ms']:.2f} ms (costs + all trees) | {100*r['frac']:.0f} % HBM (VALU-bound entropy terms) | {d['inverse']['avg_launch_ms']:.2f} ms (`wpdall`) | {d['cpu_baseline']['value']:.1f} |"
-    d = B('ldb'); r = d['roofline']
-    rows['ldb'] = f"| ldb `energy_map` 4 classes 16384x4096 f64 (+`wpdall`) | {d['value']:.0f} | {r['avg_launch_ms']:.2f} ms (class kernel + norms + host labels) | {100*r['frac']:.0f} % HBM | {d['inverse']['avg_launch_ms']:.2f} ms (`wpdall`) | {d['cpu_baseline']['value']:.1f} |"
-    d = B('siwt'); r = d['roofline']
-    rows['siwt'] = f"| siwt `siwpdall` (+costs) / best basis + `isiwpdall` 4096x1024 f64 db4 L=10 d=3 | {d['value']:.0f} | {r['avg_launch_ms']:.2f} ms, {r['achieved']/1000:.2f} TB/s | {100*r['frac']:.0f} % HBM (entropy terms VALU-bound) | {d['inverse']['avg_launch_ms']:.2f} ms (trees + inverse) | {d['cpu_baseline']['value']:.4f} |"
+
+    def hbm(d):
+        r = d["roofline"]
+        return "%.2f ms, %.2f TB/s" % (r["avg_launch_ms"], r["achieved"] / 1000), "%.1f %% of HBM peak" % (100 * r["frac"])
+
+    def inv(d, note=""):
+        i = d["inverse"]
+        return "%.2f ms (%.0f %%)%s" % (i["avg_launch_ms"], 100 * i["frac"], note)
+
+    d = B("cfg2"); a, f = hbm(d)
+    rows["cfg2"] = "| cfg2 `wpdall`+`iwpdall` 65536x4096 f64 db8 L=12 | **%.0f** | %s | **%s** (PMC traffic %.3f x) | %s | %.1f |" % (
+        d["value"], a, f, d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"], inv(d), d["cpu_baseline"]["value"])
+    d = B("target"); a, f = hbm(d)
+    rows["target"] = "| target `wptall`+`iwptall` 65536x4096 f64 db4 L=10 | **%.0f** | %s | **%s** (PMC traffic %.3f x) | %s | %.1f |" % (
+        d["value"], a, f, d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"], inv(d), d["cpu_baseline"]["value"])
+    d = B("target_haar"); a, f = hbm(d)
+    rows["target_haar"] = "| target_haar `wptall`+`iwptall` 65536x4096 f64 haar L=10 | %.0f | %s | %s | %s | %.1f |" % (
+        d["value"], a, f, inv(d), d["cpu_baseline"]["value"])
+    d = B("cfg3"); a, f = hbm(d)
+    rows["cfg3"] = "| cfg3 `swptall`+`iswptall` 8192x16384 f64 haar L=12 (128 chunks of 64 signals) | %.1f | %s per chunk | **%s** (PMC traffic %.2f x) | %s | %.4f |" % (
+        d["value"], a, f, d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"], inv(d), d["cpu_baseline"]["value"])
+    d = B("cfg4"); a, f = hbm(d)
+    rows["cfg4"] = "| cfg4 2-D `wptall`+`iwptall` 4096x(512x512) f32 db4 L=6 | **%.0f** | %s | %s over the algorithmic bytes; two passes, each 64 %% of peak | %s | %.1f |" % (
+        d["value"], a, f, inv(d), d["cpu_baseline"]["value"])
+    d = B("cfg5"); r = d["roofline"]
+    rows["cfg5"] = "| cfg5 acwpd+JBB 262144x2048 f64 coif6 L=11 (128 chunks of 2048) | **%.0f** | %.0f ms = %.2f ms per chunk, %.0f TFLOP/s-equiv. (direct form) | FP64 vector + matrix pipe (§4.7): 2.0 ms of issue in 3.8 ms | %.2f ms (costs+tree) | %.4f |" % (
+        d["value"], r["avg_launch_ms"], r["avg_launch_ms"] / 128, r["achieved"], d["inverse"]["avg_launch_ms"], d["cpu_baseline"]["value"])
+    d = B("bb"); r = d["roofline"]
+    rows["bb"] = "| bb `bestbasistreeall(·, BB())` 16384x4096 f64 (+`wpdall`) | %.0f | %.2f ms (costs + all trees) | %.0f %% HBM (VALU-bound entropy terms) | %.2f ms (`wpdall`) | %.1f |" % (
+        d["value"], r["avg_launch_ms"], 100 * r["frac"], d["inverse"]["avg_launch_ms"], d["cpu_baseline"]["value"])
+    d = B("ldb"); r = d["roofline"]
+    rows["ldb"] = "| ldb `energy_map` 4 classes 16384x4096 f64 (+`wpdall`) | %.0f | %.2f ms (class kernel + norms + host labels) | %.0f %% HBM | %.2f ms (`wpdall`) | %.1f |" % (
+        d["value"], r["avg_launch_ms"], 100 * r["frac"], d["inverse"]["avg_launch_ms"], d["cpu_baseline"]["value"])
+    d = B("siwt"); r = d["roofline"]
+    rows["siwt"] = "| siwt `siwpdall` (+costs) / best basis + `isiwpdall` 4096x1024 f64 db4 L=10 d=3 | %.0f | %.2f ms, %.2f TB/s | %.0f %% HBM (entropy terms VALU-bound) | %.2f ms (trees + inverse) | %.4f |" % (
+        d["value"], r["avg_launch_ms"], r["achieved"] / 1000, 100 * r["frac"], d["inverse"]["avg_launch_ms"], d["cpu_baseline"]["value"])
     out = []
-    for ln in s.split('\n'):
-        m = re.match(r'\| (cfg2|target_haar|target|cfg3|cfg4|cfg5|bb|ldb|siwt) ', ln)
+    for ln in s.split("\n"):
+        m = re.match(r"\| (cfg2|target_haar|target|cfg3|cfg4|cfg5|bb|ldb|siwt) ", ln)
         out.append(rows[m.group(1)] if m else ln)
-    open(p, "w").write('\n'.join(out))
+    open(p, "w").write("\n".join(out))
 
 
 if __name__ == "__main__":
