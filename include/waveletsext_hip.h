@@ -275,6 +275,22 @@ int wx_threshold_f64(const double *X, double *Y, int64_t n, int64_t k, int64_t b
 int wx_threshold_f32(const float *X, float *Y, int64_t n, int64_t k, int64_t batch, int th_kind, const float *t,
                      int64_t nt, int64_t row_lo, const uint8_t *colmask, void *stream);
 
+/* Order statistics over the signal axis for Local Discriminant Basis (X: (nk, N) column-major, cls[i] in [0, nc) the class
+ * of signal i, as wx_class_mean_*):
+ * wx_class_median_mad_*: med[e, c] = median, mad[e, c] = mad(normalize = false) of X[e, class c] -- the two tables of
+ *     discriminant_power(coefs, y, RobustFishersClassSeparability()), ldb/ldb_measures.jl:481-519;
+ * wx_emd_measure_*:      D[e] = sum over the class pairs of the earth mover's distance between the signatures
+ *     (X[e, class a], weight 1/N_a) and (X[e, class b], weight 1/N_b): discriminant_measure(energy_map(Xw, y,
+ *     Signatures(:equal)), EarthMoverDistance()), ldb/ldb_energymap.jl:186-238, ldb/ldb_measures.jl:185-201, 254-360.
+ * The padded signals of one coefficient must fit a 128 KiB LDS window (sum over classes of nextpow2(N_c) <= 16384
+ * Float64 / 32768 Float32 values).  Pointers may be host or device; cls is a host array. */
+int wx_class_median_mad_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *med, double *mad,
+                            void *stream);
+int wx_class_median_mad_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, float *med, float *mad,
+                            void *stream);
+int wx_emd_measure_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *D, void *stream);
+int wx_emd_measure_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, float *D, void *stream);
+
 /* 3-D discrete wavelet transform of a batch of cubes: dwtall / idwtall on 4-D arrays (dwt/dwt_all.jl:39-54, 95-110 over
  * Wavelets.jl's 3-D dwt! / idwt!, which is not vendored: the separable pyramid -- one analysis step along dimension 1,
  * 2, 3 of the low-pass sub-cube per level -- is restated from its published source).  x, y: (n1, n2, n3, batch)

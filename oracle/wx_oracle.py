@@ -879,6 +879,67 @@ def ldb_fisher_power(coefs, y):
     return np.asfortranarray((((E - Ea * E) ** 2) * p).sum(axis=-1) / (V * p).sum(axis=-1))
 
 
+# ---- LDB order statistics: robust Fisher power (ldb_measures.jl:481-519) and the earth mover's distance between class
+# ---- signatures with equal weights (ldb_energymap.jl:186-238, ldb_measures.jl:254-285, 327-360): plain loops ---------
+def _median(v):
+    """Statistics.median: middle(a, b) = a/2 + b/2 for an even count"""
+    s = np.sort(np.asarray(v))
+    n = s.size
+    return s[n // 2] if n & 1 else s[n // 2 - 1] / 2 + s[n // 2] / 2
+
+
+def ldb_robust_fishers(coefs, y):
+    coefs = _f(coefs)
+    classes = _unique(y)
+    yl = list(np.asarray(y).tolist())
+    sz = coefs.shape[:-1]
+    flat = coefs.reshape(-1, coefs.shape[-1], order="F")
+    nc = len(classes)
+    med = np.empty((flat.shape[0], nc), dtype=coefs.dtype)
+    mad = np.empty((flat.shape[0], nc), dtype=coefs.dtype)
+    Ni = np.empty(nc, dtype=coefs.dtype)
+    for ci, c in enumerate(classes):
+        idx = [i for i, v in enumerate(yl) if v == c]
+        Ni[ci] = len(idx)
+        for e in range(flat.shape[0]):
+            v = flat[e, idx]
+            med[e, ci] = _median(v)
+            mad[e, ci] = _median(np.abs(v - med[e, ci]))                # mad(x, normalize = false)
+    meda = np.array([_median(med[e]) for e in range(flat.shape[0])], dtype=coefs.dtype)
+    p = Ni / Ni.sum()
+    power = (((med - meda[:, None] * med) ** 2) @ p) / (mad @ p)
+    return np.asfortranarray(power.reshape(sz, order="F")), np.argsort(-power, kind="stable") + 1
+
+
+def emd_pair(p, q, wp, wq):
+    """pairwise_discriminant_measure(P, Q, EarthMoverDistance()) ldb_measures.jl:327-360 (scalar weights)"""
+    p, q = np.sort(np.asarray(p)), np.sort(np.asarray(q))
+    w_p, w_q = np.full(p.size, wp), np.full(q.size, wq)
+    r = np.sort(np.concatenate([p, q]))
+    emd = 0
+    for i in range(r.size - 1):
+        sp = np.sum(w_p[p <= r[i]])
+        sq = np.sum(w_q[q <= r[i]])
+        emd += abs(sp - sq) * (r[i + 1] - r[i])
+    return emd / (np.sum(w_p) + np.sum(w_q))
+
+
+def ldb_emd_measure(Xw, y):
+    """discriminant_measure(energy_map(Xw, y, Signatures()), EarthMoverDistance()) ldb_measures.jl:185-201"""
+    Xw = _f(Xw)
+    classes = _unique(y)
+    yl = list(np.asarray(y).tolist())
+    groups = [[i for i, v in enumerate(yl) if v == c] for c in classes]
+    sz = Xw.shape[:-1]
+    flat = Xw.reshape(-1, Xw.shape[-1], order="F")
+    D = np.zeros(flat.shape[0], dtype=Xw.dtype)
+    for a in range(len(classes)):
+        for b in range(a + 1, len(classes)):
+            for e in range(flat.shape[0]):
+                D[e] += emd_pair(flat[e, groups[a]], flat[e, groups[b]], 1 / len(groups[a]), 1 / len(groups[b]))
+    return np.asfortranarray(D.reshape(sz, order="F"))
+
+
 # ---- shift-invariant wavelet packet decomposition (SIWT.jl; SURVEY 8f row 4) ---------------------------
 class SIWTObject:
     """ShiftInvariantWaveletTransformObject (siwt/siwt_utls.jl:75-90) with the same field names.  Nodes maps

@@ -122,6 +122,10 @@ _PLAIN_SIGS = {
     "wx_class_mean_f32": [_P, _L, _L, _P, _I, _P, _P],
     "wx_class_var_f64": [_P, _L, _L, _P, _I, _P, _P, _P],
     "wx_class_var_f32": [_P, _L, _L, _P, _I, _P, _P, _P],
+    "wx_class_median_mad_f64": [_P, _L, _L, _P, _I, _P, _P, _P],
+    "wx_class_median_mad_f32": [_P, _L, _L, _P, _I, _P, _P, _P],
+    "wx_emd_measure_f64": [_P, _L, _L, _P, _I, _P, _P],
+    "wx_emd_measure_f32": [_P, _L, _L, _P, _I, _P, _P],
     "wx_noisest_f64": [_P, _L, _L, _L, _L, _L, _P, _P],
     "wx_noisest_f32": [_P, _L, _L, _L, _L, _L, _P, _P],
     "wx_threshold_f64": [_P, _P, _L, _L, _L, _I, _P, _L, _L, _P, _P],

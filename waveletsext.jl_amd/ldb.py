@@ -5,8 +5,10 @@ The batch-sized steps run on the device: the packet decomposition (`wpdall`), th
 (`wx_energy_map_*`), the class means / variances for Fisher's separability (`wx_class_mean_*`, `wx_class_var_*`),
 the basis gather (`getbasiscoefall` / `wptall`) and the inverse (`iwptall`).  The discriminant measure, the node
 costs with top_k, the (host) tree selection and the ordering work on the small (n, levels, classes) maps.
-ProbabilityDensity / Signatures energy maps (kernel density estimates), EarthMoverDistance and
-RobustFishersClassSeparability (medians over the signal axis) are not on the device path and raise."""
+Order statistics over the signal axis are device kernels too (csrc/wx_ldbstat.hip): the class medians / MADs of
+RobustFishersClassSeparability and the earth mover's distance between the class signatures of Signatures(:equal).
+The ProbabilityDensity map and Signatures(:pdf) rest on AverageShiftedHistograms.jl (outside the reference tree)
+and raise."""
 import ctypes
 import itertools
 
@@ -43,6 +45,46 @@ class HellingerDistance:
     """ldb_measures.jl:88"""
 
 
+class EarthMoverDistance:
+    """ldb_measures.jl:104"""
+
+
+class Signatures:
+    """ldb_energymap.jl:63-67"""
+
+    def __init__(self, weight="equal"):
+        if weight not in ("equal", "pdf"):
+            raise ValueError("Invalid weight type. Valid weight types are :equal and :pdf.")
+        self.weight = weight
+
+
+class SignatureMap(list):
+    """energy_map(Xw, y, Signatures(:equal)): one (coef, weight) entry per class (ldb_energymap.jl:186-238), indexable
+    like the reference's vector of named tuples; the coefficient table itself stays where it is (the entries gather
+    their class lazily) and discriminant_measure works on it in place"""
+
+    class Entry:
+        def __init__(self, owner, c):
+            self._o, self._c = owner, c
+            self.weight = 1.0 / float((owner.idx == c).sum())
+
+        @property
+        def coef(self):
+            X = to_numpy(self._o.Xw)
+            return np.asfortranarray(X[..., np.flatnonzero(self._o.idx == self._c)])
+
+        def __getitem__(self, k):
+            return self.coef if k in (0, "coef") else self.weight
+
+    def __init__(self, Xw, classes, idx):
+        self.Xw, self.classes, self.idx = Xw, classes, idx
+        super().__init__(SignatureMap.Entry(self, c) for c in range(len(classes)))
+
+
+class RobustFishersClassSeparability:
+    """ldb_measures.jl:401"""
+
+
 class BasisDiscriminantMeasure:
     """ldb_measures.jl:378"""
 
@@ -66,8 +108,18 @@ def energy_map(Xw, y, method=None, classes=None, return_norm_sum=False):
     order (a shard of a multi-GPU batch passes the global unique(y)); `return_norm_sum` also returns the per-class
     denominators so that shards can be combined (distributed.energy_map_sharded)."""
     method = TimeFrequency() if method is None else method
+    if isinstance(method, Signatures):
+        if method.weight != "equal":
+            raise _lib.WxError(_lib.WX_EUNSUPPORTED, "Signatures(:pdf) needs AverageShiftedHistograms.jl's ash / pdf: not on the device path")
+        Xa = Arg(Xw)
+        N = Xa.arr.ndim
+        assert 3 <= N <= 4
+        cl, idx = _classes(y)
+        assert Xa.shape[-1] == idx.size and len(cl) > 1
+        assert 1 <= Xa.shape[N - 2] - 1 <= maxtransformlevels(int(min(Xa.shape[:N - 2])))
+        return SignatureMap(Xw, cl, idx)
     if not isinstance(method, TimeFrequency):
-        raise _lib.WxError(_lib.WX_EUNSUPPORTED, "only the TimeFrequency energy map is on the device path")
+        raise _lib.WxError(_lib.WX_EUNSUPPORTED, "the TimeFrequency and Signatures(:equal) energy maps are on the device path")
     Xa = Arg(Xw)
     N = Xa.arr.ndim
     assert 3 <= N <= 4
@@ -110,6 +162,16 @@ def _pair(p, q, dm):
 
 def discriminant_measure(G, dm=None):
     """discriminant_measure(Gamma, dm) ldb_measures.jl:139-183 for time-frequency maps: sum over class pairs"""
+    if isinstance(G, SignatureMap):                                   # ldb_measures.jl:185-201: sum of the pairwise EMDs
+        if dm is not None and not isinstance(dm, EarthMoverDistance):
+            raise TypeError("a Signatures energy map takes a SignaturesDM (EarthMoverDistance)")
+        Xa = Arg(G.Xw)
+        sz = Xa.shape[:-1]
+        ne = int(np.prod(sz, dtype=np.int64))
+        D = Xa.new(tuple(sz))
+        fn = getattr(_lib.lib(), "wx_emd_measure" + Xa.suffix)
+        _lib.check(fn(Xa.ptr, ne, Xa.shape[-1], ctypes.c_void_p(G.idx.ctypes.data), len(G.classes), D.ptr, Xa.stream()))
+        return D.arr
     dm = AsymmetricRelativeEntropy() if dm is None else dm
     G = to_numpy(G)
     nc = G.shape[-1]
@@ -166,8 +228,25 @@ def discriminant_power(a, b, dp=None):
         Ea = E.mean(axis=-1, keepdims=True)
         p = Ni / Ni.sum()
         power = (((E - Ea * E) ** 2) * p).sum(axis=-1) / (V * p).sum(axis=-1)        # :472-477
+    elif isinstance(dp, RobustFishersClassSeparability):              # ldb_measures.jl:481-519
+        Xa = Arg(a)
+        assert 2 <= Xa.arr.ndim <= 3
+        classes, idx = _classes(b)
+        nc = len(classes)
+        sz, N = Xa.shape[:-1], Xa.shape[-1]
+        ne = int(np.prod(sz, dtype=np.int64))
+        med = Xa.new(tuple(sz) + (nc,))
+        mad = Xa.new(tuple(sz) + (nc,))
+        fn = getattr(_lib.lib(), "wx_class_median_mad" + Xa.suffix)
+        _lib.check(fn(Xa.ptr, ne, N, ctypes.c_void_p(idx.ctypes.data), nc, med.ptr, mad.ptr, Xa.stream()))
+        M, A = to_numpy(med.arr), to_numpy(mad.arr)
+        Ni = np.array([(idx == c).sum() for c in range(nc)], dtype=M.dtype)
+        srt = np.sort(M, axis=-1)                                      # median(Medαᵢ, dims = N): middle(a, b) = a/2 + b/2
+        Ma = srt[..., nc // 2:nc // 2 + 1] if nc & 1 else srt[..., nc // 2 - 1:nc // 2] / 2 + srt[..., nc // 2:nc // 2 + 1] / 2
+        p = Ni / Ni.sum()
+        power = (((M - Ma * M) ** 2) * p).sum(axis=-1) / (A * p).sum(axis=-1)        # :509-515
     else:
-        raise _lib.WxError(_lib.WX_EUNSUPPORTED, "RobustFishersClassSeparability is not on the device path")
+        raise _lib.WxError(_lib.WX_EARG, "unknown discriminant power")
     order = np.argsort(-power.ravel(order="F"), kind="stable") + 1                 # sortperm(vec(power), rev=true)
     return np.asfortranarray(power), order
 
