@@ -291,6 +291,23 @@ int wx_class_median_mad_f32(const float *X, int64_t nk, int64_t N, const int32_t
 int wx_emd_measure_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *D, void *stream);
 int wx_emd_measure_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, float *D, void *stream);
 
+/* Average-shifted-histogram densities over the signal axis (same X / cls convention as above).  `ash`, `xy`, `pdf` belong to
+ * AverageShiftedHistograms.jl (Project.toml compat "0.8, 0.9"), which is not in the reference tree: its published
+ * algorithm is restated (csrc/wx_ldbstat.hip), parity unpinned.
+ * wx_pdf_energy_map_*:        Gamma (nk, pdf_len, nc) Float64 = energy_map(Xw, y, ProbabilityDensity()),
+ *     ldb/ldb_energymap.jl:143-184; pdf_len = (nbins + 1) mbins, nbins = ceil((30 N)^(1/5)), mbins = ceil(100 / nbins);
+ * wx_signature_weights_*:     W (nk, N) = the :pdf weights of energy_map(Xw, y, Signatures(:pdf)), ldb_energymap.jl:216-232;
+ * wx_emd_measure_weighted_*:  D[e] = sum over the class pairs of the earth mover's distance between the signatures
+ *     (X[e, class], W[e, class]), ldb/ldb_measures.jl:185-201, 254-360. */
+int wx_pdf_energy_map_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *Gamma, void *stream);
+int wx_pdf_energy_map_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *Gamma, void *stream);
+int wx_signature_weights_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *W, void *stream);
+int wx_signature_weights_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, float *W, void *stream);
+int wx_emd_measure_weighted_f64(const double *X, const double *W, int64_t nk, int64_t N, const int32_t *cls, int nc,
+                                double *D, void *stream);
+int wx_emd_measure_weighted_f32(const float *X, const float *W, int64_t nk, int64_t N, const int32_t *cls, int nc,
+                                float *D, void *stream);
+
 /* 3-D discrete wavelet transform of a batch of cubes: dwtall / idwtall on 4-D arrays (dwt/dwt_all.jl:39-54, 95-110 over
  * Wavelets.jl's 3-D dwt! / idwt!, which is not vendored: the separable pyramid -- one analysis step along dimension 1,
  * 2, 3 of the low-pass sub-cube per level -- is restated from its published source).  x, y: (n1, n2, n3, batch)

@@ -940,6 +940,119 @@ def ldb_emd_measure(Xw, y):
     return np.asfortranarray(D.reshape(sz, order="F"))
 
 
+# ---- average shifted histograms (AverageShiftedHistograms.jl 0.8 / 0.9, NOT in the reference tree: its published
+# ---- algorithm restated, parity unpinned) and the two energy maps built on them (ldb_energymap.jl:143-184, 216-232) ----
+def ash_density(z, a, delta, length, m):
+    """ash(z, rng = range(a, step = delta, length = length), m = m, kernel = Kernels.triangular).density"""
+    counts = np.zeros(length, dtype=np.int64)
+    dinv = 1.0 / delta
+    for yi in np.asarray(z, dtype=np.float64):
+        ki = int(np.floor((yi - a) * dinv + 1.5))
+        if 1 <= ki <= length:
+            counts[ki - 1] += 1
+    dens = np.zeros(length)
+    for k in range(1, length + 1):
+        if counts[k - 1] != 0:
+            for i in range(max(1, k - m + 1), min(length, k + m - 1) + 1):
+                dens[i - 1] += counts[k - 1] * (1.0 - abs((i - k) / m))
+    return dens * (1.0 / (dens.sum() * delta))
+
+
+def ash_pdf(dens, a, delta, x):
+    """pdf(o, x): linear interpolation between the points of rng around x, 0 outside"""
+    length = dens.size
+    rng = a + np.arange(length) * delta
+    i = int(np.searchsorted(rng, x, side="right"))                      # searchsortedlast, 1-based
+    if 1 <= i < length:
+        return dens[i - 1] + (dens[i] - dens[i - 1]) * (x - rng[i - 1]) / (rng[i] - rng[i - 1])
+    return 0.0
+
+
+def _ash_params(Nx):
+    nbins = int(np.ceil((30 * Nx) ** (1 / 5)))
+    mbins = int(np.ceil(100 / nbins))
+    return nbins, mbins, (nbins + 1) * mbins
+
+
+def ldb_pdf_energy_map(Xw, y):
+    """energy_map(Xw, y, ProbabilityDensity()) ldb_energymap.jl:143-184"""
+    Xw = _f(Xw)
+    classes = _unique(y)
+    yl = list(np.asarray(y).tolist())
+    Nx = Xw.shape[-1]
+    nbins, mbins, plen = _ash_params(Nx)
+    flat = Xw.reshape(-1, Nx, order="F").astype(np.float64)
+    G = np.empty((flat.shape[0], plen, len(classes)))
+    for ci, c in enumerate(classes):
+        idx = [i for i, v in enumerate(yl) if v == c]
+        for j in range(flat.shape[0]):
+            z = flat[j]
+            sd = np.std(z, ddof=1)
+            delta = (z.max() - z.min() + sd) / (plen - 1)
+            G[j, :, ci] = ash_density(z[idx], z.min() - 0.5 * sd, delta, plen, mbins)
+    return np.asfortranarray(G.reshape(Xw.shape[:-1] + (plen, len(classes)), order="F"))
+
+
+def ldb_signature_weights(Xw, y):
+    """the :pdf weights of energy_map(Xw, y, Signatures(:pdf)) ldb_energymap.jl:216-232, as an array shaped like Xw"""
+    Xw = _f(Xw)
+    classes = _unique(y)
+    yl = list(np.asarray(y).tolist())
+    Nx = Xw.shape[-1]
+    nbins, mbins, plen = _ash_params(Nx)
+    flat = Xw.reshape(-1, Nx, order="F").astype(np.float64)
+    W = np.empty_like(flat)
+    for c in classes:
+        idx = [i for i, v in enumerate(yl) if v == c]
+        for j in range(flat.shape[0]):
+            z = flat[j, idx]
+            sd = np.std(z, ddof=1)
+            delta = (z.max() - z.min() + sd) / (plen - 1)
+            a = z.min() - 0.5 * sd
+            dens = ash_density(z, a, delta, plen, mbins)
+            for k, i in enumerate(idx):
+                W[j, i] = ash_pdf(dens, a, delta, z[k])
+    return np.asfortranarray(W.reshape(Xw.shape, order="F"))
+
+
+def emd_pair_weighted(p, q, w_p, w_q):
+    """ldb_measures.jl:327-360 with weight vectors"""
+    po, qo = np.argsort(p, kind="stable"), np.argsort(q, kind="stable")
+    p, q, w_p, w_q = np.asarray(p)[po], np.asarray(q)[qo], np.asarray(w_p)[po], np.asarray(w_q)[qo]
+    r = np.sort(np.concatenate([p, q]))
+    emd = 0
+    for i in range(r.size - 1):
+        emd += abs(np.sum(w_p[p <= r[i]]) - np.sum(w_q[q <= r[i]])) * (r[i + 1] - r[i])
+    return emd / (np.sum(w_p) + np.sum(w_q))
+
+
+def ldb_emd_measure_weighted(Xw, W, y):
+    Xw, W = _f(Xw), _f(W)
+    classes = _unique(y)
+    yl = list(np.asarray(y).tolist())
+    groups = [[i for i, v in enumerate(yl) if v == c] for c in classes]
+    flat, wf = Xw.reshape(-1, Xw.shape[-1], order="F"), W.reshape(-1, Xw.shape[-1], order="F")
+    D = np.zeros(flat.shape[0], dtype=Xw.dtype)
+    for a in range(len(classes)):
+        for b in range(a + 1, len(classes)):
+            for e in range(flat.shape[0]):
+                D[e] += emd_pair_weighted(flat[e, groups[a]], flat[e, groups[b]], wf[e, groups[a]], wf[e, groups[b]])
+    return np.asfortranarray(D.reshape(Xw.shape[:-1], order="F"))
+
+
+def ldb_pdf_discriminant(G, dm="are", lp=2):
+    """discriminant_measure(Gamma, dm) for a density map ldb_measures.jl:139-183, 217-251: pairs of classes, summed over the
+    density axis"""
+    G = _f(G)
+    nc = G.shape[-1]
+    D = np.zeros(G.shape[:-2], dtype=G.dtype, order="F")
+    for i in range(nc):
+        for j in range(i + 1, nc):
+            P = np.vectorize(lambda a, b: _ldb_pair(a, b, dm, lp), otypes=[G.dtype])(G[..., i], G[..., j])
+            D = D + np.cumsum(P, axis=-1)[..., -1]
+    return D
+
+
 # ---- shift-invariant wavelet packet decomposition (SIWT.jl; SURVEY 8f row 4) ---------------------------
 class SIWTObject:
     """ShiftInvariantWaveletTransformObject (siwt/siwt_utls.jl:75-90) with the same field names.  Nodes maps

@@ -73,9 +73,75 @@ def test_emd_with_ties_and_float32(wx, oracle):
     assert relerr(D32.astype(np.float64), oracle.ldb_emd_measure(X32.astype(np.float64), y)) <= 1e-5
 
 
-def test_signatures_pdf_weights_are_declared_unsupported(wx):
-    X = np.zeros((8, 3, 4), order="F")
-    with pytest.raises(wx.WxError):
-        wx.energy_map(X, [0, 1, 0, 1], wx.Signatures("pdf"))
+def test_signatures_weight_types(wx):
     with pytest.raises(ValueError):
         wx.Signatures("other")
+
+
+def test_probability_density_energy_map_matches_oracle(wx, oracle):
+    """energy_map(Xw, y, ProbabilityDensity()) ldb_energymap.jl:143-184 and its discriminant measures"""
+    rng = np.random.default_rng(11)
+    wt = wx.wavelet(wx.WT.haar)
+    N, nc = 50, 3
+    yv = rng.integers(0, nc, size=N); yv[:nc] = np.arange(nc)
+    x = np.asfortranarray(rng.standard_normal((8, N)) + 0.7 * yv)
+    Xw = wx.wpdall(x, wt, 2)                                            # (8, 3, N)
+    G = wx.energy_map(Xw, list(yv), wx.ProbabilityDensity())
+    exp = oracle.ldb_pdf_energy_map(Xw, list(yv))
+    assert G.shape == exp.shape and G.shape[2] >= 100 and G.dtype == np.float64
+    assert relerr(G, exp) <= 1e-12
+    # every density integrates to one over its own grid: sum(density) * step = 1
+    flat = Xw.reshape(-1, N, order="F")
+    sd = flat.std(axis=1, ddof=1)
+    step = (flat.max(axis=1) - flat.min(axis=1) + sd) / (G.shape[2] - 1)
+    integ = G.reshape(-1, G.shape[2], nc, order="F").sum(axis=1) * step[:, None]
+    assert np.abs(integ - 1.0).max() <= 1e-12
+    for dm, name in ((wx.AsymmetricRelativeEntropy(), "are"), (wx.LpDistance(), "lp"), (wx.HellingerDistance(), "hellinger"),
+                     (wx.SymmetricRelativeEntropy(), "sre")):
+        D = wx.discriminant_measure(G, dm)
+        assert D.shape == (8, 3)
+        assert relerr(D, oracle.ldb_pdf_discriminant(exp, name)) <= 1e-11, name
+
+
+def test_signatures_with_pdf_weights_matches_oracle(wx, oracle):
+    rng = np.random.default_rng(12)
+    N, nc = 40, 2
+    yv = np.array([i % nc for i in range(N)])
+    Xw = np.asfortranarray(rng.standard_normal((8, 3, N)) + 0.4 * yv)
+    y = list(yv)
+    G = wx.energy_map(Xw, y, wx.Signatures("pdf"))
+    W = oracle.ldb_signature_weights(Xw, y)
+    assert relerr(G.W, W) <= 1e-11
+    assert G[1].weight.shape == (8, 3, N // 2) and (G.W >= 0).all()
+    D = wx.discriminant_measure(G, wx.EarthMoverDistance())
+    assert relerr(D, oracle.ldb_emd_measure_weighted(Xw, W, y)) <= 1e-11
+
+
+@pytest.mark.parametrize("en_name", ["signatures", "density"])
+def test_local_discriminant_basis_with_the_other_energy_maps(wx, oracle, en_name):
+    """fitdec! (LDB.jl:186-251) through the Signatures / ProbabilityDensity maps and the robust Fisher power"""
+    rng = np.random.default_rng(21)
+    wt = wx.wavelet(wx.WT.db2)
+    N, nc, n = 36, 3, 16
+    yv = np.array([i % nc for i in range(N)])
+    t = np.arange(n)[:, None]
+    x = np.asfortranarray(rng.standard_normal((n, N)) * 0.3 + np.sin(2 * np.pi * (yv + 1) * t / n))
+    y = list(yv)
+    if en_name == "signatures":
+        f = wx.LocalDiscriminantBasis(wt=wt, max_dec_level=3, dm=wx.EarthMoverDistance(), en=wx.Signatures(),
+                                      dp=wx.RobustFishersClassSeparability(), n_features=5)
+    else:
+        f = wx.LocalDiscriminantBasis(wt=wt, max_dec_level=3, dm=wx.LpDistance(), en=wx.ProbabilityDensity(),
+                                      dp=wx.RobustFishersClassSeparability(), n_features=5)
+    feats = wx.fit_transform(f, x, y)
+    assert feats.shape == (5, N)
+    Xw = wx.wpdall(x, wt, 3)
+    if en_name == "signatures":
+        assert relerr(f.DM, oracle.ldb_emd_measure(Xw, y)) <= 1e-12
+    else:
+        assert relerr(f.DM, oracle.ldb_pdf_discriminant(oracle.ldb_pdf_energy_map(Xw, y), "lp")) <= 1e-11
+    assert wx.isvalidtree(np.empty(n), f.tree)
+    coefs = wx.getbasiscoefall(Xw, f.tree)
+    ep, eo = oracle.ldb_robust_fishers(coefs, y)
+    assert relerr(f.DP, ep) <= 1e-12 and np.array_equal(f.order, eo)
+    assert relerr(feats, coefs[np.asarray(f.order[:5]) - 1, :]) == 0.0

@@ -28,7 +28,7 @@ from .denoising import (HardTH, SoftTH, SemiSoftTH, SteinTH, VisuShrink, SureShr
                         noisest, threshold, denoise, denoiseall, surethreshold, relerrorthreshold,
                         surethresholdall, relerrorthresholdall)
 from .ldb import (TimeFrequency, AsymmetricRelativeEntropy, SymmetricRelativeEntropy, LpDistance,        # noqa: F401,E402
-                  HellingerDistance, EarthMoverDistance, Signatures, SignatureMap, BasisDiscriminantMeasure,
+                  HellingerDistance, EarthMoverDistance, ProbabilityDensity, Signatures, SignatureMap, BasisDiscriminantMeasure,
                   FishersClassSeparability, RobustFishersClassSeparability, energy_map,
                   discriminant_measure, discriminant_power, LocalDiscriminantBasis, fit_, fitdec_, transform,
                   fit_transform, inverse_transform, change_nfeatures)

@@ -100,13 +100,14 @@ class Arg:
         self.shape = tuple(int(s) for s in self.arr.shape)
         self.suffix = _NP2SUF[np.dtype(self.dtype)]
 
-    def new(self, shape):
-        """Uninitialised output of the same kind."""
+    def new(self, shape, dtype=None):
+        """Uninitialised output of the same kind (and element type, unless `dtype` says otherwise)."""
         shape = tuple(int(s) for s in shape)
+        dt = self.dtype if dtype is None else np.dtype(dtype)
         if self.kind == "torch":
-            td = torch.float64 if self.dtype == np.float64 else torch.float32
+            td = torch.float64 if dt == np.float64 else torch.float32
             return Arg(jl_empty(shape, td, self.device))
-        return Arg(np.empty(shape, dtype=self.dtype, order="F"))
+        return Arg(np.empty(shape, dtype=dt, order="F"))
 
     def stream(self):
         if self.kind == "torch":

@@ -126,6 +126,12 @@ _PLAIN_SIGS = {
     "wx_class_median_mad_f32": [_P, _L, _L, _P, _I, _P, _P, _P],
     "wx_emd_measure_f64": [_P, _L, _L, _P, _I, _P, _P],
     "wx_emd_measure_f32": [_P, _L, _L, _P, _I, _P, _P],
+    "wx_pdf_energy_map_f64": [_P, _L, _L, _P, _I, _P, _P],
+    "wx_pdf_energy_map_f32": [_P, _L, _L, _P, _I, _P, _P],
+    "wx_signature_weights_f64": [_P, _L, _L, _P, _I, _P, _P],
+    "wx_signature_weights_f32": [_P, _L, _L, _P, _I, _P, _P],
+    "wx_emd_measure_weighted_f64": [_P, _P, _L, _L, _P, _I, _P, _P],
+    "wx_emd_measure_weighted_f32": [_P, _P, _L, _L, _P, _I, _P, _P],
     "wx_noisest_f64": [_P, _L, _L, _L, _L, _L, _P, _P],
     "wx_noisest_f32": [_P, _L, _L, _L, _L, _L, _P, _P],
     "wx_threshold_f64": [_P, _P, _L, _L, _L, _I, _P, _L, _L, _P, _P],

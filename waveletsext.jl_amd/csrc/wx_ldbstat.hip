@@ -289,3 +289,352 @@ int wx_emd_measure_f64(const double *X, int64_t nk, int64_t N, const int32_t *cl
 int wx_emd_measure_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, float *D, void *stream)
 { return api_class_rows<float>(1, X, nk, N, cls, nc, D, nullptr, stream); }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Average shifted histograms: the ProbabilityDensity energy map and the weights of Signatures(:pdf)
+//   energy_map(Xw, y, ProbabilityDensity())   ldb/ldb_energymap.jl:143-184
+//       per coefficient j: z = the coefficient of ALL signals; sigma = std(z); nbins = ceil((30 Nx)^(1/5)),
+//       mbins = ceil(100 / nbins), pdf_len = (nbins + 1) mbins; delta = (max z - min z + sigma) / (pdf_len - 1);
+//       rng = range(min z - sigma / 2, step = delta, length = pdf_len); Gamma[j, :, c] = density of
+//       ash(z of class c, rng = rng, m = mbins, kernel = Kernels.triangular)
+//   energy_map(Xw, y, Signatures(:pdf))       ldb/ldb_energymap.jl:216-232: the same construction per class (sigma, min, max
+//       of the class's own values), weight of signal k = pdf(epdf, z[k])
+// `ash`, `xy` and `pdf` belong to AverageShiftedHistograms.jl (Project.toml compat "0.8, 0.9"), which is NOT in the
+// reference tree.  Its published algorithm, restated: bin index of an observation ki = floor((y - first(rng)) / step + 1.5)
+// (1-based; the points of rng are bin centres), counted if 1 <= ki <= length(rng); density[i] = sum over the non-empty
+// bins k with |i - k| < m of counts[k] * kernel((i - k) / m), triangular kernel 1 - |u|; scaled by 1 / (sum(density) *
+// step) so that it integrates to one; pdf(o, x) interpolates the density linearly between the two points of rng around x
+// (0 outside).  Parity unpinned (no copy of that package and no Julia here): pinned by the oracle's restatement of the
+// same text and by the defining properties (unit integral, weights inside the density's range).
+// One workgroup per coefficient: its N values are staged in LDS (the loads of neighbouring coefficients share cache
+// lines: XCD-aware order), mean / deviation / extrema are workgroup reductions, the class histograms are LDS atomics.
+// ------------------------------------------------------------------------------------------------------------------
+struct LsAsh { int nbins, mbins, len; };
+
+template <typename T> __device__ T ls_block_red(T v, T *red, int op)          // op 0 sum, 1 min, 2 max
+{
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = LS_NT >> 1; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const T a = red[threadIdx.x], b = red[threadIdx.x + s];
+            red[threadIdx.x] = op == 0 ? a + b : op == 1 ? (b < a ? b : a) : (b > a ? b : a);
+        }
+        __syncthreads();
+    }
+    const T r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// sigma (corrected, two passes), min, max of z[0, cnt)
+__device__ void ls_moments(const double *z, int cnt, double *red, double &sigma, double &zmin, double &zmax)
+{
+    double s = 0, mn = ls_inf<double>(), mx = -ls_inf<double>();
+    for (int i = threadIdx.x; i < cnt; i += LS_NT) { const double v = z[i]; s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    const double mean = ls_block_red<double>(s, red, 0) / cnt;
+    zmin = ls_block_red<double>(mn, red, 1);
+    zmax = ls_block_red<double>(mx, red, 2);
+    double q = 0;
+    for (int i = threadIdx.x; i < cnt; i += LS_NT) { const double d = z[i] - mean; q += d * d; }
+    sigma = sqrt(ls_block_red<double>(q, red, 0) / (cnt - 1));
+}
+
+// counts -> density (in place semantics of _ash!): dens[i], i in [0, len)
+__device__ void ls_ash_density(const int *counts, double *dens, int len, int m, double delta, double *red)
+{
+    double part = 0;
+    for (int i = threadIdx.x; i < len; i += LS_NT) {
+        double d = 0;
+        const int k0 = max(0, i - m + 1), k1 = min(len - 1, i + m - 1);
+        for (int k = k0; k <= k1; ++k)
+            if (counts[k]) d += counts[k] * (1.0 - fabs((double)(i - k) / m));
+        dens[i] = d;
+        part += d;
+    }
+    const double denom = 1.0 / (ls_block_red<double>(part, red, 0) * delta);
+    for (int i = threadIdx.x; i < len; i += LS_NT) dens[i] *= denom;
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(LS_NT) void k_pdf_energy_map(const T *__restrict__ X, int64_t nk, int N, const int *__restrict__ cls, int nc,
+                                                          LsAsh A, double *__restrict__ Gamma)
+{
+    extern __shared__ __attribute__((aligned(16))) char ls_smem[];
+    double *z = reinterpret_cast<double *>(ls_smem);                     // N values
+    double *dens = z + N;                                                // len
+    int *counts = reinterpret_cast<int *>(dens + A.len);                 // len
+    __shared__ double red[LS_NT];
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int64_t e = bid;
+    for (int i = threadIdx.x; i < N; i += LS_NT) z[i] = (double)X[e + nk * (int64_t)i];
+    __syncthreads();
+    double sigma, zmin, zmax;
+    ls_moments(z, N, red, sigma, zmin, zmax);
+    const double delta = (zmax - zmin + sigma) / (A.len - 1);
+    const double a = zmin - 0.5 * sigma, dinv = 1.0 / delta;
+    for (int c = 0; c < nc; ++c) {
+        for (int i = threadIdx.x; i < A.len; i += LS_NT) counts[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < N; i += LS_NT)
+            if (cls[i] == c) {
+                const int ki = (int)floor((z[i] - a) * dinv + 1.5);
+                if (ki >= 1 && ki <= A.len) atomicAdd(&counts[ki - 1], 1);
+            }
+        __syncthreads();
+        ls_ash_density(counts, dens, A.len, A.mbins, delta, red);
+        for (int i = threadIdx.x; i < A.len; i += LS_NT) Gamma[e + nk * ((int64_t)i + (int64_t)A.len * c)] = dens[i];
+        __syncthreads();
+    }
+}
+
+// W[e, signal] = pdf(ash of the signal's class at coefficient e, X[e, signal])
+template <typename T>
+__global__ __launch_bounds__(LS_NT) void k_signature_weights(const T *__restrict__ X, int64_t nk, int N, const int *__restrict__ order,
+                                                             LsClasses C, LsAsh A, T *__restrict__ W)
+{
+    extern __shared__ __attribute__((aligned(16))) char ls_smem[];
+    double *z = reinterpret_cast<double *>(ls_smem);                     // the class's values (<= N)
+    double *dens = z + N;
+    int *counts = reinterpret_cast<int *>(dens + A.len);
+    __shared__ double red[LS_NT];
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int64_t e = bid;
+    for (int c = 0; c < C.nc; ++c) {
+        const int cnt = C.cnt[c];
+        const int *ord = order + C.sigoff[c];
+        for (int i = threadIdx.x; i < cnt; i += LS_NT) z[i] = (double)X[e + nk * (int64_t)ord[i]];
+        for (int i = threadIdx.x; i < A.len; i += LS_NT) counts[i] = 0;
+        __syncthreads();
+        double sigma, zmin, zmax;
+        ls_moments(z, cnt, red, sigma, zmin, zmax);
+        const double delta = (zmax - zmin + sigma) / (A.len - 1);
+        const double a = zmin - 0.5 * sigma, dinv = 1.0 / delta;
+        for (int i = threadIdx.x; i < cnt; i += LS_NT) {
+            const int ki = (int)floor((z[i] - a) * dinv + 1.5);
+            if (ki >= 1 && ki <= A.len) atomicAdd(&counts[ki - 1], 1);
+        }
+        __syncthreads();
+        ls_ash_density(counts, dens, A.len, A.mbins, delta, red);
+        for (int i = threadIdx.x; i < cnt; i += LS_NT) {
+            // searchsortedlast(rng, x) with rng[j] = a + (j - 1) delta (1-based), then linear interpolation
+            const double x = z[i];
+            int j = (int)floor((x - a) * dinv) + 1;
+            while (j >= 1 && a + (j - 1) * delta > x) --j;
+            while (j < A.len && a + j * delta <= x) ++j;
+            double w = 0.0;
+            if (j >= 1 && j < A.len) {
+                const double r0 = a + (j - 1) * delta, r1 = a + j * delta;
+                w = dens[j - 1] + (dens[j] - dens[j - 1]) * (x - r0) / (r1 - r0);
+            }
+            W[e + nk * (int64_t)ord[i]] = (T)w;
+        }
+        __syncthreads();
+    }
+}
+
+// earth mover's distance with one weight per (coefficient, signal): rows of weights travel with the keys
+template <typename T>
+__global__ __launch_bounds__(LS_NT) void k_emd_weighted(const T *__restrict__ X, const T *__restrict__ Wt, int64_t nk, const int *__restrict__ order,
+                                                        LsClasses C, T *__restrict__ D)
+{
+    extern __shared__ __attribute__((aligned(16))) char ls_smem[];
+    T *win = reinterpret_cast<T *>(ls_smem);                             // keys: one row per class (TC = 1)
+    int rows = 0;
+    for (int c = 0; c < C.nc; ++c) rows += C.npad[c];
+    T *wts = win + rows;                                                 // weights, then their inclusive prefix sums
+    __shared__ T red[LS_NT];
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int64_t e = bid;
+    for (int c = 0; c < C.nc; ++c) {
+        const int np = C.npad[c];
+        for (int k = threadIdx.x; k < np; k += LS_NT) {
+            T v = ls_inf<T>(), w = 0;
+            if (k < C.cnt[c]) { const int64_t a = e + nk * (int64_t)order[C.sigoff[c] + k]; v = X[a]; w = Wt[a]; }
+            win[C.rowoff[c] + k] = v; wts[C.rowoff[c] + k] = w;
+        }
+    }
+    __syncthreads();
+    {   // key-value bitonic sort of every row
+        int npmax = 2;
+        for (int c = 0; c < C.nc; ++c) npmax = max(npmax, C.npad[c]);
+        for (int k = 2; k <= npmax; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int c = 0; c < C.nc; ++c) {
+                    const int np = C.npad[c];
+                    if (k > np) continue;
+                    T *v = win + C.rowoff[c], *w = wts + C.rowoff[c];
+                    for (int i = threadIdx.x; i < (np >> 1); i += LS_NT) {
+                        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+                        const bool up = (lo & k) == 0;
+                        const T a = v[lo], b = v[hi];
+                        if ((a > b) == up) { v[lo] = b; v[hi] = a; const T t = w[lo]; w[lo] = w[hi]; w[hi] = t; }
+                    }
+                }
+                __syncthreads();
+            }
+    }
+    if (threadIdx.x < C.nc) {                                            // prefix sums of the sorted weights (sequential per row)
+        T *w = wts + C.rowoff[threadIdx.x];
+        T run = 0;
+        for (int k = 0; k < C.cnt[threadIdx.x]; ++k) { run += w[k]; w[k] = run; }
+    }
+    __syncthreads();
+    T total = 0;
+    for (int c1 = 0; c1 < C.nc; ++c1)
+        for (int c2 = c1 + 1; c2 < C.nc; ++c2) {
+            const T *p = win + C.rowoff[c1], *q = win + C.rowoff[c2], *Pw = wts + C.rowoff[c1], *Qw = wts + C.rowoff[c2];
+            const int n1 = C.cnt[c1], n2 = C.cnt[c2];
+            T acc = 0;
+            for (int i = threadIdx.x; i < n1 + n2; i += LS_NT) {
+                T x, succ;
+                if (i < n1) {
+                    x = p[i];
+                    const int lb = ls_lower<T>(q, n2, x);
+                    succ = i + 1 < n1 ? p[i + 1] : ls_inf<T>();
+                    if (lb < n2 && q[lb] < succ) succ = q[lb];
+                } else {
+                    const int j = i - n1;
+                    x = q[j];
+                    const int ub = ls_upper<T>(p, n1, x);
+                    succ = j + 1 < n2 ? q[j + 1] : ls_inf<T>();
+                    if (ub < n1 && p[ub] < succ) succ = p[ub];
+                }
+                if (succ < ls_inf<T>()) {
+                    const int up = ls_upper<T>(p, n1, x), uq = ls_upper<T>(q, n2, x);
+                    const T Fp = up ? Pw[up - 1] : (T)0, Fq = uq ? Qw[uq - 1] : (T)0;
+                    acc += (T)fabs((double)(T)(Fp - Fq)) * (succ - x);
+                }
+            }
+            const T s = ls_block_sum<T>(acc, red);
+            total += s / (Pw[n1 - 1] + Qw[n2 - 1]);
+        }
+    if (threadIdx.x == 0) D[e] = total;
+}
+
+namespace {
+
+int ls_classes(const int32_t *cls, int64_t N, int nc, LsClasses *C, std::vector<int> *order)
+{
+    WX_REQUIRE(cls != nullptr, WX_EARG, "NULL labels");
+    WX_REQUIRE(nc > 1, WX_EASSERT, "@assert nc > 1");
+    WX_REQUIRE(nc <= LS_MAXC, WX_EUNSUPPORTED, "more than 64 classes");
+    WX_REQUIRE(N >= 1 && N < ((int64_t)1 << 31), WX_EUNSUPPORTED, "bad number of signals");
+    C->nc = nc;
+    order->assign((size_t)N, 0);
+    std::vector<int> offs((size_t)nc + 1, 0);
+    for (int64_t i = 0; i < N; ++i) {
+        WX_REQUIRE(cls[i] >= 0 && cls[i] < nc, WX_EARG, "class index outside [0, nc)");
+        offs[(size_t)cls[i] + 1]++;
+    }
+    for (int c = 0; c < nc; ++c) {
+        WX_REQUIRE(offs[(size_t)c + 1] > 0, WX_EARG, "a class has no signal");
+        offs[(size_t)c + 1] += offs[(size_t)c];
+    }
+    std::vector<int> pos(offs.begin(), offs.end() - 1);
+    for (int64_t i = 0; i < N; ++i) (*order)[(size_t)pos[(size_t)cls[i]]++] = (int)i;
+    int off = 0;
+    for (int c = 0; c < nc; ++c) {
+        C->cnt[c] = offs[(size_t)c + 1] - offs[(size_t)c];
+        C->sigoff[c] = offs[(size_t)c];
+        int np = 2;
+        while (np < C->cnt[c]) np <<= 1;
+        C->npad[c] = np;
+        C->rowoff[c] = off;
+        off += np;
+    }
+    return WX_OK;
+}
+
+LsAsh ls_ash_params(int64_t Nx)
+{
+    LsAsh A;
+    A.nbins = (int)ceil(pow(30.0 * (double)Nx, 0.2));                    // ceil(Int, (30 Nx)^(1/5)), ldb_energymap.jl:158
+    A.mbins = (int)ceil(100.0 / A.nbins);
+    A.len = (A.nbins + 1) * A.mbins;
+    return A;
+}
+
+template <typename T>
+int api_pdf_map(const T *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *Gamma, void *stream)
+{
+    WX_REQUIRE(nk >= 1 && N >= 2, WX_EARG, "bad dimensions");
+    LsClasses C;
+    std::vector<int> order;
+    int rc = ls_classes(cls, N, nc, &C, &order);
+    if (rc) return rc;
+    const LsAsh A = ls_ash_params(N);
+    const size_t lds = sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len;
+    WX_REQUIRE(lds <= 150 * 1024, WX_EUNSUPPORTED, "more signals than fit the LDS window of one coefficient");
+    if ((rc = need_device())) return rc;
+    hipStream_t st = wx_stream(stream);
+    WxScratch scr(st);
+    WxIO io(st);
+    const T *dX = (const T *)io.in(X, sizeof(T) * nk * N);
+    double *dG = (double *)io.out(Gamma, sizeof(double) * nk * A.len * nc);
+    if (!dX || !dG) return io.finish(WX_EHIP);
+    const int *dcls = (const int *)scr.upload(cls, sizeof(int32_t) * (size_t)N);
+    if (!dcls) return io.finish(WX_EHIP);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_pdf_energy_map<T>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return io.finish(wx_set_error(WX_EHIP, "hipFuncSetAttribute(LDS)"));
+    hipLaunchKernelGGL(k_pdf_energy_map<T>, dim3((unsigned)nk), dim3(LS_NT), lds, st, dX, nk, (int)N, dcls, nc, A, dG);
+    if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "density map kernel failed to launch"));
+    return io.finish(WX_OK);
+}
+
+// kind 0: W = signature weights; kind 1: D = weighted earth mover's distance summed over the class pairs
+template <typename T>
+int api_signature(int kind, const T *X, const T *Win, int64_t nk, int64_t N, int64_t Ntot, const int32_t *cls, int nc, T *out, void *stream)
+{
+    WX_REQUIRE(nk >= 1 && N >= 2, WX_EARG, "bad dimensions");
+    LsClasses C;
+    std::vector<int> order;
+    int rc = ls_classes(cls, N, nc, &C, &order);
+    if (rc) return rc;
+    const LsAsh A = ls_ash_params(Ntot);
+    int64_t rows = 0;
+    for (int c = 0; c < nc; ++c) { WX_REQUIRE(kind == 1 || C.cnt[c] >= 2, WX_EARG, "a class needs two signals for its deviation"); rows += C.npad[c]; }
+    const size_t lds = kind == 0 ? sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len : sizeof(T) * 2 * (size_t)rows;
+    WX_REQUIRE(lds <= 150 * 1024, WX_EUNSUPPORTED, "more signals than fit the LDS window of one coefficient");
+    if ((rc = need_device())) return rc;
+    hipStream_t st = wx_stream(stream);
+    WxScratch scr(st);
+    WxIO io(st);
+    const T *dX = (const T *)io.in(X, sizeof(T) * nk * N);
+    const T *dW = kind == 1 ? (const T *)io.in(Win, sizeof(T) * nk * N) : nullptr;
+    T *dout = (T *)io.out(out, sizeof(T) * nk * (kind == 0 ? N : 1));
+    if (!dX || !dout || (kind == 1 && !dW)) return io.finish(WX_EHIP);
+    const int *dorder = (const int *)scr.upload(order.data(), order.size() * sizeof(int));
+    if (!dorder) return io.finish(WX_EHIP);
+    const void *f = kind == 0 ? reinterpret_cast<const void *>(k_signature_weights<T>) : reinterpret_cast<const void *>(k_emd_weighted<T>);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return io.finish(wx_set_error(WX_EHIP, "hipFuncSetAttribute(LDS)"));
+    if (kind == 0)
+        hipLaunchKernelGGL(k_signature_weights<T>, dim3((unsigned)nk), dim3(LS_NT), lds, st, dX, nk, (int)N, dorder, C, A, dout);
+    else
+        hipLaunchKernelGGL(k_emd_weighted<T>, dim3((unsigned)nk), dim3(LS_NT), lds, st, dX, dW, nk, dorder, C, dout);
+    if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "signature kernel failed to launch"));
+    return io.finish(WX_OK);
+}
+
+}  // namespace
+
+extern "C" {
+int wx_pdf_energy_map_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *Gamma, void *stream)
+{ return api_pdf_map<double>(X, nk, N, cls, nc, Gamma, stream); }
+int wx_pdf_energy_map_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *Gamma, void *stream)
+{ return api_pdf_map<float>(X, nk, N, cls, nc, Gamma, stream); }
+int wx_signature_weights_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *W, void *stream)
+{ return api_signature<double>(0, X, nullptr, nk, N, N, cls, nc, W, stream); }
+int wx_signature_weights_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, float *W, void *stream)
+{ return api_signature<float>(0, X, nullptr, nk, N, N, cls, nc, W, stream); }
+int wx_emd_measure_weighted_f64(const double *X, const double *W, int64_t nk, int64_t N, const int32_t *cls, int nc, double *D, void *stream)
+{ return api_signature<double>(1, X, W, nk, N, N, cls, nc, D, stream); }
+int wx_emd_measure_weighted_f32(const float *X, const float *W, int64_t nk, int64_t N, const int32_t *cls, int nc, float *D, void *stream)
+{ return api_signature<float>(1, X, W, nk, N, N, cls, nc, D, stream); }
+}

@@ -7,8 +7,8 @@ the basis gather (`getbasiscoefall` / `wptall`) and the inverse (`iwptall`).  Th
 costs with top_k, the (host) tree selection and the ordering work on the small (n, levels, classes) maps.
 Order statistics over the signal axis are device kernels too (csrc/wx_ldbstat.hip): the class medians / MADs of
 RobustFishersClassSeparability and the earth mover's distance between the class signatures of Signatures(:equal).
-The ProbabilityDensity map and Signatures(:pdf) rest on AverageShiftedHistograms.jl (outside the reference tree)
-and raise."""
+The ProbabilityDensity map and the Signatures(:pdf) weights are average shifted histograms over the signal axis
+(AverageShiftedHistograms.jl is outside the reference tree: its published algorithm is restated in the kernels)."""
 import ctypes
 import itertools
 
@@ -45,6 +45,10 @@ class HellingerDistance:
     """ldb_measures.jl:88"""
 
 
+class ProbabilityDensity:
+    """ldb_energymap.jl:32"""
+
+
 class EarthMoverDistance:
     """ldb_measures.jl:104"""
 
@@ -66,7 +70,12 @@ class SignatureMap(list):
     class Entry:
         def __init__(self, owner, c):
             self._o, self._c = owner, c
-            self.weight = 1.0 / float((owner.idx == c).sum())
+
+        @property
+        def weight(self):
+            if self._o.W is None:
+                return 1.0 / float((self._o.idx == self._c).sum())
+            return np.asfortranarray(to_numpy(self._o.W)[..., np.flatnonzero(self._o.idx == self._c)])
 
         @property
         def coef(self):
@@ -76,8 +85,8 @@ class SignatureMap(list):
         def __getitem__(self, k):
             return self.coef if k in (0, "coef") else self.weight
 
-    def __init__(self, Xw, classes, idx):
-        self.Xw, self.classes, self.idx = Xw, classes, idx
+    def __init__(self, Xw, classes, idx, W=None):
+        self.Xw, self.classes, self.idx, self.W = Xw, classes, idx, W
         super().__init__(SignatureMap.Entry(self, c) for c in range(len(classes)))
 
 
@@ -108,18 +117,31 @@ def energy_map(Xw, y, method=None, classes=None, return_norm_sum=False):
     order (a shard of a multi-GPU batch passes the global unique(y)); `return_norm_sum` also returns the per-class
     denominators so that shards can be combined (distributed.energy_map_sharded)."""
     method = TimeFrequency() if method is None else method
-    if isinstance(method, Signatures):
-        if method.weight != "equal":
-            raise _lib.WxError(_lib.WX_EUNSUPPORTED, "Signatures(:pdf) needs AverageShiftedHistograms.jl's ash / pdf: not on the device path")
+    if isinstance(method, (Signatures, ProbabilityDensity)):
         Xa = Arg(Xw)
         N = Xa.arr.ndim
         assert 3 <= N <= 4
         cl, idx = _classes(y)
         assert Xa.shape[-1] == idx.size and len(cl) > 1
         assert 1 <= Xa.shape[N - 2] - 1 <= maxtransformlevels(int(min(Xa.shape[:N - 2])))
-        return SignatureMap(Xw, cl, idx)
+        ne = int(np.prod(Xa.shape[:-1], dtype=np.int64))
+        Nx = Xa.shape[-1]
+        cp = ctypes.c_void_p(idx.ctypes.data)
+        if isinstance(method, ProbabilityDensity):                     # ldb_energymap.jl:143-184: Array{Float64}
+            nbins = int(np.ceil((30 * Nx) ** (1 / 5)))
+            pdf_len = (nbins + 1) * int(np.ceil(100 / nbins))
+            G = Xa.new(tuple(Xa.shape[:-1]) + (pdf_len, len(cl)), np.float64)
+            fn = getattr(_lib.lib(), "wx_pdf_energy_map" + Xa.suffix)
+            _lib.check(fn(Xa.ptr, ne, Nx, cp, len(cl), G.ptr, Xa.stream()))
+            return G.arr
+        if method.weight == "equal":
+            return SignatureMap(Xw, cl, idx)
+        W = Xa.new(Xa.shape)
+        fn = getattr(_lib.lib(), "wx_signature_weights" + Xa.suffix)
+        _lib.check(fn(Xa.ptr, ne, Nx, cp, len(cl), W.ptr, Xa.stream()))
+        return SignatureMap(Xw, cl, idx, W.arr)
     if not isinstance(method, TimeFrequency):
-        raise _lib.WxError(_lib.WX_EUNSUPPORTED, "the TimeFrequency and Signatures(:equal) energy maps are on the device path")
+        raise _lib.WxError(_lib.WX_EARG, "unknown energy map")
     Xa = Arg(Xw)
     N = Xa.arr.ndim
     assert 3 <= N <= 4
@@ -169,16 +191,25 @@ def discriminant_measure(G, dm=None):
         sz = Xa.shape[:-1]
         ne = int(np.prod(sz, dtype=np.int64))
         D = Xa.new(tuple(sz))
-        fn = getattr(_lib.lib(), "wx_emd_measure" + Xa.suffix)
-        _lib.check(fn(Xa.ptr, ne, Xa.shape[-1], ctypes.c_void_p(G.idx.ctypes.data), len(G.classes), D.ptr, Xa.stream()))
-        return D.arr
+        cp = ctypes.c_void_p(G.idx.ctypes.data)
+        if G.W is None:
+            fn = getattr(_lib.lib(), "wx_emd_measure" + Xa.suffix)
+            _lib.check(fn(Xa.ptr, ne, Xa.shape[-1], cp, len(G.classes), D.ptr, Xa.stream()))
+        else:
+            Wa = Arg(G.W)
+            fn = getattr(_lib.lib(), "wx_emd_measure_weighted" + Xa.suffix)
+            _lib.check(fn(Xa.ptr, Wa.ptr, ne, Xa.shape[-1], cp, len(G.classes), D.ptr, Xa.stream()))
+        return np.asfortranarray(to_numpy(D.arr))                     # a small (sz..., L) map, like the other measures
     dm = AsymmetricRelativeEntropy() if dm is None else dm
     G = to_numpy(G)
     nc = G.shape[-1]
-    assert 3 <= G.ndim <= 4 and nc > 1
-    D = np.zeros(G.shape[:-1], dtype=G.dtype, order="F")
+    assert 3 <= G.ndim <= 5 and nc > 1
+    # ldb_measures.jl:146-164: a 4-D map whose third axis is long (>= 100) is a density map of 1-D signals, 5-D of 2-D
+    density = G.ndim == 5 or (G.ndim == 4 and G.shape[2] >= 100)
+    D = np.zeros(G.shape[:-2] if density else G.shape[:-1], dtype=G.dtype, order="F")
     for i, j in itertools.combinations(range(nc), 2):
-        D = D + _pair(G[..., i], G[..., j], dm)
+        P = _pair(G[..., i], G[..., j], dm)
+        D = D + (np.cumsum(P, axis=-1)[..., -1] if density else P)      # sum over the density axis in index order (:245-249)
     return np.asfortranarray(D)
 
 
