@@ -259,6 +259,85 @@ function thresholdall!(xw::HIP{Float64,2}, th, t::Vector{Float64}; row_lo::Integ
     return xw
 end
 
+# threshold selection of SureShrink / RelErrorShrink for every signal (Denoising.jl:146-166, 285-327): what
+# `SureShrink(xw, redundant, tree)` and `denoiseall(...; estnoise = relerrorthreshold)` evaluate signal by signal.
+# `leaves` = getleaf(tree, :binary) for swpd / acwpd tables (nothing = every column).
+function _colmask(leaves, k)
+    leaves === nothing && return C_NULL
+    return UInt8.(leaves[1:k])
+end
+function surethresholdall(xw::HIP{Float64}, leaves = nothing)
+    n = size(xw, 1); N = size(xw, ndims(xw)); k = ndims(xw) == 2 ? 1 : size(xw, 2)
+    t = Vector{Float64}(undef, N)
+    check(ccall((:wx_surethreshold_f64, LIB), Cint, (Ptr{Float64}, Int64, Int64, Int64, Ptr{UInt8}, Ptr{Float64}, Ptr{Cvoid}),
+                parent(xw), n, k, N, _colmask(leaves, k), t, C_NULL))
+    return t
+end
+function relerrorthresholdall(xw::HIP{Float64}, leaves = nothing, elbows::Integer = 2)
+    n = size(xw, 1); N = size(xw, ndims(xw)); k = ndims(xw) == 2 ? 1 : size(xw, 2)
+    t = Vector{Float64}(undef, N)
+    check(ccall((:wx_relerrorthreshold_f64, LIB), Cint,
+                (Ptr{Float64}, Int64, Int64, Int64, Ptr{UInt8}, Cint, Ptr{Float64}, Ptr{Cvoid}),
+                parent(xw), n, k, N, _colmask(leaves, k), elbows, t, C_NULL))
+    return t
+end
+
+# 3-D dwtall / idwtall (dwt_all.jl:39-54, 95-110 on 4-D arrays: cubes with dyadic sides)
+function WaveletsExt.dwtall(x::HIP{Float64,4}, wt::OrthoFilter, L::Integer = maxtransformlevels(size(x, 1)))
+    y = similar(x); q = WT.qmf(wt)
+    check(ccall((:wx_dwt3d_f64, LIB), Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Cint, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                parent(x), parent(y), size(x, 1), size(x, 2), size(x, 3), L, size(x, 4), q, length(q), C_NULL))
+    return y
+end
+function WaveletsExt.idwtall(xw::HIP{Float64,4}, wt::OrthoFilter, L::Integer = maxtransformlevels(size(xw, 1)))
+    y = similar(xw); q = WT.qmf(wt)
+    check(ccall((:wx_idwt3d_f64, LIB), Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Cint, Int64, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                parent(xw), parent(y), size(xw, 1), size(xw, 2), size(xw, 3), L, size(xw, 4), q, length(q), C_NULL))
+    return y
+end
+
+# LDB order statistics and density maps over the signal axis (ldb/ldb_measures.jl:185-201, 254-360, 481-519,
+# ldb/ldb_energymap.jl:143-238).  cls[i] in 0:nc-1 = index of y[i] in unique(y).
+function _cls(y)
+    c = unique(y)
+    return Int32[findfirst(==(v), c) - 1 for v in y], length(c)
+end
+function class_median_mad(coefs::HIP{Float64}, y)
+    cls, nc = _cls(y); N = size(coefs, ndims(coefs)); ne = length(coefs) ÷ N
+    med = Array{Float64}(undef, size(coefs)[1:end-1]..., nc); mad = similar(med)
+    check(ccall((:wx_class_median_mad_f64, LIB), Cint, (Ptr{Float64}, Int64, Int64, Ptr{Int32}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                parent(coefs), ne, N, cls, nc, med, mad, C_NULL))
+    return med, mad                       # discriminant_power(coefs, y, RobustFishersClassSeparability()) finishes on these
+end
+function emd_measure(Xw::HIP{Float64}, y, W::Union{Nothing,HIP{Float64}} = nothing)   # discriminant_measure(energy_map(Xw, y, Signatures()), EarthMoverDistance())
+    cls, nc = _cls(y); N = size(Xw, ndims(Xw)); ne = length(Xw) ÷ N
+    D = Array{Float64}(undef, size(Xw)[1:end-1]...)
+    if W === nothing
+        check(ccall((:wx_emd_measure_f64, LIB), Cint, (Ptr{Float64}, Int64, Int64, Ptr{Int32}, Cint, Ptr{Float64}, Ptr{Cvoid}),
+                    parent(Xw), ne, N, cls, nc, D, C_NULL))
+    else
+        check(ccall((:wx_emd_measure_weighted_f64, LIB), Cint,
+                    (Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Int32}, Cint, Ptr{Float64}, Ptr{Cvoid}),
+                    parent(Xw), parent(W), ne, N, cls, nc, D, C_NULL))
+    end
+    return D
+end
+function WaveletsExt.energy_map(Xw::HIP{Float64}, y, ::ProbabilityDensity)
+    cls, nc = _cls(y); N = size(Xw, ndims(Xw)); ne = length(Xw) ÷ N
+    nbins = ceil(Int, (30 * N)^(1 / 5)); plen = (nbins + 1) * ceil(Int, 100 / nbins)
+    G = Array{Float64}(undef, size(Xw)[1:end-1]..., plen, nc)
+    check(ccall((:wx_pdf_energy_map_f64, LIB), Cint, (Ptr{Float64}, Int64, Int64, Ptr{Int32}, Cint, Ptr{Float64}, Ptr{Cvoid}),
+                parent(Xw), ne, N, cls, nc, G, C_NULL))
+    return G
+end
+function signature_weights(Xw::HIP{Float64}, y)          # the :pdf weights of energy_map(Xw, y, Signatures(:pdf))
+    cls, nc = _cls(y); N = size(Xw, ndims(Xw)); ne = length(Xw) ÷ N
+    W = similar(Xw)
+    check(ccall((:wx_signature_weights_f64, LIB), Cint, (Ptr{Float64}, Int64, Int64, Ptr{Int32}, Cint, Ptr{Float64}, Ptr{Cvoid}),
+                parent(Xw), ne, N, cls, nc, parent(W), C_NULL))
+    return W
+end
+
 # ---- shift-invariant packet decomposition for a whole batch (SIWT.jl:57-229 per signal) --------------------------
 # The flat table of include/waveletsext_hip.h instead of one Dict of node objects per signal: W (n, NS, N), node
 # (j, i, t) = W[i*(n>>j)+1 : (i+1)*(n>>j), coloff(j) + (t >> max(0, j-d)) + 1, signal].  `siwt_node` rebuilds the
