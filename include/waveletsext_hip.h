@@ -321,6 +321,18 @@ int wx_idwt3d_f64(const double *x, double *y, int64_t n1, int64_t n2, int64_t n3
 int wx_idwt3d_f32(const float *x, float *y, int64_t n1, int64_t n2, int64_t n3, int L, int64_t batch, const double *qmf,
                   int F, void *stream);
 
+/* iwpt / idwt with the thresholding step of denoise() applied while the coefficients are loaded (Denoising.jl:510-533:
+ * threshold(x, dnt.th, sigma * dnt.t) followed by idwt / iwpt): one pass over the coefficient array instead of two.
+ * Arguments as wx_iwpt1d_* plus those of wx_threshold_* (k = 1): rows [row_lo, n) of signal i are thresholded with
+ * scale * t[0] (nt = 1) or scale * t[i] (nt = batch) -- t may be the device vector wx_noisest_* just wrote and scale =
+ * dnt.t, so that the noise estimates never visit the host.  xw is not modified. */
+int wx_iwpt1d_thresh_f64(const double *xw, double *xhat, int64_t n, int L, const uint8_t *tree, int64_t ntree,
+                         int64_t batch, const double *qmf, int F, int th_kind, const double *t, int64_t nt,
+                         int64_t row_lo, double scale, void *stream);
+int wx_iwpt1d_thresh_f32(const float *xw, float *xhat, int64_t n, int L, const uint8_t *tree, int64_t ntree,
+                         int64_t batch, const double *qmf, int F, int th_kind, const float *t, int64_t nt,
+                         int64_t row_lo, double scale, void *stream);
+
 /* Threshold selection of SureShrink and RelErrorShrink for every signal of the batch (they are what
  * denoiseall(...; estnoise = relerrorthreshold) and the SureShrink(xw, redundant, tree) constructor evaluate):
  * wx_surethreshold_*:     surethreshold(coef, redundant, tree)             Denoising.jl:146-166

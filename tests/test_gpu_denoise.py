@@ -154,3 +154,32 @@ def test_noisest_degenerate_distributions(wx, oracle):
             v32 = v.astype(np.float32)
         if np.isfinite(v32).all():
             assert wx.noisest(v32, False) == oracle.noisest(v32, False)
+
+
+@pytest.mark.parametrize("inputtype", ["sig", "dwt", "wpt"])
+@pytest.mark.parametrize("smooth", ["regular", "undersmooth"])
+def test_device_resident_pipeline_equals_the_host_staged_one(wx, oracle, inputtype, smooth):
+    """device tensors take the pipeline whose noise estimates stay on the device and whose threshold rides on the loads of the
+    inverse (wx_iwpt1d_thresh_*, Denoising.jl:510-533 in one pass): same numbers as the numpy path, which is checked against
+    the oracle above; every threshold rule, a tree-driven and a full-tree inverse (the latter falls back to threshold + lattice)"""
+    import torch
+    rng = np.random.default_rng(77)
+    wt = wx.wavelet(wx.WT.db4)
+    for n, L, B in ((256, 4, 7), (4096, 6, 3)):
+        x = np.asfortranarray(rng.standard_normal((n, B)) + np.sin(np.arange(n) / 9.0)[:, None] * 3)
+        tree = wx.maketree(n, L, "full")
+        xin = {"sig": x, "dwt": wx.dwtall(x, wt, L), "wpt": wx.wptall(x, wt, tree)}[inputtype]
+        for th in (wx.HardTH(), wx.SoftTH(), wx.SemiSoftTH(), wx.SteinTH()):
+            dnt = wx.VisuShrink(n, th)
+            ref = wx.denoiseall(xin, inputtype, wt, L=L, tree=tree, dnt=dnt, smooth=smooth)
+            xd = wx.to_colmajor(torch.from_numpy(np.ascontiguousarray(xin)).cuda())
+            got = wx.denoiseall(xd, inputtype, wt, L=L, tree=tree, dnt=dnt, smooth=smooth)
+            assert got.is_cuda
+            assert relerr(got.cpu().numpy(), ref) <= 1e-13, (inputtype, smooth, type(th).__name__, n)
+    # and the numpy path against the oracle at the larger size (tree-driven inverse with the fused threshold)
+    x = np.asfortranarray(rng.standard_normal((4096, 2)))
+    xw = wx.dwtall(x, wt, 5)
+    y = wx.denoiseall(xw, "dwt", wt, L=5, dnt=wx.VisuShrink(4096, wx.SoftTH()), smooth=smooth)
+    for i in range(2):
+        exp = oracle.denoise(xw[:, i], "dwt", wt.qmf, L=5, th="soft", smooth=smooth)
+        assert relerr(y[:, i], exp) <= 1e-10

@@ -123,6 +123,52 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     return io.finish(rc);
 }
 
+// ---- iwpt with the threshold of denoise() in its load stage ------------------------------------------------
+template <typename T>
+static int api_iwpt1d_thresh(const T *x, T *y, int64_t n, int L, const uint8_t *tree, int64_t ntree, int64_t batch, const double *qmf,
+                             int F, int th_kind, const T *t, int64_t nt, int64_t row_lo, double scale, void *stream)
+{
+    WxFilt filt;
+    int rc = wx_pack_filter(qmf, F, &filt);
+    if (rc) return rc;
+    WX_REQUIRE(n >= 1 && batch >= 0, WX_EARG, "iwpt: bad dimensions");
+    WX_REQUIRE(n < ((int64_t)1 << 30), WX_EUNSUPPORTED, "iwpt: signal length >= 2^30 not supported");
+    WX_REQUIRE(th_kind >= 0 && th_kind <= 3, WX_EARG, "th_kind: 0 HardTH, 1 SoftTH, 2 SemiSoftTH, 3 SteinTH");
+    WX_REQUIRE(t != nullptr && (nt == 1 || nt == batch), WX_EARG, "one threshold, or one per signal");
+    WX_REQUIRE(0 <= row_lo && row_lo <= n, WX_EBOUNDS, "row range outside the array");
+    hipStream_t st = wx_stream(stream);
+    WxScratch scr(st);
+    WxTree1d tr;
+    if (tree) WX_REQUIRE(wx_isdyadic(n) && wx_isvalidtree1d(n, tree, ntree), WX_EASSERT, "@assert isvalidtree(x, tree)");
+    else WX_REQUIRE(wx_isdyadic(n) && 0 <= L && L <= wx_maxtransformlevels(n), WX_EASSERT,
+                    "maketree: isdyadic(n) and 0 <= L <= maxtransformlevels(n)");
+    if ((rc = wx_need_device())) return rc;
+    if ((rc = wx_resolve_tree1d(n, L, tree, ntree, scr, &tr, "iwpt"))) return rc;
+    WxIO io(st);
+    const T *dx = (const T *)io.in(x, sizeof(T) * n * batch);
+    T *dy = (T *)io.out(y, sizeof(T) * n * batch);
+    const T *dt = (const T *)io.in(t, sizeof(T) * nt);
+    if ((batch && n) && (!dx || !dy || !dt)) return io.finish(WX_EHIP);
+    if (batch == 0) return io.finish(WX_OK);
+    const int per = nt == batch && batch > 1 ? 1 : 0;
+    if (tr.Leff >= 1 && !wx_force_generic() && wx_iwpt1d_thresh_fusable<T>(n, F, tr.dstatus)) {
+        const WxThreshArg thr{dt, th_kind, (int)row_lo, per, scale};
+        return io.finish(wx_dev_iwpt1d_thresh<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, thr, st));
+    }
+    // other kernels (full trees on the lattice, long signals, L = 0): threshold into a scratch copy, then the inverse
+    T *xt = (T *)scr.alloc(sizeof(T) * n * batch);
+    if (!xt) return io.finish(WX_EHIP);
+    if ((rc = wx_dev_threshold_copy<T>(dx, xt, n, batch, th_kind, dt, per, row_lo, scale, st))) return io.finish(rc);
+    const int force = wx_force_generic();
+    T *s1 = nullptr;
+    if (!(!force && wx_fused1d_ok<T>(n, F)) && tr.Leff > 1) {
+        s1 = (T *)scr.alloc(sizeof(T) * n * batch);
+        if (!s1) return io.finish(WX_EHIP);
+    }
+    rc = wx_dev_iwpt1d<T>(xt, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, nullptr, 0, n, s1, nullptr, st, force);
+    return io.finish(rc);
+}
+
 // ---- iwpd ---------------------------------------------------------------------------------
 template <typename T>
 static int api_iwpd1d(const T *xw, T *xh, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
@@ -219,6 +265,15 @@ int wx_iwpt1d_f64(const double *xw, double *xhat, int64_t n, int L, const uint8_
 int wx_iwpt1d_f32(const float *xw, float *xhat, int64_t n, int L, const uint8_t *tree, int64_t ntree,
                   int64_t batch, const double *qmf, int F, void *stream)
 { return api_wpt1d<float, true>(xw, xhat, n, L, tree, ntree, batch, qmf, F, stream); }
+
+int wx_iwpt1d_thresh_f64(const double *xw, double *xhat, int64_t n, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
+                         const double *qmf, int F, int th_kind, const double *t, int64_t nt, int64_t row_lo, double scale,
+                         void *stream)
+{ return api_iwpt1d_thresh<double>(xw, xhat, n, L, tree, ntree, batch, qmf, F, th_kind, t, nt, row_lo, scale, stream); }
+int wx_iwpt1d_thresh_f32(const float *xw, float *xhat, int64_t n, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
+                         const double *qmf, int F, int th_kind, const float *t, int64_t nt, int64_t row_lo, double scale,
+                         void *stream)
+{ return api_iwpt1d_thresh<float>(xw, xhat, n, L, tree, ntree, batch, qmf, F, th_kind, t, nt, row_lo, scale, stream); }
 
 int wx_iwpd1d_f64(const double *xw, double *xhat, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree,
                   int64_t batch, const double *qmf, int F, void *stream)

@@ -35,6 +35,32 @@ template <typename T> struct WxVec2;
 template <> struct WxVec2<double> { typedef double2 type; };
 template <> struct WxVec2<float> { typedef float2 type; };
 
+// Wavelets.Threshold rules (HardTH 0, SoftTH 1, SemiSoftTH 2, SteinTH 3), see wx_denoise.hip
+template <typename T> __device__ __forceinline__ T wx_thresh(T v, T tt, int th_kind)
+{
+    if (th_kind == 0) return (T)fabs((double)v) <= tt ? (T)0 : v;
+    const T sg = v > (T)0 ? (T)1 : (v < (T)0 ? (T)-1 : v);
+    if (th_kind == 1) { const T sh = (T)((T)fabs((double)v) - tt); return sh < (T)0 ? (T)0 : (T)(sg * sh); }
+    if (th_kind == 2) {
+        // semisoft (Gao-Bruce, upper knee at 2t): 0 below t, sign(x) * 2(|x| - t) up to 2t, x above
+        const T av = (T)fabs((double)v);
+        if (av > (T)((T)2 * tt)) return v;
+        const T tmp = (T)((T)((T)2 * av) - (T)((T)2 * tt));
+        return tmp < (T)0 ? (T)0 : (T)(sg * tmp);
+    }
+    const T sh = (T)((T)1 - (T)((T)(tt * tt) / (T)(v * v)));
+    return sh < (T)0 ? (T)0 : (T)(v * sh);
+}
+
+
+// optional threshold applied by an inverse transform while it loads the coefficients (denoise: threshold + inverse in one
+// pass over the table): rows [lo, n) of every signal, t[0] or t[signal]
+struct WxThreshArg {
+    const void *t;
+    int kind, lo, per_signal;
+    double scale;               // threshold = t[...] * scale (sigma_i * dnt.t with sigma left on the device)
+};
+
 static __device__ __forceinline__ int wx_modn(int x, int n)
 {
     int r = x % n;

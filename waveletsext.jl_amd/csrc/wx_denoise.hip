@@ -18,28 +18,13 @@ extern "C" int wx_device_count(void);
 
 namespace {
 
-template <typename T> __device__ __forceinline__ T wx_thresh(T v, T tt, int th_kind)
-{
-    if (th_kind == 0) return (T)fabs((double)v) <= tt ? (T)0 : v;
-    const T sg = v > (T)0 ? (T)1 : (v < (T)0 ? (T)-1 : v);
-    if (th_kind == 1) { const T sh = (T)((T)fabs((double)v) - tt); return sh < (T)0 ? (T)0 : (T)(sg * sh); }
-    if (th_kind == 2) {
-        // semisoft (Gao-Bruce, upper knee at 2t): 0 below t, sign(x) * 2(|x| - t) up to 2t, x above
-        const T av = (T)fabs((double)v);
-        if (av > (T)((T)2 * tt)) return v;
-        const T tmp = (T)((T)((T)2 * av) - (T)((T)2 * tt));
-        return tmp < (T)0 ? (T)0 : (T)(sg * tmp);
-    }
-    const T sh = (T)((T)1 - (T)((T)(tt * tt) / (T)(v * v)));
-    return sh < (T)0 ? (T)0 : (T)(v * sh);
-}
-
 // out of place: Y = X with the selected rows / columns thresholded (one read + one write of the table instead
 // of a copy followed by an in-place pass); colflag[c] != 0 selects column c (nullptr = all)
 template <typename T>
 __global__ __launch_bounds__(256) void k_threshold_copy(const T *__restrict__ X, T *__restrict__ Y, int n, int k,
                                                         int64_t batch, int th_kind, const T *__restrict__ t,
-                                                        int per_signal, int row_lo, const uint8_t *__restrict__ colflag)
+                                                        int per_signal, int row_lo, const uint8_t *__restrict__ colflag,
+                                                        double scale = 1.0)
 {
     const int64_t per_sig = (int64_t)n * k;
     const int64_t total = per_sig * batch;
@@ -49,7 +34,7 @@ __global__ __launch_bounds__(256) void k_threshold_copy(const T *__restrict__ X,
         const int c = (int)(rem / n), r = (int)(rem - (int64_t)c * n);
         const T v = X[g];
         const bool sel = r >= row_lo && (!colflag || colflag[c]);
-        Y[g] = sel ? wx_thresh<T>(v, per_signal ? t[sig] : t[0], th_kind) : v;
+        Y[g] = sel ? wx_thresh<T>(v, (T)((double)(per_signal ? t[sig] : t[0]) * scale), th_kind) : v;
     }
 }
 
@@ -223,6 +208,27 @@ __global__ __launch_bounds__(256) void k_mad(const T *__restrict__ X, int64_t si
     const T r = wx_median_lds<T>(v, cnt, &S);
     if (threadIdx.x == 0) sigma[blockIdx.x] = (T)(r / (T)0.6745);
 }
+
+}  // namespace
+
+// Y = X with rows [row_lo, n) thresholded (k = 1): used by the thresholding inverse when its kernel cannot take the
+// threshold in its own load stage
+template <typename T>
+int wx_dev_threshold_copy(const T *X, T *Y, int64_t n, int64_t batch, int th_kind, const T *t, int per_signal, int64_t row_lo,
+                          double scale, hipStream_t st)
+{
+    const int64_t total = n * batch;
+    int64_t grid = (total + 255) / 256;
+    if (grid > 256 * 32) grid = 256 * 32;
+    hipLaunchKernelGGL(k_threshold_copy<T>, dim3((unsigned)grid), dim3(256), 0, st, X, Y, (int)n, 1, batch, th_kind, t, per_signal,
+                       (int)row_lo, (const uint8_t *)nullptr, scale);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+template int wx_dev_threshold_copy<double>(const double *, double *, int64_t, int64_t, int, const double *, int, int64_t, double, hipStream_t);
+template int wx_dev_threshold_copy<float>(const float *, float *, int64_t, int64_t, int, const float *, int, int64_t, double, hipStream_t);
+
+namespace {
 
 int need_device()
 {

@@ -735,7 +735,7 @@ __global__ __launch_bounds__(NT, 4) void k_inv1d_fused(const T *__restrict__ xw,
                                                        int log2n, int L, int64_t batch, int64_t in_stride,
                                                        int64_t out_stride, WxFilt filt, WxFoldInv fold,
                                                        const uint8_t *__restrict__ status_g, int64_t nstatus,
-                                                       const int *__restrict__ colmap, int log2blk)
+                                                       const int *__restrict__ colmap, int log2blk, WxThreshArg thr)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     typedef typename WxVec2<T>::type V2;
@@ -773,7 +773,14 @@ __global__ __launch_bounds__(NT, 4) void k_inv1d_fused(const T *__restrict__ xw,
                     pre[2 * k] = reinterpret_cast<const V2 *>(xs + (int64_t)c0 * n)[2 * u];
                     pre[2 * k + 1] = reinterpret_cast<const V2 *>(xs + (int64_t)c1 * n)[2 * u + 1];
                 } else {
-                    const V4 v = reinterpret_cast<const V4 *>(xs)[u];
+                    V4 v = reinterpret_cast<const V4 *>(xs)[u];
+                    if (thr.t) {                 // denoise: the threshold rides on the load (rows >= thr.lo)
+                        const T tt = (T)((double)reinterpret_cast<const T *>(thr.t)[thr.per_signal ? sig : 0] * thr.scale);
+                        if (4 * u >= thr.lo) v.x = wx_thresh<T>(v.x, tt, thr.kind);
+                        if (4 * u + 1 >= thr.lo) v.y = wx_thresh<T>(v.y, tt, thr.kind);
+                        if (4 * u + 2 >= thr.lo) v.z = wx_thresh<T>(v.z, tt, thr.kind);
+                        if (4 * u + 3 >= thr.lo) v.w = wx_thresh<T>(v.w, tt, thr.kind);
+                    }
                     pre[2 * k].x = v.x; pre[2 * k].y = v.y; pre[2 * k + 1].x = v.z; pre[2 * k + 1].y = v.w;
                 }
             }
@@ -1119,53 +1126,73 @@ static int launch_fwd_fused(const T *x, T *y, int64_t n, int L, int64_t batch, i
 template <typename T, int F, int NT, int PF>
 static int launch_inv_fused_FNP(const T *xw, T *xh, int64_t n, int L, int64_t batch, int64_t is, int64_t os,
                                 const WxFilt &filt, const uint8_t *status, int64_t nstatus, const int *colmap,
-                                int log2blk, hipStream_t st)
+                                int log2blk, hipStream_t st, const WxThreshArg &thr)
 {
     const size_t lds = wx_fused_lds_bytes<T>(n) + (status ? (size_t)n : 0);     // + the tree bytes
     auto kern = k_inv1d_fused<T, F, NT, PF>;
     WX_HIP_CHECK(wx_allow_lds(kern, lds));
     const WxFoldInv fold = wx_make_fold_inv(filt);
     hipLaunchKernelGGL(kern, dim3(wx_fused_grid(lds, batch, NT)), dim3(NT), lds, st, xw, xh, wx_log2(n), L, batch,
-                       is, os, filt, fold, status, nstatus, colmap, log2blk);
+                       is, os, filt, fold, status, nstatus, colmap, log2blk, thr);
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
 template <typename T, int F, int NT>
 static int launch_inv_fused_FN(const T *xw, T *xh, int64_t n, int L, int64_t batch, int64_t is, int64_t os,
                                const WxFilt &filt, const uint8_t *status, int64_t nstatus, const int *colmap,
-                               int log2blk, hipStream_t st)
+                               int log2blk, hipStream_t st, const WxThreshArg &thr)
 {
-    if (n / 4 <= 2 * NT) return launch_inv_fused_FNP<T, F, NT, 2>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
+    if (n / 4 <= 2 * NT) return launch_inv_fused_FNP<T, F, NT, 2>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st, thr);
     if (NT >= 512 && n / 4 <= 4 * NT)
-        return launch_inv_fused_FNP<T, F, (NT >= 512 ? NT : 512), 4>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
+        return launch_inv_fused_FNP<T, F, (NT >= 512 ? NT : 512), 4>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st, thr);
     return wx_set_error(WX_EUNSUPPORTED, "fused inverse: signal too long for the staging registers");
 }
 template <typename T, int F>
 static int launch_inv_fused_F(const T *xw, T *xh, int64_t n, int L, int64_t batch, int64_t is, int64_t os,
                               const WxFilt &filt, const uint8_t *status, int64_t nstatus, const int *colmap,
-                              int log2blk, hipStream_t st)
+                              int log2blk, hipStream_t st, const WxThreshArg &thr)
 {
     switch (wx_fused_nt(n)) {
-    case 64: return launch_inv_fused_FN<T, F, 64>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
-    case 128: return launch_inv_fused_FN<T, F, 128>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
-    case 256: return launch_inv_fused_FN<T, F, 256>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
-    case 512: return launch_inv_fused_FN<T, F, 512>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
-    default: return launch_inv_fused_FN<T, F, 1024>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
+    case 64: return launch_inv_fused_FN<T, F, 64>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st, thr);
+    case 128: return launch_inv_fused_FN<T, F, 128>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st, thr);
+    case 256: return launch_inv_fused_FN<T, F, 256>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st, thr);
+    case 512: return launch_inv_fused_FN<T, F, 512>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st, thr);
+    default: return launch_inv_fused_FN<T, F, 1024>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st, thr);
     }
 }
 
 template <typename T>
 static int launch_inv_fused(const T *xw, T *xh, int64_t n, int L, int64_t batch, int64_t is, int64_t os,
                             const WxFilt &filt, const uint8_t *status, int64_t nstatus, const int *colmap,
-                            int log2blk, hipStream_t st)
+                            int log2blk, hipStream_t st, const WxThreshArg &thr = WxThreshArg{nullptr, 0, 0, 0, 1.0})
 {
     switch (filt.F) {
-#define WX_CASE(FF) case FF: return launch_inv_fused_F<T, FF>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st);
+#define WX_CASE(FF) case FF: return launch_inv_fused_F<T, FF>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st, thr);
         WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
     }
     return wx_set_error(WX_EUNSUPPORTED, "no fused instantiation for this filter length");
 }
+
+// iwpt along a tree with the threshold of denoise() applied while the coefficients are loaded; the caller has checked
+// wx_iwpt1d_thresh_fusable
+template <typename T> bool wx_iwpt1d_thresh_fusable(int64_t n, int F, const uint8_t *status)
+{
+    return status != nullptr && wx_fused1d_ok<T>(n, F);
+}
+template <typename T>
+int wx_dev_iwpt1d_thresh(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxFilt &filt, const uint8_t *status,
+                         int64_t nstatus, const WxThreshArg &thr, hipStream_t st)
+{
+    if (batch == 0 || n == 0) return WX_OK;
+    return launch_inv_fused<T>(xw, xh, n, L, batch, n, n, filt, status, nstatus, nullptr, 0, st, thr);
+}
+template bool wx_iwpt1d_thresh_fusable<double>(int64_t, int, const uint8_t *);
+template bool wx_iwpt1d_thresh_fusable<float>(int64_t, int, const uint8_t *);
+template int wx_dev_iwpt1d_thresh<double>(const double *, double *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t,
+                                          const WxThreshArg &, hipStream_t);
+template int wx_dev_iwpt1d_thresh<float>(const float *, float *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t,
+                                         const WxThreshArg &, hipStream_t);
 
 // wpd: y is (n, L+1, batch); all device pointers
 template <typename T>

@@ -77,6 +77,13 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
 
 // ---- fused acwpd + JBB moments (wx_jbb.hip) ----
 int wx_acwpd_fused_depth(int64_t n, int L, int F);
+template <typename T>
+int wx_dev_threshold_copy(const T *X, T *Y, int64_t n, int64_t batch, int th_kind, const T *t, int per_signal, int64_t row_lo,
+                          double scale, hipStream_t st);                                // wx_denoise.hip
+template <typename T> bool wx_iwpt1d_thresh_fusable(int64_t n, int F, const uint8_t *status);
+template <typename T>
+int wx_dev_iwpt1d_thresh(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxFilt &filt, const uint8_t *status,
+                         int64_t nstatus, const WxThreshArg &thr, hipStream_t st);
 bool wx_acwpd_mfma_ok(int64_t n, int L, int D0);                    // wx_acsubtree.hip: one wavefront per subtree, matrix pipe
 int wx_dev_acwpd_subtree_mfma(const double *top, double *sum, double *sumsq, int64_t n, int L, int D0, int64_t batch,
                               const WxAcFilt &ac, int accumulate, hipStream_t st);

@@ -127,14 +127,19 @@ def _detail_range(n, k, inputtype, tree):
     return 0, finestdetailrange(n, tree, True)[1] - 1
 
 
-def _noisest(xa, batched, inputtype, tree):
+def _noisest(xa, batched, inputtype, tree, on_device=False):
+    """sigma of every signal; on_device: an Arg of the input's kind (nothing is copied to the host, no synchronisation)"""
     n = xa.shape[0]
     assert isdyadic(n)                                                 # Denoising.jl:218
     N = xa.shape[-1] if batched else 1
     k = 1 if inputtype in ("dwt", "wpt") else xa.shape[1]
     lo, col = _detail_range(n, k, inputtype, tree)
-    sig = np.empty(N, dtype=xa.dtype)
     fn = getattr(_lib.lib(), "wx_noisest" + xa.suffix)
+    if on_device:
+        sig = xa.new((N,))
+        _lib.check(fn(xa.ptr, n, k, N, lo, col, sig.ptr, xa.stream()))
+        return sig
+    sig = np.empty(N, dtype=xa.dtype)
     _lib.check(fn(xa.ptr, n, k, N, lo, col, ctypes.c_void_p(sig.ctypes.data), xa.stream()))
     return sig
 
@@ -156,6 +161,25 @@ def _threshold(xa, out, batched, th, t, row_lo=0, colmask=None):
     fn = getattr(_lib.lib(), "wx_threshold" + xa.suffix)
     _lib.check(fn(xa.ptr, out.ptr, n, k, N, th.kind, ctypes.c_void_p(tv.ctypes.data), tv.size, int(row_lo),
                   ctypes.c_void_p(cm.ctypes.data) if cm is not None else ctypes.c_void_p(0), xa.stream()))
+
+
+def _iwpt_thresh(xa, wt, tree, batched, th, t, row_lo, scale=1.0):
+    """threshold(x, th, scale * t) on rows [row_lo, n) followed by iwpt(x, wt, tree), in one pass (wx_iwpt1d_thresh_*);
+    t: host values, or an Arg on the device (the noise estimates where wx_noisest_* left them)"""
+    from ._arrays import qmf_arg, tree_arg
+    n = xa.shape[0]
+    N = xa.shape[-1] if batched else 1
+    q, qp, F = qmf_arg(wt)
+    tk, tp, nt = tree_arg(np.asarray(tree, dtype=bool))
+    if isinstance(t, Arg):
+        tptr, tn = t.ptr, int(np.prod(t.shape))
+    else:
+        tv = np.ascontiguousarray(np.atleast_1d(np.asarray(t, dtype=xa.dtype)))
+        tptr, tn = ctypes.c_void_p(tv.ctypes.data), tv.size
+    out = xa.new(xa.shape)
+    fn = getattr(_lib.lib(), "wx_iwpt1d_thresh" + xa.suffix)
+    _lib.check(fn(xa.ptr, out.ptr, n, 0, tp, nt, N, qp, F, th.kind, tptr, tn, int(row_lo), float(scale), xa.stream()))
+    return out.arr
 
 
 def threshold(x, th, t):
@@ -183,9 +207,17 @@ def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
     if inputtype not in ("dwt", "wpt"):
         assert xa.arr.ndim > (2 if batched else 1)                     # @assert ndims(x) > 1
     N = xa.shape[-1] if batched else 1
-    xt = xa.new(xa.shape)              # thresholded copy (the reference leaves x alone): written by _threshold
     # noise estimation
     tr = None if inputtype in ("dwt", "sdwt", "acdwt") else tree
+    if (xa.kind == "torch" and bestTH is None and wt is not None and inputtype in ("dwt", "wpt") and
+            (estnoise is None or estnoise is noisest) and (inputtype == "wpt" or L >= 1)):
+        # device-resident pipeline: MAD -> threshold riding on the inverse's loads; sigma never visits the host
+        sig = _noisest(xa, batched, inputtype, tr, on_device=True)
+        if inputtype == "dwt":
+            return _iwpt_thresh(xa, wt, maketree(n, L, "dwt"), batched, dnt.th, sig,
+                                nodelength(n, L) if smooth == "undersmooth" else 0, dnt.t)
+        return _iwpt_thresh(xa, wt, tree, batched, dnt.th, sig,
+                            coarsestscalingrange(n, tree)[-1] if smooth == "undersmooth" else 0, dnt.t)
     if estnoise is None or callable(estnoise):
         red = inputtype in ("sdwt", "swpd", "acdwt", "acwpd")
         if estnoise is None or estnoise is noisest:
@@ -205,16 +237,23 @@ def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
     # thresholding + reconstruction
     if inputtype == "dwt":
         lo = nodelength(n, L) if smooth == "undersmooth" else 0
+        if wt is not None and xa.arr.ndim == (2 if batched else 1) and L >= 1:      # threshold rides on the inverse's loads
+            return _iwpt_thresh(xa, wt, maketree(n, L, "dwt"), batched, dnt.th, t, lo)
+        xt = xa.new(xa.shape)          # thresholded copy (the reference leaves x alone)
         _threshold(xa, xt, batched, dnt.th, t, lo)
         if wt is None:
             return xt.arr
         return idwtall(xt.arr, wt, L) if batched else idwt(xt.arr, wt, L)
     if inputtype == "wpt":
         lo = coarsestscalingrange(n, tree)[-1] if smooth == "undersmooth" else 0
+        if wt is not None and xa.arr.ndim == (2 if batched else 1):
+            return _iwpt_thresh(xa, wt, tree, batched, dnt.th, t, lo)
+        xt = xa.new(xa.shape)          # thresholded copy (the reference leaves x alone)
         _threshold(xa, xt, batched, dnt.th, t, lo)
         if wt is None:
             return xt.arr
         return iwptall(xt.arr, wt, tree) if batched else iwpt(xt.arr, wt, tree)
+    xt = xa.new(xa.shape)
     k = xt.shape[1]
     if inputtype in ("sdwt", "acdwt"):
         mask = np.ones(k, dtype=np.uint8)
