@@ -634,35 +634,41 @@ def main():
 
     gather = None
     if W.gatherable:
-        # second loop: the all-gather of the reconstructed output inside the step, overlapped with the inverse
-        for _ in range(max(1, min(a.warmup, 2))):
-            W.step_gather(Legs(torch))
-        sync()
-        g_elapsed, g_per_rank, _ = timed(W.step_gather)
-        # the exchange alone (nothing to overlap with), for the budget: one step's worth of posts
-        from waveletsext_jl_amd import distributed as wd
-        full = W.output(True)
-        sync()
-        t1 = time.perf_counter()
-        gg = wd.OverlappedAllGather(full, full.shape[-1], nchunks=a.chunks)
-        nposts = max(len(wd.chunk_ranges(n_r, a.chunks)) for n_r in wd.shard_sizes(full.shape[-1], world))
-        for c in range(nposts):
-            gg.post(c)
-        gg.finish()
-        sync()
-        alone_ms = (time.perf_counter() - t1) * 1e3
-        gather = {"ms_per_step": g_elapsed / a.steps * 1e3,
-                  "value": samples_all * a.steps / g_elapsed / 1e6,
-                  "allgather_alone_ms": alone_ms,
-                  "exposed_ms": (g_elapsed - elapsed) / a.steps * 1e3,
-                  "overlap_ms": max(0.0, alone_ms - (g_elapsed - elapsed) / a.steps * 1e3),
-                  "chunks": a.chunks, "bytes_received_per_rank": float(info.get("gather_bytes", 0)),
-                  "per_rank_ms": [v / a.steps * 1e3 for v in g_per_rank],
-                  "schedule": "inverse in %d chunks; chunk c's exchange (grouped point-to-point, every piece lands in "
-                              "place) on a side stream while chunk c+1 is transformed" % a.chunks}
-        gerr = float((full[..., W.lo:W.hi] - W.keep[0]).abs().max() / W.keep[0].abs().max()) if a.scaling == "strong" else None
-        if gerr is not None:
-            assert gerr < tol, "gathered output broken: %g" % gerr
+      try:
+          # second loop: the all-gather of the reconstructed output inside the step, overlapped with the inverse
+          for _ in range(max(1, min(a.warmup, 2))):
+              W.step_gather(Legs(torch))
+          sync()
+          g_elapsed, g_per_rank, _ = timed(W.step_gather)
+          # the exchange alone (nothing to overlap with), for the budget: one step's worth of posts
+          from waveletsext_jl_amd import distributed as wd
+          full = W.output(True)
+          sync()
+          t1 = time.perf_counter()
+          gg = wd.OverlappedAllGather(full, full.shape[-1], nchunks=a.chunks)
+          nposts = max(len(wd.chunk_ranges(n_r, a.chunks)) for n_r in wd.shard_sizes(full.shape[-1], world))
+          for c in range(nposts):
+              gg.post(c)
+          gg.finish()
+          sync()
+          alone_ms = (time.perf_counter() - t1) * 1e3
+          gather = {"ms_per_step": g_elapsed / a.steps * 1e3,
+                    "value": samples_all * a.steps / g_elapsed / 1e6,
+                    "allgather_alone_ms": alone_ms,
+                    "exposed_ms": (g_elapsed - elapsed) / a.steps * 1e3,
+                    "overlap_ms": max(0.0, alone_ms - (g_elapsed - elapsed) / a.steps * 1e3),
+                    "chunks": a.chunks, "bytes_received_per_rank": float(info.get("gather_bytes", 0)),
+                    "per_rank_ms": [v / a.steps * 1e3 for v in g_per_rank],
+                    "schedule": "inverse in %d chunks; chunk c's exchange (grouped point-to-point, every piece lands in "
+                                "place) on a side stream while chunk c+1 is transformed" % a.chunks}
+          gerr = float((full[..., W.lo:W.hi] - W.keep[0]).abs().max() / W.keep[0].abs().max()) if a.scaling == "strong" else None
+          if gerr is not None:
+              assert gerr < tol, "gathered output broken: %g" % gerr
+      except AssertionError:
+          raise
+      except Exception as e:  # pragma: no cover - the exchange is reported next to `value`, never part of it
+          gather = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if a.dump:
         import numpy as np
         outp = W.output(W.gatherable)
