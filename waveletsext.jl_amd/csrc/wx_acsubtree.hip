@@ -277,7 +277,10 @@ void k_acwpd_subtree_mfma(const double *__restrict__ top, double *__restrict__ s
 bool wx_acwpd_mfma_ok(int64_t n, int L, int D0)
 {
     static const bool off = getenv("WX_ACWPD_MFMA") && atoi(getenv("WX_ACWPD_MFMA")) == 0;
-    return !off && D0 >= 0 && D0 <= 12 && (n >> D0) == 32 && L - D0 == 5;
+    if (off || D0 < 0 || D0 > 12 || (n >> D0) != 32 || L - D0 != 5) return false;
+    // a block's eight signals are addressed with 32-bit byte offsets from a uniform base
+    const int64_t sig_stride = n * ((((int64_t)1) << (D0 + 1)) - 1);
+    return 8 * 8 * sig_stride < ((int64_t)1 << 32);
 }
 
 int wx_dev_acwpd_subtree_mfma(const double *top, double *sum, double *sumsq, int64_t n, int L, int D0, int64_t batch,

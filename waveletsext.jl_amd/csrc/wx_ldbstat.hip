@@ -216,6 +216,7 @@ template <typename T>
 int api_class_rows(int kind, const T *X, int64_t nk, int64_t N, const int32_t *cls, int nc, T *out1, T *out2, void *stream)
 {
     WX_REQUIRE(nk >= 1 && N >= 1, WX_EARG, "bad dimensions");
+    WX_REQUIRE(nk < ((int64_t)1 << 31), WX_EUNSUPPORTED, "more than 2^31 coefficients per signal");
     WX_REQUIRE(cls != nullptr, WX_EARG, "NULL labels");
     WX_REQUIRE(nc > 1, WX_EASSERT, "@assert nc > 1");
     WX_REQUIRE(nc <= LS_MAXC, WX_EUNSUPPORTED, "more than 64 classes");
@@ -563,6 +564,7 @@ template <typename T>
 int api_pdf_map(const T *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *Gamma, void *stream)
 {
     WX_REQUIRE(nk >= 1 && N >= 2, WX_EARG, "bad dimensions");
+    WX_REQUIRE(nk < ((int64_t)1 << 31), WX_EUNSUPPORTED, "more than 2^31 coefficients per signal");
     LsClasses C;
     std::vector<int> order;
     int rc = ls_classes(cls, N, nc, &C, &order);
@@ -592,6 +594,7 @@ template <typename T>
 int api_signature(int kind, const T *X, const T *Win, int64_t nk, int64_t N, int64_t Ntot, const int32_t *cls, int nc, T *out, void *stream)
 {
     WX_REQUIRE(nk >= 1 && N >= 2, WX_EARG, "bad dimensions");
+    WX_REQUIRE(nk < ((int64_t)1 << 31), WX_EUNSUPPORTED, "more than 2^31 coefficients per signal");
     LsClasses C;
     std::vector<int> order;
     int rc = ls_classes(cls, N, nc, &C, &order);
