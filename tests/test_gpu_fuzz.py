@@ -296,3 +296,51 @@ def test_fuzz_long_signals_tiles_and_siwt(wx, oracle):
         assert wx.isvalidtree(obj), tag
         assert abs(obj.MinCost - ref.MinCost) <= (1e-9 if dt == np.float64 else 2e-4) * max(1.0, abs(ref.MinCost)), tag
         assert relerr(wx.isiwpdall(batch), X) <= 50 * TOL[dt], tag
+
+
+def test_fuzz_register_kernels(wx, oracle):
+    """the round-2 kernels that only exist for one geometry: lattice wpt / iwpt / wpd (n = 4096 Float64), the 2-D lattice
+    (512 x 512 Float32, L = 6), the matrix-pipe subtree moments (n / 2^D0 = 32, full depth) -- random depth, filter, batch
+    (ragged tails of the 8-signal blocks, batches larger than one wavefront round), host and device pointers"""
+    rng = np.random.default_rng(4242)
+    lat = ["db2", "db3", "db4", "db5", "db6", "db8", "coif6", "db10"]
+    for _ in range(10 * SCALE):
+        wt = wx.wavelet(getattr(wx.WT, str(rng.choice(lat))))
+        B = int(rng.choice([1, 2, 3, 5, 9]))
+        dev = bool(rng.random() < 0.5)
+        x = np.asfortranarray(rng.standard_normal((4096, B)))
+        L = int(rng.integers(1, 13))
+        tab = _stack(oracle.wpd, x, wt.qmf, L)
+        assert relerr(wx.to_numpy(wx.wpdall(_put(wx, x, dev), wt, L)), tab) <= 1e-11, (wt.name if hasattr(wt, "name") else "", L, B)
+        assert relerr(wx.to_numpy(wx.iwpdall(_put(wx, tab, dev), wt, L)), x) <= 1e-11
+        Lt = int(rng.integers(6, 13))
+        exp = _stack(oracle.wpt, x, wt.qmf, Lt)
+        assert relerr(wx.to_numpy(wx.wptall(_put(wx, x, dev), wt, Lt)), exp) <= 1e-11
+        assert relerr(wx.to_numpy(wx.iwptall(_put(wx, exp, dev), wt, Lt)), x) <= 1e-11
+    # subtree moments: other lengths (D0 = log2(n) - 5), filters of every length class, batches that are not multiples of 8
+    for _ in range(6 * SCALE):
+        n = int(rng.choice([64, 128, 256, 1024]))
+        L = int(np.log2(n))
+        wt = wx.wavelet(getattr(wx.WT, str(rng.choice(["haar", "db2", "db4", "db8", "coif2", "coif6"]))))
+        B = int(rng.choice([1, 3, 8, 13, 21]))
+        x = np.asfortranarray(rng.standard_normal((n, B)))
+        X = np.asfortranarray(np.stack([oracle.acwpd(x[:, b], wt.qmf, L) for b in range(B)], axis=-1))
+        s, q = wx.acwpd_jbb_moments(x, wt, L)
+        assert relerr(s, X.sum(axis=2)) <= 1e-12 and relerr(q, (X ** 2).sum(axis=2)) <= 1e-12, (n, B)
+        # accumulate_into over two ragged pieces == one call
+        if B > 1:
+            k = int(rng.integers(1, B))
+            xd = wx.to_device(x)
+            sa, qa = wx.acwpd_jbb_moments(xd[:, :k], wt, L)
+            wx.acwpd_jbb_moments(xd[:, k:], wt, L, accumulate_into=(sa, qa))
+            assert relerr(sa.cpu().numpy(), s) <= 1e-13 and relerr(qa.cpu().numpy(), q) <= 1e-13
+    # 2-D lattice: random batch sizes, both filters
+    import torch
+    for _ in range(3 * SCALE):
+        wt = wx.wavelet(getattr(wx.WT, str(rng.choice(["db2", "db4"]))))
+        B = int(rng.choice([1, 2, 5]))
+        x = np.asfortranarray(rng.standard_normal((512, 512, B)).astype(np.float32))
+        got = wx.wptall(x, wt, 6)
+        exp = _stack(oracle.wpt, x.astype(np.float64), wt.qmf, 6)
+        assert relerr(got.astype(np.float64), exp) <= 2e-6
+        assert relerr(wx.iwptall(exp.astype(np.float32), wt, 6).astype(np.float64), x.astype(np.float64)) <= 2e-6
