@@ -303,7 +303,7 @@ def test_fuzz_register_kernels(wx, oracle):
     (512 x 512 Float32, L = 6), the matrix-pipe subtree moments (n / 2^D0 = 32, full depth) -- random depth, filter, batch
     (ragged tails of the 8-signal blocks, batches larger than one wavefront round), host and device pointers"""
     rng = np.random.default_rng(4242)
-    lat = ["db2", "db3", "db4", "db5", "db6", "db8", "coif6", "db10"]
+    lat = ["db2", "db3", "db4", "db5", "db6", "db7", "db8", "db9", "coif6", "db10"]
     for _ in range(10 * SCALE):
         wt = wx.wavelet(getattr(wx.WT, str(rng.choice(lat))))
         B = int(rng.choice([1, 2, 3, 5, 9]))
@@ -321,7 +321,7 @@ def test_fuzz_register_kernels(wx, oracle):
     for _ in range(6 * SCALE):
         n = int(rng.choice([64, 128, 256, 1024]))
         L = int(np.log2(n))
-        wt = wx.wavelet(getattr(wx.WT, str(rng.choice(["haar", "db2", "db4", "db8", "coif2", "coif6"]))))
+        wt = wx.wavelet(getattr(wx.WT, str(rng.choice(["haar", "db2", "db4", "db7", "db8", "coif2", "coif6"]))))
         B = int(rng.choice([1, 3, 8, 13, 21]))
         x = np.asfortranarray(rng.standard_normal((n, B)))
         X = np.asfortranarray(np.stack([oracle.acwpd(x[:, b], wt.qmf, L) for b in range(B)], axis=-1))

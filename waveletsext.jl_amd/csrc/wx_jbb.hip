@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_acwpd_subtree_moments(const double *__r
 int wx_acwpd_fused_depth(int64_t n, int L, int F)
 {
     const int NL = F / 2;
-    if (!(NL >= 1 && NL <= 10 && NL != 7)) return -1;
+    if (NL < 1) return -1;
     if (n < 2 || (n & (n - 1))) return -1;
     int log2n = 0;
     while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
@@ -360,7 +360,12 @@ int wx_acwpd_fused_depth(int64_t n, int L, int F)
         const int LP = L - D0;
         if (LP > 6 || D0 > log2n) continue;
         const int64_t cnt = (n >> D0) << (LP - 1);
-        if (cnt <= 512 && (n >> D0) >= 1 && (n >> D0) * 4 <= 256) return D0;   // 4 signals x n' fetched by 256 threads
+        if (cnt <= 512 && (n >> D0) >= 1 && (n >> D0) * 4 <= 256) {   // 4 signals x n' fetched by 256 threads
+            // the LDS kernel of this file is instantiated for F/2 in {1..6, 8, 9, 10}; the matrix-pipe kernel
+            // (wx_acsubtree.hip) periodises any filter
+            if (NL <= 10 && NL != 7) return D0;
+            return wx_acwpd_mfma_ok(n, L, D0) ? D0 : -1;
+        }
     }
     return -1;
 }

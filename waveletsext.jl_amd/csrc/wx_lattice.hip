@@ -1014,7 +1014,7 @@ static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n
             hipLaunchKernelGGL((k_lat_wpt_f64<NSS, 3>), dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, cf);  \
         break;
     switch (filt.F / 2) {
-        WX_GO(2) WX_GO(3) WX_GO(4) WX_GO(5) WX_GO(6) WX_GO(8) WX_GO(9) WX_GO(10)
+        WX_GO(2) WX_GO(3) WX_GO(4) WX_GO(5) WX_GO(6) WX_GO(7) WX_GO(8) WX_GO(9) WX_GO(10)
     default: return 0;
     }
 #undef WX_GO
@@ -1049,7 +1049,7 @@ int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t bat
         hipLaunchKernelGGL((k_lat_wpd_f64<NSS, 2>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L, batch, cw);     \
         break;
     switch (filt.F / 2) {
-        WX_GOW(2) WX_GOW(3) WX_GOW(4) WX_GOW(5) WX_GOW(6) WX_GOW(8) WX_GOW(9) WX_GOW(10)
+        WX_GOW(2) WX_GOW(3) WX_GOW(4) WX_GOW(5) WX_GOW(6) WX_GOW(7) WX_GOW(8) WX_GOW(9) WX_GOW(10)
     default: return 0;
     }
 #undef WX_GOW
