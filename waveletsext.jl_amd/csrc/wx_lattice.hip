@@ -503,7 +503,17 @@ constexpr int lat_pbit(int lay, int reg, int bit)           // sample-index bit 
         if (lat_src(lay, t).reg == reg && lat_src(lay, t).bit == bit) return t;
     return -1;
 }
-constexpr int lat_obit(int l, int t) { return t < l ? 11 - t : t - l; }
+// level code lc = l + 16 sh: sh low index bits are a signal number (2^sh signals of 4096 >> sh samples interleaved in the
+// registers, see k_lat_wpt_f64<.., SH>), the l levels acted on bits sh .. sh + l - 1: the signal number goes to the top of the
+// address, the path bits are reversed below it, the rest is the position inside the node
+constexpr int lat_lv(int lc) { return lc & 15; }
+constexpr int lat_sh(int lc) { return lc >> 4; }
+constexpr bool lat_on_path(int lc, int t) { return t >= lat_sh(lc) && t < lat_sh(lc) + lat_lv(lc); }   // t = -1: old code counted it; never occurs for k, i < 6
+constexpr int lat_obit(int lc, int t)
+{
+    if (t < 0) return 12;                                    // "no such bit" (lat_pbit / lat_round_bit = -1): above the address
+    return t < lat_sh(lc) ? 12 - lat_sh(lc) + t : (t < lat_sh(lc) + lat_lv(lc) ? 11 - t : t - lat_sh(lc) - lat_lv(lc));
+}
 constexpr int lat_reg_o(int lay, int l, int i) { return lat_obit(l, lat_pbit(lay, 1, i)); }
 constexpr int lat_lane_o(int lay, int l, int k) { return lat_obit(l, lat_pbit(lay, 0, k)); }
 // the j-th (j = 0, 1) register bit fixed per round: the lowest register bits that land on a line-address bit
@@ -555,7 +565,7 @@ constexpr int lat_emit_pc_reg(int lay, int l, int r)        // detail branches o
 {
     int c = 0;
     for (int i = 0; i < 6; ++i)
-        if (lat_pbit(lay, 1, i) < l) c += (r >> i) & 1;
+        if (lat_on_path(l, lat_pbit(lay, 1, i))) c += (r >> i) & 1;
     return c;
 }
 constexpr int lat_emit_o_round(int lay, int l, int rho)
@@ -581,12 +591,12 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
 {
     // lane parts: line-address bits, in-line position bits, detail branches of the path
     int hi_lane = 0, pos_lane = 0;
-    double b = cw.gl[LVL];
+    double b = cw.gl[lat_lv(LVL)];
     lat_for<6>([&](auto Kc) {
         constexpr int k = Kc;
         constexpr int ob = lat_lane_o(LAY, LVL, k);
         if constexpr (ob < 4) pos_lane |= ((lane >> k) & 1) << ob;
-        if constexpr (lat_pbit(LAY, 0, k) < LVL) b = ((lane >> k) & 1) ? b * cw.c.g2 : b;
+        if constexpr (lat_on_path(LVL, lat_pbit(LAY, 0, k))) b = ((lane >> k) & 1) ? b * cw.c.g2 : b;
     });
     lat_for<6>([&](auto Qc) {
         constexpr int q = Qc;
@@ -603,7 +613,8 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
     int o_lane = 2 * (lane & 7);
     lat_for<3>([&](auto Qc) {
         constexpr int q = Qc;
-        o_lane |= ((qq >> q) & 1) << lat_line(LAY, LVL, q).ob;
+        constexpr int ob = lat_line(LAY, LVL, q).ob;           // forced constant evaluation: left to the optimiser the
+        o_lane |= ((qq >> q) & 1) << ob;                          // bit-map loops are not always folded
     });
     const unsigned ra = lds0 + 8u * (unsigned)(17 * qq + 2 * (lane & 7));
     const unsigned yo = (unsigned)o_lane;
@@ -611,7 +622,8 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
         constexpr int rho = Rc;
         lat_for<16>([&](auto Vc) {
             constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
-            lds_wr<8 * lat_emit_slot_reg(LAY, LVL, r)>(wa, x[r] * gf[lat_emit_pc_reg(LAY, LVL, r)]);
+            constexpr int pc = lat_emit_pc_reg(LAY, LVL, r);
+            lds_wr<8 * lat_emit_slot_reg(LAY, LVL, r)>(wa, x[r] * gf[pc]);
         });
         lat_for<2>([&](auto HH) {
             constexpr int hh = HH;
@@ -627,7 +639,8 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
                 lat_d2 o;
                 o.x = v[2 * I];
                 o.y = v[2 * I + 1];
-                lat_st2w(lat_sbase(ycol + lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i)) + yo, o);
+                constexpr int oc = lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i);
+                lat_st2w(lat_sbase(ycol + oc) + yo, o);
             });
         });
     });
@@ -768,6 +781,87 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (L < 12) return;
     lat_level<5, 0, NS, false>(c, cf);
     lat_emit<6, 12>(c, lds0, ys + 4096 * 12, lane, cw);
+}
+
+// ---------------------------------------------------------------- shorter signals: 2^SH of them interleaved in one wavefront
+// 4096 >> SH samples per signal (2048, 1024): sample i of signal s sits at register-file index p = (i << SH) | s, i.e. the
+// low SH index bits are a signal number that no level touches and level l acts on bit SH + l - 1 -- the same rotations,
+// exchanges and halos as the 4096-sample kernel from its level SH + 1 on (the halo wraps at p + 4096 = i + 4096 >> SH of the
+// same signal).  The 2^SH signals are adjacent in memory, so the wavefront still owns one contiguous 32 KiB block: it is read
+// with 8-byte loads (a lane's two registers belong to different signals) and written through the static bit routing of
+// lat_emit with the bit map of lat_obit(l + 16 SH, .): signal number on top, path bits reversed below it.
+__device__ __forceinline__ double lat_ld1(const double __attribute__((address_space(1))) *p) { return *p; }
+template <int SH> constexpr int lat_rotr(int p) { return (p >> SH) | ((p & ((1 << SH) - 1)) << (12 - SH)); }
+
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_sh_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw)
+{
+    static_assert(SH == 1 || SH == 2, "two or four signals per wavefront");
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    // the last wavefront of a batch that is not a multiple of 2^SH re-does the last 2^SH signals (out of place only)
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const int64_t off = (int64_t)sig0 * (4096 >> SH);
+    const double *xs = x + off;
+    double *ys = y + off;
+    const WxLat &cf = cw.c;
+    double a[64];
+    {
+        lat_d2 r[32];
+        const int lp = 64 * (lane >> 3) + 2 * (lane & 7);
+        const unsigned xo = (unsigned)((lp >> SH) | ((lp & ((1 << SH) - 1)) << (12 - SH)));
+        lat_for<32>([&](auto Q) {
+            constexpr int hi3 = Q / 4, f = Q % 4;
+            r[Q].x = lat_ld1(lat_sbase(xs + lat_rotr<SH>(512 * hi3 + 16 * f)) + xo);
+            r[Q].y = lat_ld1(lat_sbase(xs + lat_rotr<SH>(512 * hi3 + 16 * f + 1)) + xo);
+        });
+        const unsigned wa = lds0 + 8u * (17u * (lane >> 3) + 2u * (lane & 7)), ra = lds0 + 8u * 17u * lane;
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<8>([&](auto Hq) {
+                constexpr int hi3 = Hq;
+                lds_wr<8 * (136 * hi3)>(wa, r[4 * hi3 + f].x);
+                lds_wr<8 * (136 * hi3 + 1)>(wa, r[4 * hi3 + f].y);
+            });
+            double t[16];
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                t[m] = lds_rd<8 * m>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                a[16 * f + m] = t[m];
+            });
+        });
+    }
+    if constexpr (SH < 2) lat_level<1, 6, NS, false>(a, cf);
+    double bb[64];
+    lat_t2(a, bb, lds0, lane);
+    lat_level<0, 4, NS, false>(bb, cf);
+    lat_level<1, 4, NS, false>(bb, cf);
+    lat_level<2, 4, NS, false>(bb, cf);
+    lat_level<3, 4, NS, false>(bb, cf);
+    double c[64];
+    lat_t3(bb, c, lds0, lane);
+    const int Le = L + SH;                                  // highest index bit + 1 that a level acts on: 6 .. 12
+    if (Le > 6) lat_level<0, 0, NS, false>(c, cf);
+    if (Le > 7) lat_level<1, 0, NS, false>(c, cf);
+    if (Le > 8) lat_level<2, 0, NS, false>(c, cf);
+    if (Le > 9) lat_level<3, 0, NS, false>(c, cf);
+    if (Le > 10) lat_level<4, 0, NS, false>(c, cf);
+    if (Le > 11) lat_level<5, 0, NS, false>(c, cf);
+    switch (Le) {
+    case 6: lat_emit<6, 6 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 7: lat_emit<6, 7 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 8: lat_emit<6, 8 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 9: lat_emit<6, 9 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 10: lat_emit<6, 10 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 11: lat_emit<6, 11 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    default: lat_emit<6, 12 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    }
 }
 
 // ---------------------------------------------------------------- inverse
@@ -986,10 +1080,44 @@ bool wx_lattice_coeffs(const WxFilt &filt, int L, bool inverse, double *p, doubl
 }
 
 // 0 = not applicable (the caller takes the general kernels), 1 = launched, < 0 = HIP error code of the C ABI
+// 2^SH signals of 4096 >> SH samples per wavefront (forward wpt)
+static int wx_lattice_launch_sh(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
+{
+    const int SH = n == 2048 ? 1 : 2;
+    const int64_t per = (int64_t)1 << SH;
+    if (L + SH < 6 || L + SH > 12 || filt.F < 4 || batch < per) return 0;
+    if ((batch & (per - 1)) && x == y) return 0;             // the tail wavefront re-does signals: out of place only
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
+    WxLatW cw;
+    if (!wx_lattice_factor(filt, L, false, &cw.c)) return 0;
+    for (int l = 0; l <= 12; ++l) cw.gl[l] = 0.0;
+    cw.gl[L] = cw.c.g0;                                       // only the leaves are written
+    const int64_t nwave = (batch + per - 1) / per;
+    if (batch > 0x7fffffff) return 0;
+    const int last_sig = (int)(batch - per);
+#define WX_GOS(NSS)                                                                                                  \
+    case NSS:                                                                                                        \
+        if (SH == 1)                                                                                                 \
+            hipLaunchKernelGGL((k_lat_wpt_sh_f64<NSS, 2, 1>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_lat_wpt_sh_f64<NSS, 2, 2>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
+        break;
+    switch (filt.F / 2) {
+        WX_GOS(2) WX_GOS(3) WX_GOS(4) WX_GOS(5) WX_GOS(6) WX_GOS(7) WX_GOS(8) WX_GOS(9) WX_GOS(10)
+    default: return 0;
+    }
+#undef WX_GOS
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wx_set_hip_error(e, "lattice wpt launch (interleaved signals)", __FILE__, __LINE__);
+    return 1;
+}
+
 static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                              const WxFilt &filt, hipStream_t st)
 {
     static const bool off = getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0;
+    static const bool off_sh = getenv("WX_LATTICE_SH") && atoi(getenv("WX_LATTICE_SH")) == 0;
+    if (!off && !off_sh && !inverse && (n == 2048 || n == 1024)) return wx_lattice_launch_sh(x, y, n, L, batch, filt, st);
     if (off || n != 4096 || L < 6 || L > 12 || filt.F < 4 || batch <= 0) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     if (inverse && (in_stride & 3)) return 0;
