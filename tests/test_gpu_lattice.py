@@ -144,3 +144,44 @@ def test_lattice_wpd_every_depth_matches_oracle(wx, oracle, wname):
         assert relerr(wx.wpdall(x, wt, 12), exp) <= 1e-10
     finally:
         wx.set_force_generic(0)
+
+
+@pytest.mark.parametrize("n", [2048, 1024])
+@pytest.mark.parametrize("wname", ["db2", "db4", "db7", "coif6"])
+def test_interleaved_short_signals_match_oracle(wx, oracle, n, wname):
+    """2048- and 1024-sample signals: 2 / 4 signals interleaved in one wavefront (k_lat_wpt_sh_f64 / k_lat_iwpt_sh_f64), every
+    depth the kernels take (L + log2(4096 / n) >= 6) and the depths below it (other kernels), batches that are and are not
+    multiples of the signals per wavefront (the last wavefront re-does signals), host and device pointers"""
+    rng = np.random.default_rng(n)
+    wt = _wt(wx, wname)
+    for B in (1, 2, 3, 4, 5, 9):
+        x = np.asfortranarray(rng.standard_normal((n, B)))
+        for L in range(2, int(np.log2(n)) + 1):
+            exp = oracle.wptall(x, wt.qmf, L)
+            assert relerr(wx.wptall(x, wt, L), exp) <= 1e-12, (n, wname, B, L)
+            assert relerr(wx.iwptall(exp, wt, L), x) <= 1e-12, (n, wname, B, L)
+    xd = wx.to_device(np.asfortranarray(rng.standard_normal((n, 7))))
+    L = int(np.log2(n)) - 1
+    yd = wx.wptall(xd, wt, L)
+    assert relerr(yd.cpu().numpy(), oracle.wptall(xd.cpu().numpy(), wt.qmf, L)) <= 1e-12
+    assert relerr(wx.iwptall(yd, wt, L).cpu().numpy(), xd.cpu().numpy()) <= 1e-12
+
+
+def test_interleaved_short_signals_large_batch_properties(wx):
+    """131072 x 2048 and 262144 x 1024 (the target's byte count): reconstruction, energy, agreement with the LDS kernels"""
+    import torch
+    wt = _wt(wx, "db4")
+    for n, B, L in ((2048, 131072, 10), (1024, 262144, 9)):
+        x = wx.jl_empty((n, B), torch.float64, "cuda")
+        x.normal_(generator=torch.Generator(device="cuda").manual_seed(n))
+        y = wx.wptall(x, wt, L)
+        e0, e1 = (x * x).sum(dim=0), (y * y).sum(dim=0)
+        assert float(((e1 - e0).abs() / e0).max()) <= 1e-12
+        assert float((wx.iwptall(y, wt, L) - x).abs().max()) <= 1e-12
+        wx.set_force_generic(2)                                       # the fused LDS kernels
+        try:
+            y2 = wx.wptall(x[:, :4096], wt, L)
+        finally:
+            wx.set_force_generic(0)
+        assert float((y2 - y[:, :4096]).abs().max()) <= 1e-12
+        del x, y, y2

@@ -13,5 +13,9 @@ for n in (2048, 1024):
                 got = wx.wptall(x, wt, L)
                 e = np.abs(got - exp).max() / np.abs(exp).max()
                 if e > 1e-12:
-                    print("FAIL", n, wname, B, L, e)
+                    print("FAIL fwd", n, wname, B, L, e)
+                back = wx.iwptall(exp, wt, L)
+                e2 = np.abs(back - x).max() / np.abs(x).max()
+                if e2 > 1e-12:
+                    print("FAIL inv", n, wname, B, L, e2)
 print("done")

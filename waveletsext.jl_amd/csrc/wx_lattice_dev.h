@@ -1,0 +1,1141 @@
+#pragma once
+// wx_lattice.hip -- full-tree 1-D wavelet packets (wpt / iwpt by level, Float64, n = 4096, L >= 6) as a lattice of
+// plane rotations held in the registers of ONE wavefront per signal.
+//
+// Reference semantics: dwt/dwt_one_level.jl:79-107 (analysis step) and :192-223 (synthesis step), driven level by
+// level by Wavelets.jl's wpt / iwpt (call sites dwt/dwt_all.jl:152-166, 210-225).
+//
+// Why: the direct form costs 2F multiply-adds per output pair; at F = 8, L = 10 that is 4.3e10 Float64 flops per
+// 65536 x 4096 batch = the whole FP64 budget of the 60 %-of-HBM target (0.89 ms).  The 2x2 polyphase matrix of an
+// orthonormal QMF is paraunitary:
+//     [a]   [ Qe(w)      Qo(w)   ] [v_even]      Qe(w) = sum q[2m] w^m, Qo(w) = sum q[2m+1] w^m, w = advance one pair
+//     [d] = [-Qo(1/w)    Qe(1/w) ] [v_odd ]
+// and factors into F/2 rotations c_j [[1, t_j], [-t_j, 1]] separated by "advance the odd channel by one pair"
+// (Vaidyanathan's lattice; factorisation on the host in long double, wx_lattice_factor): F multiply-adds per pair,
+// half the direct form, and the common gain (prod c_j)^L is applied once at the end.
+//
+// Layout: level l acts on index bit b = l - 1 of the natural sample index p with dilation 2^b and period n (the
+// a-children stay on the slots with bit b = 0, the d-children on bit b = 1), so the depth-L transform is L in-place
+// stencils followed by a bit reversal of the low L index bits (Wavelets.jl's packet order).  A wavefront holds the
+// 4096 samples as 64 registers per lane and changes which six index bits are register-resident four times:
+//     L0 (eight full 128-byte lines per load)       ->  A: reg p[5:0]   levels 1-2,  halo = wave rotate (DPP)
+//                                                   ->  B: reg p[7:2]   levels 3-6,  halo = row rotate (DPP)
+//                                                   ->  C: reg p[11:6]  levels 7-12, whole sequences in registers
+//                                                   ->  S: full 128-byte lines per 8 lanes for the stores
+// Each exchange moves 16 registers per round through an 8.6 KiB LDS window with conflict-free ds_write_b64 /
+// ds_read_b64 (maps derived and checked in tools/lattice_lds_maps.py).  No workgroup barrier anywhere: one wavefront
+// = one workgroup, ordering is wave-level.  Per signal and lane: F/2 * 64 * L FMAs (2560 for db4, L = 10), ~110
+// DPP moves for the halos, 256 LDS writes + 256 LDS reads, one 32 KiB read and one 32 KiB write of HBM.
+//
+// Rounding: the rotations reassociate the reference's tap sums; measured difference from the oracle <= 3e-15
+// relative for every filter of the table at L = 12 (tools/lattice_proto.py), far inside the 1e-10 bar.
+#include "wx_common.h"
+#include "wx_kernels.h"
+#include <cmath>
+#include <cstdlib>
+#include <utility>
+
+#define WX_LAT_MAXS 10        // rotations per level = F / 2 (F <= 20)
+#define WX_LAT_LDS 1104       // elements of the LDS window (max over the eight exchanges: 1102)
+
+// Rotation j (c_j [[1, t_j], [-t_j, 1]]) is applied as two in-place shears on (u, w = sigma_j v):
+//     u += p_j w,  w -= kap_j u      p_j = t_j / sigma_j,  kap_j = sigma_j t_j c_j^2,  sigma_{j+1} = sigma_j c_j^2
+// (no temporary: the 128 data registers of a lane leave room for 3 wavefronts per SIMD).  After a level the a-slot
+// holds a / g and the d-slot d * g (g = prod c_j), so a leaf whose path took k detail branches carries g^(2k - L):
+// one multiply per element at the end (analysis) or at the start (synthesis).
+struct WxLat {
+    double p[WX_LAT_MAXS];
+    double kap[WX_LAT_MAXS];
+    double g0;                // analysis: g^L, synthesis: g^-L      (leaf with k = 0)
+    double g2;                // analysis: g^-2, synthesis: g^2      (per detail branch on the path)
+};
+
+namespace {
+
+__device__ __forceinline__ void lat_sync()
+{
+    // wave-level ordering of LDS traffic: the hardware executes a wavefront's DS operations in order; this only
+    // stops the compiler from moving a lane's loads above another lane's stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// keeps a wave-uniform pointer in scalar registers and opaque to address reassociation, so that the accesses below use
+// the "scalar base + 32-bit lane offset + immediate" form (one address VGPR instead of a 64-bit pair per access)
+typedef double lat_d2 __attribute__((ext_vector_type(2)));
+typedef double lat_d4 __attribute__((ext_vector_type(4)));
+typedef const double __attribute__((address_space(1))) *lat_gc;
+typedef double __attribute__((address_space(1))) *lat_gm;
+// global accesses of the kernels: 16 bytes per lane, streamed once (WX_LAT_NT: non-temporal hint)
+#ifndef WX_LAT_NT
+#define WX_LAT_NT 3     // measured (db4, L = 10, 65536 signals): forward 0.82 -> 0.79 ms, inverse 0.88 -> 0.80 ms
+#endif
+__device__ __forceinline__ lat_d2 lat_ld2(const double __attribute__((address_space(1))) *p)
+{
+    typedef const lat_d2 __attribute__((address_space(1))) *P;
+#if WX_LAT_NT & 1
+    return __builtin_nontemporal_load((P)p);
+#else
+    return *(P)p;
+#endif
+}
+__device__ __forceinline__ void lat_st2(double __attribute__((address_space(1))) *p, lat_d2 v)
+{
+    typedef lat_d2 __attribute__((address_space(1))) *P;
+#if WX_LAT_NT & 2
+    __builtin_nontemporal_store(v, (P)p);
+#else
+    *(P)p = v;
+#endif
+}
+// stores of the wpd kernel (28 of the 30 GiB it moves): WX_LAT_WPD_NT selects the hint separately
+#ifndef WX_LAT_WPD_NT
+#define WX_LAT_WPD_NT 0     // measured on config 2 (same box): plain stores 5.95 ms, non-temporal 6.20 ms
+#endif
+__device__ __forceinline__ void lat_st2w(double __attribute__((address_space(1))) *p, lat_d2 v)
+{
+    typedef lat_d2 __attribute__((address_space(1))) *P;
+#if WX_LAT_WPD_NT
+    __builtin_nontemporal_store(v, (P)p);
+#else
+    *(P)p = v;
+#endif
+}
+__device__ __forceinline__ lat_gc lat_sbase(const double *p)
+{
+    lat_gc g = (lat_gc)p;
+    asm("" : "+s"(g));
+    return g;
+}
+__device__ __forceinline__ lat_gm lat_sbase(double *p)
+{
+    lat_gm g = (lat_gm)p;
+    asm("" : "+s"(g));
+    return g;
+}
+
+// LDS traffic as explicit single ds_write_b64 / ds_read_b64 (byte address VGPR + 16-bit immediate).  The compiler would
+// pair them into ds_write2_b64 / ds_read2_b64: half the read rate (MI355X_MICROARCH.md, LDS table) and, worse, pairs of
+// destination registers that must be adjacent -- with the depth-dependent register order of the C layout that costs
+// hundreds of copies and spills.  volatile asm statements keep their program order, the hardware executes a
+// wavefront's DS operations in order, and lat_wait() is the only wait the reads need.
+template <int OFF> __device__ __forceinline__ void lds_wr(unsigned addr, double v)
+{
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ double lds_rd(unsigned addr)
+{
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// all outstanding DS reads have landed; the operands tie the values to the wait so that no use is scheduled above it
+__device__ __forceinline__ void lat_wait8(double &a, double &b, double &c, double &d, double &e, double &f, double &g, double &h)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "memory");
+}
+
+template <int CTRL> __device__ __forceinline__ double lat_dpp(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    // rotations: every lane has a source, so with bound_ctrl the old value is dead and no initialising move is emitted
+    const int plo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    const int phi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(phi, plo);
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <int... I, typename F> __device__ __forceinline__ void lat_for_impl(std::integer_sequence<int, I...>, F &&f)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void lat_for(F &&f)
+{
+    lat_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+// value held by the lane that owns the chunk D places further along the same dilated sequence (D < 0: back);
+// H = number of cyclic lane bits (they are the low bits of the lane id): 6 wave (|D| <= 1), 4 row of 16, 0 = the whole
+// sequence is in this lane
+template <int H, int D> __device__ __forceinline__ double lat_nbr(double v)
+{
+    if constexpr (H == 0 || D == 0) return v;
+    else if constexpr (H == 6) {
+        static_assert(D == 1 || D == -1, "wave rotations move one lane");
+        return lat_dpp<(D > 0 ? 0x134 : 0x13C)>(v);                           // wave_rol:1 / wave_ror:1
+    } else {
+        static_assert(H == 4 && D > -16 && D < 16, "row rotations");
+        return lat_dpp<0x120 + ((16 - D) & 15)>(v);                           // row_ror:n: lane i takes lane i - n (mod 16)
+    }
+}
+
+// one packet level on register-index bit K (2^K interleaved sequences of 32 >> K pairs per lane)
+template <int K, int H, int NS, bool INV> __device__ __forceinline__ void lat_level(double (&x)[64], const WxLat &cf)
+{
+    constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
+    auto U = [](int s, int m) { return s + ((2 * m) << K); };
+    // odd channel: pair m takes the value of pair m + SH of the periodic sequence (SH < 0: delay); the pairs that come
+    // from another lane's chunk are one DPP move each, all independent
+    auto shift = [&](auto SHc) {
+        constexpr int SH = decltype(SHc)::value;
+        if constexpr (SH != 0) {
+#pragma unroll
+            for (int s = 0; s < NSEQ; ++s) {
+                double old[M];
+#pragma unroll
+                for (int m = 0; m < M; ++m) old[m] = x[U(s, m) + S];
+                lat_for<M>([&](auto Mc) {
+                    constexpr int m = Mc;
+                    constexpr int g = m + SH;                                  // source pair in sequence order
+                    constexpr int d = (g >= 0) ? g / M : -((-g + M - 1) / M);   // floor(g / M): chunks away
+                    constexpr int src = g - d * M;
+                    x[U(s, m) + S] = lat_nbr<H, d>(old[src]);
+                });
+            }
+        }
+    };
+    constexpr bool one_shot = (H != 6) || (NS - 1 <= M);                       // wave rotations reach one lane only
+    if constexpr (!INV) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const double pj = cf.p[j], kj = cf.kap[j];
+#pragma unroll
+            for (int s = 0; s < NSEQ; ++s)
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    x[U(s, m)] = fma(pj, x[U(s, m) + S], x[U(s, m)]);
+                    x[U(s, m) + S] = fma(-kj, x[U(s, m)], x[U(s, m) + S]);
+                }
+            if (j + 1 < NS) shift(std::integral_constant<int, 1>{});
+        }
+        if constexpr (one_shot) shift(std::integral_constant<int, -(NS - 1)>{});
+        else {
+#pragma unroll
+            for (int j = 0; j + 1 < NS; ++j) shift(std::integral_constant<int, -1>{});
+        }
+    } else {
+        if constexpr (one_shot) shift(std::integral_constant<int, NS - 1>{});
+        else {
+#pragma unroll
+            for (int j = 0; j + 1 < NS; ++j) shift(std::integral_constant<int, 1>{});
+        }
+#pragma unroll
+        for (int j = NS - 1; j >= 0; --j) {
+            const double pj = cf.p[j], kj = cf.kap[j];
+#pragma unroll
+            for (int s = 0; s < NSEQ; ++s)
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    x[U(s, m) + S] = fma(kj, x[U(s, m)], x[U(s, m) + S]);
+                    x[U(s, m)] = fma(-pj, x[U(s, m) + S], x[U(s, m)]);
+                }
+            if (j > 0) shift(std::integral_constant<int, -1>{});
+        }
+    }
+}
+
+__device__ __forceinline__ int lat_rev6(int v) { return (int)(__builtin_bitreverse32((unsigned)v) >> 26); }
+
+template <int B0, typename A> __device__ __forceinline__ void lat_wait16(A &x)
+{
+    // x[B0 .. B0+15] are the destinations of the 16 reads just issued
+    lat_wait8(x[B0], x[B0 + 1], x[B0 + 2], x[B0 + 3], x[B0 + 4], x[B0 + 5], x[B0 + 6], x[B0 + 7]);
+    lat_wait8(x[B0 + 8], x[B0 + 9], x[B0 + 10], x[B0 + 11], x[B0 + 12], x[B0 + 13], x[B0 + 14], x[B0 + 15]);
+}
+
+// element e of a lane's 64-sample output chunk held by C register r, depth L (6 <= L <= 12):
+// e[k] = r[L-6+k] for k < 12-L, e[12-L+j] = r[L-7-j] for j <= L-7
+constexpr int lat_pi(int L, int r)
+{
+    int e = 0;
+    for (int k = 0; k < 12 - L; ++k) e |= ((r >> (L - 6 + k)) & 1) << k;
+    for (int j = 0; j <= L - 7; ++j) e |= ((r >> (L - 7 - j)) & 1) << (12 - L + j);
+    return e;
+}
+constexpr int lat_pi_inv(int L, int e)
+{
+    for (int r = 0; r < 64; ++r)
+        if (lat_pi(L, r) == e) return r;
+    return -1;
+}
+
+// f[m] = g0 * g2^(popcount(lane) + m): the gain of a leaf whose path has popcount(lane) detail branches in the lane bits
+// (levels 1-6) and m in the register bits (levels 7-L)
+__device__ __forceinline__ void lat_gains(double (&f)[7], int lane, const WxLat &cf)
+{
+    double b = cf.g0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b = ((lane >> k) & 1) ? b * cf.g2 : b;
+    f[0] = b;
+#pragma unroll
+    for (int m = 1; m < 7; ++m) f[m] = f[m - 1] * cf.g2;
+}
+constexpr int lat_pc(int v)
+{
+    int c = 0;
+    for (; v; v >>= 1) c += v & 1;
+    return c;
+}
+
+// C -> S exchange + stores for a compile-time depth (exchange T4 of tools/lattice_lds_maps.py)
+template <int L> __device__ __forceinline__ void lat_store_c(double (&c)[64], unsigned lds0, double *__restrict__ ys,
+                                                             int lane, const WxLat &cf)
+{
+    double gf[7];
+    lat_gains(gf, lane, cf);
+    const int ch = lat_rev6(lane);
+    const int c0 = ch & 1, c1 = (ch >> 1) & 1, c2 = (ch >> 2) & 1;
+    const int wrow = (c0 ^ c2) | ((ch >> 3) << 1) | (c1 << 4) | (c2 << 5);
+    const unsigned wa = lds0 + 8u * 17u * wrow;
+    const int q = lane >> 3;                              // chunk within the instruction's group of 8
+    const int q0 = q & 1, q1 = (q >> 1) & 1, q2 = q >> 2;
+    const unsigned ra = lds0 + 8u * (17u * ((q0 ^ q2) + 16 * q1 + 32 * q2) + 2u * (lane & 7));
+    const unsigned yo = 64u * q + 2u * (lane & 7);       // lane part of the store address (elements)
+    lat_for<4>([&](auto K) {
+        constexpr int k = K;
+        lat_for<16>([&](auto E) {
+            constexpr int e4 = E;
+            constexpr int rr = lat_pi_inv(L, 16 * k + e4);
+            lds_wr<8 * e4>(wa, c[rr] * gf[lat_pc(rr & ((1 << (L - 6)) - 1))]);
+        });
+        lat_for<2>([&](auto HH) {
+            constexpr int hh = HH;
+            double v[8];
+            lat_for<4>([&](auto I) {
+                constexpr int i = 4 * hh + I;
+                v[2 * I] = lds_rd<8 * (34 * i)>(ra);
+                v[2 * I + 1] = lds_rd<8 * (34 * i + 1)>(ra);
+            });
+            lat_wait8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            lat_for<4>([&](auto I) {
+                constexpr int i = 4 * hh + I;
+                lat_d2 o;
+                o.x = v[2 * I];
+                o.y = v[2 * I + 1];
+                lat_st2(lat_sbase(ys + 512 * i + 16 * k) + yo, o);
+            });
+        });
+    });
+}
+
+// loads + S -> C exchange (T4i)
+template <int L> __device__ __forceinline__ void lat_load_c(double (&c)[64], unsigned lds0, const double *__restrict__ xs,
+                                                            int lane, const WxLat &cf)
+{
+    double gf[7];
+    lat_gains(gf, lane, cf);
+    const int ch = lat_rev6(lane);
+    const int rrow = (((ch >> 1) ^ ch) & 1) | ((ch >> 2) << 1) | ((ch & 1) << 5);
+    const unsigned ra = lds0 + 8u * 17u * rrow;
+    const int lanepart = (((lane >> 4) ^ (lane >> 3)) & 1) | (((lane >> 5) & 1) << 1) | (((lane >> 3) & 1) << 5);
+    const unsigned wa = lds0 + 8u * (17u * lanepart + 2u * (lane & 7));
+    const unsigned xo = 64u * (lane >> 3) + 2u * (lane & 7);
+    lat_d2 v[8];
+    lat_for<8>([&](auto I) {
+        constexpr int i = I;
+        v[i] = lat_ld2(lat_sbase(xs + 512 * i) + xo);
+    });
+    lat_for<4>([&](auto K) {
+        constexpr int k = K;
+        lat_for<8>([&](auto I) {
+            constexpr int i = I;
+            lds_wr<8 * (68 * i)>(wa, v[i].x);
+            lds_wr<8 * (68 * i + 1)>(wa, v[i].y);
+        });
+        // the next round's loads go out as soon as their registers are free (the asm statements are memory barriers
+        // for the compiler, so this order is kept)
+        if constexpr (k < 3)
+            lat_for<8>([&](auto I) {
+                constexpr int i = I;
+                v[i] = lat_ld2(lat_sbase(xs + 512 * i + 16 * (k + 1)) + xo);
+            });
+        lat_for<16>([&](auto E) {
+            constexpr int e4 = E;
+            c[lat_pi_inv(L, 16 * k + e4)] = lds_rd<8 * e4>(ra);
+        });
+        lat_for<2>([&](auto G) {
+            constexpr int g = G;
+            lat_wait8(c[lat_pi_inv(L, 16 * k + 8 * g)], c[lat_pi_inv(L, 16 * k + 8 * g + 1)], c[lat_pi_inv(L, 16 * k + 8 * g + 2)],
+                      c[lat_pi_inv(L, 16 * k + 8 * g + 3)], c[lat_pi_inv(L, 16 * k + 8 * g + 4)], c[lat_pi_inv(L, 16 * k + 8 * g + 5)],
+                      c[lat_pi_inv(L, 16 * k + 8 * g + 6)], c[lat_pi_inv(L, 16 * k + 8 * g + 7)]);
+        });
+        lat_for<16>([&](auto E) {
+            constexpr int rr = lat_pi_inv(L, 16 * k + E);
+            c[rr] *= gf[lat_pc(rr & ((1 << (L - 6)) - 1))];
+        });
+    });
+}
+
+// ---------------------------------------------------------------- forward
+template <int NS, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, int64_t batch, WxLat cf)
+{
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int64_t sig = blockIdx.x;
+    const double *xs = x + sig * 4096;
+    double a[64];
+    {
+        // L0: instruction (hi3 = p[11:9], f = p[5:4]) loads eight complete 128-byte lines: lane holds p[8:6] = lane >> 3,
+        // p[3:1] = lane & 7, register e = p[0].  T1: L0 -> A (reg p[5:0], lane p[11:6]), round f
+        lat_d2 r[32];
+        const unsigned xo = 64u * (lane >> 3) + 2u * (lane & 7);
+        lat_for<32>([&](auto Q) {
+            constexpr int hi3 = Q / 4, f = Q % 4;
+            r[Q] = lat_ld2(lat_sbase(xs + 512 * hi3 + 16 * f) + xo);
+        });
+        const unsigned wa = lds0 + 8u * (17u * (lane >> 3) + 2u * (lane & 7)), ra = lds0 + 8u * 17u * lane;
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<8>([&](auto Hq) {
+                constexpr int hi3 = Hq;
+                lds_wr<8 * (136 * hi3)>(wa, r[4 * hi3 + f].x);
+                lds_wr<8 * (136 * hi3 + 1)>(wa, r[4 * hi3 + f].y);
+            });
+            double t[16];
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                t[m] = lds_rd<8 * m>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                a[16 * f + m] = t[m];
+            });
+        });
+    }
+    lat_level<0, 6, NS, false>(a, cf);
+    lat_level<1, 6, NS, false>(a, cf);
+    // T2: A -> B (reg p[7:2], lane mu = p[11:8] | p[1:0] << 4)
+    double bb[64];
+    {
+        const int sw = lane ^ ((lane >> 5) << 1);
+        const unsigned wa0 = lds0 + 8u * sw, wa1 = lds0 + 8u * (sw ^ 1);
+        const int H = lane & 15, p10 = lane >> 4;
+        const int lam0 = 4 * H, sg = (p10 & 1) | ((lam0 >> 5) << 1);
+        unsigned ra[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ra[h] = lds0 + 8u * (64 * p10 + ((lam0 + h) ^ sg));
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                lds_wr<8 * 64 * j>((j & 1) ? wa1 : wa0, a[16 * f + j]);
+            });
+            double t[16];
+            lat_for<16>([&](auto Q) {
+                constexpr int h = Q / 4, g = Q % 4;
+                t[Q] = lds_rd<8 * 256 * g>(ra[h]);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto Q) {
+                constexpr int h = Q / 4, g = Q % 4;
+                bb[16 * h + 4 * f + g] = t[Q];
+            });
+        });
+    }
+    lat_level<0, 4, NS, false>(bb, cf);
+    lat_level<1, 4, NS, false>(bb, cf);
+    lat_level<2, 4, NS, false>(bb, cf);
+    lat_level<3, 4, NS, false>(bb, cf);
+    // T3: B -> C (reg p[11:6], lane nu = p[5:0])
+    double c[64];
+    {
+        const unsigned wa = lds0 + 8u * (lane + (lane >> 5));
+        const unsigned ra = lds0 + 8u * (66 * (lane >> 2) + 16 * (lane & 1) + 33 * ((lane >> 1) & 1));
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                lds_wr<8 * 66 * j>(wa, bb[16 * f + j]);
+            });
+            double t[16];
+            lat_for<16>([&](auto Hq) {
+                constexpr int H = Hq;
+                t[H] = lds_rd<8 * H>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto Hq) {
+                constexpr int H = Hq;
+                c[4 * H + f] = t[H];
+            });
+        });
+    }
+    if (L > 6) lat_level<0, 0, NS, false>(c, cf);
+    if (L > 7) lat_level<1, 0, NS, false>(c, cf);
+    if (L > 8) lat_level<2, 0, NS, false>(c, cf);
+    if (L > 9) lat_level<3, 0, NS, false>(c, cf);
+    if (L > 10) lat_level<4, 0, NS, false>(c, cf);
+    if (L > 11) lat_level<5, 0, NS, false>(c, cf);
+    double *ys = y + sig * 4096;
+    switch (L) {
+    case 6: lat_store_c<6>(c, lds0, ys, lane, cf); break;
+    case 7: lat_store_c<7>(c, lds0, ys, lane, cf); break;
+    case 8: lat_store_c<8>(c, lds0, ys, lane, cf); break;
+    case 9: lat_store_c<9>(c, lds0, ys, lane, cf); break;
+    case 10: lat_store_c<10>(c, lds0, ys, lane, cf); break;
+    case 11: lat_store_c<11>(c, lds0, ys, lane, cf); break;
+    default: lat_store_c<12>(c, lds0, ys, lane, cf); break;
+    }
+}
+
+// ---------------------------------------------------------------- wpd: every level leaves through an LDS transposition
+// After level l the registers hold level l of the packet table in the in-place order: the coefficient at sample index p
+// belongs at position  o = bitreverse_l(p[l-1:0]) << (12 - l) | p >> l  of column l (DWT.jl:145-158: node j of depth l =
+// rows [j n/2^l, (j+1) n/2^l)), scaled by g^(l - 2 popcount(p[l-1:0])).  o is a bit permutation of p, so "which register
+// of which lane" -> "which byte of which 128-byte line" is static routing: p bit t sits in a register or lane bit that
+// depends on the layout (A, B, C) and lands on o bit (t < l ? 11 - t : t - l).  An exchange round moves 16 registers per
+// lane (two register bits that land on line-address bits are fixed per round): slot = 17 * line + position, where the six
+// line-address bits of the round are ordered with the low lane bits first (conflict-free ds_write_b64 for every
+// layout and level, 2-way ds_read_b64; enumerated in tools/lattice_emu.py::emit_plan and checked against the oracle's
+// wpd there); the read side hands every group of 8 lanes one complete line for a 16-byte-per-lane store.
+struct LatSrc { int reg; int bit; };                       // reg = 1: register-index bit, 0: lane-id bit
+constexpr LatSrc lat_src(int lay, int t)
+{
+    if (lay == 0) return t < 6 ? LatSrc{1, t} : LatSrc{0, t - 6};
+    if (lay == 2) return (t >= 2 && t < 8) ? LatSrc{1, t - 2} : (t >= 8 ? LatSrc{0, t - 8} : LatSrc{0, 4 + t});
+    return t >= 6 ? LatSrc{1, t - 6} : LatSrc{0, t};
+}
+constexpr int lat_pbit(int lay, int reg, int bit)           // sample-index bit held by that register / lane bit
+{
+    for (int t = 0; t < 12; ++t)
+        if (lat_src(lay, t).reg == reg && lat_src(lay, t).bit == bit) return t;
+    return -1;
+}
+// level code lc = l + 16 sh: sh low index bits are a signal number (2^sh signals of 4096 >> sh samples interleaved in the
+// registers, see k_lat_wpt_f64<.., SH>), the l levels acted on bits sh .. sh + l - 1: the signal number goes to the top of the
+// address, the path bits are reversed below it, the rest is the position inside the node
+constexpr int lat_lv(int lc) { return lc & 15; }
+constexpr int lat_sh(int lc) { return lc >> 4; }
+constexpr bool lat_on_path(int lc, int t) { return t >= lat_sh(lc) && t < lat_sh(lc) + lat_lv(lc); }   // t = -1: old code counted it; never occurs for k, i < 6
+constexpr int lat_obit(int lc, int t)
+{
+    if (t < 0) return 12;                                    // "no such bit" (lat_pbit / lat_round_bit = -1): above the address
+    return t < lat_sh(lc) ? 12 - lat_sh(lc) + t : (t < lat_sh(lc) + lat_lv(lc) ? 11 - t : t - lat_sh(lc) - lat_lv(lc));
+}
+constexpr int lat_reg_o(int lay, int l, int i) { return lat_obit(l, lat_pbit(lay, 1, i)); }
+constexpr int lat_lane_o(int lay, int l, int k) { return lat_obit(l, lat_pbit(lay, 0, k)); }
+// the j-th (j = 0, 1) register bit fixed per round: the lowest register bits that land on a line-address bit
+constexpr int lat_round_bit(int lay, int l, int j)
+{
+    int c = 0;
+    for (int i = 0; i < 6; ++i)
+        if (lat_reg_o(lay, l, i) >= 4) { if (c == j) return i; ++c; }
+    return -1;
+}
+constexpr bool lat_is_round_bit(int lay, int l, int i) { return i == lat_round_bit(lay, l, 0) || i == lat_round_bit(lay, l, 1); }
+constexpr int lat_vbit(int lay, int l, int j)               // j-th of the four register bits that vary inside a round
+{
+    int c = 0;
+    for (int i = 0; i < 6; ++i)
+        if (!lat_is_round_bit(lay, l, i)) { if (c == j) return i; ++c; }
+    return -1;
+}
+// the q-th line-address bit of a round: {is_reg, source bit, o bit}; low lane bits first, then lane bits 4, 5, then registers
+struct LatLine { int reg; int bit; int ob; };
+constexpr LatLine lat_line(int lay, int l, int q)
+{
+    int c = 0;
+    for (int k = 0; k < 6; ++k)
+        if (lat_lane_o(lay, l, k) >= 4) { if (c == q) return LatLine{0, k, lat_lane_o(lay, l, k)}; ++c; }
+    for (int j = 0; j < 4; ++j) {
+        const int i = lat_vbit(lay, l, j);
+        if (lat_reg_o(lay, l, i) >= 4) { if (c == q) return LatLine{1, i, lat_reg_o(lay, l, i)}; ++c; }
+    }
+    return LatLine{-1, -1, -1};
+}
+constexpr int lat_emit_reg(int lay, int l, int rho, int v)  // register of round rho, v = 0..15
+{
+    int r = 0;
+    for (int j = 0; j < 4; ++j) r |= ((v >> j) & 1) << lat_vbit(lay, l, j);
+    for (int j = 0; j < 2; ++j) r |= ((rho >> j) & 1) << lat_round_bit(lay, l, j);
+    return r;
+}
+constexpr int lat_emit_slot_reg(int lay, int l, int r)      // register part of the LDS slot (elements)
+{
+    int hi = 0, pos = 0;
+    for (int i = 0; i < 6; ++i)
+        if (lat_reg_o(lay, l, i) < 4) pos |= ((r >> i) & 1) << lat_reg_o(lay, l, i);
+    for (int q = 0; q < 6; ++q)
+        if (lat_line(lay, l, q).reg == 1) hi |= ((r >> lat_line(lay, l, q).bit) & 1) << q;
+    return 17 * hi + pos;
+}
+constexpr int lat_emit_pc_reg(int lay, int l, int r)        // detail branches on the path held in register bits
+{
+    int c = 0;
+    for (int i = 0; i < 6; ++i)
+        if (lat_on_path(l, lat_pbit(lay, 1, i))) c += (r >> i) & 1;
+    return c;
+}
+constexpr int lat_emit_o_round(int lay, int l, int rho)
+{
+    int o = 0;
+    for (int j = 0; j < 2; ++j) o |= ((rho >> j) & 1) << lat_reg_o(lay, l, lat_round_bit(lay, l, j));
+    return o;
+}
+constexpr int lat_emit_o_instr(int lay, int l, int i)       // line-address bits 3..5 of the round come from the store index
+{
+    int o = 0;
+    for (int q = 3; q < 6; ++q) o |= ((i >> (q - 3)) & 1) << lat_line(lay, l, q).ob;
+    return o;
+}
+
+struct WxLatW {
+    WxLat c;
+    double gl[13];            // g^l
+};
+
+template <int LAY, int LVL>
+__device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double *__restrict__ ycol, int lane, const WxLatW &cw)
+{
+    // lane parts: line-address bits, in-line position bits, detail branches of the path
+    int hi_lane = 0, pos_lane = 0;
+    double b = cw.gl[lat_lv(LVL)];
+    lat_for<6>([&](auto Kc) {
+        constexpr int k = Kc;
+        constexpr int ob = lat_lane_o(LAY, LVL, k);
+        if constexpr (ob < 4) pos_lane |= ((lane >> k) & 1) << ob;
+        if constexpr (lat_on_path(LVL, lat_pbit(LAY, 0, k))) b = ((lane >> k) & 1) ? b * cw.c.g2 : b;
+    });
+    lat_for<6>([&](auto Qc) {
+        constexpr int q = Qc;
+        constexpr LatLine ln = lat_line(LAY, LVL, q);
+        if constexpr (ln.reg == 0) hi_lane |= ((lane >> ln.bit) & 1) << q;
+    });
+    double gf[7];
+    gf[0] = b;
+#pragma unroll
+    for (int m = 1; m < 7; ++m) gf[m] = gf[m - 1] * cw.c.g2;
+    const unsigned wa = lds0 + 8u * (unsigned)(17 * hi_lane + pos_lane);
+    // read side: store instruction i of a round covers lines 8 i + (lane >> 3), a lane takes elements 2 (lane & 7), +1
+    const int qq = lane >> 3;
+    int o_lane = 2 * (lane & 7);
+    lat_for<3>([&](auto Qc) {
+        constexpr int q = Qc;
+        constexpr int ob = lat_line(LAY, LVL, q).ob;           // forced constant evaluation: left to the optimiser the
+        o_lane |= ((qq >> q) & 1) << ob;                          // bit-map loops are not always folded
+    });
+    const unsigned ra = lds0 + 8u * (unsigned)(17 * qq + 2 * (lane & 7));
+    const unsigned yo = (unsigned)o_lane;
+    lat_for<4>([&](auto Rc) {
+        constexpr int rho = Rc;
+        lat_for<16>([&](auto Vc) {
+            constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
+            constexpr int pc = lat_emit_pc_reg(LAY, LVL, r);
+            lds_wr<8 * lat_emit_slot_reg(LAY, LVL, r)>(wa, x[r] * gf[pc]);
+        });
+        lat_for<2>([&](auto HH) {
+            constexpr int hh = HH;
+            double v[8];
+            lat_for<4>([&](auto I) {
+                constexpr int i = 4 * hh + I;
+                v[2 * I] = lds_rd<8 * (17 * 8 * i)>(ra);
+                v[2 * I + 1] = lds_rd<8 * (17 * 8 * i + 1)>(ra);
+            });
+            lat_wait8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            lat_for<4>([&](auto I) {
+                constexpr int i = 4 * hh + I;
+                lat_d2 o;
+                o.x = v[2 * I];
+                o.y = v[2 * I + 1];
+                constexpr int oc = lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i);
+                lat_st2w(lat_sbase(ycol + oc) + yo, o);
+            });
+        });
+    });
+}
+
+// the mirror of lat_emit: a column in the order of lat_obit(LVL, .) -> the registers of layout LAY, scaled by the path gains
+// (the two LDS address patterns swap roles: 16-byte loads of complete lines are written where lat_emit reads, the registers
+// are read where lat_emit writes)
+__device__ __forceinline__ void lat_st1(double __attribute__((address_space(1))) *p, double v) { *p = v; }
+template <int LAY, int LVL>
+__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const double *__restrict__ xcol, int lane, const WxLatW &cw)
+{
+    int hi_lane = 0, pos_lane = 0;
+    double b = cw.gl[lat_lv(LVL)];
+    lat_for<6>([&](auto Kc) {
+        constexpr int k = Kc;
+        constexpr int ob = lat_lane_o(LAY, LVL, k);
+        if constexpr (ob < 4) pos_lane |= ((lane >> k) & 1) << ob;
+        if constexpr (lat_on_path(LVL, lat_pbit(LAY, 0, k))) b = ((lane >> k) & 1) ? b * cw.c.g2 : b;
+    });
+    lat_for<6>([&](auto Qc) {
+        constexpr int q = Qc;
+        constexpr LatLine ln = lat_line(LAY, LVL, q);
+        if constexpr (ln.reg == 0) hi_lane |= ((lane >> ln.bit) & 1) << q;
+    });
+    double gf[7];
+    gf[0] = b;
+#pragma unroll
+    for (int m = 1; m < 7; ++m) gf[m] = gf[m - 1] * cw.c.g2;
+    const unsigned rda = lds0 + 8u * (unsigned)(17 * hi_lane + pos_lane);
+    const int qq = lane >> 3;
+    int o_lane = 2 * (lane & 7);
+    lat_for<3>([&](auto Qc) {
+        constexpr int q = Qc;
+        constexpr int ob = lat_line(LAY, LVL, q).ob;
+        o_lane |= ((qq >> q) & 1) << ob;
+    });
+    const unsigned wra = lds0 + 8u * (unsigned)(17 * qq + 2 * (lane & 7));
+    const unsigned xo = (unsigned)o_lane;
+    lat_d2 v[8];
+    lat_for<8>([&](auto I) {
+        constexpr int i = I;
+        constexpr int oc = lat_emit_o_round(LAY, LVL, 0) + lat_emit_o_instr(LAY, LVL, i);
+        v[i] = lat_ld2(lat_sbase(xcol + oc) + xo);
+    });
+    lat_for<4>([&](auto Rc) {
+        constexpr int rho = Rc;
+        lat_for<8>([&](auto I) {
+            constexpr int i = I;
+            lds_wr<8 * (17 * 8 * i)>(wra, v[i].x);
+            lds_wr<8 * (17 * 8 * i + 1)>(wra, v[i].y);
+        });
+        if constexpr (rho < 3)                                  // the next round's lines travel while this one is exchanged
+            lat_for<8>([&](auto I) {
+                constexpr int i = I;
+                constexpr int oc = lat_emit_o_round(LAY, LVL, rho + 1) + lat_emit_o_instr(LAY, LVL, i);
+                v[i] = lat_ld2(lat_sbase(xcol + oc) + xo);
+            });
+        double t[16];
+        lat_for<16>([&](auto Vc) {
+            constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
+            t[Vc] = lds_rd<8 * lat_emit_slot_reg(LAY, LVL, r)>(rda);
+        });
+        lat_wait16<0>(t);
+        lat_for<16>([&](auto Vc) {
+            constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
+            constexpr int pc = lat_emit_pc_reg(LAY, LVL, r);
+            x[r] = t[Vc] * gf[pc];
+        });
+    });
+}
+
+// the three layout changes of the forward direction, shared by wpt and wpd
+__device__ __forceinline__ void lat_t2(double (&a)[64], double (&bb)[64], unsigned lds0, int lane)
+{
+    const int sw = lane ^ ((lane >> 5) << 1);
+    const unsigned wa0 = lds0 + 8u * sw, wa1 = lds0 + 8u * (sw ^ 1);
+    const int H = lane & 15, p10 = lane >> 4;
+    const int lam0 = 4 * H, sg = (p10 & 1) | ((lam0 >> 5) << 1);
+    unsigned ra[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) ra[h] = lds0 + 8u * (64 * p10 + ((lam0 + h) ^ sg));
+    lat_for<4>([&](auto Fq) {
+        constexpr int f = Fq;
+        lat_for<16>([&](auto Jq) {
+            constexpr int j = Jq;
+            lds_wr<8 * 64 * j>((j & 1) ? wa1 : wa0, a[16 * f + j]);
+        });
+        double t[16];
+        lat_for<16>([&](auto Q) {
+            constexpr int h = Q / 4, g = Q % 4;
+            t[Q] = lds_rd<8 * 256 * g>(ra[h]);
+        });
+        lat_wait16<0>(t);
+        lat_for<16>([&](auto Q) {
+            constexpr int h = Q / 4, g = Q % 4;
+            bb[16 * h + 4 * f + g] = t[Q];
+        });
+    });
+}
+__device__ __forceinline__ void lat_t3(double (&bb)[64], double (&c)[64], unsigned lds0, int lane)
+{
+    const unsigned wa = lds0 + 8u * (lane + (lane >> 5));
+    const unsigned ra = lds0 + 8u * (66 * (lane >> 2) + 16 * (lane & 1) + 33 * ((lane >> 1) & 1));
+    lat_for<4>([&](auto Fq) {
+        constexpr int f = Fq;
+        lat_for<16>([&](auto Jq) {
+            constexpr int j = Jq;
+            lds_wr<8 * 66 * j>(wa, bb[16 * f + j]);
+        });
+        double t[16];
+        lat_for<16>([&](auto Hq) {
+            constexpr int H = Hq;
+            t[H] = lds_rd<8 * H>(ra);
+        });
+        lat_wait16<0>(t);
+        lat_for<16>([&](auto Hq) {
+            constexpr int H = Hq;
+            c[4 * H + f] = t[H];
+        });
+    });
+}
+
+// wpd!(y, x, wt, L) DWT.jl:131-161 / wpdall dwt/dwt_all.jl:260-282 for 4096-sample Float64 signals: y is (4096, L+1, batch)
+template <int NS, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpd_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, int64_t batch, WxLatW cw)
+{
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int64_t sig = blockIdx.x;
+    const double *xs = x + sig * 4096;
+    double *ys = y + sig * 4096 * (int64_t)(L + 1);
+    const WxLat &cf = cw.c;
+    double a[64];
+    {
+        lat_d2 r[32];
+        const unsigned xo = 64u * (lane >> 3) + 2u * (lane & 7);
+        lat_for<32>([&](auto Q) {
+            constexpr int hi3 = Q / 4, f = Q % 4;
+            r[Q] = lat_ld2(lat_sbase(xs + 512 * hi3 + 16 * f) + xo);
+        });
+        // column 0 of the table is the signal (DWT.jl:145)
+        lat_for<32>([&](auto Q) {
+            constexpr int hi3 = Q / 4, f = Q % 4;
+            lat_st2w(lat_sbase(ys + 512 * hi3 + 16 * f) + xo, r[Q]);
+        });
+        const unsigned wa = lds0 + 8u * (17u * (lane >> 3) + 2u * (lane & 7)), ra = lds0 + 8u * 17u * lane;
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<8>([&](auto Hq) {
+                constexpr int hi3 = Hq;
+                lds_wr<8 * (136 * hi3)>(wa, r[4 * hi3 + f].x);
+                lds_wr<8 * (136 * hi3 + 1)>(wa, r[4 * hi3 + f].y);
+            });
+            double t[16];
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                t[m] = lds_rd<8 * m>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                a[16 * f + m] = t[m];
+            });
+        });
+    }
+    lat_level<0, 6, NS, false>(a, cf);
+    lat_emit<0, 1>(a, lds0, ys + 4096 * 1, lane, cw);
+    if (L < 2) return;
+    lat_level<1, 6, NS, false>(a, cf);
+    lat_emit<0, 2>(a, lds0, ys + 4096 * 2, lane, cw);
+    if (L < 3) return;
+    double bb[64];
+    lat_t2(a, bb, lds0, lane);
+    lat_level<0, 4, NS, false>(bb, cf);
+    lat_emit<2, 3>(bb, lds0, ys + 4096 * 3, lane, cw);
+    if (L < 4) return;
+    lat_level<1, 4, NS, false>(bb, cf);
+    lat_emit<2, 4>(bb, lds0, ys + 4096 * 4, lane, cw);
+    if (L < 5) return;
+    lat_level<2, 4, NS, false>(bb, cf);
+    lat_emit<2, 5>(bb, lds0, ys + 4096 * 5, lane, cw);
+    if (L < 6) return;
+    lat_level<3, 4, NS, false>(bb, cf);
+    lat_emit<2, 6>(bb, lds0, ys + 4096 * 6, lane, cw);
+    if (L < 7) return;
+    double c[64];
+    lat_t3(bb, c, lds0, lane);
+    lat_level<0, 0, NS, false>(c, cf);
+    lat_emit<6, 7>(c, lds0, ys + 4096 * 7, lane, cw);
+    if (L < 8) return;
+    lat_level<1, 0, NS, false>(c, cf);
+    lat_emit<6, 8>(c, lds0, ys + 4096 * 8, lane, cw);
+    if (L < 9) return;
+    lat_level<2, 0, NS, false>(c, cf);
+    lat_emit<6, 9>(c, lds0, ys + 4096 * 9, lane, cw);
+    if (L < 10) return;
+    lat_level<3, 0, NS, false>(c, cf);
+    lat_emit<6, 10>(c, lds0, ys + 4096 * 10, lane, cw);
+    if (L < 11) return;
+    lat_level<4, 0, NS, false>(c, cf);
+    lat_emit<6, 11>(c, lds0, ys + 4096 * 11, lane, cw);
+    if (L < 12) return;
+    lat_level<5, 0, NS, false>(c, cf);
+    lat_emit<6, 12>(c, lds0, ys + 4096 * 12, lane, cw);
+}
+
+// ---------------------------------------------------------------- shorter signals: 2^SH of them interleaved in one wavefront
+// 4096 >> SH samples per signal (2048, 1024): sample i of signal s sits at register-file index p = (i << SH) | s, i.e. the
+// low SH index bits are a signal number that no level touches and level l acts on bit SH + l - 1 -- the same rotations,
+// exchanges and halos as the 4096-sample kernel from its level SH + 1 on (the halo wraps at p + 4096 = i + 4096 >> SH of the
+// same signal).  The 2^SH signals are adjacent in memory, so the wavefront still owns one contiguous 32 KiB block: it is read
+// with 8-byte loads (a lane's two registers belong to different signals) and written through the static bit routing of
+// lat_emit with the bit map of lat_obit(l + 16 SH, .): signal number on top, path bits reversed below it.
+__device__ __forceinline__ double lat_ld1(const double __attribute__((address_space(1))) *p) { return *p; }
+template <int SH> constexpr int lat_rotr(int p) { return (p >> SH) | ((p & ((1 << SH) - 1)) << (12 - SH)); }
+
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_sh_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw)
+{
+    static_assert(SH == 1 || SH == 2, "two or four signals per wavefront");
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    // the last wavefront of a batch that is not a multiple of 2^SH re-does the last 2^SH signals (out of place only)
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const int64_t off = (int64_t)sig0 * (4096 >> SH);
+    const double *xs = x + off;
+    double *ys = y + off;
+    const WxLat &cf = cw.c;
+    double a[64];
+    {
+        lat_d2 r[32];
+        const int lp = 64 * (lane >> 3) + 2 * (lane & 7);
+        const unsigned xo = (unsigned)((lp >> SH) | ((lp & ((1 << SH) - 1)) << (12 - SH)));
+        lat_for<32>([&](auto Q) {
+            constexpr int hi3 = Q / 4, f = Q % 4;
+            r[Q].x = lat_ld1(lat_sbase(xs + lat_rotr<SH>(512 * hi3 + 16 * f)) + xo);
+            r[Q].y = lat_ld1(lat_sbase(xs + lat_rotr<SH>(512 * hi3 + 16 * f + 1)) + xo);
+        });
+        const unsigned wa = lds0 + 8u * (17u * (lane >> 3) + 2u * (lane & 7)), ra = lds0 + 8u * 17u * lane;
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<8>([&](auto Hq) {
+                constexpr int hi3 = Hq;
+                lds_wr<8 * (136 * hi3)>(wa, r[4 * hi3 + f].x);
+                lds_wr<8 * (136 * hi3 + 1)>(wa, r[4 * hi3 + f].y);
+            });
+            double t[16];
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                t[m] = lds_rd<8 * m>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                a[16 * f + m] = t[m];
+            });
+        });
+    }
+    if constexpr (SH < 2) lat_level<1, 6, NS, false>(a, cf);
+    double bb[64];
+    lat_t2(a, bb, lds0, lane);
+    lat_level<0, 4, NS, false>(bb, cf);
+    lat_level<1, 4, NS, false>(bb, cf);
+    lat_level<2, 4, NS, false>(bb, cf);
+    lat_level<3, 4, NS, false>(bb, cf);
+    double c[64];
+    lat_t3(bb, c, lds0, lane);
+    const int Le = L + SH;                                  // highest index bit + 1 that a level acts on: 6 .. 12
+    if (Le > 6) lat_level<0, 0, NS, false>(c, cf);
+    if (Le > 7) lat_level<1, 0, NS, false>(c, cf);
+    if (Le > 8) lat_level<2, 0, NS, false>(c, cf);
+    if (Le > 9) lat_level<3, 0, NS, false>(c, cf);
+    if (Le > 10) lat_level<4, 0, NS, false>(c, cf);
+    if (Le > 11) lat_level<5, 0, NS, false>(c, cf);
+    switch (Le) {
+    case 6: lat_emit<6, 6 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 7: lat_emit<6, 7 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 8: lat_emit<6, 8 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 9: lat_emit<6, 9 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 10: lat_emit<6, 10 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 11: lat_emit<6, 11 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    default: lat_emit<6, 12 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    }
+}
+
+// ---------------------------------------------------------------- inverse
+template <int NS, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_f64(
+    const double *__restrict__ xw, double *__restrict__ y, int L, int64_t batch, int64_t in_stride, WxLat cf)
+{
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int64_t sig = blockIdx.x;
+    const double *xs = xw + sig * in_stride;
+    double c[64];
+    switch (L) {
+    case 6: lat_load_c<6>(c, lds0, xs, lane, cf); break;
+    case 7: lat_load_c<7>(c, lds0, xs, lane, cf); break;
+    case 8: lat_load_c<8>(c, lds0, xs, lane, cf); break;
+    case 9: lat_load_c<9>(c, lds0, xs, lane, cf); break;
+    case 10: lat_load_c<10>(c, lds0, xs, lane, cf); break;
+    case 11: lat_load_c<11>(c, lds0, xs, lane, cf); break;
+    default: lat_load_c<12>(c, lds0, xs, lane, cf); break;
+    }
+    if (L > 11) lat_level<5, 0, NS, true>(c, cf);
+    if (L > 10) lat_level<4, 0, NS, true>(c, cf);
+    if (L > 9) lat_level<3, 0, NS, true>(c, cf);
+    if (L > 8) lat_level<2, 0, NS, true>(c, cf);
+    if (L > 7) lat_level<1, 0, NS, true>(c, cf);
+    if (L > 6) lat_level<0, 0, NS, true>(c, cf);
+    // T3i: C -> B
+    double bb[64];
+    {
+        const unsigned wa = lds0 + 8u * (34 * (lane >> 1) + (lane & 1));
+        const int H = lane & 15, p0 = (lane >> 4) & 1, p1 = lane >> 5;
+        const unsigned ra = lds0 + 8u * (34 * p1 + 2 * H + p0);
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<16>([&](auto Hq) {
+                constexpr int Hh = Hq;
+                lds_wr<8 * 2 * Hh>(wa, c[4 * Hh + f]);
+            });
+            double t[16];
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                t[j] = lds_rd<8 * 68 * j>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                bb[16 * f + j] = t[j];
+            });
+        });
+    }
+    lat_level<3, 4, NS, true>(bb, cf);
+    lat_level<2, 4, NS, true>(bb, cf);
+    lat_level<1, 4, NS, true>(bb, cf);
+    lat_level<0, 4, NS, true>(bb, cf);
+    // T2i: B -> A
+    double a[64];
+    {
+        const int H = lane & 15, p10 = lane >> 4;
+        unsigned wa[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            wa[h] = lds0 + 8u * (((h ^ (H >> 2)) | ((H & 3) << 2) | (((H >> 2) & 1) << 4) | ((H >> 3) << 5)) + 64 * p10);
+        const int Ha = lane >> 2, ha = lane & 3;
+        const unsigned ra = lds0 + 8u * ((ha ^ (Ha >> 2)) | ((Ha & 3) << 2) | (((Ha >> 2) & 1) << 4) | ((Ha >> 3) << 5));
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<16>([&](auto Q) {
+                constexpr int h = Q / 4, g = Q % 4;
+                lds_wr<8 * 256 * g>(wa[h], bb[16 * h + 4 * f + g]);
+            });
+            double t[16];
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                t[j] = lds_rd<8 * 64 * j>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                a[16 * f + j] = t[j];
+            });
+        });
+    }
+    lat_level<1, 6, NS, true>(a, cf);
+    lat_level<0, 6, NS, true>(a, cf);
+    // T1i: A -> L0 and the stores (eight complete 128-byte lines per instruction), round f = p[5:4]
+    {
+        const unsigned wa = lds0 + 8u * 17u * lane, ra = lds0 + 8u * (17u * (lane >> 3) + 4u * (lane & 7));
+        const unsigned yo = 64u * (lane >> 3) + 2u * (lane & 7);
+        double *ys = y + sig * 4096;
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;                     // m = 2 j + e
+                lds_wr<8 * (4 * (m >> 1) + 2 * (m & 1))>(wa, a[16 * f + m]);
+            });
+            double t[16];
+            lat_for<16>([&](auto M) {
+                constexpr int hi3 = M / 2, e = M % 2;
+                t[M] = lds_rd<8 * (136 * hi3 + 2 * e)>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<8>([&](auto Hq) {
+                constexpr int hi3 = Hq;
+                lat_d2 o;
+                o.x = t[2 * hi3];
+                o.y = t[2 * hi3 + 1];
+                lat_st2(lat_sbase(ys + 512 * hi3 + 16 * f) + yo, o);
+            });
+        });
+    }
+}
+
+// inverse of k_lat_wpt_sh_f64: 2^SH signals of 4096 >> SH samples per wavefront, leaves dense and adjacent in memory
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_sh_f64(
+    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, WxLatW cw)
+{
+    static_assert(SH == 1 || SH == 2, "two or four signals per wavefront");
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const int64_t off = (int64_t)sig0 * (4096 >> SH);
+    const double *xs = xw + off;
+    double *ys = y + off;
+    const WxLat &cf = cw.c;
+    const int Le = L + SH;
+    double c[64];
+    switch (Le) {
+    case 6: lat_absorb<6, 6 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
+    case 7: lat_absorb<6, 7 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
+    case 8: lat_absorb<6, 8 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
+    case 9: lat_absorb<6, 9 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
+    case 10: lat_absorb<6, 10 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
+    case 11: lat_absorb<6, 11 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
+    default: lat_absorb<6, 12 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
+    }
+    if (Le > 11) lat_level<5, 0, NS, true>(c, cf);
+    if (Le > 10) lat_level<4, 0, NS, true>(c, cf);
+    if (Le > 9) lat_level<3, 0, NS, true>(c, cf);
+    if (Le > 8) lat_level<2, 0, NS, true>(c, cf);
+    if (Le > 7) lat_level<1, 0, NS, true>(c, cf);
+    if (Le > 6) lat_level<0, 0, NS, true>(c, cf);
+    // T3i: C -> B
+    double bb[64];
+    {
+        const unsigned wa = lds0 + 8u * (34 * (lane >> 1) + (lane & 1));
+        const int H = lane & 15, p0 = (lane >> 4) & 1, p1 = lane >> 5;
+        const unsigned ra = lds0 + 8u * (34 * p1 + 2 * H + p0);
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<16>([&](auto Hq) {
+                constexpr int Hh = Hq;
+                lds_wr<8 * 2 * Hh>(wa, c[4 * Hh + f]);
+            });
+            double t[16];
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                t[j] = lds_rd<8 * 68 * j>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                bb[16 * f + j] = t[j];
+            });
+        });
+    }
+    lat_level<3, 4, NS, true>(bb, cf);
+    lat_level<2, 4, NS, true>(bb, cf);
+    lat_level<1, 4, NS, true>(bb, cf);
+    lat_level<0, 4, NS, true>(bb, cf);
+    // T2i: B -> A
+    double a[64];
+    {
+        const int H = lane & 15, p10 = lane >> 4;
+        unsigned wa[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            wa[h] = lds0 + 8u * (((h ^ (H >> 2)) | ((H & 3) << 2) | (((H >> 2) & 1) << 4) | ((H >> 3) << 5)) + 64 * p10);
+        const int Ha = lane >> 2, ha = lane & 3;
+        const unsigned ra = lds0 + 8u * ((ha ^ (Ha >> 2)) | ((Ha & 3) << 2) | (((Ha >> 2) & 1) << 4) | ((Ha >> 3) << 5));
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<16>([&](auto Q) {
+                constexpr int h = Q / 4, g = Q % 4;
+                lds_wr<8 * 256 * g>(wa[h], bb[16 * h + 4 * f + g]);
+            });
+            double t[16];
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                t[j] = lds_rd<8 * 64 * j>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto Jq) {
+                constexpr int j = Jq;
+                a[16 * f + j] = t[j];
+            });
+        });
+    }
+    if constexpr (SH < 2) lat_level<1, 6, NS, true>(a, cf);
+    // layout A -> memory through the static bit routing (complete lines): address = the index rotated right by SH
+    lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw);
+}
+
+}  // namespace
+
+bool wx_lattice_factor(const WxFilt &filt, int L, bool inverse, WxLat *out);      // wx_lattice.hip
