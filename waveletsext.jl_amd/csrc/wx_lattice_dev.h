@@ -588,8 +588,12 @@ struct WxLatW {
 };
 
 template <int LAY, int LVL>
-__device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double *__restrict__ ycol, int lane, const WxLatW &cw)
+__device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double *__restrict__ ycol, int lane, const WxLatW &cw,
+                                         unsigned sstride = 4096u >> lat_sh(LVL))
 {
+    // sstride: elements between the columns of consecutive signals of the wavefront (interleaved kernels; the signal
+    // number is the top lat_sh(LVL) bits of the routed address)
+    constexpr int SB = 12 - lat_sh(LVL);
     // lane parts: line-address bits, in-line position bits, detail branches of the path
     int hi_lane = 0, pos_lane = 0;
     double b = cw.gl[lat_lv(LVL)];
@@ -618,7 +622,7 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
         o_lane |= ((qq >> q) & 1) << ob;                          // bit-map loops are not always folded
     });
     const unsigned ra = lds0 + 8u * (unsigned)(17 * qq + 2 * (lane & 7));
-    const unsigned yo = (unsigned)o_lane;
+    const unsigned yo = (unsigned)(o_lane & ((1 << SB) - 1)) + (unsigned)(o_lane >> SB) * sstride;
     lat_for<4>([&](auto Rc) {
         constexpr int rho = Rc;
         lat_for<16>([&](auto Vc) {
@@ -641,7 +645,7 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
                 o.x = v[2 * I];
                 o.y = v[2 * I + 1];
                 constexpr int oc = lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i);
-                lat_st2w(lat_sbase(ycol + oc) + yo, o);
+                lat_st2w(lat_sbase(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + yo, o);
             });
         });
     });
@@ -652,8 +656,10 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
 // are read where lat_emit writes)
 __device__ __forceinline__ void lat_st1(double __attribute__((address_space(1))) *p, double v) { *p = v; }
 template <int LAY, int LVL>
-__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const double *__restrict__ xcol, int lane, const WxLatW &cw)
+__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const double *__restrict__ xcol, int lane, const WxLatW &cw,
+                                           unsigned sstride = 4096u >> lat_sh(LVL))
 {
+    constexpr int SB = 12 - lat_sh(LVL);
     int hi_lane = 0, pos_lane = 0;
     double b = cw.gl[lat_lv(LVL)];
     lat_for<6>([&](auto Kc) {
@@ -680,12 +686,12 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
         o_lane |= ((qq >> q) & 1) << ob;
     });
     const unsigned wra = lds0 + 8u * (unsigned)(17 * qq + 2 * (lane & 7));
-    const unsigned xo = (unsigned)o_lane;
+    const unsigned xo = (unsigned)(o_lane & ((1 << SB) - 1)) + (unsigned)(o_lane >> SB) * sstride;
     lat_d2 v[8];
     lat_for<8>([&](auto I) {
         constexpr int i = I;
         constexpr int oc = lat_emit_o_round(LAY, LVL, 0) + lat_emit_o_instr(LAY, LVL, i);
-        v[i] = lat_ld2(lat_sbase(xcol + oc) + xo);
+        v[i] = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
     });
     lat_for<4>([&](auto Rc) {
         constexpr int rho = Rc;
@@ -698,7 +704,7 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
             lat_for<8>([&](auto I) {
                 constexpr int i = I;
                 constexpr int oc = lat_emit_o_round(LAY, LVL, rho + 1) + lat_emit_o_instr(LAY, LVL, i);
-                v[i] = lat_ld2(lat_sbase(xcol + oc) + xo);
+                v[i] = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
             });
         double t[16];
         lat_for<16>([&](auto Vc) {
@@ -1047,27 +1053,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 // inverse of k_lat_wpt_sh_f64: 2^SH signals of 4096 >> SH samples per wavefront, leaves dense and adjacent in memory
 template <int NS, int WPE, int SH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_sh_f64(
-    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, WxLatW cw)
+    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, WxLatW cw)
 {
     static_assert(SH == 1 || SH == 2, "two or four signals per wavefront");
     __shared__ double lds[WX_LAT_LDS];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
     const int sig0 = min((int)blockIdx.x << SH, last_sig);
-    const int64_t off = (int64_t)sig0 * (4096 >> SH);
-    const double *xs = xw + off;
-    double *ys = y + off;
+    const double *xs = xw + (int64_t)sig0 * in_stride;        // leaves of signal s at xs + s in_stride (a packet table's last column)
+    double *ys = y + (int64_t)sig0 * (4096 >> SH);
     const WxLat &cf = cw.c;
     const int Le = L + SH;
     double c[64];
     switch (Le) {
-    case 6: lat_absorb<6, 6 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
-    case 7: lat_absorb<6, 7 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
-    case 8: lat_absorb<6, 8 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
-    case 9: lat_absorb<6, 9 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
-    case 10: lat_absorb<6, 10 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
-    case 11: lat_absorb<6, 11 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
-    default: lat_absorb<6, 12 - SH + 16 * SH>(c, lds0, xs, lane, cw); break;
+    case 6: lat_absorb<6, 6 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    case 7: lat_absorb<6, 7 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    case 8: lat_absorb<6, 8 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    case 9: lat_absorb<6, 9 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    case 10: lat_absorb<6, 10 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    case 11: lat_absorb<6, 11 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    default: lat_absorb<6, 12 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
     }
     if (Le > 11) lat_level<5, 0, NS, true>(c, cf);
     if (Le > 10) lat_level<4, 0, NS, true>(c, cf);
