@@ -319,6 +319,9 @@ def test_fuzz_register_kernels(wx, oracle):
         es = _stack(oracle.wpt, xs, wt.qmf, Ls)
         assert relerr(wx.to_numpy(wx.wptall(_put(wx, xs, dev), wt, Ls)), es) <= 1e-11, (ns, Ls, B)
         assert relerr(wx.to_numpy(wx.iwptall(_put(wx, es, dev), wt, Ls)), xs) <= 1e-11, (ns, Ls, B)
+        ts = _stack(oracle.wpd, xs, wt.qmf, Ls)
+        assert relerr(wx.to_numpy(wx.wpdall(_put(wx, xs, dev), wt, Ls)), ts) <= 1e-11, (ns, Ls, B)
+        assert relerr(wx.to_numpy(wx.iwpdall(_put(wx, ts, dev), wt, Ls)), xs) <= 1e-11, (ns, Ls, B)
         Lt = int(rng.integers(6, 13))
         exp = _stack(oracle.wpt, x, wt.qmf, Lt)
         assert relerr(wx.to_numpy(wx.wptall(_put(wx, x, dev), wt, Lt)), exp) <= 1e-11

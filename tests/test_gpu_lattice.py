@@ -160,6 +160,13 @@ def test_interleaved_short_signals_match_oracle(wx, oracle, n, wname):
             exp = oracle.wptall(x, wt.qmf, L)
             assert relerr(wx.wptall(x, wt, L), exp) <= 1e-12, (n, wname, B, L)
             assert relerr(wx.iwptall(exp, wt, L), x) <= 1e-12, (n, wname, B, L)
+    # wpd / iwpd: every level leaves through the routed stores, the inverse reads the last column of the tables in place
+    for B in (2, 3, 4, 6):
+        x = np.asfortranarray(rng.standard_normal((n, B)))
+        for L in (1, 2, 5, int(np.log2(n)) - 1, int(np.log2(n))):
+            tab = np.asfortranarray(np.stack([oracle.wpd(x[:, b], wt.qmf, L) for b in range(B)], axis=-1))
+            assert relerr(wx.wpdall(x, wt, L), tab) <= 1e-12, (n, wname, B, L)
+            assert relerr(wx.iwpdall(tab, wt, L), x) <= 1e-12, (n, wname, B, L)
     xd = wx.to_device(np.asfortranarray(rng.standard_normal((n, 7))))
     L = int(np.log2(n)) - 1
     yd = wx.wptall(xd, wt, L)

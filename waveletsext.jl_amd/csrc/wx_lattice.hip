@@ -149,10 +149,14 @@ static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n
 }
 
 // wpd: 0 = not applicable, 1 = launched, < 0 = error
+int wx_lattice_wpd_sh_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);   // wx_lattice_shw.hip
+
 int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
 {
     static const bool off = (getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0) ||
                             (getenv("WX_LATTICE_WPD") && atoi(getenv("WX_LATTICE_WPD")) == 0);
+    static const bool off_sh = getenv("WX_LATTICE_SH") && atoi(getenv("WX_LATTICE_SH")) == 0;
+    if (!off && !off_sh && (n == 2048 || n == 1024) && x != (const double *)y) return wx_lattice_wpd_sh_f64(x, y, n, L, batch, filt, st);
     if (off || n != 4096 || L < 1 || L > 12 || filt.F < 4 || batch <= 0 || batch > 0x7fffffff) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     WxLatW cw;

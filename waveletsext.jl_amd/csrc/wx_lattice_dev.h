@@ -1050,6 +1050,88 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     }
 }
 
+// wpd of 2^SH interleaved signals: y is (n, L+1, batch), n = 4096 >> SH; every level leaves through lat_emit with the
+// signal number routed to the table of its signal (sstride = n (L+1))
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpd_sh_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw)
+{
+    static_assert(SH == 1 || SH == 2, "two or four signals per wavefront");
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    constexpr int N = 4096 >> SH;
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const double *xs = x + (int64_t)sig0 * N;
+    const unsigned ts = (unsigned)(N * (L + 1));                          // table stride between signals
+    double *ys = y + (int64_t)sig0 * ts;
+    const WxLat &cf = cw.c;
+    double a[64];
+    {
+        lat_d2 r[32];
+        const int lp = 64 * (lane >> 3) + 2 * (lane & 7);
+        const unsigned xo = (unsigned)((lp >> SH) | ((lp & ((1 << SH) - 1)) << (12 - SH)));
+        lat_for<32>([&](auto Q) {
+            constexpr int hi3 = Q / 4, f = Q % 4;
+            r[Q].x = lat_ld1(lat_sbase(xs + lat_rotr<SH>(512 * hi3 + 16 * f)) + xo);
+            r[Q].y = lat_ld1(lat_sbase(xs + lat_rotr<SH>(512 * hi3 + 16 * f + 1)) + xo);
+        });
+        const unsigned wa = lds0 + 8u * (17u * (lane >> 3) + 2u * (lane & 7)), ra = lds0 + 8u * 17u * lane;
+        lat_for<4>([&](auto Fq) {
+            constexpr int f = Fq;
+            lat_for<8>([&](auto Hq) {
+                constexpr int hi3 = Hq;
+                lds_wr<8 * (136 * hi3)>(wa, r[4 * hi3 + f].x);
+                lds_wr<8 * (136 * hi3 + 1)>(wa, r[4 * hi3 + f].y);
+            });
+            double t[16];
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                t[m] = lds_rd<8 * m>(ra);
+            });
+            lat_wait16<0>(t);
+            lat_for<16>([&](auto M) {
+                constexpr int m = M;
+                a[16 * f + m] = t[m];
+            });
+        });
+    }
+    // column 0 of every table is the signal (DWT.jl:145): the plain rotation of the index
+    lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw, ts);
+    // level l acts on bit SH + l - 1: layout A holds bits 0, 1, layout B bits 2..5, layout C bits 6..11
+#define WX_LVL_A(K)                                                                               \
+    if constexpr (K >= SH) {                                                                      \
+        constexpr int l = K - SH + 1;                                                             \
+        lat_level<K, 6, NS, false>(a, cf);                                                        \
+        lat_emit<0, l + 16 * SH>(a, lds0, ys + N * l, lane, cw, ts);                              \
+        if (L <= l) return;                                                                       \
+    }
+    WX_LVL_A(1)
+#undef WX_LVL_A
+    double bb[64];
+    lat_t2(a, bb, lds0, lane);
+#define WX_LVL_B(K)                                                                               \
+    {                                                                                             \
+        constexpr int l = K + 2 - SH + 1;                                                         \
+        lat_level<K, 4, NS, false>(bb, cf);                                                       \
+        lat_emit<2, l + 16 * SH>(bb, lds0, ys + N * l, lane, cw, ts);                             \
+        if (L <= l) return;                                                                       \
+    }
+    WX_LVL_B(0) WX_LVL_B(1) WX_LVL_B(2) WX_LVL_B(3)
+#undef WX_LVL_B
+    double c[64];
+    lat_t3(bb, c, lds0, lane);
+#define WX_LVL_C(K)                                                                               \
+    {                                                                                             \
+        constexpr int l = K + 6 - SH + 1;                                                         \
+        lat_level<K, 0, NS, false>(c, cf);                                                        \
+        lat_emit<6, l + 16 * SH>(c, lds0, ys + N * l, lane, cw, ts);                              \
+        if (L <= l) return;                                                                       \
+    }
+    WX_LVL_C(0) WX_LVL_C(1) WX_LVL_C(2) WX_LVL_C(3) WX_LVL_C(4) WX_LVL_C(5)
+#undef WX_LVL_C
+}
+
 // inverse of k_lat_wpt_sh_f64: 2^SH signals of 4096 >> SH samples per wavefront, leaves dense and adjacent in memory
 template <int NS, int WPE, int SH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_sh_f64(
