@@ -192,3 +192,18 @@ def test_interleaved_short_signals_large_batch_properties(wx):
             wx.set_force_generic(0)
         assert float((y2 - y[:, :4096]).abs().max()) <= 1e-12
         del x, y, y2
+
+
+@pytest.mark.parametrize("n", [8192, 16384, 32768])
+def test_long_signals_top_levels_then_lattice(wx, oracle, n):
+    """signals longer than 4096: log2(n / 4096) top levels of one pass each, then the lattice kernels on the 4096-sample nodes
+    (wx_dev_wpt1d / wx_dev_iwpt1d); depths on both sides of the switch-over (L - log2(n / 4096) >= 6)"""
+    rng = np.random.default_rng(n)
+    for wname in ("db2", "db4", "coif6"):
+        wt = _wt(wx, wname)
+        x = np.asfortranarray(rng.standard_normal((n, 3)))
+        dl = int(np.log2(n)) - 12
+        for L in (dl + 5, dl + 6, dl + 8, int(np.log2(n))):
+            exp = oracle.wptall(x, wt.qmf, L)
+            assert relerr(wx.wptall(x, wt, L), exp) <= 1e-12, (n, wname, L)
+            assert relerr(wx.iwptall(exp, wt, L), x) <= 1e-12, (n, wname, L)

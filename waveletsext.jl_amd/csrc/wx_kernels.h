@@ -4,6 +4,7 @@
 #include "wx_common.h"
 
 template <typename T> bool wx_fused1d_ok(int64_t n, int F);
+bool wx_lattice_applicable_f64(const WxFilt &filt);     // wx_lattice.hip: the filter has a lattice instantiation and factorises
 int wx_skip_register_kernels();   // test hook (wx_set_force_generic(2)): skip the Haar / lattice register kernels
 
 // ---- 1-D decimated (wx_dwt1d.hip) ----

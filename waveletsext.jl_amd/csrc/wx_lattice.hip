@@ -187,6 +187,14 @@ int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t bat
     return 1;
 }
 
+bool wx_lattice_applicable_f64(const WxFilt &filt)
+{
+    static const bool off = getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0;
+    if (off || filt.F < 4 || filt.F / 2 > WX_LAT_MAXS) return false;
+    WxLat tmp;
+    return wx_lattice_factor(filt, 6, false, &tmp);
+}
+
 int wx_lattice_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
 {
     return wx_lattice_launch(false, x, y, n, L, batch, n, filt, st);
