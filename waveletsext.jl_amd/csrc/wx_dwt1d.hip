@@ -105,6 +105,79 @@ __global__ __launch_bounds__(256) void k_inv1d_level(const T *__restrict__ src, 
     }
 }
 
+// One level of long nodes (np >= 2 WX_LT samples, every node decomposed) through LDS tiles: a workgroup stages WX_LT
+// outputs pairs' worth of input (2 WX_LT samples plus the F - 1 wrap-around halo on both sides, coalesced 8-byte runs),
+// and every thread computes its pairs out of LDS -- the per-level kernels above read their 2 F taps per pair through
+// L1 (8 x the bytes of the output for F = 8) and stop at 3.5 TB/s.  Same arithmetic and tap order as k_fwd1d_level /
+// k_inv1d_level.  Used for the top levels of signals of 16384 samples and more (wx_dev_wpt1d / wx_dev_iwpt1d).
+constexpr int WX_LT = 2048;                                  // output pairs per tile
+
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void k_level1_tile(const T *__restrict__ src, T *__restrict__ dst, int np, int64_t nnodes,
+                                                     WxFilt filt)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    T *buf = reinterpret_cast<T *>(wx_smem);
+    const int F = filt.F, h = np >> 1;
+    const int tiles = h / WX_LT;
+    const int64_t node = blockIdx.x / tiles;
+    const int t0 = (int)(blockIdx.x - node * tiles) * WX_LT;            // first output pair of the tile
+    const T *v = src + node * (int64_t)np;
+    T *o = dst + node * (int64_t)np;
+    if (!INVERSE) {
+        // inputs 2 t0 - (F - 2) .. 2 t0 + 2 WX_LT + F - 2 (mod np): buf[e] = v[(2 t0 - (F - 2) + e) mod np]
+        const int cnt = 2 * WX_LT + 2 * F - 3;
+        const int lo = 2 * t0 - (F - 2);
+        for (int e = threadIdx.x; e < cnt; e += 256) buf[e] = v[wx_modn(lo + e, np)];
+        __syncthreads();
+        for (int t = threadIdx.x; t < WX_LT; t += 256) {
+            double a = 0.0, d = 0.0;
+            int k1 = 2 * t + (F - 2), k2 = 2 * t + 1 + (F - 2);        // positions of v[2 (t0 + t)], v[2 (t0 + t) + 1] in buf
+            for (int k = 0; k < F; ++k) {
+                a = fma(filt.q[k], (double)buf[k1], a);
+                d = fma((k & 1) ? -filt.q[k] : filt.q[k], (double)buf[k2], d);
+                ++k1; --k2;
+            }
+            o[t0 + t] = (T)a;
+            o[h + t0 + t] = (T)d;
+        }
+    } else {
+        // a[k - m], m = 0 .. F/2 - 1 and d[k + m]: bufA[e] = a[(t0 - (F/2 - 1) + e) mod h], bufD[e] = d[(t0 + e) mod h]
+        const int HF = F >> 1, cnt = WX_LT + HF - 1;
+        T *bufA = buf, *bufD = buf + cnt + 1;
+        for (int e = threadIdx.x; e < cnt; e += 256) {
+            bufA[e] = v[wx_modn(t0 - (HF - 1) + e, h)];
+            bufD[e] = v[h + wx_modn(t0 + e, h)];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < WX_LT; t += 256) {
+            double v0 = 0.0, v1 = 0.0;
+            int k1 = t + HF - 1, k2 = t;
+            for (int m = 0; m < HF; ++m) {
+                const double av = (double)bufA[k1], dv = (double)bufD[k2];
+                v0 = fma(filt.q[2 * m], av, v0);
+                v0 = fma(-filt.q[2 * m + 1], dv, v0);
+                v1 = fma(filt.q[2 * m + 1], av, v1);
+                v1 = fma(filt.q[2 * m], dv, v1);
+                --k1; ++k2;
+            }
+            reinterpret_cast<typename WxVec2<T>::type *>(o)[t0 + t] = typename WxVec2<T>::type{(T)v0, (T)v1};
+        }
+    }
+}
+
+// one full level of every node of np samples (np a multiple of 2 WX_LT), nnodes nodes contiguous in memory
+template <typename T, bool INVERSE>
+static int launch_level1_tile(const T *src, T *dst, int64_t np, int64_t nnodes, const WxFilt &filt, hipStream_t st)
+{
+    const int64_t grid = nnodes * ((np >> 1) / WX_LT);
+    if (grid <= 0 || grid > 0x7fffffff) return wx_set_error(WX_EUNSUPPORTED, "tiled level: grid too large");
+    const size_t lds = sizeof(T) * (size_t)(2 * WX_LT + 2 * WX_MAXF + 4);
+    hipLaunchKernelGGL((k_level1_tile<T, INVERSE>), dim3((unsigned)grid), dim3(256), lds, st, src, dst, (int)np, nnodes, filt);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
 // getbasiscoef gather (Utils.jl:117-131): out[p] = Xw[p, col(p)] for every signal
 template <typename T>
 __global__ __launch_bounds__(256) void k_gather_leaves1d(const T *__restrict__ Xw, T *__restrict__ out,
@@ -1276,12 +1349,8 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
                 int rc = WX_OK;
                 if (wx_fused1d_ok<T>(nd, filt.F))
                     rc = launch_fwd_fused<T, false>(src, dst, nd, 1, batch << d, nd, nd, filt, nullptr, 0, st);
-                else {
-                    const int64_t total = batch * (n / 2);
-                    hipLaunchKernelGGL(k_fwd1d_level<T>, dim3(wx_grid_for(total, 256)), dim3(256), 0, st, src, dst, n, n, (int)n,
-                                       (int)nd, d, batch, filt, (const uint8_t *)nullptr, (int64_t)0);
-                    WX_HIP_CHECK(hipGetLastError());
-                }
+                else
+                    rc = launch_level1_tile<T, false>(src, dst, nd, batch << d, filt, st);
                 if (rc) return rc;
                 src = dst;
             }
@@ -1373,12 +1442,8 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
                     int rc = WX_OK;
                     if (wx_fused1d_ok<T>(nd, filt.F))
                         rc = launch_inv_fused<T>(src2, dst, nd, 1, batch << d, nd, nd, filt, nullptr, 0, nullptr, 0, st);
-                    else {
-                        const int64_t total = batch * (n / 2);
-                        hipLaunchKernelGGL(k_inv1d_level<T>, dim3(wx_grid_for(total, 256)), dim3(256), 0, st, src2, dst, n, n, (int)n,
-                                           (int)nd, d, batch, filt, (const uint8_t *)nullptr, (int64_t)0);
-                        WX_HIP_CHECK(hipGetLastError());
-                    }
+                    else
+                        rc = launch_level1_tile<T, true>(src2, dst, nd, batch << d, filt, st);
                     if (rc) return rc;
                     src2 = dst;
                 }
