@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void k_inv1d_level(const T *__restrict__ src, 
 constexpr int WX_LT = 2048;                                  // output pairs per tile
 
 template <typename T, bool INVERSE>
-__global__ __launch_bounds__(256) void k_level1_tile(const T *__restrict__ src, T *__restrict__ dst, int np, int64_t nnodes,
-                                                     WxFilt filt)
+__global__ __launch_bounds__(256) void k_level1_tile(const T *__restrict__ src, T *__restrict__ dst, int np, int nper,
+                                                     int64_t src_stride, int64_t dst_stride, WxFilt filt)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     T *buf = reinterpret_cast<T *>(wx_smem);
@@ -122,8 +122,10 @@ __global__ __launch_bounds__(256) void k_level1_tile(const T *__restrict__ src, 
     const int tiles = h / WX_LT;
     const int64_t node = blockIdx.x / tiles;
     const int t0 = (int)(blockIdx.x - node * tiles) * WX_LT;            // first output pair of the tile
-    const T *v = src + node * (int64_t)np;
-    T *o = dst + node * (int64_t)np;
+    const int64_t sig = node / nper;                                    // nper nodes per signal, signals src_stride / dst_stride apart
+    const int64_t jn = node - sig * nper;
+    const T *v = src + sig * src_stride + jn * (int64_t)np;
+    T *o = dst + sig * dst_stride + jn * (int64_t)np;
     if (!INVERSE) {
         // inputs 2 t0 - (F - 2) .. 2 t0 + 2 WX_LT + F - 2 (mod np): buf[e] = v[(2 t0 - (F - 2) + e) mod np]
         const int cnt = 2 * WX_LT + 2 * F - 3;
@@ -166,14 +168,16 @@ __global__ __launch_bounds__(256) void k_level1_tile(const T *__restrict__ src, 
     }
 }
 
-// one full level of every node of np samples (np a multiple of 2 WX_LT), nnodes nodes contiguous in memory
+// one full level of every node of np samples (np a multiple of 2 WX_LT): nper nodes per signal, `nsig` signals
 template <typename T, bool INVERSE>
-static int launch_level1_tile(const T *src, T *dst, int64_t np, int64_t nnodes, const WxFilt &filt, hipStream_t st)
+static int launch_level1_tile(const T *src, T *dst, int64_t np, int64_t nper, int64_t nsig, int64_t src_stride, int64_t dst_stride,
+                              const WxFilt &filt, hipStream_t st)
 {
-    const int64_t grid = nnodes * ((np >> 1) / WX_LT);
+    const int64_t grid = nper * nsig * ((np >> 1) / WX_LT);
     if (grid <= 0 || grid > 0x7fffffff) return wx_set_error(WX_EUNSUPPORTED, "tiled level: grid too large");
     const size_t lds = sizeof(T) * (size_t)(2 * WX_LT + 2 * WX_MAXF + 4);
-    hipLaunchKernelGGL((k_level1_tile<T, INVERSE>), dim3((unsigned)grid), dim3(256), lds, st, src, dst, (int)np, nnodes, filt);
+    hipLaunchKernelGGL((k_level1_tile<T, INVERSE>), dim3((unsigned)grid), dim3(256), lds, st, src, dst, (int)np, (int)nper, src_stride,
+                       dst_stride, filt);
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
@@ -1295,6 +1299,11 @@ int wx_dev_wpd1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
         if (d0 < L && (!wx_fused1d_ok<T>(n >> d0, filt.F) || (batch << d0) > ((int64_t)1 << 40))) d0 = L;
     }
     for (int d = 0; d < (d0 < L ? d0 : L); ++d) {
+        if (!force_generic && (n >> d) >= 4 * WX_LT && wx_is_pow2(n)) {
+            const int rc = launch_level1_tile<T, false>(y + d * n, y + (d + 1) * n, n >> d, (int64_t)1 << d, batch, ys, ys, filt, st);
+            if (rc) return rc;
+            continue;
+        }
         const int64_t total = batch * (n / 2);
         hipLaunchKernelGGL(k_fwd1d_level<T>, dim3(wx_grid_for(total, 256)), dim3(256), 0, st, y + d * n,
                            y + (d + 1) * n, ys, ys, (int)n, (int)(n >> d), d, batch, filt,
@@ -1350,7 +1359,7 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
                 if (wx_fused1d_ok<T>(nd, filt.F))
                     rc = launch_fwd_fused<T, false>(src, dst, nd, 1, batch << d, nd, nd, filt, nullptr, 0, st);
                 else
-                    rc = launch_level1_tile<T, false>(src, dst, nd, batch << d, filt, st);
+                    rc = launch_level1_tile<T, false>(src, dst, nd, (int64_t)1 << d, batch, n, n, filt, st);
                 if (rc) return rc;
                 src = dst;
             }
@@ -1375,9 +1384,14 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
         const T *src = x;
         for (int d = 0; d < d0; ++d) {
             T *dst = ((d0 - 1 - d) & 1) ? y : scratch;                 // depth d0 lands in scratch
-            const int64_t total = batch * (n / 2);
-            hipLaunchKernelGGL(k_fwd1d_level<T>, dim3(wx_grid_for(total, 256)), dim3(256), 0, st, src, dst, n, n,
-                               (int)n, (int)(n >> d), d, batch, filt, (const uint8_t *)nullptr, (int64_t)0);
+            if ((n >> d) >= 4 * WX_LT) {
+                const int rc = launch_level1_tile<T, false>(src, dst, n >> d, (int64_t)1 << d, batch, n, n, filt, st);
+                if (rc) return rc;
+            } else {
+                const int64_t total = batch * (n / 2);
+                hipLaunchKernelGGL(k_fwd1d_level<T>, dim3(wx_grid_for(total, 256)), dim3(256), 0, st, src, dst, n, n,
+                                   (int)n, (int)(n >> d), d, batch, filt, (const uint8_t *)nullptr, (int64_t)0);
+            }
             src = dst;
         }
         WX_HIP_CHECK(hipGetLastError());
@@ -1443,7 +1457,7 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
                     if (wx_fused1d_ok<T>(nd, filt.F))
                         rc = launch_inv_fused<T>(src2, dst, nd, 1, batch << d, nd, nd, filt, nullptr, 0, nullptr, 0, st);
                     else
-                        rc = launch_level1_tile<T, true>(src2, dst, nd, batch << d, filt, st);
+                        rc = launch_level1_tile<T, true>(src2, dst, nd, (int64_t)1 << d, batch, n, n, filt, st);
                     if (rc) return rc;
                     src2 = dst;
                 }
@@ -1474,9 +1488,14 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
         const T *src2 = fbuf;
         for (int d = d0 - 1; d >= 0; --d) {
             T *dst = (d & 1) ? scratch : xh;
-            const int64_t total = batch * (n / 2);
-            hipLaunchKernelGGL(k_inv1d_level<T>, dim3(wx_grid_for(total, 256)), dim3(256), 0, st, src2, dst, n, n, (int)n,
-                               (int)(n >> d), d, batch, filt, (const uint8_t *)nullptr, (int64_t)0);
+            if ((n >> d) >= 4 * WX_LT) {
+                const int rc = launch_level1_tile<T, true>(src2, dst, n >> d, (int64_t)1 << d, batch, n, n, filt, st);
+                if (rc) return rc;
+            } else {
+                const int64_t total = batch * (n / 2);
+                hipLaunchKernelGGL(k_inv1d_level<T>, dim3(wx_grid_for(total, 256)), dim3(256), 0, st, src2, dst, n, n, (int)n,
+                                   (int)(n >> d), d, batch, filt, (const uint8_t *)nullptr, (int64_t)0);
+            }
             src2 = dst;
         }
         WX_HIP_CHECK(hipGetLastError());
