@@ -44,6 +44,16 @@ WORKLOADS = {
                    kernel="k_lat_wpt_f64<4, 3>", inv_kernel="k_lat_iwpt_f64<4, 2>",
                    fwd_kernels=[("k_lat_wpt_f64<4, 3>", 1)],
                    desc="north-star target: wptall+iwptall 65536x4096 f64 db4 L=10"),
+    "target_n2048": dict(kind="wpt", n=2048, batch=131072, wavelet="db4", L=10, dtype="f64",
+                         kernel="k_lat_wpt_sh_f64<4, 2, 1>", inv_kernel="k_lat_iwpt_sh_f64<4, 2, 1>",
+                         fwd_kernels=[("k_lat_wpt_sh_f64<4, 2, 1>", 1)],
+                         desc="the target's byte count with 2048-sample signals: wptall+iwptall 131072x2048 f64 db4 L=10 "
+                              "(two signals interleaved per wavefront, DESIGN 4.20)"),
+    "target_n1024": dict(kind="wpt", n=1024, batch=262144, wavelet="db4", L=9, dtype="f64",
+                         kernel="k_lat_wpt_sh_f64<4, 2, 2>", inv_kernel="k_lat_iwpt_sh_f64<4, 2, 2>",
+                         fwd_kernels=[("k_lat_wpt_sh_f64<4, 2, 2>", 1)],
+                         desc="the target's byte count with 1024-sample signals: wptall+iwptall 262144x1024 f64 db4 L=9 "
+                              "(four signals interleaved per wavefront, DESIGN 4.20)"),
     "target_haar": dict(kind="wpt", n=4096, batch=65536, wavelet="haar", L=10, dtype="f64",
                         kernel="k_haar_wpt_f64<256>",
                         fwd_kernels=[("k_haar_wpt_f64<256>", 1)],

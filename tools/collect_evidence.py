@@ -15,8 +15,9 @@ import summarize_prof  # noqa: E402
 
 
 def main(tag, prefix):
-    traffic = {}
-    for w in ("cfg2", "target", "target_haar", "cfg3", "cfg4", "cfg5", "bb", "ldb", "siwt"):
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}      # workloads not in this run keep their entries
+    for w in ("cfg2", "target", "target_n2048", "target_n1024", "target_haar", "cfg3", "cfg4", "cfg5", "bb", "ldb", "siwt"):
         src = os.path.join(ROOT, "gpurun_out", "prof_" + tag, w)
         if os.path.isdir(src):
             dst = os.path.join(ROOT, "profiles", "%s_%s" % (prefix, w))
@@ -31,7 +32,7 @@ def main(tag, prefix):
             line = open(b).read().strip().splitlines()[-1]
             json.loads(line)
             open(os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (prefix, w)), "w").write(line + "\n")
-    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    json.dump(traffic, open(tpath, "w"), indent=1)
     log = os.path.join(ROOT, "gpurun_out", "pytest_gpu_%s.log" % tag)
     if os.path.exists(log):
         shutil.copy(log, os.path.join(ROOT, "profiles", "%s_pytest_gpu.log" % prefix))
