@@ -313,8 +313,8 @@ def test_fuzz_register_kernels(wx, oracle):
         tab = _stack(oracle.wpd, x, wt.qmf, L)
         assert relerr(wx.to_numpy(wx.wpdall(_put(wx, x, dev), wt, L)), tab) <= 1e-11, (wt.name if hasattr(wt, "name") else "", L, B)
         assert relerr(wx.to_numpy(wx.iwpdall(_put(wx, tab, dev), wt, L)), x) <= 1e-11
-        ns = int(rng.choice([1024, 2048]))                             # interleaved short signals
-        xs = np.asfortranarray(rng.standard_normal((ns, B)))
+        ns = int(rng.choice([64, 128, 256, 512, 1024, 2048]))          # interleaved short signals
+        xs = np.asfortranarray(rng.standard_normal((ns, B + int(rng.integers(0, 70)))))
         Ls = int(rng.integers(1, int(np.log2(ns)) + 1))
         es = _stack(oracle.wpt, xs, wt.qmf, Ls)
         assert relerr(wx.to_numpy(wx.wptall(_put(wx, xs, dev), wt, Ls)), es) <= 1e-11, (ns, Ls, B)

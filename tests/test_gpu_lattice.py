@@ -207,3 +207,29 @@ def test_long_signals_top_levels_then_lattice(wx, oracle, n):
             exp = oracle.wptall(x, wt.qmf, L)
             assert relerr(wx.wptall(x, wt, L), exp) <= 1e-12, (n, wname, L)
             assert relerr(wx.iwptall(exp, wt, L), x) <= 1e-12, (n, wname, L)
+
+
+@pytest.mark.parametrize("n", [512, 256, 128, 64])
+def test_short_signals_8_to_64_per_wavefront(wx, oracle, n):
+    """512 .. 64 samples: 8 .. 64 signals interleaved in one wavefront (k_lat_wpt_g_f64 / k_lat_iwpt_g_f64 / k_lat_wpd_g_f64,
+    filters of 4, 6, 8 taps), every depth, batches around the signals-per-wavefront count (tail wavefront), a longer filter
+    that keeps the LDS kernels, device pointers"""
+    rng = np.random.default_rng(n)
+    per = 4096 // n
+    for wname in ("db2", "db3", "db4", "db8"):
+        wt = _wt(wx, wname)
+        for B in (1, per - 1, per, per + 1, 2 * per + 3):
+            x = np.asfortranarray(rng.standard_normal((n, B)))
+            for L in range(1, int(np.log2(n)) + 1):
+                exp = oracle.wptall(x, wt.qmf, L)
+                assert relerr(wx.wptall(x, wt, L), exp) <= 1e-12, (n, wname, B, L)
+                assert relerr(wx.iwptall(exp, wt, L), x) <= 1e-12, (n, wname, B, L)
+                tab = np.asfortranarray(np.stack([oracle.wpd(x[:, b], wt.qmf, L) for b in range(B)], axis=-1))
+                assert relerr(wx.wpdall(x, wt, L), tab) <= 1e-12, (n, wname, B, L)
+                assert relerr(wx.iwpdall(tab, wt, L), x) <= 1e-12, (n, wname, B, L)
+    wt = _wt(wx, "db4")
+    xd = wx.to_device(np.asfortranarray(rng.standard_normal((n, 3 * per + 1))))
+    L = int(np.log2(n))
+    yd = wx.wptall(xd, wt, L)
+    assert relerr(yd.cpu().numpy(), oracle.wptall(xd.cpu().numpy(), wt.qmf, L)) <= 1e-12
+    assert relerr(wx.iwptall(yd, wt, L).cpu().numpy(), xd.cpu().numpy()) <= 1e-12

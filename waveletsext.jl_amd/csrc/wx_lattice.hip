@@ -107,6 +107,9 @@ bool wx_lattice_coeffs(const WxFilt &filt, int L, bool inverse, double *p, doubl
 // 0 = not applicable (the caller takes the general kernels), 1 = launched, < 0 = HIP error code of the C ABI
 int wx_lattice_launch_sh(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                          const WxFilt &filt, hipStream_t st);          // wx_lattice_sh.hip
+int wx_lattice_launch_g(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
+                        const WxFilt &filt, hipStream_t st);           // wx_lattice_sg.hip
+int wx_lattice_wpd_g_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);   // wx_lattice_sgw.hip
 
 static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                              const WxFilt &filt, hipStream_t st)
@@ -115,6 +118,8 @@ static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n
     static const bool off_sh = getenv("WX_LATTICE_SH") && atoi(getenv("WX_LATTICE_SH")) == 0;
     if (!off && !off_sh && (n == 2048 || n == 1024))
         return wx_lattice_launch_sh(inverse, x, y, n, L, batch, inverse ? in_stride : n, filt, st);
+    if (!off && !off_sh && n >= 64 && n <= 512)
+        return wx_lattice_launch_g(inverse, x, y, n, L, batch, inverse ? in_stride : n, filt, st);
     if (off || n != 4096 || L < 6 || L > 12 || filt.F < 4 || batch <= 0) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     if (inverse && (in_stride & 3)) return 0;
@@ -157,6 +162,7 @@ int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t bat
                             (getenv("WX_LATTICE_WPD") && atoi(getenv("WX_LATTICE_WPD")) == 0);
     static const bool off_sh = getenv("WX_LATTICE_SH") && atoi(getenv("WX_LATTICE_SH")) == 0;
     if (!off && !off_sh && (n == 2048 || n == 1024) && x != (const double *)y) return wx_lattice_wpd_sh_f64(x, y, n, L, batch, filt, st);
+    if (!off && !off_sh && n >= 64 && n <= 512 && x != (const double *)y) return wx_lattice_wpd_g_f64(x, y, n, L, batch, filt, st);
     if (off || n != 4096 || L < 1 || L > 12 || filt.F < 4 || batch <= 0 || batch > 0x7fffffff) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     WxLatW cw;

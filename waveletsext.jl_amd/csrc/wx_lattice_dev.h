@@ -1223,6 +1223,213 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw);
 }
 
+// ---------------------------------------------------------------- short signals, general form: 2^SH signals per wavefront
+// SH = 3 .. 6 (512, 256, 128, 64 samples; the same code is valid for SH = 1, 2).  Both ends are the bit routing of
+// lat_absorb / lat_emit (complete lines), and the data enters in the first layout that has a level to run: bits 0, 1 live
+// in layout A, bits 2..5 in B, bits 6..11 in C, so for SH >= 2 the exchange A -> B disappears and for SH = 6 (64 signals of
+// 64 samples) the whole transform happens in layout C between one absorb and one emit.
+template <int SH> constexpr int lat_lay0() { return SH < 2 ? 0 : (SH < 6 ? 2 : 6); }
+
+// T3i: C -> B and T2i: B -> A (the exchanges of k_lat_iwpt_f64)
+__device__ __forceinline__ void lat_t3i(double (&c)[64], double (&bb)[64], unsigned lds0, int lane)
+{
+    const unsigned wa = lds0 + 8u * (34 * (lane >> 1) + (lane & 1));
+    const int H = lane & 15, p0 = (lane >> 4) & 1, p1 = lane >> 5;
+    const unsigned ra = lds0 + 8u * (34 * p1 + 2 * H + p0);
+    lat_for<4>([&](auto Fq) {
+        constexpr int f = Fq;
+        lat_for<16>([&](auto Hq) {
+            constexpr int Hh = Hq;
+            lds_wr<8 * 2 * Hh>(wa, c[4 * Hh + f]);
+        });
+        double t[16];
+        lat_for<16>([&](auto Jq) {
+            constexpr int j = Jq;
+            t[j] = lds_rd<8 * 68 * j>(ra);
+        });
+        lat_wait16<0>(t);
+        lat_for<16>([&](auto Jq) {
+            constexpr int j = Jq;
+            bb[16 * f + j] = t[j];
+        });
+    });
+}
+__device__ __forceinline__ void lat_t2i(double (&bb)[64], double (&a)[64], unsigned lds0, int lane)
+{
+    const int H = lane & 15, p10 = lane >> 4;
+    unsigned wa[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+        wa[h] = lds0 + 8u * (((h ^ (H >> 2)) | ((H & 3) << 2) | (((H >> 2) & 1) << 4) | ((H >> 3) << 5)) + 64 * p10);
+    const int Ha = lane >> 2, ha = lane & 3;
+    const unsigned ra = lds0 + 8u * ((ha ^ (Ha >> 2)) | ((Ha & 3) << 2) | (((Ha >> 2) & 1) << 4) | ((Ha >> 3) << 5));
+    lat_for<4>([&](auto Fq) {
+        constexpr int f = Fq;
+        lat_for<16>([&](auto Q) {
+            constexpr int h = Q / 4, g = Q % 4;
+            lds_wr<8 * 256 * g>(wa[h], bb[16 * h + 4 * f + g]);
+        });
+        double t[16];
+        lat_for<16>([&](auto Jq) {
+            constexpr int j = Jq;
+            t[j] = lds_rd<8 * 64 * j>(ra);
+        });
+        lat_wait16<0>(t);
+        lat_for<16>([&](auto Jq) {
+            constexpr int j = Jq;
+            a[16 * f + j] = t[j];
+        });
+    });
+}
+
+// forward wpt, leaves only: Le = L + SH in 6 .. 12 (the last level runs in layout C)
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_g_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw)
+{
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const int64_t off = (int64_t)sig0 * (4096 >> SH);
+    const double *xs = x + off;
+    double *ys = y + off;
+    const WxLat &cf = cw.c;
+    double c[64];
+    if constexpr (SH < 2) {
+        double a[64], bb[64];
+        lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw);
+        if constexpr (SH < 1) lat_level<0, 6, NS, false>(a, cf);
+        lat_level<1, 6, NS, false>(a, cf);
+        lat_t2(a, bb, lds0, lane);
+        lat_level<0, 4, NS, false>(bb, cf);
+        lat_level<1, 4, NS, false>(bb, cf);
+        lat_level<2, 4, NS, false>(bb, cf);
+        lat_level<3, 4, NS, false>(bb, cf);
+        lat_t3(bb, c, lds0, lane);
+    } else if constexpr (SH < 6) {
+        double bb[64];
+        lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw);
+        if constexpr (SH <= 2) lat_level<0, 4, NS, false>(bb, cf);
+        if constexpr (SH <= 3) lat_level<1, 4, NS, false>(bb, cf);
+        if constexpr (SH <= 4) lat_level<2, 4, NS, false>(bb, cf);
+        lat_level<3, 4, NS, false>(bb, cf);
+        lat_t3(bb, c, lds0, lane);
+    } else {
+        lat_absorb<6, 16 * SH>(c, lds0, xs, lane, cw);
+    }
+    const int Le = L + SH;
+    if (Le > 6) lat_level<0, 0, NS, false>(c, cf);
+    if (Le > 7) lat_level<1, 0, NS, false>(c, cf);
+    if (Le > 8) lat_level<2, 0, NS, false>(c, cf);
+    if (Le > 9) lat_level<3, 0, NS, false>(c, cf);
+    if (Le > 10) lat_level<4, 0, NS, false>(c, cf);
+    if (Le > 11) lat_level<5, 0, NS, false>(c, cf);
+    switch (Le) {
+    case 6: if constexpr (SH < 6) lat_emit<6, 6 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 7: lat_emit<6, 7 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 8: lat_emit<6, 8 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 9: lat_emit<6, 9 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 10: lat_emit<6, 10 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 11: lat_emit<6, 11 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    default: lat_emit<6, 12 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    }
+}
+
+// inverse wpt: leaves of signal s at xw + s in_stride (dense array or the last column of packet tables)
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_g_f64(
+    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, WxLatW cw)
+{
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const double *xs = xw + (int64_t)sig0 * in_stride;
+    double *ys = y + (int64_t)sig0 * (4096 >> SH);
+    const WxLat &cf = cw.c;
+    const int Le = L + SH;
+    double c[64];
+    switch (Le) {
+    case 6: if constexpr (SH < 6) lat_absorb<6, 6 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    case 7: lat_absorb<6, 7 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    case 8: lat_absorb<6, 8 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    case 9: lat_absorb<6, 9 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    case 10: lat_absorb<6, 10 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    case 11: lat_absorb<6, 11 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    default: lat_absorb<6, 12 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    }
+    if (Le > 11) lat_level<5, 0, NS, true>(c, cf);
+    if (Le > 10) lat_level<4, 0, NS, true>(c, cf);
+    if (Le > 9) lat_level<3, 0, NS, true>(c, cf);
+    if (Le > 8) lat_level<2, 0, NS, true>(c, cf);
+    if (Le > 7) lat_level<1, 0, NS, true>(c, cf);
+    if (Le > 6) lat_level<0, 0, NS, true>(c, cf);
+    if constexpr (SH >= 6) {
+        lat_emit<6, 16 * SH>(c, lds0, ys, lane, cw);
+    } else {
+        double bb[64];
+        lat_t3i(c, bb, lds0, lane);
+        lat_level<3, 4, NS, true>(bb, cf);
+        if constexpr (SH <= 4) lat_level<2, 4, NS, true>(bb, cf);
+        if constexpr (SH <= 3) lat_level<1, 4, NS, true>(bb, cf);
+        if constexpr (SH <= 2) lat_level<0, 4, NS, true>(bb, cf);
+        if constexpr (SH >= 2) {
+            lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw);
+        } else {
+            double a[64];
+            lat_t2i(bb, a, lds0, lane);
+            lat_level<1, 6, NS, true>(a, cf);
+            if constexpr (SH < 1) lat_level<0, 6, NS, true>(a, cf);
+            lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw);
+        }
+    }
+}
+
+// wpd: y is (n, L+1, batch), every level leaves through lat_emit into the table of its signal (L >= 1, L + SH <= 12)
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpd_g_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw)
+{
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    constexpr int N = 4096 >> SH;
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const double *xs = x + (int64_t)sig0 * N;
+    const unsigned ts = (unsigned)(N * (L + 1));
+    double *ys = y + (int64_t)sig0 * ts;
+    const WxLat &cf = cw.c;
+#define WX_LVL(LAY, KK, HH, REG, BIT)                                                           \
+    if constexpr (BIT >= SH) {                                                                  \
+        constexpr int l = BIT - SH + 1;                                                         \
+        lat_level<KK, HH, NS, false>(REG, cf);                                                  \
+        lat_emit<LAY, l + 16 * SH>(REG, lds0, ys + N * l, lane, cw, ts);                        \
+        if (L <= l) return;                                                                     \
+    }
+    double c[64];
+    if constexpr (SH < 2) {
+        double a[64], bb[64];
+        lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw);
+        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw, ts);                   // column 0 = the signal
+        WX_LVL(0, 0, 6, a, 0) WX_LVL(0, 1, 6, a, 1)
+        lat_t2(a, bb, lds0, lane);
+        WX_LVL(2, 0, 4, bb, 2) WX_LVL(2, 1, 4, bb, 3) WX_LVL(2, 2, 4, bb, 4) WX_LVL(2, 3, 4, bb, 5)
+        lat_t3(bb, c, lds0, lane);
+    } else if constexpr (SH < 6) {
+        double bb[64];
+        lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw);
+        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw, ts);
+        WX_LVL(2, 0, 4, bb, 2) WX_LVL(2, 1, 4, bb, 3) WX_LVL(2, 2, 4, bb, 4) WX_LVL(2, 3, 4, bb, 5)
+        lat_t3(bb, c, lds0, lane);
+    } else {
+        lat_absorb<6, 16 * SH>(c, lds0, xs, lane, cw);
+        lat_emit<6, 16 * SH>(c, lds0, ys, lane, cw, ts);
+    }
+    WX_LVL(6, 0, 0, c, 6) WX_LVL(6, 1, 0, c, 7) WX_LVL(6, 2, 0, c, 8) WX_LVL(6, 3, 0, c, 9) WX_LVL(6, 4, 0, c, 10) WX_LVL(6, 5, 0, c, 11)
+#undef WX_LVL
+}
+
 }  // namespace
 
 bool wx_lattice_factor(const WxFilt &filt, int L, bool inverse, WxLat *out);      // wx_lattice.hip
