@@ -233,3 +233,19 @@ def test_short_signals_8_to_64_per_wavefront(wx, oracle, n):
     yd = wx.wptall(xd, wt, L)
     assert relerr(yd.cpu().numpy(), oracle.wptall(xd.cpu().numpy(), wt.qmf, L)) <= 1e-12
     assert relerr(wx.iwptall(yd, wt, L).cpu().numpy(), xd.cpu().numpy()) <= 1e-12
+
+
+def test_float32_signals_through_the_lattice(wx, oracle):
+    """Float32 signals of 4096 samples: Float32 in memory, Float64 in the registers (wx_lattice_f32.hip): the Float64 transform
+    rounded once; tolerance of the Float32 path 1e-5, observed < 1e-6"""
+    rng = np.random.default_rng(32)
+    for wname in ("db2", "db4", "db7", "coif6"):
+        wt = _wt(wx, wname)
+        x = np.asfortranarray(rng.standard_normal((4096, 3)).astype(np.float32))
+        for L in (5, 6, 9, 12):
+            exp = oracle.wptall(x.astype(np.float64), wt.qmf, L)
+            got = wx.wptall(x, wt, L)
+            assert got.dtype == np.float32 and relerr(got.astype(np.float64), exp) <= 1e-6, (wname, L)
+            assert relerr(wx.iwptall(exp.astype(np.float32), wt, L).astype(np.float64), x.astype(np.float64)) <= 1e-6
+            tab = np.stack([oracle.wpd(x[:, b].astype(np.float64), wt.qmf, L) for b in range(3)], axis=-1)
+            assert relerr(wx.iwpdall(np.asfortranarray(tab.astype(np.float32)), wt, L).astype(np.float64), x.astype(np.float64)) <= 1e-6

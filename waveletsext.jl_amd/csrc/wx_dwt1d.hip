@@ -1342,6 +1342,13 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
             if (r) return r < 0 ? r : WX_OK;
         }
     }
+    if constexpr (sizeof(T) == 4) {
+        // Float32 signals of 4096 samples, full tree: the lattice kernels with Float32 at the two ends (wx_lattice_f32.hip)
+        if (!force_generic && !noreg && !status) {
+            const int r = wx_lattice_f32(false, (const float *)x, (float *)y, n, L, batch, n, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
+    }
     if constexpr (sizeof(T) == 8) {
         // Longer signals, full tree: after d0 = log2(n / 4096) levels every node is an independent 4096-sample signal --
         // contiguous, (4096, batch << d0) in Julia layout -- which the lattice kernels finish at their own rate.  The top
@@ -1435,6 +1442,12 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
         }
         if (!force_generic && !noreg && !status && !colmap) {
             const int r = wx_lattice_iwpt_f64((const double *)xw, (double *)xh, n, L, batch, is, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (!force_generic && !noreg && !status && !colmap) {
+            const int r = wx_lattice_f32(true, (const float *)xw, (float *)xh, n, L, batch, is, filt, st);
             if (r) return r < 0 ? r : WX_OK;
         }
     }

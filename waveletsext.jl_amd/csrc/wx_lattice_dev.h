@@ -89,6 +89,28 @@ __device__ __forceinline__ void lat_st2(double __attribute__((address_space(1)))
     *(P)p = v;
 #endif
 }
+// Float32 signals in memory, Float64 in the registers (k_lat_wpt_f64<.., float> / k_lat_iwpt_f64<.., float>): the same
+// element offsets, 8 bytes per lane instead of 16
+typedef float lat_f2 __attribute__((ext_vector_type(2)));
+typedef const float __attribute__((address_space(1))) *lat_gcf;
+typedef float __attribute__((address_space(1))) *lat_gmf;
+__device__ __forceinline__ lat_d2 lat_ld2(const float __attribute__((address_space(1))) *p)
+{
+    typedef const lat_f2 __attribute__((address_space(1))) *P;
+    const lat_f2 v = *(P)p;
+    lat_d2 r;
+    r.x = (double)v.x;
+    r.y = (double)v.y;
+    return r;
+}
+__device__ __forceinline__ void lat_st2(float __attribute__((address_space(1))) *p, lat_d2 v)
+{
+    typedef lat_f2 __attribute__((address_space(1))) *P;
+    lat_f2 o;
+    o.x = (float)v.x;
+    o.y = (float)v.y;
+    *(P)p = o;
+}
 // stores of the wpd kernel (28 of the 30 GiB it moves): WX_LAT_WPD_NT selects the hint separately
 #ifndef WX_LAT_WPD_NT
 #define WX_LAT_WPD_NT 0     // measured on config 2 (same box): plain stores 5.95 ms, non-temporal 6.20 ms
@@ -111,6 +133,18 @@ __device__ __forceinline__ lat_gc lat_sbase(const double *p)
 __device__ __forceinline__ lat_gm lat_sbase(double *p)
 {
     lat_gm g = (lat_gm)p;
+    asm("" : "+s"(g));
+    return g;
+}
+__device__ __forceinline__ lat_gcf lat_sbase(const float *p)
+{
+    lat_gcf g = (lat_gcf)p;
+    asm("" : "+s"(g));
+    return g;
+}
+__device__ __forceinline__ lat_gmf lat_sbase(float *p)
+{
+    lat_gmf g = (lat_gmf)p;
     asm("" : "+s"(g));
     return g;
 }
@@ -278,7 +312,7 @@ constexpr int lat_pc(int v)
 }
 
 // C -> S exchange + stores for a compile-time depth (exchange T4 of tools/lattice_lds_maps.py)
-template <int L> __device__ __forceinline__ void lat_store_c(double (&c)[64], unsigned lds0, double *__restrict__ ys,
+template <int L, typename TM> __device__ __forceinline__ void lat_store_c(double (&c)[64], unsigned lds0, TM *__restrict__ ys,
                                                              int lane, const WxLat &cf)
 {
     double gf[7];
@@ -319,7 +353,7 @@ template <int L> __device__ __forceinline__ void lat_store_c(double (&c)[64], un
 }
 
 // loads + S -> C exchange (T4i)
-template <int L> __device__ __forceinline__ void lat_load_c(double (&c)[64], unsigned lds0, const double *__restrict__ xs,
+template <int L, typename TM> __device__ __forceinline__ void lat_load_c(double (&c)[64], unsigned lds0, const TM *__restrict__ xs,
                                                             int lane, const WxLat &cf)
 {
     double gf[7];
@@ -367,15 +401,15 @@ template <int L> __device__ __forceinline__ void lat_load_c(double (&c)[64], uns
 }
 
 // ---------------------------------------------------------------- forward
-template <int NS, int WPE>
+template <int NS, int WPE, typename TM = double>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_f64(
-    const double *__restrict__ x, double *__restrict__ y, int L, int64_t batch, WxLat cf)
+    const TM *__restrict__ x, TM *__restrict__ y, int L, int64_t batch, WxLat cf)
 {
     __shared__ double lds[WX_LAT_LDS];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
     const int64_t sig = blockIdx.x;
-    const double *xs = x + sig * 4096;
+    const TM *xs = x + sig * 4096;
     double a[64];
     {
         // L0: instruction (hi3 = p[11:9], f = p[5:4]) loads eight complete 128-byte lines: lane holds p[8:6] = lane >> 3,
@@ -469,7 +503,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (L > 9) lat_level<3, 0, NS, false>(c, cf);
     if (L > 10) lat_level<4, 0, NS, false>(c, cf);
     if (L > 11) lat_level<5, 0, NS, false>(c, cf);
-    double *ys = y + sig * 4096;
+    TM *ys = y + sig * 4096;
     switch (L) {
     case 6: lat_store_c<6>(c, lds0, ys, lane, cf); break;
     case 7: lat_store_c<7>(c, lds0, ys, lane, cf); break;
@@ -939,15 +973,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 }
 
 // ---------------------------------------------------------------- inverse
-template <int NS, int WPE>
+template <int NS, int WPE, typename TM = double>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_f64(
-    const double *__restrict__ xw, double *__restrict__ y, int L, int64_t batch, int64_t in_stride, WxLat cf)
+    const TM *__restrict__ xw, TM *__restrict__ y, int L, int64_t batch, int64_t in_stride, WxLat cf)
 {
     __shared__ double lds[WX_LAT_LDS];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
     const int64_t sig = blockIdx.x;
-    const double *xs = xw + sig * in_stride;
+    const TM *xs = xw + sig * in_stride;
     double c[64];
     switch (L) {
     case 6: lat_load_c<6>(c, lds0, xs, lane, cf); break;
@@ -1026,7 +1060,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     {
         const unsigned wa = lds0 + 8u * 17u * lane, ra = lds0 + 8u * (17u * (lane >> 3) + 4u * (lane & 7));
         const unsigned yo = 64u * (lane >> 3) + 2u * (lane & 7);
-        double *ys = y + sig * 4096;
+        TM *ys = y + sig * 4096;
         lat_for<4>([&](auto Fq) {
             constexpr int f = Fq;
             lat_for<16>([&](auto M) {

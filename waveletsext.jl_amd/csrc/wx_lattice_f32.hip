@@ -1,0 +1,34 @@
+// wx_lattice_f32.hip -- Float32 signals of 4096 samples through the lattice kernels: Float32 in memory, Float64 in the
+// registers (k_lat_wpt_f64<NS, WPE, float>, k_lat_iwpt_f64<NS, WPE, float> of wx_lattice_dev.h: the same element offsets with
+// 8 bytes per lane, conversions at the two ends).  Half the bytes of the Float64 transform at the same arithmetic: the
+// kernels are bound by FP64 issue and LDS here, not by HBM.  The result is the Float64 transform rounded once to Float32
+// (the reference computes in Float32 throughout: the difference is inside the 1e-5 tolerance of the Float32 path).
+#include "wx_lattice_dev.h"
+
+// 0 = not applicable, 1 = launched, < 0 = error
+int wx_lattice_f32(bool inverse, const float *x, float *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt,
+                   hipStream_t st)
+{
+    static const bool off = (getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0) ||
+                            (getenv("WX_LATTICE_F32") && atoi(getenv("WX_LATTICE_F32")) == 0);
+    if (off || n != 4096 || L < 6 || L > 12 || filt.F < 4 || batch <= 0 || batch > 0x7fffffff) return 0;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return 0;
+    if (inverse && (in_stride & 3)) return 0;
+    WxLat cf;
+    if (!wx_lattice_factor(filt, L, inverse, &cf)) return 0;
+#define WX_GOF(NSS)                                                                                                  \
+    case NSS:                                                                                                        \
+        if (inverse)                                                                                                 \
+            hipLaunchKernelGGL((k_lat_iwpt_f64<NSS, 2, float>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L, batch, in_stride, cf); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_lat_wpt_f64<NSS, 3, float>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L, batch, cf); \
+        break;
+    switch (filt.F / 2) {
+        WX_GOF(2) WX_GOF(3) WX_GOF(4) WX_GOF(5) WX_GOF(6) WX_GOF(7) WX_GOF(8) WX_GOF(9) WX_GOF(10)
+    default: return 0;
+    }
+#undef WX_GOF
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wx_set_hip_error(e, "lattice wpt launch (Float32 memory)", __FILE__, __LINE__);
+    return 1;
+}
