@@ -113,7 +113,7 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     T *s1 = nullptr;
     const bool fused = !force && wx_fused1d_ok<T>(n, F);
     // long Float64 signals with a full tree take one pass per top level and then the lattice kernels: one scratch array
-    const bool long_lattice = sizeof(T) == 8 && !force && !tr.dstatus && n > 4096 && n <= 65536 && tr.Leff > 1;
+    const bool long_lattice = !force && !tr.dstatus && n > 4096 && n <= 65536 && tr.Leff > 1;
     if (((!fused && tr.Leff > 1) || long_lattice) && batch) {
         s1 = (T *)scr.alloc(sizeof(T) * n * batch);
         if (!s1) return io.finish(WX_EHIP);

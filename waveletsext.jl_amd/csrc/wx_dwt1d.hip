@@ -1349,7 +1349,7 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
             if (r) return r < 0 ? r : WX_OK;
         }
     }
-    if constexpr (sizeof(T) == 8) {
+    {
         // Longer signals, full tree: after d0 = log2(n / 4096) levels every node is an independent 4096-sample signal --
         // contiguous, (4096, batch << d0) in Julia layout -- which the lattice kernels finish at their own rate.  The top
         // levels are one pass each (the fused LDS kernel with L = 1 while the node fits a CU, the per-level kernel above
@@ -1370,7 +1370,11 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
                 if (rc) return rc;
                 src = dst;
             }
-            const int r = wx_lattice_wpt_f64((const double *)scratch, (double *)y, 4096, L - dl, batch << dl, filt, st);
+            int r;
+            if constexpr (sizeof(T) == 8)
+                r = wx_lattice_wpt_f64((const double *)scratch, (double *)y, 4096, L - dl, batch << dl, filt, st);
+            else
+                r = wx_lattice_f32(false, (const float *)scratch, (float *)y, 4096, L - dl, batch << dl, 4096, filt, st);
             if (r < 0) return r;
             if (r == 1) return WX_OK;
             // not taken after all (alignment): the top levels are in scratch, finish with the fused kernel below
@@ -1451,7 +1455,7 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
             if (r) return r < 0 ? r : WX_OK;
         }
     }
-    if constexpr (sizeof(T) == 8) {
+    {
         // mirror of the long-signal path of wx_dev_wpt1d: the lattice inverse on the 4096-sample nodes of depth dl, then dl
         // synthesis levels of one pass each
         int dl = 0;
@@ -1459,7 +1463,11 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
         if (!force_generic && !noreg && !status && !colmap && is == n && scratch && dl >= 1 && dl <= 4 &&
             n == ((int64_t)4096 << dl) && L - dl >= 6 && xw != xh && wx_lattice_applicable_f64(filt)) {
             T *first = (dl & 1) ? scratch : xh;                        // as if depth dl were one more level of the ping-pong
-            const int r = wx_lattice_iwpt_f64((const double *)xw, (double *)first, 4096, L - dl, batch << dl, 4096, filt, st);
+            int r;
+            if constexpr (sizeof(T) == 8)
+                r = wx_lattice_iwpt_f64((const double *)xw, (double *)first, 4096, L - dl, batch << dl, 4096, filt, st);
+            else
+                r = wx_lattice_f32(true, (const float *)xw, (float *)first, 4096, L - dl, batch << dl, 4096, filt, st);
             if (r < 0) return r;
             if (r == 1) {
                 const T *src2 = first;
