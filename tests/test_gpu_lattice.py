@@ -216,7 +216,7 @@ def test_short_signals_8_to_64_per_wavefront(wx, oracle, n):
     that keeps the LDS kernels, device pointers"""
     rng = np.random.default_rng(n)
     per = 4096 // n
-    for wname in ("db2", "db3", "db4", "db8"):
+    for wname in ("haar", "db2", "db3", "db4", "db8"):
         wt = _wt(wx, wname)
         for B in (1, per - 1, per, per + 1, 2 * per + 3):
             x = np.asfortranarray(rng.standard_normal((n, B)))

@@ -10,7 +10,7 @@ int wx_lattice_launch_g(bool inverse, const double *x, double *y, int64_t n, int
     while (((int64_t)4096 >> SH) > n) ++SH;
     if (SH < 3 || SH > 6 || ((int64_t)4096 >> SH) != n) return 0;
     const int64_t per = (int64_t)1 << SH;
-    if (L < 1 || L + SH < 6 || L + SH > 12 || filt.F < 4 || filt.F > 8 || batch < per || batch > 0x7fffffff) return 0;
+    if (L < 1 || L + SH < 6 || L + SH > 12 || filt.F < 2 || filt.F > 8 || batch < per || batch > 0x7fffffff) return 0;
     if ((batch & (per - 1)) && x == y) return 0;             // the tail wavefront re-does signals: out of place only
     if (in_stride < n || in_stride * (per - 1) + 4096 > 0x7fffffff || (in_stride & 1)) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
@@ -29,6 +29,7 @@ int wx_lattice_launch_g(bool inverse, const double *x, double *y, int64_t n, int
         else                                                                                                         \
             hipLaunchKernelGGL((k_lat_wpt_g_f64<NSS, 2, SHH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
     }
+    WX_GOG(1, 3) WX_GOG(1, 4) WX_GOG(1, 5) WX_GOG(1, 6)
     WX_GOG(2, 3) WX_GOG(3, 3) WX_GOG(4, 3) WX_GOG(2, 4) WX_GOG(3, 4) WX_GOG(4, 4)
     WX_GOG(2, 5) WX_GOG(3, 5) WX_GOG(4, 5) WX_GOG(2, 6) WX_GOG(3, 6) WX_GOG(4, 6)
 #undef WX_GOG

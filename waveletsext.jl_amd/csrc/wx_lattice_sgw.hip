@@ -8,7 +8,7 @@ int wx_lattice_wpd_g_f64(const double *x, double *y, int64_t n, int L, int64_t b
     while (((int64_t)4096 >> SH) > n) ++SH;
     if (SH < 3 || SH > 6 || ((int64_t)4096 >> SH) != n) return 0;
     const int64_t per = (int64_t)1 << SH;
-    if (L < 1 || L + SH > 12 || filt.F < 4 || filt.F > 8 || batch < per || batch > 0x7fffffff) return 0;
+    if (L < 1 || L + SH > 12 || filt.F < 2 || filt.F > 8 || batch < per || batch > 0x7fffffff) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     if ((n * (L + 1)) * (per - 1) + 4096 > 0x7fffffff) return 0;
     if ((n * (L + 1)) & 1) return 0;
@@ -26,6 +26,7 @@ int wx_lattice_wpd_g_f64(const double *x, double *y, int64_t n, int L, int64_t b
 #define WX_GOGW(NSS, SHH)                                                                                            \
     if (filt.F / 2 == NSS && SH == SHH)                                                                              \
         hipLaunchKernelGGL((k_lat_wpd_g_f64<NSS, 2, SHH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw);
+    WX_GOGW(1, 3) WX_GOGW(1, 4) WX_GOGW(1, 5) WX_GOGW(1, 6)
     WX_GOGW(2, 3) WX_GOGW(3, 3) WX_GOGW(4, 3) WX_GOGW(2, 4) WX_GOGW(3, 4) WX_GOGW(4, 4)
     WX_GOGW(2, 5) WX_GOGW(3, 5) WX_GOGW(4, 5) WX_GOGW(2, 6) WX_GOGW(3, 6) WX_GOGW(4, 6)
 #undef WX_GOGW

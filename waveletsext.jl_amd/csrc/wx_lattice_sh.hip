@@ -8,7 +8,7 @@ int wx_lattice_launch_sh(bool inverse, const double *x, double *y, int64_t n, in
 {
     const int SH = n == 2048 ? 1 : 2;
     const int64_t per = (int64_t)1 << SH;
-    if (L + SH < 6 || L + SH > 12 || filt.F < 4 || batch < per) return 0;
+    if (L + SH < 6 || L + SH > 12 || filt.F < 2 || batch < per) return 0;
     if ((batch & (per - 1)) && x == y) return 0;             // the tail wavefront re-does signals: out of place only
     if (in_stride < n || in_stride * (per - 1) + 4096 > 0x7fffffff || (in_stride & 1)) return 0;
     const unsigned is32 = (unsigned)in_stride;
@@ -33,7 +33,7 @@ int wx_lattice_launch_sh(bool inverse, const double *x, double *y, int64_t n, in
             hipLaunchKernelGGL((k_lat_wpt_sh_f64<NSS, 2, 2>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
         break;
     switch (filt.F / 2) {
-        WX_GOS(2) WX_GOS(3) WX_GOS(4) WX_GOS(5) WX_GOS(6) WX_GOS(7) WX_GOS(8) WX_GOS(9) WX_GOS(10)
+        WX_GOS(1) WX_GOS(2) WX_GOS(3) WX_GOS(4) WX_GOS(5) WX_GOS(6) WX_GOS(7) WX_GOS(8) WX_GOS(9) WX_GOS(10)
     default: return 0;
     }
 #undef WX_GOS

@@ -7,7 +7,7 @@ int wx_lattice_wpd_sh_f64(const double *x, double *y, int64_t n, int L, int64_t 
 {
     const int SH = n == 2048 ? 1 : 2;
     const int64_t per = (int64_t)1 << SH;
-    if (L < 1 || L + SH > 12 || filt.F < 4 || batch < per || batch > 0x7fffffff) return 0;
+    if (L < 1 || L + SH > 12 || filt.F < 2 || batch < per || batch > 0x7fffffff) return 0;
     if (SH == 2 && L < 1) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     if ((n * (L + 1)) * (per - 1) + 4096 > 0x7fffffff) return 0;
@@ -30,7 +30,7 @@ int wx_lattice_wpd_sh_f64(const double *x, double *y, int64_t n, int L, int64_t 
             hipLaunchKernelGGL((k_lat_wpd_sh_f64<NSS, 2, 2>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
         break;
     switch (filt.F / 2) {
-        WX_GOSW(2) WX_GOSW(3) WX_GOSW(4) WX_GOSW(5) WX_GOSW(6) WX_GOSW(7) WX_GOSW(8) WX_GOSW(9) WX_GOSW(10)
+        WX_GOSW(1) WX_GOSW(2) WX_GOSW(3) WX_GOSW(4) WX_GOSW(5) WX_GOSW(6) WX_GOSW(7) WX_GOSW(8) WX_GOSW(9) WX_GOSW(10)
     default: return 0;
     }
 #undef WX_GOSW
