@@ -241,3 +241,25 @@ def test_jbb_identical_signals_give_zero_sigma(wx, oracle):
             s_, q_ = wx.acwpd_jbb_moments(x, wt)
             cf = wx.to_numpy(wx.costs_from_moments(s_, q_, B, wx.JBB(redundant=True)))
             assert np.isneginf(cf).all(), B
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db6", "coif6", "db10"])
+def test_deep_levels_of_swpt_and_acwpt_in_registers(wx, oracle, wname):
+    """swpt / acwpt of signals of 1024 samples and more: the levels from depth log2(n) - 4 on run lane-locally in registers
+    (csrc/wx_swtdeep.hip); depths with 0 .. 4 such levels, swt/swt_one_level.jl:99-127, acwt/acwt_one_level.jl"""
+    rng = np.random.default_rng(77)
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    for n in (1024, 2048):
+        x = np.asfortranarray(rng.standard_normal((n, 2)))
+        D0 = int(np.log2(n)) - 4
+        for L in (D0, D0 + 1, D0 + 2, D0 + 3, D0 + 4):
+            exp = np.stack([oracle.swpt(x[:, b], wt.qmf, L) for b in range(2)], axis=-1)
+            assert relerr(wx.swptall(x, wt, L), exp) <= 1e-12, (n, wname, L)
+            assert relerr(wx.iswptall(exp, wt), x) <= 1e-10, (n, wname, L)
+            expa = np.stack([oracle.acwpt(x[:, b], wt.qmf, L) for b in range(2)], axis=-1)
+            assert relerr(wx.acwptall(x, wt, L), expa) <= 1e-12, (n, wname, L)
+    # one signal through the single-signal entry points, device memory
+    xd = wx.to_device(np.asfortranarray(rng.standard_normal((1024, 3))))
+    got = wx.swptall(xd, wt, 10)
+    exp = np.stack([oracle.swpt(xd.cpu().numpy()[:, b], wt.qmf, 10) for b in range(3)], axis=-1)
+    assert relerr(got.cpu().numpy(), exp) <= 1e-12

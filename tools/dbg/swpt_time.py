@@ -1,0 +1,23 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+import torch
+import waveletsext_jl_amd as wx
+def t(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+for wname in ("haar", "db4", "coif6"):
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    for n, B, L in ((16384, 64, 12), (4096, 2048, 8), (1024, 8192, 8)):
+        x = wx.jl_empty((n, B), torch.float64, "cuda"); x.normal_()
+        gb = 8e-9 * n * B * (1 << L)
+        f = t(lambda: wx.swptall(x, wt, L))
+        y = wx.swptall(x, wt, L)
+        i = t(lambda: wx.iswptall(y, wt))
+        a = t(lambda: wx.acwptall(x, wt, L))
+        print("%-5s n %5d B %5d L %2d (%.1f GB leaves): swptall %.2f ms (%.0f %% HBM)  iswptall %.2f ms (%.0f %%)  acwptall %.2f ms (%.0f %%)" % (
+            wname, n, B, L, gb, f, 100 * gb / f / 8, i, 100 * gb / i / 8, a, 100 * gb / a / 8))
+        del x, y

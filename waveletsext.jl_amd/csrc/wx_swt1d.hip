@@ -693,7 +693,10 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
     int d = 0;
     // Haar, deep trees: the last six levels are one register pass (wx_haarswt.hip); the passes here stop at depth L - 6
     const bool haar6 = !ac && layout == WX_LAYOUT_WPT && !wx_force_generic_swt() && wx_haar_swpt6_ok(n, L, filt, sizeof(T));
-    const int dstop = haar6 ? L - 6 : L;
+    // any filter, deep trees: the levels from depth log2(n) - 4 on are a lane-local register pass (wx_swtdeep.hip)
+    const int deepLP = (!haar6 && layout == WX_LAYOUT_WPT && !wx_force_generic_swt())
+                           ? wx_swpt_deep_levels(n, L, ac ? ac->F : filt.F, ac != nullptr, sizeof(T)) : 0;
+    const int dstop = haar6 ? L - 6 : L - deepLP;
     while (d < dstop) {
         const int K = (KF > 1 && dstop - d >= 2) ? (dstop - d >= KF ? KF : dstop - d) : 1;
         int64_t gy = batch;
@@ -763,6 +766,11 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
     WX_HIP_CHECK(hipGetLastError());
     if constexpr (sizeof(T) == 8) {
         if (haar6) return wx_haar_swpt6_fwd((double *)xw, n, L, batch, filt, st);
+        if (deepLP) {
+            if (dstop == 0)                                              // the root column of the table is the signal
+                WX_HIP_CHECK(hipMemcpy2DAsync(xw, sizeof(T) * n * ncols, x, sizeof(T) * n, sizeof(T) * n, batch, hipMemcpyDeviceToDevice, st));
+            return wx_swpt_deep_fwd((double *)xw, n, L, batch, filt, ac, st);
+        }
     }
     return WX_OK;
 }

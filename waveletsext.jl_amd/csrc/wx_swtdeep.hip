@@ -1,0 +1,136 @@
+// wx_swtdeep.hip -- the last levels of the stationary / autocorrelation packet transforms (swpt, acwpt) for any filter, in
+// the registers of a lane.
+//
+// Reference (paths relative to /root/reference/src/mod): sdwt_step! swt/swt_one_level.jl:99-127 (a[i] = sum_j q[j] v[i + (j-1) s],
+// d[i] = sum_j (-1)^j q[j] v[i - j s], s = 2^d), acdwt_step! acwt/acwt_one_level.jl (w1 = v/sqrt2 + S, w2 = v/sqrt2 - S, S over the
+// odd lags), swpt! SWT.jl:439-472 / acwpt! ACWT.jl:427-460 (the (n, 2^L) table, children overwrite the parent column).
+//
+// From depth D0 = log2(n) - 4 on a level of dilation 2^d only moves inside a residue class mod 2^D0, and a class has
+// n' = 16 samples: the whole subtree below (node q of depth D0, class r) is a lane-local problem.  A wavefront takes 64
+// consecutive classes of one node -- every load and every store is one contiguous 512-byte run -- each lane reads its 16
+// samples once and walks the packet tree depth first: a node's two children are computed together (16 x 2 F multiply-adds with
+// compile-time register indices, the taps wrapping inside the 16 samples), the detail child waits in registers while the
+// approximation child's subtree is finished, leaves are stored as soon as they exist.  No LDS, no barrier; the level
+// kernels of wx_swt1d.hip, which read F taps per output from LDS and run one or two levels per pass over the table, stop
+// at depth D0 (1/16 of the final volume for a full-depth transform).  Same tap order and arithmetic as k_swt_fwd_level.
+#include "wx_common.h"
+#include "wx_kernels.h"
+#include "wx_host.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int SD_NP = 16;                                   // samples per residue class
+
+// children of one node at class-local dilation t = 2^J
+template <int F, bool AC, int J>
+__device__ __forceinline__ void sd_split(const double (&v)[SD_NP], double (&a)[SD_NP], double (&d)[SD_NP], const WxFilt &filt,
+                                         const WxAcFilt &ac)
+{
+    constexpr int t = 1 << J;
+#pragma unroll
+    for (int m = 0; m < SD_NP; ++m) {
+        if constexpr (!AC) {
+            double sa = 0.0, sd = 0.0;
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                sa = fma(filt.q[j], v[(m + (j - 1) * t) & (SD_NP - 1)], sa);
+                sd = fma((j & 1) ? -filt.q[j] : filt.q[j], v[(m - j * t) & (SD_NP - 1)], sd);
+            }
+            a[m] = sa;
+            d[m] = sd;
+        } else {
+            double S = 0.0;
+#pragma unroll
+            for (int l = 1; l < F; l += 2)
+                S = fma(ac.b[l - 1], v[(m - l * t) & (SD_NP - 1)] + v[(m + l * t) & (SD_NP - 1)], S);
+            const double c = ac.c1 * v[m];
+            a[m] = c + S;
+            d[m] = c - S;
+        }
+    }
+}
+
+template <int F, bool AC, int J, int LP>
+__device__ __forceinline__ void sd_node(const double (&v)[SD_NP], double *__restrict__ col, int64_t n, int64_t pstride, const WxFilt &filt,
+                                        const WxAcFilt &ac)
+{
+    double a[SD_NP], d[SD_NP];
+    sd_split<F, AC, J>(v, a, d, filt, ac);
+    double *hi = col + ((int64_t)(1 << (LP - J - 1))) * n;             // the detail child sits half the node's width further
+    if constexpr (J + 1 == LP) {
+#pragma unroll
+        for (int m = 0; m < SD_NP; ++m) col[m * pstride] = a[m];
+#pragma unroll
+        for (int m = 0; m < SD_NP; ++m) hi[m * pstride] = d[m];
+    } else {
+        sd_node<F, AC, J + 1, LP>(a, col, n, pstride, filt, ac);
+        sd_node<F, AC, J + 1, LP>(d, hi, n, pstride, filt, ac);
+    }
+}
+
+// xw: (n, 2^L, batch) wpt layout; node q of depth D0 = L - LP lives in column q 2^LP
+template <int F, bool AC, int LP>
+__global__ __launch_bounds__(64) void k_swpt_deep_fwd(double *__restrict__ xw, int log2n, int L, int64_t batch, WxFilt filt, WxAcFilt ac)
+{
+    const int D0 = log2n - 4;
+    const int64_t n = (int64_t)1 << log2n, pstride = (int64_t)1 << D0;
+    const int cblocks = 1 << (D0 - 6);                                   // blocks of 64 classes per node
+    const int q = blockIdx.x / cblocks, cb = blockIdx.x - q * cblocks;
+    const int r = cb * 64 + threadIdx.x;
+    for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
+        double *col = xw + (sig << L) * n + ((int64_t)q << LP) * n + r;
+        double v[SD_NP];
+#pragma unroll
+        for (int m = 0; m < SD_NP; ++m) v[m] = col[m * pstride];
+        sd_node<F, AC, 0, LP>(v, col, n, pstride, filt, ac);
+    }
+}
+
+typedef void (*sd_kern)(double *, int, int, int64_t, WxFilt, WxAcFilt);
+template <int F, bool AC> sd_kern sd_pick(int LP)
+{
+    switch (LP) {
+    case 1: return k_swpt_deep_fwd<F, AC, 1>;
+    case 2: return k_swpt_deep_fwd<F, AC, 2>;
+    case 3: return k_swpt_deep_fwd<F, AC, 3>;
+    default: return k_swpt_deep_fwd<F, AC, 4>;
+    }
+}
+
+}  // namespace
+
+// number of levels the lane-local kernel takes off the end of a depth-L swpt / acwpt of n-sample Float64 signals (0 = none)
+int wx_swpt_deep_levels(int64_t n, int L, int F, bool ac, size_t esz)
+{
+    static const bool off = getenv("WX_SWPT_DEEP") && atoi(getenv("WX_SWPT_DEEP")) == 0;
+    if (off || esz != 8 || n < 1024 || (n & (n - 1))) return 0;
+    switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 16: case 18: case 20: break; default: return 0; }
+    int log2n = 0;
+    while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
+    const int D0 = log2n - 4;
+    const int LP = L - D0;
+    return (LP >= 1 && LP <= 4) ? LP : 0;
+}
+
+int wx_swpt_deep_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt &filt, const WxAcFilt *ac, hipStream_t st)
+{
+    const bool isac = ac != nullptr;
+    const int F = isac ? ac->F : filt.F;
+    const int LP = wx_swpt_deep_levels(n, L, F, isac, 8);
+    if (!LP) return wx_set_error(WX_EHIP, "swpt deep levels: not applicable");
+    int log2n = 0;
+    while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
+    const int D0 = log2n - 4;
+    sd_kern k = nullptr;
+#define WX_SD(FF) case FF: k = isac ? sd_pick<FF, true>(LP) : sd_pick<FF, false>(LP); break;
+    switch (F) { WX_SD(2) WX_SD(4) WX_SD(6) WX_SD(8) WX_SD(10) WX_SD(12) WX_SD(16) WX_SD(18) WX_SD(20) }
+#undef WX_SD
+    WxAcFilt acz;
+    if (isac) acz = *ac; else { acz.F = 0; acz.c1 = 0; }
+    const int64_t gx = ((int64_t)1 << D0) * ((int64_t)1 << (D0 - 6));
+    int64_t gy = batch > 65535 ? 65535 : batch;
+    hipLaunchKernelGGL(k, dim3((unsigned)gx, (unsigned)gy), dim3(64), 0, st, xw, log2n, L, batch, filt, acz);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
