@@ -14,6 +14,8 @@ for n in (1024, 2048):
             expa = np.stack([O.acwpt(x[:, b], wt.qmf, L) for b in range(2)], axis=-1)
             gota = wx.acwptall(x, wt, L)
             e2 = np.abs(gota - expa).max() / np.abs(expa).max()
-            if e > 1e-12 or e2 > 1e-12:
-                print("FAIL", n, wname, L, e, e2)
+            back = wx.iswptall(exp, wt)
+            e3 = np.abs(back - x).max() / np.abs(x).max()
+            if e > 1e-12 or e2 > 1e-12 or e3 > 1e-11:
+                print("FAIL", n, wname, L, e, e2, e3)
 print("done")

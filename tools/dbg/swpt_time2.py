@@ -16,6 +16,8 @@ for wname in ("db2", "db4", "coif6"):
         gb = 8e-9 * n * B * (1 << L)
         f = t(lambda: wx.swptall(x, wt, L))
         a = t(lambda: wx.acwptall(x, wt, L))
-        print("%-5s n %5d B %5d L %2d (%.1f GB leaves): swptall %.2f ms (%.0f %% HBM)  acwptall %.2f ms (%.0f %%)" % (
-            wname, n, B, L, gb, f, 100 * gb / f / 8, a, 100 * gb / a / 8))
-        del x
+        y = wx.swptall(x, wt, L)
+        i = t(lambda: wx.iswptall(y, wt))
+        print("%-5s n %5d B %5d L %2d (%.1f GB leaves): swptall %.2f ms (%.0f %% HBM)  acwptall %.2f ms (%.0f %%)  iswptall %.2f ms (%.0f %%)" % (
+            wname, n, B, L, gb, f, 100 * gb / f / 8, a, 100 * gb / a / 8, i, 100 * gb / i / 8))
+        del x, y

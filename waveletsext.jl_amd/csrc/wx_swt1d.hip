@@ -800,6 +800,10 @@ void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz
     while (d > 0) {
         int K = 1, R = 0, OPT = 1;
         if (fuse && haar6 && d == L) { K = wx_haar_iswpt_levels(); R = 64; OPT = 0; }   // register pass of wx_haarswt.hip (OPT = 0 marks it)
+        if (K == 1 && d == L && layout == WX_LAYOUT_WPT && sm < 0 && !has_tree && !haar6 && !wx_force_generic_swt()) {
+            const int lp = wx_swpt_deep_levels(n, L, F, false, esz);   // lane-local pass of wx_swtdeep.hip (OPT = -1 marks it)
+            if (lp) { K = lp; R = 64; OPT = -1; }
+        }
         for (int Kt = (F <= 4 ? 3 : 2); fuse && Kt >= 2 && K == 1; --Kt) {
             if (d < Kt) continue;
             const int dp = d - Kt;
@@ -884,7 +888,15 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
         const int nodes_d = layout == WX_LAYOUT_DWT ? 1 : (1 << d);
         T *outp = plan.buf[i] < 0 ? x : bufs[plan.buf[i]];
         const int64_t out_cols = plan.buf[i] < 0 ? 1 : nodes_d;
-        if (K >= 5 && plan.OPT[i] == 0) {
+        if (plan.OPT[i] == -1) {
+            if constexpr (sizeof(T) == 8) {
+                const int rcd = wx_swpt_deep_inv((const double *)(prev ? prev : xw), prev ? prev_cols : ncols, (double *)outp, out_cols, n,
+                                                 plan.from[i], K, batch, filt, st);
+                if (rcd) return rcd;
+            } else {
+                return wx_set_error(WX_EHIP, "iswpt: the lane-local pass is Float64 only");
+            }
+        } else if (K >= 5 && plan.OPT[i] == 0) {
             if constexpr (sizeof(T) == 8) {
                 const T *srcp6 = prev ? prev : xw;
                 const int rc6 = wx_haar_iswpt6((const double *)srcp6, prev ? prev_cols : ncols, (double *)outp, out_cols, n,

@@ -87,6 +87,73 @@ __global__ __launch_bounds__(64) void k_swpt_deep_fwd(double *__restrict__ xw, i
     }
 }
 
+// ---- inverse (average-based iswpt): the mirror walk.  The average of the two shift variants of a stationary synthesis step
+// is the adjoint of the analysis step, parent[p] = 1/2 sum_j q[j] lo[p + (1 - j) s] + (-1)^j q[j] hi[p + j s]
+// (swt/swt_one_level.jl:257-318; wx_swt1d.hip uses the same identity for its fused passes)
+template <int F, int J>
+__device__ __forceinline__ void sd_merge(double (&out)[SD_NP], const double (&lo)[SD_NP], const double (&hi)[SD_NP], const WxFilt &filt)
+{
+    constexpr int t = 1 << J;
+#pragma unroll
+    for (int m = 0; m < SD_NP; ++m) {
+        double sa = 0.0, sd = 0.0;
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            sa = fma(filt.q[j], lo[(m + (1 - j) * t) & (SD_NP - 1)], sa);
+            sd = fma((j & 1) ? -filt.q[j] : filt.q[j], hi[(m + j * t) & (SD_NP - 1)], sd);
+        }
+        out[m] = (sa + sd) * 0.5;
+    }
+}
+
+template <int F, int J, int LP>
+__device__ __forceinline__ void sd_inode(double (&out)[SD_NP], const double *__restrict__ col, int64_t n, int64_t pstride, const WxFilt &filt)
+{
+    double lo[SD_NP], hi[SD_NP];
+    const double *hcol = col + ((int64_t)(1 << (LP - J - 1))) * n;
+    if constexpr (J + 1 == LP) {
+#pragma unroll
+        for (int m = 0; m < SD_NP; ++m) lo[m] = col[m * pstride];
+#pragma unroll
+        for (int m = 0; m < SD_NP; ++m) hi[m] = hcol[m * pstride];
+    } else {
+        sd_inode<F, J + 1, LP>(lo, col, n, pstride, filt);
+        sd_inode<F, J + 1, LP>(hi, hcol, n, pstride, filt);
+    }
+    sd_merge<F, J>(out, lo, hi, filt);
+}
+
+// src: (n, src_cols, batch) leaves in wpt order (leaf q 2^LP + j in that column); dst: (n, dst_cols, batch), node q -> column q
+template <int F, int LP>
+__global__ __launch_bounds__(64) void k_swpt_deep_inv(const double *__restrict__ src, int64_t src_cols, double *__restrict__ dst,
+                                                      int64_t dst_cols, int log2n, int64_t batch, WxFilt filt)
+{
+    const int D0 = log2n - 4;
+    const int64_t n = (int64_t)1 << log2n, pstride = (int64_t)1 << D0;
+    const int cblocks = 1 << (D0 - 6);
+    const int q = blockIdx.x / cblocks, cb = blockIdx.x - q * cblocks;
+    const int r = cb * 64 + threadIdx.x;
+    for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
+        const double *col = src + sig * src_cols * n + ((int64_t)q << LP) * n + r;
+        double out[SD_NP];
+        sd_inode<F, 0, LP>(out, col, n, pstride, filt);
+        double *o = dst + sig * dst_cols * n + (int64_t)q * n + r;
+#pragma unroll
+        for (int m = 0; m < SD_NP; ++m) o[m * pstride] = out[m];
+    }
+}
+
+typedef void (*sd_ikern)(const double *, int64_t, double *, int64_t, int, int64_t, WxFilt);
+template <int F> sd_ikern sd_ipick(int LP)
+{
+    switch (LP) {
+    case 1: return k_swpt_deep_inv<F, 1>;
+    case 2: return k_swpt_deep_inv<F, 2>;
+    case 3: return k_swpt_deep_inv<F, 3>;
+    default: return k_swpt_deep_inv<F, 4>;
+    }
+}
+
 typedef void (*sd_kern)(double *, int, int, int64_t, WxFilt, WxAcFilt);
 template <int F, bool AC> sd_kern sd_pick(int LP)
 {
@@ -131,6 +198,26 @@ int wx_swpt_deep_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt &
     const int64_t gx = ((int64_t)1 << D0) * ((int64_t)1 << (D0 - 6));
     int64_t gy = batch > 65535 ? 65535 : batch;
     hipLaunchKernelGGL(k, dim3((unsigned)gx, (unsigned)gy), dim3(64), 0, st, xw, log2n, L, batch, filt, acz);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
+// the deepest LP = L - (log2(n) - 4) levels of the average-based iswpt: leaves (n, src_cols) -> nodes of depth L - LP (n, dst_cols)
+int wx_swpt_deep_inv(const double *src, int64_t src_cols, double *dst, int64_t dst_cols, int64_t n, int L, int LP, int64_t batch,
+                     const WxFilt &filt, hipStream_t st)
+{
+    int log2n = 0;
+    while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
+    const int D0 = log2n - 4;
+    if (LP < 1 || LP > 4 || L - LP != D0) return wx_set_error(WX_EHIP, "iswpt deep levels: inconsistent plan");
+    sd_ikern k = nullptr;
+#define WX_SDI(FF) case FF: k = sd_ipick<FF>(LP); break;
+    switch (filt.F) { WX_SDI(2) WX_SDI(4) WX_SDI(6) WX_SDI(8) WX_SDI(10) WX_SDI(12) WX_SDI(16) WX_SDI(18) WX_SDI(20) default: break; }
+#undef WX_SDI
+    if (!k) return wx_set_error(WX_EHIP, "iswpt deep levels: no instantiation for this filter length");
+    const int64_t gx = ((int64_t)1 << D0) * ((int64_t)1 << (D0 - 6));
+    const int64_t gy = batch > 65535 ? 65535 : batch;
+    hipLaunchKernelGGL(k, dim3((unsigned)gx, (unsigned)gy), dim3(64), 0, st, src, src_cols, dst, dst_cols, log2n, batch, filt);
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
