@@ -263,3 +263,16 @@ def test_deep_levels_of_swpt_and_acwpt_in_registers(wx, oracle, wname):
     got = wx.swptall(xd, wt, 10)
     exp = np.stack([oracle.swpt(xd.cpu().numpy()[:, b], wt.qmf, 10) for b in range(3)], axis=-1)
     assert relerr(got.cpu().numpy(), exp) <= 1e-12
+
+
+def test_deep_levels_of_swpd_and_acwpd_tables(wx, oracle):
+    """the heap-ordered tables (every node kept): the same lane-local walk stores both children at every level"""
+    rng = np.random.default_rng(78)
+    for wname in ("db2", "db4", "coif6"):
+        wt = wx.wavelet(getattr(wx.WT, wname))
+        x = np.asfortranarray(rng.standard_normal((1024, 2)))
+        for L in (6, 7, 9, 10):
+            exp = np.stack([oracle.swpd(x[:, b], wt.qmf, L) for b in range(2)], axis=-1)
+            assert relerr(wx.swpdall(x, wt, L), exp) <= 1e-12, (wname, L)
+            expa = np.stack([oracle.acwpd(x[:, b], wt.qmf, L) for b in range(2)], axis=-1)
+            assert relerr(wx.acwpdall(x, wt, L), expa) <= 1e-12, (wname, L)

@@ -7,7 +7,7 @@ template <typename T> bool wx_fused1d_ok(int64_t n, int F);
 int wx_lattice_f32(bool inverse, const float *x, float *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt,
                    hipStream_t st);                                       // wx_lattice_f32.hip
 int wx_swpt_deep_levels(int64_t n, int L, int F, bool ac, size_t esz);      // wx_swtdeep.hip
-int wx_swpt_deep_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt &filt, const WxAcFilt *ac, hipStream_t st);
+int wx_swpt_deep_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt &filt, const WxAcFilt *ac, bool wpd, hipStream_t st);
 int wx_swpt_deep_inv(const double *src, int64_t src_cols, double *dst, int64_t dst_cols, int64_t n, int L, int LP, int64_t batch,
                      const WxFilt &filt, hipStream_t st);
 bool wx_lattice_applicable_f64(const WxFilt &filt);     // wx_lattice.hip: the filter has a lattice instantiation and factorises

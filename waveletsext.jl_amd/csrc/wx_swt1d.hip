@@ -694,7 +694,7 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
     // Haar, deep trees: the last six levels are one register pass (wx_haarswt.hip); the passes here stop at depth L - 6
     const bool haar6 = !ac && layout == WX_LAYOUT_WPT && !wx_force_generic_swt() && wx_haar_swpt6_ok(n, L, filt, sizeof(T));
     // any filter, deep trees: the levels from depth log2(n) - 4 on are a lane-local register pass (wx_swtdeep.hip)
-    const int deepLP = (!haar6 && layout == WX_LAYOUT_WPT && !wx_force_generic_swt())
+    const int deepLP = (!haar6 && (layout == WX_LAYOUT_WPT || layout == WX_LAYOUT_WPD) && !wx_force_generic_swt())
                            ? wx_swpt_deep_levels(n, L, ac ? ac->F : filt.F, ac != nullptr, sizeof(T)) : 0;
     const int dstop = haar6 ? L - 6 : L - deepLP;
     while (d < dstop) {
@@ -769,7 +769,7 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         if (deepLP) {
             if (dstop == 0)                                              // the root column of the table is the signal
                 WX_HIP_CHECK(hipMemcpy2DAsync(xw, sizeof(T) * n * ncols, x, sizeof(T) * n, sizeof(T) * n, batch, hipMemcpyDeviceToDevice, st));
-            return wx_swpt_deep_fwd((double *)xw, n, L, batch, filt, ac, st);
+            return wx_swpt_deep_fwd((double *)xw, n, L, batch, filt, ac, layout == WX_LAYOUT_WPD, st);
         }
     }
     return WX_OK;

@@ -1,171 +1,5 @@
-// wx_swtdeep.hip -- the last levels of the stationary / autocorrelation packet transforms (swpt, acwpt) for any filter, in
-// the registers of a lane.
-//
-// Reference (paths relative to /root/reference/src/mod): sdwt_step! swt/swt_one_level.jl:99-127 (a[i] = sum_j q[j] v[i + (j-1) s],
-// d[i] = sum_j (-1)^j q[j] v[i - j s], s = 2^d), acdwt_step! acwt/acwt_one_level.jl (w1 = v/sqrt2 + S, w2 = v/sqrt2 - S, S over the
-// odd lags), swpt! SWT.jl:439-472 / acwpt! ACWT.jl:427-460 (the (n, 2^L) table, children overwrite the parent column).
-//
-// From depth D0 = log2(n) - 4 on a level of dilation 2^d only moves inside a residue class mod 2^D0, and a class has
-// n' = 16 samples: the whole subtree below (node q of depth D0, class r) is a lane-local problem.  A wavefront takes 64
-// consecutive classes of one node -- every load and every store is one contiguous 512-byte run -- each lane reads its 16
-// samples once and walks the packet tree depth first: a node's two children are computed together (16 x 2 F multiply-adds with
-// compile-time register indices, the taps wrapping inside the 16 samples), the detail child waits in registers while the
-// approximation child's subtree is finished, leaves are stored as soon as they exist.  No LDS, no barrier; the level
-// kernels of wx_swt1d.hip, which read F taps per output from LDS and run one or two levels per pass over the table, stop
-// at depth D0 (1/16 of the final volume for a full-depth transform).  Same tap order and arithmetic as k_swt_fwd_level.
-#include "wx_common.h"
-#include "wx_kernels.h"
-#include "wx_host.h"
-#include <cstdlib>
-
-namespace {
-
-constexpr int SD_NP = 16;                                   // samples per residue class
-
-// children of one node at class-local dilation t = 2^J
-template <int F, bool AC, int J>
-__device__ __forceinline__ void sd_split(const double (&v)[SD_NP], double (&a)[SD_NP], double (&d)[SD_NP], const WxFilt &filt,
-                                         const WxAcFilt &ac)
-{
-    constexpr int t = 1 << J;
-#pragma unroll
-    for (int m = 0; m < SD_NP; ++m) {
-        if constexpr (!AC) {
-            double sa = 0.0, sd = 0.0;
-#pragma unroll
-            for (int j = 0; j < F; ++j) {
-                sa = fma(filt.q[j], v[(m + (j - 1) * t) & (SD_NP - 1)], sa);
-                sd = fma((j & 1) ? -filt.q[j] : filt.q[j], v[(m - j * t) & (SD_NP - 1)], sd);
-            }
-            a[m] = sa;
-            d[m] = sd;
-        } else {
-            double S = 0.0;
-#pragma unroll
-            for (int l = 1; l < F; l += 2)
-                S = fma(ac.b[l - 1], v[(m - l * t) & (SD_NP - 1)] + v[(m + l * t) & (SD_NP - 1)], S);
-            const double c = ac.c1 * v[m];
-            a[m] = c + S;
-            d[m] = c - S;
-        }
-    }
-}
-
-template <int F, bool AC, int J, int LP>
-__device__ __forceinline__ void sd_node(const double (&v)[SD_NP], double *__restrict__ col, int64_t n, int64_t pstride, const WxFilt &filt,
-                                        const WxAcFilt &ac)
-{
-    double a[SD_NP], d[SD_NP];
-    sd_split<F, AC, J>(v, a, d, filt, ac);
-    double *hi = col + ((int64_t)(1 << (LP - J - 1))) * n;             // the detail child sits half the node's width further
-    if constexpr (J + 1 == LP) {
-#pragma unroll
-        for (int m = 0; m < SD_NP; ++m) col[m * pstride] = a[m];
-#pragma unroll
-        for (int m = 0; m < SD_NP; ++m) hi[m * pstride] = d[m];
-    } else {
-        sd_node<F, AC, J + 1, LP>(a, col, n, pstride, filt, ac);
-        sd_node<F, AC, J + 1, LP>(d, hi, n, pstride, filt, ac);
-    }
-}
-
-// xw: (n, 2^L, batch) wpt layout; node q of depth D0 = L - LP lives in column q 2^LP
-template <int F, bool AC, int LP>
-__global__ __launch_bounds__(64) void k_swpt_deep_fwd(double *__restrict__ xw, int log2n, int L, int64_t batch, WxFilt filt, WxAcFilt ac)
-{
-    const int D0 = log2n - 4;
-    const int64_t n = (int64_t)1 << log2n, pstride = (int64_t)1 << D0;
-    const int cblocks = 1 << (D0 - 6);                                   // blocks of 64 classes per node
-    const int q = blockIdx.x / cblocks, cb = blockIdx.x - q * cblocks;
-    const int r = cb * 64 + threadIdx.x;
-    for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
-        double *col = xw + (sig << L) * n + ((int64_t)q << LP) * n + r;
-        double v[SD_NP];
-#pragma unroll
-        for (int m = 0; m < SD_NP; ++m) v[m] = col[m * pstride];
-        sd_node<F, AC, 0, LP>(v, col, n, pstride, filt, ac);
-    }
-}
-
-// ---- inverse (average-based iswpt): the mirror walk.  The average of the two shift variants of a stationary synthesis step
-// is the adjoint of the analysis step, parent[p] = 1/2 sum_j q[j] lo[p + (1 - j) s] + (-1)^j q[j] hi[p + j s]
-// (swt/swt_one_level.jl:257-318; wx_swt1d.hip uses the same identity for its fused passes)
-template <int F, int J>
-__device__ __forceinline__ void sd_merge(double (&out)[SD_NP], const double (&lo)[SD_NP], const double (&hi)[SD_NP], const WxFilt &filt)
-{
-    constexpr int t = 1 << J;
-#pragma unroll
-    for (int m = 0; m < SD_NP; ++m) {
-        double sa = 0.0, sd = 0.0;
-#pragma unroll
-        for (int j = 0; j < F; ++j) {
-            sa = fma(filt.q[j], lo[(m + (1 - j) * t) & (SD_NP - 1)], sa);
-            sd = fma((j & 1) ? -filt.q[j] : filt.q[j], hi[(m + j * t) & (SD_NP - 1)], sd);
-        }
-        out[m] = (sa + sd) * 0.5;
-    }
-}
-
-template <int F, int J, int LP>
-__device__ __forceinline__ void sd_inode(double (&out)[SD_NP], const double *__restrict__ col, int64_t n, int64_t pstride, const WxFilt &filt)
-{
-    double lo[SD_NP], hi[SD_NP];
-    const double *hcol = col + ((int64_t)(1 << (LP - J - 1))) * n;
-    if constexpr (J + 1 == LP) {
-#pragma unroll
-        for (int m = 0; m < SD_NP; ++m) lo[m] = col[m * pstride];
-#pragma unroll
-        for (int m = 0; m < SD_NP; ++m) hi[m] = hcol[m * pstride];
-    } else {
-        sd_inode<F, J + 1, LP>(lo, col, n, pstride, filt);
-        sd_inode<F, J + 1, LP>(hi, hcol, n, pstride, filt);
-    }
-    sd_merge<F, J>(out, lo, hi, filt);
-}
-
-// src: (n, src_cols, batch) leaves in wpt order (leaf q 2^LP + j in that column); dst: (n, dst_cols, batch), node q -> column q
-template <int F, int LP>
-__global__ __launch_bounds__(64) void k_swpt_deep_inv(const double *__restrict__ src, int64_t src_cols, double *__restrict__ dst,
-                                                      int64_t dst_cols, int log2n, int64_t batch, WxFilt filt)
-{
-    const int D0 = log2n - 4;
-    const int64_t n = (int64_t)1 << log2n, pstride = (int64_t)1 << D0;
-    const int cblocks = 1 << (D0 - 6);
-    const int q = blockIdx.x / cblocks, cb = blockIdx.x - q * cblocks;
-    const int r = cb * 64 + threadIdx.x;
-    for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
-        const double *col = src + sig * src_cols * n + ((int64_t)q << LP) * n + r;
-        double out[SD_NP];
-        sd_inode<F, 0, LP>(out, col, n, pstride, filt);
-        double *o = dst + sig * dst_cols * n + (int64_t)q * n + r;
-#pragma unroll
-        for (int m = 0; m < SD_NP; ++m) o[m * pstride] = out[m];
-    }
-}
-
-typedef void (*sd_ikern)(const double *, int64_t, double *, int64_t, int, int64_t, WxFilt);
-template <int F> sd_ikern sd_ipick(int LP)
-{
-    switch (LP) {
-    case 1: return k_swpt_deep_inv<F, 1>;
-    case 2: return k_swpt_deep_inv<F, 2>;
-    case 3: return k_swpt_deep_inv<F, 3>;
-    default: return k_swpt_deep_inv<F, 4>;
-    }
-}
-
-typedef void (*sd_kern)(double *, int, int, int64_t, WxFilt, WxAcFilt);
-template <int F, bool AC> sd_kern sd_pick(int LP)
-{
-    switch (LP) {
-    case 1: return k_swpt_deep_fwd<F, AC, 1>;
-    case 2: return k_swpt_deep_fwd<F, AC, 2>;
-    case 3: return k_swpt_deep_fwd<F, AC, 3>;
-    default: return k_swpt_deep_fwd<F, AC, 4>;
-    }
-}
-
-}  // namespace
+// wx_swtdeep.hip -- launchers of the lane-local deep levels of swpt / acwpt (device code and the design notes: wx_swtdeep.h)
+#include "wx_swtdeep.h"
 
 // number of levels the lane-local kernel takes off the end of a depth-L swpt / acwpt of n-sample Float64 signals (0 = none)
 int wx_swpt_deep_levels(int64_t n, int L, int F, bool ac, size_t esz)
@@ -180,8 +14,11 @@ int wx_swpt_deep_levels(int64_t n, int L, int F, bool ac, size_t esz)
     return (LP >= 1 && LP <= 4) ? LP : 0;
 }
 
-int wx_swpt_deep_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt &filt, const WxAcFilt *ac, hipStream_t st)
+int wx_swpd_deep_fwd_impl(double *xw, int64_t n, int L, int64_t batch, const WxFilt &filt, const WxAcFilt *ac, hipStream_t st);   // wx_swtdeep_w.hip
+
+int wx_swpt_deep_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt &filt, const WxAcFilt *ac, bool wpd, hipStream_t st)
 {
+    if (wpd) return wx_swpd_deep_fwd_impl(xw, n, L, batch, filt, ac, st);
     const bool isac = ac != nullptr;
     const int F = isac ? ac->F : filt.F;
     const int LP = wx_swpt_deep_levels(n, L, F, isac, 8);
@@ -190,7 +27,7 @@ int wx_swpt_deep_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt &
     while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
     const int D0 = log2n - 4;
     sd_kern k = nullptr;
-#define WX_SD(FF) case FF: k = isac ? sd_pick<FF, true>(LP) : sd_pick<FF, false>(LP); break;
+#define WX_SD(FF) case FF: k = isac ? sd_pick<FF, true, false>(LP) : sd_pick<FF, false, false>(LP); break;
     switch (F) { WX_SD(2) WX_SD(4) WX_SD(6) WX_SD(8) WX_SD(10) WX_SD(12) WX_SD(16) WX_SD(18) WX_SD(20) }
 #undef WX_SD
     WxAcFilt acz;
@@ -202,22 +39,3 @@ int wx_swpt_deep_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt &
     return WX_OK;
 }
 
-// the deepest LP = L - (log2(n) - 4) levels of the average-based iswpt: leaves (n, src_cols) -> nodes of depth L - LP (n, dst_cols)
-int wx_swpt_deep_inv(const double *src, int64_t src_cols, double *dst, int64_t dst_cols, int64_t n, int L, int LP, int64_t batch,
-                     const WxFilt &filt, hipStream_t st)
-{
-    int log2n = 0;
-    while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
-    const int D0 = log2n - 4;
-    if (LP < 1 || LP > 4 || L - LP != D0) return wx_set_error(WX_EHIP, "iswpt deep levels: inconsistent plan");
-    sd_ikern k = nullptr;
-#define WX_SDI(FF) case FF: k = sd_ipick<FF>(LP); break;
-    switch (filt.F) { WX_SDI(2) WX_SDI(4) WX_SDI(6) WX_SDI(8) WX_SDI(10) WX_SDI(12) WX_SDI(16) WX_SDI(18) WX_SDI(20) default: break; }
-#undef WX_SDI
-    if (!k) return wx_set_error(WX_EHIP, "iswpt deep levels: no instantiation for this filter length");
-    const int64_t gx = ((int64_t)1 << D0) * ((int64_t)1 << (D0 - 6));
-    const int64_t gy = batch > 65535 ? 65535 : batch;
-    hipLaunchKernelGGL(k, dim3((unsigned)gx, (unsigned)gy), dim3(64), 0, st, src, src_cols, dst, dst_cols, log2n, batch, filt);
-    WX_HIP_CHECK(hipGetLastError());
-    return WX_OK;
-}
