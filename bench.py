@@ -37,12 +37,12 @@ FP64_PEAK_TFLOPS = 78.6        # FP64 vector spec; tools/ubench.hip 
 
 WORKLOADS = {
     "cfg2": dict(kind="wpd", n=4096, batch=65536, wavelet="db8", L=12, dtype="f64",
-                 kernel="k_lat_wpd_f64<8, 2>", inv_kernel="k_lat_iwpt_f64<8, 2>",
+                 kernel="k_lat_wpd_f64<8, 2>", inv_kernel="k_lat_iwpt_f64<8, 2, double>",
                  fwd_kernels=[("k_lat_wpd_f64<8, 2>", 1)],
                  desc="BASELINE config 2: wpdall+iwpdall 65536x4096 f64 db8 full tree L=12"),
     "target": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=10, dtype="f64",
-                   kernel="k_lat_wpt_f64<4, 3>", inv_kernel="k_lat_iwpt_f64<4, 2>",
-                   fwd_kernels=[("k_lat_wpt_f64<4, 3>", 1)],
+                   kernel="k_lat_wpt_f64<4, 3, double>", inv_kernel="k_lat_iwpt_f64<4, 2, double>",
+                   fwd_kernels=[("k_lat_wpt_f64<4, 3, double>", 1)],
                    desc="north-star target: wptall+iwptall 65536x4096 f64 db4 L=10"),
     "target_n2048": dict(kind="wpt", n=2048, batch=131072, wavelet="db4", L=10, dtype="f64",
                          kernel="k_lat_wpt_sh_f64<4, 2, 1>", inv_kernel="k_lat_iwpt_sh_f64<4, 2, 1>",
