@@ -794,7 +794,7 @@ void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz
 {
     P->npass = 0;
     P->need_cols[0] = P->need_cols[1] = 0;
-    const bool fuse = layout == WX_LAYOUT_WPT && sm < 0 && !has_tree && F <= 16 && !wx_force_generic_swt();
+    const bool fuse = layout == WX_LAYOUT_WPT && sm < 0 && !has_tree && F <= 20 && !wx_force_generic_swt();
     const int64_t budget = wx_swtinv_lds_bytes();
     int d = L, pp = 0;
     while (d > 0) {
