@@ -64,6 +64,12 @@ WORKLOADS = {
                  fwd_kernels=[("k_swt_fwd_multi<double, 8>", 2), ("k_haar_swpt6_fwd<1>", 1)],
                  desc="BASELINE config 3: swptall+iswptall (average-based) 8192x16384 f64 haar L=12; the leaves exist one "
                       "resident chunk of 64 signals (32 GiB) at a time, a step loops over every chunk of the shard"),
+    "swpt_db4": dict(kind="swpt", n=1024, batch=16384, chunk=2048, wavelet="db4", L=10, dtype="f64",
+                     kernel="k_swpt_deep_fwd<8, false, 4>", inv_kernel="k_swpt_deep_inv<8, 4>",
+                     fwd_kernels=[("k_swpt_deep_fwd<8, false, 4>", 1)],
+                     desc="the redundant packet transform with a general filter at full depth: swptall+iswptall (average-based) "
+                          "16384x1024 f64 db4 L=10 in resident chunks of 2048 signals (16 GiB of leaves each); the last four "
+                          "levels are the lane-local kernels of DESIGN 4.21 (`traffic` is that kernel's)"),
     "cfg4": dict(kind="wpt2d", m=512, n=512, batch=4096, wavelet="db4", L=6, dtype="f32",
                  kernel="k_lat2d_colT_f32<4>", inv_kernel="k_lat2d_icolT_f32<4>",
                  fwd_kernels=[("k_lat2d_colT_f32<4>", 2)],
