@@ -21,7 +21,10 @@
 
 namespace {
 
-constexpr int SD_NP = 16;                                   // samples per residue class
+#ifndef WX_SD_LOG
+#define WX_SD_LOG 4
+#endif
+constexpr int SD_LOG = WX_SD_LOG, SD_NP = 1 << SD_LOG;      // samples per residue class
 
 // children of one node at class-local dilation t = 2^J
 template <int F, bool AC, int J>
@@ -93,7 +96,7 @@ __device__ __forceinline__ void sd_node_wpd(const double (&v)[SD_NP], double *__
 template <int F, bool AC, int LP>
 __global__ __launch_bounds__(64) void k_swpd_deep_fwd(double *__restrict__ xw, int log2n, int L, int64_t batch, WxFilt filt, WxAcFilt ac)
 {
-    const int D0 = log2n - 4;
+    const int D0 = log2n - SD_LOG;
     const int64_t n = (int64_t)1 << log2n, pstride = (int64_t)1 << D0;
     const int64_t ncols = ((int64_t)1 << (L + 1)) - 1;
     const int cblocks = 1 << (D0 - 6);
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(64) void k_swpd_deep_fwd(double *__restrict__ xw, i
 template <int F, bool AC, int LP>
 __global__ __launch_bounds__(64) void k_swpt_deep_fwd(double *__restrict__ xw, int log2n, int L, int64_t batch, WxFilt filt, WxAcFilt ac)
 {
-    const int D0 = log2n - 4;
+    const int D0 = log2n - SD_LOG;
     const int64_t n = (int64_t)1 << log2n, pstride = (int64_t)1 << D0;
     const int cblocks = 1 << (D0 - 6);                                   // blocks of 64 classes per node
     const int q = blockIdx.x / cblocks, cb = blockIdx.x - q * cblocks;
@@ -168,7 +171,7 @@ template <int F, int LP>
 __global__ __launch_bounds__(64) void k_swpt_deep_inv(const double *__restrict__ src, int64_t src_cols, double *__restrict__ dst,
                                                       int64_t dst_cols, int log2n, int64_t batch, WxFilt filt)
 {
-    const int D0 = log2n - 4;
+    const int D0 = log2n - SD_LOG;
     const int64_t n = (int64_t)1 << log2n, pstride = (int64_t)1 << D0;
     const int cblocks = 1 << (D0 - 6);
     const int q = blockIdx.x / cblocks, cb = blockIdx.x - q * cblocks;
