@@ -55,10 +55,10 @@ WORKLOADS = {
                          desc="the target's byte count with 1024-sample signals: wptall+iwptall 262144x1024 f64 db4 L=9 "
                               "(four signals interleaved per wavefront, DESIGN 4.20)"),
     "target_haar": dict(kind="wpt", n=4096, batch=65536, wavelet="haar", L=10, dtype="f64",
-                        kernel="k_haar_wpt_f64<256>",
-                        fwd_kernels=[("k_haar_wpt_f64<256>", 1)],
+                        kernel="k_lat_wpt_f64<1, 3, double>", inv_kernel="k_lat_iwpt_f64<1, 2, double>",
+                        fwd_kernels=[("k_lat_wpt_f64<1, 3, double>", 1)],
                         desc="north-star target with the Haar filter: wptall+iwptall 65536x4096 f64 haar L=10 "
-                             "(Walsh-Hadamard kernels, wx_haar.hip)"),
+                             "(the lattice kernels with one rotation; WX_LATTICE=0 selects the Walsh-Hadamard kernels of wx_haar.hip)"),
     "cfg3": dict(kind="swpt", n=16384, batch=8192, chunk=64, wavelet="haar", L=12, dtype="f64",
                  kernel="k_haar_swpt6_fwd<1>", inv_kernel="k_haar_iswpt<5, 1>",
                  fwd_kernels=[("k_swt_fwd_multi<double, 8>", 2), ("k_haar_swpt6_fwd<1>", 1)],

@@ -1331,14 +1331,15 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
     }
     const bool noreg = wx_skip_register_kernels();      // test hook: fused LDS kernels only
     if constexpr (sizeof(T) == 8) {
-        // Haar, full tree: Walsh-Hadamard formulation (wx_haar.hip)
-        if (!force_generic && !noreg && !status) {
-            const int r = wx_haar_wpt_f64((const double *)x, (double *)y, n, L, batch, filt, st);
-            if (r) return r < 0 ? r : WX_OK;
-        }
-        // longer filters, full tree: rotations in registers (wx_lattice.hip)
+        // full tree: rotations in registers (wx_lattice.hip; Haar is the lattice with one rotation: 0.78 ms against the
+        // 0.94 ms of the Walsh-Hadamard kernel at the target's size)
         if (!force_generic && !noreg && !status) {
             const int r = wx_lattice_wpt_f64((const double *)x, (double *)y, n, L, batch, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
+        // Haar where the lattice does not apply (depths below 6, ...): Walsh-Hadamard formulation (wx_haar.hip)
+        if (!force_generic && !noreg && !status) {
+            const int r = wx_haar_wpt_f64((const double *)x, (double *)y, n, L, batch, filt, st);
             if (r) return r < 0 ? r : WX_OK;
         }
     }
@@ -1439,13 +1440,13 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
     }
     const bool noreg = wx_skip_register_kernels();
     if constexpr (sizeof(T) == 8) {
-        // Haar, full tree, dense leaves: inverse Walsh-Hadamard formulation (wx_haar.hip)
-        if (!force_generic && !noreg && !status && !colmap && is == n) {
-            const int r = wx_haar_iwpt_f64((const double *)xw, (double *)xh, n, L, batch, filt, st);
-            if (r) return r < 0 ? r : WX_OK;
-        }
         if (!force_generic && !noreg && !status && !colmap) {
             const int r = wx_lattice_iwpt_f64((const double *)xw, (double *)xh, n, L, batch, is, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
+        // Haar where the lattice does not apply, dense leaves: inverse Walsh-Hadamard formulation (wx_haar.hip)
+        if (!force_generic && !noreg && !status && !colmap && is == n) {
+            const int r = wx_haar_iwpt_f64((const double *)xw, (double *)xh, n, L, batch, filt, st);
             if (r) return r < 0 ? r : WX_OK;
         }
     }

@@ -120,7 +120,7 @@ static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n
         return wx_lattice_launch_sh(inverse, x, y, n, L, batch, inverse ? in_stride : n, filt, st);
     if (!off && !off_sh && n >= 64 && n <= 512)
         return wx_lattice_launch_g(inverse, x, y, n, L, batch, inverse ? in_stride : n, filt, st);
-    if (off || n != 4096 || L < 6 || L > 12 || filt.F < 4 || batch <= 0) return 0;
+    if (off || n != 4096 || L < 6 || L > 12 || filt.F < 2 || batch <= 0) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     if (inverse && (in_stride & 3)) return 0;
     WxLat cf;
@@ -144,7 +144,7 @@ static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n
             hipLaunchKernelGGL((k_lat_wpt_f64<NSS, 3>), dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, cf);  \
         break;
     switch (filt.F / 2) {
-        WX_GO(2) WX_GO(3) WX_GO(4) WX_GO(5) WX_GO(6) WX_GO(7) WX_GO(8) WX_GO(9) WX_GO(10)
+        WX_GO(1) WX_GO(2) WX_GO(3) WX_GO(4) WX_GO(5) WX_GO(6) WX_GO(7) WX_GO(8) WX_GO(9) WX_GO(10)
     default: return 0;
     }
 #undef WX_GO
@@ -163,7 +163,7 @@ int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t bat
     static const bool off_sh = getenv("WX_LATTICE_SH") && atoi(getenv("WX_LATTICE_SH")) == 0;
     if (!off && !off_sh && (n == 2048 || n == 1024) && x != (const double *)y) return wx_lattice_wpd_sh_f64(x, y, n, L, batch, filt, st);
     if (!off && !off_sh && n >= 64 && n <= 512 && x != (const double *)y) return wx_lattice_wpd_g_f64(x, y, n, L, batch, filt, st);
-    if (off || n != 4096 || L < 1 || L > 12 || filt.F < 4 || batch <= 0 || batch > 0x7fffffff) return 0;
+    if (off || n != 4096 || L < 1 || L > 12 || filt.F < 2 || batch <= 0 || batch > 0x7fffffff) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     WxLatW cw;
     if (!wx_lattice_factor(filt, L, false, &cw.c)) return 0;
@@ -184,7 +184,7 @@ int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t bat
         hipLaunchKernelGGL((k_lat_wpd_f64<NSS, 2>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L, batch, cw);     \
         break;
     switch (filt.F / 2) {
-        WX_GOW(2) WX_GOW(3) WX_GOW(4) WX_GOW(5) WX_GOW(6) WX_GOW(7) WX_GOW(8) WX_GOW(9) WX_GOW(10)
+        WX_GOW(1) WX_GOW(2) WX_GOW(3) WX_GOW(4) WX_GOW(5) WX_GOW(6) WX_GOW(7) WX_GOW(8) WX_GOW(9) WX_GOW(10)
     default: return 0;
     }
 #undef WX_GOW
@@ -196,7 +196,7 @@ int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t bat
 bool wx_lattice_applicable_f64(const WxFilt &filt)
 {
     static const bool off = getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0;
-    if (off || filt.F < 4 || filt.F / 2 > WX_LAT_MAXS) return false;
+    if (off || filt.F < 2 || filt.F / 2 > WX_LAT_MAXS) return false;
     WxLat tmp;
     return wx_lattice_factor(filt, 6, false, &tmp);
 }
