@@ -18,7 +18,7 @@ def _wt(wx, name):
     return wx.wavelet(getattr(wx.WT, name))
 
 
-@pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db5", "db6", "db7", "db8", "coif6", "db10"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "db6", "db7", "db8", "coif6", "db10"])
 def test_lattice_every_depth_matches_oracle(wx, oracle, wname):
     """dwt/dwt_all.jl:152-166, 210-225 over Wavelets.jl's wpt / iwpt by level, every depth the lattice kernels take"""
     rng = np.random.default_rng(4096)
@@ -125,7 +125,7 @@ def test_filter_without_a_lattice_falls_back(wx, oracle):
     assert relerr(wx.wptall(x, wt, 8), oracle.wptall(x, q, 8)) <= 1e-10
 
 
-@pytest.mark.parametrize("wname", ["db2", "db3", "db4", "db7", "db8", "coif6", "db10"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db7", "db8", "coif6", "db10"])
 def test_lattice_wpd_every_depth_matches_oracle(wx, oracle, wname):
     """wpdall of 4096-sample Float64 signals (DWT.jl:131-161, dwt/dwt_all.jl:260-282) through k_lat_wpd_f64: every level
     leaves the registers through its own LDS transposition; every depth 1..12, every column of the table"""
