@@ -119,7 +119,8 @@ def _run_bench(args, env_extra, timeout=900):
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("workload,batch", [("cfg2", 37), ("target", 64), ("cfg4", 6)])
+@pytest.mark.parametrize("workload,batch", [("cfg2", 37), ("target", 64), ("cfg4", 6), ("cfg3", 12), ("swpt_db4", 40),
+                                            ("target_n2048", 96), ("target_haar", 70)])
 def test_bench_two_ranks_gather_equals_one_rank(tmp_path, workload, batch):
     """bench.py's N > 1 path in its validation mode (two fresh child processes share this GPU, gloo instead of RCCL):
     strong scaling of a small batch, the all-gather of the reconstructed output inside the step, and the gathered array
