@@ -259,7 +259,7 @@ __global__ __launch_bounds__(1024) void k_isdwt_avg_fused(const T *__restrict__ 
 // K levels per pass (swpt only): the 2^K descendants of depth d+K are computed straight from the
 // LDS-resident parent with composite taps (products of the K per-level taps, merged per offset on
 // the host).  The intermediate levels never touch HBM: a pass reads 2^d*n and writes 2^(d+K)*n.
-//   table layout: coef[c * U + t] multiplies v[(i + shift[t]) mod n], c = descendant (natural
+//   table layout: coef[t * 2^K + c] multiplies v[(i + shift[t]) mod n], c = descendant (natural
 //   order), t = index into the union of offsets
 // ------------------------------------------------------------------------------------------
 template <typename T, int NC>
@@ -282,11 +282,26 @@ __global__ __launch_bounds__(1024) void k_swt_fwd_multi(const T *__restrict__ x,
             double acc[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-            for (int t = 0; t < U; ++t) {
+            // taps in groups of four: the table entries of a group (wave-uniform, scalar loads) and its four LDS reads
+            // are issued together instead of one wait per tap; same order of the multiply-adds as one tap at a time
+            int t = 0;
+            for (; t + 4 <= U; t += 4) {
+                double vv[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    int k = i + shift[t + tt]; if (k >= n) k -= n;
+                    vv[tt] = (double)v[k];
+                }
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[c] = fma(coef[(t + tt) * NC + c], vv[tt], acc[c]);
+            }
+            for (; t < U; ++t) {
                 int k = i + shift[t]; if (k >= n) k -= n;
                 const double vv = (double)v[k];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) acc[c] = fma(coef[c * U + t], vv, acc[c]);
+                for (int c = 0; c < NC; ++c) acc[c] = fma(coef[t * NC + c], vv, acc[c]);
             }
 #pragma unroll
             for (int c = 0; c < NC; ++c) base[(int64_t)((b * NC + c) * wc) * n + i] = (T)acc[c];
@@ -296,15 +311,48 @@ __global__ __launch_bounds__(1024) void k_swt_fwd_multi(const T *__restrict__ x,
 }
 
 
+// Sliding taps of one descendant: a thread owns OPT consecutive rows (class samples) u0 .. u0 + OPT - 1 of one residue, the W
+// = U + OPT - 1 class samples from row k on are read once each and feed the OPT running sums; cp[w - j] is the tap table of
+// the descendant, zero padded by OPT - 1 on both sides.  Window samples go in groups of four: the table entries of a group
+// (wave-uniform, scalar loads) and its four LDS reads are issued together, not one wait per sample.  vb = tile + residue.
+template <typename T, int OPT>
+static __device__ __forceinline__ void wx_slide_taps(const T *vb, int lgR, int k, int nu, const double *__restrict__ cp, int W,
+                                                     double (&acc)[OPT])
+{
+    int w = 0;
+    for (; w + 4 <= W; w += 4) {
+        double val[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            val[tt] = (double)vb[k << lgR];
+            k = (k + 1 == nu) ? 0 : k + 1;
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int j = 0; j < OPT; ++j) acc[j] = fma(cp[w + tt - j], val[tt], acc[j]);
+    }
+    for (; w < W; ++w) {
+        const double val = (double)vb[k << lgR];
+        k = (k + 1 == nu) ? 0 : k + 1;
+#pragma unroll
+        for (int j = 0; j < OPT; ++j) acc[j] = fma(cp[w - j], val, acc[j]);
+    }
+}
+
 // Residue-class variant for deep passes (s = 2^d large): descendant samples of class r (mod s)
 // depend only on the parent's samples of class r, so a workgroup stages an (n/s) x R tile of the
 // parent (runs of R consecutive samples every s) instead of the whole column: small LDS footprint,
-// several workgroups per CU.  uoff[t] = composite offset in units of s, reduced mod n/s.
+// several workgroups per CU.  The composite taps of one descendant are U contiguous offsets (in units of s) from
+// ustart[c] on (reduced mod n/s): each descendant slides over its own window (wx_slide_taps), so no multiply-add is spent
+// on the offsets that only the other descendants use, and the address arithmetic is per window sample, not per tap.
+// coefp[c][OPT - 1 + t] = tap t of descendant c, zero padded by OPT - 1 on both sides (pitch U + 2 (OPT - 1)).
+// blockDim.x = (n/s) R / OPT exactly; (n/s) is a multiple of OPT.
 template <typename T, int NC, int OPT>
 __global__ __launch_bounds__(512) void k_swt_fwd_multi_rc(const T *__restrict__ x, T *__restrict__ xw, int n,
                                                           int ncols, int64_t batch, int L, int d, int K, int R,
-                                                          const double *__restrict__ coef,
-                                                          const int *__restrict__ uoff, int U)
+                                                          const double *__restrict__ coefp,
+                                                          const int *__restrict__ ustart, int U)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     T *v = reinterpret_cast<T *>(wx_smem);
@@ -313,37 +361,33 @@ __global__ __launch_bounds__(512) void k_swt_fwd_multi_rc(const T *__restrict__ 
     const int nblk = s / R;
     const int b = blockIdx.x / nblk;
     const int r0 = (blockIdx.x - b * nblk) * R;
-    const int tile = nu * R;
     const int lgR = __ffs(R) - 1;
     const int NT = blockDim.x;
     const int wp = 1 << (L - d);
     const int wc = 1 << (L - d - K);
+    const int r = threadIdx.x & (R - 1);
+    const int u0 = (threadIdx.x >> lgR) * OPT;
+    const int UP = U + 2 * (OPT - 1);
     for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
         T *base = xw + sig * (int64_t)n * ncols;
         const T *src = ((d == 0) ? x + sig * (int64_t)n : base + (int64_t)(b * wp) * n) + r0;
 #pragma unroll
         for (int j = 0; j < OPT; ++j) {
             const int o = threadIdx.x + j * NT;
-            if (o < tile) v[o] = src[(o & (R - 1)) + (int64_t)(o >> lgR) * s];
+            v[o] = src[(o & (R - 1)) + (int64_t)(o >> lgR) * s];
         }
         __syncthreads();
+        T *dp = base + r0 + r + (int64_t)u0 * s;
 #pragma unroll 1
-        for (int j = 0; j < OPT; ++j) {
-            const int o = threadIdx.x + j * NT;
-            if (o >= tile) break;
-            const int r = o & (R - 1), u = o >> lgR;
-            double acc[NC];
+        for (int c = 0; c < NC; ++c) {
+            double acc[OPT];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-            for (int t = 0; t < U; ++t) {
-                int k = u + uoff[t]; if (k >= nu) k -= nu;
-                const double vv = (double)v[(k << lgR) + r];
+            for (int j = 0; j < OPT; ++j) acc[j] = 0.0;
+            int k = u0 + ustart[c]; if (k >= nu) k -= nu;
+            wx_slide_taps<T, OPT>(v + r, lgR, k, nu, coefp + c * UP + (OPT - 1), U + OPT - 1, acc);
+            T *dc = dp + (int64_t)((b * NC + c) * wc) * n;
 #pragma unroll
-                for (int c = 0; c < NC; ++c) acc[c] = fma(coef[c * U + t], vv, acc[c]);
-            }
-            T *dp = base + r0 + r + (int64_t)u * s;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) dp[(int64_t)((b * NC + c) * wc) * n] = (T)acc[c];
+            for (int j = 0; j < OPT; ++j) dc[(int64_t)j * s] = (T)acc[j];
         }
         __syncthreads();
     }
@@ -720,8 +764,8 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
             if (sh < 0) sh += n;
             shift[t] = (int)sh;
         }
-        // residue-class tiles when runs of >= 64 bytes fit the per-workgroup tile budget
-        int Rrc = 0;
+        // residue-class tiles when runs of >= 64 bytes fit the per-workgroup tile budget (and 512 threads x 8 rows)
+        int Rrc = 0, OPTrc = 0;
         {
             const int64_t nu = n >> d;
             int64_t r = (int64_t)(wx_swtfwd_lds_bytes() / sizeof(T)) / nu, rp = 1;
@@ -729,32 +773,63 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
             if (r < 1) rp = 0;
             if (rp > sdil) rp = sdil;
             if (rp > 128) rp = 128;
-            if (rp * (int64_t)sizeof(T) >= 64) Rrc = (int)rp;
-            if (Rrc) for (int t = 0; t < U; ++t) {
-                int64_t o = (int64_t)offs[t] % nu;
-                if (o < 0) o += nu;
-                shift[t] = (int)o;
+            while (rp > 1 && nu * rp > 4096) rp >>= 1;
+            if (rp * (int64_t)sizeof(T) >= 64 && nu * rp <= 4096) {
+                // rows per thread: four when the tile gives at least a wavefront of threads, at most 512 threads
+                int o = 4;
+                while (o > 1 && (nu % o != 0 || nu * rp / o < 64)) o >>= 1;
+                while (o < 8 && nu * rp / o > 512 && nu % (2 * o) == 0) o <<= 1;
+                if (nu % o == 0 && nu * rp / o <= 512) { Rrc = (int)rp; OPTrc = o; }
             }
+        }
+        if (Rrc) {
+            // per descendant: the contiguous run of offsets it uses, padded for the sliding window
+            const int64_t nu = n >> d;
+            const int NCc = 1 << K;
+            for (int t = 1; t < U; ++t)
+                if (offs[t] != offs[0] + t) return wx_set_error(WX_EHIP, "swpt: composite taps are not contiguous");
+            std::vector<int> first(NCc, 0), len(NCc, 1);
+            int Uc = 1;
+            for (int c = 0; c < NCc; ++c) {
+                int f = -1, l = -1;
+                for (int t = 0; t < U; ++t) if (coef[(size_t)c * U + t] != 0.0) { if (f < 0) f = t; l = t; }
+                if (f < 0) { f = 0; l = 0; }
+                first[c] = f; len[c] = l - f + 1;
+                if (len[c] > Uc) Uc = len[c];
+            }
+            const int UP = Uc + 2 * (OPTrc - 1);
+            std::vector<double> pad((size_t)NCc * UP, 0.0);
+            std::vector<int> ust(NCc);
+            for (int c = 0; c < NCc; ++c) {
+                for (int t = 0; t < len[c]; ++t) pad[(size_t)c * UP + (OPTrc - 1) + t] = coef[(size_t)c * U + first[c] + t];
+                int64_t o = (int64_t)offs[first[c]] % nu;
+                if (o < 0) o += nu;
+                ust[c] = (int)o;
+            }
+            dcoef = (double *)wx_const_upload(pad.data(), pad.size() * sizeof(double), st, true);
+            dshift = (int *)wx_const_upload(ust.data(), ust.size() * sizeof(int), st, true);
+            if (!dcoef || !dshift) return WX_EHIP;
+            const int64_t tile = nu * Rrc;
+            const int NT = (int)(tile / OPTrc);
+            typedef void (*KM)(const T *, T *, int, int, int64_t, int, int, int, int, const double *, const int *, int);
+            KM kr = nullptr;
+            if (K == 2) kr = OPTrc == 8 ? k_swt_fwd_multi_rc<T, 4, 8> : OPTrc == 4 ? k_swt_fwd_multi_rc<T, 4, 4> : OPTrc == 2 ? k_swt_fwd_multi_rc<T, 4, 2> : k_swt_fwd_multi_rc<T, 4, 1>;
+            else kr = OPTrc == 8 ? k_swt_fwd_multi_rc<T, 8, 8> : OPTrc == 4 ? k_swt_fwd_multi_rc<T, 8, 4> : OPTrc == 2 ? k_swt_fwd_multi_rc<T, 8, 2> : k_swt_fwd_multi_rc<T, 8, 1>;
+            hipLaunchKernelGGL(kr, dim3((unsigned)(((int64_t)1 << d) * (sdil / Rrc)), (unsigned)gy), dim3(NT),
+                               (size_t)tile * sizeof(T), st, x, xw, (int)n, ncols, batch, L, d, K, Rrc,
+                               (const double *)dcoef, (const int *)dshift, Uc);
+            d += K;
+            continue;
+        }
+        {   // the whole-column kernel reads the table tap-major: the 2^K coefficients of one offset are one contiguous scalar load
+            const int NCc = 1 << K;
+            std::vector<double> ct(coef.size());
+            for (int c = 0; c < NCc; ++c) for (int t = 0; t < U; ++t) ct[(size_t)t * NCc + c] = coef[(size_t)c * U + t];
+            coef.swap(ct);
         }
         dcoef = (double *)wx_const_upload(coef.data(), coef.size() * sizeof(double), st, true);
         dshift = (int *)wx_const_upload(shift.data(), shift.size() * sizeof(int), st, true);
         if (!dcoef || !dshift) return WX_EHIP;
-        if (Rrc) {
-            const int64_t tile = (n >> d) * Rrc;
-            int NT = 512;
-            while (NT > 64 && NT >= 2 * tile) NT >>= 1;
-            const int64_t opt = (tile + NT - 1) / NT;
-            if (opt > 16) return wx_set_error(WX_EHIP, "swpt: inconsistent fused-pass plan");
-            typedef void (*KM)(const T *, T *, int, int, int64_t, int, int, int, int, const double *, const int *, int);
-            KM kr = nullptr;
-            if (K == 2) kr = opt <= 2 ? k_swt_fwd_multi_rc<T, 4, 2> : opt <= 4 ? k_swt_fwd_multi_rc<T, 4, 4> : opt <= 8 ? k_swt_fwd_multi_rc<T, 4, 8> : k_swt_fwd_multi_rc<T, 4, 16>;
-            else kr = opt <= 2 ? k_swt_fwd_multi_rc<T, 8, 2> : opt <= 4 ? k_swt_fwd_multi_rc<T, 8, 4> : opt <= 8 ? k_swt_fwd_multi_rc<T, 8, 8> : k_swt_fwd_multi_rc<T, 8, 16>;
-            hipLaunchKernelGGL(kr, dim3((unsigned)(((int64_t)1 << d) * (sdil / Rrc)), (unsigned)gy), dim3(NT),
-                               (size_t)tile * sizeof(T), st, x, xw, (int)n, ncols, batch, L, d, K, Rrc,
-                               (const double *)dcoef, (const int *)dshift, U);
-            d += K;
-            continue;
-        }
         auto km = K == 2 ? k_swt_fwd_multi<T, 4> : k_swt_fwd_multi<T, 8>;
         if (lds > 64 * 1024)
             WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(km),
