@@ -11,3 +11,7 @@ x = wx.jl_empty((n, B), torch.float64, "cuda"); x.normal_()
 for _ in range(6):
     y = wx.swptall(x, wt, L)
 torch.cuda.synchronize()
+for _ in range(6):
+    xr = wx.iswptall(y, wt)
+torch.cuda.synchronize()
+print("roundtrip", float((xr - x).abs().max()))

@@ -508,14 +508,14 @@ __global__ __launch_bounds__(256) void k_swt_inv_level(WxInvDesc D, int n, int64
 template <typename T, int NC, int OPT>
 __global__ __launch_bounds__(512) void k_swt_inv_multi(const T *__restrict__ src, int64_t src_cols,
                                                        T *__restrict__ dst, int64_t dst_cols, int n, int64_t batch,
-                                                       int d, int R, const double *__restrict__ coefp, int ustart,
-                                                       int U)
+                                                       int d, int R, const double *__restrict__ coefp,
+                                                       const int *__restrict__ ustart, int U)
 {
     // One descendant column tile at a time through a double-buffered LDS tile, accumulators in
     // registers; the next column's tile is fetched into registers while the current one is used.
-    // A thread owns OPT consecutive rows u0..u0+OPT-1 of one residue r, so the U contiguous taps
-    // slide over a window of OPT+U-1 LDS values (not OPT*U): coefp[c][w - j + OPT-1] is the tap
-    // table zero-padded by OPT-1 on both sides, ustart = first tap offset reduced mod nu.
+    // A thread owns OPT consecutive rows u0..u0+OPT-1 of one residue r, so the U contiguous taps of a descendant
+    // slide over a window of OPT+U-1 LDS values (not OPT*U, wx_slide_taps): coefp[c][w - j + OPT-1] is the tap
+    // table of descendant c zero-padded by OPT-1 on both sides, ustart[c] = its first tap offset reduced mod nu.
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     T *v = reinterpret_cast<T *>(wx_smem);
     const int s = 1 << d;
@@ -529,7 +529,6 @@ __global__ __launch_bounds__(512) void k_swt_inv_multi(const T *__restrict__ src
     const int u0 = (threadIdx.x >> lgR) * OPT;
     const int UP = U + 2 * (OPT - 1);
     const int64_t g0 = r + (int64_t)u0 * s;
-    int kstart = u0 + ustart; if (kstart >= nu) kstart -= nu;
     for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
         const T *sp = src + (sig * src_cols + (int64_t)b * NC) * n + r0 + g0;
         T pre[OPT];
@@ -544,14 +543,8 @@ __global__ __launch_bounds__(512) void k_swt_inv_multi(const T *__restrict__ src
 #pragma unroll
                 for (int j = 0; j < OPT; ++j) pre[j] = sp[(int64_t)(c + 1) * n + (int64_t)j * s];
             }
-            const double *cp = coefp + c * UP + (OPT - 1);
-            int k = kstart;
-            for (int w = 0; w < U + OPT - 1; ++w) {
-                const double val = (double)vb[k << lgR];
-                k = (k + 1 == nu) ? 0 : k + 1;
-#pragma unroll
-                for (int j = 0; j < OPT; ++j) acc[j] = fma(cp[w - j], val, acc[j]);
-            }
+            int k = u0 + ustart[c]; if (k >= nu) k -= nu;
+            wx_slide_taps<T, OPT>(vb, lgR, k, nu, coefp + c * UP + (OPT - 1), U + OPT - 1, acc);
             if (c + 1 < NC) {
                 T *vn = v + ((c + 1) & 1) * tile;
 #pragma unroll
@@ -891,7 +884,8 @@ void wx_swt_inv_plan(int layout, int L, int F, int64_t sm, int64_t n, size_t esz
             // rows per thread: the largest of 8/4/2/1 dividing nu that keeps >= 64 threads; at most 512 threads
             int o = 1;
             for (;; rp >>= 1) {
-                if (rp * (int64_t)esz < 64) { rp = 0; break; }
+                // runs shorter than 64 bytes only when the tile is the whole column (every residue: contiguous)
+                if (rp < 1 || (rp * (int64_t)esz < 64 && rp != s)) { rp = 0; break; }
                 o = 1;
                 for (int oo = 8; oo >= 2; oo >>= 1) if (nu % oo == 0 && nu * rp / oo >= 64) { o = oo; break; }
                 while (nu * rp / o > 512 && o < 8 && nu % (o * 2) == 0) o *= 2;
@@ -954,7 +948,7 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
     T *bufs[2] = {scratch0, scratch1};
     double *dcoef[16] = {nullptr};                       // padded tap tables per (K, rows-per-thread)
     int Utab[16] = {0};
-    int omin[16] = {0};
+    std::vector<int> omin[16];                           // per descendant: smallest offset of its adjoint taps
     T *prev = nullptr;                                   // buffer holding depth plan.from[i] (nullptr = xw)
     int64_t prev_cols = 0;
     for (int i = 0; i < plan.npass; ++i) {
@@ -996,20 +990,39 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
                 const int U = (int)offs.size();
                 for (int t = 1; t < U; ++t)
                     if (offs[t] != offs[0] + t) return wx_set_error(WX_EHIP, "iswpt: composite taps are not contiguous");
-                const int UP = U + 2 * (OPT - 1), NCk = 1 << K;
+                // every descendant uses its own contiguous run of the offsets: the window slides over that run only
+                const int NCk = 1 << K;
+                std::vector<int> first(NCk, 0), len(NCk, 1);
+                int Uc = 1;
+                for (int c = 0; c < NCk; ++c) {
+                    int f = -1, l = -1;
+                    for (int t = 0; t < U; ++t) if (coef[(size_t)c * U + (U - 1 - t)] != 0.0) { if (f < 0) f = t; l = t; }
+                    if (f < 0) { f = 0; l = 0; }
+                    first[c] = f; len[c] = l - f + 1;
+                    if (len[c] > Uc) Uc = len[c];
+                }
+                const int UP = Uc + 2 * (OPT - 1);
                 std::vector<double> pad((size_t)NCk * UP, 0.0);
-                for (int c = 0; c < NCk; ++c)
-                    for (int t = 0; t < U; ++t)
-                        pad[(size_t)c * UP + (OPT - 1) + t] = coef[(size_t)c * U + (U - 1 - t)] * (K == 2 ? 0.25 : 0.125);
+                omin[slot].assign(NCk, 0);
+                for (int c = 0; c < NCk; ++c) {
+                    for (int t = 0; t < len[c]; ++t)
+                        pad[(size_t)c * UP + (OPT - 1) + t] = coef[(size_t)c * U + (U - 1 - (first[c] + t))] * (K == 2 ? 0.25 : 0.125);
+                    omin[slot][c] = -offs[U - 1 - first[c]];
+                }
                 dcoef[slot] = (double *)wx_const_upload(pad.data(), pad.size() * sizeof(double), st, true);
                 if (!dcoef[slot]) return WX_EHIP;
-                Utab[slot] = U;
-                omin[slot] = -offs[U - 1];                   // smallest offset of the adjoint taps
+                Utab[slot] = Uc;
             }
-            int64_t ustart = omin[slot] % nu;
-            if (ustart < 0) ustart += nu;
+            std::vector<int> ust(omin[slot].size());
+            for (size_t c = 0; c < ust.size(); ++c) {
+                int64_t o = omin[slot][c] % nu;
+                if (o < 0) o += nu;
+                ust[c] = (int)o;
+            }
+            const int *dust = (const int *)wx_const_upload(ust.data(), ust.size() * sizeof(int), st, true);
+            if (!dust) return WX_EHIP;
             const size_t lds = (size_t)2 * tile * sizeof(T);
-            typedef void (*KM)(const T *, int64_t, T *, int64_t, int, int64_t, int, int, const double *, int, int);
+            typedef void (*KM)(const T *, int64_t, T *, int64_t, int, int64_t, int, int, const double *, const int *, int);
             KM km = nullptr;
             if (K == 2) km = OPT == 8 ? k_swt_inv_multi<T, 4, 8> : OPT == 4 ? k_swt_inv_multi<T, 4, 4> : OPT == 2 ? k_swt_inv_multi<T, 4, 2> : k_swt_inv_multi<T, 4, 1>;
             else km = OPT == 8 ? k_swt_inv_multi<T, 8, 8> : OPT == 4 ? k_swt_inv_multi<T, 8, 4> : OPT == 2 ? k_swt_inv_multi<T, 8, 2> : k_swt_inv_multi<T, 8, 1>;
@@ -1022,7 +1035,7 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
             const int64_t src_cols = prev ? prev_cols : ncols;
             hipLaunchKernelGGL(km, dim3((unsigned)(nodes_d * (((int64_t)1 << d) / R)), (unsigned)gy), dim3(NT), lds, st,
                                srcp, src_cols, outp, out_cols, (int)n, batch, d, R, (const double *)dcoef[slot],
-                               (int)ustart, Utab[slot]);
+                               dust, Utab[slot]);
         } else {
             WxInvDesc D;
             D.in = xw; D.ncols = ncols; D.layout = layout; D.L = L; D.d = d; D.tree = dtree; D.ntree = ntree;
