@@ -8,11 +8,12 @@ TAG=$1
 mkdir -p $R/gpurun_out/bench_$TAG
 cd $R
 timeout 900 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu_$TAG.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu_$TAG.log | tail -1
-for w in cfg2 target target_n2048 target_n1024 target_haar cfg3 swpt_db4 cfg4 cfg5 bb ldb siwt; do
+WL=${WX_EVIDENCE_WORKLOADS:-cfg2 target target_n2048 target_n1024 target_haar cfg3 swpt_db4 cfg4 cfg5 bb ldb siwt}   # subset: only the workloads whose kernels changed
+for w in $WL; do
   bash tools/profile.sh $TAG $w pmc > /dev/null 2>&1
 done
 python tools/collect_evidence.py $TAG ${2:-r02} > /dev/null 2>&1      # profiles/traffic.json of this build, read by bench.py
-for w in cfg2 target target_n2048 target_n1024 target_haar cfg3 swpt_db4 cfg4 cfg5 bb ldb siwt; do
+for w in $WL; do
   timeout 600 python bench.py --workload $w > gpurun_out/bench_$TAG/$w.json 2> gpurun_out/bench_$TAG/$w.err
   tail -c 200 gpurun_out/bench_$TAG/$w.json; echo
 done

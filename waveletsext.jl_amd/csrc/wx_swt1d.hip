@@ -724,7 +724,8 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
     }
     // swpt: fuse K levels per pass (K = 3 for very short filters, else 2); the tables live in a
     // stream-ordered scratch buffer
-    const int KF = (!ac && layout == WX_LAYOUT_WPT && !wx_force_generic_swt()) ? (filt.F <= 4 ? 3 : (filt.F <= 16 ? 2 : 1)) : 1;
+    static const int kf_maxf = getenv("WX_SWTFWD_KF_MAXF") ? atoi(getenv("WX_SWTFWD_KF_MAXF")) : 16;
+    const int KF = (!ac && layout == WX_LAYOUT_WPT && !wx_force_generic_swt()) ? (filt.F <= 4 ? 3 : (filt.F <= kf_maxf ? 2 : 1)) : 1;
     double *dcoef = nullptr;
     int *dshift = nullptr;
     int d = 0;
