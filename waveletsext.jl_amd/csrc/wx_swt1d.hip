@@ -33,6 +33,18 @@ static int wx_force_generic_swt() { return wx_force_generic(); }
 
 enum { WX_LAYOUT_DWT = 0, WX_LAYOUT_WPT = 1, WX_LAYOUT_WPD = 2 };
 
+// smallest dilation at which the fused sdwt / isdwt kernels slide register windows over a residue class (below it: one
+// LDS read per tap)
+static int wx_sdwt_window_min()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("WX_SDWT_WIN_S"); v = (e && atoi(e) >= 1) ? atoi(e) : 0; }
+    return v;
+}
+// default: every level for filters of four taps or more (db4, n = 4096, L = 6: sdwt 1.48 -> 1.02 ms, isdwt 2.40 -> 1.85 ms --
+// the 4-way LDS bank conflicts of the narrow classes cost less than the tap-by-tap loop); Haar has nothing to slide over
+static int wx_sdwt_window_min_for(int F) { const int e = wx_sdwt_window_min(); return e ? e : (F >= 4 ? 1 : 16); }
+
 static __device__ __forceinline__ void wx_fwd_cols(int layout, int L, int d, int b, int &pcol, int &lcol, int &hcol)
 {
     if (layout == WX_LAYOUT_DWT) { pcol = L - d; lcol = L - d - 1; hcol = L - d; }
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(1024) void k_swt_fwd_level(const T *__restrict__ x,
 // (22 LDS reads instead of 64 for F = 8); lanes run over consecutive residues, i.e. consecutive LDS words.
 template <typename T, bool AC, int FT>
 __global__ __launch_bounds__(1024) void k_sdwt_fused(const T *__restrict__ x, T *__restrict__ xw, int n, int64_t batch,
-                                                    int L, WxFilt filt, WxAcFilt ac)
+                                                    int L, WxFilt filt, WxAcFilt ac, int wmin)
 {
     constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(1024) void k_sdwt_fused(const T *__restrict__ x, T 
             const int s = (1 << d) % n;
             T *hi = base + (int64_t)(L - d) * n;
             const int M = s > 0 ? n / s : 0;
-            if (!AC && FT > 0 && s >= 16 && M >= R && M % R == 0 && (int64_t)M * s == n) {
+            if (!AC && FT > 0 && s >= wmin && M >= R && M % R == 0 && (int64_t)M * s == n) {
                 constexpr int FW = FT > 0 ? FT : 2;
                 constexpr int WN = R + 2 * FW - 3;
                 for (int qi = threadIdx.x; qi < n / R; qi += blockDim.x) {
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_sdwt_fused(const T *__restrict__ x, T 
 // to it; HBM sees every input column once and the signal once.
 template <typename T, int FT>
 __global__ __launch_bounds__(1024) void k_isdwt_avg_fused(const T *__restrict__ xw, T *__restrict__ x, int n,
-                                                         int64_t batch, int L, WxFilt filt)
+                                                         int64_t batch, int L, WxFilt filt, int wmin)
 {
     constexpr int R = 4;
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(1024) void k_isdwt_avg_fused(const T *__restrict__ 
             __syncthreads();
             const int s = (1 << d) % n;
             const int M = s > 0 ? n / s : 0;
-            if (FT > 0 && s >= 16 && M >= R && M % R == 0 && (int64_t)M * s == n) {
+            if (FT > 0 && s >= wmin && M >= R && M % R == 0 && (int64_t)M * s == n) {
                 // R samples of one residue class per lane: r_c[u + 1 - j] and w_c[u + j] slide over R + F - 1 values each
                 constexpr int FW = FT > 0 ? FT : 2;
                 constexpr int WN = R + FW - 1;
@@ -703,13 +715,13 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
     const int nt = n >= 8192 ? 1024 : (n >= 2048 ? 512 : 256);
     if (layout == WX_LAYOUT_DWT && L >= 2 && 2 * lds <= 160 * 1024 && !wx_force_generic_swt()) {
         // sdwt / acdwt: every level in one kernel, approximation resident in LDS
-        typedef void (*KF)(const T *, T *, int, int64_t, int, WxFilt, WxAcFilt);
+        typedef void (*KF)(const T *, T *, int, int64_t, int, WxFilt, WxAcFilt, int);
         KF kf = ac ? k_sdwt_fused<T, true, 0> : k_sdwt_fused<T, false, 0>;
         if (!ac) switch (filt.F) {
 #define WX_CASE(FF) case FF: kf = k_sdwt_fused<T, false, FF>; break;
-            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12)
+            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
-            default: break;                              // longer filters: runtime tap loop (register budget)
+            default: break;                              // other lengths: runtime tap loop
         }
         if (2 * lds > 64 * 1024)
             WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf),
@@ -718,7 +730,7 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         if (per_cu > 8) per_cu = 8;
         int64_t grid = (int64_t)256 * per_cu;
         if (grid > batch) grid = batch;
-        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(nt), 2 * lds, st, x, xw, (int)n, batch, L, filt, acz);
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(nt), 2 * lds, st, x, xw, (int)n, batch, L, filt, acz, wx_sdwt_window_min_for(filt.F));
         WX_HIP_CHECK(hipGetLastError());
         return WX_OK;
     }
@@ -925,11 +937,11 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
     if (layout == WX_LAYOUT_DWT && sm < 0 && L >= 2 && (size_t)3 * n * sizeof(T) <= 160 * 1024 && !wx_force_generic_swt()) {
         // average-based isdwt: every level in one kernel
         const size_t lds3 = (size_t)3 * n * sizeof(T);
-        typedef void (*KI)(const T *, T *, int, int64_t, int, WxFilt);
+        typedef void (*KI)(const T *, T *, int, int64_t, int, WxFilt, int);
         KI ki = k_isdwt_avg_fused<T, 0>;
         switch (filt.F) {
 #define WX_CASE(FF) case FF: ki = k_isdwt_avg_fused<T, FF>; break;
-            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12)
+            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
             default: break;
         }
@@ -941,7 +953,7 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
         int64_t grid = (int64_t)256 * per_cu;
         if (grid > batch) grid = batch;
         const int nt = n >= 4096 ? 1024 : (n >= 1024 ? 512 : 256);
-        hipLaunchKernelGGL(ki, dim3((unsigned)grid), dim3(nt), lds3, st, xw, x, (int)n, batch, L, filt);
+        hipLaunchKernelGGL(ki, dim3((unsigned)grid), dim3(nt), lds3, st, xw, x, (int)n, batch, L, filt, wx_sdwt_window_min_for(filt.F));
         WX_HIP_CHECK(hipGetLastError());
         return WX_OK;
     }
