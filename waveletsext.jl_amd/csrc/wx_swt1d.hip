@@ -201,7 +201,7 @@ __global__ __launch_bounds__(1024) void k_sdwt_fused(const T *__restrict__ x, T 
 //   r_d[p] = 1/2 sum_j q[j] r_{d+1}[p + (1-j) s] + (-1)^j q[j] w_d[p + j s],   s = 2^d,
 // r_L = column 0, w_d = detail column L-d.  r ping-pongs in LDS, the detail column of the level is staged next
 // to it; HBM sees every input column once and the signal once.
-template <typename T, int FT>
+template <typename T, int FT, bool PIPE>
 __global__ __launch_bounds__(1024) void k_isdwt_avg_fused(const T *__restrict__ xw, T *__restrict__ x, int n,
                                                          int64_t batch, int L, WxFilt filt, int wmin)
 {
@@ -210,13 +210,42 @@ __global__ __launch_bounds__(1024) void k_isdwt_avg_fused(const T *__restrict__ 
     T *a = reinterpret_cast<T *>(wx_smem);
     T *b = a + n;
     T *wd = b + n;
+    // PIPE (the host sets it when a CU holds a single workgroup and n <= PF blockDim.x): the detail column of the next level
+    // is fetched into registers while the current level is computed -- a load issued only after the level's barrier left
+    // HBM idle for its whole latency, L + 1 times per signal (now once, for the first two columns).  With several
+    // workgroups per CU the other workgroups cover the latency and the registers are better spent on occupancy.
+    constexpr int PF = PIPE ? 32 / sizeof(T) : 1;
+    T pre[PF];
+    const int NT = blockDim.x;
     for (int64_t sig = blockIdx.x; sig < batch; sig += gridDim.x) {
         const T *base = xw + sig * (int64_t)n * (L + 1);
+        if (PIPE) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int i = threadIdx.x + k * NT;
+                pre[k] = i < n ? base[n + i] : (T)0;
+            }
+        }
         wx_stage<T>(a, base, n);
         T *r = a, *rn = b;
         for (int d = L - 1; d >= 0; --d) {
-            const T *wcol = base + (int64_t)(L - d) * n;
-            wx_stage<T>(wd, wcol, n);
+            if (PIPE) {
+#pragma unroll
+                for (int k = 0; k < PF; ++k) {
+                    const int i = threadIdx.x + k * NT;
+                    if (i < n) wd[i] = pre[k];
+                }
+                if (d > 0) {
+                    const T *wnext = base + (int64_t)(L - d + 1) * n;
+#pragma unroll
+                    for (int k = 0; k < PF; ++k) {
+                        const int i = threadIdx.x + k * NT;
+                        pre[k] = i < n ? wnext[i] : (T)0;
+                    }
+                }
+            } else {
+                wx_stage<T>(wd, base + (int64_t)(L - d) * n, n);
+            }
             __syncthreads();
             const int s = (1 << d) % n;
             const int M = s > 0 ? n / s : 0;
@@ -938,9 +967,13 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
         // average-based isdwt: every level in one kernel
         const size_t lds3 = (size_t)3 * n * sizeof(T);
         typedef void (*KI)(const T *, T *, int, int64_t, int, WxFilt, int);
-        KI ki = k_isdwt_avg_fused<T, 0>;
+        int per_cu = (int)((160 * 1024) / lds3);
+        if (per_cu > 8) per_cu = 8;
+        const int nt = n >= 4096 ? 1024 : (n >= 1024 ? 512 : 256);
+        const bool pipe = per_cu == 1 && n <= (int64_t)(32 / sizeof(T)) * nt;
+        KI ki = pipe ? k_isdwt_avg_fused<T, 0, true> : k_isdwt_avg_fused<T, 0, false>;
         switch (filt.F) {
-#define WX_CASE(FF) case FF: ki = k_isdwt_avg_fused<T, FF>; break;
+#define WX_CASE(FF) case FF: ki = pipe ? k_isdwt_avg_fused<T, FF, true> : k_isdwt_avg_fused<T, FF, false>; break;
             WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
             default: break;
@@ -948,11 +981,8 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
         if (lds3 > 64 * 1024)
             WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-        int per_cu = (int)((160 * 1024) / lds3);
-        if (per_cu > 8) per_cu = 8;
         int64_t grid = (int64_t)256 * per_cu;
         if (grid > batch) grid = batch;
-        const int nt = n >= 4096 ? 1024 : (n >= 1024 ? 512 : 256);
         hipLaunchKernelGGL(ki, dim3((unsigned)grid), dim3(nt), lds3, st, xw, x, (int)n, batch, L, filt, wx_sdwt_window_min_for(filt.F));
         WX_HIP_CHECK(hipGetLastError());
         return WX_OK;
