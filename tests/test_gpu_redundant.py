@@ -276,3 +276,28 @@ def test_deep_levels_of_swpd_and_acwpd_tables(wx, oracle):
             assert relerr(wx.swpdall(x, wt, L), exp) <= 1e-12, (wname, L)
             expa = np.stack([oracle.acwpd(x[:, b], wt.qmf, L) for b in range(2)], axis=-1)
             assert relerr(wx.acwpdall(x, wt, L), expa) <= 1e-12, (wname, L)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db4", "db6", "db8", "coif6", "db10"])
+def test_fused_sdwt_isdwt_at_one_workgroup_per_cu(wx, oracle, wname):
+    """sdwt / average isdwt of 4096-sample Float64 signals: the all-levels kernels (csrc/wx_swt1d.hip) with register windows at
+    every dilation, compile-time taps up to 20, and -- three 32 KiB arrays, one workgroup per CU -- the inverse that fetches
+    the next detail column under the current level; more signals than workgroups so that a workgroup walks several.
+    swt/swt_one_level.jl:99-127, 257-318, SWT.jl:86-110, 286-325"""
+    rng = np.random.default_rng(2026)
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    n, B = 4096, 300
+    x = np.asfortranarray(rng.standard_normal((n, B)))
+    for L in (2, 7, 12):
+        sd = wx.to_numpy(wx.sdwtall(x, wt, L))
+        for b in (0, 1, 255, 256, 299):
+            assert relerr(sd[:, :, b], oracle.sdwt(x[:, b], wt.qmf, L)) <= 1e-12, (wname, L, b)
+        xr = wx.to_numpy(wx.isdwtall(sd, wt))
+        assert relerr(xr, x) <= 1e-10, (wname, L)
+        for b in (0, 256, 299):
+            assert relerr(xr[:, b], oracle.isdwt(np.asfortranarray(sd[:, :, b]), wt.qmf, None)) <= 1e-12, (wname, L, b)
+    # Float32 signals of 8192 samples: 96 KiB of LDS, the same pipeline with eight values per thread
+    x32 = np.asfortranarray(rng.standard_normal((8192, 260)).astype(np.float32))
+    sd32 = wx.to_numpy(wx.sdwtall(x32, wt, 9))
+    assert relerr(sd32[:, :, 259], oracle.sdwt(x32[:, 259], wt.qmf, 9)) <= 1e-5, wname
+    assert relerr(wx.to_numpy(wx.isdwtall(sd32, wt)), x32) <= 5e-4, wname
