@@ -315,6 +315,8 @@ static int api_acwpd_jbb_moments(const double *x, double *sum, double *sumsq, in
         const int64_t ncols_top = ((int64_t)1 << (D0 + 1)) - 1;
         const int64_t nk_top = n * ncols_top;
         int64_t chunk = ((int64_t)8 << 30) / (int64_t)(sizeof(double) * nk_top);
+        static const int64_t chunk_env = getenv("WX_ACWPD_CHUNK") ? atoll(getenv("WX_ACWPD_CHUNK")) : 0;   // signals per pass (experiment: table in the Infinity Cache)
+        if (chunk_env > 0 && chunk_env < chunk) chunk = chunk_env;
         if (chunk < 1) chunk = 1;
         if (chunk > batch) chunk = batch;
         double *tab = batch ? (double *)scr.alloc(sizeof(double) * nk_top * chunk) : nullptr;
