@@ -20,11 +20,12 @@ def _wt(wx, name):
 
 @pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "db6", "db7", "db8", "coif6", "db10"])
 def test_lattice_every_depth_matches_oracle(wx, oracle, wname):
-    """dwt/dwt_all.jl:152-166, 210-225 over Wavelets.jl's wpt / iwpt by level, every depth the lattice kernels take"""
+    """dwt/dwt_all.jl:152-166, 210-225 over Wavelets.jl's wpt / iwpt by level, every depth the lattice kernels take
+    (depths 1 .. 5: csrc/wx_lattice_lo.hip for filters of up to eight taps, the fused LDS kernels for the longer ones)"""
     rng = np.random.default_rng(4096)
     wt = _wt(wx, wname)
     n, B = 4096, 3
-    for L in range(6, 13):
+    for L in range(1, 13):
         x = np.asfortranarray(rng.standard_normal((n, B)))
         exp = oracle.wptall(x, wt.qmf, L)
         got = wx.wptall(x, wt, L)
@@ -82,6 +83,10 @@ def test_config2_inverse_reads_the_packet_table(wx, oracle):
     for Lp in (6, 9):                                     # shallower full trees of the same table
         exp = oracle.iwpdall(tab, wt.qmf, Lp)
         assert relerr(wx.iwpdall(tab, wt, Lp), exp) <= 1e-10
+    wt4 = _wt(wx, "db4")                                  # depths 1 .. 5: the shallow lattice inverse on row L of the table
+    tab4 = oracle.wpdall(x, wt4.qmf, 7)
+    for Lp in (1, 2, 3, 4, 5):
+        assert relerr(wx.iwpdall(tab4, wt4, Lp), oracle.iwpdall(tab4, wt4.qmf, Lp)) <= 1e-10, Lp
 
 
 def test_lattice_batches_larger_than_one_wave_of_workgroups(wx, oracle):

@@ -110,6 +110,8 @@ int wx_lattice_launch_sh(bool inverse, const double *x, double *y, int64_t n, in
 int wx_lattice_launch_g(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                         const WxFilt &filt, hipStream_t st);           // wx_lattice_sg.hip
 int wx_lattice_wpd_g_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);   // wx_lattice_sgw.hip
+int wx_lattice_launch_lo(bool inverse, const double *x, double *y, int L, int64_t batch, int64_t in_stride, const WxFilt &filt,
+                         hipStream_t st);                              // wx_lattice_lo.hip
 
 static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                              const WxFilt &filt, hipStream_t st)
@@ -120,6 +122,8 @@ static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n
         return wx_lattice_launch_sh(inverse, x, y, n, L, batch, inverse ? in_stride : n, filt, st);
     if (!off && !off_sh && n >= 64 && n <= 512)
         return wx_lattice_launch_g(inverse, x, y, n, L, batch, inverse ? in_stride : n, filt, st);
+    static const bool off_lo = getenv("WX_LATTICE_LO") && atoi(getenv("WX_LATTICE_LO")) == 0;
+    if (!off && !off_lo && n == 4096 && L >= 1 && L <= 5) return wx_lattice_launch_lo(inverse, x, y, L, batch, inverse ? in_stride : n, filt, st);
     if (off || n != 4096 || L < 6 || L > 12 || filt.F < 2 || batch <= 0) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     if (inverse && (in_stride & 3)) return 0;
