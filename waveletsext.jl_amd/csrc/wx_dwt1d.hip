@@ -734,6 +734,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int j = 2 * jj + c;
+                    if (!to_global && !node_active(d, j)) continue;           // sparse trees (the dwt pyramid): nothing to read
                     const int pp = j & 1, idx = j >> 1;
                     const V2 ev = pp ? E1[idx] : E0[idx];
                     const V2 ov = pp ? O1[idx] : O0[idx];
@@ -762,6 +763,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd1d_inplace(const T *__restrict__ x
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int u = 2 * uu + c;
+                    if (!to_global && !node_active(d, 2 * u) && !node_active(d, 2 * u + 1)) continue;
                     const int pp = u & 1, idx = u >> 1;
                     const V2 ev = pp ? E1[idx] : E0[idx];
                     const V2 ov = pp ? O1[idx] : O0[idx];
