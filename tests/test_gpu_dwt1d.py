@@ -182,6 +182,33 @@ def test_dwtall_is_the_dwt_tree_packet_transform(wx, oracle):
     assert relerr(wx.idwtall(yi, wt), img) <= 1e-10
 
 
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db8", "coif6", "db10"])
+def test_pyramid_deep_levels_in_the_registers_of_a_lane(wx, oracle, wname):
+    """dwtall to depths where the approximation has fewer than 64 samples: the tree-driven kernel stops at 64 samples and
+    csrc/wx_dwttail.hip finishes the pyramid, one lane per signal (dwt/dwt_all.jl:39-54, dwt/dwt_one_level.jl:79-107);
+    more signals than one wavefront, a ragged last wavefront, Float64 and Float32, wpt with the same tree, idwtall back"""
+    rng = np.random.default_rng(808)
+    wt = _wt(wx, wname)
+    for n, B in ((128, 70), (1024, 130), (4096, 67)):
+        Lmax = int(np.log2(n))
+        x = np.asfortranarray(rng.standard_normal((n, B)))
+        for L in range(Lmax - 6 + 1, Lmax + 1):
+            exp = oracle.wptall(x, wt.qmf, wx.maketree(n, L, "dwt"))
+            y = wx.dwtall(x, wt, L)
+            assert relerr(y, exp) <= 1e-12, (wname, n, L)
+            assert relerr(wx.to_numpy(wx.wptall(wx.to_device(x), wt, wx.maketree(n, L, "dwt"))), exp) <= 1e-12, (wname, n, L)
+            assert relerr(wx.idwtall(y, wt, L), x) <= 1e-10, (wname, n, L)
+        x32 = x.astype(np.float32)
+        y32 = wx.dwtall(x32, wt)
+        assert y32.dtype == np.float32
+        assert relerr(y32, oracle.wptall(x32, wt.qmf, wx.maketree(n, Lmax, "dwt"))) <= 1e-5, (wname, n)
+    # a tree that is not the pyramid keeps the tree-driven kernel for every level
+    tree = wx.maketree(1024, 10, "dwt").copy()
+    tree[2] = True                                         # node 3 (the first detail) decomposed once
+    x = np.asfortranarray(rng.standard_normal((1024, 9)))
+    assert relerr(wx.wptall(x, wt, tree), oracle.wptall(x, wt.qmf, tree)) <= 1e-12
+
+
 def test_native_rccl_exchange_single_rank(wx):
     """the library's own RCCL entry points (C1 all-gather, C2 all-reduce) with a one-rank communicator:
     plumbing, dtype dispatch and stream ordering; multi-rank behaviour is RCCL's"""

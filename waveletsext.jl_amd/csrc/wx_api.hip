@@ -104,6 +104,19 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     else WX_REQUIRE(wx_isdyadic(n) && 0 <= L && L <= wx_maxtransformlevels(n), WX_EASSERT,
                     "maketree: isdyadic(n) and 0 <= L <= maxtransformlevels(n)");
     if ((rc = wx_need_device())) return rc;
+    // the pyramid (dwt / dwtall): the levels from 64 samples down run in the registers of a lane (wx_dwttail.hip)
+    int tail = 0;
+    std::vector<uint8_t> ttree;
+    if (!INVERSE && tree && !wx_force_generic()) {
+        const int Ld = wx_tree_depth1d(tree, ntree);
+        bool pyramid = Ld >= 1;
+        for (int64_t i = 1; i <= ntree && pyramid; ++i) pyramid = (tree[i - 1] != 0) == ((i & (i - 1)) == 0 && i < ((int64_t)1 << Ld));
+        if (pyramid && (tail = wx_dwt_tail_levels(n, Ld, F, sizeof(T)))) {
+            ttree.assign(tree, tree + ntree);
+            for (int64_t i = (int64_t)1 << (Ld - tail); i <= ntree; ++i) ttree[i - 1] = 0;
+            tree = ttree.data();
+        }
+    }
     if ((rc = wx_resolve_tree1d(n, L, tree, ntree, scr, &tr, "wpt"))) return rc;
     WxIO io(st);
     const T *dx = (const T *)io.in(x, sizeof(T) * n * batch);
@@ -122,6 +135,7 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
         rc = wx_dev_iwpt1d<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, nullptr, 0, n, s1, nullptr, st, force);
     else
         rc = wx_dev_wpt1d<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, s1, st, force);
+    if (rc == WX_OK && tail) rc = wx_dwt_tail<T>(dy, n, tail, batch, filt, st);
     return io.finish(rc);
 }
 

@@ -1,0 +1,89 @@
+// wx_dwttail.hip -- the deep levels of the wavelet pyramid (dwt / dwtall: the tree whose only decomposed nodes are the
+// approximations) in the registers of a lane.
+//
+// Reference: dwt! of Wavelets.jl as called by dwtall (dwt/dwt_all.jl:39-54) = wpt with maketree(n, L, :dwt); one level is
+// dwt_step! (dwt/dwt_one_level.jl:79-107): a[t] = sum_k q[k] v[(2t + k) mod m], d[t] = sum_k (-1)^k q[k] v[(2t + 1 - k) mod m].
+//
+// In the fused LDS kernels (wx_dwt1d.hip) every level of a tree is a dependent chain with a wavefront-level fence, and below
+// 512 samples one wavefront of the workgroup runs it while the others wait: 0.07 ms per level and launch for 65536 signals,
+// although the levels from 64 samples down hold 1.6 % of the data.  Here the tree-driven kernel stops at the depth where the
+// approximation has 64 samples, and one LANE per signal finishes the pyramid: 64 values in registers, every level unrolled
+// with compile-time indices (the taps wrap inside the node by masking), results written back over the 64 values as
+// [a_L | d_L | ... ] -- the layout of the pyramid.  33 MB of traffic for 65536 signals of 4096 Float64 samples.
+#include "wx_common.h"
+#include "wx_kernels.h"
+#include "wx_host.h"
+#include <cstdlib>
+
+namespace {
+
+template <int F, int M>
+__device__ __forceinline__ void tail_level(double (&v)[64], const WxFilt &filt)
+{
+    double a[M / 2], d[M / 2];
+#pragma unroll
+    for (int t = 0; t < M / 2; ++t) {
+        double sa = 0.0, sd = 0.0;
+#pragma unroll
+        for (int k = 0; k < F; ++k) {
+            sa = fma(filt.q[k], v[(2 * t + k) & (M - 1)], sa);
+            sd = fma((k & 1) ? -filt.q[k] : filt.q[k], v[(2 * t + 1 - k) & (M - 1)], sd);
+        }
+        a[t] = sa; d[t] = sd;
+    }
+#pragma unroll
+    for (int t = 0; t < M / 2; ++t) { v[t] = a[t]; v[M / 2 + t] = d[t]; }
+}
+
+// y: (n, batch), the first 64 samples of every signal hold the approximation of depth log2(n) - 6; Lt = 1 .. 6 more levels
+template <typename T, int F>
+__global__ __launch_bounds__(64) void k_dwt_tail(T *__restrict__ y, int64_t n, int64_t batch, int Lt, WxFilt filt)
+{
+    const int64_t sig = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (sig >= batch) return;
+    T *p = y + sig * n;
+    double v[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = (double)p[i];
+    tail_level<F, 64>(v, filt);
+    if (Lt >= 2) tail_level<F, 32>(v, filt);
+    if (Lt >= 3) tail_level<F, 16>(v, filt);
+    if (Lt >= 4) tail_level<F, 8>(v, filt);
+    if (Lt >= 5) tail_level<F, 4>(v, filt);
+    if (Lt >= 6) tail_level<F, 2>(v, filt);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) p[i] = (T)v[i];
+}
+
+}  // namespace
+
+// number of levels the tail takes off the end of a pyramid of depth L (0 = none): the tree-driven kernel then runs L - that
+int wx_dwt_tail_levels(int64_t n, int L, int F, size_t esz)
+{
+    static const bool off = getenv("WX_DWT_TAIL") && atoi(getenv("WX_DWT_TAIL")) == 0;
+    if (off || (esz != 8 && esz != 4) || n < 128 || (n & (n - 1))) return 0;
+    switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 16: case 18: case 20: break; default: return 0; }
+    int log2n = 0;
+    while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
+    const int Ls = log2n - 6;
+    return L - Ls >= 2 ? L - Ls : 0;
+}
+
+template <typename T>
+int wx_dwt_tail(T *y, int64_t n, int Lt, int64_t batch, const WxFilt &filt, hipStream_t st)
+{
+    if (batch <= 0) return WX_OK;
+    typedef void (*KT)(T *, int64_t, int64_t, int, WxFilt);
+    KT k = nullptr;
+    switch (filt.F) {
+#define WX_TL(FF) case FF: k = k_dwt_tail<T, FF>; break;
+        WX_TL(2) WX_TL(4) WX_TL(6) WX_TL(8) WX_TL(10) WX_TL(12) WX_TL(16) WX_TL(18) WX_TL(20)
+#undef WX_TL
+        default: return wx_set_error(WX_EHIP, "dwt tail: unsupported filter length");
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, y, n, batch, Lt, filt);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+template int wx_dwt_tail<double>(double *, int64_t, int, int64_t, const WxFilt &, hipStream_t);
+template int wx_dwt_tail<float>(float *, int64_t, int, int64_t, const WxFilt &, hipStream_t);
