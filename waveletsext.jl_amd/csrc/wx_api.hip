@@ -107,11 +107,14 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     // the pyramid (dwt / dwtall): the levels from 64 samples down run in the registers of a lane (wx_dwttail.hip)
     int tail = 0;
     std::vector<uint8_t> ttree;
-    if (!INVERSE && tree && !wx_force_generic()) {
+    if (tree && !wx_force_generic()) {
         const int Ld = wx_tree_depth1d(tree, ntree);
         bool pyramid = Ld >= 1;
         for (int64_t i = 1; i <= ntree && pyramid; ++i) pyramid = (tree[i - 1] != 0) == ((i & (i - 1)) == 0 && i < ((int64_t)1 << Ld));
-        if (pyramid && (tail = wx_dwt_tail_levels(n, Ld, F, sizeof(T)))) {
+        // (the inverse feeds the 64 rebuilt samples to the loads of the fused tree-driven kernel: that kernel must apply and
+        // the remaining pyramid must not be a full tree, which takes other kernels)
+        if (pyramid && (!INVERSE || (wx_fused1d_ok<T>(n, F) && Ld - wx_dwt_tail_levels(n, Ld, F, sizeof(T)) >= 2)) &&
+            (tail = wx_dwt_tail_levels(n, Ld, F, sizeof(T)))) {
             ttree.assign(tree, tree + ntree);
             for (int64_t i = (int64_t)1 << (Ld - tail); i <= ntree; ++i) ttree[i - 1] = 0;
             tree = ttree.data();
@@ -131,11 +134,18 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
         s1 = (T *)scr.alloc(sizeof(T) * n * batch);
         if (!s1) return io.finish(WX_EHIP);
     }
-    if (INVERSE)
+    if (INVERSE && tail && batch) {
+        T *head = (T *)scr.alloc(sizeof(T) * 64 * batch);
+        if (!head) return io.finish(WX_EHIP);
+        rc = wx_idwt_tail<T>(dx, head, n, tail, batch, filt, st);
+        WxThreshArg thr{nullptr, 0, 0, 0, 1.0};
+        thr.head = head;
+        if (rc == WX_OK) rc = wx_dev_iwpt1d_thresh<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, thr, st);
+    } else if (INVERSE)
         rc = wx_dev_iwpt1d<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, nullptr, 0, n, s1, nullptr, st, force);
     else
         rc = wx_dev_wpt1d<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, s1, st, force);
-    if (rc == WX_OK && tail) rc = wx_dwt_tail<T>(dy, n, tail, batch, filt, st);
+    if (rc == WX_OK && tail && !INVERSE) rc = wx_dwt_tail<T>(dy, n, tail, batch, filt, st);
     return io.finish(rc);
 }
 

@@ -59,6 +59,7 @@ struct WxThreshArg {
     const void *t;
     int kind, lo, per_signal;
     double scale;               // threshold = t[...] * scale (sigma_i * dnt.t with sigma left on the device)
+    const void *head = nullptr; // idwt of a pyramid: samples 0 .. 63 of signal s come from head + 64 s (wx_dwttail.hip)
 };
 
 static __device__ __forceinline__ int wx_modn(int x, int n)

@@ -55,6 +55,52 @@ __global__ __launch_bounds__(64) void k_dwt_tail(T *__restrict__ y, int64_t n, i
     for (int i = 0; i < 64; ++i) p[i] = (T)v[i];
 }
 
+// idwt_step! (dwt/dwt_one_level.jl:192-223) on [a (M/2) | d (M/2)] -> M samples:
+// x[2t] = sum_m q[2m] a[t - m] - q[2m+1] d[t + m], x[2t+1] = sum_m q[2m+1] a[t - m] + q[2m] d[t + m]  (indices mod M/2)
+template <int F, int M>
+__device__ __forceinline__ void tail_ilevel(double (&v)[64], const WxFilt &filt)
+{
+    constexpr int H = M / 2;
+    double o[M];
+#pragma unroll
+    for (int t = 0; t < H; ++t) {
+        double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < F / 2; ++m) {
+            const double av = v[(t - m) & (H - 1)], dv = v[H + ((t + m) & (H - 1))];
+            v0 = fma(filt.q[2 * m], av, v0);
+            v0 = fma(-filt.q[2 * m + 1], dv, v0);
+            v1 = fma(filt.q[2 * m + 1], av, v1);
+            v1 = fma(filt.q[2 * m], dv, v1);
+        }
+        o[2 * t] = v0; o[2 * t + 1] = v1;
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) v[i] = o[i];
+}
+
+// xw: (n, batch) pyramids of depth log2(n) - 6 + Lt; head: (64, batch) <- the approximation of depth log2(n) - 6
+template <typename T, int F>
+__global__ __launch_bounds__(64) void k_idwt_tail(const T *__restrict__ xw, T *__restrict__ head, int64_t n, int64_t batch, int Lt,
+                                                  WxFilt filt)
+{
+    const int64_t sig = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (sig >= batch) return;
+    const T *p = xw + sig * n;
+    double v[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = (double)p[i];
+    if (Lt >= 6) tail_ilevel<F, 2>(v, filt);
+    if (Lt >= 5) tail_ilevel<F, 4>(v, filt);
+    if (Lt >= 4) tail_ilevel<F, 8>(v, filt);
+    if (Lt >= 3) tail_ilevel<F, 16>(v, filt);
+    if (Lt >= 2) tail_ilevel<F, 32>(v, filt);
+    tail_ilevel<F, 64>(v, filt);
+    T *o = head + sig * 64;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) o[i] = (T)v[i];
+}
+
 }  // namespace
 
 // number of levels the tail takes off the end of a pyramid of depth L (0 = none): the tree-driven kernel then runs L - that
@@ -87,3 +133,22 @@ int wx_dwt_tail(T *y, int64_t n, int Lt, int64_t batch, const WxFilt &filt, hipS
 }
 template int wx_dwt_tail<double>(double *, int64_t, int, int64_t, const WxFilt &, hipStream_t);
 template int wx_dwt_tail<float>(float *, int64_t, int, int64_t, const WxFilt &, hipStream_t);
+
+template <typename T>
+int wx_idwt_tail(const T *xw, T *head, int64_t n, int Lt, int64_t batch, const WxFilt &filt, hipStream_t st)
+{
+    if (batch <= 0) return WX_OK;
+    typedef void (*KT)(const T *, T *, int64_t, int64_t, int, WxFilt);
+    KT k = nullptr;
+    switch (filt.F) {
+#define WX_TL(FF) case FF: k = k_idwt_tail<T, FF>; break;
+        WX_TL(2) WX_TL(4) WX_TL(6) WX_TL(8) WX_TL(10) WX_TL(12) WX_TL(16) WX_TL(18) WX_TL(20)
+#undef WX_TL
+        default: return wx_set_error(WX_EHIP, "idwt tail: unsupported filter length");
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, xw, head, n, batch, Lt, filt);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+template int wx_idwt_tail<double>(const double *, double *, int64_t, int, int64_t, const WxFilt &, hipStream_t);
+template int wx_idwt_tail<float>(const float *, float *, int64_t, int, int64_t, const WxFilt &, hipStream_t);
