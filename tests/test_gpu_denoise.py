@@ -183,3 +183,20 @@ def test_device_resident_pipeline_equals_the_host_staged_one(wx, oracle, inputty
     for i in range(2):
         exp = oracle.denoise(xw[:, i], "dwt", wt.qmf, L=5, th="soft", smooth=smooth)
         assert relerr(y[:, i], exp) <= 1e-10
+
+
+@pytest.mark.parametrize("smooth", ["regular", "undersmooth"])
+def test_denoise_dwt_full_depth_pyramid_tail(wx, oracle, smooth):
+    """denoiseall(:dwt) at the default (maximum) depth: the thresholded pyramid's levels below 64 samples are rebuilt lane-locally
+    (csrc/wx_dwttail.hip, threshold on its loads) and handed to the fused inverse; Denoising.jl:510-533 against the oracle"""
+    rng = np.random.default_rng(99)
+    wt = wx.wavelet(wx.WT.db4)
+    for n, B in ((1024, 70), (4096, 3)):
+        L = int(np.log2(n))
+        x = np.asfortranarray(rng.standard_normal((n, B)) + np.sin(np.arange(n) / 11.0)[:, None] * 3)
+        xw = wx.dwtall(x, wt)
+        for thname, th in (("hard", wx.HardTH()), ("soft", wx.SoftTH())):
+            y = wx.denoiseall(xw, "dwt", wt, dnt=wx.VisuShrink(n, th), smooth=smooth)
+            for i in (0, B - 1):
+                exp = oracle.denoise(xw[:, i], "dwt", wt.qmf, L=L, th=thname, smooth=smooth)
+                assert relerr(y[:, i], exp) <= 1e-10, (n, thname, smooth, i)

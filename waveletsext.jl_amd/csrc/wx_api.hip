@@ -86,6 +86,24 @@ static int wx_resolve_tree1d(int64_t n, int L, const uint8_t *tree, int64_t ntre
     return WX_OK;
 }
 
+// tree = the pyramid of depth Ld and its deep levels can run lane-locally (wx_dwttail.hip): returns the number of those
+// levels and the pyramid cut above them in `cut`; 0 otherwise.  The inverse feeds the 64 rebuilt samples to the loads of the
+// fused tree-driven kernel: that kernel must apply, and the remaining pyramid must not be a full tree (other kernels).
+template <typename T>
+static int wx_pyramid_tail(int64_t n, int F, bool inverse, const uint8_t *tree, int64_t ntree, std::vector<uint8_t> &cut)
+{
+    if (!tree || wx_force_generic()) return 0;
+    const int Ld = wx_tree_depth1d(tree, ntree);
+    bool pyramid = Ld >= 1;
+    for (int64_t i = 1; i <= ntree && pyramid; ++i) pyramid = (tree[i - 1] != 0) == ((i & (i - 1)) == 0 && i < ((int64_t)1 << Ld));
+    if (!pyramid) return 0;
+    const int tail = wx_dwt_tail_levels(n, Ld, F, sizeof(T));
+    if (!tail || (inverse && !(wx_fused1d_ok<T>(n, F) && Ld - tail >= 2))) return 0;
+    cut.assign(tree, tree + ntree);
+    for (int64_t i = (int64_t)1 << (Ld - tail); i <= ntree; ++i) cut[i - 1] = 0;
+    return tail;
+}
+
 // ---- wpt / iwpt ---------------------------------------------------------------------------
 template <typename T, bool INVERSE>
 static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
@@ -105,21 +123,9 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
                     "maketree: isdyadic(n) and 0 <= L <= maxtransformlevels(n)");
     if ((rc = wx_need_device())) return rc;
     // the pyramid (dwt / dwtall): the levels from 64 samples down run in the registers of a lane (wx_dwttail.hip)
-    int tail = 0;
     std::vector<uint8_t> ttree;
-    if (tree && !wx_force_generic()) {
-        const int Ld = wx_tree_depth1d(tree, ntree);
-        bool pyramid = Ld >= 1;
-        for (int64_t i = 1; i <= ntree && pyramid; ++i) pyramid = (tree[i - 1] != 0) == ((i & (i - 1)) == 0 && i < ((int64_t)1 << Ld));
-        // (the inverse feeds the 64 rebuilt samples to the loads of the fused tree-driven kernel: that kernel must apply and
-        // the remaining pyramid must not be a full tree, which takes other kernels)
-        if (pyramid && (!INVERSE || (wx_fused1d_ok<T>(n, F) && Ld - wx_dwt_tail_levels(n, Ld, F, sizeof(T)) >= 2)) &&
-            (tail = wx_dwt_tail_levels(n, Ld, F, sizeof(T)))) {
-            ttree.assign(tree, tree + ntree);
-            for (int64_t i = (int64_t)1 << (Ld - tail); i <= ntree; ++i) ttree[i - 1] = 0;
-            tree = ttree.data();
-        }
-    }
+    const int tail = wx_pyramid_tail<T>(n, F, INVERSE, tree, ntree, ttree);
+    if (tail) tree = ttree.data();
     if ((rc = wx_resolve_tree1d(n, L, tree, ntree, scr, &tr, "wpt"))) return rc;
     WxIO io(st);
     const T *dx = (const T *)io.in(x, sizeof(T) * n * batch);
@@ -137,8 +143,8 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     if (INVERSE && tail && batch) {
         T *head = (T *)scr.alloc(sizeof(T) * 64 * batch);
         if (!head) return io.finish(WX_EHIP);
-        rc = wx_idwt_tail<T>(dx, head, n, tail, batch, filt, st);
         WxThreshArg thr{nullptr, 0, 0, 0, 1.0};
+        rc = wx_idwt_tail<T>(dx, head, n, tail, batch, filt, thr, st);
         thr.head = head;
         if (rc == WX_OK) rc = wx_dev_iwpt1d_thresh<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, thr, st);
     } else if (INVERSE)
@@ -169,6 +175,9 @@ static int api_iwpt1d_thresh(const T *x, T *y, int64_t n, int L, const uint8_t *
     else WX_REQUIRE(wx_isdyadic(n) && 0 <= L && L <= wx_maxtransformlevels(n), WX_EASSERT,
                     "maketree: isdyadic(n) and 0 <= L <= maxtransformlevels(n)");
     if ((rc = wx_need_device())) return rc;
+    std::vector<uint8_t> ttree;
+    const int tail = wx_pyramid_tail<T>(n, F, true, tree, ntree, ttree);      // denoise(:dwt): the pyramid's deep levels lane-locally
+    if (tail) tree = ttree.data();
     if ((rc = wx_resolve_tree1d(n, L, tree, ntree, scr, &tr, "iwpt"))) return rc;
     WxIO io(st);
     const T *dx = (const T *)io.in(x, sizeof(T) * n * batch);
@@ -178,9 +187,16 @@ static int api_iwpt1d_thresh(const T *x, T *y, int64_t n, int L, const uint8_t *
     if (batch == 0) return io.finish(WX_OK);
     const int per = nt == batch && batch > 1 ? 1 : 0;
     if (tr.Leff >= 1 && !wx_force_generic() && wx_iwpt1d_thresh_fusable<T>(n, F, tr.dstatus)) {
-        const WxThreshArg thr{dt, th_kind, (int)row_lo, per, scale};
+        WxThreshArg thr{dt, th_kind, (int)row_lo, per, scale};
+        if (tail) {
+            T *head = (T *)scr.alloc(sizeof(T) * 64 * batch);
+            if (!head) return io.finish(WX_EHIP);
+            if ((rc = wx_idwt_tail<T>(dx, head, n, tail, batch, filt, thr, st))) return io.finish(rc);
+            thr.head = head;
+        }
         return io.finish(wx_dev_iwpt1d_thresh<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, thr, st));
     }
+    if (tail) return io.finish(wx_set_error(WX_EHIP, "iwpt: inconsistent pyramid plan"));
     // other kernels (full trees on the lattice, long signals, L = 0): threshold into a scratch copy, then the inverse
     T *xt = (T *)scr.alloc(sizeof(T) * n * batch);
     if (!xt) return io.finish(WX_EHIP);

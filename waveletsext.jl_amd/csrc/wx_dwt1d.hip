@@ -854,7 +854,7 @@ __global__ __launch_bounds__(NT, 4) void k_inv1d_fused(const T *__restrict__ xw,
                 } else {
                     V4 v = (thr.head && u < 16) ? reinterpret_cast<const V4 *>(reinterpret_cast<const T *>(thr.head) + sig * 64)[u]
                                                 : reinterpret_cast<const V4 *>(xs)[u];
-                    if (thr.t) {                 // denoise: the threshold rides on the load (rows >= thr.lo)
+                    if (thr.t && !(thr.head && u < 16)) {   // denoise: the threshold rides on the load (rows >= thr.lo)
                         const T tt = (T)((double)reinterpret_cast<const T *>(thr.t)[thr.per_signal ? sig : 0] * thr.scale);
                         if (4 * u >= thr.lo) v.x = wx_thresh<T>(v.x, tt, thr.kind);
                         if (4 * u + 1 >= thr.lo) v.y = wx_thresh<T>(v.y, tt, thr.kind);

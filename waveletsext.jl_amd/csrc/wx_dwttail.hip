@@ -82,14 +82,20 @@ __device__ __forceinline__ void tail_ilevel(double (&v)[64], const WxFilt &filt)
 // xw: (n, batch) pyramids of depth log2(n) - 6 + Lt; head: (64, batch) <- the approximation of depth log2(n) - 6
 template <typename T, int F>
 __global__ __launch_bounds__(64) void k_idwt_tail(const T *__restrict__ xw, T *__restrict__ head, int64_t n, int64_t batch, int Lt,
-                                                  WxFilt filt)
+                                                  WxFilt filt, WxThreshArg thr)
 {
     const int64_t sig = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (sig >= batch) return;
     const T *p = xw + sig * n;
     double v[64];
+    if (thr.t) {                                     // denoise: the threshold of rows >= thr.lo rides on the load
+        const T tt = (T)((double)reinterpret_cast<const T *>(thr.t)[thr.per_signal ? sig : 0] * thr.scale);
 #pragma unroll
-    for (int i = 0; i < 64; ++i) v[i] = (double)p[i];
+        for (int i = 0; i < 64; ++i) { const T c = p[i]; v[i] = (double)(i >= thr.lo ? wx_thresh<T>(c, tt, thr.kind) : c); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) v[i] = (double)p[i];
+    }
     if (Lt >= 6) tail_ilevel<F, 2>(v, filt);
     if (Lt >= 5) tail_ilevel<F, 4>(v, filt);
     if (Lt >= 4) tail_ilevel<F, 8>(v, filt);
@@ -135,10 +141,10 @@ template int wx_dwt_tail<double>(double *, int64_t, int, int64_t, const WxFilt &
 template int wx_dwt_tail<float>(float *, int64_t, int, int64_t, const WxFilt &, hipStream_t);
 
 template <typename T>
-int wx_idwt_tail(const T *xw, T *head, int64_t n, int Lt, int64_t batch, const WxFilt &filt, hipStream_t st)
+int wx_idwt_tail(const T *xw, T *head, int64_t n, int Lt, int64_t batch, const WxFilt &filt, const WxThreshArg &thr, hipStream_t st)
 {
     if (batch <= 0) return WX_OK;
-    typedef void (*KT)(const T *, T *, int64_t, int64_t, int, WxFilt);
+    typedef void (*KT)(const T *, T *, int64_t, int64_t, int, WxFilt, WxThreshArg);
     KT k = nullptr;
     switch (filt.F) {
 #define WX_TL(FF) case FF: k = k_idwt_tail<T, FF>; break;
@@ -146,9 +152,9 @@ int wx_idwt_tail(const T *xw, T *head, int64_t n, int Lt, int64_t batch, const W
 #undef WX_TL
         default: return wx_set_error(WX_EHIP, "idwt tail: unsupported filter length");
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, xw, head, n, batch, Lt, filt);
+    hipLaunchKernelGGL(k, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, xw, head, n, batch, Lt, filt, thr);
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
-template int wx_idwt_tail<double>(const double *, double *, int64_t, int, int64_t, const WxFilt &, hipStream_t);
-template int wx_idwt_tail<float>(const float *, float *, int64_t, int, int64_t, const WxFilt &, hipStream_t);
+template int wx_idwt_tail<double>(const double *, double *, int64_t, int, int64_t, const WxFilt &, const WxThreshArg &, hipStream_t);
+template int wx_idwt_tail<float>(const float *, float *, int64_t, int, int64_t, const WxFilt &, const WxThreshArg &, hipStream_t);

@@ -127,4 +127,5 @@ int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t batch, const WxF
 // the deep levels of the pyramid in the registers of a lane (wx_dwttail.hip)
 int wx_dwt_tail_levels(int64_t n, int L, int F, size_t esz);
 template <typename T> int wx_dwt_tail(T *y, int64_t n, int Lt, int64_t batch, const WxFilt &filt, hipStream_t st);
-template <typename T> int wx_idwt_tail(const T *xw, T *head, int64_t n, int Lt, int64_t batch, const WxFilt &filt, hipStream_t st);
+template <typename T> int wx_idwt_tail(const T *xw, T *head, int64_t n, int Lt, int64_t batch, const WxFilt &filt, const WxThreshArg &thr,
+                                        hipStream_t st);
