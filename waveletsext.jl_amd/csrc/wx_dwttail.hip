@@ -118,7 +118,7 @@ int wx_dwt_tail_levels(int64_t n, int L, int F, size_t esz)
     int log2n = 0;
     while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
     const int Ls = log2n - 6;
-    return L - Ls >= 2 ? L - Ls : 0;
+    return L - Ls >= 1 ? L - Ls : 0;
 }
 
 template <typename T>
