@@ -140,3 +140,27 @@ def test_full_tree_rows_in_place_kernel(wx, oracle, wname):
         got = wx.wptall(x, wt, L)
         assert relerr(got, exp) <= TOL[np.dtype(dtype)], (m, n, L)
         assert relerr(wx.iwptall(exp, wt, L), x) <= 20 * TOL[np.dtype(dtype)], (m, n, L)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("wname", ["haar", "db4", "coif6"])
+def test_pyramid2d_levels_below_8x8_in_the_registers_of_a_lane(wx, oracle, wname, dtype):
+    """dwtall of square images to depths where the approximation is smaller than 8 x 8: the tree-driven levels stop at 8 x 8 and
+    csrc/wx_dwttail.hip (k_dwt2d_tail) finishes the pyramid, one lane per image (dwt/dwt_all.jl:39-54,
+    dwt/dwt_one_level.jl:319-354); more images than one wavefront, ragged last wavefront, idwtall back"""
+    rng = np.random.default_rng(919)
+    wt = _wt(wx, wname)
+    tol = TOL[np.dtype(dtype)]
+    for m, B in ((16, 70), (64, 67)):
+        x = np.asfortranarray(rng.standard_normal((m, m, B)).astype(dtype))
+        Lmax = int(np.log2(m))
+        for L in range(Lmax - 3 + 1, Lmax + 1):
+            tree = wx.maketree(m, m, L, "dwt")
+            got = wx.dwtall(x, wt, L)
+            for b in (0, 63, 64, B - 1):
+                assert relerr(got[:, :, b], oracle.wpt(x[:, :, b], wt.qmf, tree)) <= tol, (wname, m, L, b)
+            assert relerr(wx.idwtall(got, wt, L), x) <= 20 * tol, (wname, m, L)
+    # rectangular images keep the tree-driven levels
+    xr = np.asfortranarray(rng.standard_normal((32, 64, 3)).astype(dtype))
+    tr = wx.maketree(32, 64, 5, "dwt")
+    assert relerr(wx.dwtall(xr, wt)[:, :, 2], oracle.wpt(xr[:, :, 2], wt.qmf, tr)) <= tol

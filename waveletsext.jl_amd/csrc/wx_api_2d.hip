@@ -114,6 +114,24 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
     hipStream_t st = wx_stream(stream);
     WxScratch scr(st);
     WxTree2d tr;
+    // forward pyramid (dwt / dwtall of images): the levels from the 8 x 8 approximation down run in the registers of a lane
+    // (wx_dwttail.hip); the quad tree's approximation chain is 1, 2, 6, 22, ... (first child of i = 4 i - 2)
+    int tail = 0;
+    std::vector<uint8_t> ttree;
+    if (!INVERSE && tree && !wx_force_generic()) {
+        const int Ld = wx_tree_depth2d(tree, ntree);
+        std::vector<uint8_t> chain((size_t)ntree, 0);
+        int64_t node = 1;
+        for (int d = 0; d < Ld && node <= ntree; ++d, node = 4 * node - 2) chain[(size_t)node - 1] = 1;
+        bool pyramid = Ld >= 1;
+        for (int64_t i = 0; i < ntree && pyramid; ++i) pyramid = (tree[i] != 0) == (chain[(size_t)i] != 0);
+        if (pyramid && (tail = wx_dwt2d_tail_levels(m, n, Ld, F, sizeof(T)))) {
+            ttree.assign(tree, tree + ntree);
+            node = 1;
+            for (int d = 0; d < Ld && node <= ntree; ++d, node = 4 * node - 2) if (d >= Ld - tail) ttree[(size_t)node - 1] = 0;
+            tree = ttree.data();
+        }
+    }
     if ((rc = wx_resolve_tree2d(L, tree, ntree, scr, &tr))) return rc;
     WxIO io(st);
     const T *dx = (const T *)io.in(x, sizeof(T) * m * n * batch);
@@ -123,10 +141,12 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
     if (batch && tr.Leff > 0) { tmp = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!tmp) return io.finish(WX_EHIP); }
     if (tr.full && tr.Leff > 0 && !wx_force_generic() && wx_wpt2d_fast_ok<T>(m, n, F)) {
         rc = wx_dev_wpt2d_fast<T>(dx, dy, m, n, tr.Leff, batch, filt, tmp, INVERSE, m * n, st);
+        if (rc == WX_OK && tail) rc = wx_dwt2d_tail<T>(dy, m, tail, batch, filt, st);
         return io.finish(rc);
     }
     if (batch && tr.Leff > 1) { pong = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!pong) return io.finish(WX_EHIP); }
     rc = wx_dev_wpt2d<T>(dx, dy, m, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, tmp, pong, INVERSE, m * n, st, tr.htree);
+    if (rc == WX_OK && tail) rc = wx_dwt2d_tail<T>(dy, m, tail, batch, filt, st);
     return io.finish(rc);
 }
 

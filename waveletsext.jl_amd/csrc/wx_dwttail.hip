@@ -107,7 +107,92 @@ __global__ __launch_bounds__(64) void k_idwt_tail(const T *__restrict__ xw, T *_
     for (int i = 0; i < 64; ++i) o[i] = (T)v[i];
 }
 
+// ---- 2-D pyramid: the levels from an 8 x 8 approximation down, one lane per image (dwt_step! 2-D, dwt/dwt_one_level.jl:319-354:
+// the 1-D step along dimension 1 of every column, then along dimension 2 of every row; quadrants [aa ad; da dd] in place)
+template <int F, int M>
+__device__ __forceinline__ void tail2d_level(double (&v)[8][8], const WxFilt &filt)
+{
+    constexpr int H = M / 2;
+    double t[M][M];
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            double sa = 0.0, sd = 0.0;
+#pragma unroll
+            for (int k = 0; k < F; ++k) {
+                sa = fma(filt.q[k], v[(2 * r + k) & (M - 1)][j], sa);
+                sd = fma((k & 1) ? -filt.q[k] : filt.q[k], v[(2 * r + 1 - k) & (M - 1)][j], sd);
+            }
+            t[r][j] = sa; t[H + r][j] = sd;
+        }
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            double sa = 0.0, sd = 0.0;
+#pragma unroll
+            for (int k = 0; k < F; ++k) {
+                sa = fma(filt.q[k], t[i][(2 * r + k) & (M - 1)], sa);
+                sd = fma((k & 1) ? -filt.q[k] : filt.q[k], t[i][(2 * r + 1 - k) & (M - 1)], sd);
+            }
+            v[i][r] = sa; v[i][H + r] = sd;
+        }
+}
+
+// y: (m, m, batch) column-major images whose top-left 8 x 8 block is the approximation of depth log2(m) - 3; Lt = 1 .. 3
+template <typename T, int F>
+__global__ __launch_bounds__(64) void k_dwt2d_tail(T *__restrict__ y, int64_t m, int64_t batch, int Lt, WxFilt filt)
+{
+    const int64_t sig = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (sig >= batch) return;
+    T *p = y + sig * m * m;
+    double v[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i][j] = (double)p[i + j * m];
+    tail2d_level<F, 8>(v, filt);
+    if (Lt >= 2) tail2d_level<F, 4>(v, filt);
+    if (Lt >= 3) tail2d_level<F, 2>(v, filt);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i + j * m] = (T)v[i][j];
+}
+
 }  // namespace
+
+// 2-D: levels the tail takes off a pyramid of depth L of m x m images (0 = none)
+int wx_dwt2d_tail_levels(int64_t m, int64_t n, int L, int F, size_t esz)
+{
+    static const bool off = getenv("WX_DWT_TAIL") && atoi(getenv("WX_DWT_TAIL")) == 0;
+    if (off || (esz != 8 && esz != 4) || m != n || m < 16 || (m & (m - 1))) return 0;
+    switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 16: case 18: case 20: break; default: return 0; }
+    int log2m = 0;
+    while (((int64_t)1 << (log2m + 1)) <= m) ++log2m;
+    const int Ls = log2m - 3;
+    return L - Ls >= 1 ? L - Ls : 0;
+}
+
+template <typename T>
+int wx_dwt2d_tail(T *y, int64_t m, int Lt, int64_t batch, const WxFilt &filt, hipStream_t st)
+{
+    if (batch <= 0) return WX_OK;
+    typedef void (*KT)(T *, int64_t, int64_t, int, WxFilt);
+    KT k = nullptr;
+    switch (filt.F) {
+#define WX_TL(FF) case FF: k = k_dwt2d_tail<T, FF>; break;
+        WX_TL(2) WX_TL(4) WX_TL(6) WX_TL(8) WX_TL(10) WX_TL(12) WX_TL(16) WX_TL(18) WX_TL(20)
+#undef WX_TL
+        default: return wx_set_error(WX_EHIP, "dwt 2-D tail: unsupported filter length");
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, y, m, batch, Lt, filt);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+template int wx_dwt2d_tail<double>(double *, int64_t, int, int64_t, const WxFilt &, hipStream_t);
+template int wx_dwt2d_tail<float>(float *, int64_t, int, int64_t, const WxFilt &, hipStream_t);
 
 // number of levels the tail takes off the end of a pyramid of depth L (0 = none): the tree-driven kernel then runs L - that
 int wx_dwt_tail_levels(int64_t n, int L, int F, size_t esz)

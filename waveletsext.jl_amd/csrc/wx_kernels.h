@@ -129,3 +129,5 @@ int wx_dwt_tail_levels(int64_t n, int L, int F, size_t esz);
 template <typename T> int wx_dwt_tail(T *y, int64_t n, int Lt, int64_t batch, const WxFilt &filt, hipStream_t st);
 template <typename T> int wx_idwt_tail(const T *xw, T *head, int64_t n, int Lt, int64_t batch, const WxFilt &filt, const WxThreshArg &thr,
                                         hipStream_t st);
+int wx_dwt2d_tail_levels(int64_t m, int64_t n, int L, int F, size_t esz);
+template <typename T> int wx_dwt2d_tail(T *y, int64_t m, int Lt, int64_t batch, const WxFilt &filt, hipStream_t st);
