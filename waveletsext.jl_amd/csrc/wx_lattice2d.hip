@@ -9,8 +9,16 @@
 // 16 columns = 4096 Float32 pairs per wavefront, the same register layouts A and B and the same intra-wavefront LDS
 // exchanges as the Float64 kernel -- and writes Z[j + 512 o(i)]: position o(i) of the packet order becomes the column,
 // the column index j the contiguous dimension.  The second application transforms the former rows and restores the
-// orientation.  A workgroup of two wavefronts covers 32 columns = one 128-byte line of the transposed image per row;
+// orientation.  A workgroup of W = 4 wavefronts covers 64 columns = a 256-byte run of every row of the transposed image;
 // the transposition goes through LDS in four rounds of 128 rows (two register bits fixed per round).
+//
+// What bounds a pass is its memory access shape, not arithmetic (tools/dbg/l2d_pattern.hip times the shapes without any
+// arithmetic on 4096 images: the round-2 shape, 128-byte runs per row, 1.67 ms; 256-byte runs with the non-temporal hint
+// 1.51 ms; a plain copy 1.45 ms; the kernel without its global accesses 0.72 ms).  Hence (round 3): W = 4 instead of 2,
+// non-temporal loads and stores, two wavefronts per SIMD without the 13-22 spilled registers of the three-wavefront build
+// (their scratch traffic was the 1.17 x of round 2's PMC bytes), and the intermediate image -- which nobody outside the
+// library sees -- in a BLOCKED layout (l2_src_off) that makes the first pass's stores and the second pass's loads
+// contiguous: only the last store of a transform is a strided one.  3.39 -> 2.95 ms per direction on config 4.
 //
 // Halo: the columns of a wavefront are independent periodic sequences of 512 samples: in layout A (reg i[5:0]) the
 // neighbouring chunk is the next of 8 lanes (cyclic: two DPP moves and a select), in layout B (reg i[7:2]) the other of 2
@@ -24,6 +32,18 @@ bool wx_lattice_coeffs(const WxFilt &filt, int L, bool inverse, double *p, doubl
 
 #define WX_L2_MAXS 10
 #define WX_L2_WIN 1104        // 8-byte slots of one wavefront's exchange window
+#ifndef WX_L2D_G
+#define WX_L2D_G 16            // LDS reads in flight per wait of an exchange (8 or 16)
+#endif
+#ifndef WX_L2D_W
+#define WX_L2D_W 4             // wavefronts per workgroup = 16 W columns = a 64 W byte run of every transposed row
+#endif
+#ifndef WX_L2D_NT
+#define WX_L2D_NT 1            // non-temporal hint on the loads and stores (every byte is touched once)
+#endif
+#ifndef WX_L2D_WPE
+#define WX_L2D_WPE 2           // wavefronts per SIMD the kernels are built for (3: 168 registers, 13-22 of them spilled)
+#endif
 
 struct WxLat2 {
     float p[WX_L2_MAXS];
@@ -49,6 +69,27 @@ __device__ __forceinline__ l2_gm l2_sbase(float *p)
     l2_gm g = (l2_gm)p;
     asm("" : "+s"(g));
     return g;
+}
+__device__ __forceinline__ f4 l2_ld(l2_gc p)
+{
+    const f4 __attribute__((address_space(1))) *q = (const f4 __attribute__((address_space(1))) *)p;
+    return WX_L2D_NT ? __builtin_nontemporal_load(q) : *q;
+}
+__device__ __forceinline__ void l2_st(l2_gm p, f4 v)
+{
+    f4 __attribute__((address_space(1))) *q = (f4 __attribute__((address_space(1))) *)p;
+    if (WX_L2D_NT) __builtin_nontemporal_store(v, q);
+    else *q = v;
+}
+// The intermediate image between the two passes is the library's own: instead of the plain transposed image
+// Z[j + 512 o] the first pass writes it in blocks of 16 W source columns, Zb[(j / 16 W) * 512 * 16 W + o * 16 W + j % 16 W],
+// so that a workgroup's 512 runs of 64 W bytes are one contiguous 32 W KiB block (BS), and the second pass reads its
+// columns o out of those blocks (BL): sample j of column o at (j / 64) * WX_L2D_BLK + 64 o + j % 64.
+#define WX_L2D_BLK (512 * 16 * WX_L2D_W)
+template <bool BL> __device__ __forceinline__ int64_t l2_src_off(int col, int smp)
+{
+    if constexpr (BL) return (int64_t)(smp >> 6) * WX_L2D_BLK + (int64_t)col * 64 + (smp & 63);
+    else return (int64_t)col * 512 + smp;
 }
 template <int... I, typename F> __device__ __forceinline__ void l2_for_impl(std::integer_sequence<int, I...>, F &&f)
 {
@@ -79,11 +120,12 @@ __device__ __forceinline__ void l2_wait8(double &a, double &b, double &c, double
 {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "memory");
 }
-__device__ __forceinline__ void l2_wait16(double (&x)[16])
+__device__ __forceinline__ void l2_waitn(double (&x)[16])
 {
     l2_wait8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
     l2_wait8(x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15]);
 }
+__device__ __forceinline__ void l2_waitn(double (&x)[8]) { l2_wait8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]); }
 // keeps a coefficient pair in vector registers (see the note at l2_level)
 __device__ __forceinline__ void l2_vgpr(f2 &v)
 {
@@ -220,42 +262,45 @@ __device__ __forceinline__ void l2_t2(f2 (&a)[64], f2 (&bb)[64], unsigned lds0, 
             constexpr int j = Jq;
             l2_wr64<8 * 64 * j>((j & 1) ? wa1 : wa0, a[16 * f + j]);
         });
-        double t[16];
-        l2_for<16>([&](auto Q) {
-            constexpr int h = Q / 4, g = Q % 4;
-            t[Q] = l2_rd64<8 * 256 * g>(ra[h]);
-        });
-        l2_wait16(t);
-        l2_for<16>([&](auto Q) {
-            constexpr int h = Q / 4, g = Q % 4;
-            bb[16 * h + 4 * f + g] = __builtin_bit_cast(f2, t[Q]);
+        l2_for<16 / WX_L2D_G>([&](auto Hq) {
+            constexpr int q0 = WX_L2D_G * Hq;
+            double t[WX_L2D_G];
+            l2_for<WX_L2D_G>([&](auto Q) {
+                constexpr int h = (q0 + Q) / 4, g = (q0 + Q) % 4;
+                t[Q] = l2_rd64<8 * 256 * g>(ra[h]);
+            });
+            l2_waitn(t);
+            l2_for<WX_L2D_G>([&](auto Q) {
+                constexpr int h = (q0 + Q) / 4, g = (q0 + Q) % 4;
+                bb[16 * h + 4 * f + g] = __builtin_bit_cast(f2, t[Q]);
+            });
         });
     });
 }
 
 // forward: src image (column j = 512 contiguous samples at src + 512 j) -> dst image transposed and in packet order:
 // dst[j + 512 o(i)], o(i) = bitreverse6(i[5:0]) << 3 | i[8:6].  grid (16, images), 128 threads.
-template <int NS>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lat2d_colT_f32(
+template <int NS, bool BL, bool BS>
+__global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_colT_f32(
     const float *__restrict__ src, float *__restrict__ dst, int64_t img, WxLat2 cf)
 {
-    __shared__ double lds[2 * WX_L2_WIN];
+    __shared__ double lds[WX_L2D_W * WX_L2_WIN];
     const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
     const float *simg = src + img * blockIdx.y;
     float *dimg = dst + img * blockIdx.y;
-    const int j0 = 32 * blockIdx.x + 16 * wave;
+    const int j0 = 16 * WX_L2D_W * blockIdx.x + 16 * wave;
     f2 a[64];
     {
         // loads: instruction (cp, i7, i8) covers 8 complete lines: lane = sub | h << 3 | i5 << 4 | i6 << 5 holds samples
         // i = 256 i8 + 128 i7 + 64 i6 + 32 i5 + 4 sub + {0..3} of column 2 cp + h
         const int sub = lane & 7, h = (lane >> 3) & 1, i5 = (lane >> 4) & 1, i6 = lane >> 5;
-        const unsigned lo = 512u * h + 64u * i6 + 32u * i5 + 4u * sub;
+        const unsigned lo = BL ? 64u * h + (unsigned)WX_L2D_BLK * i6 + 32u * i5 + 4u * sub : 512u * h + 64u * i6 + 32u * i5 + 4u * sub;
         f4 r[32];
         l2_for<32>([&](auto Q) {
             constexpr int cp = Q >> 2, i7 = Q & 1, i8 = (Q >> 1) & 1;
-            r[Q] = *(const f4 __attribute__((address_space(1))) *)(l2_sbase(simg + (int64_t)(j0 + 2 * cp) * 512 + 256 * i8 + 128 * i7) + lo);
+            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL>(j0 + 2 * cp, 256 * i8 + 128 * i7)) + lo);
         });
         // T1: the two columns of a pair meet in one 8-byte slot (two ds_write_b32): slot = 17 lam + m, lam = i[8:6] | cp << 3,
         // m = i[5:2]; round rho = i[1:0]
@@ -266,15 +311,18 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 constexpr int cp = Q >> 2, i7 = Q & 1, i8 = (Q >> 1) & 1;
                 l2_wr32<4 * 34 * (2 * i7 + 4 * i8 + 8 * cp)>(wa, r[Q][rho]);
             });
-            double t[16];
-            l2_for<16>([&](auto M) {
-                constexpr int m = M;
-                t[m] = l2_rd64<8 * m>(ra);
-            });
-            l2_wait16(t);
-            l2_for<16>([&](auto M) {
-                constexpr int m = M;
-                a[4 * m + rho] = __builtin_bit_cast(f2, t[m]);
+            l2_for<16 / WX_L2D_G>([&](auto Hq) {
+                constexpr int m0 = WX_L2D_G * Hq;
+                double t[WX_L2D_G];
+                l2_for<WX_L2D_G>([&](auto M) {
+                    constexpr int m = m0 + M;
+                    t[M] = l2_rd64<8 * m>(ra);
+                });
+                l2_waitn(t);
+                l2_for<WX_L2D_G>([&](auto M) {
+                    constexpr int m = m0 + M;
+                    a[4 * m + rho] = __builtin_bit_cast(f2, t[M]);
+                });
             });
         });
     }
@@ -298,9 +346,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int m = 1; m < 5; ++m) gf[m] = gf[m - 1] * cf.g2;
     }
     // transposed store: round rho fixes (i2, i3) = register bits 0, 1 -> 128 of the 512 rows o(i); a row of the
-    // workgroup is 16 column pairs = 128 bytes.  slot = 16 row + (pair ^ 8 i8)
+    // workgroup is 8 W column pairs = 64 W bytes.  slot = 8 W row + (pair ^ 8 i8)
+    constexpr int RS = 8 * WX_L2D_W, LPR = 4 * WX_L2D_W, RPI = 16;           // slots per row, lanes per row, rows per read
     const int i8 = lane & 1, cp = (lane >> 1) & 7, i0 = (lane >> 4) & 1, i1 = lane >> 5;
-    const unsigned wa = ldsb + 8u * (16u * ((i8 << 2) | (i1 << 5) | (i0 << 6)) + (unsigned)((8 * wave + cp) ^ (8 * i8)));
+    const unsigned wa = ldsb + 8u * ((unsigned)RS * ((i8 << 2) | (i1 << 5) | (i0 << 6)) + (unsigned)((8 * wave + cp) ^ (8 * i8)));
     l2_barrier();                                      // the exchange windows are reused as the row buffer
     l2_for<4>([&](auto Rq) {
         constexpr int rho = Rq;
@@ -312,16 +361,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             f2 val = bb[r];
             val.x *= gf[pc];
             val.y *= gf[pc];
-            l2_wr64<8 * 16 * rowreg>(wa, val);
+            l2_wr64<8 * RS * rowreg>(wa, val);
         });
         l2_barrier();
-        l2_for<8>([&](auto Kq) {
+        l2_for<128 / RPI>([&](auto Kq) {
             constexpr int k = Kq;
-            const int rr = 16 * k + (tid >> 3), u = tid & 7;
+            const int rr = RPI * k + tid / LPR, u = tid % LPR;
             const int o2 = (rr >> 2) & 1;
-            const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * (16u * rr + (unsigned)((2 * u) ^ (8 * o2))));
+            const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (8 * o2))));
             const int o = (rr & 31) | ((rho >> 1) << 5) | ((rho & 1) << 6) | ((rr >> 5) << 7);
-            *(f4 __attribute__((address_space(1))) *)(l2_sbase(dimg + 32 * blockIdx.x) + (unsigned)(512 * o + 4 * u)) = val;
+            l2_st(l2_sbase(dimg + (BS ? WX_L2D_BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)((BS ? 16 * WX_L2D_W : 512) * o + 4 * u), val);
         });
         l2_barrier();
     });
@@ -343,42 +392,45 @@ __device__ __forceinline__ void l2_t2i(f2 (&bb)[64], f2 (&a)[64], unsigned lds0,
             constexpr int h = Q / 4, g = Q % 4;
             l2_wr64<8 * 256 * g>(wa[h], bb[16 * h + 4 * f + g]);
         });
-        double t[16];
-        l2_for<16>([&](auto Jq) {
-            constexpr int j = Jq;
-            t[j] = l2_rd64<8 * 64 * j>(ra);
-        });
-        l2_wait16(t);
-        l2_for<16>([&](auto Jq) {
-            constexpr int j = Jq;
-            a[16 * f + j] = __builtin_bit_cast(f2, t[j]);
+        l2_for<16 / WX_L2D_G>([&](auto Hq) {
+            constexpr int j0 = WX_L2D_G * Hq;
+            double t[WX_L2D_G];
+            l2_for<WX_L2D_G>([&](auto Jq) {
+                constexpr int j = j0 + Jq;
+                t[Jq] = l2_rd64<8 * 64 * j>(ra);
+            });
+            l2_waitn(t);
+            l2_for<WX_L2D_G>([&](auto Jq) {
+                constexpr int j = j0 + Jq;
+                a[16 * f + j] = __builtin_bit_cast(f2, t[Jq]);
+            });
         });
     });
 }
 
 // inverse: src image (column j = 512 contiguous packet coefficients, position o(i) = bitreverse6(i[5:0]) << 3 | i[8:6]) ->
 // dst image transposed, natural order: dst[j + 512 i].  grid (16, images), 128 threads.
-template <int NS>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lat2d_icolT_f32(
+template <int NS, bool BL, bool BS>
+__global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_icolT_f32(
     const float *__restrict__ src, float *__restrict__ dst, int64_t img, WxLat2 cf)
 {
-    __shared__ double lds[2 * WX_L2_WIN];
+    __shared__ double lds[WX_L2D_W * WX_L2_WIN];
     const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
     const float *simg = src + img * blockIdx.y;
     float *dimg = dst + img * blockIdx.y;
-    const int j0 = 32 * blockIdx.x + 16 * wave;
+    const int j0 = 16 * WX_L2D_W * blockIdx.x + 16 * wave;
     f2 bb[64];
     {
         // loads as in the forward kernel, in packet order: lane = sub | h << 3 | o5 << 4 | o6 << 5, instruction (cp, o7, o8);
         // o8 = i0, o7 = i1, o6 = i2, o5 = i3, o4 = i4, o3 = i5, o2 = i8, o1 = i7, o0 = i6
         const int sub = lane & 7, h = (lane >> 3) & 1, o5 = (lane >> 4) & 1, o6 = lane >> 5;
-        const unsigned lo = 512u * h + 64u * o6 + 32u * o5 + 4u * sub;
+        const unsigned lo = BL ? 64u * h + (unsigned)WX_L2D_BLK * o6 + 32u * o5 + 4u * sub : 512u * h + 64u * o6 + 32u * o5 + 4u * sub;
         f4 r[32];
         l2_for<32>([&](auto Q) {
             constexpr int cp = Q >> 2, o7 = Q & 1, o8 = (Q >> 1) & 1;
-            r[Q] = *(const f4 __attribute__((address_space(1))) *)(l2_sbase(simg + (int64_t)(j0 + 2 * cp) * 512 + 256 * o8 + 128 * o7) + lo);
+            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL>(j0 + 2 * cp, 256 * o8 + 128 * o7)) + lo);
         });
         // into layout B (reg i[7:2], lane mu = i8 | cp << 1 | i0 << 4 | i1 << 5): round rho = o[1:0] = (i6, i7 << 1) fixes
         // register bits 4, 5; slot = 17 mu + v, v = i2 | i3 << 1 | i4 << 2 | i5 << 3
@@ -400,19 +452,22 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 constexpr int cp = Q >> 2, i1 = Q & 1, i0 = (Q >> 1) & 1;
                 l2_wr32<4 * 34 * (2 * cp + 16 * i0 + 32 * i1)>(wa, r[Q][rho]);
             });
-            double t[16];
-            l2_for<16>([&](auto V) {
-                constexpr int v = V;
-                t[v] = l2_rd64<8 * v>(ra);
-            });
-            l2_wait16(t);
-            l2_for<16>([&](auto V) {
-                constexpr int v = V;
-                constexpr int pc = (v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1) + ((v >> 3) & 1);
-                f2 e = __builtin_bit_cast(f2, t[v]);
-                e.x *= gf[pc];
-                e.y *= gf[pc];
-                bb[v + 16 * rho] = e;                     // register index i[7:2] = v | i6 << 4 | i7 << 5
+            l2_for<16 / WX_L2D_G>([&](auto Hq) {
+                constexpr int v0 = WX_L2D_G * Hq;
+                double t[WX_L2D_G];
+                l2_for<WX_L2D_G>([&](auto V) {
+                    constexpr int v = v0 + V;
+                    t[V] = l2_rd64<8 * v>(ra);
+                });
+                l2_waitn(t);
+                l2_for<WX_L2D_G>([&](auto V) {
+                    constexpr int v = v0 + V;
+                    constexpr int pc = (v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1) + ((v >> 3) & 1);
+                    f2 e = __builtin_bit_cast(f2, t[V]);
+                    e.x *= gf[pc];
+                    e.y *= gf[pc];
+                    bb[v + 16 * rho] = e;                 // register index i[7:2] = v | i6 << 4 | i7 << 5
+                });
             });
         });
     }
@@ -425,24 +480,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     l2_level<1, 3, NS, true>(a, cf, lane);
     l2_level<0, 3, NS, true>(a, cf, lane);
     // transposed store, natural row order: layout A (reg i[5:0], lane i[8:6] | cp << 3); round rho = i[5:4];
-    // row of the round rr = i[3:0] | i[8:6] << 4, slot = 16 rr + (pair ^ i[8:6] << 1)
+    // row of the round rr = i[3:0] | i[8:6] << 4, slot = 8 W rr + (pair ^ i[8:6] << 1)
+    constexpr int RS = 8 * WX_L2D_W, LPR = 4 * WX_L2D_W, RPI = 16;
     const int i86 = lane & 7, cp = lane >> 3;
-    const unsigned wa = ldsb + 8u * (16u * (unsigned)(i86 << 4) + (unsigned)((8 * wave + cp) ^ (i86 << 1)));
+    const unsigned wa = ldsb + 8u * ((unsigned)RS * (unsigned)(i86 << 4) + (unsigned)((8 * wave + cp) ^ (i86 << 1)));
     l2_barrier();
     l2_for<4>([&](auto Rq) {
         constexpr int rho = Rq;
         l2_for<16>([&](auto Vq) {
             constexpr int v = Vq;                         // i[3:0]
-            l2_wr64<8 * 16 * v>(wa, a[v + 16 * rho]);
+            l2_wr64<8 * RS * v>(wa, a[v + 16 * rho]);
         });
         l2_barrier();
-        l2_for<8>([&](auto Kq) {
+        l2_for<128 / RPI>([&](auto Kq) {
             constexpr int k = Kq;
-            const int rr = 16 * k + (tid >> 3), u = tid & 7;
+            const int rr = RPI * k + tid / LPR, u = tid % LPR;
             const int s86 = rr >> 4;
-            const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * (16u * rr + (unsigned)((2 * u) ^ (s86 << 1))));
+            const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (s86 << 1))));
             const int i = (rr & 15) | (rho << 4) | (s86 << 6);
-            *(f4 __attribute__((address_space(1))) *)(l2_sbase(dimg + 32 * blockIdx.x) + (unsigned)(512 * i + 4 * u)) = val;
+            l2_st(l2_sbase(dimg + (BS ? WX_L2D_BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)((BS ? 16 * WX_L2D_W : 512) * i + 4 * u), val);
         });
         l2_barrier();
     });
@@ -456,9 +512,12 @@ bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz
     return !off && esz == 4 && m == 512 && n == 512 && L == 6 && filt.F >= 4 && filt.F / 2 <= WX_L2_MAXS;
 }
 
-// one transposing pass over `batch` images: 0 = not applicable, 1 = launched, < 0 = error
-int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t batch, const WxFilt &filt, bool inverse, hipStream_t st)
+// one transposing pass over `batch` images: 0 = not applicable, 1 = launched, < 0 = error.  pass 0: natural image in,
+// transposed image out (what one application of the kernel is); pass 1 / 2: the first / second pass of a transform, with
+// the intermediate image in the blocked layout above (the caller's scratch buffer, never seen outside the library).
+int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
 {
+    static const bool blocked = WX_L2D_W == 4 && !(getenv("WX_L2D_BLOCKED") && atoi(getenv("WX_L2D_BLOCKED")) == 0);
     double p[WX_L2_MAXS], kap[WX_L2_MAXS], g0, g2;
     if (!wx_lattice_coeffs(filt, 6, inverse, p, kap, &g0, &g2)) return 0;
     WxLat2 cf;
@@ -466,18 +525,26 @@ int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t batch, const WxF
     cf.g0 = (float)g0;
     cf.g2 = (float)g2;
     if (batch > 65535 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return 0;
-#define WX_GO2(NSS)                                                                                                       \
+    const bool bl = blocked && pass == 2, bs = blocked && pass == 1;
+    const dim3 grid(32 / WX_L2D_W, (unsigned)batch), wg(64 * WX_L2D_W);
+    const int64_t img = (int64_t)512 * 512;
+#define WX_GO2K(K, NSS)                                                                                                  \
+    do {                                                                                                                 \
+        if (bl) hipLaunchKernelGGL((K<NSS, true, false>), grid, wg, 0, st, src, dst, img, cf);                           \
+        else if (bs) hipLaunchKernelGGL((K<NSS, false, true>), grid, wg, 0, st, src, dst, img, cf);                      \
+        else hipLaunchKernelGGL((K<NSS, false, false>), grid, wg, 0, st, src, dst, img, cf);                             \
+    } while (0)
+#define WX_GO2(NSS)                                                                                                      \
     case NSS:                                                                                                            \
-        if (inverse)                                                                                                     \
-            hipLaunchKernelGGL(k_lat2d_icolT_f32<NSS>, dim3(16, (unsigned)batch), dim3(128), 0, st, src, dst, (int64_t)512 * 512, cf); \
-        else                                                                                                             \
-            hipLaunchKernelGGL(k_lat2d_colT_f32<NSS>, dim3(16, (unsigned)batch), dim3(128), 0, st, src, dst, (int64_t)512 * 512, cf); \
+        if (inverse) WX_GO2K(k_lat2d_icolT_f32, NSS);                                                                    \
+        else WX_GO2K(k_lat2d_colT_f32, NSS);                                                                             \
         break;
     switch (filt.F / 2) {
         WX_GO2(2) WX_GO2(4)
     default: return 0;
     }
 #undef WX_GO2
+#undef WX_GO2K
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wx_set_hip_error(e, "lattice2d launch", __FILE__, __LINE__);
     return 1;
