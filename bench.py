@@ -115,6 +115,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the all-gather loop is on by default)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the `also` block (the other headline workloads, hipEvent-timed in the same run; N = 1 only)")
     return ap.parse_args()
 
 
@@ -483,10 +485,12 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
         W.step = step
         W.check = lambda: 0.0 if wx.isvalidtree(torch.empty(n), state["tree"]) else 1.0
         W.output = lambda gathered: torch.from_numpy(state["tree"].astype("float64"))
-        # structure exploited by the kernel: odd lags only, S shared by both children
-        flops = (ncols - (1 << L)) * n * (2.0 * (F // 2) * 2 + 4) * Bl
+        flops = acwpd_jbb_min_flops(n, L, F) * Bl
         W.info = dict(fwd_bytes=es * (n * Bl + 2 * n * ncols), inv_bytes=es * 2 * n * ncols, fwd_flops=flops, samples=n * Bl,
-                      bound="fp64", launch_unit="the rank's whole shard: %d chunks of <= %d signals" % (len(chunks), CH),
+                      bound="fp64", flops_note="minimal algorithm: per depth the periodised autocorrelation filter (odd lags and the "
+                      "centre tap only, symmetric pairs folded), S shared by both children, 3 flops per node sample for sum x and "
+                      "sum x^2 (acwpd_jbb_min_flops); what the kernels execute is more (circulant tiles on the matrix pipe)",
+                      launch_unit="the rank's whole shard: %d chunks of <= %d signals" % (len(chunks), CH),
                       collective="all-reduce of 2 x %d moments inside the second leg" % (n * ncols) if world > 1 else None)
         W.keep = (x,)
         return W
@@ -568,6 +572,83 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
 
     W.step, W.check = step, check
     return W
+
+def acwpd_jbb_min_flops(n, L, F):
+    """Float64 operations per signal of acwpd + the two JBB moments by the cheapest direct algorithm (an FMA = 2).
+    acwt/acwt_one_level.jl:101-128: children w1 = c v + S, w2 = c v - S with S = sum over the non-zero taps of the
+    autocorrelation filter (2F - 1 taps, only odd lags and the centre are non-zero, symmetric) at dilation 2^d; on a
+    signal of n samples the taps of depth d wrap onto n / 2^d positions, taps that land on one position merge.
+    bestbasis_tree.jl:150-158: sum x and sum x^2 of every coefficient of every node."""
+    total = 3.0 * n                                             # moments of the root column
+    for d in range(L):
+        t = n >> d                                              # distinct positions k + m 2^d (mod n)
+        pos = {l % t for l in range(-(F - 1), F, 2) if l % 2} - {0}
+        pairs = len({min(p, t - p) for p in pos if p != t - p and (t - p) in pos})
+        singles = len(pos) - 2 * pairs
+        per_parent = 3.0 * pairs + 2.0 * singles + 3.0          # S (pair: add + FMA), then c v + S and c v - S
+        total += (1 << d) * n * (per_parent + 2 * 3.0)          # + the moments of the two children
+    return total
+
+
+# ------------------------------------------------------------------------------------------------
+# `also`: the other headline workloads under the same clock as the default line (N = 1): the north-star target, one
+# resident chunk of config 3, config 4, four 2048-signal chunks of config 5 -- per leg the dominant kernel's name, the
+# hipEvent-timed average launch (>= 10 launches after 2 warm-up steps), the algorithmic bytes (or flops) of one launch and
+# the roofline fraction.  Same code path as `--workload <name>` (make_workload), smaller step counts.
+# ------------------------------------------------------------------------------------------------
+ALSO = (("target", {}), ("cfg3", {"batch": 64}), ("cfg3_sdwt", {}), ("cfg4", {}), ("cfg5", {"batch": 8192}))
+
+
+def also_block(wx, torch, dev, a, dist, steps=10):
+    out = {}
+    for name, over in ALSO:
+        if name not in WORKLOADS:
+            continue
+        t0 = time.perf_counter()
+        try:
+            w = dict(WORKLOADS[name])
+            w.update(over)
+            W = make_workload(w, wx, torch, dev, 0, 1, a, dist)
+            warm = Legs(torch)
+            for _ in range(2):
+                W.step(warm)
+            torch.cuda.synchronize(dev)
+            err = W.check()
+            legs = Legs(torch)
+            for _ in range(steps):
+                W.step(legs)
+            torch.cuda.synchronize(dev)
+            info = W.info
+            per_step = {k: len(legs.ev[k]) // steps for k in ("fwd", "inv")}
+            fwd = sum(legs.ms("fwd")) / steps          # all forward launches of a step (one, or one per resident chunk)
+            inv = sum(legs.ms("inv")) / steps
+            fb, ib = float(info["fwd_bytes"]) * per_step["fwd"], float(info["inv_bytes"]) * per_step["inv"]
+            rec = {"workload": w["desc"], "batch": w["batch"], "roundtrip_rel_err": err}
+            if info["bound"] == "hbm":
+                rec["fwd"] = {"kernel": w["kernel"], "avg_launch_ms": fwd, "algorithmic_bytes": fb,
+                              "achieved_GBs": fb / fwd / 1e6, "frac": fb / fwd / 1e6 / HBM_PEAK_GBS}
+                rec["inv"] = {"kernel": w.get("inv_kernel"), "avg_launch_ms": inv, "algorithmic_bytes": ib,
+                              "achieved_GBs": ib / inv / 1e6, "frac": ib / inv / 1e6 / HBM_PEAK_GBS}
+            else:
+                fl = float(info["fwd_flops"])
+                rec["fwd"] = {"kernel": w["kernel"], "avg_launch_ms": fwd, "algorithmic_flops": fl,
+                              "achieved_TFLOPs": fl / fwd / 1e9, "frac": fl / fwd / 1e9 / FP64_PEAK_TFLOPS,
+                              "bound": info["bound"], "hbm_GBs": fb / fwd / 1e6}
+                if "chunk" in w:                         # the first chunk of a step allocates the moments, the others accumulate
+                    nch = -(-w["batch"] // w["chunk"])
+                    rec["fwd"]["chunks_per_launch"] = nch
+                    rec["fwd"]["avg_chunk_ms"] = fwd / nch
+                rec["inv"] = {"kernel": None, "avg_launch_ms": inv, "note": "costs + tree selection from the moments"}
+                if "flops_note" in info:
+                    rec["fwd"]["flops_note"] = info["flops_note"]
+            rec["Msamples_per_s"] = info["samples"] / ((fwd + inv) * 1e-3) / 1e6
+            rec["wall_s"] = time.perf_counter() - t0
+            out[name] = rec
+            del W, legs, warm
+        except Exception as e:  # pragma: no cover - never lose the headline line to a side measurement
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -713,6 +794,7 @@ def main():
             roof = {"bound": "fp64 (vector + matrix pipe share the FP64 rate; flops counted for the direct form)", "kernel": w["kernel"], "achieved": achieved,
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                     "algorithmic_flops_per_step": info["fwd_flops"], "hbm_GBs": fb / (fwd_avg * 1e-3) / 1e9}
+        roof["traffic_source"] = "profiles/traffic.json (offline rocprofv3 --pmc passes of this command, not measured in this run)" if traffic is not None else None
         roof.update({"avg_launch_ms": fwd_avg, "median_launch_ms": fwd_ms[len(fwd_ms) // 2],
                      "launches_per_step": len(fwd_ms) // a.steps,
                      "fwd_TFLOPs_direct_form": info["fwd_flops"] / (fwd_avg * 1e-3) / 1e12})
@@ -730,7 +812,7 @@ def main():
             "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": a.scaling if world > 1 else "none", "vs_baseline": None,
             "dtype": w["dtype"],
             "data": "synthetic N(0,1), seed 1002 (one batch, sliced per rank; weak scaling: 1002 + rank), resident in HBM",
             "config": cfg,
@@ -746,6 +828,11 @@ def main():
         }
         if gather is not None:
             out["with_allgather"] = gather
+        if world == 1 and not a.no_also and not a.batch and a.workload == "cfg2":
+            W.keep = None
+            del W, legs, warm
+            torch.cuda.empty_cache()
+            out["also"] = also_block(wx, torch, dev, a, dist)
         if not a.no_cpu and world == 1:
             try:
                 pc = pcie_inclusive(w, wx)
