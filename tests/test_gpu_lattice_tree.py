@@ -1,0 +1,135 @@
+"""Tree-driven wpt / iwpt / iwpd on the lattice kernels (csrc/wx_lattice_tree.h) against the oracle.
+
+Reference behaviour: Wavelets.jl's wpt / iwpt with a tree::BitVector as called at dwt/dwt_all.jl:152-166, 210-225,
+DWT.jl:340-351 (iwpd by tree = getbasiscoef + iwpt, Utils.jl:101-134).  Float64, tolerance 1e-10 relative; the routing of
+every coefficient is exact, so wpt(x, tree) must equal getbasiscoef(wpd(x), tree) of the device's own packet table bit for
+bit (same lattice arithmetic on both sides).
+"""
+import numpy as np
+import pytest
+
+from helpers import random_tree_1d, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def _wt(wx, name):
+    return wx.wavelet(getattr(wx.WT, name))
+
+
+def _depth(tree):
+    nz = np.flatnonzero(tree)
+    return 0 if nz.size == 0 else int(np.floor(np.log2(nz.max() + 1))) + 1
+
+
+def _trees(wx, n, rng, count):
+    Lmax = wx.maxtransformlevels(n)
+    out = [wx.maketree(n, Lmax, "dwt"), wx.maketree(n, 3, "dwt"), wx.maketree(n, 7, "dwt")]
+    # one leaf at every depth on the detail side (mirror of the pyramid), a tree with a single deep path in the middle
+    t = np.zeros(n - 1, dtype=bool)
+    i = 1
+    while i <= n - 1:
+        t[i - 1] = True
+        i = 2 * i + 1
+    out.append(t)
+    t = np.zeros(n - 1, dtype=bool)
+    i, k = 1, 0
+    while i <= n - 1:
+        t[i - 1] = True
+        i = 2 * i + (k & 1)
+        k += 1
+    out.append(t)
+    # a full tree of depth 4 with one leaf opened to the bottom
+    t = np.array(wx.maketree(n, 4, "full"), dtype=bool).copy()
+    i = 16 + 5
+    while i <= n - 1:
+        t[i - 1] = True
+        i = 2 * i
+    out.append(t)
+    for p in (0.3, 0.5, 0.7, 0.85, 0.95):
+        for _ in range(max(1, count // 5)):
+            tr = random_tree_1d(n, rng, p)
+            tr[0] = True
+            out.append(tr)
+    return out
+
+
+@pytest.mark.parametrize("n", [4096, 2048, 1024])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db8", "coif6"])
+def test_tree_wpt_iwpt_match_oracle(wx, oracle, n, wname):
+    rng = np.random.default_rng(4096 + n + len(wname))
+    wt = _wt(wx, wname)
+    B = 5                                             # not a multiple of the signals per wavefront (tail wavefront)
+    x = np.asfortranarray(rng.standard_normal((n, B)))
+    for tree in _trees(wx, n, rng, 10):
+        got = wx.wptall(x, wt, tree)
+        exp = oracle.wptall(x, wt.qmf, tree)
+        assert relerr(got, exp) <= TOL, (n, wname, int(tree.sum()))
+        back = wx.iwptall(exp, wt, tree)
+        assert relerr(back, x) <= TOL, (n, wname, int(tree.sum()))
+
+
+@pytest.mark.parametrize("n,count", [(4096, 200), (1024, 200)])
+def test_tree_fuzz_db4(wx, oracle, n, count):
+    """>= 200 fuzzed trees per length: forward against the oracle, inverse against the signal"""
+    rng = np.random.default_rng(n)
+    wt = _wt(wx, "db4")
+    x = np.asfortranarray(rng.standard_normal((n, 4)))
+    xw_full = oracle.wpdall(x, wt.qmf)                 # (n, L+1, B): every leaf of every tree is an entry of this table
+    worst = 0.0
+    for tree in _trees(wx, n, rng, count):
+        exp = np.stack([oracle.getbasiscoef(xw_full[:, :, b], tree) for b in range(x.shape[1])], axis=1)
+        got = wx.wptall(x, wt, tree)
+        e = relerr(got, exp)
+        worst = max(worst, e)
+        assert e <= TOL, int(tree.sum())
+        assert relerr(wx.iwptall(got, wt, tree), x) <= TOL
+    assert worst > 0.0                                # the comparison is not vacuous
+
+
+@pytest.mark.parametrize("n", [4096, 2048, 1024])
+def test_tree_wpt_equals_gather_of_the_device_table(wx, n):
+    """the tree only routes: the leaves written by the tree-driven kernel are the entries of the device's own wpd table"""
+    rng = np.random.default_rng(n + 1)
+    wt = _wt(wx, "db4")
+    x = np.asfortranarray(rng.standard_normal((n, 8)))
+    xw = wx.wpdall(x, wt)
+    for tree in _trees(wx, n, rng, 10):
+        got = wx.wptall(x, wt, tree)
+        gath = wx.getbasiscoefall(xw, tree)
+        # (trees of depth < 6 - SH take their table from other kernels: same values to rounding, not the same bits)
+        if _depth(tree) + (12 - int(np.log2(n))) >= 6:
+            assert np.array_equal(np.asarray(got), np.asarray(gath)), int(tree.sum())
+        assert relerr(got, gath) <= 1e-13, int(tree.sum())
+
+
+@pytest.mark.parametrize("n", [4096, 1024])
+def test_tree_iwpd_reads_the_packet_table(wx, oracle, n):
+    rng = np.random.default_rng(n + 2)
+    wt = _wt(wx, "db4")
+    x = np.asfortranarray(rng.standard_normal((n, 6)))
+    xw = oracle.wpdall(x, wt.qmf)
+    for tree in _trees(wx, n, rng, 10):
+        got = wx.iwpdall(xw, wt, tree)
+        assert relerr(got, x) <= TOL, int(tree.sum())
+        assert relerr(got, oracle.iwpdall(xw, wt.qmf, tree)) <= TOL
+
+
+def test_tree_large_batch_and_device_arrays(wx, oracle):
+    """device-resident batch of the benchmark's shape (fewer signals): every signal is transformed, not just the first ones"""
+    import torch
+    rng = np.random.default_rng(5)
+    n, B = 4096, 3000
+    wt = _wt(wx, "db4")
+    tree = random_tree_1d(n, rng, 0.7)
+    tree[0] = True
+    x = wx.jl_empty((n, B), torch.float64, "cuda")
+    x.normal_()
+    y = wx.wptall(x, wt, tree)
+    xr = wx.iwptall(y, wt, tree)
+    assert float((xr - x).abs().max() / x.abs().max()) <= TOL
+    idx = [0, 1, B // 2, B - 2, B - 1]
+    exp = oracle.wptall(np.asfortranarray(x[:, idx].cpu().numpy()), wt.qmf, tree)
+    assert relerr(y[:, idx].cpu().numpy(), exp) <= TOL

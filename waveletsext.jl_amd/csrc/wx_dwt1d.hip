@@ -1385,6 +1385,14 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
             return launch_fwd_fused<T, false>(scratch, y, 4096, L - dl, batch << dl, 4096, 4096, filt, nullptr, 0, st);
         }
     }
+    if constexpr (sizeof(T) == 8) {
+        // a tree (bestbasistree, maketree(:dwt), ...): the lattice computes every node in registers, the tree decides which
+        // lines leave after which level (wx_lattice_tree.h)
+        if (!force_generic && !noreg && status) {
+            const int r = wx_lattice_tree_f64(false, (const double *)x, (double *)y, n, L, batch, n, 0, filt, status, nstatus, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
+    }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))
         return launch_fwd_fused<T, false>(x, y, n, L, batch, n, n, filt, status, nstatus, st);
     // Signals too long for the LDS of one CU (full tree): the first d0 levels run one level per launch; from
@@ -1488,6 +1496,15 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
                 }
                 return WX_OK;
             }
+        }
+    }
+    if constexpr (sizeof(T) == 8) {
+        // leaves of a tree, dense (iwpt) or in the columns of a packet table (iwpd by tree: colmap is set, the leaves of depth
+        // l sit in column l): the lattice inverse takes them in level by level (wx_lattice_tree.h)
+        if (!force_generic && !noreg && status) {
+            const int r = wx_lattice_tree_f64(true, (const double *)xw, (double *)xh, n, L, batch, is, colmap ? n : 0, filt, status,
+                                              nstatus, st);
+            if (r) return r < 0 ? r : WX_OK;
         }
     }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))

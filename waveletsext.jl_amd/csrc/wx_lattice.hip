@@ -214,3 +214,26 @@ int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t b
 {
     return wx_lattice_launch(true, xw, y, n, L, batch, in_stride, filt, st);
 }
+
+// ---- tree-driven transforms (wx_lattice_tree.h) -----------------------------------------------------------------
+#define WX_TREE_DECL(k)                                                                                              \
+    int wx_lattice_tree##k##_f64(bool, const double *, double *, int64_t, int, int64_t, int64_t, int64_t, const WxFilt &, \
+                                 const uint8_t *, int64_t, hipStream_t);
+WX_TREE_DECL(0) WX_TREE_DECL(1) WX_TREE_DECL(2)
+#undef WX_TREE_DECL
+
+bool wx_lattice_tree_applicable_f64(int64_t n, const WxFilt &filt)
+{
+    static const bool off = (getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0) ||
+                            (getenv("WX_LATTICE_TREE") && atoi(getenv("WX_LATTICE_TREE")) == 0);
+    return !off && (n == 4096 || n == 2048 || n == 1024) && wx_lattice_applicable_f64(filt);
+}
+
+int wx_lattice_tree_f64(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
+                        int64_t col_stride, const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, hipStream_t st)
+{
+    if (!wx_lattice_tree_applicable_f64(n, filt)) return 0;
+    if (n == 4096) return wx_lattice_tree0_f64(inverse, x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st);
+    if (n == 2048) return wx_lattice_tree1_f64(inverse, x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st);
+    return wx_lattice_tree2_f64(inverse, x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st);
+}

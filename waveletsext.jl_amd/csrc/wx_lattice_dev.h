@@ -621,9 +621,13 @@ struct WxLatW {
     double gl[13];            // g^l
 };
 
-template <int LAY, int LVL>
+// PRED (tree-driven transforms, k_lat_wpt_tree_f64): only the lines of the nodes that are LEAVES at this depth are stored --
+// bit 8 rho + i of `word` says whether this lane's 16 bytes of store instruction i of round rho belong to one (a table made
+// by k_lat_tree_prep with the same routing functions), `anyw` is the OR of the words over the lanes (wave-uniform: rounds and
+// half-rounds without a leaf line are skipped, exchange included).
+template <int LAY, int LVL, bool PRED = false>
 __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double *__restrict__ ycol, int lane, const WxLatW &cw,
-                                         unsigned sstride = 4096u >> lat_sh(LVL))
+                                         unsigned sstride = 4096u >> lat_sh(LVL), unsigned word = 0, unsigned anyw = 0)
 {
     // sstride: elements between the columns of consecutive signals of the wavefront (interleaved kernels; the signal
     // number is the top lat_sh(LVL) bits of the routed address)
@@ -659,6 +663,7 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
     const unsigned yo = (unsigned)(o_lane & ((1 << SB) - 1)) + (unsigned)(o_lane >> SB) * sstride;
     lat_for<4>([&](auto Rc) {
         constexpr int rho = Rc;
+        if (PRED && ((anyw >> (8 * rho)) & 0xffu) == 0) return;
         lat_for<16>([&](auto Vc) {
             constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
             constexpr int pc = lat_emit_pc_reg(LAY, LVL, r);
@@ -666,6 +671,7 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
         });
         lat_for<2>([&](auto HH) {
             constexpr int hh = HH;
+            if (PRED && ((anyw >> (8 * rho + 4 * hh)) & 0xfu) == 0) return;
             double v[8];
             lat_for<4>([&](auto I) {
                 constexpr int i = 4 * hh + I;
@@ -679,7 +685,10 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
                 o.x = v[2 * I];
                 o.y = v[2 * I + 1];
                 constexpr int oc = lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i);
-                lat_st2w(lat_sbase(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + yo, o);
+                if constexpr (PRED) {
+                    if ((word >> (8 * rho + i)) & 1u) lat_st2(lat_sbase(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + yo, o);
+                } else
+                    lat_st2w(lat_sbase(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + yo, o);
             });
         });
     });
@@ -689,9 +698,13 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
 // (the two LDS address patterns swap roles: 16-byte loads of complete lines are written where lat_emit reads, the registers
 // are read where lat_emit writes)
 __device__ __forceinline__ void lat_st1(double __attribute__((address_space(1))) *p, double v) { *p = v; }
-template <int LAY, int LVL>
+// PRED (k_lat_iwpt_tree_f64): only the lines of this depth's leaves are loaded (`word`, `anyw` as in lat_emit) and only the
+// registers that hold a leaf of this depth take the loaded value (bit r of `rmask`), the others keep what the deeper
+// levels have synthesised.
+template <int LAY, int LVL, bool PRED = false>
 __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const double *__restrict__ xcol, int lane, const WxLatW &cw,
-                                           unsigned sstride = 4096u >> lat_sh(LVL))
+                                           unsigned sstride = 4096u >> lat_sh(LVL), unsigned word = 0, unsigned anyw = 0,
+                                           unsigned long long rmask = 0)
 {
     constexpr int SB = 12 - lat_sh(LVL);
     int hi_lane = 0, pos_lane = 0;
@@ -722,24 +735,30 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
     const unsigned wra = lds0 + 8u * (unsigned)(17 * qq + 2 * (lane & 7));
     const unsigned xo = (unsigned)(o_lane & ((1 << SB) - 1)) + (unsigned)(o_lane >> SB) * sstride;
     lat_d2 v[8];
-    lat_for<8>([&](auto I) {
-        constexpr int i = I;
-        constexpr int oc = lat_emit_o_round(LAY, LVL, 0) + lat_emit_o_instr(LAY, LVL, i);
-        v[i] = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
-    });
-    lat_for<4>([&](auto Rc) {
-        constexpr int rho = Rc;
+    auto fetch = [&](auto Rn) {
+        constexpr int rn = Rn;
         lat_for<8>([&](auto I) {
             constexpr int i = I;
-            lds_wr<8 * (17 * 8 * i)>(wra, v[i].x);
-            lds_wr<8 * (17 * 8 * i + 1)>(wra, v[i].y);
+            constexpr int oc = lat_emit_o_round(LAY, LVL, rn) + lat_emit_o_instr(LAY, LVL, i);
+            if constexpr (PRED) {
+                v[i].x = v[i].y = 0.0;
+                if ((word >> (8 * rn + i)) & 1u) v[i] = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
+            } else
+                v[i] = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
         });
-        if constexpr (rho < 3)                                  // the next round's lines travel while this one is exchanged
+    };
+    fetch(std::integral_constant<int, 0>{});
+    lat_for<4>([&](auto Rc) {
+        constexpr int rho = Rc;
+        const bool live = !PRED || ((anyw >> (8 * rho)) & 0xffu) != 0;       // wave-uniform
+        if (live)
             lat_for<8>([&](auto I) {
                 constexpr int i = I;
-                constexpr int oc = lat_emit_o_round(LAY, LVL, rho + 1) + lat_emit_o_instr(LAY, LVL, i);
-                v[i] = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
+                lds_wr<8 * (17 * 8 * i)>(wra, v[i].x);
+                lds_wr<8 * (17 * 8 * i + 1)>(wra, v[i].y);
             });
+        if constexpr (rho < 3) fetch(std::integral_constant<int, rho + 1>{});   // the next round's lines travel while this one is exchanged
+        if (!live) return;
         double t[16];
         lat_for<16>([&](auto Vc) {
             constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
@@ -749,7 +768,8 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
         lat_for<16>([&](auto Vc) {
             constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
             constexpr int pc = lat_emit_pc_reg(LAY, LVL, r);
-            x[r] = t[Vc] * gf[pc];
+            if constexpr (PRED) x[r] = ((rmask >> r) & 1ull) ? t[Vc] * gf[pc] : x[r];
+            else x[r] = t[Vc] * gf[pc];
         });
     });
 }
@@ -1462,6 +1482,161 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     }
     WX_LVL(6, 0, 0, c, 6) WX_LVL(6, 1, 0, c, 7) WX_LVL(6, 2, 0, c, 8) WX_LVL(6, 3, 0, c, 9) WX_LVL(6, 4, 0, c, 10) WX_LVL(6, 5, 0, c, 11)
 #undef WX_LVL
+}
+
+
+// ---------------------------------------------------------------- tree-driven wpt / iwpt / iwpd (wx_lattice_tree.hip)
+// wpt(x, wt, tree) is the set of leaves of the tree picked out of the packet table (Wavelets.jl's wpt along a tree;
+// Utils.jl:101-134 getbasiscoef; call sites DWT.jl:340-351, dwt/dwt_all.jl:152-166, 210-225, LDB.jl:303, 409,
+// Denoising.jl:527).  The lattice computes every node of every level anyway, in registers, so the tree only decides
+// WHERE a coefficient leaves (forward) or enters (inverse): after level l the static routing of lat_emit writes the lines of
+// the nodes that are leaves at depth l -- and only those -- to their place in the output; the inverse takes the leaves of
+// depth l in through lat_absorb before it runs synthesis level l on top of what the deeper levels have rebuilt.  Nodes
+// below a leaf are computed and never stored (forward) or are zeros (inverse).  The predicates are tables of a tree,
+// made once per call by k_lat_tree_prep with the same routing functions the kernels are compiled from.
+//
+// Level code LVL = l + 16 SH as everywhere in this file: 2^SH signals of N = 4096 >> SH samples per wavefront.
+__device__ __forceinline__ bool lat_tree_leaf(const uint8_t *status, int64_t nstatus, int l, int j)
+{
+    const int idx = (1 << l) + j;                                   // heap index (1-based) of node j of depth l
+    for (int d = 1; d <= l; ++d) {
+        const int anc = idx >> d;
+        if (anc - 1 >= nstatus || !status[anc - 1]) return false;     // an ancestor is a leaf: the node does not exist
+    }
+    return idx - 1 >= nstatus || !status[idx - 1];
+}
+constexpr int lat_tree_lay(int bit) { return bit < 2 ? 0 : (bit < 6 ? 2 : 6); }      // layout in which index bit `bit` is transformed
+
+// words[64 l + lane], rmask[64 l + lane], any[l] for l = 1 .. 12 - SH (block l - 1, 64 threads)
+template <int SH>
+__global__ __launch_bounds__(64) void k_lat_tree_prep(const uint8_t *__restrict__ status, int64_t nstatus, int L,
+                                                       unsigned *__restrict__ words, unsigned long long *__restrict__ rmask,
+                                                       unsigned *__restrict__ any)
+{
+    const int l = blockIdx.x + 1, lane = threadIdx.x;
+    constexpr int SB = 12 - SH;
+    unsigned w = 0;
+    unsigned long long rm = 0;
+    if (l <= L && l <= SB) {
+        const int lay = lat_tree_lay(SH + l - 1), lc = l + 16 * SH;
+        // line side: the 16 bytes this lane stores / loads in instruction i of round rho (lat_emit / lat_absorb)
+        const int qq = lane >> 3;
+        int o_lane = 2 * (lane & 7);
+        for (int q = 0; q < 3; ++q) o_lane |= ((qq >> q) & 1) << lat_line(lay, lc, q).ob;
+        for (int rho = 0; rho < 4; ++rho)
+            for (int i = 0; i < 8; ++i) {
+                const int o = o_lane | lat_emit_o_round(lay, lc, rho) | lat_emit_o_instr(lay, lc, i);
+                const int pos = o & ((1 << SB) - 1);                   // position inside the signal (the signal number is above)
+                if (lat_tree_leaf(status, nstatus, l, pos >> (SB - l))) w |= 1u << (8 * rho + i);
+            }
+        // register side: sample index p held by register r of this lane in layout `lay`
+        for (int r = 0; r < 64; ++r) {
+            int p = 0;
+            for (int t = 0; t < 12; ++t) {
+                const LatSrc sc = lat_src(lay, t);
+                p |= (((sc.reg ? r : lane) >> sc.bit) & 1) << t;
+            }
+            int j = 0;
+            for (int t = 0; t < l; ++t) j |= ((p >> (SH + t)) & 1) << (l - 1 - t);
+            if (lat_tree_leaf(status, nstatus, l, j)) rm |= 1ull << r;
+        }
+    }
+    words[64 * l + lane] = w;
+    rmask[64 * l + lane] = rm;
+    unsigned a = w;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a |= __shfl_xor(a, d, 64);
+    if (lane == 0) any[l] = a;
+}
+
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_tree_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw, const unsigned *__restrict__ words,
+    const unsigned *__restrict__ any)
+{
+    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    constexpr int N = 4096 >> SH;
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const double *xs = x + (int64_t)sig0 * N;
+    double *ys = y + (int64_t)sig0 * N;
+    const WxLat &cf = cw.c;
+    unsigned wd[13];
+#pragma unroll
+    for (int l = 1; l <= 12 - SH; ++l) wd[l] = words[64 * l + lane];
+#define WX_LVL(LAY, KK, HH, REG, BIT)                                                           \
+    if constexpr (BIT >= SH) {                                                                  \
+        constexpr int l = BIT - SH + 1;                                                         \
+        lat_level<KK, HH, NS, false>(REG, cf);                                                  \
+        {                                                                                       \
+            const unsigned aw = (unsigned)__builtin_amdgcn_readfirstlane((int)any[l]);          \
+            if (aw) lat_emit<LAY, l + 16 * SH, true>(REG, lds0, ys, lane, cw, (unsigned)N, wd[l], aw); \
+        }                                                                                       \
+        if (L <= l) return;                                                                     \
+    }
+    double c[64];
+    if constexpr (SH < 2) {
+        double a[64], bb[64];
+        lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw);
+        WX_LVL(0, 0, 6, a, 0) WX_LVL(0, 1, 6, a, 1)
+        lat_t2(a, bb, lds0, lane);
+        WX_LVL(2, 0, 4, bb, 2) WX_LVL(2, 1, 4, bb, 3) WX_LVL(2, 2, 4, bb, 4) WX_LVL(2, 3, 4, bb, 5)
+        lat_t3(bb, c, lds0, lane);
+    } else {
+        double bb[64];
+        lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw);
+        WX_LVL(2, 0, 4, bb, 2) WX_LVL(2, 1, 4, bb, 3) WX_LVL(2, 2, 4, bb, 4) WX_LVL(2, 3, 4, bb, 5)
+        lat_t3(bb, c, lds0, lane);
+    }
+    WX_LVL(6, 0, 0, c, 6) WX_LVL(6, 1, 0, c, 7) WX_LVL(6, 2, 0, c, 8) WX_LVL(6, 3, 0, c, 9) WX_LVL(6, 4, 0, c, 10) WX_LVL(6, 5, 0, c, 11)
+#undef WX_LVL
+}
+
+// leaves of signal s of the wavefront: depth l at xs + s in_stride + l col_stride (col_stride = 0: the dense leaf array of
+// iwpt; col_stride = N: the packet table of iwpd, DWT.jl:340-351)
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_tree_f64(
+    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride, WxLatW cw,
+    const unsigned *__restrict__ words, const unsigned long long *__restrict__ rmask, const unsigned *__restrict__ any)
+{
+    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    constexpr int N = 4096 >> SH;
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const double *xs = xw + (int64_t)sig0 * in_stride;
+    double *ys = y + (int64_t)sig0 * N;
+    const WxLat &cf = cw.c;
+#define WX_ILVL(LAY, KK, HH, REG, BIT)                                                          \
+    if constexpr (BIT >= SH) {                                                                  \
+        constexpr int l = BIT - SH + 1;                                                         \
+        if (L >= l) {                                                                           \
+            const unsigned aw = (unsigned)__builtin_amdgcn_readfirstlane((int)any[l]);          \
+            if (aw)                                                                             \
+                lat_absorb<LAY, l + 16 * SH, true>(REG, lds0, xs + (size_t)l * col_stride, lane, cw, in_stride,  \
+                                                   words[64 * l + lane], aw, rmask[64 * l + lane]);             \
+            lat_level<KK, HH, NS, true>(REG, cf);                                               \
+        }                                                                                       \
+    }
+    double c[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) c[r] = 0.0;
+    WX_ILVL(6, 5, 0, c, 11) WX_ILVL(6, 4, 0, c, 10) WX_ILVL(6, 3, 0, c, 9) WX_ILVL(6, 2, 0, c, 8) WX_ILVL(6, 1, 0, c, 7) WX_ILVL(6, 0, 0, c, 6)
+    double bb[64];
+    lat_t3i(c, bb, lds0, lane);
+    WX_ILVL(2, 3, 4, bb, 5) WX_ILVL(2, 2, 4, bb, 4) WX_ILVL(2, 1, 4, bb, 3) WX_ILVL(2, 0, 4, bb, 2)
+    if constexpr (SH >= 2) {
+        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw);
+    } else {
+        double a[64];
+        lat_t2i(bb, a, lds0, lane);
+        WX_ILVL(0, 1, 6, a, 1) WX_ILVL(0, 0, 6, a, 0)
+        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw);
+    }
+#undef WX_ILVL
 }
 
 }  // namespace

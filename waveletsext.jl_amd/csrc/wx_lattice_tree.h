@@ -1,0 +1,58 @@
+// wx_lattice_tree.h -- launcher of the tree-driven lattice kernels (k_lat_wpt_tree_f64, k_lat_iwpt_tree_f64,
+// k_lat_tree_prep in wx_lattice_dev.h): wpt / iwpt along a tree and iwpd by tree for Float64 signals of 4096, 2048 and
+// 1024 samples.  Reference: Wavelets.jl's wpt / iwpt with a tree::BitVector as called by wptall / iwptall
+// (dwt/dwt_all.jl:152-166, 210-225), iwpd (DWT.jl:340-351), LDB (LDB.jl:303, 409) and denoise (Denoising.jl:527).
+#include "wx_lattice_dev.h"
+#include "wx_host.h"
+
+// included by wx_lattice_tree0.hip / tree1 / tree2 with WX_LAT_TREE_SH = 0, 1, 2 (signal length 4096 >> SH) and
+// WX_LAT_TREE_FN = the launcher's name: one translation unit per length so that the 60 kernels compile in parallel
+
+// 0 = not applicable (the caller takes the fused LDS kernels), 1 = launched, < 0 = error.
+// inverse: leaves of signal b, depth l at x + b in_stride + l col_stride (col_stride = 0: dense leaves, n: packet table)
+int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride, int64_t col_stride,
+                   const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, hipStream_t st)
+{
+    constexpr int SH = WX_LAT_TREE_SH;
+    constexpr int64_t per = (int64_t)1 << SH;
+    if (n != (4096 >> SH) || L < 1 || L + SH > 12 || filt.F < 2 || batch < per || batch > 0x7fffffff || !dstatus) return 0;
+    if ((batch & (per - 1)) && x == y) return 0;             // the tail wavefront re-does signals: out of place only
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
+    if (inverse && (in_stride < n || (in_stride & 3) || (col_stride & 3) || in_stride * (per - 1) + 13 * col_stride + 4096 > 0x7fffffff)) return 0;
+    WxLatW cw;
+    if (!wx_lattice_factor(filt, L, inverse, &cw.c)) return 0;
+    {
+        WxLat one;
+        if (!wx_lattice_factor(filt, 1, false, &one)) return 0;
+        const long double g = one.g0;                           // product of the cosines of one level
+        long double acc = 1;
+        for (int l = 0; l <= 12; ++l) { cw.gl[l] = (double)acc; acc *= inverse ? 1 / g : g; }
+    }
+    WxScratch scr(st);
+    unsigned char *tab = (unsigned char *)scr.alloc(13 * 64 * 4 + 13 * 64 * 8 + 64);
+    if (!tab) return WX_EHIP;
+    unsigned long long *rmask = (unsigned long long *)tab;
+    unsigned *words = (unsigned *)(tab + 13 * 64 * 8);
+    unsigned *any = (unsigned *)(tab + 13 * 64 * 8 + 13 * 64 * 4);
+    hipLaunchKernelGGL((k_lat_tree_prep<SH>), dim3(12), dim3(64), 0, st, dstatus, nstatus, L, words, rmask, any);
+    const int64_t nwave = (batch + per - 1) / per;
+    const int last_sig = (int)(batch - per);
+#define WX_GOT(NSS)                                                                                                  \
+    case NSS:                                                                                                        \
+        if (inverse)                                                                                                 \
+            hipLaunchKernelGGL((k_lat_iwpt_tree_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, \
+                               (unsigned)in_stride, (unsigned)col_stride, cw, (const unsigned *)words,               \
+                               (const unsigned long long *)rmask, (const unsigned *)any);                            \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_lat_wpt_tree_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw, \
+                               (const unsigned *)words, (const unsigned *)any);                                      \
+        break;
+    switch (filt.F / 2) {
+        WX_GOT(1) WX_GOT(2) WX_GOT(3) WX_GOT(4) WX_GOT(5) WX_GOT(6) WX_GOT(7) WX_GOT(8) WX_GOT(9) WX_GOT(10)
+    default: return 0;
+    }
+#undef WX_GOT
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wx_set_hip_error(e, "lattice tree launch", __FILE__, __LINE__);
+    return 1;
+}
