@@ -96,11 +96,12 @@ def test_tree_wpt_equals_gather_of_the_device_table(wx, n):
     wt = _wt(wx, "db4")
     x = np.asfortranarray(rng.standard_normal((n, 8)))
     xw = wx.wpdall(x, wt)
-    for tree in _trees(wx, n, rng, 10):
+    for k, tree in enumerate(_trees(wx, n, rng, 10)):
         got = wx.wptall(x, wt, tree)
         gath = wx.getbasiscoefall(xw, tree)
-        # (trees of depth < 6 - SH take their table from other kernels: same values to rounding, not the same bits)
-        if _depth(tree) + (12 - int(np.log2(n))) >= 6:
+        # (trees of depth < 6 - SH take their table from other kernels, and the deep levels of the pyramids k = 0 .. 2 run
+        # in the direct form of wx_dwttail.hip: same values to rounding, not the same bits)
+        if k >= 3 and _depth(tree) + (12 - int(np.log2(n))) >= 6:
             assert np.array_equal(np.asarray(got), np.asarray(gath)), int(tree.sum())
         assert relerr(got, gath) <= 1e-13, int(tree.sum())
 

@@ -698,14 +698,49 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
 // (the two LDS address patterns swap roles: 16-byte loads of complete lines are written where lat_emit reads, the registers
 // are read where lat_emit writes)
 __device__ __forceinline__ void lat_st1(double __attribute__((address_space(1))) *p, double v) { *p = v; }
-// PRED (k_lat_iwpt_tree_f64): only the lines of this depth's leaves are loaded (`word`, `anyw` as in lat_emit) and only the
-// registers that hold a leaf of this depth take the loaded value (bit r of `rmask`), the others keep what the deeper
-// levels have synthesised.
-template <int LAY, int LVL, bool PRED = false>
-__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const double *__restrict__ xcol, int lane, const WxLatW &cw,
-                                           unsigned sstride = 4096u >> lat_sh(LVL), unsigned word = 0, unsigned anyw = 0,
-                                           unsigned long long rmask = 0)
+// PRED (k_lat_iwpt_tree_f64): only the lines of this depth's leaves are loaded (`word`, `anyw` as in lat_emit), everything
+// else arrives as zeros, and the arrivals are ADDED to what the deeper levels have synthesised (see below).
+// the lines of rounds 0 and 1 of lat_absorb<LAY, LVL, true, true>, issued early (k_lat_iwpt_tree_f64 asks for them before it
+// runs the synthesis level above, so that their latency hides behind that level's arithmetic; inside the absorb the loads
+// run two rounds ahead of the exchange: one round ahead left every round waiting for memory)
+template <int LAY, int LVL>
+__device__ __forceinline__ unsigned lat_absorb_xo(int lane, unsigned sstride)
 {
+    constexpr int SB = 12 - lat_sh(LVL);
+    const int qq = lane >> 3;
+    int o_lane = 2 * (lane & 7);
+    lat_for<3>([&](auto Qc) {
+        constexpr int q = Qc;
+        constexpr int ob = lat_line(LAY, LVL, q).ob;
+        o_lane |= ((qq >> q) & 1) << ob;
+    });
+    return (unsigned)(o_lane & ((1 << SB) - 1)) + (unsigned)(o_lane >> SB) * sstride;
+}
+template <int LAY, int LVL, int RN>
+__device__ __forceinline__ void lat_absorb_fetch(lat_d2 (&v)[16], const double *__restrict__ xcol, unsigned xo, unsigned sstride, unsigned word)
+{
+    constexpr int SB = 12 - lat_sh(LVL);
+    lat_for<8>([&](auto I) {
+        constexpr int i = I;
+        constexpr int oc = lat_emit_o_round(LAY, LVL, RN) + lat_emit_o_instr(LAY, LVL, i);
+        lat_d2 &d = v[8 * (RN & 1) + i];
+        d.x = d.y = 0.0;
+        if ((word >> (8 * RN + i)) & 1u) d = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
+    });
+}
+template <int LAY, int LVL>
+__device__ __forceinline__ void lat_absorb_fetch01(lat_d2 (&v)[16], const double *__restrict__ xcol, int lane, unsigned sstride, unsigned word)
+{
+    const unsigned xo = lat_absorb_xo<LAY, LVL>(lane, sstride);
+    lat_absorb_fetch<LAY, LVL, 0>(v, xcol, xo, sstride, word);
+    lat_absorb_fetch<LAY, LVL, 1>(v, xcol, xo, sstride, word);
+}
+
+template <int LAY, int LVL, bool PRED = false, bool PRE = false>
+__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const double *__restrict__ xcol, int lane, const WxLatW &cw,
+                                           unsigned sstride, unsigned word, unsigned anyw, lat_d2 (&v)[16])
+{
+    static_assert(PRE == PRED, "prefetched lines come with the predicated form");
     constexpr int SB = 12 - lat_sh(LVL);
     int hi_lane = 0, pos_lane = 0;
     double b = cw.gl[lat_lv(LVL)];
@@ -734,30 +769,29 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
     });
     const unsigned wra = lds0 + 8u * (unsigned)(17 * qq + 2 * (lane & 7));
     const unsigned xo = (unsigned)(o_lane & ((1 << SB) - 1)) + (unsigned)(o_lane >> SB) * sstride;
-    lat_d2 v[8];
     auto fetch = [&](auto Rn) {
         constexpr int rn = Rn;
-        lat_for<8>([&](auto I) {
-            constexpr int i = I;
-            constexpr int oc = lat_emit_o_round(LAY, LVL, rn) + lat_emit_o_instr(LAY, LVL, i);
-            if constexpr (PRED) {
-                v[i].x = v[i].y = 0.0;
-                if ((word >> (8 * rn + i)) & 1u) v[i] = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
-            } else
-                v[i] = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
-        });
+        if constexpr (PRED) lat_absorb_fetch<LAY, LVL, rn>(v, xcol, xo, sstride, word);
+        else
+            lat_for<8>([&](auto I) {
+                constexpr int i = I;
+                constexpr int oc = lat_emit_o_round(LAY, LVL, rn) + lat_emit_o_instr(LAY, LVL, i);
+                v[8 * (rn & 1) + i] = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
+            });
     };
-    fetch(std::integral_constant<int, 0>{});
+    if constexpr (!PRE) fetch(std::integral_constant<int, 0>{});
     lat_for<4>([&](auto Rc) {
         constexpr int rho = Rc;
         const bool live = !PRED || ((anyw >> (8 * rho)) & 0xffu) != 0;       // wave-uniform
         if (live)
             lat_for<8>([&](auto I) {
                 constexpr int i = I;
-                lds_wr<8 * (17 * 8 * i)>(wra, v[i].x);
-                lds_wr<8 * (17 * 8 * i + 1)>(wra, v[i].y);
+                lds_wr<8 * (17 * 8 * i)>(wra, v[8 * (rho & 1) + i].x);
+                lds_wr<8 * (17 * 8 * i + 1)>(wra, v[8 * (rho & 1) + i].y);
             });
-        if constexpr (rho < 3) fetch(std::integral_constant<int, rho + 1>{});   // the next round's lines travel while this one is exchanged
+        // the next lines travel while this round is exchanged: one round ahead (plain), two rounds ahead (tree-driven)
+        if constexpr (!PRE && rho < 3) fetch(std::integral_constant<int, rho + 1>{});
+        if constexpr (PRE && rho < 2) fetch(std::integral_constant<int, rho + 2>{});
         if (!live) return;
         double t[16];
         lat_for<16>([&](auto Vc) {
@@ -768,10 +802,27 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
         lat_for<16>([&](auto Vc) {
             constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
             constexpr int pc = lat_emit_pc_reg(LAY, LVL, r);
-            if constexpr (PRED) x[r] = ((rmask >> r) & 1ull) ? t[Vc] * gf[pc] : x[r];
+            // PRED: the transform is linear and a register that holds a leaf of this depth holds an exact zero so far (its
+            // descendants do not exist: zeros in, zeros out), while every loaded value that is not a leaf's is a zero too
+            // (whole 16-byte pieces are predicated): adding is selecting
+            if constexpr (PRED) x[r] = fma(t[Vc], gf[pc], x[r]);
             else x[r] = t[Vc] * gf[pc];
         });
     });
+}
+
+template <int LAY, int LVL, bool PRED = false>
+__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const double *__restrict__ xcol, int lane, const WxLatW &cw,
+                                           unsigned sstride = 4096u >> lat_sh(LVL), unsigned word = 0, unsigned anyw = 0,
+                                           unsigned long long rmask = 0)
+{
+    (void)rmask;
+    lat_d2 v[16];
+    if constexpr (PRED) {
+        lat_absorb_fetch01<LAY, LVL>(v, xcol, lane, sstride, word);
+        lat_absorb<LAY, LVL, true, true>(x, lds0, xcol, lane, cw, sstride, word, anyw, v);
+    } else
+        lat_absorb<LAY, LVL, false, false>(x, lds0, xcol, lane, cw, sstride, word, anyw, v);
 }
 
 // the three layout changes of the forward direction, shared by wpt and wpd
@@ -1610,14 +1661,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const double *xs = xw + (int64_t)sig0 * in_stride;
     double *ys = y + (int64_t)sig0 * N;
     const WxLat &cf = cw.c;
+    // the lines of the next (shallower) depth's leaves are requested before a synthesis level runs and taken in after it
+    lat_d2 pv[16];
 #define WX_ILVL(LAY, KK, HH, REG, BIT)                                                          \
     if constexpr (BIT >= SH) {                                                                  \
         constexpr int l = BIT - SH + 1;                                                         \
         if (L >= l) {                                                                           \
             const unsigned aw = (unsigned)__builtin_amdgcn_readfirstlane((int)any[l]);          \
-            if (aw)                                                                             \
-                lat_absorb<LAY, l + 16 * SH, true>(REG, lds0, xs + (size_t)l * col_stride, lane, cw, in_stride,  \
-                                                   words[64 * l + lane], aw, rmask[64 * l + lane]);             \
+            if (aw) {                                                                           \
+                const unsigned wl = words[64 * l + lane];                                       \
+                if (L == l) lat_absorb_fetch01<LAY, l + 16 * SH>(pv, xs + (size_t)l * col_stride, lane, in_stride, wl);  \
+                lat_absorb<LAY, l + 16 * SH, true, true>(REG, lds0, xs + (size_t)l * col_stride, lane, cw, in_stride, wl, aw, pv); \
+            }                                                                                   \
+            if constexpr (l > 1) {                                                              \
+                if (__builtin_amdgcn_readfirstlane((int)any[l - 1]))                            \
+                    lat_absorb_fetch01<lat_tree_lay(BIT - 1), l - 1 + 16 * SH>(pv, xs + (size_t)(l - 1) * col_stride, lane, in_stride, \
+                                                                               words[64 * (l - 1) + lane]);     \
+            }                                                                                   \
             lat_level<KK, HH, NS, true>(REG, cf);                                               \
         }                                                                                       \
     }
