@@ -111,6 +111,71 @@ __global__ __launch_bounds__(1024) void k_swt_fwd_level(const T *__restrict__ x,
 
 
 // ------------------------------------------------------------------------------------------
+// swpd / acwpd (heap-ordered table), two levels per pass: the parent column and its two children stay in LDS, so the table
+// is read once per six written columns instead of once per two (swt/swt_one_level.jl:99-127, acwt/acwt_one_level.jl:101-128
+// as driven by SWT.jl:840-902 / ACWT.jl:733-759).  blockIdx.x = node of depth d, blockIdx.y = signal (grid-strided).
+// ------------------------------------------------------------------------------------------
+template <typename T, bool AC>
+__global__ __launch_bounds__(1024) void k_swpd_fwd_two(const T *__restrict__ x, T *__restrict__ xw, int n, int ncols,
+                                                      int64_t batch, int d, WxFilt filt, WxAcFilt ac)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    T *v = reinterpret_cast<T *>(wx_smem), *c0 = v + n, *c1 = c0 + n;
+    const int b = blockIdx.x;
+    const int pcol = (1 << d) - 1 + b, ccol = (1 << (d + 1)) - 1 + 2 * b, gcol = (1 << (d + 2)) - 1 + 4 * b;
+    // one analysis step at dilation s: src (LDS) -> lo, hi (global) and, if keep, -> klo, khi (LDS)
+    auto step = [&](const T *src, int s, T *lo, T *hi, T *klo, T *khi) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            double a, dd;
+            if (!AC) {
+                a = 0.0; dd = 0.0;
+                int k1 = i - s; if (k1 < 0) k1 += n;
+                int k2 = i;
+                for (int j = 0; j < filt.F; ++j) {
+                    a = fma(filt.q[j], (double)src[k1], a);
+                    dd = fma((j & 1) ? -filt.q[j] : filt.q[j], (double)src[k2], dd);
+                    k1 += s; if (k1 >= n) k1 -= n;
+                    k2 -= s; if (k2 < 0) k2 += n;
+                }
+            } else {
+                double S = 0.0;
+                int km = i, kp = i;
+                const int s2 = (2 * s) % n;
+                km -= s; if (km < 0) km += n;
+                kp += s; if (kp >= n) kp -= n;
+                for (int l = 1; l < ac.F; l += 2) {                  // odd lags only
+                    S = fma(ac.b[l - 1], (double)src[km] + (double)src[kp], S);
+                    km -= s2; if (km < 0) km += n;
+                    kp += s2; if (kp >= n) kp -= n;
+                }
+                const double c = ac.c1 * (double)src[i];
+                a = c + S;
+                dd = c - S;
+            }
+            lo[i] = (T)a;
+            hi[i] = (T)dd;
+            if (klo) { klo[i] = (T)a; khi[i] = (T)dd; }
+        }
+    };
+    const int s = (1 << d) % n, s1 = (2 << d) % n;
+    for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
+        T *base = xw + sig * (int64_t)n * ncols;
+        const T *src = (d == 0) ? x + sig * (int64_t)n : base + (int64_t)pcol * n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const T t = src[i];
+            v[i] = t;
+            if (d == 0) base[i] = t;                                 // root column of the packet table
+        }
+        __syncthreads();
+        step(v, s, base + (int64_t)ccol * n, base + (int64_t)(ccol + 1) * n, c0, c1);
+        __syncthreads();
+        step(c0, s1, base + (int64_t)gcol * n, base + (int64_t)(gcol + 1) * n, nullptr, nullptr);
+        step(c1, s1, base + (int64_t)(gcol + 2) * n, base + (int64_t)(gcol + 3) * n, nullptr, nullptr);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // sdwt / acdwt with every level in one kernel: the running approximation stays in LDS (ping-pong), each
 // level writes only its detail column, the last approximation goes to column 0.  HBM sees the signal once
 // and every output column once ((L+2) n per signal instead of 3 L n one level at a time).
@@ -783,6 +848,17 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         const int K = (KF > 1 && dstop - d >= 2) ? (dstop - d >= KF ? KF : dstop - d) : 1;
         int64_t gy = batch;
         if (gy > 65535) gy = 65535;
+        // swpd / acwpd: two levels per pass while three columns fit the LDS (WX_SWPD_TWO=0: one level per pass)
+        static const bool two_off = getenv("WX_SWPD_TWO") && atoi(getenv("WX_SWPD_TWO")) == 0;
+        if (K == 1 && layout == WX_LAYOUT_WPD && dstop - d >= 2 && 3 * lds <= 160 * 1024 && !two_off && !wx_force_generic_swt()) {
+            auto k2 = ac ? k_swpd_fwd_two<T, true> : k_swpd_fwd_two<T, false>;
+            if (3 * lds > 64 * 1024)
+                WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)(3 * lds)));
+            hipLaunchKernelGGL(k2, dim3(1 << d, (unsigned)gy), dim3(nt), 3 * lds, st, x, xw, (int)n, ncols, batch, d, filt, acz);
+            d += 2;
+            continue;
+        }
         if (K == 1) {
             const int nodes = layout == WX_LAYOUT_DWT ? 1 : (1 << d);
             // long signals occupy most of a CU's LDS (one workgroup per CU): give that workgroup 16 waves
