@@ -8,7 +8,7 @@ A step = one forward pass + one inverse pass over the whole batch of the configu
 resident in HBM.  Default workload = BASELINE config 2 (`wpdall` 65536 x 4096 Float64, db8, full packet tree L = 12, then
 `iwpdall`).  Other workloads (`--workload`): `target` (north-star target: wptall / iwptall db4 L = 10), `cfg3` (swptall /
 iswptall 8192 signals of 16384 samples, haar, L = 12: the 4 TiB of leaves exist 64 signals at a time, a step loops over
-all chunks of the rank's shard), `cfg4` (2-D wptall / iwptall 4096 images 512 x 512 Float32 db4 L = 6), `cfg5` (acwpd + JBB
+all chunks of the rank's shard), `cfg3_sdwt` (the same signals through sdwtall / isdwtall), `cfg4` (2-D wptall / iwptall 4096 images 512 x 512 Float32 db4 L = 6), `cfg5` (acwpd + JBB
 moments / costs / tree, 262144 signals of 2048 samples, coif6, L = 11: moments accumulate over chunks of 2048 signals, one
 all-reduce of the moments when N > 1, costs and tree on every rank), plus the widened rows `bb`, `ldb`, `siwt`.
 
@@ -64,6 +64,11 @@ WORKLOADS = {
                  fwd_kernels=[("k_swt_fwd_multi<double, 8>", 2), ("k_haar_swpt6_fwd<1>", 1)],
                  desc="BASELINE config 3: swptall+iswptall (average-based) 8192x16384 f64 haar L=12; the leaves exist one "
                       "resident chunk of 64 signals (32 GiB) at a time, a step loops over every chunk of the shard"),
+    "cfg3_sdwt": dict(kind="sdwt", n=16384, batch=8192, wavelet="haar", L=12, dtype="f64",
+                      kernel="k_sdwt_fused_ip<double, false, 16>", inv_kernel="k_isdwt_avg_fused_ip<double, 16>",
+                      fwd_kernels=[("k_sdwt_fused_ip<double, false, 16>", 1)],
+                      desc="BASELINE config 3 read as the non-packet transform (SURVEY 8d: report both): sdwtall + isdwtall "
+                           "(average-based) 8192x16384 f64 haar L=12, output (16384, 13, 8192) = 13 GiB"),
     "swpt_db4": dict(kind="swpt", n=1024, batch=16384, chunk=2048, wavelet="db4", L=10, dtype="f64",
                      kernel="k_swpt_deep_fwd<8, false, 4>", inv_kernel="k_swpt_deep_inv<8, 4>",
                      fwd_kernels=[("k_swpt_deep_fwd<8, false, 4>", 1)],
@@ -398,6 +403,25 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
         W.info = dict(fwd_bytes=fb, inv_bytes=es * npts * Bl * 2, fwd_flops=flops, samples=npts * Bl, bound="hbm",
                       gather_bytes=es * npts * (B_out - Bl))
         W.keep = (x, y, full)
+        return W
+
+    if kind == "sdwt":
+        n = w["n"]
+        x = signals((n,))
+        xw = wx.jl_empty((n, L + 1, Bl), td, dev)
+        xh = wx.jl_empty((n, Bl), td, dev)
+        q, qp, Fq = qmf_arg(wt)
+
+        def step(legs):
+            legs.run("fwd", lambda: D._call("wx_sdwt1d", "_f64", A(x).ptr, A(xw).ptr, n, L, Bl, qp, Fq, A(x).stream()))
+            legs.run("inv", lambda: D._call("wx_isdwt1d", "_f64", A(xw).ptr, A(xh).ptr, n, L, -1, Bl, qp, Fq, A(x).stream()))
+
+        W.step = step
+        W.check = lambda: float((xh - x).abs().max() / x.abs().max())
+        W.output = lambda gathered: xh
+        fb = es * n * Bl * (L + 2)
+        W.info = dict(fwd_bytes=fb, inv_bytes=fb, fwd_flops=4.0 * F * n * L * Bl, samples=n * Bl, bound="hbm")
+        W.keep = (x, xw, xh, q)
         return W
 
     if kind == "swpt":

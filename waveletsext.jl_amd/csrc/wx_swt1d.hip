@@ -361,6 +361,202 @@ __global__ __launch_bounds__(1024) void k_isdwt_avg_fused(const T *__restrict__ 
     }
 }
 
+// element `idx` of an array whose base is the same for the whole wavefront: the base stays in scalar registers and the lane
+// part is one 32-bit register (a generic pointer per load costs a 64-bit register pair each -- the unrolled tap loads of
+// the fused kernels below spilled hundreds of registers that way)
+template <typename T> static __device__ __forceinline__ T wx_uld(const T *base, unsigned idx)
+{
+    typedef const T __attribute__((address_space(1))) *P;
+    P g = (P)base;
+    asm("" : "+s"(g));
+    return g[idx];
+}
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load and store
+// (vmcnt(0)), which puts the memory latency of a level's detail column in front of every barrier of the fused kernels below
+static __device__ __forceinline__ void wx_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// Signals longer than the LDS of a CU (n sizeof(T) > 160 KiB; the reference has no length limit: swt/swt_one_level.jl:99-127,
+// acwt/acwt_one_level.jl:101-128): one level per launch straight from global memory.  Thread i of a tile reads the taps
+// v[(i + k s) mod n] -- consecutive lanes, consecutive addresses for every tap, the re-reads are served by L1 / L2.
+// grid (tiles of the column, node, signal-strided).
+// ------------------------------------------------------------------------------------------
+template <typename T, bool AC>
+__global__ __launch_bounds__(256) void k_swt_fwd_level_g(const T *__restrict__ x, T *__restrict__ xw, int n, int ncols,
+                                                        int64_t batch, int L, int d, int layout, WxFilt filt, WxAcFilt ac,
+                                                        const T *__restrict__ alt_in, T *__restrict__ alt_out, int alt_nc)
+{
+    const int b = blockIdx.y;
+    int pcol, lcol, hcol;
+    wx_fwd_cols(layout, L, d, b, pcol, lcol, hcol);
+    const int s = (int)(((int64_t)1 << d) % n);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int64_t sig = blockIdx.z; sig < batch; sig += gridDim.z) {
+        T *base = xw + sig * (int64_t)n * ncols;
+        // sdwt / acdwt and swpt / acwpt write a child over the column their parent is read from (the one-CU kernels stage the
+        // parent in LDS first): here the nodes a later level reads travel through two scratch arrays as well -- alt_in
+        // (n, nodes of this depth, batch), alt_out (n, alt_nc x nodes, batch): the low child only (sdwt) or both (swpt)
+        const int nodes = gridDim.y;
+        const T *v = (d == 0) ? x + sig * (int64_t)n : (alt_in ? alt_in + (sig * nodes + b) * (int64_t)n : base + (int64_t)pcol * n);
+        if (d == 0 && layout == WX_LAYOUT_WPD) base[i] = v[i];      // root column of the packet table
+        double a, dd;
+        if (!AC) {
+            a = 0.0; dd = 0.0;
+            int k1 = i - s; if (k1 < 0) k1 += n;
+            int k2 = i;
+            for (int j = 0; j < filt.F; ++j) {
+                a = fma(filt.q[j], (double)v[k1], a);
+                dd = fma((j & 1) ? -filt.q[j] : filt.q[j], (double)v[k2], dd);
+                k1 += s; if (k1 >= n) k1 -= n;
+                k2 -= s; if (k2 < 0) k2 += n;
+            }
+        } else {
+            double S = 0.0;
+            int km = i, kp = i;
+            const int s2 = (int)((2 * (int64_t)s) % n);
+            km -= s; if (km < 0) km += n;
+            kp += s; if (kp >= n) kp -= n;
+            for (int l = 1; l < ac.F; l += 2) {
+                S = fma(ac.b[l - 1], (double)v[km] + (double)v[kp], S);
+                km -= s2; if (km < 0) km += n;
+                kp += s2; if (kp >= n) kp -= n;
+            }
+            const double c = ac.c1 * (double)v[i];
+            a = c + S;
+            dd = c - S;
+        }
+        base[(int64_t)lcol * n + i] = (T)a;
+        base[(int64_t)hcol * n + i] = (T)dd;
+        if (alt_out) {
+            T *o = alt_out + ((sig * nodes + b) * alt_nc) * (int64_t)n;
+            o[i] = (T)a;
+            if (alt_nc > 1) o[n + i] = (T)dd;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// sdwt / acdwt, every level in one kernel, ONE column of LDS (k_sdwt_fused needs two): a thread keeps the NPT approximation
+// samples it has computed in registers across the barrier and writes them over the parent afterwards.  For signals whose
+// column fills most of a CU's LDS (n = 16384 Float64: 128 KiB, config 3's length).  n == NPT * blockDim.x, a power of two.
+// Loop order: taps outside (run-time count), the thread's NPT outputs inside (unrolled): NPT independent LDS reads or global
+// loads per tap are in flight together, and nothing but the NPT accumulators lives across a tap.  (Unrolling the taps as well
+// made the compiler hoist every index and spill 40 .. 850 registers; a tap loop inside the output loop made every tap a load
+// followed by its use: 32 round trips per level.)
+// ------------------------------------------------------------------------------------------
+template <typename T, bool AC, int NPT>
+__global__ __launch_bounds__(1024) void k_sdwt_fused_ip(const T *__restrict__ x, T *__restrict__ xw, int n, int64_t batch,
+                                                       int L, WxFilt filt, WxAcFilt ac)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    T *v = reinterpret_cast<T *>(wx_smem);
+    const int NT = blockDim.x, msk = n - 1, t0 = threadIdx.x;
+    for (int64_t sig = blockIdx.x; sig < batch; sig += gridDim.x) {
+        T *base = xw + sig * (int64_t)n * (L + 1);
+        wx_stage<T>(v, x + sig * (int64_t)n, n);
+        wx_lds_barrier();
+        for (int d = 0; d < L; ++d) {
+            const int s = (1 << d) & msk;
+            T *hi = base + (int64_t)(L - d) * n;
+            double lo[NPT], dd[NPT];
+#pragma unroll
+            for (int it = 0; it < NPT; ++it) lo[it] = dd[it] = 0.0;
+            if (!AC) {
+                for (int j = 0; j < filt.F; ++j) {
+                    const double qa = filt.q[j], qd = (j & 1) ? -qa : qa;
+                    const int o1 = (j - 1) * s, o2 = -j * s;                 // v[i + (j-1) s], v[i - j s]
+#pragma unroll
+                    for (int it = 0; it < NPT; ++it) {
+                        const int i = t0 + it * NT;
+                        lo[it] = fma(qa, (double)v[(i + o1) & msk], lo[it]);
+                        dd[it] = fma(qd, (double)v[(i + o2) & msk], dd[it]);
+                    }
+                }
+            } else {
+                for (int l = 1; l < ac.F; l += 2) {                          // odd lags only: S = sum b_l (v[i - l s] + v[i + l s])
+                    const double bl = ac.b[l - 1];
+                    const int o = l * s;
+#pragma unroll
+                    for (int it = 0; it < NPT; ++it) {
+                        const int i = t0 + it * NT;
+                        lo[it] = fma(bl, (double)v[(i - o) & msk] + (double)v[(i + o) & msk], lo[it]);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < NPT; ++it) {
+                    const double c = ac.c1 * (double)v[t0 + it * NT], S = lo[it];
+                    lo[it] = c + S;
+                    dd[it] = c - S;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NPT; ++it) hi[t0 + it * NT] = (T)dd[it];
+            wx_lds_barrier();
+            if (d + 1 < L) {
+#pragma unroll
+                for (int it = 0; it < NPT; ++it) v[t0 + it * NT] = (T)lo[it];
+                wx_lds_barrier();
+            } else {
+#pragma unroll
+                for (int it = 0; it < NPT; ++it) base[t0 + it * NT] = (T)lo[it];      // the last approximation is column 0
+            }
+        }
+    }
+}
+
+// Average-based isdwt, every level in one kernel, ONE column of LDS: the running reconstruction r lives in LDS and is
+// overwritten in place (outputs in registers across the barrier), the detail column of a level is read straight from
+// global memory (F reads per sample, consecutive lanes on consecutive addresses).  See k_isdwt_avg_fused for the step:
+//   r_d[p] = 1/2 sum_j q[j] r_{d+1}[p + (1 - j) s] + (-1)^j q[j] w_d[p + j s]
+template <typename T, int NPT>
+__global__ __launch_bounds__(1024) void k_isdwt_avg_fused_ip(const T *__restrict__ xw, T *__restrict__ x, int n, int64_t batch,
+                                                            int L, WxFilt filt)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    T *r = reinterpret_cast<T *>(wx_smem);
+    const int NT = blockDim.x, msk = n - 1, t0 = threadIdx.x;
+    for (int64_t sig = blockIdx.x; sig < batch; sig += gridDim.x) {
+        const T *base = xw + sig * (int64_t)n * (L + 1);
+        wx_stage<T>(r, base, n);
+        wx_lds_barrier();
+        for (int d = L - 1; d >= 0; --d) {
+            const T *wd = base + (int64_t)(L - d) * n;
+            const int s = (1 << d) & msk;
+            double acc[NPT];
+#pragma unroll
+            for (int it = 0; it < NPT; ++it) acc[it] = 0.0;
+            for (int j = 0; j < filt.F; ++j) {
+                const double qa = filt.q[j], qd = (j & 1) ? -qa : qa;
+                const int o1 = (1 - j) * s, o2 = j * s;
+                T w[NPT];
+#pragma unroll
+                for (int it = 0; it < NPT; ++it) w[it] = wx_uld<T>(wd, (unsigned)((t0 + it * NT + o2) & msk));
+#pragma unroll
+                for (int it = 0; it < NPT; ++it) {
+                    const int p = t0 + it * NT;
+                    acc[it] = fma(qa, (double)r[(p + o1) & msk], acc[it]);
+                    acc[it] = fma(qd, (double)w[it], acc[it]);
+                }
+            }
+            wx_lds_barrier();
+            if (d > 0) {
+#pragma unroll
+                for (int it = 0; it < NPT; ++it) r[t0 + it * NT] = (T)(0.5 * acc[it]);
+                wx_lds_barrier();
+            } else {
+                T *dst = x + sig * (int64_t)n;
+#pragma unroll
+                for (int it = 0; it < NPT; ++it) dst[t0 + it * NT] = (T)(0.5 * acc[it]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K levels per pass (swpt only): the 2^K descendants of depth d+K are computed straight from the
 // LDS-resident parent with composite taps (products of the K per-level taps, merged per offset on
@@ -797,11 +993,36 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
 {
     if (batch == 0 || n == 0) return WX_OK;
     const size_t lds = (size_t)n * sizeof(T);
-    if (lds > 160 * 1024)
-        return wx_set_error(WX_EUNSUPPORTED, "redundant transforms: signal does not fit the 160 KiB LDS of one CU");
     const int ncols = layout == WX_LAYOUT_DWT ? L + 1 : (layout == WX_LAYOUT_WPT ? (1 << L) : (1 << (L + 1)) - 1);
     WxAcFilt acz;
     if (ac) acz = *ac; else { acz.F = 0; acz.c1 = 0; }
+    if (lds > 160 * 1024) {
+        // longer than a CU's LDS: one level per launch from global memory (any length below 2^30)
+        if (n >= ((int64_t)1 << 30)) return wx_set_error(WX_EUNSUPPORTED, "redundant transforms: signal length >= 2^30");
+        auto kg = ac ? k_swt_fwd_level_g<T, true> : k_swt_fwd_level_g<T, false>;
+        const unsigned tiles = (unsigned)((n + 255) / 256);
+        if (L > 16) return wx_set_error(WX_EUNSUPPORTED, "redundant transforms of long signals: more than 65535 nodes per level");
+        WxScratch scr(st);
+        T *alt[2] = {nullptr, nullptr};
+        const bool inplace_layout = layout != WX_LAYOUT_WPD;       // DWT, WPT: a child replaces its parent's column
+        const int alt_nc = layout == WX_LAYOUT_WPT ? 2 : 1;
+        if (inplace_layout && L >= 2) {
+            // the widest array a level reads: (n, 2^(L-1), batch) for swpt, (n, 1, batch) for sdwt
+            const size_t cols = layout == WX_LAYOUT_WPT ? ((size_t)1 << (L - 1)) : 1;
+            alt[0] = (T *)scr.alloc(sizeof(T) * n * cols * batch);
+            alt[1] = L >= 3 ? (T *)scr.alloc(sizeof(T) * n * cols * batch) : nullptr;
+            if (!alt[0] || (L >= 3 && !alt[1])) return WX_EHIP;
+        }
+        for (int d = 0; d < L; ++d) {
+            const int nodes = layout == WX_LAYOUT_DWT ? 1 : (1 << d);
+            const T *ain = (inplace_layout && d > 0) ? alt[(d - 1) & 1] : nullptr;
+            T *aout = (inplace_layout && d + 1 < L) ? alt[d & 1] : nullptr;
+            hipLaunchKernelGGL(kg, dim3(tiles, (unsigned)nodes, (unsigned)(batch > 1024 ? 1024 : batch)), dim3(256), 0, st, x, xw,
+                               (int)n, ncols, batch, L, d, layout, filt, acz, ain, aout, alt_nc);
+        }
+        WX_HIP_CHECK(hipGetLastError());
+        return WX_OK;
+    }
     auto kern = ac ? k_swt_fwd_level<T, true> : k_swt_fwd_level<T, false>;
     if (lds > 64 * 1024)
         WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -825,6 +1046,18 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         int64_t grid = (int64_t)256 * per_cu;
         if (grid > batch) grid = batch;
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(nt), 2 * lds, st, x, xw, (int)n, batch, L, filt, acz, wx_sdwt_window_min_for(filt.F));
+        WX_HIP_CHECK(hipGetLastError());
+        return WX_OK;
+    }
+    if (layout == WX_LAYOUT_DWT && L >= 2 && n == 1024 * (int64_t)(128 / sizeof(T)) && !wx_force_generic_swt() &&
+        !(getenv("WX_SDWT_INPLACE") && atoi(getenv("WX_SDWT_INPLACE")) == 0)) {
+        // the column fills more than half of a CU's LDS: in-place fused kernel, one workgroup of 1024 threads per CU
+        constexpr int NPT = 128 / sizeof(T);
+        auto ki = ac ? k_sdwt_fused_ip<T, true, NPT> : k_sdwt_fused_ip<T, false, NPT>;
+        WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int64_t grid = 256;
+        if (grid > batch) grid = batch;
+        hipLaunchKernelGGL(ki, dim3((unsigned)grid), dim3(1024), lds, st, x, xw, (int)n, batch, L, filt, acz);
         WX_HIP_CHECK(hipGetLastError());
         return WX_OK;
     }
@@ -1060,6 +1293,19 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
         int64_t grid = (int64_t)256 * per_cu;
         if (grid > batch) grid = batch;
         hipLaunchKernelGGL(ki, dim3((unsigned)grid), dim3(nt), lds3, st, xw, x, (int)n, batch, L, filt, wx_sdwt_window_min_for(filt.F));
+        WX_HIP_CHECK(hipGetLastError());
+        return WX_OK;
+    }
+    if (layout == WX_LAYOUT_DWT && sm < 0 && L >= 2 && n == 1024 * (int64_t)(128 / sizeof(T)) &&
+        !wx_force_generic_swt() && !(getenv("WX_SDWT_INPLACE") && atoi(getenv("WX_SDWT_INPLACE")) == 0)) {
+        // the three columns of k_isdwt_avg_fused do not fit: reconstruction in place in one column of LDS, details from global
+        constexpr int NPT = 128 / sizeof(T);
+        auto ki = k_isdwt_avg_fused_ip<T, NPT>;
+        const size_t lds1 = (size_t)n * sizeof(T);
+        WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        int64_t grid = 256;
+        if (grid > batch) grid = batch;
+        hipLaunchKernelGGL(ki, dim3((unsigned)grid), dim3(1024), lds1, st, xw, x, (int)n, batch, L, filt);
         WX_HIP_CHECK(hipGetLastError());
         return WX_OK;
     }
