@@ -852,6 +852,8 @@ def main():
         }
         if gather is not None:
             out["with_allgather"] = gather
+            # the sharded compute (`value`) and the throughput with the exchange inside the step, side by side
+            out["with_allgather_value"] = gather.get("value")
         if world == 1 and not a.no_also and not a.batch and a.workload == "cfg2":
             W.keep = None
             del W, legs, warm

@@ -141,6 +141,39 @@ def test_bench_two_ranks_gather_equals_one_rank(tmp_path, workload, batch):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("workload,batch", [("cfg2", 43), ("cfg4", 11), ("target", 75)])
+def test_bench_eight_ranks_ragged_shards(tmp_path, workload, batch):
+    """the N = 8 geometry the driver will launch, on one GPU in the gloo validation mode (eight fresh child processes):
+    batches that 8 does not divide (shards of 6 and 5, of 2 and 1, of 10 and 9 signals), eight ranks reported, the gathered
+    reconstruction of eight ranks bit-identical to one rank's (dwt/dwt_all.jl:277-279)"""
+    import numpy as np
+    one = str(tmp_path / "one.npy")
+    eight = str(tmp_path / "eight.npy")
+    common = ["--workload", workload, "--batch", str(batch), "--steps", "2", "--warmup", "1", "--no-cpu"]
+    _run_bench(common + ["--dump", one], {})
+    j8 = _run_bench(common + ["--gpus", "8", "--scaling", "strong", "--chunks", "4", "--dump", eight],
+                    {"WX_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert j8["n_gpus"] == 8 and j8["scaling"] == "strong"
+    assert j8["ranks"]["nranks"] == 8 and len(j8["ranks"]["per_rank_ms"]) == 8
+    assert j8["with_allgather"]["ms_per_step"] > 0 and j8["with_allgather_value"] == j8["with_allgather"]["value"]
+    a, b = np.load(one), np.load(eight)
+    assert a.shape == b.shape and a.shape[-1] == batch
+    assert np.array_equal(a, b)
+
+
+def test_bench_config5_eight_ranks_same_tree(tmp_path):
+    """config 5 on eight ranks with a batch 8 does not divide: the all-reduced moments give the tree of one rank
+    (bestbasis/bestbasis_tree.jl:153-154)"""
+    import numpy as np
+    one = str(tmp_path / "one.npy")
+    eight = str(tmp_path / "eight.npy")
+    common = ["--workload", "cfg5", "--batch", "4103", "--steps", "1", "--warmup", "1", "--no-cpu"]
+    _run_bench(common + ["--dump", one], {})
+    j8 = _run_bench(common + ["--gpus", "8", "--dump", eight], {"WX_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert j8["ranks"]["nranks"] == 8 and "all-reduce" in j8["config"]["collective"]
+    assert np.array_equal(np.load(one), np.load(eight))
+
+
 def test_bench_config5_two_ranks_same_tree(tmp_path):
     """config 5 sharded: moments per shard (accumulated over chunks), the all-reduce inside the step, the same tree on
     two ranks as on one (bestbasis/bestbasis_tree.jl:153-154 sums over the signal axis)"""
