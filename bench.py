@@ -382,7 +382,7 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
             # strong: the shards of one batch; weak: every rank's own batch, concatenated
             g = wd.OverlappedAllGather(full, B_out, nchunks=a.chunks)
             assert (g.lo, g.hi) == (out_lo, out_lo + Bl), "shards of the gather and of the bench disagree"
-            nposts = max(len(wd.chunk_ranges(n_r, a.chunks)) for n_r in wd.shard_sizes(B_out, world))
+            nposts = g.nposts
 
         def step(legs):
             legs.run("fwd", fwd)
@@ -444,7 +444,7 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
         W.gatherable = want_gather
         if want_gather:
             g = wd.OverlappedAllGather(full, B_out, nchunks=a.chunks)
-            nposts = max(len(wd.chunk_ranges(n_r, a.chunks)) for n_r in wd.shard_sizes(B_out, world))
+            nposts = g.nposts
 
         def step(legs):
             for c0, c1 in chunks:
@@ -767,8 +767,7 @@ def main():
           sync()
           t1 = time.perf_counter()
           gg = wd.OverlappedAllGather(full, full.shape[-1], nchunks=a.chunks)
-          nposts = max(len(wd.chunk_ranges(n_r, a.chunks)) for n_r in wd.shard_sizes(full.shape[-1], world))
-          for c in range(nposts):
+          for c in range(gg.nposts):
               gg.post(c)
           gg.finish()
           sync()

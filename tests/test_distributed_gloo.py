@@ -85,14 +85,25 @@ def _worker(rank, world, port, B, out_dir):
             fullt = torch.full((B, n), float("nan"), dtype=torch.float64).T          # column-major (n, B)
             g = wd.OverlappedAllGather(fullt, B, nchunks=nchunks)
             assert (g.lo, g.hi) == (lo, hi)
-            nposts = max(len(wd.chunk_ranges(sz, nchunks)) for sz in wd.shard_sizes(B, world))
-            for c in range(nposts):
+            assert g.nposts == max(len(wd.chunk_ranges(sz, nchunks)) for sz in wd.shard_sizes(B, world))
+            for c in range(g.nposts):
                 if c < len(g.chunks):
                     c0, c1 = g.chunks[c]
                     g.local_chunk(c).copy_(torch.from_numpy(np.ascontiguousarray(xr[:, c0:c1].T)).T)
                 g.post(c)
             g.finish()
             np.testing.assert_allclose(fullt.numpy(), X, atol=1e-12)
+            # a caller that loops over its OWN chunks only (the shards are ragged: the ranks' chunk counts differ when there
+            # are more pieces than signals): finish() posts the exchanges it has left out, and the object is reusable
+            fullt.fill_(float("nan"))
+            for c in range(len(g.chunks)):
+                c0, c1 = g.chunks[c]
+                g.local_chunk(c).copy_(torch.from_numpy(np.ascontiguousarray(xr[:, c0:c1].T)).T)
+                g.post(c)
+            g.finish()
+            np.testing.assert_allclose(fullt.numpy(), X, atol=1e-12)
+            with pytest.raises(ValueError):
+                g.post(1)                                   # exchanges are posted in order
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -84,7 +84,10 @@ def test_denoise_and_denoiseall(wx, oracle, inputtype, dtype):
         if inputtype == "sig":
             Xi = oracle.wpt(Xi, wt.qmf, oracle.maketree1d(n, L, "dwt"))
         red = inputtype in ("sdwt", "swpd", "acdwt", "acwpd")
-        sig.append(oracle.noisest(Xi, red, tree if inputtype in ("wpt", "swpd", "acwpd") else None))
+        # (Denoising.jl:683-690: with a summary threshold :acdwt input takes the `else` branch, estnoise(x, true, tree) with the
+        # default :dwt tree -- the finest detail node read as a column of a heap-ordered table)
+        tr = tree if inputtype in ("wpt", "swpd", "acwpd") else (oracle.maketree1d(n, L, "dwt") if inputtype == "acdwt" else None)
+        sig.append(oracle.noisest(Xi, red, tr))
     sbar = float(np.mean(np.asarray(sig, dtype=np.float64)))
     for i in range(B):
         exp = oracle.denoise(np.asfortranarray(X[..., i]), inputtype, wt.qmf, L=L, tree=tree, t=dnt.t, estnoise=sbar)

@@ -425,18 +425,18 @@ class WxHostPool {
     const char *js = nullptr;
     size_t jn = 0, jslice = 0, jnext = 0, jtotal = 0, jdone = 0;
 };
+// The two pinned buffers are portable (any device may copy into them); the events that mark a slot as filled belong to
+// the device of the call's stream, so they are created per call (an event of another device cannot be recorded on the
+// stream: with a process-global pair every staged copy on a second device failed).
 struct WxPinRing {
     static constexpr size_t CH = (size_t)32 << 20;
     void *buf[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
     bool ok = false;
     bool init()
     {
         if (ok) return true;
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i)
             if (hipHostMalloc(&buf[i], CH, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); release(); return false; }
-            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); release(); return false; }
-        }
         ok = true;
         return true;
     }
@@ -444,8 +444,7 @@ struct WxPinRing {
     {
         for (int i = 0; i < 2; ++i) {
             if (buf[i] && hipHostFree(buf[i]) != hipSuccess) (void)hipGetLastError();
-            if (ev[i] && hipEventDestroy(ev[i]) != hipSuccess) (void)hipGetLastError();
-            buf[i] = nullptr; ev[i] = nullptr;
+            buf[i] = nullptr;
         }
         ok = false;
     }
@@ -473,19 +472,38 @@ static hipError_t wx_d2h_staged(void *user, const void *dev, size_t bytes, hipSt
     const size_t CH = WxPinRing::CH;
     const size_t nch = (bytes + CH - 1) / CH;
     auto len = [&](size_t k) { return (k + 1) * CH <= bytes ? CH : bytes - k * CH; };
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ev[0]) (void)hipEventDestroy(ev[0]);
+            return hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, st);
+        }
+    size_t done = 0;                                                   // chunks that have reached the user's array
     hipError_t e = hipMemcpyAsync(g_ring.buf[0], dev, len(0), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipEventRecord(g_ring.ev[0], st);
+    if (e == hipSuccess) e = hipEventRecord(ev[0], st);
     for (size_t k = 0; k < nch && e == hipSuccess; ++k) {
         const int s = (int)(k & 1);
         if (k + 1 < nch) {                                             // the other slot was drained in the previous round
             e = hipMemcpyAsync(g_ring.buf[s ^ 1], (const char *)dev + (k + 1) * CH, len(k + 1), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipEventRecord(g_ring.ev[s ^ 1], st);
+            if (e == hipSuccess) e = hipEventRecord(ev[s ^ 1], st);
             if (e != hipSuccess) break;
         }
-        e = hipEventSynchronize(g_ring.ev[s]);
+        e = hipEventSynchronize(ev[s]);
         if (e != hipSuccess) break;
         g_pool.parallel_memcpy((char *)user + k * CH, (const char *)g_ring.buf[s], len(k));
+        done = k + 1;
     }
+    if (e != hipSuccess) {
+        // nothing may still be writing into the ring when the lock is released; the rest goes the plain way
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(st);
+        (void)hipGetLastError();
+        e = done < nch ? hipMemcpyAsync((char *)user + done * CH, (const char *)dev + done * CH, bytes - done * CH, hipMemcpyDeviceToHost, st)
+                       : hipSuccess;
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ev[i]);
     return e;
 }
 

@@ -246,7 +246,7 @@ int api_class_rows(int kind, const T *X, int64_t nk, int64_t N, const int32_t *c
         row_elems += np;
     }
     const int64_t budget = (int64_t)(128 * 1024) / (int64_t)sizeof(T);
-    WX_REQUIRE(row_elems <= budget, WX_EUNSUPPORTED, "the signals of one coefficient (padded per class) exceed the 128 KiB LDS window");
+    WX_REQUIRE(row_elems <= budget, WX_EUNSUPPORTED, "the signals of one coefficient (each class padded to a power of two) exceed the 128 KiB LDS window: at most 16384 Float64 / 32768 Float32 values per coefficient, i.e. about 10^4 signals -- fit on a subsample or split the classes");
     int TC = (int)(budget / row_elems);
     if (TC > 16) TC = 16;
     if (TC > nk) TC = (int)nk;
@@ -571,7 +571,7 @@ int api_pdf_map(const T *X, int64_t nk, int64_t N, const int32_t *cls, int nc, d
     if (rc) return rc;
     const LsAsh A = ls_ash_params(N);
     const size_t lds = sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len;
-    WX_REQUIRE(lds <= 150 * 1024, WX_EUNSUPPORTED, "more signals than fit the LDS window of one coefficient");
+    WX_REQUIRE(lds <= 150 * 1024, WX_EUNSUPPORTED, "more signals than fit the 150 KiB LDS window of one coefficient (about 19000 Float64 / 38000 Float32 signals): fit on a subsample");
     if ((rc = need_device())) return rc;
     hipStream_t st = wx_stream(stream);
     WxScratch scr(st);
@@ -603,7 +603,7 @@ int api_signature(int kind, const T *X, const T *Win, int64_t nk, int64_t N, int
     int64_t rows = 0;
     for (int c = 0; c < nc; ++c) { WX_REQUIRE(kind == 1 || C.cnt[c] >= 2, WX_EARG, "a class needs two signals for its deviation"); rows += C.npad[c]; }
     const size_t lds = kind == 0 ? sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len : sizeof(T) * 2 * (size_t)rows;
-    WX_REQUIRE(lds <= 150 * 1024, WX_EUNSUPPORTED, "more signals than fit the LDS window of one coefficient");
+    WX_REQUIRE(lds <= 150 * 1024, WX_EUNSUPPORTED, "more signals than fit the 150 KiB LDS window of one coefficient (about 19000 Float64 / 38000 Float32 signals): fit on a subsample");
     if ((rc = need_device())) return rc;
     hipStream_t st = wx_stream(stream);
     WxScratch scr(st);

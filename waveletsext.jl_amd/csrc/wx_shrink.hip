@@ -200,7 +200,11 @@ int api_shrink(int kind, const T *X, int64_t n, int64_t k, int64_t batch, const 
     const int64_t ncols = colmask ? (int64_t)cols.size() : k;
     const int64_t cnt = n * ncols;
     WX_REQUIRE(cnt >= 1, WX_EARG, "no coefficient selected");
-    WX_REQUIRE(cnt < ((int64_t)1 << 24), WX_EUNSUPPORTED, "more than 2^24 coefficients per signal");
+    // one workgroup sorts one signal's selection (bitonic, in LDS up to 8192 Float64 values, in a global scratch window above):
+    // log2(npad)^2 / 2 barrier-bound passes, i.e. seconds per signal beyond a million coefficients -- refused instead
+    WX_REQUIRE(cnt <= ((int64_t)1 << 20), WX_EUNSUPPORTED,
+               "threshold selection over more than 2^20 coefficients per signal (redundant tables with many leaf columns): "
+               "select on fewer columns or a shallower tree");
     int rc;
     if ((rc = need_device())) return rc;
     if (batch == 0) return WX_OK;

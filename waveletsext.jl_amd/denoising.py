@@ -209,7 +209,14 @@ def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
     N = xa.shape[-1] if batched else 1
     # noise estimation
     tr = None if inputtype in ("dwt", "sdwt", "acdwt") else tree
+    noise_it = inputtype
+    if bestTH is not None and inputtype == "acdwt":
+        # denoiseall's summary-threshold branch estimates the noise of :acdwt input as estnoise(x, true, tree)
+        # (Denoising.jl:683-690: only :dwt, :wpt and :sdwt have a case of their own), i.e. on the finest detail NODE of the
+        # tree read as a column of a heap-ordered table, not on the last column
+        tr, noise_it = tree, "acwpd"
     if (xa.kind == "torch" and bestTH is None and wt is not None and inputtype in ("dwt", "wpt") and
+            xa.arr.ndim == (2 if batched else 1) and
             (estnoise is None or estnoise is noisest) and (inputtype == "wpt" or L >= 1)):
         # device-resident pipeline: MAD -> threshold riding on the inverse's loads; sigma never visits the host
         sig = _noisest(xa, batched, inputtype, tr, on_device=True)
@@ -221,7 +228,7 @@ def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
     if estnoise is None or callable(estnoise):
         red = inputtype in ("sdwt", "swpd", "acdwt", "acwpd")
         if estnoise is None or estnoise is noisest:
-            sigma = _noisest(xa, batched, inputtype, tr)
+            sigma = _noisest(xa, batched, noise_it, tr)
         elif estnoise is relerrorthreshold:                            # estnoise(x, redundant, tree), Denoising.jl:503-571
             sigma = _select(xa, batched, red, tr, 1)
         elif estnoise is surethreshold:

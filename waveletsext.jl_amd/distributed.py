@@ -90,6 +90,10 @@ class OverlappedAllGather:
         self.lo, self.hi = shard_range(B_total, self.world, self.rank)
         self.nchunks = max(1, int(nchunks))
         self.chunks = chunk_ranges(self.hi - self.lo, self.nchunks)
+        # every rank posts the same number of exchanges: the longest chunk list over all shards (a rank whose own list is
+        # shorter -- or empty -- still has to receive its peers' later chunks)
+        self.nposts = max(len(chunk_ranges(n_r, self.nchunks)) for n_r in shard_sizes(self.B_total, self.world))
+        self.posted = 0
         self.cuda = bool(full.is_cuda)
         self.host_staged = self.cuda and dist.get_backend(group) != "nccl"
         self.side = torch.cuda.Stream(full.device) if self.cuda else None
@@ -108,6 +112,11 @@ class OverlappedAllGather:
         return self.full[..., rlo + ch[c][0]: rlo + ch[c][1]]
 
     def post(self, c):
+        """exchange number c (0 .. nposts - 1, in order): this rank's chunk c goes out (if it has one), every peer's chunk c
+        comes in"""
+        if c != self.posted or c >= self.nposts:
+            raise ValueError("OverlappedAllGather.post(%d): exchanges are posted in order, %d of %d done" % (c, self.posted, self.nposts))
+        self.posted += 1
         if self.world == 1:
             return
         mine = _as_batch_major(self.local_chunk(c)) if c < len(self.chunks) else None
@@ -131,7 +140,7 @@ class OverlappedAllGather:
             return
         if self.cuda and not self.host_staged:
             ev = torch.cuda.Event()
-            ev.record()                                   # chunk c is complete on the caller's stream
+            ev.record(torch.cuda.current_stream(self.full.device))     # chunk c is complete on the caller's stream
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ev)
                 self.work.extend(dist.batch_isend_irecv(ops))
@@ -144,7 +153,12 @@ class OverlappedAllGather:
                 dbm.copy_(buf)
 
     def finish(self):
+        """posts the exchanges the caller has not posted (a caller that loops over its own chunks only would leave its
+        peers' sends unmatched), then makes the caller's stream wait for every piece"""
+        while self.posted < self.nposts:
+            self.post(self.posted)
         if self.world == 1:
+            self.posted = 0
             return
         if self.cuda and not self.host_staged:
             with torch.cuda.stream(self.side):
@@ -152,6 +166,7 @@ class OverlappedAllGather:
                     wk.wait()
             torch.cuda.current_stream(self.full.device).wait_stream(self.side)
         self.work = []
+        self.posted = 0                                    # the object serves the next step
 
 
 def allreduce_moments(s, q, group=None):

@@ -8,7 +8,12 @@ costs with top_k, the (host) tree selection and the ordering work on the small (
 Order statistics over the signal axis are device kernels too (csrc/wx_ldbstat.hip): the class medians / MADs of
 RobustFishersClassSeparability and the earth mover's distance between the class signatures of Signatures(:equal).
 The ProbabilityDensity map and the Signatures(:pdf) weights are average shifted histograms over the signal axis
-(AverageShiftedHistograms.jl is outside the reference tree: its published algorithm is restated in the kernels)."""
+(AverageShiftedHistograms.jl is outside the reference tree: its published algorithm is restated in the kernels).
+
+Limit of the order-statistic kernels (the reference has none): the signals of one coefficient are sorted inside one LDS
+window -- RobustFishersClassSeparability and EarthMoverDistance take about 10^4 signals (16384 Float64 values with every
+class padded to a power of two), ProbabilityDensity and Signatures(:pdf) about 19000; beyond that the calls raise
+WxError(WX_EUNSUPPORTED) with the limit in the message (fit on a subsample).  The TimeFrequency / Fisher path has no limit."""
 import ctypes
 import itertools
 
