@@ -44,6 +44,16 @@ WORKLOADS = {
                    kernel="k_lat_wpt_f64<4, 3, double>", inv_kernel="k_lat_iwpt_f64<4, 2, double>",
                    fwd_kernels=[("k_lat_wpt_f64<4, 3, double>", 1)],
                    desc="north-star target: wptall+iwptall 65536x4096 f64 db4 L=10"),
+    "tree_random": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=12, dtype="f64", tree="random:0.7:3",
+                        kernel="k_lat_wpt_tree_f64<4, 2, 0>", inv_kernel="k_lat_iwpt_tree_f64<4, 2, 0>",
+                        fwd_kernels=[("k_lat_wpt_tree_f64<4, 2, 0>", 1)],
+                        desc="the target's batch along a tree, as bestbasistree output is used (DWT.jl:340-351, dwt_all.jl:152-225): "
+                             "wptall+iwptall 65536x4096 f64 db4, random tree (every node split with probability 0.7, seed 3, depth 12)"),
+    "tree_pyramid": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=12, dtype="f64", tree="pyramid",
+                         kernel="k_lat_wpt_tree_f64<4, 2, 0>", inv_kernel="k_inv1d_fused",
+                         fwd_kernels=[("k_lat_wpt_tree_f64<4, 2, 0>", 1)],
+                         desc="dwtall+idwtall as wptall+iwptall along maketree(4096, 12, :dwt): 65536x4096 f64 db4 (the levels "
+                              "below 64 samples run lane-locally, wx_dwttail.hip)"),
     "target_n2048": dict(kind="wpt", n=2048, batch=131072, wavelet="db4", L=10, dtype="f64",
                          kernel="k_lat_wpt_sh_f64<4, 2, 1>", inv_kernel="k_lat_iwpt_sh_f64<4, 2, 1>",
                          fwd_kernels=[("k_lat_wpt_sh_f64<4, 2, 1>", 1)],
@@ -372,8 +382,22 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
         else:
             y = wx.jl_empty(sig + (Bl,), td, dev)
             nd = len(sig)
-            fwd = lambda: D._wpt_batched("wx_wpt", A(x), A(y), nd, wt, L, None)
-            inv_to = lambda c0, c1, dst: D._wpt_batched("wx_iwpt", A(y[..., c0:c1]), A(dst), nd, wt, L, None)
+            tree = None
+            if w.get("tree"):
+                import numpy as np
+                n1 = sig[0]
+                if w["tree"] == "pyramid":
+                    tree = np.asarray(wx.maketree(n1, L, "dwt"), dtype=bool)
+                else:                                   # "random:<p>:<seed>": tests/helpers.random_tree_1d with the root split
+                    _, pp, seed = w["tree"].split(":")
+                    rng = np.random.default_rng(int(seed))
+                    tree = np.zeros(n1 - 1, dtype=bool)
+                    tree[0] = rng.random() < 0.95
+                    for i in range(2, n1):
+                        tree[i - 1] = tree[i // 2 - 1] and (rng.random() < float(pp))
+                    tree[0] = True
+            fwd = lambda: D._wpt_batched("wx_wpt", A(x), A(y), nd, wt, L, tree)
+            inv_to = lambda c0, c1, dst: D._wpt_batched("wx_iwpt", A(y[..., c0:c1]), A(dst), nd, wt, L, tree)
             fb = es * npts * Bl * 2
             flops = (2.0 * F * npts * L * Bl) if nd == 1 else L * 2.0 * (2 * F * npts) * Bl
         W.gatherable = want_gather
@@ -620,7 +644,7 @@ def acwpd_jbb_min_flops(n, L, F):
 # hipEvent-timed average launch (>= 10 launches after 2 warm-up steps), the algorithmic bytes (or flops) of one launch and
 # the roofline fraction.  Same code path as `--workload <name>` (make_workload), smaller step counts.
 # ------------------------------------------------------------------------------------------------
-ALSO = (("target", {}), ("cfg3", {"batch": 64}), ("cfg3_sdwt", {}), ("cfg4", {}), ("cfg5", {"batch": 8192}))
+ALSO = (("target", {}), ("tree_random", {}), ("cfg3", {"batch": 64}), ("cfg3_sdwt", {}), ("cfg4", {}), ("cfg5", {"batch": 8192}))
 
 
 def also_block(wx, torch, dev, a, dist, steps=10):

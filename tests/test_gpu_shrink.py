@@ -107,10 +107,19 @@ def test_denoiseall_with_relerrorthreshold_as_estnoise(wx, oracle, inputtype):
     red = inputtype in ("sdwt", "swpd", "acdwt", "acwpd")
     tr = None if inputtype in ("dwt", "sdwt", "acdwt") else tree
     y = wx.denoiseall(xw, inputtype, wt, L=L, tree=tree, dnt=dnt, estnoise=wx.relerrorthreshold)
-    y2 = wx.denoiseall(xw, inputtype, wt, L=L, tree=tree, dnt=dnt, estnoise=wx.relerrorthreshold, bestTH=np.mean)
+    if inputtype == "acdwt":
+        # Denoising.jl:683-690 sends :acdwt input with a summary threshold through estnoise(x, true, tree), and
+        # relerrorthreshold then indexes the (n, L+1) matrix with the leaves of a heap-ordered tree (Denoising.jl:298-299):
+        # a BoundsError in the reference, an assertion here
+        with pytest.raises(AssertionError):
+            wx.denoiseall(xw, inputtype, wt, L=L, tree=tree, dnt=dnt, estnoise=wx.relerrorthreshold, bestTH=np.mean)
+        y2 = None
+    else:
+        y2 = wx.denoiseall(xw, inputtype, wt, L=L, tree=tree, dnt=dnt, estnoise=wx.relerrorthreshold, bestTH=np.mean)
     sig = [oracle.relerrorthreshold(xw[..., i], red, tr) for i in range(B)]
     for i in range(B):
         exp = oracle.denoise(xw[..., i], inputtype, wt.qmf, L=L, tree=tree, th="hard", t=0.3, estnoise=sig[i])
         assert relerr(y[:, i], exp) <= 1e-10, (inputtype, i)
-        exp2 = oracle.denoise(xw[..., i], inputtype, wt.qmf, L=L, tree=tree, th="hard", t=0.3, estnoise=float(np.mean(sig)))
-        assert relerr(y2[:, i], exp2) <= 1e-10, (inputtype, i)
+        if y2 is not None:
+            exp2 = oracle.denoise(xw[..., i], inputtype, wt.qmf, L=L, tree=tree, th="hard", t=0.3, estnoise=float(np.mean(sig)))
+            assert relerr(y2[:, i], exp2) <= 1e-10, (inputtype, i)

@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1
 mkdir -p $R/gpurun_out/bench_$TAG
 cd $R
-timeout 900 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu_$TAG.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu_$TAG.log | tail -1
-WL=${WX_EVIDENCE_WORKLOADS:-cfg2 target target_n2048 target_n1024 target_haar cfg3 swpt_db4 cfg4 cfg5 bb ldb siwt}   # subset: only the workloads whose kernels changed
+timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu_$TAG.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu_$TAG.log | tail -1
+WL=${WX_EVIDENCE_WORKLOADS:-cfg2 target target_n2048 target_n1024 target_haar tree_random tree_pyramid cfg3 cfg3_sdwt swpt_db4 cfg4 cfg5 bb ldb siwt}   # subset: only the workloads whose kernels changed
 for w in $WL; do
   bash tools/profile.sh $TAG $w pmc > /dev/null 2>&1
 done
