@@ -34,7 +34,9 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
     unsigned long long *rmask = (unsigned long long *)tab;
     unsigned *words = (unsigned *)(tab + 13 * 64 * 8);
     unsigned *any = (unsigned *)(tab + 13 * 64 * 8 + 13 * 64 * 4);
-    hipLaunchKernelGGL((k_lat_tree_prep<SH>), dim3(12), dim3(64), 0, st, dstatus, nstatus, L, words, rmask, any);
+    // (experiment: WX_TREE_DBG_CUT = l leaves the emissions / absorptions deeper than l out -- wrong results, the time of the rest)
+    static const int dbg_cut = getenv("WX_TREE_DBG_CUT") ? atoi(getenv("WX_TREE_DBG_CUT")) : 99;
+    hipLaunchKernelGGL((k_lat_tree_prep<SH>), dim3(12), dim3(64), 0, st, dstatus, nstatus, L < dbg_cut ? L : dbg_cut, words, rmask, any);
     const int64_t nwave = (batch + per - 1) / per;
     const int last_sig = (int)(batch - per);
 #define WX_GOT(NSS)                                                                                                  \
