@@ -86,8 +86,8 @@ WORKLOADS = {
                           "16384x1024 f64 db4 L=10 in resident chunks of 2048 signals (16 GiB of leaves each); the last four "
                           "levels are the lane-local kernels of DESIGN 4.21 (`traffic` is that kernel's)"),
     "cfg4": dict(kind="wpt2d", m=512, n=512, batch=4096, wavelet="db4", L=6, dtype="f32",
-                 kernel="k_lat2d_colT_f32<4>", inv_kernel="k_lat2d_icolT_f32<4>",
-                 fwd_kernels=[("k_lat2d_colT_f32<4>", 2)],
+                 kernel="k_lat2d_colT_f32<4, false, true>", inv_kernel="k_lat2d_icolT_f32<4, false, true>",
+                 fwd_kernels=[("k_lat2d_colT_f32<4, false, true>", 1), ("k_lat2d_colT_f32<4, true, false>", 1)],
                  desc="BASELINE config 4: 2-D wptall+iwptall 4096 images 512x512 f32 db4 L=6"),
     "cfg5": dict(kind="acwpd_jbb", n=2048, batch=262144, chunk=2048, wavelet="coif6", L=11, dtype="f64",
                  kernel="k_acwpd_subtree_mfma<2>",
@@ -113,6 +113,25 @@ WORKLOADS = {
                  desc="SURVEY 8(f) row 4: shift-invariant packet decomposition siwpd(x, wt, 10, 3) + node costs of 4096 "
                       "1024-sample f64 signals (71-column table, 2.4 GB); second leg = bestbasistree! + isiwpd of all signals"),
 }
+
+
+def workload_tree(w, n, L, maketree):
+    """the tree of a `wpt` workload as a bool array (None: full tree of depth L): "pyramid" = maketree(n, L, :dwt),
+    "random:<p>:<seed>" = tests/helpers.random_tree_1d with the root split"""
+    import numpy as np
+    spec = w.get("tree")
+    if not spec:
+        return None
+    if spec == "pyramid":
+        return np.asarray(maketree(n, L, "dwt"), dtype=bool)
+    _, pp, seed = spec.split(":")
+    rng = np.random.default_rng(int(seed))
+    tree = np.zeros(n - 1, dtype=bool)
+    tree[0] = rng.random() < 0.95
+    for i in range(2, n):
+        tree[i - 1] = tree[i // 2 - 1] and (rng.random() < float(pp))
+    tree[0] = True
+    return tree
 
 
 def parse():
@@ -154,7 +173,8 @@ def cpu_baseline(w, seconds):
     def run(B):
         if kind in ("wpd", "wpt"):
             n = w["n"]
-            tree = wo.maketree1d(n, L, "full").astype(np.uint8)
+            wt_tree = workload_tree(w, n, L, wo.maketree1d)
+            tree = (wo.maketree1d(n, L, "full") if wt_tree is None else wt_tree).astype(np.uint8)
             x = np.asfortranarray(rng.standard_normal((n, B)))
             xh = np.empty_like(x)
             t0 = time.perf_counter()
@@ -168,6 +188,16 @@ def cpu_baseline(w, seconds):
                 lib.wxo_iwptall1d_f64(P(xh), P(y), L64(n), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
             dt = time.perf_counter() - t0
             assert np.abs(xh - x).max() < 1e-9
+            return dt, B * n
+        if kind == "sdwt":
+            n = w["n"]
+            x = rng.standard_normal((n, B))
+            t0 = time.perf_counter()
+            for i in range(B):
+                xw = wo.sdwt(x[:, i], q, L)
+                xr = wo.isdwt(xw, q)
+            dt = time.perf_counter() - t0
+            assert np.abs(xr - x[:, B - 1]).max() < 1e-9
             return dt, B * n
         if kind == "swpt":
             n = w["n"]
@@ -256,7 +286,7 @@ def cpu_baseline(w, seconds):
            "sample": "%d of the %d signals per step, same transform pair, %s, %.1f s"
                      % (B, w["batch"], "oracle: C -O2 steps under the reference's Dict-and-recursion object model in Python, one thread"
                         if kind == "siwt" else "oracle C -O2 single thread", dt)}
-    if kind in ("wpd", "wpt"):
+    if kind in ("wpd", "wpt") and not w.get("tree"):
         nthr = int(lib.wxo_omp_max_threads())
         Bo = int(min(16384, max(256, B * max(1, nthr // 4))))
         run_omp(min(Bo, 1024))
@@ -382,20 +412,7 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
         else:
             y = wx.jl_empty(sig + (Bl,), td, dev)
             nd = len(sig)
-            tree = None
-            if w.get("tree"):
-                import numpy as np
-                n1 = sig[0]
-                if w["tree"] == "pyramid":
-                    tree = np.asarray(wx.maketree(n1, L, "dwt"), dtype=bool)
-                else:                                   # "random:<p>:<seed>": tests/helpers.random_tree_1d with the root split
-                    _, pp, seed = w["tree"].split(":")
-                    rng = np.random.default_rng(int(seed))
-                    tree = np.zeros(n1 - 1, dtype=bool)
-                    tree[0] = rng.random() < 0.95
-                    for i in range(2, n1):
-                        tree[i - 1] = tree[i // 2 - 1] and (rng.random() < float(pp))
-                    tree[0] = True
+            tree = workload_tree(w, sig[0], L, wx.maketree)
             fwd = lambda: D._wpt_batched("wx_wpt", A(x), A(y), nd, wt, L, tree)
             inv_to = lambda c0, c1, dst: D._wpt_batched("wx_iwpt", A(y[..., c0:c1]), A(dst), nd, wt, L, tree)
             fb = es * npts * Bl * 2

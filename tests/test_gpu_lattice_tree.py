@@ -2,8 +2,8 @@
 
 Reference behaviour: Wavelets.jl's wpt / iwpt with a tree::BitVector as called at dwt/dwt_all.jl:152-166, 210-225,
 DWT.jl:340-351 (iwpd by tree = getbasiscoef + iwpt, Utils.jl:101-134).  Float64, tolerance 1e-10 relative; the routing of
-every coefficient is exact, so wpt(x, tree) must equal getbasiscoef(wpd(x), tree) of the device's own packet table bit for
-bit (same lattice arithmetic on both sides).
+every coefficient is exact, so wpt(x, tree) must equal getbasiscoef(wpd(x), tree) of the device's own packet table to
+rounding (1e-13).
 """
 import numpy as np
 import pytest
@@ -99,11 +99,10 @@ def test_tree_wpt_equals_gather_of_the_device_table(wx, n):
     for k, tree in enumerate(_trees(wx, n, rng, 10)):
         got = wx.wptall(x, wt, tree)
         gath = wx.getbasiscoefall(xw, tree)
-        # (trees of depth < 6 - SH take their table from other kernels, and the deep levels of the pyramids k = 0 .. 2 run
-        # in the direct form of wx_dwttail.hip: same values to rounding, not the same bits)
-        if k >= 3 and _depth(tree) + (12 - int(np.log2(n))) >= 6:
-            assert np.array_equal(np.asarray(got), np.asarray(gath)), int(tree.sum())
-        assert relerr(got, gath) <= 1e-13, int(tree.sum())
+        # same values to rounding, not the same bits: the table's kernel defers every gain to its emission, the tree-driven
+        # one normalises the levels below depth 6 - SH one by one (and the deep levels of the pyramids run in the direct form
+        # of wx_dwttail.hip); what must be exact is the ROUTING -- a misplaced coefficient is an O(1) error
+        assert relerr(got, gath) <= 1e-13, (k, int(tree.sum()))
 
 
 @pytest.mark.parametrize("n", [4096, 1024])

@@ -716,29 +716,36 @@ __device__ __forceinline__ unsigned lat_absorb_xo(int lane, unsigned sstride)
     });
     return (unsigned)(o_lane & ((1 << SB) - 1)) + (unsigned)(o_lane >> SB) * sstride;
 }
+// dep / cstride (iwpd by tree, all depths >= 6 - SH in one absorb): the piece of store index 8 RN + i sits in the column of
+// its leaf's depth -- nibble (8 RN + i) of the lane's four `dep` words -- cstride elements per column
 template <int LAY, int LVL, int RN>
-__device__ __forceinline__ void lat_absorb_fetch(lat_d2 (&v)[16], const double *__restrict__ xcol, unsigned xo, unsigned sstride, unsigned word)
+__device__ __forceinline__ void lat_absorb_fetch(lat_d2 (&v)[16], const double *__restrict__ xcol, unsigned xo, unsigned sstride, unsigned word,
+                                                 const unsigned *dep = nullptr, unsigned cstride = 0)
 {
     constexpr int SB = 12 - lat_sh(LVL);
     lat_for<8>([&](auto I) {
         constexpr int i = I;
         constexpr int oc = lat_emit_o_round(LAY, LVL, RN) + lat_emit_o_instr(LAY, LVL, i);
+        constexpr int idx = 8 * RN + i;
         lat_d2 &d = v[8 * (RN & 1) + i];
         d.x = d.y = 0.0;
-        if ((word >> (8 * RN + i)) & 1u) d = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
+        const unsigned co = dep ? ((dep[idx >> 3] >> (4 * (idx & 7))) & 15u) * cstride : 0u;
+        if ((word >> idx) & 1u) d = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + (xo + co));
     });
 }
 template <int LAY, int LVL>
-__device__ __forceinline__ void lat_absorb_fetch01(lat_d2 (&v)[16], const double *__restrict__ xcol, int lane, unsigned sstride, unsigned word)
+__device__ __forceinline__ void lat_absorb_fetch01(lat_d2 (&v)[16], const double *__restrict__ xcol, int lane, unsigned sstride, unsigned word,
+                                                   const unsigned *dep = nullptr, unsigned cstride = 0)
 {
     const unsigned xo = lat_absorb_xo<LAY, LVL>(lane, sstride);
-    lat_absorb_fetch<LAY, LVL, 0>(v, xcol, xo, sstride, word);
-    lat_absorb_fetch<LAY, LVL, 1>(v, xcol, xo, sstride, word);
+    lat_absorb_fetch<LAY, LVL, 0>(v, xcol, xo, sstride, word, dep, cstride);
+    lat_absorb_fetch<LAY, LVL, 1>(v, xcol, xo, sstride, word, dep, cstride);
 }
 
 template <int LAY, int LVL, bool PRED = false, bool PRE = false>
 __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const double *__restrict__ xcol, int lane, const WxLatW &cw,
-                                           unsigned sstride, unsigned word, unsigned anyw, lat_d2 (&v)[16])
+                                           unsigned sstride, unsigned word, unsigned anyw, lat_d2 (&v)[16],
+                                           const unsigned *dep = nullptr, unsigned cstride = 0)
 {
     static_assert(PRE == PRED, "prefetched lines come with the predicated form");
     constexpr int SB = 12 - lat_sh(LVL);
@@ -771,7 +778,7 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
     const unsigned xo = (unsigned)(o_lane & ((1 << SB) - 1)) + (unsigned)(o_lane >> SB) * sstride;
     auto fetch = [&](auto Rn) {
         constexpr int rn = Rn;
-        if constexpr (PRED) lat_absorb_fetch<LAY, LVL, rn>(v, xcol, xo, sstride, word);
+        if constexpr (PRED) lat_absorb_fetch<LAY, LVL, rn>(v, xcol, xo, sstride, word, dep, cstride);
         else
             lat_for<8>([&](auto I) {
                 constexpr int i = I;
@@ -1685,6 +1692,348 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #pragma unroll
     for (int r = 0; r < 64; ++r) c[r] = 0.0;
     WX_ILVL(6, 5, 0, c, 11) WX_ILVL(6, 4, 0, c, 10) WX_ILVL(6, 3, 0, c, 9) WX_ILVL(6, 2, 0, c, 8) WX_ILVL(6, 1, 0, c, 7) WX_ILVL(6, 0, 0, c, 6)
+    double bb[64];
+    lat_t3i(c, bb, lds0, lane);
+    WX_ILVL(2, 3, 4, bb, 5) WX_ILVL(2, 2, 4, bb, 4) WX_ILVL(2, 1, 4, bb, 3) WX_ILVL(2, 0, 4, bb, 2)
+    if constexpr (SH >= 2) {
+        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw);
+    } else {
+        double a[64];
+        lat_t2i(bb, a, lds0, lane);
+        WX_ILVL(0, 1, 6, a, 1) WX_ILVL(0, 0, 6, a, 0)
+        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw);
+    }
+#undef WX_ILVL
+}
+
+
+// ---------------------------------------------------------------- tree-driven transforms, deep leaves in one exchange
+// In layout C (register p[11:6], lane p[5:0]) every level is lane-local and a lane owns the 64 output positions of "its"
+// node of depth 6 - SH whatever the subtree below looks like.  So for the leaves of depth >= 6 - SH:
+//  * the levels of layout C run under LANE MASKS (one 64-bit mask per level and sequence: bit = "this lane's node is split";
+//    the mask is the exec operand, __builtin_amdgcn_inverse_ballot_w64): a leaf stops changing where the tree says, nodes
+//    that do not exist are never touched.  The register renamings between the shears stay unconditional (they add up to
+//    the identity over a level); each level normalises its own gains (a g, d / g) under the same mask;
+//  * afterwards an in-register conditional UNSHUFFLE (stage j deinterleaves the blocks of 64 >> j registers whose node is
+//    split, v_cndmask on the same masks) turns the in-place dilated order into the packet order of the lane's chunk, and
+//    ONE lat_emit of depth 6 - SH stores all of them: one exchange instead of one per populated depth.
+// The inverse mirrors it: one lat_absorb of the existing chunks (for iwpd every 16-byte piece comes out of the column of its
+// leaf's depth), the conditional shuffle, the masked synthesis levels.
+struct WxLatTreeTab {
+    unsigned words[13 * 64];           // [l][lane]: leaf pieces of depth l per store instruction (lat_emit / lat_absorb, PRED)
+    unsigned any[16];                  // [l]: OR over the lanes
+    unsigned long long masks[64];      // [(1 << K) - 1 + s]: lanes whose node of depth 6 - SH + K, sequence s, is split
+    unsigned wordsF[64];               // [lane]: pieces of existing nodes of depth 6 - SH (the final exchange)
+    unsigned wdepth[4 * 64];           // [w][lane]: leaf depth of piece 8 w + k in nibble k (iwpd: the column it is read from)
+    unsigned anyF;
+    unsigned stage_any[6];             // some node of depth 6 - SH + j is split
+};
+
+__device__ __forceinline__ bool lat_tree_exists(const uint8_t *status, int64_t nstatus, int l, int j)
+{
+    const int idx = (1 << l) + j;
+    for (int d = 1; d <= l; ++d) {
+        const int anc = idx >> d;
+        if (anc - 1 >= nstatus || !status[anc - 1]) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ bool lat_tree_split(const uint8_t *status, int64_t nstatus, int l, int j)
+{
+    const int idx = (1 << l) + j;
+    return lat_tree_exists(status, nstatus, l, j) && idx - 1 < nstatus && status[idx - 1];
+}
+
+// blocks 0 .. 11: level l = block + 1 of words / any; block 12: the deep tables
+template <int SH>
+__global__ __launch_bounds__(64) void k_lat_tree_prep2(const uint8_t *__restrict__ status, int64_t nstatus, int L, int Lcut,
+                                                        WxLatTreeTab *__restrict__ tab)
+{
+    const int lane = threadIdx.x;
+    constexpr int SB = 12 - SH, L6 = 6 - SH;
+    if (blockIdx.x < 12) {
+        const int l = blockIdx.x + 1;
+        unsigned w = 0;
+        if (l <= L && l <= SB && l <= Lcut) {
+            const int lay = lat_tree_lay(SH + l - 1), lc = l + 16 * SH;
+            const int qq = lane >> 3;
+            int o_lane = 2 * (lane & 7);
+            for (int q = 0; q < 3; ++q) o_lane |= ((qq >> q) & 1) << lat_line(lay, lc, q).ob;
+            for (int rho = 0; rho < 4; ++rho)
+                for (int i = 0; i < 8; ++i) {
+                    const int o = o_lane | lat_emit_o_round(lay, lc, rho) | lat_emit_o_instr(lay, lc, i);
+                    const int pos = o & ((1 << SB) - 1);
+                    if (lat_tree_leaf(status, nstatus, l, pos >> (SB - l))) w |= 1u << (8 * rho + i);
+                }
+        }
+        tab->words[64 * l + lane] = w;
+        unsigned a = w;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) a |= __shfl_xor(a, d, 64);
+        if (lane == 0) tab->any[l] = a;
+        return;
+    }
+    // ---- deep tables
+    for (int K = 0; K < 6; ++K) {
+        unsigned long long acc = 0;
+        for (int s = 0; s < (1 << K); ++s) {
+            const int d = L6 + K;                                  // depth of the node that level d + 1 would split
+            int j = 0;
+            for (int t = 0; t < d; ++t) {
+                const int bit = t < L6 ? (lane >> (SH + t)) & 1 : (s >> (t - L6)) & 1;
+                j |= bit << (d - 1 - t);
+            }
+            const bool sp = d < L && d < SB && lat_tree_split(status, nstatus, d, j);
+            const unsigned long long m = __ballot(sp);
+            if (lane == 0) tab->masks[(1 << K) - 1 + s] = m;
+            acc |= m;
+        }
+        if (lane == 0) tab->stage_any[K] = acc != 0;
+    }
+    unsigned w = 0, dep[4] = {0, 0, 0, 0};
+    if (L >= L6) {
+        const int lay = 6, lc = L6 + 16 * SH;
+        const int qq = lane >> 3;
+        int o_lane = 2 * (lane & 7);
+        for (int q = 0; q < 3; ++q) o_lane |= ((qq >> q) & 1) << lat_line(lay, lc, q).ob;
+        for (int rho = 0; rho < 4; ++rho)
+            for (int i = 0; i < 8; ++i) {
+                const int o = o_lane | lat_emit_o_round(lay, lc, rho) | lat_emit_o_instr(lay, lc, i);
+                const int pos = o & ((1 << SB) - 1);
+                if (!lat_tree_exists(status, nstatus, L6, pos >> (SB - L6))) continue;
+                int d = L6;
+                while (d < SB && lat_tree_split(status, nstatus, d, pos >> (SB - d))) ++d;
+                const int idx = 8 * rho + i;
+                w |= 1u << idx;
+                dep[idx >> 3] |= (unsigned)d << (4 * (idx & 7));
+            }
+    }
+    tab->wordsF[lane] = w;
+    for (int k = 0; k < 4; ++k) tab->wdepth[64 * k + lane] = dep[k];
+    unsigned a = w;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a |= __shfl_xor(a, d, 64);
+    if (lane == 0) tab->anyF = a;
+}
+
+// one packet level of layout C (register-index bit K, whole sequences in a lane) under the lane masks mk[s]; ga / gd scale
+// the a- and d-slots of the split nodes: after the shears (analysis) or before them (synthesis)
+template <int K, int NS, bool INV>
+__device__ __forceinline__ void lat_level_cm(double (&x)[64], const WxLat &cf, const unsigned long long *__restrict__ mk, double ga, double gd)
+{
+    constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
+    auto U = [](int s, int m) { return s + ((2 * m) << K); };
+    lat_for<NSEQ>([&](auto Sc) {
+        constexpr int s = Sc;
+        const unsigned long long msk = mk[s];               // wave-uniform; sequences nobody splits cost one scalar load
+        if (!msk) return;
+        auto shift = [&](auto SHc) {                        // the odd channel advances SH pairs: a renaming, for every lane
+            constexpr int SHv = decltype(SHc)::value;
+            if constexpr (SHv != 0) {
+                double old[M];
+#pragma unroll
+                for (int m = 0; m < M; ++m) old[m] = x[U(s, m) + S];
+                lat_for<M>([&](auto Mc) {
+                    constexpr int m = Mc;
+                    constexpr int g = ((m + SHv) % M + M) % M;
+                    x[U(s, m) + S] = old[g];
+                });
+            }
+        };
+        auto scale = [&]() {
+            if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) { x[U(s, m)] *= ga; x[U(s, m) + S] *= gd; }
+            }
+        };
+        if constexpr (!INV) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const double pj = cf.p[j], kj = cf.kap[j];
+                if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        x[U(s, m)] = fma(pj, x[U(s, m) + S], x[U(s, m)]);
+                        x[U(s, m) + S] = fma(-kj, x[U(s, m)], x[U(s, m) + S]);
+                    }
+                }
+                if (j + 1 < NS) shift(std::integral_constant<int, 1>{});
+            }
+            shift(std::integral_constant<int, -(NS - 1)>{});
+            scale();
+        } else {
+            scale();
+            shift(std::integral_constant<int, NS - 1>{});
+#pragma unroll
+            for (int j = NS - 1; j >= 0; --j) {
+                const double pj = cf.p[j], kj = cf.kap[j];
+                if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        x[U(s, m) + S] = fma(kj, x[U(s, m)], x[U(s, m) + S]);
+                        x[U(s, m)] = fma(-pj, x[U(s, m) + S], x[U(s, m)]);
+                    }
+                }
+                if (j > 0) shift(std::integral_constant<int, -1>{});
+            }
+        }
+    });
+}
+
+constexpr int lat_brev(int v, int bits)
+{
+    int r = 0;
+    for (int k = 0; k < bits; ++k) r |= ((v >> k) & 1) << (bits - 1 - k);
+    return r;
+}
+// stage J of the conditional unshuffle (INV: shuffle): block b of 64 >> J registers (its top J index bits are the path below
+// the chunk's node, first branch on top) is deinterleaved where the node of that path is split
+template <int J, bool INV>
+__device__ __forceinline__ void lat_tree_stage(double (&y)[64], const unsigned long long *__restrict__ mk)
+{
+    constexpr int NB = 1 << J, B = 64 >> J;
+    lat_for<NB>([&](auto Bc) {
+        constexpr int b = Bc;
+        const unsigned long long m = mk[lat_brev(b, J)];
+        if (m) {
+            const bool c = __builtin_amdgcn_inverse_ballot_w64(m);
+            double t[B];
+#pragma unroll
+            for (int k = 0; k < B; ++k) t[k] = y[b * B + k];
+            lat_for<B>([&](auto Kc) {
+                constexpr int k = Kc;
+                constexpr int o = INV ? ((k & 1) * (B / 2) + (k >> 1)) : (2 * (k % (B / 2)) + k / (B / 2));
+                if constexpr (o != k) y[b * B + k] = c ? t[o] : t[k];
+            });
+        }
+    });
+}
+
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_treec_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw, const WxLatTreeTab *__restrict__ tab)
+{
+    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    constexpr int N = 4096 >> SH, L6 = 6 - SH;
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const double *xs = x + (int64_t)sig0 * N;
+    double *ys = y + (int64_t)sig0 * N;
+    const WxLat &cf = cw.c;
+    unsigned wd[6];
+#pragma unroll
+    for (int l = 1; l < L6; ++l) wd[l] = tab->words[64 * l + lane];
+    // levels above the chunk depth: every node, leaves of depth l leave after level l (as in k_lat_wpt_tree_f64)
+#define WX_LVL(LAY, KK, HH, REG, BIT)                                                           \
+    if constexpr (BIT >= SH) {                                                                  \
+        constexpr int l = BIT - SH + 1;                                                         \
+        lat_level<KK, HH, NS, false>(REG, cf);                                                  \
+        if constexpr (l < L6) {                                                                 \
+            const unsigned aw = (unsigned)__builtin_amdgcn_readfirstlane((int)tab->any[l]);     \
+            if (aw) lat_emit<LAY, l + 16 * SH, true>(REG, lds0, ys, lane, cw, (unsigned)N, wd[l], aw); \
+            if (L <= l) return;                                                                 \
+        }                                                                                       \
+    }
+    double c[64];
+    if constexpr (SH < 2) {
+        double a[64], bb[64];
+        lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw);
+        WX_LVL(0, 0, 6, a, 0) WX_LVL(0, 1, 6, a, 1)
+        lat_t2(a, bb, lds0, lane);
+        WX_LVL(2, 0, 4, bb, 2) WX_LVL(2, 1, 4, bb, 3) WX_LVL(2, 2, 4, bb, 4) WX_LVL(2, 3, 4, bb, 5)
+        lat_t3(bb, c, lds0, lane);
+    } else {
+        double bb[64];
+        lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw);
+        WX_LVL(2, 0, 4, bb, 2) WX_LVL(2, 1, 4, bb, 3) WX_LVL(2, 2, 4, bb, 4) WX_LVL(2, 3, 4, bb, 5)
+        lat_t3(bb, c, lds0, lane);
+    }
+#undef WX_LVL
+    // levels below the chunk depth: lane-masked, normalised per level (forward: gl[1] = g, g2 = g^-2)
+    const double g = cw.gl[1], ginv = cw.c.g2 * cw.gl[1];
+    const unsigned long long *mk = tab->masks;
+    if (L > L6 + 0 && tab->stage_any[0]) lat_level_cm<0, NS, false>(c, cf, mk + 0, g, ginv);
+    if (L > L6 + 1 && tab->stage_any[1]) lat_level_cm<1, NS, false>(c, cf, mk + 1, g, ginv);
+    if (L > L6 + 2 && tab->stage_any[2]) lat_level_cm<2, NS, false>(c, cf, mk + 3, g, ginv);
+    if (L > L6 + 3 && tab->stage_any[3]) lat_level_cm<3, NS, false>(c, cf, mk + 7, g, ginv);
+    if (L > L6 + 4 && tab->stage_any[4]) lat_level_cm<4, NS, false>(c, cf, mk + 15, g, ginv);
+    if (L > L6 + 5 && tab->stage_any[5]) lat_level_cm<5, NS, false>(c, cf, mk + 31, g, ginv);
+    // in-place dilated order -> packet order of the lane's chunk
+    if (tab->stage_any[0]) lat_tree_stage<0, false>(c, mk + 0);
+    if (tab->stage_any[1]) lat_tree_stage<1, false>(c, mk + 1);
+    if (tab->stage_any[2]) lat_tree_stage<2, false>(c, mk + 3);
+    if (tab->stage_any[3]) lat_tree_stage<3, false>(c, mk + 7);
+    if (tab->stage_any[4]) lat_tree_stage<4, false>(c, mk + 15);
+    const unsigned awF = (unsigned)__builtin_amdgcn_readfirstlane((int)tab->anyF);
+    if (awF) lat_emit<6, L6 + 16 * SH, true>(c, lds0, ys, lane, cw, (unsigned)N, tab->wordsF[lane], awF);
+}
+
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_treec_f64(
+    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride, WxLatW cw,
+    const WxLatTreeTab *__restrict__ tab)
+{
+    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    constexpr int N = 4096 >> SH, L6 = 6 - SH;
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const double *xs = xw + (int64_t)sig0 * in_stride;
+    double *ys = y + (int64_t)sig0 * N;
+    const WxLat &cf = cw.c;
+    lat_d2 pv[16];
+    double c[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) c[r] = 0.0;
+    const unsigned awF = (unsigned)__builtin_amdgcn_readfirstlane((int)tab->anyF);
+    if (awF) {
+        // every leaf of depth >= 6 - SH in one absorb; out of a packet table each piece sits in the column of its depth
+        const unsigned wF = tab->wordsF[lane];
+        unsigned dep[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dep[k] = tab->wdepth[64 * k + lane];
+        const unsigned *dp = col_stride ? dep : nullptr;
+        lat_absorb_fetch01<6, L6 + 16 * SH>(pv, xs, lane, in_stride, wF, dp, col_stride);
+        lat_absorb<6, L6 + 16 * SH, true, true>(c, lds0, xs, lane, cw, in_stride, wF, awF, pv, dp, col_stride);
+        const unsigned long long *mk = tab->masks;
+        if (tab->stage_any[4]) lat_tree_stage<4, true>(c, mk + 15);
+        if (tab->stage_any[3]) lat_tree_stage<3, true>(c, mk + 7);
+        if (tab->stage_any[2]) lat_tree_stage<2, true>(c, mk + 3);
+        if (tab->stage_any[1]) lat_tree_stage<1, true>(c, mk + 1);
+        if (tab->stage_any[0]) lat_tree_stage<0, true>(c, mk + 0);
+        // synthesis: gl[1] = 1 / g, g2 = g^2 -- the a-slot of a split node enters as a / g, the d-slot as d g
+        const double ga = cw.gl[1], gd = cw.c.g2 * cw.gl[1];
+        if (L > L6 + 5 && tab->stage_any[5]) lat_level_cm<5, NS, true>(c, cf, mk + 31, ga, gd);
+        if (L > L6 + 4 && tab->stage_any[4]) lat_level_cm<4, NS, true>(c, cf, mk + 15, ga, gd);
+        if (L > L6 + 3 && tab->stage_any[3]) lat_level_cm<3, NS, true>(c, cf, mk + 7, ga, gd);
+        if (L > L6 + 2 && tab->stage_any[2]) lat_level_cm<2, NS, true>(c, cf, mk + 3, ga, gd);
+        if (L > L6 + 1 && tab->stage_any[1]) lat_level_cm<1, NS, true>(c, cf, mk + 1, ga, gd);
+        if (L > L6 + 0 && tab->stage_any[0]) lat_level_cm<0, NS, true>(c, cf, mk + 0, ga, gd);
+    }
+    // the levels above the chunk depth: as in k_lat_iwpt_tree_f64 (depth 6 - SH itself has been taken in already)
+#define WX_ILVL(LAY, KK, HH, REG, BIT)                                                          \
+    if constexpr (BIT >= SH) {                                                                  \
+        constexpr int l = BIT - SH + 1;                                                         \
+        if (L >= l) {                                                                           \
+            if constexpr (l < L6) {                                                             \
+                const unsigned aw = (unsigned)__builtin_amdgcn_readfirstlane((int)tab->any[l]); \
+                if (aw) {                                                                       \
+                    const unsigned wl = tab->words[64 * l + lane];                              \
+                    if (L == l) lat_absorb_fetch01<LAY, l + 16 * SH>(pv, xs + (size_t)l * col_stride, lane, in_stride, wl); \
+                    lat_absorb<LAY, l + 16 * SH, true, true>(REG, lds0, xs + (size_t)l * col_stride, lane, cw, in_stride, wl, aw, pv); \
+                }                                                                               \
+            }                                                                                   \
+            if constexpr (l > 1 && l <= L6) {                                                   \
+                if (__builtin_amdgcn_readfirstlane((int)tab->any[l - 1]))                       \
+                    lat_absorb_fetch01<lat_tree_lay(BIT - 1), l - 1 + 16 * SH>(pv, xs + (size_t)(l - 1) * col_stride, lane, in_stride, \
+                                                                               tab->words[64 * (l - 1) + lane]); \
+            }                                                                                   \
+            lat_level<KK, HH, NS, true>(REG, cf);                                               \
+        }                                                                                       \
+    }
     double bb[64];
     lat_t3i(c, bb, lds0, lane);
     WX_ILVL(2, 3, 4, bb, 5) WX_ILVL(2, 2, 4, bb, 4) WX_ILVL(2, 1, 4, bb, 3) WX_ILVL(2, 0, 4, bb, 2)

@@ -29,25 +29,30 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
         for (int l = 0; l <= 12; ++l) { cw.gl[l] = (double)acc; acc *= inverse ? 1 / g : g; }
     }
     WxScratch scr(st);
-    unsigned char *tab = (unsigned char *)scr.alloc(13 * 64 * 4 + 13 * 64 * 8 + 64);
+    WxLatTreeTab *tab = (WxLatTreeTab *)scr.alloc(sizeof(WxLatTreeTab));
     if (!tab) return WX_EHIP;
-    unsigned long long *rmask = (unsigned long long *)tab;
-    unsigned *words = (unsigned *)(tab + 13 * 64 * 8);
-    unsigned *any = (unsigned *)(tab + 13 * 64 * 8 + 13 * 64 * 4);
     // (experiment: WX_TREE_DBG_CUT = l leaves the emissions / absorptions deeper than l out -- wrong results, the time of the rest)
     static const int dbg_cut = getenv("WX_TREE_DBG_CUT") ? atoi(getenv("WX_TREE_DBG_CUT")) : 99;
-    hipLaunchKernelGGL((k_lat_tree_prep<SH>), dim3(12), dim3(64), 0, st, dstatus, nstatus, L < dbg_cut ? L : dbg_cut, words, rmask, any);
+    // WX_LATTICE_TREE_DEEP=0: one exchange per populated depth at every depth (k_lat_wpt_tree_f64 / k_lat_iwpt_tree_f64)
+    static const bool deep = !(getenv("WX_LATTICE_TREE_DEEP") && atoi(getenv("WX_LATTICE_TREE_DEEP")) == 0);
+    hipLaunchKernelGGL((k_lat_tree_prep2<SH>), dim3(13), dim3(64), 0, st, dstatus, nstatus, L, dbg_cut, tab);
     const int64_t nwave = (batch + per - 1) / per;
     const int last_sig = (int)(batch - per);
+    const WxLatTreeTab *ctab = tab;
 #define WX_GOT(NSS)                                                                                                  \
     case NSS:                                                                                                        \
-        if (inverse)                                                                                                 \
+        if (inverse && deep)                                                                                         \
+            hipLaunchKernelGGL((k_lat_iwpt_treec_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, \
+                               (unsigned)in_stride, (unsigned)col_stride, cw, ctab);                                 \
+        else if (inverse)                                                                                            \
             hipLaunchKernelGGL((k_lat_iwpt_tree_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, \
-                               (unsigned)in_stride, (unsigned)col_stride, cw, (const unsigned *)words,               \
-                               (const unsigned long long *)rmask, (const unsigned *)any);                            \
+                               (unsigned)in_stride, (unsigned)col_stride, cw, (const unsigned *)ctab->words,         \
+                               (const unsigned long long *)nullptr, (const unsigned *)ctab->any);                    \
+        else if (deep)                                                                                               \
+            hipLaunchKernelGGL((k_lat_wpt_treec_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw, ctab); \
         else                                                                                                         \
             hipLaunchKernelGGL((k_lat_wpt_tree_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw, \
-                               (const unsigned *)words, (const unsigned *)any);                                      \
+                               (const unsigned *)ctab->words, (const unsigned *)ctab->any);                          \
         break;
     switch (filt.F / 2) {
         WX_GOT(1) WX_GOT(2) WX_GOT(3) WX_GOT(4) WX_GOT(5) WX_GOT(6) WX_GOT(7) WX_GOT(8) WX_GOT(9) WX_GOT(10)
