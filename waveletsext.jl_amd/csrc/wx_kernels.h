@@ -118,7 +118,8 @@ int wx_haar_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batc
 int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
 // tree-driven wpt / iwpt / iwpd on the lattice (wx_lattice_tree.h): 0 = not applicable, 1 = launched, < 0 = error
 int wx_lattice_tree_f64(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
-                        int64_t col_stride, const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, hipStream_t st);
+                        int64_t col_stride, const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, hipStream_t st,
+                        const WxThreshArg *thr = nullptr);
 bool wx_lattice_tree_applicable_f64(int64_t n, const WxFilt &filt);
 int wx_lattice_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
 int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,

@@ -700,6 +700,13 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double 
 __device__ __forceinline__ void lat_st1(double __attribute__((address_space(1))) *p, double v) { *p = v; }
 // PRED (k_lat_iwpt_tree_f64): only the lines of this depth's leaves are loaded (`word`, `anyw` as in lat_emit), everything
 // else arrives as zeros, and the arrivals are ADDED to what the deeper levels have synthesised (see below).
+// threshold of denoise() riding on the absorbed leaves (Denoising.jl:527 threshold!(x, th, t) before iwpt): positions
+// [lo, n) of every signal, threshold tt[s] for signal s of the wavefront; kind < 0: none
+struct LatThr {
+    double tt[4];
+    int kind, lo;
+};
+
 // the lines of rounds 0 and 1 of lat_absorb<LAY, LVL, true, true>, issued early (k_lat_iwpt_tree_f64 asks for them before it
 // runs the synthesis level above, so that their latency hides behind that level's arithmetic; inside the absorb the loads
 // run two rounds ahead of the exchange: one round ahead left every round waiting for memory)
@@ -745,7 +752,7 @@ __device__ __forceinline__ void lat_absorb_fetch01(lat_d2 (&v)[16], const double
 template <int LAY, int LVL, bool PRED = false, bool PRE = false>
 __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const double *__restrict__ xcol, int lane, const WxLatW &cw,
                                            unsigned sstride, unsigned word, unsigned anyw, lat_d2 (&v)[16],
-                                           const unsigned *dep = nullptr, unsigned cstride = 0)
+                                           const unsigned *dep = nullptr, unsigned cstride = 0, const LatThr *th = nullptr)
 {
     static_assert(PRE == PRED, "prefetched lines come with the predicated form");
     constexpr int SB = 12 - lat_sh(LVL);
@@ -793,8 +800,20 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
         if (live)
             lat_for<8>([&](auto I) {
                 constexpr int i = I;
-                lds_wr<8 * (17 * 8 * i)>(wra, v[8 * (rho & 1) + i].x);
-                lds_wr<8 * (17 * 8 * i + 1)>(wra, v[8 * (rho & 1) + i].y);
+                lat_d2 &d = v[8 * (rho & 1) + i];
+                if constexpr (PRED) {
+                    if (th && th->kind >= 0) {
+                        constexpr int oc = lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i);
+                        const int o = o_lane | oc, pos = o & ((1 << SB) - 1), sg = o >> SB;
+                        const double tt = sg == 0 ? th->tt[0] : (sg == 1 ? th->tt[1] : (sg == 2 ? th->tt[2] : th->tt[3]));
+                        if ((word >> (8 * rho + i)) & 1u) {
+                            if (pos >= th->lo) d.x = wx_thresh<double>(d.x, tt, th->kind);
+                            if (pos + 1 >= th->lo) d.y = wx_thresh<double>(d.y, tt, th->kind);
+                        }
+                    }
+                }
+                lds_wr<8 * (17 * 8 * i)>(wra, d.x);
+                lds_wr<8 * (17 * 8 * i + 1)>(wra, d.y);
             });
         // the next lines travel while this round is exchanged: one round ahead (plain), two rounds ahead (tree-driven)
         if constexpr (!PRE && rho < 3) fetch(std::integral_constant<int, rho + 1>{});
@@ -1973,7 +1992,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 template <int NS, int WPE, int SH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_treec_f64(
     const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride, WxLatW cw,
-    const WxLatTreeTab *__restrict__ tab)
+    const WxLatTreeTab *__restrict__ tab, WxThreshArg thr)
 {
     static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
     __shared__ double lds[WX_LAT_LDS];
@@ -1984,6 +2003,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const double *xs = xw + (int64_t)sig0 * in_stride;
     double *ys = y + (int64_t)sig0 * N;
     const WxLat &cf = cw.c;
+    LatThr lt;
+    lt.kind = thr.t ? thr.kind : -1;
+    lt.lo = thr.lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        lt.tt[k] = (thr.t && k < (1 << SH)) ? reinterpret_cast<const double *>(thr.t)[thr.per_signal ? sig0 + k : 0] * thr.scale : 0.0;
+    const LatThr *th = thr.t ? &lt : nullptr;
     lat_d2 pv[16];
     double c[64];
 #pragma unroll
@@ -1997,7 +2023,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         for (int k = 0; k < 4; ++k) dep[k] = tab->wdepth[64 * k + lane];
         const unsigned *dp = col_stride ? dep : nullptr;
         lat_absorb_fetch01<6, L6 + 16 * SH>(pv, xs, lane, in_stride, wF, dp, col_stride);
-        lat_absorb<6, L6 + 16 * SH, true, true>(c, lds0, xs, lane, cw, in_stride, wF, awF, pv, dp, col_stride);
+        lat_absorb<6, L6 + 16 * SH, true, true>(c, lds0, xs, lane, cw, in_stride, wF, awF, pv, dp, col_stride, th);
         const unsigned long long *mk = tab->masks;
         if (tab->stage_any[4]) lat_tree_stage<4, true>(c, mk + 15);
         if (tab->stage_any[3]) lat_tree_stage<3, true>(c, mk + 7);
@@ -2023,7 +2049,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 if (aw) {                                                                       \
                     const unsigned wl = tab->words[64 * l + lane];                              \
                     if (L == l) lat_absorb_fetch01<LAY, l + 16 * SH>(pv, xs + (size_t)l * col_stride, lane, in_stride, wl); \
-                    lat_absorb<LAY, l + 16 * SH, true, true>(REG, lds0, xs + (size_t)l * col_stride, lane, cw, in_stride, wl, aw, pv); \
+                    lat_absorb<LAY, l + 16 * SH, true, true>(REG, lds0, xs + (size_t)l * col_stride, lane, cw, in_stride, wl, aw, pv, \
+                                                             nullptr, 0u, th);                  \
                 }                                                                               \
             }                                                                                   \
             if constexpr (l > 1 && l <= L6) {                                                   \

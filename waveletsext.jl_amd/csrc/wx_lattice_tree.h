@@ -11,7 +11,7 @@
 // 0 = not applicable (the caller takes the fused LDS kernels), 1 = launched, < 0 = error.
 // inverse: leaves of signal b, depth l at x + b in_stride + l col_stride (col_stride = 0: dense leaves, n: packet table)
 int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride, int64_t col_stride,
-                   const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, hipStream_t st)
+                   const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, const WxThreshArg *thr, hipStream_t st)
 {
     constexpr int SH = WX_LAT_TREE_SH;
     constexpr int64_t per = (int64_t)1 << SH;
@@ -35,6 +35,11 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
     static const int dbg_cut = getenv("WX_TREE_DBG_CUT") ? atoi(getenv("WX_TREE_DBG_CUT")) : 99;
     // WX_LATTICE_TREE_DEEP=0: one exchange per populated depth at every depth (k_lat_wpt_tree_f64 / k_lat_iwpt_tree_f64)
     static const bool deep = !(getenv("WX_LATTICE_TREE_DEEP") && atoi(getenv("WX_LATTICE_TREE_DEEP")) == 0);
+    // the threshold of denoise() rides on the leaves the inverse takes in (k_lat_iwpt_treec_f64 only; a pyramid's head is
+    // not a leaf array: that case keeps the fused kernel)
+    if (thr && thr->t && (!inverse || !deep || thr->head)) return 0;
+    WxThreshArg ta{nullptr, 0, 0, 0, 1.0};
+    if (thr && thr->t) ta = *thr;
     hipLaunchKernelGGL((k_lat_tree_prep2<SH>), dim3(13), dim3(64), 0, st, dstatus, nstatus, L, dbg_cut, tab);
     const int64_t nwave = (batch + per - 1) / per;
     const int last_sig = (int)(batch - per);
@@ -43,7 +48,7 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
     case NSS:                                                                                                        \
         if (inverse && deep)                                                                                         \
             hipLaunchKernelGGL((k_lat_iwpt_treec_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, \
-                               (unsigned)in_stride, (unsigned)col_stride, cw, ctab);                                 \
+                               (unsigned)in_stride, (unsigned)col_stride, cw, ctab, ta);                             \
         else if (inverse)                                                                                            \
             hipLaunchKernelGGL((k_lat_iwpt_tree_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, \
                                (unsigned)in_stride, (unsigned)col_stride, cw, (const unsigned *)ctab->words,         \
