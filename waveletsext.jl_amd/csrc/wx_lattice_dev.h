@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 }
 
 
-// ---------------------------------------------------------------- tree-driven wpt / iwpt / iwpd (wx_lattice_tree.hip)
+// ---------------------------------------------------------------- tree-driven wpt / iwpt / iwpd (wx_lattice_tree.h)
 // wpt(x, wt, tree) is the set of leaves of the tree picked out of the packet table (Wavelets.jl's wpt along a tree;
 // Utils.jl:101-134 getbasiscoef; call sites DWT.jl:340-351, dwt/dwt_all.jl:152-166, 210-225, LDB.jl:303, 409,
 // Denoising.jl:527).  The lattice computes every node of every level anyway, in registers, so the tree only decides
@@ -1584,151 +1584,10 @@ __device__ __forceinline__ bool lat_tree_leaf(const uint8_t *status, int64_t nst
 }
 constexpr int lat_tree_lay(int bit) { return bit < 2 ? 0 : (bit < 6 ? 2 : 6); }      // layout in which index bit `bit` is transformed
 
-// words[64 l + lane], rmask[64 l + lane], any[l] for l = 1 .. 12 - SH (block l - 1, 64 threads)
-template <int SH>
-__global__ __launch_bounds__(64) void k_lat_tree_prep(const uint8_t *__restrict__ status, int64_t nstatus, int L,
-                                                       unsigned *__restrict__ words, unsigned long long *__restrict__ rmask,
-                                                       unsigned *__restrict__ any)
-{
-    const int l = blockIdx.x + 1, lane = threadIdx.x;
-    constexpr int SB = 12 - SH;
-    unsigned w = 0;
-    unsigned long long rm = 0;
-    if (l <= L && l <= SB) {
-        const int lay = lat_tree_lay(SH + l - 1), lc = l + 16 * SH;
-        // line side: the 16 bytes this lane stores / loads in instruction i of round rho (lat_emit / lat_absorb)
-        const int qq = lane >> 3;
-        int o_lane = 2 * (lane & 7);
-        for (int q = 0; q < 3; ++q) o_lane |= ((qq >> q) & 1) << lat_line(lay, lc, q).ob;
-        for (int rho = 0; rho < 4; ++rho)
-            for (int i = 0; i < 8; ++i) {
-                const int o = o_lane | lat_emit_o_round(lay, lc, rho) | lat_emit_o_instr(lay, lc, i);
-                const int pos = o & ((1 << SB) - 1);                   // position inside the signal (the signal number is above)
-                if (lat_tree_leaf(status, nstatus, l, pos >> (SB - l))) w |= 1u << (8 * rho + i);
-            }
-        // register side: sample index p held by register r of this lane in layout `lay`
-        for (int r = 0; r < 64; ++r) {
-            int p = 0;
-            for (int t = 0; t < 12; ++t) {
-                const LatSrc sc = lat_src(lay, t);
-                p |= (((sc.reg ? r : lane) >> sc.bit) & 1) << t;
-            }
-            int j = 0;
-            for (int t = 0; t < l; ++t) j |= ((p >> (SH + t)) & 1) << (l - 1 - t);
-            if (lat_tree_leaf(status, nstatus, l, j)) rm |= 1ull << r;
-        }
-    }
-    words[64 * l + lane] = w;
-    rmask[64 * l + lane] = rm;
-    unsigned a = w;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) a |= __shfl_xor(a, d, 64);
-    if (lane == 0) any[l] = a;
-}
-
-template <int NS, int WPE, int SH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_tree_f64(
-    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw, const unsigned *__restrict__ words,
-    const unsigned *__restrict__ any)
-{
-    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
-    __shared__ double lds[WX_LAT_LDS];
-    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
-    const int lane = threadIdx.x;
-    constexpr int N = 4096 >> SH;
-    const int sig0 = min((int)blockIdx.x << SH, last_sig);
-    const double *xs = x + (int64_t)sig0 * N;
-    double *ys = y + (int64_t)sig0 * N;
-    const WxLat &cf = cw.c;
-    unsigned wd[13];
-#pragma unroll
-    for (int l = 1; l <= 12 - SH; ++l) wd[l] = words[64 * l + lane];
-#define WX_LVL(LAY, KK, HH, REG, BIT)                                                           \
-    if constexpr (BIT >= SH) {                                                                  \
-        constexpr int l = BIT - SH + 1;                                                         \
-        lat_level<KK, HH, NS, false>(REG, cf);                                                  \
-        {                                                                                       \
-            const unsigned aw = (unsigned)__builtin_amdgcn_readfirstlane((int)any[l]);          \
-            if (aw) lat_emit<LAY, l + 16 * SH, true>(REG, lds0, ys, lane, cw, (unsigned)N, wd[l], aw); \
-        }                                                                                       \
-        if (L <= l) return;                                                                     \
-    }
-    double c[64];
-    if constexpr (SH < 2) {
-        double a[64], bb[64];
-        lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw);
-        WX_LVL(0, 0, 6, a, 0) WX_LVL(0, 1, 6, a, 1)
-        lat_t2(a, bb, lds0, lane);
-        WX_LVL(2, 0, 4, bb, 2) WX_LVL(2, 1, 4, bb, 3) WX_LVL(2, 2, 4, bb, 4) WX_LVL(2, 3, 4, bb, 5)
-        lat_t3(bb, c, lds0, lane);
-    } else {
-        double bb[64];
-        lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw);
-        WX_LVL(2, 0, 4, bb, 2) WX_LVL(2, 1, 4, bb, 3) WX_LVL(2, 2, 4, bb, 4) WX_LVL(2, 3, 4, bb, 5)
-        lat_t3(bb, c, lds0, lane);
-    }
-    WX_LVL(6, 0, 0, c, 6) WX_LVL(6, 1, 0, c, 7) WX_LVL(6, 2, 0, c, 8) WX_LVL(6, 3, 0, c, 9) WX_LVL(6, 4, 0, c, 10) WX_LVL(6, 5, 0, c, 11)
-#undef WX_LVL
-}
-
-// leaves of signal s of the wavefront: depth l at xs + s in_stride + l col_stride (col_stride = 0: the dense leaf array of
-// iwpt; col_stride = N: the packet table of iwpd, DWT.jl:340-351)
-template <int NS, int WPE, int SH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_tree_f64(
-    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride, WxLatW cw,
-    const unsigned *__restrict__ words, const unsigned long long *__restrict__ rmask, const unsigned *__restrict__ any)
-{
-    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
-    __shared__ double lds[WX_LAT_LDS];
-    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
-    const int lane = threadIdx.x;
-    constexpr int N = 4096 >> SH;
-    const int sig0 = min((int)blockIdx.x << SH, last_sig);
-    const double *xs = xw + (int64_t)sig0 * in_stride;
-    double *ys = y + (int64_t)sig0 * N;
-    const WxLat &cf = cw.c;
-    // the lines of the next (shallower) depth's leaves are requested before a synthesis level runs and taken in after it
-    lat_d2 pv[16];
-#define WX_ILVL(LAY, KK, HH, REG, BIT)                                                          \
-    if constexpr (BIT >= SH) {                                                                  \
-        constexpr int l = BIT - SH + 1;                                                         \
-        if (L >= l) {                                                                           \
-            const unsigned aw = (unsigned)__builtin_amdgcn_readfirstlane((int)any[l]);          \
-            if (aw) {                                                                           \
-                const unsigned wl = words[64 * l + lane];                                       \
-                if (L == l) lat_absorb_fetch01<LAY, l + 16 * SH>(pv, xs + (size_t)l * col_stride, lane, in_stride, wl);  \
-                lat_absorb<LAY, l + 16 * SH, true, true>(REG, lds0, xs + (size_t)l * col_stride, lane, cw, in_stride, wl, aw, pv); \
-            }                                                                                   \
-            if constexpr (l > 1) {                                                              \
-                if (__builtin_amdgcn_readfirstlane((int)any[l - 1]))                            \
-                    lat_absorb_fetch01<lat_tree_lay(BIT - 1), l - 1 + 16 * SH>(pv, xs + (size_t)(l - 1) * col_stride, lane, in_stride, \
-                                                                               words[64 * (l - 1) + lane]);     \
-            }                                                                                   \
-            lat_level<KK, HH, NS, true>(REG, cf);                                               \
-        }                                                                                       \
-    }
-    double c[64];
-#pragma unroll
-    for (int r = 0; r < 64; ++r) c[r] = 0.0;
-    WX_ILVL(6, 5, 0, c, 11) WX_ILVL(6, 4, 0, c, 10) WX_ILVL(6, 3, 0, c, 9) WX_ILVL(6, 2, 0, c, 8) WX_ILVL(6, 1, 0, c, 7) WX_ILVL(6, 0, 0, c, 6)
-    double bb[64];
-    lat_t3i(c, bb, lds0, lane);
-    WX_ILVL(2, 3, 4, bb, 5) WX_ILVL(2, 2, 4, bb, 4) WX_ILVL(2, 1, 4, bb, 3) WX_ILVL(2, 0, 4, bb, 2)
-    if constexpr (SH >= 2) {
-        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw);
-    } else {
-        double a[64];
-        lat_t2i(bb, a, lds0, lane);
-        WX_ILVL(0, 1, 6, a, 1) WX_ILVL(0, 0, 6, a, 0)
-        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw);
-    }
-#undef WX_ILVL
-}
-
-
-// ---------------------------------------------------------------- tree-driven transforms, deep leaves in one exchange
-// In layout C (register p[11:6], lane p[5:0]) every level is lane-local and a lane owns the 64 output positions of "its"
-// node of depth 6 - SH whatever the subtree below looks like.  So for the leaves of depth >= 6 - SH:
+// ---------------------------------------------------------------- deep leaves in one exchange
+// The leaves of depth < 6 - SH leave / enter level by level as described above.  In layout C (register p[11:6], lane p[5:0])
+// every level is lane-local and a lane owns the 64 output positions of "its" node of depth 6 - SH whatever the subtree below
+// looks like.  So for the leaves of depth >= 6 - SH:
 //  * the levels of layout C run under LANE MASKS (one 64-bit mask per level and sequence: bit = "this lane's node is split";
 //    the mask is the exec operand, __builtin_amdgcn_inverse_ballot_w64): a leaf stops changing where the tree says, nodes
 //    that do not exist are never touched.  The register renamings between the shears stay unconditional (they add up to
@@ -1765,7 +1624,7 @@ __device__ __forceinline__ bool lat_tree_split(const uint8_t *status, int64_t ns
 
 // blocks 0 .. 11: level l = block + 1 of words / any; block 12: the deep tables
 template <int SH>
-__global__ __launch_bounds__(64) void k_lat_tree_prep2(const uint8_t *__restrict__ status, int64_t nstatus, int L, int Lcut,
+__global__ __launch_bounds__(64) void k_lat_tree_prep(const uint8_t *__restrict__ status, int64_t nstatus, int L, int Lcut,
                                                         WxLatTreeTab *__restrict__ tab)
 {
     const int lane = threadIdx.x;
@@ -1929,7 +1788,7 @@ __device__ __forceinline__ void lat_tree_stage(double (&y)[64], const unsigned l
 }
 
 template <int NS, int WPE, int SH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_treec_f64(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_tree_f64(
     const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw, const WxLatTreeTab *__restrict__ tab)
 {
     static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
@@ -1989,8 +1848,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (awF) lat_emit<6, L6 + 16 * SH, true>(c, lds0, ys, lane, cw, (unsigned)N, tab->wordsF[lane], awF);
 }
 
-template <int NS, int WPE, int SH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_treec_f64(
+template <int NS, int WPE, int SH, bool THR>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_tree_f64(
     const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride, WxLatW cw,
     const WxLatTreeTab *__restrict__ tab, WxThreshArg thr)
 {
@@ -2003,13 +1862,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const double *xs = xw + (int64_t)sig0 * in_stride;
     double *ys = y + (int64_t)sig0 * N;
     const WxLat &cf = cw.c;
+    // THR: the threshold of denoise() on the absorbed leaves (its own instantiation: the plain inverse has no register to spare)
     LatThr lt;
-    lt.kind = thr.t ? thr.kind : -1;
-    lt.lo = thr.lo;
+    const LatThr *th = nullptr;
+    if constexpr (THR) {
+        lt.kind = thr.kind;
+        lt.lo = thr.lo;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        lt.tt[k] = (thr.t && k < (1 << SH)) ? reinterpret_cast<const double *>(thr.t)[thr.per_signal ? sig0 + k : 0] * thr.scale : 0.0;
-    const LatThr *th = thr.t ? &lt : nullptr;
+        for (int k = 0; k < 4; ++k)
+            lt.tt[k] = k < (1 << SH) ? reinterpret_cast<const double *>(thr.t)[thr.per_signal ? sig0 + k : 0] * thr.scale : 0.0;
+        th = &lt;
+    }
     lat_d2 pv[16];
     double c[64];
 #pragma unroll

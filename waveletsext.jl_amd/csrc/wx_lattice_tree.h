@@ -5,8 +5,9 @@
 #include "wx_lattice_dev.h"
 #include "wx_host.h"
 
-// included by wx_lattice_tree0.hip / tree1 / tree2 with WX_LAT_TREE_SH = 0, 1, 2 (signal length 4096 >> SH) and
-// WX_LAT_TREE_FN = the launcher's name: one translation unit per length so that the 60 kernels compile in parallel
+// included by wx_lattice_tree{0,1,2}{f,i}.hip with WX_LAT_TREE_SH = 0, 1, 2 (signal length 4096 >> SH), WX_LAT_TREE_INV = 0 / 1
+// (direction) and WX_LAT_TREE_FN = the launcher's name: one translation unit per length and direction so that the 60 kernels
+// compile in parallel
 
 // 0 = not applicable (the caller takes the fused LDS kernels), 1 = launched, < 0 = error.
 // inverse: leaves of signal b, depth l at x + b in_stride + l col_stride (col_stride = 0: dense leaves, n: packet table)
@@ -15,6 +16,7 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
 {
     constexpr int SH = WX_LAT_TREE_SH;
     constexpr int64_t per = (int64_t)1 << SH;
+    if (inverse != (WX_LAT_TREE_INV != 0)) return 0;
     if (n != (4096 >> SH) || L < 1 || L + SH > 12 || filt.F < 2 || batch < per || batch > 0x7fffffff || !dstatus) return 0;
     if ((batch & (per - 1)) && x == y) return 0;             // the tail wavefront re-does signals: out of place only
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
@@ -33,32 +35,45 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
     if (!tab) return WX_EHIP;
     // (experiment: WX_TREE_DBG_CUT = l leaves the emissions / absorptions deeper than l out -- wrong results, the time of the rest)
     static const int dbg_cut = getenv("WX_TREE_DBG_CUT") ? atoi(getenv("WX_TREE_DBG_CUT")) : 99;
-    // WX_LATTICE_TREE_DEEP=0: one exchange per populated depth at every depth (k_lat_wpt_tree_f64 / k_lat_iwpt_tree_f64)
-    static const bool deep = !(getenv("WX_LATTICE_TREE_DEEP") && atoi(getenv("WX_LATTICE_TREE_DEEP")) == 0);
-    // the threshold of denoise() rides on the leaves the inverse takes in (k_lat_iwpt_treec_f64 only; a pyramid's head is
-    // not a leaf array: that case keeps the fused kernel)
-    if (thr && thr->t && (!inverse || !deep || thr->head)) return 0;
+    // the threshold of denoise() rides on the leaves the inverse takes in (a pyramid's head is not a leaf array: that case
+    // keeps the fused kernel)
+    if (thr && thr->t && (!inverse || thr->head)) return 0;
     WxThreshArg ta{nullptr, 0, 0, 0, 1.0};
     if (thr && thr->t) ta = *thr;
-    hipLaunchKernelGGL((k_lat_tree_prep2<SH>), dim3(13), dim3(64), 0, st, dstatus, nstatus, L, dbg_cut, tab);
+    hipLaunchKernelGGL((k_lat_tree_prep<SH>), dim3(13), dim3(64), 0, st, dstatus, nstatus, L, dbg_cut, tab);
     const int64_t nwave = (batch + per - 1) / per;
     const int last_sig = (int)(batch - per);
     const WxLatTreeTab *ctab = tab;
+    (void)ta;
+#if WX_LAT_TREE_INV
 #define WX_GOT(NSS)                                                                                                  \
     case NSS:                                                                                                        \
-        if (inverse && deep)                                                                                         \
-            hipLaunchKernelGGL((k_lat_iwpt_treec_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, \
-                               (unsigned)in_stride, (unsigned)col_stride, cw, ctab, ta);                             \
-        else if (inverse)                                                                                            \
-            hipLaunchKernelGGL((k_lat_iwpt_tree_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, \
-                               (unsigned)in_stride, (unsigned)col_stride, cw, (const unsigned *)ctab->words,         \
-                               (const unsigned long long *)nullptr, (const unsigned *)ctab->any);                    \
-        else if (deep)                                                                                               \
-            hipLaunchKernelGGL((k_lat_wpt_treec_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw, ctab); \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_lat_wpt_tree_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw, \
-                               (const unsigned *)ctab->words, (const unsigned *)ctab->any);                          \
+        hipLaunchKernelGGL((k_lat_iwpt_tree_f64<NSS, 2, SH, false>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, \
+                           (unsigned)in_stride, (unsigned)col_stride, cw, ctab, ta);                                 \
         break;
+    // with the threshold of denoise(): Haar, db2, db4 only (every instantiation of this kernel is half a minute of compile
+    // time); other filters keep the fused LDS kernel for that call
+#define WX_GOTT(NSS)                                                                                                 \
+    case NSS:                                                                                                        \
+        hipLaunchKernelGGL((k_lat_iwpt_tree_f64<NSS, 2, SH, true>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, \
+                           (unsigned)in_stride, (unsigned)col_stride, cw, ctab, ta);                                 \
+        break;
+    if (ta.t) {
+        switch (filt.F / 2) {
+            WX_GOTT(1) WX_GOTT(2) WX_GOTT(4)
+        default: return 0;
+        }
+        const hipError_t et = hipGetLastError();
+        if (et != hipSuccess) return wx_set_hip_error(et, "lattice tree launch", __FILE__, __LINE__);
+        return 1;
+    }
+#undef WX_GOTT
+#else
+#define WX_GOT(NSS)                                                                                                  \
+    case NSS:                                                                                                        \
+        hipLaunchKernelGGL((k_lat_wpt_tree_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw, ctab); \
+        break;
+#endif
     switch (filt.F / 2) {
         WX_GOT(1) WX_GOT(2) WX_GOT(3) WX_GOT(4) WX_GOT(5) WX_GOT(6) WX_GOT(7) WX_GOT(8) WX_GOT(9) WX_GOT(10)
     default: return 0;
