@@ -75,8 +75,8 @@ WORKLOADS = {
                  desc="BASELINE config 3: swptall+iswptall (average-based) 8192x16384 f64 haar L=12; the leaves exist one "
                       "resident chunk of 64 signals (32 GiB) at a time, a step loops over every chunk of the shard"),
     "cfg3_sdwt": dict(kind="sdwt", n=16384, batch=8192, wavelet="haar", L=12, dtype="f64",
-                      kernel="k_sdwt_fused_ip<double, false, 16>", inv_kernel="k_isdwt_avg_fused_ip<double, 16>",
-                      fwd_kernels=[("k_sdwt_fused_ip<double, false, 16>", 1)],
+                      kernel="k_sdwt_fused_ip<double, false, 16, 2>", inv_kernel="k_isdwt_avg_fused_ip<double, 16>",
+                      fwd_kernels=[("k_sdwt_fused_ip<double, false, 16, 2>", 1)],
                       desc="BASELINE config 3 read as the non-packet transform (SURVEY 8d: report both): sdwtall + isdwtall "
                            "(average-based) 8192x16384 f64 haar L=12, output (16384, 13, 8192) = 13 GiB"),
     "swpt_db4": dict(kind="swpt", n=1024, batch=16384, chunk=2048, wavelet="db4", L=10, dtype="f64",

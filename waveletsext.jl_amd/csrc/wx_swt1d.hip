@@ -444,66 +444,86 @@ __global__ __launch_bounds__(256) void k_swt_fwd_level_g(const T *__restrict__ x
 // sdwt / acdwt, every level in one kernel, ONE column of LDS (k_sdwt_fused needs two): a thread keeps the NPT approximation
 // samples it has computed in registers across the barrier and writes them over the parent afterwards.  For signals whose
 // column fills most of a CU's LDS (n = 16384 Float64: 128 KiB, config 3's length).  n == NPT * blockDim.x, a power of two.
-// Loop order: taps outside (run-time count), the thread's NPT outputs inside (unrolled): NPT independent LDS reads or global
-// loads per tap are in flight together, and nothing but the NPT accumulators lives across a tap.  (Unrolling the taps as well
-// made the compiler hoist every index and spill 40 .. 850 registers; a tap loop inside the output loop made every tap a load
-// followed by its use: 32 round trips per level.)
+// The inverse (below) runs its taps OUTSIDE the thread's NPT outputs: NPT independent global loads per tap are in flight
+// together and nothing but the NPT accumulators lives across a tap (a tap loop inside the output loop made every tap a load
+// followed by its use, 32 round trips per level; unrolling both spilled 40 .. 850 registers).
 // ------------------------------------------------------------------------------------------
-template <typename T, bool AC, int NPT>
+template <typename T, bool AC, int NPT, int FT>
 __global__ __launch_bounds__(1024) void k_sdwt_fused_ip(const T *__restrict__ x, T *__restrict__ xw, int n, int64_t batch,
                                                        int L, WxFilt filt, WxAcFilt ac)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     T *v = reinterpret_cast<T *>(wx_smem);
-    const int NT = blockDim.x, msk = n - 1, t0 = threadIdx.x;
+    const int NT = blockDim.x;
     for (int64_t sig = blockIdx.x; sig < batch; sig += gridDim.x) {
         T *base = xw + sig * (int64_t)n * (L + 1);
         wx_stage<T>(v, x + sig * (int64_t)n, n);
         wx_lds_barrier();
         for (int d = 0; d < L; ++d) {
-            const int s = (1 << d) & msk;
+            const int s = (1 << d) % n;
             T *hi = base + (int64_t)(L - d) * n;
-            double lo[NPT], dd[NPT];
+            T lo_reg[NPT];
+            // (forward: the taps are LDS reads and the detail goes out as stores nobody waits for, so one output at a time
+            // with its taps unrolled is the fastest form measured -- 2.70 ms on config 3 against 3.30 ms with the taps outside)
 #pragma unroll
-            for (int it = 0; it < NPT; ++it) lo[it] = dd[it] = 0.0;
-            if (!AC) {
-                for (int j = 0; j < filt.F; ++j) {
-                    const double qa = filt.q[j], qd = (j & 1) ? -qa : qa;
-                    const int o1 = (j - 1) * s, o2 = -j * s;                 // v[i + (j-1) s], v[i - j s]
+            for (int it = 0; it < NPT; ++it) {
+                const int i = threadIdx.x + it * NT;
+                if (i >= n) continue;
+                if (!AC && FT > 0) {
+                    double lo = 0.0, dd = 0.0;
+                    int k1 = i - s; if (k1 < 0) k1 += n;
+                    int k2 = i;
 #pragma unroll
-                    for (int it = 0; it < NPT; ++it) {
-                        const int i = t0 + it * NT;
-                        lo[it] = fma(qa, (double)v[(i + o1) & msk], lo[it]);
-                        dd[it] = fma(qd, (double)v[(i + o2) & msk], dd[it]);
+                    for (int j = 0; j < FT; ++j) {
+                        lo = fma(filt.q[j], (double)v[k1], lo);
+                        dd = fma((j & 1) ? -filt.q[j] : filt.q[j], (double)v[k2], dd);
+                        k1 += s; if (k1 >= n) k1 -= n;
+                        k2 -= s; if (k2 < 0) k2 += n;
                     }
-                }
-            } else {
-                for (int l = 1; l < ac.F; l += 2) {                          // odd lags only: S = sum b_l (v[i - l s] + v[i + l s])
-                    const double bl = ac.b[l - 1];
-                    const int o = l * s;
-#pragma unroll
-                    for (int it = 0; it < NPT; ++it) {
-                        const int i = t0 + it * NT;
-                        lo[it] = fma(bl, (double)v[(i - o) & msk] + (double)v[(i + o) & msk], lo[it]);
+                    lo_reg[it] = (T)lo;
+                    hi[i] = (T)dd;
+                } else if (!AC) {
+                    double lo = 0.0, dd = 0.0;
+                    int k1 = i - s; if (k1 < 0) k1 += n;
+                    int k2 = i;
+                    for (int j = 0; j < filt.F; ++j) {
+                        lo = fma(filt.q[j], (double)v[k1], lo);
+                        dd = fma((j & 1) ? -filt.q[j] : filt.q[j], (double)v[k2], dd);
+                        k1 += s; if (k1 >= n) k1 -= n;
+                        k2 -= s; if (k2 < 0) k2 += n;
                     }
-                }
-#pragma unroll
-                for (int it = 0; it < NPT; ++it) {
-                    const double c = ac.c1 * (double)v[t0 + it * NT], S = lo[it];
-                    lo[it] = c + S;
-                    dd[it] = c - S;
+                    lo_reg[it] = (T)lo;
+                    hi[i] = (T)dd;
+                } else {
+                    double S = 0.0;
+                    int km = i, kp = i;
+                    const int s2 = (2 * s) % n;
+                    km -= s; if (km < 0) km += n;
+                    kp += s; if (kp >= n) kp -= n;
+                    for (int l = 1; l < ac.F; l += 2) {
+                        S = fma(ac.b[l - 1], (double)v[km] + (double)v[kp], S);
+                        km -= s2; if (km < 0) km += n;
+                        kp += s2; if (kp >= n) kp -= n;
+                    }
+                    const double c = ac.c1 * (double)v[i];
+                    lo_reg[it] = (T)(c + S);
+                    hi[i] = (T)(c - S);
                 }
             }
-#pragma unroll
-            for (int it = 0; it < NPT; ++it) hi[t0 + it * NT] = (T)dd[it];
             wx_lds_barrier();
             if (d + 1 < L) {
 #pragma unroll
-                for (int it = 0; it < NPT; ++it) v[t0 + it * NT] = (T)lo[it];
+                for (int it = 0; it < NPT; ++it) {
+                    const int i = threadIdx.x + it * NT;
+                    if (i < n) v[i] = lo_reg[it];
+                }
                 wx_lds_barrier();
             } else {
 #pragma unroll
-                for (int it = 0; it < NPT; ++it) base[t0 + it * NT] = (T)lo[it];      // the last approximation is column 0
+                for (int it = 0; it < NPT; ++it) {
+                    const int i = threadIdx.x + it * NT;
+                    if (i < n) base[i] = lo_reg[it];                  // the last approximation is column 0
+                }
             }
         }
     }
@@ -1053,7 +1073,14 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         !(getenv("WX_SDWT_INPLACE") && atoi(getenv("WX_SDWT_INPLACE")) == 0)) {
         // the column fills more than half of a CU's LDS: in-place fused kernel, one workgroup of 1024 threads per CU
         constexpr int NPT = 128 / sizeof(T);
-        auto ki = ac ? k_sdwt_fused_ip<T, true, NPT> : k_sdwt_fused_ip<T, false, NPT>;
+        typedef void (*KFI)(const T *, T *, int, int64_t, int, WxFilt, WxAcFilt);
+        KFI ki = ac ? k_sdwt_fused_ip<T, true, NPT, 0> : k_sdwt_fused_ip<T, false, NPT, 0>;
+        if (!ac) switch (filt.F) {
+#define WX_CASE(FF) case FF: ki = k_sdwt_fused_ip<T, false, NPT, FF>; break;
+            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+#undef WX_CASE
+            default: break;
+        }
         WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ki), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int64_t grid = 256;
         if (grid > batch) grid = batch;
