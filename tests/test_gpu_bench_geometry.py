@@ -97,7 +97,7 @@ def test_config5_geometry_moments_and_tree(wx, oracle, mode):
         wx.set_force_generic(0)
 
 
-@pytest.mark.parametrize("wname", ["db2", "db4"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "coif2", "db8"])
 def test_config4_geometry_2d_lattice_matches_oracle(wx, oracle, wname):
     """BASELINE config 4: 2-D wptall / iwptall of 512 x 512 Float32 images, L = 6 (dwt/dwt_all.jl:152-166, 210-225 over
     Wavelets.jl's 2-D wpt by level) through the transposing lattice column kernels (csrc/wx_lattice2d.hip).  Float32:

@@ -18,7 +18,8 @@
 // non-temporal loads and stores, two wavefronts per SIMD without the 13-22 spilled registers of the three-wavefront build
 // (their scratch traffic was the 1.17 x of round 2's PMC bytes), and the intermediate image -- which nobody outside the
 // library sees -- in a BLOCKED layout (l2_src_off) that makes the first pass's stores and the second pass's loads
-// contiguous: only the last store of a transform is a strided one.  3.39 -> 2.95 ms per direction on config 4.
+// contiguous: only the last store of a transform is a strided one.  3.39 -> 2.95 ms per direction on config 4.  Filters of
+// 2 .. 12 and 16 taps (round 2: 4 and 8) -- db8 3.5 / 3.3 ms (the levels start to show), Haar / coif2 as db4.
 //
 // Halo: the columns of a wavefront are independent periodic sequences of 512 samples: in layout A (reg i[5:0]) the
 // neighbouring chunk is the next of 8 lanes (cyclic: two DPP moves and a select), in layout B (reg i[7:2]) the other of 2
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
 bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz)
 {
     static const bool off = getenv("WX_LATTICE2D") && atoi(getenv("WX_LATTICE2D")) == 0;
-    return !off && esz == 4 && m == 512 && n == 512 && L == 6 && filt.F >= 4 && filt.F / 2 <= WX_L2_MAXS;
+    return !off && esz == 4 && m == 512 && n == 512 && L == 6 && filt.F >= 2 && filt.F / 2 <= WX_L2_MAXS;
 }
 
 // one transposing pass over `batch` images: 0 = not applicable, 1 = launched, < 0 = error.  pass 0: natural image in,
@@ -540,7 +541,7 @@ int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t batch, const WxF
         else WX_GO2K(k_lat2d_colT_f32, NSS);                                                                             \
         break;
     switch (filt.F / 2) {
-        WX_GO2(2) WX_GO2(4)
+        WX_GO2(1) WX_GO2(2) WX_GO2(3) WX_GO2(4) WX_GO2(5) WX_GO2(6) WX_GO2(8)
     default: return 0;
     }
 #undef WX_GO2
