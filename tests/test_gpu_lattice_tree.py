@@ -133,3 +133,28 @@ def test_tree_large_batch_and_device_arrays(wx, oracle):
     idx = [0, 1, B // 2, B - 2, B - 1]
     exp = oracle.wptall(np.asfortranarray(x[:, idx].cpu().numpy()), wt.qmf, tree)
     assert relerr(y[:, idx].cpu().numpy(), exp) <= TOL
+
+
+@pytest.mark.parametrize("n", [4096, 2048, 1024])
+@pytest.mark.parametrize("wname", ["haar", "db4"])
+def test_tree_denoise_threshold_rides_on_the_absorbed_leaves(wx, oracle, n, wname):
+    """denoiseall(x, :wpt, wt; tree) (Denoising.jl:527, 651-712): per-signal MAD, threshold, iwpt along the tree -- the threshold
+    is applied to the leaves as the tree-driven lattice inverse takes them in (one threshold per signal, several signals per
+    wavefront below 4096 samples); hard and soft rules, regular and undersmooth, device-resident and host arrays"""
+    rng = np.random.default_rng(n + 7)
+    wt = _wt(wx, wname)
+    B = 7
+    t = np.linspace(0, 1, n)
+    x0 = np.asfortranarray(np.stack([np.sin(2 * np.pi * (3 + b) * t) * (1 + b) for b in range(B)], axis=1))
+    x = x0 + 0.2 * rng.standard_normal((n, B)) * (1 + np.arange(B))[None, :]          # a different noise level per signal
+    for tree in (_trees(wx, n, rng, 5)[3:6] + _trees(wx, n, rng, 5)[-2:]):
+        xw = oracle.wptall(x, wt.qmf, tree)
+        for thname, TH in (("hard", wx.HardTH), ("soft", wx.SoftTH)):
+            dnt = wx.VisuShrink(n, TH())
+            for smooth in ("regular", "undersmooth"):
+                exp = np.stack([oracle.denoise(np.asfortranarray(xw[:, i]), "wpt", wt.qmf, tree=tree, th=thname, t=dnt.t, smooth=smooth)
+                                for i in range(B)], axis=1)
+                got = wx.to_numpy(wx.denoiseall(wx.to_device(xw), "wpt", wt, tree=tree, dnt=dnt, smooth=smooth))
+                assert relerr(got, exp) <= 1e-9, (n, wname, thname, smooth, int(tree.sum()))
+                got_h = wx.denoiseall(xw, "wpt", wt, tree=tree, dnt=dnt, smooth=smooth)
+                assert relerr(got_h, exp) <= 1e-9, (n, wname, thname, smooth)
