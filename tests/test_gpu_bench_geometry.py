@@ -113,6 +113,39 @@ def test_config4_geometry_2d_lattice_matches_oracle(wx, oracle, wname):
     assert relerr(back.astype(np.float64), x.astype(np.float64)) <= 2e-6, wname
 
 
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db8"])
+def test_2d_lattice_256x256_matches_oracle(wx, oracle, wname):
+    """256 x 256 Float32 images, full depth L = 5, through the same transposing lattice kernels (two images per register
+    column, csrc/wx_lattice2d.hip HB = 1): odd and even batches (the last workgroup re-does the last two images), forward
+    against the oracle, inverse against the oracle's input (DWT.jl:500-548, 662-710)"""
+    rng = np.random.default_rng(256)
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    for B in (5, 2, 8):
+        x = np.asfortranarray(rng.standard_normal((256, 256, B)).astype(np.float32))
+        exp = oracle.wptall(x.astype(np.float64), wt.qmf, 5)
+        got = wx.wptall(x, wt, 5)
+        assert got.dtype == np.float32
+        for b in range(B):
+            assert relerr(got[:, :, b].astype(np.float64), exp[:, :, b]) <= 2e-6, (wname, B, b)
+        back = wx.iwptall(exp.astype(np.float32), wt, 5)
+        for b in range(B):
+            assert relerr(back[:, :, b].astype(np.float64), x[:, :, b].astype(np.float64)) <= 2e-6, (wname, B, b)
+
+
+def test_2d_lattice_256x256_large_batch_round_trips(wx):
+    import torch
+    wt = wx.wavelet(wx.WT.db4)
+    x = wx.jl_empty((256, 256, 1001), torch.float32, "cuda")
+    x.normal_(generator=torch.Generator(device="cuda").manual_seed(7))
+    y0 = wx.wptall(x, wt, 5)
+    for _ in range(3):
+        y = wx.wptall(x, wt, 5)
+        assert torch.equal(y, y0)
+        xr = wx.iwptall(y, wt, 5)
+        err = (xr - x).abs().amax(dim=(0, 1)) / x.abs().max()
+        assert float(err.max()) <= 2e-6, (int(err.argmax()), float(err.max()))
+
+
 def test_config4_every_image_of_a_large_batch_round_trips(wx):
     """the two wavefronts of a 2-D lattice workgroup exchange columns through LDS; a missing wait before the workgroup
     barrier once corrupted one image in a few hundred, so every image of several large batches is checked, repeatedly,

@@ -86,11 +86,23 @@ __device__ __forceinline__ void l2_st(l2_gm p, f4 v)
 // Z[j + 512 o] the first pass writes it in blocks of 16 W source columns, Zb[(j / 16 W) * 512 * 16 W + o * 16 W + j % 16 W],
 // so that a workgroup's 512 runs of 64 W bytes are one contiguous 32 W KiB block (BS), and the second pass reads its
 // columns o out of those blocks (BL): sample j of column o at (j / 64) * WX_L2D_BLK + 64 o + j % 64.
-#define WX_L2D_BLK (512 * 16 * WX_L2D_W)
-template <bool BL> __device__ __forceinline__ int64_t l2_src_off(int col, int smp)
+// HB = 1 (256 x 256 images, depth 5): a register column of 512 samples is the same column of TWO consecutive images --
+// index bit 8 selects the image, the levels and their periodic halos stay inside a half (the cyclic neighbours of layout A
+// are the 4 lanes of a quad, layout B holds whole sequences), everything else is the 512-row kernel.
+template <int HB> struct L2G {
+    static constexpr int R = 512 >> HB;                   // rows = columns of an image
+    static constexpr int RB = 9 - HB;                     // bits of a row index
+    static constexpr int LD = 6 - HB;                     // levels
+    static constexpr int BLK = R * 16 * WX_L2D_W;         // elements of one block of 16 W source columns of the intermediate
+    static constexpr int IMG = R * R;
+};
+// element offset of sample smp9 (9 bits: image-select bits above the row bits) of column col
+template <bool BL, int HB> __device__ __forceinline__ int64_t l2_src_off(int col, int smp9)
 {
-    if constexpr (BL) return (int64_t)(smp >> 6) * WX_L2D_BLK + (int64_t)col * 64 + (smp & 63);
-    else return (int64_t)col * 512 + smp;
+    typedef L2G<HB> G;
+    const int im = smp9 >> G::RB, smp = smp9 & (G::R - 1);
+    if constexpr (BL) return (int64_t)im * G::IMG + (int64_t)(smp >> 6) * G::BLK + (int64_t)col * 64 + (smp & 63);
+    else return (int64_t)im * G::IMG + (int64_t)col * G::R + smp;
 }
 template <int... I, typename F> __device__ __forceinline__ void l2_for_impl(std::integer_sequence<int, I...>, F &&f)
 {
@@ -147,7 +159,7 @@ template <int CTRL> __device__ __forceinline__ int l2_dpp(int v) { return __buil
 // the 8 lanes that share lane >> 3 (cyclic); HALO 1: the 2 lanes lane, lane ^ 1
 template <int HALO, int D> __device__ __forceinline__ f2 l2_nbr(f2 v, bool edge_hi, bool edge_lo)
 {
-    if constexpr (D == 0) return v;
+    if constexpr (D == 0 || HALO == 0) return v;
     else {
         // the element travels as one 64-bit register pair (two 32-bit DPP moves), exactly like the Float64 kernel's halo:
         // per-component code on the float2 was merged by the compiler into one move for both halves
@@ -158,6 +170,11 @@ template <int HALO, int D> __device__ __forceinline__ f2 l2_nbr(f2 v, bool edge_
             if constexpr ((D & 1) == 0) return v;
             rlo = l2_dpp<0xB1>(lo);                                   // quad_perm [1,0,3,2]
             rhi = l2_dpp<0xB1>(hi);
+        } else if constexpr (HALO == 2) {
+            // 256-row images: the four chunks of a column are the lanes of a quad (cyclic)
+            static_assert(D == 1 || D == -1, "layout A moves one chunk");
+            if constexpr (D > 0) { rlo = l2_dpp<0x39>(lo); rhi = l2_dpp<0x39>(hi); }   // quad_perm [1,2,3,0]
+            else { rlo = l2_dpp<0x93>(lo); rhi = l2_dpp<0x93>(hi); }                   // quad_perm [3,0,1,2]
         } else {
             static_assert(D == 1 || D == -1, "layout A moves one chunk");
             if constexpr (D > 0) {
@@ -202,7 +219,7 @@ template <int K, int HALO, int NS, bool INV> __device__ __forceinline__ void l2_
             }
         }
     };
-    constexpr bool one_shot = (HALO == 1) || (NS - 1 <= M);
+    constexpr bool one_shot = (HALO == 1) || (HALO == 0) || (NS - 1 <= M);
     if constexpr (!INV) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -281,27 +298,30 @@ __device__ __forceinline__ void l2_t2(f2 (&a)[64], f2 (&bb)[64], unsigned lds0, 
 
 // forward: src image (column j = 512 contiguous samples at src + 512 j) -> dst image transposed and in packet order:
 // dst[j + 512 o(i)], o(i) = bitreverse6(i[5:0]) << 3 | i[8:6].  grid (16, images), 128 threads.
-template <int NS, bool BL, bool BS>
+template <int NS, bool BL, bool BS, int HB>
 __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_colT_f32(
-    const float *__restrict__ src, float *__restrict__ dst, int64_t img, WxLat2 cf)
+    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf)
 {
+    typedef L2G<HB> G;
     __shared__ double lds[WX_L2D_W * WX_L2_WIN];
     const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
-    const float *simg = src + img * blockIdx.y;
-    float *dimg = dst + img * blockIdx.y;
+    // HB = 1: a workgroup takes two consecutive images; the last workgroup of an odd batch re-does the last two
+    const int64_t img0 = min((int)blockIdx.y << HB, last_img);
+    const float *simg = src + img0 * G::IMG;
+    float *dimg = dst + img0 * G::IMG;
     const int j0 = 16 * WX_L2D_W * blockIdx.x + 16 * wave;
     f2 a[64];
     {
         // loads: instruction (cp, i7, i8) covers 8 complete lines: lane = sub | h << 3 | i5 << 4 | i6 << 5 holds samples
         // i = 256 i8 + 128 i7 + 64 i6 + 32 i5 + 4 sub + {0..3} of column 2 cp + h
         const int sub = lane & 7, h = (lane >> 3) & 1, i5 = (lane >> 4) & 1, i6 = lane >> 5;
-        const unsigned lo = BL ? 64u * h + (unsigned)WX_L2D_BLK * i6 + 32u * i5 + 4u * sub : 512u * h + 64u * i6 + 32u * i5 + 4u * sub;
+        const unsigned lo = BL ? 64u * h + (unsigned)G::BLK * i6 + 32u * i5 + 4u * sub : (unsigned)G::R * h + 64u * i6 + 32u * i5 + 4u * sub;
         f4 r[32];
         l2_for<32>([&](auto Q) {
             constexpr int cp = Q >> 2, i7 = Q & 1, i8 = (Q >> 1) & 1;
-            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL>(j0 + 2 * cp, 256 * i8 + 128 * i7)) + lo);
+            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL, HB>(j0 + 2 * cp, 256 * i8 + 128 * i7)) + lo);
         });
         // T1: the two columns of a pair meet in one 8-byte slot (two ds_write_b32): slot = 17 lam + m, lam = i[8:6] | cp << 3,
         // m = i[5:2]; round rho = i[1:0]
@@ -327,15 +347,16 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             });
         });
     }
-    l2_level<0, 3, NS, false>(a, cf, lane);
-    l2_level<1, 3, NS, false>(a, cf, lane);
+    constexpr int HA = HB ? 2 : 3, HBB = HB ? 0 : 1;      // halos of layouts A and B
+    l2_level<0, HA, NS, false>(a, cf, lane);
+    l2_level<1, HA, NS, false>(a, cf, lane);
     f2 bb[64];
     l2_t2(a, bb, lds0, lane);
-    l2_level<0, 1, NS, false>(bb, cf, lane);
-    l2_level<1, 1, NS, false>(bb, cf, lane);
-    l2_level<2, 1, NS, false>(bb, cf, lane);
-    l2_level<3, 1, NS, false>(bb, cf, lane);
-    // gains: a leaf whose path took k detail branches carries g^(2k - 6); path bits i[1:0] sit in the lane, i[5:2] in the
+    l2_level<0, HBB, NS, false>(bb, cf, lane);
+    l2_level<1, HBB, NS, false>(bb, cf, lane);
+    l2_level<2, HBB, NS, false>(bb, cf, lane);
+    if constexpr (HB == 0) l2_level<3, HBB, NS, false>(bb, cf, lane);
+    // gains: a leaf whose path took k detail branches carries g^(2k - LD); path bits i[1:0] sit in the lane, i[LD-1:2] in the
     // register index
     float gf[5];
     {
@@ -358,7 +379,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             constexpr int v = Vq;                         // v bits: i4, i5, i6, i7
             constexpr int r = rho + 4 * v;
             constexpr int rowreg = ((v & 1) << 4) | (((v >> 1) & 1) << 3) | (((v >> 3) & 1) << 1) | ((v >> 2) & 1);
-            constexpr int pc = (rho & 1) + (rho >> 1) + (v & 1) + ((v >> 1) & 1);
+            constexpr int pc = (rho & 1) + (rho >> 1) + (v & 1) + (HB == 0 ? ((v >> 1) & 1) : 0);
             f2 val = bb[r];
             val.x *= gf[pc];
             val.y *= gf[pc];
@@ -370,8 +391,16 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             const int rr = RPI * k + tid / LPR, u = tid % LPR;
             const int o2 = (rr >> 2) & 1;
             const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (8 * o2))));
-            const int o = (rr & 31) | ((rho >> 1) << 5) | ((rho & 1) << 6) | ((rr >> 5) << 7);
-            l2_st(l2_sbase(dimg + (BS ? WX_L2D_BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)((BS ? 16 * WX_L2D_W : 512) * o + 4 * u), val);
+            // row bits: i6 = rr0, i7 = rr1, i8 = rr2, i5 = rr3, i4 = rr4, i1 = rr5, i0 = rr6, i2 = rho0, i3 = rho1;
+            // o = bitreverse(i[LD-1:0]) above i[RB-1:LD]; HB = 1: i8 selects the image
+            int o, im = 0;
+            if constexpr (HB == 0) o = (rr & 31) | ((rho >> 1) << 5) | ((rho & 1) << 6) | ((rr >> 5) << 7);
+            else {
+                o = ((rr >> 3) & 1) | ((rr & 3) << 1) | (((rr >> 4) & 1) << 3) | ((rho >> 1) << 4) | ((rho & 1) << 5) | (((rr >> 5) & 1) << 6) |
+                    ((rr >> 6) << 7);
+                im = (rr >> 2) & 1;
+            }
+            l2_st(l2_sbase(dimg + (BS ? G::BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * o + 4 * u), val);
         });
         l2_barrier();
     });
@@ -411,33 +440,46 @@ __device__ __forceinline__ void l2_t2i(f2 (&bb)[64], f2 (&a)[64], unsigned lds0,
 
 // inverse: src image (column j = 512 contiguous packet coefficients, position o(i) = bitreverse6(i[5:0]) << 3 | i[8:6]) ->
 // dst image transposed, natural order: dst[j + 512 i].  grid (16, images), 128 threads.
-template <int NS, bool BL, bool BS>
+template <int NS, bool BL, bool BS, int HB>
 __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_icolT_f32(
-    const float *__restrict__ src, float *__restrict__ dst, int64_t img, WxLat2 cf)
+    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf)
 {
+    typedef L2G<HB> G;
     __shared__ double lds[WX_L2D_W * WX_L2_WIN];
     const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
-    const float *simg = src + img * blockIdx.y;
-    float *dimg = dst + img * blockIdx.y;
+    const int64_t img0 = min((int)blockIdx.y << HB, last_img);
+    const float *simg = src + img0 * G::IMG;
+    float *dimg = dst + img0 * G::IMG;
     const int j0 = 16 * WX_L2D_W * blockIdx.x + 16 * wave;
     f2 bb[64];
     {
         // loads as in the forward kernel, in packet order: lane = sub | h << 3 | o5 << 4 | o6 << 5, instruction (cp, o7, o8);
-        // o8 = i0, o7 = i1, o6 = i2, o5 = i3, o4 = i4, o3 = i5, o2 = i8, o1 = i7, o0 = i6
+        // memory index bits m8 .. m0 = (o8, o7, o6, o5, sub[2], sub[1], sub[0], component[1], component[0])
+        //   HB = 0:  m8 .. m0 = i0 i1 i2 i3 i4 i5 i8 i7 i6        (packet order of depth 6 over 512 rows)
+        //   HB = 1:  m8 .. m0 = i8 i0 i1 i2 i3 i4 i7 i6 i5        (image select, packet order of depth 5 over 256 rows)
         const int sub = lane & 7, h = (lane >> 3) & 1, o5 = (lane >> 4) & 1, o6 = lane >> 5;
-        const unsigned lo = BL ? 64u * h + (unsigned)WX_L2D_BLK * o6 + 32u * o5 + 4u * sub : 512u * h + 64u * o6 + 32u * o5 + 4u * sub;
+        const unsigned lo = BL ? 64u * h + (unsigned)G::BLK * o6 + 32u * o5 + 4u * sub : (unsigned)G::R * h + 64u * o6 + 32u * o5 + 4u * sub;
         f4 r[32];
         l2_for<32>([&](auto Q) {
             constexpr int cp = Q >> 2, o7 = Q & 1, o8 = (Q >> 1) & 1;
-            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL>(j0 + 2 * cp, 256 * o8 + 128 * o7)) + lo);
+            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL, HB>(j0 + 2 * cp, 256 * o8 + 128 * o7)) + lo);
         });
-        // into layout B (reg i[7:2], lane mu = i8 | cp << 1 | i0 << 4 | i1 << 5): round rho = o[1:0] = (i6, i7 << 1) fixes
-        // register bits 4, 5; slot = 17 mu + v, v = i2 | i3 << 1 | i4 << 2 | i5 << 3
-        const int i8 = sub & 1, i5 = (sub >> 1) & 1, i4 = sub >> 2;
-        const unsigned wa = lds0 + 4u * (34u * i8 + 2u * (o6 + 2u * o5 + 4u * i4 + 8u * i5) + h), ra = lds0 + 8u * 17u * lane;
-        // gains: the coefficient of a leaf whose path took k detail branches enters as coef * g^(2k - 6)
+        // into layout B (reg i[7:2], lane mu = i8 | cp << 1 | i0 << 4 | i1 << 5): a round (the component of the loaded
+        // vectors) fixes two register bits, the lane reads its 16 other registers out of row mu: slot = 17 mu + w
+        //   HB = 0: round = (i6, i7) = register bits 4, 5;  w = i2 | i3 << 1 | i4 << 2 | i5 << 3 = register bits 0 .. 3
+        //   HB = 1: round = (i5, i6) = register bits 3, 4;  w = i2 | i3 << 1 | i4 << 2 | i7 << 3 = register bits 0, 1, 2, 5
+        unsigned wa;
+        if constexpr (HB == 0) {
+            const int i8 = sub & 1, i5 = (sub >> 1) & 1, i4 = sub >> 2;
+            wa = lds0 + 4u * (34u * i8 + 2u * (o6 + 2u * o5 + 4u * i4 + 8u * i5) + h);
+        } else {
+            const int i7 = sub & 1, i4 = (sub >> 1) & 1, i3 = sub >> 2;
+            wa = lds0 + 4u * (34u * 32u * o6 + 2u * (o5 + 2u * i3 + 4u * i4 + 8u * i7) + h);
+        }
+        const unsigned ra = lds0 + 8u * 17u * lane;
+        // gains: the coefficient of a leaf whose path took k detail branches enters as coef * g^(2k - LD)
         float gf[5];
         {
             float b = cf.g0;
@@ -448,10 +490,12 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             for (int m = 1; m < 5; ++m) gf[m] = gf[m - 1] * cf.g2;
         }
         l2_for<4>([&](auto Rq) {
-            constexpr int rho = Rq;                       // rho bit 0 = o0 = i6, bit 1 = o1 = i7
+            constexpr int rho = Rq;
             l2_for<32>([&](auto Q) {
-                constexpr int cp = Q >> 2, i1 = Q & 1, i0 = (Q >> 1) & 1;
-                l2_wr32<4 * 34 * (2 * cp + 16 * i0 + 32 * i1)>(wa, r[Q][rho]);
+                constexpr int cp = Q >> 2, q0 = Q & 1, q1 = (Q >> 1) & 1;                 // (o7, o8)
+                // HB = 0: o7 = i1 (mu bit 5), o8 = i0 (mu bit 4);  HB = 1: o7 = i0 (mu bit 4), o8 = i8 (mu bit 0)
+                constexpr int mu_i = HB == 0 ? (2 * cp + 16 * q1 + 32 * q0) : (q1 + 2 * cp + 16 * q0);
+                l2_wr32<4 * 34 * mu_i>(wa, r[Q][rho]);
             });
             l2_for<16 / WX_L2D_G>([&](auto Hq) {
                 constexpr int v0 = WX_L2D_G * Hq;
@@ -463,23 +507,31 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
                 l2_waitn(t);
                 l2_for<WX_L2D_G>([&](auto V) {
                     constexpr int v = v0 + V;
-                    constexpr int pc = (v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1) + ((v >> 3) & 1);
                     f2 e = __builtin_bit_cast(f2, t[V]);
-                    e.x *= gf[pc];
-                    e.y *= gf[pc];
-                    bb[v + 16 * rho] = e;                 // register index i[7:2] = v | i6 << 4 | i7 << 5
+                    if constexpr (HB == 0) {
+                        constexpr int pc = (v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1) + ((v >> 3) & 1);
+                        e.x *= gf[pc];
+                        e.y *= gf[pc];
+                        bb[v + 16 * rho] = e;             // register index i[7:2] = v | i6 << 4 | i7 << 5
+                    } else {
+                        constexpr int pc = (v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1);
+                        e.x *= gf[pc];
+                        e.y *= gf[pc];
+                        bb[(v & 7) | ((rho & 1) << 3) | ((rho >> 1) << 4) | ((v >> 3) << 5)] = e;
+                    }
                 });
             });
         });
     }
-    l2_level<3, 1, NS, true>(bb, cf, lane);
-    l2_level<2, 1, NS, true>(bb, cf, lane);
-    l2_level<1, 1, NS, true>(bb, cf, lane);
-    l2_level<0, 1, NS, true>(bb, cf, lane);
+    constexpr int HA = HB ? 2 : 3, HBB = HB ? 0 : 1;
+    if constexpr (HB == 0) l2_level<3, HBB, NS, true>(bb, cf, lane);
+    l2_level<2, HBB, NS, true>(bb, cf, lane);
+    l2_level<1, HBB, NS, true>(bb, cf, lane);
+    l2_level<0, HBB, NS, true>(bb, cf, lane);
     f2 a[64];
     l2_t2i(bb, a, lds0, lane);
-    l2_level<1, 3, NS, true>(a, cf, lane);
-    l2_level<0, 3, NS, true>(a, cf, lane);
+    l2_level<1, HA, NS, true>(a, cf, lane);
+    l2_level<0, HA, NS, true>(a, cf, lane);
     // transposed store, natural row order: layout A (reg i[5:0], lane i[8:6] | cp << 3); round rho = i[5:4];
     // row of the round rr = i[3:0] | i[8:6] << 4, slot = 8 W rr + (pair ^ i[8:6] << 1)
     constexpr int RS = 8 * WX_L2D_W, LPR = 4 * WX_L2D_W, RPI = 16;
@@ -498,8 +550,8 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             const int rr = RPI * k + tid / LPR, u = tid % LPR;
             const int s86 = rr >> 4;
             const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (s86 << 1))));
-            const int i = (rr & 15) | (rho << 4) | (s86 << 6);
-            l2_st(l2_sbase(dimg + (BS ? WX_L2D_BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)((BS ? 16 * WX_L2D_W : 512) * i + 4 * u), val);
+            const int i9 = (rr & 15) | (rho << 4) | (s86 << 6), im = i9 >> G::RB, i = i9 & (G::R - 1);
+            l2_st(l2_sbase(dimg + (BS ? G::BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * i + 4 * u), val);
         });
         l2_barrier();
     });
@@ -510,35 +562,43 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
 bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz)
 {
     static const bool off = getenv("WX_LATTICE2D") && atoi(getenv("WX_LATTICE2D")) == 0;
-    return !off && esz == 4 && m == 512 && n == 512 && L == 6 && filt.F >= 2 && filt.F / 2 <= WX_L2_MAXS;
+    const bool shape = (m == 512 && n == 512 && L == 6) || (m == 256 && n == 256 && L == 5);
+    return !off && esz == 4 && shape && filt.F >= 2 && filt.F / 2 <= WX_L2_MAXS;
 }
 
-// one transposing pass over `batch` images: 0 = not applicable, 1 = launched, < 0 = error.  pass 0: natural image in,
-// transposed image out (what one application of the kernel is); pass 1 / 2: the first / second pass of a transform, with
-// the intermediate image in the blocked layout above (the caller's scratch buffer, never seen outside the library).
-int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
+// one transposing pass over `batch` images of side `m` (512: depth 6, 256: depth 5): 0 = not applicable, 1 = launched,
+// < 0 = error.  pass 0: natural image in, transposed image out (what one application of the kernel is); pass 1 / 2: the first
+// / second pass of a transform, with the intermediate image in the blocked layout above (the caller's scratch buffer, never
+// seen outside the library).
+int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t m, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
 {
     static const bool blocked = WX_L2D_W == 4 && !(getenv("WX_L2D_BLOCKED") && atoi(getenv("WX_L2D_BLOCKED")) == 0);
+    const int hb = m == 512 ? 0 : (m == 256 ? 1 : -1);
+    if (hb < 0) return 0;
     double p[WX_L2_MAXS], kap[WX_L2_MAXS], g0, g2;
-    if (!wx_lattice_coeffs(filt, 6, inverse, p, kap, &g0, &g2)) return 0;
+    if (!wx_lattice_coeffs(filt, 6 - hb, inverse, p, kap, &g0, &g2)) return 0;
     WxLat2 cf;
     for (int j = 0; j < WX_L2_MAXS; ++j) { cf.p[j] = (float)p[j]; cf.kap[j] = (float)kap[j]; }
     cf.g0 = (float)g0;
     cf.g2 = (float)g2;
-    if (batch > 65535 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return 0;
+    const int64_t per = (int64_t)1 << hb, units = (batch + per - 1) / per;
+    if (batch < per || units > 65535 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return 0;
+    if ((batch & (per - 1)) && src == dst) return 0;          // the last workgroup re-does images: out of place only
     const bool bl = blocked && pass == 2, bs = blocked && pass == 1;
-    const dim3 grid(32 / WX_L2D_W, (unsigned)batch), wg(64 * WX_L2D_W);
-    const int64_t img = (int64_t)512 * 512;
-#define WX_GO2K(K, NSS)                                                                                                  \
+    const dim3 grid((unsigned)((m / 16) / WX_L2D_W), (unsigned)units), wg(64 * WX_L2D_W);
+    const int last_img = (int)(batch - per);
+#define WX_GO2K(K, NSS, HBB)                                                                                             \
     do {                                                                                                                 \
-        if (bl) hipLaunchKernelGGL((K<NSS, true, false>), grid, wg, 0, st, src, dst, img, cf);                           \
-        else if (bs) hipLaunchKernelGGL((K<NSS, false, true>), grid, wg, 0, st, src, dst, img, cf);                      \
-        else hipLaunchKernelGGL((K<NSS, false, false>), grid, wg, 0, st, src, dst, img, cf);                             \
+        if (bl) hipLaunchKernelGGL((K<NSS, true, false, HBB>), grid, wg, 0, st, src, dst, last_img, cf);                 \
+        else if (bs) hipLaunchKernelGGL((K<NSS, false, true, HBB>), grid, wg, 0, st, src, dst, last_img, cf);            \
+        else hipLaunchKernelGGL((K<NSS, false, false, HBB>), grid, wg, 0, st, src, dst, last_img, cf);                   \
     } while (0)
 #define WX_GO2(NSS)                                                                                                      \
     case NSS:                                                                                                            \
-        if (inverse) WX_GO2K(k_lat2d_icolT_f32, NSS);                                                                    \
-        else WX_GO2K(k_lat2d_colT_f32, NSS);                                                                             \
+        if (inverse && hb) WX_GO2K(k_lat2d_icolT_f32, NSS, 1);                                                           \
+        else if (inverse) WX_GO2K(k_lat2d_icolT_f32, NSS, 0);                                                            \
+        else if (hb) WX_GO2K(k_lat2d_colT_f32, NSS, 1);                                                                  \
+        else WX_GO2K(k_lat2d_colT_f32, NSS, 0);                                                                          \
         break;
     switch (filt.F / 2) {
         WX_GO2(1) WX_GO2(2) WX_GO2(3) WX_GO2(4) WX_GO2(5) WX_GO2(6) WX_GO2(8)
