@@ -113,7 +113,7 @@ def test_config4_geometry_2d_lattice_matches_oracle(wx, oracle, wname):
     assert relerr(back.astype(np.float64), x.astype(np.float64)) <= 2e-6, wname
 
 
-@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db8"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "coif2", "db8"])
 def test_2d_lattice_256x256_matches_oracle(wx, oracle, wname):
     """256 x 256 Float32 images, full depth L = 5, through the same transposing lattice kernels (two images per register
     column, csrc/wx_lattice2d.hip HB = 1): odd and even batches (the last workgroup re-does the last two images), forward
@@ -130,6 +130,37 @@ def test_2d_lattice_256x256_matches_oracle(wx, oracle, wname):
         back = wx.iwptall(exp.astype(np.float32), wt, 5)
         for b in range(B):
             assert relerr(back[:, :, b].astype(np.float64), x[:, :, b].astype(np.float64)) <= 2e-6, (wname, B, b)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "coif2", "db8"])
+def test_2d_lattice_1024x1024_matches_oracle(wx, oracle, wname):
+    """1024 x 1024 Float32 images, full depth L = 7 (8 columns of 1024 rows per wavefront, csrc/wx_lattice2d.hip HB = 2),
+    forward against the oracle, inverse against the oracle's input"""
+    rng = np.random.default_rng(1024)
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    x = np.asfortranarray(rng.standard_normal((1024, 1024, 2)).astype(np.float32))
+    exp = oracle.wptall(x.astype(np.float64), wt.qmf, 7)
+    got = wx.wptall(x, wt, 7)
+    assert got.dtype == np.float32
+    for b in range(2):
+        assert relerr(got[:, :, b].astype(np.float64), exp[:, :, b]) <= 3e-6, (wname, b)
+    back = wx.iwptall(exp.astype(np.float32), wt, 7)
+    for b in range(2):
+        assert relerr(back[:, :, b].astype(np.float64), x[:, :, b].astype(np.float64)) <= 3e-6, (wname, b)
+
+
+def test_2d_lattice_1024x1024_batch_round_trips(wx):
+    import torch
+    wt = wx.wavelet(wx.WT.db4)
+    x = wx.jl_empty((1024, 1024, 129), torch.float32, "cuda")
+    x.normal_(generator=torch.Generator(device="cuda").manual_seed(11))
+    y0 = wx.wptall(x, wt, 7)
+    for _ in range(3):
+        y = wx.wptall(x, wt, 7)
+        assert torch.equal(y, y0)
+        xr = wx.iwptall(y, wt, 7)
+        err = (xr - x).abs().amax(dim=(0, 1)) / x.abs().max()
+        assert float(err.max()) <= 3e-6, (int(err.argmax()), float(err.max()))
 
 
 def test_2d_lattice_256x256_large_batch_round_trips(wx):

@@ -139,7 +139,7 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
     if (batch && (!dx || !dy)) return io.finish(WX_EHIP);
     T *tmp = nullptr, *pong = nullptr;
     if (batch && tr.Leff > 0) { tmp = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!tmp) return io.finish(WX_EHIP); }
-    if (tr.full && tr.Leff > 0 && !wx_force_generic() && wx_wpt2d_fast_ok<T>(m, n, F)) {
+    if (tr.full && tr.Leff > 0 && !wx_force_generic() && (wx_wpt2d_fast_ok<T>(m, n, F) || wx_lattice2d_ok(m, n, tr.Leff, filt, sizeof(T)))) {
         rc = wx_dev_wpt2d_fast<T>(dx, dy, m, n, tr.Leff, batch, filt, tmp, INVERSE, m * n, st);
         if (rc == WX_OK && tail) rc = wx_dwt2d_tail<T>(dy, m, tail, batch, filt, st);
         return io.finish(rc);
@@ -174,7 +174,7 @@ static int api_iwpd2d(const T *xw, T *xh, int64_t m, int64_t n, int k, int L, co
     if (batch && (!dxw || !dxh)) return io.finish(WX_EHIP);
     T *tmp = nullptr, *pong = nullptr, *leaves = nullptr;
     if (batch && tr.Leff > 0) { tmp = (T *)scr.alloc(sizeof(T) * mn * batch); if (!tmp) return io.finish(WX_EHIP); }
-    if (tr.full && tr.Leff > 0 && !wx_force_generic() && wx_wpt2d_fast_ok<T>(m, n, F)) {
+    if (tr.full && tr.Leff > 0 && !wx_force_generic() && (wx_wpt2d_fast_ok<T>(m, n, F) || wx_lattice2d_ok(m, n, tr.Leff, filt, sizeof(T)))) {
         rc = wx_dev_wpt2d_fast<T>(dxw + (int64_t)tr.Leff * mn, dxh, m, n, tr.Leff, batch, filt, tmp, true, mn * k, st);
         return io.finish(rc);
     }

@@ -90,19 +90,36 @@ __device__ __forceinline__ void l2_st(l2_gm p, f4 v)
 // index bit 8 selects the image, the levels and their periodic halos stay inside a half (the cyclic neighbours of layout A
 // are the 4 lanes of a quad, layout B holds whole sequences), everything else is the 512-row kernel.
 template <int HB> struct L2G {
-    static constexpr int R = 512 >> HB;                   // rows = columns of an image
-    static constexpr int RB = 9 - HB;                     // bits of a row index
-    static constexpr int LD = 6 - HB;                     // levels
-    static constexpr int BLK = R * 16 * WX_L2D_W;         // elements of one block of 16 W source columns of the intermediate
+    static constexpr int R = HB == 2 ? 1024 : (512 >> HB);  // rows = columns of an image (HB = 2: 1024, see below)
+    static constexpr int RB = HB == 2 ? 10 : 9 - HB;        // bits of a row index
+    static constexpr int LD = HB == 2 ? 7 : 6 - HB;         // levels
+    static constexpr int IB = HB == 1 ? 1 : 0;              // image-select bits of a register column
+    static constexpr int NPW = HB == 2 ? 4 : 8;             // column pairs per wavefront
+    static constexpr int BW = 2 * NPW * WX_L2D_W;           // columns per workgroup = block width of the intermediate
+    static constexpr int BLK = R * BW;                      // elements of one block of the intermediate
     static constexpr int IMG = R * R;
+    static constexpr int HA = HB == 2 ? 4 : (HB == 1 ? 2 : 3);   // halo of layout A: 16 lanes of a row / a quad / 8 lanes
+    static constexpr int HBQ = HB == 2 ? 2 : (HB == 1 ? 0 : 1);  // halo of layout B: a quad / none / lane ^ 1
 };
+// HB = 2 (1024 x 1024 images, depth 7): a wavefront holds 8 columns of 1024 rows instead of 16 of 512 -- the same 64 x 64
+// float2 registers with index bit 9 where the top column-pair bit was: layout A lane = i[9:6] | cp << 4 (the 16 chunks of a
+// column are the 16 lanes of a DPP row), layout B lane = (i[9:8] | cp << 2) | i[1:0] << 4 (the 4 chunks are a quad), one
+// more level on register bit 4 of layout B.  The exchanges T1, T2 do not change (they never look at what the lane bits mean).
 // element offset of sample smp9 (9 bits: image-select bits above the row bits) of column col
 template <bool BL, int HB> __device__ __forceinline__ int64_t l2_src_off(int col, int smp9)
 {
     typedef L2G<HB> G;
     const int im = smp9 >> G::RB, smp = smp9 & (G::R - 1);
-    if constexpr (BL) return (int64_t)im * G::IMG + (int64_t)(smp >> 6) * G::BLK + (int64_t)col * 64 + (smp & 63);
+    if constexpr (BL) return (int64_t)im * G::IMG + (int64_t)(smp / G::BW) * G::BLK + (int64_t)col * G::BW + (smp % G::BW);
     else return (int64_t)im * G::IMG + (int64_t)col * G::R + smp;
+}
+// lane part of a load address: column half h, samples 64 i6 + 32 i5 + 4 sub
+template <bool BL, int HB> __device__ __forceinline__ unsigned l2_lane_off(int h, int i6, int i5, int sub)
+{
+    typedef L2G<HB> G;
+    if constexpr (!BL) return (unsigned)G::R * h + 64u * i6 + 32u * i5 + 4u * sub;
+    else if constexpr (G::BW == 64) return 64u * h + (unsigned)G::BLK * i6 + 32u * i5 + 4u * sub;
+    else return 32u * h + (unsigned)G::BLK * (2 * i6 + i5) + 4u * sub;          // blocks of 32 columns
 }
 template <int... I, typename F> __device__ __forceinline__ void l2_for_impl(std::integer_sequence<int, I...>, F &&f)
 {
@@ -171,10 +188,17 @@ template <int HALO, int D> __device__ __forceinline__ f2 l2_nbr(f2 v, bool edge_
             rlo = l2_dpp<0xB1>(lo);                                   // quad_perm [1,0,3,2]
             rhi = l2_dpp<0xB1>(hi);
         } else if constexpr (HALO == 2) {
-            // 256-row images: the four chunks of a column are the lanes of a quad (cyclic)
-            static_assert(D == 1 || D == -1, "layout A moves one chunk");
-            if constexpr (D > 0) { rlo = l2_dpp<0x39>(lo); rhi = l2_dpp<0x39>(hi); }   // quad_perm [1,2,3,0]
-            else { rlo = l2_dpp<0x93>(lo); rhi = l2_dpp<0x93>(hi); }                   // quad_perm [3,0,1,2]
+            // the four chunks of a sequence are the lanes of a quad (cyclic): lane q takes lane (q + D) mod 4
+            constexpr int E = ((D % 4) + 4) % 4;
+            if constexpr (E == 0) return v;
+            constexpr int SEL = ((0 + E) & 3) | (((1 + E) & 3) << 2) | (((2 + E) & 3) << 4) | (((3 + E) & 3) << 6);
+            rlo = l2_dpp<SEL>(lo);
+            rhi = l2_dpp<SEL>(hi);
+        } else if constexpr (HALO == 4) {
+            // the sixteen chunks of a column are the lanes of a DPP row (cyclic): row_ror:n, lane i takes lane i - n (mod 16)
+            static_assert(D > -16 && D < 16, "row rotations");
+            rlo = l2_dpp<0x120 + ((16 - D) & 15)>(lo);
+            rhi = l2_dpp<0x120 + ((16 - D) & 15)>(hi);
         } else {
             static_assert(D == 1 || D == -1, "layout A moves one chunk");
             if constexpr (D > 0) {
@@ -219,7 +243,7 @@ template <int K, int HALO, int NS, bool INV> __device__ __forceinline__ void l2_
             }
         }
     };
-    constexpr bool one_shot = (HALO == 1) || (HALO == 0) || (NS - 1 <= M);
+    constexpr bool one_shot = (HALO != 3) || (NS - 1 <= M);
     if constexpr (!INV) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -308,20 +332,21 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
     // HB = 1: a workgroup takes two consecutive images; the last workgroup of an odd batch re-does the last two
-    const int64_t img0 = min((int)blockIdx.y << HB, last_img);
+    const int64_t img0 = min((int)blockIdx.y << G::IB, last_img);
     const float *simg = src + img0 * G::IMG;
     float *dimg = dst + img0 * G::IMG;
-    const int j0 = 16 * WX_L2D_W * blockIdx.x + 16 * wave;
+    const int j0 = 2 * G::NPW * (WX_L2D_W * blockIdx.x + wave);
     f2 a[64];
     {
-        // loads: instruction (cp, i7, i8) covers 8 complete lines: lane = sub | h << 3 | i5 << 4 | i6 << 5 holds samples
-        // i = 256 i8 + 128 i7 + 64 i6 + 32 i5 + 4 sub + {0..3} of column 2 cp + h
+        // loads: instruction Q = (cp, i8, i7) [HB = 2: (cp, i9, i8, i7)] covers 8 complete lines: lane = sub | h << 3 | i5 << 4 |
+        // i6 << 5 holds samples i = 128 (Q mod QS) + 64 i6 + 32 i5 + 4 sub + {0..3} of column 2 cp + h
+        constexpr int QS = 32 / G::NPW;                   // instructions per column pair
         const int sub = lane & 7, h = (lane >> 3) & 1, i5 = (lane >> 4) & 1, i6 = lane >> 5;
-        const unsigned lo = BL ? 64u * h + (unsigned)G::BLK * i6 + 32u * i5 + 4u * sub : (unsigned)G::R * h + 64u * i6 + 32u * i5 + 4u * sub;
+        const unsigned lo = l2_lane_off<BL, HB>(h, i6, i5, sub);
         f4 r[32];
         l2_for<32>([&](auto Q) {
-            constexpr int cp = Q >> 2, i7 = Q & 1, i8 = (Q >> 1) & 1;
-            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL, HB>(j0 + 2 * cp, 256 * i8 + 128 * i7)) + lo);
+            constexpr int cp = Q / QS, sq = Q % QS;
+            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL, HB>(j0 + 2 * cp, 128 * sq)) + lo);
         });
         // T1: the two columns of a pair meet in one 8-byte slot (two ds_write_b32): slot = 17 lam + m, lam = i[8:6] | cp << 3,
         // m = i[5:2]; round rho = i[1:0]
@@ -329,8 +354,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
         l2_for<4>([&](auto Rq) {
             constexpr int rho = Rq;
             l2_for<32>([&](auto Q) {
-                constexpr int cp = Q >> 2, i7 = Q & 1, i8 = (Q >> 1) & 1;
-                l2_wr32<4 * 34 * (2 * i7 + 4 * i8 + 8 * cp)>(wa, r[Q][rho]);
+                l2_wr32<4 * 34 * 2 * Q>(wa, r[Q][rho]);      // lam = i6 | Q << 1: the lane of layout A
             });
             l2_for<16 / WX_L2D_G>([&](auto Hq) {
                 constexpr int m0 = WX_L2D_G * Hq;
@@ -347,7 +371,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             });
         });
     }
-    constexpr int HA = HB ? 2 : 3, HBB = HB ? 0 : 1;      // halos of layouts A and B
+    constexpr int HA = G::HA, HBB = G::HBQ;               // halos of layouts A and B
     l2_level<0, HA, NS, false>(a, cf, lane);
     l2_level<1, HA, NS, false>(a, cf, lane);
     f2 bb[64];
@@ -355,17 +379,52 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
     l2_level<0, HBB, NS, false>(bb, cf, lane);
     l2_level<1, HBB, NS, false>(bb, cf, lane);
     l2_level<2, HBB, NS, false>(bb, cf, lane);
-    if constexpr (HB == 0) l2_level<3, HBB, NS, false>(bb, cf, lane);
+    if constexpr (G::LD >= 6) l2_level<3, HBB, NS, false>(bb, cf, lane);
+    if constexpr (G::LD >= 7) l2_level<4, HBB, NS, false>(bb, cf, lane);
     // gains: a leaf whose path took k detail branches carries g^(2k - LD); path bits i[1:0] sit in the lane, i[LD-1:2] in the
     // register index
-    float gf[5];
+    float gf[6];
     {
         float b = cf.g0;
         b = (lane & 16) ? b * cf.g2 : b;
         b = (lane & 32) ? b * cf.g2 : b;
         gf[0] = b;
 #pragma unroll
-        for (int m = 1; m < 5; ++m) gf[m] = gf[m - 1] * cf.g2;
+        for (int m = 1; m < 6; ++m) gf[m] = gf[m - 1] * cf.g2;
+    }
+    if constexpr (HB == 2) {
+        // 1024 rows: round rho fixes (i2, i3) -> 256 of the 1024 rows; a row of the workgroup is 4 W column pairs = 32 W bytes.
+        // row of the round = i8 | i9 << 1 | i7 << 2 | i6 << 3 | i5 << 4 | i4 << 5 | i1 << 6 | i0 << 7, slot = 16 row + (pair ^ 4 i9)
+        constexpr int RS = 4 * WX_L2D_W, LPR = 2 * WX_L2D_W, RPI = 64 * WX_L2D_W / LPR;
+        const int i8 = lane & 1, i9 = (lane >> 1) & 1, cp = (lane >> 2) & 3, i0 = (lane >> 4) & 1, i1 = lane >> 5;
+        const unsigned wa = ldsb + 8u * ((unsigned)RS * (i8 | (i9 << 1) | (i1 << 6) | (i0 << 7)) + (unsigned)((4 * wave + cp) ^ (4 * i9)));
+        l2_barrier();
+        l2_for<4>([&](auto Rq) {
+            constexpr int rho = Rq;
+            l2_for<16>([&](auto Vq) {
+                constexpr int v = Vq;                     // v bits: i4, i5, i6, i7
+                constexpr int r = rho + 4 * v;
+                constexpr int rowreg = (((v >> 3) & 1) << 2) | (((v >> 2) & 1) << 3) | (((v >> 1) & 1) << 4) | ((v & 1) << 5);
+                constexpr int pc = (rho & 1) + (rho >> 1) + (v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1);
+                f2 val = bb[r];
+                val.x *= gf[pc];
+                val.y *= gf[pc];
+                l2_wr64<8 * RS * rowreg>(wa, val);
+            });
+            l2_barrier();
+            l2_for<256 / RPI>([&](auto Kq) {
+                constexpr int k = Kq;
+                const int rr = RPI * k + tid / LPR, u = tid % LPR;
+                const int s9 = (rr >> 1) & 1;
+                const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (4 * s9))));
+                // o = i0 i1 i2 i3 i4 i5 i6 | i9 i8 i7 (bit 9 .. bit 0)
+                const int o = ((rr >> 2) & 1) | ((rr & 1) << 1) | (((rr >> 1) & 1) << 2) | (((rr >> 3) & 1) << 3) | (((rr >> 4) & 1) << 4) |
+                              (((rr >> 5) & 1) << 5) | ((rho >> 1) << 6) | ((rho & 1) << 7) | (((rr >> 6) & 1) << 8) | ((rr >> 7) << 9);
+                l2_st(l2_sbase(dimg + (BS ? G::BLK : G::BW) * blockIdx.x) + (unsigned)((BS ? G::BW : G::R) * o + 4 * u), val);
+            });
+            l2_barrier();
+        });
+        return;
     }
     // transposed store: round rho fixes (i2, i3) = register bits 0, 1 -> 128 of the 512 rows o(i); a row of the
     // workgroup is 8 W column pairs = 64 W bytes.  slot = 8 W row + (pair ^ 8 i8)
@@ -445,14 +504,14 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
     const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf)
 {
     typedef L2G<HB> G;
-    __shared__ double lds[WX_L2D_W * WX_L2_WIN];
+    __shared__ double lds[HB == 2 ? (256 * 18 > WX_L2D_W * WX_L2_WIN ? 256 * 18 : WX_L2D_W * WX_L2_WIN) : WX_L2D_W * WX_L2_WIN];
     const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
-    const int64_t img0 = min((int)blockIdx.y << HB, last_img);
+    const int64_t img0 = min((int)blockIdx.y << G::IB, last_img);
     const float *simg = src + img0 * G::IMG;
     float *dimg = dst + img0 * G::IMG;
-    const int j0 = 16 * WX_L2D_W * blockIdx.x + 16 * wave;
+    const int j0 = 2 * G::NPW * (WX_L2D_W * blockIdx.x + wave);
     f2 bb[64];
     {
         // loads as in the forward kernel, in packet order: lane = sub | h << 3 | o5 << 4 | o6 << 5, instruction (cp, o7, o8);
@@ -460,16 +519,61 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
         //   HB = 0:  m8 .. m0 = i0 i1 i2 i3 i4 i5 i8 i7 i6        (packet order of depth 6 over 512 rows)
         //   HB = 1:  m8 .. m0 = i8 i0 i1 i2 i3 i4 i7 i6 i5        (image select, packet order of depth 5 over 256 rows)
         const int sub = lane & 7, h = (lane >> 3) & 1, o5 = (lane >> 4) & 1, o6 = lane >> 5;
-        const unsigned lo = BL ? 64u * h + (unsigned)G::BLK * o6 + 32u * o5 + 4u * sub : (unsigned)G::R * h + 64u * o6 + 32u * o5 + 4u * sub;
+        constexpr int QS = 32 / G::NPW;
+        const unsigned lo = l2_lane_off<BL, HB>(h, o6, o5, sub);
         f4 r[32];
         l2_for<32>([&](auto Q) {
-            constexpr int cp = Q >> 2, o7 = Q & 1, o8 = (Q >> 1) & 1;
-            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL, HB>(j0 + 2 * cp, 256 * o8 + 128 * o7)) + lo);
+            constexpr int cp = Q / QS, sq = Q % QS;
+            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL, HB>(j0 + 2 * cp, 128 * sq)) + lo);
         });
         // into layout B (reg i[7:2], lane mu = i8 | cp << 1 | i0 << 4 | i1 << 5): a round (the component of the loaded
         // vectors) fixes two register bits, the lane reads its 16 other registers out of row mu: slot = 17 mu + w
         //   HB = 0: round = (i6, i7) = register bits 4, 5;  w = i2 | i3 << 1 | i4 << 2 | i5 << 3 = register bits 0 .. 3
         //   HB = 1: round = (i5, i6) = register bits 3, 4;  w = i2 | i3 << 1 | i4 << 2 | i7 << 3 = register bits 0, 1, 2, 5
+        // gains: the coefficient of a leaf whose path took k detail branches enters as coef * g^(2k - LD)
+        float gf[6];
+        {
+            float b = cf.g0;
+            b = (lane & 16) ? b * cf.g2 : b;
+            b = (lane & 32) ? b * cf.g2 : b;
+            gf[0] = b;
+#pragma unroll
+            for (int m = 1; m < 6; ++m) gf[m] = gf[m - 1] * cf.g2;
+        }
+        if constexpr (HB == 2) {
+            //   HB = 2:  m9 .. m0 = i0 i1 i2 i3 i4 i5 i6 i9 i8 i7 (packet order of depth 7 over 1024 rows); lane mu = i8 | i9 << 1 |
+            //   cp << 2 | i0 << 4 | i1 << 5.  The component (round) carries (i7, i8): i8 is a LANE bit of the target, so in a round
+            //   the 32 lanes with that i8 read 32 registers each (i7 fixed) out of row mu >> 1: slot = 33 (mu >> 1) + w,
+            //   w = i2 | i3 << 1 | i4 << 2 | i5 << 3 | i6 << 4
+            const unsigned wa = lds0 + 4u * (2u * (33u * (sub & 1) + 2u * o6 + 4u * o5 + 8u * (sub >> 2) + 16u * ((sub >> 1) & 1)) + h);
+            const unsigned ra = lds0 + 8u * 33u * (lane >> 1);
+            l2_for<4>([&](auto Rq) {
+                constexpr int rho = Rq;                   // rho bit 0 = i7, bit 1 = i8
+                l2_for<32>([&](auto Q) {
+                    constexpr int cp = Q / 8, i0 = (Q >> 2) & 1, i1 = (Q >> 1) & 1, i2 = Q & 1;
+                    l2_wr32<4 * 2 * (33 * (2 * cp + 8 * i0 + 16 * i1) + i2)>(wa, r[Q][rho]);
+                });
+                if ((lane & 1) == (rho >> 1)) {
+                    l2_for<2>([&](auto Hq) {
+                        constexpr int w0 = 16 * Hq;
+                        double t[16];
+                        l2_for<16>([&](auto V) {
+                            constexpr int w = w0 + V;
+                            t[V] = l2_rd64<8 * w>(ra);
+                        });
+                        l2_waitn(t);
+                        l2_for<16>([&](auto V) {
+                            constexpr int w = w0 + V;
+                            constexpr int pc = (w & 1) + ((w >> 1) & 1) + ((w >> 2) & 1) + ((w >> 3) & 1) + ((w >> 4) & 1);
+                            f2 e = __builtin_bit_cast(f2, t[V]);
+                            e.x *= gf[pc];
+                            e.y *= gf[pc];
+                            bb[w | ((rho & 1) << 5)] = e;
+                        });
+                    });
+                }
+            });
+        } else {
         unsigned wa;
         if constexpr (HB == 0) {
             const int i8 = sub & 1, i5 = (sub >> 1) & 1, i4 = sub >> 2;
@@ -479,16 +583,6 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             wa = lds0 + 4u * (34u * 32u * o6 + 2u * (o5 + 2u * i3 + 4u * i4 + 8u * i7) + h);
         }
         const unsigned ra = lds0 + 8u * 17u * lane;
-        // gains: the coefficient of a leaf whose path took k detail branches enters as coef * g^(2k - LD)
-        float gf[5];
-        {
-            float b = cf.g0;
-            b = (lane & 16) ? b * cf.g2 : b;
-            b = (lane & 32) ? b * cf.g2 : b;
-            gf[0] = b;
-#pragma unroll
-            for (int m = 1; m < 5; ++m) gf[m] = gf[m - 1] * cf.g2;
-        }
         l2_for<4>([&](auto Rq) {
             constexpr int rho = Rq;
             l2_for<32>([&](auto Q) {
@@ -522,9 +616,11 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
                 });
             });
         });
+        }
     }
-    constexpr int HA = HB ? 2 : 3, HBB = HB ? 0 : 1;
-    if constexpr (HB == 0) l2_level<3, HBB, NS, true>(bb, cf, lane);
+    constexpr int HA = G::HA, HBB = G::HBQ;
+    if constexpr (G::LD >= 7) l2_level<4, HBB, NS, true>(bb, cf, lane);
+    if constexpr (G::LD >= 6) l2_level<3, HBB, NS, true>(bb, cf, lane);
     l2_level<2, HBB, NS, true>(bb, cf, lane);
     l2_level<1, HBB, NS, true>(bb, cf, lane);
     l2_level<0, HBB, NS, true>(bb, cf, lane);
@@ -532,6 +628,31 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
     l2_t2i(bb, a, lds0, lane);
     l2_level<1, HA, NS, true>(a, cf, lane);
     l2_level<0, HA, NS, true>(a, cf, lane);
+    if constexpr (HB == 2) {
+        // 1024 rows, natural order: layout A (reg i[5:0], lane i[9:6] | cp << 4); round rho = i[5:4]; row of the round
+        // rr = i[9:6] | i[3:0] << 4 (the 16 lanes of a write land in 16 consecutive rows of 18 slots: no bank is hit twice)
+        constexpr int RS = 18, LPR = 2 * WX_L2D_W, RPI = 64 * WX_L2D_W / LPR;
+        const int i96 = lane & 15, cp = lane >> 4;
+        const unsigned wa = ldsb + 8u * ((unsigned)RS * (unsigned)i96 + (unsigned)(4 * wave + cp));
+        l2_barrier();
+        l2_for<4>([&](auto Rq) {
+            constexpr int rho = Rq;
+            l2_for<16>([&](auto Vq) {
+                constexpr int v = Vq;                     // i[3:0]
+                l2_wr64<8 * RS * 16 * v>(wa, a[v + 16 * rho]);
+            });
+            l2_barrier();
+            l2_for<256 / RPI>([&](auto Kq) {
+                constexpr int k = Kq;
+                const int rr = RPI * k + tid / LPR, u = tid % LPR;
+                const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)(2 * u)));
+                const int i = (rr >> 4) | (rho << 4) | ((rr & 15) << 6);
+                l2_st(l2_sbase(dimg + (BS ? G::BLK : G::BW) * blockIdx.x) + (unsigned)((BS ? G::BW : G::R) * i + 4 * u), val);
+            });
+            l2_barrier();
+        });
+        return;
+    }
     // transposed store, natural row order: layout A (reg i[5:0], lane i[8:6] | cp << 3); round rho = i[5:4];
     // row of the round rr = i[3:0] | i[8:6] << 4, slot = 8 W rr + (pair ^ i[8:6] << 1)
     constexpr int RS = 8 * WX_L2D_W, LPR = 4 * WX_L2D_W, RPI = 16;
@@ -562,30 +683,32 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
 bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz)
 {
     static const bool off = getenv("WX_LATTICE2D") && atoi(getenv("WX_LATTICE2D")) == 0;
-    const bool shape = (m == 512 && n == 512 && L == 6) || (m == 256 && n == 256 && L == 5);
+    const bool shape = (m == 512 && n == 512 && L == 6) || (m == 256 && n == 256 && L == 5) || (m == 1024 && n == 1024 && L == 7);
     return !off && esz == 4 && shape && filt.F >= 2 && filt.F / 2 <= WX_L2_MAXS;
 }
 
-// one transposing pass over `batch` images of side `m` (512: depth 6, 256: depth 5): 0 = not applicable, 1 = launched,
-// < 0 = error.  pass 0: natural image in, transposed image out (what one application of the kernel is); pass 1 / 2: the first
-// / second pass of a transform, with the intermediate image in the blocked layout above (the caller's scratch buffer, never
-// seen outside the library).
+// one transposing pass over `batch` images of side `m` (512: depth 6, 256: depth 5, 1024: depth 7): 0 = not applicable,
+// 1 = launched, < 0 = error.  pass 0: natural image in, transposed image out (what one application of the kernel is);
+// pass 1 / 2: the first / second pass of a transform, with the intermediate image in the blocked layout above (the caller's
+// scratch buffer, never seen outside the library).
 int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t m, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
 {
     static const bool blocked = WX_L2D_W == 4 && !(getenv("WX_L2D_BLOCKED") && atoi(getenv("WX_L2D_BLOCKED")) == 0);
-    const int hb = m == 512 ? 0 : (m == 256 ? 1 : -1);
+    const int hb = m == 512 ? 0 : (m == 256 ? 1 : (m == 1024 ? 2 : -1));
     if (hb < 0) return 0;
+    const int LD = hb == 2 ? 7 : 6 - hb;
     double p[WX_L2_MAXS], kap[WX_L2_MAXS], g0, g2;
-    if (!wx_lattice_coeffs(filt, 6 - hb, inverse, p, kap, &g0, &g2)) return 0;
+    if (!wx_lattice_coeffs(filt, LD, inverse, p, kap, &g0, &g2)) return 0;
     WxLat2 cf;
     for (int j = 0; j < WX_L2_MAXS; ++j) { cf.p[j] = (float)p[j]; cf.kap[j] = (float)kap[j]; }
     cf.g0 = (float)g0;
     cf.g2 = (float)g2;
-    const int64_t per = (int64_t)1 << hb, units = (batch + per - 1) / per;
+    const int64_t per = hb == 1 ? 2 : 1, units = (batch + per - 1) / per;
     if (batch < per || units > 65535 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return 0;
     if ((batch & (per - 1)) && src == dst) return 0;          // the last workgroup re-does images: out of place only
     const bool bl = blocked && pass == 2, bs = blocked && pass == 1;
-    const dim3 grid((unsigned)((m / 16) / WX_L2D_W), (unsigned)units), wg(64 * WX_L2D_W);
+    const int cols_wg = (hb == 2 ? 8 : 16) * WX_L2D_W;
+    const dim3 grid((unsigned)(m / cols_wg), (unsigned)units), wg(64 * WX_L2D_W);
     const int last_img = (int)(batch - per);
 #define WX_GO2K(K, NSS, HBB)                                                                                             \
     do {                                                                                                                 \
@@ -595,9 +718,11 @@ int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t m, int64_t batch
     } while (0)
 #define WX_GO2(NSS)                                                                                                      \
     case NSS:                                                                                                            \
-        if (inverse && hb) WX_GO2K(k_lat2d_icolT_f32, NSS, 1);                                                           \
+        if (inverse && hb == 2) WX_GO2K(k_lat2d_icolT_f32, NSS, 2);                                                      \
+        else if (inverse && hb == 1) WX_GO2K(k_lat2d_icolT_f32, NSS, 1);                                                 \
         else if (inverse) WX_GO2K(k_lat2d_icolT_f32, NSS, 0);                                                            \
-        else if (hb) WX_GO2K(k_lat2d_colT_f32, NSS, 1);                                                                  \
+        else if (hb == 2) WX_GO2K(k_lat2d_colT_f32, NSS, 2);                                                             \
+        else if (hb == 1) WX_GO2K(k_lat2d_colT_f32, NSS, 1);                                                             \
         else WX_GO2K(k_lat2d_colT_f32, NSS, 0);                                                                          \
         break;
     switch (filt.F / 2) {
