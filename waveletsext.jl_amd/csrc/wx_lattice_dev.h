@@ -1695,7 +1695,12 @@ __global__ __launch_bounds__(64) void k_lat_tree_prep(const uint8_t *__restrict_
 }
 
 // one packet level of layout C (register-index bit K, whole sequences in a lane) under the lane masks mk[s]; ga / gd scale
-// the a- and d-slots of the split nodes: after the shears (analysis) or before them (synthesis)
+// the a- and d-slots of the split nodes: after the shears (analysis) or before them (synthesis).
+// The plain level (lat_level) advances the odd channel by one pair after every rotation -- a renaming when the sequence sits in
+// one lane.  Under a mask a renaming would become moves, so here rotation j pairs u[m] with w[(m + j) mod M] instead (after j
+// advances that IS the partner, and the final - (NS - 1) puts every w back where it started): no renaming, and the whole level
+// of a sequence is ONE exec region.  The empty volatile asm keeps it a region: if-converted, the compiler computes the level for
+// every lane and selects per register (two v_cndmask per coefficient and level, a third of the level's instructions).
 template <int K, int NS, bool INV>
 __device__ __forceinline__ void lat_level_cm(double (&x)[64], const WxLat &cf, const unsigned long long *__restrict__ mk, double ga, double gd)
 {
@@ -1705,54 +1710,34 @@ __device__ __forceinline__ void lat_level_cm(double (&x)[64], const WxLat &cf, c
         constexpr int s = Sc;
         const unsigned long long msk = mk[s];               // wave-uniform; sequences nobody splits cost one scalar load
         if (!msk) return;
-        auto shift = [&](auto SHc) {                        // the odd channel advances SH pairs: a renaming, for every lane
-            constexpr int SHv = decltype(SHc)::value;
-            if constexpr (SHv != 0) {
-                double old[M];
+        if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
+            asm volatile("");
+            if constexpr (!INV) {
 #pragma unroll
-                for (int m = 0; m < M; ++m) old[m] = x[U(s, m) + S];
-                lat_for<M>([&](auto Mc) {
-                    constexpr int m = Mc;
-                    constexpr int g = ((m + SHv) % M + M) % M;
-                    x[U(s, m) + S] = old[g];
-                });
-            }
-        };
-        auto scale = [&]() {
-            if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
+                for (int j = 0; j < NS; ++j) {
+                    const double pj = cf.p[j], kj = cf.kap[j];
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const int u = U(s, m), w = U(s, (m + j) % M) + S;
+                        x[u] = fma(pj, x[w], x[u]);
+                        x[w] = fma(-kj, x[u], x[w]);
+                    }
+                }
 #pragma unroll
                 for (int m = 0; m < M; ++m) { x[U(s, m)] *= ga; x[U(s, m) + S] *= gd; }
-            }
-        };
-        if constexpr (!INV) {
+            } else {
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                const double pj = cf.p[j], kj = cf.kap[j];
-                if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
+                for (int m = 0; m < M; ++m) { x[U(s, m)] *= ga; x[U(s, m) + S] *= gd; }
 #pragma unroll
-                    for (int m = 0; m < M; ++m) {
-                        x[U(s, m)] = fma(pj, x[U(s, m) + S], x[U(s, m)]);
-                        x[U(s, m) + S] = fma(-kj, x[U(s, m)], x[U(s, m) + S]);
-                    }
-                }
-                if (j + 1 < NS) shift(std::integral_constant<int, 1>{});
-            }
-            shift(std::integral_constant<int, -(NS - 1)>{});
-            scale();
-        } else {
-            scale();
-            shift(std::integral_constant<int, NS - 1>{});
-#pragma unroll
-            for (int j = NS - 1; j >= 0; --j) {
-                const double pj = cf.p[j], kj = cf.kap[j];
-                if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
+                for (int j = NS - 1; j >= 0; --j) {
+                    const double pj = cf.p[j], kj = cf.kap[j];
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
-                        x[U(s, m) + S] = fma(kj, x[U(s, m)], x[U(s, m) + S]);
-                        x[U(s, m)] = fma(-pj, x[U(s, m) + S], x[U(s, m)]);
+                        const int u = U(s, m), w = U(s, (m + j) % M) + S;
+                        x[w] = fma(kj, x[u], x[w]);
+                        x[u] = fma(-pj, x[w], x[u]);
                     }
                 }
-                if (j > 0) shift(std::integral_constant<int, -1>{});
             }
         }
     });

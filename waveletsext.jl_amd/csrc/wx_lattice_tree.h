@@ -4,6 +4,9 @@
 // (dwt/dwt_all.jl:152-166, 210-225), iwpd (DWT.jl:340-351), LDB (LDB.jl:303, 409) and denoise (Denoising.jl:527).
 #include "wx_lattice_dev.h"
 #include "wx_host.h"
+#if WX_LAT_TREE_SH == 0
+#include "wx_lattice_tree_sc.h"
+#endif
 
 // included by wx_lattice_tree{0,1,2}{f,i}.hip with WX_LAT_TREE_SH = 0, 1, 2 (signal length 4096 >> SH), WX_LAT_TREE_INV = 0 / 1
 // (direction) and WX_LAT_TREE_FN = the launcher's name: one translation unit per length and direction so that the 60 kernels
@@ -31,20 +34,63 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
         for (int l = 0; l <= 12; ++l) { cw.gl[l] = (double)acc; acc *= inverse ? 1 / g : g; }
     }
     WxScratch scr(st);
-    WxLatTreeTab *tab = (WxLatTreeTab *)scr.alloc(sizeof(WxLatTreeTab));
-    if (!tab) return WX_EHIP;
-    // (experiment: WX_TREE_DBG_CUT = l leaves the emissions / absorptions deeper than l out -- wrong results, the time of the rest)
-    static const int dbg_cut = getenv("WX_TREE_DBG_CUT") ? atoi(getenv("WX_TREE_DBG_CUT")) : 99;
     // the threshold of denoise() rides on the leaves the inverse takes in (a pyramid's head is not a leaf array: that case
     // keeps the fused kernel)
     if (thr && thr->t && (!inverse || thr->head)) return 0;
     WxThreshArg ta{nullptr, 0, 0, 0, 1.0};
     if (thr && thr->t) ta = *thr;
+    (void)ta;
+#if WX_LAT_TREE_SH == 0
+    // 4096 samples: every level under the tree's masks, one permutation through LDS (wx_lattice_tree_sc.h); WX_TREE_SC=0 keeps
+    // the per-depth exchanges of the first form
+    static const bool sc_off = getenv("WX_TREE_SC") && atoi(getenv("WX_TREE_SC")) == 0;
+    if (!sc_off) {
+        WxLatTreeSc *tsc = (WxLatTreeSc *)scr.alloc(sizeof(WxLatTreeSc));
+        if (!tsc) return WX_EHIP;
+        hipLaunchKernelGGL(k_lat_treesc_prep, dim3(1), dim3(64), 0, st, dstatus, nstatus, L, tsc);
+        const WxLatTreeSc *ctsc = tsc;
+#if WX_LAT_TREE_INV
+#define WX_GOS(NSS)                                                                                                  \
+    case NSS:                                                                                                        \
+        hipLaunchKernelGGL((k_lat_iwpt_treesc_f64<NSS, 2, false>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L,  \
+                           (unsigned)in_stride, (unsigned)col_stride, cw, ctsc, ta);                                 \
+        break;
+#define WX_GOST(NSS)                                                                                                 \
+    case NSS:                                                                                                        \
+        hipLaunchKernelGGL((k_lat_iwpt_treesc_f64<NSS, 2, true>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L,   \
+                           (unsigned)in_stride, (unsigned)col_stride, cw, ctsc, ta);                                 \
+        break;
+        if (ta.t) {
+            switch (filt.F / 2) {
+                WX_GOST(1) WX_GOST(2) WX_GOST(4)
+            default: return 0;
+            }
+        } else
+#undef WX_GOST
+#else
+#define WX_GOS(NSS)                                                                                                  \
+    case NSS:                                                                                                        \
+        hipLaunchKernelGGL((k_lat_wpt_treesc_f64<NSS, 2>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L, cw, ctsc); \
+        break;
+#endif
+        switch (filt.F / 2) {
+            WX_GOS(1) WX_GOS(2) WX_GOS(3) WX_GOS(4) WX_GOS(5) WX_GOS(6) WX_GOS(7) WX_GOS(8) WX_GOS(9) WX_GOS(10)
+        default: return 0;
+        }
+#undef WX_GOS
+        const hipError_t es = hipGetLastError();
+        if (es != hipSuccess) return wx_set_hip_error(es, "lattice tree launch", __FILE__, __LINE__);
+        return 1;
+    }
+#endif
+    WxLatTreeTab *tab = (WxLatTreeTab *)scr.alloc(sizeof(WxLatTreeTab));
+    if (!tab) return WX_EHIP;
+    // (experiment: WX_TREE_DBG_CUT = l leaves the emissions / absorptions deeper than l out -- wrong results, the time of the rest)
+    static const int dbg_cut = getenv("WX_TREE_DBG_CUT") ? atoi(getenv("WX_TREE_DBG_CUT")) : 99;
     hipLaunchKernelGGL((k_lat_tree_prep<SH>), dim3(13), dim3(64), 0, st, dstatus, nstatus, L, dbg_cut, tab);
     const int64_t nwave = (batch + per - 1) / per;
     const int last_sig = (int)(batch - per);
     const WxLatTreeTab *ctab = tab;
-    (void)ta;
 #if WX_LAT_TREE_INV
 #define WX_GOT(NSS)                                                                                                  \
     case NSS:                                                                                                        \

@@ -1,0 +1,410 @@
+// wx_lattice_tree_sc.h -- tree-driven wpt / iwpt / iwpd for 4096-sample Float64 signals, second form: EVERY level runs under
+// the tree's masks and the packet order is produced by ONE permutation through LDS.
+//
+// Reference: Wavelets.jl's wpt / iwpt with a tree::BitVector as called by wptall / iwptall (dwt/dwt_all.jl:152-166, 210-225),
+// iwpd by tree (DWT.jl:340-351: getbasiscoef, Utils.jl:101-134, then iwpt), denoise(:wpt) (Denoising.jl:527).
+//
+// The first form (k_lat_wpt_tree_f64 in wx_lattice_dev.h) lets the leaves of depth l < 6 leave through their own exchange
+// right after level l: up to five dependent exchange chains per signal, which is what holds random trees at 0.42 / 0.36 of
+// the HBM peak.  Here a leaf simply stops changing: the in-place lattice keeps coefficient (path p of d levels, position k
+// in the node) at index i = k << d | p (bit t of p = branch of level t + 1), so
+//   * levels on bits 0, 1 (layout A: reg = i[5:0]): the node of a butterfly is a register-index pattern -> wave-uniform
+//     conditions (the root is always split);
+//   * levels on bits 2 .. 5 (layout B: lane = i[1:0] << 4 | i[11:8], reg = i[7:2]): node = (lane >> 4, low register bits) -> one
+//     64-bit lane mask per (level, register class), whole 16-lane rows on or off, so the halo rotations inside a row stay valid;
+//   * levels on bits 6 .. 11 (layout C: lane = i[5:0]): lat_level_cm as before; for sparse trees the levels on bits 6, 7 run in
+//     layout B instead, where 4 nodes share a register class instead of 64 and most classes are skipped outright;
+//   masks are scalar loads handed to the hardware as exec masks (__builtin_amdgcn_inverse_ballot_w64); every level
+//   normalises its own gains under the same mask, so a coefficient carries its final value whatever its depth;
+//   * the output position of coefficient i with leaf depth d is  o = bitreverse_d(i[d-1:0]) << (12 - d) | i >> d: a table of
+//     4096 16-bit LDS addresses per tree (k_lat_treesc_prep), 64 per lane.  The wavefront writes its registers to a
+//     packet-order image of the signal in LDS (two halves of 16 KiB, ds_write_b64 under "this half" masks, XOR-swizzled so that
+//     the 64 rows a register's lanes usually hit fall into different banks) and streams it out with 16-byte-per-lane stores of
+//     whole KiB: no store predicate, no per-depth exchange, no in-register unshuffle.
+// The inverse mirrors it: KiB loads -> LDS image -> 64 table-addressed ds_read_b64 per lane -> masked synthesis levels C, B, A.
+// For iwpd by tree a 16-byte piece is read from the column of its leaf's depth (4-bit table per piece).
+#pragma once
+
+struct WxLatTreeSc {
+    unsigned short perm[64 * 64];      // [r >> 3][lane][r & 7], r = register of layout C: swizzled byte address in the 32 KiB packet-order image
+    unsigned long long mA[2];          // level on bit 1: node (1, s) is split -> all lanes
+    unsigned long long mB[63];         // [(1 << K) - 1 + s]: level on bit 2 + K, register class s: lanes whose node is split
+    unsigned long long mC[63];         // [(1 << K) - 1 + s]: level on bit 6 + K
+    unsigned dep[4 * 64];              // [w][lane]: leaf depth of piece (h, k) -- elements 2048 h + 128 k + 2 lane, +1 -- nibble 16 h + k
+    unsigned anyA, anyB[6], anyC[6];
+    unsigned deepB;                    // the levels on bits 6, 7 run in layout B (sparse trees: most register classes are idle there)
+};
+
+namespace {
+
+// swizzled byte address of packet-order element o: rows of 64 elements (512 bytes); the 16-byte chunk index of a row is
+// XORed with a key of the row
+__host__ __device__ constexpr unsigned lat_sc_addr(unsigned o)
+{
+    const unsigned row = o >> 6, ch = (o >> 1) & 31u, key = (row & 31u) ^ (row >> 5);
+    return row * 512u + ((ch ^ key) << 4) + (o & 1u) * 8u;
+}
+
+__global__ __launch_bounds__(64) void k_lat_treesc_prep(const uint8_t *__restrict__ status, int64_t nstatus, int L,
+                                                          WxLatTreeSc *__restrict__ tab)
+{
+    const int lane = threadIdx.x;
+    // node (d, j) is split; the caller walks down from the root, so the ancestors are split already
+    auto sp = [&](int d, int j) {
+        const int64_t idx = ((int64_t)1 << d) + j;
+        return d < L && d < 12 && idx - 1 < nstatus && status[idx - 1] != 0;
+    };
+    for (int r = 0; r < 64; ++r) {
+        const int i = lane | (r << 6);
+        int d = 0, j = 0;
+        while (sp(d, j)) { j = (j << 1) | ((i >> d) & 1); ++d; }
+        const unsigned o = ((unsigned)j << (12 - d)) | ((unsigned)i >> d);
+        // the root is split, so the half of the image (o bit 11) is the first branch = i bit 0 = lane & 1: only the address
+        // inside the half is stored
+        tab->perm[((r >> 3) * 64 + lane) * 8 + (r & 7)] = (unsigned short)(lat_sc_addr(o & 4095u) & 0x3fffu);
+    }
+    auto node_mask = [&](int d, int j) { return __ballot(d < L && d < 12 && lat_tree_split(status, nstatus, d, j)); };
+    unsigned long long acc = 0;
+    for (int s = 0; s < 2; ++s) {
+        const unsigned long long m = node_mask(1, s);
+        if (lane == 0) tab->mA[s] = m;
+        acc |= m;
+    }
+    if (lane == 0) tab->anyA = acc != 0;
+    int nactB = 0;
+    for (int K = 0; K < 6; ++K) {
+        acc = 0;
+        const int d = 2 + K;
+        for (int s = 0; s < (1 << K); ++s) {
+            int j = 0;
+            for (int t = 0; t < d; ++t) {
+                const int bit = t < 2 ? (lane >> (4 + t)) & 1 : (s >> (t - 2)) & 1;
+                j |= bit << (d - 1 - t);
+            }
+            const unsigned long long m = node_mask(d, j);
+            if (lane == 0) tab->mB[(1 << K) - 1 + s] = m;
+            acc |= m;
+            if (K >= 4 && m) ++nactB;
+        }
+        if (lane == 0) tab->anyB[K] = acc != 0;
+    }
+    // bits 6, 7: in layout C a lane is a node of depth 6, so a register class is busy as soon as one of 64 nodes is split
+    // there; in layout B only 4 nodes share a class (at the price of halo moves): B when at most half of its 48 classes are busy
+    if (lane == 0) tab->deepB = nactB <= 24;
+    for (int K = 0; K < 6; ++K) {
+        acc = 0;
+        const int d = 6 + K;
+        for (int s = 0; s < (1 << K); ++s) {
+            int j = 0;
+            for (int t = 0; t < d; ++t) {
+                const int bit = t < 6 ? (lane >> t) & 1 : (s >> (t - 6)) & 1;
+                j |= bit << (d - 1 - t);
+            }
+            const unsigned long long m = node_mask(d, j);
+            if (lane == 0) tab->mC[(1 << K) - 1 + s] = m;
+            acc |= m;
+        }
+        if (lane == 0) tab->anyC[K] = acc != 0;
+    }
+    unsigned dep[4] = {0, 0, 0, 0};
+    for (int q = 0; q < 32; ++q) {
+        const int o = 128 * q + 2 * lane;                       // q = 16 h + k
+        int d = 0;
+        while (sp(d, o >> (12 - d))) ++d;
+        dep[q >> 3] |= (unsigned)d << (4 * (q & 7));
+    }
+    for (int w = 0; w < 4; ++w) tab->dep[64 * w + lane] = dep[w];
+}
+
+// one packet level on register-index bit K under the lane masks mk[s] (one per register class s = low K register bits),
+// H cyclic lane bits hold the rest of a sequence (lat_nbr).  The shears and the gains run under the mask; the renamings and
+// halo rotations between the shears are executed by every lane: over a level they compose to the identity, and a sequence's
+// lanes (a 16-lane row in layout B, the wavefront in layout A) are all in or all out.
+template <int K, int H, int NS, bool INV>
+__device__ __forceinline__ void lat_level_hm(double (&x)[64], const WxLat &cf, const unsigned long long *__restrict__ mk, double ga, double gd)
+{
+    constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
+    auto U = [](int s, int m) { return s + ((2 * m) << K); };
+    lat_for<NSEQ>([&](auto Sc) {
+        constexpr int s = Sc;
+        const unsigned long long msk = mk[s];
+        if (!msk) return;
+        auto shift = [&](auto SHc) {
+            constexpr int SHv = decltype(SHc)::value;
+            if constexpr (SHv != 0) {
+                double old[M];
+#pragma unroll
+                for (int m = 0; m < M; ++m) old[m] = x[U(s, m) + S];
+                lat_for<M>([&](auto Mc) {
+                    constexpr int m = Mc;
+                    constexpr int g = m + SHv;
+                    constexpr int d = (g >= 0) ? g / M : -((-g + M - 1) / M);
+                    constexpr int src = g - d * M;
+                    x[U(s, m) + S] = lat_nbr<H, d>(old[src]);
+                });
+            }
+        };
+        auto scale = [&]() {
+            if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
+                asm volatile("");                           // a real exec region (see lat_level_cm)
+#pragma unroll
+                for (int m = 0; m < M; ++m) { x[U(s, m)] *= ga; x[U(s, m) + S] *= gd; }
+            }
+        };
+        constexpr bool one_shot = (H != 6) || (NS - 1 <= M);
+        if constexpr (!INV) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const double pj = cf.p[j], kj = cf.kap[j];
+                if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
+                    asm volatile("");
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        x[U(s, m)] = fma(pj, x[U(s, m) + S], x[U(s, m)]);
+                        x[U(s, m) + S] = fma(-kj, x[U(s, m)], x[U(s, m) + S]);
+                    }
+                }
+                if (j + 1 < NS) shift(std::integral_constant<int, 1>{});
+            }
+            if constexpr (one_shot) shift(std::integral_constant<int, -(NS - 1)>{});
+            else {
+#pragma unroll
+                for (int j = 0; j + 1 < NS; ++j) shift(std::integral_constant<int, -1>{});
+            }
+            scale();
+        } else {
+            scale();
+            if constexpr (one_shot) shift(std::integral_constant<int, NS - 1>{});
+            else {
+#pragma unroll
+                for (int j = 0; j + 1 < NS; ++j) shift(std::integral_constant<int, 1>{});
+            }
+#pragma unroll
+            for (int j = NS - 1; j >= 0; --j) {
+                const double pj = cf.p[j], kj = cf.kap[j];
+                if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
+                    asm volatile("");
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        x[U(s, m) + S] = fma(kj, x[U(s, m)], x[U(s, m) + S]);
+                        x[U(s, m)] = fma(-pj, x[U(s, m) + S], x[U(s, m)]);
+                    }
+                }
+                if (j > 0) shift(std::integral_constant<int, -1>{});
+            }
+        }
+    });
+}
+
+// table-addressed reads of the inverse: into a fresh register / into a register whose other lanes keep their value
+__device__ __forceinline__ void lat_sc_rd(double &dst, unsigned ad)
+{
+    asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(ad) : "memory");
+}
+__device__ __forceinline__ void lat_sc_rd_keep(double &dst, unsigned ad)
+{
+    asm volatile("ds_read_b64 %0, %1" : "+v"(dst) : "v"(ad) : "memory");
+}
+typedef lat_d2 __attribute__((address_space(3))) *lat_l2p;
+__device__ __forceinline__ lat_l2p lat_sc_lp(unsigned a) { return (lat_l2p)(uintptr_t)a; }
+
+// byte address of the 16 bytes lane `lane` moves in instruction k of half h (elements 2048 h + 128 k + 2 lane, +1)
+template <int H, int Kk> __device__ __forceinline__ unsigned lat_sc_row(unsigned lds0, int lane)
+{
+    const unsigned hi = (unsigned)lane >> 5, ch = ((unsigned)lane & 31u) ^ hi ^ (unsigned)H;
+    return lds0 + 512u * hi + 1024u * Kk + ((ch ^ (2u * Kk)) << 4);
+}
+
+__device__ __forceinline__ void lat_sc_ptab(unsigned (&pw)[32], const WxLatTreeSc *__restrict__ tab, int lane)
+{
+    const uint4 *pp = reinterpret_cast<const uint4 *>(tab->perm) + lane;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint4 t = pp[64 * q];
+        pw[4 * q] = t.x; pw[4 * q + 1] = t.y; pw[4 * q + 2] = t.z; pw[4 * q + 3] = t.w;
+    }
+}
+
+template <int NS, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_treesc_f64(
+    const double *__restrict__ x, double *__restrict__ y, int L, WxLatW cw, const WxLatTreeSc *__restrict__ tab)
+{
+    __shared__ __attribute__((aligned(16))) double lds[2048];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const double *xs = x + (int64_t)blockIdx.x * 4096;
+    double *ys = y + (int64_t)blockIdx.x * 4096;
+    const WxLat &cf = cw.c;
+    // forward: gl[1] = g, g2 = g^-2: after the shears the a-slot holds a / g, the d-slot d g
+    const double g = cw.gl[1], ginv = cw.c.g2 * cw.gl[1];
+    double c[64];
+    {
+        double a[64], bb[64];
+        lat_absorb<0, 0>(a, lds0, xs, lane, cw);
+        lat_level<0, 6, NS, false>(a, cf);                      // the root is split (L >= 1)
+#pragma unroll
+        for (int r = 0; r < 64; ++r) a[r] *= (r & 1) ? ginv : g;
+        if (tab->anyA) lat_level_hm<1, 6, NS, false>(a, cf, tab->mA, g, ginv);
+        lat_t2(a, bb, lds0, lane);
+        if (tab->anyB[0]) lat_level_hm<0, 4, NS, false>(bb, cf, tab->mB + 0, g, ginv);
+        if (tab->anyB[1]) lat_level_hm<1, 4, NS, false>(bb, cf, tab->mB + 1, g, ginv);
+        if (tab->anyB[2]) lat_level_hm<2, 4, NS, false>(bb, cf, tab->mB + 3, g, ginv);
+        if (tab->anyB[3]) lat_level_hm<3, 4, NS, false>(bb, cf, tab->mB + 7, g, ginv);
+        if (tab->deepB) {
+            if (tab->anyB[4]) lat_level_hm<4, 4, NS, false>(bb, cf, tab->mB + 15, g, ginv);
+            if (tab->anyB[5]) lat_level_hm<5, 4, NS, false>(bb, cf, tab->mB + 31, g, ginv);
+        }
+        lat_t3(bb, c, lds0, lane);
+    }
+    unsigned pw[32];
+    lat_sc_ptab(pw, tab, lane);                                 // arrives behind the lane-local levels
+    const unsigned long long *mk = tab->mC;
+    if (!tab->deepB) {
+        if (tab->anyC[0]) lat_level_cm<0, NS, false>(c, cf, mk + 0, g, ginv);
+        if (tab->anyC[1]) lat_level_cm<1, NS, false>(c, cf, mk + 1, g, ginv);
+    }
+    if (tab->anyC[2]) lat_level_cm<2, NS, false>(c, cf, mk + 3, g, ginv);
+    if (tab->anyC[3]) lat_level_cm<3, NS, false>(c, cf, mk + 7, g, ginv);
+    if (tab->anyC[4]) lat_level_cm<4, NS, false>(c, cf, mk + 15, g, ginv);
+    if (tab->anyC[5]) lat_level_cm<5, NS, false>(c, cf, mk + 31, g, ginv);
+    lat_sync();
+    lat_for<2>([&](auto Hc) {
+        constexpr int h = Hc;
+        // half h of the packet-order image = the coefficients whose first branch is h = the lanes with lane & 1 == h
+        if ((lane & 1) == h) {
+            lat_for<64>([&](auto Rc) {
+                constexpr int r = Rc;
+                const unsigned p = (r & 1) ? (pw[r >> 1] >> 16) : (pw[r >> 1] & 0xffffu);
+                lds_wr<0>(lds0 + p, c[r]);
+            });
+        }
+        lat_sync();
+        lat_for<2>([&](auto Gc) {
+            constexpr int k0 = 8 * Gc;
+            lat_d2 v[8];
+            lat_for<8>([&](auto Kc) {
+                constexpr int k = k0 + Kc;
+                v[Kc] = *lat_sc_lp(lat_sc_row<h, k>(lds0, lane));
+            });
+            lat_for<8>([&](auto Kc) {
+                constexpr int k = k0 + Kc;
+                lat_st2(lat_sbase(ys + 2048 * h + 128 * k) + 2 * lane, v[Kc]);
+            });
+        });
+        lat_sync();
+    });
+}
+
+template <int NS, int WPE, bool THR>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_treesc_f64(
+    const double *__restrict__ xw, double *__restrict__ y, int L, unsigned in_stride, unsigned col_stride, WxLatW cw,
+    const WxLatTreeSc *__restrict__ tab, WxThreshArg thr)
+{
+    __shared__ __attribute__((aligned(16))) double lds[2048];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const double *xs = xw + (int64_t)blockIdx.x * in_stride;
+    double *ys = y + (int64_t)blockIdx.x * 4096;
+    const WxLat &cf = cw.c;
+    unsigned dep[4] = {0, 0, 0, 0};
+    if (col_stride) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) dep[w] = tab->dep[64 * w + lane];
+    }
+    lat_d2 v[16];
+    // pieces k0 .. k0 + NK - 1 of half h
+    auto fetch = [&](auto Hc, auto K0c, auto NKc) {
+        constexpr int h = Hc, k0 = K0c, nk = NKc;
+        lat_for<nk>([&](auto Kc) {
+            constexpr int k = k0 + Kc, q = 16 * h + k;
+            const unsigned co = ((dep[q >> 3] >> (4 * (q & 7))) & 15u) * col_stride;      // col_stride = 0: dense leaves
+            v[k] = lat_ld2(lat_sbase(xs + 2048 * h + 128 * k) + (2 * lane + co));
+        });
+    };
+    auto put = [&](auto Hc, auto K0c, auto NKc) {
+        constexpr int h = Hc, k0 = K0c, nk = NKc;
+        if constexpr (THR) {
+            // threshold of denoise() (Denoising.jl:527 threshold!(x, th, t) before iwpt): positions [lo, n) of the signal
+            const double tt = reinterpret_cast<const double *>(thr.t)[thr.per_signal ? blockIdx.x : 0] * thr.scale;
+            lat_for<nk>([&](auto Kc) {
+                constexpr int k = k0 + Kc;
+                const int pos = 2048 * h + 128 * k + 2 * lane;
+                if (pos >= thr.lo) v[k].x = wx_thresh<double>(v[k].x, tt, thr.kind);
+                if (pos + 1 >= thr.lo) v[k].y = wx_thresh<double>(v[k].y, tt, thr.kind);
+            });
+        }
+        lat_for<nk>([&](auto Kc) {
+            constexpr int k = k0 + Kc;
+            *lat_sc_lp(lat_sc_row<h, k>(lds0, lane)) = v[k];
+        });
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 8> I8;
+    typedef std::integral_constant<int, 16> I16;
+    fetch(I0{}, I0{}, I16{});
+    unsigned pw[32];
+    lat_sc_ptab(pw, tab, lane);
+    double c[64];
+    // half 0 (the even lanes' coefficients): every lane reads, the odd lanes' values are replaced below; the first eight pieces of
+    // half 1 travel meanwhile -- all sixteen would not fit the 256 registers next to c[] and the table
+    put(I0{}, I0{}, I16{});
+    lat_sync();
+    fetch(I1{}, I0{}, I8{});
+    lat_for<64>([&](auto Rc) {
+        constexpr int r = Rc;
+        const unsigned p = (r & 1) ? (pw[r >> 1] >> 16) : (pw[r >> 1] & 0xffffu);
+        lat_sc_rd(c[r], lds0 + p);
+    });
+    lat_wait16<0>(c);
+    lat_wait16<16>(c);
+    lat_wait16<32>(c);
+    lat_wait16<48>(c);
+    lat_sync();
+    put(I1{}, I0{}, I8{});
+    fetch(I1{}, I8{}, I8{});
+    put(I1{}, I8{}, I8{});
+    lat_sync();
+    if (lane & 1) {
+        lat_for<64>([&](auto Rc) {
+            constexpr int r = Rc;
+            const unsigned p = (r & 1) ? (pw[r >> 1] >> 16) : (pw[r >> 1] & 0xffffu);
+            lat_sc_rd_keep(c[r], lds0 + p);
+        });
+    }
+    lat_wait16<0>(c);
+    lat_wait16<16>(c);
+    lat_wait16<32>(c);
+    lat_wait16<48>(c);
+    lat_sync();
+    // synthesis: gl[1] = 1 / g, g2 = g^2 -- the a-slot of a split node enters as a / g, the d-slot as d g
+    const double ga = cw.gl[1], gd = cw.c.g2 * cw.gl[1];
+    const unsigned long long *mk = tab->mC;
+    if (tab->anyC[5]) lat_level_cm<5, NS, true>(c, cf, mk + 31, ga, gd);
+    if (tab->anyC[4]) lat_level_cm<4, NS, true>(c, cf, mk + 15, ga, gd);
+    if (tab->anyC[3]) lat_level_cm<3, NS, true>(c, cf, mk + 7, ga, gd);
+    if (tab->anyC[2]) lat_level_cm<2, NS, true>(c, cf, mk + 3, ga, gd);
+    if (!tab->deepB) {
+        if (tab->anyC[1]) lat_level_cm<1, NS, true>(c, cf, mk + 1, ga, gd);
+        if (tab->anyC[0]) lat_level_cm<0, NS, true>(c, cf, mk + 0, ga, gd);
+    }
+    double bb[64];
+    lat_t3i(c, bb, lds0, lane);
+    if (tab->deepB) {
+        if (tab->anyB[5]) lat_level_hm<5, 4, NS, true>(bb, cf, tab->mB + 31, ga, gd);
+        if (tab->anyB[4]) lat_level_hm<4, 4, NS, true>(bb, cf, tab->mB + 15, ga, gd);
+    }
+    if (tab->anyB[3]) lat_level_hm<3, 4, NS, true>(bb, cf, tab->mB + 7, ga, gd);
+    if (tab->anyB[2]) lat_level_hm<2, 4, NS, true>(bb, cf, tab->mB + 3, ga, gd);
+    if (tab->anyB[1]) lat_level_hm<1, 4, NS, true>(bb, cf, tab->mB + 1, ga, gd);
+    if (tab->anyB[0]) lat_level_hm<0, 4, NS, true>(bb, cf, tab->mB + 0, ga, gd);
+    double a[64];
+    lat_t2i(bb, a, lds0, lane);
+    if (tab->anyA) lat_level_hm<1, 6, NS, true>(a, cf, tab->mA, ga, gd);
+#pragma unroll
+    for (int r = 0; r < 64; ++r) a[r] *= (r & 1) ? gd : ga;
+    lat_level<0, 6, NS, true>(a, cf);
+    lat_emit<0, 0>(a, lds0, ys, lane, cw);
+}
+
+}  // namespace
