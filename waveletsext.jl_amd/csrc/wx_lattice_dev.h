@@ -1711,7 +1711,9 @@ __device__ __forceinline__ void lat_level_cm(double (&x)[64], const WxLat &cf, c
         const unsigned long long msk = mk[s];               // wave-uniform; sequences nobody splits cost one scalar load
         if (!msk) return;
         if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
-            asm volatile("");
+            // K >= 4 (sequences of 2 and 1 pairs): left to the compiler, which computes every lane and selects -- the rotations
+            // of a sequence are one dependent chain, and only the select form lets it interleave the 16 / 32 sequences
+            if constexpr (K < 4) asm volatile("");
             if constexpr (!INV) {
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
