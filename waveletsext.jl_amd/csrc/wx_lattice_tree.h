@@ -34,11 +34,12 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
         for (int l = 0; l <= 12; ++l) { cw.gl[l] = (double)acc; acc *= inverse ? 1 / g : g; }
     }
     WxScratch scr(st);
-    // the threshold of denoise() rides on the leaves the inverse takes in (a pyramid's head is not a leaf array: that case
-    // keeps the fused kernel)
-    if (thr && thr->t && (!inverse || thr->head)) return 0;
+    // the threshold of denoise() rides on the leaves the inverse takes in; a pyramid's head (idwt: the 64 samples rebuilt by
+    // wx_dwttail.hip stand in for positions 0 .. 63) is taken by the 4096-sample kernels of wx_lattice_tree_sc.h only
+    if (thr && (thr->t || thr->head) && !inverse) return 0;
     WxThreshArg ta{nullptr, 0, 0, 0, 1.0};
     if (thr && thr->t) ta = *thr;
+    if (thr) ta.head = thr->head;
     (void)ta;
 #if WX_LAT_TREE_SH == 0
     // 4096 samples: every level under the tree's masks, one permutation through LDS (wx_lattice_tree_sc.h); WX_TREE_SC=0 keeps
@@ -83,6 +84,7 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
         return 1;
     }
 #endif
+    if (ta.head) return 0;
     WxLatTreeTab *tab = (WxLatTreeTab *)scr.alloc(sizeof(WxLatTreeTab));
     if (!tab) return WX_EHIP;
     // (experiment: WX_TREE_DBG_CUT = l leaves the emissions / absorptions deeper than l out -- wrong results, the time of the rest)

@@ -318,7 +318,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         lat_for<nk>([&](auto Kc) {
             constexpr int k = k0 + Kc, q = 16 * h + k;
             const unsigned co = ((dep[q >> 3] >> (4 * (q & 7))) & 15u) * col_stride;      // col_stride = 0: dense leaves
-            v[k] = lat_ld2(lat_sbase(xs + 2048 * h + 128 * k) + (2 * lane + co));
+            if constexpr (q == 0) {
+                // idwt of a pyramid: positions 0 .. 63 are the samples the lane-local tail (wx_dwttail.hip) has rebuilt
+                const double *hp = reinterpret_cast<const double *>(thr.head);
+                if (hp && lane < 32) v[k] = lat_ld2((lat_gc)(hp + 64 * (int64_t)blockIdx.x + 2 * lane));
+                else v[k] = lat_ld2(lat_sbase(xs) + (2 * lane + co));
+            } else
+                v[k] = lat_ld2(lat_sbase(xs + 2048 * h + 128 * k) + (2 * lane + co));
         });
     };
     auto put = [&](auto Hc, auto K0c, auto NKc) {
@@ -329,6 +335,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             lat_for<nk>([&](auto Kc) {
                 constexpr int k = k0 + Kc;
                 const int pos = 2048 * h + 128 * k + 2 * lane;
+                if (h == 0 && k == 0 && thr.head && lane < 32) return;      // the tail has thresholded what it read
                 if (pos >= thr.lo) v[k].x = wx_thresh<double>(v[k].x, tt, thr.kind);
                 if (pos + 1 >= thr.lo) v[k].y = wx_thresh<double>(v[k].y, tt, thr.kind);
             });
