@@ -158,3 +158,33 @@ def test_tree_denoise_threshold_rides_on_the_absorbed_leaves(wx, oracle, n, wnam
                 assert relerr(got, exp) <= 1e-9, (n, wname, thname, smooth, int(tree.sum()))
                 got_h = wx.denoiseall(xw, "wpt", wt, tree=tree, dnt=dnt, smooth=smooth)
                 assert relerr(got_h, exp) <= 1e-9, (n, wname, thname, smooth)
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db8", "coif6"])
+def test_pyramid_idwt_4096_takes_the_rebuilt_head(wx, oracle, wname):
+    """idwt / denoise(:dwt) of 4096-sample signals: the levels below 64 samples run lane-locally (wx_dwttail.hip) and the
+    tree-driven lattice inverse reads the 64 rebuilt samples in place of positions 0 .. 63 (wx_lattice_tree_sc.h); every
+    pyramid depth that has a tail (L = 7 .. 12), batch sizes around a wavefront's worth of tail signals"""
+    rng = np.random.default_rng(77)
+    wt = _wt(wx, wname)
+    n = 4096
+    for L, B in ((12, 5), (9, 64), (7, 67)):
+        x = np.asfortranarray(rng.standard_normal((n, B)))
+        tree = np.asarray(wx.maketree(n, L, "dwt"))
+        xw = oracle.wptall(x, wt.qmf, tree)
+        assert relerr(wx.wptall(x, wt, tree), xw) <= TOL, (wname, L)
+        assert relerr(wx.iwptall(xw, wt, tree), x) <= TOL, (wname, L)
+        assert relerr(wx.to_numpy(wx.iwptall(wx.to_device(xw), wt, tree)), x) <= TOL, (wname, L)
+    # denoise(:dwt): the threshold on the deep coefficients is applied by the tail, on the others by the lattice inverse's loads
+    B = 6
+    t = np.linspace(0, 1, n)
+    x = np.asfortranarray(np.stack([np.sin(2 * np.pi * (2 + b) * t) for b in range(B)], axis=1) + 0.3 * rng.standard_normal((n, B)))
+    for L in (12, 8):
+        tree = np.asarray(wx.maketree(n, L, "dwt"))
+        xw = oracle.wptall(x, wt.qmf, tree)
+        for thname, TH in (("hard", wx.HardTH), ("soft", wx.SoftTH)):
+            dnt = wx.VisuShrink(n, TH())
+            exp = np.stack([oracle.denoise(np.asfortranarray(xw[:, i]), "dwt", wt.qmf, L=L, th=thname, t=dnt.t, smooth="regular")
+                            for i in range(B)], axis=1)
+            got = wx.denoiseall(xw, "dwt", wt, L=L, dnt=dnt, smooth="regular")
+            assert relerr(got, exp) <= 1e-9, (wname, L, thname)
