@@ -1267,7 +1267,7 @@ int wx_dev_iwpt1d_thresh(const T *xw, T *xh, int64_t n, int L, int64_t batch, co
     if (batch == 0 || n == 0) return WX_OK;
     if constexpr (sizeof(T) == 8) {
         // leaves of a tree (denoiseall(:wpt), Denoising.jl:527): the threshold rides on the loads of the tree-driven lattice inverse
-        if (status && (!thr.head || n == 4096) && !wx_skip_register_kernels()) {
+        if (status && !wx_skip_register_kernels()) {
             const int r = wx_lattice_tree_f64(true, (const double *)xw, (double *)xh, n, L, batch, n, 0, filt, status, nstatus, st, &thr);
             if (r) return r < 0 ? r : WX_OK;
         }

@@ -4,9 +4,7 @@
 // (dwt/dwt_all.jl:152-166, 210-225), iwpd (DWT.jl:340-351), LDB (LDB.jl:303, 409) and denoise (Denoising.jl:527).
 #include "wx_lattice_dev.h"
 #include "wx_host.h"
-#if WX_LAT_TREE_SH == 0
 #include "wx_lattice_tree_sc.h"
-#endif
 
 // included by wx_lattice_tree{0,1,2}{f,i}.hip with WX_LAT_TREE_SH = 0, 1, 2 (signal length 4096 >> SH), WX_LAT_TREE_INV = 0 / 1
 // (direction) and WX_LAT_TREE_FN = the launcher's name: one translation unit per length and direction so that the 60 kernels
@@ -35,30 +33,33 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
     }
     WxScratch scr(st);
     // the threshold of denoise() rides on the leaves the inverse takes in; a pyramid's head (idwt: the 64 samples rebuilt by
-    // wx_dwttail.hip stand in for positions 0 .. 63) is taken by the 4096-sample kernels of wx_lattice_tree_sc.h only
+    // wx_dwttail.hip stand in for positions 0 .. 63 of every signal) is taken by the kernels of wx_lattice_tree_sc.h only
     if (thr && (thr->t || thr->head) && !inverse) return 0;
     WxThreshArg ta{nullptr, 0, 0, 0, 1.0};
     if (thr && thr->t) ta = *thr;
     if (thr) ta.head = thr->head;
     (void)ta;
-#if WX_LAT_TREE_SH == 0
-    // 4096 samples: every level under the tree's masks, one permutation through LDS (wx_lattice_tree_sc.h); WX_TREE_SC=0 keeps
-    // the per-depth exchanges of the first form
-    static const bool sc_off = getenv("WX_TREE_SC") && atoi(getenv("WX_TREE_SC")) == 0;
-    if (!sc_off) {
+    // trees deeper than 4 levels: every level under the tree's masks, one permutation through LDS (wx_lattice_tree_sc.h).
+    // Shallow trees keep the first form -- its leaves leave right after their level and the kernel returns after the last one
+    // (depth-4 pyramid, 65536 x 4096 db4: 0.80 / 0.84 ms against 0.81-0.85 / 0.85-0.89; 2048 samples 0.86 / 0.80 against
+    // 0.84 / 0.91).  WX_TREE_SC=0 / 1 forces one of the two.
+    static const int sc_env = getenv("WX_TREE_SC") ? atoi(getenv("WX_TREE_SC")) : -1;
+    if (sc_env != 0 && (L > 4 || sc_env == 1 || ta.head)) {
         WxLatTreeSc *tsc = (WxLatTreeSc *)scr.alloc(sizeof(WxLatTreeSc));
         if (!tsc) return WX_EHIP;
-        hipLaunchKernelGGL(k_lat_treesc_prep, dim3(1), dim3(64), 0, st, dstatus, nstatus, L, tsc);
+        hipLaunchKernelGGL((k_lat_treesc_prep<SH>), dim3(1), dim3(64), 0, st, dstatus, nstatus, L, tsc);
         const WxLatTreeSc *ctsc = tsc;
+        const unsigned nw = (unsigned)((batch + per - 1) / per);
+        const int lsig = (int)(batch - per);
 #if WX_LAT_TREE_INV
 #define WX_GOS(NSS)                                                                                                  \
     case NSS:                                                                                                        \
-        hipLaunchKernelGGL((k_lat_iwpt_treesc_f64<NSS, 2, false>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L,  \
+        hipLaunchKernelGGL((k_lat_iwpt_treesc_f64<NSS, 2, SH, false>), dim3(nw), dim3(64), 0, st, x, y, L, lsig,      \
                            (unsigned)in_stride, (unsigned)col_stride, cw, ctsc, ta);                                 \
         break;
 #define WX_GOST(NSS)                                                                                                 \
     case NSS:                                                                                                        \
-        hipLaunchKernelGGL((k_lat_iwpt_treesc_f64<NSS, 2, true>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L,   \
+        hipLaunchKernelGGL((k_lat_iwpt_treesc_f64<NSS, 2, SH, true>), dim3(nw), dim3(64), 0, st, x, y, L, lsig,       \
                            (unsigned)in_stride, (unsigned)col_stride, cw, ctsc, ta);                                 \
         break;
         if (ta.t) {
@@ -71,7 +72,7 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
 #else
 #define WX_GOS(NSS)                                                                                                  \
     case NSS:                                                                                                        \
-        hipLaunchKernelGGL((k_lat_wpt_treesc_f64<NSS, 2>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L, cw, ctsc); \
+        hipLaunchKernelGGL((k_lat_wpt_treesc_f64<NSS, 2, SH>), dim3(nw), dim3(64), 0, st, x, y, L, lsig, cw, ctsc);   \
         break;
 #endif
         switch (filt.F / 2) {
@@ -83,7 +84,6 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
         if (es != hipSuccess) return wx_set_hip_error(es, "lattice tree launch", __FILE__, __LINE__);
         return 1;
     }
-#endif
     if (ta.head) return 0;
     WxLatTreeTab *tab = (WxLatTreeTab *)scr.alloc(sizeof(WxLatTreeTab));
     if (!tab) return WX_EHIP;

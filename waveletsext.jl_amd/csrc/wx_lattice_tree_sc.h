@@ -23,6 +23,8 @@
 //     whole KiB: no store predicate, no per-depth exchange, no in-register unshuffle.
 // The inverse mirrors it: KiB loads -> LDS image -> 64 table-addressed ds_read_b64 per lane -> masked synthesis levels C, B, A.
 // For iwpd by tree a 16-byte piece is read from the column of its leaf's depth (4-bit table per piece).
+// SH = 1, 2 (2048- and 1024-sample signals): 2^SH signals share a wavefront, index bits [SH-1:0] are the signal number, the
+// levels act on bits SH .. 11 (the first of them is the root's: unmasked), and the image in LDS is the signals one after the other.
 #pragma once
 
 struct WxLatTreeSc {
@@ -45,28 +47,36 @@ __host__ __device__ constexpr unsigned lat_sc_addr(unsigned o)
     return row * 512u + ((ch ^ key) << 4) + (o & 1u) * 8u;
 }
 
+template <int SH>
 __global__ __launch_bounds__(64) void k_lat_treesc_prep(const uint8_t *__restrict__ status, int64_t nstatus, int L,
                                                           WxLatTreeSc *__restrict__ tab)
 {
     const int lane = threadIdx.x;
+    constexpr int SB = 12 - SH;                                // index bits of one signal
     // node (d, j) is split; the caller walks down from the root, so the ancestors are split already
     auto sp = [&](int d, int j) {
         const int64_t idx = ((int64_t)1 << d) + j;
-        return d < L && d < 12 && idx - 1 < nstatus && status[idx - 1] != 0;
+        return d < L && d < SB && idx - 1 < nstatus && status[idx - 1] != 0;
     };
     for (int r = 0; r < 64; ++r) {
-        const int i = lane | (r << 6);
+        const int i = lane | (r << 6), sig = i & ((1 << SH) - 1), p = i >> SH;
         int d = 0, j = 0;
-        while (sp(d, j)) { j = (j << 1) | ((i >> d) & 1); ++d; }
-        const unsigned o = ((unsigned)j << (12 - d)) | ((unsigned)i >> d);
-        // the root is split, so the half of the image (o bit 11) is the first branch = i bit 0 = lane & 1: only the address
-        // inside the half is stored
+        while (sp(d, j)) { j = (j << 1) | ((p >> d) & 1); ++d; }
+        const unsigned o = ((unsigned)sig << SB) | ((unsigned)j << (SB - d)) | ((unsigned)p >> d);
+        // the half of the image (o bit 11) is the first branch (SH = 0: the root is split) or the signal number's top bit:
+        // index bit 0 (SH < 2) or 1 (SH = 2), a lane bit -- only the address inside the half is stored
         tab->perm[((r >> 3) * 64 + lane) * 8 + (r & 7)] = (unsigned short)(lat_sc_addr(o & 4095u) & 0x3fffu);
     }
-    auto node_mask = [&](int d, int j) { return __ballot(d < L && d < 12 && lat_tree_split(status, nstatus, d, j)); };
+    // lanes whose node -- the one the level on index bit b would split -- is split; the path of that node is index bits SH .. b - 1
+    auto level_mask = [&](int b, auto bit_of) {
+        const int d = b - SH;
+        int j = 0;
+        for (int t = 0; t < d; ++t) j |= bit_of(SH + t) << (d - 1 - t);
+        return __ballot(d >= 0 && d < L && d < SB && lat_tree_split(status, nstatus, d, j));
+    };
     unsigned long long acc = 0;
     for (int s = 0; s < 2; ++s) {
-        const unsigned long long m = node_mask(1, s);
+        const unsigned long long m = level_mask(1, [&](int) { return s; });                     // layout A: index bit 0 = register bit 0
         if (lane == 0) tab->mA[s] = m;
         acc |= m;
     }
@@ -74,14 +84,9 @@ __global__ __launch_bounds__(64) void k_lat_treesc_prep(const uint8_t *__restric
     int nactB = 0;
     for (int K = 0; K < 6; ++K) {
         acc = 0;
-        const int d = 2 + K;
         for (int s = 0; s < (1 << K); ++s) {
-            int j = 0;
-            for (int t = 0; t < d; ++t) {
-                const int bit = t < 2 ? (lane >> (4 + t)) & 1 : (s >> (t - 2)) & 1;
-                j |= bit << (d - 1 - t);
-            }
-            const unsigned long long m = node_mask(d, j);
+            // layout B: index bits 0, 1 = lane bits 4, 5; bits 2 .. = register bits 0 ..
+            const unsigned long long m = level_mask(2 + K, [&](int sb) { return sb < 2 ? (lane >> (4 + sb)) & 1 : (s >> (sb - 2)) & 1; });
             if (lane == 0) tab->mB[(1 << K) - 1 + s] = m;
             acc |= m;
             if (K >= 4 && m) ++nactB;
@@ -93,14 +98,9 @@ __global__ __launch_bounds__(64) void k_lat_treesc_prep(const uint8_t *__restric
     if (lane == 0) tab->deepB = nactB <= 24;
     for (int K = 0; K < 6; ++K) {
         acc = 0;
-        const int d = 6 + K;
         for (int s = 0; s < (1 << K); ++s) {
-            int j = 0;
-            for (int t = 0; t < d; ++t) {
-                const int bit = t < 6 ? (lane >> t) & 1 : (s >> (t - 6)) & 1;
-                j |= bit << (d - 1 - t);
-            }
-            const unsigned long long m = node_mask(d, j);
+            // layout C: index bits 0 .. 5 = lane bits, bits 6 .. = register bits
+            const unsigned long long m = level_mask(6 + K, [&](int sb) { return sb < 6 ? (lane >> sb) & 1 : (s >> (sb - 6)) & 1; });
             if (lane == 0) tab->mC[(1 << K) - 1 + s] = m;
             acc |= m;
         }
@@ -108,9 +108,9 @@ __global__ __launch_bounds__(64) void k_lat_treesc_prep(const uint8_t *__restric
     }
     unsigned dep[4] = {0, 0, 0, 0};
     for (int q = 0; q < 32; ++q) {
-        const int o = 128 * q + 2 * lane;                       // q = 16 h + k
+        const int pos = (128 * q + 2 * lane) & ((1 << SB) - 1);  // q = 16 h + k; position inside its signal
         int d = 0;
-        while (sp(d, o >> (12 - d))) ++d;
+        while (sp(d, pos >> (SB - d))) ++d;
         dep[q >> 3] |= (unsigned)d << (4 * (q & 7));
     }
     for (int w = 0; w < 4; ++w) tab->dep[64 * w + lane] = dep[w];
@@ -225,34 +225,55 @@ __device__ __forceinline__ void lat_sc_ptab(unsigned (&pw)[32], const WxLatTreeS
     }
 }
 
-template <int NS, int WPE>
+// the level on index bit BIT, register bit KK of a layout with HH cyclic lane bits: the root's (BIT = SH) is unmasked
+#define WX_SC_FWD(KK, HH, REG, BIT, MK, ANY)                                                   \
+    if constexpr (BIT == SH) {                                                                  \
+        lat_level<KK, HH, NS, false>(REG, cf);                                                  \
+        _Pragma("unroll") for (int r = 0; r < 64; ++r) REG[r] *= ((r >> KK) & 1) ? ginv : g;    \
+    } else if constexpr (BIT > SH) {                                                            \
+        if (ANY) lat_level_hm<KK, HH, NS, false>(REG, cf, MK, g, ginv);                         \
+    }
+#define WX_SC_INV(KK, HH, REG, BIT, MK, ANY)                                                   \
+    if constexpr (BIT == SH) {                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 64; ++r) REG[r] *= ((r >> KK) & 1) ? gd : ga;     \
+        lat_level<KK, HH, NS, true>(REG, cf);                                                   \
+    } else if constexpr (BIT > SH) {                                                            \
+        if (ANY) lat_level_hm<KK, HH, NS, true>(REG, cf, MK, ga, gd);                           \
+    }
+
+template <int NS, int WPE, int SH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_treesc_f64(
-    const double *__restrict__ x, double *__restrict__ y, int L, WxLatW cw, const WxLatTreeSc *__restrict__ tab)
+    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw, const WxLatTreeSc *__restrict__ tab)
 {
+    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
     __shared__ __attribute__((aligned(16))) double lds[2048];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
-    const double *xs = x + (int64_t)blockIdx.x * 4096;
-    double *ys = y + (int64_t)blockIdx.x * 4096;
+    constexpr int N = 4096 >> SH;
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);       // the last wavefront of a ragged batch re-does signals
+    const double *xs = x + (int64_t)sig0 * N;
+    double *ys = y + (int64_t)sig0 * N;
     const WxLat &cf = cw.c;
     // forward: gl[1] = g, g2 = g^-2: after the shears the a-slot holds a / g, the d-slot d g
     const double g = cw.gl[1], ginv = cw.c.g2 * cw.gl[1];
     double c[64];
     {
-        double a[64], bb[64];
-        lat_absorb<0, 0>(a, lds0, xs, lane, cw);
-        lat_level<0, 6, NS, false>(a, cf);                      // the root is split (L >= 1)
-#pragma unroll
-        for (int r = 0; r < 64; ++r) a[r] *= (r & 1) ? ginv : g;
-        if (tab->anyA) lat_level_hm<1, 6, NS, false>(a, cf, tab->mA, g, ginv);
-        lat_t2(a, bb, lds0, lane);
-        if (tab->anyB[0]) lat_level_hm<0, 4, NS, false>(bb, cf, tab->mB + 0, g, ginv);
-        if (tab->anyB[1]) lat_level_hm<1, 4, NS, false>(bb, cf, tab->mB + 1, g, ginv);
-        if (tab->anyB[2]) lat_level_hm<2, 4, NS, false>(bb, cf, tab->mB + 3, g, ginv);
-        if (tab->anyB[3]) lat_level_hm<3, 4, NS, false>(bb, cf, tab->mB + 7, g, ginv);
+        double bb[64];
+        if constexpr (SH < 2) {
+            double a[64];
+            lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw);
+            WX_SC_FWD(0, 6, a, 0, tab->mA, true)
+            WX_SC_FWD(1, 6, a, 1, tab->mA, tab->anyA)
+            lat_t2(a, bb, lds0, lane);
+        } else
+            lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw);
+        WX_SC_FWD(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
+        WX_SC_FWD(1, 4, bb, 3, tab->mB + 1, tab->anyB[1])
+        WX_SC_FWD(2, 4, bb, 4, tab->mB + 3, tab->anyB[2])
+        WX_SC_FWD(3, 4, bb, 5, tab->mB + 7, tab->anyB[3])
         if (tab->deepB) {
-            if (tab->anyB[4]) lat_level_hm<4, 4, NS, false>(bb, cf, tab->mB + 15, g, ginv);
-            if (tab->anyB[5]) lat_level_hm<5, 4, NS, false>(bb, cf, tab->mB + 31, g, ginv);
+            WX_SC_FWD(4, 4, bb, 6, tab->mB + 15, tab->anyB[4])
+            WX_SC_FWD(5, 4, bb, 7, tab->mB + 31, tab->anyB[5])
         }
         lat_t3(bb, c, lds0, lane);
     }
@@ -268,10 +289,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (tab->anyC[4]) lat_level_cm<4, NS, false>(c, cf, mk + 15, g, ginv);
     if (tab->anyC[5]) lat_level_cm<5, NS, false>(c, cf, mk + 31, g, ginv);
     lat_sync();
+    constexpr int HBIT = SH == 2 ? 1 : 0;                       // the lane bit that is bit 11 of the output position
     lat_for<2>([&](auto Hc) {
         constexpr int h = Hc;
-        // half h of the packet-order image = the coefficients whose first branch is h = the lanes with lane & 1 == h
-        if ((lane & 1) == h) {
+        if (((lane >> HBIT) & 1) == h) {
             lat_for<64>([&](auto Rc) {
                 constexpr int r = Rc;
                 const unsigned p = (r & 1) ? (pw[r >> 1] >> 16) : (pw[r >> 1] & 0xffffu);
@@ -295,16 +316,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     });
 }
 
-template <int NS, int WPE, bool THR>
+template <int NS, int WPE, int SH, bool THR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_treesc_f64(
-    const double *__restrict__ xw, double *__restrict__ y, int L, unsigned in_stride, unsigned col_stride, WxLatW cw,
+    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride, WxLatW cw,
     const WxLatTreeSc *__restrict__ tab, WxThreshArg thr)
 {
+    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
     __shared__ __attribute__((aligned(16))) double lds[2048];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
-    const double *xs = xw + (int64_t)blockIdx.x * in_stride;
-    double *ys = y + (int64_t)blockIdx.x * 4096;
+    constexpr int N = 4096 >> SH, NQ = 32 >> SH;               // samples, 128-element pieces of one signal
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    const double *xs = xw + (int64_t)sig0 * in_stride;
+    double *ys = y + (int64_t)sig0 * N;
     const WxLat &cf = cw.c;
     unsigned dep[4] = {0, 0, 0, 0};
     if (col_stride) {
@@ -312,32 +336,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         for (int w = 0; w < 4; ++w) dep[w] = tab->dep[64 * w + lane];
     }
     lat_d2 v[16];
-    // pieces k0 .. k0 + NK - 1 of half h
+    // pieces k0 .. k0 + NK - 1 of half h; piece q = 16 h + k is elements 128 (q mod NQ) + 2 lane, +1 of signal q / NQ
     auto fetch = [&](auto Hc, auto K0c, auto NKc) {
         constexpr int h = Hc, k0 = K0c, nk = NKc;
         lat_for<nk>([&](auto Kc) {
-            constexpr int k = k0 + Kc, q = 16 * h + k;
+            constexpr int k = k0 + Kc, q = 16 * h + k, sg = q / NQ, qq = q % NQ;
             const unsigned co = ((dep[q >> 3] >> (4 * (q & 7))) & 15u) * col_stride;      // col_stride = 0: dense leaves
-            if constexpr (q == 0) {
+            const double *src = xs + (size_t)sg * in_stride + 128 * qq;
+            if constexpr (qq == 0) {
                 // idwt of a pyramid: positions 0 .. 63 are the samples the lane-local tail (wx_dwttail.hip) has rebuilt
                 const double *hp = reinterpret_cast<const double *>(thr.head);
-                if (hp && lane < 32) v[k] = lat_ld2((lat_gc)(hp + 64 * (int64_t)blockIdx.x + 2 * lane));
-                else v[k] = lat_ld2(lat_sbase(xs) + (2 * lane + co));
+                if (hp && lane < 32) v[k] = lat_ld2((lat_gc)(hp + 64 * (int64_t)(sig0 + sg) + 2 * lane));
+                else v[k] = lat_ld2(lat_sbase(src) + (2 * lane + co));
             } else
-                v[k] = lat_ld2(lat_sbase(xs + 2048 * h + 128 * k) + (2 * lane + co));
+                v[k] = lat_ld2(lat_sbase(src) + (2 * lane + co));
         });
     };
+    double tt[4] = {0, 0, 0, 0};
+    if constexpr (THR) {
+#pragma unroll
+        for (int s4 = 0; s4 < (1 << SH); ++s4)
+            tt[s4] = reinterpret_cast<const double *>(thr.t)[thr.per_signal ? sig0 + s4 : 0] * thr.scale;
+    }
     auto put = [&](auto Hc, auto K0c, auto NKc) {
         constexpr int h = Hc, k0 = K0c, nk = NKc;
         if constexpr (THR) {
-            // threshold of denoise() (Denoising.jl:527 threshold!(x, th, t) before iwpt): positions [lo, n) of the signal
-            const double tt = reinterpret_cast<const double *>(thr.t)[thr.per_signal ? blockIdx.x : 0] * thr.scale;
+            // threshold of denoise() (Denoising.jl:527 threshold!(x, th, t) before iwpt): positions [lo, n) of every signal
             lat_for<nk>([&](auto Kc) {
-                constexpr int k = k0 + Kc;
-                const int pos = 2048 * h + 128 * k + 2 * lane;
-                if (h == 0 && k == 0 && thr.head && lane < 32) return;      // the tail has thresholded what it read
-                if (pos >= thr.lo) v[k].x = wx_thresh<double>(v[k].x, tt, thr.kind);
-                if (pos + 1 >= thr.lo) v[k].y = wx_thresh<double>(v[k].y, tt, thr.kind);
+                constexpr int k = k0 + Kc, q = 16 * h + k, sg = q / NQ, qq = q % NQ;
+                const int pos = 128 * qq + 2 * lane;
+                if (qq == 0 && thr.head && lane < 32) return;      // the tail has thresholded what it read
+                if (pos >= thr.lo) v[k].x = wx_thresh<double>(v[k].x, tt[sg], thr.kind);
+                if (pos + 1 >= thr.lo) v[k].y = wx_thresh<double>(v[k].y, tt[sg], thr.kind);
             });
         }
         lat_for<nk>([&](auto Kc) {
@@ -353,8 +383,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     unsigned pw[32];
     lat_sc_ptab(pw, tab, lane);
     double c[64];
-    // half 0 (the even lanes' coefficients): every lane reads, the odd lanes' values are replaced below; the first eight pieces of
-    // half 1 travel meanwhile -- all sixteen would not fit the 256 registers next to c[] and the table
+    // half 0 (the lanes with bit HBIT clear): every lane reads, the other lanes' values are replaced below; the first eight
+    // pieces of half 1 travel meanwhile -- all sixteen would not fit the 256 registers next to c[] and the table
     put(I0{}, I0{}, I16{});
     lat_sync();
     fetch(I1{}, I0{}, I8{});
@@ -372,7 +402,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     fetch(I1{}, I8{}, I8{});
     put(I1{}, I8{}, I8{});
     lat_sync();
-    if (lane & 1) {
+    constexpr int HBIT = SH == 2 ? 1 : 0;
+    if ((lane >> HBIT) & 1) {
         lat_for<64>([&](auto Rc) {
             constexpr int r = Rc;
             const unsigned p = (r & 1) ? (pw[r >> 1] >> 16) : (pw[r >> 1] & 0xffffu);
@@ -398,20 +429,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     double bb[64];
     lat_t3i(c, bb, lds0, lane);
     if (tab->deepB) {
-        if (tab->anyB[5]) lat_level_hm<5, 4, NS, true>(bb, cf, tab->mB + 31, ga, gd);
-        if (tab->anyB[4]) lat_level_hm<4, 4, NS, true>(bb, cf, tab->mB + 15, ga, gd);
+        WX_SC_INV(5, 4, bb, 7, tab->mB + 31, tab->anyB[5])
+        WX_SC_INV(4, 4, bb, 6, tab->mB + 15, tab->anyB[4])
     }
-    if (tab->anyB[3]) lat_level_hm<3, 4, NS, true>(bb, cf, tab->mB + 7, ga, gd);
-    if (tab->anyB[2]) lat_level_hm<2, 4, NS, true>(bb, cf, tab->mB + 3, ga, gd);
-    if (tab->anyB[1]) lat_level_hm<1, 4, NS, true>(bb, cf, tab->mB + 1, ga, gd);
-    if (tab->anyB[0]) lat_level_hm<0, 4, NS, true>(bb, cf, tab->mB + 0, ga, gd);
-    double a[64];
-    lat_t2i(bb, a, lds0, lane);
-    if (tab->anyA) lat_level_hm<1, 6, NS, true>(a, cf, tab->mA, ga, gd);
-#pragma unroll
-    for (int r = 0; r < 64; ++r) a[r] *= (r & 1) ? gd : ga;
-    lat_level<0, 6, NS, true>(a, cf);
-    lat_emit<0, 0>(a, lds0, ys, lane, cw);
+    WX_SC_INV(3, 4, bb, 5, tab->mB + 7, tab->anyB[3])
+    WX_SC_INV(2, 4, bb, 4, tab->mB + 3, tab->anyB[2])
+    WX_SC_INV(1, 4, bb, 3, tab->mB + 1, tab->anyB[1])
+    WX_SC_INV(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
+    if constexpr (SH >= 2) {
+        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw);
+    } else {
+        double a[64];
+        lat_t2i(bb, a, lds0, lane);
+        WX_SC_INV(1, 6, a, 1, tab->mA, tab->anyA)
+        WX_SC_INV(0, 6, a, 0, tab->mA, true)
+        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw);
+    }
 }
+#undef WX_SC_FWD
+#undef WX_SC_INV
 
 }  // namespace
