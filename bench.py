@@ -45,13 +45,13 @@ WORKLOADS = {
                    fwd_kernels=[("k_lat_wpt_f64<4, 3, double>", 1)],
                    desc="north-star target: wptall+iwptall 65536x4096 f64 db4 L=10"),
     "tree_random": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=12, dtype="f64", tree="random:0.7:3",
-                        kernel="k_lat_wpt_tree_f64<4, 2, 0>", inv_kernel="k_lat_iwpt_tree_f64<4, 2, 0, false>",
-                        fwd_kernels=[("k_lat_wpt_tree_f64<4, 2, 0>", 1)],
+                        kernel="k_lat_wpt_treesc_f64<4, 2, 0>", inv_kernel="k_lat_iwpt_treesc_f64<4, 2, 0, false>",
+                        fwd_kernels=[("k_lat_wpt_treesc_f64<4, 2, 0>", 1)],
                         desc="the target's batch along a tree, as bestbasistree output is used (DWT.jl:340-351, dwt_all.jl:152-225): "
                              "wptall+iwptall 65536x4096 f64 db4, random tree (every node split with probability 0.7, seed 3, depth 12)"),
     "tree_pyramid": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=12, dtype="f64", tree="pyramid",
-                         kernel="k_lat_wpt_tree_f64<4, 2, 0>", inv_kernel="k_inv1d_fused",
-                         fwd_kernels=[("k_lat_wpt_tree_f64<4, 2, 0>", 1)],
+                         kernel="k_lat_wpt_treesc_f64<4, 2, 0>", inv_kernel="k_lat_iwpt_treesc_f64<4, 2, 0, false>",
+                         fwd_kernels=[("k_lat_wpt_treesc_f64<4, 2, 0>", 1)],
                          desc="dwtall+idwtall as wptall+iwptall along maketree(4096, 12, :dwt): 65536x4096 f64 db4 (the levels "
                               "below 64 samples run lane-locally, wx_dwttail.hip)"),
     "target_n2048": dict(kind="wpt", n=2048, batch=131072, wavelet="db4", L=10, dtype="f64",
