@@ -1,5 +1,6 @@
-// wx_lattice2d.hip -- 2-D full-tree packets of 512 x 512 Float32 images (depth 6) as two applications of ONE kernel: a
-// lattice transform down 32 contiguous columns in registers whose result is stored TRANSPOSED.
+// wx_lattice2d.hip -- 2-D full-tree packets of 512 x 512 Float32 images (depth 6; HB = 1: 256 x 256 at depth 5, HB = 2:
+// 1024 x 1024 at depth 7, see L2G below) as two applications of ONE kernel: a lattice transform down 32 contiguous columns in
+// registers whose result is stored TRANSPOSED.  The text below describes the 512 x 512 geometry.
 //
 // Reference semantics: 2-D wpt / iwpt by level (DWT.jl:500-548, 662-710 over dwt/dwt_one_level.jl:319-354, 401-436); a
 // full tree of depth L is separable: the 1-D packet transform down every column, then along every row (§4.5 of DESIGN.md).
