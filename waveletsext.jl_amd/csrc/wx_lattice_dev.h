@@ -1701,14 +1701,46 @@ __global__ __launch_bounds__(64) void k_lat_tree_prep(const uint8_t *__restrict_
 // advances that IS the partner, and the final - (NS - 1) puts every w back where it started): no renaming, and the whole level
 // of a sequence is ONE exec region.  The empty volatile asm keeps it a region: if-converted, the compiler computes the level for
 // every lane and selects per register (two v_cndmask per coefficient and level, a third of the level's instructions).
+// the masks of G consecutive sequences in ONE scalar load, pinned in SGPRs: read one by one where they are tested, every
+// sequence starts with its own scalar-cache round trip (s_load_dwordx2 + s_waitcnt lgkmcnt(0): 127 per signal and direction)
+typedef unsigned long long lat_u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+typedef unsigned long long lat_u64x4 __attribute__((ext_vector_type(4), aligned(8)));
+typedef unsigned long long lat_u64x8 __attribute__((ext_vector_type(8), aligned(8)));
+template <int G> __device__ __forceinline__ void lat_masks(unsigned long long (&mm)[G], const unsigned long long *__restrict__ mk)
+{
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8, "groups of 1, 2, 4, 8 masks");
+    if constexpr (G == 1) {
+        mm[0] = mk[0];
+        asm volatile("" : "+s"(mm[0]));
+    } else if constexpr (G == 2) {
+        const lat_u64x2 v = *reinterpret_cast<const lat_u64x2 *>(mk);
+        mm[0] = v[0]; mm[1] = v[1];
+        asm volatile("" : "+s"(mm[0]), "+s"(mm[1]));
+    } else if constexpr (G == 4) {
+        const lat_u64x4 v = *reinterpret_cast<const lat_u64x4 *>(mk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mm[j] = v[j];
+        asm volatile("" : "+s"(mm[0]), "+s"(mm[1]), "+s"(mm[2]), "+s"(mm[3]));
+    } else {
+        const lat_u64x8 v = *reinterpret_cast<const lat_u64x8 *>(mk);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mm[j] = v[j];
+        asm volatile("" : "+s"(mm[0]), "+s"(mm[1]), "+s"(mm[2]), "+s"(mm[3]), "+s"(mm[4]), "+s"(mm[5]), "+s"(mm[6]), "+s"(mm[7]));
+    }
+}
+
 template <int K, int NS, bool INV>
 __device__ __forceinline__ void lat_level_cm(double (&x)[64], const WxLat &cf, const unsigned long long *__restrict__ mk, double ga, double gd)
 {
-    constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
+    constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K, G = NSEQ < 8 ? NSEQ : 8;
     auto U = [](int s, int m) { return s + ((2 * m) << K); };
-    lat_for<NSEQ>([&](auto Sc) {
-        constexpr int s = Sc;
-        const unsigned long long msk = mk[s];               // wave-uniform; sequences nobody splits cost one scalar load
+    lat_for<NSEQ / G>([&](auto Gc) {
+    constexpr int s0 = G * Gc;
+    unsigned long long mm[G];
+    lat_masks<G>(mm, mk + s0);
+    lat_for<G>([&](auto Sc) {
+        constexpr int s = s0 + Sc;
+        const unsigned long long msk = mm[Sc];              // wave-uniform
         if (!msk) return;
         if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
             // K >= 4 (sequences of 2 and 1 pairs): left to the compiler, which computes every lane and selects -- the rotations
@@ -1742,6 +1774,7 @@ __device__ __forceinline__ void lat_level_cm(double (&x)[64], const WxLat &cf, c
                 }
             }
         }
+    });
     });
 }
 

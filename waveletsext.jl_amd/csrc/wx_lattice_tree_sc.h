@@ -29,9 +29,9 @@
 
 struct WxLatTreeSc {
     unsigned short perm[64 * 64];      // [r >> 3][lane][r & 7], r = register of layout C: swizzled byte address in the 32 KiB packet-order image
-    unsigned long long mA[2];          // level on bit 1: node (1, s) is split -> all lanes
-    unsigned long long mB[63];         // [(1 << K) - 1 + s]: level on bit 2 + K, register class s: lanes whose node is split
-    unsigned long long mC[63];         // [(1 << K) - 1 + s]: level on bit 6 + K
+    alignas(16) unsigned long long mA[2];        // level on bit 1: node (1, s) is split -> all lanes
+    alignas(64) unsigned long long mB[6 * 32];   // [32 K + s]: level on bit 2 + K, register class s: lanes whose node is split
+    alignas(64) unsigned long long mC[6 * 32];   // [32 K + s]: level on bit 6 + K (rows of 32 so that 8 masks are one aligned scalar load)
     unsigned dep[4 * 64];              // [w][lane]: leaf depth of piece (h, k) -- elements 2048 h + 128 k + 2 lane, +1 -- nibble 16 h + k
     unsigned anyA, anyB[6], anyC[6];
     unsigned deepB;                    // the levels on bits 6, 7 run in layout B (sparse trees: most register classes are idle there)
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void k_lat_treesc_prep(const uint8_t *__restric
         for (int s = 0; s < (1 << K); ++s) {
             // layout B: index bits 0, 1 = lane bits 4, 5; bits 2 .. = register bits 0 ..
             const unsigned long long m = level_mask(2 + K, [&](int sb) { return sb < 2 ? (lane >> (4 + sb)) & 1 : (s >> (sb - 2)) & 1; });
-            if (lane == 0) tab->mB[(1 << K) - 1 + s] = m;
+            if (lane == 0) tab->mB[32 * K + s] = m;
             acc |= m;
             if (K >= 4 && m) ++nactB;
         }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void k_lat_treesc_prep(const uint8_t *__restric
         for (int s = 0; s < (1 << K); ++s) {
             // layout C: index bits 0 .. 5 = lane bits, bits 6 .. = register bits
             const unsigned long long m = level_mask(6 + K, [&](int sb) { return sb < 6 ? (lane >> sb) & 1 : (s >> (sb - 6)) & 1; });
-            if (lane == 0) tab->mC[(1 << K) - 1 + s] = m;
+            if (lane == 0) tab->mC[32 * K + s] = m;
             acc |= m;
         }
         if (lane == 0) tab->anyC[K] = acc != 0;
@@ -123,11 +123,15 @@ __global__ __launch_bounds__(64) void k_lat_treesc_prep(const uint8_t *__restric
 template <int K, int H, int NS, bool INV>
 __device__ __forceinline__ void lat_level_hm(double (&x)[64], const WxLat &cf, const unsigned long long *__restrict__ mk, double ga, double gd)
 {
-    constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
+    constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K, G = NSEQ < 8 ? NSEQ : 8;
     auto U = [](int s, int m) { return s + ((2 * m) << K); };
-    lat_for<NSEQ>([&](auto Sc) {
-        constexpr int s = Sc;
-        const unsigned long long msk = mk[s];
+    lat_for<NSEQ / G>([&](auto Gc) {
+    constexpr int s0 = G * Gc;
+    unsigned long long mm[G];
+    lat_masks<G>(mm, mk + s0);                              // one scalar load for the group (see lat_level_cm)
+    lat_for<G>([&](auto Sc) {
+        constexpr int s = s0 + Sc;
+        const unsigned long long msk = mm[Sc];
         if (!msk) return;
         auto shift = [&](auto SHc) {
             constexpr int SHv = decltype(SHc)::value;
@@ -193,6 +197,7 @@ __device__ __forceinline__ void lat_level_hm(double (&x)[64], const WxLat &cf, c
                 if (j > 0) shift(std::integral_constant<int, -1>{});
             }
         }
+    });
     });
 }
 
@@ -268,12 +273,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         } else
             lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw);
         WX_SC_FWD(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
-        WX_SC_FWD(1, 4, bb, 3, tab->mB + 1, tab->anyB[1])
-        WX_SC_FWD(2, 4, bb, 4, tab->mB + 3, tab->anyB[2])
-        WX_SC_FWD(3, 4, bb, 5, tab->mB + 7, tab->anyB[3])
+        WX_SC_FWD(1, 4, bb, 3, tab->mB + 32, tab->anyB[1])
+        WX_SC_FWD(2, 4, bb, 4, tab->mB + 64, tab->anyB[2])
+        WX_SC_FWD(3, 4, bb, 5, tab->mB + 96, tab->anyB[3])
         if (tab->deepB) {
-            WX_SC_FWD(4, 4, bb, 6, tab->mB + 15, tab->anyB[4])
-            WX_SC_FWD(5, 4, bb, 7, tab->mB + 31, tab->anyB[5])
+            WX_SC_FWD(4, 4, bb, 6, tab->mB + 128, tab->anyB[4])
+            WX_SC_FWD(5, 4, bb, 7, tab->mB + 160, tab->anyB[5])
         }
         lat_t3(bb, c, lds0, lane);
     }
@@ -282,12 +287,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const unsigned long long *mk = tab->mC;
     if (!tab->deepB) {
         if (tab->anyC[0]) lat_level_cm<0, NS, false>(c, cf, mk + 0, g, ginv);
-        if (tab->anyC[1]) lat_level_cm<1, NS, false>(c, cf, mk + 1, g, ginv);
+        if (tab->anyC[1]) lat_level_cm<1, NS, false>(c, cf, mk + 32, g, ginv);
     }
-    if (tab->anyC[2]) lat_level_cm<2, NS, false>(c, cf, mk + 3, g, ginv);
-    if (tab->anyC[3]) lat_level_cm<3, NS, false>(c, cf, mk + 7, g, ginv);
-    if (tab->anyC[4]) lat_level_cm<4, NS, false>(c, cf, mk + 15, g, ginv);
-    if (tab->anyC[5]) lat_level_cm<5, NS, false>(c, cf, mk + 31, g, ginv);
+    if (tab->anyC[2]) lat_level_cm<2, NS, false>(c, cf, mk + 64, g, ginv);
+    if (tab->anyC[3]) lat_level_cm<3, NS, false>(c, cf, mk + 96, g, ginv);
+    if (tab->anyC[4]) lat_level_cm<4, NS, false>(c, cf, mk + 128, g, ginv);
+    if (tab->anyC[5]) lat_level_cm<5, NS, false>(c, cf, mk + 160, g, ginv);
     lat_sync();
     constexpr int HBIT = SH == 2 ? 1 : 0;                       // the lane bit that is bit 11 of the output position
     lat_for<2>([&](auto Hc) {
@@ -418,23 +423,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     // synthesis: gl[1] = 1 / g, g2 = g^2 -- the a-slot of a split node enters as a / g, the d-slot as d g
     const double ga = cw.gl[1], gd = cw.c.g2 * cw.gl[1];
     const unsigned long long *mk = tab->mC;
-    if (tab->anyC[5]) lat_level_cm<5, NS, true>(c, cf, mk + 31, ga, gd);
-    if (tab->anyC[4]) lat_level_cm<4, NS, true>(c, cf, mk + 15, ga, gd);
-    if (tab->anyC[3]) lat_level_cm<3, NS, true>(c, cf, mk + 7, ga, gd);
-    if (tab->anyC[2]) lat_level_cm<2, NS, true>(c, cf, mk + 3, ga, gd);
+    if (tab->anyC[5]) lat_level_cm<5, NS, true>(c, cf, mk + 160, ga, gd);
+    if (tab->anyC[4]) lat_level_cm<4, NS, true>(c, cf, mk + 128, ga, gd);
+    if (tab->anyC[3]) lat_level_cm<3, NS, true>(c, cf, mk + 96, ga, gd);
+    if (tab->anyC[2]) lat_level_cm<2, NS, true>(c, cf, mk + 64, ga, gd);
     if (!tab->deepB) {
-        if (tab->anyC[1]) lat_level_cm<1, NS, true>(c, cf, mk + 1, ga, gd);
+        if (tab->anyC[1]) lat_level_cm<1, NS, true>(c, cf, mk + 32, ga, gd);
         if (tab->anyC[0]) lat_level_cm<0, NS, true>(c, cf, mk + 0, ga, gd);
     }
     double bb[64];
     lat_t3i(c, bb, lds0, lane);
     if (tab->deepB) {
-        WX_SC_INV(5, 4, bb, 7, tab->mB + 31, tab->anyB[5])
-        WX_SC_INV(4, 4, bb, 6, tab->mB + 15, tab->anyB[4])
+        WX_SC_INV(5, 4, bb, 7, tab->mB + 160, tab->anyB[5])
+        WX_SC_INV(4, 4, bb, 6, tab->mB + 128, tab->anyB[4])
     }
-    WX_SC_INV(3, 4, bb, 5, tab->mB + 7, tab->anyB[3])
-    WX_SC_INV(2, 4, bb, 4, tab->mB + 3, tab->anyB[2])
-    WX_SC_INV(1, 4, bb, 3, tab->mB + 1, tab->anyB[1])
+    WX_SC_INV(3, 4, bb, 5, tab->mB + 96, tab->anyB[3])
+    WX_SC_INV(2, 4, bb, 4, tab->mB + 64, tab->anyB[2])
+    WX_SC_INV(1, 4, bb, 3, tab->mB + 32, tab->anyB[1])
     WX_SC_INV(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
     if constexpr (SH >= 2) {
         lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw);
