@@ -97,7 +97,7 @@ def test_config5_geometry_moments_and_tree(wx, oracle, mode):
         wx.set_force_generic(0)
 
 
-@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "coif2", "db8"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "coif2", "db7", "db8", "coif6", "db10"])
 def test_config4_geometry_2d_lattice_matches_oracle(wx, oracle, wname):
     """BASELINE config 4: 2-D wptall / iwptall of 512 x 512 Float32 images, L = 6 (dwt/dwt_all.jl:152-166, 210-225 over
     Wavelets.jl's 2-D wpt by level) through the transposing lattice column kernels (csrc/wx_lattice2d.hip).  Float32:
@@ -113,7 +113,7 @@ def test_config4_geometry_2d_lattice_matches_oracle(wx, oracle, wname):
     assert relerr(back.astype(np.float64), x.astype(np.float64)) <= 2e-6, wname
 
 
-@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "coif2", "db8"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "coif2", "db7", "db8", "coif6", "db10"])
 def test_2d_lattice_256x256_matches_oracle(wx, oracle, wname):
     """256 x 256 Float32 images, full depth L = 5, through the same transposing lattice kernels (two images per register
     column, csrc/wx_lattice2d.hip HB = 1): odd and even batches (the last workgroup re-does the last two images), forward
@@ -132,7 +132,7 @@ def test_2d_lattice_256x256_matches_oracle(wx, oracle, wname):
             assert relerr(back[:, :, b].astype(np.float64), x[:, :, b].astype(np.float64)) <= 2e-6, (wname, B, b)
 
 
-@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "coif2", "db8"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "coif2", "db7", "db8", "coif6", "db10"])
 def test_2d_lattice_1024x1024_matches_oracle(wx, oracle, wname):
     """1024 x 1024 Float32 images, full depth L = 7 (8 columns of 1024 rows per wavefront, csrc/wx_lattice2d.hip HB = 2),
     forward against the oracle, inverse against the oracle's input"""

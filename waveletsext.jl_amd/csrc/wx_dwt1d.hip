@@ -1028,7 +1028,7 @@ template <typename T> bool wx_fused1d_ok(int64_t n, int F)
 {
     if (!wx_is_pow2(n) || n < 8) return false;
     if (wx_fused_lds_bytes<T>(n) > 160 * 1024) return false;
-    switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 16: case 18: case 20: return true; }
+    switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 14: case 16: case 18: case 20: return true; }
     return false;
 }
 template bool wx_fused1d_ok<double>(int64_t, int);
@@ -1197,7 +1197,7 @@ static int launch_fwd_fused(const T *x, T *y, int64_t n, int L, int64_t batch, i
 {
     switch (filt.F) {
 #define WX_CASE(FF) case FF: return launch_fwd_fused_F<T, FF, WRITE_ALL>(x, y, n, L, batch, xs, ys, filt, status, nstatus, st, sub);
-        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(14) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
     }
     return wx_set_error(WX_EUNSUPPORTED, "no fused instantiation for this filter length");
@@ -1248,7 +1248,7 @@ static int launch_inv_fused(const T *xw, T *xh, int64_t n, int L, int64_t batch,
 {
     switch (filt.F) {
 #define WX_CASE(FF) case FF: return launch_inv_fused_F<T, FF>(xw, xh, n, L, batch, is, os, filt, status, nstatus, colmap, log2blk, st, thr);
-        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(14) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
     }
     return wx_set_error(WX_EUNSUPPORTED, "no fused instantiation for this filter length");

@@ -422,7 +422,7 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
     if (inplace) lds = (size_t)n * S * sizeof(T);
     switch (filt.F) {
 #define WX_CASE(FF) case FF: kern = vec ? k_rows_fused<T, FF, INVERSE, VW> : k_rows_fused<T, FF, INVERSE, 1>; break;
-        WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+        WX_CASE(10) WX_CASE(12) WX_CASE(14) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
 #define WX_CASE(FF) case FF: kern = inplace ? (items_per_lane <= 1 ? k_rows_fused<T, FF, INVERSE, VW, 1> : k_rows_fused<T, FF, INVERSE, VW, 2>) \
                                    : (vec ? k_rows_fused<T, FF, INVERSE, VW> : k_rows_fused<T, FF, INVERSE, 1>); break;
@@ -741,7 +741,7 @@ template <typename T> static bool wx_level_tile_ok(int m, int n, int d, int F)
     const int mp = m >> d, np = n >> d;
     if ((m & (m - 1)) || (n & (n - 1)) || mp < 8 || np < 8) return false;
     if (m % WX_TILE_CR || n % wx_tile_cc<T>()) return false;
-    return F == 2 || F == 4 || F == 6 || F == 8 || F == 10 || F == 12 || F == 16 || F == 20;
+    return F == 2 || F == 4 || F == 6 || F == 8 || F == 10 || F == 12 || F == 14 || F == 16 || F == 18 || F == 20;
 }
 
 template <typename T>
@@ -752,7 +752,7 @@ static bool wx_launch_level_tile(const T *src, T *dst, int64_t src_img, int64_t 
     constexpr int CR = WX_TILE_CR, CC = wx_tile_cc<T>();
     switch (filt.F) {
 #define WX_CASE(FF) case FF: return wx_launch_level_tile_F<T, FF, CR, CC>(src, dst, src_img, dst_img, m, n, d, batch, filt, st, tt);
-        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(20)
+        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(14) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
     }
     return false;
@@ -950,7 +950,7 @@ static bool wx_launch_ilevel_tile(const T *src_leaf, int64_t leaf_img, const T *
     constexpr int CR = WX_TILE_CR, CC = wx_tile_cc<T>();
     switch (filt.F) {
 #define WX_CASE(FF) case FF: return wx_launch_ilevel_tile_F<T, FF, CR, CC>(src_leaf, leaf_img, src_int, dst, dst_img, m, n, d, batch, filt, st, tt);
-        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(20)
+        WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(14) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
     }
     return false;

@@ -168,7 +168,7 @@ int wx_dwt2d_tail_levels(int64_t m, int64_t n, int L, int F, size_t esz)
 {
     static const bool off = getenv("WX_DWT_TAIL") && atoi(getenv("WX_DWT_TAIL")) == 0;
     if (off || (esz != 8 && esz != 4) || m != n || m < 16 || (m & (m - 1))) return 0;
-    switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 16: case 18: case 20: break; default: return 0; }
+    switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 14: case 16: case 18: case 20: break; default: return 0; }
     int log2m = 0;
     while (((int64_t)1 << (log2m + 1)) <= m) ++log2m;
     const int Ls = log2m - 3;
@@ -183,7 +183,7 @@ int wx_dwt2d_tail(T *y, int64_t m, int Lt, int64_t batch, const WxFilt &filt, hi
     KT k = nullptr;
     switch (filt.F) {
 #define WX_TL(FF) case FF: k = k_dwt2d_tail<T, FF>; break;
-        WX_TL(2) WX_TL(4) WX_TL(6) WX_TL(8) WX_TL(10) WX_TL(12) WX_TL(16) WX_TL(18) WX_TL(20)
+        WX_TL(2) WX_TL(4) WX_TL(6) WX_TL(8) WX_TL(10) WX_TL(12) WX_TL(14) WX_TL(16) WX_TL(18) WX_TL(20)
 #undef WX_TL
         default: return wx_set_error(WX_EHIP, "dwt 2-D tail: unsupported filter length");
     }
@@ -199,7 +199,7 @@ int wx_dwt_tail_levels(int64_t n, int L, int F, size_t esz)
 {
     static const bool off = getenv("WX_DWT_TAIL") && atoi(getenv("WX_DWT_TAIL")) == 0;
     if (off || (esz != 8 && esz != 4) || n < 128 || (n & (n - 1))) return 0;
-    switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 16: case 18: case 20: break; default: return 0; }
+    switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 14: case 16: case 18: case 20: break; default: return 0; }
     int log2n = 0;
     while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
     const int Ls = log2n - 6;
@@ -214,7 +214,7 @@ int wx_dwt_tail(T *y, int64_t n, int Lt, int64_t batch, const WxFilt &filt, hipS
     KT k = nullptr;
     switch (filt.F) {
 #define WX_TL(FF) case FF: k = k_dwt_tail<T, FF>; break;
-        WX_TL(2) WX_TL(4) WX_TL(6) WX_TL(8) WX_TL(10) WX_TL(12) WX_TL(16) WX_TL(18) WX_TL(20)
+        WX_TL(2) WX_TL(4) WX_TL(6) WX_TL(8) WX_TL(10) WX_TL(12) WX_TL(14) WX_TL(16) WX_TL(18) WX_TL(20)
 #undef WX_TL
         default: return wx_set_error(WX_EHIP, "dwt tail: unsupported filter length");
     }
@@ -233,7 +233,7 @@ int wx_idwt_tail(const T *xw, T *head, int64_t n, int Lt, int64_t batch, const W
     KT k = nullptr;
     switch (filt.F) {
 #define WX_TL(FF) case FF: k = k_idwt_tail<T, FF>; break;
-        WX_TL(2) WX_TL(4) WX_TL(6) WX_TL(8) WX_TL(10) WX_TL(12) WX_TL(16) WX_TL(18) WX_TL(20)
+        WX_TL(2) WX_TL(4) WX_TL(6) WX_TL(8) WX_TL(10) WX_TL(12) WX_TL(14) WX_TL(16) WX_TL(18) WX_TL(20)
 #undef WX_TL
         default: return wx_set_error(WX_EHIP, "idwt tail: unsupported filter length");
     }

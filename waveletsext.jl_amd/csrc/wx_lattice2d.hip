@@ -1,738 +1,25 @@
-// wx_lattice2d.hip -- 2-D full-tree packets of 512 x 512 Float32 images (depth 6; HB = 1: 256 x 256 at depth 5, HB = 2:
-// 1024 x 1024 at depth 7, see L2G below) as two applications of ONE kernel: a lattice transform down 32 contiguous columns in
-// registers whose result is stored TRANSPOSED.  The text below describes the 512 x 512 geometry.
-//
-// Reference semantics: 2-D wpt / iwpt by level (DWT.jl:500-548, 662-710 over dwt/dwt_one_level.jl:319-354, 401-436); a
-// full tree of depth L is separable: the 1-D packet transform down every column, then along every row (§4.5 of DESIGN.md).
-// The round-1 path runs the row pass out of LDS strips (LDS-issue bound, 2.5 TB/s) and the column pass one wavefront per
-// column (latency bound).  Here both passes are the same contiguous-signal kernel: it reads the columns of the image
-// (contiguous), transforms them with the rotation lattice of wx_lattice.hip -- v_pk_fma_f32 on pairs of adjacent columns,
-// 16 columns = 4096 Float32 pairs per wavefront, the same register layouts A and B and the same intra-wavefront LDS
-// exchanges as the Float64 kernel -- and writes Z[j + 512 o(i)]: position o(i) of the packet order becomes the column,
-// the column index j the contiguous dimension.  The second application transforms the former rows and restores the
-// orientation.  A workgroup of W = 4 wavefronts covers 64 columns = a 256-byte run of every row of the transposed image;
-// the transposition goes through LDS in four rounds of 128 rows (two register bits fixed per round).
-//
-// What bounds a pass is its memory access shape, not arithmetic (tools/dbg/l2d_pattern.hip times the shapes without any
-// arithmetic on 4096 images: the round-2 shape, 128-byte runs per row, 1.67 ms; 256-byte runs with the non-temporal hint
-// 1.51 ms; a plain copy 1.45 ms; the kernel without its global accesses 0.72 ms).  Hence (round 3): W = 4 instead of 2,
-// non-temporal loads and stores, two wavefronts per SIMD without the 13-22 spilled registers of the three-wavefront build
-// (their scratch traffic was the 1.17 x of round 2's PMC bytes), and the intermediate image -- which nobody outside the
-// library sees -- in a BLOCKED layout (l2_src_off) that makes the first pass's stores and the second pass's loads
-// contiguous: only the last store of a transform is a strided one.  3.39 -> 2.95 ms per direction on config 4.  Filters of
-// 2 .. 12 and 16 taps (round 2: 4 and 8) -- db8 3.5 / 3.3 ms (the levels start to show), Haar / coif2 as db4.
-//
-// Halo: the columns of a wavefront are independent periodic sequences of 512 samples: in layout A (reg i[5:0]) the
-// neighbouring chunk is the next of 8 lanes (cyclic: two DPP moves and a select), in layout B (reg i[7:2]) the other of 2
-// lanes (quad_perm).  Depth 6 needs levels on index bits 0..5 only: A takes 0-1, B takes 2-5.
-#include "wx_common.h"
-#include "wx_kernels.h"
-#include <cstdlib>
-#include <utility>
+// wx_lattice2d.hip -- 2-D full-tree packets of Float32 images on the transposing lattice kernel (wx_lattice2d.h): dispatch, and
+// the kernels of the 512 x 512 geometry (depth 6).  Reference: 2-D wpt / iwpt by level, DWT.jl:500-548, 662-710.
+#include "wx_lattice2d.h"
 
-bool wx_lattice_coeffs(const WxFilt &filt, int L, bool inverse, double *p, double *kap, double *g0, double *g2);
-
-#define WX_L2_MAXS 10
-#define WX_L2_WIN 1104        // 8-byte slots of one wavefront's exchange window
-#ifndef WX_L2D_G
-#define WX_L2D_G 16            // LDS reads in flight per wait of an exchange (8 or 16)
-#endif
-#ifndef WX_L2D_W
-#define WX_L2D_W 4             // wavefronts per workgroup = 16 W columns = a 64 W byte run of every transposed row
-#endif
-#ifndef WX_L2D_NT
-#define WX_L2D_NT 1            // non-temporal hint on the loads and stores (every byte is touched once)
-#endif
-#ifndef WX_L2D_WPE
-#define WX_L2D_WPE 2           // wavefronts per SIMD the kernels are built for (3: 168 registers, 13-22 of them spilled)
-#endif
-
-struct WxLat2 {
-    float p[WX_L2_MAXS];
-    float kap[WX_L2_MAXS];
-    float g0, g2;
-};
-
-namespace {
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef const float __attribute__((address_space(1))) *l2_gc;
-typedef float __attribute__((address_space(1))) *l2_gm;
-
-__device__ __forceinline__ l2_gc l2_sbase(const float *p)
-{
-    l2_gc g = (l2_gc)p;
-    asm("" : "+s"(g));
-    return g;
-}
-__device__ __forceinline__ l2_gm l2_sbase(float *p)
-{
-    l2_gm g = (l2_gm)p;
-    asm("" : "+s"(g));
-    return g;
-}
-__device__ __forceinline__ f4 l2_ld(l2_gc p)
-{
-    const f4 __attribute__((address_space(1))) *q = (const f4 __attribute__((address_space(1))) *)p;
-    return WX_L2D_NT ? __builtin_nontemporal_load(q) : *q;
-}
-__device__ __forceinline__ void l2_st(l2_gm p, f4 v)
-{
-    f4 __attribute__((address_space(1))) *q = (f4 __attribute__((address_space(1))) *)p;
-    if (WX_L2D_NT) __builtin_nontemporal_store(v, q);
-    else *q = v;
-}
-// The intermediate image between the two passes is the library's own: instead of the plain transposed image
-// Z[j + 512 o] the first pass writes it in blocks of 16 W source columns, Zb[(j / 16 W) * 512 * 16 W + o * 16 W + j % 16 W],
-// so that a workgroup's 512 runs of 64 W bytes are one contiguous 32 W KiB block (BS), and the second pass reads its
-// columns o out of those blocks (BL): sample j of column o at (j / 64) * WX_L2D_BLK + 64 o + j % 64.
-// HB = 1 (256 x 256 images, depth 5): a register column of 512 samples is the same column of TWO consecutive images --
-// index bit 8 selects the image, the levels and their periodic halos stay inside a half (the cyclic neighbours of layout A
-// are the 4 lanes of a quad, layout B holds whole sequences), everything else is the 512-row kernel.
-template <int HB> struct L2G {
-    static constexpr int R = HB == 2 ? 1024 : (512 >> HB);  // rows = columns of an image (HB = 2: 1024, see below)
-    static constexpr int RB = HB == 2 ? 10 : 9 - HB;        // bits of a row index
-    static constexpr int LD = HB == 2 ? 7 : 6 - HB;         // levels
-    static constexpr int IB = HB == 1 ? 1 : 0;              // image-select bits of a register column
-    static constexpr int NPW = HB == 2 ? 4 : 8;             // column pairs per wavefront
-    static constexpr int BW = 2 * NPW * WX_L2D_W;           // columns per workgroup = block width of the intermediate
-    static constexpr int BLK = R * BW;                      // elements of one block of the intermediate
-    static constexpr int IMG = R * R;
-    static constexpr int HA = HB == 2 ? 4 : (HB == 1 ? 2 : 3);   // halo of layout A: 16 lanes of a row / a quad / 8 lanes
-    static constexpr int HBQ = HB == 2 ? 2 : (HB == 1 ? 0 : 1);  // halo of layout B: a quad / none / lane ^ 1
-};
-// HB = 2 (1024 x 1024 images, depth 7): a wavefront holds 8 columns of 1024 rows instead of 16 of 512 -- the same 64 x 64
-// float2 registers with index bit 9 where the top column-pair bit was: layout A lane = i[9:6] | cp << 4 (the 16 chunks of a
-// column are the 16 lanes of a DPP row), layout B lane = (i[9:8] | cp << 2) | i[1:0] << 4 (the 4 chunks are a quad), one
-// more level on register bit 4 of layout B.  The exchanges T1, T2 do not change (they never look at what the lane bits mean).
-// element offset of sample smp9 (9 bits: image-select bits above the row bits) of column col
-template <bool BL, int HB> __device__ __forceinline__ int64_t l2_src_off(int col, int smp9)
-{
-    typedef L2G<HB> G;
-    const int im = smp9 >> G::RB, smp = smp9 & (G::R - 1);
-    if constexpr (BL) return (int64_t)im * G::IMG + (int64_t)(smp / G::BW) * G::BLK + (int64_t)col * G::BW + (smp % G::BW);
-    else return (int64_t)im * G::IMG + (int64_t)col * G::R + smp;
-}
-// lane part of a load address: column half h, samples 64 i6 + 32 i5 + 4 sub
-template <bool BL, int HB> __device__ __forceinline__ unsigned l2_lane_off(int h, int i6, int i5, int sub)
-{
-    typedef L2G<HB> G;
-    if constexpr (!BL) return (unsigned)G::R * h + 64u * i6 + 32u * i5 + 4u * sub;
-    else if constexpr (G::BW == 64) return 64u * h + (unsigned)G::BLK * i6 + 32u * i5 + 4u * sub;
-    else return 32u * h + (unsigned)G::BLK * (2 * i6 + i5) + 4u * sub;          // blocks of 32 columns
-}
-template <int... I, typename F> __device__ __forceinline__ void l2_for_impl(std::integer_sequence<int, I...>, F &&f)
-{
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F> __device__ __forceinline__ void l2_for(F &&f)
-{
-    l2_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-template <int OFF> __device__ __forceinline__ void l2_wr32(unsigned addr, float v)
-{
-    asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
-}
-template <int OFF> __device__ __forceinline__ void l2_wr64(unsigned addr, f2 v)
-{
-    const double d = __builtin_bit_cast(double, v);
-    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(d), "n"(OFF) : "memory");
-}
-// the value of a pending LDS read stays an untouched 64-bit register pair until the wait: turning it into a float2 first
-// lets the compiler move its halves (it does not know the data has not landed) -- only l2_wait16 hands out float2
-template <int OFF> __device__ __forceinline__ double l2_rd64(unsigned addr)
-{
-    double d;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-    return d;
-}
-__device__ __forceinline__ void l2_wait8(double &a, double &b, double &c, double &d, double &e, double &f, double &g, double &h)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "memory");
-}
-__device__ __forceinline__ void l2_waitn(double (&x)[16])
-{
-    l2_wait8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
-    l2_wait8(x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15]);
-}
-__device__ __forceinline__ void l2_waitn(double (&x)[8]) { l2_wait8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]); }
-// keeps a coefficient pair in vector registers (see the note at l2_level)
-__device__ __forceinline__ void l2_vgpr(f2 &v)
-{
-    double d = __builtin_bit_cast(double, v);
-    asm volatile("" : "+v"(d));
-    v = __builtin_bit_cast(f2, d);
-}
-// workgroup barrier after inline-asm LDS stores: the compiler does not count them, so the wait that makes them visible to
-// the other wavefront is explicit (without it the transposed store raced: one image in a few hundred came out wrong)
-__device__ __forceinline__ void l2_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-    __syncthreads();
-}
-template <int CTRL> __device__ __forceinline__ int l2_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-
-// value held by the lane that owns the chunk D places further along the same column; HALO 3: the chunks of a column are
-// the 8 lanes that share lane >> 3 (cyclic); HALO 1: the 2 lanes lane, lane ^ 1
-template <int HALO, int D> __device__ __forceinline__ f2 l2_nbr(f2 v, bool edge_hi, bool edge_lo)
-{
-    if constexpr (D == 0 || HALO == 0) return v;
-    else {
-        // the element travels as one 64-bit register pair (two 32-bit DPP moves), exactly like the Float64 kernel's halo:
-        // per-component code on the float2 was merged by the compiler into one move for both halves
-        const double dv = __builtin_bit_cast(double, v);
-        const int lo = __double2loint(dv), hi = __double2hiint(dv);
-        int rlo, rhi;
-        if constexpr (HALO == 1) {
-            if constexpr ((D & 1) == 0) return v;
-            rlo = l2_dpp<0xB1>(lo);                                   // quad_perm [1,0,3,2]
-            rhi = l2_dpp<0xB1>(hi);
-        } else if constexpr (HALO == 2) {
-            // the four chunks of a sequence are the lanes of a quad (cyclic): lane q takes lane (q + D) mod 4
-            constexpr int E = ((D % 4) + 4) % 4;
-            if constexpr (E == 0) return v;
-            constexpr int SEL = ((0 + E) & 3) | (((1 + E) & 3) << 2) | (((2 + E) & 3) << 4) | (((3 + E) & 3) << 6);
-            rlo = l2_dpp<SEL>(lo);
-            rhi = l2_dpp<SEL>(hi);
-        } else if constexpr (HALO == 4) {
-            // the sixteen chunks of a column are the lanes of a DPP row (cyclic): row_ror:n, lane i takes lane i - n (mod 16)
-            static_assert(D > -16 && D < 16, "row rotations");
-            rlo = l2_dpp<0x120 + ((16 - D) & 15)>(lo);
-            rhi = l2_dpp<0x120 + ((16 - D) & 15)>(hi);
-        } else {
-            static_assert(D == 1 || D == -1, "layout A moves one chunk");
-            if constexpr (D > 0) {
-                // lanes 0..6 of a group of 8 take lane + 1 (row_shl:1), lane 7 takes lane - 7 (row_shr:7)
-                const int alo = l2_dpp<0x101>(lo), ahi = l2_dpp<0x101>(hi);
-                const int blo = l2_dpp<0x117>(lo), bhi = l2_dpp<0x117>(hi);
-                rlo = edge_hi ? blo : alo;
-                rhi = edge_hi ? bhi : ahi;
-            } else {
-                const int alo = l2_dpp<0x111>(lo), ahi = l2_dpp<0x111>(hi);
-                const int blo = l2_dpp<0x107>(lo), bhi = l2_dpp<0x107>(hi);
-                rlo = edge_lo ? blo : alo;
-                rhi = edge_lo ? bhi : ahi;
-            }
-        }
-        return __builtin_bit_cast(f2, __hiloint2double(rhi, rlo));
-    }
-}
-
-// one packet level on register-index bit K (see lat_level of wx_lattice.hip); both halves of an element (two adjacent
-// columns) take the same rotation: v_pk_fma_f32
-template <int K, int HALO, int NS, bool INV> __device__ __forceinline__ void l2_level(f2 (&x)[64], const WxLat2 &cf, int lane)
-{
-    constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
-    auto U = [](int s, int m) { return s + ((2 * m) << K); };
-    const bool edge_hi = (lane & 7) == 7, edge_lo = (lane & 7) == 0;
-    auto shift = [&](auto SHc) {
-        constexpr int SH = decltype(SHc)::value;
-        if constexpr (SH != 0) {
-#pragma unroll
-            for (int s = 0; s < NSEQ; ++s) {
-                f2 old[M];
-#pragma unroll
-                for (int m = 0; m < M; ++m) old[m] = x[U(s, m) + S];
-                l2_for<M>([&](auto Mc) {
-                    constexpr int m = Mc;
-                    constexpr int g = m + SH;
-                    constexpr int d = (g >= 0) ? g / M : -((-g + M - 1) / M);
-                    constexpr int src = g - d * M;
-                    x[U(s, m) + S] = l2_nbr<HALO, d>(old[src], edge_hi, edge_lo);
-                });
-            }
-        }
-    };
-    constexpr bool one_shot = (HALO != 3) || (NS - 1 <= M);
-    if constexpr (!INV) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            f2 pj = {cf.p[j], cf.p[j]}, kj = {-cf.kap[j], -cf.kap[j]};
-            l2_vgpr(pj);
-            l2_vgpr(kj);
-#pragma unroll
-            for (int s = 0; s < NSEQ; ++s)
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    x[U(s, m)] = __builtin_elementwise_fma(pj, x[U(s, m) + S], x[U(s, m)]);
-                    x[U(s, m) + S] = __builtin_elementwise_fma(kj, x[U(s, m)], x[U(s, m) + S]);
-                }
-            if (j + 1 < NS) shift(std::integral_constant<int, 1>{});
-        }
-        if constexpr (one_shot) shift(std::integral_constant<int, -(NS - 1)>{});
-        else {
-#pragma unroll
-            for (int j = 0; j + 1 < NS; ++j) shift(std::integral_constant<int, -1>{});
-        }
-    } else {
-        if constexpr (one_shot) shift(std::integral_constant<int, NS - 1>{});
-        else {
-#pragma unroll
-            for (int j = 0; j + 1 < NS; ++j) shift(std::integral_constant<int, 1>{});
-        }
-#pragma unroll
-        for (int j = NS - 1; j >= 0; --j) {
-            f2 pj = {-cf.p[j], -cf.p[j]}, kj = {cf.kap[j], cf.kap[j]};
-            l2_vgpr(pj);
-            l2_vgpr(kj);
-#pragma unroll
-            for (int s = 0; s < NSEQ; ++s)
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    x[U(s, m) + S] = __builtin_elementwise_fma(kj, x[U(s, m)], x[U(s, m) + S]);
-                    x[U(s, m)] = __builtin_elementwise_fma(pj, x[U(s, m) + S], x[U(s, m)]);
-                }
-            if (j > 0) shift(std::integral_constant<int, -1>{});
-        }
-    }
-}
-
-// A (reg i[5:0], lane i[8:6] | cp << 3)  ->  B (reg i[7:2], lane (i8 | cp << 1) | i[1:0] << 4): exchange T2 of
-// tools/lattice_lds_maps.py (the lane numbers are those of the Float64 kernel with p[11:9] = cp)
-__device__ __forceinline__ void l2_t2(f2 (&a)[64], f2 (&bb)[64], unsigned lds0, int lane)
-{
-    const int sw = lane ^ ((lane >> 5) << 1);
-    const unsigned wa0 = lds0 + 8u * sw, wa1 = lds0 + 8u * (sw ^ 1);
-    const int H = lane & 15, p10 = lane >> 4;
-    const int lam0 = 4 * H, sg = (p10 & 1) | ((lam0 >> 5) << 1);
-    unsigned ra[4];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) ra[h] = lds0 + 8u * (64 * p10 + ((lam0 + h) ^ sg));
-    l2_for<4>([&](auto Fq) {
-        constexpr int f = Fq;
-        l2_for<16>([&](auto Jq) {
-            constexpr int j = Jq;
-            l2_wr64<8 * 64 * j>((j & 1) ? wa1 : wa0, a[16 * f + j]);
-        });
-        l2_for<16 / WX_L2D_G>([&](auto Hq) {
-            constexpr int q0 = WX_L2D_G * Hq;
-            double t[WX_L2D_G];
-            l2_for<WX_L2D_G>([&](auto Q) {
-                constexpr int h = (q0 + Q) / 4, g = (q0 + Q) % 4;
-                t[Q] = l2_rd64<8 * 256 * g>(ra[h]);
-            });
-            l2_waitn(t);
-            l2_for<WX_L2D_G>([&](auto Q) {
-                constexpr int h = (q0 + Q) / 4, g = (q0 + Q) % 4;
-                bb[16 * h + 4 * f + g] = __builtin_bit_cast(f2, t[Q]);
-            });
-        });
-    });
-}
-
-// forward: src image (column j = 512 contiguous samples at src + 512 j) -> dst image transposed and in packet order:
-// dst[j + 512 o(i)], o(i) = bitreverse6(i[5:0]) << 3 | i[8:6].  grid (16, images), 128 threads.
-template <int NS, bool BL, bool BS, int HB>
-__global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_colT_f32(
-    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf)
-{
-    typedef L2G<HB> G;
-    __shared__ double lds[WX_L2D_W * WX_L2_WIN];
-    const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
-    // HB = 1: a workgroup takes two consecutive images; the last workgroup of an odd batch re-does the last two
-    const int64_t img0 = min((int)blockIdx.y << G::IB, last_img);
-    const float *simg = src + img0 * G::IMG;
-    float *dimg = dst + img0 * G::IMG;
-    const int j0 = 2 * G::NPW * (WX_L2D_W * blockIdx.x + wave);
-    f2 a[64];
-    {
-        // loads: instruction Q = (cp, i8, i7) [HB = 2: (cp, i9, i8, i7)] covers 8 complete lines: lane = sub | h << 3 | i5 << 4 |
-        // i6 << 5 holds samples i = 128 (Q mod QS) + 64 i6 + 32 i5 + 4 sub + {0..3} of column 2 cp + h
-        constexpr int QS = 32 / G::NPW;                   // instructions per column pair
-        const int sub = lane & 7, h = (lane >> 3) & 1, i5 = (lane >> 4) & 1, i6 = lane >> 5;
-        const unsigned lo = l2_lane_off<BL, HB>(h, i6, i5, sub);
-        f4 r[32];
-        l2_for<32>([&](auto Q) {
-            constexpr int cp = Q / QS, sq = Q % QS;
-            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL, HB>(j0 + 2 * cp, 128 * sq)) + lo);
-        });
-        // T1: the two columns of a pair meet in one 8-byte slot (two ds_write_b32): slot = 17 lam + m, lam = i[8:6] | cp << 3,
-        // m = i[5:2]; round rho = i[1:0]
-        const unsigned wa = lds0 + 4u * (34u * i6 + 2u * sub + 16u * i5 + h), ra = lds0 + 8u * 17u * lane;
-        l2_for<4>([&](auto Rq) {
-            constexpr int rho = Rq;
-            l2_for<32>([&](auto Q) {
-                l2_wr32<4 * 34 * 2 * Q>(wa, r[Q][rho]);      // lam = i6 | Q << 1: the lane of layout A
-            });
-            l2_for<16 / WX_L2D_G>([&](auto Hq) {
-                constexpr int m0 = WX_L2D_G * Hq;
-                double t[WX_L2D_G];
-                l2_for<WX_L2D_G>([&](auto M) {
-                    constexpr int m = m0 + M;
-                    t[M] = l2_rd64<8 * m>(ra);
-                });
-                l2_waitn(t);
-                l2_for<WX_L2D_G>([&](auto M) {
-                    constexpr int m = m0 + M;
-                    a[4 * m + rho] = __builtin_bit_cast(f2, t[M]);
-                });
-            });
-        });
-    }
-    constexpr int HA = G::HA, HBB = G::HBQ;               // halos of layouts A and B
-    l2_level<0, HA, NS, false>(a, cf, lane);
-    l2_level<1, HA, NS, false>(a, cf, lane);
-    f2 bb[64];
-    l2_t2(a, bb, lds0, lane);
-    l2_level<0, HBB, NS, false>(bb, cf, lane);
-    l2_level<1, HBB, NS, false>(bb, cf, lane);
-    l2_level<2, HBB, NS, false>(bb, cf, lane);
-    if constexpr (G::LD >= 6) l2_level<3, HBB, NS, false>(bb, cf, lane);
-    if constexpr (G::LD >= 7) l2_level<4, HBB, NS, false>(bb, cf, lane);
-    // gains: a leaf whose path took k detail branches carries g^(2k - LD); path bits i[1:0] sit in the lane, i[LD-1:2] in the
-    // register index
-    float gf[6];
-    {
-        float b = cf.g0;
-        b = (lane & 16) ? b * cf.g2 : b;
-        b = (lane & 32) ? b * cf.g2 : b;
-        gf[0] = b;
-#pragma unroll
-        for (int m = 1; m < 6; ++m) gf[m] = gf[m - 1] * cf.g2;
-    }
-    if constexpr (HB == 2) {
-        // 1024 rows: round rho fixes (i2, i3) -> 256 of the 1024 rows; a row of the workgroup is 4 W column pairs = 32 W bytes.
-        // row of the round = i8 | i9 << 1 | i7 << 2 | i6 << 3 | i5 << 4 | i4 << 5 | i1 << 6 | i0 << 7, slot = 16 row + (pair ^ 4 i9)
-        constexpr int RS = 4 * WX_L2D_W, LPR = 2 * WX_L2D_W, RPI = 64 * WX_L2D_W / LPR;
-        const int i8 = lane & 1, i9 = (lane >> 1) & 1, cp = (lane >> 2) & 3, i0 = (lane >> 4) & 1, i1 = lane >> 5;
-        const unsigned wa = ldsb + 8u * ((unsigned)RS * (i8 | (i9 << 1) | (i1 << 6) | (i0 << 7)) + (unsigned)((4 * wave + cp) ^ (4 * i9)));
-        l2_barrier();
-        l2_for<4>([&](auto Rq) {
-            constexpr int rho = Rq;
-            l2_for<16>([&](auto Vq) {
-                constexpr int v = Vq;                     // v bits: i4, i5, i6, i7
-                constexpr int r = rho + 4 * v;
-                constexpr int rowreg = (((v >> 3) & 1) << 2) | (((v >> 2) & 1) << 3) | (((v >> 1) & 1) << 4) | ((v & 1) << 5);
-                constexpr int pc = (rho & 1) + (rho >> 1) + (v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1);
-                f2 val = bb[r];
-                val.x *= gf[pc];
-                val.y *= gf[pc];
-                l2_wr64<8 * RS * rowreg>(wa, val);
-            });
-            l2_barrier();
-            l2_for<256 / RPI>([&](auto Kq) {
-                constexpr int k = Kq;
-                const int rr = RPI * k + tid / LPR, u = tid % LPR;
-                const int s9 = (rr >> 1) & 1;
-                const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (4 * s9))));
-                // o = i0 i1 i2 i3 i4 i5 i6 | i9 i8 i7 (bit 9 .. bit 0)
-                const int o = ((rr >> 2) & 1) | ((rr & 1) << 1) | (((rr >> 1) & 1) << 2) | (((rr >> 3) & 1) << 3) | (((rr >> 4) & 1) << 4) |
-                              (((rr >> 5) & 1) << 5) | ((rho >> 1) << 6) | ((rho & 1) << 7) | (((rr >> 6) & 1) << 8) | ((rr >> 7) << 9);
-                l2_st(l2_sbase(dimg + (BS ? G::BLK : G::BW) * blockIdx.x) + (unsigned)((BS ? G::BW : G::R) * o + 4 * u), val);
-            });
-            l2_barrier();
-        });
-        return;
-    }
-    // transposed store: round rho fixes (i2, i3) = register bits 0, 1 -> 128 of the 512 rows o(i); a row of the
-    // workgroup is 8 W column pairs = 64 W bytes.  slot = 8 W row + (pair ^ 8 i8)
-    constexpr int RS = 8 * WX_L2D_W, LPR = 4 * WX_L2D_W, RPI = 16;           // slots per row, lanes per row, rows per read
-    const int i8 = lane & 1, cp = (lane >> 1) & 7, i0 = (lane >> 4) & 1, i1 = lane >> 5;
-    const unsigned wa = ldsb + 8u * ((unsigned)RS * ((i8 << 2) | (i1 << 5) | (i0 << 6)) + (unsigned)((8 * wave + cp) ^ (8 * i8)));
-    l2_barrier();                                      // the exchange windows are reused as the row buffer
-    l2_for<4>([&](auto Rq) {
-        constexpr int rho = Rq;
-        l2_for<16>([&](auto Vq) {
-            constexpr int v = Vq;                         // v bits: i4, i5, i6, i7
-            constexpr int r = rho + 4 * v;
-            constexpr int rowreg = ((v & 1) << 4) | (((v >> 1) & 1) << 3) | (((v >> 3) & 1) << 1) | ((v >> 2) & 1);
-            constexpr int pc = (rho & 1) + (rho >> 1) + (v & 1) + (HB == 0 ? ((v >> 1) & 1) : 0);
-            f2 val = bb[r];
-            val.x *= gf[pc];
-            val.y *= gf[pc];
-            l2_wr64<8 * RS * rowreg>(wa, val);
-        });
-        l2_barrier();
-        l2_for<128 / RPI>([&](auto Kq) {
-            constexpr int k = Kq;
-            const int rr = RPI * k + tid / LPR, u = tid % LPR;
-            const int o2 = (rr >> 2) & 1;
-            const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (8 * o2))));
-            // row bits: i6 = rr0, i7 = rr1, i8 = rr2, i5 = rr3, i4 = rr4, i1 = rr5, i0 = rr6, i2 = rho0, i3 = rho1;
-            // o = bitreverse(i[LD-1:0]) above i[RB-1:LD]; HB = 1: i8 selects the image
-            int o, im = 0;
-            if constexpr (HB == 0) o = (rr & 31) | ((rho >> 1) << 5) | ((rho & 1) << 6) | ((rr >> 5) << 7);
-            else {
-                o = ((rr >> 3) & 1) | ((rr & 3) << 1) | (((rr >> 4) & 1) << 3) | ((rho >> 1) << 4) | ((rho & 1) << 5) | (((rr >> 5) & 1) << 6) |
-                    ((rr >> 6) << 7);
-                im = (rr >> 2) & 1;
-            }
-            l2_st(l2_sbase(dimg + (BS ? G::BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * o + 4 * u), val);
-        });
-        l2_barrier();
-    });
-}
-
-// B -> A (exchange T2i of tools/lattice_lds_maps.py)
-__device__ __forceinline__ void l2_t2i(f2 (&bb)[64], f2 (&a)[64], unsigned lds0, int lane)
-{
-    const int H = lane & 15, p10 = lane >> 4;
-    unsigned wa[4];
-#pragma unroll
-    for (int h = 0; h < 4; ++h)
-        wa[h] = lds0 + 8u * (((h ^ (H >> 2)) | ((H & 3) << 2) | (((H >> 2) & 1) << 4) | ((H >> 3) << 5)) + 64 * p10);
-    const int Ha = lane >> 2, ha = lane & 3;
-    const unsigned ra = lds0 + 8u * ((ha ^ (Ha >> 2)) | ((Ha & 3) << 2) | (((Ha >> 2) & 1) << 4) | ((Ha >> 3) << 5));
-    l2_for<4>([&](auto Fq) {
-        constexpr int f = Fq;
-        l2_for<16>([&](auto Q) {
-            constexpr int h = Q / 4, g = Q % 4;
-            l2_wr64<8 * 256 * g>(wa[h], bb[16 * h + 4 * f + g]);
-        });
-        l2_for<16 / WX_L2D_G>([&](auto Hq) {
-            constexpr int j0 = WX_L2D_G * Hq;
-            double t[WX_L2D_G];
-            l2_for<WX_L2D_G>([&](auto Jq) {
-                constexpr int j = j0 + Jq;
-                t[Jq] = l2_rd64<8 * 64 * j>(ra);
-            });
-            l2_waitn(t);
-            l2_for<WX_L2D_G>([&](auto Jq) {
-                constexpr int j = j0 + Jq;
-                a[16 * f + j] = __builtin_bit_cast(f2, t[Jq]);
-            });
-        });
-    });
-}
-
-// inverse: src image (column j = 512 contiguous packet coefficients, position o(i) = bitreverse6(i[5:0]) << 3 | i[8:6]) ->
-// dst image transposed, natural order: dst[j + 512 i].  grid (16, images), 128 threads.
-template <int NS, bool BL, bool BS, int HB>
-__global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_icolT_f32(
-    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf)
-{
-    typedef L2G<HB> G;
-    __shared__ double lds[HB == 2 ? (256 * 18 > WX_L2D_W * WX_L2_WIN ? 256 * 18 : WX_L2D_W * WX_L2_WIN) : WX_L2D_W * WX_L2_WIN];
-    const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
-    const int64_t img0 = min((int)blockIdx.y << G::IB, last_img);
-    const float *simg = src + img0 * G::IMG;
-    float *dimg = dst + img0 * G::IMG;
-    const int j0 = 2 * G::NPW * (WX_L2D_W * blockIdx.x + wave);
-    f2 bb[64];
-    {
-        // loads as in the forward kernel, in packet order: lane = sub | h << 3 | o5 << 4 | o6 << 5, instruction (cp, o7, o8);
-        // memory index bits m8 .. m0 = (o8, o7, o6, o5, sub[2], sub[1], sub[0], component[1], component[0])
-        //   HB = 0:  m8 .. m0 = i0 i1 i2 i3 i4 i5 i8 i7 i6        (packet order of depth 6 over 512 rows)
-        //   HB = 1:  m8 .. m0 = i8 i0 i1 i2 i3 i4 i7 i6 i5        (image select, packet order of depth 5 over 256 rows)
-        const int sub = lane & 7, h = (lane >> 3) & 1, o5 = (lane >> 4) & 1, o6 = lane >> 5;
-        constexpr int QS = 32 / G::NPW;
-        const unsigned lo = l2_lane_off<BL, HB>(h, o6, o5, sub);
-        f4 r[32];
-        l2_for<32>([&](auto Q) {
-            constexpr int cp = Q / QS, sq = Q % QS;
-            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL, HB>(j0 + 2 * cp, 128 * sq)) + lo);
-        });
-        // into layout B (reg i[7:2], lane mu = i8 | cp << 1 | i0 << 4 | i1 << 5): a round (the component of the loaded
-        // vectors) fixes two register bits, the lane reads its 16 other registers out of row mu: slot = 17 mu + w
-        //   HB = 0: round = (i6, i7) = register bits 4, 5;  w = i2 | i3 << 1 | i4 << 2 | i5 << 3 = register bits 0 .. 3
-        //   HB = 1: round = (i5, i6) = register bits 3, 4;  w = i2 | i3 << 1 | i4 << 2 | i7 << 3 = register bits 0, 1, 2, 5
-        // gains: the coefficient of a leaf whose path took k detail branches enters as coef * g^(2k - LD)
-        float gf[6];
-        {
-            float b = cf.g0;
-            b = (lane & 16) ? b * cf.g2 : b;
-            b = (lane & 32) ? b * cf.g2 : b;
-            gf[0] = b;
-#pragma unroll
-            for (int m = 1; m < 6; ++m) gf[m] = gf[m - 1] * cf.g2;
-        }
-        if constexpr (HB == 2) {
-            //   HB = 2:  m9 .. m0 = i0 i1 i2 i3 i4 i5 i6 i9 i8 i7 (packet order of depth 7 over 1024 rows); lane mu = i8 | i9 << 1 |
-            //   cp << 2 | i0 << 4 | i1 << 5.  The component (round) carries (i7, i8): i8 is a LANE bit of the target, so in a round
-            //   the 32 lanes with that i8 read 32 registers each (i7 fixed) out of row mu >> 1: slot = 33 (mu >> 1) + w,
-            //   w = i2 | i3 << 1 | i4 << 2 | i5 << 3 | i6 << 4
-            const unsigned wa = lds0 + 4u * (2u * (33u * (sub & 1) + 2u * o6 + 4u * o5 + 8u * (sub >> 2) + 16u * ((sub >> 1) & 1)) + h);
-            const unsigned ra = lds0 + 8u * 33u * (lane >> 1);
-            l2_for<4>([&](auto Rq) {
-                constexpr int rho = Rq;                   // rho bit 0 = i7, bit 1 = i8
-                l2_for<32>([&](auto Q) {
-                    constexpr int cp = Q / 8, i0 = (Q >> 2) & 1, i1 = (Q >> 1) & 1, i2 = Q & 1;
-                    l2_wr32<4 * 2 * (33 * (2 * cp + 8 * i0 + 16 * i1) + i2)>(wa, r[Q][rho]);
-                });
-                if ((lane & 1) == (rho >> 1)) {
-                    l2_for<2>([&](auto Hq) {
-                        constexpr int w0 = 16 * Hq;
-                        double t[16];
-                        l2_for<16>([&](auto V) {
-                            constexpr int w = w0 + V;
-                            t[V] = l2_rd64<8 * w>(ra);
-                        });
-                        l2_waitn(t);
-                        l2_for<16>([&](auto V) {
-                            constexpr int w = w0 + V;
-                            constexpr int pc = (w & 1) + ((w >> 1) & 1) + ((w >> 2) & 1) + ((w >> 3) & 1) + ((w >> 4) & 1);
-                            f2 e = __builtin_bit_cast(f2, t[V]);
-                            e.x *= gf[pc];
-                            e.y *= gf[pc];
-                            bb[w | ((rho & 1) << 5)] = e;
-                        });
-                    });
-                }
-            });
-        } else {
-        unsigned wa;
-        if constexpr (HB == 0) {
-            const int i8 = sub & 1, i5 = (sub >> 1) & 1, i4 = sub >> 2;
-            wa = lds0 + 4u * (34u * i8 + 2u * (o6 + 2u * o5 + 4u * i4 + 8u * i5) + h);
-        } else {
-            const int i7 = sub & 1, i4 = (sub >> 1) & 1, i3 = sub >> 2;
-            wa = lds0 + 4u * (34u * 32u * o6 + 2u * (o5 + 2u * i3 + 4u * i4 + 8u * i7) + h);
-        }
-        const unsigned ra = lds0 + 8u * 17u * lane;
-        l2_for<4>([&](auto Rq) {
-            constexpr int rho = Rq;
-            l2_for<32>([&](auto Q) {
-                constexpr int cp = Q >> 2, q0 = Q & 1, q1 = (Q >> 1) & 1;                 // (o7, o8)
-                // HB = 0: o7 = i1 (mu bit 5), o8 = i0 (mu bit 4);  HB = 1: o7 = i0 (mu bit 4), o8 = i8 (mu bit 0)
-                constexpr int mu_i = HB == 0 ? (2 * cp + 16 * q1 + 32 * q0) : (q1 + 2 * cp + 16 * q0);
-                l2_wr32<4 * 34 * mu_i>(wa, r[Q][rho]);
-            });
-            l2_for<16 / WX_L2D_G>([&](auto Hq) {
-                constexpr int v0 = WX_L2D_G * Hq;
-                double t[WX_L2D_G];
-                l2_for<WX_L2D_G>([&](auto V) {
-                    constexpr int v = v0 + V;
-                    t[V] = l2_rd64<8 * v>(ra);
-                });
-                l2_waitn(t);
-                l2_for<WX_L2D_G>([&](auto V) {
-                    constexpr int v = v0 + V;
-                    f2 e = __builtin_bit_cast(f2, t[V]);
-                    if constexpr (HB == 0) {
-                        constexpr int pc = (v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1) + ((v >> 3) & 1);
-                        e.x *= gf[pc];
-                        e.y *= gf[pc];
-                        bb[v + 16 * rho] = e;             // register index i[7:2] = v | i6 << 4 | i7 << 5
-                    } else {
-                        constexpr int pc = (v & 1) + ((v >> 1) & 1) + ((v >> 2) & 1);
-                        e.x *= gf[pc];
-                        e.y *= gf[pc];
-                        bb[(v & 7) | ((rho & 1) << 3) | ((rho >> 1) << 4) | ((v >> 3) << 5)] = e;
-                    }
-                });
-            });
-        });
-        }
-    }
-    constexpr int HA = G::HA, HBB = G::HBQ;
-    if constexpr (G::LD >= 7) l2_level<4, HBB, NS, true>(bb, cf, lane);
-    if constexpr (G::LD >= 6) l2_level<3, HBB, NS, true>(bb, cf, lane);
-    l2_level<2, HBB, NS, true>(bb, cf, lane);
-    l2_level<1, HBB, NS, true>(bb, cf, lane);
-    l2_level<0, HBB, NS, true>(bb, cf, lane);
-    f2 a[64];
-    l2_t2i(bb, a, lds0, lane);
-    l2_level<1, HA, NS, true>(a, cf, lane);
-    l2_level<0, HA, NS, true>(a, cf, lane);
-    if constexpr (HB == 2) {
-        // 1024 rows, natural order: layout A (reg i[5:0], lane i[9:6] | cp << 4); round rho = i[5:4]; row of the round
-        // rr = i[9:6] | i[3:0] << 4 (the 16 lanes of a write land in 16 consecutive rows of 18 slots: no bank is hit twice)
-        constexpr int RS = 18, LPR = 2 * WX_L2D_W, RPI = 64 * WX_L2D_W / LPR;
-        const int i96 = lane & 15, cp = lane >> 4;
-        const unsigned wa = ldsb + 8u * ((unsigned)RS * (unsigned)i96 + (unsigned)(4 * wave + cp));
-        l2_barrier();
-        l2_for<4>([&](auto Rq) {
-            constexpr int rho = Rq;
-            l2_for<16>([&](auto Vq) {
-                constexpr int v = Vq;                     // i[3:0]
-                l2_wr64<8 * RS * 16 * v>(wa, a[v + 16 * rho]);
-            });
-            l2_barrier();
-            l2_for<256 / RPI>([&](auto Kq) {
-                constexpr int k = Kq;
-                const int rr = RPI * k + tid / LPR, u = tid % LPR;
-                const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)(2 * u)));
-                const int i = (rr >> 4) | (rho << 4) | ((rr & 15) << 6);
-                l2_st(l2_sbase(dimg + (BS ? G::BLK : G::BW) * blockIdx.x) + (unsigned)((BS ? G::BW : G::R) * i + 4 * u), val);
-            });
-            l2_barrier();
-        });
-        return;
-    }
-    // transposed store, natural row order: layout A (reg i[5:0], lane i[8:6] | cp << 3); round rho = i[5:4];
-    // row of the round rr = i[3:0] | i[8:6] << 4, slot = 8 W rr + (pair ^ i[8:6] << 1)
-    constexpr int RS = 8 * WX_L2D_W, LPR = 4 * WX_L2D_W, RPI = 16;
-    const int i86 = lane & 7, cp = lane >> 3;
-    const unsigned wa = ldsb + 8u * ((unsigned)RS * (unsigned)(i86 << 4) + (unsigned)((8 * wave + cp) ^ (i86 << 1)));
-    l2_barrier();
-    l2_for<4>([&](auto Rq) {
-        constexpr int rho = Rq;
-        l2_for<16>([&](auto Vq) {
-            constexpr int v = Vq;                         // i[3:0]
-            l2_wr64<8 * RS * v>(wa, a[v + 16 * rho]);
-        });
-        l2_barrier();
-        l2_for<128 / RPI>([&](auto Kq) {
-            constexpr int k = Kq;
-            const int rr = RPI * k + tid / LPR, u = tid % LPR;
-            const int s86 = rr >> 4;
-            const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (s86 << 1))));
-            const int i9 = (rr & 15) | (rho << 4) | (s86 << 6), im = i9 >> G::RB, i = i9 & (G::R - 1);
-            l2_st(l2_sbase(dimg + (BS ? G::BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * i + 4 * u), val);
-        });
-        l2_barrier();
-    });
-}
-
-}  // namespace
+int wx_lattice2d_launch_256(const float *, float *, int64_t, int64_t, const WxFilt &, bool, int, hipStream_t);    // wx_lattice2d_256.hip
+int wx_lattice2d_launch_1024(const float *, float *, int64_t, int64_t, const WxFilt &, bool, int, hipStream_t);   // wx_lattice2d_1024.hip
 
 bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz)
 {
     static const bool off = getenv("WX_LATTICE2D") && atoi(getenv("WX_LATTICE2D")) == 0;
     const bool shape = (m == 512 && n == 512 && L == 6) || (m == 256 && n == 256 && L == 5) || (m == 1024 && n == 1024 && L == 7);
-    return !off && esz == 4 && shape && filt.F >= 2 && filt.F / 2 <= WX_L2_MAXS;
+    return !off && esz == 4 && shape && filt.F >= 2 && (filt.F & 1) == 0 && filt.F / 2 <= WX_L2_MAXS;
 }
 
 // one transposing pass over `batch` images of side `m` (512: depth 6, 256: depth 5, 1024: depth 7): 0 = not applicable,
 // 1 = launched, < 0 = error.  pass 0: natural image in, transposed image out (what one application of the kernel is);
-// pass 1 / 2: the first / second pass of a transform, with the intermediate image in the blocked layout above (the caller's
-// scratch buffer, never seen outside the library).
+// pass 1 / 2: the first / second pass of a transform, with the intermediate image in the blocked layout of wx_lattice2d.h (the
+// caller's scratch buffer, never seen outside the library).
 int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t m, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
 {
-    static const bool blocked = WX_L2D_W == 4 && !(getenv("WX_L2D_BLOCKED") && atoi(getenv("WX_L2D_BLOCKED")) == 0);
-    const int hb = m == 512 ? 0 : (m == 256 ? 1 : (m == 1024 ? 2 : -1));
-    if (hb < 0) return 0;
-    const int LD = hb == 2 ? 7 : 6 - hb;
-    double p[WX_L2_MAXS], kap[WX_L2_MAXS], g0, g2;
-    if (!wx_lattice_coeffs(filt, LD, inverse, p, kap, &g0, &g2)) return 0;
-    WxLat2 cf;
-    for (int j = 0; j < WX_L2_MAXS; ++j) { cf.p[j] = (float)p[j]; cf.kap[j] = (float)kap[j]; }
-    cf.g0 = (float)g0;
-    cf.g2 = (float)g2;
-    const int64_t per = hb == 1 ? 2 : 1, units = (batch + per - 1) / per;
-    if (batch < per || units > 65535 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return 0;
-    if ((batch & (per - 1)) && src == dst) return 0;          // the last workgroup re-does images: out of place only
-    const bool bl = blocked && pass == 2, bs = blocked && pass == 1;
-    const int cols_wg = (hb == 2 ? 8 : 16) * WX_L2D_W;
-    const dim3 grid((unsigned)(m / cols_wg), (unsigned)units), wg(64 * WX_L2D_W);
-    const int last_img = (int)(batch - per);
-#define WX_GO2K(K, NSS, HBB)                                                                                             \
-    do {                                                                                                                 \
-        if (bl) hipLaunchKernelGGL((K<NSS, true, false, HBB>), grid, wg, 0, st, src, dst, last_img, cf);                 \
-        else if (bs) hipLaunchKernelGGL((K<NSS, false, true, HBB>), grid, wg, 0, st, src, dst, last_img, cf);            \
-        else hipLaunchKernelGGL((K<NSS, false, false, HBB>), grid, wg, 0, st, src, dst, last_img, cf);                   \
-    } while (0)
-#define WX_GO2(NSS)                                                                                                      \
-    case NSS:                                                                                                            \
-        if (inverse && hb == 2) WX_GO2K(k_lat2d_icolT_f32, NSS, 2);                                                      \
-        else if (inverse && hb == 1) WX_GO2K(k_lat2d_icolT_f32, NSS, 1);                                                 \
-        else if (inverse) WX_GO2K(k_lat2d_icolT_f32, NSS, 0);                                                            \
-        else if (hb == 2) WX_GO2K(k_lat2d_colT_f32, NSS, 2);                                                             \
-        else if (hb == 1) WX_GO2K(k_lat2d_colT_f32, NSS, 1);                                                             \
-        else WX_GO2K(k_lat2d_colT_f32, NSS, 0);                                                                          \
-        break;
-    switch (filt.F / 2) {
-        WX_GO2(1) WX_GO2(2) WX_GO2(3) WX_GO2(4) WX_GO2(5) WX_GO2(6) WX_GO2(8)
-    default: return 0;
-    }
-#undef WX_GO2
-#undef WX_GO2K
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return wx_set_hip_error(e, "lattice2d launch", __FILE__, __LINE__);
-    return 1;
+    if (m == 512) return wx_lattice2d_launch<0>(src, dst, m, batch, filt, inverse, pass, st);
+    if (m == 256) return wx_lattice2d_launch_256(src, dst, m, batch, filt, inverse, pass, st);
+    if (m == 1024) return wx_lattice2d_launch_1024(src, dst, m, batch, filt, inverse, pass, st);
+    return 0;
 }

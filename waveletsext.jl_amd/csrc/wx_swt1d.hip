@@ -1054,7 +1054,7 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         KF kf = ac ? k_sdwt_fused<T, true, 0> : k_sdwt_fused<T, false, 0>;
         if (!ac) switch (filt.F) {
 #define WX_CASE(FF) case FF: kf = k_sdwt_fused<T, false, FF>; break;
-            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(14) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
             default: break;                              // other lengths: runtime tap loop
         }
@@ -1077,7 +1077,7 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         KFI ki = ac ? k_sdwt_fused_ip<T, true, NPT, 0> : k_sdwt_fused_ip<T, false, NPT, 0>;
         if (!ac) switch (filt.F) {
 #define WX_CASE(FF) case FF: ki = k_sdwt_fused_ip<T, false, NPT, FF>; break;
-            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(14) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
             default: break;
         }
@@ -1310,7 +1310,7 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
         KI ki = pipe ? k_isdwt_avg_fused<T, 0, true> : k_isdwt_avg_fused<T, 0, false>;
         switch (filt.F) {
 #define WX_CASE(FF) case FF: ki = pipe ? k_isdwt_avg_fused<T, FF, true> : k_isdwt_avg_fused<T, FF, false>; break;
-            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(16) WX_CASE(18) WX_CASE(20)
+            WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(14) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
             default: break;
         }
