@@ -1,0 +1,49 @@
+"""dwt / idwt (the pyramid) of long Float64 signals, 16384 .. 65536 samples: tiled top levels on the approximation branch, then
+the 4096-sample pyramid on the tree-driven lattice kernels reading / writing with the long signal's stride, the deepest levels
+lane-locally (csrc/wx_dwt1d.hip: wx_dev_dwt_long / wx_dev_idwt_long).
+
+Reference: Wavelets.jl dwt / idwt as called by dwtall / idwtall (dwt/dwt_all.jl:33-121) = wpt / iwpt along maketree(n, L, :dwt).
+Float64, 1e-10 relative.
+"""
+import numpy as np
+import pytest
+
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [16384, 32768, 65536])
+@pytest.mark.parametrize("wname", ["haar", "db4", "db7", "coif6"])
+def test_long_pyramids_match_oracle(wx, oracle, n, wname):
+    rng = np.random.default_rng(n + len(wname))
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    Lmax = wx.maxtransformlevels(n)
+    dl = int(np.log2(n // 4096))
+    B = 3
+    x = np.asfortranarray(rng.standard_normal((n, B)))
+    # full depth (lane-local tail), a depth that ends inside the lattice part, one that ends in the tiled top levels, depth 1
+    for L in (Lmax, dl + 3, dl, 1):
+        tree = np.asarray(wx.maketree(n, L, "dwt"))
+        exp = oracle.wptall(x, wt.qmf, tree)
+        got = wx.wptall(x, wt, tree)
+        assert relerr(got, exp) <= 1e-10, (n, wname, L)
+        back = wx.iwptall(exp, wt, tree)
+        assert relerr(back, x) <= 1e-10, (n, wname, L)
+    # the named entry points
+    assert relerr(wx.dwtall(x, wt), oracle.wptall(x, wt.qmf, np.asarray(wx.maketree(n, Lmax, "dwt")))) <= 1e-10
+    assert relerr(wx.idwtall(wx.dwtall(x, wt), wt), x) <= 1e-10
+
+
+def test_long_pyramid_device_batch_round_trips(wx):
+    import torch
+    wt = wx.wavelet(wx.WT.db4)
+    n, B = 16384, 1000
+    x = wx.jl_empty((n, B), torch.float64, "cuda")
+    x.normal_(generator=torch.Generator(device="cuda").manual_seed(3))
+    y = wx.dwtall(x, wt)
+    xr = wx.idwtall(y, wt)
+    err = (xr - x).abs().amax(dim=0) / x.abs().max()
+    assert float(err.max()) <= 1e-12, int(err.argmax())
+    # linearity / energy: an orthogonal transform keeps the norm of every signal
+    assert float(((y * y).sum(dim=0) / (x * x).sum(dim=0) - 1).abs().max()) <= 1e-12

@@ -90,7 +90,8 @@ static int wx_resolve_tree1d(int64_t n, int L, const uint8_t *tree, int64_t ntre
 // levels and the pyramid cut above them in `cut`; 0 otherwise.  The inverse feeds the 64 rebuilt samples to the loads of the
 // fused tree-driven kernel: that kernel must apply, and the remaining pyramid must not be a full tree (other kernels).
 template <typename T>
-static int wx_pyramid_tail(int64_t n, int F, bool inverse, const uint8_t *tree, int64_t ntree, std::vector<uint8_t> &cut)
+static int wx_pyramid_tail(int64_t n, int F, bool inverse, const uint8_t *tree, int64_t ntree, std::vector<uint8_t> &cut, const WxFilt &filt,
+                           bool allow_long = false)
 {
     if (!tree || wx_force_generic()) return 0;
     const int Ld = wx_tree_depth1d(tree, ntree);
@@ -98,7 +99,7 @@ static int wx_pyramid_tail(int64_t n, int F, bool inverse, const uint8_t *tree, 
     for (int64_t i = 1; i <= ntree && pyramid; ++i) pyramid = (tree[i - 1] != 0) == ((i & (i - 1)) == 0 && i < ((int64_t)1 << Ld));
     if (!pyramid) return 0;
     const int tail = wx_dwt_tail_levels(n, Ld, F, sizeof(T));
-    if (!tail || (inverse && !(wx_fused1d_ok<T>(n, F) && Ld - tail >= 2))) return 0;
+    if (!tail || (inverse && !((wx_fused1d_ok<T>(n, F) || (allow_long && wx_dwt_long_ok<T>(n, filt))) && Ld - tail >= 2))) return 0;
     cut.assign(tree, tree + ntree);
     for (int64_t i = (int64_t)1 << (Ld - tail); i <= ntree; ++i) cut[i - 1] = 0;
     return tail;
@@ -126,9 +127,15 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     std::vector<uint8_t> ttree;
     // (measured, 65536 x 4096 Float64 db4, depth-12 pyramid: the whole pyramid through the tree-driven lattice kernels 1.22 /
     // 1.51 ms, with the tail 1.15 / 1.00 ms -- the tail stays; the levels above it take the lattice in the forward direction)
-    const int tail = wx_pyramid_tail<T>(n, F, INVERSE, tree, ntree, ttree);
+    const int tail = wx_pyramid_tail<T>(n, F, INVERSE, tree, ntree, ttree, filt, true);
     if (tail) tree = ttree.data();
     if ((rc = wx_resolve_tree1d(n, L, tree, ntree, scr, &tr, "wpt"))) return rc;
+    // the pyramid of a long signal (dwt / idwt of 16384 .. 65536 samples): tiled top levels + the lattice (wx_dev_dwt_long)
+    bool longp = false;
+    if (tree && tr.dstatus && tr.Leff >= 1 && !wx_force_generic() && wx_dwt_long_ok<T>(n, filt)) {
+        longp = true;
+        for (int64_t i = 1; i <= ntree && longp; ++i) longp = (tree[i - 1] != 0) == ((i & (i - 1)) == 0 && i < ((int64_t)1 << tr.Leff));
+    }
     WxIO io(st);
     const T *dx = (const T *)io.in(x, sizeof(T) * n * batch);
     T *dy = (T *)io.out(y, sizeof(T) * n * batch);
@@ -138,9 +145,25 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     const bool fused = !force && wx_fused1d_ok<T>(n, F);
     // long Float64 signals with a full tree take one pass per top level and then the lattice kernels: one scratch array
     const bool long_lattice = !force && !tr.dstatus && n > 4096 && n <= 65536 && tr.Leff > 1;
-    if (((!fused && tr.Leff > 1) || long_lattice) && batch) {
+    if (((!fused && tr.Leff > 1) || long_lattice || longp) && batch) {
         s1 = (T *)scr.alloc(sizeof(T) * n * batch);
         if (!s1) return io.finish(WX_EHIP);
+    }
+    if (longp && batch && dx != dy) {
+        if (INVERSE) {
+            WxThreshArg thr{nullptr, 0, 0, 0, 1.0};
+            if (tail) {
+                T *head = (T *)scr.alloc(sizeof(T) * 64 * batch);
+                if (!head) return io.finish(WX_EHIP);
+                if ((rc = wx_idwt_tail<T>(dx, head, n, tail, batch, filt, thr, st))) return io.finish(rc);
+                thr.head = head;
+            }
+            rc = wx_dev_idwt_long<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, thr, s1, st);
+        } else {
+            rc = wx_dev_dwt_long<T>(dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, s1, st);
+            if (rc == WX_OK && tail) rc = wx_dwt_tail<T>(dy, n, tail, batch, filt, st);
+        }
+        return io.finish(rc);
     }
     if (INVERSE && tail && batch) {
         T *head = (T *)scr.alloc(sizeof(T) * 64 * batch);
@@ -178,7 +201,7 @@ static int api_iwpt1d_thresh(const T *x, T *y, int64_t n, int L, const uint8_t *
                     "maketree: isdyadic(n) and 0 <= L <= maxtransformlevels(n)");
     if ((rc = wx_need_device())) return rc;
     std::vector<uint8_t> ttree;
-    const int tail = wx_pyramid_tail<T>(n, F, true, tree, ntree, ttree);      // denoise(:dwt): the pyramid's deep levels lane-locally
+    const int tail = wx_pyramid_tail<T>(n, F, true, tree, ntree, ttree, filt);   // denoise(:dwt): the pyramid's deep levels lane-locally
     if (tail) tree = ttree.data();
     if ((rc = wx_resolve_tree1d(n, L, tree, ntree, scr, &tr, "iwpt"))) return rc;
     WxIO io(st);

@@ -112,9 +112,14 @@ __global__ __launch_bounds__(256) void k_inv1d_level(const T *__restrict__ src, 
 // k_inv1d_level.  Used for the top levels of signals of 16384 samples and more (wx_dev_wpt1d / wx_dev_iwpt1d).
 constexpr int WX_LT = 2048;                                  // output pairs per tile
 
+// Split form (the pyramid of a long signal, wx_dev_dwt_long / wx_dev_idwt_long): the detail half lives elsewhere -- forward:
+// approximations to dst, details to dst2; inverse: approximations from src, details from src2 (each with its own stride
+// between signals); src2 / dst2 = nullptr: the two halves are one array as above.
 template <typename T, bool INVERSE>
 __global__ __launch_bounds__(256) void k_level1_tile(const T *__restrict__ src, T *__restrict__ dst, int np, int nper,
-                                                     int64_t src_stride, int64_t dst_stride, WxFilt filt)
+                                                     int64_t src_stride, int64_t dst_stride, WxFilt filt,
+                                                     const T *__restrict__ src2 = nullptr, int64_t src2_stride = 0,
+                                                     T *__restrict__ dst2 = nullptr, int64_t dst2_stride = 0)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     T *buf = reinterpret_cast<T *>(wx_smem);
@@ -126,6 +131,8 @@ __global__ __launch_bounds__(256) void k_level1_tile(const T *__restrict__ src, 
     const int64_t jn = node - sig * nper;
     const T *v = src + sig * src_stride + jn * (int64_t)np;
     T *o = dst + sig * dst_stride + jn * (int64_t)np;
+    const T *vd = src2 ? src2 + sig * src2_stride + jn * (int64_t)np : v + (np >> 1);      // details in (inverse)
+    T *od = dst2 ? dst2 + sig * dst2_stride + jn * (int64_t)np : o + (np >> 1);           // details out (forward)
     if (!INVERSE) {
         // inputs 2 t0 - (F - 2) .. 2 t0 + 2 WX_LT + F - 2 (mod np): buf[e] = v[(2 t0 - (F - 2) + e) mod np]
         const int cnt = 2 * WX_LT + 2 * F - 3;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void k_level1_tile(const T *__restrict__ src, 
                 ++k1; --k2;
             }
             o[t0 + t] = (T)a;
-            o[h + t0 + t] = (T)d;
+            od[t0 + t] = (T)d;
         }
     } else {
         // a[k - m], m = 0 .. F/2 - 1 and d[k + m]: bufA[e] = a[(t0 - (F/2 - 1) + e) mod h], bufD[e] = d[(t0 + e) mod h]
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(256) void k_level1_tile(const T *__restrict__ src, 
         T *bufA = buf, *bufD = buf + cnt + 1;
         for (int e = threadIdx.x; e < cnt; e += 256) {
             bufA[e] = v[wx_modn(t0 - (HF - 1) + e, h)];
-            bufD[e] = v[h + wx_modn(t0 + e, h)];
+            bufD[e] = vd[wx_modn(t0 + e, h)];
         }
         __syncthreads();
         for (int t = threadIdx.x; t < WX_LT; t += 256) {
@@ -171,13 +178,14 @@ __global__ __launch_bounds__(256) void k_level1_tile(const T *__restrict__ src, 
 // one full level of every node of np samples (np a multiple of 2 WX_LT): nper nodes per signal, `nsig` signals
 template <typename T, bool INVERSE>
 static int launch_level1_tile(const T *src, T *dst, int64_t np, int64_t nper, int64_t nsig, int64_t src_stride, int64_t dst_stride,
-                              const WxFilt &filt, hipStream_t st)
+                              const WxFilt &filt, hipStream_t st, const T *src2 = nullptr, int64_t src2_stride = 0, T *dst2 = nullptr,
+                              int64_t dst2_stride = 0)
 {
     const int64_t grid = nper * nsig * ((np >> 1) / WX_LT);
     if (grid <= 0 || grid > 0x7fffffff) return wx_set_error(WX_EUNSUPPORTED, "tiled level: grid too large");
     const size_t lds = sizeof(T) * (size_t)(2 * WX_LT + 2 * WX_MAXF + 4);
     hipLaunchKernelGGL((k_level1_tile<T, INVERSE>), dim3((unsigned)grid), dim3(256), lds, st, src, dst, (int)np, (int)nper, src_stride,
-                       dst_stride, filt);
+                       dst_stride, filt, src2, src2_stride, dst2, dst2_stride);
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
@@ -1440,6 +1448,95 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
+
+// ---- dwt / idwt of long signals (the pyramid; Wavelets.jl dwt / idwt as called by dwtall / idwtall, dwt/dwt_all.jl:33-121) ----
+// A pyramid only ever splits its approximation: level d reads the n >> d approximation samples and writes n >> (d + 1)
+// approximations and as many details, so the whole transform moves 2 n (1 + 1/2 + 1/4 + ...) < 4 n samples.  The per-level
+// kernels for trees (k_fwd1d_level, one launch per level over the WHOLE signal) moved 2 n L: 13 ms for 65536 x 4096 samples'
+// worth of 16384-sample signals (4 % of the HBM peak).  Here: the top dl levels are one tiled pass each on the approximation
+// (k_level1_tile, details straight to their final place, approximations ping-pong in scratch), and from 4096 samples on the
+// tree-driven lattice kernel finishes the pyramid reading / writing with the long signal's stride.
+template <typename T> bool wx_dwt_long_ok(int64_t n, const WxFilt &filt)
+{
+    static const bool off = getenv("WX_DWT_LONG") && atoi(getenv("WX_DWT_LONG")) == 0;
+    if (off || sizeof(T) != 8 || wx_skip_register_kernels()) return false;
+    return (n == 16384 || n == 32768 || n == 65536) && wx_lattice_tree_applicable_f64(4096, filt);
+}
+template bool wx_dwt_long_ok<double>(int64_t, const WxFilt &);
+template bool wx_dwt_long_ok<float>(int64_t, const WxFilt &);
+
+template <typename T>
+int wx_dev_dwt_long(const T *x, T *y, int64_t n, int Lp, int64_t batch, const WxFilt &filt, const uint8_t *status, int64_t nstatus,
+                    T *scratch, hipStream_t st)
+{
+    if (batch == 0 || n == 0) return WX_OK;
+    if constexpr (sizeof(T) == 8) {
+        int dl = 0;
+        while (((int64_t)4096 << dl) < n) ++dl;
+        const int top = Lp < dl ? Lp : dl;
+        const int64_t S = n / 2 + n / 4;                           // scratch per signal: approximations of odd / even depth
+        T *bufs[2] = {scratch, scratch + n / 2};
+        const T *src = x;
+        int64_t src_stride = n;
+        for (int d = 0; d < top; ++d) {
+            const int64_t np = n >> d;
+            const int rc = launch_level1_tile<T, false>(src, bufs[d & 1], np, 1, batch, src_stride, S, filt, st, nullptr, 0, y + (np >> 1), n);
+            if (rc) return rc;
+            src = bufs[d & 1];
+            src_stride = S;
+        }
+        if (Lp > top) {
+            const int r = wx_lattice_tree_f64(false, (const double *)src, (double *)y, 4096, Lp - dl, batch, S, 0, filt, status, nstatus, st,
+                                              nullptr, n);
+            if (r < 0) return r;
+            if (r != 1) return wx_set_error(WX_EHIP, "dwt of a long signal: the lattice kernel did not take the 4096-sample pyramid");
+            return WX_OK;
+        }
+        WX_HIP_CHECK(hipMemcpy2DAsync(y, n * sizeof(T), src, S * sizeof(T), (n >> top) * sizeof(T), batch, hipMemcpyDeviceToDevice, st));
+        return WX_OK;
+    } else {
+        return wx_set_error(WX_EUNSUPPORTED, "dwt of a long signal: Float64 only");
+    }
+}
+
+template <typename T>
+int wx_dev_idwt_long(const T *xw, T *y, int64_t n, int Lp, int64_t batch, const WxFilt &filt, const uint8_t *status, int64_t nstatus,
+                     const WxThreshArg &thr, T *scratch, hipStream_t st)
+{
+    if (batch == 0 || n == 0) return WX_OK;
+    if constexpr (sizeof(T) == 8) {
+        int dl = 0;
+        while (((int64_t)4096 << dl) < n) ++dl;
+        const int top = Lp < dl ? Lp : dl;
+        const int64_t S = n / 2 + n / 4;
+        T *bufs[2] = {scratch, scratch + n / 2};
+        // the approximation of depth `top` goes where the forward left it: bufs[(top - 1) & 1]
+        T *cur = bufs[(top - 1) & 1];
+        if (Lp > top) {
+            const int r = wx_lattice_tree_f64(true, (const double *)xw, (double *)cur, 4096, Lp - dl, batch, n, 0, filt, status, nstatus, st,
+                                              &thr, S);
+            if (r < 0) return r;
+            if (r != 1) return wx_set_error(WX_EHIP, "idwt of a long signal: the lattice kernel did not take the 4096-sample pyramid");
+        } else {
+            WX_HIP_CHECK(hipMemcpy2DAsync(cur, S * sizeof(T), xw, n * sizeof(T), (n >> top) * sizeof(T), batch, hipMemcpyDeviceToDevice, st));
+        }
+        for (int d = top - 1; d >= 0; --d) {
+            const int64_t np = n >> d;
+            T *dst = d == 0 ? y : bufs[(d - 1) & 1];
+            const int rc = launch_level1_tile<T, true>(bufs[d & 1], dst, np, 1, batch, S, d == 0 ? n : S, filt, st, xw + (np >> 1), n);
+            if (rc) return rc;
+        }
+        return WX_OK;
+    } else {
+        return wx_set_error(WX_EUNSUPPORTED, "idwt of a long signal: Float64 only");
+    }
+}
+template int wx_dev_dwt_long<double>(const double *, double *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t, double *, hipStream_t);
+template int wx_dev_dwt_long<float>(const float *, float *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t, float *, hipStream_t);
+template int wx_dev_idwt_long<double>(const double *, double *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t,
+                                      const WxThreshArg &, double *, hipStream_t);
+template int wx_dev_idwt_long<float>(const float *, float *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t,
+                                     const WxThreshArg &, float *, hipStream_t);
 
 // iwpt / iwpd.  in_stride = elements between consecutive signals of xw.  colmap != nullptr: xw is
 // the (n, k, batch) packet table (in_stride = n*k) and colmap[blk] names the column each block

@@ -24,6 +24,15 @@ template <typename T>
 int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxFilt &filt,
                   const uint8_t *status, int64_t nstatus, const int *colmap, int log2blk, int64_t in_stride,
                   T *scratch, T *scratch2, hipStream_t st, int force_generic);
+// dwt / idwt (the pyramid of depth Lp) of long signals, n = 4096 << dl, dl = 2 .. 4: one tiled pass per top level on the
+// approximation branch, then the 4096-sample pyramid on the tree-driven lattice kernels (wx_dwt1d.hip); scratch: n * batch
+template <typename T> bool wx_dwt_long_ok(int64_t n, const WxFilt &filt);
+template <typename T>
+int wx_dev_dwt_long(const T *x, T *y, int64_t n, int Lp, int64_t batch, const WxFilt &filt, const uint8_t *status, int64_t nstatus,
+                    T *scratch, hipStream_t st);
+template <typename T>
+int wx_dev_idwt_long(const T *xw, T *y, int64_t n, int Lp, int64_t batch, const WxFilt &filt, const uint8_t *status, int64_t nstatus,
+                     const WxThreshArg &thr, T *scratch, hipStream_t st);
 template <typename T>
 int wx_dev_getbasiscoef1d(const T *Xw, T *out, int64_t n, int k, int64_t batch, const int *colmap, int blk,
                           hipStream_t st);
@@ -116,10 +125,11 @@ int wx_haar_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batc
 // full-tree Float64 packets as a lattice of plane rotations in the registers of one wavefront per signal
 // (wx_lattice.hip); 0 = not applicable, 1 = launched, < 0 = error
 int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
-// tree-driven wpt / iwpt / iwpd on the lattice (wx_lattice_tree.h): 0 = not applicable, 1 = launched, < 0 = error
+// tree-driven wpt / iwpt / iwpd on the lattice (wx_lattice_tree.h): 0 = not applicable, 1 = launched, < 0 = error.
+// in_stride / out_stride: elements between consecutive signals of x / y (out_stride = 0: n)
 int wx_lattice_tree_f64(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                         int64_t col_stride, const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, hipStream_t st,
-                        const WxThreshArg *thr = nullptr);
+                        const WxThreshArg *thr = nullptr, int64_t out_stride = 0);
 bool wx_lattice_tree_applicable_f64(int64_t n, const WxFilt &filt);
 int wx_lattice_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
 int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,

@@ -218,7 +218,7 @@ int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t b
 // ---- tree-driven transforms (wx_lattice_tree.h) -----------------------------------------------------------------
 #define WX_TREE_DECL(k)                                                                                              \
     int wx_lattice_tree##k##_f64(bool, const double *, double *, int64_t, int, int64_t, int64_t, int64_t, const WxFilt &, \
-                                 const uint8_t *, int64_t, const WxThreshArg *, hipStream_t);
+                                 const uint8_t *, int64_t, const WxThreshArg *, hipStream_t, int64_t);
 WX_TREE_DECL(0f) WX_TREE_DECL(0i) WX_TREE_DECL(1f) WX_TREE_DECL(1i) WX_TREE_DECL(2f) WX_TREE_DECL(2i)
 #undef WX_TREE_DECL
 
@@ -231,11 +231,11 @@ bool wx_lattice_tree_applicable_f64(int64_t n, const WxFilt &filt)
 
 int wx_lattice_tree_f64(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                         int64_t col_stride, const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, hipStream_t st,
-                        const WxThreshArg *thr)
+                        const WxThreshArg *thr, int64_t out_stride)
 {
     if (!wx_lattice_tree_applicable_f64(n, filt)) return 0;
-#define WX_TREE_GO(k) (inverse ? wx_lattice_tree##k##i_f64(inverse, x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, thr, st) \
-                               : wx_lattice_tree##k##f_f64(inverse, x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, thr, st))
+#define WX_TREE_GO(k) (inverse ? wx_lattice_tree##k##i_f64(inverse, x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, thr, st, out_stride) \
+                               : wx_lattice_tree##k##f_f64(inverse, x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, thr, st, out_stride))
     if (n == 4096) return WX_TREE_GO(0);
     if (n == 2048) return WX_TREE_GO(1);
     return WX_TREE_GO(2);

@@ -11,9 +11,10 @@
 // compile in parallel
 
 // 0 = not applicable (the caller takes the fused LDS kernels), 1 = launched, < 0 = error.
-// inverse: leaves of signal b, depth l at x + b in_stride + l col_stride (col_stride = 0: dense leaves, n: packet table)
+// inverse: leaves of signal b, depth l at x + b in_stride + l col_stride (col_stride = 0: dense leaves, n: packet table);
+// signal b of the output at y + b out_stride (0: n), of the forward's input at x + b in_stride
 int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride, int64_t col_stride,
-                   const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, const WxThreshArg *thr, hipStream_t st)
+                   const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, const WxThreshArg *thr, hipStream_t st, int64_t out_stride)
 {
     constexpr int SH = WX_LAT_TREE_SH;
     constexpr int64_t per = (int64_t)1 << SH;
@@ -21,7 +22,10 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
     if (n != (4096 >> SH) || L < 1 || L + SH > 12 || filt.F < 2 || batch < per || batch > 0x7fffffff || !dstatus) return 0;
     if ((batch & (per - 1)) && x == y) return 0;             // the tail wavefront re-does signals: out of place only
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
-    if (inverse && (in_stride < n || (in_stride & 3) || (col_stride & 3) || in_stride * (per - 1) + 13 * col_stride + 4096 > 0x7fffffff)) return 0;
+    if (in_stride < n || (in_stride & 3) || (col_stride & 3) || in_stride * (per - 1) + 13 * col_stride + 4096 > 0x7fffffff) return 0;
+    const int64_t ostr = out_stride ? out_stride : n;
+    if (ostr < n || (ostr & 3) || ostr * (per - 1) + 4096 > 0x7fffffff) return 0;
+    const bool strided = ostr != n || (!inverse && in_stride != n);      // the per-depth form below takes dense signals only
     WxLatW cw;
     if (!wx_lattice_factor(filt, L, inverse, &cw.c)) return 0;
     {
@@ -44,7 +48,7 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
     // (depth-4 pyramid, 65536 x 4096 db4: 0.80 / 0.84 ms against 0.81-0.85 / 0.85-0.89; 2048 samples 0.86 / 0.80 against
     // 0.84 / 0.91).  WX_TREE_SC=0 / 1 forces one of the two.
     static const int sc_env = getenv("WX_TREE_SC") ? atoi(getenv("WX_TREE_SC")) : -1;
-    if (sc_env != 0 && (L > 4 || sc_env == 1 || ta.head)) {
+    if ((sc_env != 0 && (L > 4 || sc_env == 1 || ta.head)) || strided) {
         WxLatTreeSc *tsc = (WxLatTreeSc *)scr.alloc(sizeof(WxLatTreeSc));
         if (!tsc) return WX_EHIP;
         hipLaunchKernelGGL((k_lat_treesc_prep<SH>), dim3(1), dim3(64), 0, st, dstatus, nstatus, L, tsc);
@@ -55,12 +59,12 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
 #define WX_GOS(NSS)                                                                                                  \
     case NSS:                                                                                                        \
         hipLaunchKernelGGL((k_lat_iwpt_treesc_f64<NSS, 2, SH, false>), dim3(nw), dim3(64), 0, st, x, y, L, lsig,      \
-                           (unsigned)in_stride, (unsigned)col_stride, cw, ctsc, ta);                                 \
+                           (unsigned)in_stride, (unsigned)col_stride, (unsigned)ostr, cw, ctsc, ta);                 \
         break;
 #define WX_GOST(NSS)                                                                                                 \
     case NSS:                                                                                                        \
         hipLaunchKernelGGL((k_lat_iwpt_treesc_f64<NSS, 2, SH, true>), dim3(nw), dim3(64), 0, st, x, y, L, lsig,       \
-                           (unsigned)in_stride, (unsigned)col_stride, cw, ctsc, ta);                                 \
+                           (unsigned)in_stride, (unsigned)col_stride, (unsigned)ostr, cw, ctsc, ta);                 \
         break;
         if (ta.t) {
             switch (filt.F / 2) {
@@ -72,7 +76,8 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
 #else
 #define WX_GOS(NSS)                                                                                                  \
     case NSS:                                                                                                        \
-        hipLaunchKernelGGL((k_lat_wpt_treesc_f64<NSS, 2, SH>), dim3(nw), dim3(64), 0, st, x, y, L, lsig, cw, ctsc);   \
+        hipLaunchKernelGGL((k_lat_wpt_treesc_f64<NSS, 2, SH>), dim3(nw), dim3(64), 0, st, x, y, L, lsig,             \
+                           (unsigned)in_stride, (unsigned)ostr, cw, ctsc);                                           \
         break;
 #endif
         switch (filt.F / 2) {

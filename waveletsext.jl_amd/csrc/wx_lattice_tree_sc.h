@@ -248,16 +248,17 @@ __device__ __forceinline__ void lat_sc_ptab(unsigned (&pw)[32], const WxLatTreeS
 
 template <int NS, int WPE, int SH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_treesc_f64(
-    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw, const WxLatTreeSc *__restrict__ tab)
+    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned out_stride, WxLatW cw,
+    const WxLatTreeSc *__restrict__ tab)
 {
     static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
     __shared__ __attribute__((aligned(16))) double lds[2048];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
-    constexpr int N = 4096 >> SH;
+    constexpr int NQ = 32 >> SH;                                 // 128-element pieces of one signal
     const int sig0 = min((int)blockIdx.x << SH, last_sig);       // the last wavefront of a ragged batch re-does signals
-    const double *xs = x + (int64_t)sig0 * N;
-    double *ys = y + (int64_t)sig0 * N;
+    const double *xs = x + (int64_t)sig0 * in_stride;            // signals in_stride / out_stride elements apart
+    double *ys = y + (int64_t)sig0 * out_stride;
     const WxLat &cf = cw.c;
     // forward: gl[1] = g, g2 = g^-2: after the shears the a-slot holds a / g, the d-slot d g
     const double g = cw.gl[1], ginv = cw.c.g2 * cw.gl[1];
@@ -266,12 +267,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         double bb[64];
         if constexpr (SH < 2) {
             double a[64];
-            lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw);
+            lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw, in_stride);
             WX_SC_FWD(0, 6, a, 0, tab->mA, true)
             WX_SC_FWD(1, 6, a, 1, tab->mA, tab->anyA)
             lat_t2(a, bb, lds0, lane);
         } else
-            lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw);
+            lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw, in_stride);
         WX_SC_FWD(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
         WX_SC_FWD(1, 4, bb, 3, tab->mB + 32, tab->anyB[1])
         WX_SC_FWD(2, 4, bb, 4, tab->mB + 64, tab->anyB[2])
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 v[Kc] = *lat_sc_lp(lat_sc_row<h, k>(lds0, lane));
             });
             lat_for<8>([&](auto Kc) {
-                constexpr int k = k0 + Kc;
-                lat_st2(lat_sbase(ys + 2048 * h + 128 * k) + 2 * lane, v[Kc]);
+                constexpr int k = k0 + Kc, q = 16 * h + k, sg = q / NQ, qq = q % NQ;
+                lat_st2(lat_sbase(ys + (size_t)sg * out_stride + 128 * qq) + 2 * lane, v[Kc]);
             });
         });
         lat_sync();
@@ -323,17 +324,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
 template <int NS, int WPE, int SH, bool THR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_treesc_f64(
-    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride, WxLatW cw,
-    const WxLatTreeSc *__restrict__ tab, WxThreshArg thr)
+    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride,
+    unsigned out_stride, WxLatW cw, const WxLatTreeSc *__restrict__ tab, WxThreshArg thr)
 {
     static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
     __shared__ __attribute__((aligned(16))) double lds[2048];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
-    constexpr int N = 4096 >> SH, NQ = 32 >> SH;               // samples, 128-element pieces of one signal
+    constexpr int NQ = 32 >> SH;                               // 128-element pieces of one signal
     const int sig0 = min((int)blockIdx.x << SH, last_sig);
     const double *xs = xw + (int64_t)sig0 * in_stride;
-    double *ys = y + (int64_t)sig0 * N;
+    double *ys = y + (int64_t)sig0 * out_stride;
     const WxLat &cf = cw.c;
     unsigned dep[4] = {0, 0, 0, 0};
     if (col_stride) {
@@ -442,13 +443,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     WX_SC_INV(1, 4, bb, 3, tab->mB + 32, tab->anyB[1])
     WX_SC_INV(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
     if constexpr (SH >= 2) {
-        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw);
+        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw, out_stride);
     } else {
         double a[64];
         lat_t2i(bb, a, lds0, lane);
         WX_SC_INV(1, 6, a, 1, tab->mA, tab->anyA)
         WX_SC_INV(0, 6, a, 0, tab->mA, true)
-        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw);
+        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw, out_stride);
     }
 }
 #undef WX_SC_FWD
