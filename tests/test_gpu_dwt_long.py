@@ -47,3 +47,22 @@ def test_long_pyramid_device_batch_round_trips(wx):
     assert float(err.max()) <= 1e-12, int(err.argmax())
     # linearity / energy: an orthogonal transform keeps the norm of every signal
     assert float(((y * y).sum(dim=0) / (x * x).sum(dim=0) - 1).abs().max()) <= 1e-12
+
+
+@pytest.mark.parametrize("n,dt,tol", [(32768, np.float32, 2e-5), (65536, np.float32, 2e-5), (131072, np.float64, 1e-10),
+                                      (262144, np.float32, 2e-5)])
+@pytest.mark.parametrize("wname", ["haar", "db4", "coif6"])
+def test_long_pyramids_other_types_and_lengths(wx, oracle, n, dt, tol, wname):
+    """Float32 signals (the fused LDS kernel finishes the pyramid at 16384 samples) and lengths beyond 65536"""
+    rng = np.random.default_rng(n)
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    Lmax = wx.maxtransformlevels(n)
+    x = np.asfortranarray(rng.standard_normal((n, 2)).astype(dt))
+    for L in (Lmax, 5, 2):
+        tree = np.asarray(wx.maketree(n, L, "dwt"))
+        exp = oracle.wptall(x.astype(np.float64), wt.qmf, tree)
+        got = wx.wptall(x, wt, tree)
+        assert got.dtype == dt
+        assert relerr(np.asarray(got, dtype=np.float64), exp) <= tol, (n, wname, L)
+        back = wx.iwptall(exp.astype(dt), wt, tree)
+        assert relerr(np.asarray(back, dtype=np.float64), x.astype(np.float64)) <= tol, (n, wname, L)

@@ -11,11 +11,13 @@ def t(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 wname = sys.argv[1] if len(sys.argv) > 1 else "db4"
+dt = torch.float32 if len(sys.argv) > 2 and sys.argv[2] == "f32" else torch.float64
+esz = 4 if dt == torch.float32 else 8
 wt = wx.wavelet(getattr(wx.WT, wname))
 for n in (4096, 8192, 16384, 32768, 65536):
     B = 65536 * 4096 // n
-    x = wx.jl_empty((n, B), torch.float64, "cuda"); x.normal_()
-    gb = 2e-9 * n * B * 8
+    x = wx.jl_empty((n, B), dt, "cuda"); x.normal_()
+    gb = 2e-9 * n * B * esz
     L = wx.maxtransformlevels(n)
     f = t(lambda: wx.dwtall(x, wt)); y = wx.dwtall(x, wt); i = t(lambda: wx.idwtall(y, wt))
     err = float((wx.idwtall(y, wt) - x).abs().max())

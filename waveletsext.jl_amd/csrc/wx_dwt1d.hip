@@ -1456,11 +1456,25 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
 // worth of 16384-sample signals (4 % of the HBM peak).  Here: the top dl levels are one tiled pass each on the approximation
 // (k_level1_tile, details straight to their final place, approximations ping-pong in scratch), and from 4096 samples on the
 // tree-driven lattice kernel finishes the pyramid reading / writing with the long signal's stride.
-template <typename T> bool wx_dwt_long_ok(int64_t n, const WxFilt &filt)
+// the length the tiled top levels stop at (0: the long-signal path does not apply) and who finishes: the lattice kernels at 4096
+// samples (Float64, filters the lattice factors), otherwise the fused LDS kernel at the longest signal that fits a CU's LDS
+// (8192 Float64 / 16384 Float32 samples)
+template <typename T> static int64_t wx_dwt_long_plan(int64_t n, const WxFilt &filt, bool *lattice)
 {
     static const bool off = getenv("WX_DWT_LONG") && atoi(getenv("WX_DWT_LONG")) == 0;
-    if (off || sizeof(T) != 8 || wx_skip_register_kernels()) return false;
-    return (n == 16384 || n == 32768 || n == 65536) && wx_lattice_tree_applicable_f64(4096, filt);   // 8192: the fused LDS kernel is as fast (1.37 / 1.40 ms against 1.67 / 1.38)
+    *lattice = false;
+    if (off || !wx_is_pow2(n) || n > ((int64_t)1 << 24) || wx_fused1d_ok<T>(n, filt.F)) return 0;
+    if constexpr (sizeof(T) == 8) {
+        if (n >= 16384 && !wx_skip_register_kernels() && wx_lattice_tree_applicable_f64(4096, filt)) { *lattice = true; return 4096; }
+    }
+    int64_t n2 = n;
+    while (n2 > 4096 && !wx_fused1d_ok<T>(n2, filt.F)) n2 >>= 1;
+    return (n2 >= 4096 && n2 < n && wx_fused1d_ok<T>(n2, filt.F)) ? n2 : 0;
+}
+template <typename T> bool wx_dwt_long_ok(int64_t n, const WxFilt &filt)
+{
+    bool lat;
+    return wx_dwt_long_plan<T>(n, filt, &lat) != 0;
 }
 template bool wx_dwt_long_ok<double>(int64_t, const WxFilt &);
 template bool wx_dwt_long_ok<float>(int64_t, const WxFilt &);
@@ -1470,33 +1484,37 @@ int wx_dev_dwt_long(const T *x, T *y, int64_t n, int Lp, int64_t batch, const Wx
                     T *scratch, hipStream_t st)
 {
     if (batch == 0 || n == 0) return WX_OK;
-    if constexpr (sizeof(T) == 8) {
-        int dl = 0;
-        while (((int64_t)4096 << dl) < n) ++dl;
-        const int top = Lp < dl ? Lp : dl;
-        const int64_t S = n / 2 + n / 4;                           // scratch per signal: approximations of odd / even depth
-        T *bufs[2] = {scratch, scratch + n / 2};
-        const T *src = x;
-        int64_t src_stride = n;
-        for (int d = 0; d < top; ++d) {
-            const int64_t np = n >> d;
-            const int rc = launch_level1_tile<T, false>(src, bufs[d & 1], np, 1, batch, src_stride, S, filt, st, nullptr, 0, y + (np >> 1), n);
-            if (rc) return rc;
-            src = bufs[d & 1];
-            src_stride = S;
-        }
-        if (Lp > top) {
-            const int r = wx_lattice_tree_f64(false, (const double *)src, (double *)y, 4096, Lp - dl, batch, S, 0, filt, status, nstatus, st,
-                                              nullptr, n);
-            if (r < 0) return r;
-            if (r != 1) return wx_set_error(WX_EHIP, "dwt of a long signal: the lattice kernel did not take the 4096-sample pyramid");
-            return WX_OK;
-        }
-        WX_HIP_CHECK(hipMemcpy2DAsync(y, n * sizeof(T), src, S * sizeof(T), (n >> top) * sizeof(T), batch, hipMemcpyDeviceToDevice, st));
-        return WX_OK;
-    } else {
-        return wx_set_error(WX_EUNSUPPORTED, "dwt of a long signal: Float64 only");
+    bool lattice;
+    const int64_t n2 = wx_dwt_long_plan<T>(n, filt, &lattice);
+    if (!n2) return wx_set_error(WX_EUNSUPPORTED, "dwt of a long signal: no plan for this length / filter");
+    int dl = 0;
+    while ((n2 << dl) < n) ++dl;
+    const int top = Lp < dl ? Lp : dl;
+    const int64_t S = n / 2 + n / 4;                           // scratch per signal: approximations of odd / even depth
+    T *bufs[2] = {scratch, scratch + n / 2};
+    const T *src = x;
+    int64_t src_stride = n;
+    for (int d = 0; d < top; ++d) {
+        const int64_t np = n >> d;
+        const int rc = launch_level1_tile<T, false>(src, bufs[d & 1], np, 1, batch, src_stride, S, filt, st, nullptr, 0, y + (np >> 1), n);
+        if (rc) return rc;
+        src = bufs[d & 1];
+        src_stride = S;
     }
+    if (Lp > top) {
+        if constexpr (sizeof(T) == 8) {
+            if (lattice) {
+                const int r = wx_lattice_tree_f64(false, (const double *)src, (double *)y, 4096, Lp - dl, batch, S, 0, filt, status, nstatus, st,
+                                                  nullptr, n);
+                if (r < 0) return r;
+                if (r == 1) return WX_OK;
+                if (!wx_fused1d_ok<T>(n2, filt.F)) return wx_set_error(WX_EHIP, "dwt of a long signal: the lattice kernel did not take the pyramid");
+            }
+        }
+        return launch_fwd_fused<T, false>(src, y, n2, Lp - dl, batch, S, n, filt, status, n2 - 1 < nstatus ? n2 - 1 : nstatus, st);
+    }
+    WX_HIP_CHECK(hipMemcpy2DAsync(y, n * sizeof(T), src, S * sizeof(T), (n >> top) * sizeof(T), batch, hipMemcpyDeviceToDevice, st));
+    return WX_OK;
 }
 
 template <typename T>
@@ -1504,32 +1522,43 @@ int wx_dev_idwt_long(const T *xw, T *y, int64_t n, int Lp, int64_t batch, const 
                      const WxThreshArg &thr, T *scratch, hipStream_t st)
 {
     if (batch == 0 || n == 0) return WX_OK;
-    if constexpr (sizeof(T) == 8) {
-        int dl = 0;
-        while (((int64_t)4096 << dl) < n) ++dl;
-        const int top = Lp < dl ? Lp : dl;
-        const int64_t S = n / 2 + n / 4;
-        T *bufs[2] = {scratch, scratch + n / 2};
-        // the approximation of depth `top` goes where the forward left it: bufs[(top - 1) & 1]
-        T *cur = bufs[(top - 1) & 1];
-        if (Lp > top) {
-            const int r = wx_lattice_tree_f64(true, (const double *)xw, (double *)cur, 4096, Lp - dl, batch, n, 0, filt, status, nstatus, st,
-                                              &thr, S);
-            if (r < 0) return r;
-            if (r != 1) return wx_set_error(WX_EHIP, "idwt of a long signal: the lattice kernel did not take the 4096-sample pyramid");
-        } else {
-            WX_HIP_CHECK(hipMemcpy2DAsync(cur, S * sizeof(T), xw, n * sizeof(T), (n >> top) * sizeof(T), batch, hipMemcpyDeviceToDevice, st));
+    bool lattice;
+    const int64_t n2 = wx_dwt_long_plan<T>(n, filt, &lattice);
+    if (!n2) return wx_set_error(WX_EUNSUPPORTED, "idwt of a long signal: no plan for this length / filter");
+    int dl = 0;
+    while ((n2 << dl) < n) ++dl;
+    const int top = Lp < dl ? Lp : dl;
+    const int64_t S = n / 2 + n / 4;
+    T *bufs[2] = {scratch, scratch + n / 2};
+    // the approximation of depth `top` goes where the forward left it: bufs[(top - 1) & 1]
+    T *cur = bufs[(top - 1) & 1];
+    if (Lp > top) {
+        bool done = false;
+        if constexpr (sizeof(T) == 8) {
+            if (lattice) {
+                const int r = wx_lattice_tree_f64(true, (const double *)xw, (double *)cur, 4096, Lp - dl, batch, n, 0, filt, status, nstatus, st,
+                                                  &thr, S);
+                if (r < 0) return r;
+                done = r == 1;
+                if (!done && !wx_fused1d_ok<T>(n2, filt.F))
+                    return wx_set_error(WX_EHIP, "idwt of a long signal: the lattice kernel did not take the pyramid");
+            }
         }
-        for (int d = top - 1; d >= 0; --d) {
-            const int64_t np = n >> d;
-            T *dst = d == 0 ? y : bufs[(d - 1) & 1];
-            const int rc = launch_level1_tile<T, true>(bufs[d & 1], dst, np, 1, batch, S, d == 0 ? n : S, filt, st, xw + (np >> 1), n);
+        if (!done) {
+            const int rc = launch_inv_fused<T>(xw, cur, n2, Lp - dl, batch, n, S, filt, status, n2 - 1 < nstatus ? n2 - 1 : nstatus, nullptr, 0,
+                                               st, thr);
             if (rc) return rc;
         }
-        return WX_OK;
     } else {
-        return wx_set_error(WX_EUNSUPPORTED, "idwt of a long signal: Float64 only");
+        WX_HIP_CHECK(hipMemcpy2DAsync(cur, S * sizeof(T), xw, n * sizeof(T), (n >> top) * sizeof(T), batch, hipMemcpyDeviceToDevice, st));
     }
+    for (int d = top - 1; d >= 0; --d) {
+        const int64_t np = n >> d;
+        T *dst = d == 0 ? y : bufs[(d - 1) & 1];
+        const int rc = launch_level1_tile<T, true>(bufs[d & 1], dst, np, 1, batch, S, d == 0 ? n : S, filt, st, xw + (np >> 1), n);
+        if (rc) return rc;
+    }
+    return WX_OK;
 }
 template int wx_dev_dwt_long<double>(const double *, double *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t, double *, hipStream_t);
 template int wx_dev_dwt_long<float>(const float *, float *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t, float *, hipStream_t);
