@@ -66,3 +66,39 @@ def test_long_pyramids_other_types_and_lengths(wx, oracle, n, dt, tol, wname):
         assert relerr(np.asarray(got, dtype=np.float64), exp) <= tol, (n, wname, L)
         back = wx.iwptall(exp.astype(dt), wt, tree)
         assert relerr(np.asarray(back, dtype=np.float64), x.astype(np.float64)) <= tol, (n, wname, L)
+
+
+@pytest.mark.parametrize("n", [16384, 65536])
+@pytest.mark.parametrize("wname", ["db4", "coif6"])
+def test_long_signals_along_any_tree(wx, oracle, n, wname):
+    """wptall / iwptall along trees other than the pyramid (bestbasistree output) on long Float64 signals: tiled passes on the split
+    nodes of the top levels, one lattice launch per 4096-sample node with its own subtree (wx_dev_wpt_long_tree)"""
+    from helpers import random_tree_1d
+    rng = np.random.default_rng(n + 5)
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    x = np.asfortranarray(rng.standard_normal((n, 3)))
+    Lmax = wx.maxtransformlevels(n)
+    trees = []
+    for p in (0.4, 0.7, 0.9):
+        for _ in range(3):
+            tr = random_tree_1d(n, rng, p)
+            tr[0] = True
+            trees.append(tr)
+    t = np.zeros(n - 1, dtype=bool)              # the mirror of the pyramid: always the detail child
+    i = 1
+    while i <= n - 1:
+        t[i - 1] = True
+        i = 2 * i + 1
+    trees.append(t)
+    t = np.array(wx.maketree(n, 3, "full"), dtype=bool).copy()      # full to depth 3, one node opened to the bottom
+    i = 8 + 5
+    while i <= n - 1:
+        t[i - 1] = True
+        i = 2 * i
+    trees.append(t)
+    trees.append(np.array(wx.maketree(n, 2, "full"), dtype=bool))   # ends inside the tiled levels
+    for k, tree in enumerate(trees):
+        exp = oracle.wptall(x, wt.qmf, tree)
+        got = wx.wptall(x, wt, tree)
+        assert relerr(got, exp) <= 1e-10, (n, wname, k)
+        assert relerr(wx.iwptall(exp, wt, tree), x) <= 1e-10, (n, wname, k)

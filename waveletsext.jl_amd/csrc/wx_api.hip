@@ -145,10 +145,13 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     const bool fused = !force && wx_fused1d_ok<T>(n, F);
     // long Float64 signals with a full tree take one pass per top level and then the lattice kernels: one scratch array
     const bool long_lattice = !force && !tr.dstatus && n > 4096 && n <= 65536 && tr.Leff > 1;
-    if (((!fused && tr.Leff > 1) || long_lattice || longp) && batch) {
+    // any other tree on a long Float64 signal: tiled top levels node by node + one lattice launch per 4096-sample subtree
+    const bool longt = !longp && tree && tr.dstatus && tr.Leff >= 1 && !force && wx_wpt_long_tree_ok<T>(n, filt) && dx != dy;
+    if (((!fused && tr.Leff > 1) || long_lattice || longp || longt) && batch) {
         s1 = (T *)scr.alloc(sizeof(T) * n * batch);
         if (!s1) return io.finish(WX_EHIP);
     }
+    if (longt && batch) return io.finish(wx_dev_wpt_long_tree<T>(dx, dy, n, tr.Leff, batch, filt, tree, ntree, s1, INVERSE, st));
     if (longp && batch && dx != dy) {
         if (INVERSE) {
             WxThreshArg thr{nullptr, 0, 0, 0, 1.0};

@@ -19,6 +19,7 @@
 //     n = odd * 2^k, signals that do not fit LDS, and filters without a fused instantiation.
 #include "wx_common.h"
 #include "wx_kernels.h"
+#include "wx_host.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -1566,6 +1567,130 @@ template int wx_dev_idwt_long<double>(const double *, double *, int64_t, int, in
                                       const WxThreshArg &, double *, hipStream_t);
 template int wx_dev_idwt_long<float>(const float *, float *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t,
                                      const WxThreshArg &, float *, hipStream_t);
+
+// ---- wpt / iwpt along any tree of long signals ------------------------------------------------------------------------------
+// (what bestbasistree returns for signals of 16384 samples and more; until round 3: one launch per level over the whole signal,
+// 2-3 % of the HBM peak).  Nodes of depth d < dl = log2(n / 4096) that are split take one tiled pass (runs of consecutive split
+// nodes share a launch), children ping-pong between scratch and y at their own positions; a leaf is copied to / from its place; every
+// node of 4096 samples that is split further is one launch of the tree-driven lattice kernels with its own subtree.
+template <typename T> bool wx_wpt_long_tree_ok(int64_t n, const WxFilt &filt)
+{
+    bool lattice;
+    return wx_dwt_long_plan<T>(n, filt, &lattice) == 4096 && lattice && n <= 65536;
+}
+template bool wx_wpt_long_tree_ok<double>(int64_t, const WxFilt &);
+template bool wx_wpt_long_tree_ok<float>(int64_t, const WxFilt &);
+
+template <typename T>
+int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, const WxFilt &filt, const uint8_t *htree, int64_t ntree,
+                         T *scratch, bool inverse, hipStream_t st)
+{
+    if (batch == 0 || n == 0) return WX_OK;
+    if constexpr (sizeof(T) == 8) {
+        int dl = 0;
+        while (((int64_t)4096 << dl) < n) ++dl;
+        auto split = [&](int d, int64_t j) {                       // node (d, j) exists and is decomposed
+            const int64_t idx = ((int64_t)1 << d) + j;
+            for (int t = 1; t <= d; ++t) { const int64_t a = idx >> t; if (a - 1 >= ntree || !htree[a - 1]) return false; }
+            return d < Lp && idx - 1 < ntree && htree[idx - 1] != 0;
+        };
+        auto exists = [&](int d, int64_t j) { return d == 0 || split(d - 1, j >> 1); };
+        // subtrees of the 4096-sample nodes that are split: one status array each (heap order from the node), uploaded together
+        const int64_t NS = 4095;
+        std::vector<int64_t> sub_nodes;
+        std::vector<int> sub_depth;
+        std::vector<uint8_t> hsub;
+        if (Lp > dl) {
+            for (int64_t j = 0; j < ((int64_t)1 << dl); ++j) {
+                if (!split(dl, j)) continue;
+                const int64_t h = ((int64_t)1 << dl) + j;               // heap index of the node
+                const size_t base = hsub.size();
+                hsub.resize(base + NS, 0);
+                int depth = 0;
+                for (int d2 = 0; d2 < 12 && dl + d2 < Lp; ++d2)
+                    for (int64_t j2 = 0; j2 < ((int64_t)1 << d2); ++j2) {
+                        const int64_t g = (h << d2) + j2;
+                        if (g - 1 < ntree && htree[g - 1] && split(dl + d2, (j << d2) + j2)) { hsub[base + ((int64_t)1 << d2) + j2 - 1] = 1; depth = d2 + 1; }
+                    }
+                sub_nodes.push_back(j);
+                sub_depth.push_back(depth);
+            }
+        }
+        const uint8_t *dsub = nullptr;
+        if (!hsub.empty()) {
+            dsub = (const uint8_t *)wx_const_upload(hsub.data(), hsub.size(), st, true);
+            if (!dsub) return WX_EHIP;
+        }
+        const int top = Lp < dl ? Lp : dl;
+        // depth-d nodes live in P(d): the input / output for d = 0, then scratch, y, scratch, ... (forward) -- every node at its own
+        // positions, so a leaf's range is never touched by deeper nodes
+        auto P = [&](int d) -> T * { return (d & 1) ? scratch : y; };
+        auto copy = [&](const T *src, T *dst, int64_t off, int64_t len) {
+            return hipMemcpy2DAsync(dst + off, n * sizeof(T), src + off, n * sizeof(T), len * sizeof(T), batch, hipMemcpyDeviceToDevice, st);
+        };
+        if (!inverse) {
+            for (int d = 0; d <= top; ++d) {
+                const int64_t np = n >> d, cnt = (int64_t)1 << d;
+                const T *src = d == 0 ? x : P(d);
+                for (int64_t j = 0; j < cnt;) {
+                    if (!exists(d, j)) { ++j; continue; }
+                    if (d < top && split(d, j)) {
+                        int64_t j1 = j;
+                        while (j1 < cnt && exists(d, j1) && split(d, j1)) ++j1;
+                        const int rc = launch_level1_tile<T, false>(src + j * np, P(d + 1) + j * np, np, j1 - j, batch, n, n, filt, st);
+                        if (rc) return rc;
+                        j = j1;
+                        continue;
+                    }
+                    if (d == dl && Lp > dl && split(d, j)) { ++j; continue; }       // finished by the lattice below
+                    if (src != y) WX_HIP_CHECK(copy(src, y, j * np, np));            // a leaf of depth d
+                    ++j;
+                }
+            }
+            for (size_t k = 0; k < sub_nodes.size(); ++k) {
+                const int64_t off = sub_nodes[k] * 4096;
+                const int r = wx_lattice_tree_f64(false, (const double *)((dl == 0 ? x : P(dl)) + off), (double *)(y + off), 4096, sub_depth[k], batch, n,
+                                                  0, filt, dsub + k * NS, NS, st, nullptr, n);
+                if (r < 0) return r;
+                if (r != 1) return wx_set_error(WX_EHIP, "wpt of a long signal: the lattice kernel did not take a subtree");
+            }
+            return WX_OK;
+        }
+        // inverse: depth-d nodes are rebuilt into Q(d) = y for d = 0, then scratch, y, ...; leaves come from xw
+        auto Q = [&](int d) -> T * { return (d & 1) ? scratch : y; };
+        for (size_t k = 0; k < sub_nodes.size(); ++k) {
+            const int64_t off = sub_nodes[k] * 4096;
+            const int r = wx_lattice_tree_f64(true, (const double *)(x + off), (double *)(Q(dl) + off), 4096, sub_depth[k], batch, n, 0, filt,
+                                              dsub + k * NS, NS, st, nullptr, n);
+            if (r < 0) return r;
+            if (r != 1) return wx_set_error(WX_EHIP, "iwpt of a long signal: the lattice kernel did not take a subtree");
+        }
+        for (int d = top; d >= 0; --d) {
+            const int64_t np = n >> d, cnt = (int64_t)1 << d;
+            for (int64_t j = 0; j < cnt;) {
+                if (!exists(d, j)) { ++j; continue; }
+                if (d < top && split(d, j)) {
+                    int64_t j1 = j;
+                    while (j1 < cnt && exists(d, j1) && split(d, j1)) ++j1;
+                    const int rc = launch_level1_tile<T, true>(Q(d + 1) + j * np, Q(d) + j * np, np, j1 - j, batch, n, n, filt, st);
+                    if (rc) return rc;
+                    j = j1;
+                    continue;
+                }
+                if (d == dl && Lp > dl && split(d, j)) { ++j; continue; }           // rebuilt by the lattice above
+                WX_HIP_CHECK(copy(x, Q(d), j * np, np));                             // a leaf of depth d: from the input
+                ++j;
+            }
+        }
+        return WX_OK;
+    } else {
+        return wx_set_error(WX_EUNSUPPORTED, "wpt along a tree of a long signal: Float64 only");
+    }
+}
+template int wx_dev_wpt_long_tree<double>(const double *, double *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t, double *, bool,
+                                          hipStream_t);
+template int wx_dev_wpt_long_tree<float>(const float *, float *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t, float *, bool,
+                                         hipStream_t);
 
 // iwpt / iwpd.  in_stride = elements between consecutive signals of xw.  colmap != nullptr: xw is
 // the (n, k, batch) packet table (in_stride = n*k) and colmap[blk] names the column each block

@@ -33,6 +33,12 @@ int wx_dev_dwt_long(const T *x, T *y, int64_t n, int Lp, int64_t batch, const Wx
 template <typename T>
 int wx_dev_idwt_long(const T *xw, T *y, int64_t n, int Lp, int64_t batch, const WxFilt &filt, const uint8_t *status, int64_t nstatus,
                      const WxThreshArg &thr, T *scratch, hipStream_t st);
+// wpt / iwpt along any tree (host copy `htree`) of long Float64 signals the lattice takes at 4096 samples: the split nodes of the
+// top levels one tiled pass per level, one tree-driven lattice launch per 4096-sample node that is split further
+template <typename T> bool wx_wpt_long_tree_ok(int64_t n, const WxFilt &filt);
+template <typename T>
+int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, const WxFilt &filt, const uint8_t *htree, int64_t ntree,
+                         T *scratch, bool inverse, hipStream_t st);
 template <typename T>
 int wx_dev_getbasiscoef1d(const T *Xw, T *out, int64_t n, int k, int64_t batch, const int *colmap, int blk,
                           hipStream_t st);
