@@ -8,7 +8,7 @@ A step = one forward pass + one inverse pass over the whole batch of the configu
 resident in HBM.  Default workload = BASELINE config 2 (`wpdall` 65536 x 4096 Float64, db8, full packet tree L = 12, then
 `iwpdall`).  Other workloads (`--workload`): `target` (north-star target: wptall / iwptall db4 L = 10), `cfg3` (swptall /
 iswptall 8192 signals of 16384 samples, haar, L = 12: the 4 TiB of leaves exist 64 signals at a time, a step loops over
-all chunks of the rank's shard), `cfg3_sdwt` (the same signals through sdwtall / isdwtall), `cfg4` (2-D wptall / iwptall 4096 images 512 x 512 Float32 db4 L = 6), `cfg5` (acwpd + JBB
+all chunks of the rank's shard), `cfg3_sdwt` (the same signals through sdwtall / isdwtall), `dwt_long` (dwtall / idwtall of 16384-sample signals), `cfg4` (2-D wptall / iwptall 4096 images 512 x 512 Float32 db4 L = 6), `cfg5` (acwpd + JBB
 moments / costs / tree, 262144 signals of 2048 samples, coif6, L = 11: moments accumulate over chunks of 2048 signals, one
 all-reduce of the moments when N > 1, costs and tree on every rank), plus the widened rows `bb`, `ldb`, `siwt`.
 
@@ -54,6 +54,12 @@ WORKLOADS = {
                          fwd_kernels=[("k_lat_wpt_treesc_f64<4, 2, 0>", 1)],
                          desc="dwtall+idwtall as wptall+iwptall along maketree(4096, 12, :dwt): 65536x4096 f64 db4 (the levels "
                               "below 64 samples run lane-locally, wx_dwttail.hip)"),
+    "dwt_long": dict(kind="wpt", n=16384, batch=16384, wavelet="db4", L=14, dtype="f64", tree="pyramid",
+                     kernel="k_level1_tile<double, false>", inv_kernel="k_level1_tile<double, true>",
+                     fwd_kernels=[("k_level1_tile<double, false>", 2), ("k_lat_wpt_treesc_f64<4, 2, 0>", 1)],
+                     desc="dwtall+idwtall of long signals as wptall+iwptall along maketree(16384, 14, :dwt): 16384x16384 f64 db4 -- two "
+                          "tiled top levels on the approximation branch, the 4096-sample pyramid on the lattice kernels, the levels "
+                          "below 64 samples lane-locally (wx_dev_dwt_long)"),
     "target_n2048": dict(kind="wpt", n=2048, batch=131072, wavelet="db4", L=10, dtype="f64",
                          kernel="k_lat_wpt_sh_f64<4, 2, 1>", inv_kernel="k_lat_iwpt_sh_f64<4, 2, 1>",
                          fwd_kernels=[("k_lat_wpt_sh_f64<4, 2, 1>", 1)],

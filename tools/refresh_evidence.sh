@@ -8,7 +8,7 @@ TAG=$1
 mkdir -p $R/gpurun_out/bench_$TAG
 cd $R
 timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu_$TAG.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu_$TAG.log | tail -1
-WL=${WX_EVIDENCE_WORKLOADS:-cfg2 target target_n2048 target_n1024 target_haar tree_random tree_pyramid cfg3 cfg3_sdwt swpt_db4 cfg4 cfg4_256 cfg4_1024 cfg5 bb ldb siwt}   # subset: only the workloads whose kernels changed
+WL=${WX_EVIDENCE_WORKLOADS:-cfg2 target target_n2048 target_n1024 target_haar tree_random tree_pyramid cfg3 cfg3_sdwt swpt_db4 cfg4 cfg4_256 cfg4_1024 cfg5 bb ldb siwt dwt_long}   # subset: only the workloads whose kernels changed
 for w in $WL; do
   bash tools/profile.sh $TAG $w pmc > /dev/null 2>&1
 done
