@@ -47,73 +47,97 @@ __host__ __device__ constexpr unsigned lat_sc_addr(unsigned o)
     return row * 512u + ((ch ^ key) << 4) + (o & 1u) * 8u;
 }
 
+// 256 threads: the tree goes to LDS once as "exists and is split" flags (eff[heap index], made top-down level by level), after
+// which every walk is a handful of LDS reads -- the first version walked the tree in global memory from one wavefront and took
+// 0.11 ms per call, a tenth of the transform it prepares.
 template <int SH>
-__global__ __launch_bounds__(64) void k_lat_treesc_prep(const uint8_t *__restrict__ status, int64_t nstatus, int L,
-                                                          WxLatTreeSc *__restrict__ tab)
+__global__ __launch_bounds__(256) void k_lat_treesc_prep(const uint8_t *__restrict__ status, int64_t nstatus, int L,
+                                                           WxLatTreeSc *__restrict__ tab)
 {
-    const int lane = threadIdx.x;
     constexpr int SB = 12 - SH;                                // index bits of one signal
-    // node (d, j) is split; the caller walks down from the root, so the ancestors are split already
-    auto sp = [&](int d, int j) {
-        const int64_t idx = ((int64_t)1 << d) + j;
-        return d < L && d < SB && idx - 1 < nstatus && status[idx - 1] != 0;
-    };
-    for (int r = 0; r < 64; ++r) {
-        const int i = lane | (r << 6), sig = i & ((1 << SH) - 1), p = i >> SH;
+    __shared__ uint8_t eff[4096];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid + 1; idx < (1 << SB); idx += 256) {
+        const int d = 31 - __clz(idx);
+        eff[idx] = (d < L && idx - 1 < nstatus && status[idx - 1] != 0) ? 1 : 0;
+    }
+    if (tid == 0) eff[0] = 0;
+    __syncthreads();
+    for (int d = 1; d < SB; ++d) {
+        for (int idx = (1 << d) + tid; idx < (2 << d); idx += 256) eff[idx] = eff[idx] & eff[idx >> 1];
+        __syncthreads();
+    }
+    // node (d, j) exists and is split
+    auto sp = [&](int d, int j) { return d < SB && eff[(1 << d) + j] != 0; };
+    for (int e = tid; e < 4096; e += 256) {
+        const int ln = e & 63, r = e >> 6;
+        const int i = ln | (r << 6), sig = i & ((1 << SH) - 1), p = i >> SH;
         int d = 0, j = 0;
         while (sp(d, j)) { j = (j << 1) | ((p >> d) & 1); ++d; }
         const unsigned o = ((unsigned)sig << SB) | ((unsigned)j << (SB - d)) | ((unsigned)p >> d);
         // the half of the image (o bit 11) is the first branch (SH = 0: the root is split) or the signal number's top bit:
         // index bit 0 (SH < 2) or 1 (SH = 2), a lane bit -- only the address inside the half is stored
-        tab->perm[((r >> 3) * 64 + lane) * 8 + (r & 7)] = (unsigned short)(lat_sc_addr(o & 4095u) & 0x3fffu);
+        tab->perm[((r >> 3) * 64 + ln) * 8 + (r & 7)] = (unsigned short)(lat_sc_addr(o & 4095u) & 0x3fffu);
     }
-    // lanes whose node -- the one the level on index bit b would split -- is split; the path of that node is index bits SH .. b - 1
-    auto level_mask = [&](int b, auto bit_of) {
+    // lanes whose node -- the one the level on index bit b would split -- is split; the path of that node is index bits SH .. b - 1.
+    // Mask q of the 2 + 192 + 192 is made by wavefront q mod 4.
+    auto level_bit = [&](int b, auto bit_of) {
         const int d = b - SH;
+        if (d < 0) return false;
         int j = 0;
         for (int t = 0; t < d; ++t) j |= bit_of(SH + t) << (d - 1 - t);
-        return __ballot(d >= 0 && d < L && d < SB && lat_tree_split(status, nstatus, d, j));
+        return sp(d, j);
     };
-    unsigned long long acc = 0;
-    for (int s = 0; s < 2; ++s) {
-        const unsigned long long m = level_mask(1, [&](int) { return s; });                     // layout A: index bit 0 = register bit 0
-        if (lane == 0) tab->mA[s] = m;
-        acc |= m;
-    }
-    if (lane == 0) tab->anyA = acc != 0;
-    int nactB = 0;
-    for (int K = 0; K < 6; ++K) {
-        acc = 0;
-        for (int s = 0; s < (1 << K); ++s) {
+    for (int q = wave; q < 2 + 192 + 192; q += 4) {
+        bool bit;
+        if (q < 2) {
+            const int s = q;
+            bit = level_bit(1, [&](int) { return s; });                                      // layout A: index bit 0 = register bit 0
+        } else if (q < 2 + 192) {
+            const int K = (q - 2) >> 5, s = (q - 2) & 31;
             // layout B: index bits 0, 1 = lane bits 4, 5; bits 2 .. = register bits 0 ..
-            const unsigned long long m = level_mask(2 + K, [&](int sb) { return sb < 2 ? (lane >> (4 + sb)) & 1 : (s >> (sb - 2)) & 1; });
-            if (lane == 0) tab->mB[32 * K + s] = m;
-            acc |= m;
-            if (K >= 4 && m) ++nactB;
-        }
-        if (lane == 0) tab->anyB[K] = acc != 0;
-    }
-    // bits 6, 7: in layout C a lane is a node of depth 6, so a register class is busy as soon as one of 64 nodes is split
-    // there; in layout B only 4 nodes share a class (at the price of halo moves): B when at most half of its 48 classes are busy
-    if (lane == 0) tab->deepB = nactB <= 24;
-    for (int K = 0; K < 6; ++K) {
-        acc = 0;
-        for (int s = 0; s < (1 << K); ++s) {
+            bit = s < (1 << K) && level_bit(2 + K, [&](int sb) { return sb < 2 ? (lane >> (4 + sb)) & 1 : (s >> (sb - 2)) & 1; });
+        } else {
+            const int K = (q - 194) >> 5, s = (q - 194) & 31;
             // layout C: index bits 0 .. 5 = lane bits, bits 6 .. = register bits
-            const unsigned long long m = level_mask(6 + K, [&](int sb) { return sb < 6 ? (lane >> sb) & 1 : (s >> (sb - 6)) & 1; });
-            if (lane == 0) tab->mC[32 * K + s] = m;
-            acc |= m;
+            bit = s < (1 << K) && level_bit(6 + K, [&](int sb) { return sb < 6 ? (lane >> sb) & 1 : (s >> (sb - 6)) & 1; });
         }
-        if (lane == 0) tab->anyC[K] = acc != 0;
+        const unsigned long long m = __ballot(bit);
+        if (lane == 0) {
+            if (q < 2) tab->mA[q] = m;
+            else if (q < 194) tab->mB[q - 2] = m;
+            else tab->mC[q - 194] = m;
+        }
     }
-    unsigned dep[4] = {0, 0, 0, 0};
-    for (int q = 0; q < 32; ++q) {
-        const int pos = (128 * q + 2 * lane) & ((1 << SB) - 1);  // q = 16 h + k; position inside its signal
+    for (int e = tid; e < 2048; e += 256) {
+        const int ln = e & 63, q = e >> 6;                         // piece q = 16 h + k of lane ln: elements 128 q + 2 ln, +1
+        const int pos = (128 * q + 2 * ln) & ((1 << SB) - 1);
         int d = 0;
         while (sp(d, pos >> (SB - d))) ++d;
-        dep[q >> 3] |= (unsigned)d << (4 * (q & 7));
+        atomicOr(&tab->dep[64 * (q >> 3) + ln], (unsigned)d << (4 * (q & 7)));
     }
-    for (int w = 0; w < 4; ++w) tab->dep[64 * w + lane] = dep[w];
+}
+// second step: the "any" flags and the choice of layout for the levels on bits 6, 7 out of the masks (one wavefront)
+__global__ __launch_bounds__(64) void k_lat_treesc_prep2(WxLatTreeSc *__restrict__ tab)
+{
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        tab->anyA = (tab->mA[0] | tab->mA[1]) != 0;
+        int nactB = 0;
+        for (int K = 0; K < 6; ++K) {
+            unsigned long long aB = 0, aC = 0;
+            for (int s = 0; s < (1 << K); ++s) {
+                aB |= tab->mB[32 * K + s];
+                aC |= tab->mC[32 * K + s];
+                if (K >= 4 && tab->mB[32 * K + s]) ++nactB;
+            }
+            tab->anyB[K] = aB != 0;
+            tab->anyC[K] = aC != 0;
+        }
+        // bits 6, 7: in layout C a lane is a node of depth 6, so a register class is busy as soon as one of 64 nodes is split
+        // there; in layout B only 4 nodes share a class (at the price of halo moves): B when at most half of its 48 classes are busy
+        tab->deepB = nactB <= 24;
+    }
 }
 
 // one packet level on register-index bit K under the lane masks mk[s] (one per register class s = low K register bits),
