@@ -52,7 +52,7 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
         WxLatTreeSc *tsc = (WxLatTreeSc *)scr.alloc(sizeof(WxLatTreeSc));
         if (!tsc) return WX_EHIP;
         if (hipMemsetAsync(tsc->dep, 0, sizeof(tsc->dep), st) != hipSuccess) return wx_set_error(WX_EHIP, "lattice tree tables");
-        hipLaunchKernelGGL((k_lat_treesc_prep<SH>), dim3(1), dim3(256), 0, st, dstatus, nstatus, L, tsc);
+        hipLaunchKernelGGL((k_lat_treesc_prep<SH>), dim3(8), dim3(256), 0, st, dstatus, nstatus, L, tsc);
         hipLaunchKernelGGL(k_lat_treesc_prep2, dim3(1), dim3(64), 0, st, tsc);
         const WxLatTreeSc *ctsc = tsc;
         const unsigned nw = (unsigned)((batch + per - 1) / per);

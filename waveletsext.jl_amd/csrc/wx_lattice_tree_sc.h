@@ -47,7 +47,7 @@ __host__ __device__ constexpr unsigned lat_sc_addr(unsigned o)
     return row * 512u + ((ch ^ key) << 4) + (o & 1u) * 8u;
 }
 
-// 256 threads: the tree goes to LDS once as "exists and is split" flags (eff[heap index], made top-down level by level), after
+// 8 workgroups of 256 threads, each with its own LDS copy of the tree and an eighth of the tables: the tree goes to LDS as "exists and is split" flags (eff[heap index], made top-down level by level), after
 // which every walk is a handful of LDS reads -- the first version walked the tree in global memory from one wavefront and took
 // 0.11 ms per call, a tenth of the transform it prepares.
 template <int SH>
@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void k_lat_treesc_prep(const uint8_t *__restri
     }
     // node (d, j) exists and is split
     auto sp = [&](int d, int j) { return d < SB && eff[(1 << d) + j] != 0; };
-    for (int e = tid; e < 4096; e += 256) {
+    constexpr int NB = 8;                                      // workgroups (the launch's grid)
+    const int blk = blockIdx.x;
+    for (int e = 512 * blk + tid; e < 512 * (blk + 1); e += 256) {
         const int ln = e & 63, r = e >> 6;
         const int i = ln | (r << 6), sig = i & ((1 << SH) - 1), p = i >> SH;
         int d = 0, j = 0;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void k_lat_treesc_prep(const uint8_t *__restri
         for (int t = 0; t < d; ++t) j |= bit_of(SH + t) << (d - 1 - t);
         return sp(d, j);
     };
-    for (int q = wave; q < 2 + 192 + 192; q += 4) {
+    for (int q = 4 * blk + wave; q < 2 + 192 + 192; q += 4 * NB) {
         bool bit;
         if (q < 2) {
             const int s = q;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void k_lat_treesc_prep(const uint8_t *__restri
             else tab->mC[q - 194] = m;
         }
     }
-    for (int e = tid; e < 2048; e += 256) {
+    for (int e = 256 * blk + tid; e < 256 * (blk + 1); e += 256) {
         const int ln = e & 63, q = e >> 6;                         // piece q = 16 h + k of lane ln: elements 128 q + 2 ln, +1
         const int pos = (128 * q + 2 * ln) & ((1 << SB) - 1);
         int d = 0;
