@@ -43,12 +43,12 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
     if (thr && thr->t) ta = *thr;
     if (thr) ta.head = thr->head;
     (void)ta;
-    // trees deeper than 4 levels: every level under the tree's masks, one permutation through LDS (wx_lattice_tree_sc.h).
-    // Shallow trees keep the first form -- its leaves leave right after their level and the kernel returns after the last one
-    // (depth-4 pyramid, 65536 x 4096 db4: 0.80 / 0.84 ms against 0.81-0.85 / 0.85-0.89; 2048 samples 0.86 / 0.80 against
-    // 0.84 / 0.91).  WX_TREE_SC=0 / 1 forces one of the two.
+    // every level under the tree's masks, one permutation through LDS (wx_lattice_tree_sc.h).  The first form of round 3 -- leaves
+    // leave right after their level, the kernel returns after the last one -- is kept behind WX_TREE_SC=0 for dense signals: with the
+    // tables made in LDS the masked form is at least as fast on every tree measured (depth-4 pyramid, 65536 x 4096 db4: 0.77 / 0.83 ms
+    // against 0.85 / 0.82; deep random trees 0.86 / 0.85 against 1.15 / 1.33).
     static const int sc_env = getenv("WX_TREE_SC") ? atoi(getenv("WX_TREE_SC")) : -1;
-    if ((sc_env != 0 && (L > 4 || sc_env == 1 || ta.head)) || strided) {
+    if (sc_env != 0 || strided || ta.head) {
         WxLatTreeSc *tsc = (WxLatTreeSc *)scr.alloc(sizeof(WxLatTreeSc));
         if (!tsc) return WX_EHIP;
         if (hipMemsetAsync(tsc->dep, 0, sizeof(tsc->dep), st) != hipSuccess) return wx_set_error(WX_EHIP, "lattice tree tables");
