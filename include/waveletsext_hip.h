@@ -48,6 +48,9 @@ extern "C" {
 int wx_version(void);                       /* 10000*major + 100*minor + patch */
 const char *wx_last_error(void);            /* message of the last failing call on this thread */
 int wx_device_count(void);                  /* number of visible HIP devices (0 if none) */
+/* what this binary was built from: "libwaveletsext_hip <version> src=<digest of the kernel sources> git=<commit>[+dirty]
+ * arch=<gfx target> hip=<HIP version> clang=<compiler> flags=[...]" (static string; bench.py prints it in its line) */
+const char *wx_build_info(void);
 /* releases the library's only state, the cached stream-ordered scratch of the current device */
 int wx_shutdown(void);
 /* test hook: 1 forces the one-level-per-launch kernels instead of the fused kernels; 2 keeps the fused LDS kernels

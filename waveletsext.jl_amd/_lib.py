@@ -43,6 +43,7 @@ def _declare(L):
     L.wx_version.restype = _I
     L.wx_last_error.restype = ctypes.c_char_p
     L.wx_device_count.restype = _I
+    L.wx_build_info.restype = ctypes.c_char_p
     L.wx_set_force_generic.argtypes = [_I]
     L.wx_set_force_generic.restype = None
     sigs = {
@@ -178,6 +179,11 @@ def check(rc):
 
 def device_count():
     return lib().wx_device_count()
+
+
+def build_info():
+    """what the loaded binary was built from (source digest, commit, compiler, flags): wx_build_info"""
+    return lib().wx_build_info().decode("utf-8", "replace")
 
 
 def shutdown():
