@@ -162,7 +162,12 @@ def parse():
     ap.add_argument("--dump", default="", help="validation: rank 0 saves the (gathered) reconstructed output as .npy")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the all-gather loop is on by default)")
+    ap.add_argument("--gather", nargs="?", const="auto", default="auto", choices=["p2p", "collective", "auto"],
+                    help="N > 1: exchange schedule of the all-gather loop -- grouped point-to-point (every piece lands in place), "
+                         "one all_gather collective per chunk, or auto = point-to-point, switching to the collective if it raises")
+    ap.add_argument("--watchdog", type=float, default=900.0,
+                    help="seconds after which a rank that has not finished dumps where it is and exits 3 (a hung collective must "
+                         "not hold the machine); 0 disables")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the `also` block (the other headline workloads, hipEvent-timed in the same run; N = 1 only)")
     return ap.parse_args()
@@ -406,6 +411,8 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
 
     W = Workload()
     W.lo, W.hi, W.B_all = lo, hi, B_all
+    G = {"g": None, "mode": "collective" if a.gather == "collective" else "p2p"}     # the exchange object of step_gather
+    W.G = G
 
     if kind in ("wpd", "wpt", "wpt2d"):
         sig = (w["n"],) if kind != "wpt2d" else (w["m"], w["n"])
@@ -435,15 +442,17 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
         g = None
         if want_gather:
             # strong: the shards of one batch; weak: every rank's own batch, concatenated
-            g = wd.OverlappedAllGather(full, B_out, nchunks=a.chunks)
+            G["g"] = g = wd.make_gather(full, B_out, nchunks=a.chunks, mode=G["mode"])
             assert (g.lo, g.hi) == (out_lo, out_lo + Bl), "shards of the gather and of the bench disagree"
             nposts = g.nposts
+            W.set_gather_mode = lambda mode: G.update(mode=mode, g=wd.make_gather(full, B_out, nchunks=a.chunks, mode=mode))
 
         def step(legs):
             legs.run("fwd", fwd)
             legs.run("inv", lambda: inv_to(0, Bl, xh))
 
         def step_gather(legs):
+            g = G["g"]
             legs.run("fwd", fwd)
             for c in range(nposts):
                 if c < len(g.chunks):
@@ -498,8 +507,9 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
 
         W.gatherable = want_gather
         if want_gather:
-            g = wd.OverlappedAllGather(full, B_out, nchunks=a.chunks)
+            G["g"] = g = wd.make_gather(full, B_out, nchunks=a.chunks, mode=G["mode"])
             nposts = g.nposts
+            W.set_gather_mode = lambda mode: G.update(mode=mode, g=wd.make_gather(full, B_out, nchunks=a.chunks, mode=mode))
 
         def step(legs):
             for c0, c1 in chunks:
@@ -508,6 +518,7 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
 
         def step_gather(legs):
             # the gather's pieces are groups of whole resident chunks
+            g = G["g"]
             for c in range(nposts):
                 if c < len(g.chunks):
                     g0, g1 = g.chunks[c]
@@ -742,7 +753,20 @@ def main():
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.run(cmd).returncode)
+        # the ranks are fresh child processes in their own process group (never a re-exec of this one); if they outlive the
+        # watchdog -- each rank has its own, this is the backstop -- the whole group is killed and the exit code says so
+        import signal
+        child = subprocess.Popen(cmd, start_new_session=True)
+        try:
+            sys.exit(child.wait(timeout=(a.watchdog + 120.0) if a.watchdog > 0 else None))
+        except subprocess.TimeoutExpired:
+            sys.stderr.write("bench.py: ranks still running after %.0f s, killing process group %d\n" % (a.watchdog + 120.0, child.pid))
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            child.wait()
+            sys.exit(3)
     import torch
     import torch.distributed as dist
     import waveletsext_jl_amd as wx
@@ -750,6 +774,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    stage = {"at": "start"}                              # where this rank is, for the watchdog's last words
+    wd_timer = None
+    if a.watchdog > 0:
+        import faulthandler
+        import threading
+
+        def _abort():
+            sys.stderr.write("bench.py watchdog: rank %d of %d not finished after %.0f s (at: %s); exiting 3\n"
+                             % (rank, world, a.watchdog, stage["at"]))
+            faulthandler.dump_traceback(file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(3)
+
+        wd_timer = threading.Timer(a.watchdog, _abort)
+        wd_timer.daemon = True
+        wd_timer.start()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -769,9 +809,22 @@ def main():
     w = dict(WORKLOADS[a.workload])
     if a.batch:
         w["batch"] = a.batch
+    stage["at"] = "make_workload"
     W = make_workload(w, wx, torch, dev, rank, world, a, dist)
     info = W.info
     red_dev = dev if backend == "nccl" else "cpu"
+
+    def across_ranks(v):
+        """one number per rank, in rank order, on every rank"""
+        if world == 1:
+            return [float(v)]
+        t = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        t[rank] = float(v)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
+
+    stage["at"] = "first collective (device indices)"
+    rank_devices = [int(v) for v in across_ranks(local)]
 
     def sync():
         if world > 1:
@@ -794,6 +847,7 @@ def main():
             per_rank = [float(v) for v in t.tolist()]
         return max(per_rank), per_rank, legs
 
+    stage["at"] = "warm-up steps"
     warm = Legs(torch)
     for _ in range(a.warmup):
         W.step(warm)
@@ -802,6 +856,7 @@ def main():
     tol = 1e-10 if w["dtype"] == "f64" else 1e-5
     assert err < tol, "round trip broken: %g" % err
 
+    stage["at"] = "timed steps"
     elapsed, per_rank, legs = timed(W.step)
     fwd_ms, inv_ms = legs.ms("fwd"), legs.ms("inv")
     fwd_avg = sum(fwd_ms) / len(fwd_ms)
@@ -812,16 +867,32 @@ def main():
     if W.gatherable:
       try:
           # second loop: the all-gather of the reconstructed output inside the step, overlapped with the inverse
-          for _ in range(max(1, min(a.warmup, 2))):
-              W.step_gather(Legs(torch))
+          stage["at"] = "all-gather loop, warm-up (%s)" % W.G["mode"]
+          p2p_error = None
+          try:
+              for _ in range(max(1, min(a.warmup, 2))):
+                  W.step_gather(Legs(torch))
+              torch.cuda.synchronize(dev)
+              failed = 0.0
+          except Exception as e:
+              if a.gather != "auto" or W.G["mode"] != "p2p":
+                  raise
+              p2p_error, failed = "%s: %s" % (type(e).__name__, e), 1.0
+          if a.gather == "auto" and W.G["mode"] == "p2p" and max(across_ranks(failed)) > 0:
+              # the grouped point-to-point exchange raised on some rank: every rank switches to one collective per chunk
+              W.set_gather_mode("collective")
+              stage["at"] = "all-gather loop, warm-up (collective, after the point-to-point group raised)"
+              for _ in range(max(1, min(a.warmup, 2))):
+                  W.step_gather(Legs(torch))
           sync()
+          stage["at"] = "all-gather loop, timed (%s)" % W.G["mode"]
           g_elapsed, g_per_rank, _ = timed(W.step_gather)
           # the exchange alone (nothing to overlap with), for the budget: one step's worth of posts
           from waveletsext_jl_amd import distributed as wd
           full = W.output(True)
           sync()
           t1 = time.perf_counter()
-          gg = wd.OverlappedAllGather(full, full.shape[-1], nchunks=a.chunks)
+          gg = wd.make_gather(full, full.shape[-1], nchunks=a.chunks, mode=W.G["mode"])
           for c in range(gg.nposts):
               gg.post(c)
           gg.finish()
@@ -832,10 +903,12 @@ def main():
                     "allgather_alone_ms": alone_ms,
                     "exposed_ms": (g_elapsed - elapsed) / a.steps * 1e3,
                     "overlap_ms": max(0.0, alone_ms - (g_elapsed - elapsed) / a.steps * 1e3),
-                    "chunks": a.chunks, "bytes_received_per_rank": float(info.get("gather_bytes", 0)),
+                    "chunks": a.chunks, "mode": W.G["mode"], "p2p_error": p2p_error,
+                    "bytes_received_per_rank": float(info.get("gather_bytes", 0)),
                     "per_rank_ms": [v / a.steps * 1e3 for v in g_per_rank],
-                    "schedule": "inverse in %d chunks; chunk c's exchange (grouped point-to-point, every piece lands in "
-                                "place) on a side stream while chunk c+1 is transformed" % a.chunks}
+                    "schedule": "inverse in %d chunks; chunk c's exchange (%s) on a side stream while chunk c+1 is transformed"
+                                % (a.chunks, "grouped point-to-point, every piece lands in place" if W.G["mode"] == "p2p"
+                                   else "one all_gather collective per chunk")}
           gerr = float((full[..., W.lo:W.hi] - W.keep[0]).abs().max() / W.keep[0].abs().max()) if a.scaling == "strong" else None
           if gerr is not None:
               assert gerr < tol, "gathered output broken: %g" % gerr
@@ -900,7 +973,12 @@ def main():
                         "achieved_GBs": info["inv_bytes"] / (inv_avg * 1e-3) / 1e9,
                         "frac": info["inv_bytes"] / (inv_avg * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "roundtrip_rel_err": err,
+            "build": wx.build_info(),
             "ranks": {"nranks": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
+                      "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version())
+                                       if world > 1 and backend == "nccl" else None),
+                      "devices": rank_devices, "device_name": torch.cuda.get_device_name(dev),
+                      "visible_devices": torch.cuda.device_count(),
                       "per_rank_ms": [v / a.steps * 1e3 for v in per_rank],
                       "min_ms": min(per_rank) / a.steps * 1e3, "max_ms": max(per_rank) / a.steps * 1e3},
         }
@@ -926,9 +1004,12 @@ def main():
             out["cpu_baseline"] = cb
             if allc is not None:
                 out["cpu_baseline_all_cores"] = allc
+    stage["at"] = "final barrier"
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if wd_timer is not None:
+        wd_timer.cancel()
     if rank == 0:
         print(json.dumps(out))
 

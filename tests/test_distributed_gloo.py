@@ -81,9 +81,11 @@ def _worker(rank, world, port, B, out_dir):
         np.testing.assert_allclose(Gfull, wo.ldb_energy_map(Y, labels), rtol=1e-12, atol=1e-14)
         # C1 in pieces (the bench's overlapped schedule): every rank fills the chunks of its own shard of `full` in
         # place and posts them; afterwards every rank holds the whole array.  Ragged shards, more pieces than signals.
-        for nchunks in (1, 3, 4, 16):
+        # ... through both exchange schedules: grouped point-to-point, and one all_gather collective per chunk
+        for nchunks, mode in [(k, m) for k in (1, 3, 4, 16) for m in ("p2p", "collective")]:
             fullt = torch.full((B, n), float("nan"), dtype=torch.float64).T          # column-major (n, B)
-            g = wd.OverlappedAllGather(fullt, B, nchunks=nchunks)
+            g = wd.make_gather(fullt, B, nchunks=nchunks, mode=mode)
+            assert type(g) is (wd.OverlappedAllGather if mode == "p2p" else wd.CollectiveAllGather)
             assert (g.lo, g.hi) == (lo, hi)
             assert g.nposts == max(len(wd.chunk_ranges(sz, nchunks)) for sz in wd.shard_sizes(B, world))
             for c in range(g.nposts):

@@ -169,6 +169,75 @@ class OverlappedAllGather:
         self.posted = 0                                    # the object serves the next step
 
 
+class CollectiveAllGather(OverlappedAllGather):
+    """The same exchange schedule as OverlappedAllGather -- chunk c of every shard while chunk c + 1 is computed -- with one
+    `all_gather` collective per chunk instead of the grouped point-to-point pattern (`bench.py --gather collective`, and
+    what `make_gather(..., mode="auto")` falls back to when the point-to-point group raises).  Pieces of equal size are
+    gathered straight into their places in `full`; when the ranks' chunk c differ in size (by at most one signal) they are
+    padded to the largest, gathered into a staging buffer and copied to their places."""
+
+    def post(self, c):
+        if c != self.posted or c >= self.nposts:
+            raise ValueError("CollectiveAllGather.post(%d): exchanges are posted in order, %d of %d done" % (c, self.posted, self.nposts))
+        self.posted += 1
+        if self.world == 1:
+            return
+        pieces = [self._peer_chunk(r, c) if r != self.rank else (self.local_chunk(c) if c < len(self.chunks) else None)
+                  for r in range(self.world)]
+        sizes = [0 if p is None else int(p.shape[-1]) for p in pieces]
+        smax = max(sizes)
+        if smax == 0:
+            return
+        dev = self.full.device
+        rev = tuple(reversed(tuple(self.full.shape[:-1])))
+        stage = "cpu" if self.host_staged else dev
+
+        def run():
+            if len(set(sizes)) == 1 and not self.host_staged:
+                outs = [_as_batch_major(p) for p in pieces]               # every piece lands in its place
+                return [dist.all_gather(outs, outs[self.rank], group=self.group, async_op=True)], None
+            src = torch.zeros((smax,) + rev, dtype=self.full.dtype, device=stage)
+            if sizes[self.rank]:
+                src[: sizes[self.rank]].copy_(_as_batch_major(pieces[self.rank]))
+            buf = torch.empty((self.world * smax,) + rev, dtype=self.full.dtype, device=stage)
+            wk = dist.all_gather_into_tensor(buf, src, group=self.group, async_op=True)
+            return [wk], buf
+
+        def place(buf):
+            for r in range(self.world):
+                if r != self.rank and sizes[r]:
+                    _as_batch_major(pieces[r]).copy_(buf[r * smax: r * smax + sizes[r]])
+
+        if self.cuda and not self.host_staged:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))                       # chunk c is complete on the caller's stream
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                works, buf = run()
+                if buf is not None:
+                    for wk in works:
+                        wk.wait()
+                    place(buf)
+                else:
+                    self.work.extend(works)
+        else:
+            if self.cuda:
+                torch.cuda.current_stream(dev).synchronize()
+            works, buf = run()
+            for wk in works:
+                wk.wait()
+            if buf is not None:
+                place(buf)
+
+
+def make_gather(full, B_total, nchunks=4, group=None, mode="p2p"):
+    """the exchange object of the reconstructed output: mode "p2p" (grouped point-to-point, every piece lands in place) or
+    "collective" (one all_gather per chunk)"""
+    if mode not in ("p2p", "collective"):
+        raise ValueError("gather mode must be p2p or collective")
+    return (OverlappedAllGather if mode == "p2p" else CollectiveAllGather)(full, B_total, nchunks=nchunks, group=group)
+
+
 def allreduce_moments(s, q, group=None):
     """C2: in-place all-reduce(sum) of the JBB moment arrays (one fused buffer, one collective)."""
     fused = torch.stack([_as_batch_major(s).contiguous().reshape(-1), _as_batch_major(q).contiguous().reshape(-1)])
