@@ -1,0 +1,27 @@
+"""No cliff next to the benchmarked shapes: every dyadic signal length 64 ... 65536, depths 1 / 4 / full, full
+trees, pyramids (dwtall / idwtall, dwt/dwt_all.jl:39-110) and a random tree (wptall / iwptall along a tree, dwt_all.jl:152-225),
+Float64 and Float32, 1 GiB batches, must run at >= 15 % of the HBM peak on the algorithmic bytes in BOTH directions, and round-trip.
+The table goes to gpurun_out/r04_floor.txt (copied to profiles/ by the builder)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+FLOOR = 0.15
+
+
+def test_no_entry_below_the_floor(wx):
+    import floor_scan
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r04_floor.txt"), "w") as f:
+        f.write("# tools/floor_scan.py db4, one MI355X, 1 GiB batches; fraction of 8 TB/s on signal-read-once + written-once bytes\n")
+        rows = floor_scan.scan("db4", out=f)
+    assert len(rows) >= 100
+    bad = [r for r in rows if r["fwd_frac"] < FLOOR or r["inv_frac"] < FLOOR]
+    assert not bad, "below %.0f %% of the HBM peak: %s" % (100 * FLOOR, [(r["dtype"], r["n"], r["case"], round(r["fwd_frac"], 3), round(r["inv_frac"], 3)) for r in bad])
+    tol = {"f64": 1e-10, "f32": 1e-5}
+    assert all(r["roundtrip"] <= tol[r["dtype"]] for r in rows)

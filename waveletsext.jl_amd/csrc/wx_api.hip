@@ -3,7 +3,9 @@
 #include "../../include/waveletsext_hip.h"
 #include "wx_host.h"
 #include "wx_kernels.h"
+#include "wx_lanetree.h"
 #include <atomic>
+#include <cstring>
 
 const char *wx_err_cstr();
 static std::atomic<int> g_force_generic{0};
@@ -127,9 +129,18 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     std::vector<uint8_t> ttree;
     // (measured, 65536 x 4096 Float64 db4, depth-12 pyramid: the whole pyramid through the tree-driven lattice kernels 1.22 /
     // 1.51 ms, with the tail 1.15 / 1.00 ms -- the tail stays; the levels above it take the lattice in the forward direction)
-    const int tail = wx_pyramid_tail<T>(n, F, INVERSE, tree, ntree, ttree, filt, true);
+    // short signals take the small-signal kernel whole (wx_smalltree.hip), pyramids included: no tail cut for them
+    bool is_pyr = false;
+    if (tree) {
+        const int Ld = wx_tree_depth1d(tree, ntree);
+        is_pyr = Ld >= 1;
+        for (int64_t i = 1; i <= ntree && is_pyr; ++i) is_pyr = (tree[i - 1] != 0) == ((i & (i - 1)) == 0 && i < ((int64_t)1 << Ld));
+    }
+    const bool small_pyr = is_pyr && !wx_force_generic() && wx_small_tree_wanted<T>(n, F, true, true);
+    const int tail = small_pyr ? 0 : wx_pyramid_tail<T>(n, F, INVERSE, tree, ntree, ttree, filt, true);
     if (tail) tree = ttree.data();
     if ((rc = wx_resolve_tree1d(n, L, tree, ntree, scr, &tr, "wpt"))) return rc;
+    const bool small = !wx_force_generic() && !tail && wx_small_tree_wanted<T>(n, F, !tr.full, is_pyr);
     // the pyramid of a long signal (dwt / idwt of 16384 .. 65536 samples): tiled top levels + the lattice (wx_dev_dwt_long)
     bool longp = false;
     if (tree && tr.dstatus && tr.Leff >= 1 && !wx_force_generic() && wx_dwt_long_ok<T>(n, filt)) {
@@ -141,6 +152,22 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     T *dy = (T *)io.out(y, sizeof(T) * n * batch);
     if ((batch && n) && (!dx || !dy)) return io.finish(WX_EHIP);
     const int force = wx_force_generic();
+    if (small && tr.Leff >= 1 && batch && dx != dy) {
+        static const bool lane_off = getenv("WX_LANETREE") && atoi(getenv("WX_LANETREE")) == 0;
+        if (!lane_off && (n <= 64 || (n <= 128 && sizeof(T) == 4))) {
+            // one lane per signal: the tree as a bit mask (at most 255 nodes of depth < Leff)
+            WxLaneTree lt;
+            memset(&lt, 0, sizeof lt);
+            const int64_t nn = ((int64_t)1 << tr.Leff) - 1;
+            for (int64_t h = 0; h < nn; ++h)
+                if (tr.full || (h < ntree && tree[h])) lt.bits[h >> 5] |= 1u << (h & 31);
+            if constexpr (sizeof(T) == 8)
+                return io.finish(wx_lane_tree_f64(INVERSE, (const double *)dx, (double *)dy, n, tr.Leff, batch, lt, filt, st));
+            else
+                return io.finish(wx_lane_tree_f32(INVERSE, (const float *)dx, (float *)dy, n, tr.Leff, batch, lt, filt, st));
+        }
+        return io.finish(wx_dev_small_tree<T>(INVERSE, dx, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, st));
+    }
     T *s1 = nullptr;
     const bool fused = !force && wx_fused1d_ok<T>(n, F);
     // long Float64 signals with a full tree take one pass per top level and then the lattice kernels: one scratch array

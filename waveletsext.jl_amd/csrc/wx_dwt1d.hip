@@ -20,6 +20,27 @@
 #include "wx_common.h"
 #include "wx_kernels.h"
 #include "wx_host.h"
+#include "wx_toptile.h"
+
+// the tree-driven lattice kernels for either signal type (Float32: dense leaves only, no threshold riding on the loads)
+template <typename T>
+static int wx_lattice_tree_T(bool inverse, const T *x, T *y, int64_t n, int L, int64_t batch, int64_t in_stride, int64_t col_stride,
+                             const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, hipStream_t st, const WxThreshArg *thr = nullptr,
+                             int64_t out_stride = 0)
+{
+    if constexpr (sizeof(T) == 8)
+        return wx_lattice_tree_f64(inverse, (const double *)x, (double *)y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, thr,
+                                   out_stride);
+    else {
+        if (col_stride) return 0;
+        return wx_lattice_tree_f32(inverse, (const float *)x, (float *)y, n, L, batch, in_stride, filt, dstatus, nstatus, st, thr, out_stride);
+    }
+}
+template <typename T> static bool wx_lattice_tree_applicable_T(int64_t n, const WxFilt &filt)
+{
+    if constexpr (sizeof(T) == 8) return wx_lattice_tree_applicable_f64(n, filt);
+    else return wx_lattice_tree_applicable_f32(n, filt);
+}
 #include <stdlib.h>
 #include <string.h>
 
@@ -1369,6 +1390,45 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
             if (r) return r < 0 ? r : WX_OK;
         }
     }
+    // Long signals, full tree: the top levels up to four per pass through LDS (wx_toptile.h; one pass per level until round 4),
+    // after which every node is an independent signal -- contiguous, (n2, batch << d0) in Julia layout -- that the lattice
+    // kernels (n2 = 4096) or the fused LDS kernel (the longest signal a CU's LDS holds) finish at their own rate.
+    if (!force_generic && !status && x != y && wx_is_pow2(n) && n > 4096 && wx_top_levels_ok(filt.F)) {
+        int dl = 0;
+        while (((int64_t)4096 << dl) < n) ++dl;
+        bool lat = !noreg && L - dl >= 6 && n < ((int64_t)1 << 30);
+        if constexpr (sizeof(T) == 8) lat = lat && wx_lattice_applicable_f64(filt);
+        int64_t n2 = 4096;
+        if (!lat) { n2 = n; while (n2 > 2 && !wx_fused1d_ok<T>(n2, filt.F)) n2 >>= 1; }
+        int d0 = 0;
+        while ((n2 << d0) < n) ++d0;
+        if (d0 >= 1 && wx_fused1d_ok<T>(lat ? 4096 : n2, filt.F) && (scratch || (L <= d0 && L <= 4))) {
+            const int Ltop = L < d0 ? L : d0;
+            const int npass = (Ltop + 3) / 4;
+            // the nodes of depth Ltop land in scratch when a finishing kernel follows (it writes y), in y otherwise
+            T *target = L > Ltop ? scratch : y;
+            const T *src = x;
+            for (int p = 0; p < npass; ++p) {
+                T *dst = ((npass - 1 - p) & 1) ? (target == y ? scratch : y) : target;
+                const int NLp = Ltop - 4 * p < 4 ? Ltop - 4 * p : 4;
+                const int64_t np = n >> (4 * p);
+                const int rc = wx_dev_top_levels<T>(false, src, dst, (T *)nullptr, np, NLp, batch << (4 * p), np, np, np, 0xffffffffu, 0u, filt, st);
+                if (rc) return rc;
+                src = dst;
+            }
+            if (L == Ltop) return WX_OK;
+            if (lat) {
+                int r;
+                if constexpr (sizeof(T) == 8)
+                    r = wx_lattice_wpt_f64((const double *)scratch, (double *)y, 4096, L - d0, batch << d0, filt, st);
+                else
+                    r = wx_lattice_f32(false, (const float *)scratch, (float *)y, 4096, L - d0, batch << d0, 4096, filt, st);
+                if (r < 0) return r;
+                if (r == 1) return WX_OK;
+            }
+            return launch_fwd_fused<T, false>(scratch, y, n2, L - d0, batch << d0, n2, n2, filt, nullptr, 0, st);
+        }
+    }
     {
         // Longer signals, full tree: after d0 = log2(n / 4096) levels every node is an independent 4096-sample signal --
         // contiguous, (4096, batch << d0) in Julia layout -- which the lattice kernels finish at their own rate.  The top
@@ -1401,11 +1461,11 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
             return launch_fwd_fused<T, false>(scratch, y, 4096, L - dl, batch << dl, 4096, 4096, filt, nullptr, 0, st);
         }
     }
-    if constexpr (sizeof(T) == 8) {
+    {
         // a tree (bestbasistree, maketree(:dwt), ...): the lattice computes every node in registers, the tree decides which
-        // lines leave after which level (wx_lattice_tree.h)
+        // lines leave after which level (wx_lattice_tree.h; Float32 signals since round 4: wx_lattice_tree32.h)
         if (!force_generic && !noreg && status) {
-            const int r = wx_lattice_tree_f64(false, (const double *)x, (double *)y, n, L, batch, n, 0, filt, status, nstatus, st);
+            const int r = wx_lattice_tree_T<T>(false, x, y, n, L, batch, n, 0, filt, status, nstatus, st);
             if (r) return r < 0 ? r : WX_OK;
         }
     }
@@ -1464,10 +1524,15 @@ template <typename T> static int64_t wx_dwt_long_plan(int64_t n, const WxFilt &f
 {
     static const bool off = getenv("WX_DWT_LONG") && atoi(getenv("WX_DWT_LONG")) == 0;
     *lattice = false;
-    if (off || !wx_is_pow2(n) || n > ((int64_t)1 << 24) || wx_fused1d_ok<T>(n, filt.F)) return 0;
-    if constexpr (sizeof(T) == 8) {
-        if (n >= 16384 && !wx_skip_register_kernels() && wx_lattice_tree_applicable_f64(4096, filt)) { *lattice = true; return 4096; }
+    if (off || !wx_is_pow2(n) || n > ((int64_t)1 << 24)) return 0;
+    // 8192 samples (and, Float32, 16384) fit the fused LDS kernel, but one top pass + the lattice pyramid on the approximation
+    // moves 3 n samples at memory speed (Float64 8192 samples: 1.38 -> 1.2 ms per 2 GiB)
+    if (n >= 8192 && wx_top_levels_ok(filt.F) && !wx_skip_register_kernels() && wx_lattice_tree_applicable_T<T>(4096, filt)) {
+        *lattice = true;
+        return 4096;
     }
+    if (wx_fused1d_ok<T>(n, filt.F)) return 0;
+    if (n >= 16384 && !wx_skip_register_kernels() && wx_lattice_tree_applicable_T<T>(4096, filt)) { *lattice = true; return 4096; }
     int64_t n2 = n;
     while (n2 > 4096 && !wx_fused1d_ok<T>(n2, filt.F)) n2 >>= 1;
     return (n2 >= 4096 && n2 < n && wx_fused1d_ok<T>(n2, filt.F)) ? n2 : 0;
@@ -1490,7 +1555,41 @@ int wx_dev_dwt_long(const T *x, T *y, int64_t n, int Lp, int64_t batch, const Wx
     if (!n2) return wx_set_error(WX_EUNSUPPORTED, "dwt of a long signal: no plan for this length / filter");
     int dl = 0;
     while ((n2 << dl) < n) ++dl;
-    const int top = Lp < dl ? Lp : dl;
+    int top = Lp < dl ? Lp : dl;
+    if (wx_top_levels_ok(filt.F)) {
+        if (Lp <= 4 || (Lp > dl && Lp - dl <= 2 && Lp <= 8 && (n >> 4) >= 4096)) top = Lp;       // see wx_dev_idwt_long
+        // up to four levels per pass (wx_toptile.h): the details leave at their final places in y, the approximation that is
+        // split further goes to scratch (signal stride n; passes alternate between its two halves)
+        const T *src = x;
+        int64_t cur_n = n;
+        int done = 0, pidx = 0;
+        while (done < top) {
+            const int NLp = top - done < 4 ? top - done : 4;
+            const bool more = done + NLp < top || Lp > top;
+            T *deep = scratch + ((pidx & 1) ? n / 2 : 0);
+            unsigned split = 0;
+            for (int l = 0; l < NLp; ++l) split |= 1u << ((1 << l) - 1);           // heap nodes 1, 2, 4, 8: the approximation branch
+            const int rc = wx_dev_top_levels<T>(false, src, y, deep, cur_n, NLp, batch, n, n, n, split, more ? 1u : 0u, filt, st);
+            if (rc) return rc;
+            src = deep;
+            cur_n >>= NLp;
+            done += NLp;
+            ++pidx;
+        }
+        if (Lp > top) {
+            {
+                if (lattice) {
+                    const int r = wx_lattice_tree_T<T>(false, src, y, 4096, Lp - dl, batch, n, 0, filt, status, nstatus, st,
+                                                      nullptr, n);
+                    if (r < 0) return r;
+                    if (r == 1) return WX_OK;
+                    if (!wx_fused1d_ok<T>(n2, filt.F)) return wx_set_error(WX_EHIP, "dwt of a long signal: the lattice kernel did not take the pyramid");
+                }
+            }
+            return launch_fwd_fused<T, false>(src, y, n2, Lp - dl, batch, n, n, filt, status, n2 - 1 < nstatus ? n2 - 1 : nstatus, st);
+        }
+        return WX_OK;
+    }
     const int64_t S = n / 2 + n / 4;                           // scratch per signal: approximations of odd / even depth
     T *bufs[2] = {scratch, scratch + n / 2};
     const T *src = x;
@@ -1503,9 +1602,9 @@ int wx_dev_dwt_long(const T *x, T *y, int64_t n, int Lp, int64_t batch, const Wx
         src_stride = S;
     }
     if (Lp > top) {
-        if constexpr (sizeof(T) == 8) {
+        {
             if (lattice) {
-                const int r = wx_lattice_tree_f64(false, (const double *)src, (double *)y, 4096, Lp - dl, batch, S, 0, filt, status, nstatus, st,
+                const int r = wx_lattice_tree_T<T>(false, src, y, 4096, Lp - dl, batch, S, 0, filt, status, nstatus, st,
                                                   nullptr, n);
                 if (r < 0) return r;
                 if (r == 1) return WX_OK;
@@ -1528,16 +1627,54 @@ int wx_dev_idwt_long(const T *xw, T *y, int64_t n, int Lp, int64_t batch, const 
     if (!n2) return wx_set_error(WX_EUNSUPPORTED, "idwt of a long signal: no plan for this length / filter");
     int dl = 0;
     while ((n2 << dl) < n) ++dl;
-    const int top = Lp < dl ? Lp : dl;
+    int top = Lp < dl ? Lp : dl;
+    if (wx_top_levels_ok(filt.F)) {
+        // a shallow pyramid, or one that leaves only a level or two for the finishing kernel (which is slow or not applicable
+        // there: idwtall of 32768-sample signals with L = 4 took 9.8 ms in round 3), runs entirely in the top passes
+        if (Lp <= 4 || (Lp > dl && Lp - dl <= 2 && Lp <= 8 && (n >> 4) >= 4096)) top = Lp;   // every pass's input is at least a tile long
+        // mirror of wx_dev_dwt_long: the lattice (or fused) inverse rebuilds the approximation of depth `top` in scratch, then up to
+        // four synthesis levels per pass, the details coming straight from xw
+        const int npass = (top + 3) / 4;
+        auto buf = [&](int p) -> T * { return scratch + ((p & 1) ? n / 2 : 0); };
+        if (Lp > top) {
+            T *cur = buf(npass - 1);
+            bool done = false;
+            {
+                if (lattice) {
+                    const int r = wx_lattice_tree_T<T>(true, xw, cur, 4096, Lp - dl, batch, n, 0, filt, status, nstatus, st,
+                                                      &thr, n);
+                    if (r < 0) return r;
+                    done = r == 1;
+                    if (!done && !wx_fused1d_ok<T>(n2, filt.F))
+                        return wx_set_error(WX_EHIP, "idwt of a long signal: the lattice kernel did not take the pyramid");
+                }
+            }
+            if (!done) {
+                const int rc = launch_inv_fused<T>(xw, cur, n2, Lp - dl, batch, n, n, filt, status, n2 - 1 < nstatus ? n2 - 1 : nstatus, nullptr, 0,
+                                                   st, thr);
+                if (rc) return rc;
+            }
+        }
+        for (int p = npass - 1; p >= 0; --p) {
+            const int NLp = top - 4 * p < 4 ? top - 4 * p : 4;
+            const bool more = p < npass - 1 || Lp > top;
+            unsigned split = 0;
+            for (int l = 0; l < NLp; ++l) split |= 1u << ((1 << l) - 1);
+            T *dst = p == 0 ? y : buf(p - 1);
+            const int rc = wx_dev_top_levels<T>(true, xw, dst, buf(p), n >> (4 * p), NLp, batch, n, n, n, split, more ? 1u : 0u, filt, st);
+            if (rc) return rc;
+        }
+        return WX_OK;
+    }
     const int64_t S = n / 2 + n / 4;
     T *bufs[2] = {scratch, scratch + n / 2};
     // the approximation of depth `top` goes where the forward left it: bufs[(top - 1) & 1]
     T *cur = bufs[(top - 1) & 1];
     if (Lp > top) {
         bool done = false;
-        if constexpr (sizeof(T) == 8) {
+        {
             if (lattice) {
-                const int r = wx_lattice_tree_f64(true, (const double *)xw, (double *)cur, 4096, Lp - dl, batch, n, 0, filt, status, nstatus, st,
+                const int r = wx_lattice_tree_T<T>(true, xw, cur, 4096, Lp - dl, batch, n, 0, filt, status, nstatus, st,
                                                   &thr, S);
                 if (r < 0) return r;
                 done = r == 1;
@@ -1576,7 +1713,7 @@ template int wx_dev_idwt_long<float>(const float *, float *, int64_t, int, int64
 template <typename T> bool wx_wpt_long_tree_ok(int64_t n, const WxFilt &filt)
 {
     bool lattice;
-    return wx_dwt_long_plan<T>(n, filt, &lattice) == 4096 && lattice && n <= 65536;
+    return n >= 16384 && wx_dwt_long_plan<T>(n, filt, &lattice) == 4096 && lattice && n <= 65536;
 }
 template bool wx_wpt_long_tree_ok<double>(int64_t, const WxFilt &);
 template bool wx_wpt_long_tree_ok<float>(int64_t, const WxFilt &);
@@ -1586,7 +1723,7 @@ int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, con
                          T *scratch, bool inverse, hipStream_t st)
 {
     if (batch == 0 || n == 0) return WX_OK;
-    if constexpr (sizeof(T) == 8) {
+    {
         int dl = 0;
         while (((int64_t)4096 << dl) < n) ++dl;
         auto split = [&](int d, int64_t j) {                       // node (d, j) exists and is decomposed
@@ -1622,6 +1759,30 @@ int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, con
             if (!dsub) return WX_EHIP;
         }
         const int top = Lp < dl ? Lp : dl;
+        if (wx_top_levels_ok(filt.F) && top >= 1 && top <= 4) {
+            // all top levels in one pass through LDS (wx_toptile.h): leaves leave / enter at their own places, the 4096-sample nodes
+            // that are split further pass through scratch at theirs
+            unsigned smask = 0, deepmask = 0;
+            for (int d = 0; d < top; ++d)
+                for (int64_t j = 0; j < ((int64_t)1 << d); ++j)
+                    if (split(d, j)) smask |= 1u << (((int64_t)1 << d) - 1 + j);
+            for (int64_t j : sub_nodes) deepmask |= 1u << j;
+            if (!inverse) {
+                const int rc = wx_dev_top_levels<T>(false, x, y, scratch, n, top, batch, n, n, n, smask, deepmask, filt, st);
+                if (rc) return rc;
+            }
+            for (size_t k = 0; k < sub_nodes.size(); ++k) {
+                const int64_t off = sub_nodes[k] * 4096;
+                const int r = inverse ? wx_lattice_tree_T<T>(true, x + off, scratch + off, 4096, sub_depth[k], batch, n, 0,
+                                                            filt, dsub + k * NS, NS, st, nullptr, n)
+                                      : wx_lattice_tree_T<T>(false, scratch + off, y + off, 4096, sub_depth[k], batch, n, 0,
+                                                            filt, dsub + k * NS, NS, st, nullptr, n);
+                if (r < 0) return r;
+                if (r != 1) return wx_set_error(WX_EHIP, "wpt of a long signal: the lattice kernel did not take a subtree");
+            }
+            if (inverse) return wx_dev_top_levels<T>(true, x, y, scratch, n, top, batch, n, n, n, smask, deepmask, filt, st);
+            return WX_OK;
+        }
         // depth-d nodes live in P(d): the input / output for d = 0, then scratch, y, scratch, ... (forward) -- every node at its own
         // positions, so a leaf's range is never touched by deeper nodes
         auto P = [&](int d) -> T * { return (d & 1) ? scratch : y; };
@@ -1649,7 +1810,7 @@ int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, con
             }
             for (size_t k = 0; k < sub_nodes.size(); ++k) {
                 const int64_t off = sub_nodes[k] * 4096;
-                const int r = wx_lattice_tree_f64(false, (const double *)((dl == 0 ? x : P(dl)) + off), (double *)(y + off), 4096, sub_depth[k], batch, n,
+                const int r = wx_lattice_tree_T<T>(false, (dl == 0 ? x : P(dl)) + off, y + off, 4096, sub_depth[k], batch, n,
                                                   0, filt, dsub + k * NS, NS, st, nullptr, n);
                 if (r < 0) return r;
                 if (r != 1) return wx_set_error(WX_EHIP, "wpt of a long signal: the lattice kernel did not take a subtree");
@@ -1660,7 +1821,7 @@ int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, con
         auto Q = [&](int d) -> T * { return (d & 1) ? scratch : y; };
         for (size_t k = 0; k < sub_nodes.size(); ++k) {
             const int64_t off = sub_nodes[k] * 4096;
-            const int r = wx_lattice_tree_f64(true, (const double *)(x + off), (double *)(Q(dl) + off), 4096, sub_depth[k], batch, n, 0, filt,
+            const int r = wx_lattice_tree_T<T>(true, x + off, Q(dl) + off, 4096, sub_depth[k], batch, n, 0, filt,
                                               dsub + k * NS, NS, st, nullptr, n);
             if (r < 0) return r;
             if (r != 1) return wx_set_error(WX_EHIP, "iwpt of a long signal: the lattice kernel did not take a subtree");
@@ -1683,8 +1844,6 @@ int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, con
             }
         }
         return WX_OK;
-    } else {
-        return wx_set_error(WX_EUNSUPPORTED, "wpt along a tree of a long signal: Float64 only");
     }
 }
 template int wx_dev_wpt_long_tree<double>(const double *, double *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t, double *, bool,
@@ -1725,6 +1884,51 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
             if (r) return r < 0 ? r : WX_OK;
         }
     }
+    // mirror of the long-signal path of wx_dev_wpt1d: the finishing kernels rebuild the nodes of depth d0 (the lattice inverse
+    // on 4096-sample nodes, or the fused LDS kernel), then the top levels up to four per pass (wx_toptile.h)
+    if (!force_generic && !status && !colmap && is == n && xw != xh && wx_is_pow2(n) && n > 4096 && wx_top_levels_ok(filt.F)) {
+        int dl = 0;
+        while (((int64_t)4096 << dl) < n) ++dl;
+        bool lat = !noreg && L - dl >= 6 && n < ((int64_t)1 << 30);
+        if constexpr (sizeof(T) == 8) lat = lat && wx_lattice_applicable_f64(filt);
+        int64_t n2 = 4096;
+        if (!lat) { n2 = n; while (n2 > 2 && !wx_fused1d_ok<T>(n2, filt.F)) n2 >>= 1; }
+        int d0 = 0;
+        while ((n2 << d0) < n) ++d0;
+        if (d0 >= 1 && wx_fused1d_ok<T>(lat ? 4096 : n2, filt.F) && (scratch || (L <= d0 && L <= 4))) {
+            const int Ltop = L < d0 ? L : d0;
+            const int npass = (Ltop + 3) / 4;
+            // pass p (npass-1 .. 0) writes buffer B(p): xh for p = 0, then scratch, xh, ...; the finishing kernels write B(npass)
+            auto B = [&](int p) -> T * { return (p & 1) ? scratch : xh; };
+            const T *src = xw;
+            if (L > Ltop) {
+                T *first = B(npass);
+                bool done = false;
+                if (lat) {
+                    int r;
+                    if constexpr (sizeof(T) == 8)
+                        r = wx_lattice_iwpt_f64((const double *)xw, (double *)first, 4096, L - d0, batch << d0, 4096, filt, st);
+                    else
+                        r = wx_lattice_f32(true, (const float *)xw, (float *)first, 4096, L - d0, batch << d0, 4096, filt, st);
+                    if (r < 0) return r;
+                    done = r == 1;
+                }
+                if (!done) {
+                    const int rc = launch_inv_fused<T>(xw, first, n2, L - d0, batch << d0, n2, n2, filt, nullptr, 0, nullptr, 0, st);
+                    if (rc) return rc;
+                }
+                src = first;
+            }
+            for (int p = npass - 1; p >= 0; --p) {
+                const int NLp = Ltop - 4 * p < 4 ? Ltop - 4 * p : 4;
+                const int64_t np = n >> (4 * p);
+                const int rc = wx_dev_top_levels<T>(true, src, B(p), (T *)nullptr, np, NLp, batch << (4 * p), np, np, np, 0xffffffffu, 0u, filt, st);
+                if (rc) return rc;
+                src = B(p);
+            }
+            return WX_OK;
+        }
+    }
     {
         // mirror of the long-signal path of wx_dev_wpt1d: the lattice inverse on the 4096-sample nodes of depth dl, then dl
         // synthesis levels of one pass each
@@ -1756,11 +1960,11 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
             }
         }
     }
-    if constexpr (sizeof(T) == 8) {
+    {
         // leaves of a tree, dense (iwpt) or in the columns of a packet table (iwpd by tree: colmap is set, the leaves of depth
         // l sit in column l): the lattice inverse takes them in level by level (wx_lattice_tree.h)
         if (!force_generic && !noreg && status) {
-            const int r = wx_lattice_tree_f64(true, (const double *)xw, (double *)xh, n, L, batch, is, colmap ? n : 0, filt, status,
+            const int r = wx_lattice_tree_T<T>(true, xw, xh, n, L, batch, is, colmap ? n : 0, filt, status,
                                               nstatus, st);
             if (r) return r < 0 ? r : WX_OK;
         }

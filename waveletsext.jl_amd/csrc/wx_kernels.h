@@ -13,6 +13,21 @@ int wx_swpt_deep_inv(const double *src, int64_t src_cols, double *dst, int64_t d
 bool wx_lattice_applicable_f64(const WxFilt &filt);     // wx_lattice.hip: the filter has a lattice instantiation and factorises
 int wx_skip_register_kernels();   // test hook (wx_set_force_generic(2)): skip the Haar / lattice register kernels
 
+// ---- short signals (16 .. 512 samples) along any tree: n / 8 lanes per signal, uniform level loop (wx_smalltree.hip) ----
+template <typename T> bool wx_small_tree_ok(int64_t n, int F);
+// which trees of which lengths take it (status != NULL: a tree; pyramid: that tree is a pyramid)
+template <typename T> bool wx_small_tree_wanted(int64_t n, int F, bool has_tree, bool pyramid);
+template <typename T>
+int wx_dev_small_tree(bool inverse, const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt &filt, const uint8_t *status,
+                      int64_t nstatus, hipStream_t st);
+
+// ---- very short signals, one lane per signal (wx_lanetree.h): 16 .. 64 samples, 128 for Float32; the tree as a bit mask ----
+struct WxLaneTree;
+int wx_lane_tree_f64(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, const WxLaneTree &tree, const WxFilt &filt,
+                     hipStream_t st);
+int wx_lane_tree_f32(bool inverse, const float *x, float *y, int64_t n, int L, int64_t batch, const WxLaneTree &tree, const WxFilt &filt,
+                     hipStream_t st);
+
 // ---- 1-D decimated (wx_dwt1d.hip) ----
 template <typename T>
 int wx_dev_wpd1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st,
@@ -137,6 +152,10 @@ int wx_lattice_tree_f64(bool inverse, const double *x, double *y, int64_t n, int
                         int64_t col_stride, const WxFilt &filt, const uint8_t *dstatus, int64_t nstatus, hipStream_t st,
                         const WxThreshArg *thr = nullptr, int64_t out_stride = 0);
 bool wx_lattice_tree_applicable_f64(int64_t n, const WxFilt &filt);
+// the same for Float32 signals (dense leaves; wx_lattice_tree32.h)
+int wx_lattice_tree_f32(bool inverse, const float *x, float *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt,
+                        const uint8_t *dstatus, int64_t nstatus, hipStream_t st, const WxThreshArg *thr = nullptr, int64_t out_stride = 0);
+bool wx_lattice_tree_applicable_f32(int64_t n, const WxFilt &filt);
 int wx_lattice_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
 int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                         const WxFilt &filt, hipStream_t st);

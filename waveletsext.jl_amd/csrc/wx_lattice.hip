@@ -241,3 +241,25 @@ int wx_lattice_tree_f64(bool inverse, const double *x, double *y, int64_t n, int
     return WX_TREE_GO(2);
 #undef WX_TREE_GO
 }
+
+// ---- Float32 signals along a tree (wx_lattice_tree32.h) ------------------------------------------------------------------------
+#define WX_T32(k, d) int wx_lattice_tree32_##k##d(bool, const float *, float *, int64_t, int, int64_t, int64_t, const WxFilt &, const uint8_t *, int64_t, \
+                                                  const WxThreshArg *, hipStream_t, int64_t);
+WX_T32(0, f) WX_T32(0, i) WX_T32(1, f) WX_T32(1, i) WX_T32(2, f) WX_T32(2, i)
+#undef WX_T32
+bool wx_lattice_tree_applicable_f32(int64_t n, const WxFilt &filt)
+{
+    static const bool off = getenv("WX_LATTICE_TREE32") && atoi(getenv("WX_LATTICE_TREE32")) == 0;
+    return !off && wx_lattice_tree_applicable_f64(n, filt);
+}
+int wx_lattice_tree_f32(bool inverse, const float *x, float *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt,
+                        const uint8_t *dstatus, int64_t nstatus, hipStream_t st, const WxThreshArg *thr, int64_t out_stride)
+{
+    if (!wx_lattice_tree_applicable_f32(n, filt)) return 0;
+#define WX_TREE_GO(k) (inverse ? wx_lattice_tree32_##k##i(inverse, x, y, n, L, batch, in_stride, filt, dstatus, nstatus, thr, st, out_stride) \
+                               : wx_lattice_tree32_##k##f(inverse, x, y, n, L, batch, in_stride, filt, dstatus, nstatus, thr, st, out_stride))
+    if (n == 4096) return WX_TREE_GO(0);
+    if (n == 2048) return WX_TREE_GO(1);
+    return WX_TREE_GO(2);
+#undef WX_TREE_GO
+}

@@ -124,6 +124,7 @@ __device__ __forceinline__ void lat_st2w(double __attribute__((address_space(1))
     *(P)p = v;
 #endif
 }
+__device__ __forceinline__ void lat_st2w(float __attribute__((address_space(1))) *p, lat_d2 v) { lat_st2(p, v); }
 __device__ __forceinline__ lat_gc lat_sbase(const double *p)
 {
     lat_gc g = (lat_gc)p;
@@ -625,8 +626,8 @@ struct WxLatW {
 // bit 8 rho + i of `word` says whether this lane's 16 bytes of store instruction i of round rho belong to one (a table made
 // by k_lat_tree_prep with the same routing functions), `anyw` is the OR of the words over the lanes (wave-uniform: rounds and
 // half-rounds without a leaf line are skipped, exchange included).
-template <int LAY, int LVL, bool PRED = false>
-__device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, double *__restrict__ ycol, int lane, const WxLatW &cw,
+template <int LAY, int LVL, bool PRED = false, typename IO = double>
+__device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, IO *__restrict__ ycol, int lane, const WxLatW &cw,
                                          unsigned sstride = 4096u >> lat_sh(LVL), unsigned word = 0, unsigned anyw = 0)
 {
     // sstride: elements between the columns of consecutive signals of the wavefront (interleaved kernels; the signal
@@ -725,8 +726,8 @@ __device__ __forceinline__ unsigned lat_absorb_xo(int lane, unsigned sstride)
 }
 // dep / cstride (iwpd by tree, all depths >= 6 - SH in one absorb): the piece of store index 8 RN + i sits in the column of
 // its leaf's depth -- nibble (8 RN + i) of the lane's four `dep` words -- cstride elements per column
-template <int LAY, int LVL, int RN>
-__device__ __forceinline__ void lat_absorb_fetch(lat_d2 (&v)[16], const double *__restrict__ xcol, unsigned xo, unsigned sstride, unsigned word,
+template <int LAY, int LVL, int RN, typename IO = double>
+__device__ __forceinline__ void lat_absorb_fetch(lat_d2 (&v)[16], const IO *__restrict__ xcol, unsigned xo, unsigned sstride, unsigned word,
                                                  const unsigned *dep = nullptr, unsigned cstride = 0)
 {
     constexpr int SB = 12 - lat_sh(LVL);
@@ -740,8 +741,8 @@ __device__ __forceinline__ void lat_absorb_fetch(lat_d2 (&v)[16], const double *
         if ((word >> idx) & 1u) d = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + (xo + co));
     });
 }
-template <int LAY, int LVL>
-__device__ __forceinline__ void lat_absorb_fetch01(lat_d2 (&v)[16], const double *__restrict__ xcol, int lane, unsigned sstride, unsigned word,
+template <int LAY, int LVL, typename IO = double>
+__device__ __forceinline__ void lat_absorb_fetch01(lat_d2 (&v)[16], const IO *__restrict__ xcol, int lane, unsigned sstride, unsigned word,
                                                    const unsigned *dep = nullptr, unsigned cstride = 0)
 {
     const unsigned xo = lat_absorb_xo<LAY, LVL>(lane, sstride);
@@ -749,8 +750,8 @@ __device__ __forceinline__ void lat_absorb_fetch01(lat_d2 (&v)[16], const double
     lat_absorb_fetch<LAY, LVL, 1>(v, xcol, xo, sstride, word, dep, cstride);
 }
 
-template <int LAY, int LVL, bool PRED = false, bool PRE = false>
-__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const double *__restrict__ xcol, int lane, const WxLatW &cw,
+template <int LAY, int LVL, bool PRED = false, bool PRE = false, typename IO = double>
+__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const IO *__restrict__ xcol, int lane, const WxLatW &cw,
                                            unsigned sstride, unsigned word, unsigned anyw, lat_d2 (&v)[16],
                                            const unsigned *dep = nullptr, unsigned cstride = 0, const LatThr *th = nullptr)
 {
@@ -837,8 +838,8 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
     });
 }
 
-template <int LAY, int LVL, bool PRED = false>
-__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const double *__restrict__ xcol, int lane, const WxLatW &cw,
+template <int LAY, int LVL, bool PRED = false, typename IO = double>
+__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const IO *__restrict__ xcol, int lane, const WxLatW &cw,
                                            unsigned sstride = 4096u >> lat_sh(LVL), unsigned word = 0, unsigned anyw = 0,
                                            unsigned long long rmask = 0)
 {
@@ -846,9 +847,9 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
     lat_d2 v[16];
     if constexpr (PRED) {
         lat_absorb_fetch01<LAY, LVL>(v, xcol, lane, sstride, word);
-        lat_absorb<LAY, LVL, true, true>(x, lds0, xcol, lane, cw, sstride, word, anyw, v);
+        lat_absorb<LAY, LVL, true, true, IO>(x, lds0, xcol, lane, cw, sstride, word, anyw, v);
     } else
-        lat_absorb<LAY, LVL, false, false>(x, lds0, xcol, lane, cw, sstride, word, anyw, v);
+        lat_absorb<LAY, LVL, false, false, IO>(x, lds0, xcol, lane, cw, sstride, word, anyw, v);
 }
 
 // the three layout changes of the forward direction, shared by wpt and wpd

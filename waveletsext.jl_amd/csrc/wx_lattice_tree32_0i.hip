@@ -1,0 +1,5 @@
+// tree-driven lattice kernels for Float32 signals of 4096 samples, inverse (wx_lattice_tree32.h): one translation unit per length and direction
+#define WX_LAT_TREE_SH 0
+#define WX_LAT_TREE_INV 1
+#define WX_LAT_TREE_FN wx_lattice_tree32_0i
+#include "wx_lattice_tree32.h"

@@ -272,9 +272,11 @@ __device__ __forceinline__ void lat_sc_ptab(unsigned (&pw)[32], const WxLatTreeS
         if (ANY) lat_level_hm<KK, HH, NS, true>(REG, cf, MK, ga, gd);                           \
     }
 
-template <int NS, int WPE, int SH>
+// IO: the signal's type in memory (Float64 in the registers either way: Float32 signals are widened by the loads and rounded once by the
+// stores, like the full-tree kernels k_lat_wpt_f64<.., float>)
+template <int NS, int WPE, int SH, typename IO = double>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_treesc_f64(
-    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned out_stride, WxLatW cw,
+    const IO *__restrict__ x, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned out_stride, WxLatW cw,
     const WxLatTreeSc *__restrict__ tab)
 {
     static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
@@ -283,8 +285,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const int lane = threadIdx.x;
     constexpr int NQ = 32 >> SH;                                 // 128-element pieces of one signal
     const int sig0 = min((int)blockIdx.x << SH, last_sig);       // the last wavefront of a ragged batch re-does signals
-    const double *xs = x + (int64_t)sig0 * in_stride;            // signals in_stride / out_stride elements apart
-    double *ys = y + (int64_t)sig0 * out_stride;
+    const IO *xs = x + (int64_t)sig0 * in_stride;                // signals in_stride / out_stride elements apart
+    IO *ys = y + (int64_t)sig0 * out_stride;
     const WxLat &cf = cw.c;
     // forward: gl[1] = g, g2 = g^-2: after the shears the a-slot holds a / g, the d-slot d g
     const double g = cw.gl[1], ginv = cw.c.g2 * cw.gl[1];
@@ -348,9 +350,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     });
 }
 
-template <int NS, int WPE, int SH, bool THR>
+template <int NS, int WPE, int SH, bool THR, typename IO = double>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_treesc_f64(
-    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride,
+    const IO *__restrict__ xw, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride,
     unsigned out_stride, WxLatW cw, const WxLatTreeSc *__restrict__ tab, WxThreshArg thr)
 {
     static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
@@ -359,8 +361,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const int lane = threadIdx.x;
     constexpr int NQ = 32 >> SH;                               // 128-element pieces of one signal
     const int sig0 = min((int)blockIdx.x << SH, last_sig);
-    const double *xs = xw + (int64_t)sig0 * in_stride;
-    double *ys = y + (int64_t)sig0 * out_stride;
+    const IO *xs = xw + (int64_t)sig0 * in_stride;
+    IO *ys = y + (int64_t)sig0 * out_stride;
     const WxLat &cf = cw.c;
     unsigned dep[4] = {0, 0, 0, 0};
     if (col_stride) {
@@ -374,11 +376,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         lat_for<nk>([&](auto Kc) {
             constexpr int k = k0 + Kc, q = 16 * h + k, sg = q / NQ, qq = q % NQ;
             const unsigned co = ((dep[q >> 3] >> (4 * (q & 7))) & 15u) * col_stride;      // col_stride = 0: dense leaves
-            const double *src = xs + (size_t)sg * in_stride + 128 * qq;
+            const IO *src = xs + (size_t)sg * in_stride + 128 * qq;
             if constexpr (qq == 0) {
                 // idwt of a pyramid: positions 0 .. 63 are the samples the lane-local tail (wx_dwttail.hip) has rebuilt
-                const double *hp = reinterpret_cast<const double *>(thr.head);
-                if (hp && lane < 32) v[k] = lat_ld2((lat_gc)(hp + 64 * (int64_t)(sig0 + sg) + 2 * lane));
+                const IO *hp = reinterpret_cast<const IO *>(thr.head);
+                if (hp && lane < 32) v[k] = lat_ld2(lat_sbase(hp + 64 * (int64_t)(sig0 + sg)) + 2 * lane);
                 else v[k] = lat_ld2(lat_sbase(src) + (2 * lane + co));
             } else
                 v[k] = lat_ld2(lat_sbase(src) + (2 * lane + co));
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if constexpr (THR) {
 #pragma unroll
         for (int s4 = 0; s4 < (1 << SH); ++s4)
-            tt[s4] = reinterpret_cast<const double *>(thr.t)[thr.per_signal ? sig0 + s4 : 0] * thr.scale;
+            tt[s4] = (double)reinterpret_cast<const IO *>(thr.t)[thr.per_signal ? sig0 + s4 : 0] * thr.scale;
     }
     auto put = [&](auto Hc, auto K0c, auto NKc) {
         constexpr int h = Hc, k0 = K0c, nk = NKc;
