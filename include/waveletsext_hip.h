@@ -262,7 +262,7 @@ int wx_treeselect_batch_f32(float *costs, int64_t ncost, int64_t m, int64_t n, i
  * k = 1 for dwt / wpt leaves, L+1 for sdwt / acdwt, 2^(L+1)-1 for swpd / acwpd.
  * wx_noisest_*: noisest(x, redundant, tree) Denoising.jl:214-232 = Wavelets.Threshold.mad!(dr)/0.6745 for every
  * signal, dr = rows [row_lo, n) of column `col` (the caller resolves finestdetailrange, Utils.jl:416-436);
- * exact order statistics (radix select in LDS), sigma has `batch` entries.
+ * exact order statistics (radix select in LDS; over a global-memory copy for more than 128 KiB of details), sigma has `batch` entries.
  * wx_threshold_*: Y = Wavelets.Threshold.threshold(X, TH, t) on rows [row_lo, n) of the columns with
  * colmask != 0 (NULL = all), everything else copied; Y == X thresholds in place (threshold!) and touches only the
  * selected elements: th_kind 0 HardTH, 1 SoftTH, 2 SemiSoftTH, 3 SteinTH; t holds nt = 1 or `batch`
@@ -285,8 +285,9 @@ int wx_threshold_f32(const float *X, float *Y, int64_t n, int64_t k, int64_t bat
  * wx_emd_measure_*:      D[e] = sum over the class pairs of the earth mover's distance between the signatures
  *     (X[e, class a], weight 1/N_a) and (X[e, class b], weight 1/N_b): discriminant_measure(energy_map(Xw, y,
  *     Signatures(:equal)), EarthMoverDistance()), ldb/ldb_energymap.jl:186-238, ldb/ldb_measures.jl:185-201, 254-360.
- * The padded signals of one coefficient must fit a 128 KiB LDS window (sum over classes of nextpow2(N_c) <= 16384
- * Float64 / 32768 Float32 values).  Pointers may be host or device; cls is a host array. */
+ * Any number of signals and classes: the padded signals of one coefficient are sorted in a 128 KiB LDS window while they fit (sum
+ * over classes of nextpow2(N_c) <= 16384 Float64 / 32768 Float32 values) and in a global-memory window beyond that.  Pointers may
+ * be host or device; cls is a host array. */
 int wx_class_median_mad_f64(const double *X, int64_t nk, int64_t N, const int32_t *cls, int nc, double *med, double *mad,
                             void *stream);
 int wx_class_median_mad_f32(const float *X, int64_t nk, int64_t N, const int32_t *cls, int nc, float *med, float *mad,

@@ -5,6 +5,7 @@
 //   bestbasistreeall(X, ::BB)      BestBasis.jl:253-262  (the batch loop: one tree per signal)
 // Every signal is independent: costs are one workgroup per (node, signal), the tree selection one
 // workgroup per signal with the signal's cost vector in LDS.
+#include "../../include/waveletsext_hip.h"     // the definitions below must match the public prototypes
 #include "wx_common.h"
 #include "wx_host.h"
 #include "wx_kernels.h"
@@ -187,16 +188,18 @@ __global__ __launch_bounds__(256) void k_bb_costs2d(const T *__restrict__ X, con
 // decision needs only its children's final costs, and deleting a subtree clears exactly the nodes that
 // have a pruned ancestor-or-self, so   tree[i] = full[i] && !pruned[i] && tree[parent(i)].
 // costs (T, mutated like the reference) and the flags live in LDS.
-template <typename T, int ARITY>
+// GM: cost vectors that do not fit a CU's LDS (signals of more than about 8000 samples' worth of nodes) are updated where they are, in
+// global memory, with the flags in a scratch row (the reference has no limit: BestBasis.jl:253-262)
+template <typename T, int ARITY, bool GM>
 __global__ __launch_bounds__(256) void k_bb_treeselect(T *__restrict__ costs, int64_t ncost, int L, int64_t ntree,
-                                                       int type_max, uint8_t *__restrict__ trees)
+                                                       int type_max, uint8_t *__restrict__ trees, uint8_t *__restrict__ gflags)
 {
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
-    T *c = reinterpret_cast<T *>(wx_smem);
-    uint8_t *flag = reinterpret_cast<uint8_t *>(c + ncost);       // 1 = pruned, later reused as the tree bit
     const int64_t sig = blockIdx.x;
     T *gc = costs + sig * ncost;
-    {
+    T *c = GM ? gc : reinterpret_cast<T *>(wx_smem);
+    uint8_t *flag = GM ? gflags + sig * ncost : reinterpret_cast<uint8_t *>(reinterpret_cast<T *>(wx_smem) + ncost);   // 1 = pruned, later the tree bit
+    if (!GM) {
         // eight loads of a lane in flight together
         int64_t i = threadIdx.x;
         for (; i + 7 * 256 < ncost; i += 8 * 256) {
@@ -240,7 +243,8 @@ __global__ __launch_bounds__(256) void k_bb_treeselect(T *__restrict__ costs, in
     uint8_t *out = trees + sig * ntree;
     const int64_t nfull = first(L) - 1;
     for (int64_t i = threadIdx.x; i < ntree; i += blockDim.x) out[i] = i < nfull ? flag[i] : 0;
-    for (int64_t i = threadIdx.x; i < ncost; i += blockDim.x) gc[i] = c[i];
+    if (!GM)
+        for (int64_t i = threadIdx.x; i < ncost; i += blockDim.x) gc[i] = c[i];
 }
 
 int need_device()
@@ -315,7 +319,7 @@ int api_treeselect_batch(T *costs, int64_t ncost, int64_t m, int64_t n, int type
         WX_REQUIRE(ncost >= ((((int64_t)1 << (2 * (L + 1))) - 1) / 3) || L == 0, WX_EBOUNDS, "costs do not cover the children of depth L-1");
     }
     const size_t lds = (size_t)ncost * sizeof(T) + (size_t)ncost + 16;
-    WX_REQUIRE(lds <= 150 * 1024, WX_EUNSUPPORTED, "cost vector does not fit the LDS of one CU");
+    const bool gm = lds > 150 * 1024;
     int rc;
     if ((rc = need_device())) return rc;
     if (batch == 0 || ntree == 0) return WX_OK;
@@ -325,12 +329,28 @@ int api_treeselect_batch(T *costs, int64_t ncost, int64_t m, int64_t n, int type
     for (auto &it : io.items) if (it.user == costs) it.copy_out = true;      // costs are mutated like the reference
     uint8_t *dt = (uint8_t *)io.out(trees, (size_t)ntree * batch);
     if (!dc || !dt) return io.finish(WX_EHIP);
-    auto kern = two_d ? k_bb_treeselect<T, 4> : k_bb_treeselect<T, 2>;
+    if (gm) {
+        WxScratch scr(st);
+        // flags of at most 1 GiB of signals at a time
+        int64_t per = ((int64_t)1 << 30) / ncost;
+        if (per < 1) per = 1;
+        if (per > batch) per = batch;
+        uint8_t *gflags = (uint8_t *)scr.alloc((size_t)per * ncost);
+        if (!gflags) return io.finish(WX_EHIP);
+        auto kg = two_d ? k_bb_treeselect<T, 4, true> : k_bb_treeselect<T, 2, true>;
+        for (int64_t b0 = 0; b0 < batch; b0 += per) {
+            const int64_t nb = batch - b0 < per ? batch - b0 : per;
+            hipLaunchKernelGGL(kg, dim3((unsigned)nb), dim3(256), 0, st, dc + b0 * ncost, ncost, L, ntree, type_max, dt + b0 * ntree, gflags);
+        }
+        if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "tree selection kernel failed to launch"));
+        return io.finish(WX_OK);
+    }
+    auto kern = two_d ? k_bb_treeselect<T, 4, false> : k_bb_treeselect<T, 2, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "hipFuncSetAttribute(LDS)"));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(256), lds, st, dc, ncost, L, ntree, type_max, dt);
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(256), lds, st, dc, ncost, L, ntree, type_max, dt, (uint8_t *)nullptr);
     if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "tree selection kernel failed to launch"));
     return io.finish(WX_OK);
 }

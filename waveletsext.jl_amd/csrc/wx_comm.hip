@@ -4,6 +4,7 @@
 // RCCL is bound lazily (dlopen) so that single-GPU callers never load it.  Transforms themselves need
 // no collective.  The Python mirror uses torch.distributed for the same two steps; these entry points
 // are for hosts without it (the Julia shim: MPI.jl / Distributed.jl broadcasts the 128-byte id).
+#include "../../include/waveletsext_hip.h"     // the definitions below must match the public prototypes
 #include "wx_common.h"
 #include "wx_host.h"
 #include <dlfcn.h>

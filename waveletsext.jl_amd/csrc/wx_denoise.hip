@@ -6,6 +6,7 @@
 //                                    in denoise(), Denoising.jl:483-599, to the rows / columns it selects
 // Wavelets.jl is not vendored in the reference tree: mad! and the four threshold loops are restated from its
 // published source (parity unpinned, like the filter tables).
+#include "../../include/waveletsext_hip.h"     // the definitions below must match the public prototypes
 #include "wx_common.h"
 #include "wx_host.h"
 #include "wx_kernels.h"
@@ -209,6 +210,24 @@ __global__ __launch_bounds__(256) void k_mad(const T *__restrict__ X, int64_t si
     if (threadIdx.x == 0) sigma[blockIdx.x] = (T)(r / (T)0.6745);
 }
 
+// the same on detail ranges that do not fit a CU's LDS (signals of more than 32768 Float64 / 65536 Float32 samples' worth of details):
+// the copy that the second median overwrites lives in a global scratch row instead; the selection (wx_select_kth: counting passes
+// over the values) reads it through L2
+template <typename T>
+__global__ __launch_bounds__(256) void k_mad_g(const T *__restrict__ X, int64_t sig_stride, int64_t off, int cnt, T *__restrict__ work,
+                                               T *__restrict__ sigma)
+{
+    __shared__ WxSelScratch S;
+    const T *x = X + (int64_t)blockIdx.x * sig_stride + off;
+    T *v = work + (int64_t)blockIdx.x * cnt;
+    const T m = wx_median_lds<T>(x, cnt, &S);
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) v[i] = (T)fabs((double)(T)(x[i] - m));
+    __threadfence_block();
+    __syncthreads();
+    const T r = wx_median_lds<T>(v, cnt, &S);
+    if (threadIdx.x == 0) sigma[blockIdx.x] = (T)(r / (T)0.6745);
+}
+
 }  // namespace
 
 // Y = X with rows [row_lo, n) thresholded (k = 1): used by the thresholding inverse when its kernel cannot take the
@@ -243,7 +262,7 @@ int api_noisest(const T *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo,
     WX_REQUIRE(wx_isdyadic(n), WX_EASSERT, "@assert isdyadic(size(x,1)) (Denoising.jl:218)");
     WX_REQUIRE(0 <= row_lo && row_lo < n && 0 <= col && col < k, WX_EBOUNDS, "detail range outside the array");
     const int64_t cnt = n - row_lo;
-    WX_REQUIRE((size_t)cnt * sizeof(T) <= 128 * 1024, WX_EUNSUPPORTED, "noisest: more detail coefficients than fit the LDS of one CU");
+    WX_REQUIRE(cnt < ((int64_t)1 << 30), WX_EUNSUPPORTED, "noisest: 2^30 detail coefficients or more per signal");
     int rc;
     if ((rc = need_device())) return rc;
     if (batch == 0) return WX_OK;
@@ -253,6 +272,22 @@ int api_noisest(const T *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo,
     T *ds = (T *)io.out(sigma, sizeof(T) * batch);
     if (!dX || !ds) return io.finish(WX_EHIP);
     const size_t lds = (size_t)cnt * sizeof(T);
+    if (lds > 128 * 1024) {
+        // long signals (the reference has no limit: Denoising.jl:214-232): absolute deviations in a global scratch row per signal,
+        // at most 1 GiB of them at a time
+        WxScratch scr(st);
+        int64_t per = ((int64_t)1 << 30) / (int64_t)lds;
+        if (per < 1) per = 1;
+        if (per > batch) per = batch;
+        T *work = (T *)scr.alloc((size_t)per * lds);
+        if (!work) return io.finish(WX_EHIP);
+        for (int64_t b0 = 0; b0 < batch; b0 += per) {
+            const int64_t nb = batch - b0 < per ? batch - b0 : per;
+            hipLaunchKernelGGL(k_mad_g<T>, dim3((unsigned)nb), dim3(256), 0, st, dX + b0 * n * k, n * k, col * n + row_lo, (int)cnt, work, ds + b0);
+        }
+        if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "noisest kernel failed to launch"));
+        return io.finish(WX_OK);
+    }
     if (lds > 60 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "hipFuncSetAttribute(LDS)"));

@@ -14,6 +14,7 @@
 // the line runs along dimension 1), so every pass reads and writes whole cache lines.  A level is three passes through one
 // scratch cube plus the copy of the sub-cube back (HBM-bound, 8 sub-cube traversals per level: the row is breadth, the
 // batched 1-D / 2-D kernels are where the bytes of this library go).
+#include "../../include/waveletsext_hip.h"     // the definitions below must match the public prototypes
 #include "wx_common.h"
 #include "wx_kernels.h"
 #include "wx_host.h"
@@ -121,7 +122,9 @@ int api_dwt3d(const T *x, T *y, int64_t n1, int64_t n2, int64_t n3, int L, int64
     WX_REQUIRE(n1 == n2 && n2 == n3, WX_EASSERT, "3-D dwt: the array must be a cube (Wavelets.jl 3-D transform)");
     WX_REQUIRE(wx_isdyadic(n1) && 0 <= L && L <= wx_maxtransformlevels(n1), WX_EASSERT,
                "3-D dwt: dyadic sides and 0 <= L <= maxtransformlevels(x)");
-    WX_REQUIRE(n1 <= 1024, WX_EUNSUPPORTED, "3-D dwt: side > 1024 not supported");
+    // (sides beyond 1024 were refused until round 4; the kernels index with 64 bits, what bounds the side is the memory of the
+    // device: a 2048^3 Float32 cube is 32 GiB, plus as much scratch)
+    WX_REQUIRE(n1 < ((int64_t)1 << 20), WX_EUNSUPPORTED, "3-D dwt: side of 2^20 or more");
     if (wx_device_count() < 1) return wx_set_error(WX_EHIP, "no HIP device visible: the MI355X kernels cannot run");
     const int64_t cube = n1 * n1 * n1;
     if (batch == 0) return WX_OK;

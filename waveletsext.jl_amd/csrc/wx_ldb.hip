@@ -6,6 +6,7 @@
 // Everything else of fitdec! (discriminant measure on the small (n, k, classes) map, node costs with top_k,
 // tree selection, ordering) is host logic on small arrays in the Python / Julia layer; the feature gather is
 // wx_getbasiscoef* + an index selection.
+#include "../../include/waveletsext_hip.h"     // the definitions below must match the public prototypes
 #include "wx_common.h"
 #include "wx_host.h"
 #include "wx_kernels.h"
@@ -17,7 +18,7 @@ extern "C" int wx_device_count(void);
 
 namespace {
 
-constexpr int LDB_MAXC = 64;
+constexpr int LDB_MAXC = 65535;          // gridDim.y = classes x chunks
 
 // squared 2-norm of the root of every signal, as norm(x, 2)^2: sqrt then square
 template <typename T>
@@ -118,7 +119,7 @@ int check_labels(const int32_t *cls, int64_t N, int nc, bool allow_empty)
 {
     WX_REQUIRE(cls != nullptr, WX_EARG, "class labels are NULL");
     WX_REQUIRE(nc > 1, WX_EASSERT, "@assert nc > 1 (ldb_energymap.jl:122)");
-    WX_REQUIRE(nc <= LDB_MAXC, WX_EUNSUPPORTED, "more than 64 classes");
+    WX_REQUIRE(nc <= LDB_MAXC, WX_EUNSUPPORTED, "more than 65535 classes");
     std::vector<char> seen((size_t)nc, 0);
     for (int64_t i = 0; i < N; ++i) {
         WX_REQUIRE(cls[i] >= 0 && cls[i] < nc, WX_EARG, "class index outside [0, nc)");

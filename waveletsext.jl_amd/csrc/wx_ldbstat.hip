@@ -18,6 +18,7 @@
 //     rows) -- no merged array is built, every element is independent, the sum is a workgroup reduction (the reference
 //     adds the gaps in merged order: the difference is rounding, 1e-12 in the tests).
 // Workgroups that share cache lines of the table (consecutive coefficients) are placed on the same XCD.
+#include "../../include/waveletsext_hip.h"     // the definitions below must match the public prototypes
 #include "wx_common.h"
 #include "wx_kernels.h"
 #include "wx_host.h"
@@ -31,19 +32,26 @@ extern "C" int wx_device_count(void);
 namespace {
 
 constexpr int LS_NT = 256;
-constexpr int LS_MAXC = 64;
 
 template <typename T> __device__ __forceinline__ T ls_inf();
 template <> __device__ __forceinline__ double ls_inf<double>() { return __longlong_as_double(0x7ff0000000000000LL); }
 template <> __device__ __forceinline__ float ls_inf<float>() { return __int_as_float(0x7f800000); }
 
+// per class, in device memory (any number of classes; 64 was the limit while the tables travelled as a kernel argument)
 struct LsClasses {
     int nc;
-    int cnt[LS_MAXC];       // signals per class
-    int npad[LS_MAXC];      // power of two >= cnt
-    int rowoff[LS_MAXC];    // offset of the class's TC rows in the window (elements)
-    int sigoff[LS_MAXC];    // offset of the class in `order`
+    const int *cnt;         // signals per class
+    const int *npad;        // power of two >= cnt
+    const int *rowoff;      // offset of the class's TC rows in the window (elements)
+    const int *sigoff;      // offset of the class in `order`
 };
+// The window of a workgroup -- the rows it sorts, the values it bins -- is LDS when it fits (GM = false) and a slice of a global
+// scratch array when it does not (GM = true: more than about 10^4 signals per coefficient; the reference has no limit,
+// ldb/ldb_measures.jl:481-519).  With GM a workgroup walks several coefficient groups (grid-stride), its window reused.
+template <bool GM> __device__ __forceinline__ char *ls_window(char *lds, char *gwork, size_t wbytes)
+{
+    return GM ? gwork + (size_t)blockIdx.x * wbytes : lds;
+}
 
 template <typename T>
 __device__ void ls_stage(T *win, const T *__restrict__ X, int64_t nk, int64_t e0, int tc, int TC, const int *__restrict__ order,
@@ -94,39 +102,44 @@ template <typename T> __device__ __forceinline__ T ls_median_sorted(const T *v, 
     return (T)((T)(a / (T)2) + (T)(b / (T)2));
 }
 
-template <typename T>
+template <typename T, bool GM>
 __global__ __launch_bounds__(LS_NT) void k_class_median_mad(const T *__restrict__ X, int64_t nk, const int *__restrict__ order, LsClasses C,
-                                                            int TC, T *__restrict__ med, T *__restrict__ mad)
+                                                            int TC, int64_t row_elems, T *__restrict__ med, T *__restrict__ mad, char *gwork,
+                                                            size_t wbytes)
 {
     extern __shared__ __attribute__((aligned(16))) char ls_smem[];
-    T *win = reinterpret_cast<T *>(ls_smem);
-    __shared__ T meds[LS_MAXC * 16];
-    int bid = blockIdx.x;
-    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-    const int64_t e0 = (int64_t)bid * TC;
-    const int tc = (int)min((int64_t)TC, nk - e0);
-    ls_stage<T>(win, X, nk, e0, tc, TC, order, C);
-    ls_sort<T>(win, TC, C);
-    for (int idx = threadIdx.x; idx < C.nc * TC; idx += LS_NT) {
-        const int c = idx / TC, te = idx - c * TC;
-        const T m = ls_median_sorted<T>(win + C.rowoff[c] + te * C.npad[c], C.cnt[c]);
-        meds[idx] = m;
-        if (te < tc) med[e0 + te + nk * c] = m;
-    }
-    __syncthreads();
-    for (int c = 0; c < C.nc; ++c) {
-        T *rows = win + C.rowoff[c];
-        const int np = C.npad[c];
-        for (int idx = threadIdx.x; idx < TC * C.cnt[c]; idx += LS_NT) {
-            const int te = idx / C.cnt[c], k = idx - te * C.cnt[c];
-            rows[te * np + k] = (T)fabs((double)(T)(rows[te * np + k] - meds[c * TC + te]));
+    T *win = reinterpret_cast<T *>(ls_window<GM>(ls_smem, gwork, wbytes));
+    T *meds = win + (int64_t)TC * row_elems;                // nc * TC medians behind the rows
+    const int64_t ngroups = (nk + TC - 1) / TC;
+    for (int64_t g0 = blockIdx.x; g0 < ngroups; g0 += gridDim.x) {
+        int64_t bid = g0;
+        if (!GM && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+        const int64_t e0 = bid * TC;
+        const int tc = (int)min((int64_t)TC, nk - e0);
+        ls_stage<T>(win, X, nk, e0, tc, TC, order, C);
+        ls_sort<T>(win, TC, C);
+        for (int idx = threadIdx.x; idx < C.nc * TC; idx += LS_NT) {
+            const int c = idx / TC, te = idx - c * TC;
+            const T m = ls_median_sorted<T>(win + C.rowoff[c] + te * C.npad[c], C.cnt[c]);
+            meds[idx] = m;
+            if (te < tc) med[e0 + te + nk * c] = m;
         }
-    }
-    __syncthreads();
-    ls_sort<T>(win, TC, C);
-    for (int idx = threadIdx.x; idx < C.nc * TC; idx += LS_NT) {
-        const int c = idx / TC, te = idx - c * TC;
-        if (te < tc) mad[e0 + te + nk * c] = ls_median_sorted<T>(win + C.rowoff[c] + te * C.npad[c], C.cnt[c]);
+        __syncthreads();
+        for (int c = 0; c < C.nc; ++c) {
+            T *rows = win + C.rowoff[c];
+            const int np = C.npad[c];
+            for (int idx = threadIdx.x; idx < TC * C.cnt[c]; idx += LS_NT) {
+                const int te = idx / C.cnt[c], k = idx - te * C.cnt[c];
+                rows[te * np + k] = (T)fabs((double)(T)(rows[te * np + k] - meds[c * TC + te]));
+            }
+        }
+        __syncthreads();
+        ls_sort<T>(win, TC, C);
+        for (int idx = threadIdx.x; idx < C.nc * TC; idx += LS_NT) {
+            const int c = idx / TC, te = idx - c * TC;
+            if (te < tc) mad[e0 + te + nk * c] = ls_median_sorted<T>(win + C.rowoff[c] + te * C.npad[c], C.cnt[c]);
+        }
+        __syncthreads();
     }
 }
 
@@ -158,16 +171,18 @@ template <typename T> __device__ T ls_block_sum(T v, T *red)
 }
 
 // equal weights (Signatures(:equal)): w_c = 1 / N_c
-template <typename T>
+template <typename T, bool GM>
 __global__ __launch_bounds__(LS_NT) void k_emd_equal(const T *__restrict__ X, int64_t nk, const int *__restrict__ order, LsClasses C, int TC,
-                                                     T *__restrict__ D)
+                                                     T *__restrict__ D, char *gwork, size_t wbytes)
 {
     extern __shared__ __attribute__((aligned(16))) char ls_smem[];
-    T *win = reinterpret_cast<T *>(ls_smem);
+    T *win = reinterpret_cast<T *>(ls_window<GM>(ls_smem, gwork, wbytes));
     __shared__ T red[LS_NT];
-    int bid = blockIdx.x;
-    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-    const int64_t e0 = (int64_t)bid * TC;
+    const int64_t ngroups = (nk + TC - 1) / TC;
+    for (int64_t g0 = blockIdx.x; g0 < ngroups; g0 += gridDim.x) {
+    int64_t bid = g0;
+    if (!GM && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int64_t e0 = bid * TC;
     const int tc = (int)min((int64_t)TC, nk - e0);
     ls_stage<T>(win, X, nk, e0, tc, TC, order, C);
     ls_sort<T>(win, TC, C);
@@ -203,11 +218,78 @@ __global__ __launch_bounds__(LS_NT) void k_emd_equal(const T *__restrict__ X, in
             }
         if (threadIdx.x == 0) D[e0 + te] = total;
     }
+    __syncthreads();
+    }
 }
 
 int need_device()
 {
     if (wx_device_count() < 1) return wx_set_error(WX_EHIP, "no HIP device visible: the MI355X kernels cannot run");
+    return WX_OK;
+}
+
+// host copy of the class tables and their upload
+struct LsHost {
+    int nc = 0;
+    std::vector<int> cnt, npad, rowoff, sigoff;
+};
+static bool ls_upload(const LsHost &H, WxScratch &scr, LsClasses *C)
+{
+    std::vector<int> all;
+    all.reserve((size_t)4 * H.nc);
+    all.insert(all.end(), H.cnt.begin(), H.cnt.end());
+    all.insert(all.end(), H.npad.begin(), H.npad.end());
+    all.insert(all.end(), H.rowoff.begin(), H.rowoff.end());
+    all.insert(all.end(), H.sigoff.begin(), H.sigoff.end());
+    const int *d = (const int *)scr.upload(all.data(), all.size() * sizeof(int));
+    if (!d) return false;
+    C->nc = H.nc;
+    C->cnt = d; C->npad = d + H.nc; C->rowoff = d + 2 * (size_t)H.nc; C->sigoff = d + 3 * (size_t)H.nc;
+    return true;
+}
+// signals class by class (stable) + the per-class counts, padded lengths and offsets (rowoff for one row per class)
+static int ls_classes(const int32_t *cls, int64_t N, int nc, LsHost *H, std::vector<int> *order)
+{
+    WX_REQUIRE(cls != nullptr, WX_EARG, "NULL labels");
+    WX_REQUIRE(nc > 1, WX_EASSERT, "@assert nc > 1");
+    WX_REQUIRE(N >= 1 && N < ((int64_t)1 << 30), WX_EUNSUPPORTED, "2^30 signals or more");
+    H->nc = nc;
+    order->assign((size_t)N, 0);
+    std::vector<int> offs((size_t)nc + 1, 0);
+    for (int64_t i = 0; i < N; ++i) {
+        WX_REQUIRE(cls[i] >= 0 && cls[i] < nc, WX_EARG, "class index outside [0, nc)");
+        offs[(size_t)cls[i] + 1]++;
+    }
+    for (int c = 0; c < nc; ++c) {
+        WX_REQUIRE(offs[(size_t)c + 1] > 0, WX_EARG, "a class has no signal");
+        offs[(size_t)c + 1] += offs[(size_t)c];
+    }
+    std::vector<int> pos(offs.begin(), offs.end() - 1);
+    for (int64_t i = 0; i < N; ++i) (*order)[(size_t)pos[(size_t)cls[i]]++] = (int)i;
+    H->cnt.resize(nc); H->npad.resize(nc); H->rowoff.resize(nc); H->sigoff.resize(nc);
+    int64_t off = 0;
+    for (int c = 0; c < nc; ++c) {
+        H->cnt[c] = offs[(size_t)c + 1] - offs[(size_t)c];
+        H->sigoff[c] = offs[(size_t)c];
+        int np = 2;
+        while (np < H->cnt[c]) np <<= 1;
+        H->npad[c] = np;
+        H->rowoff[c] = (int)off;
+        off += np;
+        WX_REQUIRE(off < ((int64_t)1 << 31), WX_EUNSUPPORTED, "too many (padded) signals per coefficient");
+    }
+    return WX_OK;
+}
+// a global window per resident workgroup when the LDS window does not fit: at most 2 GiB of them
+static int ls_global_windows(size_t wbytes, int64_t ngroups, WxScratch &scr, char **gwork, unsigned *grid)
+{
+    int64_t g = ((int64_t)2 << 30) / (int64_t)wbytes;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    if (g > ngroups) g = ngroups;
+    *gwork = (char *)scr.alloc((size_t)g * wbytes);
+    if (!*gwork) return WX_EHIP;
+    *grid = (unsigned)g;
     return WX_OK;
 }
 
@@ -217,44 +299,22 @@ int api_class_rows(int kind, const T *X, int64_t nk, int64_t N, const int32_t *c
 {
     WX_REQUIRE(nk >= 1 && N >= 1, WX_EARG, "bad dimensions");
     WX_REQUIRE(nk < ((int64_t)1 << 31), WX_EUNSUPPORTED, "more than 2^31 coefficients per signal");
-    WX_REQUIRE(cls != nullptr, WX_EARG, "NULL labels");
-    WX_REQUIRE(nc > 1, WX_EASSERT, "@assert nc > 1");
-    WX_REQUIRE(nc <= LS_MAXC, WX_EUNSUPPORTED, "more than 64 classes");
-    WX_REQUIRE(N < ((int64_t)1 << 31), WX_EUNSUPPORTED, "too many signals");
-    LsClasses C;
-    C.nc = nc;
-    std::vector<int> order((size_t)N), offs((size_t)nc + 1, 0);
-    for (int64_t i = 0; i < N; ++i) {
-        WX_REQUIRE(cls[i] >= 0 && cls[i] < nc, WX_EARG, "class index outside [0, nc)");
-        offs[(size_t)cls[i] + 1]++;
-    }
-    for (int c = 0; c < nc; ++c) {
-        WX_REQUIRE(offs[(size_t)c + 1] > 0, WX_EARG, "a class has no signal");
-        offs[(size_t)c + 1] += offs[(size_t)c];
-    }
-    {
-        std::vector<int> pos(offs.begin(), offs.end() - 1);
-        for (int64_t i = 0; i < N; ++i) order[(size_t)pos[(size_t)cls[i]]++] = (int)i;
-    }
+    LsHost H;
+    std::vector<int> order;
+    int rc = ls_classes(cls, N, nc, &H, &order);
+    if (rc) return rc;
     int64_t row_elems = 0;                                              // one row of every class
-    for (int c = 0; c < nc; ++c) {
-        C.cnt[c] = offs[(size_t)c + 1] - offs[(size_t)c];
-        C.sigoff[c] = offs[(size_t)c];
-        int np = 2;
-        while (np < C.cnt[c]) np <<= 1;
-        C.npad[c] = np;
-        row_elems += np;
-    }
+    for (int c = 0; c < nc; ++c) row_elems += H.npad[c];
+    // LDS window: TC rows of every class + nc * TC medians; a global window (one coefficient per step) when one row does not fit
     const int64_t budget = (int64_t)(128 * 1024) / (int64_t)sizeof(T);
-    WX_REQUIRE(row_elems <= budget, WX_EUNSUPPORTED, "the signals of one coefficient (each class padded to a power of two) exceed the 128 KiB LDS window: at most 16384 Float64 / 32768 Float32 values per coefficient, i.e. about 10^4 signals -- fit on a subsample or split the classes");
-    int TC = (int)(budget / row_elems);
+    const bool gm = row_elems + nc > budget;
+    int TC = gm ? 1 : (int)(budget / (row_elems + nc));
     if (TC > 16) TC = 16;
     if (TC > nk) TC = (int)nk;
     {
-        int off = 0;
-        for (int c = 0; c < nc; ++c) { C.rowoff[c] = off; off += TC * C.npad[c]; }
+        int64_t off = 0;
+        for (int c = 0; c < nc; ++c) { H.rowoff[c] = (int)off; off += (int64_t)TC * H.npad[c]; }
     }
-    int rc;
     if ((rc = need_device())) return rc;
     hipStream_t st = wx_stream(stream);
     WxScratch scr(st);
@@ -264,16 +324,28 @@ int api_class_rows(int kind, const T *X, int64_t nk, int64_t N, const int32_t *c
     T *d2 = kind == 0 ? (T *)io.out(out2, sizeof(T) * nk * nc) : nullptr;
     if (!dX || !d1 || (kind == 0 && !d2)) return io.finish(WX_EHIP);
     const int *dorder = (const int *)scr.upload(order.data(), order.size() * sizeof(int));
-    if (!dorder) return io.finish(WX_EHIP);
-    const size_t lds = (size_t)TC * row_elems * sizeof(T);
-    const void *f = kind == 0 ? reinterpret_cast<const void *>(k_class_median_mad<T>) : reinterpret_cast<const void *>(k_emd_equal<T>);
-    if (lds > 48 * 1024 && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return io.finish(wx_set_error(WX_EHIP, "hipFuncSetAttribute(LDS)"));
-    const unsigned grid = (unsigned)((nk + TC - 1) / TC);
-    if (kind == 0)
-        hipLaunchKernelGGL(k_class_median_mad<T>, dim3(grid), dim3(LS_NT), lds, st, dX, nk, dorder, C, TC, d1, d2);
-    else
-        hipLaunchKernelGGL(k_emd_equal<T>, dim3(grid), dim3(LS_NT), lds, st, dX, nk, dorder, C, TC, d1);
+    LsClasses C;
+    if (!dorder || !ls_upload(H, scr, &C)) return io.finish(WX_EHIP);
+    const size_t wbytes = ((size_t)TC * row_elems + (size_t)nc * TC) * sizeof(T);
+    const int64_t ngroups = (nk + TC - 1) / TC;
+    if (gm) {
+        char *gwork = nullptr;
+        unsigned grid = 0;
+        if ((rc = ls_global_windows(wbytes, ngroups, scr, &gwork, &grid))) return io.finish(rc);
+        if (kind == 0)
+            hipLaunchKernelGGL((k_class_median_mad<T, true>), dim3(grid), dim3(LS_NT), 0, st, dX, nk, dorder, C, TC, row_elems, d1, d2, gwork, wbytes);
+        else
+            hipLaunchKernelGGL((k_emd_equal<T, true>), dim3(grid), dim3(LS_NT), 0, st, dX, nk, dorder, C, TC, d1, gwork, wbytes);
+    } else {
+        const void *f = kind == 0 ? reinterpret_cast<const void *>(k_class_median_mad<T, false>) : reinterpret_cast<const void *>(k_emd_equal<T, false>);
+        if (wbytes > 48 * 1024 && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes) != hipSuccess)
+            return io.finish(wx_set_error(WX_EHIP, "hipFuncSetAttribute(LDS)"));
+        if (kind == 0)
+            hipLaunchKernelGGL((k_class_median_mad<T, false>), dim3((unsigned)ngroups), dim3(LS_NT), wbytes, st, dX, nk, dorder, C, TC, row_elems, d1, d2,
+                               (char *)nullptr, (size_t)0);
+        else
+            hipLaunchKernelGGL((k_emd_equal<T, false>), dim3((unsigned)ngroups), dim3(LS_NT), wbytes, st, dX, nk, dorder, C, TC, d1, (char *)nullptr, (size_t)0);
+    }
     if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "LDB order-statistics kernel failed to launch"));
     return io.finish(WX_OK);
 }
@@ -358,17 +430,18 @@ __device__ void ls_ash_density(const int *counts, double *dens, int len, int m, 
     __syncthreads();
 }
 
-template <typename T>
+template <typename T, bool GM>
 __global__ __launch_bounds__(LS_NT) void k_pdf_energy_map(const T *__restrict__ X, int64_t nk, int N, const int *__restrict__ cls, int nc,
-                                                          LsAsh A, double *__restrict__ Gamma)
+                                                          LsAsh A, double *__restrict__ Gamma, char *gwork, size_t wbytes)
 {
     extern __shared__ __attribute__((aligned(16))) char ls_smem[];
-    double *z = reinterpret_cast<double *>(ls_smem);                     // N values
+    double *z = reinterpret_cast<double *>(ls_window<GM>(ls_smem, gwork, wbytes));   // N values
     double *dens = z + N;                                                // len
     int *counts = reinterpret_cast<int *>(dens + A.len);                 // len
     __shared__ double red[LS_NT];
-    int bid = blockIdx.x;
-    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    for (int64_t g0 = blockIdx.x; g0 < nk; g0 += gridDim.x) {
+    int64_t bid = g0;
+    if (!GM && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int64_t e = bid;
     for (int i = threadIdx.x; i < N; i += LS_NT) z[i] = (double)X[e + nk * (int64_t)i];
     __syncthreads();
@@ -389,20 +462,22 @@ __global__ __launch_bounds__(LS_NT) void k_pdf_energy_map(const T *__restrict__ 
         for (int i = threadIdx.x; i < A.len; i += LS_NT) Gamma[e + nk * ((int64_t)i + (int64_t)A.len * c)] = dens[i];
         __syncthreads();
     }
+    }
 }
 
 // W[e, signal] = pdf(ash of the signal's class at coefficient e, X[e, signal])
-template <typename T>
+template <typename T, bool GM>
 __global__ __launch_bounds__(LS_NT) void k_signature_weights(const T *__restrict__ X, int64_t nk, int N, const int *__restrict__ order,
-                                                             LsClasses C, LsAsh A, T *__restrict__ W)
+                                                             LsClasses C, LsAsh A, T *__restrict__ W, char *gwork, size_t wbytes)
 {
     extern __shared__ __attribute__((aligned(16))) char ls_smem[];
-    double *z = reinterpret_cast<double *>(ls_smem);                     // the class's values (<= N)
+    double *z = reinterpret_cast<double *>(ls_window<GM>(ls_smem, gwork, wbytes));   // the class's values (<= N)
     double *dens = z + N;
     int *counts = reinterpret_cast<int *>(dens + A.len);
     __shared__ double red[LS_NT];
-    int bid = blockIdx.x;
-    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    for (int64_t g0 = blockIdx.x; g0 < nk; g0 += gridDim.x) {
+    int64_t bid = g0;
+    if (!GM && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int64_t e = bid;
     for (int c = 0; c < C.nc; ++c) {
         const int cnt = C.cnt[c];
@@ -435,21 +510,21 @@ __global__ __launch_bounds__(LS_NT) void k_signature_weights(const T *__restrict
         }
         __syncthreads();
     }
+    }
 }
 
 // earth mover's distance with one weight per (coefficient, signal): rows of weights travel with the keys
-template <typename T>
+template <typename T, bool GM>
 __global__ __launch_bounds__(LS_NT) void k_emd_weighted(const T *__restrict__ X, const T *__restrict__ Wt, int64_t nk, const int *__restrict__ order,
-                                                        LsClasses C, T *__restrict__ D)
+                                                        LsClasses C, int64_t rows, T *__restrict__ D, char *gwork, size_t wbytes)
 {
     extern __shared__ __attribute__((aligned(16))) char ls_smem[];
-    T *win = reinterpret_cast<T *>(ls_smem);                             // keys: one row per class (TC = 1)
-    int rows = 0;
-    for (int c = 0; c < C.nc; ++c) rows += C.npad[c];
+    T *win = reinterpret_cast<T *>(ls_window<GM>(ls_smem, gwork, wbytes));   // keys: one row per class (TC = 1)
     T *wts = win + rows;                                                 // weights, then their inclusive prefix sums
     __shared__ T red[LS_NT];
-    int bid = blockIdx.x;
-    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    for (int64_t g0 = blockIdx.x; g0 < nk; g0 += gridDim.x) {
+    int64_t bid = g0;
+    if (!GM && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int64_t e = bid;
     for (int c = 0; c < C.nc; ++c) {
         const int np = C.npad[c];
@@ -479,10 +554,10 @@ __global__ __launch_bounds__(LS_NT) void k_emd_weighted(const T *__restrict__ X,
                 __syncthreads();
             }
     }
-    if (threadIdx.x < C.nc) {                                            // prefix sums of the sorted weights (sequential per row)
-        T *w = wts + C.rowoff[threadIdx.x];
+    for (int c = threadIdx.x; c < C.nc; c += LS_NT) {                     // prefix sums of the sorted weights (sequential per row)
+        T *w = wts + C.rowoff[c];
         T run = 0;
-        for (int k = 0; k < C.cnt[threadIdx.x]; ++k) { run += w[k]; w[k] = run; }
+        for (int k = 0; k < C.cnt[c]; ++k) { run += w[k]; w[k] = run; }
     }
     __syncthreads();
     T total = 0;
@@ -515,41 +590,11 @@ __global__ __launch_bounds__(LS_NT) void k_emd_weighted(const T *__restrict__ X,
             total += s / (Pw[n1 - 1] + Qw[n2 - 1]);
         }
     if (threadIdx.x == 0) D[e] = total;
+    __syncthreads();
+    }
 }
 
 namespace {
-
-int ls_classes(const int32_t *cls, int64_t N, int nc, LsClasses *C, std::vector<int> *order)
-{
-    WX_REQUIRE(cls != nullptr, WX_EARG, "NULL labels");
-    WX_REQUIRE(nc > 1, WX_EASSERT, "@assert nc > 1");
-    WX_REQUIRE(nc <= LS_MAXC, WX_EUNSUPPORTED, "more than 64 classes");
-    WX_REQUIRE(N >= 1 && N < ((int64_t)1 << 31), WX_EUNSUPPORTED, "bad number of signals");
-    C->nc = nc;
-    order->assign((size_t)N, 0);
-    std::vector<int> offs((size_t)nc + 1, 0);
-    for (int64_t i = 0; i < N; ++i) {
-        WX_REQUIRE(cls[i] >= 0 && cls[i] < nc, WX_EARG, "class index outside [0, nc)");
-        offs[(size_t)cls[i] + 1]++;
-    }
-    for (int c = 0; c < nc; ++c) {
-        WX_REQUIRE(offs[(size_t)c + 1] > 0, WX_EARG, "a class has no signal");
-        offs[(size_t)c + 1] += offs[(size_t)c];
-    }
-    std::vector<int> pos(offs.begin(), offs.end() - 1);
-    for (int64_t i = 0; i < N; ++i) (*order)[(size_t)pos[(size_t)cls[i]]++] = (int)i;
-    int off = 0;
-    for (int c = 0; c < nc; ++c) {
-        C->cnt[c] = offs[(size_t)c + 1] - offs[(size_t)c];
-        C->sigoff[c] = offs[(size_t)c];
-        int np = 2;
-        while (np < C->cnt[c]) np <<= 1;
-        C->npad[c] = np;
-        C->rowoff[c] = off;
-        off += np;
-    }
-    return WX_OK;
-}
 
 LsAsh ls_ash_params(int64_t Nx)
 {
@@ -565,13 +610,13 @@ int api_pdf_map(const T *X, int64_t nk, int64_t N, const int32_t *cls, int nc, d
 {
     WX_REQUIRE(nk >= 1 && N >= 2, WX_EARG, "bad dimensions");
     WX_REQUIRE(nk < ((int64_t)1 << 31), WX_EUNSUPPORTED, "more than 2^31 coefficients per signal");
-    LsClasses C;
+    LsHost H;
     std::vector<int> order;
-    int rc = ls_classes(cls, N, nc, &C, &order);
+    int rc = ls_classes(cls, N, nc, &H, &order);
     if (rc) return rc;
     const LsAsh A = ls_ash_params(N);
-    const size_t lds = sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len;
-    WX_REQUIRE(lds <= 150 * 1024, WX_EUNSUPPORTED, "more signals than fit the 150 KiB LDS window of one coefficient (about 19000 Float64 / 38000 Float32 signals): fit on a subsample");
+    const size_t wbytes = sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len + 16;
+    const bool gm = wbytes > 150 * 1024;                    // more than about 19000 signals: the values of a coefficient in a global window
     if ((rc = need_device())) return rc;
     hipStream_t st = wx_stream(stream);
     WxScratch scr(st);
@@ -581,10 +626,18 @@ int api_pdf_map(const T *X, int64_t nk, int64_t N, const int32_t *cls, int nc, d
     if (!dX || !dG) return io.finish(WX_EHIP);
     const int *dcls = (const int *)scr.upload(cls, sizeof(int32_t) * (size_t)N);
     if (!dcls) return io.finish(WX_EHIP);
-    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_pdf_energy_map<T>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return io.finish(wx_set_error(WX_EHIP, "hipFuncSetAttribute(LDS)"));
-    hipLaunchKernelGGL(k_pdf_energy_map<T>, dim3((unsigned)nk), dim3(LS_NT), lds, st, dX, nk, (int)N, dcls, nc, A, dG);
+    if (gm) {
+        char *gwork = nullptr;
+        unsigned grid = 0;
+        if ((rc = ls_global_windows(wbytes, nk, scr, &gwork, &grid))) return io.finish(rc);
+        hipLaunchKernelGGL((k_pdf_energy_map<T, true>), dim3(grid), dim3(LS_NT), 0, st, dX, nk, (int)N, dcls, nc, A, dG, gwork, wbytes);
+    } else {
+        if (wbytes > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_pdf_energy_map<T, false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes) != hipSuccess)
+            return io.finish(wx_set_error(WX_EHIP, "hipFuncSetAttribute(LDS)"));
+        hipLaunchKernelGGL((k_pdf_energy_map<T, false>), dim3((unsigned)nk), dim3(LS_NT), wbytes, st, dX, nk, (int)N, dcls, nc, A, dG, (char *)nullptr,
+                           (size_t)0);
+    }
     if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "density map kernel failed to launch"));
     return io.finish(WX_OK);
 }
@@ -595,15 +648,15 @@ int api_signature(int kind, const T *X, const T *Win, int64_t nk, int64_t N, int
 {
     WX_REQUIRE(nk >= 1 && N >= 2, WX_EARG, "bad dimensions");
     WX_REQUIRE(nk < ((int64_t)1 << 31), WX_EUNSUPPORTED, "more than 2^31 coefficients per signal");
-    LsClasses C;
+    LsHost H;
     std::vector<int> order;
-    int rc = ls_classes(cls, N, nc, &C, &order);
+    int rc = ls_classes(cls, N, nc, &H, &order);
     if (rc) return rc;
     const LsAsh A = ls_ash_params(Ntot);
     int64_t rows = 0;
-    for (int c = 0; c < nc; ++c) { WX_REQUIRE(kind == 1 || C.cnt[c] >= 2, WX_EARG, "a class needs two signals for its deviation"); rows += C.npad[c]; }
-    const size_t lds = kind == 0 ? sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len : sizeof(T) * 2 * (size_t)rows;
-    WX_REQUIRE(lds <= 150 * 1024, WX_EUNSUPPORTED, "more signals than fit the 150 KiB LDS window of one coefficient (about 19000 Float64 / 38000 Float32 signals): fit on a subsample");
+    for (int c = 0; c < nc; ++c) { WX_REQUIRE(kind == 1 || H.cnt[c] >= 2, WX_EARG, "a class needs two signals for its deviation"); rows += H.npad[c]; }
+    const size_t wbytes = (kind == 0 ? sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len : sizeof(T) * 2 * (size_t)rows) + 16;
+    const bool gm = wbytes > 150 * 1024;
     if ((rc = need_device())) return rc;
     hipStream_t st = wx_stream(stream);
     WxScratch scr(st);
@@ -613,14 +666,27 @@ int api_signature(int kind, const T *X, const T *Win, int64_t nk, int64_t N, int
     T *dout = (T *)io.out(out, sizeof(T) * nk * (kind == 0 ? N : 1));
     if (!dX || !dout || (kind == 1 && !dW)) return io.finish(WX_EHIP);
     const int *dorder = (const int *)scr.upload(order.data(), order.size() * sizeof(int));
-    if (!dorder) return io.finish(WX_EHIP);
-    const void *f = kind == 0 ? reinterpret_cast<const void *>(k_signature_weights<T>) : reinterpret_cast<const void *>(k_emd_weighted<T>);
-    if (lds > 48 * 1024 && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return io.finish(wx_set_error(WX_EHIP, "hipFuncSetAttribute(LDS)"));
-    if (kind == 0)
-        hipLaunchKernelGGL(k_signature_weights<T>, dim3((unsigned)nk), dim3(LS_NT), lds, st, dX, nk, (int)N, dorder, C, A, dout);
-    else
-        hipLaunchKernelGGL(k_emd_weighted<T>, dim3((unsigned)nk), dim3(LS_NT), lds, st, dX, dW, nk, dorder, C, dout);
+    LsClasses C;
+    if (!dorder || !ls_upload(H, scr, &C)) return io.finish(WX_EHIP);
+    if (gm) {
+        char *gwork = nullptr;
+        unsigned grid = 0;
+        if ((rc = ls_global_windows(wbytes, nk, scr, &gwork, &grid))) return io.finish(rc);
+        if (kind == 0)
+            hipLaunchKernelGGL((k_signature_weights<T, true>), dim3(grid), dim3(LS_NT), 0, st, dX, nk, (int)N, dorder, C, A, dout, gwork, wbytes);
+        else
+            hipLaunchKernelGGL((k_emd_weighted<T, true>), dim3(grid), dim3(LS_NT), 0, st, dX, dW, nk, dorder, C, rows, dout, gwork, wbytes);
+    } else {
+        const void *f = kind == 0 ? reinterpret_cast<const void *>(k_signature_weights<T, false>) : reinterpret_cast<const void *>(k_emd_weighted<T, false>);
+        if (wbytes > 48 * 1024 && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes) != hipSuccess)
+            return io.finish(wx_set_error(WX_EHIP, "hipFuncSetAttribute(LDS)"));
+        if (kind == 0)
+            hipLaunchKernelGGL((k_signature_weights<T, false>), dim3((unsigned)nk), dim3(LS_NT), wbytes, st, dX, nk, (int)N, dorder, C, A, dout,
+                               (char *)nullptr, (size_t)0);
+        else
+            hipLaunchKernelGGL((k_emd_weighted<T, false>), dim3((unsigned)nk), dim3(LS_NT), wbytes, st, dX, dW, nk, dorder, C, rows, dout, (char *)nullptr,
+                               (size_t)0);
+    }
     if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "signature kernel failed to launch"));
     return io.finish(WX_OK);
 }

@@ -15,6 +15,7 @@
 // the cumulative sums are a workgroup scan, and argmin / argmax keep the first index on ties like Julia's findmin /
 // findmax.  The results are picks from the sorted magnitudes, so they equal the reference's unless two candidates tie to
 // within the rounding of the sums (the reference adds sequentially / pairwise, the scan adds by chunks).
+#include "../../include/waveletsext_hip.h"     // the definitions below must match the public prototypes
 #include "wx_common.h"
 #include "wx_kernels.h"
 #include "wx_host.h"

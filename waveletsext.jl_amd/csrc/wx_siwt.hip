@@ -13,6 +13,7 @@
 // one launch over all of its columns and all signals; costs, the three-way (node / children / shifted children)
 // selection and the inverse are level-synchronous launches as well.  Built with -ffp-contract=off and the
 // reference's tap order: the Float64 coefficients are bit-identical to the scalar restatement in oracle/.
+#include "../../include/waveletsext_hip.h"     // the definitions below must match the public prototypes
 #include "wx_common.h"
 #include "wx_host.h"
 #include "wx_kernels.h"

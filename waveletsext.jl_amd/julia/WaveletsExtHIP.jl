@@ -730,7 +730,7 @@ end
 "the :pdf weights of energy_map(Xw, y, Signatures(:pdf)) (ldb_energymap.jl:216-232), one per coefficient and signal"
 function signature_weights(Xw::HIP{T}, y::AbstractVector) where T<:FT
     cls, nc = classindex(y); N = size(Xw)[end]; ne = length(Xw) ÷ N
-    W = newlike(Xw, Float64, size(Xw))
+    W = newlike(Xw, T, size(Xw))
     check(wx_signature_weights(T, raw(Xw), ne, N, cls, nc, W, stream()))
     return W
 end

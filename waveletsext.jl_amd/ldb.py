@@ -10,10 +10,9 @@ RobustFishersClassSeparability and the earth mover's distance between the class 
 The ProbabilityDensity map and the Signatures(:pdf) weights are average shifted histograms over the signal axis
 (AverageShiftedHistograms.jl is outside the reference tree: its published algorithm is restated in the kernels).
 
-Limit of the order-statistic kernels (the reference has none): the signals of one coefficient are sorted inside one LDS
-window -- RobustFishersClassSeparability and EarthMoverDistance take about 10^4 signals (16384 Float64 values with every
-class padded to a power of two), ProbabilityDensity and Signatures(:pdf) about 19000; beyond that the calls raise
-WxError(WX_EUNSUPPORTED) with the limit in the message (fit on a subsample).  The TimeFrequency / Fisher path has no limit."""
+No size limit (round 4): the signals of one coefficient are sorted / binned inside one LDS window while they fit (about 10^4 signals
+per coefficient for RobustFishersClassSeparability and EarthMoverDistance, 19000 for ProbabilityDensity and Signatures(:pdf)) and in
+a global-memory window per workgroup beyond that (slower, same results); any number of classes."""
 import ctypes
 import itertools
 
