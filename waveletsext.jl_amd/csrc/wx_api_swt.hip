@@ -324,9 +324,15 @@ static int api_acwpd_jbb_moments(const double *x, double *sum, double *sumsq, in
         for (int64_t b0 = 0; b0 < batch && rc == WX_OK; b0 += chunk) {
             const int64_t bc = (batch - b0 < chunk) ? batch - b0 : chunk;
             const int acc = (accumulate || b0 > 0) ? 1 : 0;
-            if (D0 > 0) rc = wx_dev_swt_fwd<double>(dx + b0 * n, tab, n, D0, LAYOUT_WPD, bc, filt, &acf, st);
-            else WX_HIP_CHECK(hipMemcpyAsync(tab, dx + b0 * n, sizeof(double) * n * bc, hipMemcpyDeviceToDevice, st));
-            if (rc == WX_OK) rc = wx_dev_jbb_moments<double>(tab, dsum, dsq, nk_top, bc, acc, nullptr, 1, st);
+            // the top table and its moments in the same passes (only what the subtree kernel and the next pass read is written);
+            // otherwise three plain passes and the moment kernel over the whole top table
+            int fusedm = D0 > 0 ? wx_dev_acwpd_top_moments(dx + b0 * n, tab, n, D0, bc, acf, dsum, dsq, acc, st) : 0;
+            if (fusedm < 0) rc = fusedm;
+            if (fusedm == 0) {
+                if (D0 > 0) rc = wx_dev_swt_fwd<double>(dx + b0 * n, tab, n, D0, LAYOUT_WPD, bc, filt, &acf, st);
+                else WX_HIP_CHECK(hipMemcpyAsync(tab, dx + b0 * n, sizeof(double) * n * bc, hipMemcpyDeviceToDevice, st));
+                if (rc == WX_OK) rc = wx_dev_jbb_moments<double>(tab, dsum, dsq, nk_top, bc, acc, nullptr, 1, st);
+            }
             if (rc == WX_OK)
                 rc = wx_acwpd_mfma_ok(n, L, D0) ? wx_dev_acwpd_subtree_mfma(tab, dsum, dsq, n, L, D0, bc, acf, acc, st)
                                                 : wx_dev_acwpd_subtree_moments(tab, dsum, dsq, n, L, D0, bc, acf, acc, st);

@@ -88,6 +88,10 @@ template <typename T>
 int wx_dev_iacwpd(const T *xw, T *x, int64_t n, int ncols, int64_t batch, const uint8_t *dtree, int64_t ntree,
                   int Lfull, hipStream_t st);
 
+// acwpd top table (depths 0 .. D0) + the JBB moments of its columns in the passes that produce them (wx_swt1d.hip): 1 = done, 0 = n/a
+int wx_dev_acwpd_top_moments(const double *x, double *tab, int64_t n, int D0, int64_t batch, const WxAcFilt &ac, double *sum, double *sumsq,
+                             int acc, hipStream_t st);
+
 // ---- JBB (wx_jbb.hip) ----
 template <typename T>
 int wx_dev_jbb_moments(const T *X, T *sum, T *sumsq, int64_t nk, int64_t batch, int accumulate, T *scratch,

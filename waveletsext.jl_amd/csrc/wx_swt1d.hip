@@ -176,6 +176,175 @@ __global__ __launch_bounds__(1024) void k_swpd_fwd_two(const T *__restrict__ x, 
 }
 
 // ------------------------------------------------------------------------------------------
+// acwpd top table WITH the JBB moments of its columns (BASELINE config 5).  The table of depths 0 .. D0 was
+// written by three two-level passes, read back by the moment kernel (4.3 GB per 2048 signals) and read again, depth D0 only, by the
+// subtree kernel.  Here a workgroup keeps its parent node and walks `its` signals in order (blockIdx.y, grid-strided), so the sums
+// over the signal axis of everything it produces -- the root, two children, four grandchildren -- accumulate in registers: a thread
+// owns NP positions of every column.  The columns nobody reads again (odd depths, the root) are not written at all; partial sums
+// per workgroup go to a scratch array and k_acwpd_top_combine adds them in the fixed order of blockIdx.y (deterministic; the
+// association differs from one sequential sum over the signals by rounding only: bestbasis/bestbasis_tree.jl:153-154).
+// x * x is rounded on its own like the moment kernel (wx_sq_unfused, wx_jbb.hip): no fused multiply-add into the sum.
+// ------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(1024) void k_acwpd_top_two_mom(const double *__restrict__ x, double *__restrict__ xw, int n, int ncols,
+                                                            int64_t batch, int d, int last, WxAcFilt ac, double *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    double *v = reinterpret_cast<double *>(wx_smem), *c0 = v + n, *c1 = c0 + n;
+    const int b = blockIdx.x;
+    const int pcol = (1 << d) - 1 + b, gcol = (1 << (d + 2)) - 1 + 4 * b;
+    const int s = (1 << d) % n, s1 = (2 << d) % n;
+    // moments: slot 0 = root (d == 0 only), 1, 2 = children, 3 .. 6 = grandchildren
+    double ms[7][NP], mq[7][NP];
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) ms[c][p] = mq[c][p] = 0.0;
+    auto add = [&](double &sm, double &sq, double val) {
+        sm = __dadd_rn(sm, val);
+        sq = __dadd_rn(sq, __dmul_rn(val, val));
+    };
+    // one autocorrelation step at dilation st (acwt/acwt_one_level.jl:101-128): lo = c + S, hi = c - S
+    const int nm = n - 1;                                    // n is a power of two: the periodic wrap is a mask
+    auto step = [&](const double *src, int st, int i, double &lo, double &hi) {
+        double S = 0.0;
+        int lag = st;                                         // wave-uniform: the index arithmetic per tap is two adds and two ands
+        for (int l = 1; l < ac.F; l += 2) {                  // odd lags only
+            S = fma(ac.b[l - 1], src[(i - lag) & nm] + src[(i + lag) & nm], S);
+            lag += 2 * st;
+        }
+        const double c = ac.c1 * src[i];
+        lo = c + S;
+        hi = c - S;
+    };
+    // the parent column of the next signal travels while this one is computed
+    double nxt[NP];
+    auto fetch = [&](int64_t sig) {
+        const double *src = (d == 0) ? x + sig * (int64_t)n : xw + sig * (int64_t)n * ncols + (int64_t)pcol * n;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) nxt[p] = src[threadIdx.x + p * 1024];
+    };
+    if ((int64_t)blockIdx.y < batch) fetch(blockIdx.y);
+    for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
+        double *base = xw + sig * (int64_t)n * ncols;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = threadIdx.x + p * 1024;
+            const double t = nxt[p];
+            v[i] = t;
+            if (d == 0) add(ms[0][p], mq[0][p], t);
+        }
+        if (sig + gridDim.y < batch) fetch(sig + gridDim.y);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = threadIdx.x + p * 1024;
+            double lo, hi;
+            step(v, s, i, lo, hi);
+            c0[i] = lo; c1[i] = hi;
+            add(ms[1][p], mq[1][p], lo);
+            add(ms[2][p], mq[2][p], hi);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = threadIdx.x + p * 1024;
+            double g0, g1, g2, g3;
+            step(c0, s1, i, g0, g1);
+            step(c1, s1, i, g2, g3);
+            // the grandchildren are the next pass's parents (or, after the last pass, the subtree kernel's input): they are written
+            base[(int64_t)gcol * n + i] = g0;
+            base[(int64_t)(gcol + 1) * n + i] = g1;
+            base[(int64_t)(gcol + 2) * n + i] = g2;
+            base[(int64_t)(gcol + 3) * n + i] = g3;
+            add(ms[3][p], mq[3][p], g0);
+            add(ms[4][p], mq[4][p], g1);
+            add(ms[5][p], mq[5][p], g2);
+            add(ms[6][p], mq[6][p], g3);
+        }
+        __syncthreads();
+    }
+    (void)last;
+    // partial sums of this workgroup: part[((y * nodes + b) * 7 + slot) * n + i], sums first, squares behind them
+    const int64_t nodes = gridDim.x;
+    const int64_t slab = ((int64_t)blockIdx.y * nodes + b) * 7;
+    const int64_t half = (int64_t)gridDim.y * nodes * 7 * n;
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = threadIdx.x + p * 1024;
+            part[(slab + c) * n + i] = ms[c][p];
+            part[half + (slab + c) * n + i] = mq[c][p];
+        }
+}
+
+// sum[col, i] (+)= sum over y of the partials, y ascending; col of (node b, slot): root 0, children 2^(d+1)-1 + 2b + {0,1},
+// grandchildren 2^(d+2)-1 + 4b + {0..3}
+__global__ __launch_bounds__(256) void k_acwpd_top_combine(const double *__restrict__ part, int n, int d, int nodes, int gy, int acc,
+                                                           double *__restrict__ sum, double *__restrict__ sumsq)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;               // over nodes * 7 * n
+    if (e >= (int64_t)nodes * 7 * n) return;
+    const int i = (int)(e % n);
+    const int64_t t = e / n;
+    const int slot = (int)(t % 7), b = (int)(t / 7);
+    if (slot == 0 && d != 0) return;
+    const int col = slot == 0 ? 0 : (slot <= 2 ? (1 << (d + 1)) - 1 + 2 * b + (slot - 1) : (1 << (d + 2)) - 1 + 4 * b + (slot - 3));
+    const int64_t half = (int64_t)gy * nodes * 7 * n;
+    double a = 0.0, q = 0.0;
+    for (int y = 0; y < gy; ++y) {
+        const int64_t o = (((int64_t)y * nodes + b) * 7 + slot) * n + i;
+        a = __dadd_rn(a, part[o]);
+        q = __dadd_rn(q, part[half + o]);
+    }
+    const int64_t dst = (int64_t)col * n + i;
+    sum[dst] = acc ? __dadd_rn(sum[dst], a) : a;
+    sumsq[dst] = acc ? __dadd_rn(sumsq[dst], q) : q;
+}
+
+// the top table of depths 0 .. D0 (only the even depths >= 2 are written: tab is (n, 2^(D0+1)-1, batch) like acwpd's) and the
+// moments of ALL its columns; 1 = done, 0 = not applicable (the caller takes the three plain passes + the moment kernel), < 0 = error
+int wx_dev_acwpd_top_moments(const double *x, double *tab, int64_t n, int D0, int64_t batch, const WxAcFilt &ac, double *sum, double *sumsq,
+                             int acc, hipStream_t st)
+{
+    static const bool off = getenv("WX_ACWPD_TOPMOM") && atoi(getenv("WX_ACWPD_TOPMOM")) == 0;
+    if (off || wx_force_generic_swt() || D0 < 2 || (D0 & 1) || batch < 1) return 0;
+    if (n != 1024 && n != 2048 && n != 4096) return 0;
+    const int NP = (int)(n / 1024);
+    const int ncols = (1 << (D0 + 1)) - 1;
+    const size_t lds = (size_t)3 * n * sizeof(double);
+    WxScratch scr(st);
+    // per pass nodes * gy workgroups, gy = 128, 64, 32, ... signal groups (the last pass has the most nodes)
+    size_t pbytes = 0;
+    for (int d = 0; d < D0; d += 2) {
+        const int nodes = 1 << d;
+        int64_t gy = 128 >> (d / 2); if (gy < 32) gy = 32; if (gy > batch) gy = batch;
+        const size_t need = (size_t)2 * gy * nodes * 7 * n * sizeof(double);
+        if (need > pbytes) pbytes = need;
+    }
+    double *part = (double *)scr.alloc(pbytes);
+    if (!part) return WX_EHIP;
+    for (int d = 0; d < D0; d += 2) {
+        const int nodes = 1 << d;
+        int64_t gy = 128 >> (d / 2); if (gy < 32) gy = 32; if (gy > batch) gy = batch;    // the partials' count: the combine walks them in order
+#define WX_TM(NPP)                                                                                                                     \
+        {                                                                                                                              \
+            auto k = k_acwpd_top_two_mom<NPP>;                                                                                         \
+            if (lds > 64 * 1024) WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(k, dim3(nodes, (unsigned)gy), dim3(1024), lds, st, x, tab, (int)n, ncols, batch, d, d + 2 >= D0 ? 1 : 0, ac, part); \
+        }
+        if (NP == 1) WX_TM(1) else if (NP == 2) WX_TM(2) else WX_TM(4)
+#undef WX_TM
+        const int64_t tot = (int64_t)nodes * 7 * n;
+        hipLaunchKernelGGL(k_acwpd_top_combine, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double *)part, (int)n, d, nodes, (int)gy,
+                           acc, sum, sumsq);
+        WX_HIP_CHECK(hipGetLastError());
+    }
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // sdwt / acdwt with every level in one kernel: the running approximation stays in LDS (ping-pong), each
 // level writes only its detail column, the last approximation goes to column 0.  HBM sees the signal once
 // and every output column once ((L+2) n per signal instead of 3 L n one level at a time).
