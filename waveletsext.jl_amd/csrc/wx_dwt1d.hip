@@ -21,6 +21,7 @@
 #include "wx_kernels.h"
 #include "wx_host.h"
 #include "wx_toptile.h"
+#include "wx_lanetree.h"
 
 // the tree-driven lattice kernels for either signal type (Float32: dense leaves only, no threshold riding on the loads)
 template <typename T>
@@ -1370,6 +1371,14 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
         return WX_OK;
     }
     const bool noreg = wx_skip_register_kernels();      // test hook: fused LDS kernels only
+    if constexpr (sizeof(T) == 4) {
+        // very short Float32 signals, full tree (the columns of small images arrive here too): one lane per signal (wx_lanetree.h)
+        if (!force_generic && !noreg && !status && wx_small_tree_wanted<T>(n, filt.F, false, false) && n <= 128 && x != y) {
+            WxLaneTree lt;
+            for (int i = 0; i < 8; ++i) lt.bits[i] = 0xffffffffu;
+            return wx_lane_tree_f32(false, (const float *)x, (float *)y, n, L, batch, lt, filt, st);
+        }
+    }
     if constexpr (sizeof(T) == 8) {
         // full tree: rotations in registers (wx_lattice.hip; Haar is the lattice with one rotation: 0.78 ms against the
         // 0.94 ms of the Walsh-Hadamard kernel at the target's size)
@@ -1867,6 +1876,13 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
         return WX_OK;
     }
     const bool noreg = wx_skip_register_kernels();
+    if constexpr (sizeof(T) == 4) {
+        if (!force_generic && !noreg && !status && !colmap && is == n && wx_small_tree_wanted<T>(n, filt.F, false, false) && n <= 128 && xw != xh) {
+            WxLaneTree lt;
+            for (int i = 0; i < 8; ++i) lt.bits[i] = 0xffffffffu;
+            return wx_lane_tree_f32(true, (const float *)xw, (float *)xh, n, L, batch, lt, filt, st);
+        }
+    }
     if constexpr (sizeof(T) == 8) {
         if (!force_generic && !noreg && !status && !colmap) {
             const int r = wx_lattice_iwpt_f64((const double *)xw, (double *)xh, n, L, batch, is, filt, st);

@@ -378,7 +378,11 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
     }
 }
 
-template <typename T> static void wx_rows_geometry(int &R, int &S)
+// strip height R (rows of an image a workgroup takes through all levels of the row pass) and LDS column pitch S >= R.  Wide images
+// get lower strips, so that the two LDS images of a strip (2 n S elements) still fit: until round 4 the geometry was fixed and images
+// wider than 256 (Float64) / 512 (Float32) columns fell off the fast path onto two naive launches per level (full-depth trees of
+// 512 x 512 Float64 images: 21 ms per GiB, 1 % of the HBM peak).
+template <typename T> static void wx_rows_geometry(int64_t n, int &R, int &S)
 {
     if (sizeof(T) == 4) { R = 32; S = 32; } else { R = 16; S = 24; }
     // tuning knobs (strip height, a power of two, and LDS column pitch >= R)
@@ -387,12 +391,17 @@ template <typename T> static void wx_rows_geometry(int &R, int &S)
         const int r = atoi(er), s2 = atoi(es);
         if (r >= 4 && r <= 64 && (r & (r - 1)) == 0 && s2 >= r && s2 <= 128) { R = r; S = s2; }
     }
+    constexpr int VW = 16 / (int)sizeof(T);
+    while (R > VW && (size_t)2 * n * S * sizeof(T) > 160 * 1024) {
+        R >>= 1;
+        S = sizeof(T) == 4 ? R : R + R / 2;
+    }
 }
 
 template <typename T> bool wx_wpt2d_fast_ok(int64_t m, int64_t n, int F)
 {
     int R, S;
-    wx_rows_geometry<T>(R, S);
+    wx_rows_geometry<T>(n, R, S);
     const bool pow2 = n >= 2 && (n & (n - 1)) == 0;
     return pow2 && wx_fused1d_ok<T>(m, F) && (size_t)2 * n * S * sizeof(T) <= 160 * 1024 && n * m < ((int64_t)1 << 31);
 }
@@ -402,7 +411,7 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
                           int64_t batch, const WxFilt &filt, hipStream_t st)
 {
     int R, S;
-    wx_rows_geometry<T>(R, S);
+    wx_rows_geometry<T>(n, R, S);
     size_t lds = (size_t)2 * n * S * sizeof(T);
     // 16-byte row vectors when the geometry and the pointers allow it
     constexpr int VW = 16 / (int)sizeof(T);
@@ -1002,6 +1011,24 @@ int wx_dev_wpd2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, c
     return WX_OK;
 }
 
+// copies the blocks (jr, jc) of depth d listed in `act` -- (m >> d) x (n >> d) elements each -- of every image from src to dst
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy_blocks2d(const T *__restrict__ src, T *__restrict__ dst, int64_t src_img, int64_t dst_img, int m,
+                                                       int d, int64_t batch, const int *__restrict__ act, int nact, int n)
+{
+    const int mp = m >> d, np = n >> d;
+    const int64_t per = (int64_t)mp * np, total = per * nact * batch;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = g / (per * nact);
+        int64_t r = g - b * per * nact;
+        const int a = (int)(r / per);
+        r -= (int64_t)a * per;
+        const int c = (int)(r / mp), i = (int)(r - (int64_t)c * mp);
+        const int64_t e = (int64_t)(act[2 * a + 1] * np + c) * m + act[2 * a] * mp + i;
+        dst[b * dst_img + e] = src[b * src_img + e];
+    }
+}
+
 // wpt / iwpt 2-D on (m, n, batch); tmp and pong hold m*n*batch elements each (pong only if L > 1)
 template <typename T>
 int wx_dev_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const WxFilt &filt,
@@ -1049,11 +1076,28 @@ int wx_dev_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, c
             else wx_launch_level2d<T, false>(src, tmp, y, simg, mn, (int)m, (int)n, d, batch, filt, status, nstatus, st, copy,
                                              htree ? dact[(size_t)d] : nullptr, nact[(size_t)d]);
         };
-        if (!inverse && htree && (L == 1 || pong) && wx_level_tile_ok<T>((int)m, (int)n, L - 1, filt.F)) {
+        // levels whose nodes are at least 8 x 8 run as one tile pass each; a tree that goes deeper (a pyramid of full depth ends at
+        // 1 x 1) continues on the small nodes with the two-pass level, block by block: until round 4 such a tree took the two-pass
+        // level for EVERY level, the root's included -- four trips of the whole image (2-D idwtall: 8 % of the HBM peak)
+        // (a tile pass walks the whole image unless its nodes are at least a tile large: it pays while the nodes are, or while the
+        // decomposed nodes of the level cover at least half of the image)
+        int Lt = 0;
+        while (Lt < L && wx_level_tile_ok<T>((int)m, (int)n, Lt, filt.F) &&
+               (((m >> Lt) >= WX_TILE_CR && (n >> Lt) >= wx_tile_cc<T>()) ||
+                2 * (int64_t)nact[(size_t)Lt] * (m >> Lt) * (n >> Lt) >= mn))
+            ++Lt;
+        auto level2 = [&](const T *src, int64_t simg, T *dstb, T *interm, int d, bool inv) {
+            if (nact[(size_t)d] == 0) return;
+            if (inv) wx_launch_level2d<T, true>(src, interm, dstb, simg, mn, (int)m, (int)n, d, batch, filt, status, nstatus, st, 0,
+                                                dact[(size_t)d], nact[(size_t)d]);
+            else wx_launch_level2d<T, false>(src, interm, dstb, simg, mn, (int)m, (int)n, d, batch, filt, status, nstatus, st, 0,
+                                             dact[(size_t)d], nact[(size_t)d]);
+        };
+        if (!inverse && htree && (L == 1 || pong) && Lt >= 1) {
             // one pass per level: a level reads its nodes from the scratch image of its parity (the root from x),
             // sends the children that are decomposed further to the other scratch image and the leaves to y
             T *sc[2] = {tmp, pong};
-            for (int d = 0; d < L; ++d) {
+            for (int d = 0; d < Lt; ++d) {
                 if (nact[(size_t)d] == 0) continue;
                 WxTileTree tt;
                 tt.dst_int = sc[(d + 1) & 1]; tt.int_img = mn;
@@ -1063,15 +1107,26 @@ int wx_dev_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, c
                                              filt, st, tt))
                     return wx_set_error(WX_EHIP, "2-D tile level failed to launch");
             }
+            // the nodes of depth Lt that are decomposed further sit in sc[Lt & 1]: the first small level takes them from there
+            // into y (the other scratch image is its intermediate), the rest run in place on y
+            for (int d = Lt; d < L; ++d) level2(d == Lt ? (const T *)sc[Lt & 1] : (const T *)y, mn, y, sc[(Lt + 1) & 1], d, false);
             WX_HIP_CHECK(hipGetLastError());
             return WX_OK;
         }
-        if (inverse && htree && (L == 1 || pong) && wx_level_tile_ok<T>((int)m, (int)n, L - 1, filt.F)) {
+        if (inverse && htree && (L == 1 || pong) && Lt >= 1) {
             // the mirror image: a level takes the children that were rebuilt one level earlier from the scratch
             // image of their parity and the leaves from x, and writes the parents into the other scratch image (the
             // root into y)
             T *sc[2] = {tmp, pong};
-            for (int d = L - 1; d >= 0; --d) {
+            if (Lt < L && nact[(size_t)Lt]) {
+                // the small nodes first, in place in sc[Lt & 1]: the blocks of depth Lt that are decomposed come over from x
+                T *B = sc[Lt & 1];
+                const int64_t tot = (int64_t)(m >> Lt) * (n >> Lt) * nact[(size_t)Lt] * batch;
+                hipLaunchKernelGGL(k_copy_blocks2d<T>, dim3(wx_grid2(tot)), dim3(256), 0, st, x, B, in_img, mn, (int)m, Lt, batch,
+                                   dact[(size_t)Lt], nact[(size_t)Lt], (int)n);
+                for (int d = L - 1; d >= Lt; --d) level2(B, mn, B, sc[(Lt + 1) & 1], d, true);
+            }
+            for (int d = Lt - 1; d >= 0; --d) {
                 if (nact[(size_t)d] == 0) continue;
                 WxTileTree tt;
                 tt.int_img = mn;
