@@ -152,6 +152,13 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     T *dy = (T *)io.out(y, sizeof(T) * n * batch);
     if ((batch && n) && (!dx || !dy)) return io.finish(WX_EHIP);
     const int force = wx_force_generic();
+    if constexpr (sizeof(T) == 4) {
+        // Float32 full trees of 64 .. 2048 samples: the interleaved lattice kernels where they apply (wx_lattice_sg32.h)
+        if (small && tr.full && tr.Leff >= 1 && batch && dx != dy && !wx_skip_register_kernels()) {
+            const int r = wx_lattice_f32(INVERSE, (const float *)dx, (float *)dy, n, tr.Leff, batch, n, filt, st);
+            if (r) return io.finish(r < 0 ? r : WX_OK);
+        }
+    }
     if (small && tr.Leff >= 1 && batch && dx != dy) {
         static const bool lane_off = getenv("WX_LANETREE") && atoi(getenv("WX_LANETREE")) == 0;
         if (!lane_off && (n <= 64 || (n <= 128 && sizeof(T) == 4))) {

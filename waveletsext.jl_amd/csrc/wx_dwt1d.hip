@@ -44,6 +44,31 @@ template <typename T> static bool wx_lattice_tree_applicable_T(int64_t n, const 
 }
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
+
+// A full tree of depth L <= 12 in the form the tree-driven kernels take: 2^L - 1 status bytes of one.  One constant buffer
+// per device, made at the first use.  (Full trees that no dedicated kernel takes -- Float32 signals of 1024 and 2048 samples,
+// shallow trees on 2048 -- run 1.5-2 x faster on the tree-driven lattice than on the fused LDS kernels.)
+static const uint8_t *wx_full_tree_ones(hipStream_t st)
+{
+    static std::mutex mu;
+    static uint8_t *ones[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ones[dev]) {
+        uint8_t *p = nullptr;
+        if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
+        if (hipMemsetAsync(p, 1, 4096, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        ones[dev] = p;
+    }
+    return ones[dev];
+}
+static bool wx_full_as_tree()
+{
+    static const bool off = getenv("WX_FULL_AS_TREE") && atoi(getenv("WX_FULL_AS_TREE")) == 0;
+    return !off;
+}
 
 // ------------------------------------------------------------------------------------------
 // generic (one level per launch)
@@ -1373,6 +1398,10 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
     const bool noreg = wx_skip_register_kernels();      // test hook: fused LDS kernels only
     if constexpr (sizeof(T) == 4) {
         // very short Float32 signals, full tree (the columns of small images arrive here too): one lane per signal (wx_lanetree.h)
+        if (!force_generic && !noreg && !status && n <= 128) {
+            const int r = wx_lattice_f32(false, (const float *)x, (float *)y, n, L, batch, n, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
         if (!force_generic && !noreg && !status && wx_small_tree_wanted<T>(n, filt.F, false, false) && n <= 128 && x != y) {
             WxLaneTree lt;
             for (int i = 0; i < 8; ++i) lt.bits[i] = 0xffffffffu;
@@ -1476,6 +1505,15 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
         if (!force_generic && !noreg && status) {
             const int r = wx_lattice_tree_T<T>(false, x, y, n, L, batch, n, 0, filt, status, nstatus, st);
             if (r) return r < 0 ? r : WX_OK;
+        }
+        // a full tree nothing above took, as a tree
+        if (!force_generic && !noreg && !status && L <= 12 && n >= 1024 && n <= 4096 && wx_full_as_tree() &&
+            wx_lattice_tree_applicable_T<T>(n, filt)) {
+            const uint8_t *ones = wx_full_tree_ones(st);
+            if (ones) {
+                const int r = wx_lattice_tree_T<T>(false, x, y, n, L, batch, n, 0, filt, ones, ((int64_t)1 << L) - 1, st);
+                if (r) return r < 0 ? r : WX_OK;
+            }
         }
     }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))
@@ -1877,6 +1915,10 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
     }
     const bool noreg = wx_skip_register_kernels();
     if constexpr (sizeof(T) == 4) {
+        if (!force_generic && !noreg && !status && !colmap && n <= 128) {
+            const int r = wx_lattice_f32(true, (const float *)xw, (float *)xh, n, L, batch, is, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
         if (!force_generic && !noreg && !status && !colmap && is == n && wx_small_tree_wanted<T>(n, filt.F, false, false) && n <= 128 && xw != xh) {
             WxLaneTree lt;
             for (int i = 0; i < 8; ++i) lt.bits[i] = 0xffffffffu;
@@ -1983,6 +2025,14 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
             const int r = wx_lattice_tree_T<T>(true, xw, xh, n, L, batch, is, colmap ? n : 0, filt, status,
                                               nstatus, st);
             if (r) return r < 0 ? r : WX_OK;
+        }
+        if (!force_generic && !noreg && !status && !colmap && L <= 12 && n >= 1024 && n <= 4096 && wx_full_as_tree() &&
+            wx_lattice_tree_applicable_T<T>(n, filt)) {
+            const uint8_t *ones = wx_full_tree_ones(st);
+            if (ones) {
+                const int r = wx_lattice_tree_T<T>(true, xw, xh, n, L, batch, is, 0, filt, ones, ((int64_t)1 << L) - 1, st);
+                if (r) return r < 0 ? r : WX_OK;
+            }
         }
     }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))

@@ -15,6 +15,7 @@
 // Images are column-major (m rows contiguous).  Consecutive lanes always walk dim 1 so every
 // global access is coalesced; a level is two passes (columns, rows) through a scratch image.
 #include "wx_common.h"
+#include <type_traits>
 #include "wx_kernels.h"
 #include "wx_host.h"
 #include <cstdlib>
@@ -205,12 +206,59 @@ __global__ __launch_bounds__(256) void k_gather_leaves2d(const T *__restrict__ X
 // ------------------------------------------------------------------------------------------
 template <typename T, int V> struct alignas(sizeof(T) * V) WxRowVec { T e[V]; };
 
+// NLV packet levels of a block of 16 samples held in registers (the block is a whole node of 16 samples, so every periodic wrap
+// stays inside it; all indices are compile-time after unrolling).  Same sums in the same tap order as the per-level code of
+// k_rows_fused below (dwt_step! / idwt_step!, dwt/dwt_one_level.jl:94-105, 207-221).
+template <typename T, int F, int NLV, bool INVERSE>
+__device__ __forceinline__ void wx_reg_levels16(T (&x)[16], const T (&q)[F])
+{
+#pragma unroll
+    for (int s = 0; s < NLV; ++s) {
+        const int l = INVERSE ? NLV - 1 - s : s;
+        const int M = 16 >> l, HM = M >> 1;
+#pragma unroll
+        for (int j = 0; j < (1 << l); ++j) {
+            const int b = j * M;
+            T r[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) r[e] = e < M ? x[b + (e < M ? e : 0)] : (T)0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < HM) {
+                    if (!INVERSE) {
+                        T a = 0, d = 0;
+#pragma unroll
+                        for (int k = 0; k < F; ++k) {
+                            a = fma(q[k], r[(2 * i + k) % M], a);
+                            d = fma((k & 1) ? -q[k] : q[k], r[((2 * i + 1 - k) % M + M) % M], d);
+                        }
+                        x[b + i] = a;
+                        x[b + HM + i] = d;
+                    } else {
+                        T v0 = 0, v1 = 0;
+#pragma unroll
+                        for (int m = 0; m < F / 2; ++m) {
+                            const T av = r[((i - m) % HM + HM) % HM], dv = r[HM + (i + m) % HM];
+                            v0 = fma(q[2 * m], av, v0);
+                            v0 = fma(-q[2 * m + 1], dv, v0);
+                            v1 = fma(q[2 * m + 1], av, v1);
+                            v1 = fma(q[2 * m], dv, v1);
+                        }
+                        x[b + 2 * i] = v0;
+                        x[b + 2 * i + 1] = v1;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // V = rows per lane (16-byte LDS / HBM accesses when V * sizeof(T) = 16): the filter work per LDS
 // instruction grows V-fold, which is what bounds this kernel (LDS instruction issue, not bytes).
 template <typename T, int F, bool INVERSE, int V, int KI = 0>
 __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, T *__restrict__ dst,
                                                      int64_t src_img, int64_t dst_img, int m, int log2n, int L,
-                                                     int64_t nimg, WxFilt filt, int log2R, int S)
+                                                     int64_t nimg, WxFilt filt, int log2R, int S, int xcd, int regl)
 {
     // KI == 0: two LDS images, a level reads one and writes the other.  KI > 0: one LDS image, every lane keeps the
     // results of its (at most KI) items in registers across a barrier and writes them back in place -- half the
@@ -297,7 +345,44 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
         }
     };
 
-    for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    // regl: the levels on nodes of at most 16 samples (depths log2n - 4 ... L - 1) run in registers -- a lane takes whole blocks of
+    // 16 columns of its rows through all of them between one LDS read and one LDS write, in place (wx_reg_levels16); a level
+    // through LDS costs 2F / 4 reads and a write per sample.  Full-depth rows of 256 columns: 8 LDS levels -> 4 + 1.
+    const int dreg = log2n - 4;
+    const int nreg = (regl && log2n >= 4 && L > dreg) ? L - dreg : 0;
+    const int Llds = L - nreg;
+    auto reg_phase = [&](TV *a, auto nlv_c) {
+        constexpr int NLV = decltype(nlv_c)::value;
+        for (int blk = g0; blk < (n >> 4); blk += gstep) {
+            // one row at a time (element accesses: with the lanes 16 bytes apart they cost the LDS what the vector accesses
+            // cost, and 16 samples + their results are all a lane holds)
+            T *p = reinterpret_cast<T *>(a + (size_t)(blk << 4) * SV);
+#pragma unroll 1
+            for (int c = 0; c < V; ++c) {
+                T x[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) x[e] = p[e * SV * V + c];
+                wx_reg_levels16<T, F, NLV, INVERSE>(x, q);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) p[e * SV * V + c] = x[e];
+            }
+        }
+    };
+    auto reg_levels = [&](TV *a) {
+        switch (nreg) {
+        case 1: reg_phase(a, std::integral_constant<int, 1>{}); break;
+        case 2: reg_phase(a, std::integral_constant<int, 2>{}); break;
+        case 3: reg_phase(a, std::integral_constant<int, 3>{}); break;
+        default: reg_phase(a, std::integral_constant<int, 4>{}); break;
+        }
+        __syncthreads();
+    };
+    // xcd: workgroups are dealt to the 8 XCDs in turn, and neighbouring strips share 128-byte lines (a strip's run per column is
+    // R elements): every XCD takes a contiguous eighth of the strips, so that the neighbours meet in one L2
+    const int64_t per_x = (nstrips + 7) >> 3;
+    for (int64_t s0 = blockIdx.x; s0 < (xcd ? per_x * 8 : nstrips); s0 += gridDim.x) {
+        const int64_t sidx = xcd ? (s0 & 7) * per_x + (s0 >> 3) : s0;
+        if (sidx >= nstrips) continue;                  // (uniform in the workgroup, no barrier skipped: the body is whole)
         const int64_t img = sidx / strips_per_img;
         const int r0 = (int)(sidx - img * strips_per_img) << log2R;
         const T *sp = src + img * src_img + r0 + r * V;
@@ -317,8 +402,9 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
             for (; c < n; c += gstep) a[c * SV] = *reinterpret_cast<const TV *>(sp + (int64_t)c * m);
         }
         __syncthreads();
-        for (int s = 0; s < L; ++s) {
-            const int d = INVERSE ? L - 1 - s : s;
+        if (INVERSE && nreg) reg_levels(a);
+        for (int s = 0; s < Llds; ++s) {
+            const int d = INVERSE ? Llds - 1 - s : s;
             const int lnp = log2n - d;               // log2(node length)
             const int np = 1 << lnp, h = np >> 1;
             if (h >= 2) {
@@ -372,6 +458,7 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
             __syncthreads();
             if (!INPLACE) { TV *tmp = a; a = b; b = tmp; }
         }
+        if (!INVERSE && nreg) reg_levels(a);
         if (row_ok)
             for (int c = g0; c < n; c += gstep) *reinterpret_cast<TV *>(dp + (int64_t)c * m) = a[c * SV];
         __syncthreads();
@@ -418,7 +505,9 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
     const bool vec = m % VW == 0 && R % VW == 0 && S % VW == 0 && src_img % VW == 0 && dst_img % VW == 0 &&
                      ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) && filt.F <= 12 &&   // 2F-tap window of vectors in registers
                      !getenv("WX_ROWS_SCALAR");
-    void (*kern)(const T *, T *, int64_t, int64_t, int, int, int, int64_t, WxFilt, int, int) = nullptr;
+    void (*kern)(const T *, T *, int64_t, int64_t, int, int, int, int64_t, WxFilt, int, int, int, int) = nullptr;
+    static const int xcd_env = getenv("WX_ROWS_XCD") ? atoi(getenv("WX_ROWS_XCD")) : 1;
+    static const int regl_env = getenv("WX_ROWS_REGL") ? atoi(getenv("WX_ROWS_REGL")) : 1;
     // in place (one LDS image, two workgroups of 1024 lanes per CU) when a lane has at most two items per level
     static const int inplace_env = getenv("WX_ROWS_INPLACE") ? atoi(getenv("WX_ROWS_INPLACE")) : 1;
     // (two workgroups of 512 lanes: the same 16 wavefronts per CU as one workgroup of 1024 with two LDS images,
@@ -453,7 +542,10 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
     int log2R = 0;
     while ((1 << (log2R + 1)) <= R) ++log2R;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), lds, st, src, dst, src_img, dst_img, (int)m, log2n, L, batch,
-                       filt, log2R, S);
+                       filt, log2R, S, xcd_env,
+                       // measured (db4, full depth, 1 GiB): rows of 256 Float64 columns 1.11 -> 0.97 ms, 1024 Float32 columns 1.89 -> 1.65 ms;
+                       // short Float32 rows lose (64 columns 1.02 -> 1.34 ms: the kernel is as much FMA- as LDS-bound there)
+                       (regl_env && (sizeof(T) == 8 || n >= 1024)) ? 1 : 0);
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }

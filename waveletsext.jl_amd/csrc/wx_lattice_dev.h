@@ -1415,17 +1415,18 @@ __device__ __forceinline__ void lat_t2i(double (&bb)[64], double (&a)[64], unsig
 }
 
 // forward wpt, leaves only: Le = L + SH in 6 .. 12 (the last level runs in layout C)
-template <int NS, int WPE, int SH>
+// (IO = float: Float32 signals -- the loads widen, the stores round once, as in k_lat_wpt_f64<NS, WPE, float>)
+template <int NS, int WPE, int SH, typename IO = double>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_g_f64(
-    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw)
+    const IO *__restrict__ x, IO *__restrict__ y, int L, int last_sig, WxLatW cw)
 {
     __shared__ double lds[WX_LAT_LDS];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
     const int sig0 = min((int)blockIdx.x << SH, last_sig);
     const int64_t off = (int64_t)sig0 * (4096 >> SH);
-    const double *xs = x + off;
-    double *ys = y + off;
+    const IO *xs = x + off;
+    IO *ys = y + off;
     const WxLat &cf = cw.c;
     double c[64];
     if constexpr (SH < 2) {
@@ -1469,16 +1470,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 }
 
 // inverse wpt: leaves of signal s at xw + s in_stride (dense array or the last column of packet tables)
-template <int NS, int WPE, int SH>
+template <int NS, int WPE, int SH, typename IO = double>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_g_f64(
-    const double *__restrict__ xw, double *__restrict__ y, int L, int last_sig, unsigned in_stride, WxLatW cw)
+    const IO *__restrict__ xw, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, WxLatW cw)
 {
     __shared__ double lds[WX_LAT_LDS];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
     const int sig0 = min((int)blockIdx.x << SH, last_sig);
-    const double *xs = xw + (int64_t)sig0 * in_stride;
-    double *ys = y + (int64_t)sig0 * (4096 >> SH);
+    const IO *xs = xw + (int64_t)sig0 * in_stride;
+    IO *ys = y + (int64_t)sig0 * (4096 >> SH);
     const WxLat &cf = cw.c;
     const int Le = L + SH;
     double c[64];

@@ -5,13 +5,31 @@
 // (the reference computes in Float32 throughout: the difference is inside the 1e-5 tolerance of the Float32 path).
 #include "wx_lattice_dev.h"
 
+#define WX_G32(k) int wx_lattice_g32_##k(bool, const float *, float *, int64_t, int, int64_t, int64_t, const WxFilt &, hipStream_t);
+WX_G32(1) WX_G32(2) WX_G32(3) WX_G32(4) WX_G32(5) WX_G32(6)
+#undef WX_G32
+
 // 0 = not applicable, 1 = launched, < 0 = error
 int wx_lattice_f32(bool inverse, const float *x, float *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt,
                    hipStream_t st)
 {
     static const bool off = (getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0) ||
                             (getenv("WX_LATTICE_F32") && atoi(getenv("WX_LATTICE_F32")) == 0);
-    if (off || n != 4096 || L < 6 || L > 12 || filt.F < 4 || batch <= 0 || batch > 0x7fffffff) return 0;
+    if (off) return 0;
+    // shorter signals: 2^SH of them per wavefront (wx_lattice_sg32.h)
+    static const bool off_g = getenv("WX_LATTICE_G32") && atoi(getenv("WX_LATTICE_G32")) == 0;
+    if (n != 4096 && !off_g) {
+        switch (n) {
+        case 2048: return wx_lattice_g32_1(inverse, x, y, n, L, batch, in_stride, filt, st);
+        case 1024: return wx_lattice_g32_2(inverse, x, y, n, L, batch, in_stride, filt, st);
+        case 512: return wx_lattice_g32_3(inverse, x, y, n, L, batch, in_stride, filt, st);
+        case 256: return wx_lattice_g32_4(inverse, x, y, n, L, batch, in_stride, filt, st);
+        case 128: return wx_lattice_g32_5(inverse, x, y, n, L, batch, in_stride, filt, st);
+        case 64: return wx_lattice_g32_6(inverse, x, y, n, L, batch, in_stride, filt, st);
+        default: return 0;
+        }
+    }
+    if (n != 4096 || L < 6 || L > 12 || filt.F < 4 || batch <= 0 || batch > 0x7fffffff) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return 0;
     if (inverse && (in_stride & 3)) return 0;
     WxLat cf;
