@@ -652,8 +652,12 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
         NS = sum(1 << min(j, d) for j in range(L + 1))
         NN = sum((1 << min(j, d)) << j for j in range(L + 1))
         # parents read once, every column written once, one cost per node (the costs of nodes of <= 256 samples
-        # come out of the level that creates them; only the top depths are read a second time)
-        fb = es * B * (n * (NS - (1 << min(L, d))) + n * NS + NN)
+        # come out of the level that creates them; only the top depths are read a second time).  Below depth d only half
+        # of a depth's columns have children: a node of shift t has the children of shifts t and t + 2^j, and depth j + 1
+        # keeps the multiples of 2^(j+1-d) (SIWT.jl:119-131) -- until round 4 every column was counted as read and the
+        # PMC traffic came out BELOW these bytes (0.86 x; profiles/r04_siwt_bytes.txt has the counters)
+        RC = sum((1 << j) if j < d else max(1, (1 << d) >> 1) for j in range(L))
+        fb = es * B * (n * RC + n * NS + NN)
         W.info = dict(fwd_bytes=fb, inv_bytes=es * B * (2 * NN + 3 * n * L) + 2 * NN * B,
                       fwd_flops=4.0 * F * (n / 2) * (NS - 1) * B, samples=n * B, bound="hbm")
         W.keep = (x,)
