@@ -1760,7 +1760,8 @@ template int wx_dev_idwt_long<float>(const float *, float *, int64_t, int, int64
 template <typename T> bool wx_wpt_long_tree_ok(int64_t n, const WxFilt &filt)
 {
     bool lattice;
-    return n >= 16384 && wx_dwt_long_plan<T>(n, filt, &lattice) == 4096 && lattice && n <= 65536;
+    static const int64_t minn = getenv("WX_LONG_TREE_MINN") ? atoll(getenv("WX_LONG_TREE_MINN")) : 16384;
+    return n >= minn && wx_dwt_long_plan<T>(n, filt, &lattice) == 4096 && lattice && n <= 65536;
 }
 template bool wx_wpt_long_tree_ok<double>(int64_t, const WxFilt &);
 template bool wx_wpt_long_tree_ok<float>(int64_t, const WxFilt &);
