@@ -1760,7 +1760,7 @@ template int wx_dev_idwt_long<float>(const float *, float *, int64_t, int, int64
 template <typename T> bool wx_wpt_long_tree_ok(int64_t n, const WxFilt &filt)
 {
     bool lattice;
-    static const int64_t minn = getenv("WX_LONG_TREE_MINN") ? atoll(getenv("WX_LONG_TREE_MINN")) : 16384;
+    static const int64_t minn = getenv("WX_LONG_TREE_MINN") ? atoll(getenv("WX_LONG_TREE_MINN")) : 8192;     // 8192: random trees 0.30 / 0.22 -> 0.40 / 0.39 of the HBM peak against the fused LDS kernel
     return n >= minn && wx_dwt_long_plan<T>(n, filt, &lattice) == 4096 && lattice && n <= 65536;
 }
 template bool wx_wpt_long_tree_ok<double>(int64_t, const WxFilt &);

@@ -204,7 +204,19 @@ __global__ __launch_bounds__(256) void k_gather_leaves2d(const T *__restrict__ X
 // and the HBM side moves R contiguous elements per column.  4 image passes in total instead of 4
 // per level.  (Rounding differs from the per-level order by O(eps); inside the 1e-5 / 1e-10 budget.)
 // ------------------------------------------------------------------------------------------
-template <typename T, int V> struct alignas(sizeof(T) * V) WxRowVec { T e[V]; };
+// V rows of one column as a hardware vector: element access e[i] as before, and whole-vector arithmetic that stays a vector
+// operation down to the ISA (Float32: v_pk_fma_f32 -- built from four scalars the compiler takes a vector fma apart again)
+template <typename T, int V> struct alignas(sizeof(T) * V) WxRowVec {
+    typedef T vt __attribute__((ext_vector_type(V)));
+    vt e;
+};
+
+// acc += q * w on the V rows of a vector; Float32 rows in pairs (v_pk_fma_f32: the row pass is as much FMA- as LDS-bound)
+template <typename T, int V> __device__ __forceinline__ void wx_vfma(WxRowVec<T, V> &acc, T q, const WxRowVec<T, V> &w)
+{
+    typedef typename WxRowVec<T, V>::vt vt;
+    acc.e = __builtin_elementwise_fma((vt)(q), w.e, acc.e);
+}
 
 // NLV packet levels of a block of 16 samples held in registers (the block is a whole node of 16 samples, so every periodic wrap
 // stays inside it; all indices are compile-time after unrolling).  Same sums in the same tap order as the per-level code of
@@ -255,8 +267,10 @@ __device__ __forceinline__ void wx_reg_levels16(T (&x)[16], const T (&q)[F])
 
 // V = rows per lane (16-byte LDS / HBM accesses when V * sizeof(T) = 16): the filter work per LDS
 // instruction grows V-fold, which is what bounds this kernel (LDS instruction issue, not bytes).
-template <typename T, int F, bool INVERSE, int V, int KI = 0>
-__global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, T *__restrict__ dst,
+// P4 (with NT <= 512 lanes, i.e. a 256-register budget): an item is FOUR output pairs of a node -- a window of 2F + 4 samples for 8
+// outputs (2.5 LDS reads per output instead of 4; inverse F/2 + 3 pairs of children for 8 parent samples: 1.75 instead of 2.5).
+template <typename T, int F, bool INVERSE, int V, int KI = 0, int NT = 1024, bool P4 = false>
+__global__ __launch_bounds__(NT) void k_rows_fused(const T *__restrict__ src, T *__restrict__ dst,
                                                      int64_t src_img, int64_t dst_img, int m, int log2n, int L,
                                                      int64_t nimg, WxFilt filt, int log2R, int S, int xcd, int regl)
 {
@@ -299,13 +313,10 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
 #pragma unroll
             for (int k = 0; k < F; ++k) {
                 const T qd = (k & 1) ? -q[k] : q[k];
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    res[0].e[e] = fma(q[k], w[F - 2 + k].e[e], res[0].e[e]);
-                    res[1].e[e] = fma(q[k], w[F + k].e[e], res[1].e[e]);
-                    res[2].e[e] = fma(qd, w[F - 1 - k].e[e], res[2].e[e]);
-                    res[3].e[e] = fma(qd, w[F + 1 - k].e[e], res[3].e[e]);
-                }
+                wx_vfma<T, V>(res[0], q[k], w[F - 2 + k]);
+                wx_vfma<T, V>(res[1], q[k], w[F + k]);
+                wx_vfma<T, V>(res[2], qd, w[F - 1 - k]);
+                wx_vfma<T, V>(res[3], qd, w[F + 1 - k]);
             }
         } else {
             // parent samples 4t..4t+3 (k = 2t, 2t+1) from a[k-m], d[k+m]
@@ -318,17 +329,14 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
             }
 #pragma unroll
             for (int mm = 0; mm < HF; ++mm) {
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    res[0].e[e] = fma(q[2 * mm], aw[HF - 1 - mm].e[e], res[0].e[e]);
-                    res[0].e[e] = fma(-q[2 * mm + 1], dw[mm].e[e], res[0].e[e]);
-                    res[1].e[e] = fma(q[2 * mm + 1], aw[HF - 1 - mm].e[e], res[1].e[e]);
-                    res[1].e[e] = fma(q[2 * mm], dw[mm].e[e], res[1].e[e]);
-                    res[2].e[e] = fma(q[2 * mm], aw[HF - mm].e[e], res[2].e[e]);
-                    res[2].e[e] = fma(-q[2 * mm + 1], dw[1 + mm].e[e], res[2].e[e]);
-                    res[3].e[e] = fma(q[2 * mm + 1], aw[HF - mm].e[e], res[3].e[e]);
-                    res[3].e[e] = fma(q[2 * mm], dw[1 + mm].e[e], res[3].e[e]);
-                }
+                wx_vfma<T, V>(res[0], q[2 * mm], aw[HF - 1 - mm]);
+                wx_vfma<T, V>(res[0], -q[2 * mm + 1], dw[mm]);
+                wx_vfma<T, V>(res[1], q[2 * mm + 1], aw[HF - 1 - mm]);
+                wx_vfma<T, V>(res[1], q[2 * mm], dw[mm]);
+                wx_vfma<T, V>(res[2], q[2 * mm], aw[HF - mm]);
+                wx_vfma<T, V>(res[2], -q[2 * mm + 1], dw[1 + mm]);
+                wx_vfma<T, V>(res[3], q[2 * mm + 1], aw[HF - mm]);
+                wx_vfma<T, V>(res[3], q[2 * mm], dw[1 + mm]);
             }
         }
     };
@@ -345,6 +353,61 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
         }
     };
 
+    auto compute4 = [&](const TV *a, int lnp, int it, TV (&res)[8]) {
+        const int np = 1 << lnp, h = np >> 1;
+        const int j = it >> (lnp - 3), t = it & ((h >> 2) - 1);
+        const TV *v = a + (size_t)(j << lnp) * SV;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < V; ++e) res[u].e[e] = 0;
+        if (!INVERSE) {
+            // outputs i = 4t .. 4t+3: a[i] needs v[2i .. 2i+F-1], d[i] needs v[2i+2-F .. 2i+1]: window v[8t+2-F .. 8t+F+5]
+            TV w[2 * F + 4];
+#pragma unroll
+            for (int k = 0; k < 2 * F + 4; ++k) w[k] = v[((8 * t + 2 - F + k) & (np - 1)) * SV];
+#pragma unroll
+            for (int k = 0; k < F; ++k) {
+                const T qd = (k & 1) ? -q[k] : q[k];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    wx_vfma<T, V>(res[u], q[k], w[F - 2 + 2 * u + k]);
+                    wx_vfma<T, V>(res[4 + u], qd, w[F - 1 + 2 * u - k]);
+                }
+            }
+        } else {
+            // parent samples 8t .. 8t+7 = pairs kk = 4t + u from a[kk-m], d[kk+m]
+            constexpr int HF = F / 2;
+            TV aw[HF + 3], dw[HF + 3];
+#pragma unroll
+            for (int k = 0; k < HF + 3; ++k) {
+                aw[k] = v[((4 * t + 1 - HF + k) & (h - 1)) * SV];        // a[4t+1-HF .. 4t+3]
+                dw[k] = v[(h + ((4 * t + k) & (h - 1))) * SV];           // d[4t .. 4t+HF+2]
+            }
+#pragma unroll
+            for (int mm = 0; mm < HF; ++mm) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    wx_vfma<T, V>(res[2 * u], q[2 * mm], aw[HF - 1 + u - mm]);
+                    wx_vfma<T, V>(res[2 * u], -q[2 * mm + 1], dw[u + mm]);
+                    wx_vfma<T, V>(res[2 * u + 1], q[2 * mm + 1], aw[HF - 1 + u - mm]);
+                    wx_vfma<T, V>(res[2 * u + 1], q[2 * mm], dw[u + mm]);
+                }
+            }
+        }
+    };
+    auto store4 = [&](TV *b, int lnp, int it, const TV (&res)[8]) {
+        const int np = 1 << lnp, h = np >> 1;
+        const int j = it >> (lnp - 3), t = it & ((h >> 2) - 1);
+        TV *o = b + (size_t)(j << lnp) * SV;
+        if (!INVERSE) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { o[(4 * t + u) * SV] = res[u]; o[(h + 4 * t + u) * SV] = res[4 + u]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[(8 * t + u) * SV] = res[u];
+        }
+    };
     // regl: the levels on nodes of at most 16 samples (depths log2n - 4 ... L - 1) run in registers -- a lane takes whole blocks of
     // 16 columns of its rows through all of them between one LDS read and one LDS write, in place (wx_reg_levels16); a level
     // through LDS costs 2F / 4 reads and a write per sample.  Full-depth rows of 256 columns: 8 LDS levels -> 4 + 1.
@@ -420,6 +483,12 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
                     for (int ki = 0; ki < KM; ++ki) {
                         const int it = g0 + ki * gstep;
                         if (it < (n >> 2)) store(b, lnp, it, res[ki]);
+                    }
+                } else if (P4 && h >= 4) {
+                    for (int it = g0; it < (n >> 3); it += gstep) {
+                        TV res[8];
+                        compute4(a, lnp, it, res);
+                        store4(b, lnp, it, res);
                     }
                 } else {
                     for (int it = g0; it < (n >> 2); it += gstep) {
@@ -518,12 +587,19 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
     const bool inplace = inplace_env && vec && filt.F <= 8 && lanes_per_col <= nt_ip && items_per_lane <= 2 &&
                          (size_t)n * S * sizeof(T) <= 80 * 1024 && (size_t)n * S * sizeof(T) > 40 * 1024;
     if (inplace) lds = (size_t)n * S * sizeof(T);
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    const int nt = inplace ? nt_ip : (per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024));
+    // four output pairs per item where the workgroup leaves a lane 256 registers (two LDS images, <= 512 lanes)
+    static const int p4_env = getenv("WX_ROWS_P4") ? atoi(getenv("WX_ROWS_P4")) : 0;    // measured slower (f32 256 columns 1.13 -> 1.33 ms): off
+    const bool p4 = p4_env && vec && !inplace && nt <= 512 && filt.F <= 8 && n >= 8;
     switch (filt.F) {
 #define WX_CASE(FF) case FF: kern = vec ? k_rows_fused<T, FF, INVERSE, VW> : k_rows_fused<T, FF, INVERSE, 1>; break;
         WX_CASE(10) WX_CASE(12) WX_CASE(14) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
 #define WX_CASE(FF) case FF: kern = inplace ? (items_per_lane <= 1 ? k_rows_fused<T, FF, INVERSE, VW, 1> : k_rows_fused<T, FF, INVERSE, VW, 2>) \
-                                   : (vec ? k_rows_fused<T, FF, INVERSE, VW> : k_rows_fused<T, FF, INVERSE, 1>); break;
+                                   : (p4 ? k_rows_fused<T, FF, INVERSE, VW, 0, 512, true>                                                         \
+                                         : (vec ? k_rows_fused<T, FF, INVERSE, VW> : k_rows_fused<T, FF, INVERSE, 1>)); break;
         WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8)
 #undef WX_CASE
     default: return wx_set_error(WX_EUNSUPPORTED, "no fused row kernel for this filter length");
@@ -534,9 +610,6 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
     int log2n = 0;
     while (((int64_t)1 << (log2n + 1)) <= n) ++log2n;
     const int64_t nstrips = batch * ((m + R - 1) / R);
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu < 1) per_cu = 1;
-    const int nt = inplace ? nt_ip : (per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024));
     int64_t grid = (int64_t)256 * per_cu;
     if (grid > nstrips) grid = nstrips;
     int log2R = 0;
