@@ -24,6 +24,7 @@ Prints ONE JSON line (rank 0).
 """
 import argparse
 import ctypes
+import gc
 import json
 import os
 import sys
@@ -712,10 +713,22 @@ def also_block(wx, torch, dev, a, dist, steps=10):
                 W.step(warm)
             torch.cuda.synchronize(dev)
             err = W.check()
+            # the check's temporaries reshuffle the caching allocator's blocks: one more untimed step, or the first timed
+            # launch can carry a 20 ms hipMalloc (seen in round 4 as also.target.inv avg 2.9 ms, median 0.80 ms)
+            W.step(warm)
+            torch.cuda.synchronize(dev)
             legs = Legs(torch)
+            n_alloc0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+            gc.collect()
+            gc.disable()             # (round 4: also.target.inv showed one 22-97 ms launch in ten -- the collector, not the allocator)
             for _ in range(steps):
                 W.step(legs)
             torch.cuda.synchronize(dev)
+            gc.enable()
+            n_alloc = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - n_alloc0
+            if os.environ.get("WX_BENCH_DEBUG"):
+                sys.stderr.write("also.%s: device allocations inside the timed steps: %d; inv launches (ms, in order): %s\n" % (
+                    name, n_alloc, " ".join("%.2f" % a_.elapsed_time(b_) for a_, b_ in legs.ev["inv"])))
             info = W.info
             per_step = {k: len(legs.ev[k]) // steps for k in ("fwd", "inv")}
             fwd = sum(legs.ms("fwd")) / steps          # all forward launches of a step (one, or one per resident chunk)
@@ -727,6 +740,11 @@ def also_block(wx, torch, dev, a, dist, steps=10):
                               "achieved_GBs": fb / fwd / 1e6, "frac": fb / fwd / 1e6 / HBM_PEAK_GBS}
                 rec["inv"] = {"kernel": w.get("inv_kernel"), "avg_launch_ms": inv, "algorithmic_bytes": ib,
                               "achieved_GBs": ib / inv / 1e6, "frac": ib / inv / 1e6 / HBM_PEAK_GBS}
+                for leg in ("fwd", "inv"):               # one slow launch (an allocation inside the region) shows as avg >> median
+                    t = legs.ms(leg)
+                    rec[leg]["median_launch_ms"] = t[len(t) // 2]
+                    rec[leg]["max_launch_ms"] = t[-1]
+                    rec[leg]["launches_per_step"] = per_step[leg]
             else:
                 fl = float(info["fwd_flops"])
                 rec["fwd"] = {"kernel": w["kernel"], "avg_launch_ms": fwd, "algorithmic_flops": fl,
@@ -841,12 +859,15 @@ def main():
 
     def timed(step_fn):
         legs = Legs(torch)
+        gc.collect()
+        gc.disable()                                     # a generation-2 collection between an event and its launch is a 20-100 ms leg
         sync()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step_fn(legs)
         sync()
         mine = time.perf_counter() - t0
+        gc.enable()
         per_rank = [mine]
         if world > 1:
             t = torch.zeros(world, dtype=torch.float64, device=red_dev)
