@@ -50,20 +50,20 @@ WORKLOADS = {
                     fwd_kernels=[("k_lat_wpt_f64<8, 2, double>", 1)],
                     desc="config 2's signals and filter through wptall+iwptall: 65536x4096 f64 db8 L=12 (the F = 16 lattice kernels)"),
     "tree_random": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=12, dtype="f64", tree="random:0.7:3",
-                        kernel="k_lat_wpt_treesc_f64<4, 2, 0>", inv_kernel="k_lat_iwpt_treesc_f64<4, 2, 0, false>",
-                        fwd_kernels=[("k_lat_wpt_treesc_f64<4, 2, 0>", 1)],
+                        kernel="k_lat_wpt_treesc_f64<4, 2, 0, double>", inv_kernel="k_lat_iwpt_treesc_f64<4, 2, 0, false, double>",
+                        fwd_kernels=[("k_lat_wpt_treesc_f64<4, 2, 0, double>", 1)],
                         desc="the target's batch along a tree, as bestbasistree output is used (DWT.jl:340-351, dwt_all.jl:152-225): "
                              "wptall+iwptall 65536x4096 f64 db4, random tree (every node split with probability 0.7, seed 3, depth 12)"),
     "tree_pyramid": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=12, dtype="f64", tree="pyramid",
-                         kernel="k_lat_wpt_treesc_f64<4, 2, 0>", inv_kernel="k_lat_iwpt_treesc_f64<4, 2, 0, false>",
-                         fwd_kernels=[("k_lat_wpt_treesc_f64<4, 2, 0>", 1)],
+                         kernel="k_lat_wpt_treesc_f64<4, 2, 0, double>", inv_kernel="k_lat_iwpt_treesc_f64<4, 2, 0, false, double>",
+                         fwd_kernels=[("k_lat_wpt_treesc_f64<4, 2, 0, double>", 1)],
                          desc="dwtall+idwtall as wptall+iwptall along maketree(4096, 12, :dwt): 65536x4096 f64 db4 (the levels "
                               "below 64 samples run lane-locally, wx_dwttail.hip)"),
     "dwt_long": dict(kind="wpt", n=16384, batch=16384, wavelet="db4", L=14, dtype="f64", tree="pyramid",
-                     kernel="k_level1_tile<double, false>", inv_kernel="k_level1_tile<double, true>",
-                     fwd_kernels=[("k_level1_tile<double, false>", 2), ("k_lat_wpt_treesc_f64<4, 2, 0>", 1)],
-                     desc="dwtall+idwtall of long signals as wptall+iwptall along maketree(16384, 14, :dwt): 16384x16384 f64 db4 -- two "
-                          "tiled top levels on the approximation branch, the 4096-sample pyramid on the lattice kernels, the levels "
+                     kernel="k_top_tile_fwd<double, 8, 2, 4096>", inv_kernel="k_top_tile_inv<double, 8, 2, 2048>",
+                     fwd_kernels=[("k_top_tile_fwd<double, 8, 2, 4096>", 1), ("k_lat_wpt_treesc_f64<4, 2, 0, double>", 1)],
+                     desc="dwtall+idwtall of long signals as wptall+iwptall along maketree(16384, 14, :dwt): 16384x16384 f64 db4 -- the two "
+                          "top levels in one tiled pass (wx_toptile.h), the 4096-sample pyramid on the lattice kernels, the levels "
                           "below 64 samples lane-locally (wx_dev_dwt_long)"),
     "target_n2048": dict(kind="wpt", n=2048, batch=131072, wavelet="db4", L=10, dtype="f64",
                          kernel="k_lat_wpt_sh_f64<4, 2, 1>", inv_kernel="k_lat_iwpt_sh_f64<4, 2, 1>",
@@ -110,7 +110,7 @@ WORKLOADS = {
                       desc="config 4's bytes as 1024 images 1024x1024 f32 db4 L=7 (eight columns per wavefront)"),
     "cfg5": dict(kind="acwpd_jbb", n=2048, batch=262144, chunk=2048, wavelet="coif6", L=11, dtype="f64",
                  kernel="k_acwpd_subtree_mfma<2>",
-                 fwd_kernels=[("k_swt_fwd_level<double, true>", 6), ("k_jbb_moments<double>", 1),
+                 fwd_kernels=[("k_acwpd_top_two_mom<2>", 3), ("k_acwpd_top_combine", 1),
                               ("k_acwpd_subtree_mfma<2>", 1), ("k_jbb_costs<double>", 1)],
                  desc="BASELINE config 5: acwpd + JBB moments/costs/tree 262144x2048 f64 coif6 L=11; moments accumulate over "
                       "chunks of 2048 signals, all-reduce of the moments when N > 1 (no inverse: the output is the tree)"),

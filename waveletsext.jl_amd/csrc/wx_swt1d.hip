@@ -281,9 +281,17 @@ __global__ __launch_bounds__(1024) void k_acwpd_top_two_mom(const double *__rest
 
 // sum[col, i] (+)= sum over y of the partials, y ascending; col of (node b, slot): root 0, children 2^(d+1)-1 + 2b + {0,1},
 // grandchildren 2^(d+2)-1 + 4b + {0..3}
-__global__ __launch_bounds__(256) void k_acwpd_top_combine(const double *__restrict__ part, int n, int d, int nodes, int gy, int acc,
+struct WxTopComb {                       // the passes of one chunk: one combine launch for all of them (blockIdx.y = pass)
+    int npass;
+    int d[8], nodes[8], gy[8];
+    int64_t off[8];                      // element offset of the pass's partials
+};
+__global__ __launch_bounds__(256) void k_acwpd_top_combine(const double *__restrict__ part_all, int n, WxTopComb tc, int acc,
                                                            double *__restrict__ sum, double *__restrict__ sumsq)
 {
+    const int ps = blockIdx.y;
+    const int d = tc.d[ps], nodes = tc.nodes[ps], gy = tc.gy[ps];
+    const double *part = part_all + tc.off[ps];
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;               // over nodes * 7 * n
     if (e >= (int64_t)nodes * 7 * n) return;
     const int i = (int)(e % n);
@@ -315,32 +323,38 @@ int wx_dev_acwpd_top_moments(const double *x, double *tab, int64_t n, int D0, in
     const int ncols = (1 << (D0 + 1)) - 1;
     const size_t lds = (size_t)3 * n * sizeof(double);
     WxScratch scr(st);
-    // per pass nodes * gy workgroups, gy = 128, 64, 32, ... signal groups (the last pass has the most nodes)
-    size_t pbytes = 0;
+    // per pass nodes * gy workgroups, gy = 128, 64, 32, ... signal groups (the last pass has the most nodes); every pass keeps its
+    // own partials and ONE combine launch adds them all at the end (one launch per pass until late in round 4: 3 x 29 us per chunk)
+    WxTopComb tc = {};
+    int64_t pelems = 0;
     for (int d = 0; d < D0; d += 2) {
-        const int nodes = 1 << d;
-        int64_t gy = 128 >> (d / 2); if (gy < 32) gy = 32; if (gy > batch) gy = batch;
-        const size_t need = (size_t)2 * gy * nodes * 7 * n * sizeof(double);
-        if (need > pbytes) pbytes = need;
-    }
-    double *part = (double *)scr.alloc(pbytes);
-    if (!part) return WX_EHIP;
-    for (int d = 0; d < D0; d += 2) {
+        if (tc.npass >= 8) return 0;
         const int nodes = 1 << d;
         int64_t gy = 128 >> (d / 2); if (gy < 32) gy = 32; if (gy > batch) gy = batch;    // the partials' count: the combine walks them in order
+        tc.d[tc.npass] = d; tc.nodes[tc.npass] = nodes; tc.gy[tc.npass] = (int)gy; tc.off[tc.npass] = pelems;
+        pelems += (int64_t)2 * gy * nodes * 7 * n;
+        ++tc.npass;
+    }
+    double *part = (double *)scr.alloc((size_t)pelems * sizeof(double));
+    if (!part) return WX_EHIP;
+    int64_t totmax = 0;
+    for (int ps = 0; ps < tc.npass; ++ps) {
+        const int d = tc.d[ps], nodes = tc.nodes[ps];
+        const int64_t gy = tc.gy[ps];
 #define WX_TM(NPP)                                                                                                                     \
         {                                                                                                                              \
             auto k = k_acwpd_top_two_mom<NPP>;                                                                                         \
             if (lds > 64 * 1024) WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL(k, dim3(nodes, (unsigned)gy), dim3(1024), lds, st, x, tab, (int)n, ncols, batch, d, d + 2 >= D0 ? 1 : 0, ac, part); \
+            hipLaunchKernelGGL(k, dim3(nodes, (unsigned)gy), dim3(1024), lds, st, x, tab, (int)n, ncols, batch, d, d + 2 >= D0 ? 1 : 0, ac, part + tc.off[ps]); \
         }
         if (NP == 1) WX_TM(1) else if (NP == 2) WX_TM(2) else WX_TM(4)
 #undef WX_TM
         const int64_t tot = (int64_t)nodes * 7 * n;
-        hipLaunchKernelGGL(k_acwpd_top_combine, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double *)part, (int)n, d, nodes, (int)gy,
-                           acc, sum, sumsq);
-        WX_HIP_CHECK(hipGetLastError());
+        if (tot > totmax) totmax = tot;
     }
+    hipLaunchKernelGGL(k_acwpd_top_combine, dim3((unsigned)((totmax + 255) / 256), (unsigned)tc.npass), dim3(256), 0, st, (const double *)part,
+                       (int)n, tc, acc, sum, sumsq);
+    WX_HIP_CHECK(hipGetLastError());
     return 1;
 }
 
