@@ -46,8 +46,8 @@ WORKLOADS = {
                    fwd_kernels=[("k_lat_wpt_f64<4, 3, double>", 1)],
                    desc="north-star target: wptall+iwptall 65536x4096 f64 db4 L=10"),
     "wpt_db8": dict(kind="wpt", n=4096, batch=65536, wavelet="db8", L=12, dtype="f64",
-                    kernel="k_lat_wpt_f64<8, 2, double>", inv_kernel="k_lat_iwpt_f64<8, 2, double>",
-                    fwd_kernels=[("k_lat_wpt_f64<8, 2, double>", 1)],
+                    kernel="k_lat_wpt_f64<8, 3, double>", inv_kernel="k_lat_iwpt_f64<8, 2, double>",
+                    fwd_kernels=[("k_lat_wpt_f64<8, 3, double>", 1)],
                     desc="config 2's signals and filter through wptall+iwptall: 65536x4096 f64 db8 L=12 (the F = 16 lattice kernels)"),
     "tree_random": dict(kind="wpt", n=4096, batch=65536, wavelet="db4", L=12, dtype="f64", tree="random:0.7:3",
                         kernel="k_lat_wpt_treesc_f64<4, 2, 0, double>", inv_kernel="k_lat_iwpt_treesc_f64<4, 2, 0, false, double>",

@@ -871,6 +871,158 @@ __global__ __launch_bounds__(256) void k_dwt2d_level_tile(const T *__restrict__ 
     }
 }
 
+// ---- the same level with persistent workgroups: the next tile's loads fly while this tile is filtered -----------------
+// k_dwt2d_level_tile issues a tile's loads, waits for them, filters, stores and ends: with three workgroups per CU (43-50 KiB of
+// LDS each) nothing hides the load latency (a level of a GiB of 1024 x 1024 Float32 images: 0.8 ms, a quarter of the HBM peak).
+// Here a workgroup walks tiles (tile index fastest, then image) and holds the NEXT tile's samples in registers while it works on
+// the current one in LDS.  For the modes whose tiles all do work (no tree, or the active-node list `act`) and tiles + halo of at
+// most NB x 256 samples.
+template <typename T, int F, int CR, int CC>
+__global__ __launch_bounds__(256) void k_dwt2d_level_tile_p(const T *__restrict__ src, T *__restrict__ dst,
+                                                            int64_t src_img, int64_t dst_img, int m, int n, int d,
+                                                            WxFilt filt, T *__restrict__ dst_int, int64_t int_img,
+                                                            const uint8_t *__restrict__ status, int64_t nstatus,
+                                                            const int *__restrict__ act, unsigned tiles, int64_t total)
+{
+    constexpr int OPT = 4, H = F - 2, W = 2 * F + 2 * OPT - 4;
+    constexpr int PIN = (CR + 2 * H) | 1;
+    constexpr int PT = CR | 1;
+    constexpr int NB = ((CR + 2 * H) * (CC + 2 * H) + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char wx_smem2[];
+    T *in = reinterpret_cast<T *>(wx_smem2);
+    T *tmp = in + (CC + 2 * H) * PIN;
+    const int tid = threadIdx.x;
+    const int mp = m >> d, np = n >> d;
+    const bool bigR = mp > CR, bigC = np > CC;
+    const int HR = bigR ? H : 0, HC = bigC ? H : 0;
+    const int NR = CR + 2 * HR, NC = CC + 2 * HC;
+    const int lmp = 31 - __clz(mp), lnp = 31 - __clz(np);
+    T q[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
+    // where the staged element e of a tile goes in LDS (the same for every tile) and where it comes from in a tile at (R0, C0)
+    int at[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int e = tid + u * 256;
+        at[u] = -1;
+        if (e < NR * NC) { const int lc = e / NR, lr = e - lc * NR; at[u] = lc * PIN + lr; }
+    }
+    auto coords = [&](int64_t t, int &R0, int &C0, int64_t &img) {
+        img = t / tiles;
+        const int tt = (int)(t - img * tiles);
+        if (act) {
+            const int tpr = mp / CR, tpn = tpr * (np / CC);
+            const int a = tt / tpn, w = tt - a * tpn;
+            R0 = act[2 * a] * mp + (w % tpr) * CR;
+            C0 = act[2 * a + 1] * np + (w / tpr) * CC;
+        } else {
+            const int tiles_r = m / CR;
+            R0 = (tt % tiles_r) * CR;
+            C0 = (tt / tiles_r) * CC;
+        }
+    };
+    auto fetch = [&](int64_t t, T (&v)[NB]) {
+        int R0, C0; int64_t img;
+        coords(t, R0, C0, img);
+        const int nbR = R0 & ~(mp - 1), nbC = C0 & ~(np - 1);
+        const T *simg = src + img * src_img;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = tid + u * 256;
+            if (e < NR * NC) {
+                const int lc = e / NR, lr = e - lc * NR;
+                const int gr = bigR ? nbR + ((R0 - nbR + lr - H) & (mp - 1)) : R0 + lr;
+                const int gc = bigC ? nbC + ((C0 - nbC + lc - H) & (np - 1)) : C0 + lc;
+                v[u] = simg[(int64_t)gc * m + gr];
+            }
+        }
+    };
+    T v[NB];
+    int64_t t = blockIdx.x;
+    if (t < total) fetch(t, v);
+    for (; t < total; t += gridDim.x) {
+        int R0, C0; int64_t img;
+        coords(t, R0, C0, img);
+        T *dimg = dst + img * dst_img;
+        T *iimg = dst_int ? dst_int + img * int_img : dimg;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) if (at[u] >= 0) in[at[u]] = v[u];
+        __syncthreads();
+        if (t + gridDim.x < total) fetch(t + gridDim.x, v);          // in flight during both passes
+        // columns: item = (staged column, group of OPT row pairs)
+        const int dgi = 256 / NC, dli = 256 - dgi * NC;
+        int ig = tid / NC, lc = tid - ig * NC;
+        for (int e = tid; e < NC * (CR / 2 / OPT); e += 256, lc += dli, ig += dgi) {
+            if (lc >= NC) { lc -= NC; ++ig; }
+            const int i0 = ig * OPT;
+            const T *col = in + lc * PIN;
+            T w[W];
+            if (bigR) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) w[k] = col[2 * i0 + k];
+            } else {
+                const int nb = (2 * i0) & ~(mp - 1), p = 2 * i0 - nb - H;
+#pragma unroll
+                for (int k = 0; k < W; ++k) w[k] = col[nb + ((p + k) & (mp - 1))];
+            }
+            T *to = tmp + lc * PT;
+#pragma unroll
+            for (int s2 = 0; s2 < OPT; ++s2) {
+                T a = 0, dd = 0;
+#pragma unroll
+                for (int k = 0; k < F; ++k) {
+                    a = fma(q[k], w[2 * s2 + H + k], a);
+                    dd = fma((k & 1) ? -q[k] : q[k], w[2 * s2 + 1 + H - k], dd);
+                }
+                to[i0 + s2] = a;
+                to[CR / 2 + i0 + s2] = dd;
+            }
+        }
+        __syncthreads();
+        // rows: item = (row of the intermediate, group of OPT column pairs)
+        for (int e = tid; e < CR * (CC / 2 / OPT); e += 256) {
+            const int jg = e / CR, tr = e - jg * CR;
+            const int j0 = jg * OPT;
+            T w[W];
+            if (bigC) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) w[k] = tmp[(2 * j0 + k) * PT + tr];
+            } else {
+                const int nb = (2 * j0) & ~(np - 1), p = 2 * j0 - nb - H;
+#pragma unroll
+                for (int k = 0; k < W; ++k) w[k] = tmp[(nb + ((p + k) & (np - 1))) * PT + tr];
+            }
+            const int hi = tr >= CR / 2, i = tr - hi * (CR / 2);
+            const int rs = R0 + 2 * i, nr = rs & ~(mp - 1);
+            const int grow = nr + hi * (mp >> 1) + ((rs - nr) >> 1);
+            T *olo = dimg, *ohi = dimg;
+            if (status) {
+                const int64_t h = wx_quad_heap(d, rs >> lmp, (C0 + 2 * j0) >> lnp);
+                if (!(h <= nstatus && status[h - 1])) continue;
+                const int64_t c0 = 4 * h - 2 + 2 * hi;
+                if (c0 <= nstatus && status[c0 - 1]) olo = iimg;
+                if (c0 + 1 <= nstatus && status[c0]) ohi = iimg;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < OPT; ++s2) {
+                T a = 0, dd = 0;
+#pragma unroll
+                for (int k = 0; k < F; ++k) {
+                    a = fma(q[k], w[2 * s2 + H + k], a);
+                    dd = fma((k & 1) ? -q[k] : q[k], w[2 * s2 + 1 + H - k], dd);
+                }
+                const int cs = C0 + 2 * (j0 + s2), nc = cs & ~(np - 1);
+                const int gcol = nc + ((cs - nc) >> 1);
+                olo[(int64_t)gcol * m + grow] = a;
+                ohi[(int64_t)(gcol + (np >> 1)) * m + grow] = dd;
+            }
+        }
+        // the next tile's samples overwrite `in` only after this barrier; `tmp` is rewritten after the barrier that follows them
+        __syncthreads();
+    }
+}
+
 struct WxTileTree {                       // tree-driven level: see k_dwt2d_level_tile
     void *dst_int = nullptr;
     int64_t int_img = 0;
@@ -898,6 +1050,25 @@ static bool wx_launch_level_tile_F(const T *src, T *dst, int64_t src_img, int64_
     const unsigned tiles = by_node ? (unsigned)(tt.nact * (mp / CR) * (np / CC)) : (unsigned)((m / CR) * (n / CC));
     if (tiles == 0) return true;
     T *di = (T *)tt.dst_int;
+    // persistent workgroups with the next tile prefetched (k_dwt2d_level_tile_p): every tile does work (no tree, or the node list)
+    static const int persist = getenv("WX_TILE_PERSIST") ? atoi(getenv("WX_TILE_PERSIST")) : 1;
+    constexpr int NBP = ((CR + 2 * H) * (CC + 2 * H) + 255) / 256;
+    if (persist && NBP <= 24 && (!tt.status || by_node)) {
+        auto kp = k_dwt2d_level_tile_p<T, F, CR, CC>;
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return false;
+        const int64_t total = (int64_t)tiles * batch;
+        int per_cu = (int)((160 * 1024) / lds);
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        static const int wgs_env = getenv("WX_TILE_WGS") ? atoi(getenv("WX_TILE_WGS")) : 0;
+        int64_t grid = (int64_t)256 * (wgs_env > 0 ? wgs_env : per_cu);
+        if (grid > total) grid = total;
+        hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(256), lds, st, src, dst, src_img, dst_img, m, n, d, filt, di, tt.int_img, tt.status,
+                           tt.nstatus, by_node ? tt.act : (const int *)nullptr, tiles, total);
+        return true;
+    }
     for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
         const unsigned bc = (unsigned)(batch - b0 < 65535 ? batch - b0 : 65535);
         hipLaunchKernelGGL(kern, dim3(tiles, bc), dim3(256), lds, st, src + b0 * src_img, dst + b0 * dst_img, src_img,
@@ -1093,6 +1264,158 @@ __global__ __launch_bounds__(256) void k_idwt2d_level_tile(const T *__restrict__
     }
 }
 
+// ---- the inverse level with persistent workgroups and the next tile's children prefetched (see k_dwt2d_level_tile_p) -------
+// For the node-list mode (nodes at least as large as a tile: one node per tile, every tile active): the flags of the four children
+// come straight from the status bytes of the tile's node (wave-uniform), no flag table in LDS.
+template <typename T, int F, int CR, int CC>
+__global__ __launch_bounds__(256) void k_idwt2d_level_tile_p(const T *__restrict__ src_leaf, int64_t leaf_img,
+                                                             const T *__restrict__ src_int, int64_t int_img,
+                                                             T *__restrict__ dst, int64_t dst_img, int m, int n, int d,
+                                                             WxFilt filt, const uint8_t *__restrict__ status,
+                                                             int64_t nstatus, const int *__restrict__ act, unsigned tiles, int64_t total)
+{
+    constexpr int OPT = 4, HF = F / 2, G = HF - 1, WN = G + OPT;
+    constexpr int HRm = CR / 2 + 2 * G, HCm = CC / 2 + 2 * G;
+    constexpr int PCH = HRm | 1;
+    constexpr int PTP = (2 * HRm) | 1;
+    constexpr int POUT = CR | 1;
+    constexpr int NB = (4 * HRm * HCm + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char wx_smem3[];
+    T *ch = reinterpret_cast<T *>(wx_smem3);
+    T *tmp = ch + 4 * HCm * PCH;
+    T *out = ch;
+    const int tid = threadIdx.x;
+    const int mp = m >> d, np = n >> d, hr = mp >> 1, hc = np >> 1;
+    const int lmp = 31 - __clz(mp), lnp = 31 - __clz(np);
+    const bool bigR = mp > CR, bigC = np > CC;              // mp >= CR and np >= CC here: a tile lies in one node
+    const int GR = bigR ? G : 0, GC = bigC ? G : 0;
+    const int NRc = CR / 2 + 2 * GR, NCc = CC / 2 + 2 * GC;
+    const int per = NRc * NCc, tot = 4 * per;
+    T q[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
+    int at[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int e = tid + u * 256;
+        at[u] = -1;
+        if (e < tot) {
+            const int c = e / per, r2 = e - c * per;
+            const int lc = r2 / NRc, lr = r2 - lc * NRc;
+            at[u] = (c * HCm + lc) * PCH + lr;
+        }
+    }
+    auto coords = [&](int64_t t, int &R0, int &C0, int64_t &img) {
+        img = t / tiles;
+        const int tt = (int)(t - img * tiles);
+        const int tpr = mp / CR, tpn = tpr * (np / CC);
+        const int a = tt / tpn, w = tt - a * tpn;
+        R0 = act[2 * a] * mp + (w % tpr) * CR;
+        C0 = act[2 * a + 1] * np + (w / tpr) * CC;
+    };
+    auto fetch = [&](int64_t t, T (&v)[NB]) {
+        int R0, C0; int64_t img;
+        coords(t, R0, C0, img);
+        const int nbR = R0 & ~(mp - 1), nbC = C0 & ~(np - 1);
+        const T *limg = src_leaf + img * leaf_img;
+        const T *iimg = src_int ? src_int + img * int_img : limg;
+        const int64_t h = wx_quad_heap(d, R0 >> lmp, C0 >> lnp);
+        const T *from[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t hch = 4 * h - 2 + c;
+            from[c] = (hch <= nstatus && status[hch - 1]) ? iimg : limg;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = tid + u * 256;
+            if (e < tot) {
+                const int c = e / per, r2 = e - c * per;
+                const int lc = r2 / NRc, lr = r2 - lc * NRc;
+                const int grow = bigR ? nbR + (c >> 1) * hr + ((((R0 - nbR) >> 1) + lr - G) & (hr - 1)) : R0 + (c >> 1) * hr + lr;
+                const int gcol = bigC ? nbC + (c & 1) * hc + ((((C0 - nbC) >> 1) + lc - G) & (hc - 1)) : C0 + (c & 1) * hc + lc;
+                const T *fp = c == 0 ? from[0] : (c == 1 ? from[1] : (c == 2 ? from[2] : from[3]));
+                v[u] = fp[(int64_t)gcol * m + grow];
+            }
+        }
+    };
+    T v[NB];
+    int64_t t = blockIdx.x;
+    if (t < total) fetch(t, v);
+    for (; t < total; t += gridDim.x) {
+        int R0, C0; int64_t img;
+        coords(t, R0, C0, img);
+        T *dimg = dst + img * dst_img;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) if (at[u] >= 0) ch[at[u]] = v[u];
+        __syncthreads();
+        if (t + gridDim.x < total) fetch(t + gridDim.x, v);
+        // dim 2: item = (row half, staged child row, group of OPT column pairs); lanes down the rows
+        for (int e = tid; e < 2 * NRc * (CC / 2 / OPT); e += 256) {
+            const int g = e / (2 * NRc), r2 = e - g * (2 * NRc);
+            const int rh = r2 / NRc, lr = r2 - rh * NRc;
+            const T *ca = ch + (rh * 2) * HCm * PCH + lr, *cd = ch + (rh * 2 + 1) * HCm * PCH + lr;
+            T aw[WN], dw[WN];
+            if (bigC) {
+#pragma unroll
+                for (int k = 0; k < WN; ++k) { aw[k] = ca[(g * OPT + k) * PCH]; dw[k] = cd[(g * OPT + k + G) * PCH]; }
+            } else {
+                const int base = (g * OPT) & ~(hc - 1), p = g * OPT - base;
+#pragma unroll
+                for (int k = 0; k < WN; ++k) {
+                    aw[k] = ca[(base + ((p - G + k) & (hc - 1))) * PCH];
+                    dw[k] = cd[(base + ((p + k) & (hc - 1))) * PCH];
+                }
+            }
+            T *to = tmp + rh * HRm + lr;
+#pragma unroll
+            for (int s2 = 0; s2 < OPT; ++s2) {
+                T v0 = 0, v1 = 0;
+#pragma unroll
+                for (int mm = 0; mm < HF; ++mm) {
+                    v0 = fma(q[2 * mm], aw[s2 + G - mm], v0); v0 = fma(-q[2 * mm + 1], dw[s2 + mm], v0);
+                    v1 = fma(q[2 * mm + 1], aw[s2 + G - mm], v1); v1 = fma(q[2 * mm], dw[s2 + mm], v1);
+                }
+                to[(2 * (g * OPT + s2)) * PTP] = v0;
+                to[(2 * (g * OPT + s2) + 1) * PTP] = v1;
+            }
+        }
+        __syncthreads();
+        // dim 1: item = (column, group of OPT row pairs); lanes across the columns
+        for (int e = tid; e < CC * (CR / 2 / OPT); e += 256) {
+            const int g = e / CC, c = e - g * CC;
+            const T *lo = tmp + c * PTP, *hi = lo + HRm;
+            T aw[WN], dw[WN];
+            if (bigR) {
+#pragma unroll
+                for (int k = 0; k < WN; ++k) { aw[k] = lo[g * OPT + k]; dw[k] = hi[g * OPT + k + G]; }
+            } else {
+                const int base = (g * OPT) & ~(hr - 1), p = g * OPT - base;
+#pragma unroll
+                for (int k = 0; k < WN; ++k) { aw[k] = lo[base + ((p - G + k) & (hr - 1))]; dw[k] = hi[base + ((p + k) & (hr - 1))]; }
+            }
+            T *to = out + c * POUT;
+#pragma unroll
+            for (int s2 = 0; s2 < OPT; ++s2) {
+                T v0 = 0, v1 = 0;
+#pragma unroll
+                for (int mm = 0; mm < HF; ++mm) {
+                    v0 = fma(q[2 * mm], aw[s2 + G - mm], v0); v0 = fma(-q[2 * mm + 1], dw[s2 + mm], v0);
+                    v1 = fma(q[2 * mm + 1], aw[s2 + G - mm], v1); v1 = fma(q[2 * mm], dw[s2 + mm], v1);
+                }
+                to[2 * (g * OPT + s2)] = v0;
+                to[2 * (g * OPT + s2) + 1] = v1;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < CR * CC; e += 256) {
+            const int c = e / CR, r = e - c * CR;
+            dimg[(int64_t)(C0 + c) * m + R0 + r] = out[c * POUT + r];
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T, int F, int CR, int CC>
 static bool wx_launch_ilevel_tile_F(const T *src_leaf, int64_t leaf_img, const T *src_int, T *dst, int64_t dst_img, int m,
                                     int n, int d, int64_t batch, const WxFilt &filt, hipStream_t st, const WxTileTree &tt)
@@ -1107,6 +1430,24 @@ static bool wx_launch_ilevel_tile_F(const T *src_leaf, int64_t leaf_img, const T
     const bool by_node = tt.act && mp >= CR && np >= CC;
     const unsigned tiles = by_node ? (unsigned)(tt.nact * (mp / CR) * (np / CC)) : (unsigned)((m / CR) * (n / CC));
     if (tiles == 0) return true;
+    static const int persist = getenv("WX_TILE_PERSIST") ? atoi(getenv("WX_TILE_PERSIST")) : 1;
+    constexpr int NBP = (4 * HRm * HCm + 255) / 256;
+    if (persist && NBP <= 24 && by_node) {
+        auto kp = k_idwt2d_level_tile_p<T, F, CR, CC>;
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return false;
+        const int64_t total = (int64_t)tiles * batch;
+        int per_cu = (int)((160 * 1024) / lds);
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        static const int wgs_env = getenv("WX_TILE_WGS") ? atoi(getenv("WX_TILE_WGS")) : 0;
+        int64_t grid = (int64_t)256 * (wgs_env > 0 ? wgs_env : per_cu);
+        if (grid > total) grid = total;
+        hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(256), lds, st, src_leaf, leaf_img, src_int, tt.int_img, dst, dst_img, m, n, d, filt,
+                           tt.status, tt.nstatus, tt.act, tiles, total);
+        return true;
+    }
     for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
         const unsigned bc = (unsigned)(batch - b0 < 65535 ? batch - b0 : 65535);
         hipLaunchKernelGGL(kern, dim3(tiles, bc), dim3(256), lds, st, src_leaf + b0 * leaf_img, leaf_img,
