@@ -204,18 +204,14 @@ __global__ __launch_bounds__(256) void k_gather_leaves2d(const T *__restrict__ X
 // and the HBM side moves R contiguous elements per column.  4 image passes in total instead of 4
 // per level.  (Rounding differs from the per-level order by O(eps); inside the 1e-5 / 1e-10 budget.)
 // ------------------------------------------------------------------------------------------
-// V rows of one column as a hardware vector: element access e[i] as before, and whole-vector arithmetic that stays a vector
-// operation down to the ISA (Float32: v_pk_fma_f32 -- built from four scalars the compiler takes a vector fma apart again)
-template <typename T, int V> struct alignas(sizeof(T) * V) WxRowVec {
-    typedef T vt __attribute__((ext_vector_type(V)));
-    vt e;
-};
+template <typename T, int V> struct alignas(sizeof(T) * V) WxRowVec { T e[V]; };
 
-// acc += q * w on the V rows of a vector; Float32 rows in pairs (v_pk_fma_f32: the row pass is as much FMA- as LDS-bound)
+// acc += q * w on the V rows of a vector (the compiler pairs Float32 rows into v_pk_fma_f32 by itself; a hardware-vector member type
+// was tried in round 4 and made the in-place variants spill: 1024-column Float32 rows 1.15 -> 1.8 ms)
 template <typename T, int V> __device__ __forceinline__ void wx_vfma(WxRowVec<T, V> &acc, T q, const WxRowVec<T, V> &w)
 {
-    typedef typename WxRowVec<T, V>::vt vt;
-    acc.e = __builtin_elementwise_fma((vt)(q), w.e, acc.e);
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc.e[e] = fma(q, w.e[e], acc.e[e]);
 }
 
 // NLV packet levels of a block of 16 samples held in registers (the block is a whole node of 16 samples, so every periodic wrap
@@ -267,10 +263,12 @@ __device__ __forceinline__ void wx_reg_levels16(T (&x)[16], const T (&q)[F])
 
 // V = rows per lane (16-byte LDS / HBM accesses when V * sizeof(T) = 16): the filter work per LDS
 // instruction grows V-fold, which is what bounds this kernel (LDS instruction issue, not bytes).
-// P4 (with NT <= 512 lanes, i.e. a 256-register budget): an item is FOUR output pairs of a node -- a window of 2F + 4 samples for 8
-// outputs (2.5 LDS reads per output instead of 4; inverse F/2 + 3 pairs of children for 8 parent samples: 1.75 instead of 2.5).
-template <typename T, int F, bool INVERSE, int V, int KI = 0, int NT = 1024, bool P4 = false>
-__global__ __launch_bounds__(NT) void k_rows_fused(const T *__restrict__ src, T *__restrict__ dst,
+// REGL: the levels on nodes of at most 16 columns run in registers (below); its own instantiation, because the extra code costs the
+// variants that do not use it registers (Float64 rows of 64 columns: 1.04 -> 1.22 ms with the code merely present).
+// (Tried in round 4 and removed: four output pairs per item -- 2.5 instead of 4 LDS reads per output -- was slower everywhere,
+// 256-column Float32 rows 1.13 -> 1.33 ms: the kernel is bound by the latency of its phases, not by LDS bytes or FMA issue.)
+template <typename T, int F, bool INVERSE, int V, int KI = 0, bool REGL = false>
+__global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, T *__restrict__ dst,
                                                      int64_t src_img, int64_t dst_img, int m, int log2n, int L,
                                                      int64_t nimg, WxFilt filt, int log2R, int S, int xcd, int regl)
 {
@@ -353,66 +351,11 @@ __global__ __launch_bounds__(NT) void k_rows_fused(const T *__restrict__ src, T 
         }
     };
 
-    auto compute4 = [&](const TV *a, int lnp, int it, TV (&res)[8]) {
-        const int np = 1 << lnp, h = np >> 1;
-        const int j = it >> (lnp - 3), t = it & ((h >> 2) - 1);
-        const TV *v = a + (size_t)(j << lnp) * SV;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int e = 0; e < V; ++e) res[u].e[e] = 0;
-        if (!INVERSE) {
-            // outputs i = 4t .. 4t+3: a[i] needs v[2i .. 2i+F-1], d[i] needs v[2i+2-F .. 2i+1]: window v[8t+2-F .. 8t+F+5]
-            TV w[2 * F + 4];
-#pragma unroll
-            for (int k = 0; k < 2 * F + 4; ++k) w[k] = v[((8 * t + 2 - F + k) & (np - 1)) * SV];
-#pragma unroll
-            for (int k = 0; k < F; ++k) {
-                const T qd = (k & 1) ? -q[k] : q[k];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    wx_vfma<T, V>(res[u], q[k], w[F - 2 + 2 * u + k]);
-                    wx_vfma<T, V>(res[4 + u], qd, w[F - 1 + 2 * u - k]);
-                }
-            }
-        } else {
-            // parent samples 8t .. 8t+7 = pairs kk = 4t + u from a[kk-m], d[kk+m]
-            constexpr int HF = F / 2;
-            TV aw[HF + 3], dw[HF + 3];
-#pragma unroll
-            for (int k = 0; k < HF + 3; ++k) {
-                aw[k] = v[((4 * t + 1 - HF + k) & (h - 1)) * SV];        // a[4t+1-HF .. 4t+3]
-                dw[k] = v[(h + ((4 * t + k) & (h - 1))) * SV];           // d[4t .. 4t+HF+2]
-            }
-#pragma unroll
-            for (int mm = 0; mm < HF; ++mm) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    wx_vfma<T, V>(res[2 * u], q[2 * mm], aw[HF - 1 + u - mm]);
-                    wx_vfma<T, V>(res[2 * u], -q[2 * mm + 1], dw[u + mm]);
-                    wx_vfma<T, V>(res[2 * u + 1], q[2 * mm + 1], aw[HF - 1 + u - mm]);
-                    wx_vfma<T, V>(res[2 * u + 1], q[2 * mm], dw[u + mm]);
-                }
-            }
-        }
-    };
-    auto store4 = [&](TV *b, int lnp, int it, const TV (&res)[8]) {
-        const int np = 1 << lnp, h = np >> 1;
-        const int j = it >> (lnp - 3), t = it & ((h >> 2) - 1);
-        TV *o = b + (size_t)(j << lnp) * SV;
-        if (!INVERSE) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { o[(4 * t + u) * SV] = res[u]; o[(h + 4 * t + u) * SV] = res[4 + u]; }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) o[(8 * t + u) * SV] = res[u];
-        }
-    };
     // regl: the levels on nodes of at most 16 samples (depths log2n - 4 ... L - 1) run in registers -- a lane takes whole blocks of
     // 16 columns of its rows through all of them between one LDS read and one LDS write, in place (wx_reg_levels16); a level
     // through LDS costs 2F / 4 reads and a write per sample.  Full-depth rows of 256 columns: 8 LDS levels -> 4 + 1.
     const int dreg = log2n - 4;
-    const int nreg = (regl && log2n >= 4 && L > dreg) ? L - dreg : 0;
+    const int nreg = (REGL && regl && log2n >= 4 && L > dreg) ? L - dreg : 0;
     const int Llds = L - nreg;
     auto reg_phase = [&](TV *a, auto nlv_c) {
         constexpr int NLV = decltype(nlv_c)::value;
@@ -465,7 +408,7 @@ __global__ __launch_bounds__(NT) void k_rows_fused(const T *__restrict__ src, T 
             for (; c < n; c += gstep) a[c * SV] = *reinterpret_cast<const TV *>(sp + (int64_t)c * m);
         }
         __syncthreads();
-        if (INVERSE && nreg) reg_levels(a);
+        if constexpr (REGL && INVERSE) { if (nreg) reg_levels(a); }
         for (int s = 0; s < Llds; ++s) {
             const int d = INVERSE ? Llds - 1 - s : s;
             const int lnp = log2n - d;               // log2(node length)
@@ -483,12 +426,6 @@ __global__ __launch_bounds__(NT) void k_rows_fused(const T *__restrict__ src, T 
                     for (int ki = 0; ki < KM; ++ki) {
                         const int it = g0 + ki * gstep;
                         if (it < (n >> 2)) store(b, lnp, it, res[ki]);
-                    }
-                } else if (P4 && h >= 4) {
-                    for (int it = g0; it < (n >> 3); it += gstep) {
-                        TV res[8];
-                        compute4(a, lnp, it, res);
-                        store4(b, lnp, it, res);
                     }
                 } else {
                     for (int it = g0; it < (n >> 2); it += gstep) {
@@ -527,7 +464,7 @@ __global__ __launch_bounds__(NT) void k_rows_fused(const T *__restrict__ src, T 
             __syncthreads();
             if (!INPLACE) { TV *tmp = a; a = b; b = tmp; }
         }
-        if (!INVERSE && nreg) reg_levels(a);
+        if constexpr (REGL && !INVERSE) { if (nreg) reg_levels(a); }
         if (row_ok)
             for (int c = g0; c < n; c += gstep) *reinterpret_cast<TV *>(dp + (int64_t)c * m) = a[c * SV];
         __syncthreads();
@@ -590,16 +527,19 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
     const int nt = inplace ? nt_ip : (per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024));
-    // four output pairs per item where the workgroup leaves a lane 256 registers (two LDS images, <= 512 lanes)
-    static const int p4_env = getenv("WX_ROWS_P4") ? atoi(getenv("WX_ROWS_P4")) : 0;    // measured slower (f32 256 columns 1.13 -> 1.33 ms): off
-    const bool p4 = p4_env && vec && !inplace && nt <= 512 && filt.F <= 8 && n >= 8;
+    // measured (db4, full depth, 1 GiB): rows of 256 Float64 columns 1.11 -> 0.97 ms, 1024 Float32 columns 1.89 -> 1.65 ms; short rows lose
+    // (64 Float32 columns 1.02 -> 1.34 ms, 64 / 128 Float64 columns 1.04 -> 1.39 ms)
+    const bool regl = regl_env && vec && filt.F <= 8 && ((sizeof(T) == 8 && n >= 256) || n >= 1024);
     switch (filt.F) {
 #define WX_CASE(FF) case FF: kern = vec ? k_rows_fused<T, FF, INVERSE, VW> : k_rows_fused<T, FF, INVERSE, 1>; break;
         WX_CASE(10) WX_CASE(12) WX_CASE(14) WX_CASE(16) WX_CASE(18) WX_CASE(20)
 #undef WX_CASE
-#define WX_CASE(FF) case FF: kern = inplace ? (items_per_lane <= 1 ? k_rows_fused<T, FF, INVERSE, VW, 1> : k_rows_fused<T, FF, INVERSE, VW, 2>) \
-                                   : (p4 ? k_rows_fused<T, FF, INVERSE, VW, 0, 512, true>                                                         \
-                                         : (vec ? k_rows_fused<T, FF, INVERSE, VW> : k_rows_fused<T, FF, INVERSE, 1>)); break;
+#define WX_CASE(FF) case FF:                                                                                                                  \
+        if (regl) kern = inplace ? (items_per_lane <= 1 ? k_rows_fused<T, FF, INVERSE, VW, 1, true> : k_rows_fused<T, FF, INVERSE, VW, 2, true>) \
+                                 : k_rows_fused<T, FF, INVERSE, VW, 0, true>;                                                                 \
+        else kern = inplace ? (items_per_lane <= 1 ? k_rows_fused<T, FF, INVERSE, VW, 1> : k_rows_fused<T, FF, INVERSE, VW, 2>)              \
+                            : (vec ? k_rows_fused<T, FF, INVERSE, VW> : k_rows_fused<T, FF, INVERSE, 1>);                                    \
+        break;
         WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8)
 #undef WX_CASE
     default: return wx_set_error(WX_EUNSUPPORTED, "no fused row kernel for this filter length");
@@ -615,10 +555,7 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
     int log2R = 0;
     while ((1 << (log2R + 1)) <= R) ++log2R;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), lds, st, src, dst, src_img, dst_img, (int)m, log2n, L, batch,
-                       filt, log2R, S, xcd_env,
-                       // measured (db4, full depth, 1 GiB): rows of 256 Float64 columns 1.11 -> 0.97 ms, 1024 Float32 columns 1.89 -> 1.65 ms;
-                       // short Float32 rows lose (64 columns 1.02 -> 1.34 ms: the kernel is as much FMA- as LDS-bound there)
-                       (regl_env && (sizeof(T) == 8 || n >= 1024)) ? 1 : 0);
+                       filt, log2R, S, xcd_env, regl ? 1 : 0);
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }
@@ -878,7 +815,7 @@ __global__ __launch_bounds__(256) void k_dwt2d_level_tile(const T *__restrict__ 
 // the current one in LDS.  For the modes whose tiles all do work (no tree, or the active-node list `act`) and tiles + halo of at
 // most NB x 256 samples.
 template <typename T, int F, int CR, int CC>
-__global__ __launch_bounds__(256) void k_dwt2d_level_tile_p(const T *__restrict__ src, T *__restrict__ dst,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_dwt2d_level_tile_p(const T *__restrict__ src, T *__restrict__ dst,
                                                             int64_t src_img, int64_t dst_img, int m, int n, int d,
                                                             WxFilt filt, T *__restrict__ dst_int, int64_t int_img,
                                                             const uint8_t *__restrict__ status, int64_t nstatus,
@@ -900,14 +837,6 @@ __global__ __launch_bounds__(256) void k_dwt2d_level_tile_p(const T *__restrict_
     T q[F];
 #pragma unroll
     for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
-    // where the staged element e of a tile goes in LDS (the same for every tile) and where it comes from in a tile at (R0, C0)
-    int at[NB];
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-        const int e = tid + u * 256;
-        at[u] = -1;
-        if (e < NR * NC) { const int lc = e / NR, lr = e - lc * NR; at[u] = lc * PIN + lr; }
-    }
     auto coords = [&](int64_t t, int &R0, int &C0, int64_t &img) {
         img = t / tiles;
         const int tt = (int)(t - img * tiles);
@@ -946,8 +875,13 @@ __global__ __launch_bounds__(256) void k_dwt2d_level_tile_p(const T *__restrict_
         coords(t, R0, C0, img);
         T *dimg = dst + img * dst_img;
         T *iimg = dst_int ? dst_int + img * int_img : dimg;
+        // (the LDS address of staged element e is recomputed per tile: 3 waves per SIMD need <= 168 registers, and a table of
+        // NB addresses beside the NB prefetched samples does not fit)
 #pragma unroll
-        for (int u = 0; u < NB; ++u) if (at[u] >= 0) in[at[u]] = v[u];
+        for (int u = 0; u < NB; ++u) {
+            const int e = tid + u * 256;
+            if (e < NR * NC) { const int lc = e / NR, lr = e - lc * NR; in[lc * PIN + lr] = v[u]; }
+        }
         __syncthreads();
         if (t + gridDim.x < total) fetch(t + gridDim.x, v);          // in flight during both passes
         // columns: item = (staged column, group of OPT row pairs)
@@ -1053,7 +987,7 @@ static bool wx_launch_level_tile_F(const T *src, T *dst, int64_t src_img, int64_
     // persistent workgroups with the next tile prefetched (k_dwt2d_level_tile_p): every tile does work (no tree, or the node list)
     static const int persist = getenv("WX_TILE_PERSIST") ? atoi(getenv("WX_TILE_PERSIST")) : 1;
     constexpr int NBP = ((CR + 2 * H) * (CC + 2 * H) + 255) / 256;
-    if (persist && NBP <= 24 && (!tt.status || by_node)) {
+    if (persist && NBP <= 24 && F <= 10 && (!tt.status || by_node)) {          // (longer filters spill at three wavefronts per SIMD)
         auto kp = k_dwt2d_level_tile_p<T, F, CR, CC>;
         if (lds > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1268,7 +1202,7 @@ __global__ __launch_bounds__(256) void k_idwt2d_level_tile(const T *__restrict__
 // For the node-list mode (nodes at least as large as a tile: one node per tile, every tile active): the flags of the four children
 // come straight from the status bytes of the tile's node (wave-uniform), no flag table in LDS.
 template <typename T, int F, int CR, int CC>
-__global__ __launch_bounds__(256) void k_idwt2d_level_tile_p(const T *__restrict__ src_leaf, int64_t leaf_img,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_idwt2d_level_tile_p(const T *__restrict__ src_leaf, int64_t leaf_img,
                                                              const T *__restrict__ src_int, int64_t int_img,
                                                              T *__restrict__ dst, int64_t dst_img, int m, int n, int d,
                                                              WxFilt filt, const uint8_t *__restrict__ status,
@@ -1294,17 +1228,6 @@ __global__ __launch_bounds__(256) void k_idwt2d_level_tile_p(const T *__restrict
     T q[F];
 #pragma unroll
     for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
-    int at[NB];
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-        const int e = tid + u * 256;
-        at[u] = -1;
-        if (e < tot) {
-            const int c = e / per, r2 = e - c * per;
-            const int lc = r2 / NRc, lr = r2 - lc * NRc;
-            at[u] = (c * HCm + lc) * PCH + lr;
-        }
-    }
     auto coords = [&](int64_t t, int &R0, int &C0, int64_t &img) {
         img = t / tiles;
         const int tt = (int)(t - img * tiles);
@@ -1347,7 +1270,14 @@ __global__ __launch_bounds__(256) void k_idwt2d_level_tile_p(const T *__restrict
         coords(t, R0, C0, img);
         T *dimg = dst + img * dst_img;
 #pragma unroll
-        for (int u = 0; u < NB; ++u) if (at[u] >= 0) ch[at[u]] = v[u];
+        for (int u = 0; u < NB; ++u) {
+            const int e = tid + u * 256;
+            if (e < tot) {
+                const int c = e / per, r2 = e - c * per;
+                const int lc = r2 / NRc, lr = r2 - lc * NRc;
+                ch[(c * HCm + lc) * PCH + lr] = v[u];
+            }
+        }
         __syncthreads();
         if (t + gridDim.x < total) fetch(t + gridDim.x, v);
         // dim 2: item = (row half, staged child row, group of OPT column pairs); lanes down the rows
@@ -1432,7 +1362,7 @@ static bool wx_launch_ilevel_tile_F(const T *src_leaf, int64_t leaf_img, const T
     if (tiles == 0) return true;
     static const int persist = getenv("WX_TILE_PERSIST") ? atoi(getenv("WX_TILE_PERSIST")) : 1;
     constexpr int NBP = (4 * HRm * HCm + 255) / 256;
-    if (persist && NBP <= 24 && by_node) {
+    if (persist && NBP <= 24 && F <= (sizeof(T) == 8 ? 8 : 6) && by_node) {     // (Float32 at 8 taps spills 124 bytes per lane at three wavefronts per SIMD: 1.5 -> 1.8 ms)
         auto kp = k_idwt2d_level_tile_p<T, F, CR, CC>;
         if (lds > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
