@@ -123,3 +123,34 @@ def test_dwt3d_side_2048(wx, oracle):
     back = wx.idwtall(y, wt, 1)
     for (j, k) in ((3, 9), (2000, 1000)):
         assert relerr(back[:, j, k, 0].cpu().numpy(), a * b[j] * c[k]) <= 2e-5
+
+
+@pytest.mark.parametrize("shape", [(140000, 2), (1 << 21, 2), ((1 << 20) + 17, 1)])
+def test_threshold_selection_beyond_2_pow_20_coefficients(wx, oracle, shape):
+    """SureShrink / RelErrorShrink selections sort every coefficient of a signal (Denoising.jl:214-232, 275-330).  Above 2^16 values the
+    sort runs as launches over the chip (csrc/wx_shrink.hip: chunks of 4096 in LDS, larger strides in global memory); until round 4
+    2^20 coefficients per signal were refused.  Sizes: between the one-workgroup window and the old limit, twice the old limit, and
+    a length that is no power of two."""
+    n, B = shape
+    rng = np.random.default_rng(n % 1000)
+    x = np.asfortranarray(rng.standard_normal((n, B)) * np.exp(rng.standard_normal((n, B))))
+    s = wx.surethresholdall(x, False)
+    r = wx.relerrorthresholdall(x, False)
+    for i in range(B):
+        assert s[i] == pytest.approx(oracle.surethreshold(x[:, i], False), rel=1e-13)
+        assert r[i] == pytest.approx(oracle.relerrorthreshold(x[:, i], False), rel=1e-12)
+
+
+def test_threshold_selection_chip_sort_equals_window_sort(wx):
+    """the same selection through the one-workgroup window (WX_SHRINK_WG_MAX raised) and through the chip-wide sort: identical bits"""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np, waveletsext_jl_amd as wx\n"
+            "rng = np.random.default_rng(5); x = np.asfortranarray(rng.standard_normal((70000, 3)))\n"
+            "print(repr(list(wx.surethresholdall(x, False)) + list(wx.relerrorthresholdall(x, False))))\n")
+    outs = []
+    for wg in ("65536", "1048576"):
+        env = dict(os.environ, WX_SHRINK_WG_MAX=wg)
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    assert outs[0] == outs[1] and len(outs[0]) > 20

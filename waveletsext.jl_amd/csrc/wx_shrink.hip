@@ -11,7 +11,8 @@
 //       from the chord between the first and the last point of the current prefix); t = x[elbow] * xmax
 // Both are what `denoiseall(...; estnoise = relerrorthreshold)` evaluates for every signal (test/denoising.jl:59-83), so
 // they are batched here exactly like the MAD noise estimate of wx_denoise.hip: the selected coefficients of one signal are
-// sorted by a bitonic network in LDS (up to 8192 Float64 / 16384 Float32 coefficients; above that in a global scratch window that stays in L2),
+// sorted by a bitonic network in LDS (up to 8192 Float64 / 16384 Float32 coefficients; above that in a global scratch window that stays in L2;
+// above the LDS window with launches over the whole chip),
 // the cumulative sums are a workgroup scan, and argmin / argmax keep the first index on ties like Julia's findmin /
 // findmax.  The results are picks from the sorted magnitudes, so they equal the reference's unless two candidates tie to
 // within the rounding of the sums (the reference adds sequentially / pairwise, the scan adds by chunks).
@@ -119,18 +120,75 @@ template <typename T>
 __device__ __forceinline__ T *sh_window(T *gscratch, int npad)
 {
     extern __shared__ __attribute__((aligned(16))) char sh_smem[];
-    return gscratch ? gscratch + (int64_t)blockIdx.x * (2 * npad + 8) : reinterpret_cast<T *>(sh_smem);
+    return gscratch ? gscratch + (int64_t)blockIdx.x * (2 * (int64_t)npad + 8) : reinterpret_cast<T *>(sh_smem);
+}
+
+// ---- large selections: the sort as launches over the whole chip ------------------------------------------------------------
+// Above SH_WG_MAX values one workgroup per signal would spend log2(npad)^2 / 2 barrier-bound passes over a window in global memory
+// (minutes per signal at 2^24).  Instead: stage, then a bitonic network whose passes are launches over (pairs, signals) -- strides
+// of at least SH_CH in global memory (k_sh_bitonic_g), all smaller strides of a merge step inside a chunk of SH_CH values in LDS
+// (k_sh_bitonic_lds): 44 launches for 2^20 values, 90 for 2^24.  The selection kernels below then run on the sorted window (SORTED).
+constexpr int SH_CH = 4096;
+template <typename T>
+__global__ __launch_bounds__(SH_NT) void k_sh_stage_g(const T *__restrict__ X, int64_t sig_stride, int n, const int *__restrict__ cols, int cnt,
+                                                      int npad, T *__restrict__ gs)
+{
+    const T *x = X + (int64_t)blockIdx.y * sig_stride;
+    T *v = gs + (int64_t)blockIdx.y * (2 * (int64_t)npad + 8);
+    for (int64_t e = (int64_t)blockIdx.x * SH_NT + threadIdx.x; e < npad; e += (int64_t)gridDim.x * SH_NT) {
+        T val = sh_inf<T>();
+        if (e < cnt) {
+            const int c = (int)(e / n), row = (int)(e - (int64_t)c * n);
+            val = (T)fabs((double)x[(int64_t)(cols ? cols[c] : c) * n + row]);
+        }
+        v[e] = val;
+    }
+}
+// one compare-exchange pass of stride j >= SH_CH of the merge step k
+template <typename T>
+__global__ __launch_bounds__(SH_NT) void k_sh_bitonic_g(T *__restrict__ gs, int npad, int k, int j)
+{
+    T *v = gs + (int64_t)blockIdx.y * (2 * (int64_t)npad + 8);
+    for (int64_t i = (int64_t)blockIdx.x * SH_NT + threadIdx.x; i < (npad >> 1); i += (int64_t)gridDim.x * SH_NT) {
+        const int64_t lo = ((i & ~(int64_t)(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const T a = v[lo], b = v[hi];
+        if ((a > b) == up) { v[lo] = b; v[hi] = a; }
+    }
+}
+// chunk of SH_CH values in LDS: every merge step up to SH_CH (FIRST), or the strides below SH_CH of the merge step k
+template <typename T, bool FIRST>
+__global__ __launch_bounds__(SH_NT) void k_sh_bitonic_lds(T *__restrict__ gs, int npad, int k)
+{
+    __shared__ T w[SH_CH];
+    T *v = gs + (int64_t)blockIdx.y * (2 * (int64_t)npad + 8) + (int64_t)blockIdx.x * SH_CH;
+    const int64_t g0 = (int64_t)blockIdx.x * SH_CH;                        // global index of w[0]: the direction of a pair depends on it
+    for (int e = threadIdx.x; e < SH_CH; e += SH_NT) w[e] = v[e];
+    __syncthreads();
+    for (int kk = FIRST ? 2 : k; kk <= (FIRST ? SH_CH : k); kk <<= 1)
+        for (int j = (FIRST ? kk : SH_CH) >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < (SH_CH >> 1); i += SH_NT) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+                const bool up = ((g0 + lo) & kk) == 0;
+                const T a = w[lo], b = w[hi];
+                if ((a > b) == up) { w[lo] = b; w[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int e = threadIdx.x; e < SH_CH; e += SH_NT) v[e] = w[e];
 }
 
 // ---- SureShrink: t = sqrt(a[argmin risk]) ---------------------------------------------------------------
-template <typename T>
+template <typename T, bool SORTED = false>
 __global__ __launch_bounds__(SH_NT) void k_surethreshold(const T *__restrict__ X, int64_t sig_stride, int n, const int *__restrict__ cols,
                                                          int ncols, int cnt, int npad, T *gscratch, T *__restrict__ tout)
 {
     __shared__ ShShared<T> S;
     T *v = sh_window<T>(gscratch, npad), *b = v + npad;
-    sh_stage<T>(v, X + (int64_t)blockIdx.x * sig_stride, n, cols, ncols, cnt, npad);
-    sh_bitonic<T>(v, npad);
+    if (!SORTED) {
+        sh_stage<T>(v, X + (int64_t)blockIdx.x * sig_stride, n, cols, ncols, cnt, npad);
+        sh_bitonic<T>(v, npad);
+    }
     sh_scan<T>(cnt, S.part, [&](int e) { const T a = v[e] * v[e]; return a; }, [&](int e, T run) { b[e] = run; });
     const int im = sh_argext<T, false>(cnt, S.rv, S.ri, [&](int i) {
         const T a = v[i] * v[i];
@@ -142,15 +200,17 @@ __global__ __launch_bounds__(SH_NT) void k_surethreshold(const T *__restrict__ X
 }
 
 // ---- RelErrorShrink ---------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool SORTED = false>
 __global__ __launch_bounds__(SH_NT) void k_relerrorthreshold(const T *__restrict__ X, int64_t sig_stride, int n,
                                                              const int *__restrict__ cols, int ncols, int cnt, int npad, int elbows,
                                                              T *gscratch, T *__restrict__ tout)
 {
     __shared__ ShShared<T> S;
     T *v = sh_window<T>(gscratch, npad), *w = v + npad;                   // cnt + 1 <= npad + 8 entries
-    sh_stage<T>(v, X + (int64_t)blockIdx.x * sig_stride, n, cols, ncols, cnt, npad);
-    sh_bitonic<T>(v, npad);
+    if (!SORTED) {
+        sh_stage<T>(v, X + (int64_t)blockIdx.x * sig_stride, n, cols, ncols, cnt, npad);
+        sh_bitonic<T>(v, npad);
+    }
     // orth2relerror: squares sorted downwards, sum, |sum - cumsum|^0.5 / sum^0.5; r_k lands at curve position cnt - k
     auto sq_desc = [&](int e) { const T a = v[cnt - 1 - e] * v[cnt - 1 - e]; return a; };
     const T total = sh_scan<T>(cnt, S.part, sq_desc, [&](int e, T run) { w[cnt - 1 - e] = run; });
@@ -201,11 +261,10 @@ int api_shrink(int kind, const T *X, int64_t n, int64_t k, int64_t batch, const 
     const int64_t ncols = colmask ? (int64_t)cols.size() : k;
     const int64_t cnt = n * ncols;
     WX_REQUIRE(cnt >= 1, WX_EARG, "no coefficient selected");
-    // one workgroup sorts one signal's selection (bitonic, in LDS up to 8192 Float64 values, in a global scratch window above):
-    // log2(npad)^2 / 2 barrier-bound passes, i.e. seconds per signal beyond a million coefficients -- refused instead
-    WX_REQUIRE(cnt <= ((int64_t)1 << 20), WX_EUNSUPPORTED,
-               "threshold selection over more than 2^20 coefficients per signal (redundant tables with many leaf columns): "
-               "select on fewer columns or a shallower tree");
+    // one workgroup sorts one signal's selection in LDS (up to 8192 Float64 values) or in a global scratch window (WX_SHRINK_WG_MAX, a knob: nothing by default);
+    // larger selections -- redundant tables with many leaf columns -- sort with launches over the whole chip (round 4: until then
+    // 2^20 coefficients per signal were the limit, and the window path above 2^16 took seconds per signal)
+    WX_REQUIRE(cnt <= ((int64_t)1 << 27), WX_EUNSUPPORTED, "threshold selection over more than 2^27 coefficients per signal");
     int rc;
     if ((rc = need_device())) return rc;
     if (batch == 0) return WX_OK;
@@ -239,8 +298,33 @@ int api_shrink(int kind, const T *X, int64_t n, int64_t k, int64_t batch, const 
         gs = (T *)scr.alloc(win * per);
         if (!gs) return io.finish(WX_EHIP);
     }
+    static const int64_t wg_max = getenv("WX_SHRINK_WG_MAX") ? atoll(getenv("WX_SHRINK_WG_MAX")) : ((int64_t)1 << 13);     // (2^16 values, 4 signals: 7.7 ms in the window, under 3 ms with launches)
+    const bool chip_sort = !in_lds && npad > wg_max && npad >= 2 * SH_CH;
     for (int64_t b0 = 0; b0 < batch; b0 += per) {
         const int64_t nb = batch - b0 < per ? batch - b0 : per;
+        if (chip_sort) {
+            const unsigned gx = (unsigned)((npad / 2 + SH_NT - 1) / SH_NT < 65535 ? (npad / 2 + SH_NT - 1) / SH_NT : 65535);
+            for (int64_t s0 = 0; s0 < nb; s0 += 65535) {                  // gridDim.y limit
+                const unsigned ns = (unsigned)(nb - s0 < 65535 ? nb - s0 : 65535);
+                T *g0 = gs + s0 * (2 * npad + 8);
+                hipLaunchKernelGGL(k_sh_stage_g<T>, dim3(gx, ns), dim3(SH_NT), 0, st, dX + (b0 + s0) * n * k, n * k, (int)n, dcols, (int)cnt,
+                                   (int)npad, g0);
+                hipLaunchKernelGGL((k_sh_bitonic_lds<T, true>), dim3((unsigned)(npad / SH_CH), ns), dim3(SH_NT), 0, st, g0, (int)npad, 0);
+                for (int64_t kk = 2 * SH_CH; kk <= npad; kk <<= 1) {
+                    for (int64_t j = kk >> 1; j >= SH_CH; j >>= 1)
+                        hipLaunchKernelGGL(k_sh_bitonic_g<T>, dim3(gx, ns), dim3(SH_NT), 0, st, g0, (int)npad, (int)kk, (int)j);
+                    hipLaunchKernelGGL((k_sh_bitonic_lds<T, false>), dim3((unsigned)(npad / SH_CH), ns), dim3(SH_NT), 0, st, g0, (int)npad, (int)kk);
+                }
+            }
+            if (kind == 0)
+                hipLaunchKernelGGL((k_surethreshold<T, true>), dim3((unsigned)nb), dim3(SH_NT), 0, st, dX + b0 * n * k, n * k, (int)n,
+                                   dcols, (int)ncols, (int)cnt, (int)npad, gs, dt + b0);
+            else
+                hipLaunchKernelGGL((k_relerrorthreshold<T, true>), dim3((unsigned)nb), dim3(SH_NT), 0, st, dX + b0 * n * k, n * k, (int)n,
+                                   dcols, (int)ncols, (int)cnt, (int)npad, elbows, gs, dt + b0);
+            if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "threshold selection kernel failed to launch"));
+            continue;
+        }
         if (kind == 0)
             hipLaunchKernelGGL(k_surethreshold<T>, dim3((unsigned)nb), dim3(SH_NT), in_lds ? win : 0, st, dX + b0 * n * k, n * k, (int)n,
                                dcols, (int)ncols, (int)cnt, (int)npad, gs, dt + b0);
