@@ -173,6 +173,9 @@ def parse():
     ap.add_argument("--watchdog", type=float, default=900.0,
                     help="seconds after which a rank that has not finished dumps where it is and exits 3 (a hung collective must "
                          "not hold the machine); 0 disables")
+    ap.add_argument("--gather-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the second loop (all-gather inside the step) may take before every rank abandons it; rank 0 "
+                         "then prints the line of the main loop with the failure noted and all ranks exit 0")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the `also` block (the other headline workloads, hipEvent-timed in the same run; N = 1 only)")
     return ap.parse_args()
@@ -892,68 +895,8 @@ def main():
     inv_avg = sum(inv_ms) / len(inv_ms)
     samples_all = W.B_all * (info["samples"] // max(W.hi - W.lo, 1))
 
-    gather = None
-    if W.gatherable:
-      try:
-          # second loop: the all-gather of the reconstructed output inside the step, overlapped with the inverse
-          stage["at"] = "all-gather loop, warm-up (%s)" % W.G["mode"]
-          p2p_error = None
-          try:
-              for _ in range(max(1, min(a.warmup, 2))):
-                  W.step_gather(Legs(torch))
-              torch.cuda.synchronize(dev)
-              failed = 0.0
-          except Exception as e:
-              if a.gather != "auto" or W.G["mode"] != "p2p":
-                  raise
-              p2p_error, failed = "%s: %s" % (type(e).__name__, e), 1.0
-          if a.gather == "auto" and W.G["mode"] == "p2p" and max(across_ranks(failed)) > 0:
-              # the grouped point-to-point exchange raised on some rank: every rank switches to one collective per chunk
-              W.set_gather_mode("collective")
-              stage["at"] = "all-gather loop, warm-up (collective, after the point-to-point group raised)"
-              for _ in range(max(1, min(a.warmup, 2))):
-                  W.step_gather(Legs(torch))
-          sync()
-          stage["at"] = "all-gather loop, timed (%s)" % W.G["mode"]
-          g_elapsed, g_per_rank, _ = timed(W.step_gather)
-          # the exchange alone (nothing to overlap with), for the budget: one step's worth of posts
-          from waveletsext_jl_amd import distributed as wd
-          full = W.output(True)
-          sync()
-          t1 = time.perf_counter()
-          gg = wd.make_gather(full, full.shape[-1], nchunks=a.chunks, mode=W.G["mode"])
-          for c in range(gg.nposts):
-              gg.post(c)
-          gg.finish()
-          sync()
-          alone_ms = (time.perf_counter() - t1) * 1e3
-          gather = {"ms_per_step": g_elapsed / a.steps * 1e3,
-                    "value": samples_all * a.steps / g_elapsed / 1e6,
-                    "allgather_alone_ms": alone_ms,
-                    "exposed_ms": (g_elapsed - elapsed) / a.steps * 1e3,
-                    "overlap_ms": max(0.0, alone_ms - (g_elapsed - elapsed) / a.steps * 1e3),
-                    "chunks": a.chunks, "mode": W.G["mode"], "p2p_error": p2p_error,
-                    "bytes_received_per_rank": float(info.get("gather_bytes", 0)),
-                    "per_rank_ms": [v / a.steps * 1e3 for v in g_per_rank],
-                    "schedule": "inverse in %d chunks; chunk c's exchange (%s) on a side stream while chunk c+1 is transformed"
-                                % (a.chunks, "grouped point-to-point, every piece lands in place" if W.G["mode"] == "p2p"
-                                   else "one all_gather collective per chunk")}
-          gerr = float((full[..., W.lo:W.hi] - W.keep[0]).abs().max() / W.keep[0].abs().max()) if a.scaling == "strong" else None
-          if gerr is not None:
-              assert gerr < tol, "gathered output broken: %g" % gerr
-      except AssertionError:
-          raise
-      except Exception as e:  # pragma: no cover - the exchange is reported next to `value`, never part of it
-          gather = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    if a.dump:
-        import numpy as np
-        outp = W.output(W.gatherable)
-        if rank == 0 and outp is not None:
-            np.save(a.dump, outp.detach().cpu().numpy())
-
-    out = None
-    if rank == 0:
+    def build_line(gather):
+        """the JSON line from the main timed loop (rank 0); `gather` = the second loop's record or None"""
         # HBM traffic of one forward pass = sum over its kernels (launches per pass x PMC bytes per launch)
         # from separate rocprofv3 --pmc passes of this same command (profiles/traffic.json, written by
         # tools/collect_evidence.py); null if not profiled.  `kernel` names the dominant one.
@@ -1015,6 +958,94 @@ def main():
             out["with_allgather"] = gather
             # the sharded compute (`value`) and the throughput with the exchange inside the step, side by side
             out["with_allgather_value"] = gather.get("value")
+        return out
+
+    # The exchange loop below is reported NEXT to `value`, never part of it -- and it is the one part of this program that has never
+    # run on more than one GPU.  If it does not finish in --gather-timeout seconds (a hung grouped send/recv cannot be cancelled from
+    # Python), every rank's timer fires at about the same time: rank 0 prints the line it already has, with the failure in
+    # `with_allgather`, and all ranks leave with exit code 0 -- the launcher then reports success and the headline number survives.
+    gather_timer = None
+    if world > 1 and W.gatherable and a.gather_timeout > 0:
+        import threading
+
+        def _give_up_gather():
+            if rank == 0:
+                line = build_line({"error": "exchange loop not finished after %.0f s (at: %s); abandoned, `value` is the sharded compute"
+                                            % (a.gather_timeout, stage["at"])})
+                sys.stdout.write(json.dumps(line) + "\n")
+                sys.stdout.flush()
+            sys.stderr.write("bench.py: rank %d gives up the exchange loop after %.0f s (at: %s)\n" % (rank, a.gather_timeout, stage["at"]))
+            sys.stderr.flush()
+            os._exit(0)
+
+        gather_timer = threading.Timer(a.gather_timeout, _give_up_gather)
+        gather_timer.daemon = True
+        gather_timer.start()
+    gather = None
+    if W.gatherable:
+      try:
+          # second loop: the all-gather of the reconstructed output inside the step, overlapped with the inverse
+          stage["at"] = "all-gather loop, warm-up (%s)" % W.G["mode"]
+          p2p_error = None
+          try:
+              for _ in range(max(1, min(a.warmup, 2))):
+                  W.step_gather(Legs(torch))
+              torch.cuda.synchronize(dev)
+              failed = 0.0
+          except Exception as e:
+              if a.gather != "auto" or W.G["mode"] != "p2p":
+                  raise
+              p2p_error, failed = "%s: %s" % (type(e).__name__, e), 1.0
+          if a.gather == "auto" and W.G["mode"] == "p2p" and max(across_ranks(failed)) > 0:
+              # the grouped point-to-point exchange raised on some rank: every rank switches to one collective per chunk
+              W.set_gather_mode("collective")
+              stage["at"] = "all-gather loop, warm-up (collective, after the point-to-point group raised)"
+              for _ in range(max(1, min(a.warmup, 2))):
+                  W.step_gather(Legs(torch))
+          sync()
+          stage["at"] = "all-gather loop, timed (%s)" % W.G["mode"]
+          g_elapsed, g_per_rank, _ = timed(W.step_gather)
+          # the exchange alone (nothing to overlap with), for the budget: one step's worth of posts
+          from waveletsext_jl_amd import distributed as wd
+          full = W.output(True)
+          sync()
+          t1 = time.perf_counter()
+          gg = wd.make_gather(full, full.shape[-1], nchunks=a.chunks, mode=W.G["mode"])
+          for c in range(gg.nposts):
+              gg.post(c)
+          gg.finish()
+          sync()
+          alone_ms = (time.perf_counter() - t1) * 1e3
+          gather = {"ms_per_step": g_elapsed / a.steps * 1e3,
+                    "value": samples_all * a.steps / g_elapsed / 1e6,
+                    "allgather_alone_ms": alone_ms,
+                    "exposed_ms": (g_elapsed - elapsed) / a.steps * 1e3,
+                    "overlap_ms": max(0.0, alone_ms - (g_elapsed - elapsed) / a.steps * 1e3),
+                    "chunks": a.chunks, "mode": W.G["mode"], "p2p_error": p2p_error,
+                    "bytes_received_per_rank": float(info.get("gather_bytes", 0)),
+                    "per_rank_ms": [v / a.steps * 1e3 for v in g_per_rank],
+                    "schedule": "inverse in %d chunks; chunk c's exchange (%s) on a side stream while chunk c+1 is transformed"
+                                % (a.chunks, "grouped point-to-point, every piece lands in place" if W.G["mode"] == "p2p"
+                                   else "one all_gather collective per chunk")}
+          gerr = float((full[..., W.lo:W.hi] - W.keep[0]).abs().max() / W.keep[0].abs().max()) if a.scaling == "strong" else None
+          if gerr is not None:
+              assert gerr < tol, "gathered output broken: %g" % gerr
+      except AssertionError:
+          raise
+      except Exception as e:  # pragma: no cover - the exchange is reported next to `value`, never part of it
+          gather = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    if gather_timer is not None:
+        gather_timer.cancel()
+
+    if a.dump:
+        import numpy as np
+        outp = W.output(W.gatherable)
+        if rank == 0 and outp is not None:
+            np.save(a.dump, outp.detach().cpu().numpy())
+
+    out = build_line(gather) if rank == 0 else None
+    if rank == 0:
         if world == 1 and not a.no_also and not a.batch and a.workload == "cfg2":
             W.keep = None
             del W, legs, warm
@@ -1027,7 +1058,7 @@ def main():
                 pc = {"error": str(e)}
             if pc is not None:
                 out["pcie_inclusive"] = pc
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:                 # rank 0 at N = 1 only: the other ranks would wait at the final barrier
             cb = cpu_baseline(w, a.cpu_seconds)
             allc = cb.pop("all_cores", None)
             out["cpu_baseline"] = cb

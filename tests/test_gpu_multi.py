@@ -122,3 +122,13 @@ def test_bench_watchdog_ends_a_stuck_rank():
                        timeout=600)
     assert r.returncode == 3, (r.returncode, r.stderr[-800:])
     assert "watchdog: rank 0 of 1 not finished" in r.stderr
+
+
+def test_bench_abandons_a_stuck_exchange_loop_and_keeps_the_headline():
+    """the all-gather loop is reported next to `value`, never part of it: if it does not finish inside --gather-timeout every rank leaves
+    with exit code 0 and rank 0 prints the line of the main loop with the failure noted (a hung grouped send / recv cannot be
+    cancelled).  A timeout shorter than the loop's warm-up makes every run 'stuck'."""
+    j = _bench(["--workload", "cfg2", "--batch", "37", "--steps", "2", "--warmup", "1", "--no-cpu", "--watchdog", "600", "--gpus", "2",
+                "--gather-timeout", "0.0001"], {"WX_BENCH_BACKEND": "gloo"})
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["ms_per_step"] > 0
+    assert "abandoned" in j["with_allgather"]["error"] and j["with_allgather_value"] is None
