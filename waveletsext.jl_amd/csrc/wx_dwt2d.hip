@@ -477,18 +477,25 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
 // 512 x 512 Float64 images: 21 ms per GiB, 1 % of the HBM peak).
 template <typename T> static void wx_rows_geometry(int64_t n, int &R, int &S)
 {
-    if (sizeof(T) == 4) { R = 32; S = 32; } else { R = 16; S = 24; }
+    // Strips of 256 bytes per column (64 Float32 / 32 Float64 rows) where the two LDS images fit, halved until they do; low strips get a
+    // quarter of padding on the pitch when that still fits (bank conflicts between the columns of a window).  Measured in round 4
+    // (tools/dbg/rows_sweep.sh, full depth, ms per GiB fwd / inv): Float64 256 columns (16, 24) 1.00 / 0.94 -> (32, 32) 0.83 / 0.79; Float32
+    // 64 columns (32, 32) 1.02 / 0.94 -> (64, 64) 0.83 / 0.77; Float32 1024 columns (16, 16) 1.67 / 1.14 -> (16, 20) 1.34 / 1.18.
+    constexpr int VW = 16 / (int)sizeof(T);
+    R = 256 / (int)sizeof(T);
+    S = R;
     // tuning knobs (strip height, a power of two, and LDS column pitch >= R)
     const char *er = getenv("WX_ROWS_R"), *es = getenv("WX_ROWS_S");
     if (er && es) {
         const int r = atoi(er), s2 = atoi(es);
         if (r >= 4 && r <= 64 && (r & (r - 1)) == 0 && s2 >= r && s2 <= 128) { R = r; S = s2; }
     }
-    constexpr int VW = 16 / (int)sizeof(T);
     while (R > VW && (size_t)2 * n * S * sizeof(T) > 160 * 1024) {
         R >>= 1;
-        S = sizeof(T) == 4 ? R : R + R / 2;
+        S = R;
     }
+    if (!(er && es) && R <= 16 && R >= 8 && (size_t)2 * n * (R + R / 4) * sizeof(T) <= 160 * 1024 && (R + R / 4) % VW == 0)
+        S = R + R / 4;
 }
 
 template <typename T> bool wx_wpt2d_fast_ok(int64_t m, int64_t n, int F)
