@@ -974,6 +974,7 @@ struct WxTileTree {                       // tree-driven level: see k_dwt2d_leve
 };
 
 template <typename T> static constexpr int wx_tile_cc() { return sizeof(T) == 4 ? 64 : 32; }
+static constexpr int WX_ITILE_CC = 32;                   // columns of a tile of the inverse level kernels (both types)
 static constexpr int WX_TILE_CR = 64;
 
 template <typename T, int F, int CR, int CC>
@@ -1369,7 +1370,7 @@ static bool wx_launch_ilevel_tile_F(const T *src_leaf, int64_t leaf_img, const T
     if (tiles == 0) return true;
     static const int persist = getenv("WX_TILE_PERSIST") ? atoi(getenv("WX_TILE_PERSIST")) : 1;
     constexpr int NBP = (4 * HRm * HCm + 255) / 256;
-    if (persist && NBP <= 24 && F <= (sizeof(T) == 8 ? 8 : 6) && by_node) {     // (Float32 at 8 taps spills 124 bytes per lane at three wavefronts per SIMD: 1.5 -> 1.8 ms)
+    if (persist && NBP <= 24 && F <= 8 && sizeof(T) == 8 && by_node) {          // (Float32: no gain, 1.32 vs 1.34 ms: instruction-bound)     // (Float32 at 8 taps spills 124 bytes per lane at three wavefronts per SIMD: 1.5 -> 1.8 ms)
         auto kp = k_idwt2d_level_tile_p<T, F, CR, CC>;
         if (lds > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1399,7 +1400,9 @@ static bool wx_launch_ilevel_tile(const T *src_leaf, int64_t leaf_img, const T *
                                   int n, int d, int64_t batch, const WxFilt &filt, hipStream_t st, const WxTileTree &tt)
 {
     if (!wx_level_tile_ok<T>(m, n, d, filt.F) || !tt.status) return false;
-    constexpr int CR = WX_TILE_CR, CC = wx_tile_cc<T>();
+    // (Float32: 32 columns per tile like Float64 -- half the prefetched samples per lane, so the persistent form fits three wavefronts
+    // per SIMD without spilling)
+    constexpr int CR = WX_TILE_CR, CC = WX_ITILE_CC;
     switch (filt.F) {
 #define WX_CASE(FF) case FF: return wx_launch_ilevel_tile_F<T, FF, CR, CC>(src_leaf, leaf_img, src_int, dst, dst_img, m, n, d, batch, filt, st, tt);
         WX_CASE(2) WX_CASE(4) WX_CASE(6) WX_CASE(8) WX_CASE(10) WX_CASE(12) WX_CASE(14) WX_CASE(16) WX_CASE(18) WX_CASE(20)
