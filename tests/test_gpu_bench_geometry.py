@@ -220,3 +220,55 @@ def test_config4_lattice_and_lds_kernels_agree():
             outs.append((np.load(f1), np.load(f2)))
         assert relerr(outs[0][0], outs[1][0]) <= 2e-6
         assert relerr(outs[0][1], outs[1][1]) <= 2e-6
+
+
+@pytest.mark.parametrize("m,LD,B", [(256, 5, 3), (256, 5, 4), (512, 6, 2), (1024, 7, 1)])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "coif2", "db8", "db10"])
+def test_2d_lattice_deeper_than_the_lattice_levels(wx, oracle, m, LD, B, wname):
+    """Depths LD + 1 ... LD + 3 on the three lattice geometries -- the FULL depth, the reference's default L = maxtransformlevels
+    (DWT.jl:500-548, 662-710), included: the lattice rotates down to nodes of 8 x 8 and the remaining levels are one orthogonal 8 x 8
+    matrix per node, applied in the store phase of the forward pass and (transposed) in the load phase of the inverse pass
+    (csrc/wx_lattice2d.h, WxL2M; round 4).  Forward against the oracle per image, inverse of the oracle's coefficients against its input;
+    odd and even batches for the two-images-per-column geometry."""
+    rng = np.random.default_rng(m + len(wname))
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    x = np.asfortranarray(rng.standard_normal((m, m, B)).astype(np.float32))
+    for L in ((LD + 1, LD + 2, LD + 3) if m < 1024 else (LD + 3,)):
+        exp = oracle.wptall(x.astype(np.float64), wt.qmf, L)
+        got = wx.wptall(x, wt, L)
+        assert got.dtype == np.float32
+        for b in range(B):
+            assert relerr(got[:, :, b].astype(np.float64), exp[:, :, b]) <= 3e-6, (m, wname, L, b)
+        back = wx.iwptall(exp.astype(np.float32), wt, L)
+        for b in range(B):
+            assert relerr(back[:, :, b].astype(np.float64), x[:, :, b].astype(np.float64)) <= 3e-6, (m, wname, L, b)
+
+
+def test_2d_lattice_full_depth_is_the_lattice_path_and_deterministic(wx):
+    """full-depth transforms of a chip-filling batch: bit-identical across launches, every image round-trips, and the deep path agrees
+    with the generic two-pass path (WX_LATTICE2D_DEEP=0 in a child process) to Float32 rounding"""
+    import os
+    import subprocess
+    import sys
+    import torch
+    wt = wx.wavelet(wx.WT.db4)
+    for m, L, B in ((512, 9, 257), (256, 8, 1001)):
+        x = wx.jl_empty((m, m, B), torch.float32, "cuda")
+        x.normal_(generator=torch.Generator(device="cuda").manual_seed(m))
+        y0 = wx.wptall(x, wt, L)
+        y = wx.wptall(x, wt, L)
+        assert torch.equal(y, y0)
+        xr = wx.iwptall(y, wt, L)
+        err = (xr - x).abs().amax(dim=(0, 1)) / x.abs().max()
+        assert float(err.max()) <= 3e-6, (m, int(err.argmax()), float(err.max()))
+    code = ("import numpy as np, waveletsext_jl_amd as wx\n"
+            "rng = np.random.default_rng(3); x = np.asfortranarray(rng.standard_normal((512, 512, 2)).astype(np.float32))\n"
+            "y = wx.wptall(x, wx.wavelet(wx.WT.db4), 9); np.save(%r, y)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for deep in ("1", "0"):
+        f = os.path.join(root, "gpurun_out", "deep_%s.npy" % deep)
+        os.makedirs(os.path.dirname(f), exist_ok=True)
+        subprocess.check_call([sys.executable, "-c", code % f], env=dict(os.environ, WX_LATTICE2D_DEEP=deep), cwd=root)
+        outs.append(np.load(f).astype(np.float64))
+    assert relerr(outs[0], outs[1]) <= 3e-6 and not np.array_equal(outs[0], outs[1])

@@ -591,7 +591,7 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
         // 512 x 512 Float32, depth 6: the transposing lattice kernel applied twice (wx_lattice2d.hip)
         if (wx_lattice2d_ok(m, n, L, filt, sizeof(T)) && in_img == mn && !(inverse && getenv("WX_LATTICE2D_NOINV"))) {
             if (getenv("WX_LATTICE2D_DEBUG")) {                  // diagnostics: one pass only, straight into y
-                const int rd = wx_lattice2d_colT_f32((const float *)x, (float *)y, m, batch, filt, inverse, 0, st);
+                const int rd = wx_lattice2d_colT_f32((const float *)x, (float *)y, m, L, batch, filt, inverse, 0, st);
                 return rd == 1 ? WX_OK : WX_EHIP;
             }
             // WX_2D_STREAMS=1 with a sub-batch size: column pass of sub-batch k+1 and row pass of sub-batch k on two side
@@ -622,11 +622,11 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
                     const int slot = (int)(kk % 3);
                     T *ring = tmp + (int64_t)slot * S * mn;
                     if (kk >= 3) WX_HIP_CHECK(hipStreamWaitEvent(sA, evR[slot], 0));
-                    if (wx_lattice2d_colT_f32((const float *)x + b0 * mn, (float *)ring, m, nb, filt, inverse, 1, sA) != 1)
+                    if (wx_lattice2d_colT_f32((const float *)x + b0 * mn, (float *)ring, m, L, nb, filt, inverse, 1, sA) != 1)
                         return wx_set_error(WX_EHIP, "lattice2d: pass refused");
                     WX_HIP_CHECK(hipEventRecord(evC[slot], sA));
                     WX_HIP_CHECK(hipStreamWaitEvent(sB, evC[slot], 0));
-                    if (wx_lattice2d_colT_f32((const float *)ring, (float *)y + b0 * mn, m, nb, filt, inverse, 2, sB) != 1)
+                    if (wx_lattice2d_colT_f32((const float *)ring, (float *)y + b0 * mn, m, L, nb, filt, inverse, 2, sB) != 1)
                         return wx_set_error(WX_EHIP, "lattice2d: second pass refused");
                     WX_HIP_CHECK(hipEventRecord(evR[slot], sB));
                 }
@@ -637,10 +637,10 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
             bool took = true;
             for (int64_t b0 = 0; b0 < batch && took; b0 += S) {
                 const int64_t nb = (batch - b0 < S) ? batch - b0 : S;
-                const int r1 = wx_lattice2d_colT_f32((const float *)x + b0 * mn, (float *)tmp, m, nb, filt, inverse, 1, st);
+                const int r1 = wx_lattice2d_colT_f32((const float *)x + b0 * mn, (float *)tmp, m, L, nb, filt, inverse, 1, st);
                 if (r1 < 0) return r1;
                 if (r1 == 0) { if (b0) return wx_set_error(WX_EHIP, "lattice2d: pass refused"); took = false; break; }
-                const int r2 = wx_lattice2d_colT_f32((const float *)tmp, (float *)y + b0 * mn, m, nb, filt, inverse, 2, st);
+                const int r2 = wx_lattice2d_colT_f32((const float *)tmp, (float *)y + b0 * mn, m, L, nb, filt, inverse, 2, st);
                 if (r2 != 1) return r2 < 0 ? r2 : wx_set_error(WX_EHIP, "lattice2d: second pass refused");
             }
             if (took) return WX_OK;

@@ -166,7 +166,7 @@ int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t b
 
 // 512 x 512 Float32 images, depth 6: one transposing lattice pass (wx_lattice2d.hip); 0 = not applicable, 1 = launched
 bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz);
-int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t m, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st);
+int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t m, int L, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st);
 
 // the deep levels of the pyramid in the registers of a lane (wx_dwttail.hip)
 int wx_dwt_tail_levels(int64_t n, int L, int F, size_t esz);

@@ -53,6 +53,13 @@ struct WxLat2 {
     float kap[WX_L2_MAXS];
     float g0, g2;
 };
+// The levels below the lattice's (nodes of 8 samples: up to three more) as ONE orthogonal 8 x 8 matrix per node: m[r][c] = coefficient r
+// (wpt layout of a full tree of depth e on 8 samples) from sample c, periodic inside the node like dwt_step! on a node of 8, 4, 2
+// samples (dwt/dwt_one_level.jl:94-105).  The forward pass applies it in its store phase, the inverse pass its transpose in the load phase.
+struct WxL2M {
+    float m[8][8];
+    int e;                                // 0: the lattice's depth exactly, no matrix
+};
 
 namespace {
 
@@ -326,7 +333,7 @@ __device__ __forceinline__ void l2_t2(f2 (&a)[64], f2 (&bb)[64], unsigned lds0, 
 // dst[j + 512 o(i)], o(i) = bitreverse6(i[5:0]) << 3 | i[8:6].  grid (16, images), 128 threads.
 template <int NS, bool BL, bool BS, int HB>
 __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_colT_f32(
-    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf)
+    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf, WxL2M mm)
 {
     typedef L2G<HB> G;
     __shared__ double lds[WX_L2D_W * WX_L2_WIN];
@@ -414,16 +421,41 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
                 l2_wr64<8 * RS * rowreg>(wa, val);
             });
             l2_barrier();
+            auto row_o = [&](int rr) {                    // o = i0 i1 i2 i3 i4 i5 i6 | i9 i8 i7 (bit 9 .. bit 0)
+                return ((rr >> 2) & 1) | ((rr & 1) << 1) | (((rr >> 1) & 1) << 2) | (((rr >> 3) & 1) << 3) | (((rr >> 4) & 1) << 4) |
+                       (((rr >> 5) & 1) << 5) | ((rho >> 1) << 6) | ((rho & 1) << 7) | (((rr >> 6) & 1) << 8) | ((rr >> 7) << 9);
+            };
+            auto row_ld = [&](int rr, int u) {
+                const int s9 = (rr >> 1) & 1;
+                return *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (4 * s9))));
+            };
+            if (mm.e) {
+                // the levels below depth 7: a thread takes the 8 rows of a node (o bits 2..0 = rr bits 1, 0, 2) for its column pairs
+                const int g = tid / LPR, u = tid % LPR;
+                f4 in[8], out[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) in[e] = row_ld(8 * g + (4 * (e & 1) + ((e >> 1) & 1) + 2 * (e >> 2)), u);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    f4 acc = mm.m[r][0] * in[0];
+#pragma unroll
+                    for (int c = 1; c < 8; ++c) acc += mm.m[r][c] * in[c];
+                    out[r] = acc;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int o = row_o(8 * g + (4 * (e & 1) + ((e >> 1) & 1) + 2 * (e >> 2)));
+                    l2_st(l2_sbase(dimg + (BS ? G::BLK : G::BW) * blockIdx.x) + (unsigned)((BS ? G::BW : G::R) * o + 4 * u), out[e]);
+                }
+            } else {
             l2_for<256 / RPI>([&](auto Kq) {
                 constexpr int k = Kq;
                 const int rr = RPI * k + tid / LPR, u = tid % LPR;
-                const int s9 = (rr >> 1) & 1;
-                const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (4 * s9))));
-                // o = i0 i1 i2 i3 i4 i5 i6 | i9 i8 i7 (bit 9 .. bit 0)
-                const int o = ((rr >> 2) & 1) | ((rr & 1) << 1) | (((rr >> 1) & 1) << 2) | (((rr >> 3) & 1) << 3) | (((rr >> 4) & 1) << 4) |
-                              (((rr >> 5) & 1) << 5) | ((rho >> 1) << 6) | ((rho & 1) << 7) | (((rr >> 6) & 1) << 8) | ((rr >> 7) << 9);
+                const f4 val = row_ld(rr, u);
+                const int o = row_o(rr);
                 l2_st(l2_sbase(dimg + (BS ? G::BLK : G::BW) * blockIdx.x) + (unsigned)((BS ? G::BW : G::R) * o + 4 * u), val);
             });
+            }
             l2_barrier();
         });
         return;
@@ -447,22 +479,55 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             l2_wr64<8 * RS * rowreg>(wa, val);
         });
         l2_barrier();
+        // row bits: i6 = rr0, i7 = rr1, i8 = rr2, i5 = rr3, i4 = rr4, i1 = rr5, i0 = rr6, i2 = rho0, i3 = rho1;
+        // o = bitreverse(i[LD-1:0]) above i[RB-1:LD]; HB = 1: i8 selects the image
+        auto row_o = [&](int rr, int &im) {
+            im = 0;
+            if constexpr (HB == 0) return (rr & 31) | ((rho >> 1) << 5) | ((rho & 1) << 6) | ((rr >> 5) << 7);
+            else {
+                im = (rr >> 2) & 1;
+                return ((rr >> 3) & 1) | ((rr & 3) << 1) | (((rr >> 4) & 1) << 3) | ((rho >> 1) << 4) | ((rho & 1) << 5) | (((rr >> 5) & 1) << 6) |
+                       ((rr >> 6) << 7);
+            }
+        };
+        auto row_ld = [&](int rr, int u) {
+            const int o2 = (rr >> 2) & 1;
+            return *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (8 * o2))));
+        };
+        if (mm.e) {
+            // the levels below the lattice's depth: a thread takes the 8 rows of a node for its column pairs.  HB = 0: the node's
+            // samples are rows 8 g .. 8 g + 7 in order; HB = 1: o bits 2..0 = rr bits 1, 0, 3, the image bit rr2 belongs to the group
+            const int g = tid / LPR, u = tid % LPR;
+            auto node_row = [&](int e) {
+                if constexpr (HB == 0) return 8 * g + e;
+                else return ((e >> 1) & 1) | ((e >> 2) << 1) | ((g & 1) << 2) | ((e & 1) << 3) | ((g >> 1) << 4);
+            };
+            f4 in[8], out[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) in[e] = row_ld(node_row(e), u);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                f4 acc = mm.m[r][0] * in[0];
+#pragma unroll
+                for (int c = 1; c < 8; ++c) acc += mm.m[r][c] * in[c];
+                out[r] = acc;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int im;
+                const int o = row_o(node_row(e), im);
+                l2_st(l2_sbase(dimg + (BS ? G::BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * o + 4 * u), out[e]);
+            }
+        } else {
         l2_for<128 / RPI>([&](auto Kq) {
             constexpr int k = Kq;
             const int rr = RPI * k + tid / LPR, u = tid % LPR;
-            const int o2 = (rr >> 2) & 1;
-            const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (8 * o2))));
-            // row bits: i6 = rr0, i7 = rr1, i8 = rr2, i5 = rr3, i4 = rr4, i1 = rr5, i0 = rr6, i2 = rho0, i3 = rho1;
-            // o = bitreverse(i[LD-1:0]) above i[RB-1:LD]; HB = 1: i8 selects the image
-            int o, im = 0;
-            if constexpr (HB == 0) o = (rr & 31) | ((rho >> 1) << 5) | ((rho & 1) << 6) | ((rr >> 5) << 7);
-            else {
-                o = ((rr >> 3) & 1) | ((rr & 3) << 1) | (((rr >> 4) & 1) << 3) | ((rho >> 1) << 4) | ((rho & 1) << 5) | (((rr >> 5) & 1) << 6) |
-                    ((rr >> 6) << 7);
-                im = (rr >> 2) & 1;
-            }
+            const f4 val = row_ld(rr, u);
+            int im;
+            const int o = row_o(rr, im);
             l2_st(l2_sbase(dimg + (BS ? G::BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * o + 4 * u), val);
         });
+        }
         l2_barrier();
     });
 }
@@ -503,7 +568,7 @@ __device__ __forceinline__ void l2_t2i(f2 (&bb)[64], f2 (&a)[64], unsigned lds0,
 // dst image transposed, natural order: dst[j + 512 i].  grid (16, images), 128 threads.
 template <int NS, bool BL, bool BS, int HB>
 __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_icolT_f32(
-    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf)
+    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf, WxL2M mm)
 {
     typedef L2G<HB> G;
     __shared__ double lds[HB == 2 ? (256 * 18 > WX_L2D_W * WX_L2_WIN ? 256 * 18 : WX_L2D_W * WX_L2_WIN) : WX_L2D_W * WX_L2_WIN];
@@ -528,6 +593,31 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             constexpr int cp = Q / QS, sq = Q % QS;
             r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL, HB>(j0 + 2 * cp, 128 * sq)) + lo);
         });
+        if (mm.e) {
+            // undo the levels below the lattice's depth first: the 8 coefficients of a node are 8 consecutive floats of the column -- this
+            // lane's vector and its neighbour's (lane ^ 1: sub bit 0 is memory index bit 2); x = M^T y
+            const bool up = lane & 1;
+            // per lane: column k of the two 4 x 4 blocks that act on its own vector and on the neighbour's (vector operations: the
+            // kernel has about 6000 SIMD cycles per wavefront in all, a scalar form of this product doubled its time)
+            f4 Ac[4], Bc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    Ac[k][c] = up ? mm.m[k + 4][c + 4] : mm.m[k][c];
+                    Bc[k][c] = up ? mm.m[k][c + 4] : mm.m[k + 4][c];
+                }
+            l2_for<32>([&](auto Q) {
+                const f4 mine = r[Q];
+                f4 oth;
+                oth.x = __shfl_xor(mine.x, 1); oth.y = __shfl_xor(mine.y, 1); oth.z = __shfl_xor(mine.z, 1); oth.w = __shfl_xor(mine.w, 1);
+                f4 res = Ac[0] * mine.x + Bc[0] * oth.x;
+                res += Ac[1] * mine.y + Bc[1] * oth.y;
+                res += Ac[2] * mine.z + Bc[2] * oth.z;
+                res += Ac[3] * mine.w + Bc[3] * oth.w;
+                r[Q] = res;
+            });
+        }
         // into layout B (reg i[7:2], lane mu = i8 | cp << 1 | i0 << 4 | i1 << 5): a round (the component of the loaded
         // vectors) fixes two register bits, the lane reads its 16 other registers out of row mu: slot = 17 mu + w
         //   HB = 0: round = (i6, i7) = register bits 4, 5;  w = i2 | i3 << 1 | i4 << 2 | i5 << 3 = register bits 0 .. 3
@@ -685,7 +775,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
 // launch of one transposing pass for geometry HB (0: 512 x 512, 1: 256 x 256, 2: 1024 x 1024): one translation unit per geometry
 // (wx_lattice2d.hip, wx_lattice2d_256.hip, wx_lattice2d_1024.hip) so that the 60 kernels of each compile in parallel
 template <int HB>
-static int wx_lattice2d_launch(const float *src, float *dst, int64_t m, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
+static int wx_lattice2d_launch(const float *src, float *dst, int64_t m, int L, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
 {
     static const bool blocked = WX_L2D_W == 4 && !(getenv("WX_L2D_BLOCKED") && atoi(getenv("WX_L2D_BLOCKED")) == 0);
     constexpr int LD = L2G<HB>::LD;
@@ -695,6 +785,32 @@ static int wx_lattice2d_launch(const float *src, float *dst, int64_t m, int64_t 
     for (int j = 0; j < WX_L2_MAXS; ++j) { cf.p[j] = (float)p[j]; cf.kap[j] = (float)kap[j]; }
     cf.g0 = (float)g0;
     cf.g2 = (float)g2;
+    // depths beyond the lattice's: e = L - LD levels on the 8-sample nodes as one matrix (columns = images of the unit vectors)
+    WxL2M mm;
+    mm.e = L - LD;
+    if (mm.e < 0 || mm.e > 3) return 0;
+    for (int c = 0; c < 8; ++c) {
+        double v[8], w[8];
+        for (int i = 0; i < 8; ++i) v[i] = i == c ? 1.0 : 0.0;
+        for (int l = 0; l < mm.e; ++l) {
+            const int np = 8 >> l, h = np >> 1;
+            for (int j = 0; j < (1 << l); ++j) {
+                const double *x = v + j * np;
+                double *y = w + j * np;
+                for (int i = 0; i < h; ++i) {
+                    double a = 0.0, d = 0.0;
+                    for (int k = 0; k < filt.F; ++k) {
+                        a += filt.q[k] * x[(2 * i + k) % np];
+                        d += ((k & 1) ? -filt.q[k] : filt.q[k]) * x[(((2 * i + 1 - k) % np) + np) % np];
+                    }
+                    y[i] = a;
+                    y[h + i] = d;
+                }
+            }
+            for (int i = 0; i < 8; ++i) v[i] = w[i];
+        }
+        for (int r = 0; r < 8; ++r) mm.m[r][c] = (float)v[r];
+    }
     const int64_t per = HB == 1 ? 2 : 1, units = (batch + per - 1) / per;
     if (batch < per || units > 65535 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return 0;
     if ((batch & (per - 1)) && src == dst) return 0;          // the last workgroup re-does images: out of place only
@@ -704,9 +820,9 @@ static int wx_lattice2d_launch(const float *src, float *dst, int64_t m, int64_t 
     const int last_img = (int)(batch - per);
 #define WX_GO2K(K, NSS)                                                                                                  \
     do {                                                                                                                 \
-        if (bl) hipLaunchKernelGGL((K<NSS, true, false, HB>), grid, wg, 0, st, src, dst, last_img, cf);                  \
-        else if (bs) hipLaunchKernelGGL((K<NSS, false, true, HB>), grid, wg, 0, st, src, dst, last_img, cf);             \
-        else hipLaunchKernelGGL((K<NSS, false, false, HB>), grid, wg, 0, st, src, dst, last_img, cf);                    \
+        if (bl) hipLaunchKernelGGL((K<NSS, true, false, HB>), grid, wg, 0, st, src, dst, last_img, cf, mm);                  \
+        else if (bs) hipLaunchKernelGGL((K<NSS, false, true, HB>), grid, wg, 0, st, src, dst, last_img, cf, mm);             \
+        else hipLaunchKernelGGL((K<NSS, false, false, HB>), grid, wg, 0, st, src, dst, last_img, cf, mm);                    \
     } while (0)
 #define WX_GO2(NSS)                                                                                                      \
     case NSS:                                                                                                            \

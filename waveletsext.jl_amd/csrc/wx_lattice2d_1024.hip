@@ -1,7 +1,7 @@
 // the kernels of the 1024 x 1024 geometry (depth 7, eight columns per wavefront) of wx_lattice2d.h
 #include "wx_lattice2d.h"
 
-int wx_lattice2d_launch_1024(const float *src, float *dst, int64_t m, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
+int wx_lattice2d_launch_1024(const float *src, float *dst, int64_t m, int L, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
 {
-    return wx_lattice2d_launch<2>(src, dst, m, batch, filt, inverse, pass, st);
+    return wx_lattice2d_launch<2>(src, dst, m, L, batch, filt, inverse, pass, st);
 }
