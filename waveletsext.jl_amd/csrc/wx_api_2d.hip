@@ -118,14 +118,22 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
     // (wx_dwttail.hip); the quad tree's approximation chain is 1, 2, 6, 22, ... (first child of i = 4 i - 2)
     int tail = 0;
     std::vector<uint8_t> ttree;
-    if (!INVERSE && tree && !wx_force_generic()) {
+    if (tree && !wx_force_generic()) {
         const int Ld = wx_tree_depth2d(tree, ntree);
         std::vector<uint8_t> chain((size_t)ntree, 0);
         int64_t node = 1;
         for (int d = 0; d < Ld && node <= ntree; ++d, node = 4 * node - 2) chain[(size_t)node - 1] = 1;
         bool pyramid = Ld >= 1;
         for (int64_t i = 0; i < ntree && pyramid; ++i) pyramid = (tree[i] != 0) == (chain[(size_t)i] != 0);
-        if (pyramid && (tail = wx_dwt2d_tail_levels(m, n, Ld, F, sizeof(T)))) {
+        // small images: the whole pyramid of an image in LDS, one read and one write of the batch (wx_pyr2d.hip)
+        if (pyramid && wx_pyr2d_small_ok<T>(m, n, Ld, F)) {
+            WxIO io(st);
+            const T *dx = (const T *)io.in(x, sizeof(T) * m * n * batch);
+            T *dy = (T *)io.out(y, sizeof(T) * m * n * batch);
+            if (batch && (!dx || !dy)) return io.finish(WX_EHIP);
+            return io.finish(wx_dev_pyr2d_small<T>(INVERSE, dx, dy, m, n, Ld, batch, filt, st));
+        }
+        if (!INVERSE && pyramid && (tail = wx_dwt2d_tail_levels(m, n, Ld, F, sizeof(T)))) {
             ttree.assign(tree, tree + ntree);
             node = 1;
             for (int d = 0; d < Ld && node <= ntree; ++d, node = 4 * node - 2) if (d >= Ld - tail) ttree[(size_t)node - 1] = 0;

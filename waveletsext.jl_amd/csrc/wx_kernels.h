@@ -174,4 +174,7 @@ template <typename T> int wx_dwt_tail(T *y, int64_t n, int Lt, int64_t batch, co
 template <typename T> int wx_idwt_tail(const T *xw, T *head, int64_t n, int Lt, int64_t batch, const WxFilt &filt, const WxThreshArg &thr,
                                         hipStream_t st);
 int wx_dwt2d_tail_levels(int64_t m, int64_t n, int L, int F, size_t esz);
+// pyramids of small images, a whole image per workgroup in LDS (wx_pyr2d.hip)
+template <typename T> bool wx_pyr2d_small_ok(int64_t m, int64_t n, int L, int F);
+template <typename T> int wx_dev_pyr2d_small(bool inverse, const T *x, T *y, int64_t m, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
 template <typename T> int wx_dwt2d_tail(T *y, int64_t m, int Lt, int64_t batch, const WxFilt &filt, hipStream_t st);
