@@ -304,15 +304,17 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
 #pragma unroll
             for (int e = 0; e < V; ++e) res[u].e[e] = 0;
         if (!INVERSE) {
-            // outputs i = 2t, 2t+1: a[i] needs v[2i..2i+F-1], d[i] needs v[2i+2-F..2i+1]
-            TV w[2 * F];
+            // a[i] needs v[2i .. 2i+F-1] and d[i'] needs v[2i'+2-F .. 2i'+1]: the window of a[2t], a[2t+1] -- v[4t .. 4t+F+1] -- is also the
+            // window of d[2t+F/2-1], d[2t+F/2], so an item produces those four from F + 2 LDS reads (2F with d[2t], d[2t+1]; the taps
+            // and their order per output are unchanged: same bits)
+            TV w[F + 2];
 #pragma unroll
-            for (int k = 0; k < 2 * F; ++k) w[k] = v[((4 * t + 2 - F + k) & (np - 1)) * SV];
+            for (int k = 0; k < F + 2; ++k) w[k] = v[((4 * t + k) & (np - 1)) * SV];
 #pragma unroll
             for (int k = 0; k < F; ++k) {
                 const T qd = (k & 1) ? -q[k] : q[k];
-                wx_vfma<T, V>(res[0], q[k], w[F - 2 + k]);
-                wx_vfma<T, V>(res[1], q[k], w[F + k]);
+                wx_vfma<T, V>(res[0], q[k], w[k]);
+                wx_vfma<T, V>(res[1], q[k], w[2 + k]);
                 wx_vfma<T, V>(res[2], qd, w[F - 1 - k]);
                 wx_vfma<T, V>(res[3], qd, w[F + 1 - k]);
             }
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(1024) void k_rows_fused(const T *__restrict__ src, 
         TV *o = b + (size_t)(j << lnp) * SV;
         if (!INVERSE) {
             o[(2 * t) * SV] = res[0]; o[(2 * t + 1) * SV] = res[1];
-            o[(h + 2 * t) * SV] = res[2]; o[(h + 2 * t + 1) * SV] = res[3];
+            o[(h + ((2 * t + F / 2 - 1) & (h - 1))) * SV] = res[2]; o[(h + ((2 * t + F / 2) & (h - 1))) * SV] = res[3];
         } else {
             o[(4 * t) * SV] = res[0]; o[(4 * t + 1) * SV] = res[1];
             o[(4 * t + 2) * SV] = res[2]; o[(4 * t + 3) * SV] = res[3];
