@@ -664,6 +664,13 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
     return WX_OK;
 }
 
+// Quotients by a divisor that is uniform for the launch but not known to the compiler (staged tile sides): one division per thread
+// for the multiplier, a multiply-high per quotient.  Exact for n * d < 2^32, d >= 2.  (The staging loops of the tile kernels divided
+// twice per element: 1300 vector instructions per thread and tile around 80 multiply-adds -- the Float32 inverse level ran its
+// vector ALUs flat out on index arithmetic, profiles PMC of round 4.)
+__device__ __forceinline__ unsigned wx_magic(unsigned d) { return 0xFFFFFFFFu / d + 1u; }
+__device__ __forceinline__ int wx_mdiv(int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); }
+
 // ---- one packet level in one pass: both dimensions of a tile through LDS ---------------------------------
 // The two-pass level above moves every image four times (read, write, read, write).  Here a workgroup stages
 // a CR x CC tile of the source slice (plus F-2 halo samples on every side when the node is larger than the tile;
@@ -695,6 +702,7 @@ __global__ __launch_bounds__(256) void k_dwt2d_level_tile(const T *__restrict__ 
     const bool bigR = mp > CR, bigC = np > CC;
     const int HR = bigR ? H : 0, HC = bigC ? H : 0;
     const int NR = CR + 2 * HR, NC = CC + 2 * HC;
+    const unsigned mNR = wx_magic((unsigned)NR);
     const int lmp = 31 - __clz(mp), lnp = 31 - __clz(np);
     int R0, C0;
     if (act) {
@@ -736,7 +744,7 @@ __global__ __launch_bounds__(256) void k_dwt2d_level_tile(const T *__restrict__ 
             const int e = e0 + u * 256;
             at[u] = -1;
             if (e < NR * NC) {
-                const int lc = e / NR, lr = e - lc * NR;
+                const int lc = wx_mdiv(e, mNR), lr = e - lc * NR;
                 const int gr = bigR ? nbR + ((R0 - nbR + lr - H) & (mp - 1)) : R0 + lr;
                 const int gc = bigC ? nbC + ((C0 - nbC + lc - H) & (np - 1)) : C0 + lc;
                 v[u] = simg[(int64_t)gc * m + gr];
@@ -842,6 +850,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const bool bigR = mp > CR, bigC = np > CC;
     const int HR = bigR ? H : 0, HC = bigC ? H : 0;
     const int NR = CR + 2 * HR, NC = CC + 2 * HC;
+    const unsigned mNR = wx_magic((unsigned)NR);
     const int lmp = 31 - __clz(mp), lnp = 31 - __clz(np);
     T q[F];
 #pragma unroll
@@ -869,7 +878,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int u = 0; u < NB; ++u) {
             const int e = tid + u * 256;
             if (e < NR * NC) {
-                const int lc = e / NR, lr = e - lc * NR;
+                const int lc = wx_mdiv(e, mNR), lr = e - lc * NR;
                 const int gr = bigR ? nbR + ((R0 - nbR + lr - H) & (mp - 1)) : R0 + lr;
                 const int gc = bigC ? nbC + ((C0 - nbC + lc - H) & (np - 1)) : C0 + lc;
                 v[u] = simg[(int64_t)gc * m + gr];
@@ -889,7 +898,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int e = tid + u * 256;
-            if (e < NR * NC) { const int lc = e / NR, lr = e - lc * NR; in[lc * PIN + lr] = v[u]; }
+            if (e < NR * NC) { const int lc = wx_mdiv(e, mNR), lr = e - lc * NR; in[lc * PIN + lr] = v[u]; }
         }
         __syncthreads();
         if (t + gridDim.x < total) fetch(t + gridDim.x, v);          // in flight during both passes
@@ -1080,6 +1089,7 @@ __global__ __launch_bounds__(256) void k_idwt2d_level_tile(const T *__restrict__
     const bool bigR = mp > CR, bigC = np > CC;
     const int GR = bigR ? G : 0, GC = bigC ? G : 0;
     const int NRc = CR / 2 + 2 * GR, NCc = CC / 2 + 2 * GC;          // staged rows / columns of a child
+    const unsigned mNRc = wx_magic((unsigned)NRc), m2NRc = wx_magic((unsigned)(2 * NRc));
     int R0, C0;
     if (act) {
         const int tpr = mp / CR, tpn = tpr * (np / CC);
@@ -1113,40 +1123,47 @@ __global__ __launch_bounds__(256) void k_idwt2d_level_tile(const T *__restrict__
 #pragma unroll
     for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
 
-    // stage the four children (batches of independent loads, see k_dwt2d_level_tile)
+    // stage the four children: every load in flight before the first LDS store (see k_dwt2d_level_tile).  A thread keeps ONE staged
+    // row (tid & 63; rows beyond the NRc <= 64 staged ones idle) and walks the columns four apart, so the row part of the address is
+    // made once per child and a column costs a mask and an add -- an element index decoded by two divisions per element made this
+    // loop 500 of the kernel's 950 vector instructions per thread (round 4, PMC: the vector ALUs were the bound of the Float32 level).
     {
-        const int per = NRc * NCc, tot = 4 * per;
-        constexpr int NBMAX = (4 * HRm * HCm + 255) / 256;
-        constexpr int NB = NBMAX < 24 ? NBMAX : 24;
-        for (int e0 = tid; e0 < tot; e0 += NB * 256) {
-            T v[NB];
-            int at[NB];
+        static_assert(HRm <= 64, "one staged row per lane of a wavefront");
+        constexpr int ITER = (HCm + 3) / 4;
+        const int lr = tid & 63, lcg = tid >> 6;
+        const bool rok = lr < NRc;
+        T v[4][ITER];
 #pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int e = e0 + u * 256;
-                at[u] = -1;
-                if (e < tot) {
-                    const int c = e / per, r2 = e - c * per;
-                    const int lc = r2 / NRc, lr = r2 - lc * NRc;
-                    int grow, gcol, jn = 0, kn = 0;
-                    if (bigR) grow = nbR + (c >> 1) * hr + ((((R0 - nbR) >> 1) + lr - G) & (hr - 1));
-                    else { jn = lr >> (lmp - 1); grow = R0 + jn * mp + (c >> 1) * hr + (lr & (hr - 1)); }
+        for (int c = 0; c < 4; ++c) {
+            int grow, jn = 0;
+            if (bigR) grow = nbR + (c >> 1) * hr + ((((R0 - nbR) >> 1) + lr - G) & (hr - 1));
+            else { jn = lr >> (lmp - 1); grow = R0 + jn * mp + (c >> 1) * hr + (lr & (hr - 1)); }
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int lc = lcg + 4 * it;
+                v[c][it] = (T)0;
+                if (rok && lc < NCc) {
+                    int gcol, kn = 0;
                     if (bigC) gcol = nbC + (c & 1) * hc + ((((C0 - nbC) >> 1) + lc - G) & (hc - 1));
                     else { kn = lc >> (lnp - 1); gcol = C0 + kn * np + (c & 1) * hc + (lc & (hc - 1)); }
                     const uint8_t f = fl[(kn * nnr + jn) * 4 + c];
-                    v[u] = f ? (f == 2 ? iimg : limg)[(int64_t)gcol * m + grow] : (T)0;
-                    at[u] = (c * HCm + lc) * PCH + lr;
+                    if (f) v[c][it] = (f == 2 ? iimg : limg)[(int64_t)gcol * m + grow];
                 }
             }
-#pragma unroll
-            for (int u = 0; u < NB; ++u) if (at[u] >= 0) ch[at[u]] = v[u];
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int lc = lcg + 4 * it;
+                if (rok && lc < NCc) ch[(c * HCm + lc) * PCH + lr] = v[c][it];
+            }
     }
     __syncthreads();
     // dim 2: item = (row half, staged child row, group of OPT column pairs); lanes down the rows
     for (int e = tid; e < 2 * NRc * (CC / 2 / OPT); e += 256) {
-        const int g = e / (2 * NRc), r2 = e - g * (2 * NRc);
-        const int rh = r2 / NRc, lr = r2 - rh * NRc;
+        const int g = wx_mdiv(e, m2NRc), r2 = e - g * (2 * NRc);
+        const int rh = wx_mdiv(r2, mNRc), lr = r2 - rh * NRc;
         const T *ca = ch + (rh * 2) * HCm * PCH + lr, *cd = ch + (rh * 2 + 1) * HCm * PCH + lr;
         T aw[WN], dw[WN];
         if (bigC) {
@@ -1235,6 +1252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int GR = bigR ? G : 0, GC = bigC ? G : 0;
     const int NRc = CR / 2 + 2 * GR, NCc = CC / 2 + 2 * GC;
     const int per = NRc * NCc, tot = 4 * per;
+    const unsigned mNRc = wx_magic((unsigned)NRc), mper = wx_magic((unsigned)per), m2NRc = wx_magic((unsigned)(2 * NRc));
     T q[F];
 #pragma unroll
     for (int k = 0; k < F; ++k) q[k] = (T)filt.q[k];
@@ -1263,8 +1281,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int u = 0; u < NB; ++u) {
             const int e = tid + u * 256;
             if (e < tot) {
-                const int c = e / per, r2 = e - c * per;
-                const int lc = r2 / NRc, lr = r2 - lc * NRc;
+                const int c = wx_mdiv(e, mper), r2 = e - c * per;
+                const int lc = wx_mdiv(r2, mNRc), lr = r2 - lc * NRc;
                 const int grow = bigR ? nbR + (c >> 1) * hr + ((((R0 - nbR) >> 1) + lr - G) & (hr - 1)) : R0 + (c >> 1) * hr + lr;
                 const int gcol = bigC ? nbC + (c & 1) * hc + ((((C0 - nbC) >> 1) + lc - G) & (hc - 1)) : C0 + (c & 1) * hc + lc;
                 const T *fp = c == 0 ? from[0] : (c == 1 ? from[1] : (c == 2 ? from[2] : from[3]));
@@ -1283,8 +1301,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int u = 0; u < NB; ++u) {
             const int e = tid + u * 256;
             if (e < tot) {
-                const int c = e / per, r2 = e - c * per;
-                const int lc = r2 / NRc, lr = r2 - lc * NRc;
+                const int c = wx_mdiv(e, mper), r2 = e - c * per;
+                const int lc = wx_mdiv(r2, mNRc), lr = r2 - lc * NRc;
                 ch[(c * HCm + lc) * PCH + lr] = v[u];
             }
         }
@@ -1292,8 +1310,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (t + gridDim.x < total) fetch(t + gridDim.x, v);
         // dim 2: item = (row half, staged child row, group of OPT column pairs); lanes down the rows
         for (int e = tid; e < 2 * NRc * (CC / 2 / OPT); e += 256) {
-            const int g = e / (2 * NRc), r2 = e - g * (2 * NRc);
-            const int rh = r2 / NRc, lr = r2 - rh * NRc;
+            const int g = wx_mdiv(e, m2NRc), r2 = e - g * (2 * NRc);
+            const int rh = wx_mdiv(r2, mNRc), lr = r2 - rh * NRc;
             const T *ca = ch + (rh * 2) * HCm * PCH + lr, *cd = ch + (rh * 2 + 1) * HCm * PCH + lr;
             T aw[WN], dw[WN];
             if (bigC) {
