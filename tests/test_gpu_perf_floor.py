@@ -25,3 +25,20 @@ def test_no_entry_below_the_floor(wx):
     assert not bad, "below %.0f %% of the HBM peak: %s" % (100 * FLOOR, [(r["dtype"], r["n"], r["case"], round(r["fwd_frac"], 3), round(r["inv_frac"], 3)) for r in bad])
     tol = {"f64": 1e-10, "f32": 1e-5}
     assert all(r["roundtrip"] <= tol[r["dtype"]] for r in rows)
+
+
+FLOOR_2D = 0.12
+
+
+def test_no_2d_entry_below_its_floor(wx):
+    """the 2-D companion (tools/floor_scan2d.py): square images 64 ... 1024, Float32 and Float64, full trees (full depth and L = 3),
+    pyramids, wpdall; the floor is lower than in 1-D -- the generic two-pass path is at 0.19-0.27 -- but the holes of round 3 (0.01 at
+    Float64 512 x 512) cannot come back unnoticed.  Table to gpurun_out/r04_floor2d.txt."""
+    import floor_scan2d
+    with open(os.path.join(ROOT, "gpurun_out", "r04_floor2d.txt"), "w") as f:
+        rows = floor_scan2d.scan("db4", out=f)
+    assert len(rows) >= 40
+    bad = [r for r in rows if r["fwd_frac"] < FLOOR_2D or r["inv_frac"] < FLOOR_2D]
+    assert not bad, "below %.0f %% of the HBM peak: %s" % (100 * FLOOR_2D, [(r["dtype"], r["m"], r["case"], round(r["fwd_frac"], 3), round(r["inv_frac"], 3)) for r in bad])
+    tol = {"f64": 1e-10, "f32": 1e-5}
+    assert all(r["roundtrip"] <= tol[r["dtype"]] for r in rows)
