@@ -87,17 +87,19 @@ __global__ __launch_bounds__(ST_NT) void k_small_tree(const T *__restrict__ x, T
                         continue;
                     }
                     if (!INVERSE) {
-                        A w[2 * F - 2];
+                        // a[i] reads v[2i .. 2i+F-1]; d[i'] reads v[2i'+2-F .. 2i'+1], the same window for i' = i + F/2 - 1 (mod m/2): one
+                        // window of F samples gives both (2F - 2 reads with d[i]; the taps and their order per output are unchanged)
+                        A w[F];
 #pragma unroll
-                        for (int e = 0; e < 2 * F - 2; ++e) w[e] = (A)lds[co + base + ((2 * i - (F - 2) + e) & (m - 1))];
+                        for (int e = 0; e < F; ++e) w[e] = (A)lds[co + base + ((2 * i + e) & (m - 1))];
                         A a = 0, dd = 0;
 #pragma unroll
                         for (int k = 0; k < F; ++k) {
-                            a = fma(q[k], w[k + F - 2], a);
+                            a = fma(q[k], w[k], a);
                             dd = fma((k & 1) ? -q[k] : q[k], w[F - 1 - k], dd);
                         }
                         lds[no + base + i] = (T)a;
-                        lds[no + base + hm + i] = (T)dd;
+                        lds[no + base + hm + ((i + F / 2 - 1) & (hm - 1))] = (T)dd;
                     } else {
                         A v0 = 0, v1 = 0;
 #pragma unroll
