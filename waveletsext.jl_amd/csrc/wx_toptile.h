@@ -93,6 +93,12 @@ __global__ __launch_bounds__(WX_TT_NT) void k_top_tile_fwd(const T *__restrict__
 {
     typedef typename WxVec2<T>::type V2;
     typedef WxTTGeo<F, NL, TS, false> G;
+    // Float32 signals filter in Float32 like the reference (dwt/dwt_one_level.jl:79-83 is generic in T); until late in round 4 they
+    // were widened to Float64 per LDS read: the pass is instruction-bound for Float32 (twice the samples per byte)
+    typedef typename std::conditional<sizeof(T) == 8, double, float>::type AT;
+    AT qq[F];
+#pragma unroll
+    for (int kq = 0; kq < F; ++kq) qq[kq] = (AT)filt.q[kq];
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     constexpr int PP = WX_TT_P, H = G::H, WIN = 2 * PP + F - 2, NB = G::held;
     T *lds = reinterpret_cast<T *>(wx_smem);
@@ -144,19 +150,19 @@ __global__ __launch_bounds__(WX_TT_NT) void k_top_tile_fwd(const T *__restrict__
                 const int j = (int)((spl >> (4 * k)) & 15u);
                 // parent slot j starts at a multiple of 8: ph(j Sp + base + 8 gi + e) = j (Sp + Sp / 8) + 9 gi + ph-part of (base + e)
                 const T *pw = lds + co + j * (Sp + Sp / 8) + 9 * gi;
-                double w[WIN];
+                AT w[WIN];
 #pragma unroll
-                for (int e = 0; e < WIN; ++e) w[e] = (double)pw[base + e + ((base + e) >> 3)];
+                for (int e = 0; e < WIN; ++e) w[e] = (AT)pw[base + e + ((base + e) >> 3)];
                 // children slots 2 j and 2 j + 1; their windows start O words in; this group writes a[c0 ..] and d[c0 + H ..]
                 const int cw = G::O + gi * PP - H;          // >= 0 by the choice of O
                 T *aw = lds + no + 2 * j * (Sc + Sc / 8), *dw = aw + (Sc + Sc / 8);
 #pragma unroll
                 for (int p = 0; p < PP; ++p) {
-                    double a = 0.0, d = 0.0;
+                    AT a = 0, d = 0;
 #pragma unroll
                     for (int kk = 0; kk < F; ++kk) {
-                        a = fma(filt.q[kk], w[2 * p + kk], a);
-                        d = fma((kk & 1) ? -filt.q[kk] : filt.q[kk], w[2 * p + F - 1 - kk], d);
+                        a = fma(qq[kk], w[2 * p + kk], a);
+                        d = fma((kk & 1) ? -qq[kk] : qq[kk], w[2 * p + F - 1 - kk], d);
                     }
                     const int ca = cw + p, cd = cw + p + H;
                     aw[ca + (ca >> 3)] = (T)a;               // the first H and the last few land in the slot's padding
@@ -196,6 +202,12 @@ __global__ __launch_bounds__(WX_TT_NT) void k_top_tile_inv(const T *__restrict__
 {
     typedef typename WxVec2<T>::type V2;
     typedef WxTTGeo<F, NL, TS, true> G;
+    // Float32 signals filter in Float32 like the reference (dwt/dwt_one_level.jl:79-83 is generic in T); until late in round 4 they
+    // were widened to Float64 per LDS read: the pass is instruction-bound for Float32 (twice the samples per byte)
+    typedef typename std::conditional<sizeof(T) == 8, double, float>::type AT;
+    AT qq[F];
+#pragma unroll
+    for (int kq = 0; kq < F; ++kq) qq[kq] = (AT)filt.q[kq];
     extern __shared__ __attribute__((aligned(16))) char wx_smem[];
     constexpr int PP = WX_TT_P, HF = G::HF, WIN = PP + HF - 1;
     // every window that enters a tile -- the leaves of each depth, at depth NL every node -- is one flat list of element pairs
@@ -271,24 +283,24 @@ __global__ __launch_bounds__(WX_TT_NT) void k_top_tile_inv(const T *__restrict__
                 const int j = (int)((spl >> (4 * k)) & 15u);
                 // children slots 2 j, 2 j + 1 (multiples of 8 words): ph(slot + x + 4 gi) = slot + slot / 4 + 5 gi + x + (x >> 2)
                 const T *aw = lds + co + 2 * j * (Sc + Sc / 4) + 5 * gi, *dw = aw + (Sc + Sc / 4);
-                double wa[WIN], wd[WIN];
+                AT wa[WIN], wd[WIN];
 #pragma unroll
                 for (int e = 0; e < WIN; ++e) {
-                    wa[e] = (double)aw[ab + e + ((ab + e) >> 2)];
-                    wd[e] = (double)dw[db + e + ((db + e) >> 2)];
+                    wa[e] = (AT)aw[ab + e + ((ab + e) >> 2)];
+                    wd[e] = (AT)dw[db + e + ((db + e) >> 2)];
                 }
                 T *pw = lds + po + j * (Sp + Sp / 4) + 10 * gi;         // parent words 8 gi ..: the skew adds 2 gi
 #pragma unroll
                 for (int p = 0; p < PP; ++p) {
                     // a[k - m] = wa[p + HF - 1 - m], d[k + m] = wd[p + m]
-                    double v0 = 0.0, v1 = 0.0;
+                    AT v0 = 0, v1 = 0;
 #pragma unroll
                     for (int m = 0; m < HF; ++m) {
-                        const double av = wa[p + HF - 1 - m], dv = wd[p + m];
-                        v0 = fma(filt.q[2 * m], av, v0);
-                        v0 = fma(-filt.q[2 * m + 1], dv, v0);
-                        v1 = fma(filt.q[2 * m + 1], av, v1);
-                        v1 = fma(filt.q[2 * m], dv, v1);
+                        const AT av = wa[p + HF - 1 - m], dv = wd[p + m];
+                        v0 = fma(qq[2 * m], av, v0);
+                        v0 = fma(-qq[2 * m + 1], dv, v0);
+                        v1 = fma(qq[2 * m + 1], av, v1);
+                        v1 = fma(qq[2 * m], dv, v1);
                     }
                     pw[2 * p + ((2 * p) >> 2)] = (T)v0;      // the last group of a node runs into the slot's padding
                     pw[2 * p + 1 + ((2 * p + 1) >> 2)] = (T)v1;
