@@ -263,6 +263,8 @@ __device__ __forceinline__ void wx_reg_levels16(T (&x)[16], const T (&q)[F])
 
 // V = rows per lane (16-byte LDS / HBM accesses when V * sizeof(T) = 16): the filter work per LDS
 // instruction grows V-fold, which is what bounds this kernel (LDS instruction issue, not bytes).
+// (Tried and dropped: the four register levels as one 16 x 16 matrix from the kernel arguments -- half the multiply-adds, but 256
+// coefficients do not fit the scalar registers and their reloads per block stalled the loop: 256-column Float64 rows 1.07 -> 1.64 ms.)
 // REGL: the levels on nodes of at most 16 columns run in registers (below); its own instantiation, because the extra code costs the
 // variants that do not use it registers (Float64 rows of 64 columns: 1.04 -> 1.22 ms with the code merely present).
 // (Tried in round 4 and removed: four output pairs per item -- 2.5 instead of 4 LDS reads per output -- was slower everywhere,
