@@ -175,7 +175,7 @@ def parse():
                          "not hold the machine); 0 disables")
     ap.add_argument("--gather-timeout", type=float, default=240.0,
                     help="N > 1: seconds the second loop (all-gather inside the step) may take before every rank abandons it; rank 0 "
-                         "then prints the line of the main loop with the failure noted and all ranks exit 0")
+                         "then prints the line of the main loop with the failure noted (`exchange_abandoned`) and all ranks exit 4")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the `also` block (the other headline workloads, hipEvent-timed in the same run; N = 1 only)")
     return ap.parse_args()
@@ -574,13 +574,16 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
                     sc, qc = wd.allreduce_moments(s.cpu(), q.cpu())
                     s, q = wx.to_colmajor(sc.to(dev)), wx.to_colmajor(qc.to(dev))
             costs = wx.costs_from_moments(s, q, N_total, method)
-            state["tree"] = wx.bestbasis_treeselection(costs, n)
+            # the tree and the margin of its closest `cc < pc` decision (BestBasis.jl:72): "bit-exact tree indices" holds across
+            # summation orders only while this margin is far above the rounding of the costs (~1e-13)
+            state["tree"], state["gap"] = wx.bestbasis_treeselection(costs, n, return_gap=True)
 
         def step(legs):
             legs.run("fwd", moments)
             legs.run("inv", tree)
 
         W.step = step
+        W.extra = lambda: {"min_rel_cost_gap": state.get("gap"), "tree_split_nodes": int(state["tree"].sum())}
         W.check = lambda: 0.0 if wx.isvalidtree(torch.empty(n), state["tree"]) else 1.0
         W.output = lambda gathered: torch.from_numpy(state["tree"].astype("float64"))
         flops = acwpd_jbb_min_flops(n, L, F) * Bl
@@ -724,10 +727,12 @@ def also_block(wx, torch, dev, a, dist, steps=10):
             n_alloc0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
             gc.collect()
             gc.disable()             # (round 4: also.target.inv showed one 22-97 ms launch in ten -- the collector, not the allocator)
-            for _ in range(steps):
-                W.step(legs)
-            torch.cuda.synchronize(dev)
-            gc.enable()
+            try:
+                for _ in range(steps):
+                    W.step(legs)
+                torch.cuda.synchronize(dev)
+            finally:
+                gc.enable()
             n_alloc = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - n_alloc0
             if os.environ.get("WX_BENCH_DEBUG"):
                 sys.stderr.write("also.%s: device allocations inside the timed steps: %d; inv launches (ms, in order): %s\n" % (
@@ -761,6 +766,8 @@ def also_block(wx, torch, dev, a, dist, steps=10):
                 if "flops_note" in info:
                     rec["fwd"]["flops_note"] = info["flops_note"]
             rec["Msamples_per_s"] = info["samples"] / ((fwd + inv) * 1e-3) / 1e6
+            if getattr(W, "extra", None):
+                rec.update(W.extra())
             rec["wall_s"] = time.perf_counter() - t0
             out[name] = rec
             del W, legs, warm
@@ -864,13 +871,15 @@ def main():
         legs = Legs(torch)
         gc.collect()
         gc.disable()                                     # a generation-2 collection between an event and its launch is a 20-100 ms leg
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step_fn(legs)
-        sync()
-        mine = time.perf_counter() - t0
-        gc.enable()
+        try:
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step_fn(legs)
+            sync()
+            mine = time.perf_counter() - t0
+        finally:
+            gc.enable()
         per_rank = [mine]
         if world > 1:
             t = torch.zeros(world, dtype=torch.float64, device=red_dev)
@@ -954,6 +963,8 @@ def main():
                       "per_rank_ms": [v / a.steps * 1e3 for v in per_rank],
                       "min_ms": min(per_rank) / a.steps * 1e3, "max_ms": max(per_rank) / a.steps * 1e3},
         }
+        if getattr(W, "extra", None):
+            out["config"].update(W.extra())
         if gather is not None:
             out["with_allgather"] = gather
             # the sharded compute (`value`) and the throughput with the exchange inside the step, side by side
@@ -962,21 +973,40 @@ def main():
 
     # The exchange loop below is reported NEXT to `value`, never part of it -- and it is the one part of this program that has never
     # run on more than one GPU.  If it does not finish in --gather-timeout seconds (a hung grouped send/recv cannot be cancelled from
-    # Python), every rank's timer fires at about the same time: rank 0 prints the line it already has, with the failure in
-    # `with_allgather`, and all ranks leave with exit code 0 -- the launcher then reports success and the headline number survives.
+    # Python), every rank's timer fires at about the same time: rank 0 writes the line of the main loop -- BUILT AND SERIALISED HERE,
+    # in the main thread, before the loop starts: the timer thread touches neither torch nor the library while the main thread may sit
+    # in RCCL -- with the failure in `with_allgather` and `"exchange_abandoned": true`, and every rank leaves with exit code 4: the
+    # headline number survives on stdout, and a launcher that only reads exit codes still sees that the collective hung.
+    EXIT_EXCHANGE_ABANDONED = 4
     gather_timer = None
+    import threading
+    print_lock = threading.Lock()
+    printed = {"done": False}
+
+    def emit(text):
+        """the ONE JSON line of this process: whoever comes first (main thread or the give-up timer) prints, the other does not"""
+        with print_lock:
+            if printed["done"]:
+                return False
+            printed["done"] = True
+            sys.stdout.write(text + "\n")
+            sys.stdout.flush()
+            return True
+
     if world > 1 and W.gatherable and a.gather_timeout > 0:
-        import threading
+        abandoned_line = None
+        if rank == 0:
+            ab = build_line({"error": "exchange loop not finished after %.0f s; abandoned, `value` is the sharded compute" % a.gather_timeout})
+            ab["exchange_abandoned"] = True
+            abandoned_line = json.dumps(ab)
 
         def _give_up_gather():
             if rank == 0:
-                line = build_line({"error": "exchange loop not finished after %.0f s (at: %s); abandoned, `value` is the sharded compute"
-                                            % (a.gather_timeout, stage["at"])})
-                sys.stdout.write(json.dumps(line) + "\n")
-                sys.stdout.flush()
-            sys.stderr.write("bench.py: rank %d gives up the exchange loop after %.0f s (at: %s)\n" % (rank, a.gather_timeout, stage["at"]))
+                emit(abandoned_line)
+            sys.stderr.write("bench.py: rank %d gives up the exchange loop after %.0f s (at: %s); exit code %d\n"
+                             % (rank, a.gather_timeout, stage["at"], EXIT_EXCHANGE_ABANDONED))
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(EXIT_EXCHANGE_ABANDONED)
 
         gather_timer = threading.Timer(a.gather_timeout, _give_up_gather)
         gather_timer.daemon = True
@@ -1071,7 +1101,7 @@ def main():
     if wd_timer is not None:
         wd_timer.cancel()
     if rank == 0:
-        print(json.dumps(out))
+        emit(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -182,6 +182,12 @@ int wx_jbb_costs_f32(const float *sum, const float *sumsq, int64_t Ntot, int64_t
  * (k entries) is mutated like the reference; tree receives n-1 bytes. */
 int wx_treeselect_f64(double *costs, int64_t k, int64_t n, int type_max, uint8_t *tree);
 int wx_treeselect_f32(float *costs, int64_t k, int64_t n, int type_max, uint8_t *tree);
+/* The same selection, and *min_rel_gap = min over the split decisions taken (nodes still in the tree when visited,
+ * BestBasis.jl:70-76) of |cc - pc| / |pc|: the margin by which the closest `cc < pc` was decided.  The reference prunes on
+ * a strict Float64 comparison of log-sums, so a tree is reproducible across summation orders only while this margin is
+ * far above the costs' rounding error (~1e-13); +inf when no decision was taken (L = 0). */
+int wx_treeselect_gap_f64(double *costs, int64_t k, int64_t n, int type_max, uint8_t *tree, double *min_rel_gap);
+int wx_treeselect_gap_f32(float *costs, int64_t k, int64_t n, int type_max, uint8_t *tree, double *min_rel_gap);
 /* acwpdall + the JBB moments of its output without materialising the (n, 2^(L+1)-1, batch)
  * table (BASELINE config 5): sum / sumsq are (n, 2^(L+1)-1). */
 int wx_acwpd_jbb_moments_f64(const double *x, double *sum, double *sumsq, int64_t n, int L, int64_t batch,

@@ -327,3 +327,44 @@ void wxo_wpt_iwpt_roundtrip_omp_f64(double *xh, double *y, const double *x, int6
         wxo_iwpt1d_tree_f64(xh + b * n, y + b * n, n, tree, ntree, qmf, F);
     }
 }
+
+/* sum(X, dims=3) and sum(X.^2, dims=3) of X = acwpdall(x) (acwt/acwt_all.jl:239-259 + bestbasis/bestbasis_tree.jl:153-154)
+ * for batches whose (n, 2^(L+1)-1, N) table cannot be held: tables of a window of signals are made in parallel (each by the
+ * per-signal restatement wxo_acwpd1d), then added signal by signal IN ORDER -- threads split the coefficient axis, never the
+ * signal axis, so every EX[e] / EX2[e] sees the roundings of the sequential sums.  EX / EX2 are (n, 2^(L+1)-1), zeroed here. */
+int wxo_acwpd_jbb_sums_f64(double *EX, double *EX2, const double *x, int64_t n, int L, int64_t N, const double *qmf, int F)
+{
+    const int64_t nl = n * (((int64_t)1 << (L + 1)) - 1);
+    int W = wxo_omp_max_threads();
+    if (W > 32) W = 32;
+    if (W > N) W = (int)N;
+    if (W < 1) W = 1;
+    double *tab = (double *)malloc(sizeof(double) * nl * W);
+    if (!tab) return -1;
+    memset(EX, 0, sizeof(double) * nl); memset(EX2, 0, sizeof(double) * nl);
+    int rc = 0;
+    for (int64_t b0 = 0; b0 < N && rc == 0; b0 += W) {
+        const int w = (int)(N - b0 < W ? N - b0 : W);
+#pragma omp parallel for schedule(static)
+        for (int s = 0; s < w; s++) {
+            int r = wxo_acwpd1d_f64(tab + s * nl, x + (b0 + s) * n, n, L, qmf, F);
+            if (r) {
+#pragma omp atomic write
+                rc = r;
+            }
+        }
+        if (rc) break;
+#pragma omp parallel for schedule(static)
+        for (int64_t e = 0; e < nl; e++) {
+            double a = EX[e], q = EX2[e];
+            for (int s = 0; s < w; s++) {
+                const double xv = tab[s * nl + e];
+                a = a + xv;
+                q = q + xv * xv;                 /* -ffp-contract=off: the square is rounded on its own, like X.^2 */
+            }
+            EX[e] = a; EX2[e] = q;
+        }
+    }
+    free(tab);
+    return rc;
+}

@@ -525,6 +525,30 @@ def tree_costs_jbb(X, redundant=False, cost="loglp", p=None):
     return costs
 
 
+def tree_costs_jbb_sums(EX, EX2, N, redundant=False, cost="loglp", p=None):
+    """tree_costs(X, JBB) after its two sums over the signal axis (bestbasis_tree.jl:155-179): EX = sum(X, dims=3),
+    EX2 = sum(X.^2, dims=3), both (n, L), of N signals."""
+    EX = np.array(_f(EX), copy=True, order="F"); EX2 = np.array(_f(EX2, EX.dtype), copy=True, order="F")
+    n, L = EX.shape
+    p = (2.0 if cost == "loglp" else 1.0) if p is None else float(p)
+    costs = np.empty(L if redundant else (1 << L) - 1, EX.dtype)
+    _chk(_call("wxo_tree_costs_jbb_sums", EX.dtype, _p(costs), _p(EX), _p(EX2), n, L, N, _I(int(redundant)),
+               _I(0 if cost == "loglp" else 1), _D(p)))
+    return costs
+
+
+def acwpd_jbb_sums(x, qmf, L=None):
+    """sum(X, dims=3), sum(X.^2, dims=3) of X = acwpdall(x) (acwt_all.jl:239-259, bestbasis_tree.jl:153-154) without
+    holding X: tables of a window of signals at a time, added in signal order with the same roundings as the sequential
+    sums (x*x rounded on its own, then the add); threads split the coefficient axis only."""
+    x = _f(x, np.float64); n, N = x.shape
+    L = maxtransformlevels(n) if L is None else L
+    q, qp, F = _q(qmf)
+    EX = np.empty((n, (1 << (L + 1)) - 1), np.float64, order="F"); EX2 = np.empty_like(EX)
+    _chk(_call("wxo_acwpd_jbb_sums", np.float64, _p(EX), _p(EX2), _p(x), n, _I(L), N, qp, _I(F)))
+    return EX, EX2
+
+
 def bestbasis_treeselection(costs, n, kind="min"):
     costs = np.array(costs, copy=True)
     if costs.dtype not in (np.float32, np.float64):

@@ -1132,18 +1132,14 @@ int FN(wxo_bestbasis_treeselection2d)(uint8_t *tree, T *costs, int64_t k, int64_
 /* (bestbasis_costs.jl:127-132).  costs must hold L (redundant) or 2^L-1      */
 /* entries.  Returns -1 if the @assert all(sigma .>= 0) fails (NaN sigma).    */
 /* ------------------------------------------------------------------------- */
-int FN(wxo_tree_costs_jbb)(T *costs, const T *X, int64_t n, int64_t L, int64_t N, int redundant,
-                           int cost_kind, double p)
+/* the part of tree_costs after the two sums over the signal axis (bestbasis_tree.jl:155-179): EX / EX2 hold
+ * sum(X, dims=3) and sum(X.^2, dims=3) and are overwritten.  Split out so that a test can accumulate the sums signal by
+ * signal (same order, same roundings) without holding the (n, L, N) table. */
+int FN(wxo_tree_costs_jbb_sums)(T *costs, T *EX, T *EX2, int64_t n, int64_t L, int64_t N, int redundant,
+                                int cost_kind, double p)
 {
     int64_t nl = n * L;
-    T *EX = (T *)calloc(nl, sizeof(T)), *EX2 = (T *)calloc(nl, sizeof(T)), *sig = (T *)malloc(sizeof(T) * nl);
-    /* sum(X, dims=3): sequential over the signal axis for each (i,j) */
-    for (int64_t s = 0; s < N; s++)
-        for (int64_t e = 0; e < nl; e++) {
-            T xv = X[s * nl + e];
-            EX[e] = (T)(EX[e] + xv);
-            EX2[e] = (T)(EX2[e] + (T)(xv * xv));
-        }
+    T *sig = (T *)malloc(sizeof(T) * nl);
     int bad = 0;
     for (int64_t e = 0; e < nl; e++) {
         T ex = (T)(EX[e] / (T)N), ex2 = (T)(EX2[e] / (T)N);
@@ -1151,7 +1147,7 @@ int FN(wxo_tree_costs_jbb)(T *costs, const T *X, int64_t n, int64_t L, int64_t N
         sig[e] = (T)sqrt((double)var);           /* VarX .^ 0.5 (DomainError if var<0 in Julia) */
         if (!(sig[e] >= 0)) bad = 1;
     }
-    if (bad) { free(EX); free(EX2); free(sig); return -1; }
+    if (bad) { free(sig); return -1; }
     if (redundant) {
         for (int64_t i = 1; i <= L; i++) {
             int j = wxo_getdepth_binary(i);
@@ -1167,8 +1163,25 @@ int FN(wxo_tree_costs_jbb)(T *costs, const T *X, int64_t n, int64_t L, int64_t N
             }
         }
     }
-    free(EX); free(EX2); free(sig);
+    free(sig);
     return 0;
+}
+
+int FN(wxo_tree_costs_jbb)(T *costs, const T *X, int64_t n, int64_t L, int64_t N, int redundant,
+                           int cost_kind, double p)
+{
+    int64_t nl = n * L;
+    T *EX = (T *)calloc(nl, sizeof(T)), *EX2 = (T *)calloc(nl, sizeof(T));
+    /* sum(X, dims=3): sequential over the signal axis for each (i,j) */
+    for (int64_t s = 0; s < N; s++)
+        for (int64_t e = 0; e < nl; e++) {
+            T xv = X[s * nl + e];
+            EX[e] = (T)(EX[e] + xv);
+            EX2[e] = (T)(EX2[e] + (T)(xv * xv));
+        }
+    int rc = FN(wxo_tree_costs_jbb_sums)(costs, EX, EX2, n, L, N, redundant, cost_kind, p);
+    free(EX); free(EX2);
+    return rc;
 }
 
 /* BestBasis.jl:59-83  bestbasis_treeselection(costs, n, type) (costs is mutated) */

@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: throughput floors on an MI355X (box-dependent; NOT part of the -m gpu parity gate)")
 
 
 @pytest.fixture(scope="session")

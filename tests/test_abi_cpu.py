@@ -96,6 +96,42 @@ def test_treeselect_host_routine_matches_oracle(wx, oracle):
         wx.bestbasis_treeselection(rng.standard_normal(7), 4, 4)                # quad tree: 5 costs of depth 1 needed
 
 
+def test_treeselect_gap_host_routine(wx, oracle):
+    """wx_treeselect_gap_*: the same tree as wx_treeselect_* / the oracle, and the margin of the closest decision TAKEN
+    (nodes pruned with an ancestor's subtree before their turn do not count), against a restatement of BestBasis.jl:59-83."""
+    rng = np.random.default_rng(44)
+    for n in (4, 16, 64, 256):
+        for kind in ("min", "max"):
+            for dt in (np.float64, np.float32):
+                costs = (rng.standard_normal(2 * n - 1) ** 2).astype(dt)
+                tree, gap = wx.bestbasis_treeselection(costs, n, kind, return_gap=True)
+                assert (tree == oracle.bestbasis_treeselection(costs, n, kind)).all()
+                c = costs.astype(dt).copy()
+                alive = np.zeros(n - 1, dtype=bool)
+                alive[:n - 1] = True
+                ref = np.inf
+                for i in range(n - 1, 0, -1):
+                    if not alive[i - 1]:
+                        continue
+                    pc, cc = c[i - 1], dt(c[2 * i - 1] + c[2 * i])
+                    ref = min(ref, abs(float(cc) - float(pc)) / abs(float(pc)))
+                    if (cc < pc) if kind == "min" else (cc > pc):
+                        c[i - 1] = cc
+                    else:
+                        stack = [i]
+                        while stack:
+                            j = stack.pop()
+                            if j <= n - 1 and alive[j - 1]:
+                                alive[j - 1] = False
+                                stack += [2 * j, 2 * j + 1]
+                assert (alive == tree).all()
+                assert gap == pytest.approx(ref, rel=1e-12)
+    ties = np.ones(7)
+    ties[1:] = 0.5
+    assert wx.bestbasis_treeselection(ties, 4, return_gap=True)[1] == 0.0       # an exact tie is margin 0
+    assert wx.bestbasis_treeselection(np.ones(1), 4, return_gap=True)[1] == np.inf   # L = 0: no decision
+
+
 def test_acwpd_jbb_moments_is_float64_only(wx):
     """ACWT is Float64-only like the reference (acwt_one_level.jl:101-106): Float32 data must be refused, never
     reinterpreted (there is no wx_acwpd_jbb_moments_f32)"""

@@ -76,11 +76,11 @@ def test_all_gpus_over_rccl(tmp_path):
     _run_ranks(n, "nccl", tmp_path, 8 * n + 3)
 
 
-def _bench(args, env_extra=None, timeout=900):
+def _bench(args, env_extra=None, timeout=900, expect_failure=False):
     env = dict(os.environ, **(env_extra or {}))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
                        timeout=timeout)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert (r.returncode != 0) if expect_failure else (r.returncode == 0), (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
 
@@ -125,10 +125,12 @@ def test_bench_watchdog_ends_a_stuck_rank():
 
 
 def test_bench_abandons_a_stuck_exchange_loop_and_keeps_the_headline():
-    """the all-gather loop is reported next to `value`, never part of it: if it does not finish inside --gather-timeout every rank leaves
-    with exit code 0 and rank 0 prints the line of the main loop with the failure noted (a hung grouped send / recv cannot be
-    cancelled).  A timeout shorter than the loop's warm-up makes every run 'stuck'."""
+    """the all-gather loop is reported next to `value`, never part of it: if it does not finish inside --gather-timeout rank 0 prints
+    the line of the main loop (serialised before the loop started) with the failure noted and `exchange_abandoned`, and every rank
+    leaves with exit code 4 -- so the launcher reports a NON-ZERO code (a hung collective is never a healthy run) while the headline
+    number survives on stdout.  A timeout shorter than the loop's warm-up makes every run 'stuck'."""
     j = _bench(["--workload", "cfg2", "--batch", "37", "--steps", "2", "--warmup", "1", "--no-cpu", "--watchdog", "600", "--gpus", "2",
-                "--gather-timeout", "0.0001"], {"WX_BENCH_BACKEND": "gloo"})
+                "--gather-timeout", "0.0001"], {"WX_BENCH_BACKEND": "gloo"}, expect_failure=True)
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["ms_per_step"] > 0
     assert "abandoned" in j["with_allgather"]["error"] and j["with_allgather_value"] is None
+    assert j["exchange_abandoned"] is True

@@ -301,6 +301,26 @@ def test_float32_rounding_rule(oracle, wx):
     assert 0 < err < 1e-5
 
 
+def test_streaming_acwpd_sums_equal_tree_costs_sums(oracle, wx):
+    """oracle.acwpd_jbb_sums + tree_costs_jbb_sums (what the large-batch config-5 test compares with) are bit-identical to
+    tree_costs on the materialised table: bestbasis_tree.jl:153-154 sums sequentially over the signal axis."""
+    rng = np.random.default_rng(150)
+    q = wx.wavelet(wx.WT.coif6).qmf
+    for n, L, N in ((64, 6, 37), (128, 5, 70), (32, 5, 1)):
+        x = np.asfortranarray(rng.standard_normal((n, N)))
+        X = np.asfortranarray(np.stack([oracle.acwpd(x[:, b], q, L) for b in range(N)], axis=-1))
+        s, s2 = oracle.acwpd_jbb_sums(x, q, L)
+        ex = np.zeros_like(s); ex2 = np.zeros_like(s)
+        for b in range(N):
+            ex += X[:, :, b]; ex2 += X[:, :, b] * X[:, :, b]
+        assert (s == ex).all() and (s2 == ex2).all()
+        for red in (True, False):
+            for cost in ("loglp", "norm"):
+                a = oracle.tree_costs_jbb(X[:, :L + 1] if not red else X, red, cost)
+                b = oracle.tree_costs_jbb_sums(s[:, :L + 1] if not red else s, s2[:, :L + 1] if not red else s2, N, red, cost)
+                assert (a == b).all()
+
+
 def test_jbb_tree_is_valid_and_costs_shape(oracle, wx):
     """test/bestbasis.jl:25-32 only asserts isvalidtree (tree parity is unpinned by the reference)."""
     rng = np.random.default_rng(11)

@@ -114,6 +114,8 @@ _EXTRA_SIGS = {
 _PLAIN_SIGS = {
     "wx_treeselect_f64": [_P, _L, _L, _I, _P],
     "wx_treeselect_f32": [_P, _L, _L, _I, _P],
+    "wx_treeselect_gap_f64": [_P, _L, _L, _I, _P, _P],
+    "wx_treeselect_gap_f32": [_P, _L, _L, _I, _P, _P],
     "wx_treeselect2d_f64": [_P, _L, _L, _L, _I, _P],
     "wx_treeselect2d_f32": [_P, _L, _L, _L, _I, _P],
     "wx_shutdown": [],

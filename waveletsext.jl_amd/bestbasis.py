@@ -161,9 +161,10 @@ def tree_costs(X, method=None):
     return costs
 
 
-def bestbasis_treeselection(costs, n, *args):
+def bestbasis_treeselection(costs, n, *args, return_gap=False):
     """bestbasis_treeselection(costs, n[, type]) BestBasis.jl:59-83 and (costs, n, m[, type]) :85-110; `costs`
-    (host copy) is mutated like the reference, returns the BitVector."""
+    (host copy) is mutated like the reference, returns the BitVector.  return_gap=True (1-D) also returns the margin of the
+    closest split decision, min |cc - pc| / |pc| over the decisions taken (`wx_treeselect_gap_*`)."""
     args = list(args)
     kind = args.pop() if args and isinstance(args[-1], str) else "min"
     if kind not in ("min", "max"):
@@ -182,6 +183,12 @@ def bestbasis_treeselection(costs, n, *args):
         return tree.astype(bool)
     assert k <= gettreelength(2 * n)                                  # BestBasis.jl:63
     tree = np.zeros(max(n - 1, 0), dtype=np.uint8)
+    if return_gap:
+        gap = ctypes.c_double(0.0)
+        fn = getattr(_lib.lib(), "wx_treeselect_gap_f64" if c.dtype == np.float64 else "wx_treeselect_gap_f32")
+        _lib.check(fn(ctypes.c_void_p(c.ctypes.data), k, n, 0 if kind == "min" else 1, ctypes.c_void_p(tree.ctypes.data),
+                      ctypes.byref(gap)))
+        return tree.astype(bool), float(gap.value)
     fn = getattr(_lib.lib(), "wx_treeselect_f64" if c.dtype == np.float64 else "wx_treeselect_f32")
     _lib.check(fn(ctypes.c_void_p(c.ctypes.data), k, n, 0 if kind == "min" else 1, ctypes.c_void_p(tree.ctypes.data)))
     return tree.astype(bool)

@@ -248,7 +248,7 @@ static void wx_delete_subtree(uint8_t *bt, int64_t len, int64_t i)
     }
 }
 template <typename T>
-static int api_treeselect(T *costs, int64_t k, int64_t n, int type_max, uint8_t *tree)
+static int api_treeselect(T *costs, int64_t k, int64_t n, int type_max, uint8_t *tree, double *min_rel_gap = nullptr)
 {
     WX_REQUIRE(costs && tree, WX_EARG, "NULL argument");
     WX_REQUIRE(type_max == 0 || type_max == 1, WX_EARG, "Unsupported type (BestBasis.jl:64)");
@@ -263,14 +263,24 @@ static int api_treeselect(T *costs, int64_t k, int64_t n, int type_max, uint8_t 
     const int64_t ntree = n - 1;
     memset(tree, 0, (size_t)ntree);
     for (int64_t i = 1; i <= ((int64_t)1 << L) - 1; ++i) tree[i - 1] = 1;
+    // the margin of the closest decision actually taken: min |cc - pc| / |pc| ("report the minimum relative cost gap
+    // next to the tree"): a device / reference difference in summation order can only flip a split whose margin is of the
+    // order of the costs' rounding error
+    double gap = INFINITY;
     for (int64_t i = ntree; i >= 1; --i) {
         if (!tree[i - 1]) continue;
         const T pc = costs[i - 1];
         const T cc = (T)(costs[2 * i - 1] + costs[2 * i]);
+        if (min_rel_gap) {
+            const double diff = fabs((double)cc - (double)pc), den = fabs((double)pc);
+            const double g = diff == 0.0 ? 0.0 : (den > 0.0 ? diff / den : INFINITY);
+            if (g < gap) gap = g;                                    // NaN / inf - inf margins never lower it
+        }
         if (!type_max && cc < pc) costs[i - 1] = cc;
         else if (type_max && cc > pc) costs[i - 1] = cc;
         else wx_delete_subtree(tree, ntree, i);
     }
+    if (min_rel_gap) *min_rel_gap = gap;
     WX_REQUIRE(wx_isvalidtree1d(n, tree, ntree), WX_EASSERT, "@assert isvalidtree(zeros(n), tree)");
     return WX_OK;
 }
@@ -409,6 +419,10 @@ int wx_treeselect_f64(double *costs, int64_t k, int64_t n, int type_max, uint8_t
 { return api_treeselect<double>(costs, k, n, type_max, tree); }
 int wx_treeselect_f32(float *costs, int64_t k, int64_t n, int type_max, uint8_t *tree)
 { return api_treeselect<float>(costs, k, n, type_max, tree); }
+int wx_treeselect_gap_f64(double *costs, int64_t k, int64_t n, int type_max, uint8_t *tree, double *min_rel_gap)
+{ WX_REQUIRE(min_rel_gap, WX_EARG, "NULL argument"); return api_treeselect<double>(costs, k, n, type_max, tree, min_rel_gap); }
+int wx_treeselect_gap_f32(float *costs, int64_t k, int64_t n, int type_max, uint8_t *tree, double *min_rel_gap)
+{ WX_REQUIRE(min_rel_gap, WX_EARG, "NULL argument"); return api_treeselect<float>(costs, k, n, type_max, tree, min_rel_gap); }
 int wx_acwpd_jbb_moments_f64(const double *x, double *sum, double *sumsq, int64_t n, int L, int64_t batch,
                              const double *qmf, int F, int accumulate, void *stream)
 { return api_acwpd_jbb_moments(x, sum, sumsq, n, L, batch, qmf, F, accumulate, stream); }

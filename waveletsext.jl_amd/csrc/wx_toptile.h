@@ -35,6 +35,7 @@
 #pragma once
 #include "wx_common.h"
 #include <type_traits>
+#include <atomic>
 
 constexpr int WX_TT_P = 4;          // pairs per thread and window
 constexpr int WX_TT_NT = 256;

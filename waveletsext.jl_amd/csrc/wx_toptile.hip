@@ -37,12 +37,16 @@ bool wx_top_tree(int NL, unsigned split, unsigned deep, const int *W2, WxTopTree
 // workgroups that are resident at once (each walks its share of the tiles, the next tile's input in registers)
 int64_t wx_top_grid(int64_t ntiles, size_t lds)
 {
-    static int cus = 0;
+    // per device (a process may drive several GPUs): the CU count of the CURRENT device, cached per index
+    static std::atomic<int> cus_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    int cus = cus_of[dev & 63].load(std::memory_order_relaxed);
     if (!cus) {
-        int dev = 0;
         hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; else (void)hipGetLastError();
         if (cus <= 0) cus = 256;
+        cus_of[dev & 63].store(cus, std::memory_order_relaxed);
     }
     static const int env = getenv("WX_TOPTILE_WGS") ? atoi(getenv("WX_TOPTILE_WGS")) : 0;
     int per = (int)((160 * 1024) / (lds + 512));
@@ -67,8 +71,16 @@ static int launch_top_fwd(const T *src, T *dst, T *deep, int64_t n, int64_t batc
     constexpr size_t lds = G::lds_bytes(sizeof(T));
     auto kern = k_top_tile_fwd<T, F, NL, TS>;
     if (lds > 64 * 1024) {
-        static bool raised = false;                              // per instantiation
-        if (!raised) { WX_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); raised = true; }
+        // per instantiation AND per device: the attribute belongs to the function on one device (a process-wide flag made
+        // the launch on a second GPU fail with more than 64 KiB of LDS)
+        static std::atomic<uint64_t> raised{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+        const uint64_t bit = (uint64_t)1 << (dev & 63);
+        if (dev > 63 || !(raised.load(std::memory_order_acquire) & bit)) {
+            WX_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised.fetch_or(bit, std::memory_order_release);
+        }
     }
     const int64_t ntiles = batch * ((n >> NL) / G::TL);
     if (ntiles >= ((int64_t)1 << 31)) return wx_set_error(WX_EUNSUPPORTED, "top levels: too many tiles");

@@ -15,8 +15,14 @@ static int launch_top_inv(const T *src, T *dst, const T *deep, int64_t n, int64_
     constexpr size_t lds = G::lds_bytes(sizeof(T));
     auto kern = k_top_tile_inv<T, F, NL, TS>;
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) { WX_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); raised = true; }
+        static std::atomic<uint64_t> raised{0};                  // per instantiation and per device (see wx_toptile.hip)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+        const uint64_t bit = (uint64_t)1 << (dev & 63);
+        if (dev > 63 || !(raised.load(std::memory_order_acquire) & bit)) {
+            WX_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised.fetch_or(bit, std::memory_order_release);
+        }
     }
     const int64_t ntiles = batch * ((n >> NL) / G::TL);
     if (ntiles >= ((int64_t)1 << 31)) return wx_set_error(WX_EUNSUPPORTED, "top levels: too many tiles");

@@ -575,6 +575,15 @@ function treeselect!(costs::Vector{T}, sig::Tuple, type::Symbol = :min) where T<
     c_treeselect(T, costs, length(costs), sig, type === :max ? 1 : 0, tree)
     return BitVector(tree .!= 0)
 end
+"the same selection for 1-D signals plus the margin of its closest decision, min |cc - pc| / |pc| (a tree is reproducible across
+summation orders only while this is far above the rounding of the costs, ~1e-13): `(tree, min_rel_gap)`"
+function treeselect_gap!(costs::Vector{T}, n::Integer, type::Symbol = :min) where T<:FT
+    type in (:min, :max) || throw(ArgumentError("Unsupported type $type."))
+    tree = Vector{UInt8}(undef, treelen((Int(n),)))
+    gap = Ref{Float64}(Inf)
+    check(wx_treeselect_gap(T, costs, length(costs), Int(n), type === :max ? 1 : 0, tree, gap))
+    return BitVector(tree .!= 0), gap[]
+end
 bestbasis_treeselection(costs::HIP{T,1}, n::Integer, type::Symbol = :min) where T<:FT = treeselect!(raw(costs), (Int(n),), type)
 bestbasis_treeselection(costs::HIP{T,1}, n::Integer, m::Integer, type::Symbol = :min) where T<:FT =
     treeselect!(raw(costs), (Int(n), Int(m)), type)
@@ -610,6 +619,9 @@ function tree_costs(x::HIP{Float64,2}, wt::OrthoFilter, L::Integer, method::JBB)
 end
 bestbasistree(x::HIP{Float64,2}, wt::OrthoFilter, L::Integer = maxtransformlevels(size(x, 1)), method::JBB = JBB(redundant = true)) =
     treeselect!(tree_costs(x, wt, L, method), (size(x, 1),))
+"`(tree, min_rel_gap)` of the fused config-5 path"
+bestbasistree_gap(x::HIP{Float64,2}, wt::OrthoFilter, L::Integer = maxtransformlevels(size(x, 1)), method::JBB = JBB(redundant = true)) =
+    treeselect_gap!(tree_costs(x, wt, L, method), size(x, 1))
 
 # ---------------------------------------------------------------------------------------------------------------------
 # denoising -- Denoising.jl:146-166, 214-232, 285-327, 483-712
