@@ -26,7 +26,14 @@
  *    arguments; wx_last_error() gives the message.  Nothing throws across the boundary.
  *  - In/out buffers must not alias unless stated.  The library is re-entrant (callable from several host
  *    threads on their own streams); its only state is the per-thread last-error string, the cached scratch
- *    pool and the cache of small constant tables.  examples/roundtrip.c drives it from plain C.
+ *    pool, the cache of small constant tables (both per device) and, for host-array calls, one pinned
+ *    staging ring with its copy threads -- all released by wx_shutdown().  examples/roundtrip.c drives it from plain C.
+ *  - Host arrays of 64 MiB and more: inputs travel through the pinned ring (host threads fill one buffer while the
+ *    DMA engine drains the other), result arrays receive madvise(MADV_HUGEPAGE) before their first touch so that a
+ *    freshly allocated array faults in 2 MiB steps (nothing else about the caller's memory changes).
+ *  - Dispatch does not depend on the environment: the library's WX_* tuning knobs (profiles/NOTES.md, DESIGN.md
+ *    section 10) are read only when the process also sets WX_KNOBS=1.  The parity suite's dispatch override lives in
+ *    csrc/wx_debug.h, outside this header.
  */
 #ifndef WAVELETSEXT_HIP_H
 #define WAVELETSEXT_HIP_H
@@ -53,9 +60,6 @@ int wx_device_count(void);                  /* number of visible HIP devices (0 
 const char *wx_build_info(void);
 /* releases the library's only state, the cached stream-ordered scratch of the current device */
 int wx_shutdown(void);
-/* test hook: 1 forces the one-level-per-launch kernels instead of the fused kernels; 2 keeps the fused LDS kernels
- * but skips the register-resident ones (Haar Walsh-Hadamard, lattice) so that both families can be checked */
-void wx_set_force_generic(int on);
 
 /* ------------------------------------------------------------------------------------------
  * 1-D decimated wavelet packets
@@ -236,6 +240,19 @@ int wx_getbasiscoef2d_f64(const double *Xw, double *out, int64_t m, int64_t n, i
                           int64_t batch, void *stream);
 int wx_getbasiscoef2d_f32(const float *Xw, float *out, int64_t m, int64_t n, int k, const uint8_t *tree, int64_t ntree,
                           int64_t batch, void *stream);
+/* getbasiscoefall(Xw, tree::BitArray{2}) Utils.jl:199-225: ONE tree per signal -- what bestbasistreeall (BestBasis.jl:253-262)
+ * returns.  trees: HOST pointer, (ntree, batch) bytes, column b = the tree of signal b (a Julia BitMatrix converted with
+ * Matrix{UInt8}); every tree is checked like the reference does (:209), one launch gathers all signals.
+ * 1-D: Xw (n, k, batch) -> out (n, batch); 2-D: Xw (m, n, k, batch) -> out (m, n, batch). */
+int wx_getbasiscoef1d_trees_f64(const double *Xw, double *out, int64_t n, int k, const uint8_t *trees, int64_t ntree, int64_t batch,
+                                void *stream);
+int wx_getbasiscoef1d_trees_f32(const float *Xw, float *out, int64_t n, int k, const uint8_t *trees, int64_t ntree, int64_t batch,
+                                void *stream);
+int wx_getbasiscoef2d_trees_f64(const double *Xw, double *out, int64_t m, int64_t n, int k, const uint8_t *trees, int64_t ntree,
+                                int64_t batch, void *stream);
+int wx_getbasiscoef2d_trees_f32(const float *Xw, float *out, int64_t m, int64_t n, int k, const uint8_t *trees, int64_t ntree,
+                                int64_t batch, void *stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Standard (per-signal) best basis, BB -- SURVEY 8(f) row 3, widened after the 8(a) rows.
@@ -429,13 +446,19 @@ int wx_isiwpd_f32(float *W, const uint8_t *status, float *xh, int64_t n, int L, 
  *      all signals of bestbasis/bestbasis_tree.jl:153-154.
  * id128: 128-byte RCCL unique id made by rank 0 (wx_comm_unique_id) and broadcast by the launcher
  * (MPI.jl / Distributed.jl / torch.distributed).  Buffers are device pointers; `count` elements per
- * rank (equal on every rank: pad ragged shards), recv holds nranks*count; asynchronous on `stream`.
+ * rank (equal on every rank; wx_allgatherv_out_* takes ragged shards), recv holds nranks*count; asynchronous on `stream`.
  * ------------------------------------------------------------------------------------------ */
 int wx_comm_unique_id(void *id128);
 int wx_comm_init(int nranks, int rank, const void *id128, void **comm);
 int wx_comm_destroy(void *comm);
 int wx_allgather_out_f64(const double *send, double *recv, int64_t count, void *comm, void *stream);
 int wx_allgather_out_f32(const float *send, float *recv, int64_t count, void *comm, void *stream);
+/* C1 for RAGGED shards (B mod nranks != 0; the reference's drivers take any batch, dwt/dwt_all.jl:277-279): counts[r]
+ * (host array, nranks entries, identical on every rank) = elements rank r contributes -- signal length x its share of the
+ * batch; they land at element offset counts[0] + ... + counts[r-1] of recv on every rank.  One grouped point-to-point
+ * exchange (ncclSend / ncclRecv), no padding; `send` may already be recv + this rank's offset (in place). */
+int wx_allgatherv_out_f64(const double *send, double *recv, const int64_t *counts, int nranks, void *comm, void *stream);
+int wx_allgatherv_out_f32(const float *send, float *recv, const int64_t *counts, int nranks, void *comm, void *stream);
 int wx_allreduce_moments_f64(double *buf, int64_t count, void *comm, void *stream);
 int wx_allreduce_moments_f32(float *buf, int64_t count, void *comm, void *stream);
 

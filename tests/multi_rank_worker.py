@@ -101,6 +101,13 @@ def main():
                 fulln = comm.allgather_batch(piece, Be)
                 torch.cuda.synchronize(dev)
                 assert torch.equal(fulln, R_all[:, :Be]), "NativeComm.allgather_batch"
+                # ragged shards through the C ABI (wx_allgatherv_out_*): the whole batch B, B mod world != 0 in the callers' runs
+                lo_r, hi_r = wd.shard_range(B, world, rank)
+                rag = wx.jl_empty((n, hi_r - lo_r), torch.float64, dev)
+                rag.copy_(R_all[:, lo_r:hi_r])
+                fullv = comm.allgatherv_batch(rag, B)
+                torch.cuda.synchronize(dev)
+                assert torch.equal(fullv, R_all), "NativeComm.allgatherv_batch (ragged)"
                 s2, q2 = bb.jbb_moments(yl)
                 s2, q2 = comm.allreduce_moments(s2, q2)
                 torch.cuda.synchronize(dev)

@@ -214,7 +214,7 @@ def test_config4_lattice_and_lds_kernels_agree():
         outs = []
         for flag in ("1", "0"):
             f1, f2 = os.path.join(d, "y%s.npy" % flag), os.path.join(d, "x%s.npy" % flag)
-            r = subprocess.run([sys.executable, "-c", code, f1, f2], env=dict(os.environ, WX_LATTICE2D=flag),
+            r = subprocess.run([sys.executable, "-c", code, f1, f2], env=dict(os.environ, WX_KNOBS="1", WX_LATTICE2D=flag),
                                capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             outs.append((np.load(f1), np.load(f2)))
@@ -269,6 +269,6 @@ def test_2d_lattice_full_depth_is_the_lattice_path_and_deterministic(wx):
     for deep in ("1", "0"):
         f = os.path.join(root, "gpurun_out", "deep_%s.npy" % deep)
         os.makedirs(os.path.dirname(f), exist_ok=True)
-        subprocess.check_call([sys.executable, "-c", code % f], env=dict(os.environ, WX_LATTICE2D_DEEP=deep), cwd=root)
+        subprocess.check_call([sys.executable, "-c", code % f], env=dict(os.environ, WX_KNOBS="1", WX_LATTICE2D_DEEP=deep), cwd=root)
         outs.append(np.load(f).astype(np.float64))
     assert relerr(outs[0], outs[1]) <= 3e-6 and not np.array_equal(outs[0], outs[1])

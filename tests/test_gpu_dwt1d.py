@@ -224,6 +224,9 @@ def test_native_rccl_exchange_single_rank(wx):
             full = comm.allgather_batch(x, 5)
             torch.cuda.synchronize()
             assert full.shape == x.shape and torch.equal(full, x)
+            fullv = comm.allgatherv_batch(x, 5)                       # the ragged form: counts = [64 * 5]
+            torch.cuda.synchronize()
+            assert torch.equal(fullv, x)
             s = wx.jl_empty((64, 3), dt, "cuda"); s.normal_()
             q = wx.jl_empty((64, 3), dt, "cuda"); q.normal_()
             s2, q2 = comm.allreduce_moments(s, q)
@@ -234,6 +237,9 @@ def test_native_rccl_exchange_single_rank(wx):
             from waveletsext_jl_amd import _lib
             host = np.zeros(4)
             _lib.check(_lib.lib().wx_allreduce_moments_f64(host.ctypes.data, 4, comm.handle, None))
+        with pytest.raises(wx.ArgumentError):                         # one count per rank of the communicator
+            two = (ctypes.c_int64 * 2)(3, 4)
+            _lib.check(_lib.lib().wx_allgatherv_out_f64(x.data_ptr(), x.data_ptr(), ctypes.cast(two, ctypes.c_void_p), 2, comm.handle, None))
     finally:
         comm.close()
     wx.shutdown()

@@ -64,7 +64,7 @@ def test_target_geometry_fused_forward_modes(fwd_mode):
         "e1 = np.abs(wx.wptall(x, wt, 10) - exp).max() / np.abs(exp).max()\n"
         "e2 = np.abs(wx.iwptall(exp, wt, 10) - x).max() / np.abs(x).max()\n"
         "assert e1 <= 1e-10 and e2 <= 1e-10, (e1, e2)\n" % (ROOT, os.path.join(ROOT, "oracle")))
-    env = dict(os.environ, WX_FWD_MODE=fwd_mode)
+    env = dict(os.environ, WX_KNOBS="1", WX_FWD_MODE=fwd_mode)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
 
@@ -241,8 +241,10 @@ def test_short_signals_8_to_64_per_wavefront(wx, oracle, n):
 
 
 def test_float32_signals_through_the_lattice(wx, oracle):
-    """Float32 signals of 4096 samples: Float32 in memory, Float64 in the registers (wx_lattice_f32.hip): the Float64 transform
-    rounded once; tolerance of the Float32 path 1e-5, observed < 1e-6"""
+    """Float32 signals of 4096 samples (wx_lattice_f32.hip).  Round 5: Float32 ARITHMETIC on pairs of signals (the reference itself
+    rounds to Float32 at every accumulate, dwt/dwt_one_level.jl:97-103): against the reference's Float32 semantics (the oracle's
+    Float32 instantiation) within the 1e-5 budget, and against the exact Float64 transform within 4e-6 (observed 1.1e-6 at L = 12;
+    the Float64-register kernels of round 4 rounded once: < 1e-6).  A batch of 3: one full pair + the lone last signal."""
     rng = np.random.default_rng(32)
     for wname in ("db2", "db4", "db7", "coif6"):
         wt = _wt(wx, wname)
@@ -250,7 +252,8 @@ def test_float32_signals_through_the_lattice(wx, oracle):
         for L in (5, 6, 9, 12):
             exp = oracle.wptall(x.astype(np.float64), wt.qmf, L)
             got = wx.wptall(x, wt, L)
-            assert got.dtype == np.float32 and relerr(got.astype(np.float64), exp) <= 1e-6, (wname, L)
-            assert relerr(wx.iwptall(exp.astype(np.float32), wt, L).astype(np.float64), x.astype(np.float64)) <= 1e-6
+            assert got.dtype == np.float32 and relerr(got.astype(np.float64), exp) <= 4e-6, (wname, L)
+            assert relerr(got, oracle.wptall(x, wt.qmf, L)) <= 1e-5, (wname, L)
+            assert relerr(wx.iwptall(exp.astype(np.float32), wt, L).astype(np.float64), x.astype(np.float64)) <= 4e-6
             tab = np.stack([oracle.wpd(x[:, b].astype(np.float64), wt.qmf, L) for b in range(3)], axis=-1)
-            assert relerr(wx.iwpdall(np.asfortranarray(tab.astype(np.float32)), wt, L).astype(np.float64), x.astype(np.float64)) <= 1e-6
+            assert relerr(wx.iwpdall(np.asfortranarray(tab.astype(np.float32)), wt, L).astype(np.float64), x.astype(np.float64)) <= 4e-6

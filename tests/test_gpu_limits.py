@@ -151,6 +151,6 @@ def test_threshold_selection_chip_sort_equals_window_sort(wx):
             "print(repr(list(wx.surethresholdall(x, False)) + list(wx.relerrorthresholdall(x, False))))\n")
     outs = []
     for wg in ("65536", "1048576"):
-        env = dict(os.environ, WX_SHRINK_WG_MAX=wg)
+        env = dict(os.environ, WX_KNOBS="1", WX_SHRINK_WG_MAX=wg)
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     assert outs[0] == outs[1] and len(outs[0]) > 20

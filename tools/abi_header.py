@@ -13,6 +13,7 @@ CTYPES = {
     "float *": ("Ptr{Float32}", "P"),
     "uint8_t *": ("Ptr{UInt8}", "P"),
     "int32_t *": ("Ptr{Int32}", "P"),
+    "int64_t *": ("Ptr{Int64}", "P"),
     "void *": ("Ptr{Cvoid}", "P"),
     "void **": ("Ptr{Ptr{Cvoid}}", "PP"),
     "char *": ("Cstring", "S"),

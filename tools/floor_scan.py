@@ -31,7 +31,7 @@ def timed(torch, fn, calls=5, batches=3):
     return best
 
 
-def scan(wname="db4", lengths=None, out=None):
+def scan(wname="db4", lengths=None, out=None, dtypes=("f64", "f32")):
     import numpy as np
     import torch
     import waveletsext_jl_amd as wx
@@ -39,6 +39,8 @@ def scan(wname="db4", lengths=None, out=None):
     wt = wx.wavelet(getattr(wx.WT, wname))
     rows = []
     for dt, esz, dn in ((torch.float64, 8, "f64"), (torch.float32, 4, "f32")):
+        if dn not in dtypes:
+            continue
         for n in lengths or [1 << k for k in range(6, 17)]:
             B = (1 << 30) // (n * esz)
             x = wx.jl_empty((n, B), dt, "cuda")
@@ -73,4 +75,6 @@ def scan(wname="db4", lengths=None, out=None):
 
 
 if __name__ == "__main__":
-    scan(sys.argv[1] if len(sys.argv) > 1 else "db4")
+    # python tools/floor_scan.py [wavelet] [f64|f32|both] [n ...]
+    dts = ("f64", "f32") if len(sys.argv) < 3 or sys.argv[2] == "both" else (sys.argv[2],)
+    scan(sys.argv[1] if len(sys.argv) > 1 else "db4", [int(v) for v in sys.argv[3:]] or None, dtypes=dts)

@@ -44,8 +44,8 @@ def _declare(L):
     L.wx_last_error.restype = ctypes.c_char_p
     L.wx_device_count.restype = _I
     L.wx_build_info.restype = ctypes.c_char_p
-    L.wx_set_force_generic.argtypes = [_I]
-    L.wx_set_force_generic.restype = None
+    L.wx_debug_set_dispatch.argtypes = [_I]           # csrc/wx_debug.h: test-suite hook, not in the public header
+    L.wx_debug_set_dispatch.restype = None
     sigs = {
         # name: argtypes (without the _f64/_f32 suffix)
         "wx_wpd1d": [_P, _P, _L, _I, _L, _P, _I, _P],
@@ -104,6 +104,8 @@ _EXTRA_SIGS = {
     "wx_iacwpd2d": [_P, _P, _L, _L, _L, _I, _P, _L, _L, _P],
     "wx_jbb_costs2d": [_P, _P, _L, _L, _L, _L, _I, _I, ctypes.c_double, _P, _P],
     "wx_getbasiscoef2d": [_P, _P, _L, _L, _I, _P, _L, _L, _P],
+    "wx_getbasiscoef1d_trees": [_P, _P, _L, _I, _P, _L, _L, _P],
+    "wx_getbasiscoef2d_trees": [_P, _P, _L, _L, _I, _P, _L, _L, _P],
     "wx_jbb_moments": [_P, _P, _P, _L, _L, _I, _P],
     "wx_jbb_costs": [_P, _P, _L, _L, _L, _I, _I, ctypes.c_double, _P, _P],
     "wx_acwpd_jbb_moments": [_P, _P, _P, _L, _I, _L, _P, _I, _I, _P],
@@ -160,6 +162,8 @@ _PLAIN_SIGS = {
     "wx_comm_destroy": [_P],
     "wx_allgather_out_f64": [_P, _P, _L, _P, _P],
     "wx_allgather_out_f32": [_P, _P, _L, _P, _P],
+    "wx_allgatherv_out_f64": [_P, _P, _P, _I, _P, _P],
+    "wx_allgatherv_out_f32": [_P, _P, _P, _I, _P, _P],
     "wx_allreduce_moments_f64": [_P, _L, _P, _P],
     "wx_allreduce_moments_f32": [_P, _L, _P, _P],
 }
@@ -194,4 +198,4 @@ def shutdown():
 
 
 def set_force_generic(on):
-    lib().wx_set_force_generic(2 if on == 2 else (1 if on else 0))
+    lib().wx_debug_set_dispatch(2 if on == 2 else (1 if on else 0))

@@ -69,7 +69,11 @@ static __device__ __forceinline__ int acs_rbase(int lane, int c)
     return lane * 8 + (((c ^ (lane >> 2)) & 3) << 1);
 }
 
-template <int WPE>
+// SUMS = false (round 5): only the sums of squares.  The first moments of EVERY node are the transform of the sum signal
+// (sum_b acwpd(x_b) = acwpd(sum_b x_b): api_acwpd_jbb_moments runs one extra signal through the plain acwpd kernels), which removes one
+// of the three vector instructions per coefficient and signal -- 248 of the ~1120 this kernel issues per 8-signal block; it is bound
+// by FP64 issue (profiles/r03_cfg5.md), so the time follows.
+template <int WPE, bool SUMS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void k_acwpd_subtree_mfma(const double *__restrict__ top, double *__restrict__ sum, double *__restrict__ sumsq,
                           const double *__restrict__ tab, int D0, int ncols_top, int64_t batch, int accumulate)
@@ -188,12 +192,14 @@ void k_acwpd_subtree_mfma(const double *__restrict__ top, double *__restrict__ s
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                a1s += v1[c].x; a1q += acs_sq(v1[c].x);
+                if (SUMS) a1s += v1[c].x;
+                a1q += acs_sq(v1[c].x);
 #pragma unroll
-                for (int e = 0; e < 2; ++e) { a2s[e] += v2[e][c].x; a2q[e] += acs_sq(v2[e][c].x); }
-                a1s += v1[c].y; a1q += acs_sq(v1[c].y);
+                for (int e = 0; e < 2; ++e) { if (SUMS) a2s[e] += v2[e][c].x; a2q[e] += acs_sq(v2[e][c].x); }
+                if (SUMS) a1s += v1[c].y;
+                a1q += acs_sq(v1[c].y);
 #pragma unroll
-                for (int e = 0; e < 2; ++e) { a2s[e] += v2[e][c].y; a2q[e] += acs_sq(v2[e][c].y); }
+                for (int e = 0; e < 2; ++e) { if (SUMS) a2s[e] += v2[e][c].y; a2q[e] += acs_sq(v2[e][c].y); }
             }
         }
         // the depth-3 slots overlay the two regions just read: same wavefront, LDS operations complete in order
@@ -235,7 +241,8 @@ void k_acwpd_subtree_mfma(const double *__restrict__ top, double *__restrict__ s
                 double y[2][4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    a3s[m] += x[m]; a3q[m] += acs_sq(x[m]);
+                    if (SUMS) a3s[m] += x[m];
+                    a3q[m] += acs_sq(x[m]);
                     const double S3 = fma(B31, x[(m + 3) & 3], B30 * x[(m + 1) & 3]);
                     y[0][m] = fma(c1, x[m], S3); y[1][m] = fma(c1, x[m], -S3);
                 }
@@ -243,11 +250,13 @@ void k_acwpd_subtree_mfma(const double *__restrict__ top, double *__restrict__ s
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        a4s[b][m] += y[b][m]; a4q[b][m] += acs_sq(y[b][m]);
+                        if (SUMS) a4s[b][m] += y[b][m];
+                        a4q[b][m] += acs_sq(y[b][m]);
                         const double S4 = B40 * y[b][(m + 2) & 3];
                         const double lo = fma(c1, y[b][m], S4), hi = fma(c1, y[b][m], -S4);
-                        a5s[2 * b][m] += lo; a5q[2 * b][m] += acs_sq(lo);
-                        a5s[2 * b + 1][m] += hi; a5q[2 * b + 1][m] += acs_sq(hi);
+                        if (SUMS) { a5s[2 * b][m] += lo; a5s[2 * b + 1][m] += hi; }
+                        a5q[2 * b][m] += acs_sq(lo);
+                        a5q[2 * b + 1][m] += acs_sq(hi);
                     }
             }
         }
@@ -257,8 +266,8 @@ void k_acwpd_subtree_mfma(const double *__restrict__ top, double *__restrict__ s
     const int64_t H = ((int64_t)1 << D0) + q;
     auto put = [&](int k, int pk, int i, double vs, double vq) {
         const int64_t e = (((H << k) + pk) - 1) * n + r + ((int64_t)i << D0);
-        if (accumulate) { sum[e] += vs; sumsq[e] += vq; }
-        else { sum[e] = vs; sumsq[e] = vq; }
+        if (accumulate) { if (SUMS) sum[e] += vs; sumsq[e] += vq; }
+        else { if (SUMS) sum[e] = vs; sumsq[e] = vq; }
     };
     put(1, p3 >> 2, c3 + 8 * (p3 & 3), a1s, a1q);
 #pragma unroll
@@ -276,15 +285,64 @@ void k_acwpd_subtree_mfma(const double *__restrict__ top, double *__restrict__ s
 // the MFMA subtree kernel takes the full-depth case: n' = n / 2^D0 = 32 samples, 5 levels below D0
 bool wx_acwpd_mfma_ok(int64_t n, int L, int D0)
 {
-    static const bool off = getenv("WX_ACWPD_MFMA") && atoi(getenv("WX_ACWPD_MFMA")) == 0;
+    static const bool off = wx_getenv("WX_ACWPD_MFMA") && atoi(wx_getenv("WX_ACWPD_MFMA")) == 0;
     if (off || D0 < 0 || D0 > 12 || (n >> D0) != 32 || L - D0 != 5) return false;
     // a block's eight signals are addressed with 32-bit byte offsets from a uniform base
     const int64_t sig_stride = n * ((((int64_t)1) << (D0 + 1)) - 1);
     return 8 * 8 * sig_stride < ((int64_t)1 << 32);
 }
 
+// ---- the linear path of the first moments ------------------------------------------------------------------------------------
+// part[g][i] = sum of x[i, b] over the signals b of group g, in order; then out[i] = sum over g in order.  (One thread per coefficient
+// walking all signals would be 2048 dependent loads: the groups are the parallelism; the association is fixed, so the result is
+// deterministic, and differs from one sequential sum by rounding only: bestbasis_tree.jl:153.)
+__global__ __launch_bounds__(256) void k_sum_signals_part(const double *__restrict__ x, int n, int64_t batch, int groups, double *__restrict__ part)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (i >= n) return;
+    const int64_t per = (batch + groups - 1) / groups;
+    const int64_t b0 = g * per, b1 = b0 + per < batch ? b0 + per : batch;
+    double a = 0.0;
+    int64_t b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        const double v0 = x[b * n + i], v1 = x[(b + 1) * n + i], v2 = x[(b + 2) * n + i], v3 = x[(b + 3) * n + i];
+        a = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(a, v0), v1), v2), v3);
+    }
+    for (; b < b1; ++b) a = __dadd_rn(a, x[b * n + i]);
+    part[(int64_t)g * n + i] = a;
+}
+__global__ __launch_bounds__(256) void k_sum_signals_comb(const double *__restrict__ part, int n, int groups, double *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double a = 0.0;
+    for (int g = 0; g < groups; ++g) a = __dadd_rn(a, part[(int64_t)g * n + i]);
+    out[i] = a;
+}
+__global__ __launch_bounds__(256) void k_add_to(double *__restrict__ dst, const double *__restrict__ src, int64_t count)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (int64_t)gridDim.x * 256) dst[e] = __dadd_rn(dst[e], src[e]);
+}
+int wx_dev_sum_signals(const double *x, int64_t n, int64_t batch, double *out, double *part, int groups, hipStream_t st)
+{
+    if (n >= ((int64_t)1 << 31)) return wx_set_error(WX_EUNSUPPORTED, "sum of signals: n >= 2^31");
+    const unsigned gx = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_sum_signals_part, dim3(gx, (unsigned)groups), dim3(256), 0, st, x, (int)n, batch, groups, part);
+    hipLaunchKernelGGL(k_sum_signals_comb, dim3(gx), dim3(256), 0, st, (const double *)part, (int)n, groups, out);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+int wx_dev_add_to(double *dst, const double *src, int64_t count, hipStream_t st)
+{
+    int64_t g = (count + 255) / 256;
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(k_add_to, dim3((unsigned)(g < 1 ? 1 : g)), dim3(256), 0, st, dst, src, count);
+    WX_HIP_CHECK(hipGetLastError());
+    return WX_OK;
+}
+
 int wx_dev_acwpd_subtree_mfma(const double *top, double *sum, double *sumsq, int64_t n, int L, int D0, int64_t batch,
-                              const WxAcFilt &ac, int accumulate, hipStream_t st)
+                              const WxAcFilt &ac, int accumulate, hipStream_t st, bool sums)
 {
     if (!wx_acwpd_mfma_ok(n, L, D0)) return wx_set_error(WX_EUNSUPPORTED, "acwpd subtree (matrix pipe): n / 2^D0 must be 32 with 5 levels");
     // periodised taps: at subtree level j the sub-signal splits into classes of M = 32 >> j samples and only odd lags
@@ -308,14 +366,18 @@ int wx_dev_acwpd_subtree_mfma(const double *top, double *sum, double *sumsq, int
     tabh[31] = ac.c1;
     const double *tab = (const double *)wx_const_upload(tabh, sizeof tabh, st, true);
     if (!tab) return WX_EHIP;
-    static const int wpe = getenv("WX_ACWPD_MFMA_WPE") ? atoi(getenv("WX_ACWPD_MFMA_WPE")) : 2;
+    static const int wpe = wx_getenv("WX_ACWPD_MFMA_WPE") ? atoi(wx_getenv("WX_ACWPD_MFMA_WPE")) : 2;
     const unsigned grid = 1u << (2 * D0);
     const int ncols_top = (1 << (D0 + 1)) - 1;
     const size_t lds = (256 * 8 + 48) * sizeof(double);
-    if (wpe == 1)
-        hipLaunchKernelGGL(k_acwpd_subtree_mfma<1>, dim3(grid), dim3(64), lds, st, top, sum, sumsq, tab, D0, ncols_top, batch, accumulate);
+    if (wpe == 1 && sums)
+        hipLaunchKernelGGL((k_acwpd_subtree_mfma<1, true>), dim3(grid), dim3(64), lds, st, top, sum, sumsq, tab, D0, ncols_top, batch, accumulate);
+    else if (wpe == 1)
+        hipLaunchKernelGGL((k_acwpd_subtree_mfma<1, false>), dim3(grid), dim3(64), lds, st, top, sum, sumsq, tab, D0, ncols_top, batch, accumulate);
+    else if (sums)
+        hipLaunchKernelGGL((k_acwpd_subtree_mfma<2, true>), dim3(grid), dim3(64), lds, st, top, sum, sumsq, tab, D0, ncols_top, batch, accumulate);
     else
-        hipLaunchKernelGGL(k_acwpd_subtree_mfma<2>, dim3(grid), dim3(64), lds, st, top, sum, sumsq, tab, D0, ncols_top, batch, accumulate);
+        hipLaunchKernelGGL((k_acwpd_subtree_mfma<2, false>), dim3(grid), dim3(64), lds, st, top, sum, sumsq, tab, D0, ncols_top, batch, accumulate);
     WX_HIP_CHECK(hipGetLastError());
     return WX_OK;
 }

@@ -2,6 +2,7 @@
 // wavelet-packet family.  Argument checks mirror the reference's @assert / throw sites.
 #include "../../include/waveletsext_hip.h"
 #include "wx_host.h"
+#include "wx_debug.h"
 #include "wx_kernels.h"
 #include "wx_lanetree.h"
 #include <atomic>
@@ -22,7 +23,7 @@ int wx_device_count(void)
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
-void wx_set_force_generic(int on) { g_force_generic.store(on == 2 ? 2 : (on ? 1 : 0)); }
+void wx_debug_set_dispatch(int on) { g_force_generic.store(on == 2 ? 2 : (on ? 1 : 0)); }   // wx_debug.h, not the public ABI
 
 }  // extern "C"
 
@@ -160,7 +161,7 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
         }
     }
     if (small && tr.Leff >= 1 && batch && dx != dy) {
-        static const bool lane_off = getenv("WX_LANETREE") && atoi(getenv("WX_LANETREE")) == 0;
+        static const bool lane_off = wx_getenv("WX_LANETREE") && atoi(wx_getenv("WX_LANETREE")) == 0;
         if (!lane_off && (n <= 64 || (n <= 128 && sizeof(T) == 4))) {
             // one lane per signal: the tree as a bit mask (at most 255 nodes of depth < Leff)
             WxLaneTree lt;

@@ -325,18 +325,37 @@ static int api_acwpd_jbb_moments(const double *x, double *sum, double *sumsq, in
         const int64_t ncols_top = ((int64_t)1 << (D0 + 1)) - 1;
         const int64_t nk_top = n * ncols_top;
         int64_t chunk = ((int64_t)8 << 30) / (int64_t)(sizeof(double) * nk_top);
-        static const int64_t chunk_env = getenv("WX_ACWPD_CHUNK") ? atoll(getenv("WX_ACWPD_CHUNK")) : 0;   // signals per pass (experiment: table in the Infinity Cache)
+        static const int64_t chunk_env = wx_getenv("WX_ACWPD_CHUNK") ? atoll(wx_getenv("WX_ACWPD_CHUNK")) : 0;   // signals per pass (experiment: table in the Infinity Cache)
         if (chunk_env > 0 && chunk_env < chunk) chunk = chunk_env;
         if (chunk < 1) chunk = 1;
         if (chunk > batch) chunk = batch;
         double *tab = batch ? (double *)scr.alloc(sizeof(double) * nk_top * chunk) : nullptr;
         if (batch && !tab) return io.finish(WX_EHIP);
+        // First moments by LINEARITY (round 5): sum_b acwpd(x_b) = acwpd(sum_b x_b), so the sums of all 2^(L+1)-1 columns are ONE
+        // extra signal through the plain acwpd kernels (64 MiB for n = 2048) instead of an add per coefficient and signal inside the
+        // moment kernels, which are bound by FP64 issue.  Rounding differs from the reference's sequential sum(X, dims=3)
+        // (bestbasis_tree.jl:153) by the association only; identical signals in a power-of-two batch still give sigma = 0 exactly
+        // (scaling by 2^k commutes with every rounding of the transform).
+        static const bool lin_off = wx_getenv("WX_ACWPD_LINSUM") && atoi(wx_getenv("WX_ACWPD_LINSUM")) == 0;
+        const bool linear = !lin_off && batch > 0 && D0 > 0 && wx_acwpd_top_moments_ok(n, D0) && wx_acwpd_mfma_ok(n, L, D0);
+        if (linear) {
+            const int groups = 64;
+            double *part = (double *)scr.alloc(sizeof(double) * n * (groups + 1));
+            double *tsum = accumulate ? (double *)scr.alloc(sizeof(double) * nk) : dsum;
+            if (!part || !tsum) return io.finish(WX_EHIP);
+            double *ssig = part + (int64_t)groups * n;
+            rc = wx_dev_sum_signals(dx, n, batch, ssig, part, groups, st);
+            if (rc == WX_OK) rc = wx_dev_swt_fwd<double>(ssig, tsum, n, L, LAYOUT_WPD, 1, filt, &acf, st);
+            if (rc == WX_OK && accumulate) rc = wx_dev_add_to(dsum, tsum, nk, st);
+            if (rc != WX_OK) return io.finish(rc);
+        }
         for (int64_t b0 = 0; b0 < batch && rc == WX_OK; b0 += chunk) {
             const int64_t bc = (batch - b0 < chunk) ? batch - b0 : chunk;
             const int acc = (accumulate || b0 > 0) ? 1 : 0;
             // the top table and its moments in the same passes (only what the subtree kernel and the next pass read is written);
             // otherwise three plain passes and the moment kernel over the whole top table
-            int fusedm = D0 > 0 ? wx_dev_acwpd_top_moments(dx + b0 * n, tab, n, D0, bc, acf, dsum, dsq, acc, st) : 0;
+            int fusedm = D0 > 0 ? wx_dev_acwpd_top_moments(dx + b0 * n, tab, n, D0, bc, acf, dsum, dsq, acc, st, !linear) : 0;
+            if (linear && fusedm == 0) fusedm = wx_set_error(WX_EHIP, "acwpd moments: the fused top pass declined after its own predicate accepted");
             if (fusedm < 0) rc = fusedm;
             if (fusedm == 0) {
                 if (D0 > 0) rc = wx_dev_swt_fwd<double>(dx + b0 * n, tab, n, D0, LAYOUT_WPD, bc, filt, &acf, st);
@@ -344,7 +363,7 @@ static int api_acwpd_jbb_moments(const double *x, double *sum, double *sumsq, in
                 if (rc == WX_OK) rc = wx_dev_jbb_moments<double>(tab, dsum, dsq, nk_top, bc, acc, nullptr, 1, st);
             }
             if (rc == WX_OK)
-                rc = wx_acwpd_mfma_ok(n, L, D0) ? wx_dev_acwpd_subtree_mfma(tab, dsum, dsq, n, L, D0, bc, acf, acc, st)
+                rc = wx_acwpd_mfma_ok(n, L, D0) ? wx_dev_acwpd_subtree_mfma(tab, dsum, dsq, n, L, D0, bc, acf, acc, st, !linear)
                                                 : wx_dev_acwpd_subtree_moments(tab, dsum, dsq, n, L, D0, bc, acf, acc, st);
         }
         return io.finish(rc);

@@ -31,6 +31,10 @@ typedef int (*fn_destroy)(void *);
 typedef int (*fn_allgather)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*fn_allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef const char *(*fn_errstr)(int);
+typedef int (*fn_send)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_recv)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_group)(void);
+typedef int (*fn_count)(void *, int *);
 struct Rccl {
     void *h = nullptr;
     fn_getid getid = nullptr;
@@ -39,6 +43,10 @@ struct Rccl {
     fn_allgather allgather = nullptr;
     fn_allreduce allreduce = nullptr;
     fn_errstr errstr = nullptr;
+    fn_send send = nullptr;
+    fn_recv recv = nullptr;
+    fn_group gstart = nullptr, gend = nullptr;
+    fn_count count = nullptr, userrank = nullptr;
 };
 Rccl g_rccl;
 std::mutex g_mu;
@@ -47,7 +55,7 @@ int load_rccl()
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_rccl.h) return WX_OK;
-    const char *names[] = {getenv("WX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const char *names[] = {wx_getenv("WX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     for (const char *nm : names) {
         if (!nm || !*nm) continue;
@@ -63,6 +71,12 @@ int load_rccl()
     r.allgather = (fn_allgather)dlsym(h, "ncclAllGather");
     r.allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
     r.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+    r.send = (fn_send)dlsym(h, "ncclSend");
+    r.recv = (fn_recv)dlsym(h, "ncclRecv");
+    r.gstart = (fn_group)dlsym(h, "ncclGroupStart");
+    r.gend = (fn_group)dlsym(h, "ncclGroupEnd");
+    r.count = (fn_count)dlsym(h, "ncclCommCount");
+    r.userrank = (fn_count)dlsym(h, "ncclCommUserRank");
     if (!r.getid || !r.init || !r.destroy || !r.allgather || !r.allreduce)
         return wx_set_error(WX_EUNSUPPORTED, "RCCL library lacks the collective entry points");
     g_rccl = r;
@@ -132,6 +146,56 @@ static int allgather_impl(const void *send, void *recv, int64_t count, int dt, v
     return WX_OK;
 }
 
+// C1 with RAGGED shards (the reference's `*all` drivers take any batch, dwt/dwt_all.jl:277-279: B mod nranks != 0 is the normal
+// case): rank r contributes counts[r] elements, which land at element offset counts[0] + ... + counts[r-1] of every rank's recv.
+// One grouped point-to-point exchange -- every piece travels once over its own xGMI link and lands in place, no padding and no
+// staging copy (the schedule of distributed.OverlappedAllGather); the own piece is a device copy unless send already points
+// into recv at its offset.
+static int allgatherv_impl(const void *send, void *recv, const int64_t *counts, int nranks, int dt, size_t esz, void *comm, void *stream)
+{
+    WX_REQUIRE(comm != nullptr, WX_EARG, "comm is NULL");
+    WX_REQUIRE(counts != nullptr && nranks >= 1, WX_EARG, "counts is NULL / nranks < 1");
+    int rc = load_rccl();
+    if (rc) return rc;
+    WX_REQUIRE(g_rccl.send && g_rccl.recv && g_rccl.gstart && g_rccl.gend && g_rccl.count && g_rccl.userrank, WX_EUNSUPPORTED,
+               "RCCL library lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+    int cn = 0, rank = -1, nr;
+    if ((nr = g_rccl.count(comm, &cn))) return nccl_fail(nr, "ncclCommCount");
+    if ((nr = g_rccl.userrank(comm, &rank))) return nccl_fail(nr, "ncclCommUserRank");
+    WX_REQUIRE(cn == nranks, WX_EARG, "counts must have one entry per rank of the communicator");
+    int64_t total = 0, off = 0;
+    for (int r = 0; r < nranks; ++r) {
+        WX_REQUIRE(counts[r] >= 0, WX_EARG, "negative count");
+        if (r < rank) off += counts[r];
+        total += counts[r];
+    }
+    if (total == 0) return WX_OK;
+    WX_REQUIRE(recv != nullptr && wx_is_device_ptr(recv), WX_EARG, "collectives take device pointers");
+    const int64_t mine = counts[rank];
+    if (mine) WX_REQUIRE(send != nullptr && wx_is_device_ptr(send), WX_EARG, "collectives take device pointers");
+    hipStream_t st = wx_stream(stream);
+    char *own = (char *)recv + (size_t)off * esz;
+    if (mine && (const void *)own != send) {
+        const hipError_t e = hipMemcpyAsync(own, send, (size_t)mine * esz, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return wx_set_hip_error(e, "allgatherv: own piece", __FILE__, __LINE__);
+    }
+    if (nranks == 1) return WX_OK;
+    if ((nr = g_rccl.gstart())) return nccl_fail(nr, "ncclGroupStart");
+    int64_t o = 0;
+    int bad = 0;
+    for (int r = 0; r < nranks && !bad; ++r) {
+        if (r != rank) {
+            if (mine) bad = g_rccl.send(send, (size_t)mine, dt, r, comm, st);
+            if (!bad && counts[r]) bad = g_rccl.recv((char *)recv + (size_t)o * esz, (size_t)counts[r], dt, r, comm, st);
+        }
+        o += counts[r];
+    }
+    nr = g_rccl.gend();
+    if (bad) return nccl_fail(bad, "ncclSend / ncclRecv");
+    if (nr) return nccl_fail(nr, "ncclGroupEnd");
+    return WX_OK;
+}
+
 static int allreduce_impl(void *buf, int64_t count, int dt, void *comm, void *stream)
 {
     WX_REQUIRE(comm != nullptr, WX_EARG, "comm is NULL");
@@ -150,6 +214,10 @@ int wx_allgather_out_f64(const double *send, double *recv, int64_t count, void *
 { return allgather_impl(send, recv, count, kNcclFloat64, comm, stream); }
 int wx_allgather_out_f32(const float *send, float *recv, int64_t count, void *comm, void *stream)
 { return allgather_impl(send, recv, count, kNcclFloat32, comm, stream); }
+int wx_allgatherv_out_f64(const double *send, double *recv, const int64_t *counts, int nranks, void *comm, void *stream)
+{ return allgatherv_impl(send, recv, counts, nranks, kNcclFloat64, sizeof(double), comm, stream); }
+int wx_allgatherv_out_f32(const float *send, float *recv, const int64_t *counts, int nranks, void *comm, void *stream)
+{ return allgatherv_impl(send, recv, counts, nranks, kNcclFloat32, sizeof(float), comm, stream); }
 int wx_allreduce_moments_f64(double *buf, int64_t count, void *comm, void *stream)
 { return allreduce_impl(buf, count, kNcclFloat64, comm, stream); }
 int wx_allreduce_moments_f32(float *buf, int64_t count, void *comm, void *stream)

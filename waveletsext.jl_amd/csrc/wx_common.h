@@ -4,6 +4,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
+// Tuning / diagnostic knobs.  The library reads WX_* environment variables ONLY when the process also sets WX_KNOBS=1
+// (tools/, the A/B tests of tests/): a production process's dispatch does not depend on its environment, and the header's
+// statement about library state holds.  Each knob is read once, at its first use.
+static inline const char *wx_getenv(const char *name)
+{
+    static const bool on = [] { const char *k = getenv("WX_KNOBS"); return k && atoi(k) != 0; }();
+    return on ? getenv(name) : nullptr;
+}
+
 #define WX_MAXF 64            // longest supported QMF (even length)
 #define WX_WAVE 64
 

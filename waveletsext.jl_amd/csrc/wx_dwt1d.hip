@@ -66,7 +66,7 @@ static const uint8_t *wx_full_tree_ones(hipStream_t st)
 }
 static bool wx_full_as_tree()
 {
-    static const bool off = getenv("WX_FULL_AS_TREE") && atoi(getenv("WX_FULL_AS_TREE")) == 0;
+    static const bool off = wx_getenv("WX_FULL_AS_TREE") && atoi(wx_getenv("WX_FULL_AS_TREE")) == 0;
     return !off;
 }
 
@@ -1108,7 +1108,7 @@ static int wx_fused_nt(int64_t n)
 {
     static int cap = 0;
     if (!cap) {
-        const char *e = getenv("WX_FUSED_NT");
+        const char *e = wx_getenv("WX_FUSED_NT");
         cap = e ? atoi(e) : 512;
         if (cap != 64 && cap != 128 && cap != 256 && cap != 512 && cap != 1024) cap = 512;
     }
@@ -1193,7 +1193,7 @@ static int launch_fwd_fused_FN(const T *x, T *y, int64_t n, int L, int64_t batch
 static int wx_fwd_mode()
 {
     static int mode = -1;
-    if (mode < 0) { const char *e = getenv("WX_FWD_MODE"); mode = e ? atoi(e) : 1; }
+    if (mode < 0) { const char *e = wx_getenv("WX_FWD_MODE"); mode = e ? atoi(e) : 1; }
     return mode;                                   // 0 = ping-pong + prefetch, 1 = in-place
 }
 template <typename T> static size_t wx_inplace_lds_bytes(int64_t n) { return (size_t)n * sizeof(T) + 512 + 256; }
@@ -1569,7 +1569,7 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
 // (8192 Float64 / 16384 Float32 samples)
 template <typename T> static int64_t wx_dwt_long_plan(int64_t n, const WxFilt &filt, bool *lattice)
 {
-    static const bool off = getenv("WX_DWT_LONG") && atoi(getenv("WX_DWT_LONG")) == 0;
+    static const bool off = wx_getenv("WX_DWT_LONG") && atoi(wx_getenv("WX_DWT_LONG")) == 0;
     *lattice = false;
     if (off || !wx_is_pow2(n) || n > ((int64_t)1 << 24)) return 0;
     // 8192 samples (and, Float32, 16384) fit the fused LDS kernel, but one top pass + the lattice pyramid on the approximation
@@ -1760,7 +1760,7 @@ template int wx_dev_idwt_long<float>(const float *, float *, int64_t, int, int64
 template <typename T> bool wx_wpt_long_tree_ok(int64_t n, const WxFilt &filt)
 {
     bool lattice;
-    static const int64_t minn = getenv("WX_LONG_TREE_MINN") ? atoll(getenv("WX_LONG_TREE_MINN")) : 8192;     // 8192: random trees 0.30 / 0.22 -> 0.40 / 0.39 of the HBM peak against the fused LDS kernel
+    static const int64_t minn = wx_getenv("WX_LONG_TREE_MINN") ? atoll(wx_getenv("WX_LONG_TREE_MINN")) : 8192;     // 8192: random trees 0.30 / 0.22 -> 0.40 / 0.39 of the HBM peak against the fused LDS kernel
     return n >= minn && wx_dwt_long_plan<T>(n, filt, &lattice) == 4096 && lattice && n <= 65536;
 }
 template bool wx_wpt_long_tree_ok<double>(int64_t, const WxFilt &);

@@ -489,7 +489,7 @@ template <typename T> static void wx_rows_geometry(int64_t n, int &R, int &S)
     R = 256 / (int)sizeof(T);
     S = R;
     // tuning knobs (strip height, a power of two, and LDS column pitch >= R)
-    const char *er = getenv("WX_ROWS_R"), *es = getenv("WX_ROWS_S");
+    const char *er = wx_getenv("WX_ROWS_R"), *es = wx_getenv("WX_ROWS_S");
     if (er && es) {
         const int r = atoi(er), s2 = atoi(es);
         if (r >= 4 && r <= 64 && (r & (r - 1)) == 0 && s2 >= r && s2 <= 128) { R = r; S = s2; }
@@ -521,12 +521,12 @@ static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img
     constexpr int VW = 16 / (int)sizeof(T);
     const bool vec = m % VW == 0 && R % VW == 0 && S % VW == 0 && src_img % VW == 0 && dst_img % VW == 0 &&
                      ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) && filt.F <= 12 &&   // 2F-tap window of vectors in registers
-                     !getenv("WX_ROWS_SCALAR");
+                     !wx_getenv("WX_ROWS_SCALAR");
     void (*kern)(const T *, T *, int64_t, int64_t, int, int, int, int64_t, WxFilt, int, int, int, int) = nullptr;
-    static const int xcd_env = getenv("WX_ROWS_XCD") ? atoi(getenv("WX_ROWS_XCD")) : 1;
-    static const int regl_env = getenv("WX_ROWS_REGL") ? atoi(getenv("WX_ROWS_REGL")) : 1;
+    static const int xcd_env = wx_getenv("WX_ROWS_XCD") ? atoi(wx_getenv("WX_ROWS_XCD")) : 1;
+    static const int regl_env = wx_getenv("WX_ROWS_REGL") ? atoi(wx_getenv("WX_ROWS_REGL")) : 1;
     // in place (one LDS image, two workgroups of 1024 lanes per CU) when a lane has at most two items per level
-    static const int inplace_env = getenv("WX_ROWS_INPLACE") ? atoi(getenv("WX_ROWS_INPLACE")) : 1;
+    static const int inplace_env = wx_getenv("WX_ROWS_INPLACE") ? atoi(wx_getenv("WX_ROWS_INPLACE")) : 1;
     // (two workgroups of 512 lanes: the same 16 wavefronts per CU as one workgroup of 1024 with two LDS images,
     // but their load / compute / store phases interleave)
     const int nt_ip = 512;
@@ -587,14 +587,14 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
     // Measured again with the lattice column kernels (each pass at ~61 % of HBM peak): step 6.79 ms whole batch, 7.18 ms at
     // S = 96, 7.74 ms at S = 128, 8.7 ms at S = 64, 11.3 ms at S = 32 -- short launches lose more in ramp-up and tail than
     // the cache saves.
-    static const int64_t sub_env = getenv("WX_2D_SUB") ? atoll(getenv("WX_2D_SUB")) : 0;
+    static const int64_t sub_env = wx_getenv("WX_2D_SUB") ? atoll(wx_getenv("WX_2D_SUB")) : 0;
     int64_t S = sub_env;
     if (S <= 0 || S >= batch) S = batch;
     if (!inverse && in_img != mn) return wx_set_error(WX_EUNSUPPORTED, "fast 2-D forward needs a dense input");
     if constexpr (sizeof(T) == 4) {
         // 512 x 512 Float32, depth 6: the transposing lattice kernel applied twice (wx_lattice2d.hip)
-        if (wx_lattice2d_ok(m, n, L, filt, sizeof(T)) && in_img == mn && !(inverse && getenv("WX_LATTICE2D_NOINV"))) {
-            if (getenv("WX_LATTICE2D_DEBUG")) {                  // diagnostics: one pass only, straight into y
+        if (wx_lattice2d_ok(m, n, L, filt, sizeof(T)) && in_img == mn && !(inverse && wx_getenv("WX_LATTICE2D_NOINV"))) {
+            if (wx_getenv("WX_LATTICE2D_DEBUG")) {                  // diagnostics: one pass only, straight into y
                 const int rd = wx_lattice2d_colT_f32((const float *)x, (float *)y, m, L, batch, filt, inverse, 0, st);
                 return rd == 1 ? WX_OK : WX_EHIP;
             }
@@ -603,7 +603,7 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
             // Measured (config 4, step = forward + inverse): whole batch 6.88 ms; S = 256: 6.91, 192: 6.94, 128: 7.14,
             // 96: 8.32, 64: 8.31, 32: 9.92 ms -- no sub-batch size gains, with or without the second stream: the written
             // intermediate does not come back from the Infinity Cache any faster than from HBM.  Kept as a knob.
-            static const bool two_streams = getenv("WX_2D_STREAMS") && atoi(getenv("WX_2D_STREAMS")) != 0;
+            static const bool two_streams = wx_getenv("WX_2D_STREAMS") && atoi(wx_getenv("WX_2D_STREAMS")) != 0;
             if (two_streams && S < batch && wx_lattice2d_ok(m, n, L, filt, sizeof(T))) {
                 static hipStream_t sA = nullptr, sB = nullptr;
                 static hipEvent_t ev0 = nullptr, evC[3], evR[3], evE = nullptr;
@@ -1006,7 +1006,7 @@ static bool wx_launch_level_tile_F(const T *src, T *dst, int64_t src_img, int64_
     if (tiles == 0) return true;
     T *di = (T *)tt.dst_int;
     // persistent workgroups with the next tile prefetched (k_dwt2d_level_tile_p): every tile does work (no tree, or the node list)
-    static const int persist = getenv("WX_TILE_PERSIST") ? atoi(getenv("WX_TILE_PERSIST")) : 1;
+    static const int persist = wx_getenv("WX_TILE_PERSIST") ? atoi(wx_getenv("WX_TILE_PERSIST")) : 1;
     constexpr int NBP = ((CR + 2 * H) * (CC + 2 * H) + 255) / 256;
     if (persist && NBP <= 24 && F <= 10 && (!tt.status || by_node)) {          // (longer filters spill at three wavefronts per SIMD)
         auto kp = k_dwt2d_level_tile_p<T, F, CR, CC>;
@@ -1017,7 +1017,7 @@ static bool wx_launch_level_tile_F(const T *src, T *dst, int64_t src_img, int64_
         int per_cu = (int)((160 * 1024) / lds);
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
-        static const int wgs_env = getenv("WX_TILE_WGS") ? atoi(getenv("WX_TILE_WGS")) : 0;
+        static const int wgs_env = wx_getenv("WX_TILE_WGS") ? atoi(wx_getenv("WX_TILE_WGS")) : 0;
         int64_t grid = (int64_t)256 * (wgs_env > 0 ? wgs_env : per_cu);
         if (grid > total) grid = total;
         hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(256), lds, st, src, dst, src_img, dst_img, m, n, d, filt, di, tt.int_img, tt.status,
@@ -1036,7 +1036,7 @@ static bool wx_launch_level_tile_F(const T *src, T *dst, int64_t src_img, int64_
 // true when the level ran as one tile pass; false = not applicable (the caller takes the two-pass level)
 template <typename T> static bool wx_level_tile_ok(int m, int n, int d, int F)
 {
-    static const bool off = getenv("WX_LEVEL2D_TILE") && atoi(getenv("WX_LEVEL2D_TILE")) == 0;
+    static const bool off = wx_getenv("WX_LEVEL2D_TILE") && atoi(wx_getenv("WX_LEVEL2D_TILE")) == 0;
     if (off) return false;
     const int mp = m >> d, np = n >> d;
     if ((m & (m - 1)) || (n & (n - 1)) || mp < 8 || np < 8) return false;
@@ -1390,7 +1390,7 @@ static bool wx_launch_ilevel_tile_F(const T *src_leaf, int64_t leaf_img, const T
     const bool by_node = tt.act && mp >= CR && np >= CC;
     const unsigned tiles = by_node ? (unsigned)(tt.nact * (mp / CR) * (np / CC)) : (unsigned)((m / CR) * (n / CC));
     if (tiles == 0) return true;
-    static const int persist = getenv("WX_TILE_PERSIST") ? atoi(getenv("WX_TILE_PERSIST")) : 1;
+    static const int persist = wx_getenv("WX_TILE_PERSIST") ? atoi(wx_getenv("WX_TILE_PERSIST")) : 1;
     constexpr int NBP = (4 * HRm * HCm + 255) / 256;
     if (persist && NBP <= 24 && F <= 8 && sizeof(T) == 8 && by_node) {          // (Float32: no gain, 1.32 vs 1.34 ms: instruction-bound)     // (Float32 at 8 taps spills 124 bytes per lane at three wavefronts per SIMD: 1.5 -> 1.8 ms)
         auto kp = k_idwt2d_level_tile_p<T, F, CR, CC>;
@@ -1401,7 +1401,7 @@ static bool wx_launch_ilevel_tile_F(const T *src_leaf, int64_t leaf_img, const T
         int per_cu = (int)((160 * 1024) / lds);
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
-        static const int wgs_env = getenv("WX_TILE_WGS") ? atoi(getenv("WX_TILE_WGS")) : 0;
+        static const int wgs_env = wx_getenv("WX_TILE_WGS") ? atoi(wx_getenv("WX_TILE_WGS")) : 0;
         int64_t grid = (int64_t)256 * (wgs_env > 0 ? wgs_env : per_cu);
         if (grid > total) grid = total;
         hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(256), lds, st, src_leaf, leaf_img, src_int, tt.int_img, dst, dst_img, m, n, d, filt,

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void k_dwt2d_tail(T *__restrict__ y, int64_t m,
 // 2-D: levels the tail takes off a pyramid of depth L of m x m images (0 = none)
 int wx_dwt2d_tail_levels(int64_t m, int64_t n, int L, int F, size_t esz)
 {
-    static const bool off = getenv("WX_DWT_TAIL") && atoi(getenv("WX_DWT_TAIL")) == 0;
+    static const bool off = wx_getenv("WX_DWT_TAIL") && atoi(wx_getenv("WX_DWT_TAIL")) == 0;
     if (off || (esz != 8 && esz != 4) || m != n || m < 16 || (m & (m - 1))) return 0;
     switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 14: case 16: case 18: case 20: break; default: return 0; }
     int log2m = 0;
@@ -197,7 +197,7 @@ template int wx_dwt2d_tail<float>(float *, int64_t, int, int64_t, const WxFilt &
 // number of levels the tail takes off the end of a pyramid of depth L (0 = none): the tree-driven kernel then runs L - that
 int wx_dwt_tail_levels(int64_t n, int L, int F, size_t esz)
 {
-    static const bool off = getenv("WX_DWT_TAIL") && atoi(getenv("WX_DWT_TAIL")) == 0;
+    static const bool off = wx_getenv("WX_DWT_TAIL") && atoi(wx_getenv("WX_DWT_TAIL")) == 0;
     if (off || (esz != 8 && esz != 4) || n < 128 || (n & (n - 1))) return 0;
     switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 14: case 16: case 18: case 20: break; default: return 0; }
     int log2n = 0;

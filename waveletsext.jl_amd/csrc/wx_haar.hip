@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NT) void k_haar_iwpt_f64(const double *__restrict__
 static int wx_haar_launch(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt,
                           hipStream_t st)
 {
-    static const bool off = getenv("WX_HAAR_WHT") && atoi(getenv("WX_HAAR_WHT")) == 0;
+    static const bool off = wx_getenv("WX_HAAR_WHT") && atoi(wx_getenv("WX_HAAR_WHT")) == 0;
     if (off || filt.F != 2 || filt.q[0] != filt.q[1]) return 0;
     if ((n & (n - 1)) || n < 1024 || n > 8192 || L < 1 || L > 10) return 0;
     int log2n = 0;

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void k_haar_iswpt(const double *__restrict__ sr
 
 static bool hs_enabled()
 {
-    static const bool off = getenv("WX_HAAR_SWT6") && atoi(getenv("WX_HAAR_SWT6")) == 0;
+    static const bool off = wx_getenv("WX_HAAR_SWT6") && atoi(wx_getenv("WX_HAAR_SWT6")) == 0;
     return !off;
 }
 bool wx_haar_swpt6_ok(int64_t n, int L, const WxFilt &filt, size_t esz)
@@ -241,7 +241,7 @@ int wx_haar_swpt6_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt 
     const int64_t blocks = ((int64_t)1 << d0) * (((int64_t)1 << d0) >> 6);
     int64_t gy = batch > 65535 ? 65535 : batch;
     // steps per loop iteration: 1 measured best (7.0 ms per 32 GiB; 8.1 at 2, 11.8 at 4: the unrolled bodies spill)
-    static const int U = getenv("WX_HAAR_SWT6_U") ? atoi(getenv("WX_HAAR_SWT6_U")) : 1;
+    static const int U = wx_getenv("WX_HAAR_SWT6_U") ? atoi(wx_getenv("WX_HAAR_SWT6_U")) : 1;
     if (U == 1)
         hipLaunchKernelGGL(k_haar_swpt6_fwd<1>, dim3((unsigned)blocks, (unsigned)gy), dim3(64), 0, st, xw, (int)n, 1 << L, batch, d0, gain);
     else if (U == 2)
@@ -257,7 +257,7 @@ int wx_haar_swpt6_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt 
 // wpt layout, dst gets the 2^(L-K) node columns
 int wx_haar_iswpt_levels()
 {
-    static const int k = getenv("WX_HAAR_ISWT_K") ? atoi(getenv("WX_HAAR_ISWT_K")) : 5;
+    static const int k = wx_getenv("WX_HAAR_ISWT_K") ? atoi(wx_getenv("WX_HAAR_ISWT_K")) : 5;
     return k == 6 ? 6 : 5;
 }
 int wx_haar_iswpt6(const double *src, int64_t src_cols, double *dst, int64_t dst_cols, int64_t n, int L, int64_t batch,

@@ -303,6 +303,15 @@ void *WxScratch::upload(const void *host, size_t bytes)
 }
 
 // ---- staged IO ----------------------------------------------------------------------------
+#include <chrono>
+static bool wx_host_trace()
+{
+    static const bool on = wx_getenv("WX_HOST_TRACE") && atoi(wx_getenv("WX_HOST_TRACE")) != 0;
+    return on;
+}
+static double wx_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static hipError_t wx_h2d_staged(void *dev, const void *user, size_t bytes, hipStream_t st);
+static void wx_advise_hugepages(void *user, size_t bytes);
 WxIO::~WxIO()
 {
     for (auto &it : items)
@@ -318,7 +327,12 @@ const void *WxIO::in(const void *p, size_t bytes)
     if (e != hipSuccess) { wx_set_hip_error(e, "hipMalloc(stage in)", __FILE__, __LINE__); return nullptr; }
     items.push_back({const_cast<void *>(p), d, bytes, true, false});
     any_staged = true;
-    e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, st);
+    const double t0 = wx_host_trace() ? wx_now_ms() : 0.0;
+    e = wx_h2d_staged(d, p, bytes, st);
+    if (wx_host_trace()) {
+        (void)hipStreamSynchronize(st);
+        fprintf(stderr, "wx host: H2D %.1f MiB in %.2f ms (%.1f GB/s)\n", bytes / 1048576.0, wx_now_ms() - t0, bytes / (wx_now_ms() - t0) / 1e6);
+    }
     if (e != hipSuccess) { wx_set_hip_error(e, "hipMemcpyAsync(H2D)", __FILE__, __LINE__); return nullptr; }
     return d;
 }
@@ -332,6 +346,7 @@ void *WxIO::out(void *p, size_t bytes)
     if (e != hipSuccess) { wx_set_hip_error(e, "hipMalloc(stage out)", __FILE__, __LINE__); return nullptr; }
     items.push_back({p, d, bytes, true, true});
     any_staged = true;
+    wx_advise_hugepages(p, bytes);
     return d;
 }
 // ---- device -> pageable host memory at PCIe speed ------------------------------------------------------------
@@ -382,7 +397,7 @@ class WxHostPool {
         std::lock_guard<std::mutex> lk(mu);
         if (started) return;
         started = true;
-        int n = getenv("WX_HOST_THREADS") ? atoi(getenv("WX_HOST_THREADS")) : 16;
+        int n = wx_getenv("WX_HOST_THREADS") ? atoi(wx_getenv("WX_HOST_THREADS")) : 16;
         const int hw = (int)std::thread::hardware_concurrency();
         if (hw > 0 && n > hw) n = hw;
         if (n < 1) n = 1;
@@ -462,7 +477,7 @@ void wx_release_host_staging()
 // D2H of a large array into pageable memory through the pinned ring; returns hipSuccess or the first error
 static hipError_t wx_d2h_staged(void *user, const void *dev, size_t bytes, hipStream_t st)
 {
-    static const bool off = getenv("WX_HOST_STAGING") && atoi(getenv("WX_HOST_STAGING")) == 0;
+    static const bool off = wx_getenv("WX_HOST_STAGING") && atoi(wx_getenv("WX_HOST_STAGING")) == 0;
     hipPointerAttribute_t at;
     const bool pinned_user = hipPointerGetAttributes(&at, user) == hipSuccess && at.type == hipMemoryTypeHost;
     (void)hipGetLastError();
@@ -507,6 +522,69 @@ static hipError_t wx_d2h_staged(void *user, const void *dev, size_t bytes, hipSt
     return e;
 }
 
+// A freshly allocated result array (Julia's Array{T}(undef, ...), numpy.empty) has no pages yet: every 4 KiB page the copy
+// threads touch is one fault -- measured on the GPU box (tools/dbg/hostpath_probe.hip, profiles/r05_hostpath_probe.txt) 14.6 GB/s
+// with 16 threads, which is what bounded `wpdall` of host arrays at 15.8 GB/s in round 4.  With transparent huge pages in
+// `madvise` mode (this image) the same first touch runs at 275 GB/s once the range carries MADV_HUGEPAGE: one fault per 2 MiB.
+// The advice changes nothing else about the caller's memory; ranges under 64 MiB and failures are ignored.
+#include <sys/mman.h>
+static void wx_advise_hugepages(void *user, size_t bytes)
+{
+    static const bool off = wx_getenv("WX_HOST_HUGEPAGES") && atoi(wx_getenv("WX_HOST_HUGEPAGES")) == 0;
+    if (off || bytes < ((size_t)64 << 20)) return;
+    const uintptr_t a = ((uintptr_t)user + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+    const uintptr_t b = ((uintptr_t)user + bytes) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+    if (b > a) (void)madvise((void *)a, (size_t)(b - a), MADV_HUGEPAGE);
+}
+
+// H2D of a large pageable array through the pinned ring: the host threads copy chunk k + 1 into one pinned buffer while the
+// DMA engine sends chunk k from the other (the runtime's own path for pageable memory reached 28 GB/s on the GPU box, the ring
+// is bound by the link: 57 GB/s).  Ordered on `st` like a plain hipMemcpyAsync; returns once the last chunk is queued AND the
+// ring is free again (the buffers belong to the next staged copy).
+static hipError_t wx_h2d_staged(void *dev, const void *user, size_t bytes, hipStream_t st)
+{
+    static const bool off = wx_getenv("WX_HOST_STAGING") && atoi(wx_getenv("WX_HOST_STAGING")) == 0;
+    hipPointerAttribute_t at;
+    const bool pinned_user = hipPointerGetAttributes(&at, user) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    std::unique_lock<std::mutex> lk(g_stage_mu, std::try_to_lock);
+    if (off || pinned_user || bytes < ((size_t)64 << 20) || !lk.owns_lock() || !g_ring.init())
+        return hipMemcpyAsync(dev, user, bytes, hipMemcpyHostToDevice, st);
+    const size_t CH = WxPinRing::CH;
+    const size_t nch = (bytes + CH - 1) / CH;
+    auto len = [&](size_t k) { return (k + 1) * CH <= bytes ? CH : bytes - k * CH; };
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ev[0]) (void)hipEventDestroy(ev[0]);
+            return hipMemcpyAsync(dev, user, bytes, hipMemcpyHostToDevice, st);
+        }
+    hipError_t e = hipSuccess;
+    size_t sent = 0;
+    for (size_t k = 0; k < nch && e == hipSuccess; ++k) {
+        const int s = (int)(k & 1);
+        if (k >= 2) e = hipEventSynchronize(ev[s]);                    // the DMA out of this slot (chunk k - 2) has finished
+        if (e != hipSuccess) break;
+        g_pool.parallel_memcpy((char *)g_ring.buf[s], (const char *)user + k * CH, len(k));
+        e = hipMemcpyAsync((char *)dev + k * CH, g_ring.buf[s], len(k), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(ev[s], st);
+        if (e == hipSuccess) sent = k + 1;
+    }
+    // the ring must be idle before the lock goes: wait for the (up to) two chunks still in flight
+    for (int i = 0; i < 2; ++i) {
+        const hipError_t w = hipEventSynchronize(ev[i]);
+        if (w != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(st); (void)hipGetLastError(); }
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = sent < nch ? hipMemcpyAsync((char *)dev + sent * CH, (const char *)user + sent * CH, bytes - sent * CH, hipMemcpyHostToDevice, st)
+                       : hipSuccess;
+    }
+    for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ev[i]);
+    return e;
+}
+
 int WxIO::finish(int rc)
 {
     if (err != WX_OK) rc = err;                    // an argument error outranks the caller's generic code
@@ -514,7 +592,13 @@ int WxIO::finish(int rc)
     if (rc == WX_OK) {
         for (auto &it : items)
             if (it.copy_out) {
+                double t0 = 0.0;
+                if (wx_host_trace()) { (void)hipStreamSynchronize(st); t0 = wx_now_ms(); }
                 hipError_t e = wx_d2h_staged(it.user, it.dev, it.bytes, st);
+                if (wx_host_trace()) {
+                    (void)hipStreamSynchronize(st);
+                    fprintf(stderr, "wx host: D2H %.1f MiB in %.2f ms (%.1f GB/s)\n", it.bytes / 1048576.0, wx_now_ms() - t0, it.bytes / (wx_now_ms() - t0) / 1e6);
+                }
                 if (e != hipSuccess) rc = wx_set_hip_error(e, "hipMemcpyAsync(D2H)", __FILE__, __LINE__);
             }
     }

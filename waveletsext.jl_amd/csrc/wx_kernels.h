@@ -11,7 +11,7 @@ int wx_swpt_deep_fwd(double *xw, int64_t n, int L, int64_t batch, const WxFilt &
 int wx_swpt_deep_inv(const double *src, int64_t src_cols, double *dst, int64_t dst_cols, int64_t n, int L, int LP, int64_t batch,
                      const WxFilt &filt, hipStream_t st);
 bool wx_lattice_applicable_f64(const WxFilt &filt);     // wx_lattice.hip: the filter has a lattice instantiation and factorises
-int wx_skip_register_kernels();   // test hook (wx_set_force_generic(2)): skip the Haar / lattice register kernels
+int wx_skip_register_kernels();   // test hook (wx_debug_set_dispatch(2), wx_debug.h): skip the Haar / lattice register kernels
 
 // ---- short signals (16 .. 512 samples) along any tree: n / 8 lanes per signal, uniform level loop (wx_smalltree.hip) ----
 template <typename T> bool wx_small_tree_ok(int64_t n, int F);
@@ -89,8 +89,10 @@ int wx_dev_iacwpd(const T *xw, T *x, int64_t n, int ncols, int64_t batch, const 
                   int Lfull, hipStream_t st);
 
 // acwpd top table (depths 0 .. D0) + the JBB moments of its columns in the passes that produce them (wx_swt1d.hip): 1 = done, 0 = n/a
+bool wx_acwpd_top_moments_ok(int64_t n, int D0);
+// sums = false: only sumsq is produced (the first moments come from the transform of the sum signal, see api_acwpd_jbb_moments)
 int wx_dev_acwpd_top_moments(const double *x, double *tab, int64_t n, int D0, int64_t batch, const WxAcFilt &ac, double *sum, double *sumsq,
-                             int acc, hipStream_t st);
+                             int acc, hipStream_t st, bool sums = true);
 
 // ---- JBB (wx_jbb.hip) ----
 template <typename T>
@@ -127,7 +129,11 @@ int wx_dev_iwpt1d_thresh(const T *xw, T *xh, int64_t n, int L, int64_t batch, co
                          int64_t nstatus, const WxThreshArg &thr, hipStream_t st);
 bool wx_acwpd_mfma_ok(int64_t n, int L, int D0);                    // wx_acsubtree.hip: one wavefront per subtree, matrix pipe
 int wx_dev_acwpd_subtree_mfma(const double *top, double *sum, double *sumsq, int64_t n, int L, int D0, int64_t batch,
-                              const WxAcFilt &ac, int accumulate, hipStream_t st);
+                              const WxAcFilt &ac, int accumulate, hipStream_t st, bool sums = true);
+// sum of the signals of a batch, in signal order inside each of a fixed number of groups, groups added in order (deterministic), and
+// dst += src: the linear path of the first moments (wx_acsubtree.hip)
+int wx_dev_sum_signals(const double *x, int64_t n, int64_t batch, double *out, double *part, int groups, hipStream_t st);
+int wx_dev_add_to(double *dst, const double *src, int64_t count, hipStream_t st);
 int wx_dev_acwpd_subtree_moments(const double *top, double *sum, double *sumsq, int64_t n, int L, int D0,
                                  int64_t batch, const WxAcFilt &ac, int accumulate, hipStream_t st);
 

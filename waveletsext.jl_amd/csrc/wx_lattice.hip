@@ -116,20 +116,20 @@ int wx_lattice_launch_lo(bool inverse, const double *x, double *y, int L, int64_
 static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                              const WxFilt &filt, hipStream_t st)
 {
-    static const bool off = getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0;
-    static const bool off_sh = getenv("WX_LATTICE_SH") && atoi(getenv("WX_LATTICE_SH")) == 0;
+    static const bool off = wx_getenv("WX_LATTICE") && atoi(wx_getenv("WX_LATTICE")) == 0;
+    static const bool off_sh = wx_getenv("WX_LATTICE_SH") && atoi(wx_getenv("WX_LATTICE_SH")) == 0;
     if (!off && !off_sh && (n == 2048 || n == 1024))
         return wx_lattice_launch_sh(inverse, x, y, n, L, batch, inverse ? in_stride : n, filt, st);
     if (!off && !off_sh && n >= 64 && n <= 512)
         return wx_lattice_launch_g(inverse, x, y, n, L, batch, inverse ? in_stride : n, filt, st);
-    static const bool off_lo = getenv("WX_LATTICE_LO") && atoi(getenv("WX_LATTICE_LO")) == 0;
+    static const bool off_lo = wx_getenv("WX_LATTICE_LO") && atoi(wx_getenv("WX_LATTICE_LO")) == 0;
     if (!off && !off_lo && n == 4096 && L >= 1 && L <= 5) return wx_lattice_launch_lo(inverse, x, y, L, batch, inverse ? in_stride : n, filt, st);
     if (off || n != 4096 || L < 6 || L > 12 || filt.F < 2 || batch <= 0) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     if (inverse && (in_stride & 3)) return 0;
     WxLat cf;
     if (!wx_lattice_factor(filt, L, inverse, &cf)) return 0;
-    static const int wg_per_cu = getenv("WX_LATTICE_WG") ? atoi(getenv("WX_LATTICE_WG")) : 0;
+    static const int wg_per_cu = wx_getenv("WX_LATTICE_WG") ? atoi(wx_getenv("WX_LATTICE_WG")) : 0;
     int64_t grid = batch;
     if (wg_per_cu > 0 && grid > (int64_t)256 * wg_per_cu) grid = (int64_t)256 * wg_per_cu;
     if (grid > 0x7fffffff) grid = 0x7fffffff;
@@ -137,7 +137,7 @@ static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n
     // inverse needs 194 registers without spills, and its spills at 3 cost 15 % extra HBM traffic (scratch) and 6 % time
     // (db4 L = 10: 0.84 ms at 3, 0.78 ms at 2; the forward built for 2 is 2 % slower than for 3).  WX_LATTICE_INV_WPE = 3
     // selects the other build of the inverse.
-    static const int inv_wpe = getenv("WX_LATTICE_INV_WPE") ? atoi(getenv("WX_LATTICE_INV_WPE")) : 2;
+    static const int inv_wpe = wx_getenv("WX_LATTICE_INV_WPE") ? atoi(wx_getenv("WX_LATTICE_INV_WPE")) : 2;
 #define WX_GO(NSS)                                                                                                  \
     case NSS:                                                                                                       \
         if (inverse && inv_wpe == 3)                                                                                \
@@ -162,9 +162,9 @@ int wx_lattice_wpd_sh_f64(const double *x, double *y, int64_t n, int L, int64_t 
 
 int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
 {
-    static const bool off = (getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0) ||
-                            (getenv("WX_LATTICE_WPD") && atoi(getenv("WX_LATTICE_WPD")) == 0);
-    static const bool off_sh = getenv("WX_LATTICE_SH") && atoi(getenv("WX_LATTICE_SH")) == 0;
+    static const bool off = (wx_getenv("WX_LATTICE") && atoi(wx_getenv("WX_LATTICE")) == 0) ||
+                            (wx_getenv("WX_LATTICE_WPD") && atoi(wx_getenv("WX_LATTICE_WPD")) == 0);
+    static const bool off_sh = wx_getenv("WX_LATTICE_SH") && atoi(wx_getenv("WX_LATTICE_SH")) == 0;
     if (!off && !off_sh && (n == 2048 || n == 1024) && x != (const double *)y) return wx_lattice_wpd_sh_f64(x, y, n, L, batch, filt, st);
     if (!off && !off_sh && n >= 64 && n <= 512 && x != (const double *)y) return wx_lattice_wpd_g_f64(x, y, n, L, batch, filt, st);
     if (off || n != 4096 || L < 1 || L > 12 || filt.F < 2 || batch <= 0 || batch > 0x7fffffff) return 0;
@@ -199,7 +199,7 @@ int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t bat
 
 bool wx_lattice_applicable_f64(const WxFilt &filt)
 {
-    static const bool off = getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0;
+    static const bool off = wx_getenv("WX_LATTICE") && atoi(wx_getenv("WX_LATTICE")) == 0;
     if (off || filt.F < 2 || filt.F / 2 > WX_LAT_MAXS) return false;
     WxLat tmp;
     return wx_lattice_factor(filt, 6, false, &tmp);
@@ -224,8 +224,8 @@ WX_TREE_DECL(0f) WX_TREE_DECL(0i) WX_TREE_DECL(1f) WX_TREE_DECL(1i) WX_TREE_DECL
 
 bool wx_lattice_tree_applicable_f64(int64_t n, const WxFilt &filt)
 {
-    static const bool off = (getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0) ||
-                            (getenv("WX_LATTICE_TREE") && atoi(getenv("WX_LATTICE_TREE")) == 0);
+    static const bool off = (wx_getenv("WX_LATTICE") && atoi(wx_getenv("WX_LATTICE")) == 0) ||
+                            (wx_getenv("WX_LATTICE_TREE") && atoi(wx_getenv("WX_LATTICE_TREE")) == 0);
     return !off && (n == 4096 || n == 2048 || n == 1024) && wx_lattice_applicable_f64(filt);
 }
 
@@ -249,7 +249,7 @@ WX_T32(0, f) WX_T32(0, i) WX_T32(1, f) WX_T32(1, i) WX_T32(2, f) WX_T32(2, i)
 #undef WX_T32
 bool wx_lattice_tree_applicable_f32(int64_t n, const WxFilt &filt)
 {
-    static const bool off = getenv("WX_LATTICE_TREE32") && atoi(getenv("WX_LATTICE_TREE32")) == 0;
+    static const bool off = wx_getenv("WX_LATTICE_TREE32") && atoi(wx_getenv("WX_LATTICE_TREE32")) == 0;
     return !off && wx_lattice_tree_applicable_f64(n, filt);
 }
 int wx_lattice_tree_f32(bool inverse, const float *x, float *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt,

@@ -777,7 +777,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
 template <int HB>
 static int wx_lattice2d_launch(const float *src, float *dst, int64_t m, int L, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
 {
-    static const bool blocked = WX_L2D_W == 4 && !(getenv("WX_L2D_BLOCKED") && atoi(getenv("WX_L2D_BLOCKED")) == 0);
+    static const bool blocked = WX_L2D_W == 4 && !(wx_getenv("WX_L2D_BLOCKED") && atoi(wx_getenv("WX_L2D_BLOCKED")) == 0);
     constexpr int LD = L2G<HB>::LD;
     double p[WX_L2_MAXS], kap[WX_L2_MAXS], g0, g2;
     if (!wx_lattice_coeffs(filt, LD, inverse, p, kap, &g0, &g2)) return 0;

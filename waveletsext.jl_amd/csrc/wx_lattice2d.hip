@@ -7,11 +7,11 @@ int wx_lattice2d_launch_1024(const float *, float *, int64_t, int, int64_t, cons
 
 bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz)
 {
-    static const bool off = getenv("WX_LATTICE2D") && atoi(getenv("WX_LATTICE2D")) == 0;
+    static const bool off = wx_getenv("WX_LATTICE2D") && atoi(wx_getenv("WX_LATTICE2D")) == 0;
     // the lattice levels (6 / 5 / 7: down to nodes of 8 x 8) and, since round 4, up to three more levels as one 8 x 8 matrix per node in the
     // store of the forward pass / the load of the inverse pass: depths 6 .. 9, 5 .. 8, 7 .. 10 -- the full depth, which is the
     // reference's default L, included
-    static const bool deep = !(getenv("WX_LATTICE2D_DEEP") && atoi(getenv("WX_LATTICE2D_DEEP")) == 0);
+    static const bool deep = !(wx_getenv("WX_LATTICE2D_DEEP") && atoi(wx_getenv("WX_LATTICE2D_DEEP")) == 0);
     const int ex = deep ? 3 : 0;
     const bool shape = (m == 512 && n == 512 && L >= 6 && L <= 6 + ex) || (m == 256 && n == 256 && L >= 5 && L <= 5 + ex) ||
                        (m == 1024 && n == 1024 && L >= 7 && L <= 7 + ex);

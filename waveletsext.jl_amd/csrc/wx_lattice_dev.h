@@ -67,6 +67,25 @@ typedef double lat_d2 __attribute__((ext_vector_type(2)));
 typedef double lat_d4 __attribute__((ext_vector_type(4)));
 typedef const double __attribute__((address_space(1))) *lat_gc;
 typedef double __attribute__((address_space(1))) *lat_gm;
+// What one 64-bit register slot holds (V): a Float64 sample, or -- Float32 ARITHMETIC, round 5 -- the Float32 samples of TWO
+// signals (A in .x, B in .y).  With the pair every rotation is one v_pk_fma_f32 (the issue cost of one v_fma_f64), every halo move,
+// LDS exchange and address is shared by the two signals, so a wavefront does for 2 x 4096 Float32 samples exactly what it does for
+// 4096 Float64 samples: same bytes, same instructions.  The reference itself rounds to Float32 at every accumulate
+// (dwt/dwt_one_level.jl:97-103); until round 4 Float32 signals were transformed in Float64 registers, bound by FP64 issue at half
+// the bytes.
+typedef float lat_f2v __attribute__((ext_vector_type(2)));
+template <typename V> struct lat_vtraits;
+template <> struct lat_vtraits<double> { typedef double coef; static constexpr int pair = 0; };
+template <> struct lat_vtraits<lat_f2v> { typedef float coef; static constexpr int pair = 1; };
+__device__ __forceinline__ double lat_fma(double c, double a, double b) { return fma(c, a, b); }
+__device__ __forceinline__ lat_f2v lat_fma(float c, lat_f2v a, lat_f2v b)
+{
+    const lat_f2v cc = {c, c};
+    return __builtin_elementwise_fma(cc, a, b);
+}
+__device__ __forceinline__ double lat_mul(double a, double g) { return a * g; }
+__device__ __forceinline__ lat_f2v lat_mul(lat_f2v a, float g) { const lat_f2v gg = {g, g}; return a * gg; }
+template <typename V> struct lat_v2 { V x, y; };            // two consecutive samples (of each signal)
 // global accesses of the kernels: 16 bytes per lane, streamed once (WX_LAT_NT: non-temporal hint)
 #ifndef WX_LAT_NT
 #define WX_LAT_NT 3     // measured (db4, L = 10, 65536 signals): forward 0.82 -> 0.79 ms, inverse 0.88 -> 0.80 ms
@@ -125,6 +144,48 @@ __device__ __forceinline__ void lat_st2w(double __attribute__((address_space(1))
 #endif
 }
 __device__ __forceinline__ void lat_st2w(float __attribute__((address_space(1))) *p, lat_d2 v) { lat_st2(p, v); }
+// two consecutive samples as register values V from memory of element type IO: (double, double) 16 bytes per lane, (double, float)
+// 8 bytes widened, (lat_f2v, float) 8 bytes from signal A at p and 8 bytes from signal B at p + boff, interleaved
+__device__ __forceinline__ lat_v2<double> lat_ldv(const double __attribute__((address_space(1))) *p, unsigned, double *)
+{
+    const lat_d2 t = lat_ld2(p);
+    return lat_v2<double>{t.x, t.y};
+}
+__device__ __forceinline__ lat_v2<double> lat_ldv(const float __attribute__((address_space(1))) *p, unsigned, double *)
+{
+    const lat_d2 t = lat_ld2(p);
+    return lat_v2<double>{t.x, t.y};
+}
+__device__ __forceinline__ lat_v2<lat_f2v> lat_ldv(const float __attribute__((address_space(1))) *p, unsigned boff, lat_f2v *)
+{
+    typedef const lat_f2 __attribute__((address_space(1))) *P;
+    const lat_f2 a = *(P)p, b = *(P)(p + boff);
+    lat_v2<lat_f2v> r;
+    r.x.x = a.x; r.x.y = b.x;
+    r.y.x = a.y; r.y.y = b.y;
+    return r;
+}
+__device__ __forceinline__ void lat_stv(double __attribute__((address_space(1))) *p, unsigned, double v0, double v1, bool wpd)
+{
+    lat_d2 o;
+    o.x = v0; o.y = v1;
+    if (wpd) lat_st2w(p, o); else lat_st2(p, o);
+}
+__device__ __forceinline__ void lat_stv(float __attribute__((address_space(1))) *p, unsigned, double v0, double v1, bool)
+{
+    lat_d2 o;
+    o.x = v0; o.y = v1;
+    lat_st2(p, o);
+}
+__device__ __forceinline__ void lat_stv(float __attribute__((address_space(1))) *p, unsigned boff, lat_f2v v0, lat_f2v v1, bool)
+{
+    typedef lat_f2 __attribute__((address_space(1))) *P;
+    lat_f2 a, b;
+    a.x = v0.x; a.y = v1.x;
+    b.x = v0.y; b.y = v1.y;
+    *(P)p = a;
+    *(P)(p + boff) = b;
+}
 __device__ __forceinline__ lat_gc lat_sbase(const double *p)
 {
     lat_gc g = (lat_gc)p;
@@ -155,18 +216,20 @@ __device__ __forceinline__ lat_gmf lat_sbase(float *p)
 // destination registers that must be adjacent -- with the depth-dependent register order of the C layout that costs
 // hundreds of copies and spills.  volatile asm statements keep their program order, the hardware executes a
 // wavefront's DS operations in order, and lat_wait() is the only wait the reads need.
-template <int OFF> __device__ __forceinline__ void lds_wr(unsigned addr, double v)
+template <int OFF, typename V> __device__ __forceinline__ void lds_wr(unsigned addr, V v)
 {
+    static_assert(sizeof(V) == 8, "one 64-bit slot");
     asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
 }
-template <int OFF> __device__ __forceinline__ double lds_rd(unsigned addr)
+template <int OFF, typename V = double> __device__ __forceinline__ V lds_rd(unsigned addr)
 {
-    double v;
+    static_assert(sizeof(V) == 8, "one 64-bit slot");
+    V v;
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
 // all outstanding DS reads have landed; the operands tie the values to the wait so that no use is scheduled above it
-__device__ __forceinline__ void lat_wait8(double &a, double &b, double &c, double &d, double &e, double &f, double &g, double &h)
+template <typename V> __device__ __forceinline__ void lat_wait8(V &a, V &b, V &c, V &d, V &e, V &f, V &g, V &h)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "memory");
 }
@@ -178,6 +241,15 @@ template <int CTRL> __device__ __forceinline__ double lat_dpp(double v)
     const int plo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
     const int phi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(phi, plo);
+}
+template <int CTRL> __device__ __forceinline__ lat_f2v lat_dpp(lat_f2v v)
+{
+    const int plo = __builtin_amdgcn_update_dpp(0, __float_as_int(v.x), CTRL, 0xF, 0xF, true);
+    const int phi = __builtin_amdgcn_update_dpp(0, __float_as_int(v.y), CTRL, 0xF, 0xF, true);
+    lat_f2v r;
+    r.x = __int_as_float(plo);
+    r.y = __int_as_float(phi);
+    return r;
 }
 
 // compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
@@ -192,7 +264,7 @@ template <int N, typename F> __device__ __forceinline__ void lat_for(F &&f)
 // value held by the lane that owns the chunk D places further along the same dilated sequence (D < 0: back);
 // H = number of cyclic lane bits (they are the low bits of the lane id): 6 wave (|D| <= 1), 4 row of 16, 0 = the whole
 // sequence is in this lane
-template <int H, int D> __device__ __forceinline__ double lat_nbr(double v)
+template <int H, int D, typename V> __device__ __forceinline__ V lat_nbr(V v)
 {
     if constexpr (H == 0 || D == 0) return v;
     else if constexpr (H == 6) {
@@ -205,8 +277,9 @@ template <int H, int D> __device__ __forceinline__ double lat_nbr(double v)
 }
 
 // one packet level on register-index bit K (2^K interleaved sequences of 32 >> K pairs per lane)
-template <int K, int H, int NS, bool INV> __device__ __forceinline__ void lat_level(double (&x)[64], const WxLat &cf)
+template <int K, int H, int NS, bool INV, typename V> __device__ __forceinline__ void lat_level(V (&x)[64], const WxLat &cf)
 {
+    typedef typename lat_vtraits<V>::coef CF;
     constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
     auto U = [](int s, int m) { return s + ((2 * m) << K); };
     // odd channel: pair m takes the value of pair m + SH of the periodic sequence (SH < 0: delay); the pairs that come
@@ -216,7 +289,7 @@ template <int K, int H, int NS, bool INV> __device__ __forceinline__ void lat_le
         if constexpr (SH != 0) {
 #pragma unroll
             for (int s = 0; s < NSEQ; ++s) {
-                double old[M];
+                V old[M];
 #pragma unroll
                 for (int m = 0; m < M; ++m) old[m] = x[U(s, m) + S];
                 lat_for<M>([&](auto Mc) {
@@ -233,13 +306,13 @@ template <int K, int H, int NS, bool INV> __device__ __forceinline__ void lat_le
     if constexpr (!INV) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            const double pj = cf.p[j], kj = cf.kap[j];
+            const CF pj = (CF)cf.p[j], kj = (CF)cf.kap[j];
 #pragma unroll
             for (int s = 0; s < NSEQ; ++s)
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    x[U(s, m)] = fma(pj, x[U(s, m) + S], x[U(s, m)]);
-                    x[U(s, m) + S] = fma(-kj, x[U(s, m)], x[U(s, m) + S]);
+                    x[U(s, m)] = lat_fma(pj, x[U(s, m) + S], x[U(s, m)]);
+                    x[U(s, m) + S] = lat_fma(-kj, x[U(s, m)], x[U(s, m) + S]);
                 }
             if (j + 1 < NS) shift(std::integral_constant<int, 1>{});
         }
@@ -256,13 +329,13 @@ template <int K, int H, int NS, bool INV> __device__ __forceinline__ void lat_le
         }
 #pragma unroll
         for (int j = NS - 1; j >= 0; --j) {
-            const double pj = cf.p[j], kj = cf.kap[j];
+            const CF pj = (CF)cf.p[j], kj = (CF)cf.kap[j];
 #pragma unroll
             for (int s = 0; s < NSEQ; ++s)
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    x[U(s, m) + S] = fma(kj, x[U(s, m)], x[U(s, m) + S]);
-                    x[U(s, m)] = fma(-pj, x[U(s, m) + S], x[U(s, m)]);
+                    x[U(s, m) + S] = lat_fma(kj, x[U(s, m)], x[U(s, m) + S]);
+                    x[U(s, m)] = lat_fma(-pj, x[U(s, m) + S], x[U(s, m)]);
                 }
             if (j > 0) shift(std::integral_constant<int, -1>{});
         }
@@ -620,16 +693,43 @@ constexpr int lat_emit_o_instr(int lay, int l, int i)       // line-address bits
 struct WxLatW {
     WxLat c;
     double gl[13];            // g^l
+    int tail_bsig;            // pair kernels (lat_f2v): signals between the two signal sets of the LAST wavefront (see lat_pair_sig)
 };
+// Pair kernels: wavefront w takes the signal sets [w per, w per + half) and [w per + half, (w + 1) per), per = 2 half = 2^(SH+1).  The
+// last wavefront of a batch that is not a multiple of per starts at `tail_sig` and its second set follows `tail_bsig` signals after the
+// first: a remainder r >= half gives tail_sig = batch - r, tail_bsig = r - half (the sets overlap INSIDE the wavefront, whose loads all
+// precede its stores: valid in place, for SH = 0 the lone last signal is simply both halves of the pair); r < half re-does the last per
+// signals (tail_sig = batch - per: out of place only).  lat_pair_plan fills the launch; false = not applicable.
+struct WxPairPlan { unsigned nwave; int tail_sig; int tail_bsig; };
+static inline bool wx_lat_pair_plan(int64_t batch, int SH, bool in_place, WxPairPlan *pp)
+{
+    const int64_t half = (int64_t)1 << SH, per = 2 * half;
+    if (batch < half || batch > 0x7fffffff) return false;
+    int64_t r = batch % per;
+    if (r == 0) r = per;
+    if (batch < per) {                                       // one wavefront: the second set ends with the batch
+        pp->nwave = 1; pp->tail_sig = 0; pp->tail_bsig = (int)(batch - half);
+        return true;
+    }
+    pp->nwave = (unsigned)((batch + per - 1) / per);
+    if (r >= half) { pp->tail_sig = (int)(batch - r); pp->tail_bsig = (int)(r - half); return true; }
+    if (in_place) return false;
+    pp->tail_sig = (int)(batch - per); pp->tail_bsig = (int)half;
+    return true;
+}
 
 // PRED (tree-driven transforms, k_lat_wpt_tree_f64): only the lines of the nodes that are LEAVES at this depth are stored --
 // bit 8 rho + i of `word` says whether this lane's 16 bytes of store instruction i of round rho belong to one (a table made
 // by k_lat_tree_prep with the same routing functions), `anyw` is the OR of the words over the lanes (wave-uniform: rounds and
 // half-rounds without a leaf line are skipped, exchange included).
-template <int LAY, int LVL, bool PRED = false, typename IO = double>
-__device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, IO *__restrict__ ycol, int lane, const WxLatW &cw,
-                                         unsigned sstride = 4096u >> lat_sh(LVL), unsigned word = 0, unsigned anyw = 0)
+template <int LAY, int LVL, bool PRED = false, typename IO = double, typename V = double>
+__device__ __forceinline__ void lat_emit(V (&x)[64], unsigned lds0, IO *__restrict__ ycol, int lane, const WxLatW &cw,
+                                         unsigned sstride = 4096u >> lat_sh(LVL), unsigned word = 0, unsigned anyw = 0,
+                                         unsigned bofs = 0xffffffffu)
 {
+    typedef typename lat_vtraits<V>::coef CF;
+    // V = lat_f2v: the second signal set of the wavefront follows the first at 2^sh signals' distance (bofs elements when given)
+    const unsigned boff = bofs != 0xffffffffu ? bofs : (sstride << lat_sh(LVL));
     // sstride: elements between the columns of consecutive signals of the wavefront (interleaved kernels; the signal
     // number is the top lat_sh(LVL) bits of the routed address)
     constexpr int SB = 12 - lat_sh(LVL);
@@ -647,10 +747,13 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, IO *__r
         constexpr LatLine ln = lat_line(LAY, LVL, q);
         if constexpr (ln.reg == 0) hi_lane |= ((lane >> ln.bit) & 1) << q;
     });
-    double gf[7];
-    gf[0] = b;
+    double gfd[7];
+    gfd[0] = b;
 #pragma unroll
-    for (int m = 1; m < 7; ++m) gf[m] = gf[m - 1] * cw.c.g2;
+    for (int m = 1; m < 7; ++m) gfd[m] = gfd[m - 1] * cw.c.g2;
+    CF gf[7];
+#pragma unroll
+    for (int m = 0; m < 7; ++m) gf[m] = (CF)gfd[m];
     const unsigned wa = lds0 + 8u * (unsigned)(17 * hi_lane + pos_lane);
     // read side: store instruction i of a round covers lines 8 i + (lane >> 3), a lane takes elements 2 (lane & 7), +1
     const int qq = lane >> 3;
@@ -668,28 +771,26 @@ __device__ __forceinline__ void lat_emit(double (&x)[64], unsigned lds0, IO *__r
         lat_for<16>([&](auto Vc) {
             constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
             constexpr int pc = lat_emit_pc_reg(LAY, LVL, r);
-            lds_wr<8 * lat_emit_slot_reg(LAY, LVL, r)>(wa, x[r] * gf[pc]);
+            lds_wr<8 * lat_emit_slot_reg(LAY, LVL, r)>(wa, lat_mul(x[r], gf[pc]));
         });
         lat_for<2>([&](auto HH) {
             constexpr int hh = HH;
             if (PRED && ((anyw >> (8 * rho + 4 * hh)) & 0xfu) == 0) return;
-            double v[8];
+            V v[8];
             lat_for<4>([&](auto I) {
                 constexpr int i = 4 * hh + I;
-                v[2 * I] = lds_rd<8 * (17 * 8 * i)>(ra);
-                v[2 * I + 1] = lds_rd<8 * (17 * 8 * i + 1)>(ra);
+                v[2 * I] = lds_rd<8 * (17 * 8 * i), V>(ra);
+                v[2 * I + 1] = lds_rd<8 * (17 * 8 * i + 1), V>(ra);
             });
             lat_wait8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
             lat_for<4>([&](auto I) {
                 constexpr int i = 4 * hh + I;
-                lat_d2 o;
-                o.x = v[2 * I];
-                o.y = v[2 * I + 1];
                 constexpr int oc = lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i);
                 if constexpr (PRED) {
-                    if ((word >> (8 * rho + i)) & 1u) lat_st2(lat_sbase(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + yo, o);
+                    if ((word >> (8 * rho + i)) & 1u)
+                        lat_stv(lat_sbase(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + yo, boff, v[2 * I], v[2 * I + 1], false);
                 } else
-                    lat_st2w(lat_sbase(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + yo, o);
+                    lat_stv(lat_sbase(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + yo, boff, v[2 * I], v[2 * I + 1], true);
             });
         });
     });
@@ -726,8 +827,8 @@ __device__ __forceinline__ unsigned lat_absorb_xo(int lane, unsigned sstride)
 }
 // dep / cstride (iwpd by tree, all depths >= 6 - SH in one absorb): the piece of store index 8 RN + i sits in the column of
 // its leaf's depth -- nibble (8 RN + i) of the lane's four `dep` words -- cstride elements per column
-template <int LAY, int LVL, int RN, typename IO = double>
-__device__ __forceinline__ void lat_absorb_fetch(lat_d2 (&v)[16], const IO *__restrict__ xcol, unsigned xo, unsigned sstride, unsigned word,
+template <int LAY, int LVL, int RN, typename IO = double, typename V = double>
+__device__ __forceinline__ void lat_absorb_fetch(lat_v2<V> (&v)[16], const IO *__restrict__ xcol, unsigned xo, unsigned sstride, unsigned word,
                                                  const unsigned *dep = nullptr, unsigned cstride = 0)
 {
     constexpr int SB = 12 - lat_sh(LVL);
@@ -735,14 +836,14 @@ __device__ __forceinline__ void lat_absorb_fetch(lat_d2 (&v)[16], const IO *__re
         constexpr int i = I;
         constexpr int oc = lat_emit_o_round(LAY, LVL, RN) + lat_emit_o_instr(LAY, LVL, i);
         constexpr int idx = 8 * RN + i;
-        lat_d2 &d = v[8 * (RN & 1) + i];
-        d.x = d.y = 0.0;
+        lat_v2<V> &d = v[8 * (RN & 1) + i];
+        d.x = d.y = V{};
         const unsigned co = dep ? ((dep[idx >> 3] >> (4 * (idx & 7))) & 15u) * cstride : 0u;
-        if ((word >> idx) & 1u) d = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + (xo + co));
+        if ((word >> idx) & 1u) d = lat_ldv(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + (xo + co), sstride << lat_sh(LVL), (V *)nullptr);
     });
 }
-template <int LAY, int LVL, typename IO = double>
-__device__ __forceinline__ void lat_absorb_fetch01(lat_d2 (&v)[16], const IO *__restrict__ xcol, int lane, unsigned sstride, unsigned word,
+template <int LAY, int LVL, typename IO = double, typename V = double>
+__device__ __forceinline__ void lat_absorb_fetch01(lat_v2<V> (&v)[16], const IO *__restrict__ xcol, int lane, unsigned sstride, unsigned word,
                                                    const unsigned *dep = nullptr, unsigned cstride = 0)
 {
     const unsigned xo = lat_absorb_xo<LAY, LVL>(lane, sstride);
@@ -750,11 +851,14 @@ __device__ __forceinline__ void lat_absorb_fetch01(lat_d2 (&v)[16], const IO *__
     lat_absorb_fetch<LAY, LVL, 1>(v, xcol, xo, sstride, word, dep, cstride);
 }
 
-template <int LAY, int LVL, bool PRED = false, bool PRE = false, typename IO = double>
-__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const IO *__restrict__ xcol, int lane, const WxLatW &cw,
-                                           unsigned sstride, unsigned word, unsigned anyw, lat_d2 (&v)[16],
-                                           const unsigned *dep = nullptr, unsigned cstride = 0, const LatThr *th = nullptr)
+template <int LAY, int LVL, bool PRED = false, bool PRE = false, typename IO = double, typename V = double>
+__device__ __forceinline__ void lat_absorb(V (&x)[64], unsigned lds0, const IO *__restrict__ xcol, int lane, const WxLatW &cw,
+                                           unsigned sstride, unsigned word, unsigned anyw, lat_v2<V> (&v)[16],
+                                           const unsigned *dep = nullptr, unsigned cstride = 0, const LatThr *th = nullptr,
+                                           unsigned bofs = 0xffffffffu)
 {
+    typedef typename lat_vtraits<V>::coef CF;
+    const unsigned boff = bofs != 0xffffffffu ? bofs : (sstride << lat_sh(LVL));   // V = lat_f2v: where the second signal set starts
     static_assert(PRE == PRED, "prefetched lines come with the predicated form");
     constexpr int SB = 12 - lat_sh(LVL);
     int hi_lane = 0, pos_lane = 0;
@@ -770,10 +874,13 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
         constexpr LatLine ln = lat_line(LAY, LVL, q);
         if constexpr (ln.reg == 0) hi_lane |= ((lane >> ln.bit) & 1) << q;
     });
-    double gf[7];
-    gf[0] = b;
+    double gfd[7];
+    gfd[0] = b;
 #pragma unroll
-    for (int m = 1; m < 7; ++m) gf[m] = gf[m - 1] * cw.c.g2;
+    for (int m = 1; m < 7; ++m) gfd[m] = gfd[m - 1] * cw.c.g2;
+    CF gf[7];
+#pragma unroll
+    for (int m = 0; m < 7; ++m) gf[m] = (CF)gfd[m];
     const unsigned rda = lds0 + 8u * (unsigned)(17 * hi_lane + pos_lane);
     const int qq = lane >> 3;
     int o_lane = 2 * (lane & 7);
@@ -791,7 +898,7 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
             lat_for<8>([&](auto I) {
                 constexpr int i = I;
                 constexpr int oc = lat_emit_o_round(LAY, LVL, rn) + lat_emit_o_instr(LAY, LVL, i);
-                v[8 * (rn & 1) + i] = lat_ld2(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo);
+                v[8 * (rn & 1) + i] = lat_ldv(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo, boff, (V *)nullptr);
             });
     };
     if constexpr (!PRE) fetch(std::integral_constant<int, 0>{});
@@ -801,8 +908,8 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
         if (live)
             lat_for<8>([&](auto I) {
                 constexpr int i = I;
-                lat_d2 &d = v[8 * (rho & 1) + i];
-                if constexpr (PRED) {
+                lat_v2<V> &d = v[8 * (rho & 1) + i];
+                if constexpr (PRED && std::is_same<V, double>::value) {
                     if (th && th->kind >= 0) {
                         constexpr int oc = lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i);
                         const int o = o_lane | oc, pos = o & ((1 << SB) - 1), sg = o >> SB;
@@ -820,10 +927,10 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
         if constexpr (!PRE && rho < 3) fetch(std::integral_constant<int, rho + 1>{});
         if constexpr (PRE && rho < 2) fetch(std::integral_constant<int, rho + 2>{});
         if (!live) return;
-        double t[16];
+        V t[16];
         lat_for<16>([&](auto Vc) {
             constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
-            t[Vc] = lds_rd<8 * lat_emit_slot_reg(LAY, LVL, r)>(rda);
+            t[Vc] = lds_rd<8 * lat_emit_slot_reg(LAY, LVL, r), V>(rda);
         });
         lat_wait16<0>(t);
         lat_for<16>([&](auto Vc) {
@@ -832,28 +939,28 @@ __device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const
             // PRED: the transform is linear and a register that holds a leaf of this depth holds an exact zero so far (its
             // descendants do not exist: zeros in, zeros out), while every loaded value that is not a leaf's is a zero too
             // (whole 16-byte pieces are predicated): adding is selecting
-            if constexpr (PRED) x[r] = fma(t[Vc], gf[pc], x[r]);
-            else x[r] = t[Vc] * gf[pc];
+            if constexpr (PRED) x[r] = lat_fma(gf[pc], t[Vc], x[r]);
+            else x[r] = lat_mul(t[Vc], gf[pc]);
         });
     });
 }
 
-template <int LAY, int LVL, bool PRED = false, typename IO = double>
-__device__ __forceinline__ void lat_absorb(double (&x)[64], unsigned lds0, const IO *__restrict__ xcol, int lane, const WxLatW &cw,
+template <int LAY, int LVL, bool PRED = false, typename IO = double, typename V = double>
+__device__ __forceinline__ void lat_absorb(V (&x)[64], unsigned lds0, const IO *__restrict__ xcol, int lane, const WxLatW &cw,
                                            unsigned sstride = 4096u >> lat_sh(LVL), unsigned word = 0, unsigned anyw = 0,
-                                           unsigned long long rmask = 0)
+                                           unsigned long long rmask = 0, unsigned bofs = 0xffffffffu)
 {
     (void)rmask;
-    lat_d2 v[16];
+    lat_v2<V> v[16];
     if constexpr (PRED) {
         lat_absorb_fetch01<LAY, LVL>(v, xcol, lane, sstride, word);
         lat_absorb<LAY, LVL, true, true, IO>(x, lds0, xcol, lane, cw, sstride, word, anyw, v);
     } else
-        lat_absorb<LAY, LVL, false, false, IO>(x, lds0, xcol, lane, cw, sstride, word, anyw, v);
+        lat_absorb<LAY, LVL, false, false, IO>(x, lds0, xcol, lane, cw, sstride, word, anyw, v, nullptr, 0, nullptr, bofs);
 }
 
 // the three layout changes of the forward direction, shared by wpt and wpd
-__device__ __forceinline__ void lat_t2(double (&a)[64], double (&bb)[64], unsigned lds0, int lane)
+template <typename V> __device__ __forceinline__ void lat_t2(V (&a)[64], V (&bb)[64], unsigned lds0, int lane)
 {
     const int sw = lane ^ ((lane >> 5) << 1);
     const unsigned wa0 = lds0 + 8u * sw, wa1 = lds0 + 8u * (sw ^ 1);
@@ -868,10 +975,10 @@ __device__ __forceinline__ void lat_t2(double (&a)[64], double (&bb)[64], unsign
             constexpr int j = Jq;
             lds_wr<8 * 64 * j>((j & 1) ? wa1 : wa0, a[16 * f + j]);
         });
-        double t[16];
+        V t[16];
         lat_for<16>([&](auto Q) {
             constexpr int h = Q / 4, g = Q % 4;
-            t[Q] = lds_rd<8 * 256 * g>(ra[h]);
+            t[Q] = lds_rd<8 * 256 * g, V>(ra[h]);
         });
         lat_wait16<0>(t);
         lat_for<16>([&](auto Q) {
@@ -880,7 +987,7 @@ __device__ __forceinline__ void lat_t2(double (&a)[64], double (&bb)[64], unsign
         });
     });
 }
-__device__ __forceinline__ void lat_t3(double (&bb)[64], double (&c)[64], unsigned lds0, int lane)
+template <typename V> __device__ __forceinline__ void lat_t3(V (&bb)[64], V (&c)[64], unsigned lds0, int lane)
 {
     const unsigned wa = lds0 + 8u * (lane + (lane >> 5));
     const unsigned ra = lds0 + 8u * (66 * (lane >> 2) + 16 * (lane & 1) + 33 * ((lane >> 1) & 1));
@@ -890,10 +997,10 @@ __device__ __forceinline__ void lat_t3(double (&bb)[64], double (&c)[64], unsign
             constexpr int j = Jq;
             lds_wr<8 * 66 * j>(wa, bb[16 * f + j]);
         });
-        double t[16];
+        V t[16];
         lat_for<16>([&](auto Hq) {
             constexpr int H = Hq;
-            t[H] = lds_rd<8 * H>(ra);
+            t[H] = lds_rd<8 * H, V>(ra);
         });
         lat_wait16<0>(t);
         lat_for<16>([&](auto Hq) {
@@ -1363,7 +1470,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 template <int SH> constexpr int lat_lay0() { return SH < 2 ? 0 : (SH < 6 ? 2 : 6); }
 
 // T3i: C -> B and T2i: B -> A (the exchanges of k_lat_iwpt_f64)
-__device__ __forceinline__ void lat_t3i(double (&c)[64], double (&bb)[64], unsigned lds0, int lane)
+template <typename V> __device__ __forceinline__ void lat_t3i(V (&c)[64], V (&bb)[64], unsigned lds0, int lane)
 {
     const unsigned wa = lds0 + 8u * (34 * (lane >> 1) + (lane & 1));
     const int H = lane & 15, p0 = (lane >> 4) & 1, p1 = lane >> 5;
@@ -1374,10 +1481,10 @@ __device__ __forceinline__ void lat_t3i(double (&c)[64], double (&bb)[64], unsig
             constexpr int Hh = Hq;
             lds_wr<8 * 2 * Hh>(wa, c[4 * Hh + f]);
         });
-        double t[16];
+        V t[16];
         lat_for<16>([&](auto Jq) {
             constexpr int j = Jq;
-            t[j] = lds_rd<8 * 68 * j>(ra);
+            t[j] = lds_rd<8 * 68 * j, V>(ra);
         });
         lat_wait16<0>(t);
         lat_for<16>([&](auto Jq) {
@@ -1386,7 +1493,7 @@ __device__ __forceinline__ void lat_t3i(double (&c)[64], double (&bb)[64], unsig
         });
     });
 }
-__device__ __forceinline__ void lat_t2i(double (&bb)[64], double (&a)[64], unsigned lds0, int lane)
+template <typename V> __device__ __forceinline__ void lat_t2i(V (&bb)[64], V (&a)[64], unsigned lds0, int lane)
 {
     const int H = lane & 15, p10 = lane >> 4;
     unsigned wa[4];
@@ -1401,10 +1508,10 @@ __device__ __forceinline__ void lat_t2i(double (&bb)[64], double (&a)[64], unsig
             constexpr int h = Q / 4, g = Q % 4;
             lds_wr<8 * 256 * g>(wa[h], bb[16 * h + 4 * f + g]);
         });
-        double t[16];
+        V t[16];
         lat_for<16>([&](auto Jq) {
             constexpr int j = Jq;
-            t[j] = lds_rd<8 * 64 * j>(ra);
+            t[j] = lds_rd<8 * 64 * j, V>(ra);
         });
         lat_wait16<0>(t);
         lat_for<16>([&](auto Jq) {
@@ -1423,15 +1530,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     __shared__ double lds[WX_LAT_LDS];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
-    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    // IO = float: Float32 arithmetic on pairs of signals (lat_f2v) -- the wavefront takes 2 x 2^SH signals, the second set follows the
+    // first in memory; last_sig is then batch - 2 x 2^SH
+    typedef typename std::conditional<std::is_same<IO, float>::value, lat_f2v, double>::type V;
+    constexpr bool PAIR = lat_vtraits<V>::pair != 0;
+    // pair kernels: last_sig is the tail wavefront's first signal, cw.tail_bsig its second set's distance (wx_lat_pair_plan)
+    const bool lastw = PAIR && blockIdx.x == gridDim.x - 1;
+    const int sig0 = PAIR ? (lastw ? last_sig : (int)(blockIdx.x << (SH + 1))) : min((int)blockIdx.x << SH, last_sig);
+    const unsigned bofs = PAIR ? (unsigned)(lastw ? cw.tail_bsig : (1 << SH)) * (4096u >> SH) : 0xffffffffu;
     const int64_t off = (int64_t)sig0 * (4096 >> SH);
     const IO *xs = x + off;
     IO *ys = y + off;
     const WxLat &cf = cw.c;
-    double c[64];
+    V c[64];
     if constexpr (SH < 2) {
-        double a[64], bb[64];
-        lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw);
+        V a[64], bb[64];
+        lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw, 4096u >> SH, 0, 0, 0, bofs);
         if constexpr (SH < 1) lat_level<0, 6, NS, false>(a, cf);
         lat_level<1, 6, NS, false>(a, cf);
         lat_t2(a, bb, lds0, lane);
@@ -1441,15 +1555,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         lat_level<3, 4, NS, false>(bb, cf);
         lat_t3(bb, c, lds0, lane);
     } else if constexpr (SH < 6) {
-        double bb[64];
-        lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw);
+        V bb[64];
+        lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw, 4096u >> SH, 0, 0, 0, bofs);
         if constexpr (SH <= 2) lat_level<0, 4, NS, false>(bb, cf);
         if constexpr (SH <= 3) lat_level<1, 4, NS, false>(bb, cf);
         if constexpr (SH <= 4) lat_level<2, 4, NS, false>(bb, cf);
         lat_level<3, 4, NS, false>(bb, cf);
         lat_t3(bb, c, lds0, lane);
     } else {
-        lat_absorb<6, 16 * SH>(c, lds0, xs, lane, cw);
+        lat_absorb<6, 16 * SH>(c, lds0, xs, lane, cw, 4096u >> SH, 0, 0, 0, bofs);
     }
     const int Le = L + SH;
     if (Le > 6) lat_level<0, 0, NS, false>(c, cf);
@@ -1459,13 +1573,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (Le > 10) lat_level<4, 0, NS, false>(c, cf);
     if (Le > 11) lat_level<5, 0, NS, false>(c, cf);
     switch (Le) {
-    case 6: if constexpr (SH < 6) lat_emit<6, 6 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
-    case 7: lat_emit<6, 7 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
-    case 8: lat_emit<6, 8 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
-    case 9: lat_emit<6, 9 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
-    case 10: lat_emit<6, 10 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
-    case 11: lat_emit<6, 11 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
-    default: lat_emit<6, 12 - SH + 16 * SH>(c, lds0, ys, lane, cw); break;
+    case 6: if constexpr (SH < 6) lat_emit<6, 6 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
+    case 7: lat_emit<6, 7 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
+    case 8: lat_emit<6, 8 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
+    case 9: lat_emit<6, 9 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
+    case 10: lat_emit<6, 10 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
+    case 11: lat_emit<6, 11 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
+    default: lat_emit<6, 12 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
     }
 }
 
@@ -1477,20 +1591,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     __shared__ double lds[WX_LAT_LDS];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
-    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    typedef typename std::conditional<std::is_same<IO, float>::value, lat_f2v, double>::type V;
+    constexpr bool PAIR = lat_vtraits<V>::pair != 0;
+    const bool lastw = PAIR && blockIdx.x == gridDim.x - 1;
+    const int sig0 = PAIR ? (lastw ? last_sig : (int)(blockIdx.x << (SH + 1))) : min((int)blockIdx.x << SH, last_sig);
+    const unsigned bsig = (unsigned)(lastw ? cw.tail_bsig : (1 << SH));
+    const unsigned bofs_in = PAIR ? bsig * in_stride : 0xffffffffu, bofs = PAIR ? bsig * (4096u >> SH) : 0xffffffffu;
     const IO *xs = xw + (int64_t)sig0 * in_stride;
     IO *ys = y + (int64_t)sig0 * (4096 >> SH);
     const WxLat &cf = cw.c;
     const int Le = L + SH;
-    double c[64];
+    V c[64];
     switch (Le) {
-    case 6: if constexpr (SH < 6) lat_absorb<6, 6 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
-    case 7: lat_absorb<6, 7 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
-    case 8: lat_absorb<6, 8 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
-    case 9: lat_absorb<6, 9 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
-    case 10: lat_absorb<6, 10 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
-    case 11: lat_absorb<6, 11 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
-    default: lat_absorb<6, 12 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride); break;
+    case 6: if constexpr (SH < 6) lat_absorb<6, 6 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
+    case 7: lat_absorb<6, 7 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
+    case 8: lat_absorb<6, 8 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
+    case 9: lat_absorb<6, 9 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
+    case 10: lat_absorb<6, 10 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
+    case 11: lat_absorb<6, 11 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
+    default: lat_absorb<6, 12 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
     }
     if (Le > 11) lat_level<5, 0, NS, true>(c, cf);
     if (Le > 10) lat_level<4, 0, NS, true>(c, cf);
@@ -1499,22 +1618,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (Le > 7) lat_level<1, 0, NS, true>(c, cf);
     if (Le > 6) lat_level<0, 0, NS, true>(c, cf);
     if constexpr (SH >= 6) {
-        lat_emit<6, 16 * SH>(c, lds0, ys, lane, cw);
+        lat_emit<6, 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs);
     } else {
-        double bb[64];
+        V bb[64];
         lat_t3i(c, bb, lds0, lane);
         lat_level<3, 4, NS, true>(bb, cf);
         if constexpr (SH <= 4) lat_level<2, 4, NS, true>(bb, cf);
         if constexpr (SH <= 3) lat_level<1, 4, NS, true>(bb, cf);
         if constexpr (SH <= 2) lat_level<0, 4, NS, true>(bb, cf);
         if constexpr (SH >= 2) {
-            lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw);
+            lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs);
         } else {
-            double a[64];
+            V a[64];
             lat_t2i(bb, a, lds0, lane);
             lat_level<1, 6, NS, true>(a, cf);
             if constexpr (SH < 1) lat_level<0, 6, NS, true>(a, cf);
-            lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw);
+            lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs);
         }
     }
 }
@@ -1731,9 +1850,11 @@ template <int G> __device__ __forceinline__ void lat_masks(unsigned long long (&
     }
 }
 
-template <int K, int NS, bool INV>
-__device__ __forceinline__ void lat_level_cm(double (&x)[64], const WxLat &cf, const unsigned long long *__restrict__ mk, double ga, double gd)
+template <int K, int NS, bool INV, typename V>
+__device__ __forceinline__ void lat_level_cm(V (&x)[64], const WxLat &cf, const unsigned long long *__restrict__ mk, double ga_, double gd_)
 {
+    typedef typename lat_vtraits<V>::coef CF;
+    const CF ga = (CF)ga_, gd = (CF)gd_;
     constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K, G = NSEQ < 8 ? NSEQ : 8;
     auto U = [](int s, int m) { return s + ((2 * m) << K); };
     lat_for<NSEQ / G>([&](auto Gc) {
@@ -1751,27 +1872,27 @@ __device__ __forceinline__ void lat_level_cm(double (&x)[64], const WxLat &cf, c
             if constexpr (!INV) {
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
-                    const double pj = cf.p[j], kj = cf.kap[j];
+                    const CF pj = (CF)cf.p[j], kj = (CF)cf.kap[j];
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
                         const int u = U(s, m), w = U(s, (m + j) % M) + S;
-                        x[u] = fma(pj, x[w], x[u]);
-                        x[w] = fma(-kj, x[u], x[w]);
+                        x[u] = lat_fma(pj, x[w], x[u]);
+                        x[w] = lat_fma(-kj, x[u], x[w]);
                     }
                 }
 #pragma unroll
-                for (int m = 0; m < M; ++m) { x[U(s, m)] *= ga; x[U(s, m) + S] *= gd; }
+                for (int m = 0; m < M; ++m) { x[U(s, m)] = lat_mul(x[U(s, m)], ga); x[U(s, m) + S] = lat_mul(x[U(s, m) + S], gd); }
             } else {
 #pragma unroll
-                for (int m = 0; m < M; ++m) { x[U(s, m)] *= ga; x[U(s, m) + S] *= gd; }
+                for (int m = 0; m < M; ++m) { x[U(s, m)] = lat_mul(x[U(s, m)], ga); x[U(s, m) + S] = lat_mul(x[U(s, m) + S], gd); }
 #pragma unroll
                 for (int j = NS - 1; j >= 0; --j) {
-                    const double pj = cf.p[j], kj = cf.kap[j];
+                    const CF pj = (CF)cf.p[j], kj = (CF)cf.kap[j];
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
                         const int u = U(s, m), w = U(s, (m + j) % M) + S;
-                        x[w] = fma(kj, x[u], x[w]);
-                        x[u] = fma(-pj, x[w], x[u]);
+                        x[w] = lat_fma(kj, x[u], x[w]);
+                        x[u] = lat_fma(-pj, x[w], x[u]);
                     }
                 }
             }
@@ -1895,7 +2016,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             lt.tt[k] = k < (1 << SH) ? reinterpret_cast<const double *>(thr.t)[thr.per_signal ? sig0 + k : 0] * thr.scale : 0.0;
         th = &lt;
     }
-    lat_d2 pv[16];
+    lat_v2<double> pv[16];
     double c[64];
 #pragma unroll
     for (int r = 0; r < 64; ++r) c[r] = 0.0;

@@ -1,23 +1,24 @@
-// wx_lattice_f32.hip -- Float32 signals of 4096 samples through the lattice kernels: Float32 in memory, Float64 in the
-// registers (k_lat_wpt_f64<NS, WPE, float>, k_lat_iwpt_f64<NS, WPE, float> of wx_lattice_dev.h: the same element offsets with
+// wx_lattice_f32.hip -- Float32 full trees on the lattice kernels.  Round 5: pairs of signals in Float32 arithmetic
+// (wx_lattice_sg32.h, lat_f2v); what those launchers decline (a single signal, an odd batch in place) keeps the round-4 form:
+// Float32 in memory, Float64 in the registers (k_lat_wpt_f64<NS, WPE, float>, k_lat_iwpt_f64<NS, WPE, float> of wx_lattice_dev.h: the same element offsets with
 // 8 bytes per lane, conversions at the two ends).  Half the bytes of the Float64 transform at the same arithmetic: the
 // kernels are bound by FP64 issue and LDS here, not by HBM.  The result is the Float64 transform rounded once to Float32
 // (the reference computes in Float32 throughout: the difference is inside the 1e-5 tolerance of the Float32 path).
 #include "wx_lattice_dev.h"
 
 #define WX_G32(k) int wx_lattice_g32_##k(bool, const float *, float *, int64_t, int, int64_t, int64_t, const WxFilt &, hipStream_t);
-WX_G32(1) WX_G32(2) WX_G32(3) WX_G32(4) WX_G32(5) WX_G32(6)
+WX_G32(0) WX_G32(1) WX_G32(2) WX_G32(3) WX_G32(4) WX_G32(5) WX_G32(6)
 #undef WX_G32
 
 // 0 = not applicable, 1 = launched, < 0 = error
 int wx_lattice_f32(bool inverse, const float *x, float *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt,
                    hipStream_t st)
 {
-    static const bool off = (getenv("WX_LATTICE") && atoi(getenv("WX_LATTICE")) == 0) ||
-                            (getenv("WX_LATTICE_F32") && atoi(getenv("WX_LATTICE_F32")) == 0);
+    static const bool off = (wx_getenv("WX_LATTICE") && atoi(wx_getenv("WX_LATTICE")) == 0) ||
+                            (wx_getenv("WX_LATTICE_F32") && atoi(wx_getenv("WX_LATTICE_F32")) == 0);
     if (off) return 0;
     // shorter signals: 2^SH of them per wavefront (wx_lattice_sg32.h)
-    static const bool off_g = getenv("WX_LATTICE_G32") && atoi(getenv("WX_LATTICE_G32")) == 0;
+    static const bool off_g = wx_getenv("WX_LATTICE_G32") && atoi(wx_getenv("WX_LATTICE_G32")) == 0;
     if (n != 4096 && !off_g) {
         switch (n) {
         case 2048: return wx_lattice_g32_1(inverse, x, y, n, L, batch, in_stride, filt, st);
@@ -28,6 +29,10 @@ int wx_lattice_f32(bool inverse, const float *x, float *y, int64_t n, int L, int
         case 64: return wx_lattice_g32_6(inverse, x, y, n, L, batch, in_stride, filt, st);
         default: return 0;
         }
+    }
+    if (n == 4096 && !off_g) {                               // pairs of signals in Float32 arithmetic; 0 = not taken (odd batch in place, one signal)
+        const int r = wx_lattice_g32_0(inverse, x, y, n, L, batch, in_stride, filt, st);
+        if (r) return r;
     }
     if (n != 4096 || L < 6 || L > 12 || filt.F < 4 || batch <= 0 || batch > 0x7fffffff) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return 0;

@@ -47,7 +47,7 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
     // leave right after their level, the kernel returns after the last one -- is kept behind WX_TREE_SC=0 for dense signals: with the
     // tables made in LDS the masked form is at least as fast on every tree measured (depth-4 pyramid, 65536 x 4096 db4: 0.77 / 0.83 ms
     // against 0.85 / 0.82; deep random trees 0.86 / 0.85 against 1.15 / 1.33).
-    static const int sc_env = getenv("WX_TREE_SC") ? atoi(getenv("WX_TREE_SC")) : -1;
+    static const int sc_env = wx_getenv("WX_TREE_SC") ? atoi(wx_getenv("WX_TREE_SC")) : -1;
     if (sc_env != 0 || strided || ta.head) {
         WxLatTreeSc *tsc = (WxLatTreeSc *)scr.alloc(sizeof(WxLatTreeSc));
         if (!tsc) return WX_EHIP;
@@ -95,7 +95,7 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
     WxLatTreeTab *tab = (WxLatTreeTab *)scr.alloc(sizeof(WxLatTreeTab));
     if (!tab) return WX_EHIP;
     // (experiment: WX_TREE_DBG_CUT = l leaves the emissions / absorptions deeper than l out -- wrong results, the time of the rest)
-    static const int dbg_cut = getenv("WX_TREE_DBG_CUT") ? atoi(getenv("WX_TREE_DBG_CUT")) : 99;
+    static const int dbg_cut = wx_getenv("WX_TREE_DBG_CUT") ? atoi(wx_getenv("WX_TREE_DBG_CUT")) : 99;
     hipLaunchKernelGGL((k_lat_tree_prep<SH>), dim3(13), dim3(64), 0, st, dstatus, nstatus, L, dbg_cut, tab);
     const int64_t nwave = (batch + per - 1) / per;
     const int last_sig = (int)(batch - per);

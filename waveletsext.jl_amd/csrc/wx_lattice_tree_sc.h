@@ -146,9 +146,11 @@ __global__ __launch_bounds__(64) void k_lat_treesc_prep2(WxLatTreeSc *__restrict
 // H cyclic lane bits hold the rest of a sequence (lat_nbr).  The shears and the gains run under the mask; the renamings and
 // halo rotations between the shears are executed by every lane: over a level they compose to the identity, and a sequence's
 // lanes (a 16-lane row in layout B, the wavefront in layout A) are all in or all out.
-template <int K, int H, int NS, bool INV>
-__device__ __forceinline__ void lat_level_hm(double (&x)[64], const WxLat &cf, const unsigned long long *__restrict__ mk, double ga, double gd)
+template <int K, int H, int NS, bool INV, typename V>
+__device__ __forceinline__ void lat_level_hm(V (&x)[64], const WxLat &cf, const unsigned long long *__restrict__ mk, double ga_, double gd_)
 {
+    typedef typename lat_vtraits<V>::coef CF;
+    const CF ga = (CF)ga_, gd = (CF)gd_;
     constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K, G = NSEQ < 8 ? NSEQ : 8;
     auto U = [](int s, int m) { return s + ((2 * m) << K); };
     lat_for<NSEQ / G>([&](auto Gc) {
@@ -162,7 +164,7 @@ __device__ __forceinline__ void lat_level_hm(double (&x)[64], const WxLat &cf, c
         auto shift = [&](auto SHc) {
             constexpr int SHv = decltype(SHc)::value;
             if constexpr (SHv != 0) {
-                double old[M];
+                V old[M];
 #pragma unroll
                 for (int m = 0; m < M; ++m) old[m] = x[U(s, m) + S];
                 lat_for<M>([&](auto Mc) {
@@ -178,20 +180,20 @@ __device__ __forceinline__ void lat_level_hm(double (&x)[64], const WxLat &cf, c
             if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
                 asm volatile("");                           // a real exec region (see lat_level_cm)
 #pragma unroll
-                for (int m = 0; m < M; ++m) { x[U(s, m)] *= ga; x[U(s, m) + S] *= gd; }
+                for (int m = 0; m < M; ++m) { x[U(s, m)] = lat_mul(x[U(s, m)], ga); x[U(s, m) + S] = lat_mul(x[U(s, m) + S], gd); }
             }
         };
         constexpr bool one_shot = (H != 6) || (NS - 1 <= M);
         if constexpr (!INV) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                const double pj = cf.p[j], kj = cf.kap[j];
+                const CF pj = (CF)cf.p[j], kj = (CF)cf.kap[j];
                 if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
                     asm volatile("");
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
-                        x[U(s, m)] = fma(pj, x[U(s, m) + S], x[U(s, m)]);
-                        x[U(s, m) + S] = fma(-kj, x[U(s, m)], x[U(s, m) + S]);
+                        x[U(s, m)] = lat_fma(pj, x[U(s, m) + S], x[U(s, m)]);
+                        x[U(s, m) + S] = lat_fma(-kj, x[U(s, m)], x[U(s, m) + S]);
                     }
                 }
                 if (j + 1 < NS) shift(std::integral_constant<int, 1>{});
@@ -211,13 +213,13 @@ __device__ __forceinline__ void lat_level_hm(double (&x)[64], const WxLat &cf, c
             }
 #pragma unroll
             for (int j = NS - 1; j >= 0; --j) {
-                const double pj = cf.p[j], kj = cf.kap[j];
+                const CF pj = (CF)cf.p[j], kj = (CF)cf.kap[j];
                 if (__builtin_amdgcn_inverse_ballot_w64(msk)) {
                     asm volatile("");
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
-                        x[U(s, m) + S] = fma(kj, x[U(s, m)], x[U(s, m) + S]);
-                        x[U(s, m)] = fma(-pj, x[U(s, m) + S], x[U(s, m)]);
+                        x[U(s, m) + S] = lat_fma(kj, x[U(s, m)], x[U(s, m) + S]);
+                        x[U(s, m)] = lat_fma(-pj, x[U(s, m) + S], x[U(s, m)]);
                     }
                 }
                 if (j > 0) shift(std::integral_constant<int, -1>{});
@@ -228,16 +230,44 @@ __device__ __forceinline__ void lat_level_hm(double (&x)[64], const WxLat &cf, c
 }
 
 // table-addressed reads of the inverse: into a fresh register / into a register whose other lanes keep their value
-__device__ __forceinline__ void lat_sc_rd(double &dst, unsigned ad)
+template <typename V> __device__ __forceinline__ void lat_sc_rd(V &dst, unsigned ad)
 {
     asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(ad) : "memory");
 }
-__device__ __forceinline__ void lat_sc_rd_keep(double &dst, unsigned ad)
+template <typename V> __device__ __forceinline__ void lat_sc_rd_keep(V &dst, unsigned ad)
 {
     asm volatile("ds_read_b64 %0, %1" : "+v"(dst) : "v"(ad) : "memory");
 }
 typedef lat_d2 __attribute__((address_space(3))) *lat_l2p;
 __device__ __forceinline__ lat_l2p lat_sc_lp(unsigned a) { return (lat_l2p)(uintptr_t)a; }
+// a 16-byte row of the LDS image = two consecutive slots <-> global memory.  V = lat_f2v: the row holds (A[p], B[p], A[p+1], B[p+1]),
+// signal A's two samples go to p, signal B's to p + boff
+typedef float lat_f4v __attribute__((ext_vector_type(4)));
+typedef lat_f4v __attribute__((address_space(3))) *lat_l4p;
+template <typename V> struct lat_row;
+template <> struct lat_row<double> { typedef lat_d2 type; };
+template <> struct lat_row<lat_f2v> { typedef lat_f4v type; };
+__device__ __forceinline__ void lat_sc_ldrow(lat_d2 &r, unsigned a) { r = *lat_sc_lp(a); }
+__device__ __forceinline__ void lat_sc_ldrow(lat_f4v &r, unsigned a) { r = *(lat_l4p)(uintptr_t)a; }
+__device__ __forceinline__ void lat_sc_strow(unsigned a, lat_d2 r) { *lat_sc_lp(a) = r; }
+__device__ __forceinline__ void lat_sc_strow(unsigned a, lat_f4v r) { *(lat_l4p)(uintptr_t)a = r; }
+template <typename GP> __device__ __forceinline__ void lat_sc_gst(GP p, unsigned, lat_d2 r) { lat_st2(p, r); }
+__device__ __forceinline__ void lat_sc_gst(float __attribute__((address_space(1))) *p, unsigned boff, lat_f4v r)
+{
+    typedef lat_f2 __attribute__((address_space(1))) *P;
+    lat_f2 a, b;
+    a.x = r.x; a.y = r.z;
+    b.x = r.y; b.y = r.w;
+    *(P)p = a;
+    *(P)(p + boff) = b;
+}
+template <typename GP> __device__ __forceinline__ void lat_sc_gld(lat_d2 &r, GP p, unsigned) { r = lat_ld2(p); }
+__device__ __forceinline__ void lat_sc_gld(lat_f4v &r, const float __attribute__((address_space(1))) *p, unsigned boff)
+{
+    typedef const lat_f2 __attribute__((address_space(1))) *P;
+    const lat_f2 a = *(P)p, b = *(P)(p + boff);
+    r.x = a.x; r.y = b.x; r.z = a.y; r.w = b.y;
+}
 
 // byte address of the 16 bytes lane `lane` moves in instruction k of half h (elements 2048 h + 128 k + 2 lane, +1)
 template <int H, int Kk> __device__ __forceinline__ unsigned lat_sc_row(unsigned lds0, int lane)
@@ -260,13 +290,13 @@ __device__ __forceinline__ void lat_sc_ptab(unsigned (&pw)[32], const WxLatTreeS
 #define WX_SC_FWD(KK, HH, REG, BIT, MK, ANY)                                                   \
     if constexpr (BIT == SH) {                                                                  \
         lat_level<KK, HH, NS, false>(REG, cf);                                                  \
-        _Pragma("unroll") for (int r = 0; r < 64; ++r) REG[r] *= ((r >> KK) & 1) ? ginv : g;    \
+        _Pragma("unroll") for (int r = 0; r < 64; ++r) REG[r] = lat_mul(REG[r], ((r >> KK) & 1) ? (CF)ginv : (CF)g);    \
     } else if constexpr (BIT > SH) {                                                            \
         if (ANY) lat_level_hm<KK, HH, NS, false>(REG, cf, MK, g, ginv);                         \
     }
 #define WX_SC_INV(KK, HH, REG, BIT, MK, ANY)                                                   \
     if constexpr (BIT == SH) {                                                                  \
-        _Pragma("unroll") for (int r = 0; r < 64; ++r) REG[r] *= ((r >> KK) & 1) ? gd : ga;     \
+        _Pragma("unroll") for (int r = 0; r < 64; ++r) REG[r] = lat_mul(REG[r], ((r >> KK) & 1) ? (CF)gd : (CF)ga);     \
         lat_level<KK, HH, NS, true>(REG, cf);                                                   \
     } else if constexpr (BIT > SH) {                                                            \
         if (ANY) lat_level_hm<KK, HH, NS, true>(REG, cf, MK, ga, gd);                           \
@@ -274,7 +304,7 @@ __device__ __forceinline__ void lat_sc_ptab(unsigned (&pw)[32], const WxLatTreeS
 
 // IO: the signal's type in memory (Float64 in the registers either way: Float32 signals are widened by the loads and rounded once by the
 // stores, like the full-tree kernels k_lat_wpt_f64<.., float>)
-template <int NS, int WPE, int SH, typename IO = double>
+template <int NS, int WPE, int SH, typename IO = double, bool FP32A = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_treesc_f64(
     const IO *__restrict__ x, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned out_stride, WxLatW cw,
     const WxLatTreeSc *__restrict__ tab)
@@ -284,23 +314,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
     constexpr int NQ = 32 >> SH;                                 // 128-element pieces of one signal
-    const int sig0 = min((int)blockIdx.x << SH, last_sig);       // the last wavefront of a ragged batch re-does signals
+    // FP32A (IO = float with WX_LAT_TREE_F32A): Float32 arithmetic on PAIRS of signals (lat_f2v, wx_lattice_dev.h) -- the wavefront takes
+    // 2 x 2^SH signals with the one tree of the call; the second set follows the first at 2^SH signals' distance
+    typedef typename std::conditional<FP32A, lat_f2v, double>::type V;
+    typedef typename lat_vtraits<V>::coef CF;
+    typedef typename lat_row<V>::type ROW;
+    constexpr bool PAIR = lat_vtraits<V>::pair != 0;
+    // pair kernels: last_sig = the tail wavefront's first signal, cw.tail_bsig = its second set's distance (wx_lat_pair_plan)
+    const bool lastw = PAIR && blockIdx.x == gridDim.x - 1;
+    const int sig0 = PAIR ? (lastw ? last_sig : (int)(blockIdx.x << (SH + 1))) : min((int)blockIdx.x << SH, last_sig);
+    const unsigned bsig = (unsigned)(lastw ? cw.tail_bsig : (1 << SH));
+    const unsigned boff_out = bsig * out_stride, boff_in = PAIR ? bsig * in_stride : 0xffffffffu;
     const IO *xs = x + (int64_t)sig0 * in_stride;                // signals in_stride / out_stride elements apart
     IO *ys = y + (int64_t)sig0 * out_stride;
     const WxLat &cf = cw.c;
     // forward: gl[1] = g, g2 = g^-2: after the shears the a-slot holds a / g, the d-slot d g
     const double g = cw.gl[1], ginv = cw.c.g2 * cw.gl[1];
-    double c[64];
+    V c[64];
     {
-        double bb[64];
+        V bb[64];
         if constexpr (SH < 2) {
-            double a[64];
-            lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw, in_stride);
+            V a[64];
+            lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw, in_stride, 0, 0, 0, boff_in);
             WX_SC_FWD(0, 6, a, 0, tab->mA, true)
             WX_SC_FWD(1, 6, a, 1, tab->mA, tab->anyA)
             lat_t2(a, bb, lds0, lane);
         } else
-            lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw, in_stride);
+            lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw, in_stride, 0, 0, 0, boff_in);
         WX_SC_FWD(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
         WX_SC_FWD(1, 4, bb, 3, tab->mB + 32, tab->anyB[1])
         WX_SC_FWD(2, 4, bb, 4, tab->mB + 64, tab->anyB[2])
@@ -336,21 +376,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         lat_sync();
         lat_for<2>([&](auto Gc) {
             constexpr int k0 = 8 * Gc;
-            lat_d2 v[8];
+            ROW v[8];
             lat_for<8>([&](auto Kc) {
                 constexpr int k = k0 + Kc;
-                v[Kc] = *lat_sc_lp(lat_sc_row<h, k>(lds0, lane));
+                lat_sc_ldrow(v[Kc], lat_sc_row<h, k>(lds0, lane));
             });
             lat_for<8>([&](auto Kc) {
                 constexpr int k = k0 + Kc, q = 16 * h + k, sg = q / NQ, qq = q % NQ;
-                lat_st2(lat_sbase(ys + (size_t)sg * out_stride + 128 * qq) + 2 * lane, v[Kc]);
+                lat_sc_gst(lat_sbase(ys + (size_t)sg * out_stride + 128 * qq) + 2 * lane, boff_out, v[Kc]);
             });
         });
         lat_sync();
     });
 }
 
-template <int NS, int WPE, int SH, bool THR, typename IO = double>
+template <int NS, int WPE, int SH, bool THR, typename IO = double, bool FP32A = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_treesc_f64(
     const IO *__restrict__ xw, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride,
     unsigned out_stride, WxLatW cw, const WxLatTreeSc *__restrict__ tab, WxThreshArg thr)
@@ -360,7 +400,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
     constexpr int NQ = 32 >> SH;                               // 128-element pieces of one signal
-    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    typedef typename std::conditional<FP32A, lat_f2v, double>::type V;
+    typedef typename lat_vtraits<V>::coef CF;
+    typedef typename lat_row<V>::type ROW;
+    static_assert(!(FP32A && THR), "the threshold of denoise() rides on the Float64-register kernels");
+    constexpr bool PAIR = lat_vtraits<V>::pair != 0;
+    const bool lastw = PAIR && blockIdx.x == gridDim.x - 1;
+    const int sig0 = PAIR ? (lastw ? last_sig : (int)(blockIdx.x << (SH + 1))) : min((int)blockIdx.x << SH, last_sig);
+    const unsigned bsig = (unsigned)(lastw ? cw.tail_bsig : (1 << SH));
+    const unsigned boff_in = bsig * in_stride, boff_out = PAIR ? bsig * out_stride : 0xffffffffu;
     const IO *xs = xw + (int64_t)sig0 * in_stride;
     IO *ys = y + (int64_t)sig0 * out_stride;
     const WxLat &cf = cw.c;
@@ -369,7 +417,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #pragma unroll
         for (int w = 0; w < 4; ++w) dep[w] = tab->dep[64 * w + lane];
     }
-    lat_d2 v[16];
+    ROW v[16];
     // pieces k0 .. k0 + NK - 1 of half h; piece q = 16 h + k is elements 128 (q mod NQ) + 2 lane, +1 of signal q / NQ
     auto fetch = [&](auto Hc, auto K0c, auto NKc) {
         constexpr int h = Hc, k0 = K0c, nk = NKc;
@@ -380,10 +428,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             if constexpr (qq == 0) {
                 // idwt of a pyramid: positions 0 .. 63 are the samples the lane-local tail (wx_dwttail.hip) has rebuilt
                 const IO *hp = reinterpret_cast<const IO *>(thr.head);
-                if (hp && lane < 32) v[k] = lat_ld2(lat_sbase(hp + 64 * (int64_t)(sig0 + sg)) + 2 * lane);
-                else v[k] = lat_ld2(lat_sbase(src) + (2 * lane + co));
+                if (hp && lane < 32) lat_sc_gld(v[k], lat_sbase(hp + 64 * (int64_t)(sig0 + sg)) + 2 * lane, 64u * bsig);
+                else lat_sc_gld(v[k], lat_sbase(src) + (2 * lane + co), boff_in);
             } else
-                v[k] = lat_ld2(lat_sbase(src) + (2 * lane + co));
+                lat_sc_gld(v[k], lat_sbase(src) + (2 * lane + co), boff_in);
         });
     };
     double tt[4] = {0, 0, 0, 0};
@@ -394,7 +442,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     }
     auto put = [&](auto Hc, auto K0c, auto NKc) {
         constexpr int h = Hc, k0 = K0c, nk = NKc;
-        if constexpr (THR) {
+        if constexpr (THR && !FP32A) {
             // threshold of denoise() (Denoising.jl:527 threshold!(x, th, t) before iwpt): positions [lo, n) of every signal
             lat_for<nk>([&](auto Kc) {
                 constexpr int k = k0 + Kc, q = 16 * h + k, sg = q / NQ, qq = q % NQ;
@@ -406,7 +454,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         }
         lat_for<nk>([&](auto Kc) {
             constexpr int k = k0 + Kc;
-            *lat_sc_lp(lat_sc_row<h, k>(lds0, lane)) = v[k];
+            lat_sc_strow(lat_sc_row<h, k>(lds0, lane), v[k]);
         });
     };
     typedef std::integral_constant<int, 0> I0;
@@ -416,7 +464,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     fetch(I0{}, I0{}, I16{});
     unsigned pw[32];
     lat_sc_ptab(pw, tab, lane);
-    double c[64];
+    V c[64];
     // half 0 (the lanes with bit HBIT clear): every lane reads, the other lanes' values are replaced below; the first eight
     // pieces of half 1 travel meanwhile -- all sixteen would not fit the 256 registers next to c[] and the table
     put(I0{}, I0{}, I16{});
@@ -460,7 +508,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         if (tab->anyC[1]) lat_level_cm<1, NS, true>(c, cf, mk + 32, ga, gd);
         if (tab->anyC[0]) lat_level_cm<0, NS, true>(c, cf, mk + 0, ga, gd);
     }
-    double bb[64];
+    V bb[64];
     lat_t3i(c, bb, lds0, lane);
     if (tab->deepB) {
         WX_SC_INV(5, 4, bb, 7, tab->mB + 160, tab->anyB[5])
@@ -471,13 +519,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     WX_SC_INV(1, 4, bb, 3, tab->mB + 32, tab->anyB[1])
     WX_SC_INV(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
     if constexpr (SH >= 2) {
-        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw, out_stride);
+        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw, out_stride, 0, 0, boff_out);
     } else {
-        double a[64];
+        V a[64];
         lat_t2i(bb, a, lds0, lane);
         WX_SC_INV(1, 6, a, 1, tab->mA, tab->anyA)
         WX_SC_INV(0, 6, a, 0, tab->mA, true)
-        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw, out_stride);
+        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw, out_stride, 0, 0, boff_out);
     }
 }
 #undef WX_SC_FWD

@@ -175,8 +175,8 @@ int launch(bool inverse, const T *x, T *y, int lm, int ln, int L, int64_t batch,
 // images whose two LDS copies fit 128 KiB; dyadic sides of at least 4
 template <typename T> bool wx_pyr2d_small_ok(int64_t m, int64_t n, int L, int F)
 {
-    static const bool off = getenv("WX_PYR2D_SMALL") && atoi(getenv("WX_PYR2D_SMALL")) == 0;
-    static const int64_t maxb = getenv("WX_PYR2D_SMALL_MAXKB") ? atoll(getenv("WX_PYR2D_SMALL_MAXKB")) * 1024 : 128 * 1024;
+    static const bool off = wx_getenv("WX_PYR2D_SMALL") && atoi(wx_getenv("WX_PYR2D_SMALL")) == 0;
+    static const int64_t maxb = wx_getenv("WX_PYR2D_SMALL_MAXKB") ? atoll(wx_getenv("WX_PYR2D_SMALL_MAXKB")) * 1024 : 128 * 1024;
     if (off || m < 4 || n < 4 || (m & (m - 1)) || (n & (n - 1)) || L < 1 || F < 2 || (F & 1) || F > WX_MAXF) return false;
     if (((m < n ? m : n) >> L) < 1) return false;
     return (int64_t)2 * n * (m + 1) * (int64_t)sizeof(T) <= maxb;

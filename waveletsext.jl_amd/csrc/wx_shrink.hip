@@ -298,7 +298,7 @@ int api_shrink(int kind, const T *X, int64_t n, int64_t k, int64_t batch, const 
         gs = (T *)scr.alloc(win * per);
         if (!gs) return io.finish(WX_EHIP);
     }
-    static const int64_t wg_max = getenv("WX_SHRINK_WG_MAX") ? atoll(getenv("WX_SHRINK_WG_MAX")) : ((int64_t)1 << 13);     // (2^16 values, 4 signals: 7.7 ms in the window, under 3 ms with launches)
+    static const int64_t wg_max = wx_getenv("WX_SHRINK_WG_MAX") ? atoll(wx_getenv("WX_SHRINK_WG_MAX")) : ((int64_t)1 << 13);     // (2^16 values, 4 signals: 7.7 ms in the window, under 3 ms with launches)
     const bool chip_sort = !in_lds && npad > wg_max && npad >= 2 * SH_CH;
     for (int64_t b0 = 0; b0 < batch; b0 += per) {
         const int64_t nb = batch - b0 < per ? batch - b0 : per;

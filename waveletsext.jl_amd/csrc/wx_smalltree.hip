@@ -161,7 +161,7 @@ int launch_small(bool inverse, const T *x, T *y, int64_t n, int L, int64_t batch
 
 template <typename T> bool wx_small_tree_ok(int64_t n, int F)
 {
-    static const bool off = getenv("WX_SMALLTREE") && atoi(getenv("WX_SMALLTREE")) == 0;
+    static const bool off = wx_getenv("WX_SMALLTREE") && atoi(wx_getenv("WX_SMALLTREE")) == 0;
     return !off && n >= 16 && n <= 512 && (n & (n - 1)) == 0 && F >= 2 && F <= 20 && (F & 1) == 0;
 }
 template bool wx_small_tree_ok<double>(int64_t, int);
@@ -174,7 +174,7 @@ template bool wx_small_tree_ok<float>(int64_t, int);
 template <typename T> bool wx_small_tree_wanted(int64_t n, int F, bool has_tree, bool pyramid)
 {
     if (!wx_small_tree_ok<T>(n, F)) return false;
-    static const int maxn = getenv("WX_SMALLTREE_MAXN") ? atoi(getenv("WX_SMALLTREE_MAXN")) : 256;
+    static const int maxn = wx_getenv("WX_SMALLTREE_MAXN") ? atoi(wx_getenv("WX_SMALLTREE_MAXN")) : 256;
     if (has_tree) return pyramid ? n <= 128 : n <= maxn;
     return sizeof(T) == 4 && n <= 128;
 }

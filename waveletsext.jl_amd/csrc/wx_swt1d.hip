@@ -38,7 +38,7 @@ enum { WX_LAYOUT_DWT = 0, WX_LAYOUT_WPT = 1, WX_LAYOUT_WPD = 2 };
 static int wx_sdwt_window_min()
 {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("WX_SDWT_WIN_S"); v = (e && atoi(e) >= 1) ? atoi(e) : 0; }
+    if (v < 0) { const char *e = wx_getenv("WX_SDWT_WIN_S"); v = (e && atoi(e) >= 1) ? atoi(e) : 0; }
     return v;
 }
 // default: every level for filters of four taps or more (db4, n = 4096, L = 6: sdwt 1.48 -> 1.02 ms, isdwt 2.40 -> 1.85 ms --
@@ -185,7 +185,9 @@ __global__ __launch_bounds__(1024) void k_swpd_fwd_two(const T *__restrict__ x, 
 // association differs from one sequential sum over the signals by rounding only: bestbasis/bestbasis_tree.jl:153-154).
 // x * x is rounded on its own like the moment kernel (wx_sq_unfused, wx_jbb.hip): no fused multiply-add into the sum.
 // ------------------------------------------------------------------------------------------
-template <int NP>
+// SUMS = false (round 5): only the sums of squares -- the first moments of every column come from the transform of the SUM of the signals
+// (the transform is linear: sum_b acwpd(x_b) = acwpd(sum_b x_b), api_acwpd_jbb_moments), one add less per coefficient and signal
+template <int NP, bool SUMS>
 __global__ __launch_bounds__(1024) void k_acwpd_top_two_mom(const double *__restrict__ x, double *__restrict__ xw, int n, int ncols,
                                                             int64_t batch, int d, int last, WxAcFilt ac, double *__restrict__ part)
 {
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_acwpd_top_two_mom(const double *__rest
 #pragma unroll
         for (int p = 0; p < NP; ++p) ms[c][p] = mq[c][p] = 0.0;
     auto add = [&](double &sm, double &sq, double val) {
-        sm = __dadd_rn(sm, val);
+        if (SUMS) sm = __dadd_rn(sm, val);
         sq = __dadd_rn(sq, __dmul_rn(val, val));
     };
     // one autocorrelation step at dilation st (acwt/acwt_one_level.jl:101-128): lo = c + S, hi = c - S
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(1024) void k_acwpd_top_two_mom(const double *__rest
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int i = threadIdx.x + p * 1024;
-            part[(slab + c) * n + i] = ms[c][p];
+            if (SUMS) part[(slab + c) * n + i] = ms[c][p];
             part[half + (slab + c) * n + i] = mq[c][p];
         }
 }
@@ -287,7 +289,7 @@ struct WxTopComb {                       // the passes of one chunk: one combine
     int64_t off[8];                      // element offset of the pass's partials
 };
 __global__ __launch_bounds__(256) void k_acwpd_top_combine(const double *__restrict__ part_all, int n, WxTopComb tc, int acc,
-                                                           double *__restrict__ sum, double *__restrict__ sumsq)
+                                                           double *__restrict__ sum, double *__restrict__ sumsq, int sums)
 {
     const int ps = blockIdx.y;
     const int d = tc.d[ps], nodes = tc.nodes[ps], gy = tc.gy[ps];
@@ -303,22 +305,26 @@ __global__ __launch_bounds__(256) void k_acwpd_top_combine(const double *__restr
     double a = 0.0, q = 0.0;
     for (int y = 0; y < gy; ++y) {
         const int64_t o = (((int64_t)y * nodes + b) * 7 + slot) * n + i;
-        a = __dadd_rn(a, part[o]);
+        if (sums) a = __dadd_rn(a, part[o]);
         q = __dadd_rn(q, part[half + o]);
     }
     const int64_t dst = (int64_t)col * n + i;
-    sum[dst] = acc ? __dadd_rn(sum[dst], a) : a;
+    if (sums) sum[dst] = acc ? __dadd_rn(sum[dst], a) : a;
     sumsq[dst] = acc ? __dadd_rn(sumsq[dst], q) : q;
 }
 
 // the top table of depths 0 .. D0 (only the even depths >= 2 are written: tab is (n, 2^(D0+1)-1, batch) like acwpd's) and the
 // moments of ALL its columns; 1 = done, 0 = not applicable (the caller takes the three plain passes + the moment kernel), < 0 = error
-int wx_dev_acwpd_top_moments(const double *x, double *tab, int64_t n, int D0, int64_t batch, const WxAcFilt &ac, double *sum, double *sumsq,
-                             int acc, hipStream_t st)
+bool wx_acwpd_top_moments_ok(int64_t n, int D0)
 {
-    static const bool off = getenv("WX_ACWPD_TOPMOM") && atoi(getenv("WX_ACWPD_TOPMOM")) == 0;
-    if (off || wx_force_generic_swt() || D0 < 2 || (D0 & 1) || batch < 1) return 0;
-    if (n != 1024 && n != 2048 && n != 4096) return 0;
+    static const bool off = wx_getenv("WX_ACWPD_TOPMOM") && atoi(wx_getenv("WX_ACWPD_TOPMOM")) == 0;
+    if (off || wx_force_generic_swt() || D0 < 2 || (D0 & 1) || D0 > 14) return false;
+    return n == 1024 || n == 2048 || n == 4096;
+}
+int wx_dev_acwpd_top_moments(const double *x, double *tab, int64_t n, int D0, int64_t batch, const WxAcFilt &ac, double *sum, double *sumsq,
+                             int acc, hipStream_t st, bool sums)
+{
+    if (!wx_acwpd_top_moments_ok(n, D0) || batch < 1) return 0;
     const int NP = (int)(n / 1024);
     const int ncols = (1 << (D0 + 1)) - 1;
     const size_t lds = (size_t)3 * n * sizeof(double);
@@ -343,7 +349,7 @@ int wx_dev_acwpd_top_moments(const double *x, double *tab, int64_t n, int D0, in
         const int64_t gy = tc.gy[ps];
 #define WX_TM(NPP)                                                                                                                     \
         {                                                                                                                              \
-            auto k = k_acwpd_top_two_mom<NPP>;                                                                                         \
+            auto k = sums ? k_acwpd_top_two_mom<NPP, true> : k_acwpd_top_two_mom<NPP, false>;                                           \
             if (lds > 64 * 1024) WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL(k, dim3(nodes, (unsigned)gy), dim3(1024), lds, st, x, tab, (int)n, ncols, batch, d, d + 2 >= D0 ? 1 : 0, ac, part + tc.off[ps]); \
         }
@@ -353,7 +359,7 @@ int wx_dev_acwpd_top_moments(const double *x, double *tab, int64_t n, int D0, in
         if (tot > totmax) totmax = tot;
     }
     hipLaunchKernelGGL(k_acwpd_top_combine, dim3((unsigned)((totmax + 255) / 256), (unsigned)tc.npass), dim3(256), 0, st, (const double *)part,
-                       (int)n, tc, acc, sum, sumsq);
+                       (int)n, tc, acc, sum, sumsq, sums ? 1 : 0);
     WX_HIP_CHECK(hipGetLastError());
     return 1;
 }
@@ -1148,7 +1154,7 @@ __global__ __launch_bounds__(256) void k_iacwpd(const T *__restrict__ xw, T *__r
 static int64_t wx_swtfwd_lds_bytes()
 {
     static int64_t v = -1;
-    if (v < 0) { const char *e = getenv("WX_SWTFWD_LDS_KIB"); v = (e && atoi(e) > 0 && atoi(e) <= 64 ? atoi(e) : 32) * 1024; }
+    if (v < 0) { const char *e = wx_getenv("WX_SWTFWD_LDS_KIB"); v = (e && atoi(e) > 0 && atoi(e) <= 64 ? atoi(e) : 32) * 1024; }
     return v;
 }
 static int wx_grid1(int64_t total)
@@ -1253,7 +1259,7 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         return WX_OK;
     }
     if (layout == WX_LAYOUT_DWT && L >= 2 && n == 1024 * (int64_t)(128 / sizeof(T)) && !wx_force_generic_swt() &&
-        !(getenv("WX_SDWT_INPLACE") && atoi(getenv("WX_SDWT_INPLACE")) == 0)) {
+        !(wx_getenv("WX_SDWT_INPLACE") && atoi(wx_getenv("WX_SDWT_INPLACE")) == 0)) {
         // the column fills more than half of a CU's LDS: in-place fused kernel, one workgroup of 1024 threads per CU
         constexpr int NPT = 128 / sizeof(T);
         typedef void (*KFI)(const T *, T *, int, int64_t, int, WxFilt, WxAcFilt);
@@ -1275,8 +1281,8 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
     // stream-ordered scratch buffer
     // with the sliding windows of k_swt_fwd_multi_rc the two-level passes win for every filter length of the library
     // (coif6 / db10, n = 16384, L = 12: 20.3 -> 13.4 ms against single levels)
-    static const int kf_maxf = getenv("WX_SWTFWD_KF_MAXF") ? atoi(getenv("WX_SWTFWD_KF_MAXF")) : 20;
-    static const int k3_maxf = getenv("WX_SWTFWD_K3_MAXF") ? atoi(getenv("WX_SWTFWD_K3_MAXF")) : 4;
+    static const int kf_maxf = wx_getenv("WX_SWTFWD_KF_MAXF") ? atoi(wx_getenv("WX_SWTFWD_KF_MAXF")) : 20;
+    static const int k3_maxf = wx_getenv("WX_SWTFWD_K3_MAXF") ? atoi(wx_getenv("WX_SWTFWD_K3_MAXF")) : 4;
     const int KF = (!ac && layout == WX_LAYOUT_WPT && !wx_force_generic_swt()) ? (filt.F <= k3_maxf ? 3 : (filt.F <= kf_maxf ? 2 : 1)) : 1;
     double *dcoef = nullptr;
     int *dshift = nullptr;
@@ -1292,7 +1298,7 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
         int64_t gy = batch;
         if (gy > 65535) gy = 65535;
         // swpd / acwpd: two levels per pass while three columns fit the LDS (WX_SWPD_TWO=0: one level per pass)
-        static const bool two_off = getenv("WX_SWPD_TWO") && atoi(getenv("WX_SWPD_TWO")) == 0;
+        static const bool two_off = wx_getenv("WX_SWPD_TWO") && atoi(wx_getenv("WX_SWPD_TWO")) == 0;
         if (K == 1 && layout == WX_LAYOUT_WPD && dstop - d >= 2 && 3 * lds <= 160 * 1024 && !two_off && !wx_force_generic_swt()) {
             auto k2 = ac ? k_swpd_fwd_two<T, true> : k_swpd_fwd_two<T, false>;
             if (3 * lds > 64 * 1024)
@@ -1410,13 +1416,13 @@ int wx_dev_swt_fwd(const T *x, T *xw, int64_t n, int L, int layout, int64_t batc
 static int64_t wx_swtinv_lds_bytes()
 {
     static int64_t v = -1;
-    if (v < 0) { const char *e = getenv("WX_SWTINV_LDS_KIB"); v = (e && atoi(e) > 0 && atoi(e) <= 64 ? atoi(e) : 32) * 1024; }
+    if (v < 0) { const char *e = wx_getenv("WX_SWTINV_LDS_KIB"); v = (e && atoi(e) > 0 && atoi(e) <= 64 ? atoi(e) : 32) * 1024; }
     return v;
 }
 static int wx_swtinv_threads()
 {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("WX_SWTINV_NT"); v = (e && (atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256)) ? atoi(e) : 512; }
+    if (v < 0) { const char *e = wx_getenv("WX_SWTINV_NT"); v = (e && (atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256)) ? atoi(e) : 512; }
     return v;
 }
 // inverse schedule (see WxSwtInvPlan): fused two-level (three for F <= 4) passes for the average-based full iswpt while the
@@ -1507,7 +1513,7 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
         return WX_OK;
     }
     if (layout == WX_LAYOUT_DWT && sm < 0 && L >= 2 && n == 1024 * (int64_t)(128 / sizeof(T)) &&
-        !wx_force_generic_swt() && !(getenv("WX_SDWT_INPLACE") && atoi(getenv("WX_SDWT_INPLACE")) == 0)) {
+        !wx_force_generic_swt() && !(wx_getenv("WX_SDWT_INPLACE") && atoi(wx_getenv("WX_SDWT_INPLACE")) == 0)) {
         // the three columns of k_isdwt_avg_fused do not fit: reconstruction in place in one column of LDS, details from global
         constexpr int NPT = 128 / sizeof(T);
         auto ki = k_isdwt_avg_fused_ip<T, NPT>;

@@ -406,11 +406,11 @@ __global__ __launch_bounds__(256) void k_red2d_fwd_fused(const T *__restrict__ x
 struct WxRedTile { int R, CT, hb, W; };
 template <typename T> static WxRedTile wx_red2d_fused_geom(int64_t m, int64_t n, int s, int F, bool ac)
 {
-    static const bool off = getenv("WX_RED2D_FUSED") && atoi(getenv("WX_RED2D_FUSED")) == 0;
+    static const bool off = wx_getenv("WX_RED2D_FUSED") && atoi(wx_getenv("WX_RED2D_FUSED")) == 0;
     // LDS budget of a strip: 32 KiB (4 workgroups per CU hide the tap loads' latency; measured 64 / 32 / 16 KiB:
     // sdwt 2.11 / 1.65 / 2.47 ms, swpt 10.5 / 8.2 / 16.5 ms); the autocorrelation step has half the taps and is
     // indifferent (6.6 / 6.9 ms)
-    static const size_t kib_env = getenv("WX_RED2D_LDS_KIB") ? (size_t)atoi(getenv("WX_RED2D_LDS_KIB")) : 0;
+    static const size_t kib_env = wx_getenv("WX_RED2D_LDS_KIB") ? (size_t)atoi(wx_getenv("WX_RED2D_LDS_KIB")) : 0;
     const size_t kib = kib_env ? kib_env : 32;
     WxRedTile g = {0, 0, 0, 0};
     if (off || s >= n) return g;

@@ -4,7 +4,7 @@
 // number of levels the lane-local kernel takes off the end of a depth-L swpt / acwpt of n-sample Float64 signals (0 = none)
 int wx_swpt_deep_levels(int64_t n, int L, int F, bool ac, size_t esz)
 {
-    static const bool off = getenv("WX_SWPT_DEEP") && atoi(getenv("WX_SWPT_DEEP")) == 0;
+    static const bool off = wx_getenv("WX_SWPT_DEEP") && atoi(wx_getenv("WX_SWPT_DEEP")) == 0;
     if (off || esz != 8 || n < 1024 || (n & (n - 1))) return 0;
     switch (F) { case 2: case 4: case 6: case 8: case 10: case 12: case 16: case 18: case 20: break; default: return 0; }
     int log2n = 0;

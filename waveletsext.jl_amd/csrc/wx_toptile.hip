@@ -5,7 +5,7 @@
 
 bool wx_top_levels_ok(int F)
 {
-    static const bool off = getenv("WX_TOPTILE") && atoi(getenv("WX_TOPTILE")) == 0;
+    static const bool off = wx_getenv("WX_TOPTILE") && atoi(wx_getenv("WX_TOPTILE")) == 0;
     return !off && F >= 2 && F <= 20 && (F & 1) == 0;
 }
 
@@ -48,7 +48,7 @@ int64_t wx_top_grid(int64_t ntiles, size_t lds)
         if (cus <= 0) cus = 256;
         cus_of[dev & 63].store(cus, std::memory_order_relaxed);
     }
-    static const int env = getenv("WX_TOPTILE_WGS") ? atoi(getenv("WX_TOPTILE_WGS")) : 0;
+    static const int env = wx_getenv("WX_TOPTILE_WGS") ? atoi(wx_getenv("WX_TOPTILE_WGS")) : 0;
     int per = (int)((160 * 1024) / (lds + 512));
     if (per < 1) per = 1;
     if (per > 8) per = 8;

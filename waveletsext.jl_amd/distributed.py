@@ -329,6 +329,24 @@ class NativeComm:
         self._lib.check(self._fn("wx_allgather_out", local)(src.data_ptr(), full.data_ptr(), src.numel(), self.handle, st))
         return _as_batch_major(full) if full.dim() > 1 else full
 
+    def allgatherv_batch(self, local, B_total):
+        """C1 with ragged shards (wx_allgatherv_out_*): this rank's (sig..., B_r) block of the contiguous sharding
+        `shard_range(B_total, nranks, rank)` -> (sig..., B_total) on every rank, every piece landing in place"""
+        import ctypes
+        import numpy as np
+        assert local.is_cuda and local.dtype in (torch.float32, torch.float64)
+        sig = int(np.prod(local.shape[:-1], dtype=np.int64)) if local.dim() > 1 else 1
+        bounds = [shard_range(B_total, self.nranks, r) for r in range(self.nranks)]
+        lo, hi = bounds[self.rank]
+        assert hi - lo == local.shape[-1], "local is not this rank's shard of B_total"
+        counts = (ctypes.c_int64 * self.nranks)(*[(b - a) * sig for a, b in bounds])
+        src = _as_batch_major(local).contiguous()
+        full = torch.empty((B_total,) + tuple(src.shape[1:]), dtype=local.dtype, device=local.device)
+        st = torch.cuda.current_stream(local.device).cuda_stream
+        self._lib.check(self._fn("wx_allgatherv_out", local)(src.data_ptr(), full.data_ptr(), ctypes.cast(counts, ctypes.c_void_p),
+                                                             self.nranks, self.handle, st))
+        return _as_batch_major(full) if full.dim() > 1 else full
+
     def allreduce_moments(self, s, q):
         """C2: one in-place sum over the fused [sum | sumsq] buffer"""
         fused = torch.stack([_as_batch_major(s).contiguous().reshape(-1), _as_batch_major(q).contiguous().reshape(-1)])

@@ -275,14 +275,11 @@ def getbasiscoefall(Xw, tree):
         mm, nn, k, N = Xw.shape
         import ctypes
         out = Xw.new((mm, nn, N))
-        if tree.ndim == 2:
+        if tree.ndim == 2:                                            # Utils.jl:199-225: one tree per image, one launch
             assert N == tree.shape[1]
-            esz = Xw.dtype.itemsize
-            for i in range(N):
-                tk, tp, ntl = tree_arg(tree[:, i])
-                src = ctypes.c_void_p(Xw.ptr.value + i * mm * nn * k * esz)
-                dst = ctypes.c_void_p(out.ptr.value + i * mm * nn * esz)
-                _call("wx_getbasiscoef2d", Xw.suffix, src, dst, mm, nn, k, tp, ntl, 1, Xw.stream())
+            tb = np.asfortranarray(tree.astype(np.uint8))
+            _call("wx_getbasiscoef2d_trees", Xw.suffix, Xw.ptr, out.ptr, mm, nn, k, ctypes.c_void_p(tb.ctypes.data), tb.shape[0], N,
+                  Xw.stream())
         else:
             tk, tp, nt = tree_arg(tree)
             _call("wx_getbasiscoef2d", Xw.suffix, Xw.ptr, out.ptr, mm, nn, k, tp, nt, N, Xw.stream())
@@ -293,12 +290,8 @@ def getbasiscoefall(Xw, tree):
         assert m == mt
         out = Xw.new((n, m))
         import ctypes
-        esz = Xw.dtype.itemsize
-        for i in range(m):
-            tk, tp, ntl = tree_arg(tree[:, i])
-            src = ctypes.c_void_p(Xw.ptr.value + i * n * k * esz)
-            dst = ctypes.c_void_p(out.ptr.value + i * n * esz)
-            _call("wx_getbasiscoef1d", Xw.suffix, src, dst, n, k, tp, ntl, 1, Xw.stream())
+        tb = np.asfortranarray(tree.astype(np.uint8))                 # (ntree, m): column i = the tree of signal i
+        _call("wx_getbasiscoef1d_trees", Xw.suffix, Xw.ptr, out.ptr, n, k, ctypes.c_void_p(tb.ctypes.data), nt, m, Xw.stream())
         return out.arr
     tk, tp, nt = tree_arg(tree)
     out = Xw.new((n, m))

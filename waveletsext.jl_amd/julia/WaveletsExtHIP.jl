@@ -103,6 +103,9 @@ c_iwpd(T, xw, x, sig::NTuple{1,Int}, k, L, tb, nt, N, q) = check(wx_iwpd1d(T, xw
 c_iwpd(T, xw, x, sig::NTuple{2,Int}, k, L, tb, nt, N, q) = check(wx_iwpd2d(T, xw, x, sig[1], sig[2], k, L, tb, nt, N, q, length(q), stream()))
 c_getbasiscoef(T, Xw, out, sig::NTuple{1,Int}, k, tb, nt, N) = check(wx_getbasiscoef1d(T, Xw, out, sig[1], k, tb, nt, N, stream()))
 c_getbasiscoef(T, Xw, out, sig::NTuple{2,Int}, k, tb, nt, N) = check(wx_getbasiscoef2d(T, Xw, out, sig[1], sig[2], k, tb, nt, N, stream()))
+c_getbasiscoef_trees(T, Xw, out, sig::NTuple{1,Int}, k, tb, nt, N) = check(wx_getbasiscoef1d_trees(T, Xw, out, sig[1], k, tb, nt, N, stream()))
+c_getbasiscoef_trees(T, Xw, out, sig::NTuple{2,Int}, k, tb, nt, N) =
+    check(wx_getbasiscoef2d_trees(T, Xw, out, sig[1], sig[2], k, tb, nt, N, stream()))
 c_dwt3d(T, x, y, sig::NTuple{3,Int}, L, N, q) = check(wx_dwt3d(T, x, y, sig[1], sig[2], sig[3], L, N, q, length(q), stream()))
 c_idwt3d(T, x, y, sig::NTuple{3,Int}, L, N, q) = check(wx_idwt3d(T, x, y, sig[1], sig[2], sig[3], L, N, q, length(q), stream()))
 
@@ -315,24 +318,15 @@ function getbasiscoefall(Xw::HIP{T}, tree::BitVector) where T<:FT
     c_getbasiscoef(T, raw(Xw), out, sz, k, tb, nt, N)
     return out
 end
-# one tree per signal (Utils.jl:204-225): signals that share a tree are gathered by one call each
+# one tree per signal (Utils.jl:199-225), the consumer of bestbasistreeall: the BitMatrix goes over as bytes and ONE launch
+# gathers every signal (wx_getbasiscoef*_trees checks each tree like the reference's `@assert all(mapslices(isvalidtree, ...))`)
 function getbasiscoefall(Xw::HIP{T}, trees::BitMatrix) where T<:FT
     @assert 3 ≤ ndims(Xw) ≤ 4
     sz = size(Xw)[1:end-2]; k = size(Xw)[end-1]; N = size(Xw)[end]
     @assert size(trees, 2) == N
     out = newlike(Xw, T, (sz..., N))
-    per_in = prod(sz) * k; per_out = prod(sz)
-    src = reshape(raw(Xw), per_in, N); dst = reshape(out, per_out, N)
-    i = 1
-    while i ≤ N                                    # runs of consecutive signals with the same tree
-        j = i
-        while j < N && view(trees, :, j + 1) == view(trees, :, i)
-            j += 1
-        end
-        _, tb, nt = treearg(trees[:, i])
-        c_getbasiscoef(T, view(src, :, i:j), view(dst, :, i:j), sz, k, tb, nt, j - i + 1)
-        i = j + 1
-    end
+    tb = Matrix{UInt8}(trees)
+    c_getbasiscoef_trees(T, raw(Xw), out, sz, k, tb, size(tb, 1), N)
     return out
 end
 
@@ -849,6 +843,12 @@ Base.close(c::Comm) = check(wx_comm_destroy(c.handle))
 # C1: reconstructed output shards -> full batch on every rank (recv holds nranks*count elements)
 allgather_out!(::Type{T}, recv, send, count::Integer, c::Comm) where T<:FT =
     check(wx_allgather_out(T, send, recv, count, c.handle, stream()))
+# C1 for ragged shards (B mod nranks != 0): counts[r] = elements of rank r's shard (signal length x its share of the batch);
+# every shard lands at its offset of recv on every rank, no padding
+function allgatherv_out!(::Type{T}, recv, send, counts::AbstractVector{<:Integer}, c::Comm) where T<:FT
+    length(counts) == c.nranks || throw(ArgumentError("counts needs one entry per rank"))
+    check(wx_allgatherv_out(T, send, recv, Vector{Int64}(counts), c.nranks, c.handle, stream()))
+end
 # C2: JBB moments [Σx | Σx²] summed over ranks in place, then costs_from_moments / treeselect! on every rank
 allreduce_moments!(::Type{T}, buf, count::Integer, c::Comm) where T<:FT =
     check(wx_allreduce_moments(T, buf, count, c.handle, stream()))
