@@ -1,0 +1,49 @@
+"""8192-sample Float64 signals, full trees, in ONE pass over the data (csrc/wx_lattice_8k.h): two wavefronts per
+signal, the first level in the direct form of dwt_step! / idwt_step! (dwt/dwt_one_level.jl:79-107, 192-223) inside the load / store phase,
+the children on the lattice.  Against the oracle for every filter length the lattice factors (2 .. 20 taps: the halo of the staged
+chunks), every depth the kernels take (7 .. 13), odd batches, and iwpd reading column L of a table (signal stride 8192 (L + 1))."""
+import numpy as np
+import pytest
+
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "db5", "coif2", "db7", "db8", "coif6", "db10"])
+def test_every_filter_full_depth(wx, oracle, wname):
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    rng = np.random.default_rng(len(wt.qmf))
+    x = np.asfortranarray(rng.standard_normal((8192, 5)))
+    for L in (13, 7):
+        exp = oracle.wptall(x, wt.qmf, L)
+        y = wx.wptall(x, wt, L)
+        assert relerr(y, exp) <= 1e-12, (wname, L)
+        assert relerr(wx.iwptall(exp, wt, L), x) <= 1e-12, (wname, L)
+
+
+@pytest.mark.parametrize("L", [7, 8, 9, 10, 11, 12, 13])
+def test_every_depth_and_tables(wx, oracle, L):
+    wt = wx.wavelet(wx.WT.db4)
+    rng = np.random.default_rng(L)
+    for B in (1, 2, 7):
+        x = np.asfortranarray(rng.standard_normal((8192, B)))
+        exp = oracle.wptall(x, wt.qmf, L)
+        assert relerr(wx.wptall(x, wt, L), exp) <= 1e-12, (L, B)
+        assert relerr(wx.iwptall(exp, wt, L), x) <= 1e-12, (L, B)
+    x = np.asfortranarray(rng.standard_normal((8192, 3)))
+    tab = wx.wpdall(x, wt, L)                                          # (8192, L + 1, 3): the inverse reads column L in place
+    assert relerr(wx.iwpdall(tab, wt, L), x) <= 1e-12
+
+
+def test_chip_filling_batch_on_the_device(wx):
+    import torch
+    wt = wx.wavelet(wx.WT.db4)
+    x = wx.jl_empty((8192, 4099), torch.float64, "cuda")
+    x.normal_()
+    x *= torch.logspace(-3, 3, 4099, device="cuda", dtype=torch.float64)[None, :]
+    y = wx.wptall(x, wt, 13)
+    ex, ey = (x ** 2).sum(0), (y ** 2).sum(0)
+    assert float(((ey - ex).abs() / ex).max()) <= 1e-12              # orthonormal, per signal
+    back = wx.iwptall(y, wt, 13)
+    assert float(((back - x).abs().amax(0) / x.abs().amax(0)).max()) <= 1e-12

@@ -1,0 +1,8 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r05k
+mkdir -p $O
+python -m pytest tests/test_gpu_lattice_8k.py -m gpu -q > $O/pytest_8k.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_8k.log
+python tools/floor_scan.py db4 f64 8192 > $O/floor_f64_db4.txt 2>&1; grep "full tree" $O/floor_f64_db4.txt
+python tools/floor_scan.py db8 f64 8192 > $O/floor_f64_db8.txt 2>&1; grep "full tree" $O/floor_f64_db8.txt
+python tools/floor_scan.py haar f64 8192 > $O/floor_f64_haar.txt 2>&1; grep "full tree" $O/floor_f64_haar.txt

@@ -205,13 +205,21 @@ bool wx_lattice_applicable_f64(const WxFilt &filt)
     return wx_lattice_factor(filt, 6, false, &tmp);
 }
 
+// 8192-sample signals in one pass: two wavefronts per signal, the first level in direct form inside the load / store phase (wx_lattice_8k.h)
+int wx_lattice_wpt8k_f64(const double *x, double *y, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+int wx_lattice_iwpt8k_f64(const double *xw, double *y, int L, int64_t batch, int64_t in_stride, const WxFilt &filt, hipStream_t st);
+
 int wx_lattice_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
 {
+    static const bool off = wx_getenv("WX_LATTICE") && atoi(wx_getenv("WX_LATTICE")) == 0;
+    if (n == 8192 && !off) return wx_lattice_wpt8k_f64(x, y, L, batch, filt, st);
     return wx_lattice_launch(false, x, y, n, L, batch, n, filt, st);
 }
 int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt,
                         hipStream_t st)
 {
+    static const bool off = wx_getenv("WX_LATTICE") && atoi(wx_getenv("WX_LATTICE")) == 0;
+    if (n == 8192 && !off) return wx_lattice_iwpt8k_f64(xw, y, L, batch, in_stride, filt, st);
     return wx_lattice_launch(true, xw, y, n, L, batch, in_stride, filt, st);
 }
 

@@ -86,6 +86,31 @@ __device__ __forceinline__ lat_f2v lat_fma(float c, lat_f2v a, lat_f2v b)
 __device__ __forceinline__ double lat_mul(double a, double g) { return a * g; }
 __device__ __forceinline__ lat_f2v lat_mul(lat_f2v a, float g) { const lat_f2v gg = {g, g}; return a * gg; }
 template <typename V> struct lat_v2 { V x, y; };            // two consecutive samples (of each signal)
+// the rotation coefficients as Float32 in SCALAR registers (v_readfirstlane of the one conversion at kernel entry).  Converting at the
+// point of use -- (float)cf.p[j] inside the level functions -- left it to the compiler where the v_cvt_f32_f64 runs; in the tree-driven
+// kernels the levels are exec-masked regions, and a conversion placed inside one region was reused in the next under another mask:
+// wrong inverse transforms for 12+ taps at 1024 samples (found by tests/test_gpu_lattice_pairs.py before the kernels shipped).
+struct WxLatF {
+    float p[WX_LAT_MAXS];
+    float kap[WX_LAT_MAXS];
+};
+template <int NS> __device__ __forceinline__ WxLatF lat_cf32(const WxLat &c)
+{
+    WxLatF f;
+#pragma unroll
+    for (int j = 0; j < WX_LAT_MAXS; ++j) {
+        f.p[j] = j < NS ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)c.p[j]))) : 0.0f;
+        f.kap[j] = j < NS ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)c.kap[j]))) : 0.0f;
+    }
+    return f;
+}
+template <int NS, bool PAIR> __device__ __forceinline__ typename std::conditional<PAIR, WxLatF, const WxLat &>::type lat_cfsel(const WxLat &c)
+{
+    if constexpr (PAIR) return lat_cf32<NS>(c);
+    else return c;
+}
+__device__ __forceinline__ float lat_sgpr(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double lat_sgpr(double v) { return v; }
 // global accesses of the kernels: 16 bytes per lane, streamed once (WX_LAT_NT: non-temporal hint)
 #ifndef WX_LAT_NT
 #define WX_LAT_NT 3     // measured (db4, L = 10, 65536 signals): forward 0.82 -> 0.79 ms, inverse 0.88 -> 0.80 ms
@@ -144,48 +169,6 @@ __device__ __forceinline__ void lat_st2w(double __attribute__((address_space(1))
 #endif
 }
 __device__ __forceinline__ void lat_st2w(float __attribute__((address_space(1))) *p, lat_d2 v) { lat_st2(p, v); }
-// two consecutive samples as register values V from memory of element type IO: (double, double) 16 bytes per lane, (double, float)
-// 8 bytes widened, (lat_f2v, float) 8 bytes from signal A at p and 8 bytes from signal B at p + boff, interleaved
-__device__ __forceinline__ lat_v2<double> lat_ldv(const double __attribute__((address_space(1))) *p, unsigned, double *)
-{
-    const lat_d2 t = lat_ld2(p);
-    return lat_v2<double>{t.x, t.y};
-}
-__device__ __forceinline__ lat_v2<double> lat_ldv(const float __attribute__((address_space(1))) *p, unsigned, double *)
-{
-    const lat_d2 t = lat_ld2(p);
-    return lat_v2<double>{t.x, t.y};
-}
-__device__ __forceinline__ lat_v2<lat_f2v> lat_ldv(const float __attribute__((address_space(1))) *p, unsigned boff, lat_f2v *)
-{
-    typedef const lat_f2 __attribute__((address_space(1))) *P;
-    const lat_f2 a = *(P)p, b = *(P)(p + boff);
-    lat_v2<lat_f2v> r;
-    r.x.x = a.x; r.x.y = b.x;
-    r.y.x = a.y; r.y.y = b.y;
-    return r;
-}
-__device__ __forceinline__ void lat_stv(double __attribute__((address_space(1))) *p, unsigned, double v0, double v1, bool wpd)
-{
-    lat_d2 o;
-    o.x = v0; o.y = v1;
-    if (wpd) lat_st2w(p, o); else lat_st2(p, o);
-}
-__device__ __forceinline__ void lat_stv(float __attribute__((address_space(1))) *p, unsigned, double v0, double v1, bool)
-{
-    lat_d2 o;
-    o.x = v0; o.y = v1;
-    lat_st2(p, o);
-}
-__device__ __forceinline__ void lat_stv(float __attribute__((address_space(1))) *p, unsigned boff, lat_f2v v0, lat_f2v v1, bool)
-{
-    typedef lat_f2 __attribute__((address_space(1))) *P;
-    lat_f2 a, b;
-    a.x = v0.x; a.y = v1.x;
-    b.x = v0.y; b.y = v1.y;
-    *(P)p = a;
-    *(P)(p + boff) = b;
-}
 __device__ __forceinline__ lat_gc lat_sbase(const double *p)
 {
     lat_gc g = (lat_gc)p;
@@ -209,6 +192,49 @@ __device__ __forceinline__ lat_gmf lat_sbase(float *p)
     lat_gmf g = (lat_gmf)p;
     asm("" : "+s"(g));
     return g;
+}
+// two consecutive samples as register values V from memory of element type IO, at (wave-uniform pointer) + (32-bit lane offset):
+// (double, double) 16 bytes per lane, (double, float) 8 bytes widened, (lat_f2v, float) 8 bytes from signal A and 8 bytes from
+// signal B at base + boff, interleaved.  Both streams use the "scalar base + lane offset" address form (B's base is a scalar add).
+__device__ __forceinline__ lat_v2<double> lat_ldv(const double *base, unsigned off, unsigned, double *)
+{
+    const lat_d2 t = lat_ld2(lat_sbase(base) + off);
+    return lat_v2<double>{t.x, t.y};
+}
+__device__ __forceinline__ lat_v2<double> lat_ldv(const float *base, unsigned off, unsigned, double *)
+{
+    const lat_d2 t = lat_ld2(lat_sbase(base) + off);
+    return lat_v2<double>{t.x, t.y};
+}
+__device__ __forceinline__ lat_v2<lat_f2v> lat_ldv(const float *base, unsigned off, unsigned boff, lat_f2v *)
+{
+    typedef const lat_f2 __attribute__((address_space(1))) *P;
+    const lat_f2 a = *(P)(lat_sbase(base) + off), b = *(P)(lat_sbase(base + boff) + off);
+    lat_v2<lat_f2v> r;
+    r.x.x = a.x; r.x.y = b.x;
+    r.y.x = a.y; r.y.y = b.y;
+    return r;
+}
+__device__ __forceinline__ void lat_stv(double *base, unsigned off, unsigned, double v0, double v1, bool wpd)
+{
+    lat_d2 o;
+    o.x = v0; o.y = v1;
+    if (wpd) lat_st2w(lat_sbase(base) + off, o); else lat_st2(lat_sbase(base) + off, o);
+}
+__device__ __forceinline__ void lat_stv(float *base, unsigned off, unsigned, double v0, double v1, bool)
+{
+    lat_d2 o;
+    o.x = v0; o.y = v1;
+    lat_st2(lat_sbase(base) + off, o);
+}
+__device__ __forceinline__ void lat_stv(float *base, unsigned off, unsigned boff, lat_f2v v0, lat_f2v v1, bool)
+{
+    typedef lat_f2 __attribute__((address_space(1))) *P;
+    lat_f2 a, b;
+    a.x = v0.x; a.y = v1.x;
+    b.x = v0.y; b.y = v1.y;
+    *(P)(lat_sbase(base) + off) = a;
+    *(P)(lat_sbase(base + boff) + off) = b;
 }
 
 // LDS traffic as explicit single ds_write_b64 / ds_read_b64 (byte address VGPR + 16-bit immediate).  The compiler would
@@ -277,7 +303,7 @@ template <int H, int D, typename V> __device__ __forceinline__ V lat_nbr(V v)
 }
 
 // one packet level on register-index bit K (2^K interleaved sequences of 32 >> K pairs per lane)
-template <int K, int H, int NS, bool INV, typename V> __device__ __forceinline__ void lat_level(V (&x)[64], const WxLat &cf)
+template <int K, int H, int NS, bool INV, typename V, typename C> __device__ __forceinline__ void lat_level(V (&x)[64], const C &cf)
 {
     typedef typename lat_vtraits<V>::coef CF;
     constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
@@ -475,25 +501,16 @@ template <int L, typename TM> __device__ __forceinline__ void lat_load_c(double 
 }
 
 // ---------------------------------------------------------------- forward
-template <int NS, int WPE, typename TM = double>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_f64(
-    const TM *__restrict__ x, TM *__restrict__ y, int L, int64_t batch, WxLat cf)
+// the transform of one 4096-sample signal from its samples in the L0 arrangement (register 4 hi3 + f of a lane = the two samples
+// p, p + 1 with p[11:9] = hi3, p[8:6] = lane >> 3, p[5:4] = f, p[3:1] = lane & 7: what eight complete 128-byte lines per load give),
+// shared by the kernel that loads them (k_lat_wpt_f64) and the one that computes them as a child of an 8192-sample signal
+// (k_lat_wpt8k_f64)
+template <int NS, typename TM>
+__device__ __forceinline__ void lat_fwd_from_l0(lat_d2 (&r)[32], unsigned lds0, int lane, int L, const WxLat &cf, TM *__restrict__ ys)
 {
-    __shared__ double lds[WX_LAT_LDS];
-    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
-    const int lane = threadIdx.x;
-    const int64_t sig = blockIdx.x;
-    const TM *xs = x + sig * 4096;
     double a[64];
     {
-        // L0: instruction (hi3 = p[11:9], f = p[5:4]) loads eight complete 128-byte lines: lane holds p[8:6] = lane >> 3,
-        // p[3:1] = lane & 7, register e = p[0].  T1: L0 -> A (reg p[5:0], lane p[11:6]), round f
-        lat_d2 r[32];
-        const unsigned xo = 64u * (lane >> 3) + 2u * (lane & 7);
-        lat_for<32>([&](auto Q) {
-            constexpr int hi3 = Q / 4, f = Q % 4;
-            r[Q] = lat_ld2(lat_sbase(xs + 512 * hi3 + 16 * f) + xo);
-        });
+        // T1: L0 -> A (reg p[5:0], lane p[11:6]), round f
         const unsigned wa = lds0 + 8u * (17u * (lane >> 3) + 2u * (lane & 7)), ra = lds0 + 8u * 17u * lane;
         lat_for<4>([&](auto Fq) {
             constexpr int f = Fq;
@@ -577,7 +594,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (L > 9) lat_level<3, 0, NS, false>(c, cf);
     if (L > 10) lat_level<4, 0, NS, false>(c, cf);
     if (L > 11) lat_level<5, 0, NS, false>(c, cf);
-    TM *ys = y + sig * 4096;
     switch (L) {
     case 6: lat_store_c<6>(c, lds0, ys, lane, cf); break;
     case 7: lat_store_c<7>(c, lds0, ys, lane, cf); break;
@@ -587,6 +603,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     case 11: lat_store_c<11>(c, lds0, ys, lane, cf); break;
     default: lat_store_c<12>(c, lds0, ys, lane, cf); break;
     }
+}
+
+template <int NS, int WPE, typename TM = double>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_f64(
+    const TM *__restrict__ x, TM *__restrict__ y, int L, int64_t batch, WxLat cf)
+{
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int64_t sig = blockIdx.x;
+    const TM *xs = x + sig * 4096;
+    // L0: instruction (hi3 = p[11:9], f = p[5:4]) loads eight complete 128-byte lines: lane holds p[8:6] = lane >> 3,
+    // p[3:1] = lane & 7, register e = p[0]
+    lat_d2 r[32];
+    const unsigned xo = 64u * (lane >> 3) + 2u * (lane & 7);
+    lat_for<32>([&](auto Q) {
+        constexpr int hi3 = Q / 4, f = Q % 4;
+        r[Q] = lat_ld2(lat_sbase(xs + 512 * hi3 + 16 * f) + xo);
+    });
+    lat_fwd_from_l0<NS>(r, lds0, lane, L, cf, y + sig * 4096);
 }
 
 // ---------------------------------------------------------------- wpd: every level leaves through an LDS transposition
@@ -788,9 +824,9 @@ __device__ __forceinline__ void lat_emit(V (&x)[64], unsigned lds0, IO *__restri
                 constexpr int oc = lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i);
                 if constexpr (PRED) {
                     if ((word >> (8 * rho + i)) & 1u)
-                        lat_stv(lat_sbase(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + yo, boff, v[2 * I], v[2 * I + 1], false);
+                        lat_stv(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride, yo, boff, v[2 * I], v[2 * I + 1], false);
                 } else
-                    lat_stv(lat_sbase(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + yo, boff, v[2 * I], v[2 * I + 1], true);
+                    lat_stv(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride, yo, boff, v[2 * I], v[2 * I + 1], true);
             });
         });
     });
@@ -839,7 +875,7 @@ __device__ __forceinline__ void lat_absorb_fetch(lat_v2<V> (&v)[16], const IO *_
         lat_v2<V> &d = v[8 * (RN & 1) + i];
         d.x = d.y = V{};
         const unsigned co = dep ? ((dep[idx >> 3] >> (4 * (idx & 7))) & 15u) * cstride : 0u;
-        if ((word >> idx) & 1u) d = lat_ldv(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + (xo + co), sstride << lat_sh(LVL), (V *)nullptr);
+        if ((word >> idx) & 1u) d = lat_ldv(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride, xo + co, sstride << lat_sh(LVL), (V *)nullptr);
     });
 }
 template <int LAY, int LVL, typename IO = double, typename V = double>
@@ -898,7 +934,7 @@ __device__ __forceinline__ void lat_absorb(V (&x)[64], unsigned lds0, const IO *
             lat_for<8>([&](auto I) {
                 constexpr int i = I;
                 constexpr int oc = lat_emit_o_round(LAY, LVL, rn) + lat_emit_o_instr(LAY, LVL, i);
-                v[8 * (rn & 1) + i] = lat_ldv(lat_sbase(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride) + xo, boff, (V *)nullptr);
+                v[8 * (rn & 1) + i] = lat_ldv(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride, xo, boff, (V *)nullptr);
             });
     };
     if constexpr (!PRE) fetch(std::integral_constant<int, 0>{});
@@ -1178,15 +1214,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 }
 
 // ---------------------------------------------------------------- inverse
-template <int NS, int WPE, typename TM = double>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_f64(
-    const TM *__restrict__ xw, TM *__restrict__ y, int L, int64_t batch, int64_t in_stride, WxLat cf)
+// the inverse transform of one 4096-sample signal up to the L0 arrangement of its samples (see lat_fwd_from_l0): `sink(f, o)` receives,
+// round by round (f = p[5:4]), the eight 16-byte pieces o[hi3] = samples p, p + 1 with p[11:9] = hi3, p[8:6] = lane >> 3, p[3:1] = lane & 7.
+// k_lat_iwpt_f64 stores them (eight complete lines per instruction); k_lat_iwpt8k_f64 keeps them as one child of an 8192-sample signal.
+template <int NS, typename TM, typename SINK>
+__device__ __forceinline__ void lat_inv_to_l0(const TM *__restrict__ xs, unsigned lds0, int lane, int L, const WxLat &cf, SINK &&sink)
 {
-    __shared__ double lds[WX_LAT_LDS];
-    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
-    const int lane = threadIdx.x;
-    const int64_t sig = blockIdx.x;
-    const TM *xs = xw + sig * in_stride;
     double c[64];
     switch (L) {
     case 6: lat_load_c<6>(c, lds0, xs, lane, cf); break;
@@ -1261,11 +1294,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     }
     lat_level<1, 6, NS, true>(a, cf);
     lat_level<0, 6, NS, true>(a, cf);
-    // T1i: A -> L0 and the stores (eight complete 128-byte lines per instruction), round f = p[5:4]
+    // T1i: A -> L0, round f = p[5:4]
     {
         const unsigned wa = lds0 + 8u * 17u * lane, ra = lds0 + 8u * (17u * (lane >> 3) + 4u * (lane & 7));
-        const unsigned yo = 64u * (lane >> 3) + 2u * (lane & 7);
-        TM *ys = y + sig * 4096;
         lat_for<4>([&](auto Fq) {
             constexpr int f = Fq;
             lat_for<16>([&](auto M) {
@@ -1278,15 +1309,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 t[M] = lds_rd<8 * (136 * hi3 + 2 * e)>(ra);
             });
             lat_wait16<0>(t);
+            lat_d2 o[8];
             lat_for<8>([&](auto Hq) {
                 constexpr int hi3 = Hq;
-                lat_d2 o;
-                o.x = t[2 * hi3];
-                o.y = t[2 * hi3 + 1];
-                lat_st2(lat_sbase(ys + 512 * hi3 + 16 * f) + yo, o);
+                o[hi3].x = t[2 * hi3];
+                o[hi3].y = t[2 * hi3 + 1];
             });
+            sink(Fq, o);
         });
     }
+}
+
+template <int NS, int WPE, typename TM = double>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_f64(
+    const TM *__restrict__ xw, TM *__restrict__ y, int L, int64_t batch, int64_t in_stride, WxLat cf)
+{
+    __shared__ double lds[WX_LAT_LDS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int64_t sig = blockIdx.x;
+    const unsigned yo = 64u * (lane >> 3) + 2u * (lane & 7);
+    TM *ys = y + sig * 4096;
+    lat_inv_to_l0<NS>(xw + sig * in_stride, lds0, lane, L, cf, [&](auto Fq, lat_d2 (&o)[8]) {
+        constexpr int f = decltype(Fq)::value;
+        lat_for<8>([&](auto Hq) {
+            constexpr int hi3 = Hq;
+            lat_st2(lat_sbase(ys + 512 * hi3 + 16 * f) + yo, o[hi3]);
+        });
+    });
 }
 
 // wpd of 2^SH interleaved signals: y is (n, L+1, batch), n = 4096 >> SH; every level leaves through lat_emit with the
@@ -1523,7 +1573,9 @@ template <typename V> __device__ __forceinline__ void lat_t2i(V (&bb)[64], V (&a
 
 // forward wpt, leaves only: Le = L + SH in 6 .. 12 (the last level runs in layout C)
 // (IO = float: Float32 signals -- the loads widen, the stores round once, as in k_lat_wpt_f64<NS, WPE, float>)
-template <int NS, int WPE, int SH, typename IO = double>
+// (F32A = false with IO = float: Float32 in memory, Float64 in the registers, one signal set per wavefront -- the round-4 form, kept for
+// the 64- and 128-sample kernels where the pair form measured slower: profiles/r05_floor.txt)
+template <int NS, int WPE, int SH, typename IO = double, bool F32A = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_g_f64(
     const IO *__restrict__ x, IO *__restrict__ y, int L, int last_sig, WxLatW cw)
 {
@@ -1532,7 +1584,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const int lane = threadIdx.x;
     // IO = float: Float32 arithmetic on pairs of signals (lat_f2v) -- the wavefront takes 2 x 2^SH signals, the second set follows the
     // first in memory; last_sig is then batch - 2 x 2^SH
-    typedef typename std::conditional<std::is_same<IO, float>::value, lat_f2v, double>::type V;
+    typedef typename std::conditional<std::is_same<IO, float>::value && F32A, lat_f2v, double>::type V;
     constexpr bool PAIR = lat_vtraits<V>::pair != 0;
     // pair kernels: last_sig is the tail wavefront's first signal, cw.tail_bsig its second set's distance (wx_lat_pair_plan)
     const bool lastw = PAIR && blockIdx.x == gridDim.x - 1;
@@ -1541,7 +1593,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const int64_t off = (int64_t)sig0 * (4096 >> SH);
     const IO *xs = x + off;
     IO *ys = y + off;
-    const WxLat &cf = cw.c;
+    const typename std::conditional<PAIR, WxLatF, const WxLat &>::type cf = lat_cfsel<NS, PAIR>(cw.c);
     V c[64];
     if constexpr (SH < 2) {
         V a[64], bb[64];
@@ -1584,14 +1636,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 }
 
 // inverse wpt: leaves of signal s at xw + s in_stride (dense array or the last column of packet tables)
-template <int NS, int WPE, int SH, typename IO = double>
+template <int NS, int WPE, int SH, typename IO = double, bool F32A = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_g_f64(
     const IO *__restrict__ xw, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, WxLatW cw)
 {
     __shared__ double lds[WX_LAT_LDS];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
-    typedef typename std::conditional<std::is_same<IO, float>::value, lat_f2v, double>::type V;
+    typedef typename std::conditional<std::is_same<IO, float>::value && F32A, lat_f2v, double>::type V;
     constexpr bool PAIR = lat_vtraits<V>::pair != 0;
     const bool lastw = PAIR && blockIdx.x == gridDim.x - 1;
     const int sig0 = PAIR ? (lastw ? last_sig : (int)(blockIdx.x << (SH + 1))) : min((int)blockIdx.x << SH, last_sig);
@@ -1599,7 +1651,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const unsigned bofs_in = PAIR ? bsig * in_stride : 0xffffffffu, bofs = PAIR ? bsig * (4096u >> SH) : 0xffffffffu;
     const IO *xs = xw + (int64_t)sig0 * in_stride;
     IO *ys = y + (int64_t)sig0 * (4096 >> SH);
-    const WxLat &cf = cw.c;
+    const typename std::conditional<PAIR, WxLatF, const WxLat &>::type cf = lat_cfsel<NS, PAIR>(cw.c);
     const int Le = L + SH;
     V c[64];
     switch (Le) {
@@ -1850,11 +1902,11 @@ template <int G> __device__ __forceinline__ void lat_masks(unsigned long long (&
     }
 }
 
-template <int K, int NS, bool INV, typename V>
-__device__ __forceinline__ void lat_level_cm(V (&x)[64], const WxLat &cf, const unsigned long long *__restrict__ mk, double ga_, double gd_)
+template <int K, int NS, bool INV, typename V, typename C>
+__device__ __forceinline__ void lat_level_cm(V (&x)[64], const C &cf, const unsigned long long *__restrict__ mk, double ga_, double gd_)
 {
     typedef typename lat_vtraits<V>::coef CF;
-    const CF ga = (CF)ga_, gd = (CF)gd_;
+    const CF ga = lat_sgpr((CF)ga_), gd = lat_sgpr((CF)gd_);
     constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K, G = NSEQ < 8 ? NSEQ : 8;
     auto U = [](int s, int m) { return s + ((2 * m) << K); };
     lat_for<NSEQ / G>([&](auto Gc) {

@@ -12,13 +12,24 @@
 int WX_G32_FN(bool inverse, const float *x, float *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt, hipStream_t st)
 {
     constexpr int SH = WX_G32_SH;
-    constexpr int64_t per = (int64_t)2 << SH;                // signals per wavefront: two sets of 2^SH
+    // pairs of signals in Float32 arithmetic from 256 samples up; 64- and 128-sample signals keep Float64 registers (measured:
+    // 0.48 / 0.48 ms against 0.55 / 0.57 per GiB at n = 64, profiles/r05_floor.txt -- 64 signals x 2 per wavefront gain nothing there)
+    constexpr bool PAIRS = SH <= 4;
+    constexpr int64_t per = (int64_t)(PAIRS ? 2 : 1) << SH;  // signals per wavefront: two sets of 2^SH
 #ifndef WX_G32_NSMAX
 #define WX_G32_NSMAX 4
 #endif
     if (n != (4096 >> SH) || L < 1 || L + SH < 6 || L + SH > 12 || filt.F < 2 || filt.F > 2 * WX_G32_NSMAX) return 0;
     WxPairPlan pp;
-    if (!wx_lat_pair_plan(batch, SH, x == y, &pp)) return 0;   // a remainder below 2^SH signals re-does signals: out of place only
+    if (PAIRS) {
+        if (!wx_lat_pair_plan(batch, SH, x == y, &pp)) return 0;   // a remainder below 2^SH signals re-does signals: out of place only
+    } else {
+        if (batch < per || batch > 0x7fffffff) return 0;
+        if ((batch & (per - 1)) && x == y) return 0;         // the tail wavefront re-does signals: out of place only
+        pp.nwave = (unsigned)((batch + per - 1) / per);
+        pp.tail_sig = (int)(batch - per);
+        pp.tail_bsig = 0;
+    }
     if (in_stride < n || (in_stride & 3) || in_stride * (per - 1) + 4096 > 0x7fffffff) return 0;
     if (in_stride * (per / 2) > 0x7fffffff) return 0;         // offset of the second signal set (32-bit element offsets)
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return 0;
@@ -30,15 +41,15 @@ int WX_G32_FN(bool inverse, const float *x, float *y, int64_t n, int L, int64_t 
     const unsigned nwave = pp.nwave;
     const int last_sig = pp.tail_sig;
     cw.tail_bsig = pp.tail_bsig;
-// wavefronts per SIMD: a wavefront's phases (loads, exchanges, rotations, stores) are sequential, so residency is throughput -- three
-// where the rotations of the filter fit 168 registers (up to 8 taps; 1-12 registers spill), two beyond (NS = 8 would spill 237)
-#define WX_G32_WPE(NSS) ((NSS) <= 4 ? 3 : 2)
+// wavefronts per SIMD: three (168 registers: 1-12 spill for up to 8 taps) measured no faster than two (0.57 / 0.58 against 0.55 / 0.53 ms
+// per GiB of 4096-sample signals): the kernels are bound by vector issue, which more residency does not add to
+#define WX_G32_WPE(NSS) 2
 #define WX_GOG(NSS)                                                                                                                  \
     case NSS:                                                                                                                        \
         if (inverse)                                                                                                                 \
-            hipLaunchKernelGGL((k_lat_iwpt_g_f64<NSS, WX_G32_WPE(NSS), SH, float>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, (unsigned)in_stride, cw); \
+            hipLaunchKernelGGL((k_lat_iwpt_g_f64<NSS, WX_G32_WPE(NSS), SH, float, PAIRS>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, (unsigned)in_stride, cw); \
         else                                                                                                                         \
-            hipLaunchKernelGGL((k_lat_wpt_g_f64<NSS, WX_G32_WPE(NSS), SH, float>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
+            hipLaunchKernelGGL((k_lat_wpt_g_f64<NSS, WX_G32_WPE(NSS), SH, float, PAIRS>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
         break;
     switch (filt.F / 2) {
         WX_GOG(1) WX_GOG(2) WX_GOG(3) WX_GOG(4)

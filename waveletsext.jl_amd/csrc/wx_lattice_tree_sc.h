@@ -146,11 +146,11 @@ __global__ __launch_bounds__(64) void k_lat_treesc_prep2(WxLatTreeSc *__restrict
 // H cyclic lane bits hold the rest of a sequence (lat_nbr).  The shears and the gains run under the mask; the renamings and
 // halo rotations between the shears are executed by every lane: over a level they compose to the identity, and a sequence's
 // lanes (a 16-lane row in layout B, the wavefront in layout A) are all in or all out.
-template <int K, int H, int NS, bool INV, typename V>
-__device__ __forceinline__ void lat_level_hm(V (&x)[64], const WxLat &cf, const unsigned long long *__restrict__ mk, double ga_, double gd_)
+template <int K, int H, int NS, bool INV, typename V, typename C>
+__device__ __forceinline__ void lat_level_hm(V (&x)[64], const C &cf, const unsigned long long *__restrict__ mk, double ga_, double gd_)
 {
     typedef typename lat_vtraits<V>::coef CF;
-    const CF ga = (CF)ga_, gd = (CF)gd_;
+    const CF ga = lat_sgpr((CF)ga_), gd = lat_sgpr((CF)gd_);
     constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K, G = NSEQ < 8 ? NSEQ : 8;
     auto U = [](int s, int m) { return s + ((2 * m) << K); };
     lat_for<NSEQ / G>([&](auto Gc) {
@@ -251,21 +251,28 @@ __device__ __forceinline__ void lat_sc_ldrow(lat_d2 &r, unsigned a) { r = *lat_s
 __device__ __forceinline__ void lat_sc_ldrow(lat_f4v &r, unsigned a) { r = *(lat_l4p)(uintptr_t)a; }
 __device__ __forceinline__ void lat_sc_strow(unsigned a, lat_d2 r) { *lat_sc_lp(a) = r; }
 __device__ __forceinline__ void lat_sc_strow(unsigned a, lat_f4v r) { *(lat_l4p)(uintptr_t)a = r; }
-template <typename GP> __device__ __forceinline__ void lat_sc_gst(GP p, unsigned, lat_d2 r) { lat_st2(p, r); }
-__device__ __forceinline__ void lat_sc_gst(float __attribute__((address_space(1))) *p, unsigned boff, lat_f4v r)
+template <typename IO> __device__ __forceinline__ void lat_sc_gst(IO *base, unsigned off, unsigned, lat_d2 r) { lat_st2(lat_sbase(base) + off, r); }
+__device__ __forceinline__ void lat_sc_gst(float *base, unsigned off, unsigned boff, lat_f4v r)
 {
     typedef lat_f2 __attribute__((address_space(1))) *P;
     lat_f2 a, b;
     a.x = r.x; a.y = r.z;
     b.x = r.y; b.y = r.w;
-    *(P)p = a;
-    *(P)(p + boff) = b;
+    *(P)(lat_sbase(base) + off) = a;
+    *(P)(lat_sbase(base + boff) + off) = b;
 }
-template <typename GP> __device__ __forceinline__ void lat_sc_gld(lat_d2 &r, GP p, unsigned) { r = lat_ld2(p); }
-__device__ __forceinline__ void lat_sc_gld(lat_f4v &r, const float __attribute__((address_space(1))) *p, unsigned boff)
+template <typename GP> __device__ __forceinline__ void lat_sc_gldp(lat_d2 &r, GP pa, GP) { r = lat_ld2(pa); }
+__device__ __forceinline__ void lat_sc_gldp(lat_f4v &r, const float __attribute__((address_space(1))) *pa, const float __attribute__((address_space(1))) *pb)
 {
     typedef const lat_f2 __attribute__((address_space(1))) *P;
-    const lat_f2 a = *(P)p, b = *(P)(p + boff);
+    const lat_f2 a = *(P)pa, b = *(P)pb;
+    r.x = a.x; r.y = b.x; r.z = a.y; r.w = b.y;
+}
+template <typename IO> __device__ __forceinline__ void lat_sc_gld(lat_d2 &r, const IO *base, unsigned off, unsigned) { r = lat_ld2(lat_sbase(base) + off); }
+__device__ __forceinline__ void lat_sc_gld(lat_f4v &r, const float *base, unsigned off, unsigned boff)
+{
+    typedef const lat_f2 __attribute__((address_space(1))) *P;
+    const lat_f2 a = *(P)(lat_sbase(base) + off), b = *(P)(lat_sbase(base + boff) + off);
     r.x = a.x; r.y = b.x; r.z = a.y; r.w = b.y;
 }
 
@@ -290,13 +297,13 @@ __device__ __forceinline__ void lat_sc_ptab(unsigned (&pw)[32], const WxLatTreeS
 #define WX_SC_FWD(KK, HH, REG, BIT, MK, ANY)                                                   \
     if constexpr (BIT == SH) {                                                                  \
         lat_level<KK, HH, NS, false>(REG, cf);                                                  \
-        _Pragma("unroll") for (int r = 0; r < 64; ++r) REG[r] = lat_mul(REG[r], ((r >> KK) & 1) ? (CF)ginv : (CF)g);    \
+        _Pragma("unroll") for (int r = 0; r < 64; ++r) REG[r] = lat_mul(REG[r], ((r >> KK) & 1) ? lat_sgpr((CF)ginv) : lat_sgpr((CF)g));    \
     } else if constexpr (BIT > SH) {                                                            \
         if (ANY) lat_level_hm<KK, HH, NS, false>(REG, cf, MK, g, ginv);                         \
     }
 #define WX_SC_INV(KK, HH, REG, BIT, MK, ANY)                                                   \
     if constexpr (BIT == SH) {                                                                  \
-        _Pragma("unroll") for (int r = 0; r < 64; ++r) REG[r] = lat_mul(REG[r], ((r >> KK) & 1) ? (CF)gd : (CF)ga);     \
+        _Pragma("unroll") for (int r = 0; r < 64; ++r) REG[r] = lat_mul(REG[r], ((r >> KK) & 1) ? lat_sgpr((CF)gd) : lat_sgpr((CF)ga));     \
         lat_level<KK, HH, NS, true>(REG, cf);                                                   \
     } else if constexpr (BIT > SH) {                                                            \
         if (ANY) lat_level_hm<KK, HH, NS, true>(REG, cf, MK, ga, gd);                           \
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const unsigned boff_out = bsig * out_stride, boff_in = PAIR ? bsig * in_stride : 0xffffffffu;
     const IO *xs = x + (int64_t)sig0 * in_stride;                // signals in_stride / out_stride elements apart
     IO *ys = y + (int64_t)sig0 * out_stride;
-    const WxLat &cf = cw.c;
+    const typename std::conditional<PAIR, WxLatF, const WxLat &>::type cf = lat_cfsel<NS, PAIR>(cw.c);
     // forward: gl[1] = g, g2 = g^-2: after the shears the a-slot holds a / g, the d-slot d g
     const double g = cw.gl[1], ginv = cw.c.g2 * cw.gl[1];
     V c[64];
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             });
             lat_for<8>([&](auto Kc) {
                 constexpr int k = k0 + Kc, q = 16 * h + k, sg = q / NQ, qq = q % NQ;
-                lat_sc_gst(lat_sbase(ys + (size_t)sg * out_stride + 128 * qq) + 2 * lane, boff_out, v[Kc]);
+                lat_sc_gst(ys + (size_t)sg * out_stride + 128 * qq, 2u * lane, boff_out, v[Kc]);
             });
         });
         lat_sync();
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const unsigned boff_in = bsig * in_stride, boff_out = PAIR ? bsig * out_stride : 0xffffffffu;
     const IO *xs = xw + (int64_t)sig0 * in_stride;
     IO *ys = y + (int64_t)sig0 * out_stride;
-    const WxLat &cf = cw.c;
+    const typename std::conditional<PAIR, WxLatF, const WxLat &>::type cf = lat_cfsel<NS, PAIR>(cw.c);
     unsigned dep[4] = {0, 0, 0, 0};
     if (col_stride) {
 #pragma unroll
@@ -428,10 +435,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             if constexpr (qq == 0) {
                 // idwt of a pyramid: positions 0 .. 63 are the samples the lane-local tail (wx_dwttail.hip) has rebuilt
                 const IO *hp = reinterpret_cast<const IO *>(thr.head);
-                if (hp && lane < 32) lat_sc_gld(v[k], lat_sbase(hp + 64 * (int64_t)(sig0 + sg)) + 2 * lane, 64u * bsig);
-                else lat_sc_gld(v[k], lat_sbase(src) + (2 * lane + co), boff_in);
+                // both candidate bases are formed OUTSIDE the lane-dependent choice (a scalar-register base inside a divergent branch
+                // gets merged across the arms into a lane-dependent value), the choice is made on the complete addresses
+                const IO *hb = hp ? hp + 64 * (int64_t)(sig0 + sg) : src;
+                const auto pah = lat_sbase(hb) + 2 * lane, pbh = lat_sbase(hb + (hp ? 64u * bsig : boff_in)) + 2 * lane;
+                const auto pas = lat_sbase(src) + (2 * lane + co), pbs = lat_sbase(src + boff_in) + (2 * lane + co);
+                const bool useh = hp && lane < 32;
+                lat_sc_gldp(v[k], useh ? pah : pas, useh ? pbh : pbs);
             } else
-                lat_sc_gld(v[k], lat_sbase(src) + (2 * lane + co), boff_in);
+                lat_sc_gld(v[k], src, 2u * lane + co, boff_in);
         });
     };
     double tt[4] = {0, 0, 0, 0};
