@@ -51,18 +51,10 @@ template <typename T> static bool wx_lattice_tree_applicable_T(int64_t n, const 
 // shallow trees on 2048 -- run 1.5-2 x faster on the tree-driven lattice than on the fused LDS kernels.)
 static const uint8_t *wx_full_tree_ones(hipStream_t st)
 {
-    static std::mutex mu;
-    static uint8_t *ones[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!ones[dev]) {
-        uint8_t *p = nullptr;
-        if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
-        if (hipMemsetAsync(p, 1, 4096, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(p); return nullptr; }
-        ones[dev] = p;
-    }
-    return ones[dev];
+    // through the per-device cache of small constant tables (wx_host.hip): uploaded once per device, ordered on the caller's stream by
+    // an event (no synchronisation of that stream under a lock: graph capture stays legal), released by wx_shutdown
+    static const struct Ones { uint8_t b[4096]; Ones() { memset(b, 1, sizeof b); } } ones;
+    return (const uint8_t *)wx_const_upload(ones.b, sizeof ones.b, st, true);
 }
 static bool wx_full_as_tree()
 {
@@ -1678,7 +1670,8 @@ int wx_dev_idwt_long(const T *xw, T *y, int64_t n, int Lp, int64_t batch, const 
     if (wx_top_levels_ok(filt.F)) {
         // a shallow pyramid, or one that leaves only a level or two for the finishing kernel (which is slow or not applicable
         // there: idwtall of 32768-sample signals with L = 4 took 9.8 ms in round 3), runs entirely in the top passes
-        if (Lp <= 4 || (Lp > dl && Lp - dl <= 2 && Lp <= 8 && (n >> 4) >= 4096)) top = Lp;   // every pass's input is at least a tile long
+        // (the top passes apply neither denoise()'s threshold nor the rebuilt head of the lane-local tail: only without them)
+        if (!thr.t && !thr.head && (Lp <= 4 || (Lp > dl && Lp - dl <= 2 && Lp <= 8 && (n >> 4) >= 4096))) top = Lp;   // every pass's input is at least a tile long
         // mirror of wx_dev_dwt_long: the lattice (or fused) inverse rebuilds the approximation of depth `top` in scratch, then up to
         // four synthesis levels per pass, the details coming straight from xw
         const int npass = (top + 3) / 4;

@@ -311,29 +311,17 @@ __device__ __forceinline__ void lat_sc_ptab(unsigned (&pw)[32], const WxLatTreeS
 
 // IO: the signal's type in memory (Float64 in the registers either way: Float32 signals are widened by the loads and rounded once by the
 // stores, like the full-tree kernels k_lat_wpt_f64<.., float>)
-template <int NS, int WPE, int SH, typename IO = double, bool FP32A = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_treesc_f64(
-    const IO *__restrict__ x, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned out_stride, WxLatW cw,
-    const WxLatTreeSc *__restrict__ tab)
+// the forward transform from the first register layout on (layout A for 4096 / 2048 samples, B for 1024): `src(regs)` fills it -- from
+// memory (lat_absorb: k_lat_wpt_treesc_f64) or from a child computed in place (wx_lattice_8k.h: k_lat_wpt_treesc8k_f64)
+template <int NS, int SH, typename IO, bool FP32A, typename SRC>
+__device__ __forceinline__ void lat_treesc_fwd(IO *__restrict__ ys, unsigned lds0, int lane, unsigned out_stride, unsigned boff_out, const WxLatW &cw,
+                                               const WxLatTreeSc *__restrict__ tab, SRC &&src)
 {
-    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
-    __shared__ __attribute__((aligned(16))) double lds[2048];
-    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
-    const int lane = threadIdx.x;
-    constexpr int NQ = 32 >> SH;                                 // 128-element pieces of one signal
-    // FP32A (IO = float with WX_LAT_TREE_F32A): Float32 arithmetic on PAIRS of signals (lat_f2v, wx_lattice_dev.h) -- the wavefront takes
-    // 2 x 2^SH signals with the one tree of the call; the second set follows the first at 2^SH signals' distance
+    constexpr int NQ = 32 >> SH;
     typedef typename std::conditional<FP32A, lat_f2v, double>::type V;
     typedef typename lat_vtraits<V>::coef CF;
     typedef typename lat_row<V>::type ROW;
     constexpr bool PAIR = lat_vtraits<V>::pair != 0;
-    // pair kernels: last_sig = the tail wavefront's first signal, cw.tail_bsig = its second set's distance (wx_lat_pair_plan)
-    const bool lastw = PAIR && blockIdx.x == gridDim.x - 1;
-    const int sig0 = PAIR ? (lastw ? last_sig : (int)(blockIdx.x << (SH + 1))) : min((int)blockIdx.x << SH, last_sig);
-    const unsigned bsig = (unsigned)(lastw ? cw.tail_bsig : (1 << SH));
-    const unsigned boff_out = bsig * out_stride, boff_in = PAIR ? bsig * in_stride : 0xffffffffu;
-    const IO *xs = x + (int64_t)sig0 * in_stride;                // signals in_stride / out_stride elements apart
-    IO *ys = y + (int64_t)sig0 * out_stride;
     const typename std::conditional<PAIR, WxLatF, const WxLat &>::type cf = lat_cfsel<NS, PAIR>(cw.c);
     // forward: gl[1] = g, g2 = g^-2: after the shears the a-slot holds a / g, the d-slot d g
     const double g = cw.gl[1], ginv = cw.c.g2 * cw.gl[1];
@@ -342,12 +330,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         V bb[64];
         if constexpr (SH < 2) {
             V a[64];
-            lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw, in_stride, 0, 0, 0, boff_in);
+            src(a);
             WX_SC_FWD(0, 6, a, 0, tab->mA, true)
             WX_SC_FWD(1, 6, a, 1, tab->mA, tab->anyA)
             lat_t2(a, bb, lds0, lane);
         } else
-            lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw, in_stride, 0, 0, 0, boff_in);
+            src(bb);
         WX_SC_FWD(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
         WX_SC_FWD(1, 4, bb, 3, tab->mB + 32, tab->anyB[1])
         WX_SC_FWD(2, 4, bb, 4, tab->mB + 64, tab->anyB[2])
@@ -397,27 +385,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     });
 }
 
-template <int NS, int WPE, int SH, bool THR, typename IO = double, bool FP32A = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_treesc_f64(
-    const IO *__restrict__ xw, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride,
-    unsigned out_stride, WxLatW cw, const WxLatTreeSc *__restrict__ tab, WxThreshArg thr)
+template <int NS, int WPE, int SH, typename IO = double, bool FP32A = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_treesc_f64(
+    const IO *__restrict__ x, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned out_stride, WxLatW cw,
+    const WxLatTreeSc *__restrict__ tab)
 {
     static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
     __shared__ __attribute__((aligned(16))) double lds[2048];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
+    // FP32A (IO = float): Float32 arithmetic on PAIRS of signals (lat_f2v, wx_lattice_dev.h) -- the wavefront takes 2 x 2^SH signals with
+    // the one tree of the call; the second set follows the first at 2^SH signals' distance
+    typedef typename std::conditional<FP32A, lat_f2v, double>::type V;
+    constexpr bool PAIR = lat_vtraits<V>::pair != 0;
+    // pair kernels: last_sig = the tail wavefront's first signal, cw.tail_bsig = its second set's distance (wx_lat_pair_plan)
+    const bool lastw = PAIR && blockIdx.x == gridDim.x - 1;
+    const int sig0 = PAIR ? (lastw ? last_sig : (int)(blockIdx.x << (SH + 1))) : min((int)blockIdx.x << SH, last_sig);
+    const unsigned bsig = (unsigned)(lastw ? cw.tail_bsig : (1 << SH));
+    const unsigned boff_out = bsig * out_stride, boff_in = PAIR ? bsig * in_stride : 0xffffffffu;
+    const IO *xs = x + (int64_t)sig0 * in_stride;                // signals in_stride / out_stride elements apart
+    lat_treesc_fwd<NS, SH, IO, FP32A>(y + (int64_t)sig0 * out_stride, lds0, lane, out_stride, boff_out, cw, tab, [&](V (&regs)[64]) {
+        lat_absorb<(SH < 2 ? 0 : 2), 16 * SH>(regs, lds0, xs, lane, cw, in_stride, 0, 0, 0, boff_in);
+    });
+}
+
+// the inverse transform up to the last register layout (A for 4096 / 2048 samples, B for 1024): `sink(regs)` takes it -- to memory
+// (lat_emit: k_lat_iwpt_treesc_f64) or on to the synthesis of an 8192-sample parent (wx_lattice_8k.h)
+template <int NS, int SH, bool THR, typename IO, bool FP32A, typename SINK>
+__device__ __forceinline__ void lat_treesc_inv(const IO *__restrict__ xs, int sig0, unsigned lds0, int lane, unsigned in_stride, unsigned col_stride,
+                                               unsigned boff_in, unsigned bsig, const WxLatW &cw, const WxLatTreeSc *__restrict__ tab,
+                                               const WxThreshArg &thr, SINK &&sink)
+{
     constexpr int NQ = 32 >> SH;                               // 128-element pieces of one signal
     typedef typename std::conditional<FP32A, lat_f2v, double>::type V;
     typedef typename lat_vtraits<V>::coef CF;
     typedef typename lat_row<V>::type ROW;
-    static_assert(!(FP32A && THR), "the threshold of denoise() rides on the Float64-register kernels");
     constexpr bool PAIR = lat_vtraits<V>::pair != 0;
-    const bool lastw = PAIR && blockIdx.x == gridDim.x - 1;
-    const int sig0 = PAIR ? (lastw ? last_sig : (int)(blockIdx.x << (SH + 1))) : min((int)blockIdx.x << SH, last_sig);
-    const unsigned bsig = (unsigned)(lastw ? cw.tail_bsig : (1 << SH));
-    const unsigned boff_in = bsig * in_stride, boff_out = PAIR ? bsig * out_stride : 0xffffffffu;
-    const IO *xs = xw + (int64_t)sig0 * in_stride;
-    IO *ys = y + (int64_t)sig0 * out_stride;
     const typename std::conditional<PAIR, WxLatF, const WxLat &>::type cf = lat_cfsel<NS, PAIR>(cw.c);
     unsigned dep[4] = {0, 0, 0, 0};
     if (col_stride) {
@@ -531,14 +534,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     WX_SC_INV(1, 4, bb, 3, tab->mB + 32, tab->anyB[1])
     WX_SC_INV(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
     if constexpr (SH >= 2) {
-        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw, out_stride, 0, 0, boff_out);
+        sink(bb);
     } else {
         V a[64];
         lat_t2i(bb, a, lds0, lane);
         WX_SC_INV(1, 6, a, 1, tab->mA, tab->anyA)
         WX_SC_INV(0, 6, a, 0, tab->mA, true)
-        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw, out_stride, 0, 0, boff_out);
+        sink(a);
     }
+}
+
+template <int NS, int WPE, int SH, bool THR, typename IO = double, bool FP32A = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_treesc_f64(
+    const IO *__restrict__ xw, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride,
+    unsigned out_stride, WxLatW cw, const WxLatTreeSc *__restrict__ tab, WxThreshArg thr)
+{
+    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
+    __shared__ __attribute__((aligned(16))) double lds[2048];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    typedef typename std::conditional<FP32A, lat_f2v, double>::type V;
+    static_assert(!(FP32A && THR), "the threshold of denoise() rides on the Float64-register kernels");
+    constexpr bool PAIR = lat_vtraits<V>::pair != 0;
+    const bool lastw = PAIR && blockIdx.x == gridDim.x - 1;
+    const int sig0 = PAIR ? (lastw ? last_sig : (int)(blockIdx.x << (SH + 1))) : min((int)blockIdx.x << SH, last_sig);
+    const unsigned bsig = (unsigned)(lastw ? cw.tail_bsig : (1 << SH));
+    const unsigned boff_in = bsig * in_stride, boff_out = PAIR ? bsig * out_stride : 0xffffffffu;
+    IO *ys = y + (int64_t)sig0 * out_stride;
+    lat_treesc_inv<NS, SH, THR, IO, FP32A>(xw + (int64_t)sig0 * in_stride, sig0, lds0, lane, in_stride, col_stride, boff_in, bsig, cw, tab, thr,
+                                           [&](V (&regs)[64]) { lat_emit<(SH < 2 ? 0 : 2), 16 * SH>(regs, lds0, ys, lane, cw, out_stride, 0, 0, boff_out); });
 }
 #undef WX_SC_FWD
 #undef WX_SC_INV

@@ -326,7 +326,8 @@ int api_class_rows(int kind, const T *X, int64_t nk, int64_t N, const int32_t *c
     const int *dorder = (const int *)scr.upload(order.data(), order.size() * sizeof(int));
     LsClasses C;
     if (!dorder || !ls_upload(H, scr, &C)) return io.finish(WX_EHIP);
-    const size_t wbytes = ((size_t)TC * row_elems + (size_t)nc * TC) * sizeof(T);
+    // (a multiple of 16: block b's global-memory window starts at gwork + b * wbytes and is used as T / double arrays)
+    const size_t wbytes = ((((size_t)TC * row_elems + (size_t)nc * TC) * sizeof(T)) + 15) & ~(size_t)15;
     const int64_t ngroups = (nk + TC - 1) / TC;
     if (gm) {
         char *gwork = nullptr;
@@ -615,7 +616,7 @@ int api_pdf_map(const T *X, int64_t nk, int64_t N, const int32_t *cls, int nc, d
     int rc = ls_classes(cls, N, nc, &H, &order);
     if (rc) return rc;
     const LsAsh A = ls_ash_params(N);
-    const size_t wbytes = sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len + 16;
+    const size_t wbytes = (sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len + 16 + 15) & ~(size_t)15;   // 16-byte windows
     const bool gm = wbytes > 150 * 1024;                    // more than about 19000 signals: the values of a coefficient in a global window
     if ((rc = need_device())) return rc;
     hipStream_t st = wx_stream(stream);
@@ -655,7 +656,7 @@ int api_signature(int kind, const T *X, const T *Win, int64_t nk, int64_t N, int
     const LsAsh A = ls_ash_params(Ntot);
     int64_t rows = 0;
     for (int c = 0; c < nc; ++c) { WX_REQUIRE(kind == 1 || H.cnt[c] >= 2, WX_EARG, "a class needs two signals for its deviation"); rows += H.npad[c]; }
-    const size_t wbytes = (kind == 0 ? sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len : sizeof(T) * 2 * (size_t)rows) + 16;
+    const size_t wbytes = ((kind == 0 ? sizeof(double) * ((size_t)N + A.len) + sizeof(int) * (size_t)A.len : sizeof(T) * 2 * (size_t)rows) + 16 + 15) & ~(size_t)15;
     const bool gm = wbytes > 150 * 1024;
     if ((rc = need_device())) return rc;
     hipStream_t st = wx_stream(stream);
