@@ -47,3 +47,48 @@ def test_chip_filling_batch_on_the_device(wx):
     assert float(((ey - ex).abs() / ex).max()) <= 1e-12              # orthonormal, per signal
     back = wx.iwptall(y, wt, 13)
     assert float(((back - x).abs().amax(0) / x.abs().amax(0)).max()) <= 1e-12
+
+
+def _trees_8192(wx, rng):
+    from helpers import random_tree_1d
+    n = 8192
+    trees = {}
+    t = np.zeros(n - 1, dtype=bool); t[0] = True
+    trees["root only (two leaf children)"] = t
+    t = np.zeros(n - 1, dtype=bool); t[[0, 1]] = True
+    trees["approximation child split once, detail child a leaf"] = t
+    t = np.zeros(n - 1, dtype=bool); t[[0, 2, 6]] = True
+    trees["detail side only"] = t
+    trees["pyramid depth 13"] = wx.maketree(n, 13, "dwt")
+    trees["pyramid depth 5"] = wx.maketree(n, 5, "dwt")
+    trees["full depth 3"] = wx.maketree(n, 3, "full")
+    for i in range(4):
+        r = random_tree_1d(n, rng, p=0.8)
+        r[0] = True
+        trees["random %d" % i] = r
+    return trees
+
+
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db7", "coif6", "db10"])
+def test_trees_in_one_pass(wx, oracle, wname):
+    """wptall / iwptall of 8192-sample signals along a tree (wx_lattice_8kt.h): every child configuration of the root -- leaf / leaf, subtree /
+    leaf, leaf / subtree, subtree / subtree --, pyramids, random trees; forward against the oracle, inverse against the signal"""
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    rng = np.random.default_rng(8192 + len(wt.qmf))
+    x = np.asfortranarray(rng.standard_normal((8192, 3)))
+    for name, tree in _trees_8192(wx, rng).items():
+        exp = oracle.wptall(x, wt.qmf, tree)
+        y = wx.wptall(x, wt, tree)
+        assert relerr(y, exp) <= 1e-12, (wname, name)
+        assert relerr(wx.iwptall(exp, wt, tree), x) <= 1e-12, (wname, name)
+
+
+def test_pyramids_through_dwtall(wx, oracle):
+    wt = wx.wavelet(wx.WT.db4)
+    rng = np.random.default_rng(81)
+    x = np.asfortranarray(rng.standard_normal((8192, 5)))
+    for L in (1, 2, 6, 13):
+        tree = wx.maketree(8192, L, "dwt")
+        exp = oracle.wptall(x, wt.qmf, tree)
+        assert relerr(wx.dwtall(x, wt, L), exp) <= 1e-12, L
+        assert relerr(wx.idwtall(exp, wt, L), x) <= 1e-12, L

@@ -1799,6 +1799,18 @@ int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, con
             dsub = (const uint8_t *)wx_const_upload(hsub.data(), hsub.size(), st, true);
             if (!dsub) return WX_EHIP;
         }
+        // 8192-sample Float64 signals, inverse: ONE pass (wx_lattice_8kt.h) -- two wavefronts per signal, each rebuilds its child of the root
+        // (the masked tree kernel of its subtree, or a plain load of a leaf), the last synthesis level in direct form
+        if constexpr (sizeof(T) == 8) {
+            if (inverse && n == 8192 && Lp >= 1 && split(0, 0) && (const void *)x != (const void *)y) {
+                const uint8_t *ds[2] = {nullptr, nullptr};
+                int dp[2] = {0, 0};
+                for (size_t k = 0; k < sub_nodes.size(); ++k) { ds[sub_nodes[k]] = dsub + k * NS; dp[sub_nodes[k]] = sub_depth[k]; }
+                const int r = wx_lattice_tree8k_inv_f64((const double *)x, (double *)y, batch, filt, ds[0], dp[0], ds[1], dp[1], st);
+                if (r < 0) return r;
+                if (r == 1) return WX_OK;
+            }
+        }
         const int top = Lp < dl ? Lp : dl;
         if (wx_top_levels_ok(filt.F) && top >= 1 && top <= 4) {
             // all top levels in one pass through LDS (wx_toptile.h): leaves leave / enter at their own places, the 4096-sample nodes

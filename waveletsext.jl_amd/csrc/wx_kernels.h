@@ -167,6 +167,9 @@ int wx_lattice_tree_f32(bool inverse, const float *x, float *y, int64_t n, int L
                         const uint8_t *dstatus, int64_t nstatus, hipStream_t st, const WxThreshArg *thr = nullptr, int64_t out_stride = 0);
 bool wx_lattice_tree_applicable_f32(int64_t n, const WxFilt &filt);
 int wx_lattice_wpt_f64(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+// 8192-sample signals along a tree, inverse, in one pass (wx_lattice_8kt.h); child c is a leaf when dstatus_c is NULL
+int wx_lattice_tree8k_inv_f64(const double *x, double *y, int64_t batch, const WxFilt &filt, const uint8_t *dstatus0, int depth0,
+                              const uint8_t *dstatus1, int depth1, hipStream_t st);
 int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                         const WxFilt &filt, hipStream_t st);
 

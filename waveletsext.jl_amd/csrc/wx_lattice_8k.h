@@ -114,27 +114,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     lat_fwd_from_l0<NS>(r, lds0, lane, L1, cf, y + sig * 8192 + 4096 * child);
 }
 
-// ---- inverse ----
-template <int NS, int WPE>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt8k_f64(
-    const double *__restrict__ xw, double *__restrict__ y, int L1, int64_t batch, int64_t in_stride, WxLat cf, WxFilt filt)
+// the last synthesis level of an 8192-sample signal from its two children in the L0 arrangement (one per wavefront of the workgroup):
+// chunks of 512 child samples through the shared buffer xch, each wavefront writes half of the parent chunk (idwt_step!, direct form)
+template <int F>
+__device__ __forceinline__ void lat8k_synth(lat_d2 (&o)[32], double (&xch)[2][2][512 + 16], int child, int lane, double *__restrict__ ys,
+                                            const WxFilt &filt)
 {
-    constexpr int F = 2 * NS, HB = F / 2 - 1;                        // halo of a child chunk: a to the left, d to the right
-    constexpr int XB = 512 + 16;
-    __shared__ double lds2[2][WX_LAT_LDS];
-    __shared__ __attribute__((aligned(16))) double xch[2][2][XB];     // [chunk parity][child][HB + 512 (a) | 512 + HB (d)]
-    const int child = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds2[child];
-    const int64_t sig = blockIdx.x;
-    lat_d2 o[32];
-    lat_inv_to_l0<NS>(xw + sig * in_stride + 4096 * child, lds0, lane, L1, cf, [&](auto Fq, lat_d2 (&oo)[8]) {
-        constexpr int f = decltype(Fq)::value;
-        lat_for<8>([&](auto Hq) { o[4 * Hq + f] = oo[Hq]; });
-    });
+    constexpr int HB = F / 2 - 1;                                     // halo of a child chunk: a to the left, d to the right
     double q0[F];
 #pragma unroll
     for (int t = 0; t < F; ++t) q0[t] = filt.q[t];
-    double *ys = y + sig * 8192;
     const int g = lane >> 3, j = lane & 7;
     lat_for<8>([&](auto H3) {
         constexpr int hi3 = H3;
@@ -180,6 +169,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         }
         // the next chunk goes to the other buffer; the one after next waits for this chunk's readers at its own barrier
     });
+}
+
+// ---- inverse ----
+template <int NS, int WPE>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt8k_f64(
+    const double *__restrict__ xw, double *__restrict__ y, int L1, int64_t batch, int64_t in_stride, WxLat cf, WxFilt filt)
+{
+    __shared__ double lds2[2][WX_LAT_LDS];
+    __shared__ __attribute__((aligned(16))) double xch[2][2][512 + 16];   // [chunk parity][child][HB + 512 (a) | 512 + HB (d)]
+    const int child = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds2[child];
+    const int64_t sig = blockIdx.x;
+    lat_d2 o[32];
+    lat_inv_to_l0<NS>(xw + sig * in_stride + 4096 * child, lds0, lane, L1, cf, [&](auto Fq, lat_d2 (&oo)[8]) {
+        constexpr int f = decltype(Fq)::value;
+        lat_for<8>([&](auto Hq) { o[4 * Hq + f] = oo[Hq]; });
+    });
+    lat8k_synth<2 * NS>(o, xch, child, lane, y + sig * 8192, filt);
 }
 
 }  // namespace

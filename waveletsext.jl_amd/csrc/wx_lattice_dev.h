@@ -500,6 +500,54 @@ template <int L, typename TM> __device__ __forceinline__ void lat_load_c(double 
     });
 }
 
+// T1: L0 -> A (reg p[5:0], lane p[11:6]), round f = p[5:4]; and its inverse T1i (A -> L0)
+__device__ __forceinline__ void lat_t1(lat_d2 (&r)[32], double (&a)[64], unsigned lds0, int lane)
+{
+    const unsigned wa = lds0 + 8u * (17u * (lane >> 3) + 2u * (lane & 7)), ra = lds0 + 8u * 17u * lane;
+    lat_for<4>([&](auto Fq) {
+        constexpr int f = Fq;
+        lat_for<8>([&](auto Hq) {
+            constexpr int hi3 = Hq;
+            lds_wr<8 * (136 * hi3)>(wa, r[4 * hi3 + f].x);
+            lds_wr<8 * (136 * hi3 + 1)>(wa, r[4 * hi3 + f].y);
+        });
+        double t[16];
+        lat_for<16>([&](auto M) {
+            constexpr int m = M;
+            t[m] = lds_rd<8 * m>(ra);
+        });
+        lat_wait16<0>(t);
+        lat_for<16>([&](auto M) {
+            constexpr int m = M;
+            a[16 * f + m] = t[m];
+        });
+    });
+}
+template <typename SINK> __device__ __forceinline__ void lat_t1i(double (&a)[64], unsigned lds0, int lane, SINK &&sink)
+{
+    const unsigned wa = lds0 + 8u * 17u * lane, ra = lds0 + 8u * (17u * (lane >> 3) + 4u * (lane & 7));
+    lat_for<4>([&](auto Fq) {
+        constexpr int f = Fq;
+        lat_for<16>([&](auto M) {
+            constexpr int m = M;                     // m = 2 j + e
+            lds_wr<8 * (4 * (m >> 1) + 2 * (m & 1))>(wa, a[16 * f + m]);
+        });
+        double t[16];
+        lat_for<16>([&](auto M) {
+            constexpr int hi3 = M / 2, e = M % 2;
+            t[M] = lds_rd<8 * (136 * hi3 + 2 * e)>(ra);
+        });
+        lat_wait16<0>(t);
+        lat_d2 o[8];
+        lat_for<8>([&](auto Hq) {
+            constexpr int hi3 = Hq;
+            o[hi3].x = t[2 * hi3];
+            o[hi3].y = t[2 * hi3 + 1];
+        });
+        sink(Fq, o);
+    });
+}
+
 // ---------------------------------------------------------------- forward
 // the transform of one 4096-sample signal from its samples in the L0 arrangement (register 4 hi3 + f of a lane = the two samples
 // p, p + 1 with p[11:9] = hi3, p[8:6] = lane >> 3, p[5:4] = f, p[3:1] = lane & 7: what eight complete 128-byte lines per load give),
@@ -509,28 +557,7 @@ template <int NS, typename TM>
 __device__ __forceinline__ void lat_fwd_from_l0(lat_d2 (&r)[32], unsigned lds0, int lane, int L, const WxLat &cf, TM *__restrict__ ys)
 {
     double a[64];
-    {
-        // T1: L0 -> A (reg p[5:0], lane p[11:6]), round f
-        const unsigned wa = lds0 + 8u * (17u * (lane >> 3) + 2u * (lane & 7)), ra = lds0 + 8u * 17u * lane;
-        lat_for<4>([&](auto Fq) {
-            constexpr int f = Fq;
-            lat_for<8>([&](auto Hq) {
-                constexpr int hi3 = Hq;
-                lds_wr<8 * (136 * hi3)>(wa, r[4 * hi3 + f].x);
-                lds_wr<8 * (136 * hi3 + 1)>(wa, r[4 * hi3 + f].y);
-            });
-            double t[16];
-            lat_for<16>([&](auto M) {
-                constexpr int m = M;
-                t[m] = lds_rd<8 * m>(ra);
-            });
-            lat_wait16<0>(t);
-            lat_for<16>([&](auto M) {
-                constexpr int m = M;
-                a[16 * f + m] = t[m];
-            });
-        });
-    }
+    lat_t1(r, a, lds0, lane);
     lat_level<0, 6, NS, false>(a, cf);
     lat_level<1, 6, NS, false>(a, cf);
     // T2: A -> B (reg p[7:2], lane mu = p[11:8] | p[1:0] << 4)
@@ -1294,30 +1321,7 @@ __device__ __forceinline__ void lat_inv_to_l0(const TM *__restrict__ xs, unsigne
     }
     lat_level<1, 6, NS, true>(a, cf);
     lat_level<0, 6, NS, true>(a, cf);
-    // T1i: A -> L0, round f = p[5:4]
-    {
-        const unsigned wa = lds0 + 8u * 17u * lane, ra = lds0 + 8u * (17u * (lane >> 3) + 4u * (lane & 7));
-        lat_for<4>([&](auto Fq) {
-            constexpr int f = Fq;
-            lat_for<16>([&](auto M) {
-                constexpr int m = M;                     // m = 2 j + e
-                lds_wr<8 * (4 * (m >> 1) + 2 * (m & 1))>(wa, a[16 * f + m]);
-            });
-            double t[16];
-            lat_for<16>([&](auto M) {
-                constexpr int hi3 = M / 2, e = M % 2;
-                t[M] = lds_rd<8 * (136 * hi3 + 2 * e)>(ra);
-            });
-            lat_wait16<0>(t);
-            lat_d2 o[8];
-            lat_for<8>([&](auto Hq) {
-                constexpr int hi3 = Hq;
-                o[hi3].x = t[2 * hi3];
-                o[hi3].y = t[2 * hi3 + 1];
-            });
-            sink(Fq, o);
-        });
-    }
+    lat_t1i(a, lds0, lane, sink);
 }
 
 template <int NS, int WPE, typename TM = double>
