@@ -75,6 +75,11 @@ WORKLOADS = {
                          fwd_kernels=[("k_lat_wpt_sh_f64<4, 2, 2>", 1)],
                          desc="the target's byte count with 1024-sample signals: wptall+iwptall 262144x1024 f64 db4 L=9 "
                               "(four signals interleaved per wavefront, DESIGN 4.20)"),
+    "target_f32": dict(kind="wpt", n=4096, batch=131072, wavelet="db4", L=10, dtype="f32",
+                       kernel="k_lat_wpt_g_f64<4, 2, 0, float, true>", inv_kernel="k_lat_iwpt_g_f64<4, 2, 0, float, true>",
+                       fwd_kernels=[("k_lat_wpt_g_f64<4, 2, 0, float, true>", 1)],
+                       desc="the target's byte count in Float32: wptall+iwptall 131072x4096 f32 db4 L=10 -- Float32 arithmetic on pairs "
+                            "of signals (lat_f2v, DESIGN 4.8): a wavefront takes two signals, every rotation is one v_pk_fma_f32"),
     "target_haar": dict(kind="wpt", n=4096, batch=65536, wavelet="haar", L=10, dtype="f64",
                         kernel="k_lat_wpt_f64<1, 3, double>", inv_kernel="k_lat_iwpt_f64<1, 2, double>",
                         fwd_kernels=[("k_lat_wpt_f64<1, 3, double>", 1)],

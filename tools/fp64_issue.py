@@ -26,7 +26,7 @@ def main():
         run = f[len(root):].strip("/").split("/")[0].rsplit("_p", 1)[0]
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if not (k.startswith("k_lat") or "fma64" in k or "k_fma" in k):
+            if not (k.startswith("k_lat") or "fma64" in k or "k_fma" in k or k.startswith("k_acwpd")):
                 continue
             if run == "ubench":
                 k += " grid %s" % r["Grid_Size"]

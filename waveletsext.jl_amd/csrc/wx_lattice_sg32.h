@@ -12,14 +12,18 @@
 int WX_G32_FN(bool inverse, const float *x, float *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt, hipStream_t st)
 {
     constexpr int SH = WX_G32_SH;
-    // pairs of signals in Float32 arithmetic from 256 samples up; 64- and 128-sample signals keep Float64 registers (measured:
-    // 0.48 / 0.48 ms against 0.55 / 0.57 per GiB at n = 64, profiles/r05_floor.txt -- 64 signals x 2 per wavefront gain nothing there)
-    constexpr bool PAIRS = SH <= 4;
-    constexpr int64_t per = (int64_t)(PAIRS ? 2 : 1) << SH;  // signals per wavefront: two sets of 2^SH
+    // pairs of signals in Float32 arithmetic where the rotations dominate: from 256 samples up and from 7 levels on.  64- and 128-sample
+    // signals and shallow trees keep Float64 registers -- few levels are not bound by FP64 issue, and the pair form pays for its two
+    // 8-byte accesses per slot pair (measured per GiB: n = 64 0.48 / 0.48 ms against 0.55 / 0.57; n = 1024, L = 4 0.43 / 0.45 against
+    // 0.51-0.57; n = 1024, L = 10 0.61 / 0.62 against 0.54 / 0.55: profiles/r04_floor.txt, r05_floor.txt)
+    constexpr bool PAIRS_OK = SH <= 4;
+    const bool PAIRS = PAIRS_OK && L >= 7;
+    const int64_t per = (int64_t)(PAIRS ? 2 : 1) << SH;      // signals per wavefront: two sets of 2^SH
 #ifndef WX_G32_NSMAX
 #define WX_G32_NSMAX 4
 #endif
     if (n != (4096 >> SH) || L < 1 || L + SH < 6 || L + SH > 12 || filt.F < 2 || filt.F > 2 * WX_G32_NSMAX) return 0;
+    if (SH == 0 && !PAIRS) return 0;                         // 4096 samples, L = 6: the dedicated kernel of wx_lattice_f32.hip
     WxPairPlan pp;
     if (PAIRS) {
         if (!wx_lat_pair_plan(batch, SH, x == y, &pp)) return 0;   // a remainder below 2^SH signals re-does signals: out of place only
@@ -46,10 +50,14 @@ int WX_G32_FN(bool inverse, const float *x, float *y, int64_t n, int L, int64_t 
 #define WX_G32_WPE(NSS) 2
 #define WX_GOG(NSS)                                                                                                                  \
     case NSS:                                                                                                                        \
-        if (inverse)                                                                                                                 \
-            hipLaunchKernelGGL((k_lat_iwpt_g_f64<NSS, WX_G32_WPE(NSS), SH, float, PAIRS>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, (unsigned)in_stride, cw); \
+        if (PAIRS && inverse)                                                                                                        \
+            hipLaunchKernelGGL((k_lat_iwpt_g_f64<NSS, WX_G32_WPE(NSS), SH, float, PAIRS_OK>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, (unsigned)in_stride, cw); \
+        else if (PAIRS)                                                                                                              \
+            hipLaunchKernelGGL((k_lat_wpt_g_f64<NSS, WX_G32_WPE(NSS), SH, float, PAIRS_OK>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
+        else if (inverse)                                                                                                            \
+            hipLaunchKernelGGL((k_lat_iwpt_g_f64<NSS, 2, SH, float, false>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, (unsigned)in_stride, cw); \
         else                                                                                                                         \
-            hipLaunchKernelGGL((k_lat_wpt_g_f64<NSS, WX_G32_WPE(NSS), SH, float, PAIRS>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
+            hipLaunchKernelGGL((k_lat_wpt_g_f64<NSS, 2, SH, float, false>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, cw);     \
         break;
     switch (filt.F / 2) {
         WX_GOG(1) WX_GOG(2) WX_GOG(3) WX_GOG(4)
