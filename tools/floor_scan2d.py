@@ -55,4 +55,5 @@ def scan(wname="db4", sizes=(64, 128, 256, 512, 1024), out=None):
 
 
 if __name__ == "__main__":
-    scan(sys.argv[1] if len(sys.argv) > 1 else "db4")
+    # python tools/floor_scan2d.py [wavelet [side ...]]
+    scan(sys.argv[1] if len(sys.argv) > 1 else "db4", tuple(int(v) for v in sys.argv[2:]) or (64, 128, 256, 512, 1024))

@@ -145,6 +145,11 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
     const T *dx = (const T *)io.in(x, sizeof(T) * m * n * batch);
     T *dy = (T *)io.out(y, sizeof(T) * m * n * batch);
     if (batch && (!dx || !dy)) return io.finish(WX_EHIP);
+    // 64 x 64 images: the whole quad tree in the registers of one wavefront, one pass (wx_lattice_2d64.h)
+    if (tr.full && tr.Leff > 0 && !tail && m == 64 && n == 64 && batch && !wx_force_generic() && !wx_getenv("WX_NO_2D64")) {
+        const int r = wx_lattice_2d64(INVERSE, dx, dy, tr.Leff, batch, m * n, filt, st);
+        if (r) return io.finish(r < 0 ? r : WX_OK);
+    }
     T *tmp = nullptr, *pong = nullptr;
     if (batch && tr.Leff > 0) { tmp = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!tmp) return io.finish(WX_EHIP); }
     if (tr.full && tr.Leff > 0 && !wx_force_generic() && (wx_wpt2d_fast_ok<T>(m, n, F) || wx_lattice2d_ok(m, n, tr.Leff, filt, sizeof(T)))) {
@@ -192,6 +197,10 @@ static int api_iwpd2d(const T *xw, T *xh, int64_t m, int64_t n, int k, int L, co
     T *dxh = (T *)io.out(xh, sizeof(T) * mn * batch);
     if (batch && (!dxw || !dxh)) return io.finish(WX_EHIP);
     T *tmp = nullptr, *pong = nullptr, *leaves = nullptr;
+    if (tr.full && tr.Leff > 0 && m == 64 && n == 64 && batch && !wx_force_generic() && !wx_getenv("WX_NO_2D64")) {
+        const int r = wx_lattice_2d64(true, dxw + (int64_t)tr.Leff * mn, dxh, tr.Leff, batch, mn * k, filt, st);
+        if (r) return io.finish(r < 0 ? r : WX_OK);
+    }
     if (batch && tr.Leff > 0) { tmp = (T *)scr.alloc(sizeof(T) * mn * batch); if (!tmp) return io.finish(WX_EHIP); }
     if (tr.full && tr.Leff > 0 && !wx_force_generic() && (wx_wpt2d_fast_ok<T>(m, n, F) || wx_lattice2d_ok(m, n, tr.Leff, filt, sizeof(T)))) {
         rc = wx_dev_wpt2d_fast<T>(dxw + (int64_t)tr.Leff * mn, dxh, m, n, tr.Leff, batch, filt, tmp, true, mn * k, st);

@@ -514,6 +514,12 @@ template <typename T, bool INVERSE>
 static int wx_launch_rows(const T *src, T *dst, int64_t src_img, int64_t dst_img, int64_t m, int64_t n, int L,
                           int64_t batch, const WxFilt &filt, hipStream_t st)
 {
+    // images of 128, 256, 512 columns: the rows of a wavefront as interleaved signals of the lattice kernels (wx_lattice_rows.h)
+    static const bool latrows = !(wx_getenv("WX_LATROWS") && atoi(wx_getenv("WX_LATROWS")) == 0);
+    if (latrows && batch > 0) {
+        const int r = wx_lattice_rows(INVERSE, src, dst, src_img, dst_img, m, n, L, batch, filt, st);
+        if (r) return r < 0 ? r : WX_OK;
+    }
     int R, S;
     wx_rows_geometry<T>(n, R, S);
     size_t lds = (size_t)2 * n * S * sizeof(T);

@@ -176,6 +176,28 @@ int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t b
 // 512 x 512 Float32 images, depth 6: one transposing lattice pass (wx_lattice2d.hip); 0 = not applicable, 1 = launched
 bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz);
 int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t m, int L, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st);
+// row pass of a 2-D full tree on the lattice kernels (wx_lattice_rows.h, dispatch in wx_lattice_rows.hip): L levels along the rows of
+// (m, n) images; 0 = not applicable, 1 = launched, < 0 = error
+int wx_lattice_rows(bool inverse, const double *x, double *y, int64_t in_img, int64_t out_img, int64_t m, int64_t n, int L, int64_t batch,
+                    const WxFilt &filt, hipStream_t st);
+int wx_lattice_rows(bool inverse, const float *x, float *y, int64_t in_img, int64_t out_img, int64_t m, int64_t n, int L, int64_t batch,
+                    const WxFilt &filt, hipStream_t st);
+// 64 x 64 images, full quad tree of depth 1 .. 6 in ONE pass, an image per wavefront (wx_lattice_2d64.h); 0 = not applicable, 1 = launched.
+// in_img: elements between the images of the inverse's input (a slice of a packet table)
+int wx_lattice_2d64_fwd_f64(const double *x, double *y, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+int wx_lattice_2d64_fwd_f32(const float *x, float *y, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+int wx_lattice_2d64_inv_f64(const double *x, double *y, int L, int64_t batch, int64_t in_img, const WxFilt &filt, hipStream_t st);
+int wx_lattice_2d64_inv_f32(const float *x, float *y, int L, int64_t batch, int64_t in_img, const WxFilt &filt, hipStream_t st);
+static inline int wx_lattice_2d64(bool inverse, const double *x, double *y, int L, int64_t batch, int64_t in_img, const WxFilt &filt, hipStream_t st)
+{
+    if (inverse) return wx_lattice_2d64_inv_f64(x, y, L, batch, in_img, filt, st);
+    return in_img == 4096 ? wx_lattice_2d64_fwd_f64(x, y, L, batch, filt, st) : 0;
+}
+static inline int wx_lattice_2d64(bool inverse, const float *x, float *y, int L, int64_t batch, int64_t in_img, const WxFilt &filt, hipStream_t st)
+{
+    if (inverse) return wx_lattice_2d64_inv_f32(x, y, L, batch, in_img, filt, st);
+    return in_img == 4096 ? wx_lattice_2d64_fwd_f32(x, y, L, batch, filt, st) : 0;
+}
 
 // the deep levels of the pyramid in the registers of a lane (wx_dwttail.hip)
 int wx_dwt_tail_levels(int64_t n, int L, int F, size_t esz);

@@ -678,12 +678,26 @@ constexpr int lat_pbit(int lay, int reg, int bit)           // sample-index bit 
 // level code lc = l + 16 sh: sh low index bits are a signal number (2^sh signals of 4096 >> sh samples interleaved in the
 // registers, see k_lat_wpt_f64<.., SH>), the l levels acted on bits sh .. sh + l - 1: the signal number goes to the top of the
 // address, the path bits are reversed below it, the rest is the position inside the node
-constexpr int lat_lv(int lc) { return lc & 15; }
-constexpr int lat_sh(int lc) { return lc >> 4; }
-constexpr bool lat_on_path(int lc, int t) { return t >= lat_sh(lc) && t < lat_sh(lc) + lat_lv(lc); }   // t = -1: old code counted it; never occurs for k, i < 6
+// lc = 256 + l (wx_lattice_2d64.h): the 4096 slots are a 64 x 64 IMAGE (column-major: bits 0..5 the row, 6..11 the column) after l levels
+// down the columns (row bits 0 .. l-1) and l levels along the rows (column bits 0 .. l-1): each half of the address is routed like a
+// 64-sample signal of its own (path bits reversed on top of the position inside the node), 2 l gains on the way
+constexpr bool lat_is2d(int lc) { return lc >= 256 && lc < 512; }
+// lc = 512 + l + 16 sh (row pass of an image, k_lat_rows_g_f64): the 2^sh signals of the wavefront are adjacent ROWS -- the signal
+// number is the CONTIGUOUS dimension of the memory (address = o[sh-1:0] + (o >> sh) * column stride), the routed position of the
+// packet order lies above it
+constexpr bool lat_isT(int lc) { return lc >= 512; }
+constexpr int lat_lv(int lc) { return lat_is2d(lc) ? 2 * (lc & 15) : (lc & 15); }
+constexpr int lat_sh(int lc) { return lat_is2d(lc) ? 0 : ((lc & 255) >> 4); }
+constexpr int lat_sb(int lc) { return lat_isT(lc) ? lat_sh(lc) : 12 - lat_sh(lc); }   // address = o[sb-1:0] + (o >> sb) * sstride
+constexpr bool lat_on_path(int lc, int t)                  // t = -1: old code counted it; never occurs for k, i < 6
+{
+    return lat_is2d(lc) ? (t >= 0 && t % 6 < (lc & 15)) : (t >= lat_sh(lc) && t < lat_sh(lc) + lat_lv(lc));
+}
 constexpr int lat_obit(int lc, int t)
 {
     if (t < 0) return 12;                                    // "no such bit" (lat_pbit / lat_round_bit = -1): above the address
+    if (lat_is2d(lc)) return 6 * (t / 6) + (t % 6 < (lc & 15) ? 5 - t % 6 : t % 6 - (lc & 15));
+    if (lat_isT(lc)) return t < lat_sh(lc) ? t : (t < lat_sh(lc) + lat_lv(lc) ? 11 - t + lat_sh(lc) : t - lat_lv(lc));
     return t < lat_sh(lc) ? 12 - lat_sh(lc) + t : (t < lat_sh(lc) + lat_lv(lc) ? 11 - t : t - lat_sh(lc) - lat_lv(lc));
 }
 constexpr int lat_reg_o(int lay, int l, int i) { return lat_obit(l, lat_pbit(lay, 1, i)); }
@@ -795,7 +809,7 @@ __device__ __forceinline__ void lat_emit(V (&x)[64], unsigned lds0, IO *__restri
     const unsigned boff = bofs != 0xffffffffu ? bofs : (sstride << lat_sh(LVL));
     // sstride: elements between the columns of consecutive signals of the wavefront (interleaved kernels; the signal
     // number is the top lat_sh(LVL) bits of the routed address)
-    constexpr int SB = 12 - lat_sh(LVL);
+    constexpr int SB = lat_sb(LVL);
     // lane parts: line-address bits, in-line position bits, detail branches of the path
     int hi_lane = 0, pos_lane = 0;
     double b = cw.gl[lat_lv(LVL)];
@@ -878,7 +892,7 @@ struct LatThr {
 template <int LAY, int LVL>
 __device__ __forceinline__ unsigned lat_absorb_xo(int lane, unsigned sstride)
 {
-    constexpr int SB = 12 - lat_sh(LVL);
+    constexpr int SB = lat_sb(LVL);
     const int qq = lane >> 3;
     int o_lane = 2 * (lane & 7);
     lat_for<3>([&](auto Qc) {
@@ -894,7 +908,7 @@ template <int LAY, int LVL, int RN, typename IO = double, typename V = double>
 __device__ __forceinline__ void lat_absorb_fetch(lat_v2<V> (&v)[16], const IO *__restrict__ xcol, unsigned xo, unsigned sstride, unsigned word,
                                                  const unsigned *dep = nullptr, unsigned cstride = 0)
 {
-    constexpr int SB = 12 - lat_sh(LVL);
+    constexpr int SB = lat_sb(LVL);
     lat_for<8>([&](auto I) {
         constexpr int i = I;
         constexpr int oc = lat_emit_o_round(LAY, LVL, RN) + lat_emit_o_instr(LAY, LVL, i);
@@ -923,7 +937,7 @@ __device__ __forceinline__ void lat_absorb(V (&x)[64], unsigned lds0, const IO *
     typedef typename lat_vtraits<V>::coef CF;
     const unsigned boff = bofs != 0xffffffffu ? bofs : (sstride << lat_sh(LVL));   // V = lat_f2v: where the second signal set starts
     static_assert(PRE == PRED, "prefetched lines come with the predicated form");
-    constexpr int SB = 12 - lat_sh(LVL);
+    constexpr int SB = lat_sb(LVL);
     int hi_lane = 0, pos_lane = 0;
     double b = cw.gl[lat_lv(LVL)];
     lat_for<6>([&](auto Kc) {
@@ -1579,6 +1593,53 @@ template <typename V> __device__ __forceinline__ void lat_t2i(V (&bb)[64], V (&a
 // (IO = float: Float32 signals -- the loads widen, the stores round once, as in k_lat_wpt_f64<NS, WPE, float>)
 // (F32A = false with IO = float: Float32 in memory, Float64 in the registers, one signal set per wavefront -- the round-4 form, kept for
 // the 64- and 128-sample kernels where the pair form measured slower: profiles/r05_floor.txt)
+// the body of the interleaved forward kernels: the wavefront's 2^SH signals (two sets for V = lat_f2v) at xs -> ys.  TC = 0: signals one
+// after the other, 4096 >> SH elements apart (ss_in = ss_out); TC = 512: adjacent ROWS of an image, ss = its column stride (lat_isT)
+template <int NS, int SH, int TC, typename IO, typename V, typename CFT>
+__device__ __forceinline__ void lat_g_fwd(const IO *__restrict__ xs, IO *__restrict__ ys, int L, unsigned lds0, int lane, const WxLatW &cw,
+                                          const CFT &cf, unsigned ss_in, unsigned ss_out, unsigned bofs_in, unsigned bofs)
+{
+    V c[64];
+    if constexpr (SH < 2) {
+        V a[64], bb[64];
+        lat_absorb<0, TC + 16 * SH>(a, lds0, xs, lane, cw, ss_in, 0, 0, 0, bofs_in);
+        if constexpr (SH < 1) lat_level<0, 6, NS, false>(a, cf);
+        lat_level<1, 6, NS, false>(a, cf);
+        lat_t2(a, bb, lds0, lane);
+        lat_level<0, 4, NS, false>(bb, cf);
+        lat_level<1, 4, NS, false>(bb, cf);
+        lat_level<2, 4, NS, false>(bb, cf);
+        lat_level<3, 4, NS, false>(bb, cf);
+        lat_t3(bb, c, lds0, lane);
+    } else if constexpr (SH < 6) {
+        V bb[64];
+        lat_absorb<2, TC + 16 * SH>(bb, lds0, xs, lane, cw, ss_in, 0, 0, 0, bofs_in);
+        if constexpr (SH <= 2) lat_level<0, 4, NS, false>(bb, cf);
+        if constexpr (SH <= 3) lat_level<1, 4, NS, false>(bb, cf);
+        if constexpr (SH <= 4) lat_level<2, 4, NS, false>(bb, cf);
+        lat_level<3, 4, NS, false>(bb, cf);
+        lat_t3(bb, c, lds0, lane);
+    } else {
+        lat_absorb<6, TC + 16 * SH>(c, lds0, xs, lane, cw, ss_in, 0, 0, 0, bofs_in);
+    }
+    const int Le = L + SH;
+    if (Le > 6) lat_level<0, 0, NS, false>(c, cf);
+    if (Le > 7) lat_level<1, 0, NS, false>(c, cf);
+    if (Le > 8) lat_level<2, 0, NS, false>(c, cf);
+    if (Le > 9) lat_level<3, 0, NS, false>(c, cf);
+    if (Le > 10) lat_level<4, 0, NS, false>(c, cf);
+    if (Le > 11) lat_level<5, 0, NS, false>(c, cf);
+    switch (Le) {
+    case 6: if constexpr (SH < 6) lat_emit<6, TC + 6 - SH + 16 * SH>(c, lds0, ys, lane, cw, ss_out, 0, 0, bofs); break;
+    case 7: lat_emit<6, TC + 7 - SH + 16 * SH>(c, lds0, ys, lane, cw, ss_out, 0, 0, bofs); break;
+    case 8: lat_emit<6, TC + 8 - SH + 16 * SH>(c, lds0, ys, lane, cw, ss_out, 0, 0, bofs); break;
+    case 9: lat_emit<6, TC + 9 - SH + 16 * SH>(c, lds0, ys, lane, cw, ss_out, 0, 0, bofs); break;
+    case 10: lat_emit<6, TC + 10 - SH + 16 * SH>(c, lds0, ys, lane, cw, ss_out, 0, 0, bofs); break;
+    case 11: lat_emit<6, TC + 11 - SH + 16 * SH>(c, lds0, ys, lane, cw, ss_out, 0, 0, bofs); break;
+    default: lat_emit<6, TC + 12 - SH + 16 * SH>(c, lds0, ys, lane, cw, ss_out, 0, 0, bofs); break;
+    }
+}
+
 template <int NS, int WPE, int SH, typename IO = double, bool F32A = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpt_g_f64(
     const IO *__restrict__ x, IO *__restrict__ y, int L, int last_sig, WxLatW cw)
@@ -1595,51 +1656,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const int sig0 = PAIR ? (lastw ? last_sig : (int)(blockIdx.x << (SH + 1))) : min((int)blockIdx.x << SH, last_sig);
     const unsigned bofs = PAIR ? (unsigned)(lastw ? cw.tail_bsig : (1 << SH)) * (4096u >> SH) : 0xffffffffu;
     const int64_t off = (int64_t)sig0 * (4096 >> SH);
-    const IO *xs = x + off;
-    IO *ys = y + off;
     const typename std::conditional<PAIR, WxLatF, const WxLat &>::type cf = lat_cfsel<NS, PAIR>(cw.c);
-    V c[64];
-    if constexpr (SH < 2) {
-        V a[64], bb[64];
-        lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw, 4096u >> SH, 0, 0, 0, bofs);
-        if constexpr (SH < 1) lat_level<0, 6, NS, false>(a, cf);
-        lat_level<1, 6, NS, false>(a, cf);
-        lat_t2(a, bb, lds0, lane);
-        lat_level<0, 4, NS, false>(bb, cf);
-        lat_level<1, 4, NS, false>(bb, cf);
-        lat_level<2, 4, NS, false>(bb, cf);
-        lat_level<3, 4, NS, false>(bb, cf);
-        lat_t3(bb, c, lds0, lane);
-    } else if constexpr (SH < 6) {
-        V bb[64];
-        lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw, 4096u >> SH, 0, 0, 0, bofs);
-        if constexpr (SH <= 2) lat_level<0, 4, NS, false>(bb, cf);
-        if constexpr (SH <= 3) lat_level<1, 4, NS, false>(bb, cf);
-        if constexpr (SH <= 4) lat_level<2, 4, NS, false>(bb, cf);
-        lat_level<3, 4, NS, false>(bb, cf);
-        lat_t3(bb, c, lds0, lane);
-    } else {
-        lat_absorb<6, 16 * SH>(c, lds0, xs, lane, cw, 4096u >> SH, 0, 0, 0, bofs);
-    }
-    const int Le = L + SH;
-    if (Le > 6) lat_level<0, 0, NS, false>(c, cf);
-    if (Le > 7) lat_level<1, 0, NS, false>(c, cf);
-    if (Le > 8) lat_level<2, 0, NS, false>(c, cf);
-    if (Le > 9) lat_level<3, 0, NS, false>(c, cf);
-    if (Le > 10) lat_level<4, 0, NS, false>(c, cf);
-    if (Le > 11) lat_level<5, 0, NS, false>(c, cf);
-    switch (Le) {
-    case 6: if constexpr (SH < 6) lat_emit<6, 6 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
-    case 7: lat_emit<6, 7 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
-    case 8: lat_emit<6, 8 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
-    case 9: lat_emit<6, 9 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
-    case 10: lat_emit<6, 10 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
-    case 11: lat_emit<6, 11 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
-    default: lat_emit<6, 12 - SH + 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs); break;
-    }
+    lat_g_fwd<NS, SH, 0, IO, V>(x + off, y + off, L, lds0, lane, cw, cf, 4096u >> SH, 4096u >> SH, bofs, bofs);
 }
 
 // inverse wpt: leaves of signal s at xw + s in_stride (dense array or the last column of packet tables)
+template <int NS, int SH, int TC, typename IO, typename V, typename CFT>
+__device__ __forceinline__ void lat_g_inv(const IO *__restrict__ xs, IO *__restrict__ ys, int L, unsigned lds0, int lane, const WxLatW &cw,
+                                          const CFT &cf, unsigned ss_in, unsigned ss_out, unsigned bofs_in, unsigned bofs)
+{
+    const int Le = L + SH;
+    V c[64];
+    switch (Le) {
+    case 6: if constexpr (SH < 6) lat_absorb<6, TC + 6 - SH + 16 * SH>(c, lds0, xs, lane, cw, ss_in, 0, 0, 0, bofs_in); break;
+    case 7: lat_absorb<6, TC + 7 - SH + 16 * SH>(c, lds0, xs, lane, cw, ss_in, 0, 0, 0, bofs_in); break;
+    case 8: lat_absorb<6, TC + 8 - SH + 16 * SH>(c, lds0, xs, lane, cw, ss_in, 0, 0, 0, bofs_in); break;
+    case 9: lat_absorb<6, TC + 9 - SH + 16 * SH>(c, lds0, xs, lane, cw, ss_in, 0, 0, 0, bofs_in); break;
+    case 10: lat_absorb<6, TC + 10 - SH + 16 * SH>(c, lds0, xs, lane, cw, ss_in, 0, 0, 0, bofs_in); break;
+    case 11: lat_absorb<6, TC + 11 - SH + 16 * SH>(c, lds0, xs, lane, cw, ss_in, 0, 0, 0, bofs_in); break;
+    default: lat_absorb<6, TC + 12 - SH + 16 * SH>(c, lds0, xs, lane, cw, ss_in, 0, 0, 0, bofs_in); break;
+    }
+    if (Le > 11) lat_level<5, 0, NS, true>(c, cf);
+    if (Le > 10) lat_level<4, 0, NS, true>(c, cf);
+    if (Le > 9) lat_level<3, 0, NS, true>(c, cf);
+    if (Le > 8) lat_level<2, 0, NS, true>(c, cf);
+    if (Le > 7) lat_level<1, 0, NS, true>(c, cf);
+    if (Le > 6) lat_level<0, 0, NS, true>(c, cf);
+    if constexpr (SH >= 6) {
+        lat_emit<6, TC + 16 * SH>(c, lds0, ys, lane, cw, ss_out, 0, 0, bofs);
+    } else {
+        V bb[64];
+        lat_t3i(c, bb, lds0, lane);
+        lat_level<3, 4, NS, true>(bb, cf);
+        if constexpr (SH <= 4) lat_level<2, 4, NS, true>(bb, cf);
+        if constexpr (SH <= 3) lat_level<1, 4, NS, true>(bb, cf);
+        if constexpr (SH <= 2) lat_level<0, 4, NS, true>(bb, cf);
+        if constexpr (SH >= 2) {
+            lat_emit<2, TC + 16 * SH>(bb, lds0, ys, lane, cw, ss_out, 0, 0, bofs);
+        } else {
+            V a[64];
+            lat_t2i(bb, a, lds0, lane);
+            lat_level<1, 6, NS, true>(a, cf);
+            if constexpr (SH < 1) lat_level<0, 6, NS, true>(a, cf);
+            lat_emit<0, TC + 16 * SH>(a, lds0, ys, lane, cw, ss_out, 0, 0, bofs);
+        }
+    }
+}
+
 template <int NS, int WPE, int SH, typename IO = double, bool F32A = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_iwpt_g_f64(
     const IO *__restrict__ xw, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, WxLatW cw)
@@ -1656,42 +1719,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const IO *xs = xw + (int64_t)sig0 * in_stride;
     IO *ys = y + (int64_t)sig0 * (4096 >> SH);
     const typename std::conditional<PAIR, WxLatF, const WxLat &>::type cf = lat_cfsel<NS, PAIR>(cw.c);
-    const int Le = L + SH;
-    V c[64];
-    switch (Le) {
-    case 6: if constexpr (SH < 6) lat_absorb<6, 6 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
-    case 7: lat_absorb<6, 7 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
-    case 8: lat_absorb<6, 8 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
-    case 9: lat_absorb<6, 9 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
-    case 10: lat_absorb<6, 10 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
-    case 11: lat_absorb<6, 11 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
-    default: lat_absorb<6, 12 - SH + 16 * SH>(c, lds0, xs, lane, cw, in_stride, 0, 0, 0, bofs_in); break;
-    }
-    if (Le > 11) lat_level<5, 0, NS, true>(c, cf);
-    if (Le > 10) lat_level<4, 0, NS, true>(c, cf);
-    if (Le > 9) lat_level<3, 0, NS, true>(c, cf);
-    if (Le > 8) lat_level<2, 0, NS, true>(c, cf);
-    if (Le > 7) lat_level<1, 0, NS, true>(c, cf);
-    if (Le > 6) lat_level<0, 0, NS, true>(c, cf);
-    if constexpr (SH >= 6) {
-        lat_emit<6, 16 * SH>(c, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs);
-    } else {
-        V bb[64];
-        lat_t3i(c, bb, lds0, lane);
-        lat_level<3, 4, NS, true>(bb, cf);
-        if constexpr (SH <= 4) lat_level<2, 4, NS, true>(bb, cf);
-        if constexpr (SH <= 3) lat_level<1, 4, NS, true>(bb, cf);
-        if constexpr (SH <= 2) lat_level<0, 4, NS, true>(bb, cf);
-        if constexpr (SH >= 2) {
-            lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs);
-        } else {
-            V a[64];
-            lat_t2i(bb, a, lds0, lane);
-            lat_level<1, 6, NS, true>(a, cf);
-            if constexpr (SH < 1) lat_level<0, 6, NS, true>(a, cf);
-            lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw, 4096u >> SH, 0, 0, bofs);
-        }
-    }
+    lat_g_inv<NS, SH, 0, IO, V>(xs, ys, L, lds0, lane, cw, cf, in_stride, 4096u >> SH, bofs_in, bofs);
 }
 
 // wpd: y is (n, L+1, batch), every level leaves through lat_emit into the table of its signal (L >= 1, L + SH <= 12)
