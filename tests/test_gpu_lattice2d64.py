@@ -88,7 +88,7 @@ def test_row_pass_on_the_lattice_kernels(wx, oracle, dt, shape):
         assert relerr(wx.iwptall(c, wt, L)[:, :, 0], refi) <= _tol(dt) * 2, (shape, L)
 
 
-@pytest.mark.parametrize("name", ["haar", "db2", "db3", "coif2"])
+@pytest.mark.parametrize("name", ["haar", "db2", "db3", "coif2", "db7", "db8", "db10"])
 def test_row_pass_filters(wx, oracle, name):
     rng = np.random.default_rng(5)
     wt = wx.wavelet(getattr(wx.WT, name))

@@ -137,7 +137,10 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
         is_pyr = Ld >= 1;
         for (int64_t i = 1; i <= ntree && is_pyr; ++i) is_pyr = (tree[i - 1] != 0) == ((i & (i - 1)) == 0 && i < ((int64_t)1 << Ld));
     }
-    const bool small_pyr = is_pyr && !wx_force_generic() && wx_small_tree_wanted<T>(n, F, true, true);
+    // 64 .. 512 samples along a tree: the masked lattice kernels take the whole tree (wx_lattice_tree_s.h), pyramids included -- no tail cut
+    const bool lat_short = tree && !wx_force_generic() && !wx_skip_register_kernels() && n >= 64 && n <= 512 && batch >= 4096 / n && x != y &&
+                           (sizeof(T) == 8 ? wx_lattice_tree_applicable_f64(n, filt) : wx_lattice_tree_applicable_f32(n, filt));
+    const bool small_pyr = is_pyr && !wx_force_generic() && (lat_short || wx_small_tree_wanted<T>(n, F, true, true));
     const int tail = small_pyr ? 0 : wx_pyramid_tail<T>(n, F, INVERSE, tree, ntree, ttree, filt, true);
     if (tail) tree = ttree.data();
     if ((rc = wx_resolve_tree1d(n, L, tree, ntree, scr, &tr, "wpt"))) return rc;
@@ -159,6 +162,16 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
             const int r = wx_lattice_f32(INVERSE, (const float *)dx, (float *)dy, n, tr.Leff, batch, n, filt, st);
             if (r) return io.finish(r < 0 ? r : WX_OK);
         }
+    }
+    // short signals along a tree (pyramids, best bases, ...): 8 .. 64 signals in the registers of a wavefront, every level under the tree's
+    // masks (wx_lattice_tree_s.h); longer filters and odd geometries go on to the kernels below
+    if ((small || lat_short) && !tail && !tr.full && tr.dstatus && tr.Leff >= 1 && batch && dx != dy && !wx_skip_register_kernels()) {
+        int r;
+        if constexpr (sizeof(T) == 8)
+            r = wx_lattice_tree_f64(INVERSE, (const double *)dx, (double *)dy, n, tr.Leff, batch, n, 0, filt, tr.dstatus, tr.nstatus, st, nullptr, 0);
+        else
+            r = wx_lattice_tree_f32(INVERSE, (const float *)dx, (float *)dy, n, tr.Leff, batch, n, filt, tr.dstatus, tr.nstatus, st, nullptr, 0);
+        if (r) return io.finish(r < 0 ? r : WX_OK);
     }
     if (small && tr.Leff >= 1 && batch && dx != dy) {
         static const bool lane_off = wx_getenv("WX_LANETREE") && atoi(wx_getenv("WX_LANETREE")) == 0;

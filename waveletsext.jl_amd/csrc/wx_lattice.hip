@@ -230,11 +230,34 @@ int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t b
 WX_TREE_DECL(0f) WX_TREE_DECL(0i) WX_TREE_DECL(1f) WX_TREE_DECL(1i) WX_TREE_DECL(2f) WX_TREE_DECL(2i)
 #undef WX_TREE_DECL
 
+// short signals (512 .. 64 samples, wx_lattice_tree_s.h): filters up to 8 taps, no threshold riding on the loads
+#define WX_TREES_DECL(k)                                                                                                             \
+    int wx_lattice_trees_##k##_f64(const double *, double *, int64_t, int, int64_t, int64_t, int64_t, const WxFilt &, const uint8_t *, int64_t, hipStream_t, int64_t); \
+    int wx_lattice_trees_##k##_f32(const float *, float *, int64_t, int, int64_t, int64_t, int64_t, const WxFilt &, const uint8_t *, int64_t, hipStream_t, int64_t);
+WX_TREES_DECL(3f) WX_TREES_DECL(3i) WX_TREES_DECL(4f) WX_TREES_DECL(4i) WX_TREES_DECL(5f) WX_TREES_DECL(5i) WX_TREES_DECL(6f) WX_TREES_DECL(6i)
+#undef WX_TREES_DECL
+static bool wx_lattice_trees_short(int64_t n, const WxFilt &filt)
+{
+    static const bool off = wx_getenv("WX_LATTICE_TREES") && atoi(wx_getenv("WX_LATTICE_TREES")) == 0;
+    return !off && (n == 512 || n == 256 || n == 128 || n == 64) && filt.F <= 8;
+}
+#define WX_TREES_GO(TS)                                                                                                              \
+    switch (n) {                                                                                                                     \
+    case 512: return inverse ? wx_lattice_trees_3i_##TS(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride) \
+                             : wx_lattice_trees_3f_##TS(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride); \
+    case 256: return inverse ? wx_lattice_trees_4i_##TS(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride) \
+                             : wx_lattice_trees_4f_##TS(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride); \
+    case 128: return inverse ? wx_lattice_trees_5i_##TS(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride) \
+                             : wx_lattice_trees_5f_##TS(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride); \
+    default: return inverse ? wx_lattice_trees_6i_##TS(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride) \
+                            : wx_lattice_trees_6f_##TS(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride); \
+    }
+
 bool wx_lattice_tree_applicable_f64(int64_t n, const WxFilt &filt)
 {
     static const bool off = (wx_getenv("WX_LATTICE") && atoi(wx_getenv("WX_LATTICE")) == 0) ||
                             (wx_getenv("WX_LATTICE_TREE") && atoi(wx_getenv("WX_LATTICE_TREE")) == 0);
-    return !off && (n == 4096 || n == 2048 || n == 1024) && wx_lattice_applicable_f64(filt);
+    return !off && (n == 4096 || n == 2048 || n == 1024 || wx_lattice_trees_short(n, filt)) && wx_lattice_applicable_f64(filt);
 }
 
 int wx_lattice_tree_f64(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
@@ -242,6 +265,10 @@ int wx_lattice_tree_f64(bool inverse, const double *x, double *y, int64_t n, int
                         const WxThreshArg *thr, int64_t out_stride)
 {
     if (!wx_lattice_tree_applicable_f64(n, filt)) return 0;
+    if (n <= 512) {
+        if (thr && (thr->t || thr->head)) return 0;
+        WX_TREES_GO(f64)
+    }
 #define WX_TREE_GO(k) (inverse ? wx_lattice_tree##k##i_f64(inverse, x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, thr, st, out_stride) \
                                : wx_lattice_tree##k##f_f64(inverse, x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, thr, st, out_stride))
     if (n == 4096) return WX_TREE_GO(0);
@@ -264,6 +291,11 @@ int wx_lattice_tree_f32(bool inverse, const float *x, float *y, int64_t n, int L
                         const uint8_t *dstatus, int64_t nstatus, hipStream_t st, const WxThreshArg *thr, int64_t out_stride)
 {
     if (!wx_lattice_tree_applicable_f32(n, filt)) return 0;
+    if (n <= 512) {
+        if (thr && (thr->t || thr->head)) return 0;
+        const int64_t col_stride = 0;
+        WX_TREES_GO(f32)
+    }
 #define WX_TREE_GO(k) (inverse ? wx_lattice_tree32_##k##i(inverse, x, y, n, L, batch, in_stride, filt, dstatus, nstatus, thr, st, out_stride) \
                                : wx_lattice_tree32_##k##f(inverse, x, y, n, L, batch, in_stride, filt, dstatus, nstatus, thr, st, out_stride))
     if (n == 4096) return WX_TREE_GO(0);

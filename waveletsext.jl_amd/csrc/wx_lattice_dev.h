@@ -681,11 +681,13 @@ constexpr int lat_pbit(int lay, int reg, int bit)           // sample-index bit 
 // lc = 256 + l (wx_lattice_2d64.h): the 4096 slots are a 64 x 64 IMAGE (column-major: bits 0..5 the row, 6..11 the column) after l levels
 // down the columns (row bits 0 .. l-1) and l levels along the rows (column bits 0 .. l-1): each half of the address is routed like a
 // 64-sample signal of its own (path bits reversed on top of the position inside the node), 2 l gains on the way
-constexpr bool lat_is2d(int lc) { return lc >= 256 && lc < 512; }
+// + 1024 (LAT_ORD32, set by lat_emit / lat_absorb for 4-byte elements): another choice of the round bits, see lat_round_bit
+constexpr int LAT_ORD32 = 1024;
+constexpr bool lat_is2d(int lc) { return (lc & 1023) >= 256 && (lc & 1023) < 512; }
 // lc = 512 + l + 16 sh (row pass of an image, k_lat_rows_g_f64): the 2^sh signals of the wavefront are adjacent ROWS -- the signal
 // number is the CONTIGUOUS dimension of the memory (address = o[sh-1:0] + (o >> sh) * column stride), the routed position of the
 // packet order lies above it
-constexpr bool lat_isT(int lc) { return lc >= 512; }
+constexpr bool lat_isT(int lc) { return (lc & 1023) >= 512; }
 constexpr int lat_lv(int lc) { return lat_is2d(lc) ? 2 * (lc & 15) : (lc & 15); }
 constexpr int lat_sh(int lc) { return lat_is2d(lc) ? 0 : ((lc & 255) >> 4); }
 constexpr int lat_sb(int lc) { return lat_isT(lc) ? lat_sh(lc) : 12 - lat_sh(lc); }   // address = o[sb-1:0] + (o >> sb) * sstride
@@ -702,9 +704,24 @@ constexpr int lat_obit(int lc, int t)
 }
 constexpr int lat_reg_o(int lay, int l, int i) { return lat_obit(l, lat_pbit(lay, 1, i)); }
 constexpr int lat_lane_o(int lay, int l, int k) { return lat_obit(l, lat_pbit(lay, 0, k)); }
-// the j-th (j = 0, 1) register bit fixed per round: the lowest register bits that land on a line-address bit
+// the j-th (j = 0, 1) register bit fixed per round: the lowest register bits that land on a line-address bit.
+// LAT_ORD32 (4-byte elements: a 16-element line is HALF a 128-byte memory line): the register bits that land on the HIGHEST address bits
+// instead, so that address bit 4 -- the two halves of a memory line -- is not a round bit when there is a choice: the halves are then moved
+// by the same or by neighbouring instructions instead of by different rounds.  (PMC, 131072 x 4096 Float32, L = 10: the pair kernels
+// fetched 1.67 x and wrote 1.21 x their bytes, profiles/r05_target_f32.md -- every line came or went as two halves a round apart.)
 constexpr int lat_round_bit(int lay, int l, int j)
 {
+    if (l & LAT_ORD32) {
+        int b0 = -1, b1 = -1;                                // b0: the largest o, b1: the second largest
+        for (int i = 0; i < 6; ++i) {
+            const int o = lat_reg_o(lay, l, i);
+            if (o < 4) continue;
+            if (b0 < 0 || o > lat_reg_o(lay, l, b0)) { b1 = b0; b0 = i; }
+            else if (b1 < 0 || o > lat_reg_o(lay, l, b1)) b1 = i;
+        }
+        const int lo = b0 < b1 ? b0 : b1, hi = b0 < b1 ? b1 : b0;
+        return j == 0 ? lo : hi;
+    }
     int c = 0;
     for (int i = 0; i < 6; ++i)
         if (lat_reg_o(lay, l, i) >= 4) { if (c == j) return i; ++c; }
@@ -804,24 +821,25 @@ __device__ __forceinline__ void lat_emit(V (&x)[64], unsigned lds0, IO *__restri
                                          unsigned sstride = 4096u >> lat_sh(LVL), unsigned word = 0, unsigned anyw = 0,
                                          unsigned bofs = 0xffffffffu)
 {
+    constexpr int LV = (sizeof(IO) == 4 && !PRED) ? (LVL | LAT_ORD32) : LVL;   // 4-byte elements: the round bits of lat_round_bit's second rule
     typedef typename lat_vtraits<V>::coef CF;
     // V = lat_f2v: the second signal set of the wavefront follows the first at 2^sh signals' distance (bofs elements when given)
-    const unsigned boff = bofs != 0xffffffffu ? bofs : (sstride << lat_sh(LVL));
+    const unsigned boff = bofs != 0xffffffffu ? bofs : (sstride << lat_sh(LV));
     // sstride: elements between the columns of consecutive signals of the wavefront (interleaved kernels; the signal
-    // number is the top lat_sh(LVL) bits of the routed address)
-    constexpr int SB = lat_sb(LVL);
+    // number is the top lat_sh(LV) bits of the routed address)
+    constexpr int SB = lat_sb(LV);
     // lane parts: line-address bits, in-line position bits, detail branches of the path
     int hi_lane = 0, pos_lane = 0;
-    double b = cw.gl[lat_lv(LVL)];
+    double b = cw.gl[lat_lv(LV)];
     lat_for<6>([&](auto Kc) {
         constexpr int k = Kc;
-        constexpr int ob = lat_lane_o(LAY, LVL, k);
+        constexpr int ob = lat_lane_o(LAY, LV, k);
         if constexpr (ob < 4) pos_lane |= ((lane >> k) & 1) << ob;
-        if constexpr (lat_on_path(LVL, lat_pbit(LAY, 0, k))) b = ((lane >> k) & 1) ? b * cw.c.g2 : b;
+        if constexpr (lat_on_path(LV, lat_pbit(LAY, 0, k))) b = ((lane >> k) & 1) ? b * cw.c.g2 : b;
     });
     lat_for<6>([&](auto Qc) {
         constexpr int q = Qc;
-        constexpr LatLine ln = lat_line(LAY, LVL, q);
+        constexpr LatLine ln = lat_line(LAY, LV, q);
         if constexpr (ln.reg == 0) hi_lane |= ((lane >> ln.bit) & 1) << q;
     });
     double gfd[7];
@@ -837,7 +855,7 @@ __device__ __forceinline__ void lat_emit(V (&x)[64], unsigned lds0, IO *__restri
     int o_lane = 2 * (lane & 7);
     lat_for<3>([&](auto Qc) {
         constexpr int q = Qc;
-        constexpr int ob = lat_line(LAY, LVL, q).ob;           // forced constant evaluation: left to the optimiser the
+        constexpr int ob = lat_line(LAY, LV, q).ob;           // forced constant evaluation: left to the optimiser the
         o_lane |= ((qq >> q) & 1) << ob;                          // bit-map loops are not always folded
     });
     const unsigned ra = lds0 + 8u * (unsigned)(17 * qq + 2 * (lane & 7));
@@ -846,9 +864,9 @@ __device__ __forceinline__ void lat_emit(V (&x)[64], unsigned lds0, IO *__restri
         constexpr int rho = Rc;
         if (PRED && ((anyw >> (8 * rho)) & 0xffu) == 0) return;
         lat_for<16>([&](auto Vc) {
-            constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
-            constexpr int pc = lat_emit_pc_reg(LAY, LVL, r);
-            lds_wr<8 * lat_emit_slot_reg(LAY, LVL, r)>(wa, lat_mul(x[r], gf[pc]));
+            constexpr int r = lat_emit_reg(LAY, LV, rho, Vc);
+            constexpr int pc = lat_emit_pc_reg(LAY, LV, r);
+            lds_wr<8 * lat_emit_slot_reg(LAY, LV, r)>(wa, lat_mul(x[r], gf[pc]));
         });
         lat_for<2>([&](auto HH) {
             constexpr int hh = HH;
@@ -862,7 +880,7 @@ __device__ __forceinline__ void lat_emit(V (&x)[64], unsigned lds0, IO *__restri
             lat_wait8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
             lat_for<4>([&](auto I) {
                 constexpr int i = 4 * hh + I;
-                constexpr int oc = lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i);
+                constexpr int oc = lat_emit_o_round(LAY, LV, rho) + lat_emit_o_instr(LAY, LV, i);
                 if constexpr (PRED) {
                     if ((word >> (8 * rho + i)) & 1u)
                         lat_stv(ycol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride, yo, boff, v[2 * I], v[2 * I + 1], false);
@@ -934,21 +952,22 @@ __device__ __forceinline__ void lat_absorb(V (&x)[64], unsigned lds0, const IO *
                                            const unsigned *dep = nullptr, unsigned cstride = 0, const LatThr *th = nullptr,
                                            unsigned bofs = 0xffffffffu)
 {
+    constexpr int LV = (sizeof(IO) == 4 && !PRED) ? (LVL | LAT_ORD32) : LVL;   // as in lat_emit
     typedef typename lat_vtraits<V>::coef CF;
-    const unsigned boff = bofs != 0xffffffffu ? bofs : (sstride << lat_sh(LVL));   // V = lat_f2v: where the second signal set starts
+    const unsigned boff = bofs != 0xffffffffu ? bofs : (sstride << lat_sh(LV));   // V = lat_f2v: where the second signal set starts
     static_assert(PRE == PRED, "prefetched lines come with the predicated form");
-    constexpr int SB = lat_sb(LVL);
+    constexpr int SB = lat_sb(LV);
     int hi_lane = 0, pos_lane = 0;
-    double b = cw.gl[lat_lv(LVL)];
+    double b = cw.gl[lat_lv(LV)];
     lat_for<6>([&](auto Kc) {
         constexpr int k = Kc;
-        constexpr int ob = lat_lane_o(LAY, LVL, k);
+        constexpr int ob = lat_lane_o(LAY, LV, k);
         if constexpr (ob < 4) pos_lane |= ((lane >> k) & 1) << ob;
-        if constexpr (lat_on_path(LVL, lat_pbit(LAY, 0, k))) b = ((lane >> k) & 1) ? b * cw.c.g2 : b;
+        if constexpr (lat_on_path(LV, lat_pbit(LAY, 0, k))) b = ((lane >> k) & 1) ? b * cw.c.g2 : b;
     });
     lat_for<6>([&](auto Qc) {
         constexpr int q = Qc;
-        constexpr LatLine ln = lat_line(LAY, LVL, q);
+        constexpr LatLine ln = lat_line(LAY, LV, q);
         if constexpr (ln.reg == 0) hi_lane |= ((lane >> ln.bit) & 1) << q;
     });
     double gfd[7];
@@ -963,18 +982,18 @@ __device__ __forceinline__ void lat_absorb(V (&x)[64], unsigned lds0, const IO *
     int o_lane = 2 * (lane & 7);
     lat_for<3>([&](auto Qc) {
         constexpr int q = Qc;
-        constexpr int ob = lat_line(LAY, LVL, q).ob;
+        constexpr int ob = lat_line(LAY, LV, q).ob;
         o_lane |= ((qq >> q) & 1) << ob;
     });
     const unsigned wra = lds0 + 8u * (unsigned)(17 * qq + 2 * (lane & 7));
     const unsigned xo = (unsigned)(o_lane & ((1 << SB) - 1)) + (unsigned)(o_lane >> SB) * sstride;
     auto fetch = [&](auto Rn) {
         constexpr int rn = Rn;
-        if constexpr (PRED) lat_absorb_fetch<LAY, LVL, rn>(v, xcol, xo, sstride, word, dep, cstride);
+        if constexpr (PRED) lat_absorb_fetch<LAY, LV, rn>(v, xcol, xo, sstride, word, dep, cstride);
         else
             lat_for<8>([&](auto I) {
                 constexpr int i = I;
-                constexpr int oc = lat_emit_o_round(LAY, LVL, rn) + lat_emit_o_instr(LAY, LVL, i);
+                constexpr int oc = lat_emit_o_round(LAY, LV, rn) + lat_emit_o_instr(LAY, LV, i);
                 v[8 * (rn & 1) + i] = lat_ldv(xcol + (oc & ((1 << SB) - 1)) + (size_t)(oc >> SB) * sstride, xo, boff, (V *)nullptr);
             });
     };
@@ -988,7 +1007,7 @@ __device__ __forceinline__ void lat_absorb(V (&x)[64], unsigned lds0, const IO *
                 lat_v2<V> &d = v[8 * (rho & 1) + i];
                 if constexpr (PRED && std::is_same<V, double>::value) {
                     if (th && th->kind >= 0) {
-                        constexpr int oc = lat_emit_o_round(LAY, LVL, rho) + lat_emit_o_instr(LAY, LVL, i);
+                        constexpr int oc = lat_emit_o_round(LAY, LV, rho) + lat_emit_o_instr(LAY, LV, i);
                         const int o = o_lane | oc, pos = o & ((1 << SB) - 1), sg = o >> SB;
                         const double tt = sg == 0 ? th->tt[0] : (sg == 1 ? th->tt[1] : (sg == 2 ? th->tt[2] : th->tt[3]));
                         if ((word >> (8 * rho + i)) & 1u) {
@@ -1006,13 +1025,13 @@ __device__ __forceinline__ void lat_absorb(V (&x)[64], unsigned lds0, const IO *
         if (!live) return;
         V t[16];
         lat_for<16>([&](auto Vc) {
-            constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
-            t[Vc] = lds_rd<8 * lat_emit_slot_reg(LAY, LVL, r), V>(rda);
+            constexpr int r = lat_emit_reg(LAY, LV, rho, Vc);
+            t[Vc] = lds_rd<8 * lat_emit_slot_reg(LAY, LV, r), V>(rda);
         });
         lat_wait16<0>(t);
         lat_for<16>([&](auto Vc) {
-            constexpr int r = lat_emit_reg(LAY, LVL, rho, Vc);
-            constexpr int pc = lat_emit_pc_reg(LAY, LVL, r);
+            constexpr int r = lat_emit_reg(LAY, LV, rho, Vc);
+            constexpr int pc = lat_emit_pc_reg(LAY, LV, r);
             // PRED: the transform is linear and a register that holds a leaf of this depth holds an exact zero so far (its
             // descendants do not exist: zeros in, zeros out), while every loaded value that is not a leaf's is a zero too
             // (whole 16-byte pieces are predicated): adding is selecting

@@ -82,10 +82,10 @@ static int wx_lattice_rows_launch(const IO *x, IO *y, int64_t in_img, int64_t ou
 // included by wx_lattice_rows_{3,4,5}{f,i}.hip with WX_ROWS_SH, WX_ROWS_INV and WX_ROWS_FN(type suffix)
 int WX_ROWS_FN(f64)(const double *x, double *y, int64_t in_img, int64_t out_img, int64_t m, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
 {
-    return wx_lattice_rows_launch<double, WX_ROWS_SH, 4, WX_ROWS_INV>(x, y, in_img, out_img, m, L, batch, filt, st);
+    return wx_lattice_rows_launch<double, WX_ROWS_SH, 8, WX_ROWS_INV>(x, y, in_img, out_img, m, L, batch, filt, st);
 }
 int WX_ROWS_FN(f32)(const float *x, float *y, int64_t in_img, int64_t out_img, int64_t m, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
 {
-    return wx_lattice_rows_launch<float, WX_ROWS_SH, 4, WX_ROWS_INV>(x, y, in_img, out_img, m, L, batch, filt, st);
+    return wx_lattice_rows_launch<float, WX_ROWS_SH, 8, WX_ROWS_INV>(x, y, in_img, out_img, m, L, batch, filt, st);
 }
 #endif

@@ -25,6 +25,9 @@
 // For iwpd by tree a 16-byte piece is read from the column of its leaf's depth (4-bit table per piece).
 // SH = 1, 2 (2048- and 1024-sample signals): 2^SH signals share a wavefront, index bits [SH-1:0] are the signal number, the
 // levels act on bits SH .. 11 (the first of them is the root's: unmasked), and the image in LDS is the signals one after the other.
+// SH = 3 .. 6 (512 .. 64 samples, round 5; launcher wx_lattice_tree_s.h): the same -- the first layout is B (SH = 6: C, where the root's
+// level is a masked level whose mask is every lane), the half of the image is the signal number's top bit = lane bit SH - 1 of layout C, a
+// 128-element piece of the image is one 128-sample signal or two 64-sample signals.
 #pragma once
 
 struct WxLatTreeSc {
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void k_lat_treesc_prep(const uint8_t *__restri
     }
 }
 // second step: the "any" flags and the choice of layout for the levels on bits 6, 7 out of the masks (one wavefront)
-__global__ __launch_bounds__(64) void k_lat_treesc_prep2(WxLatTreeSc *__restrict__ tab)
+__global__ __launch_bounds__(64) void k_lat_treesc_prep2(WxLatTreeSc *__restrict__ tab, int sh = 0)
 {
     const int lane = threadIdx.x;
     if (lane == 0) {
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(64) void k_lat_treesc_prep2(WxLatTreeSc *__restrict
         }
         // bits 6, 7: in layout C a lane is a node of depth 6, so a register class is busy as soon as one of 64 nodes is split
         // there; in layout B only 4 nodes share a class (at the price of halo moves): B when at most half of its 48 classes are busy
-        tab->deepB = nactB <= 24;
+        tab->deepB = nactB <= 24 && sh < 6;                    // 64-sample signals never see layout B
     }
 }
 
@@ -326,7 +329,9 @@ __device__ __forceinline__ void lat_treesc_fwd(IO *__restrict__ ys, unsigned lds
     // forward: gl[1] = g, g2 = g^-2: after the shears the a-slot holds a / g, the d-slot d g
     const double g = cw.gl[1], ginv = cw.c.g2 * cw.gl[1];
     V c[64];
-    {
+    if constexpr (SH >= 6) {
+        src(c);
+    } else {
         V bb[64];
         if constexpr (SH < 2) {
             V a[64];
@@ -358,7 +363,7 @@ __device__ __forceinline__ void lat_treesc_fwd(IO *__restrict__ ys, unsigned lds
     if (tab->anyC[4]) lat_level_cm<4, NS, false>(c, cf, mk + 128, g, ginv);
     if (tab->anyC[5]) lat_level_cm<5, NS, false>(c, cf, mk + 160, g, ginv);
     lat_sync();
-    constexpr int HBIT = SH == 2 ? 1 : 0;                       // the lane bit that is bit 11 of the output position
+    constexpr int HBIT = SH == 0 ? 0 : SH - 1;                  // the lane bit that is bit 11 of the output position
     lat_for<2>([&](auto Hc) {
         constexpr int h = Hc;
         if (((lane >> HBIT) & 1) == h) {
@@ -377,8 +382,12 @@ __device__ __forceinline__ void lat_treesc_fwd(IO *__restrict__ ys, unsigned lds
                 lat_sc_ldrow(v[Kc], lat_sc_row<h, k>(lds0, lane));
             });
             lat_for<8>([&](auto Kc) {
-                constexpr int k = k0 + Kc, q = 16 * h + k, sg = q / NQ, qq = q % NQ;
-                lat_sc_gst(ys + (size_t)sg * out_stride + 128 * qq, 2u * lane, boff_out, v[Kc]);
+                constexpr int k = k0 + Kc, q = 16 * h + k;
+                if constexpr (NQ >= 1) {
+                    constexpr int sg = q / NQ, qq = q % NQ;
+                    lat_sc_gst(ys + (size_t)sg * out_stride + 128 * qq, 2u * lane, boff_out, v[Kc]);
+                } else                                          // 64-sample signals: the piece is signals 2 q (lanes 0 .. 31) and 2 q + 1
+                    lat_sc_gst(ys + (size_t)(2 * q) * out_stride, ((unsigned)lane >> 5) * out_stride + 2u * ((unsigned)lane & 31u), boff_out, v[Kc]);
             });
         });
         lat_sync();
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const IO *__restrict__ x, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned out_stride, WxLatW cw,
     const WxLatTreeSc *__restrict__ tab)
 {
-    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
+    static_assert(SH >= 0 && SH <= 6, "4096 .. 64 samples");
     __shared__ __attribute__((aligned(16))) double lds[2048];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const unsigned boff_out = bsig * out_stride, boff_in = PAIR ? bsig * in_stride : 0xffffffffu;
     const IO *xs = x + (int64_t)sig0 * in_stride;                // signals in_stride / out_stride elements apart
     lat_treesc_fwd<NS, SH, IO, FP32A>(y + (int64_t)sig0 * out_stride, lds0, lane, out_stride, boff_out, cw, tab, [&](V (&regs)[64]) {
-        lat_absorb<(SH < 2 ? 0 : 2), 16 * SH>(regs, lds0, xs, lane, cw, in_stride, 0, 0, 0, boff_in);
+        lat_absorb<(SH < 2 ? 0 : (SH < 6 ? 2 : 6)), 16 * SH>(regs, lds0, xs, lane, cw, in_stride, 0, 0, 0, boff_in);
     });
 }
 
@@ -432,21 +441,27 @@ __device__ __forceinline__ void lat_treesc_inv(const IO *__restrict__ xs, int si
     auto fetch = [&](auto Hc, auto K0c, auto NKc) {
         constexpr int h = Hc, k0 = K0c, nk = NKc;
         lat_for<nk>([&](auto Kc) {
-            constexpr int k = k0 + Kc, q = 16 * h + k, sg = q / NQ, qq = q % NQ;
+            constexpr int k = k0 + Kc, q = 16 * h + k;
             const unsigned co = ((dep[q >> 3] >> (4 * (q & 7))) & 15u) * col_stride;      // col_stride = 0: dense leaves
-            const IO *src = xs + (size_t)sg * in_stride + 128 * qq;
-            if constexpr (qq == 0) {
-                // idwt of a pyramid: positions 0 .. 63 are the samples the lane-local tail (wx_dwttail.hip) has rebuilt
-                const IO *hp = reinterpret_cast<const IO *>(thr.head);
-                // both candidate bases are formed OUTSIDE the lane-dependent choice (a scalar-register base inside a divergent branch
-                // gets merged across the arms into a lane-dependent value), the choice is made on the complete addresses
-                const IO *hb = hp ? hp + 64 * (int64_t)(sig0 + sg) : src;
-                const auto pah = lat_sbase(hb) + 2 * lane, pbh = lat_sbase(hb + (hp ? 64u * bsig : boff_in)) + 2 * lane;
-                const auto pas = lat_sbase(src) + (2 * lane + co), pbs = lat_sbase(src + boff_in) + (2 * lane + co);
-                const bool useh = hp && lane < 32;
-                lat_sc_gldp(v[k], useh ? pah : pas, useh ? pbh : pbs);
-            } else
-                lat_sc_gld(v[k], src, 2u * lane + co, boff_in);
+            if constexpr (NQ < 1) {
+                // 64-sample signals: the piece is signals 2 q (lanes 0 .. 31) and 2 q + 1
+                lat_sc_gld(v[k], xs + (size_t)(2 * q) * in_stride, ((unsigned)lane >> 5) * in_stride + 2u * ((unsigned)lane & 31u) + co, boff_in);
+            } else {
+                constexpr int sg = q / (NQ < 1 ? 1 : NQ), qq = q % (NQ < 1 ? 1 : NQ);
+                const IO *src = xs + (size_t)sg * in_stride + 128 * qq;
+                if constexpr (qq == 0 && SH <= 2) {
+                    // idwt of a pyramid: positions 0 .. 63 are the samples the lane-local tail (wx_dwttail.hip) has rebuilt
+                    const IO *hp = reinterpret_cast<const IO *>(thr.head);
+                    // both candidate bases are formed OUTSIDE the lane-dependent choice (a scalar-register base inside a divergent branch
+                    // gets merged across the arms into a lane-dependent value), the choice is made on the complete addresses
+                    const IO *hb = hp ? hp + 64 * (int64_t)(sig0 + sg) : src;
+                    const auto pah = lat_sbase(hb) + 2 * lane, pbh = lat_sbase(hb + (hp ? 64u * bsig : boff_in)) + 2 * lane;
+                    const auto pas = lat_sbase(src) + (2 * lane + co), pbs = lat_sbase(src + boff_in) + (2 * lane + co);
+                    const bool useh = hp && lane < 32;
+                    lat_sc_gldp(v[k], useh ? pah : pas, useh ? pbh : pbs);
+                } else
+                    lat_sc_gld(v[k], src, 2u * lane + co, boff_in);
+            }
         });
     };
     double tt[4] = {0, 0, 0, 0};
@@ -460,7 +475,7 @@ __device__ __forceinline__ void lat_treesc_inv(const IO *__restrict__ xs, int si
         if constexpr (THR && !FP32A) {
             // threshold of denoise() (Denoising.jl:527 threshold!(x, th, t) before iwpt): positions [lo, n) of every signal
             lat_for<nk>([&](auto Kc) {
-                constexpr int k = k0 + Kc, q = 16 * h + k, sg = q / NQ, qq = q % NQ;
+                constexpr int k = k0 + Kc, q = 16 * h + k, sg = q / (NQ < 1 ? 1 : NQ), qq = q % (NQ < 1 ? 1 : NQ);
                 const int pos = 128 * qq + 2 * lane;
                 if (qq == 0 && thr.head && lane < 32) return;      // the tail has thresholded what it read
                 if (pos >= thr.lo) v[k].x = wx_thresh<double>(v[k].x, tt[sg], thr.kind);
@@ -499,7 +514,7 @@ __device__ __forceinline__ void lat_treesc_inv(const IO *__restrict__ xs, int si
     fetch(I1{}, I8{}, I8{});
     put(I1{}, I8{}, I8{});
     lat_sync();
-    constexpr int HBIT = SH == 2 ? 1 : 0;
+    constexpr int HBIT = SH == 0 ? 0 : SH - 1;
     if ((lane >> HBIT) & 1) {
         lat_for<64>([&](auto Rc) {
             constexpr int r = Rc;
@@ -523,24 +538,28 @@ __device__ __forceinline__ void lat_treesc_inv(const IO *__restrict__ xs, int si
         if (tab->anyC[1]) lat_level_cm<1, NS, true>(c, cf, mk + 32, ga, gd);
         if (tab->anyC[0]) lat_level_cm<0, NS, true>(c, cf, mk + 0, ga, gd);
     }
-    V bb[64];
-    lat_t3i(c, bb, lds0, lane);
-    if (tab->deepB) {
-        WX_SC_INV(5, 4, bb, 7, tab->mB + 160, tab->anyB[5])
-        WX_SC_INV(4, 4, bb, 6, tab->mB + 128, tab->anyB[4])
-    }
-    WX_SC_INV(3, 4, bb, 5, tab->mB + 96, tab->anyB[3])
-    WX_SC_INV(2, 4, bb, 4, tab->mB + 64, tab->anyB[2])
-    WX_SC_INV(1, 4, bb, 3, tab->mB + 32, tab->anyB[1])
-    WX_SC_INV(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
-    if constexpr (SH >= 2) {
-        sink(bb);
+    if constexpr (SH >= 6) {
+        sink(c);
     } else {
-        V a[64];
-        lat_t2i(bb, a, lds0, lane);
-        WX_SC_INV(1, 6, a, 1, tab->mA, tab->anyA)
-        WX_SC_INV(0, 6, a, 0, tab->mA, true)
-        sink(a);
+        V bb[64];
+        lat_t3i(c, bb, lds0, lane);
+        if (tab->deepB) {
+            WX_SC_INV(5, 4, bb, 7, tab->mB + 160, tab->anyB[5])
+            WX_SC_INV(4, 4, bb, 6, tab->mB + 128, tab->anyB[4])
+        }
+        WX_SC_INV(3, 4, bb, 5, tab->mB + 96, tab->anyB[3])
+        WX_SC_INV(2, 4, bb, 4, tab->mB + 64, tab->anyB[2])
+        WX_SC_INV(1, 4, bb, 3, tab->mB + 32, tab->anyB[1])
+        WX_SC_INV(0, 4, bb, 2, tab->mB + 0, tab->anyB[0])
+        if constexpr (SH >= 2) {
+            sink(bb);
+        } else {
+            V a[64];
+            lat_t2i(bb, a, lds0, lane);
+            WX_SC_INV(1, 6, a, 1, tab->mA, tab->anyA)
+            WX_SC_INV(0, 6, a, 0, tab->mA, true)
+            sink(a);
+        }
     }
 }
 
@@ -549,7 +568,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const IO *__restrict__ xw, IO *__restrict__ y, int L, int last_sig, unsigned in_stride, unsigned col_stride,
     unsigned out_stride, WxLatW cw, const WxLatTreeSc *__restrict__ tab, WxThreshArg thr)
 {
-    static_assert(SH >= 0 && SH <= 2, "4096, 2048 or 1024 samples");
+    static_assert(SH >= 0 && SH <= 6, "4096 .. 64 samples");
+    static_assert(!(THR && SH > 2), "the threshold rides on the kernels of 1024 samples and more");
     __shared__ __attribute__((aligned(16))) double lds[2048];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
@@ -562,7 +582,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const unsigned boff_in = bsig * in_stride, boff_out = PAIR ? bsig * out_stride : 0xffffffffu;
     IO *ys = y + (int64_t)sig0 * out_stride;
     lat_treesc_inv<NS, SH, THR, IO, FP32A>(xw + (int64_t)sig0 * in_stride, sig0, lds0, lane, in_stride, col_stride, boff_in, bsig, cw, tab, thr,
-                                           [&](V (&regs)[64]) { lat_emit<(SH < 2 ? 0 : 2), 16 * SH>(regs, lds0, ys, lane, cw, out_stride, 0, 0, boff_out); });
+                                           [&](V (&regs)[64]) { lat_emit<(SH < 2 ? 0 : (SH < 6 ? 2 : 6)), 16 * SH>(regs, lds0, ys, lane, cw, out_stride, 0, 0, boff_out); });
 }
 #undef WX_SC_FWD
 #undef WX_SC_INV

@@ -1,0 +1,5 @@
+// tree-driven lattice kernels for signals of 256 samples, inverse (wx_lattice_tree_s.h)
+#define WX_LAT_TREES_SH 4
+#define WX_LAT_TREES_INV true
+#define WX_LAT_TREES_FN(T) wx_lattice_trees_4i_##T
+#include "wx_lattice_tree_s.h"
