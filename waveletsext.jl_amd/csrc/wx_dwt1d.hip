@@ -1432,6 +1432,9 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
         if (!lat) { n2 = n; while (n2 > 2 && !wx_fused1d_ok<T>(n2, filt.F)) n2 >>= 1; }
         int d0 = 0;
         while ((n2 << d0) < n) ++d0;
+        // at most four levels: ONE tiled pass whatever the length of the nodes it leaves (until round 5 the levels below the longest node a
+        // CU's LDS holds went to the fused kernel: two passes, 0.87-0.93 ms per GiB for a full tree of depth 4 on 8192 ... 65536 samples)
+        if (L <= 4 && d0 < L) d0 = L;
         if (d0 >= 1 && wx_fused1d_ok<T>(lat ? 4096 : n2, filt.F) && (scratch || (L <= d0 && L <= 4))) {
             const int Ltop = L < d0 ? L : d0;
             const int npass = (Ltop + 3) / 4;
@@ -1959,6 +1962,11 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
         if (!lat) { n2 = n; while (n2 > 2 && !wx_fused1d_ok<T>(n2, filt.F)) n2 >>= 1; }
         int d0 = 0;
         while ((n2 << d0) < n) ++d0;
+        // at most four levels: ONE tiled pass whatever the length of the nodes it leaves (until round 5 the levels below the longest node a
+        // CU's LDS holds went to the fused kernel: two passes, 0.87-0.93 ms per GiB for a full tree of depth 4 on 8192 ... 65536 samples)
+        // (the inverse only where the fused kernel does not take the whole signal in one pass: its single pass is faster -- 8192 Float64
+        // samples 0.52 against 0.61 ms per GiB, 16384 Float32 samples 0.55 against 0.75)
+        if (L <= 4 && d0 >= 1 && d0 < L) d0 = L;
         if (d0 >= 1 && wx_fused1d_ok<T>(lat ? 4096 : n2, filt.F) && (scratch || (L <= d0 && L <= 4))) {
             const int Ltop = L < d0 ? L : d0;
             const int npass = (Ltop + 3) / 4;
