@@ -125,3 +125,54 @@ def test_row_pass_every_geometry_and_the_strips(minsh):
     env = dict(os.environ, WX_KNOBS="1", WX_LATROWS_MINSH=minsh)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+# ---- 64 x 64 images along any quad tree in one pass (csrc/wx_lattice_2d64t.h) ----
+def _quad_trees(wx, rng):
+    from helpers import random_tree_2d
+    out = [np.asarray(wx.maketree(64, 64, L, "dwt"), dtype=bool) for L in (1, 2, 3, 5, 6)]
+    t = np.asarray(wx.maketree(64, 64, 2, "full"), dtype=bool).copy()      # depth 2 full, one grandchild opened to the bottom
+    i = 6 + 7
+    while i <= t.size:
+        t[i - 1] = True
+        i = 4 * i - 2 + 3
+    out.append(t)
+    for p in (0.3, 0.5, 0.7, 0.9):
+        for _ in range(3):
+            tr = random_tree_2d(64, 64, rng, p=p)
+            tr[0] = True
+            out.append(tr)
+    return out
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("name", ["haar", "db2", "db3", "db4"])
+def test_quad_trees_on_64x64_images(wx, oracle, dt, name):
+    rng = np.random.default_rng(64 + len(name))
+    wt = wx.wavelet(getattr(wx.WT, name))
+    for B in (1, 2, 5):
+        x = np.asfortranarray(rng.standard_normal((64, 64, B)).astype(dt))
+        for tree in _quad_trees(wx, rng):
+            y = wx.wptall(x, wt, tree)
+            for b in {0, B - 1}:
+                ref = oracle.wpt(x[:, :, b].astype(np.float64), wt.qmf, tree)
+                assert relerr(y[:, :, b], ref) <= _tol(dt) * 2, (name, B, b, int(tree.sum()))
+            c = np.asfortranarray(rng.standard_normal((64, 64, B)).astype(dt))
+            xi = wx.iwptall(c, wt, tree)
+            refi = oracle.iwpt(c[:, :, B - 1].astype(np.float64), wt.qmf, tree)
+            assert relerr(xi[:, :, B - 1], refi) <= _tol(dt) * 2, (name, B, int(tree.sum()))
+            assert relerr(wx.iwptall(y, wt, tree), x) <= _tol(dt) * 2, (name, B, int(tree.sum()))
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_pyramids_of_64x64_images(wx, oracle, dt):
+    rng = np.random.default_rng(3)
+    wt = wx.wavelet(wx.WT.db4)
+    x = np.asfortranarray(rng.standard_normal((64, 64, 7)).astype(dt))
+    for L in (1, 2, 3, 4, 5, 6):
+        y = wx.dwtall(x, wt, L)
+        ref = oracle.wpt(x[:, :, 3].astype(np.float64), wt.qmf, wx.maketree(64, 64, L, "dwt"))
+        assert relerr(y[:, :, 3], ref) <= _tol(dt) * 2, (dt, L)
+        assert relerr(wx.idwtall(y, wt, L), x) <= _tol(dt) * 2, (dt, L)
+    y1 = wx.dwt(x[:, :, 0].copy(order="F"), wt, 4)
+    assert relerr(y1, oracle.wpt(x[:, :, 0].astype(np.float64), wt.qmf, wx.maketree(64, 64, 4, "dwt"))) <= _tol(dt) * 2

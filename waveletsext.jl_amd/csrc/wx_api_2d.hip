@@ -19,6 +19,24 @@ static int wx_need_device3()
 }
 
 // leaf depth of every (2^Leff x 2^Leff) block, quad-tree traversal of getbasiscoef (Utils.jl:117-131)
+// 64 x 64 images along any quad tree in one pass (wx_lattice_2d64t.h); 0 = not applicable, 1 = launched, < 0 = error
+int wx_lattice_2d64t_fwd_f64(const double *, double *, int, int64_t, const WxFilt &, const uint8_t *, int64_t, hipStream_t);
+int wx_lattice_2d64t_fwd_f32(const float *, float *, int, int64_t, const WxFilt &, const uint8_t *, int64_t, hipStream_t);
+int wx_lattice_2d64t_inv_f64(const double *, double *, int, int64_t, int64_t, const WxFilt &, const uint8_t *, int64_t, hipStream_t);
+int wx_lattice_2d64t_inv_f32(const float *, float *, int, int64_t, int64_t, const WxFilt &, const uint8_t *, int64_t, hipStream_t);
+static inline int wx_lattice_2d64t(bool inverse, const double *x, double *y, int L, int64_t batch, int64_t in_img, const WxFilt &filt,
+                                   const uint8_t *ds, int64_t ns, hipStream_t st)
+{
+    if (inverse) return wx_lattice_2d64t_inv_f64(x, y, L, batch, in_img, filt, ds, ns, st);
+    return in_img == 4096 ? wx_lattice_2d64t_fwd_f64(x, y, L, batch, filt, ds, ns, st) : 0;
+}
+static inline int wx_lattice_2d64t(bool inverse, const float *x, float *y, int L, int64_t batch, int64_t in_img, const WxFilt &filt,
+                                   const uint8_t *ds, int64_t ns, hipStream_t st)
+{
+    if (inverse) return wx_lattice_2d64t_inv_f32(x, y, L, batch, in_img, filt, ds, ns, st);
+    return in_img == 4096 ? wx_lattice_2d64t_fwd_f32(x, y, L, batch, filt, ds, ns, st) : 0;
+}
+
 static void wx_colmap2d_rec(const uint8_t *tree, int64_t ntree, int64_t node, int d, int j, int k, int Leff,
                             std::vector<int> &col)
 {
@@ -118,6 +136,10 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
     // (wx_dwttail.hip); the quad tree's approximation chain is 1, 2, 6, 22, ... (first child of i = 4 i - 2)
     int tail = 0;
     std::vector<uint8_t> ttree;
+    // 64 x 64 images along a quad tree whose root is split: the whole tree in the registers of one wavefront (wx_lattice_2d64t.h) --
+    // pyramids included (with the policy below)
+    const bool q64 = tree && !wx_force_generic() && m == 64 && n == 64 && batch > 0 && ntree >= 1 && tree[0] && F >= 2 && F <= 8 && !(F & 1) &&
+                     x != y && !wx_getenv("WX_NO_2D64T");
     if (tree && !wx_force_generic()) {
         const int Ld = wx_tree_depth2d(tree, ntree);
         std::vector<uint8_t> chain((size_t)ntree, 0);
@@ -126,7 +148,9 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
         bool pyramid = Ld >= 1;
         for (int64_t i = 0; i < ntree && pyramid; ++i) pyramid = (tree[i] != 0) == (chain[(size_t)i] != 0);
         // small images: the whole pyramid of an image in LDS, one read and one write of the batch (wx_pyr2d.hip)
-        if (pyramid && wx_pyr2d_small_ok<T>(m, n, Ld, F)) {
+        // (64 x 64: the one-wavefront kernel pays four exchanges per level -- forward pyramids keep their lane-local tail, so it sees at most
+        // three levels; inverse pyramids deeper than four levels are faster here: 0.76 against 0.84 ms per GiB of Float64 images at depth 6)
+        if (pyramid && wx_pyr2d_small_ok<T>(m, n, Ld, F) && !(q64 && (!INVERSE || Ld <= 4))) {
             WxIO io(st);
             const T *dx = (const T *)io.in(x, sizeof(T) * m * n * batch);
             T *dy = (T *)io.out(y, sizeof(T) * m * n * batch);
@@ -145,6 +169,15 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
     const T *dx = (const T *)io.in(x, sizeof(T) * m * n * batch);
     T *dy = (T *)io.out(y, sizeof(T) * m * n * batch);
     if (batch && (!dx || !dy)) return io.finish(WX_EHIP);
+    if (q64 && !tr.full && tr.dstatus && tr.Leff >= 1) {
+        const int r = wx_lattice_2d64t(INVERSE, dx, dy, tr.Leff, batch, m * n, filt, tr.dstatus, tr.nstatus, st);
+        if (r < 0) return io.finish(r);
+        if (r == 1) {
+            rc = WX_OK;
+            if (tail) rc = wx_dwt2d_tail<T>(dy, m, tail, batch, filt, st);
+            return io.finish(rc);
+        }
+    }
     // 64 x 64 images: the whole quad tree in the registers of one wavefront, one pass (wx_lattice_2d64.h)
     if (tr.full && tr.Leff > 0 && !tail && m == 64 && n == 64 && batch && !wx_force_generic() && !wx_getenv("WX_NO_2D64")) {
         const int r = wx_lattice_2d64(INVERSE, dx, dy, tr.Leff, batch, m * n, filt, st);
