@@ -123,3 +123,21 @@ def test_short_tree_iwpd_reads_the_packet_table(wx, oracle, n):
     for tree in _trees(wx, n, rng, 5):
         got = wx.iwpdall(xw, wt, tree)
         assert relerr(got, x) <= 1e-10, int(tree.sum())
+
+
+@pytest.mark.parametrize("n", [64, 128, 256])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4"])
+def test_short_float32_wpd_on_the_lattice_kernel(wx, oracle, n, wname):
+    """wpdall of short Float32 signals (csrc/wx_lattice_sgw.hip: the interleaved lattice wpd kernel with Float32 at the two ends) against the
+    oracle's packet table (DWT.jl:164-209 via dwt/dwt_all.jl:262-281), every depth, batches at and off the multiples of a wavefront's signals"""
+    rng = np.random.default_rng(n + len(wname))
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    per = 4096 // n
+    for B in (per, 3 * per + 5):
+        x = np.asfortranarray(rng.standard_normal((n, B)).astype(np.float32))
+        for L in sorted({1, 3, wx.maxtransformlevels(n)}):
+            got = wx.wpdall(x, wt, L)
+            exp = oracle.wpdall(x.astype(np.float64), wt.qmf, L)
+            assert got.dtype == np.float32 and got.shape == exp.shape
+            assert relerr(got, exp) <= 1e-5, (n, wname, B, L)
+            assert relerr(wx.iwpdall(got, wt, L), x) <= 2e-5, (n, wname, B, L)

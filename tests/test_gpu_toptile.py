@@ -94,3 +94,23 @@ def test_device_batch_round_trip_and_ragged_tiles(wx):
             y = fwd(x)
             assert float((y * y).sum() / (x * x).sum() - 1.0) < 1e-12        # orthonormal
             assert float((inv(y) - x).abs().max() / x.abs().max()) <= 1e-10
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [8192, 16384, 65536])
+def test_wpd_of_long_signals_top_slices_in_one_pass(wx, oracle, dt, n):
+    """wpdall of long signals (DWT.jl:164-209 via dwt/dwt_all.jl:262-281): the slices of the levels above the longest node a CU's LDS holds
+    -- and slice 0, the signal -- come from ONE tiled pass (wx_dev_top_levels_wpd), the deeper ones from the fused kernel: every slice
+    against the oracle's table, several depths, two filters"""
+    rng = np.random.default_rng(n)
+    tol = 1e-10 if dt == np.float64 else 2e-5
+    for wname in ("db4", "db2"):
+        wt = wx.wavelet(getattr(wx.WT, wname))
+        x = np.asfortranarray(rng.standard_normal((n, 3)).astype(dt))
+        for L in (1, 2, 3, 4, 6, wx.maxtransformlevels(n)):
+            got = wx.wpdall(x, wt, L)
+            exp = oracle.wpdall(x.astype(np.float64), wt.qmf, L)
+            assert got.shape == exp.shape
+            for l in range(L + 1):
+                den = np.abs(exp[:, l, :]).max()
+                assert np.abs(got[:, l, :] - exp[:, l, :]).max() <= tol * den, (dt, n, wname, L, l)

@@ -1329,6 +1329,7 @@ template int wx_dev_iwpt1d_thresh<double>(const double *, double *, int64_t, int
 template int wx_dev_iwpt1d_thresh<float>(const float *, float *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t,
                                          const WxThreshArg &, hipStream_t);
 
+int wx_lattice_wpd_g_f32(const float *x, float *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);   // wx_lattice_sgw.hip
 // wpd: y is (n, L+1, batch); all device pointers
 template <typename T>
 int wx_dev_wpd1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st,
@@ -1343,11 +1344,16 @@ int wx_dev_wpd1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
             if (r) return r < 0 ? r : WX_OK;
         }
     }
+    if constexpr (sizeof(T) == 4) {
+        // short Float32 signals: the interleaved lattice wpd kernel with Float32 at the two ends (wx_lattice_sgw.hip)
+        static const bool g32w_off = wx_getenv("WX_LATTICE_WPD_G32") && atoi(wx_getenv("WX_LATTICE_WPD_G32")) == 0;
+        if (!force_generic && !wx_skip_register_kernels() && !g32w_off && n <= 128) {        // 256 samples: the fused LDS kernel is as fast (0.47-0.58 against 0.44-0.50)
+            const int r = wx_lattice_wpd_g_f32((const float *)x, (float *)y, n, L, batch, filt, st);
+            if (r) return r < 0 ? r : WX_OK;
+        }
+    }
     if (!force_generic && wx_fused1d_ok<T>(n, filt.F))
         return launch_fwd_fused<T, true>(x, y, n, L, batch, n, ys, filt, nullptr, 0, st);
-    // column 0 = x (strided 2-D copy), then level by level inside the table
-    WX_HIP_CHECK(hipMemcpy2DAsync(y, ys * sizeof(T), x, n * sizeof(T), n * sizeof(T), batch,
-                                  hipMemcpyDeviceToDevice, st));
     // long signals: from the first depth d0 whose nodes fit the LDS of a CU on, the fused kernel finishes each
     // node's subtree on chip, reading column d0 and writing columns d0+1..L of the same table
     int d0 = L;
@@ -1356,7 +1362,21 @@ int wx_dev_wpd1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
         while (d0 < L && !wx_fused1d_ok<T>(n >> d0, filt.F)) ++d0;
         if (d0 < L && (!wx_fused1d_ok<T>(n >> d0, filt.F) || (batch << d0) > ((int64_t)1 << 40))) d0 = L;
     }
-    for (int d = 0; d < (d0 < L ? d0 : L); ++d) {
+    // the top levels (at most four: signals up to 16 x the longest fused node): ONE tiled pass writes slices 0 .. dtop -- the signal is
+    // read once (round 5; until then slice 0 was a copy and every top level read the slice above it: per level a read and a write)
+    const int dtop = d0 < L ? d0 : L;
+    static const bool topwpd_off = wx_getenv("WX_TOPTILE_WPD") && atoi(wx_getenv("WX_TOPTILE_WPD")) == 0;
+    bool top_done = false;
+    if (!force_generic && !topwpd_off && dtop >= 1 && dtop <= 4 && wx_is_pow2(n) && n >= 8192 && wx_top_levels_ok(filt.F) && x != y) {
+        const int rc = wx_dev_top_levels_wpd<T>(x, y, n, dtop, batch, n, ys, n, filt, st);
+        if (rc) return rc;
+        top_done = true;
+    }
+    // column 0 = x (strided 2-D copy), then level by level inside the table
+    if (!top_done)
+        WX_HIP_CHECK(hipMemcpy2DAsync(y, ys * sizeof(T), x, n * sizeof(T), n * sizeof(T), batch,
+                                      hipMemcpyDeviceToDevice, st));
+    for (int d = 0; !top_done && d < dtop; ++d) {
         if (!force_generic && (n >> d) >= 4 * WX_LT && wx_is_pow2(n)) {
             const int rc = launch_level1_tile<T, false>(y + d * n, y + (d + 1) * n, n >> d, (int64_t)1 << d, batch, ys, ys, filt, st);
             if (rc) return rc;
@@ -1953,7 +1973,10 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
     }
     // mirror of the long-signal path of wx_dev_wpt1d: the finishing kernels rebuild the nodes of depth d0 (the lattice inverse
     // on 4096-sample nodes, or the fused LDS kernel), then the top levels up to four per pass (wx_toptile.h)
-    if (!force_generic && !status && !colmap && is == n && xw != xh && wx_is_pow2(n) && n > 4096 && wx_top_levels_ok(filt.F)) {
+    // (leaves that are not dense -- the deepest slice of a packet table, iwpd of a full tree -- only when the whole transform is one tiled
+    // pass: the pass takes the stride of its input, the finishing kernels want (node, signal) contiguous)
+    if (!force_generic && !status && !colmap && (is == n || (L <= 4 && is > n && !(is & 1))) && xw != xh && wx_is_pow2(n) && n > 4096 &&
+        wx_top_levels_ok(filt.F)) {
         int dl = 0;
         while (((int64_t)4096 << dl) < n) ++dl;
         bool lat = !noreg && L - dl >= 6 && n < ((int64_t)1 << 30);
@@ -1967,6 +1990,7 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
         // (the inverse only where the fused kernel does not take the whole signal in one pass: its single pass is faster -- 8192 Float64
         // samples 0.52 against 0.61 ms per GiB, 16384 Float32 samples 0.55 against 0.75)
         if (L <= 4 && d0 >= 1 && d0 < L) d0 = L;
+        if (is != n && d0 < L) d0 = -1;                      // strided leaves and more than one kernel: not here
         if (d0 >= 1 && wx_fused1d_ok<T>(lat ? 4096 : n2, filt.F) && (scratch || (L <= d0 && L <= 4))) {
             const int Ltop = L < d0 ? L : d0;
             const int npass = (Ltop + 3) / 4;
@@ -1994,7 +2018,8 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
             for (int p = npass - 1; p >= 0; --p) {
                 const int NLp = Ltop - 4 * p < 4 ? Ltop - 4 * p : 4;
                 const int64_t np = n >> (4 * p);
-                const int rc = wx_dev_top_levels<T>(true, src, B(p), (T *)nullptr, np, NLp, batch << (4 * p), np, np, np, 0xffffffffu, 0u, filt, st);
+                const int rc = wx_dev_top_levels<T>(true, src, B(p), (T *)nullptr, np, NLp, batch << (4 * p), (src == xw && is != n) ? is : np, np, np,
+                                                    0xffffffffu, 0u, filt, st);
                 if (rc) return rc;
                 src = B(p);
             }

@@ -1742,18 +1742,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 }
 
 // wpd: y is (n, L+1, batch), every level leaves through lat_emit into the table of its signal (L >= 1, L + SH <= 12)
-template <int NS, int WPE, int SH>
+// (IO = float: Float32 signals and table, Float64 registers -- the loads widen, every emission rounds once)
+template <int NS, int WPE, int SH, typename IO = double>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpd_g_f64(
-    const double *__restrict__ x, double *__restrict__ y, int L, int last_sig, WxLatW cw)
+    const IO *__restrict__ x, IO *__restrict__ y, int L, int last_sig, WxLatW cw)
 {
     __shared__ double lds[WX_LAT_LDS];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
     constexpr int N = 4096 >> SH;
     const int sig0 = min((int)blockIdx.x << SH, last_sig);
-    const double *xs = x + (int64_t)sig0 * N;
+    const IO *xs = x + (int64_t)sig0 * N;
     const unsigned ts = (unsigned)(N * (L + 1));
-    double *ys = y + (int64_t)sig0 * ts;
+    IO *ys = y + (int64_t)sig0 * ts;
     const WxLat &cf = cw.c;
 #define WX_LVL(LAY, KK, HH, REG, BIT)                                                           \
     if constexpr (BIT >= SH) {                                                                  \

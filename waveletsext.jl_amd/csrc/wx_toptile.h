@@ -49,6 +49,8 @@ struct WxTopTree {
     unsigned sp[5];         // the split parents of depth l - 1, four bits each
     unsigned long long fl[5];   // the final nodes of depth l, four bits each
     int pf[7];              // inverse: element pairs that enter a tile, depth by depth: pf[l] .. pf[l+1] belong to depth l
+    long long lstride;      // forward, wpd (wx_dev_top_levels_wpd): depth l leaves at dst + l * lstride (slice l of the packet table), and depth 0 -- the
+                            // signal itself -- is stored too; 0: wpt layout, only the final nodes leave
 };
 
 // compile-time part: the geometry of a tile
@@ -137,6 +139,18 @@ __global__ __launch_bounds__(WX_TT_NT) void k_top_tile_fwd(const T *__restrict__
         const unsigned next = tile + gridDim.x;
         if (next < ntiles) prefetch(next);                  // in flight while this tile's levels run
         __syncthreads();
+        if (P.lstride) {
+            // wpd: slice 0 of the table is the signal (DWT.jl:164-209 writes it first): the tile's own samples out of the staged window
+            constexpr int c0 = G::O + (G::g(0) << NL);
+            T *y0 = yo + ((int64_t)t0 << NL);
+            for (int f = threadIdx.x; f < TS / 2; f += WX_TT_NT) {
+                const int a = c0 + 2 * f;
+                V2 v;
+                v.x = lds[a + (a >> 3)];
+                v.y = lds[a + 1 + ((a + 1) >> 3)];
+                *reinterpret_cast<V2 *>(y0 + 2 * f) = v;
+            }
+        }
         auto level = [&](auto lc) {
             constexpr int l = decltype(lc)::value;
             constexpr int co = ((l - 1) & 1) ? G::boff : 0, no = (l & 1) ? G::boff : 0;
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(WX_TT_NT) void k_top_tile_fwd(const T *__restrict__
                 V2 v;
                 v.x = lds[no + a + (a >> 3)];
                 v.y = lds[no + a + 1 + ((a + 1) >> 3)];
-                T *o = ((l == NL && ((P.deep >> j) & 1u)) ? yd : yo) + (int64_t)j * (n >> l) + ((int64_t)t0 << lc2);
+                T *o = ((l == NL && ((P.deep >> j) & 1u)) ? yd : yo) + (int64_t)l * P.lstride + (int64_t)j * (n >> l) + ((int64_t)t0 << lc2);
                 *reinterpret_cast<V2 *>(o + e) = v;
             }
         };
@@ -334,10 +348,15 @@ template <typename T, int F, int NL, bool INVERSE> constexpr int wx_tt_ts()
     return 1024;
 }
 // the run-time part of a pass out of the masks (W2[l] = element pairs of a depth-l window); false: not a tree of NL levels
-bool wx_top_tree(int NL, unsigned split, unsigned deep, const int *W2, WxTopTree *P);
+bool wx_top_tree(int NL, unsigned split, unsigned deep, const int *W2, WxTopTree *P, bool wpd = false);
 int64_t wx_top_grid(int64_t ntiles, size_t lds);
 // one pass over `batch` signals; see the header comment for the layouts
 template <typename T>
 int wx_dev_top_levels(bool inverse, const T *src, T *dst, T *deep, int64_t n, int NL, int64_t batch, int64_t sstride, int64_t dstride,
                       int64_t deepstride, unsigned split, unsigned deepmask, const WxFilt &filt, hipStream_t st);
 bool wx_top_levels_ok(int F);
+// wpd of the top NL levels in one pass: x (signals sstride apart) -> slices 0 .. NL of the packet tables at dst (tables dstride apart, slices
+// lstride apart inside a table); full tree
+template <typename T>
+int wx_dev_top_levels_wpd(const T *src, T *dst, int64_t n, int NL, int64_t batch, int64_t sstride, int64_t dstride, int64_t lstride,
+                          const WxFilt &filt, hipStream_t st);

@@ -9,7 +9,7 @@ bool wx_top_levels_ok(int F)
     return !off && F >= 2 && F <= 20 && (F & 1) == 0;
 }
 
-bool wx_top_tree(int NL, unsigned split, unsigned deep, const int *W2, WxTopTree *P)
+bool wx_top_tree(int NL, unsigned split, unsigned deep, const int *W2, WxTopTree *P, bool wpd)
 {
     if (NL < 1 || NL > 4) return false;
     // which nodes exist: the root, and the children of split nodes
@@ -25,9 +25,11 @@ bool wx_top_tree(int NL, unsigned split, unsigned deep, const int *W2, WxTopTree
             if ((P->split >> ((1 << (l - 1)) - 1 + j)) & 1u) P->sp[l] |= (unsigned)j << (4 * P->ns[l]++);
         for (int j = 0; j < (1 << l); ++j) {
             const int h = (1 << l) - 1 + j;
-            if (((ex >> h) & 1u) && (l == NL || !((P->split >> h) & 1u))) P->fl[l] |= (unsigned long long)j << (4 * P->nf[l]++);
+            // wpd: every node of every depth leaves (to its slice) whether it is decomposed further or not
+            if (((ex >> h) & 1u) && (wpd || l == NL || !((P->split >> h) & 1u))) P->fl[l] |= (unsigned long long)j << (4 * P->nf[l]++);
         }
     }
+    P->lstride = 0;
     for (int l = 0; l < 7; ++l) P->pf[l] = 0;
     for (int l = 1; l <= NL; ++l) P->pf[l + 1] = P->pf[l] + P->nf[l] * W2[l];
     for (int l = NL + 2; l < 7; ++l) P->pf[l] = P->pf[NL + 1];
@@ -59,7 +61,7 @@ int64_t wx_top_grid(int64_t ntiles, size_t lds)
 
 template <typename T, int F, int NL>
 static int launch_top_fwd(const T *src, T *dst, T *deep, int64_t n, int64_t batch, int64_t ss, int64_t ds, int64_t dps, unsigned split,
-                          unsigned deepmask, const WxFilt &filt, hipStream_t st)
+                          unsigned deepmask, const WxFilt &filt, hipStream_t st, int64_t lstride = 0)
 {
     constexpr int TS = wx_tt_ts<T, F, NL, false>();
     typedef WxTTGeo<F, NL, TS, false> G;
@@ -67,7 +69,8 @@ static int launch_top_fwd(const T *src, T *dst, T *deep, int64_t n, int64_t batc
     int W2[5] = {0, 0, 0, 0, 0};
     for (int l = 0; l <= NL; ++l) W2[l] = G::W(l) / 2;
     WxTopTree P;
-    if (!wx_top_tree(NL, split, deepmask, W2, &P)) return wx_set_error(WX_EARG, "top levels: the root of the pass is not decomposed");
+    if (!wx_top_tree(NL, split, deepmask, W2, &P, lstride != 0)) return wx_set_error(WX_EARG, "top levels: the root of the pass is not decomposed");
+    P.lstride = lstride;
     constexpr size_t lds = G::lds_bytes(sizeof(T));
     auto kern = k_top_tile_fwd<T, F, NL, TS>;
     if (lds > 64 * 1024) {
@@ -115,6 +118,30 @@ int wx_dev_top_levels(bool inverse, const T *src, T *dst, T *deep, int64_t n, in
 #undef WX_TT_NL
     return wx_set_error(WX_EUNSUPPORTED, "top levels: filter length not instantiated");
 }
+// wpd of the top NL levels (full tree) in one pass: slices 0 .. NL of every signal's packet table
+template <typename T>
+int wx_dev_top_levels_wpd(const T *src, T *dst, int64_t n, int NL, int64_t batch, int64_t sstride, int64_t dstride, int64_t lstride,
+                          const WxFilt &filt, hipStream_t st)
+{
+    if (batch == 0) return WX_OK;
+    if (!wx_top_levels_ok(filt.F)) return wx_set_error(WX_EUNSUPPORTED, "top levels: filter length not instantiated");
+    if (n >= ((int64_t)1 << 30) || (n & (n - 1)) || NL < 1 || NL > 4 || lstride <= 0) return wx_set_error(WX_EUNSUPPORTED, "top levels (wpd): length / level count");
+#define WX_TT_NLW(FF)                                                                                                                 \
+    switch (NL) {                                                                                                                     \
+    case 1: return launch_top_fwd<T, FF, 1>(src, dst, (T *)nullptr, n, batch, sstride, dstride, 0, 0xffffffffu, 0u, filt, st, lstride); \
+    case 2: return launch_top_fwd<T, FF, 2>(src, dst, (T *)nullptr, n, batch, sstride, dstride, 0, 0xffffffffu, 0u, filt, st, lstride); \
+    case 3: return launch_top_fwd<T, FF, 3>(src, dst, (T *)nullptr, n, batch, sstride, dstride, 0, 0xffffffffu, 0u, filt, st, lstride); \
+    default: return launch_top_fwd<T, FF, 4>(src, dst, (T *)nullptr, n, batch, sstride, dstride, 0, 0xffffffffu, 0u, filt, st, lstride); \
+    }
+    switch (filt.F) {
+    case 2: WX_TT_NLW(2) case 4: WX_TT_NLW(4) case 6: WX_TT_NLW(6) case 8: WX_TT_NLW(8) case 10: WX_TT_NLW(10)
+    case 12: WX_TT_NLW(12) case 14: WX_TT_NLW(14) case 16: WX_TT_NLW(16) case 18: WX_TT_NLW(18) case 20: WX_TT_NLW(20)
+    }
+#undef WX_TT_NLW
+    return wx_set_error(WX_EUNSUPPORTED, "top levels: filter length not instantiated");
+}
+template int wx_dev_top_levels_wpd<double>(const double *, double *, int64_t, int, int64_t, int64_t, int64_t, int64_t, const WxFilt &, hipStream_t);
+template int wx_dev_top_levels_wpd<float>(const float *, float *, int64_t, int, int64_t, int64_t, int64_t, int64_t, const WxFilt &, hipStream_t);
 template int wx_dev_top_levels<double>(bool, const double *, double *, double *, int64_t, int, int64_t, int64_t, int64_t, int64_t, unsigned,
                                        unsigned, const WxFilt &, hipStream_t);
 template int wx_dev_top_levels<float>(bool, const float *, float *, float *, int64_t, int, int64_t, int64_t, int64_t, int64_t, unsigned, unsigned,
