@@ -114,3 +114,7 @@ def test_wpd_of_long_signals_top_slices_in_one_pass(wx, oracle, dt, n):
             for l in range(L + 1):
                 den = np.abs(exp[:, l, :]).max()
                 assert np.abs(got[:, l, :] - exp[:, l, :]).max() <= tol * den, (dt, n, wname, L, l)
+            # iwpd of the full tree reads slice L of the table: one tiled pass with the table's stride (L <= 4), a strided copy + the dense
+            # long-signal kernels (deeper)
+            back = wx.iwpdall(exp.astype(dt), wt, L)
+            assert np.abs(back - x).max() <= 4 * tol * np.abs(x).max(), (dt, n, wname, L)

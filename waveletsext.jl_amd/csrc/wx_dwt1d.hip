@@ -1936,13 +1936,22 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
                   T *scratch, T *scratch2, hipStream_t st, int force_generic)
 {
     if (batch == 0 || n == 0) return WX_OK;
-    const int64_t is = in_stride;
+    int64_t is = in_stride;
     if (L == 0) {
         WX_HIP_CHECK(hipMemcpy2DAsync(xh, n * sizeof(T), xw, is * sizeof(T), n * sizeof(T), batch,
                                       hipMemcpyDeviceToDevice, st));
         return WX_OK;
     }
     const bool noreg = wx_skip_register_kernels();
+    // iwpd of a deep full tree on a long signal: the leaves are one slice of the packet table (signals n * k apart), and the kernels of the
+    // long-signal path below want them dense -- one strided copy, then the tiled top levels + the lattice (three passes) instead of the fused
+    // kernel + one launch per top level.  (At most four levels are one tiled pass that takes the stride itself.)
+    if (!force_generic && !status && !colmap && is != n && scratch2 && L > 4 && xw != xh && wx_is_pow2(n) && n > 4096 && n < ((int64_t)1 << 30) &&
+        wx_top_levels_ok(filt.F) && !wx_fused1d_ok<T>(n, filt.F)) {
+        WX_HIP_CHECK(hipMemcpy2DAsync(scratch2, n * sizeof(T), xw, is * sizeof(T), n * sizeof(T), batch, hipMemcpyDeviceToDevice, st));
+        xw = scratch2;
+        is = n;
+    }
     if constexpr (sizeof(T) == 4) {
         if (!force_generic && !noreg && !status && !colmap && n <= 128) {
             const int r = wx_lattice_f32(true, (const float *)xw, (float *)xh, n, L, batch, is, filt, st);
