@@ -100,9 +100,9 @@ def test_short_pyramids_dwtall_idwtall(wx, oracle, dt, n):
 
 
 def test_few_signals_and_long_filters_fall_back(wx, oracle):
-    """fewer signals than one wavefront holds, and filters beyond 8 taps: the older kernels, same answers"""
+    """fewer signals than one wavefront holds, and filters beyond 16 taps: the older kernels, same answers"""
     rng = np.random.default_rng(77)
-    for n, B, wname in ((64, 5, "db4"), (256, 3, "db2"), (128, 40, "db8"), (512, 16, "coif2")):
+    for n, B, wname in ((64, 5, "db4"), (256, 3, "db2"), (128, 40, "db10"), (512, 16, "db9")):
         wt = wx.wavelet(getattr(wx.WT, wname))
         x = np.asfortranarray(rng.standard_normal((n, B)))
         tree = random_tree_1d(n, rng, 0.7)
@@ -141,3 +141,43 @@ def test_short_float32_wpd_on_the_lattice_kernel(wx, oracle, n, wname):
             assert got.dtype == np.float32 and got.shape == exp.shape
             assert relerr(got, exp) <= 1e-5, (n, wname, B, L)
             assert relerr(wx.iwpdall(got, wt, L), x) <= 2e-5, (n, wname, B, L)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("wname", ["db5", "coif2", "db7", "db8"])
+def test_short_trees_longer_filters(wx, oracle, dt, wname):
+    """10 ... 16 taps (5 ... 8 rotation stages) on the same kernels"""
+    rng = np.random.default_rng(len(wname) + 40)
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    for n in (64, 128, 256, 512):
+        B = 2 * (4096 // n) + 1
+        x = np.asfortranarray(rng.standard_normal((n, B)).astype(dt))
+        for tree in _trees(wx, n, rng, 5)[::2]:
+            got = wx.wptall(x, wt, tree)
+            exp = oracle.wptall(x.astype(np.float64), wt.qmf, tree)
+            assert relerr(got, exp) <= _tol(dt) * 2, (n, wname, int(tree.sum()))
+            assert relerr(wx.iwptall(got, wt, tree), x) <= _tol(dt) * 4, (n, wname, int(tree.sum()))
+        for L in (1, 3, wx.maxtransformlevels(n)):              # FULL trees with these filters take the same kernels
+            got = wx.wptall(x, wt, L)
+            exp = oracle.wptall(x.astype(np.float64), wt.qmf, L)
+            assert relerr(got, exp) <= _tol(dt) * 2, (n, wname, L)
+            assert relerr(wx.iwptall(got, wt, L), x) <= _tol(dt) * 4, (n, wname, L)
+
+
+@pytest.mark.parametrize("wname", ["db5", "coif2", "db7", "db8"])
+def test_short_float64_wpd_and_full_trees_longer_filters(wx, oracle, wname):
+    """10 ... 16 taps on the interleaved lattice kernels of 64 ... 512-sample Float64 signals (csrc/wx_lattice_sg_b.hip, wx_lattice_sgw_b.hip):
+    wpdall against the oracle's table, iwpdall of the full tree (the deepest slice), wptall / iwptall of full trees"""
+    rng = np.random.default_rng(len(wname) + 7)
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    for n in (64, 128, 256, 512):
+        B = 2 * (4096 // n) + 3
+        x = np.asfortranarray(rng.standard_normal((n, B)))
+        for L in sorted({1, 3, wx.maxtransformlevels(n)}):
+            tab = wx.wpdall(x, wt, L)
+            exp = oracle.wpdall(x, wt.qmf, L)
+            assert relerr(tab, exp) <= 1e-10, (n, wname, L)
+            assert relerr(wx.iwpdall(exp, wt, L), x) <= 1e-10, (n, wname, L)
+            y = wx.wptall(x, wt, L)
+            assert relerr(y, exp[:, L, :]) <= 1e-10, (n, wname, L)
+            assert relerr(wx.iwptall(y, wt, L), x) <= 1e-10, (n, wname, L)

@@ -165,12 +165,26 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     }
     // short signals along a tree (pyramids, best bases, ...): 8 .. 64 signals in the registers of a wavefront, every level under the tree's
     // masks (wx_lattice_tree_s.h); longer filters and odd geometries go on to the kernels below
-    if ((small || lat_short) && !tail && !tr.full && tr.dstatus && tr.Leff >= 1 && batch && dx != dy && !wx_skip_register_kernels()) {
-        int r;
-        if constexpr (sizeof(T) == 8)
-            r = wx_lattice_tree_f64(INVERSE, (const double *)dx, (double *)dy, n, tr.Leff, batch, n, 0, filt, tr.dstatus, tr.nstatus, st, nullptr, 0);
-        else
-            r = wx_lattice_tree_f32(INVERSE, (const float *)dx, (float *)dy, n, tr.Leff, batch, n, filt, tr.dstatus, tr.nstatus, st, nullptr, 0);
+    // (a FULL tree with a filter of 10 ... 16 taps, which the interleaved full-tree kernels are not built for, goes the same way as the tree
+    // that happens to be full: 64 samples, db8, depth 1: 1.16 -> 0.4 ms per GiB)
+    const bool full_long = tr.full && F > 8 && n >= 64 && n <= 512 && batch >= 4096 / n && !wx_force_generic() &&
+                           (sizeof(T) == 8 ? wx_lattice_tree_applicable_f64(n, filt) : wx_lattice_tree_applicable_f32(n, filt));
+    if ((small || lat_short || full_long) && !tail && (!tr.full || full_long) && tr.Leff >= 1 && batch && dx != dy && !wx_skip_register_kernels()) {
+        const uint8_t *ds = tr.dstatus;
+        int64_t ns = tr.nstatus;
+        std::vector<uint8_t> ones;
+        if (tr.full) {
+            ones.assign(((size_t)1 << tr.Leff) - 1, (uint8_t)1);
+            ds = (const uint8_t *)scr.upload(ones.data(), ones.size());
+            ns = (int64_t)ones.size();
+        }
+        int r = 0;
+        if (ds) {
+            if constexpr (sizeof(T) == 8)
+                r = wx_lattice_tree_f64(INVERSE, (const double *)dx, (double *)dy, n, tr.Leff, batch, n, 0, filt, ds, ns, st, nullptr, 0);
+            else
+                r = wx_lattice_tree_f32(INVERSE, (const float *)dx, (float *)dy, n, tr.Leff, batch, n, filt, ds, ns, st, nullptr, 0);
+        }
         if (r) return io.finish(r < 0 ? r : WX_OK);
     }
     if (small && tr.Leff >= 1 && batch && dx != dy) {

@@ -230,7 +230,7 @@ int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t b
 WX_TREE_DECL(0f) WX_TREE_DECL(0i) WX_TREE_DECL(1f) WX_TREE_DECL(1i) WX_TREE_DECL(2f) WX_TREE_DECL(2i)
 #undef WX_TREE_DECL
 
-// short signals (512 .. 64 samples, wx_lattice_tree_s.h): filters up to 8 taps, no threshold riding on the loads
+// short signals (512 .. 64 samples, wx_lattice_tree_s.h): filters up to 16 taps, no threshold riding on the loads
 #define WX_TREES_DECL(k)                                                                                                             \
     int wx_lattice_trees_##k##_f64(const double *, double *, int64_t, int, int64_t, int64_t, int64_t, const WxFilt &, const uint8_t *, int64_t, hipStream_t, int64_t); \
     int wx_lattice_trees_##k##_f32(const float *, float *, int64_t, int, int64_t, int64_t, int64_t, const WxFilt &, const uint8_t *, int64_t, hipStream_t, int64_t);
@@ -239,7 +239,7 @@ WX_TREES_DECL(3f) WX_TREES_DECL(3i) WX_TREES_DECL(4f) WX_TREES_DECL(4i) WX_TREES
 static bool wx_lattice_trees_short(int64_t n, const WxFilt &filt)
 {
     static const bool off = wx_getenv("WX_LATTICE_TREES") && atoi(wx_getenv("WX_LATTICE_TREES")) == 0;
-    return !off && (n == 512 || n == 256 || n == 128 || n == 64) && filt.F <= 8;
+    return !off && (n == 512 || n == 256 || n == 128 || n == 64) && filt.F <= 16;
 }
 #define WX_TREES_GO(TS)                                                                                                              \
     switch (n) {                                                                                                                     \

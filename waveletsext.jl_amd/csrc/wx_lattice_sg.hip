@@ -1,39 +1,12 @@
-// wx_lattice_sg.hip -- launcher of the general interleaved lattice kernels for signals of 512, 256, 128 and 64 samples
-// (k_lat_wpt_g_f64, k_lat_iwpt_g_f64 in wx_lattice_dev.h: 8 .. 64 signals per wavefront); filters of 4, 6 and 8 taps
-#include "wx_lattice_dev.h"
+// wx_lattice_sg.hip -- the interleaved lattice kernels for signals of 512 ... 64 samples, filters of 2 ... 8 taps (wx_lattice_sg.h);
+// longer filters: wx_lattice_sg_b.hip
+#include "wx_lattice_sg.h"
 
-// 0 = not applicable, 1 = launched, < 0 = error
+int wx_lattice_launch_g_b(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt, hipStream_t st);
+
 int wx_lattice_launch_g(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride,
                         const WxFilt &filt, hipStream_t st)
 {
-    int SH = 0;
-    while (((int64_t)4096 >> SH) > n) ++SH;
-    if (SH < 3 || SH > 6 || ((int64_t)4096 >> SH) != n) return 0;
-    const int64_t per = (int64_t)1 << SH;
-    if (L < 1 || L + SH < 6 || L + SH > 12 || filt.F < 2 || filt.F > 8 || batch < per || batch > 0x7fffffff) return 0;
-    if ((batch & (per - 1)) && x == y) return 0;             // the tail wavefront re-does signals: out of place only
-    if (in_stride < n || in_stride * (per - 1) + 4096 > 0x7fffffff || (in_stride & 1)) return 0;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
-    WxLatW cw;
-    if (!wx_lattice_factor(filt, L, inverse, &cw.c)) return 0;
-    for (int l = 0; l <= 12; ++l) cw.gl[l] = 0.0;
-    cw.gl[L] = cw.c.g0;
-    cw.gl[0] = 1.0;
-    const int64_t nwave = (batch + per - 1) / per;
-    const int last_sig = (int)(batch - per);
-    const unsigned is32 = (unsigned)in_stride;
-#define WX_GOG(NSS, SHH)                                                                                             \
-    if (filt.F / 2 == NSS && SH == SHH) {                                                                            \
-        if (inverse)                                                                                                 \
-            hipLaunchKernelGGL((k_lat_iwpt_g_f64<NSS, 2, SHH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, is32, cw); \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_lat_wpt_g_f64<NSS, 2, SHH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
-    }
-    WX_GOG(1, 3) WX_GOG(1, 4) WX_GOG(1, 5) WX_GOG(1, 6)
-    WX_GOG(2, 3) WX_GOG(3, 3) WX_GOG(4, 3) WX_GOG(2, 4) WX_GOG(3, 4) WX_GOG(4, 4)
-    WX_GOG(2, 5) WX_GOG(3, 5) WX_GOG(4, 5) WX_GOG(2, 6) WX_GOG(3, 6) WX_GOG(4, 6)
-#undef WX_GOG
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return wx_set_hip_error(e, "lattice wpt launch (short signals)", __FILE__, __LINE__);
-    return 1;
+    if (filt.F > 8) return wx_lattice_launch_g_b(inverse, x, y, n, L, batch, in_stride, filt, st);
+    return wx_lattice_launch_g_T<1>(inverse, x, y, n, L, batch, in_stride, filt, st);
 }

@@ -1,0 +1,7 @@
+// wx_lattice_sg_b.hip -- the interleaved lattice kernels for signals of 512 ... 64 samples, filters of 10 ... 16 taps (wx_lattice_sg.h)
+#include "wx_lattice_sg.h"
+
+int wx_lattice_launch_g_b(bool inverse, const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride, const WxFilt &filt, hipStream_t st)
+{
+    return wx_lattice_launch_g_T<5>(inverse, x, y, n, L, batch, in_stride, filt, st);
+}

@@ -1,5 +1,5 @@
 // wx_lattice_tree_s.h -- launcher of the tree-driven lattice kernels of wx_lattice_tree_sc.h for SHORT signals: 512, 256, 128, 64 samples
-// (SH = 3 .. 6: 8 .. 64 signals per wavefront), Float64 and Float32 (Float64 registers: the loads widen, the stores round once), wpt / iwpt
+// (SH = 3 .. 6: 8 .. 64 signals per wavefront), Float64 and Float32 (Float64 registers: the loads widen, the stores round once), filters up to 16 taps, wpt / iwpt
 // along any tree -- pyramids (dwt / idwt), best bases, random trees -- and iwpd by tree.  Reference: Wavelets.jl's wpt / iwpt with a
 // tree::BitVector as called by wptall / iwptall (dwt/dwt_all.jl:152-166, 210-225), dwtall / idwtall (dwt/dwt_all.jl:39-110: the tree of
 // maketree(:dwt)), iwpd (DWT.jl:340-351).
@@ -74,11 +74,11 @@ static int wx_lattice_trees_launch(const IO *x, IO *y, int64_t n, int L, int64_t
 int WX_LAT_TREES_FN(f64)(const double *x, double *y, int64_t n, int L, int64_t batch, int64_t in_stride, int64_t col_stride, const WxFilt &filt,
                          const uint8_t *dstatus, int64_t nstatus, hipStream_t st, int64_t out_stride)
 {
-    return wx_lattice_trees_launch<double, WX_LAT_TREES_SH, WX_LAT_TREES_INV, 4>(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride);
+    return wx_lattice_trees_launch<double, WX_LAT_TREES_SH, WX_LAT_TREES_INV, 8>(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride);
 }
 int WX_LAT_TREES_FN(f32)(const float *x, float *y, int64_t n, int L, int64_t batch, int64_t in_stride, int64_t col_stride, const WxFilt &filt,
                          const uint8_t *dstatus, int64_t nstatus, hipStream_t st, int64_t out_stride)
 {
-    return wx_lattice_trees_launch<float, WX_LAT_TREES_SH, WX_LAT_TREES_INV, 4>(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride);
+    return wx_lattice_trees_launch<float, WX_LAT_TREES_SH, WX_LAT_TREES_INV, 8>(x, y, n, L, batch, in_stride, col_stride, filt, dstatus, nstatus, st, out_stride);
 }
 #endif
