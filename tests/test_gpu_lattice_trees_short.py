@@ -126,7 +126,7 @@ def test_short_tree_iwpd_reads_the_packet_table(wx, oracle, n):
 
 
 @pytest.mark.parametrize("n", [64, 128, 256])
-@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db3", "db4", "coif2", "db8"])
 def test_short_float32_wpd_on_the_lattice_kernel(wx, oracle, n, wname):
     """wpdall of short Float32 signals (csrc/wx_lattice_sgw.hip: the interleaved lattice wpd kernel with Float32 at the two ends) against the
     oracle's packet table (DWT.jl:164-209 via dwt/dwt_all.jl:262-281), every depth, batches at and off the multiples of a wavefront's signals"""

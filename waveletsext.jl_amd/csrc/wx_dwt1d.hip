@@ -1522,7 +1522,7 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
             if (r) return r < 0 ? r : WX_OK;
         }
         // a full tree nothing above took, as a tree
-        if (!force_generic && !noreg && !status && L <= 12 && n >= 1024 && n <= 4096 && wx_full_as_tree() &&
+        if (!force_generic && !noreg && !status && L <= 12 && (n >= 1024 || (n >= 64 && filt.F > 8)) && n <= 4096 && wx_full_as_tree() &&
             wx_lattice_tree_applicable_T<T>(n, filt)) {
             const uint8_t *ones = wx_full_tree_ones(st);
             if (ones) {
@@ -2074,7 +2074,7 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
                                               nstatus, st);
             if (r) return r < 0 ? r : WX_OK;
         }
-        if (!force_generic && !noreg && !status && !colmap && L <= 12 && n >= 1024 && n <= 4096 && wx_full_as_tree() &&
+        if (!force_generic && !noreg && !status && !colmap && L <= 12 && (n >= 1024 || (n >= 64 && filt.F > 8)) && n <= 4096 && wx_full_as_tree() &&
             wx_lattice_tree_applicable_T<T>(n, filt)) {
             const uint8_t *ones = wx_full_tree_ones(st);
             if (ones) {
