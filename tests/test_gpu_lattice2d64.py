@@ -146,7 +146,7 @@ def _quad_trees(wx, rng):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
-@pytest.mark.parametrize("name", ["haar", "db2", "db3", "db4"])
+@pytest.mark.parametrize("name", ["haar", "db2", "db3", "db4", "coif2", "db8"])
 def test_quad_trees_on_64x64_images(wx, oracle, dt, name):
     rng = np.random.default_rng(64 + len(name))
     wt = wx.wavelet(getattr(wx.WT, name))

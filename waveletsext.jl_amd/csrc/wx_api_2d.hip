@@ -138,7 +138,7 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
     std::vector<uint8_t> ttree;
     // 64 x 64 images along a quad tree whose root is split: the whole tree in the registers of one wavefront (wx_lattice_2d64t.h) --
     // pyramids included (with the policy below)
-    const bool q64 = tree && !wx_force_generic() && m == 64 && n == 64 && batch > 0 && ntree >= 1 && tree[0] && F >= 2 && F <= 8 && !(F & 1) &&
+    const bool q64 = tree && !wx_force_generic() && m == 64 && n == 64 && batch > 0 && ntree >= 1 && tree[0] && F >= 2 && F <= 16 && !(F & 1) &&
                      x != y && !wx_getenv("WX_NO_2D64T");
     if (tree && !wx_force_generic()) {
         const int Ld = wx_tree_depth2d(tree, ntree);
@@ -150,7 +150,7 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
         // small images: the whole pyramid of an image in LDS, one read and one write of the batch (wx_pyr2d.hip)
         // (64 x 64: the one-wavefront kernel pays four exchanges per level -- forward pyramids keep their lane-local tail, so it sees at most
         // three levels; inverse pyramids deeper than four levels are faster here: 0.76 against 0.84 ms per GiB of Float64 images at depth 6)
-        if (pyramid && wx_pyr2d_small_ok<T>(m, n, Ld, F) && !(q64 && (!INVERSE || Ld <= 4))) {
+        if (pyramid && wx_pyr2d_small_ok<T>(m, n, Ld, F) && !(q64 && (!INVERSE || Ld <= 4 || F > 8))) {    // (10+ taps: the LDS kernel takes 3.3 ms per GiB)
             WxIO io(st);
             const T *dx = (const T *)io.in(x, sizeof(T) * m * n * batch);
             T *dy = (T *)io.out(y, sizeof(T) * m * n * batch);

@@ -229,7 +229,14 @@ static int wx_lattice_2d64t_launch(const IO *x, IO *y, int L, int64_t batch, int
         break;
     switch (filt.F / 2) {
         WX_GOQ(1) WX_GOQ(2) WX_GOQ(3) WX_GOQ(4)
-    default: return 0;
+    default:
+        if constexpr (NSMAX > 4) {
+            switch (filt.F / 2) {
+                WX_GOQ(5) WX_GOQ(6) WX_GOQ(7) WX_GOQ(8)
+            default: return 0;
+            }
+        } else
+            return 0;
     }
 #undef WX_GOQ
     const hipError_t e = hipGetLastError();
