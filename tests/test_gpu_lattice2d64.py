@@ -176,3 +176,33 @@ def test_pyramids_of_64x64_images(wx, oracle, dt):
         assert relerr(wx.idwtall(y, wt, L), x) <= _tol(dt) * 2, (dt, L)
     y1 = wx.dwt(x[:, :, 0].copy(order="F"), wt, 4)
     assert relerr(y1, oracle.wpt(x[:, :, 0].astype(np.float64), wt.qmf, wx.maketree(64, 64, 4, "dwt"))) <= _tol(dt) * 2
+
+
+@pytest.mark.parametrize("dt", ["float64", "float32"])
+def test_64x64_in_place_and_a_chip_filling_batch(wx, oracle, dt):
+    """the one-pass kernels of 64 x 64 images in place (x is y: a wavefront's loads precede its stores; Float32 pairs: the lone last image
+    of an odd batch is both halves of its pair) and on a batch that fills the chip several times over (device arrays)"""
+    import torch
+    from waveletsext_jl_amd.dwt import Arg, _wpt_batched
+    tdt = getattr(torch, dt)
+    tol = 1e-11 if dt == "float64" else 2e-5
+    wt = wx.wavelet(wx.WT.db4)
+    B = 20001                                            # odd: the pair tail; 20001 images = 78 (156) wavefronts per CU
+    x = wx.jl_empty((64, 64, B), tdt, "cuda")
+    x.normal_()
+    x0 = x.clone()
+    for L in (2, 6):
+        y = wx.wptall(x, wt, L)
+        z = x.clone()
+        _wpt_batched("wx_wpt", Arg(z), Arg(z), 2, wt, L, None)                  # in place
+        assert torch.equal(z, y), (dt, L)
+        _wpt_batched("wx_iwpt", Arg(z), Arg(z), 2, wt, L, None)
+        assert float((z - x0).abs().max() / x0.abs().max()) <= tol, (dt, L)
+        for b in (0, B // 2, B - 1):
+            ref = oracle.wpt(x0[:, :, b].cpu().numpy().astype(np.float64), wt.qmf, L)
+            assert relerr(y[:, :, b].cpu().numpy(), ref) <= tol, (dt, L, b)
+    tree = np.asarray(wx.maketree(64, 64, 3, "dwt"), dtype=bool)
+    y = wx.wptall(x, wt, tree)
+    for b in (0, B - 1):
+        assert relerr(y[:, :, b].cpu().numpy(), oracle.wpt(x0[:, :, b].cpu().numpy().astype(np.float64), wt.qmf, tree)) <= tol, (dt, b)
+    assert float((wx.iwptall(y, wt, tree) - x0).abs().max() / x0.abs().max()) <= tol
