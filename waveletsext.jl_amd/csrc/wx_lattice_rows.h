@@ -1,5 +1,5 @@
 #pragma once
-// wx_lattice_rows.h -- the ROW pass of the 2-D full-tree packet transforms (images of 128 or 256 columns) on the interleaved lattice
+// wx_lattice_rows.h -- the ROW pass of the 2-D full-tree packet transforms (images of 128 ... 1024 columns) on the interleaved lattice
 // kernels of wx_lattice_dev.h.  Reference: the second half of the 2-D dwt_step! / idwt_step! of every node (dwt/dwt_one_level.jl:319-354,
 // 401-436) as applied by the 2-D wpt / iwpt by level (DWT.jl:500-548, 662-710); a full tree is separable, so the L row
 // levels of all nodes are one 1-D full-tree transform of every image row.
@@ -7,26 +7,31 @@
 // A wavefront takes 2^SH ADJACENT rows of n = 4096 >> SH columns (Float32: two such sets, lat_f2v) -- in the registers exactly the
 // 2^SH interleaved signals of k_lat_wpt_g_f64, in memory the signal number is the contiguous dimension: the routing class lat_isT of
 // lat_emit / lat_absorb puts it in the LOW address bits and multiplies the rest by the column stride m.  A 16-element line of the
-// exchange is then 2^SH rows x (16 >> SH) columns: 256- and 128-byte runs of Float64 for 128 and 256 columns (512 columns -- 64-byte
-// runs -- measured slower than the LDS strips and is not built).  Until round 5 the row pass ran out of LDS strips only (k_rows_fused,
+// exchange is then 2^SH rows x (16 >> SH) columns: 256- and 128-byte runs of Float64 for 128 and 256 columns; 512 and 1024 columns (64- and
+// 32-byte runs) run in workgroups of two / four wavefronts on adjacent row groups and only pay for deep trees (policy: wx_lattice_rows.hip).  Until round 5 the row pass ran out of LDS strips only (k_rows_fused,
 // wx_dwt2d.hip: LDS-issue bound).  Measured per GiB, column pass + row pass, db4 (profiles/r05_floor2d.txt): 128 x 128 Float64 full depth
 // 1.13 -> 0.80 ms, 256 x 256 Float64 1.08 -> 0.85 ms, 128 x 128 Float32 1.25 -> 0.95 ms; Float32 at depth 3 no gain (not taken below 5).
 #include "wx_lattice_dev.h"
 
+// W wavefronts per workgroup (512 columns: 2, 1024 columns: 4): they take ADJACENT row groups, so that the 64- / 32-byte runs of a wavefront
+// are halves / quarters of 128-byte lines the workgroup's other wavefronts ask for at about the same time on the same CU
+template <int SH> struct WxRowsW { static constexpr int value = SH >= 4 ? 1 : (SH == 3 ? 2 : 4); };
 template <int NS, int WPE, int SH, typename IO, bool INV>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_rows_g_f64(
+__global__ __launch_bounds__(64 * WxRowsW<SH>::value) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_rows_g_f64(
     const IO *__restrict__ x, IO *__restrict__ y, int L, unsigned m, unsigned groups, int64_t in_img, int64_t out_img, WxLatW cw)
 {
-    __shared__ double lds[WX_LAT_LDS];
-    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
-    const int lane = threadIdx.x;
+    constexpr int W = WxRowsW<SH>::value;
+    __shared__ double lds[W][WX_LAT_LDS];
+    const int wv = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds[wv];
+    const int lane = threadIdx.x & 63;
     typedef typename std::conditional<std::is_same<IO, float>::value, lat_f2v, double>::type V;
     constexpr bool PAIR = lat_vtraits<V>::pair != 0;
     constexpr unsigned per = (PAIR ? 2u : 1u) << SH;                        // rows of a wavefront
     // consecutive workgroup ids go round-robin over the 8 XCDs: give every XCD a contiguous range of row groups, so that the wavefronts
     // whose runs are halves or quarters of the same 128-byte lines (512, 1024 columns) meet in one L2 at about the same time
     const unsigned nq = gridDim.x >> 3, b = blockIdx.x;
-    const unsigned w = b < 8 * nq ? (b & 7) * nq + (b >> 3) : b;
+    const unsigned w = (b < 8 * nq ? (b & 7) * nq + (b >> 3) : b) * W + (unsigned)wv;
     const unsigned img = w / groups, g = w - img * groups;
     const IO *xs = x + (int64_t)img * in_img + g * per;
     IO *ys = y + (int64_t)img * out_img + g * per;
@@ -48,8 +53,9 @@ static int wx_lattice_rows_launch(const IO *x, IO *y, int64_t in_img, int64_t ou
     if (m < per || m % per || (m & 3) || (in_img & 3) || (out_img & 3) || m > 0x3fffffff) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return 0;
     if (m * (int64_t)(4096 >> SH) > 0x3fffffff) return 0;                  // 32-bit element offsets inside an image
+    constexpr int W = WxRowsW<SH>::value;
     const int64_t groups = m / per, nwave = groups * batch;
-    if (batch < 1 || nwave > 0x7fffffff) return 0;
+    if (batch < 1 || nwave > 0x7fffffff || nwave % W) return 0;
     WxLatW cw;
     if (!wx_lattice_factor(filt, L, INV, &cw.c)) return 0;
     for (int l = 0; l <= 12; ++l) cw.gl[l] = 0.0;
@@ -58,7 +64,7 @@ static int wx_lattice_rows_launch(const IO *x, IO *y, int64_t in_img, int64_t ou
     cw.tail_bsig = 0;
 #define WX_GOR(NSS)                                                                                                                  \
     case NSS:                                                                                                                        \
-        hipLaunchKernelGGL((k_lat_rows_g_f64<NSS, 2, SH, IO, INV>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, (unsigned)m,    \
+        hipLaunchKernelGGL((k_lat_rows_g_f64<NSS, 2, SH, IO, INV>), dim3((unsigned)(nwave / W)), dim3(64 * W), 0, st, x, y, L, (unsigned)m, \
                            (unsigned)groups, in_img, out_img, cw);                                                                   \
         break;
     switch (filt.F / 2) {
@@ -79,7 +85,7 @@ static int wx_lattice_rows_launch(const IO *x, IO *y, int64_t in_img, int64_t ou
 }
 
 #ifdef WX_ROWS_SH
-// included by wx_lattice_rows_{3,4,5}{f,i}.hip with WX_ROWS_SH, WX_ROWS_INV and WX_ROWS_FN(type suffix)
+// included by wx_lattice_rows_{2,3,4,5}{f,i}.hip with WX_ROWS_SH, WX_ROWS_INV and WX_ROWS_FN(type suffix)
 int WX_ROWS_FN(f64)(const double *x, double *y, int64_t in_img, int64_t out_img, int64_t m, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
 {
     return wx_lattice_rows_launch<double, WX_ROWS_SH, 8, WX_ROWS_INV>(x, y, in_img, out_img, m, L, batch, filt, st);

@@ -1,0 +1,5 @@
+// row pass of the 2-D full-tree transforms on the lattice kernels (wx_lattice_rows.h): images of 1024 columns, inverse
+#define WX_ROWS_SH 2
+#define WX_ROWS_INV true
+#define WX_ROWS_FN(T) wx_lattice_rows_2i_##T
+#include "wx_lattice_rows.h"
