@@ -206,3 +206,21 @@ def test_64x64_in_place_and_a_chip_filling_batch(wx, oracle, dt):
     for b in (0, B - 1):
         assert relerr(y[:, :, b].cpu().numpy(), oracle.wpt(x0[:, :, b].cpu().numpy().astype(np.float64), wt.qmf, tree)) <= tol, (dt, b)
     assert float((wx.iwptall(y, wt, tree) - x0).abs().max() / x0.abs().max()) <= tol
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("name", ["haar", "db2", "db4"])
+def test_wpd_of_64x64_images_in_one_pass(wx, oracle, dt, name):
+    """2-D wpd (DWT.jl:164-209: slice 0 = the image, slice l = the full quad tree of depth l) of 64 x 64 images: the image read once, every
+    slice written once (csrc/wx_lattice_2d64w.hip); every depth, odd batches, against the oracle's table slice by slice; iwpd of the result"""
+    rng = np.random.default_rng(17 + len(name))
+    wt = wx.wavelet(getattr(wx.WT, name))
+    for B in (1, 2, 5):
+        x = np.asfortranarray(rng.standard_normal((64, 64, B)).astype(dt))
+        for L in (1, 2, 3, 6):
+            tab = wx.wpdall(x, wt, L)
+            assert tab.shape == (64, 64, L + 1, B)
+            ref = oracle.wpd(x[:, :, B - 1].astype(np.float64), wt.qmf, L)
+            for l in range(L + 1):
+                assert relerr(tab[:, :, l, B - 1], ref[:, :, l]) <= _tol(dt) * 2, (name, B, L, l)
+            assert relerr(wx.iwpdall(tab, wt, L), x) <= _tol(dt) * 2, (name, B, L)

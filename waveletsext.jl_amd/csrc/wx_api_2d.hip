@@ -19,6 +19,11 @@ static int wx_need_device3()
 }
 
 // leaf depth of every (2^Leff x 2^Leff) block, quad-tree traversal of getbasiscoef (Utils.jl:117-131)
+// 2-D wpd of 64 x 64 images in one pass (wx_lattice_2d64w.hip); 0 = not applicable, 1 = launched, < 0 = error
+int wx_lattice_2d64_wpd_f64(const double *x, double *y, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+int wx_lattice_2d64_wpd_f32(const float *x, float *y, int L, int64_t batch, const WxFilt &filt, hipStream_t st);
+static inline int wx_lattice_2d64_wpd(const double *x, double *y, int L, int64_t batch, const WxFilt &filt, hipStream_t st) { return wx_lattice_2d64_wpd_f64(x, y, L, batch, filt, st); }
+static inline int wx_lattice_2d64_wpd(const float *x, float *y, int L, int64_t batch, const WxFilt &filt, hipStream_t st) { return wx_lattice_2d64_wpd_f32(x, y, L, batch, filt, st); }
 // 64 x 64 images along any quad tree in one pass (wx_lattice_2d64t.h); 0 = not applicable, 1 = launched, < 0 = error
 int wx_lattice_2d64t_fwd_f64(const double *, double *, int, int64_t, const WxFilt &, const uint8_t *, int64_t, hipStream_t);
 int wx_lattice_2d64t_fwd_f32(const float *, float *, int, int64_t, const WxFilt &, const uint8_t *, int64_t, hipStream_t);
@@ -112,6 +117,11 @@ static int api_wpd2d(const T *x, T *y, int64_t m, int64_t n, int L, int64_t batc
     const T *dx = (const T *)io.in(x, sizeof(T) * m * n * batch);
     T *dy = (T *)io.out(y, sizeof(T) * m * n * (L + 1) * batch);
     if (batch && (!dx || !dy)) return io.finish(WX_EHIP);
+    // 64 x 64 images: the image read once, every slice written once (wx_lattice_2d64w.hip)
+    if (m == 64 && n == 64 && L >= 1 && batch > 0 && !wx_force_generic() && !wx_getenv("WX_NO_2D64W")) {
+        const int r = wx_lattice_2d64_wpd(dx, dy, L, batch, filt, st);
+        if (r) return io.finish(r < 0 ? r : WX_OK);
+    }
     T *tmp = nullptr;
     if (batch && L > 0) { tmp = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!tmp) return io.finish(WX_EHIP); }
     rc = wx_dev_wpd2d<T>(dx, dy, m, n, L, batch, filt, tmp, st);
