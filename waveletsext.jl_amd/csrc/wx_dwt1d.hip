@@ -1330,6 +1330,8 @@ template int wx_dev_iwpt1d_thresh<float>(const float *, float *, int64_t, int, i
                                          const WxThreshArg &, hipStream_t);
 
 int wx_lattice_wpd_g_f32(const float *x, float *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st);   // wx_lattice_sgw.hip
+int wx_lattice_tree8k_fwd_f64(const double *x, double *y, int64_t batch, const WxFilt &filt, const uint8_t *dstatus0, int depth0,
+                              const uint8_t *dstatus1, int depth1, hipStream_t st);                                          // wx_lattice_8ktf.hip
 // wpd: y is (n, L+1, batch); all device pointers
 template <typename T>
 int wx_dev_wpd1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt &filt, hipStream_t st,
@@ -1830,6 +1832,15 @@ int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, con
                 int dp[2] = {0, 0};
                 for (size_t k = 0; k < sub_nodes.size(); ++k) { ds[sub_nodes[k]] = dsub + k * NS; dp[sub_nodes[k]] = sub_depth[k]; }
                 const int r = wx_lattice_tree8k_inv_f64((const double *)x, (double *)y, batch, filt, ds[0], dp[0], ds[1], dp[1], st);
+                if (r < 0) return r;
+                if (r == 1) return WX_OK;
+            }
+            // forward: the same in one pass (wx_lattice_8ktf.hip), one wavefront per SIMD
+            if (!inverse && n == 8192 && Lp >= 1 && split(0, 0) && (const void *)x != (const void *)y) {
+                const uint8_t *ds[2] = {nullptr, nullptr};
+                int dp[2] = {0, 0};
+                for (size_t k = 0; k < sub_nodes.size(); ++k) { ds[sub_nodes[k]] = dsub + k * NS; dp[sub_nodes[k]] = sub_depth[k]; }
+                const int r = wx_lattice_tree8k_fwd_f64((const double *)x, (double *)y, batch, filt, ds[0], dp[0], ds[1], dp[1], st);
                 if (r < 0) return r;
                 if (r == 1) return WX_OK;
             }
