@@ -20,7 +20,7 @@ def _noisy(rng, n, B, dtype):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_noisest_and_threshold_exact(wx, oracle, dtype):
     rng = np.random.default_rng(5001)
-    for n in (2, 8, 64, 1024, 4096):
+    for n in (2, 8, 64, 128, 256, 1024, 4096):
         v = np.asfortranarray(rng.standard_normal((n, 3)).astype(dtype))
         # noisest on a dwt-shaped signal: MAD of the upper half
         for i in range(3):
@@ -140,7 +140,7 @@ def test_noisest_degenerate_distributions(wx, oracle):
     heavy ties, one huge outlier (everything else in one bucket -> the narrowing loop), tiny and odd/even counts"""
     rng = np.random.default_rng(5004)
     cases = []
-    for n in (4, 8, 64, 1024, 4096):
+    for n in (4, 8, 64, 128, 256, 1024, 4096):           # 128, 256: two and (64: one) elements per lane of the wavefront-per-signal kernel
         half = n // 2
         cases += [
             np.zeros(n), np.full(n, -3.5),
@@ -203,3 +203,22 @@ def test_denoise_dwt_full_depth_pyramid_tail(wx, oracle, smooth):
             for i in (0, B - 1):
                 exp = oracle.denoise(xw[:, i], "dwt", wt.qmf, L=L, th=thname, smooth=smooth)
                 assert relerr(y[:, i], exp) <= 1e-10, (n, thname, smooth, i)
+
+
+@pytest.mark.parametrize("n", [64, 128, 256])
+def test_noisest_of_a_batch_of_short_signals(wx, oracle, n):
+    """denoiseall(:dwt) of many short signals: per-signal noise estimates from one wavefront per signal, four per workgroup (csrc/wx_denoise.hip
+    k_mad_wave), a batch that is not a multiple of four, values with ties; the thresholded inverse through the masked lattice kernels"""
+    rng = np.random.default_rng(n)
+    B = 1031
+    L = wx.maxtransformlevels(n)
+    wt = wx.wavelet(wx.WT.db4)
+    x = np.asfortranarray(np.round(rng.standard_normal((n, B)) * 8) / 8)
+    X = wx.to_numpy(wx.dwtall(x, wt, L))
+    dnt = wx.VisuShrink(n)
+    Y = wx.to_numpy(wx.denoiseall(X, "dwt", wt, L=L, dnt=dnt))
+    for b in range(0, B, 103):
+        Xb = np.asfortranarray(X[:, b])
+        assert wx.noisest(Xb, False) == oracle.noisest(Xb, False)
+        exp = oracle.denoise(Xb, "dwt", wt.qmf, L=L, th="hard", t=dnt.t, smooth="regular")
+        assert relerr(Y[:, b], exp) <= 1e-10, (n, b)

@@ -266,7 +266,12 @@ static int api_iwpt1d_thresh(const T *x, T *y, int64_t n, int L, const uint8_t *
                     "maketree: isdyadic(n) and 0 <= L <= maxtransformlevels(n)");
     if ((rc = wx_need_device())) return rc;
     std::vector<uint8_t> ttree;
-    const int tail = wx_pyramid_tail<T>(n, F, true, tree, ntree, ttree, filt);   // denoise(:dwt): the pyramid's deep levels lane-locally
+    // 64 ... 512 samples: the masked lattice kernels take the whole tree (wx_lattice_tree_s.h), without a threshold in their loads -- a
+    // thresholded copy first, no lane-local tail (the fused kernel with the threshold took 4.1 ms per GiB of 64-sample signals against 0.8)
+    const bool shortlat = tree && !wx_force_generic() && !wx_skip_register_kernels() && n >= 64 && n <= 512 && batch >= 4096 / n &&
+                          (const void *)x != (const void *)y &&
+                          (sizeof(T) == 8 ? wx_lattice_tree_applicable_f64(n, filt) : wx_lattice_tree_applicable_f32(n, filt));
+    const int tail = shortlat ? 0 : wx_pyramid_tail<T>(n, F, true, tree, ntree, ttree, filt);   // denoise(:dwt): the pyramid's deep levels lane-locally
     if (tail) tree = ttree.data();
     if ((rc = wx_resolve_tree1d(n, L, tree, ntree, scr, &tr, "iwpt"))) return rc;
     WxIO io(st);
@@ -276,7 +281,7 @@ static int api_iwpt1d_thresh(const T *x, T *y, int64_t n, int L, const uint8_t *
     if ((batch && n) && (!dx || !dy || !dt)) return io.finish(WX_EHIP);
     if (batch == 0) return io.finish(WX_OK);
     const int per = nt == batch && batch > 1 ? 1 : 0;
-    if (tr.Leff >= 1 && !wx_force_generic() && wx_iwpt1d_thresh_fusable<T>(n, F, tr.dstatus)) {
+    if (tr.Leff >= 1 && !wx_force_generic() && !shortlat && wx_iwpt1d_thresh_fusable<T>(n, F, tr.dstatus)) {
         WxThreshArg thr{dt, th_kind, (int)row_lo, per, scale};
         if (tail) {
             T *head = (T *)scr.alloc(sizeof(T) * 64 * batch);
@@ -296,6 +301,16 @@ static int api_iwpt1d_thresh(const T *x, T *y, int64_t n, int L, const uint8_t *
     if (!(!force && wx_fused1d_ok<T>(n, F)) && tr.Leff > 1) {
         s1 = (T *)scr.alloc(sizeof(T) * n * batch);
         if (!s1) return io.finish(WX_EHIP);
+    }
+    // the pyramid of a long signal (denoise(:dwt) of 16384 ... 65536 samples): the tiled top levels + the lattice (wx_dev_idwt_long), as idwt takes
+    // it -- level by level it was 14 launches and 7.9 ms per GiB
+    if (tree && tr.dstatus && tr.Leff >= 1 && !force && s1 && wx_dwt_long_ok<T>(n, filt)) {
+        bool longp = true;
+        for (int64_t i = 1; i <= ntree && longp; ++i) longp = (tree[i - 1] != 0) == ((i & (i - 1)) == 0 && i < ((int64_t)1 << tr.Leff));
+        if (longp) {
+            const WxThreshArg none{nullptr, 0, 0, 0, 1.0};
+            return io.finish(wx_dev_idwt_long<T>(xt, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, none, s1, st));
+        }
     }
     rc = wx_dev_iwpt1d<T>(xt, dy, n, tr.Leff, batch, filt, tr.dstatus, tr.nstatus, nullptr, 0, n, s1, nullptr, st, force);
     return io.finish(rc);
