@@ -25,7 +25,7 @@ def _cost(wx, name):
 def test_bb_1d(wx, oracle, dtype, cost):
     rng = np.random.default_rng(3001)
     wt = _wt(wx, "db4")
-    for n, B in ((64, 5), (256, 3), (1024, 2)):
+    for n, B in ((64, 5), (128, 7), (32, 9), (256, 3), (1024, 2)):      # up to 256 samples: k_bb_costs1d_short (rows of several signals per workgroup)
         x = np.asfortranarray(rng.standard_normal((n, B)).astype(dtype))
         x[:, 0] = np.cumsum(x[:, 0])                                     # a smooth-ish signal: non-trivial tree
         Xw = wx.wpdall(x, wt)
@@ -91,3 +91,17 @@ def test_bb_device_tensors_and_edge_cases(wx, oracle):
         wx.bestbasistreeall(np.zeros((8, 4)), wx.BB())                   # needs a batch (BestBasis.jl:254)
     with pytest.raises(TypeError):
         wx.bestbasistreeall(np.zeros((8, 4, 2)), wx.JBB())
+
+
+def test_bb_many_short_signals(wx, oracle):
+    """per-signal best bases of a batch of short signals whose table is not a multiple of a workgroup's 256 elements (k_bb_costs1d_short)"""
+    rng = np.random.default_rng(3003)
+    wt = _wt(wx, "db4")
+    for n, B in ((64, 301), (16, 77)):
+        x = np.asfortranarray(np.cumsum(rng.standard_normal((n, B)), axis=0))
+        Xw = wx.wpdall(x, wt)
+        m = wx.BB()
+        trees = wx.bestbasistreeall(Xw, m)
+        for b in range(0, B, 37):
+            assert relerr(wx.tree_costs(Xw[:, :, b], m), oracle.tree_costs_bb(Xw[:, :, b], False, "shannon")) <= 1e-11
+        assert (trees[:, ::37] == oracle.bestbasistreeall_bb(Xw[:, :, ::37], False, "shannon")).all()

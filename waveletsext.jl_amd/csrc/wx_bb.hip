@@ -34,6 +34,45 @@ __global__ __launch_bounds__(256) void k_bb_norms(const T *__restrict__ X, int64
 // per (level, signal) walks the level's column once -- nodes of >= 256 coefficients are reduced by the whole
 // workgroup one after the other, smaller nodes by one thread each -- so the table is read exactly once and
 // deep levels do not launch one workgroup per two-sample node.
+// short signals (n <= 256), packet tables: the table is one contiguous array of (n, k, batch) -- thread g takes element g, the nodes of a level
+// are groups of cnt = n >> depth consecutive lanes (segmented reduction by wavefront shuffles, one LDS step for nodes of 128 / 256), so a
+// workgroup covers 256 / n (level, signal) rows at once instead of one row with most of its lanes idle (64-sample signals: 0.7 ms per 0.25 GiB
+// table and launch -- 524 k workgroups -- against 0.1)
+template <typename T>
+__global__ __launch_bounds__(256) void k_bb_costs1d_short(const T *__restrict__ X, const T *__restrict__ nrm, int n, int k, int log2n, int cost_kind,
+                                                          int64_t ncost, int64_t total, T *__restrict__ costs)
+{
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = g < total;
+    const int64_t row = (in ? g : total - 1) >> log2n;            // (signal, level) row; a workgroup never straddles rows longer than itself
+    const int i = (int)(g & (n - 1));
+    const int64_t sig = row / k;
+    const int depth = (int)(row - sig * k);
+    const int cnt = n >> depth;
+    const T nr = nrm[sig];
+    double v = 0.0;
+    if (in && nr != (T)0) {
+        const WxNorm<T> nrw(nr);
+        v = bb_term<T>(X[g], nrw, cost_kind);
+    }
+    const int w0 = cnt < 64 ? cnt : 64;
+    for (int w = w0 >> 1; w > 0; w >>= 1) v += __shfl_xor(v, w, 64);
+    T *o = costs + sig * ncost + (((int64_t)1 << depth) - 1);
+    if (cnt <= 64 && in && (lane & (cnt - 1)) == 0) o[i / cnt] = (T)v;
+    // nodes of 128 / 256 coefficients: 2 / 4 wavefronts of this workgroup (the rows of a workgroup may be of different depths: every
+    // wavefront passes the barrier, the ones with short nodes are done)
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    const int per = cnt >> 6;                                   // wavefronts per node (0: nothing left to do)
+    if (per >= 2 && lane == 0 && (wave % per) == 0 && in) {
+        double t = 0.0;
+        for (int q = 0; q < per; ++q) t += red[wave + q];
+        o[i / cnt] = (T)t;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_bb_costs1d(const T *__restrict__ X, const T *__restrict__ nrm, int n, int k,
                                                     int redundant, int cost_kind, int64_t ncost,
@@ -283,7 +322,13 @@ int api_bb_costs(const T *X, T *costs, int64_t m, int64_t n, int64_t k, int64_t 
         const T *xs = dX + b0 * sigsz * k;
         if (!two_d || redundant)
             hipLaunchKernelGGL(k_bb_norms<T>, dim3((unsigned)bc), dim3(256), 0, st, xs, sigsz, sigsz * k, dn + b0);
-        if (!two_d)
+        if (!two_d && !redundant && m <= 256 && m >= 2 && !(m & (m - 1)) && !wx_getenv("WX_BB_SHORT_OFF")) {
+            int lg = 0;
+            while (((int64_t)1 << lg) < m) ++lg;
+            const int64_t total = bc * k * m;
+            hipLaunchKernelGGL(k_bb_costs1d_short<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, xs, (const T *)(dn + b0), (int)m, (int)k, lg,
+                               cost_kind, ncost, total, dc + b0 * ncost);
+        } else if (!two_d)
             hipLaunchKernelGGL(k_bb_costs1d<T>, dim3((unsigned)(redundant ? ncost : k), (unsigned)bc), dim3(256), 0, st, xs, (const T *)(dn + b0),
                                (int)m, (int)k, redundant, cost_kind, ncost, dc + b0 * ncost);
         else
