@@ -33,6 +33,12 @@ def scan(lengths=None):
         tree = np.asarray(wx.maketree(n, L, "dwt"), dtype=bool)
         t = timed(torch, lambda: wx.getbasiscoefall(tab, tree))
         print("f64 n %6d getbasiscoefall(pyramid)   %7.3f ms (%4.1f %% on 2 x signal bytes)" % (n, t, 100 * 2.0 * n * Bq * 8 / (t * 1e-3) / HBM_PEAK), flush=True)
+        t = timed(torch, lambda: wx.bestbasistree(tab, wx.JBB()))
+        print("f64 n %6d bestbasistree(JBB)         %7.3f ms (%4.1f %% on the table's bytes)" % (n, t, 100 * tb / (t * 1e-3) / HBM_PEAK), flush=True)
+        labels = [i % 3 for i in range(Bq)]
+        f = wx.LocalDiscriminantBasis(wt=wt, n_features=10)
+        t = timed(torch, lambda: wx.fit_transform(f, xq, labels), calls=2, batches=2)
+        print("f64 n %6d LDB fit_transform          %7.3f ms (%4.1f %% on the table's bytes)" % (n, t, 100 * tb / (t * 1e-3) / HBM_PEAK), flush=True)
         del xq, tab
         torch.cuda.empty_cache()
 
