@@ -156,9 +156,13 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     T *dy = (T *)io.out(y, sizeof(T) * n * batch);
     if ((batch && n) && (!dx || !dy)) return io.finish(WX_EHIP);
     const int force = wx_force_generic();
+    // Float32 FULL trees of 128 / 256 samples: the masked tree kernels in Float32 arithmetic on pairs of signals (wx_lattice_tree_s.h) beat the
+    // interleaved full-tree kernels (256 samples: depth 1 0.53 -> 0.41 ms per GiB, depth 8 0.55 -> 0.46): taken as a tree of ones
+    static const bool f32tree_off = wx_getenv("WX_TREES32_FULL") && atoi(wx_getenv("WX_TREES32_FULL")) == 0;
+    const bool f32_full_as_tree = sizeof(T) == 4 && !f32tree_off && tr.full && (n == 256 || (n == 128 && tr.Leff >= 2)) && F <= 8 && tr.Leff >= 1;   // (128 samples, depth 1: 0.38 against 0.41)
     if constexpr (sizeof(T) == 4) {
         // Float32 full trees of 64 .. 2048 samples: the interleaved lattice kernels where they apply (wx_lattice_sg32.h)
-        if (small && tr.full && tr.Leff >= 1 && batch && dx != dy && !wx_skip_register_kernels()) {
+        if (small && tr.full && !f32_full_as_tree && tr.Leff >= 1 && batch && dx != dy && !wx_skip_register_kernels()) {
             const int r = wx_lattice_f32(INVERSE, (const float *)dx, (float *)dy, n, tr.Leff, batch, n, filt, st);
             if (r) return io.finish(r < 0 ? r : WX_OK);
         }
@@ -167,7 +171,7 @@ static int api_wpt1d(const T *x, T *y, int64_t n, int L, const uint8_t *tree, in
     // masks (wx_lattice_tree_s.h); longer filters and odd geometries go on to the kernels below
     // (a FULL tree with a filter of 10 ... 16 taps, which the interleaved full-tree kernels are not built for, goes the same way as the tree
     // that happens to be full: 64 samples, db8, depth 1: 1.16 -> 0.4 ms per GiB)
-    const bool full_long = tr.full && F > 8 && n >= 64 && n <= 512 && batch >= 4096 / n && !wx_force_generic() &&
+    const bool full_long = tr.full && (F > 8 || f32_full_as_tree) && n >= 64 && n <= 512 && batch >= 4096 / n && !wx_force_generic() &&
                            (sizeof(T) == 8 ? wx_lattice_tree_applicable_f64(n, filt) : wx_lattice_tree_applicable_f32(n, filt));
     if ((small || lat_short || full_long) && !tail && (!tr.full || full_long) && tr.Leff >= 1 && batch && dx != dy && !wx_skip_register_kernels()) {
         const uint8_t *ds = tr.dstatus;

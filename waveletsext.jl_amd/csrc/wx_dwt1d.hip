@@ -1411,6 +1411,16 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
     }
     const bool noreg = wx_skip_register_kernels();      // test hook: fused LDS kernels only
     if constexpr (sizeof(T) == 4) {
+        // Float32 full trees of 128 / 256 samples (the columns of 128- / 256-row images arrive here too): the masked tree kernels in Float32
+        // arithmetic on pairs of signals, as a tree of ones (wx_lattice_tree_s.h; policy and numbers: api_wpt1d)
+        static const bool f32tree_off = wx_getenv("WX_TREES32_FULL") && atoi(wx_getenv("WX_TREES32_FULL")) == 0;
+        if (!force_generic && !noreg && !status && !f32tree_off && (n == 256 || (n == 128 && L >= 2)) && filt.F <= 8 && x != y && batch >= 2 * 4096 / n) {
+            const uint8_t *ones = wx_full_tree_ones(st);
+            if (ones) {
+                const int r = wx_lattice_tree_T<T>(false, x, y, n, L, batch, n, 0, filt, ones, ((int64_t)1 << L) - 1, st);
+                if (r) return r < 0 ? r : WX_OK;
+            }
+        }
         // very short Float32 signals, full tree (the columns of small images arrive here too): one lane per signal (wx_lanetree.h)
         if (!force_generic && !noreg && !status && n <= 128) {
             const int r = wx_lattice_f32(false, (const float *)x, (float *)y, n, L, batch, n, filt, st);
@@ -1986,6 +1996,15 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
         }
     }
     if constexpr (sizeof(T) == 4) {
+        static const bool f32tree_off = wx_getenv("WX_TREES32_FULL") && atoi(wx_getenv("WX_TREES32_FULL")) == 0;
+        if (!force_generic && !noreg && !status && !colmap && !f32tree_off && (n == 256 || (n == 128 && L >= 2)) && filt.F <= 8 && xw != xh &&
+            batch >= 2 * 4096 / n) {
+            const uint8_t *ones = wx_full_tree_ones(st);
+            if (ones) {
+                const int r = wx_lattice_tree_T<T>(true, xw, xh, n, L, batch, is, 0, filt, ones, ((int64_t)1 << L) - 1, st);
+                if (r) return r < 0 ? r : WX_OK;
+            }
+        }
         if (!force_generic && !noreg && !status && !colmap) {
             const int r = wx_lattice_f32(true, (const float *)xw, (float *)xh, n, L, batch, is, filt, st);
             if (r) return r < 0 ? r : WX_OK;
