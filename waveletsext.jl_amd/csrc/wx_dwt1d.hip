@@ -1414,7 +1414,8 @@ int wx_dev_wpt1d(const T *x, T *y, int64_t n, int L, int64_t batch, const WxFilt
         // Float32 full trees of 128 / 256 samples (the columns of 128- / 256-row images arrive here too): the masked tree kernels in Float32
         // arithmetic on pairs of signals, as a tree of ones (wx_lattice_tree_s.h; policy and numbers: api_wpt1d)
         static const bool f32tree_off = wx_getenv("WX_TREES32_FULL") && atoi(wx_getenv("WX_TREES32_FULL")) == 0;
-        if (!force_generic && !noreg && !status && !f32tree_off && (n == 256 || (n == 128 && L >= 2)) && filt.F <= 8 && x != y && batch >= 2 * 4096 / n) {
+        static const bool f32tree_big = wx_getenv("WX_TREES32_FULL") && atoi(wx_getenv("WX_TREES32_FULL")) == 2;
+        if (!force_generic && !noreg && !status && !f32tree_off && (n == 256 || (n == 128 && L >= 2) || (f32tree_big && n >= 1024 && n <= 4096)) && filt.F <= 8 && x != y && batch >= 2 * 4096 / n) {
             const uint8_t *ones = wx_full_tree_ones(st);
             if (ones) {
                 const int r = wx_lattice_tree_T<T>(false, x, y, n, L, batch, n, 0, filt, ones, ((int64_t)1 << L) - 1, st);
@@ -1997,7 +1998,8 @@ int wx_dev_iwpt1d(const T *xw, T *xh, int64_t n, int L, int64_t batch, const WxF
     }
     if constexpr (sizeof(T) == 4) {
         static const bool f32tree_off = wx_getenv("WX_TREES32_FULL") && atoi(wx_getenv("WX_TREES32_FULL")) == 0;
-        if (!force_generic && !noreg && !status && !colmap && !f32tree_off && (n == 256 || (n == 128 && L >= 2)) && filt.F <= 8 && xw != xh &&
+        static const bool f32tree_big = wx_getenv("WX_TREES32_FULL") && atoi(wx_getenv("WX_TREES32_FULL")) == 2;
+        if (!force_generic && !noreg && !status && !colmap && !f32tree_off && (n == 256 || (n == 128 && L >= 2) || (f32tree_big && n >= 1024 && n <= 4096)) && filt.F <= 8 && xw != xh &&
             batch >= 2 * 4096 / n) {
             const uint8_t *ones = wx_full_tree_ones(st);
             if (ones) {
