@@ -1743,7 +1743,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
 // wpd: y is (n, L+1, batch), every level leaves through lat_emit into the table of its signal (L >= 1, L + SH <= 12)
 // (IO = float: Float32 signals and table, Float64 registers -- the loads widen, every emission rounds once)
-template <int NS, int WPE, int SH, typename IO = double>
+// (F32A with IO = float: Float32 arithmetic on pairs of signals, lat_f2v -- the wavefront takes 2 x 2^SH signals; last_sig / cw.tail_bsig as in
+// k_lat_wpt_g_f64)
+template <int NS, int WPE, int SH, typename IO = double, bool F32A = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_wpd_g_f64(
     const IO *__restrict__ x, IO *__restrict__ y, int L, int last_sig, WxLatW cw)
 {
@@ -1751,36 +1753,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
     constexpr int N = 4096 >> SH;
-    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    typedef typename std::conditional<std::is_same<IO, float>::value && F32A, lat_f2v, double>::type V;
+    constexpr bool PAIR = lat_vtraits<V>::pair != 0;
+    const bool lastw = PAIR && blockIdx.x == gridDim.x - 1;
+    const int sig0 = PAIR ? (lastw ? last_sig : (int)(blockIdx.x << (SH + 1))) : min((int)blockIdx.x << SH, last_sig);
     const IO *xs = x + (int64_t)sig0 * N;
     const unsigned ts = (unsigned)(N * (L + 1));
     IO *ys = y + (int64_t)sig0 * ts;
-    const WxLat &cf = cw.c;
+    const unsigned bsig = (unsigned)(lastw ? cw.tail_bsig : (1 << SH));
+    const unsigned bofs_in = PAIR ? bsig * (unsigned)N : 0xffffffffu, bofs = PAIR ? bsig * ts : 0xffffffffu;
+    const typename std::conditional<PAIR, WxLatF, const WxLat &>::type cf = lat_cfsel<NS, PAIR>(cw.c);
 #define WX_LVL(LAY, KK, HH, REG, BIT)                                                           \
     if constexpr (BIT >= SH) {                                                                  \
         constexpr int l = BIT - SH + 1;                                                         \
         lat_level<KK, HH, NS, false>(REG, cf);                                                  \
-        lat_emit<LAY, l + 16 * SH>(REG, lds0, ys + N * l, lane, cw, ts);                        \
+        lat_emit<LAY, l + 16 * SH>(REG, lds0, ys + N * l, lane, cw, ts, 0, 0, bofs);            \
         if (L <= l) return;                                                                     \
     }
-    double c[64];
+    V c[64];
     if constexpr (SH < 2) {
-        double a[64], bb[64];
-        lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw);
-        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw, ts);                   // column 0 = the signal
+        V a[64], bb[64];
+        lat_absorb<0, 16 * SH>(a, lds0, xs, lane, cw, 4096u >> SH, 0, 0, 0, bofs_in);
+        lat_emit<0, 16 * SH>(a, lds0, ys, lane, cw, ts, 0, 0, bofs);       // column 0 = the signal
         WX_LVL(0, 0, 6, a, 0) WX_LVL(0, 1, 6, a, 1)
         lat_t2(a, bb, lds0, lane);
         WX_LVL(2, 0, 4, bb, 2) WX_LVL(2, 1, 4, bb, 3) WX_LVL(2, 2, 4, bb, 4) WX_LVL(2, 3, 4, bb, 5)
         lat_t3(bb, c, lds0, lane);
     } else if constexpr (SH < 6) {
-        double bb[64];
-        lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw);
-        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw, ts);
+        V bb[64];
+        lat_absorb<2, 16 * SH>(bb, lds0, xs, lane, cw, 4096u >> SH, 0, 0, 0, bofs_in);
+        lat_emit<2, 16 * SH>(bb, lds0, ys, lane, cw, ts, 0, 0, bofs);
         WX_LVL(2, 0, 4, bb, 2) WX_LVL(2, 1, 4, bb, 3) WX_LVL(2, 2, 4, bb, 4) WX_LVL(2, 3, 4, bb, 5)
         lat_t3(bb, c, lds0, lane);
     } else {
-        lat_absorb<6, 16 * SH>(c, lds0, xs, lane, cw);
-        lat_emit<6, 16 * SH>(c, lds0, ys, lane, cw, ts);
+        lat_absorb<6, 16 * SH>(c, lds0, xs, lane, cw, 4096u >> SH, 0, 0, 0, bofs_in);
+        lat_emit<6, 16 * SH>(c, lds0, ys, lane, cw, ts, 0, 0, bofs);
     }
     WX_LVL(6, 0, 0, c, 6) WX_LVL(6, 1, 0, c, 7) WX_LVL(6, 2, 0, c, 8) WX_LVL(6, 3, 0, c, 9) WX_LVL(6, 4, 0, c, 10) WX_LVL(6, 5, 0, c, 11)
 #undef WX_LVL

@@ -54,10 +54,12 @@ int WX_G32_FN(bool inverse, const float *x, float *y, int64_t n, int L, int64_t 
             hipLaunchKernelGGL((k_lat_iwpt_g_f64<NSS, WX_G32_WPE(NSS), SH, float, PAIRS_OK>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, (unsigned)in_stride, cw); \
         else if (PAIRS)                                                                                                              \
             hipLaunchKernelGGL((k_lat_wpt_g_f64<NSS, WX_G32_WPE(NSS), SH, float, PAIRS_OK>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
-        else if (inverse)                                                                                                            \
-            hipLaunchKernelGGL((k_lat_iwpt_g_f64<NSS, 2, SH, float, false>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, (unsigned)in_stride, cw); \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((k_lat_wpt_g_f64<NSS, 2, SH, float, false>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, cw);     \
+        else if constexpr (SH != 0) {                        /* 4096 samples without pairs never get here: not instantiated */      \
+            if (inverse)                                                                                                             \
+                hipLaunchKernelGGL((k_lat_iwpt_g_f64<NSS, 2, SH, float, false>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, (unsigned)in_stride, cw); \
+            else                                                                                                                     \
+                hipLaunchKernelGGL((k_lat_wpt_g_f64<NSS, 2, SH, float, false>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
+        }                                                                                                                            \
         break;
     switch (filt.F / 2) {
         WX_GOG(1) WX_GOG(2) WX_GOG(3) WX_GOG(4)
