@@ -166,7 +166,7 @@ def test_short_trees_longer_filters(wx, oracle, dt, wname):
 
 @pytest.mark.parametrize("wname", ["db5", "coif2", "db7", "db8"])
 def test_short_float64_wpd_and_full_trees_longer_filters(wx, oracle, wname):
-    """10 ... 16 taps on the interleaved lattice kernels of 64 ... 512-sample Float64 signals (csrc/wx_lattice_sg_b.hip, wx_lattice_sgw_b.hip):
+    """10 ... 16 taps on the interleaved lattice kernels of 64 ... 512-sample Float64 signals (csrc/wx_lattice_sgw_b.hip; full trees through the masked tree kernels as a tree of ones):
     wpdall against the oracle's table, iwpdall of the full tree (the deepest slice), wptall / iwptall of full trees"""
     rng = np.random.default_rng(len(wname) + 7)
     wt = wx.wavelet(getattr(wx.WT, wname))

@@ -1,7 +1,6 @@
 // wx_lattice_sg.h -- launcher body of the general interleaved lattice kernels for signals of 512, 256, 128 and 64 samples
 // (k_lat_wpt_g_f64, k_lat_iwpt_g_f64 in wx_lattice_dev.h: 8 .. 64 signals per wavefront), four filter lengths per translation unit:
-// NS0 .. NS0 + 3 rotation stages (wx_lattice_sg.hip: 2 .. 8 taps, wx_lattice_sg_b.hip: 10 .. 16 taps -- round 5: db8, the north-star filter,
-// ran these lengths on the fused LDS kernels at 0.06-0.30 of the HBM roofline)
+// NS0 .. NS0 + 3 rotation stages (wx_lattice_sg.hip: 2 .. 8 taps)
 #pragma once
 #include "wx_lattice_dev.h"
 
