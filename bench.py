@@ -102,16 +102,17 @@ WORKLOADS = {
                           "16384x1024 f64 db4 L=10 in resident chunks of 2048 signals (16 GiB of leaves each); the last four "
                           "levels are the lane-local kernels of DESIGN 4.21 (`traffic` is that kernel's)"),
     "cfg4": dict(kind="wpt2d", m=512, n=512, batch=4096, wavelet="db4", L=6, dtype="f32",
-                 kernel="k_lat2d_colT_f32<4, false, true, 0>", inv_kernel="k_lat2d_icolT_f32<4, false, true, 0>",
-                 fwd_kernels=[("k_lat2d_colT_f32<4, false, true, 0>", 1), ("k_lat2d_colT_f32<4, true, false, 0>", 1)],
-                 desc="BASELINE config 4: 2-D wptall+iwptall 4096 images 512x512 f32 db4 L=6"),
+                 kernel="k_lat2d_fused_f32<4, false, 0, false>", inv_kernel="k_lat2d_fused_f32<4, true, 0, false>",
+                 fwd_kernels=[("k_lat2d_fused_f32<4, false, 0, false>", 1)],
+                 desc="BASELINE config 4: 2-D wptall+iwptall 4096 images 512x512 f32 db4 L=6 -- both passes of a transform in one persistent "
+                      "launch, the intermediate image in a 192 MiB ring that stays in the Infinity Cache (round 6)"),
     "cfg4_256": dict(kind="wpt2d", m=256, n=256, batch=16384, wavelet="db4", L=5, dtype="f32",
-                     kernel="k_lat2d_colT_f32<4, false, true, 1>", inv_kernel="k_lat2d_icolT_f32<4, false, true, 1>",
-                     fwd_kernels=[("k_lat2d_colT_f32<4, false, true, 1>", 1), ("k_lat2d_colT_f32<4, true, false, 1>", 1)],
+                     kernel="k_lat2d_fused_f32<4, false, 1, false>", inv_kernel="k_lat2d_fused_f32<4, true, 1, false>",
+                     fwd_kernels=[("k_lat2d_fused_f32<4, false, 1, false>", 1)],
                      desc="config 4's bytes as 16384 images 256x256 f32 db4 L=5 (two images per register column)"),
     "cfg4_1024": dict(kind="wpt2d", m=1024, n=1024, batch=1024, wavelet="db4", L=7, dtype="f32",
-                      kernel="k_lat2d_colT_f32<4, false, true, 2>", inv_kernel="k_lat2d_icolT_f32<4, false, true, 2>",
-                      fwd_kernels=[("k_lat2d_colT_f32<4, false, true, 2>", 1), ("k_lat2d_colT_f32<4, true, false, 2>", 1)],
+                      kernel="k_lat2d_fused_f32<4, false, 2, false>", inv_kernel="k_lat2d_fused_f32<4, true, 2, false>",
+                      fwd_kernels=[("k_lat2d_fused_f32<4, false, 2, false>", 1)],
                       desc="config 4's bytes as 1024 images 1024x1024 f32 db4 L=7 (eight columns per wavefront)"),
     "cfg5": dict(kind="acwpd_jbb", n=2048, batch=262144, chunk=2048, wavelet="coif6", L=11, dtype="f64",
                  kernel="k_acwpd_subtree_mfma<2>",

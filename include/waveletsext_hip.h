@@ -30,7 +30,10 @@
  *    staging ring with its copy threads -- all released by wx_shutdown().  examples/roundtrip.c drives it from plain C.
  *  - Host arrays of 64 MiB and more: inputs travel through the pinned ring (host threads fill one buffer while the
  *    DMA engine drains the other), result arrays receive madvise(MADV_HUGEPAGE) before their first touch so that a
- *    freshly allocated array faults in 2 MiB steps (nothing else about the caller's memory changes).
+ *    freshly allocated array faults in 2 MiB steps (the advice persists on the address range: wx_set_host_hugepages).
+ *  - Device arrays should start on a 32-byte boundary (what hipMalloc, CuArray-style allocators and whole columns of dyadic length
+ *    give); a device pointer that does not -- a view shifted by a few elements -- is taken through an aligned scratch copy on the
+ *    call's stream: correct, two device-to-device copies slower.
  *  - Dispatch does not depend on the environment: the library's WX_* tuning knobs (profiles/NOTES.md, DESIGN.md
  *    section 10) are read only when the process also sets WX_KNOBS=1.  The parity suite's dispatch override lives in
  *    csrc/wx_debug.h, outside this header.
@@ -60,6 +63,11 @@ int wx_device_count(void);                  /* number of visible HIP devices (0 
 const char *wx_build_info(void);
 /* releases the library's only state, the cached stream-ordered scratch of the current device */
 int wx_shutdown(void);
+/* host-array results of 64 MiB and more are advised MADV_HUGEPAGE before their first touch (on by default: 17 -> 48 GB/s of host bytes).
+ * The advice is a property of the caller's ADDRESS RANGE, not of the call: it stays after the call returns and after the array is freed
+ * and its range reused, it splits the mapping it falls into, and khugepaged may collapse pages there later.  on = 0 switches it off for
+ * the process (results that are also inputs of the same call are never advised); returns the previous setting. */
+int wx_set_host_hugepages(int on);
 
 /* ------------------------------------------------------------------------------------------
  * 1-D decimated wavelet packets

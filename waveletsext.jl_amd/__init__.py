@@ -13,7 +13,7 @@ from .util import (maxtransformlevels, isdyadic, ndyadicscales, nodelength, getc
                    getrowrange, getcolrange, main2depthshift, coarsestscalingrange,
                    finestdetailrange, delete_subtree)
 from ._arrays import jl_empty, to_device, to_numpy, to_colmajor                     # noqa: F401
-from ._lib import WxError, build_info, device_count, set_force_generic, shutdown, LIB_PATH                # noqa: F401
+from ._lib import WxError, build_info, device_count, set_force_generic, set_host_hugepages, shutdown, LIB_PATH                # noqa: F401
 from .dwt import (wpd, wpd_, wpdall, iwpd, iwpd_, iwpdall, wpt, wpt_, iwpt, iwpt_,   # noqa: F401
                   wptall, iwptall, getbasiscoef, getbasiscoefall, dwt, idwt, dwtall, idwtall)
 from .swt import (sdwt, sdwt_, sdwtall, isdwt, isdwt_, isdwtall, swpt, swpt_, swptall, iswpt, iswpt_,   # noqa: F401

@@ -121,6 +121,7 @@ _PLAIN_SIGS = {
     "wx_treeselect2d_f64": [_P, _L, _L, _L, _I, _P],
     "wx_treeselect2d_f32": [_P, _L, _L, _L, _I, _P],
     "wx_shutdown": [],
+    "wx_set_host_hugepages": [_I],
     "wx_energy_map_f64": [_P, _L, _L, _L, _P, _I, _P, _P, _P],
     "wx_energy_map_f32": [_P, _L, _L, _L, _P, _I, _P, _P, _P],
     "wx_class_mean_f64": [_P, _L, _L, _P, _I, _P, _P],
@@ -195,6 +196,12 @@ def build_info():
 def shutdown():
     """release the library's cached device scratch (wx_shutdown)"""
     check(lib().wx_shutdown())
+
+
+def set_host_hugepages(on):
+    """MADV_HUGEPAGE advice on host result arrays of 64 MiB and more (on by default; the advice persists on the caller's address range:
+    include/waveletsext_hip.h); returns the previous setting (wx_set_host_hugepages)"""
+    return bool(lib().wx_set_host_hugepages(1 if on else 0))
 
 
 def set_force_generic(on):

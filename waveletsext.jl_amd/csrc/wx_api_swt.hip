@@ -349,18 +349,26 @@ static int api_acwpd_jbb_moments(const double *x, double *sum, double *sumsq, in
             if (rc == WX_OK && accumulate) rc = wx_dev_add_to(dsum, tsum, nk, st);
             if (rc != WX_OK) return io.finish(rc);
         }
+        double *sum_dump = nullptr;
         for (int64_t b0 = 0; b0 < batch && rc == WX_OK; b0 += chunk) {
             const int64_t bc = (batch - b0 < chunk) ? batch - b0 : chunk;
             const int acc = (accumulate || b0 > 0) ? 1 : 0;
             // the top table and its moments in the same passes (only what the subtree kernel and the next pass read is written);
             // otherwise three plain passes and the moment kernel over the whole top table
             int fusedm = D0 > 0 ? wx_dev_acwpd_top_moments(dx + b0 * n, tab, n, D0, bc, acf, dsum, dsq, acc, st, !linear) : 0;
-            if (linear && fusedm == 0) fusedm = wx_set_error(WX_EHIP, "acwpd moments: the fused top pass declined after its own predicate accepted");
             if (fusedm < 0) rc = fusedm;
             if (fusedm == 0) {
+                // three plain passes + the moment kernel.  With the first moments already made from the sum signal (linear) the sums of
+                // this pass go to a scratch column that nobody reads (a decline here used to be a hard error)
+                double *sums = dsum;
+                if (linear) {
+                    if (!sum_dump) sum_dump = (double *)scr.alloc(sizeof(double) * nk_top);
+                    if (!sum_dump) return io.finish(WX_EHIP);
+                    sums = sum_dump;
+                }
                 if (D0 > 0) rc = wx_dev_swt_fwd<double>(dx + b0 * n, tab, n, D0, LAYOUT_WPD, bc, filt, &acf, st);
                 else WX_HIP_CHECK(hipMemcpyAsync(tab, dx + b0 * n, sizeof(double) * n * bc, hipMemcpyDeviceToDevice, st));
-                if (rc == WX_OK) rc = wx_dev_jbb_moments<double>(tab, dsum, dsq, nk_top, bc, acc, nullptr, 1, st);
+                if (rc == WX_OK) rc = wx_dev_jbb_moments<double>(tab, sums, dsq, nk_top, bc, acc, nullptr, 1, st);
             }
             if (rc == WX_OK)
                 rc = wx_acwpd_mfma_ok(n, L, D0) ? wx_dev_acwpd_subtree_mfma(tab, dsum, dsq, n, L, D0, bc, acf, acc, st, !linear)

@@ -55,7 +55,8 @@ int load_rccl()
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_rccl.h) return WX_OK;
-    const char *names[] = {wx_getenv("WX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // WX_RCCL_LIB is a deployment path, not a tuning knob: read with or without WX_KNOBS=1
+    const char *names[] = {getenv("WX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     for (const char *nm : names) {
         if (!nm || !*nm) continue;

@@ -232,6 +232,9 @@ __global__ __launch_bounds__(256) void k_mad_wave(const T *__restrict__ X, int64
     for (int round = 0; round < 2; ++round) {
 #pragma unroll
         for (int u = 0; u < E; ++u) { const int i = lane + 64 * u; if (i < cnt) v[i] = e[u]; }
+        // a NaN among the values makes every comparison false: the ranks are no permutation then and ranks k0, k0 + 1 may not occur --
+        // the two slots start as NaN, so the estimate is NaN like Statistics.median's instead of a stale LDS word
+        if (lane == 0) { v[512] = (T)__builtin_nan(""); v[513] = (T)__builtin_nan(""); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         int rk[E];

@@ -1658,7 +1658,7 @@ int wx_dev_dwt_long(const T *x, T *y, int64_t n, int Lp, int64_t batch, const Wx
                                                       nullptr, n);
                     if (r < 0) return r;
                     if (r == 1) return WX_OK;
-                    if (!wx_fused1d_ok<T>(n2, filt.F)) return wx_set_error(WX_EHIP, "dwt of a long signal: the lattice kernel did not take the pyramid");
+                    if (!wx_fused1d_ok<T>(n2, filt.F)) return wx_set_error(WX_EUNSUPPORTED, "dwt of a long signal: more than 2^31 - 1 signals in one call");
                 }
             }
             return launch_fwd_fused<T, false>(src, y, n2, Lp - dl, batch, n, n, filt, status, n2 - 1 < nstatus ? n2 - 1 : nstatus, st);
@@ -1683,7 +1683,7 @@ int wx_dev_dwt_long(const T *x, T *y, int64_t n, int Lp, int64_t batch, const Wx
                                                   nullptr, n);
                 if (r < 0) return r;
                 if (r == 1) return WX_OK;
-                if (!wx_fused1d_ok<T>(n2, filt.F)) return wx_set_error(WX_EHIP, "dwt of a long signal: the lattice kernel did not take the pyramid");
+                if (!wx_fused1d_ok<T>(n2, filt.F)) return wx_set_error(WX_EUNSUPPORTED, "dwt of a long signal: more than 2^31 - 1 signals in one call");
             }
         }
         return launch_fwd_fused<T, false>(src, y, n2, Lp - dl, batch, S, n, filt, status, n2 - 1 < nstatus ? n2 - 1 : nstatus, st);
@@ -1722,7 +1722,7 @@ int wx_dev_idwt_long(const T *xw, T *y, int64_t n, int Lp, int64_t batch, const 
                     if (r < 0) return r;
                     done = r == 1;
                     if (!done && !wx_fused1d_ok<T>(n2, filt.F))
-                        return wx_set_error(WX_EHIP, "idwt of a long signal: the lattice kernel did not take the pyramid");
+                        return wx_set_error(WX_EUNSUPPORTED, "idwt of a long signal: more than 2^31 - 1 signals in one call");
                 }
             }
             if (!done) {
@@ -1755,7 +1755,7 @@ int wx_dev_idwt_long(const T *xw, T *y, int64_t n, int Lp, int64_t batch, const 
                 if (r < 0) return r;
                 done = r == 1;
                 if (!done && !wx_fused1d_ok<T>(n2, filt.F))
-                    return wx_set_error(WX_EHIP, "idwt of a long signal: the lattice kernel did not take the pyramid");
+                    return wx_set_error(WX_EUNSUPPORTED, "idwt of a long signal: more than 2^31 - 1 signals in one call");
             }
         }
         if (!done) {
@@ -1781,6 +1781,9 @@ template int wx_dev_idwt_long<double>(const double *, double *, int64_t, int, in
 template int wx_dev_idwt_long<float>(const float *, float *, int64_t, int, int64_t, const WxFilt &, const uint8_t *, int64_t,
                                      const WxThreshArg &, float *, hipStream_t);
 
+// (The launchers of the tree-driven lattice kernels decline pointers that do not start on a 32-byte boundary and batches beyond 2^31 - 1
+// signals.  The first cannot reach this file any more -- WxIO hands every entry point aligned device arrays (wx_host.hip, round 6) --
+// and the second needs more memory than the device has for signals of this length: what is left below reports exactly that.)
 // ---- wpt / iwpt along any tree of long signals ------------------------------------------------------------------------------
 // (what bestbasistree returns for signals of 16384 samples and more; until round 3: one launch per level over the whole signal,
 // 2-3 % of the HBM peak).  Nodes of depth d < dl = log2(n / 4096) that are split take one tiled pass (runs of consecutive split
@@ -1876,7 +1879,7 @@ int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, con
                                       : wx_lattice_tree_T<T>(false, scratch + off, y + off, 4096, sub_depth[k], batch, n, 0,
                                                             filt, dsub + k * NS, NS, st, nullptr, n);
                 if (r < 0) return r;
-                if (r != 1) return wx_set_error(WX_EHIP, "wpt of a long signal: the lattice kernel did not take a subtree");
+                if (r != 1) return wx_set_error(WX_EUNSUPPORTED, "wpt of a long signal: more than 2^31 - 1 signals in one call");
             }
             if (inverse) return wx_dev_top_levels<T>(true, x, y, scratch, n, top, batch, n, n, n, smask, deepmask, filt, st);
             return WX_OK;
@@ -1911,7 +1914,7 @@ int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, con
                 const int r = wx_lattice_tree_T<T>(false, (dl == 0 ? x : P(dl)) + off, y + off, 4096, sub_depth[k], batch, n,
                                                   0, filt, dsub + k * NS, NS, st, nullptr, n);
                 if (r < 0) return r;
-                if (r != 1) return wx_set_error(WX_EHIP, "wpt of a long signal: the lattice kernel did not take a subtree");
+                if (r != 1) return wx_set_error(WX_EUNSUPPORTED, "wpt of a long signal: more than 2^31 - 1 signals in one call");
             }
             return WX_OK;
         }
@@ -1922,7 +1925,7 @@ int wx_dev_wpt_long_tree(const T *x, T *y, int64_t n, int Lp, int64_t batch, con
             const int r = wx_lattice_tree_T<T>(true, x + off, Q(dl) + off, 4096, sub_depth[k], batch, n, 0, filt,
                                               dsub + k * NS, NS, st, nullptr, n);
             if (r < 0) return r;
-            if (r != 1) return wx_set_error(WX_EHIP, "iwpt of a long signal: the lattice kernel did not take a subtree");
+            if (r != 1) return wx_set_error(WX_EUNSUPPORTED, "iwpt of a long signal: more than 2^31 - 1 signals in one call");
         }
         for (int d = top; d >= 0; --d) {
             const int64_t np = n >> d, cnt = (int64_t)1 << d;

@@ -644,6 +644,17 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
                 WX_HIP_CHECK(hipStreamWaitEvent(st, evE, 0));
                 return WX_OK;
             }
+            // round 6: both passes in one persistent launch, the intermediate in a ring of <= 128 MiB of `tmp` that stays in the Infinity
+            // Cache (k_lat2d_fused_f32).  A launcher that declines (alignment, in-place odd batches of 256 x 256 images) leaves the two
+            // launches below.
+            if (wx_lattice2d_fused_on() && S == batch && wx_lattice2d_ring_elems(m, batch) <= mn * batch) {
+                WxScratch fscr(st);
+                unsigned *ctl = (unsigned *)fscr.alloc(wx_lattice2d_ctl_bytes());
+                if (!ctl) return WX_EHIP;
+                const int rf = wx_lattice2d_fused_f32((const float *)x, (float *)y, (float *)tmp, ctl, m, L, batch, filt, inverse, st);
+                if (rf < 0) return rf;
+                if (rf == 1) return WX_OK;
+            }
             bool took = true;
             for (int64_t b0 = 0; b0 < batch && took; b0 += S) {
                 const int64_t nb = (batch - b0 < S) ? batch - b0 : S;

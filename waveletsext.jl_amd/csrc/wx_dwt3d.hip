@@ -138,10 +138,7 @@ int api_dwt3d(const T *x, T *y, int64_t n1, int64_t n2, int64_t n3, int L, int64
     // copy of the cube before, none after (round 5: the forward transform took a copy + three passes + a copy: 3.3 ms per GiB, 8 % of the roofline)
     const bool direct = dy != dx && L >= 1 && (!inverse || L == 1);
     if (dy != dx && !direct) WX_HIP_CHECK(hipMemcpyAsync(dy, dx, sizeof(T) * cube * batch, hipMemcpyDeviceToDevice, st));
-    if (L == 0) {
-        if (dy != dx && direct) WX_HIP_CHECK(hipMemcpyAsync(dy, dx, sizeof(T) * cube * batch, hipMemcpyDeviceToDevice, st));
-        return io.finish(WX_OK);
-    }
+    if (L == 0) return io.finish(WX_OK);                 // (direct implies L >= 1: the copy above has been made)
     T *tmp = (T *)scr.alloc(sizeof(T) * cube * batch);
     if (!tmp) return io.finish(WX_EHIP);
     const int n = (int)n1;

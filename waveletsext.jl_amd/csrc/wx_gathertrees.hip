@@ -115,14 +115,19 @@ int api_trees1d(const T *Xw, T *out, int64_t n, int k, const uint8_t *trees, int
     WxScratch scr(st);
     uint8_t *dt = (uint8_t *)scr.alloc((size_t)(ntree > 0 ? ntree : 1) * batch);
     if (!dt) return WX_EHIP;
-    if (ntree > 0) {
-        hipError_t e = hipMemcpyAsync(dt, trees, (size_t)ntree * batch, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return wx_set_hip_error(e, "getbasiscoefall: tree upload", __FILE__, __LINE__);
-    }
     WxIO io(st);
     const T *dX = (const T *)io.in(Xw, sizeof(T) * n * k * batch);
     T *dout = (T *)io.out(out, sizeof(T) * n * batch);
     if (!dX || !dout) return io.finish(WX_EHIP);
+    // the tree matrix goes over from the caller's (pageable) memory: every return behind this copy waits for the stream first, so the
+    // matrix may be released on return whatever the outcome
+    if (ntree > 0) {
+        hipError_t e = hipMemcpyAsync(dt, trees, (size_t)ntree * batch, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(st);
+            return io.finish(wx_set_hip_error(e, "getbasiscoefall: tree upload", __FILE__, __LINE__));
+        }
+    }
     const unsigned grid = (unsigned)(batch < 65536 * 4 ? batch : 65536 * 4);
     if (ntree <= GT_LDS_MAX)
         hipLaunchKernelGGL((k_gather_trees1d<T, true>), dim3(grid), dim3(256), (size_t)ntree + 16, st, dX, dout, (int)n, gt_log2(n), k, batch,
@@ -132,7 +137,10 @@ int api_trees1d(const T *Xw, T *out, int64_t n, int k, const uint8_t *trees, int
                            (const uint8_t *)dt, (int)ntree);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);                 // the host tree matrix may be released on return
-    if (e != hipSuccess) return io.finish(wx_set_hip_error(e, "getbasiscoefall launch", __FILE__, __LINE__));
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        return io.finish(wx_set_hip_error(e, "getbasiscoefall launch", __FILE__, __LINE__));
+    }
     return io.finish(WX_OK);
 }
 
@@ -157,14 +165,19 @@ int api_trees2d(const T *Xw, T *out, int64_t m, int64_t n, int k, const uint8_t 
     WxScratch scr(st);
     uint8_t *dt = (uint8_t *)scr.alloc((size_t)(ntree > 0 ? ntree : 1) * batch);
     if (!dt) return WX_EHIP;
-    if (ntree > 0) {
-        hipError_t e = hipMemcpyAsync(dt, trees, (size_t)ntree * batch, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return wx_set_hip_error(e, "getbasiscoefall: tree upload", __FILE__, __LINE__);
-    }
     WxIO io(st);
     const T *dX = (const T *)io.in(Xw, sizeof(T) * m * n * k * batch);
     T *dout = (T *)io.out(out, sizeof(T) * m * n * batch);
     if (!dX || !dout) return io.finish(WX_EHIP);
+    // the tree matrix goes over from the caller's (pageable) memory: every return behind this copy waits for the stream first, so the
+    // matrix may be released on return whatever the outcome
+    if (ntree > 0) {
+        hipError_t e = hipMemcpyAsync(dt, trees, (size_t)ntree * batch, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(st);
+            return io.finish(wx_set_hip_error(e, "getbasiscoefall: tree upload", __FILE__, __LINE__));
+        }
+    }
     const unsigned grid = (unsigned)(batch < 65536 * 4 ? batch : 65536 * 4);
     if (ntree <= GT_LDS_MAX)
         hipLaunchKernelGGL((k_gather_trees2d<T, true>), dim3(grid), dim3(256), (size_t)ntree + 16, st, dX, dout, (int)m, (int)n, k, batch,
@@ -174,7 +187,10 @@ int api_trees2d(const T *Xw, T *out, int64_t m, int64_t n, int k, const uint8_t 
                            (const uint8_t *)dt, (int)ntree);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return io.finish(wx_set_hip_error(e, "getbasiscoefall launch", __FILE__, __LINE__));
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        return io.finish(wx_set_hip_error(e, "getbasiscoefall launch", __FILE__, __LINE__));
+    }
     return io.finish(WX_OK);
 }
 

@@ -44,13 +44,14 @@ struct WxScratch {
 // Presents caller buffers (host or device) as device pointers for the duration of one call.
 struct WxIO {
     hipStream_t st;
-    struct Item { void *user; void *dev; size_t bytes; bool staged; bool copy_out; };
+    struct Item { void *user; void *dev; size_t bytes; bool staged; bool copy_out; bool realigned; };
     std::vector<Item> items;
     bool any_staged = false;
+    bool any_realigned = false;                     // a device output that does not start on a 32-byte boundary goes through an aligned copy
     int err = 0;                                    // WX_EARG when a NULL pointer was passed for a non-empty array
     explicit WxIO(hipStream_t s) : st(s) {}
     ~WxIO();
-    const void *in(const void *p, size_t bytes);    // staged H2D if p is host memory
+    const void *in(const void *p, size_t bytes);    // staged H2D if p is host memory; aligned device copy if p is a misaligned device pointer
     void *out(void *p, size_t bytes);               // staged, copied back by finish()
     int finish(int rc);                             // D2H copies + sync when anything was staged
 };

@@ -314,18 +314,36 @@ static hipError_t wx_h2d_staged(void *dev, const void *user, size_t bytes, hipSt
 static void wx_advise_hugepages(void *user, size_t bytes);
 WxIO::~WxIO()
 {
-    for (auto &it : items)
-        if (it.staged && it.dev && hipFree(it.dev) != hipSuccess) (void)hipGetLastError();
+    for (auto &it : items) {
+        if (!it.dev) continue;
+        if (it.staged && hipFree(it.dev) != hipSuccess) (void)hipGetLastError();
+        if (it.realigned && hipFreeAsync(it.dev, st) != hipSuccess) (void)hipGetLastError();
+    }
 }
+// Device arrays that do not start on a 32-byte boundary (a Julia view such as `@view x[2:end]`, a sub-array of a batch: the reference takes
+// any view, dwt/dwt_all.jl:277) pass through an aligned scratch copy on the call's stream: the register kernels address whole 16- / 32-byte
+// lines per lane and their launchers decline anything else -- until round 6 some call sites turned such a refusal into WX_EHIP
+// (the lattice kernel "did not take" its subtree) instead of a slower path.  Two device-to-device copies for the rare caller, every kernel for everybody.
+static bool wx_dev_unaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 31) != 0; }
 const void *WxIO::in(const void *p, size_t bytes)
 {
     if (bytes != 0 && p == nullptr) { err = wx_set_error(WX_EARG, "NULL data pointer for a non-empty array"); return nullptr; }
     if (bytes != 0 && wx_on_other_device(p)) { err = wx_set_error(WX_EARG, "array lives on another device than the current one"); return nullptr; }
-    if (bytes == 0 || wx_is_device_ptr(p)) return p;
+    if (bytes == 0) return p;
+    if (wx_is_device_ptr(p)) {
+        if (!wx_dev_unaligned(p)) return p;
+        void *a = nullptr;
+        hipError_t ea = hipMallocAsync(&a, bytes, st);
+        if (ea != hipSuccess) { wx_set_hip_error(ea, "hipMallocAsync(realign in)", __FILE__, __LINE__); return nullptr; }
+        items.push_back({const_cast<void *>(p), a, bytes, false, false, true});
+        ea = hipMemcpyAsync(a, p, bytes, hipMemcpyDeviceToDevice, st);
+        if (ea != hipSuccess) { wx_set_hip_error(ea, "hipMemcpyAsync(realign in)", __FILE__, __LINE__); return nullptr; }
+        return a;
+    }
     void *d = nullptr;
     hipError_t e = hipMalloc(&d, bytes);
     if (e != hipSuccess) { wx_set_hip_error(e, "hipMalloc(stage in)", __FILE__, __LINE__); return nullptr; }
-    items.push_back({const_cast<void *>(p), d, bytes, true, false});
+    items.push_back({const_cast<void *>(p), d, bytes, true, false, false});
     any_staged = true;
     const double t0 = wx_host_trace() ? wx_now_ms() : 0.0;
     e = wx_h2d_staged(d, p, bytes, st);
@@ -340,13 +358,24 @@ void *WxIO::out(void *p, size_t bytes)
 {
     if (bytes != 0 && p == nullptr) { err = wx_set_error(WX_EARG, "NULL data pointer for a non-empty array"); return nullptr; }
     if (bytes != 0 && wx_on_other_device(p)) { err = wx_set_error(WX_EARG, "array lives on another device than the current one"); return nullptr; }
-    if (bytes == 0 || wx_is_device_ptr(p)) return p;
+    if (bytes == 0) return p;
+    if (wx_is_device_ptr(p)) {
+        if (!wx_dev_unaligned(p)) return p;
+        void *a = nullptr;
+        hipError_t ea = hipMallocAsync(&a, bytes, st);
+        if (ea != hipSuccess) { wx_set_hip_error(ea, "hipMallocAsync(realign out)", __FILE__, __LINE__); return nullptr; }
+        items.push_back({p, a, bytes, false, true, true});
+        any_realigned = true;
+        return a;
+    }
     void *d = nullptr;
     hipError_t e = hipMalloc(&d, bytes);
     if (e != hipSuccess) { wx_set_hip_error(e, "hipMalloc(stage out)", __FILE__, __LINE__); return nullptr; }
-    items.push_back({p, d, bytes, true, true});
+    bool also_input = false;                       // an in-place result has been faulted in by its owner already
+    for (const auto &it : items) also_input = also_input || it.user == p;
+    items.push_back({p, d, bytes, true, true, false});
     any_staged = true;
-    wx_advise_hugepages(p, bytes);
+    if (!also_input) wx_advise_hugepages(p, bytes);
     return d;
 }
 // ---- device -> pageable host memory at PCIe speed ------------------------------------------------------------
@@ -528,10 +557,18 @@ static hipError_t wx_d2h_staged(void *user, const void *dev, size_t bytes, hipSt
 // `madvise` mode (this image) the same first touch runs at 275 GB/s once the range carries MADV_HUGEPAGE: one fault per 2 MiB.
 // The advice changes nothing else about the caller's memory; ranges under 64 MiB and failures are ignored.
 #include <sys/mman.h>
+static std::atomic<int> g_host_hugepages{1};
+// process-wide switch for the advice (on by default; wx_set_host_hugepages(0) before the first host-array call turns it off): the advice
+// STAYS on the caller's address range after the call -- and after the caller frees it and the allocator reuses the range --, splits the
+// mapping it falls into, and lets khugepaged collapse pages there later.  A host that minds says so here.
+extern "C" int wx_set_host_hugepages(int on)
+{
+    return g_host_hugepages.exchange(on ? 1 : 0);
+}
 static void wx_advise_hugepages(void *user, size_t bytes)
 {
     static const bool off = wx_getenv("WX_HOST_HUGEPAGES") && atoi(wx_getenv("WX_HOST_HUGEPAGES")) == 0;
-    if (off || bytes < ((size_t)64 << 20)) return;
+    if (off || !g_host_hugepages.load(std::memory_order_relaxed) || bytes < ((size_t)64 << 20)) return;
     const uintptr_t a = ((uintptr_t)user + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1);
     const uintptr_t b = ((uintptr_t)user + bytes) & ~(uintptr_t)(((size_t)2 << 20) - 1);
     if (b > a) (void)madvise((void *)a, (size_t)(b - a), MADV_HUGEPAGE);
@@ -588,10 +625,16 @@ static hipError_t wx_h2d_staged(void *dev, const void *user, size_t bytes, hipSt
 int WxIO::finish(int rc)
 {
     if (err != WX_OK) rc = err;                    // an argument error outranks the caller's generic code
+    if (any_realigned && rc == WX_OK)              // results of realigned device outputs go back on the stream, nothing waits
+        for (auto &it : items)
+            if (it.realigned && it.copy_out) {
+                const hipError_t e = hipMemcpyAsync(it.user, it.dev, it.bytes, hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) rc = wx_set_hip_error(e, "hipMemcpyAsync(realign out)", __FILE__, __LINE__);
+            }
     if (!any_staged) return rc;
     if (rc == WX_OK) {
         for (auto &it : items)
-            if (it.copy_out) {
+            if (it.copy_out && it.staged) {
                 double t0 = 0.0;
                 if (wx_host_trace()) { (void)hipStreamSynchronize(st); t0 = wx_now_ms(); }
                 hipError_t e = wx_d2h_staged(it.user, it.dev, it.bytes, st);

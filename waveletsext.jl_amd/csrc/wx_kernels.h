@@ -176,6 +176,12 @@ int wx_lattice_iwpt_f64(const double *xw, double *y, int64_t n, int L, int64_t b
 // 512 x 512 Float32 images, depth 6: one transposing lattice pass (wx_lattice2d.hip); 0 = not applicable, 1 = launched
 bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz);
 int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t m, int L, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st);
+// both passes in one persistent launch through a cache-resident ring (round 6): 0 = not applicable, 1 = launched, < 0 = error
+int wx_lattice2d_fused_f32(const float *src, float *dst, float *ring, unsigned *ctl, int64_t m, int L, int64_t batch, const WxFilt &filt, bool inverse,
+                           hipStream_t st);
+int64_t wx_lattice2d_ring_elems(int64_t m, int64_t batch);
+size_t wx_lattice2d_ctl_bytes();
+bool wx_lattice2d_fused_on();
 // row pass of a 2-D full tree on the lattice kernels (wx_lattice_rows.h, dispatch in wx_lattice_rows.hip): L levels along the rows of
 // (m, n) images; 0 = not applicable, 1 = launched, < 0 = error
 int wx_lattice_rows(bool inverse, const double *x, double *y, int64_t in_img, int64_t out_img, int64_t m, int64_t n, int L, int64_t batch,

@@ -28,10 +28,13 @@
 // lanes (quad_perm).  Depth 6 needs levels on index bits 0..5 only: A takes 0-1, B takes 2-5.
 #include "wx_common.h"
 #include "wx_kernels.h"
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <utility>
 
 bool wx_lattice_coeffs(const WxFilt &filt, int L, bool inverse, double *p, double *kap, double *g0, double *g2);
+const void *wx_const_upload(const void *host, size_t bytes, hipStream_t st, bool have_stream);   // wx_host.hip: content-keyed constant cache
 
 #define WX_L2_MAXS 10
 #define WX_L2_WIN 1104        // 8-byte slots of one wavefront's exchange window
@@ -90,6 +93,33 @@ __device__ __forceinline__ void l2_st(l2_gm p, f4 v)
     f4 __attribute__((address_space(1))) *q = (f4 __attribute__((address_space(1))) *)p;
     if (WX_L2D_NT) __builtin_nontemporal_store(v, q);
     else *q = v;
+}
+// Memory flavour MF of a pass.  0: non-temporal global accesses on both sides (one launch per pass).  The fused kernel (k_lat2d_fused_f32)
+// hands the intermediate image from pass to pass through a ring that is rewritten in place every few hundred microseconds by workgroups
+// on any XCD, so the ring side is accessed at agent scope or wider -- 1 (first pass): image in non-temporal, ring out through sc1 buffer
+// stores (written through to the memory side, no dirty line stays in the writer's L2); 2 (second pass): ring in through sc0 sc1 buffer
+// loads (never served by this CU's L1; the XCD L2s are kept coherent for such stores: tools/dbg/ring_stale.hip), image out non-temporal.
+// Buffer instructions because the builtins carry the cache policy AND stay visible to the compiler's wait-count / hazard passes (an
+// inline-asm sc1 store followed by a write of its data registers lost 3.6 % of the words: profiles/r06_cfg4_fused.md).
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t l2_rsrc(const float *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, 0x7fffffff, 0x00020000);
+}
+template <int MF> __device__ __forceinline__ f4 l2_ldm(const float *img, __amdgpu_buffer_rsrc_t rs, int soff, unsigned lo)
+{
+    if constexpr (MF == 2) return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, 4u * lo, 4 * soff, 17));
+    else return l2_ld(l2_sbase(img + soff) + lo);
+}
+// The store's scalar offset is folded into the vector offset: with a REGISTER soffset the compiler assumes that a VALU write of the data
+// registers right behind a 16-byte buffer store is safe (GCNHazardRecognizer: "this hazard only exists if the instruction is not using a
+// register in the soffset field") and schedules one there; on gfx950 that write reached the store -- one store instruction of the
+// 256 x 256 forward kernel wrote garbage in every run, others under load only (profiles/r06_cfg4_fused.md).  With soffset 0 the
+// recogniser inserts the wait state itself.
+template <int MF> __device__ __forceinline__ void l2_stm(float *img, __amdgpu_buffer_rsrc_t rs, int soff, unsigned lo, f4 v)
+{
+    if constexpr (MF == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rs, 4u * (lo + (unsigned)soff), 0, 16);
+    else l2_st(l2_sbase(img + soff) + lo, v);
 }
 // The intermediate image between the two passes is the library's own: instead of the plain transposed image
 // Z[j + 512 o] the first pass writes it in blocks of 16 W source columns, Zb[(j / 16 W) * 512 * 16 W + o * 16 W + j % 16 W],
@@ -229,7 +259,7 @@ template <int HALO, int D> __device__ __forceinline__ f2 l2_nbr(f2 v, bool edge_
 
 // one packet level on register-index bit K (see lat_level of wx_lattice.hip); both halves of an element (two adjacent
 // columns) take the same rotation: v_pk_fma_f32
-template <int K, int HALO, int NS, bool INV> __device__ __forceinline__ void l2_level(f2 (&x)[64], const WxLat2 &cf, int lane)
+template <int K, int HALO, int NS, bool INV, typename CF> __device__ __forceinline__ void l2_level(f2 (&x)[64], const CF &cf, int lane)
 {
     constexpr int NSEQ = 1 << K, M = 32 >> K, S = 1 << K;
     auto U = [](int s, int m) { return s + ((2 * m) << K); };
@@ -331,20 +361,17 @@ __device__ __forceinline__ void l2_t2(f2 (&a)[64], f2 (&bb)[64], unsigned lds0, 
 
 // forward: src image (column j = 512 contiguous samples at src + 512 j) -> dst image transposed and in packet order:
 // dst[j + 512 o(i)], o(i) = bitreverse6(i[5:0]) << 3 | i[8:6].  grid (16, images), 128 threads.
-template <int NS, bool BL, bool BS, int HB>
-__global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_colT_f32(
-    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf, WxL2M mm)
+// simg / dimg: the unit's images (HB = 1: two consecutive ones) in the source and the destination; bx: the workgroup's column block
+// ME = false: compiled without the 8 x 8 matrix of the levels below the lattice's depth (the fused kernel: see k_lat2d_fused_f32)
+template <int NS, bool BL, bool BS, int HB, int MF, bool ME = true, typename CF, typename MM>
+__device__ __forceinline__ void l2_fwd_body(const float *__restrict__ simg, float *__restrict__ dimg, int bx, const CF &cf, const MM &mm,
+                                            unsigned ldsb, int tid)
 {
     typedef L2G<HB> G;
-    __shared__ double lds[WX_L2D_W * WX_L2_WIN];
-    const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
-    // HB = 1: a workgroup takes two consecutive images; the last workgroup of an odd batch re-does the last two
-    const int64_t img0 = min((int)blockIdx.y << G::IB, last_img);
-    const float *simg = src + img0 * G::IMG;
-    float *dimg = dst + img0 * G::IMG;
-    const int j0 = 2 * G::NPW * (WX_L2D_W * blockIdx.x + wave);
+    const __amdgpu_buffer_rsrc_t rs = l2_rsrc(MF == 2 ? simg : dimg);      // the ring side of a fused pass
+    const int j0 = 2 * G::NPW * (WX_L2D_W * bx + wave);
     f2 a[64];
     {
         // loads: instruction Q = (cp, i8, i7) [HB = 2: (cp, i9, i8, i7)] covers 8 complete lines: lane = sub | h << 3 | i5 << 4 |
@@ -355,7 +382,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
         f4 r[32];
         l2_for<32>([&](auto Q) {
             constexpr int cp = Q / QS, sq = Q % QS;
-            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL, HB>(j0 + 2 * cp, 128 * sq)) + lo);
+            r[Q] = l2_ldm<MF>(simg, rs, (int)l2_src_off<BL, HB>(j0 + 2 * cp, 128 * sq), lo);
         });
         // T1: the two columns of a pair meet in one 8-byte slot (two ds_write_b32): slot = 17 lam + m, lam = i[8:6] | cp << 3,
         // m = i[5:2]; round rho = i[1:0]
@@ -429,7 +456,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
                 const int s9 = (rr >> 1) & 1;
                 return *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (4 * s9))));
             };
-            if (mm.e) {
+            if (ME && mm.e) {
                 // the levels below depth 7: a thread takes the 8 rows of a node (o bits 2..0 = rr bits 1, 0, 2) for its column pairs
                 const int g = tid / LPR, u = tid % LPR;
                 f4 in[8], out[8];
@@ -445,7 +472,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int o = row_o(8 * g + (4 * (e & 1) + ((e >> 1) & 1) + 2 * (e >> 2)));
-                    l2_st(l2_sbase(dimg + (BS ? G::BLK : G::BW) * blockIdx.x) + (unsigned)((BS ? G::BW : G::R) * o + 4 * u), out[e]);
+                    l2_stm<MF>(dimg, rs, (BS ? G::BLK : G::BW) * bx, (unsigned)((BS ? G::BW : G::R) * o + 4 * u), out[e]);
                 }
             } else {
             l2_for<256 / RPI>([&](auto Kq) {
@@ -453,7 +480,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
                 const int rr = RPI * k + tid / LPR, u = tid % LPR;
                 const f4 val = row_ld(rr, u);
                 const int o = row_o(rr);
-                l2_st(l2_sbase(dimg + (BS ? G::BLK : G::BW) * blockIdx.x) + (unsigned)((BS ? G::BW : G::R) * o + 4 * u), val);
+                l2_stm<MF>(dimg, rs, (BS ? G::BLK : G::BW) * bx, (unsigned)((BS ? G::BW : G::R) * o + 4 * u), val);
             });
             }
             l2_barrier();
@@ -494,7 +521,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             const int o2 = (rr >> 2) & 1;
             return *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (8 * o2))));
         };
-        if (mm.e) {
+        if (ME && mm.e) {
             // the levels below the lattice's depth: a thread takes the 8 rows of a node for its column pairs.  HB = 0: the node's
             // samples are rows 8 g .. 8 g + 7 in order; HB = 1: o bits 2..0 = rr bits 1, 0, 3, the image bit rr2 belongs to the group
             const int g = tid / LPR, u = tid % LPR;
@@ -516,7 +543,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             for (int e = 0; e < 8; ++e) {
                 int im;
                 const int o = row_o(node_row(e), im);
-                l2_st(l2_sbase(dimg + (BS ? G::BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * o + 4 * u), out[e]);
+                l2_stm<MF>(dimg, rs, (BS ? G::BLK : 16 * WX_L2D_W) * bx, (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * o + 4 * u), out[e]);
             }
         } else {
         l2_for<128 / RPI>([&](auto Kq) {
@@ -525,7 +552,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             const f4 val = row_ld(rr, u);
             int im;
             const int o = row_o(rr, im);
-            l2_st(l2_sbase(dimg + (BS ? G::BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * o + 4 * u), val);
+            l2_stm<MF>(dimg, rs, (BS ? G::BLK : 16 * WX_L2D_W) * bx, (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * o + 4 * u), val);
         });
         }
         l2_barrier();
@@ -566,19 +593,15 @@ __device__ __forceinline__ void l2_t2i(f2 (&bb)[64], f2 (&a)[64], unsigned lds0,
 
 // inverse: src image (column j = 512 contiguous packet coefficients, position o(i) = bitreverse6(i[5:0]) << 3 | i[8:6]) ->
 // dst image transposed, natural order: dst[j + 512 i].  grid (16, images), 128 threads.
-template <int NS, bool BL, bool BS, int HB>
-__global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_icolT_f32(
-    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf, WxL2M mm)
+template <int NS, bool BL, bool BS, int HB, int MF, bool ME = true, typename CF, typename MM>
+__device__ __forceinline__ void l2_inv_body(const float *__restrict__ simg, float *__restrict__ dimg, int bx, const CF &cf, const MM &mm,
+                                            unsigned ldsb, int tid)
 {
     typedef L2G<HB> G;
-    __shared__ double lds[HB == 2 ? (256 * 18 > WX_L2D_W * WX_L2_WIN ? 256 * 18 : WX_L2D_W * WX_L2_WIN) : WX_L2D_W * WX_L2_WIN];
-    const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = ldsb + 8u * WX_L2_WIN * wave;
-    const int64_t img0 = min((int)blockIdx.y << G::IB, last_img);
-    const float *simg = src + img0 * G::IMG;
-    float *dimg = dst + img0 * G::IMG;
-    const int j0 = 2 * G::NPW * (WX_L2D_W * blockIdx.x + wave);
+    const __amdgpu_buffer_rsrc_t rs = l2_rsrc(MF == 2 ? simg : dimg);
+    const int j0 = 2 * G::NPW * (WX_L2D_W * bx + wave);
     f2 bb[64];
     {
         // loads as in the forward kernel, in packet order: lane = sub | h << 3 | o5 << 4 | o6 << 5, instruction (cp, o7, o8);
@@ -591,9 +614,9 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
         f4 r[32];
         l2_for<32>([&](auto Q) {
             constexpr int cp = Q / QS, sq = Q % QS;
-            r[Q] = l2_ld(l2_sbase(simg + l2_src_off<BL, HB>(j0 + 2 * cp, 128 * sq)) + lo);
+            r[Q] = l2_ldm<MF>(simg, rs, (int)l2_src_off<BL, HB>(j0 + 2 * cp, 128 * sq), lo);
         });
-        if (mm.e) {
+        if (ME && mm.e) {
             // undo the levels below the lattice's depth first: the 8 coefficients of a node are 8 consecutive floats of the column -- this
             // lane's vector and its neighbour's (lane ^ 1: sub bit 0 is memory index bit 2); x = M^T y
             const bool up = lane & 1;
@@ -739,7 +762,7 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
                 const int rr = RPI * k + tid / LPR, u = tid % LPR;
                 const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)(2 * u)));
                 const int i = (rr >> 4) | (rho << 4) | ((rr & 15) << 6);
-                l2_st(l2_sbase(dimg + (BS ? G::BLK : G::BW) * blockIdx.x) + (unsigned)((BS ? G::BW : G::R) * i + 4 * u), val);
+                l2_stm<MF>(dimg, rs, (BS ? G::BLK : G::BW) * bx, (unsigned)((BS ? G::BW : G::R) * i + 4 * u), val);
             });
             l2_barrier();
         });
@@ -764,31 +787,184 @@ __global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(W
             const int s86 = rr >> 4;
             const f4 val = *(const f4 __attribute__((address_space(3))) *)(uintptr_t)(ldsb + 8u * ((unsigned)RS * rr + (unsigned)((2 * u) ^ (s86 << 1))));
             const int i9 = (rr & 15) | (rho << 4) | (s86 << 6), im = i9 >> G::RB, i = i9 & (G::R - 1);
-            l2_st(l2_sbase(dimg + (BS ? G::BLK : 16 * WX_L2D_W) * blockIdx.x) + (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * i + 4 * u), val);
+            l2_stm<MF>(dimg, rs, (BS ? G::BLK : 16 * WX_L2D_W) * bx, (unsigned)(im * G::IMG + (BS ? 16 * WX_L2D_W : G::R) * i + 4 * u), val);
         });
         l2_barrier();
     });
 }
 
+// one launch per pass: grid (column blocks, units)
+template <int NS, bool BL, bool BS, int HB>
+__global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_colT_f32(
+    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf, WxL2M mm)
+{
+    typedef L2G<HB> G;
+    __shared__ double lds[WX_L2D_W * WX_L2_WIN];
+    const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    // HB = 1: a workgroup takes two consecutive images; the last workgroup of an odd batch re-does the last two
+    const int64_t img0 = min((int)blockIdx.y << G::IB, last_img);
+    l2_fwd_body<NS, BL, BS, HB, 0>(src + img0 * G::IMG, dst + img0 * G::IMG, blockIdx.x, cf, mm, ldsb, threadIdx.x);
+}
+template <int NS, bool BL, bool BS, int HB>
+__global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_icolT_f32(
+    const float *__restrict__ src, float *__restrict__ dst, int last_img, WxLat2 cf, WxL2M mm)
+{
+    typedef L2G<HB> G;
+    __shared__ double lds[HB == 2 ? (256 * 18 > WX_L2D_W * WX_L2_WIN ? 256 * 18 : WX_L2D_W * WX_L2_WIN) : WX_L2D_W * WX_L2_WIN];
+    const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int64_t img0 = min((int)blockIdx.y << G::IB, last_img);
+    l2_inv_body<NS, BL, BS, HB, 0>(src + img0 * G::IMG, dst + img0 * G::IMG, blockIdx.x, cf, mm, ldsb, threadIdx.x);
+}
+
+// ---- both passes in ONE persistent launch, the intermediate image in a ring that stays in the Infinity Cache (round 6) -----------------
+// Two launches move every image four times through HBM (read, write the intermediate, read it, write): PMC traffic 2.0 x the
+// algorithmic bytes, each pass at 0.72 of the HBM peak, the transform at 0.35 (profiles/r05_cfg4.md).  Here the workgroups of one launch
+// draw tickets; ticket t of step s is a first-pass task of group s (even t) or a second-pass task of group s - D (odd t), a group
+// being G units (a unit = one 512 x 512 / 1024 x 1024 image or two 256 x 256 images) = TPG tasks of 128 KiB.  The intermediate of group
+// g lives in slot g mod K of a ring of K G units, so a line of the ring is written, read D steps later and overwritten K steps later --
+// often enough to stay in the 256 MiB Infinity Cache, which serves it at more than the HBM rate while HBM moves the images only
+// (tools/dbg/ring_probe.hip: the access shapes alone 3.12 ms in two launches, 2.25 ms through a 128 MiB ring).  Per slot two cumulative
+// counters: p1[slot] counts finished first-pass tasks, p2[slot] finished second-pass tasks; tenant r = g / K of a slot reads after
+// p1 >= (r + 1) TPG and writes after p2 >= r TPG (the previous tenant is consumed).  Tickets are drawn in order and a task only
+// waits for tasks with smaller tickets, which are running or done: no deadlock whatever the residency.  Hand-off protocol: every storing
+// wave waits for vmcnt(0), workgroup barrier, one lane adds to the counter (agent scope); the consumer's lane polls with an sc1 load,
+// workgroup barrier, then the flavour-2 loads (MI355X_MICROARCH.md, inter-workgroup visibility, third row of the table).
+struct WxL2Fuse {
+    unsigned *ctl;            // [0] ticket, [32 (1 + 2 s)] p1 of slot s, [32 (2 + 2 s)] p2 of slot s: zeroed before the launch
+    int units, G, D, K, NG;
+};
+// The coefficients come through a pointer into constant memory that is laundered once per task: as by-value kernel arguments (87
+// scalar registers loaded at entry) they stayed live around the whole ticket loop with both bodies inlined -- 220 scalar registers
+// spilled into vector lanes, 110 vector registers into scratch.  So do the lane constants: everything derived from the thread index is
+// recomputed per task instead of being kept across it.
+struct WxL2Consts {
+    WxLat2 cf;
+    WxL2M mm;
+};
+typedef const WxL2Consts __attribute__((address_space(4))) *l2_cst;
+#define WX_L2F_MAXK 24
+// ME: with / without the matrix of the deeper levels -- inside the ticket loop its 64 entries cost the 256 x 256 forward kernels 89 ... 194
+// spilled registers whether a launch uses them or not, so a transform at the lattice's own depth (config 4) gets a kernel without them
+template <int NS, bool INV, int HB, bool ME>
+__global__ __launch_bounds__(64 * WX_L2D_W) __attribute__((amdgpu_waves_per_eu(WX_L2D_WPE, WX_L2D_WPE))) void k_lat2d_fused_f32(
+    const float *__restrict__ src, float *__restrict__ ring, float *__restrict__ dst, int last_img, WxL2Fuse fz, const WxL2Consts *__restrict__ cst)
+{
+    typedef L2G<HB> G;
+    __shared__ double lds[(INV && HB == 2) ? (256 * 18 > WX_L2D_W * WX_L2_WIN ? 256 * 18 : WX_L2D_W * WX_L2_WIN) : WX_L2D_W * WX_L2_WIN];
+    __shared__ unsigned s_t, s_r;
+    const unsigned ldsb = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int tid0 = threadIdx.x;
+    constexpr int TPU = G::R / G::BW;                     // tasks (column blocks) per unit
+    const int TPG = fz.G * TPU;
+    const unsigned total = (unsigned)(fz.NG + fz.D) * 2u * (unsigned)TPG;
+    // what ticket t is: pass, group, task of the group; the counter its task waits for and the value it waits for (0 = nothing)
+    auto decode = [&](unsigned t, int &second, int &g, int &k, bool &in_range) {
+        const int step = t / (2u * TPG), r = t % (2u * TPG);
+        second = r & 1;
+        k = r >> 1;
+        g = second ? step - fz.D : step;
+        in_range = g >= 0 && g < fz.NG;
+    };
+    auto dependency = [&](int second, int g, const unsigned *&c) -> unsigned {
+        const int slot = g % fz.K, tenant = g / fz.K;
+        c = &fz.ctl[32 * ((second ? 1 : 2) + 2 * slot)];
+        return second ? (unsigned)(tenant + 1) * TPG : (unsigned)tenant * TPG;
+    };
+    // The per-task bookkeeping stays off the critical path: the NEXT ticket is drawn when a task starts (its value is looked at only
+    // behind the arithmetic), the counter the next task depends on is loaded by one lane behind the last store of
+    // the current task (hook; with the arithmetic's registers still live it cost 30 ... 80 spilled registers) and compared at its end -- a
+    // task whose dependency was seen satisfied there starts loading at once.  (Drawing
+    // the ticket, polling and three barriers at the start of every task: 2.78 ms on config 4; this form: see profiles/r06_cfg4_fused.md.)
+    if (tid0 == 0) {
+        s_t = __hip_atomic_fetch_add(&fz.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_r = 0;
+    }
+    __syncthreads();
+    unsigned t = __builtin_amdgcn_readfirstlane(s_t), ready = 0;
+    while (t < total) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        l2_cst cp = (l2_cst)(uintptr_t)cst;
+        asm volatile("" : "+s"(cp));
+        unsigned nt = 0, pv = 0, need_n = 0;
+        if (tid == 0) nt = __hip_atomic_fetch_add(&fz.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int second, g, k;
+        bool in_range;
+        decode(t, second, g, k, in_range);
+        const int u = g * fz.G + k / TPU, bx = k % TPU;
+        const bool work = in_range && u < fz.units;
+        const int slot = in_range ? g % fz.K : 0;
+        if (work) {
+            float *zimg = ring + ((size_t)slot * fz.G + k / TPU) * ((size_t)G::IMG << G::IB);
+            if (!ready) {
+                const unsigned *c;
+                const unsigned need = dependency(second, g, c);
+                if (need) {
+                    if (tid == 0)
+                        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+                    __syncthreads();
+                }
+            }
+            auto hook = [&]() {
+                if (tid == 0) {
+                    const unsigned ntu = __builtin_amdgcn_readfirstlane(nt);
+                    if (ntu < total) {
+                        int s2, g2, k2;
+                        bool ir2;
+                        decode(ntu, s2, g2, k2, ir2);
+                        if (ir2) {
+                            const unsigned *c;
+                            need_n = dependency(s2, g2, c);
+                            if (need_n) pv = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            };
+            const int64_t img0 = min(u << G::IB, last_img);
+            // the two bodies are laundered apart as well: with common subexpressions shared across the branch the 256 x 256 forward
+            // kernels spilled 89 ... 194 registers
+            if (!second) {
+                asm volatile("" : "+v"(tid), "+s"(cp));
+                if constexpr (INV) l2_inv_body<NS, false, true, HB, 1, ME>(src + img0 * G::IMG, zimg, bx, cp->cf, cp->mm, ldsb, tid);
+                else l2_fwd_body<NS, false, true, HB, 1, ME>(src + img0 * G::IMG, zimg, bx, cp->cf, cp->mm, ldsb, tid);
+            } else {
+                asm volatile("" : "+v"(tid), "+s"(cp));
+                if constexpr (INV) l2_inv_body<NS, true, false, HB, 2, ME>(zimg, dst + img0 * G::IMG, bx, cp->cf, cp->mm, ldsb, tid);
+                else l2_fwd_body<NS, true, false, HB, 2, ME>(zimg, dst + img0 * G::IMG, bx, cp->cf, cp->mm, ldsb, tid);
+            }
+            // the next task's dependency: its counter is loaded behind the last stores of this task, whose acknowledgements are waited for anyway
+            hook();
+            // every wave waits for its own accesses (the ring stores are acknowledged, the ring loads have landed), then one lane signals
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (tid == 0) {
+            if (in_range)                                      // the tasks of a ragged last group beyond the batch count too
+                __hip_atomic_fetch_add(&fz.ctl[32 * ((second ? 2 : 1) + 2 * slot)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_t = nt;
+            s_r = (work && pv >= need_n) ? 1u : 0u;            // need_n = 0: nothing to wait for, or nothing looked at (then the start polls)
+        }
+        __syncthreads();
+        t = __builtin_amdgcn_readfirstlane(s_t);
+        ready = __builtin_amdgcn_readfirstlane(s_r);
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
-// launch of one transposing pass for geometry HB (0: 512 x 512, 1: 256 x 256, 2: 1024 x 1024): one translation unit per geometry
-// (wx_lattice2d.hip, wx_lattice2d_256.hip, wx_lattice2d_1024.hip) so that the 60 kernels of each compile in parallel
-template <int HB>
-static int wx_lattice2d_launch(const float *src, float *dst, int64_t m, int L, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
+// coefficients of the lattice and the matrix of the levels below its depth; false = this filter / depth is not ours
+template <int HB> static bool l2_prepare(const WxFilt &filt, int L, bool inverse, WxLat2 &cf, WxL2M &mm)
 {
-    static const bool blocked = WX_L2D_W == 4 && !(wx_getenv("WX_L2D_BLOCKED") && atoi(wx_getenv("WX_L2D_BLOCKED")) == 0);
     constexpr int LD = L2G<HB>::LD;
     double p[WX_L2_MAXS], kap[WX_L2_MAXS], g0, g2;
-    if (!wx_lattice_coeffs(filt, LD, inverse, p, kap, &g0, &g2)) return 0;
-    WxLat2 cf;
+    if (!wx_lattice_coeffs(filt, LD, inverse, p, kap, &g0, &g2)) return false;
     for (int j = 0; j < WX_L2_MAXS; ++j) { cf.p[j] = (float)p[j]; cf.kap[j] = (float)kap[j]; }
     cf.g0 = (float)g0;
     cf.g2 = (float)g2;
     // depths beyond the lattice's: e = L - LD levels on the 8-sample nodes as one matrix (columns = images of the unit vectors)
-    WxL2M mm;
     mm.e = L - LD;
-    if (mm.e < 0 || mm.e > 3) return 0;
+    if (mm.e < 0 || mm.e > 3) return false;
     for (int c = 0; c < 8; ++c) {
         double v[8], w[8];
         for (int i = 0; i < 8; ++i) v[i] = i == c ? 1.0 : 0.0;
@@ -811,6 +987,101 @@ static int wx_lattice2d_launch(const float *src, float *dst, int64_t m, int L, i
         }
         for (int r = 0; r < 8; ++r) mm.m[r][c] = (float)v[r];
     }
+    return true;
+}
+
+// geometry of the fused launch for `batch` images: groups of 8 MiB (64 tasks), second pass 12 groups behind the first (1536 tickets: three
+// times the tasks in flight on 256 CUs -- the dependency of a task is looked at while the task before it computes), ring of 24 groups =
+// 192 MiB (profiles/r06_cfg4_fused.md: 2.69 ms; 8 / 16 groups 2.75 ms; less than 64 MiB behind: 3.3 ... 4.1 ms); a batch of at most 24
+// groups is its own ring (no slot is reused).  WX_L2F_G / _D / _K (knobs) override.
+template <int HB> static void l2_fuse_plan(int64_t batch, WxL2Fuse &fz)
+{
+    typedef L2G<HB> G;
+    static const int eg = wx_getenv("WX_L2F_G") ? atoi(wx_getenv("WX_L2F_G")) : 0, ed = wx_getenv("WX_L2F_D") ? atoi(wx_getenv("WX_L2F_D")) : 0,
+                     ek = wx_getenv("WX_L2F_K") ? atoi(wx_getenv("WX_L2F_K")) : 0;
+    const int64_t per = HB == 1 ? 2 : 1;
+    fz.units = (int)((batch + per - 1) / per);
+    fz.G = eg > 0 ? eg : 64 / (G::R / G::BW);
+    fz.D = ed > 0 ? ed : 12;
+    fz.K = ek > fz.D ? ek : 2 * fz.D;
+    if (fz.K > WX_L2F_MAXK) fz.K = WX_L2F_MAXK;
+    if (fz.D >= fz.K) fz.D = fz.K - 1;
+    fz.NG = (fz.units + fz.G - 1) / fz.G;
+    if (fz.NG <= fz.K) fz.K = fz.NG;
+}
+// elements of the ring the fused launch needs for `batch` images of geometry HB
+template <int HB> static int64_t wx_lattice2d_ring_elems_t(int64_t batch)
+{
+    WxL2Fuse fz;
+    l2_fuse_plan<HB>(batch, fz);
+    const int64_t slots = (int64_t)fz.K * fz.G;           // a batch that is its own ring (K = NG) needs its units only
+    return (slots < fz.units ? slots : (int64_t)fz.units) * ((int64_t)L2G<HB>::IMG << L2G<HB>::IB);
+}
+
+// both passes of a transform in one persistent launch (k_lat2d_fused_f32): 0 = not applicable, 1 = launched, < 0 = error.  ring: at least
+// wx_lattice2d_ring_elems elements; ctl: WX_L2F_CTL_BYTES bytes, both the caller's scratch on the same stream
+#define WX_L2F_CTL_BYTES (4 * 32 * (2 + 2 * WX_L2F_MAXK))
+template <int HB>
+static int wx_lattice2d_fused_launch(const float *src, float *dst, float *ring, unsigned *ctl, int64_t m, int L, int64_t batch, const WxFilt &filt,
+                                     bool inverse, hipStream_t st)
+{
+    WxL2Consts hc;
+    memset(&hc, 0, sizeof hc);                                // the upload is cached by content: no stray padding bytes
+    if (!l2_prepare<HB>(filt, L, inverse, hc.cf, hc.mm)) return 0;
+    const int64_t per = HB == 1 ? 2 : 1, units = (batch + per - 1) / per;
+    if (batch < per || units > 65535 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)ring & 15)) return 0;
+    if ((batch & (per - 1)) && src == dst) return 0;          // the last unit re-does an image: out of place only
+    WxL2Fuse fz;
+    l2_fuse_plan<HB>(batch, fz);
+    fz.ctl = ctl;
+    static std::atomic<int> cus_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    int cus = cus_of[dev & 63].load(std::memory_order_relaxed);
+    if (!cus) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; else (void)hipGetLastError();
+        if (cus <= 0) cus = 256;
+        cus_of[dev & 63].store(cus, std::memory_order_relaxed);
+    }
+    const int64_t tasks = 2 * (int64_t)fz.NG * fz.G * (L2G<HB>::R / L2G<HB>::BW);
+    int64_t nwg = (int64_t)cus * (WX_L2D_WPE * 4 / WX_L2D_W);   // what is resident at once
+    if (nwg > tasks) nwg = tasks;
+    const WxL2Consts *dc = (const WxL2Consts *)wx_const_upload(&hc, sizeof hc, st, true);
+    if (!dc) return WX_EHIP;
+    const hipError_t em = hipMemsetAsync(ctl, 0, WX_L2F_CTL_BYTES, st);
+    if (em != hipSuccess) return wx_set_hip_error(em, "lattice2d fused: counters", __FILE__, __LINE__);
+    const dim3 grid((unsigned)nwg), wg(64 * WX_L2D_W);
+    const int last_img = (int)(batch - per);
+#define WX_GO2F(NSS)                                                                                                       \
+    case NSS:                                                                                                              \
+        if (inverse) {                                                                                                     \
+            if (hc.mm.e) hipLaunchKernelGGL((k_lat2d_fused_f32<NSS, true, HB, true>), grid, wg, 0, st, src, ring, dst, last_img, fz, dc);   \
+            else hipLaunchKernelGGL((k_lat2d_fused_f32<NSS, true, HB, false>), grid, wg, 0, st, src, ring, dst, last_img, fz, dc);          \
+        } else if (hc.mm.e) {                                                                                              \
+            if constexpr (HB == 1) return 0;          /* spills: the two launches are faster */                           \
+            else hipLaunchKernelGGL((k_lat2d_fused_f32<NSS, false, HB, true>), grid, wg, 0, st, src, ring, dst, last_img, fz, dc);          \
+        } else hipLaunchKernelGGL((k_lat2d_fused_f32<NSS, false, HB, false>), grid, wg, 0, st, src, ring, dst, last_img, fz, dc);           \
+        break;
+    switch (filt.F / 2) {
+        WX_GO2F(1) WX_GO2F(2) WX_GO2F(3) WX_GO2F(4) WX_GO2F(5) WX_GO2F(6) WX_GO2F(7) WX_GO2F(8) WX_GO2F(9) WX_GO2F(10)
+    default: return 0;
+    }
+#undef WX_GO2F
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wx_set_hip_error(e, "lattice2d fused launch", __FILE__, __LINE__);
+    return 1;
+}
+
+// launch of one transposing pass for geometry HB (0: 512 x 512, 1: 256 x 256, 2: 1024 x 1024): one translation unit per geometry
+// (wx_lattice2d.hip, wx_lattice2d_256.hip, wx_lattice2d_1024.hip) so that the 60 kernels of each compile in parallel
+template <int HB>
+static int wx_lattice2d_launch(const float *src, float *dst, int64_t m, int L, int64_t batch, const WxFilt &filt, bool inverse, int pass, hipStream_t st)
+{
+    static const bool blocked = WX_L2D_W == 4 && !(wx_getenv("WX_L2D_BLOCKED") && atoi(wx_getenv("WX_L2D_BLOCKED")) == 0);
+    WxLat2 cf;
+    WxL2M mm;
+    if (!l2_prepare<HB>(filt, L, inverse, cf, mm)) return 0;
     const int64_t per = HB == 1 ? 2 : 1, units = (batch + per - 1) / per;
     if (batch < per || units > 65535 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return 0;
     if ((batch & (per - 1)) && src == dst) return 0;          // the last workgroup re-does images: out of place only

@@ -5,6 +5,11 @@
 int wx_lattice2d_launch_256(const float *, float *, int64_t, int, int64_t, const WxFilt &, bool, int, hipStream_t);    // wx_lattice2d_256.hip
 int wx_lattice2d_launch_1024(const float *, float *, int64_t, int, int64_t, const WxFilt &, bool, int, hipStream_t);   // wx_lattice2d_1024.hip
 
+int wx_lattice2d_fused_256(const float *, float *, float *, unsigned *, int64_t, int, int64_t, const WxFilt &, bool, hipStream_t);
+int wx_lattice2d_fused_1024(const float *, float *, float *, unsigned *, int64_t, int, int64_t, const WxFilt &, bool, hipStream_t);
+int64_t wx_lattice2d_ring_elems_256(int64_t batch);
+int64_t wx_lattice2d_ring_elems_1024(int64_t batch);
+
 bool wx_lattice2d_ok(int64_t m, int64_t n, int L, const WxFilt &filt, size_t esz)
 {
     static const bool off = wx_getenv("WX_LATTICE2D") && atoi(wx_getenv("WX_LATTICE2D")) == 0;
@@ -28,4 +33,29 @@ int wx_lattice2d_colT_f32(const float *src, float *dst, int64_t m, int L, int64_
     if (m == 256) return wx_lattice2d_launch_256(src, dst, m, L, batch, filt, inverse, pass, st);
     if (m == 1024) return wx_lattice2d_launch_1024(src, dst, m, L, batch, filt, inverse, pass, st);
     return 0;
+}
+
+// both passes of a transform in one persistent launch, the intermediate image in a ring of wx_lattice2d_ring_elems(m, batch) elements that
+// stays in the Infinity Cache (k_lat2d_fused_f32 in wx_lattice2d.h); ctl: wx_lattice2d_ctl_bytes() bytes of scratch.  0 = not applicable,
+// 1 = launched, < 0 = error
+int wx_lattice2d_fused_f32(const float *src, float *dst, float *ring, unsigned *ctl, int64_t m, int L, int64_t batch, const WxFilt &filt, bool inverse,
+                           hipStream_t st)
+{
+    if (m == 512) return wx_lattice2d_fused_launch<0>(src, dst, ring, ctl, m, L, batch, filt, inverse, st);
+    if (m == 256) return wx_lattice2d_fused_256(src, dst, ring, ctl, m, L, batch, filt, inverse, st);
+    if (m == 1024) return wx_lattice2d_fused_1024(src, dst, ring, ctl, m, L, batch, filt, inverse, st);
+    return 0;
+}
+int64_t wx_lattice2d_ring_elems(int64_t m, int64_t batch)
+{
+    if (m == 512) return wx_lattice2d_ring_elems_t<0>(batch);
+    if (m == 256) return wx_lattice2d_ring_elems_256(batch);
+    if (m == 1024) return wx_lattice2d_ring_elems_1024(batch);
+    return 0;
+}
+size_t wx_lattice2d_ctl_bytes() { return WX_L2F_CTL_BYTES; }
+bool wx_lattice2d_fused_on()
+{
+    static const bool off = wx_getenv("WX_L2D_FUSED") && atoi(wx_getenv("WX_L2D_FUSED")) == 0;
+    return !off;
 }

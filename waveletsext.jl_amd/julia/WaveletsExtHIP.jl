@@ -77,6 +77,8 @@ version() = Int(wx_version())
 device_count() = Int(wx_device_count())
 build_info() = unsafe_string(wx_build_info())
 shutdown() = check(wx_shutdown())
+"MADV_HUGEPAGE advice on host result arrays (on by default, persists on the address range); returns the previous setting"
+set_host_hugepages(on::Bool) = wx_set_host_hugepages(Cint(on)) != 0
 
 qmfvec(wt::OrthoFilter) = Vector{Float64}(WT.qmf(wt))
 "array of the parent's kind (Array stays Array, ROCArray stays ROCArray)"
