@@ -37,7 +37,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); m
 FP64_PEAK_TFLOPS = 78.6        # FP64 vector spec; tools/ubench.hip measures 55-61 on this part
 
 WORKLOADS = {
-    "cfg2": dict(kind="wpd", n=4096, batch=65536, wavelet="db8", L=12, dtype="f64",
+    "cfg2": dict(inv_bound="fp64 issue: an all-VALU Float64 lattice of 8 rotation stages x 12 levels (63 % of the FP64 vector peak on the lattice's own flop count, profiles/r04_fp64_issue.txt); HBM is the roofline the fraction is quoted against",
+                 kind="wpd", n=4096, batch=65536, wavelet="db8", L=12, dtype="f64",
                  kernel="k_lat_wpd_f64<8, 2>", inv_kernel="k_lat_iwpt_f64<8, 2, double>",
                  fwd_kernels=[("k_lat_wpd_f64<8, 2>", 1)],
                  desc="BASELINE config 2: wpdall+iwpdall 65536x4096 f64 db8 full tree L=12"),
@@ -45,7 +46,7 @@ WORKLOADS = {
                    kernel="k_lat_wpt_f64<4, 3, double>", inv_kernel="k_lat_iwpt_f64<4, 2, double>",
                    fwd_kernels=[("k_lat_wpt_f64<4, 3, double>", 1)],
                    desc="north-star target: wptall+iwptall 65536x4096 f64 db4 L=10"),
-    "wpt_db8": dict(kind="wpt", n=4096, batch=65536, wavelet="db8", L=12, dtype="f64",
+    "wpt_db8": dict(inv_bound="fp64 issue (as cfg2's inverse: profiles/r04_fp64_issue.txt)", kind="wpt", n=4096, batch=65536, wavelet="db8", L=12, dtype="f64",
                     kernel="k_lat_wpt_f64<8, 3, double>", inv_kernel="k_lat_iwpt_f64<8, 2, double>",
                     fwd_kernels=[("k_lat_wpt_f64<8, 3, double>", 1)],
                     desc="config 2's signals and filter through wptall+iwptall: 65536x4096 f64 db8 L=12 (the F = 16 lattice kernels)"),
@@ -293,21 +294,31 @@ def cpu_baseline(w, seconds):
             return dt, B * n
         raise ValueError(kind)
 
-    def run_omp(B):
+    def run_omp(B, min_seconds=0.0):
         """all host cores: OpenMP over the batch (1-D decimated workloads only)"""
         n = w["n"]
         tree = wo.maketree1d(n, L, "full").astype(np.uint8)
-        x = np.asfortranarray(rng.standard_normal((n, B)))
+        x0 = np.asfortranarray(rng.standard_normal((n, B)))
+        # every array is first touched by the thread that works on its signals (the static schedule over the batch of the loops in
+        # oracle/wx_oracle.c): the input through a parallel copy, the outputs by an untimed first pass; then passes until `min_seconds`
+        x = np.empty_like(x0)
+        lib.wxo_copy_omp_f64(P(x), P(x0), L64(n), L64(B))
         xh = np.empty_like(x)
         y = np.empty((n, L + 1, B) if kind == "wpd" else (n, B), order="F")
-        t0 = time.perf_counter()
-        if kind == "wpd":
-            lib.wxo_wpd_iwpd_roundtrip_omp_f64(P(xh), P(y), P(x), L64(n), I(L), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
-        else:
-            lib.wxo_wpt_iwpt_roundtrip_omp_f64(P(xh), P(y), P(x), L64(n), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
-        dt = time.perf_counter() - t0
+
+        def one():
+            if kind == "wpd":
+                lib.wxo_wpd_iwpd_roundtrip_omp_f64(P(xh), P(y), P(x), L64(n), I(L), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
+            else:
+                lib.wxo_wpt_iwpt_roundtrip_omp_f64(P(xh), P(y), P(x), L64(n), L64(B), P(tree), L64(tree.size), P(q), I(q.size))
+        one()
         assert np.abs(xh - x).max() < 1e-9
-        return dt, B * n
+        t0, passes = time.perf_counter(), 0
+        while passes == 0 or time.perf_counter() - t0 < min_seconds:
+            one()
+            passes += 1
+        dt = time.perf_counter() - t0
+        return dt, B * n * passes
 
     probe = 16 if kind in ("wpd", "wpt") else 2
     run(probe)                                   # first call: library load, page faults
@@ -322,10 +333,10 @@ def cpu_baseline(w, seconds):
     if kind in ("wpd", "wpt") and not w.get("tree"):
         nthr = int(lib.wxo_omp_max_threads())
         Bo = int(min(16384, max(256, B * max(1, nthr // 4))))
-        run_omp(min(Bo, 1024))
-        dto, so = run_omp(Bo)
+        dto, so = run_omp(Bo, min_seconds=max(5.0, seconds / 2))
         out["all_cores"] = {"value": so / dto / 1e6, "unit": "Msamples/s", "cores": nthr, "kind": "port",
-                            "sample": "%d signals, OpenMP over the batch, %.1f s" % (Bo, dto)}
+                            "sample": "%d signals x %d passes, OpenMP over the batch, every array first touched by its thread, %.1f s"
+                                      % (Bo, so // (Bo * w["n"]), dto)}
     return out
 
 
@@ -916,11 +927,19 @@ def main():
         # HBM traffic of one forward pass = sum over its kernels (launches per pass x PMC bytes per launch)
         # from separate rocprofv3 --pmc passes of this same command (profiles/traffic.json, written by
         # tools/collect_evidence.py); null if not profiled.  `kernel` names the dominant one.
-        traffic = None
+        traffic, traffic_stale = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(a.workload, {})
             if not a.batch and world == 1:
                 traffic = sum(cnt * tj[name]["hbm_bytes_per_launch"] for name, cnt in w["fwd_kernels"])
+                # the counters belong to the build they were taken with: tools/collect_evidence.py records its source digest
+                # (wx_build_info's src=...); another build gets null and says why
+                import re as _re
+                cur = _re.search(r"src=(\w+)", wx.build_info())
+                made = tj.get("_build_src")
+                if made != (cur.group(1) if cur else None):
+                    traffic_stale = "profiles/traffic.json holds the counters of build src=%s, this library is src=%s" % (made, cur.group(1) if cur else None)
+                    traffic = None
         except Exception:
             traffic = None
         fb = float(info["fwd_bytes"])
@@ -933,7 +952,9 @@ def main():
             roof = {"bound": "fp64 (vector + matrix pipe share the FP64 rate; flops counted for the direct form)", "kernel": w["kernel"], "achieved": achieved,
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                     "algorithmic_flops_per_step": info["fwd_flops"], "hbm_GBs": fb / (fwd_avg * 1e-3) / 1e9}
-        roof["traffic_source"] = "profiles/traffic.json (offline rocprofv3 --pmc passes of this command, not measured in this run)" if traffic is not None else None
+        roof["traffic_source"] = "profiles/traffic.json (offline rocprofv3 --pmc passes of this command with this build, not measured in this run)" if traffic is not None else None
+        if traffic_stale:
+            roof["traffic_stale"] = traffic_stale
         roof.update({"avg_launch_ms": fwd_avg, "median_launch_ms": fwd_ms[len(fwd_ms) // 2],
                      "launches_per_step": len(fwd_ms) // a.steps,
                      "fwd_TFLOPs_direct_form": info["fwd_flops"] / (fwd_avg * 1e-3) / 1e12})
@@ -959,7 +980,8 @@ def main():
             "inverse": {"kernel": w.get("inv_kernel"), "avg_launch_ms": inv_avg,
                         "algorithmic_bytes_per_launch": float(info["inv_bytes"]),
                         "achieved_GBs": info["inv_bytes"] / (inv_avg * 1e-3) / 1e9,
-                        "frac": info["inv_bytes"] / (inv_avg * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                        "frac": info["inv_bytes"] / (inv_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "bound": w.get("inv_bound", "hbm")},
             "roundtrip_rel_err": err,
             "build": wx.build_info(),
             "ranks": {"nranks": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,

@@ -318,6 +318,13 @@ void wxo_wpd_iwpd_roundtrip_omp_f64(double *xh, double *y, const double *x, int6
         wxo_iwpd1d_tree_f64(xh + b * n, y + b * n * (L + 1), n, L + 1, tree, ntree, qmf, F);
     }
 }
+/* first touch by the thread that will work on the signal (the same static schedule over the batch as the loops around this): dst = src */
+void wxo_copy_omp_f64(double *dst, const double *src, int64_t n, int64_t B)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; b++)
+        for (int64_t i = 0; i < n; i++) dst[b * n + i] = src[b * n + i];
+}
 void wxo_wpt_iwpt_roundtrip_omp_f64(double *xh, double *y, const double *x, int64_t n, int64_t B,
                                     const uint8_t *tree, int64_t ntree, const double *qmf, int F)
 {

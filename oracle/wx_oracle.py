@@ -12,7 +12,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libwx_oracle.so")
+# WX_ORACLE_SAN=1: the AddressSanitizer / UBSan build of the checker (tools/oracle_san.sh; python must run with the sanitizer runtime
+# preloaded, which that script arranges)
+_SAN = os.environ.get("WX_ORACLE_SAN", "") == "1"
+_SO = os.path.join(_HERE, "libwx_oracle_san.so" if _SAN else "libwx_oracle.so")
 
 
 def build(force=False):
@@ -20,7 +23,7 @@ def build(force=False):
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
         for f in ("wx_oracle.c", "wx_oracle_impl.h"))
     if force or src_newer:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libwx_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(_SO)], stdout=subprocess.DEVNULL)
     return _SO
 
 

@@ -69,8 +69,9 @@ def test_1d_packets_of_offset_pointers(wx, oracle, unaligned_outputs, wname, dty
             tab = wx.wpdall(xd, wt, L)
             expt = oracle.wpdall(x, wt.qmf, L)
             assert relerr(_np(tab), expt) <= tol, ("wpdall", n, L)
-            back = wx.iwpdall(_off(expt.astype(dtype)), wt, L)
-            assert relerr(_np(back), x) <= 10 * tol, ("iwpdall", n, L)
+            if n & (n - 1) == 0:
+                back = wx.iwpdall(_off(expt.astype(dtype)), wt, L)
+                assert relerr(_np(back), x) <= 10 * tol, ("iwpdall", n, L)
         if n & (n - 1):
             continue
         # pyramids and random trees

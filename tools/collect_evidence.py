@@ -14,6 +14,14 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import summarize_prof  # noqa: E402
 
 
+def build_src():
+    import re
+    sys.path.insert(0, ROOT)
+    import waveletsext_jl_amd as wx
+    m = re.search(r"src=(\w+)", wx.build_info())
+    return m.group(1) if m else None
+
+
 def main(tag, prefix):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}      # workloads not in this run keep their entries
@@ -28,11 +36,15 @@ def main(tag, prefix):
                               "source": "profiles/%s_%s.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
                                         "FETCH_SIZE doubled per MI355X_MICROARCH.md)" % (prefix, w)}
                           for k, v in pm.items() if k.startswith("k_") and "hbm_bytes_per_launch" in v}
+            # the counters belong to the build that was profiled -- the library in this tree, this script runs right behind the
+            # profiler (tools/refresh_evidence.sh): its source digest goes with them, bench.py reports `traffic` for that digest only
+            traffic[w]["_build_src"] = build_src()
         b = os.path.join(ROOT, "gpurun_out", "bench_" + tag, w + ".json")
         if os.path.exists(b) and os.path.getsize(b):
             line = open(b).read().strip().splitlines()[-1]
             json.loads(line)
             open(os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (prefix, w)), "w").write(line + "\n")
+
     json.dump(traffic, open(tpath, "w"), indent=1)
     log = os.path.join(ROOT, "gpurun_out", "pytest_gpu_%s.log" % tag)
     if os.path.exists(log):

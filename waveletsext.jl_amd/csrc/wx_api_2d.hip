@@ -194,7 +194,13 @@ static int api_wpt2d(const T *x, T *y, int64_t m, int64_t n, int L, const uint8_
         if (r) return io.finish(r < 0 ? r : WX_OK);
     }
     T *tmp = nullptr, *pong = nullptr;
-    if (batch && tr.Leff > 0) { tmp = (T *)scr.alloc(sizeof(T) * m * n * batch); if (!tmp) return io.finish(WX_EHIP); }
+    if (batch && tr.Leff > 0) {
+        // (the ring of the fused 2-D launch is at most the batch, plus one image for an odd batch of 256 x 256 images)
+        int64_t te = m * n * batch;
+        if (wx_lattice2d_ok(m, n, tr.Leff, filt, sizeof(T)) && wx_lattice2d_ring_elems(m, batch) > te) te = wx_lattice2d_ring_elems(m, batch);
+        tmp = (T *)scr.alloc(sizeof(T) * te);
+        if (!tmp) return io.finish(WX_EHIP);
+    }
     if (tr.full && tr.Leff > 0 && !wx_force_generic() && (wx_wpt2d_fast_ok<T>(m, n, F) || wx_lattice2d_ok(m, n, tr.Leff, filt, sizeof(T)))) {
         rc = wx_dev_wpt2d_fast<T>(dx, dy, m, n, tr.Leff, batch, filt, tmp, INVERSE, m * n, st);
         if (rc == WX_OK && tail) rc = wx_dwt2d_tail<T>(dy, m, tail, batch, filt, st);
@@ -244,7 +250,12 @@ static int api_iwpd2d(const T *xw, T *xh, int64_t m, int64_t n, int k, int L, co
         const int r = wx_lattice_2d64(true, dxw + (int64_t)tr.Leff * mn, dxh, tr.Leff, batch, mn * k, filt, st);
         if (r) return io.finish(r < 0 ? r : WX_OK);
     }
-    if (batch && tr.Leff > 0) { tmp = (T *)scr.alloc(sizeof(T) * mn * batch); if (!tmp) return io.finish(WX_EHIP); }
+    if (batch && tr.Leff > 0) {
+        int64_t te = mn * batch;
+        if (wx_lattice2d_ok(m, n, tr.Leff, filt, sizeof(T)) && wx_lattice2d_ring_elems(m, batch) > te) te = wx_lattice2d_ring_elems(m, batch);
+        tmp = (T *)scr.alloc(sizeof(T) * te);
+        if (!tmp) return io.finish(WX_EHIP);
+    }
     if (tr.full && tr.Leff > 0 && !wx_force_generic() && (wx_wpt2d_fast_ok<T>(m, n, F) || wx_lattice2d_ok(m, n, tr.Leff, filt, sizeof(T)))) {
         rc = wx_dev_wpt2d_fast<T>(dxw + (int64_t)tr.Leff * mn, dxh, m, n, tr.Leff, batch, filt, tmp, true, mn * k, st);
         return io.finish(rc);

@@ -16,6 +16,15 @@ static inline const char *wx_getenv(const char *name)
 }
 
 #define WX_MAXF 64            // longest supported QMF (even length)
+
+// Rotation stages the lattice kernels are BUILT for: 1, 2, 4, 6, 8, 10 (round 6; every count 1 ... 10 until then).  A filter of 3, 5, 7 or
+// 9 stages (db3 / coif2, db5, db7, db9 / coif6 ...) runs on the kernel of the next even count: wx_lattice_factor fills the stages a
+// filter does not have with p = kap = 0, and a rotation by zero followed by the unit advance of the odd channel is undone exactly by the
+// realignment at the end of the level -- fma(0, x, y) = y: the results are bit-identical to a kernel of the filter's own length, at the
+// cost of one idle stage (db7 runs like db8).  40 % of the lattice instantiations, which are most of the library's build time and size.
+static constexpr int wx_lat_stages_of(int ns) { return ns <= 2 ? ns : ((ns + 1) & ~1); }
+static constexpr bool wx_lat_built(int ns) { return wx_lat_stages_of(ns) == ns; }
+static inline int wx_lat_stages(int F) { return wx_lat_stages_of(F / 2); }
 #define WX_WAVE 64
 
 // status codes of the C ABI (include/waveletsext_hip.h)

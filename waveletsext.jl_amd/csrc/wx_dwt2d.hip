@@ -600,71 +600,35 @@ int wx_dev_wpt2d_fast(const T *x, T *y, int64_t m, int64_t n, int L, int64_t bat
     if constexpr (sizeof(T) == 4) {
         // 512 x 512 Float32, depth 6: the transposing lattice kernel applied twice (wx_lattice2d.hip)
         if (wx_lattice2d_ok(m, n, L, filt, sizeof(T)) && in_img == mn && !(inverse && wx_getenv("WX_LATTICE2D_NOINV"))) {
-            if (wx_getenv("WX_LATTICE2D_DEBUG")) {                  // diagnostics: one pass only, straight into y
-                const int rd = wx_lattice2d_colT_f32((const float *)x, (float *)y, m, L, batch, filt, inverse, 0, st);
-                return rd == 1 ? WX_OK : WX_EHIP;
-            }
-            // WX_2D_STREAMS=1 with a sub-batch size: column pass of sub-batch k+1 and row pass of sub-batch k on two side
-            // streams (ring of three intermediate slots, events for the hand-over), so that short launches overlap.
-            // Measured (config 4, step = forward + inverse): whole batch 6.88 ms; S = 256: 6.91, 192: 6.94, 128: 7.14,
-            // 96: 8.32, 64: 8.31, 32: 9.92 ms -- no sub-batch size gains, with or without the second stream: the written
-            // intermediate does not come back from the Infinity Cache any faster than from HBM.  Kept as a knob.
-            static const bool two_streams = wx_getenv("WX_2D_STREAMS") && atoi(wx_getenv("WX_2D_STREAMS")) != 0;
-            if (two_streams && S < batch && wx_lattice2d_ok(m, n, L, filt, sizeof(T))) {
-                static hipStream_t sA = nullptr, sB = nullptr;
-                static hipEvent_t ev0 = nullptr, evC[3], evR[3], evE = nullptr;
-                if (!sA) {
-                    WX_HIP_CHECK(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking));
-                    WX_HIP_CHECK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
-                    WX_HIP_CHECK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
-                    WX_HIP_CHECK(hipEventCreateWithFlags(&evE, hipEventDisableTiming));
-                    for (int i = 0; i < 3; ++i) {
-                        WX_HIP_CHECK(hipEventCreateWithFlags(&evC[i], hipEventDisableTiming));
-                        WX_HIP_CHECK(hipEventCreateWithFlags(&evR[i], hipEventDisableTiming));
-                    }
-                }
-                WX_HIP_CHECK(hipEventRecord(ev0, st));
-                WX_HIP_CHECK(hipStreamWaitEvent(sA, ev0, 0));
-                WX_HIP_CHECK(hipStreamWaitEvent(sB, ev0, 0));
-                int64_t kk = 0;
-                for (int64_t b0 = 0; b0 < batch; b0 += S, ++kk) {
-                    const int64_t nb = (batch - b0 < S) ? batch - b0 : S;
-                    const int slot = (int)(kk % 3);
-                    T *ring = tmp + (int64_t)slot * S * mn;
-                    if (kk >= 3) WX_HIP_CHECK(hipStreamWaitEvent(sA, evR[slot], 0));
-                    if (wx_lattice2d_colT_f32((const float *)x + b0 * mn, (float *)ring, m, L, nb, filt, inverse, 1, sA) != 1)
-                        return wx_set_error(WX_EHIP, "lattice2d: pass refused");
-                    WX_HIP_CHECK(hipEventRecord(evC[slot], sA));
-                    WX_HIP_CHECK(hipStreamWaitEvent(sB, evC[slot], 0));
-                    if (wx_lattice2d_colT_f32((const float *)ring, (float *)y + b0 * mn, m, L, nb, filt, inverse, 2, sB) != 1)
-                        return wx_set_error(WX_EHIP, "lattice2d: second pass refused");
-                    WX_HIP_CHECK(hipEventRecord(evR[slot], sB));
-                }
-                WX_HIP_CHECK(hipEventRecord(evE, sB));
-                WX_HIP_CHECK(hipStreamWaitEvent(st, evE, 0));
-                return WX_OK;
-            }
             // round 6: both passes in one persistent launch, the intermediate in a ring of <= 128 MiB of `tmp` that stays in the Infinity
             // Cache (k_lat2d_fused_f32).  A launcher that declines (alignment, in-place odd batches of 256 x 256 images) leaves the two
             // launches below.
-            if (wx_lattice2d_fused_on() && S == batch && wx_lattice2d_ring_elems(m, batch) <= mn * batch) {
+            if (wx_lattice2d_fused_on()) {                       // (`tmp` holds max(mn batch, wx_lattice2d_ring_elems) elements: wx_api_2d.hip)
                 WxScratch fscr(st);
                 unsigned *ctl = (unsigned *)fscr.alloc(wx_lattice2d_ctl_bytes());
                 if (!ctl) return WX_EHIP;
-                const int rf = wx_lattice2d_fused_f32((const float *)x, (float *)y, (float *)tmp, ctl, m, L, batch, filt, inverse, st);
-                if (rf < 0) return rf;
-                if (rf == 1) return WX_OK;
+                // a launch takes at most 65535 units (images, pairs of 256 x 256 images): longer batches in pieces, one after the other
+                const int64_t piece = 65534;
+                bool all = true;
+                for (int64_t b0 = 0; b0 < batch && all; b0 += piece) {
+                    const int64_t nb = batch - b0 < piece ? batch - b0 : piece;
+                    const int rf = wx_lattice2d_fused_f32((const float *)x + b0 * mn, (float *)y + b0 * mn, (float *)tmp, ctl, m, L, nb, filt, inverse, st);
+                    if (rf < 0) return rf;
+                    if (rf != 1) {
+                        if (b0) return wx_set_error(WX_EHIP, "lattice2d: the fused launch took a first piece of the batch and not the next");
+                        all = false;
+                    }
+                }
+                if (all) return WX_OK;
             }
-            bool took = true;
-            for (int64_t b0 = 0; b0 < batch && took; b0 += S) {
-                const int64_t nb = (batch - b0 < S) ? batch - b0 : S;
-                const int r1 = wx_lattice2d_colT_f32((const float *)x + b0 * mn, (float *)tmp, m, L, nb, filt, inverse, 1, st);
-                if (r1 < 0) return r1;
-                if (r1 == 0) { if (b0) return wx_set_error(WX_EHIP, "lattice2d: pass refused"); took = false; break; }
-                const int r2 = wx_lattice2d_colT_f32((const float *)tmp, (float *)y + b0 * mn, m, L, nb, filt, inverse, 2, st);
-                if (r2 != 1) return r2 < 0 ? r2 : wx_set_error(WX_EHIP, "lattice2d: second pass refused");
+            // one launch per pass (what is still built of it: wx_lattice2d_launch), the whole batch through `tmp`
+            const int r1 = wx_lattice2d_colT_f32((const float *)x, (float *)tmp, m, L, batch, filt, inverse, 1, st);
+            if (r1 < 0) return r1;
+            if (r1 == 1) {
+                const int r2 = wx_lattice2d_colT_f32((const float *)tmp, (float *)y, m, L, batch, filt, inverse, 2, st);
+                if (r2 != 1) return r2 < 0 ? r2 : wx_set_error(WX_EHIP, "lattice2d: second pass not built for the first one's filter");
+                return WX_OK;
             }
-            if (took) return WX_OK;
         }
     }
     for (int64_t b0 = 0, k = 0; b0 < batch; b0 += S, ++k) {

@@ -137,18 +137,16 @@ static int wx_lattice_launch(bool inverse, const double *x, double *y, int64_t n
     // inverse needs 194 registers without spills, and its spills at 3 cost 15 % extra HBM traffic (scratch) and 6 % time
     // (db4 L = 10: 0.84 ms at 3, 0.78 ms at 2; the forward built for 2 is 2 % slower than for 3).  WX_LATTICE_INV_WPE = 3
     // selects the other build of the inverse.
-    static const int inv_wpe = wx_getenv("WX_LATTICE_INV_WPE") ? atoi(wx_getenv("WX_LATTICE_INV_WPE")) : 2;
+    // (the three-wavefront build of the inverse was reachable through WX_LATTICE_INV_WPE=3 only: not built since round 6)
 #define WX_GO(NSS)                                                                                                  \
     case NSS:                                                                                                       \
-        if (inverse && inv_wpe == 3)                                                                                \
-            hipLaunchKernelGGL((k_lat_iwpt_f64<NSS, 3>), dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, in_stride, cf); \
-        else if (inverse)                                                                                           \
+        if (inverse)                                                                                                \
             hipLaunchKernelGGL((k_lat_iwpt_f64<NSS, 2>), dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, in_stride, cf); \
         else                                                                                                        \
             hipLaunchKernelGGL((k_lat_wpt_f64<NSS, 3>), dim3((unsigned)grid), dim3(64), 0, st, x, y, L, batch, cf);  \
         break;
-    switch (filt.F / 2) {
-        WX_GO(1) WX_GO(2) WX_GO(3) WX_GO(4) WX_GO(5) WX_GO(6) WX_GO(7) WX_GO(8) WX_GO(9) WX_GO(10)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GO(1) WX_GO(2) WX_GO(4) WX_GO(6) WX_GO(8) WX_GO(10)
     default: return 0;
     }
 #undef WX_GO
@@ -187,8 +185,8 @@ int wx_lattice_wpd_f64(const double *x, double *y, int64_t n, int L, int64_t bat
     case NSS:                                                                                                       \
         hipLaunchKernelGGL((k_lat_wpd_f64<NSS, 2>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L, batch, cw);     \
         break;
-    switch (filt.F / 2) {
-        WX_GOW(1) WX_GOW(2) WX_GOW(3) WX_GOW(4) WX_GOW(5) WX_GOW(6) WX_GOW(7) WX_GOW(8) WX_GOW(9) WX_GOW(10)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GOW(1) WX_GOW(2) WX_GOW(4) WX_GOW(6) WX_GOW(8) WX_GOW(10)
     default: return 0;
     }
 #undef WX_GOW

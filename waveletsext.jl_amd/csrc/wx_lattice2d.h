@@ -1063,8 +1063,8 @@ static int wx_lattice2d_fused_launch(const float *src, float *dst, float *ring, 
             else hipLaunchKernelGGL((k_lat2d_fused_f32<NSS, false, HB, true>), grid, wg, 0, st, src, ring, dst, last_img, fz, dc);          \
         } else hipLaunchKernelGGL((k_lat2d_fused_f32<NSS, false, HB, false>), grid, wg, 0, st, src, ring, dst, last_img, fz, dc);           \
         break;
-    switch (filt.F / 2) {
-        WX_GO2F(1) WX_GO2F(2) WX_GO2F(3) WX_GO2F(4) WX_GO2F(5) WX_GO2F(6) WX_GO2F(7) WX_GO2F(8) WX_GO2F(9) WX_GO2F(10)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GO2F(1) WX_GO2F(2) WX_GO2F(4) WX_GO2F(6) WX_GO2F(8) WX_GO2F(10)
     default: return 0;
     }
 #undef WX_GO2F
@@ -1085,23 +1085,30 @@ static int wx_lattice2d_launch(const float *src, float *dst, int64_t m, int L, i
     const int64_t per = HB == 1 ? 2 : 1, units = (batch + per - 1) / per;
     if (batch < per || units > 65535 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return 0;
     if ((batch & (per - 1)) && src == dst) return 0;          // the last workgroup re-does images: out of place only
-    const bool bl = blocked && pass == 2, bs = blocked && pass == 1;
+    // Since round 6 a transform is ONE launch of k_lat2d_fused_f32; what is still built of the one-launch-per-pass form: the blocked pair
+    // for the forward transform of 256 x 256 images (at full depth its fused kernel spills: the launcher above declines), and the pair of
+    // db4 in every geometry and direction so that the fused launch can be timed against it on any box (WX_L2D_FUSED=0).  Anything else:
+    // 0 = not ours, the caller takes the strip kernels.  (The unblocked variant -- pass 0, WX_L2D_BLOCKED=0 -- is gone.)
+    if (!blocked || (pass != 1 && pass != 2)) return 0;
+    const bool bl = pass == 2;
+    const int nsq = wx_lat_stages(filt.F);
+    if (!((HB == 1 && !inverse) || nsq == 4)) return 0;
     const int cols_wg = (HB == 2 ? 8 : 16) * WX_L2D_W;
     const dim3 grid((unsigned)(m / cols_wg), (unsigned)units), wg(64 * WX_L2D_W);
     const int last_img = (int)(batch - per);
 #define WX_GO2K(K, NSS)                                                                                                  \
     do {                                                                                                                 \
         if (bl) hipLaunchKernelGGL((K<NSS, true, false, HB>), grid, wg, 0, st, src, dst, last_img, cf, mm);                  \
-        else if (bs) hipLaunchKernelGGL((K<NSS, false, true, HB>), grid, wg, 0, st, src, dst, last_img, cf, mm);             \
-        else hipLaunchKernelGGL((K<NSS, false, false, HB>), grid, wg, 0, st, src, dst, last_img, cf, mm);                    \
+        else hipLaunchKernelGGL((K<NSS, false, true, HB>), grid, wg, 0, st, src, dst, last_img, cf, mm);                     \
     } while (0)
 #define WX_GO2(NSS)                                                                                                      \
     case NSS:                                                                                                            \
-        if (inverse) WX_GO2K(k_lat2d_icolT_f32, NSS);                                                                    \
-        else WX_GO2K(k_lat2d_colT_f32, NSS);                                                                             \
+        if (inverse) {                                                                                                   \
+            if constexpr (NSS == 4) WX_GO2K(k_lat2d_icolT_f32, NSS);                                                     \
+        } else if constexpr (HB == 1 || NSS == 4) WX_GO2K(k_lat2d_colT_f32, NSS);                                        \
         break;
-    switch (filt.F / 2) {
-        WX_GO2(1) WX_GO2(2) WX_GO2(3) WX_GO2(4) WX_GO2(5) WX_GO2(6) WX_GO2(7) WX_GO2(8) WX_GO2(9) WX_GO2(10)
+    switch (nsq) {
+        WX_GO2(1) WX_GO2(2) WX_GO2(4) WX_GO2(6) WX_GO2(8) WX_GO2(10)
     default: return 0;
     }
 #undef WX_GO2

@@ -111,23 +111,17 @@ static int wx_lattice_2d64_launch(const IO *x, IO *y, int L, int64_t batch, int6
     }
     cw.tail_bsig = pp.tail_bsig;
     // Float64: 166-168 registers, three wavefronts per SIMD without a spill; the Float32 pair kernels need the 256 of two
-    static const bool w3 = !PAIR && !(wx_getenv("WX_2D64_WPE") && atoi(wx_getenv("WX_2D64_WPE")) == 2);
+    // (the two-wavefront build of the Float64 kernels was reachable through WX_2D64_WPE=2 only: not built since round 6)
 #define WX_GO2(NSS)                                                                                                                  \
     case NSS:                                                                                                                        \
-        if constexpr (!PAIR) {                                                                                                       \
-            if (w3) {                                                                                                                \
-                hipLaunchKernelGGL((k_lat2d64_f64<NSS, 3, IO, INV>), dim3(pp.nwave), dim3(64), 0, st, x, y, L, pp.tail_sig, (unsigned)in_img, cw); \
-                break;                                                                                                               \
-            }                                                                                                                        \
-        }                                                                                                                            \
-        hipLaunchKernelGGL((k_lat2d64_f64<NSS, 2, IO, INV>), dim3(pp.nwave), dim3(64), 0, st, x, y, L, pp.tail_sig, (unsigned)in_img, cw); \
+        hipLaunchKernelGGL((k_lat2d64_f64<NSS, PAIR ? 2 : 3, IO, INV>), dim3(pp.nwave), dim3(64), 0, st, x, y, L, pp.tail_sig, (unsigned)in_img, cw); \
         break;
-    switch (filt.F / 2) {
-        WX_GO2(1) WX_GO2(2) WX_GO2(3) WX_GO2(4)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GO2(1) WX_GO2(2) WX_GO2(4)
     default:
         if constexpr (NSMAX > 4) {
-            switch (filt.F / 2) {
-                WX_GO2(5) WX_GO2(6) WX_GO2(7) WX_GO2(8)
+            switch (wx_lat_stages(filt.F)) {
+                WX_GO2(6) WX_GO2(8)
             default: return 0;
             }
         } else

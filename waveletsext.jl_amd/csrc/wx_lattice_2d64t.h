@@ -227,12 +227,12 @@ static int wx_lattice_2d64t_launch(const IO *x, IO *y, int L, int64_t batch, int
     case NSS:                                                                                                                        \
         hipLaunchKernelGGL((k_lat2d64t_f64<NSS, 2, IO, INV>), dim3(pp.nwave), dim3(64), 0, st, x, y, pp.tail_sig, (unsigned)in_img, cw, ctab); \
         break;
-    switch (filt.F / 2) {
-        WX_GOQ(1) WX_GOQ(2) WX_GOQ(3) WX_GOQ(4)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GOQ(1) WX_GOQ(2) WX_GOQ(4)
     default:
         if constexpr (NSMAX > 4) {
-            switch (filt.F / 2) {
-                WX_GOQ(5) WX_GOQ(6) WX_GOQ(7) WX_GOQ(8)
+            switch (wx_lat_stages(filt.F)) {
+                WX_GOQ(6) WX_GOQ(8)
             default: return 0;
             }
         } else

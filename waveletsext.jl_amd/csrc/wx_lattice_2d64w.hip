@@ -70,7 +70,7 @@ int wx_lattice_2d64_wpd_T(const IO *x, IO *y, int L, int64_t batch, const WxFilt
     cw.tail_bsig = pp.tail_bsig;
 #define WX_GOW(NSS)                                                                                                                  \
     case NSS: hipLaunchKernelGGL((k_lat2d64_wpd<NSS, IO>), dim3(pp.nwave), dim3(64), 0, st, x, y, L, pp.tail_sig, cw); break;
-    switch (filt.F / 2) {
+    switch (wx_lat_stages(filt.F)) {
         WX_GOW(1) WX_GOW(2) WX_GOW(3) WX_GOW(4)
     default: return 0;
     }

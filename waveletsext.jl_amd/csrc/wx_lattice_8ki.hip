@@ -12,8 +12,8 @@ int wx_lattice_iwpt8k_f64(const double *xw, double *y, int L, int64_t batch, int
     if (!wx_lattice_factor(filt, L - 1, true, &cf)) return 0;
 #define WX_GO8(NSS)                                                                                                      \
     case NSS: hipLaunchKernelGGL((k_lat_iwpt8k_f64<NSS, 2>), dim3((unsigned)batch), dim3(128), 0, st, xw, y, L - 1, batch, in_stride, cf, filt); break;
-    switch (filt.F / 2) {
-        WX_GO8(1) WX_GO8(2) WX_GO8(3) WX_GO8(4) WX_GO8(5) WX_GO8(6) WX_GO8(7) WX_GO8(8) WX_GO8(9) WX_GO8(10)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GO8(1) WX_GO8(2) WX_GO8(4) WX_GO8(6) WX_GO8(8) WX_GO8(10)
     default: return 0;
     }
 #undef WX_GO8

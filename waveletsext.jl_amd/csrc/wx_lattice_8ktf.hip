@@ -67,7 +67,7 @@ int wx_lattice_tree8k_fwd_f64(const double *x, double *y, int64_t batch, const W
         if (wpe == 2) hipLaunchKernelGGL((k_lat_wpt_treesc8k_f64<NSS, 2>), dim3((unsigned)batch), dim3(128), 0, st, x, y, batch, cw, t0, t1, filt); \
         else hipLaunchKernelGGL((k_lat_wpt_treesc8k_f64<NSS, 1>), dim3((unsigned)batch), dim3(128), 0, st, x, y, batch, cw, t0, t1, filt); \
         break;
-    switch (filt.F / 2) {
+    switch (wx_lat_stages(filt.F)) {
         WX_GO8F(1) WX_GO8F(2) WX_GO8F(3) WX_GO8F(4)
     default: return 0;
     }

@@ -27,8 +27,8 @@ int wx_lattice_tree8k_inv_f64(const double *x, double *y, int64_t batch, const W
     if (rc != WX_OK) return rc;
 #define WX_GO8T(NSS)                                                                                                      \
     case NSS: hipLaunchKernelGGL((k_lat_iwpt_treesc8k_f64<NSS, 2>), dim3((unsigned)batch), dim3(128), 0, st, x, y, batch, cw, t0, t1, filt); break;
-    switch (filt.F / 2) {
-        WX_GO8T(1) WX_GO8T(2) WX_GO8T(3) WX_GO8T(4) WX_GO8T(5) WX_GO8T(6) WX_GO8T(7) WX_GO8T(8) WX_GO8T(9) WX_GO8T(10)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GO8T(1) WX_GO8T(2) WX_GO8T(4) WX_GO8T(6) WX_GO8T(8) WX_GO8T(10)
     default: return 0;
     }
 #undef WX_GO8T

@@ -46,8 +46,8 @@ int wx_lattice_f32(bool inverse, const float *x, float *y, int64_t n, int L, int
         else                                                                                                         \
             hipLaunchKernelGGL((k_lat_wpt_f64<NSS, 3, float>), dim3((unsigned)batch), dim3(64), 0, st, x, y, L, batch, cf); \
         break;
-    switch (filt.F / 2) {
-        WX_GOF(2) WX_GOF(3) WX_GOF(4) WX_GOF(5) WX_GOF(6) WX_GOF(7) WX_GOF(8) WX_GOF(9) WX_GOF(10)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GOF(2) WX_GOF(4) WX_GOF(6) WX_GOF(8) WX_GOF(10)
     default: return 0;
     }
 #undef WX_GOF

@@ -114,7 +114,7 @@ int wx_lattice_launch_lo(bool inverse, const double *x, double *y, int L, int64_
     cw.gl[L] = cw.c.g0;
     cw.gl[0] = 1.0;
 #define WX_GOLL(NSS, LL)                                                                                             \
-    if (filt.F / 2 == NSS && L == LL) {                                                                              \
+    if (wx_lat_stages(filt.F) == NSS && L == LL) {                                                                              \
         if (inverse)                                                                                                 \
             hipLaunchKernelGGL((k_lat_iwpt_lo_f64<NSS, 2, LL>), dim3((unsigned)batch), dim3(64), 0, st, x, y, in_stride, cw); \
         else                                                                                                         \
@@ -122,7 +122,7 @@ int wx_lattice_launch_lo(bool inverse, const double *x, double *y, int L, int64_
     }
 #define WX_GOL(NSS) WX_GOLL(NSS, 1) WX_GOLL(NSS, 2) WX_GOLL(NSS, 3) WX_GOLL(NSS, 4) WX_GOLL(NSS, 5)
     if (filt.F / 2 < 1 || filt.F / 2 > WX_LAT_MAXS) return 0;
-    WX_GOL(1) WX_GOL(2) WX_GOL(3) WX_GOL(4) WX_GOL(5) WX_GOL(6) WX_GOL(7) WX_GOL(8) WX_GOL(9) WX_GOL(10)
+    WX_GOL(1) WX_GOL(2) WX_GOL(4) WX_GOL(6) WX_GOL(8) WX_GOL(10)
 #undef WX_GOLL
 #undef WX_GOL
     const hipError_t e = hipGetLastError();

@@ -67,12 +67,12 @@ static int wx_lattice_rows_launch(const IO *x, IO *y, int64_t in_img, int64_t ou
         hipLaunchKernelGGL((k_lat_rows_g_f64<NSS, 2, SH, IO, INV>), dim3((unsigned)(nwave / W)), dim3(64 * W), 0, st, x, y, L, (unsigned)m, \
                            (unsigned)groups, in_img, out_img, cw);                                                                   \
         break;
-    switch (filt.F / 2) {
-        WX_GOR(1) WX_GOR(2) WX_GOR(3) WX_GOR(4)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GOR(1) WX_GOR(2) WX_GOR(4)
     default:
         if constexpr (NSMAX > 4) {
-            switch (filt.F / 2) {
-                WX_GOR(5) WX_GOR(6) WX_GOR(7) WX_GOR(8)
+            switch (wx_lat_stages(filt.F)) {
+                WX_GOR(6) WX_GOR(8)
             default: return 0;
             }
         } else

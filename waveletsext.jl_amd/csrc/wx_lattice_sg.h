@@ -27,7 +27,7 @@ static int wx_lattice_launch_g_T(bool inverse, const double *x, double *y, int64
     const int last_sig = (int)(batch - per);
     const unsigned is32 = (unsigned)in_stride;
 #define WX_GOG(NSS, SHH)                                                                                             \
-    if (filt.F / 2 == NSS && SH == SHH) {                                                                            \
+    if (wx_lat_built(NSS) && wx_lat_stages(filt.F) == NSS && SH == SHH) {                                                                            \
         if (inverse)                                                                                                 \
             hipLaunchKernelGGL((k_lat_iwpt_g_f64<NSS, 2, SHH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, is32, cw); \
         else                                                                                                         \

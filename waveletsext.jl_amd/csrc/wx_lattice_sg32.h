@@ -61,13 +61,13 @@ int WX_G32_FN(bool inverse, const float *x, float *y, int64_t n, int L, int64_t 
                 hipLaunchKernelGGL((k_lat_wpt_g_f64<NSS, 2, SH, float, false>), dim3(nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
         }                                                                                                                            \
         break;
-    switch (filt.F / 2) {
-        WX_GOG(1) WX_GOG(2) WX_GOG(3) WX_GOG(4)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GOG(1) WX_GOG(2) WX_GOG(4)
 #if WX_G32_NSMAX > 4
-        WX_GOG(5) WX_GOG(6) WX_GOG(7) WX_GOG(8)
+        WX_GOG(6) WX_GOG(8)
 #endif
 #if WX_G32_NSMAX > 8
-        WX_GOG(9) WX_GOG(10)
+        WX_GOG(10)
 #endif
     default: return 0;
     }

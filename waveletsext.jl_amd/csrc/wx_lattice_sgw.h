@@ -26,7 +26,7 @@ static int wx_lattice_wpd_g_T(const double *x, double *y, int64_t n, int L, int6
     const int64_t nwave = (batch + per - 1) / per;
     const int last_sig = (int)(batch - per);
 #define WX_GOGW(NSS, SHH)                                                                                            \
-    if (filt.F / 2 == NSS && SH == SHH)                                                                              \
+    if (wx_lat_built(NSS) && wx_lat_stages(filt.F) == NSS && SH == SHH)                                                                              \
         hipLaunchKernelGGL((k_lat_wpd_g_f64<NSS, 2, SHH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw);
 #define WX_GOGW4(SHH) WX_GOGW(NS0, SHH) WX_GOGW(NS0 + 1, SHH) WX_GOGW(NS0 + 2, SHH) WX_GOGW(NS0 + 3, SHH)
     WX_GOGW4(3) WX_GOGW4(4) WX_GOGW4(5) WX_GOGW4(6)
@@ -63,7 +63,7 @@ static int wx_lattice_wpd_g32_T(const float *x, float *y, int64_t n, int L, int6
     const int64_t nwave = (batch + per - 1) / per;
     const int last_sig = (int)(batch - per);
 #define WX_GOGW(NSS, SHH)                                                                                            \
-    if (filt.F / 2 == NSS && SH == SHH)                                                                              \
+    if (wx_lat_built(NSS) && wx_lat_stages(filt.F) == NSS && SH == SHH)                                                                              \
         hipLaunchKernelGGL((k_lat_wpd_g_f64<NSS, 2, SHH, float>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw);
 #define WX_GOGW4(SHH) WX_GOGW(NS0, SHH) WX_GOGW(NS0 + 1, SHH) WX_GOGW(NS0 + 2, SHH) WX_GOGW(NS0 + 3, SHH)
     WX_GOGW4(4) WX_GOGW4(5) WX_GOGW4(6)

@@ -32,8 +32,8 @@ int wx_lattice_launch_sh(bool inverse, const double *x, double *y, int64_t n, in
         else                                                                                                         \
             hipLaunchKernelGGL((k_lat_wpt_sh_f64<NSS, 2, 2>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
         break;
-    switch (filt.F / 2) {
-        WX_GOS(1) WX_GOS(2) WX_GOS(3) WX_GOS(4) WX_GOS(5) WX_GOS(6) WX_GOS(7) WX_GOS(8) WX_GOS(9) WX_GOS(10)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GOS(1) WX_GOS(2) WX_GOS(4) WX_GOS(6) WX_GOS(8) WX_GOS(10)
     default: return 0;
     }
 #undef WX_GOS

@@ -29,8 +29,8 @@ int wx_lattice_wpd_sh_f64(const double *x, double *y, int64_t n, int L, int64_t 
         else                                                                                                         \
             hipLaunchKernelGGL((k_lat_wpd_sh_f64<NSS, 2, 2>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw); \
         break;
-    switch (filt.F / 2) {
-        WX_GOSW(1) WX_GOSW(2) WX_GOSW(3) WX_GOSW(4) WX_GOSW(5) WX_GOSW(6) WX_GOSW(7) WX_GOSW(8) WX_GOSW(9) WX_GOSW(10)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GOSW(1) WX_GOSW(2) WX_GOSW(4) WX_GOSW(6) WX_GOSW(8) WX_GOSW(10)
     default: return 0;
     }
 #undef WX_GOSW

@@ -1,3 +1,6 @@
+#ifndef WX_LAT_TREE_FIRST_FORM
+#define WX_LAT_TREE_FIRST_FORM 0
+#endif
 // wx_lattice_tree.h -- launcher of the tree-driven lattice kernels (k_lat_wpt_tree_f64, k_lat_iwpt_tree_f64,
 // k_lat_tree_prep in wx_lattice_dev.h): wpt / iwpt along a tree and iwpd by tree for Float64 signals of 4096, 2048 and
 // 1024 samples.  Reference: Wavelets.jl's wpt / iwpt with a tree::BitVector as called by wptall / iwptall
@@ -48,7 +51,7 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
     // tables made in LDS the masked form is at least as fast on every tree measured (depth-4 pyramid, 65536 x 4096 db4: 0.77 / 0.83 ms
     // against 0.85 / 0.82; deep random trees 0.86 / 0.85 against 1.15 / 1.33).
     static const int sc_env = wx_getenv("WX_TREE_SC") ? atoi(wx_getenv("WX_TREE_SC")) : -1;
-    if (sc_env != 0 || strided || ta.head) {
+    if (sc_env != 0 || strided || ta.head || !WX_LAT_TREE_FIRST_FORM) {
         WxLatTreeSc *tsc = (WxLatTreeSc *)scr.alloc(sizeof(WxLatTreeSc));
         if (!tsc) return WX_EHIP;
         if (hipMemsetAsync(tsc->dep, 0, sizeof(tsc->dep), st) != hipSuccess) return wx_set_error(WX_EHIP, "lattice tree tables");
@@ -69,7 +72,7 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
                            (unsigned)in_stride, (unsigned)col_stride, (unsigned)ostr, cw, ctsc, ta);                 \
         break;
         if (ta.t) {
-            switch (filt.F / 2) {
+            switch (wx_lat_stages(filt.F)) {
                 WX_GOST(1) WX_GOST(2) WX_GOST(4)
             default: return 0;
             }
@@ -82,8 +85,8 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
                            (unsigned)in_stride, (unsigned)ostr, cw, ctsc);                                           \
         break;
 #endif
-        switch (filt.F / 2) {
-            WX_GOS(1) WX_GOS(2) WX_GOS(3) WX_GOS(4) WX_GOS(5) WX_GOS(6) WX_GOS(7) WX_GOS(8) WX_GOS(9) WX_GOS(10)
+        switch (wx_lat_stages(filt.F)) {
+            WX_GOS(1) WX_GOS(2) WX_GOS(4) WX_GOS(6) WX_GOS(8) WX_GOS(10)
         default: return 0;
         }
 #undef WX_GOS
@@ -91,6 +94,11 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
         if (es != hipSuccess) return wx_set_hip_error(es, "lattice tree launch", __FILE__, __LINE__);
         return 1;
     }
+    // The first form is not built any more (round 6: it was reachable through the knob only and was 60 % of these translation units'
+    // code: -DWX_LAT_TREE_FIRST_FORM=1 brings it back)
+#if !WX_LAT_TREE_FIRST_FORM
+    return 0;
+#else
     if (ta.head) return 0;
     WxLatTreeTab *tab = (WxLatTreeTab *)scr.alloc(sizeof(WxLatTreeTab));
     if (!tab) return WX_EHIP;
@@ -114,7 +122,7 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
                            (unsigned)in_stride, (unsigned)col_stride, cw, ctab, ta);                                 \
         break;
     if (ta.t) {
-        switch (filt.F / 2) {
+        switch (wx_lat_stages(filt.F)) {
             WX_GOTT(1) WX_GOTT(2) WX_GOTT(4)
         default: return 0;
         }
@@ -129,12 +137,13 @@ int WX_LAT_TREE_FN(bool inverse, const double *x, double *y, int64_t n, int L, i
         hipLaunchKernelGGL((k_lat_wpt_tree_f64<NSS, 2, SH>), dim3((unsigned)nwave), dim3(64), 0, st, x, y, L, last_sig, cw, ctab); \
         break;
 #endif
-    switch (filt.F / 2) {
-        WX_GOT(1) WX_GOT(2) WX_GOT(3) WX_GOT(4) WX_GOT(5) WX_GOT(6) WX_GOT(7) WX_GOT(8) WX_GOT(9) WX_GOT(10)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GOT(1) WX_GOT(2) WX_GOT(4) WX_GOT(6) WX_GOT(8) WX_GOT(10)
     default: return 0;
     }
 #undef WX_GOT
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wx_set_hip_error(e, "lattice tree launch", __FILE__, __LINE__);
     return 1;
+#endif
 }

@@ -59,8 +59,8 @@ int WX_LAT_TREE_FN(bool inverse, const float *x, float *y, int64_t n, int L, int
                            (unsigned)in_stride, (unsigned)ostr, cw, ctsc);                                               \
         break;
 #endif
-    switch (filt.F / 2) {
-        WX_GOS(1) WX_GOS(2) WX_GOS(3) WX_GOS(4) WX_GOS(5) WX_GOS(6) WX_GOS(7) WX_GOS(8) WX_GOS(9) WX_GOS(10)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GOS(1) WX_GOS(2) WX_GOS(4) WX_GOS(6) WX_GOS(8) WX_GOS(10)
     default: return 0;
     }
 #undef WX_GOS

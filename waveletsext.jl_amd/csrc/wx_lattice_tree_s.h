@@ -60,12 +60,12 @@ static int wx_lattice_trees_launch(const IO *x, IO *y, int64_t n, int L, int64_t
             hipLaunchKernelGGL((k_lat_wpt_treesc_f64<NSS, 2, SH, IO, FP32A>), dim3(nw), dim3(64), 0, st, x, y, L, lsig,              \
                                (unsigned)in_stride, (unsigned)ostr, cw, ctsc);                                                       \
         break;
-    switch (filt.F / 2) {
-        WX_GOS(1) WX_GOS(2) WX_GOS(3) WX_GOS(4)
+    switch (wx_lat_stages(filt.F)) {
+        WX_GOS(1) WX_GOS(2) WX_GOS(4)
     default:
         if constexpr (NSMAX > 4) {
-            switch (filt.F / 2) {
-                WX_GOS(5) WX_GOS(6) WX_GOS(7) WX_GOS(8)
+            switch (wx_lat_stages(filt.F)) {
+                WX_GOS(6) WX_GOS(8)
             default: return 0;
             }
         } else
