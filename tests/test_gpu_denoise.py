@@ -140,7 +140,7 @@ def test_noisest_degenerate_distributions(wx, oracle):
     heavy ties, one huge outlier (everything else in one bucket -> the narrowing loop), tiny and odd/even counts"""
     rng = np.random.default_rng(5004)
     cases = []
-    for n in (4, 8, 64, 128, 256, 1024, 4096):           # 128, 256: two and (64: one) elements per lane of the wavefront-per-signal kernel
+    for n in (4, 8, 64, 128, 256, 512, 1024, 2048, 4096):      # from 256 on: a wavefront sorts the n / 2 details in its registers (k_mad_sort)
         half = n // 2
         cases += [
             np.zeros(n), np.full(n, -3.5),
@@ -157,6 +157,34 @@ def test_noisest_degenerate_distributions(wx, oracle):
             v32 = v.astype(np.float32)
         if np.isfinite(v32).all():
             assert wx.noisest(v32, False) == oracle.noisest(v32, False)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_noisest_wave_sort_every_size_class_batches_and_nan(wx, oracle, dtype):
+    """k_mad_sort (round 6): detail ranges of 65 ... 512 coefficients, sorted by one wavefront -- every size class with counts at, below
+    and between the powers of two (the C ABI takes any row_lo: the slots beyond the count are padded), batches that do not fill the last
+    workgroup, bit-equal to the oracle's selection; a NaN among the details gives NaN like Statistics.median, in the short
+    kernel (<= 64 values) and in the sorting one"""
+    import ctypes
+    import sys
+    lib = sys.modules[wx.__name__ + "._lib"]
+    rng = np.random.default_rng(6006)
+    suf = "_f64" if dtype == np.float64 else "_f32"
+    fn = getattr(lib.lib(), "wx_noisest" + suf)
+    for n, B in ((256, 9), (512, 6), (1024, 5), (2048, 3)):
+        X = np.asfortranarray((rng.standard_normal((n, B)) * 10.0 ** rng.integers(-3, 3, B)).astype(dtype))
+        X[:, 0] = np.round(X[:, 0] * 4) / 4                               # ties
+        for row_lo in (n // 2, n // 2 - 1, n // 2 + 3, n // 4 + 1, n - 65, n - 70):
+            if n - row_lo > 512 or n - row_lo <= 64:
+                continue
+            sig = np.empty(B, dtype=dtype)
+            lib.check(fn(X.ctypes.data_as(ctypes.c_void_p), n, 1, B, row_lo, 0, sig.ctypes.data_as(ctypes.c_void_p), None))
+            exp = np.array([oracle.noisest_range(X[row_lo:, b]) for b in range(B)], dtype=dtype)
+            assert (sig == exp).all(), (n, row_lo, sig, exp)
+    for n in (64, 128, 1024, 4096):
+        v = rng.standard_normal(n).astype(dtype)
+        v[n - 3] = np.nan
+        assert np.isnan(wx.noisest(v, False)), n
 
 
 @pytest.mark.parametrize("inputtype", ["sig", "dwt", "wpt"])

@@ -203,11 +203,15 @@ __global__ __launch_bounds__(256) void k_mad(const T *__restrict__ X, int64_t si
     const T *x = X + (int64_t)blockIdx.x * sig_stride + off;
     wx_stage<T>(v, x, cnt);
     __syncthreads();
+    // a NaN among the values: Statistics.median gives NaN; the selection's comparisons would just lose it
+    int nan = 0;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) nan |= v[i] != v[i];
+    nan = __syncthreads_or(nan);
     const T m = wx_median_lds<T>(v, cnt, &S);
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) v[i] = (T)fabs((double)(T)(v[i] - m));
     __syncthreads();
     const T r = wx_median_lds<T>(v, cnt, &S);
-    if (threadIdx.x == 0) sigma[blockIdx.x] = (T)(r / (T)0.6745);
+    if (threadIdx.x == 0) sigma[blockIdx.x] = nan ? (T)__builtin_nan("") : (T)(r / (T)0.6745);
 }
 
 // short detail ranges (at most 512 coefficients: signals up to 1024 samples at the finest level): ONE WAVEFRONT per signal, four per
@@ -227,6 +231,10 @@ __global__ __launch_bounds__(256) void k_mad_wave(const T *__restrict__ X, int64
     T e[E];                                                  // E = ceil(cnt / 64) elements per lane
 #pragma unroll
     for (int u = 0; u < E; ++u) { const int i = lane + 64 * u; e[u] = i < cnt ? x[i] : (T)0; }
+    bool nan = false;
+#pragma unroll
+    for (int u = 0; u < E; ++u) nan = nan || e[u] != e[u];
+    const bool any_nan = __builtin_amdgcn_ballot_w64(nan) != 0;          // every comparison with a NaN is false: its rank would be 0, the others' ranks ignore it
     const int k0 = (cnt - 1) / 2;
     T med = (T)0;
     for (int round = 0; round < 2; ++round) {
@@ -262,7 +270,107 @@ __global__ __launch_bounds__(256) void k_mad_wave(const T *__restrict__ X, int64
             for (int u = 0; u < E; ++u) e[u] = (T)fabs((double)(T)(e[u] - med));
         }
     }
-    if (lane == 0) sigma[sig] = (T)(med / (T)0.6745);
+    if (lane == 0) sigma[sig] = any_nan ? (T)__builtin_nan("") : (T)(med / (T)0.6745);
+}
+
+// 65 ... 512 coefficients (signals of 256 ... 1024 samples at the finest level; built up to 2048), round 6: ONE WAVEFRONT SORTS the values in its registers.
+// Element i of the P = 64 E slots (E a power of two; slots beyond cnt hold +Inf) sits in lane i / E, register i % E.  A bitonic sorting
+// network in its "every comparison ascending" form (the first stage of the merge of 2 m elements pairs i with i ^ (2 m - 1), the later
+// stages i with i ^ j): a partner inside the lane is a register pair (v_min / v_max, direction known at compile time), a partner in another
+// lane comes through the cross-lane network (__shfl: ds_bpermute, no memory) and the lane keeps the minimum or the maximum by the side it is
+// on.  The median is the element(s) of rank k0 (and k0 + 1) -- one v_readlane each; the absolute deviations of a SORTED sequence fall to the
+// median and rise again, i.e. they are bitonic, so the second median needs one merge (log2 P stages), not a second sort.  Exact like the
+// selection it replaces: same order statistics, same middle(a, b) = a/2 + b/2 (Statistics.median!), same rounded subtraction.  NaN anywhere
+// gives NaN (min / max would drop it).  (k_mad: one 256-thread workgroup per signal -- 2 M workgroups for 256 values each at n = 512: 3.7 ms
+// per GiB of signals; k_mad_wave's counting is quadratic: 2.1 ms at n = 256.  This kernel: see profiles/r06_floor_misc.txt.)
+template <typename T> __device__ __forceinline__ T mad_shfl(T v, int src_lane)
+{
+    if constexpr (sizeof(T) == 8) {
+        const double d = (double)v;
+        const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(d)), hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(d));
+        return (T)__hiloint2double(hi, lo);
+    } else {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, (float)v)));
+    }
+}
+template <typename T> __device__ __forceinline__ T mad_min(T a, T b) { return a < b ? a : b; }      // no NaN reaches the network
+template <typename T> __device__ __forceinline__ T mad_max(T a, T b) { return a < b ? b : a; }
+// one stage: partner of slot i is i ^ X (X = 2 m - 1 for the first stage of a merge, a single bit j afterwards)
+template <typename T, int E, int X> __device__ __forceinline__ void mad_stage(T (&r)[E], int lane)
+{
+    if constexpr (X < E) {
+        // inside the lane: registers u and u ^ X, the lower index keeps the minimum
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const int w = u ^ X;
+            if (w > u) { const T a = r[u], b = r[w]; r[u] = mad_min(a, b); r[w] = mad_max(a, b); }
+        }
+    } else {
+        // across lanes: lane ^ (X / E) holds the partner in register u ^ (X % E)  (X % E is 0 or E - 1)
+        constexpr int XL = X / E, XR = X % E;
+        const int pl = lane ^ XL;
+        const bool low = lane < pl;
+        T o[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) o[u] = mad_shfl<T>(r[u ^ XR], pl);
+#pragma unroll
+        for (int u = 0; u < E; ++u) { const T a = r[u], b = o[u]; r[u] = low ? mad_min(a, b) : mad_max(a, b); }
+    }
+}
+// merge of sorted (or bitonic) runs into runs of M slots: FIRST = the runs are two sorted halves (mirror pairing), else bitonic (plain pairing)
+template <typename T, int E, int M, bool FIRST> __device__ __forceinline__ void mad_merge(T (&r)[E], int lane)
+{
+    if constexpr (M >= 2) {
+        mad_stage<T, E, FIRST ? M - 1 : M / 2>(r, lane);
+        mad_merge<T, E, M / 2, false>(r, lane);
+    }
+}
+template <typename T, int E, int M> __device__ __forceinline__ void mad_sort(T (&r)[E], int lane)
+{
+    if constexpr (M >= 2) {
+        mad_sort<T, E, M / 2>(r, lane);
+        mad_merge<T, E, M, true>(r, lane);
+    }
+}
+// the element of slot idx (wave-uniform)
+template <typename T, int E> __device__ __forceinline__ T mad_pick(const T (&r)[E], int idx)
+{
+    const int u = idx % E, l = idx / E;
+    T v = r[0];
+#pragma unroll
+    for (int q = 1; q < E; ++q) v = u == q ? r[q] : v;
+    return mad_shfl<T>(v, l);
+}
+template <typename T, int E>
+__global__ __launch_bounds__(256) void k_mad_sort(const T *__restrict__ X, int64_t sig_stride, int64_t off, int cnt, int64_t batch,
+                                                  T *__restrict__ sigma)
+{
+    constexpr int P = 64 * E;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t sig = (int64_t)blockIdx.x * 4 + wave;
+    if (sig >= batch) return;
+    const T *x = X + sig * sig_stride + off;
+    const T inf = (T)__builtin_inf();
+    T r[E];
+    bool nan = false;
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const int i = lane * E + u;
+        r[u] = i < cnt ? x[i] : inf;
+        nan = nan || r[u] != r[u];
+    }
+    const bool any_nan = __builtin_amdgcn_ballot_w64(nan) != 0;
+    mad_sort<T, E, P>(r, lane);
+    const int k0 = (cnt - 1) / 2;
+    const T a = mad_pick<T, E>(r, k0), b = mad_pick<T, E>(r, k0 + ((cnt & 1) ? 0 : 1));
+    const T med = (cnt & 1) ? a : (T)((T)(a / (T)2) + (T)(b / (T)2));
+    // |v - med| of the sorted values: falls, then rises (the slots beyond cnt stay +Inf at the end): one bitonic merge sorts it
+#pragma unroll
+    for (int u = 0; u < E; ++u) r[u] = (T)fabs((double)(T)(r[u] - med));
+    mad_merge<T, E, P, false>(r, lane);
+    const T a2 = mad_pick<T, E>(r, k0), b2 = mad_pick<T, E>(r, k0 + ((cnt & 1) ? 0 : 1));
+    const T mad = (cnt & 1) ? a2 : (T)((T)(a2 / (T)2) + (T)(b2 / (T)2));
+    if (lane == 0) sigma[sig] = any_nan ? (T)__builtin_nan("") : (T)(mad / (T)0.6745);
 }
 
 // the same on detail ranges that do not fit a CU's LDS (signals of more than 32768 Float64 / 65536 Float32 samples' worth of details):
@@ -275,12 +383,15 @@ __global__ __launch_bounds__(256) void k_mad_g(const T *__restrict__ X, int64_t 
     __shared__ WxSelScratch S;
     const T *x = X + (int64_t)blockIdx.x * sig_stride + off;
     T *v = work + (int64_t)blockIdx.x * cnt;
+    int nan = 0;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) nan |= x[i] != x[i];
+    nan = __syncthreads_or(nan);
     const T m = wx_median_lds<T>(x, cnt, &S);
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) v[i] = (T)fabs((double)(T)(x[i] - m));
     __threadfence_block();
     __syncthreads();
     const T r = wx_median_lds<T>(v, cnt, &S);
-    if (threadIdx.x == 0) sigma[blockIdx.x] = (T)(r / (T)0.6745);
+    if (threadIdx.x == 0) sigma[blockIdx.x] = nan ? (T)__builtin_nan("") : (T)(r / (T)0.6745);
 }
 
 }  // namespace
@@ -340,6 +451,22 @@ int api_noisest(const T *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo,
             const int64_t nb = batch - b0 < per ? batch - b0 : per;
             hipLaunchKernelGGL(k_mad_g<T>, dim3((unsigned)nb), dim3(256), 0, st, dX + b0 * n * k, n * k, col * n + row_lo, (int)cnt, work, ds + b0);
         }
+        if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "noisest kernel failed to launch"));
+        return io.finish(WX_OK);
+    }
+    // 65 ... 2048 coefficients: one wavefront sorts the values in its registers (k_mad_sort); WX_MAD_SORT_MAX (knob) lowers the limit
+    // (measured per GiB of signals, denoiseall: n = 256 / 512 / 1024 -- 128 / 256 / 512 coefficients -- 3.13 / 4.86 / 3.24 -> 1.83 / 1.88 / 1.83 ms;
+    // 1024 / 2048 coefficients lose to the workgroup selection: 3.5 against 2.3, 4.3 against 1.8 ms -- the cross-lane stages grow with E)
+    static const int mad_sort_max = wx_getenv("WX_MAD_SORT_MAX") ? atoi(wx_getenv("WX_MAD_SORT_MAX")) : 512;
+    if (cnt > 64 && cnt <= 2048 && cnt <= mad_sort_max && batch <= 0x7ffffff0) {
+        const dim3 g((unsigned)((batch + 3) / 4));
+#define WX_MS(EE) hipLaunchKernelGGL((k_mad_sort<T, EE>), g, dim3(256), 0, st, dX, n * k, col * n + row_lo, (int)cnt, batch, ds)
+        if (cnt <= 128) WX_MS(2);
+        else if (cnt <= 256) WX_MS(4);
+        else if (cnt <= 512) WX_MS(8);
+        else if (cnt <= 1024) WX_MS(16);
+        else WX_MS(32);
+#undef WX_MS
         if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "noisest kernel failed to launch"));
         return io.finish(WX_OK);
     }

@@ -151,14 +151,19 @@ constexpr int hs_revc(int v, int bits)
 // column in dst (dst_cols columns per signal, column = node).  gain = (c / 2)^K.  K = 5: 16 + 16 transform values and
 // 32 running sums per lane leave room for three wavefronts per SIMD (K = 6 needs 258 registers: one wavefront, and the
 // 64 loads of a step are then fully exposed -- measured 16 ms per 32 GiB against 8.5 ms for the LDS passes).
-template <int K, int U>
-__global__ __launch_bounds__(64) void k_haar_iswpt(const double *__restrict__ src, int64_t src_cols,
+// ORD (round 6, experiment behind WX_HAAR_ISWT_ORDER): 0 = consecutive blocks are the position groups of one node (the two wavefronts that
+// interleave 512-byte pieces of the same 32 columns run side by side), 1 = consecutive blocks are consecutive nodes (the groups of a node
+// are 2^d0 blocks apart); WPE = wavefronts per SIMD the kernel is built for (0 = the compiler's choice: three)
+template <int K, int U, int ORD = 0, int WPE = 0>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8)))
+void k_haar_iswpt(const double *__restrict__ src, int64_t src_cols,
                                                     double *__restrict__ dst, int64_t dst_cols, int n, int64_t batch,
                                                     int d0, double gain)
 {
     constexpr int NC = 1 << K, HALF = NC / 2;
     const int s = 1 << d0, nsteps = n >> d0, groups = s >> 6;
-    const int node = blockIdx.x / groups, g = blockIdx.x - node * groups;
+    const int node = ORD ? (int)(blockIdx.x & (unsigned)(s - 1)) : (int)(blockIdx.x / groups);
+    const int g = ORD ? (int)(blockIdx.x >> d0) : (int)(blockIdx.x - node * groups);
     const int lane = threadIdx.x;
     const int64_t r = 64 * g + lane;
     for (int64_t sig = blockIdx.y; sig < batch; sig += gridDim.y) {
@@ -273,8 +278,21 @@ int wx_haar_iswpt6(const double *src, int64_t src_cols, double *dst, int64_t dst
         hipLaunchKernelGGL((k_haar_iswpt<6, 1>), dim3((unsigned)blocks, (unsigned)gy), dim3(64), 0, st, src, src_cols, dst,
                            dst_cols, (int)n, batch, d0, gain);
     else
-        hipLaunchKernelGGL((k_haar_iswpt<5, 1>), dim3((unsigned)blocks, (unsigned)gy), dim3(64), 0, st, src, src_cols, dst,
-                           dst_cols, (int)n, batch, d0, gain);
+    {
+        // profiles/r06_cfg3_inverse.txt: six consecutive processes each -- order 1 is 1-2 % faster in every placement of the table (6.88 / 7.47 /
+        // 8.12 ms against 7.03 / 7.58 / 8.19), residency 2 the same as 3, 4 (spills) 18 ms; the spread itself follows the process sequence
+        // whatever the order or the residency: it is the physical placement of the 32 GiB table (profiles/r05_cfg3_inverse.md)
+        static const int ord = wx_getenv("WX_HAAR_ISWT_ORDER") ? atoi(wx_getenv("WX_HAAR_ISWT_ORDER")) : 1;
+        static const int wpe = wx_getenv("WX_HAAR_ISWT_WPE") ? atoi(wx_getenv("WX_HAAR_ISWT_WPE")) : 0;
+#define WX_HI(O, W) hipLaunchKernelGGL((k_haar_iswpt<5, 1, O, W>), dim3((unsigned)blocks, (unsigned)gy), dim3(64), 0, st, src, src_cols, dst, dst_cols, (int)n, batch, d0, gain)
+        if (ord == 1 && wpe == 2) WX_HI(1, 2);
+        else if (ord == 1 && wpe == 4) WX_HI(1, 4);
+        else if (ord == 1) WX_HI(1, 0);
+        else if (wpe == 2) WX_HI(0, 2);
+        else if (wpe == 4) WX_HI(0, 4);
+        else WX_HI(0, 0);
+#undef WX_HI
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return wx_set_hip_error(e, "haar iswpt launch", __FILE__, __LINE__);
     return WX_OK;
