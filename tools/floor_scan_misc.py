@@ -1,6 +1,6 @@
 """The callers' side of the path at several lengths: denoiseall (dwt -> per-signal MAD -> threshold -> idwt, Denoising.jl:651-712),
 bestbasistreeall(wpdall(x), BB()) (BestBasis.jl:253-262) and getbasiscoefall along one tree (Utils.jl:199-225), Float64, db4, batches of about 1 GiB of
-signal (0.25 GiB for the packet tables).  Times in ms and effective GB/s on signal-read-once + written-once bytes (denoise) or on the table's bytes."""
+signal (and packet tables of 1 GiB).  Times in ms and effective GB/s on signal-read-once + written-once bytes (denoise) or on the table's bytes."""
 import os
 import sys
 
@@ -23,7 +23,7 @@ def scan(lengths=None):
         print("f64 n %6d denoiseall(sig, dwt)      %7.3f ms (%4.1f %% of peak on 2 x signal bytes)" % (n, t, 100 * 2.0 * n * B * 8 / (t * 1e-3) / HBM_PEAK), flush=True)
         del x
         torch.cuda.empty_cache()
-        Bq = max((1 << 28) // (n * (L + 1) * 8), 1)
+        Bq = max((1 << 30) // (n * (L + 1) * 8), 1)          # tables of 1 GiB (0.25 GiB until round 6: launch-bound at every length)
         xq = wx.jl_empty((n, Bq), torch.float64, "cuda")
         xq.normal_()
         tab = wx.wpdall(xq, wt, L)

@@ -332,7 +332,7 @@ template <typename T, int E, int M> __device__ __forceinline__ void mad_sort(T (
         mad_merge<T, E, M, true>(r, lane);
     }
 }
-// the element of slot idx (wave-uniform)
+// the element of slot idx (the same register index for every lane; the lane part may differ from group to group)
 template <typename T, int E> __device__ __forceinline__ T mad_pick(const T (&r)[E], int idx)
 {
     const int u = idx % E, l = idx / E;
@@ -341,14 +341,20 @@ template <typename T, int E> __device__ __forceinline__ T mad_pick(const T (&r)[
     for (int q = 1; q < E; ++q) v = u == q ? r[q] : v;
     return mad_shfl<T>(v, l);
 }
-template <typename T, int E>
+// PL = lanes per signal: 64 (E registers each), or 32 / 16 / 8 / 4 with E = 1 -- 2 ... 16 SHORT signals side by side in one wavefront (every
+// partner of the network is lane ^ something below PL, so the groups never meet): 64-sample signals, 32 details each, took one wavefront per
+// signal in k_mad_wave (1.3 ms per GiB of signals: 16 M wavefronts)
+template <typename T, int E, int PL = 64>
 __global__ __launch_bounds__(256) void k_mad_sort(const T *__restrict__ X, int64_t sig_stride, int64_t off, int cnt, int64_t batch,
                                                   T *__restrict__ sigma)
 {
-    constexpr int P = 64 * E;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t sig = (int64_t)blockIdx.x * 4 + wave;
-    if (sig >= batch) return;
+    static_assert(PL == 64 || E == 1, "several signals per wavefront: one slot per lane");
+    constexpr int P = PL * E, SPW = 64 / PL;
+    const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63, lane = wl & (PL - 1), sub = wl / PL;
+    int64_t sig = ((int64_t)blockIdx.x * 4 + wave) * SPW + sub;
+    const bool live = sig < batch;
+    if (SPW == 1 && !live) return;
+    if (!live) sig = batch - 1;                                       // the lanes of a group beyond the batch keep the wavefront's network company
     const T *x = X + sig * sig_stride + off;
     const T inf = (T)__builtin_inf();
     T r[E];
@@ -359,18 +365,21 @@ __global__ __launch_bounds__(256) void k_mad_sort(const T *__restrict__ X, int64
         r[u] = i < cnt ? x[i] : inf;
         nan = nan || r[u] != r[u];
     }
-    const bool any_nan = __builtin_amdgcn_ballot_w64(nan) != 0;
-    mad_sort<T, E, P>(r, lane);
+    // NaN anywhere in the SIGNAL: the ballot restricted to the signal's lanes
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(nan);
+    const bool any_nan = PL == 64 ? bal != 0 : ((bal >> (sub * PL)) & ((1ull << (PL & 63)) - 1ull)) != 0;
+    mad_sort<T, E, P>(r, wl);
     const int k0 = (cnt - 1) / 2;
-    const T a = mad_pick<T, E>(r, k0), b = mad_pick<T, E>(r, k0 + ((cnt & 1) ? 0 : 1));
+    const int base = sub * PL * E;                                    // slot 0 of this lane's signal
+    const T a = mad_pick<T, E>(r, base + k0), b = mad_pick<T, E>(r, base + k0 + ((cnt & 1) ? 0 : 1));
     const T med = (cnt & 1) ? a : (T)((T)(a / (T)2) + (T)(b / (T)2));
     // |v - med| of the sorted values: falls, then rises (the slots beyond cnt stay +Inf at the end): one bitonic merge sorts it
 #pragma unroll
     for (int u = 0; u < E; ++u) r[u] = (T)fabs((double)(T)(r[u] - med));
-    mad_merge<T, E, P, false>(r, lane);
-    const T a2 = mad_pick<T, E>(r, k0), b2 = mad_pick<T, E>(r, k0 + ((cnt & 1) ? 0 : 1));
+    mad_merge<T, E, P, false>(r, wl);
+    const T a2 = mad_pick<T, E>(r, base + k0), b2 = mad_pick<T, E>(r, base + k0 + ((cnt & 1) ? 0 : 1));
     const T mad = (cnt & 1) ? a2 : (T)((T)(a2 / (T)2) + (T)(b2 / (T)2));
-    if (lane == 0) sigma[sig] = any_nan ? (T)__builtin_nan("") : (T)(mad / (T)0.6745);
+    if (lane == 0 && live) sigma[sig] = any_nan ? (T)__builtin_nan("") : (T)(mad / (T)0.6745);
 }
 
 // the same on detail ranges that do not fit a CU's LDS (signals of more than 32768 Float64 / 65536 Float32 samples' worth of details):
@@ -458,15 +467,22 @@ int api_noisest(const T *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo,
     // (measured per GiB of signals, denoiseall: n = 256 / 512 / 1024 -- 128 / 256 / 512 coefficients -- 3.13 / 4.86 / 3.24 -> 1.83 / 1.88 / 1.83 ms;
     // 1024 / 2048 coefficients lose to the workgroup selection: 3.5 against 2.3, 4.3 against 1.8 ms -- the cross-lane stages grow with E)
     static const int mad_sort_max = wx_getenv("WX_MAD_SORT_MAX") ? atoi(wx_getenv("WX_MAD_SORT_MAX")) : 512;
-    if (cnt > 64 && cnt <= 2048 && cnt <= mad_sort_max && batch <= 0x7ffffff0) {
-        const dim3 g((unsigned)((batch + 3) / 4));
+    if (cnt >= 3 && cnt <= 2048 && cnt <= mad_sort_max && batch <= 0x7ffffff0) {
+        dim3 g((unsigned)((batch + 3) / 4));
 #define WX_MS(EE) hipLaunchKernelGGL((k_mad_sort<T, EE>), g, dim3(256), 0, st, dX, n * k, col * n + row_lo, (int)cnt, batch, ds)
-        if (cnt <= 128) WX_MS(2);
+#define WX_MSS(PLL) do { g = dim3((unsigned)((batch + 4 * (64 / PLL) - 1) / (4 * (64 / PLL)))); hipLaunchKernelGGL((k_mad_sort<T, 1, PLL>), g, dim3(256), 0, st, dX, n * k, col * n + row_lo, (int)cnt, batch, ds); } while (0)
+        if (cnt <= 4) WX_MSS(4);
+        else if (cnt <= 8) WX_MSS(8);
+        else if (cnt <= 16) WX_MSS(16);
+        else if (cnt <= 32) WX_MSS(32);
+        else if (cnt <= 64) WX_MS(1);
+        else if (cnt <= 128) WX_MS(2);
         else if (cnt <= 256) WX_MS(4);
         else if (cnt <= 512) WX_MS(8);
         else if (cnt <= 1024) WX_MS(16);
         else WX_MS(32);
 #undef WX_MS
+#undef WX_MSS
         if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "noisest kernel failed to launch"));
         return io.finish(WX_OK);
     }
