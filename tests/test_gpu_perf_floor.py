@@ -2,7 +2,7 @@
 trees, pyramids (dwtall / idwtall, dwt/dwt_all.jl:39-110) and a random tree (wptall / iwptall along a tree, dwt_all.jl:152-225),
 Float64 and Float32, 1 GiB batches, must run at >= 13 % (margin under the table's 16 %) of the HBM peak on the algorithmic bytes in BOTH
 directions, and round-trip.
-The table goes to gpurun_out/r05_floor.txt (copied to profiles/ by the builder).
+The table goes to gpurun_out/r06_floor.txt (copied to profiles/ by the builder).
 
 These are THROUGHPUT assertions: they depend on the box, its clocks and its co-tenants, so they are not part of the parity gate
 (`-m gpu`) since round 5: own marker, run with `pytest -m perf tests/test_gpu_perf_floor.py`."""
@@ -29,7 +29,7 @@ FLOOR = 0.13          # the table's minimum is 0.16 (VERDICT r03 asked for 0.15)
 def test_no_entry_below_the_floor(wx):
     import floor_scan
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r05_floor.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_floor.txt"), "w") as f:
         f.write("# tools/floor_scan.py db4, one MI355X, 1 GiB batches; fraction of 8 TB/s on signal-read-once + written-once bytes\n")
         rows = floor_scan.scan("db4", out=f)
     assert len(rows) >= 100
@@ -45,9 +45,9 @@ FLOOR_2D = 0.12
 def test_no_2d_entry_below_its_floor(wx):
     """the 2-D companion (tools/floor_scan2d.py): square images 64 ... 1024, Float32 and Float64, full trees (full depth and L = 3),
     pyramids, wpdall; the floor is lower than in 1-D -- the generic two-pass path is at 0.19-0.27 -- but the holes of round 3 (0.01 at
-    Float64 512 x 512) cannot come back unnoticed.  Table to gpurun_out/r05_floor2d.txt."""
+    Float64 512 x 512) cannot come back unnoticed.  Table to gpurun_out/r06_floor2d.txt."""
     import floor_scan2d
-    with open(os.path.join(ROOT, "gpurun_out", "r05_floor2d.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_floor2d.txt"), "w") as f:
         rows = floor_scan2d.scan("db4", out=f)
     assert len(rows) >= 40
     bad = [r for r in rows if r["fwd_frac"] < FLOOR_2D or r["inv_frac"] < FLOOR_2D]
