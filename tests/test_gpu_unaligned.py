@@ -169,6 +169,28 @@ def test_2d_packets_of_offset_pointers(wx, oracle, unaligned_outputs, wname, dty
             assert relerr(_np(back), x) <= 10 * tol, ("iwpdall 2-D", m)
 
 
+@pytest.mark.parametrize("inputtype", ["sig", "dwt", "sdwt"])
+def test_in_out_arrays_on_offset_pointers(wx, oracle, unaligned_outputs, inputtype):
+    """the callers' side mutates arrays in place (threshold!, the costs of the tree selection, the moment sums that accumulate over
+    chunks): with every array of the pipeline at an offset pointer the in / out ones pass through the aligned copy BOTH ways.  denoiseall
+    on device tensors == the same call on host arrays (checked against the oracle in test_gpu_denoise.py); bestbasistree(JBB) and
+    bestbasistreeall(BB) of an offset table == the trees of the aligned one"""
+    rng = np.random.default_rng(65)
+    wt = wx.wavelet(wx.WT.db4)
+    for n, B in ((256, 9), (1024, 4), (4096, 3)):
+        x = np.asfortranarray(rng.standard_normal((n, B)) + 3 * np.sin(np.arange(n) / 7.0)[:, None])
+        xin = {"sig": x, "dwt": np.asarray(wx.dwtall(x, wt)), "sdwt": np.asarray(wx.sdwtall(x, wt, 4))}[inputtype]
+        ref = wx.denoiseall(xin, inputtype, wt)
+        got = wx.denoiseall(_off(xin), inputtype, wt)
+        assert got.data_ptr() % 16 in (4, 8)
+        assert relerr(_np(got), ref) <= 1e-12, (inputtype, n)
+    n, B = 512, 6
+    x = np.asfortranarray(rng.standard_normal((n, B)))
+    tab = wx.wpdall(x, wt)
+    assert (np.asarray(wx.bestbasistree(_off(np.asarray(tab)), wx.JBB())) == np.asarray(wx.bestbasistree(tab, wx.JBB()))).all()
+    assert (np.asarray(wx.to_numpy(wx.bestbasistreeall(_off(np.asarray(tab)), wx.BB()))) == np.asarray(wx.bestbasistreeall(tab, wx.BB()))).all()
+
+
 def test_no_hard_error_string_left_reachable():
     """the messages of the old hard errors are gone from the library's sources"""
     import os

@@ -625,8 +625,8 @@ static hipError_t wx_h2d_staged(void *dev, const void *user, size_t bytes, hipSt
 int WxIO::finish(int rc)
 {
     if (err != WX_OK) rc = err;                    // an argument error outranks the caller's generic code
-    if (any_realigned && rc == WX_OK)              // results of realigned device outputs go back on the stream, nothing waits
-        for (auto &it : items)
+    if (rc == WX_OK)                               // results of realigned device outputs (and in / out arrays whose item a caller marked
+        for (auto &it : items)                     // copy_out) go back on the stream, nothing waits
             if (it.realigned && it.copy_out) {
                 const hipError_t e = hipMemcpyAsync(it.user, it.dev, it.bytes, hipMemcpyDeviceToDevice, st);
                 if (e != hipSuccess) rc = wx_set_hip_error(e, "hipMemcpyAsync(realign out)", __FILE__, __LINE__);

@@ -1007,6 +1007,88 @@ __global__ __launch_bounds__(256) void k_swt_inv_level(WxInvDesc D, int n, int64
     }
 }
 
+// The same level, average based, out of an LDS tile (round 6: VERDICT r5 item 6 (i)).  k_swt_inv_level gives every output sample its own 2 F
+// global loads -- the vector cache serves them, but it is the kernel's bound: the top levels of a long column, which no fused pass takes
+// (they need whole classes of a node in LDS), ran at a quarter of the HBM rate each, and `iswpt` of 16384-sample signals at depth 4 was four
+// such launches: 0.08 of the roofline.  Here a workgroup stages P consecutive positions of both children of a node plus the halo
+// H = s (F - 1) the dilated taps reach (positions are periodic in n), and every output reads its 2 F taps from LDS: with
+// t0 = u + 1 (variant A) resp. u (variant B), u = p >> d, the first tap of either child sits at q0 = p (t0 odd) or p + s (t0 even) and the
+// taps walk 2 s apart, downwards in the low child and upwards in the high one -- the index arithmetic of k_swt_inv_level without its wraps.
+// Same products, same order of additions as that kernel.
+template <typename T, int HF>
+__global__ __launch_bounds__(256) void k_swt_inv_level_tile(WxInvDesc D, int n, int64_t batch, int P, int H, WxFilt filt)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_tile_smem[];
+    T *t1 = reinterpret_cast<T *>(wx_tile_smem), *t2 = t1 + (P + 2 * H);
+    const int d = D.d, s = 1 << d;
+    const int nodes = (D.layout == WX_LAYOUT_DWT) ? 1 : (1 << d);
+    const int tiles = n / P;
+    const int64_t units = (int64_t)batch * nodes * tiles;
+    for (int64_t unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const int tl = (int)(unit % tiles);
+        const int64_t t2i = unit / tiles;
+        const int b = (int)(t2i % nodes);
+        const int64_t sig = t2i / nodes;
+        if (D.layout == WX_LAYOUT_WPD && D.tree) {
+            const int64_t heap = ((int64_t)1 << d) + b;
+            if (!(heap <= D.ntree && D.tree[heap - 1])) continue;        // node has no children: nothing to do (uniform for the workgroup)
+        }
+        bool ok1, ok2;
+        const T *w1 = wx_inv_child<T>(D, sig, n, b, 0, ok1);
+        const T *w2 = wx_inv_child<T>(D, sig, n, b, 1, ok2);
+        T *out = reinterpret_cast<T *>(D.out) + sig * (int64_t)n * D.out_cols + (int64_t)((D.layout == WX_LAYOUT_DWT || d == 0) ? 0 : b) * n;
+        const int p0 = tl * P;
+        __syncthreads();                                          // the previous unit's reads are done
+        {
+            // eight loads of either child in flight per lane (one at a time left the staging bound by the load latency)
+            const int tot = P + 2 * H;
+            int i = threadIdx.x;
+            for (; i + 3 * 256 < tot; i += 4 * 256) {
+                T a[4], c[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int q = p0 - H + i + 256 * e;
+                    q = q < 0 ? q + n : (q >= n ? q - n : q);     // H <= n
+                    a[e] = w1[q];
+                    c[e] = w2[q];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { t1[i + 256 * e] = a[e]; t2[i + 256 * e] = c[e]; }
+            }
+            for (; i < tot; i += 256) {
+                int q = p0 - H + i;
+                q = q < 0 ? q + n : (q >= n ? q - n : q);
+                t1[i] = w1[q];
+                t2[i] = w2[q];
+            }
+        }
+        __syncthreads();
+        const int np = n >> d;
+        for (int i = threadIdx.x; i < P; i += 256) {
+            const int p = p0 + i, u = p >> d;
+            double acc = 0.0;
+#pragma unroll
+            for (int var = 0; var < 2; ++var) {
+                const int t0 = var ? u : (u + 1 == np ? 0 : u + 1);
+                const bool odd = t0 & 1;
+                int k1 = H + i + (odd ? 0 : s), k2 = k1;
+                double v = 0.0;
+                T av[HF], cv[HF];
+#pragma unroll
+                for (int m = 0; m < HF; ++m) { av[m] = t1[k1 - 2 * s * m]; cv[m] = t2[k2 + 2 * s * m]; }
+#pragma unroll
+                for (int m = 0; m < HF; ++m) {
+                    const double a = (double)av[m], c = (double)cv[m];
+                    if (!odd) { v = fma(filt.q[2 * m], a, v); v = fma(-filt.q[2 * m + 1], c, v); }
+                    else { v = fma(filt.q[2 * m + 1], a, v); v = fma(filt.q[2 * m], c, v); }
+                }
+                acc += v;
+            }
+            out[p] = (T)(acc * 0.5);
+        }
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Fused average-based iswpt pass: depth d+K -> d in one kernel.  The average of the two shift
@@ -1630,6 +1712,29 @@ int wx_dev_swt_inv(const T *xw, T *x, int64_t n, int L, int layout, int ncols, i
             const int sm_mode = sm >= 0 ? 1 : 0;
             const int64_t per_node = sm_mode ? (n >> d) : n;
             const int64_t total = batch * nodes_d * per_node;
+            // average based, long columns: out of an LDS tile (k_swt_inv_level_tile) while the halo s (F - 1) of the dilated taps stays small
+            // against the tile -- the top levels, which is where the per-sample kernel is slow
+            static const bool tile_off = wx_getenv("WX_SWTINV_TILE") && atoi(wx_getenv("WX_SWTINV_TILE")) == 0;
+            const int64_t halo = ((int64_t)1 << d) * (filt.F - 1);
+            const int Ptile = 2048;
+            if (!tile_off && sm_mode == 0 && n >= 2 * Ptile && n % Ptile == 0 && halo <= 512 && !wx_force_generic_swt()) {
+                const size_t ldst = (size_t)2 * (Ptile + 2 * halo) * sizeof(T);
+                const int64_t units = batch * nodes_d * (n / Ptile);
+                const int64_t gt = units < 256 * 8 ? units : 256 * 8;
+                typedef void (*KT)(WxInvDesc, int, int64_t, int, int, WxFilt);
+                KT kt = nullptr;
+                switch (filt.F / 2) {
+#define WX_KT(h) case h: kt = k_swt_inv_level_tile<T, h>; break;
+                    WX_KT(1) WX_KT(2) WX_KT(3) WX_KT(4) WX_KT(5) WX_KT(6) WX_KT(7) WX_KT(8) WX_KT(9) WX_KT(10)
+#undef WX_KT
+                }
+                if (kt) {
+                    if (ldst > 64 * 1024)
+                        WX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
+                    hipLaunchKernelGGL(kt, dim3((unsigned)gt), dim3(256), ldst, st, D, (int)n, batch, Ptile, (int)halo, filt);
+                } else
+                    hipLaunchKernelGGL(k_swt_inv_level<T>, dim3(wx_grid1(total)), dim3(256), 0, st, D, (int)n, batch, sm_mode, 0, 0, filt);
+            } else
             hipLaunchKernelGGL(k_swt_inv_level<T>, dim3(wx_grid1(total)), dim3(256), 0, st, D, (int)n, batch, sm_mode,
                                sm >= 0 ? (int)sd[d] : 0, sm >= 0 ? (int)sd[d + 1] : 0, filt);
         }
