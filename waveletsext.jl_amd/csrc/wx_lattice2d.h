@@ -1061,6 +1061,8 @@ static int wx_lattice2d_fused_launch(const float *src, float *dst, float *ring, 
         } else if (hc.mm.e) {                                                                                              \
             if constexpr (HB == 1) return 0;          /* spills: the two launches are faster */                           \
             else hipLaunchKernelGGL((k_lat2d_fused_f32<NSS, false, HB, true>), grid, wg, 0, st, src, ring, dst, last_img, fz, dc);          \
+        } else if (HB == 1 && NSS == 10) {                                                                                 \
+            return 0;                                 /* 18 / 20 taps on 256 x 256 forward: 57 spilled registers */        \
         } else hipLaunchKernelGGL((k_lat2d_fused_f32<NSS, false, HB, false>), grid, wg, 0, st, src, ring, dst, last_img, fz, dc);           \
         break;
     switch (wx_lat_stages(filt.F)) {
