@@ -27,7 +27,7 @@ def wx():
     import subprocess
     lib = os.path.join(ROOT, "waveletsext.jl_amd", "csrc", "libwaveletsext_hip.so")
     if not os.path.exists(lib):                       # fresh checkout: the .so is not in the history
-        subprocess.run(["make", "-C", os.path.dirname(lib), "-j%d" % (os.cpu_count() or 4)], check=True)   # ~16 min on 8 cores (profiles/r06_clean_build.txt)
+        subprocess.run(["make", "-C", os.path.dirname(lib), "-j%d" % (os.cpu_count() or 4)], check=True)   # ~12 min on 8 cores (profiles/r06_clean_build.txt)
     import waveletsext_jl_amd
     return waveletsext_jl_amd
 

@@ -7,7 +7,7 @@
 #include "wx_lattice_dev.h"
 
 #define WX_G32(k) int wx_lattice_g32_##k(bool, const float *, float *, int64_t, int, int64_t, int64_t, const WxFilt &, hipStream_t);
-WX_G32(0) WX_G32(1) WX_G32(2) WX_G32(3) WX_G32(4) WX_G32(5) WX_G32(6)
+WX_G32(0) WX_G32(1) WX_G32(2) WX_G32(3) WX_G32(5) WX_G32(6)
 #undef WX_G32
 
 // 0 = not applicable, 1 = launched, < 0 = error
@@ -24,7 +24,7 @@ int wx_lattice_f32(bool inverse, const float *x, float *y, int64_t n, int L, int
         case 2048: return wx_lattice_g32_1(inverse, x, y, n, L, batch, in_stride, filt, st);
         case 1024: return wx_lattice_g32_2(inverse, x, y, n, L, batch, in_stride, filt, st);
         case 512: return wx_lattice_g32_3(inverse, x, y, n, L, batch, in_stride, filt, st);
-        case 256: return wx_lattice_g32_4(inverse, x, y, n, L, batch, in_stride, filt, st);
+        case 256: return 0;     // full trees of 256 Float32 samples go through the masked tree kernels (wx_api.hip, wx_dwt1d.hip); the dedicated unit is not built since round 6
         case 128: return wx_lattice_g32_5(inverse, x, y, n, L, batch, in_stride, filt, st);
         case 64: return wx_lattice_g32_6(inverse, x, y, n, L, batch, in_stride, filt, st);
         default: return 0;

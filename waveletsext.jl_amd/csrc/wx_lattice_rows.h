@@ -90,8 +90,12 @@ int WX_ROWS_FN(f64)(const double *x, double *y, int64_t in_img, int64_t out_img,
 {
     return wx_lattice_rows_launch<double, WX_ROWS_SH, 8, WX_ROWS_INV>(x, y, in_img, out_img, m, L, batch, filt, st);
 }
+// (the Float32 row kernels -- 128 columns: 0.22 -> 0.28 of the roofline, nothing at depth 3 -- are not built since round 6: they were half of
+// this family's 34 CPU-minutes of compile time, profiles/r06_clean_build.txt; -DWX_ROWS_F32=1 brings them back with the dispatch below)
+#if WX_ROWS_F32
 int WX_ROWS_FN(f32)(const float *x, float *y, int64_t in_img, int64_t out_img, int64_t m, int L, int64_t batch, const WxFilt &filt, hipStream_t st)
 {
     return wx_lattice_rows_launch<float, WX_ROWS_SH, 8, WX_ROWS_INV>(x, y, in_img, out_img, m, L, batch, filt, st);
 }
+#endif
 #endif
