@@ -356,6 +356,18 @@ int wx_idwt3d_f64(const double *x, double *y, int64_t n1, int64_t n2, int64_t n3
 int wx_idwt3d_f32(const float *x, float *y, int64_t n1, int64_t n2, int64_t n3, int L, int64_t batch, const double *qmf,
                   int F, void *stream);
 
+/* denoiseall(x, :sig, wt; L, dnt, estnoise = noisest, smooth) Denoising.jl:651-712 (denoise of one signal, Denoising.jl:483-599: batch = 1) for the
+ * VisuShrink family: xhat[:, i] = idwt(threshold(dwt(x[:, i], wt, L), th_kind, sigma_i * t), wt, L) with sigma_i = noisest(dwt(x[:, i])) =
+ * mad(finest detail coefficients) / 0.6745 (Denoising.jl:214-232), t = dnt.t (VisuShrink: sqrt(2 log n)), th_kind as wx_threshold_*.
+ * undersmooth != 0 (smooth = :undersmooth) leaves the coarsest scaling coefficients alone.  sigma (optional, host or device, batch values)
+ * receives the noise estimates.  Float64 signals of 1024 ... 4096 samples with filters of up to 8 taps and the Hard / Soft / SemiSoft rules
+ * take ONE pass (signal in, denoised signal out: the coefficients never leave the registers); every other case runs the three steps
+ * wx_wpt1d_* -> wx_noisest_* -> wx_iwpt1d_thresh_* on stream-ordered scratch, so the result does not depend on which applies. */
+int wx_denoiseall_sig_f64(const double *x, double *xhat, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind,
+                          double t, int undersmooth, double *sigma, void *stream);
+int wx_denoiseall_sig_f32(const float *x, float *xhat, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind,
+                          double t, int undersmooth, float *sigma, void *stream);
+
 /* iwpt / idwt with the thresholding step of denoise() applied while the coefficients are loaded (Denoising.jl:510-533:
  * threshold(x, dnt.th, sigma * dnt.t) followed by idwt / iwpt): one pass over the coefficient array instead of two.
  * Arguments as wx_iwpt1d_* plus those of wx_threshold_* (k = 1): rows [row_lo, n) of signal i are thresholded with

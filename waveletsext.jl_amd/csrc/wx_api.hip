@@ -5,6 +5,7 @@
 #include "wx_debug.h"
 #include "wx_kernels.h"
 #include "wx_lanetree.h"
+#include "wx_lattice_dn_api.h"
 #include <atomic>
 #include <cstring>
 
@@ -320,6 +321,63 @@ static int api_iwpt1d_thresh(const T *x, T *y, int64_t n, int L, const uint8_t *
     return io.finish(rc);
 }
 
+// ---- denoiseall(x, :sig, wt; L, dnt, estnoise = noisest, smooth) Denoising.jl:651-712 ------------------------------------------
+// One pass over the signals where the lattice kernel applies (wx_lattice_dn.h: Float64, 1024 ... 4096 samples, up to 8 taps, Hard / Soft /
+// SemiSoft), else the three steps the reference takes -- dwtall, noisest per signal, threshold on the loads of idwtall -- with the
+// coefficients and the estimates in stream-ordered scratch.  sigma (optional, device or host): the noise estimates.
+extern "C" int wx_noisest_f64(const double *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo, int64_t col, double *sigma, void *stream);
+extern "C" int wx_noisest_f32(const float *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo, int64_t col, float *sigma, void *stream);
+template <typename T>
+static int api_denoiseall_sig(const T *x, T *y, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind, double tscale,
+                              int undersmooth, T *sigma, void *stream)
+{
+    WxFilt filt;
+    int rc = wx_pack_filter(qmf, F, &filt);
+    if (rc) return rc;
+    WX_REQUIRE(n >= 1 && batch >= 0, WX_EARG, "denoiseall: bad dimensions");
+    WX_REQUIRE(n < ((int64_t)1 << 30), WX_EUNSUPPORTED, "denoiseall: signal length >= 2^30 not supported");
+    WX_REQUIRE(th_kind >= 0 && th_kind <= 3, WX_EARG, "th_kind: 0 HardTH, 1 SoftTH, 2 SemiSoftTH, 3 SteinTH");
+    WX_REQUIRE(wx_isdyadic(n) && n >= 2, WX_EASSERT, "@assert isdyadic(size(y,1))");                    // noisest, Denoising.jl:218
+    WX_REQUIRE(0 <= L && L <= wx_maxtransformlevels(n), WX_EASSERT, "maketree: isdyadic(n) and 0 <= L <= maxtransformlevels(n)");
+    if ((rc = wx_need_device())) return rc;
+    hipStream_t st = wx_stream(stream);
+    WxScratch scr(st);
+    WxIO io(st);
+    const T *dx = (const T *)io.in(x, sizeof(T) * n * batch);
+    T *dy = (T *)io.out(y, sizeof(T) * n * batch);
+    T *dsig = sigma ? (T *)io.out(sigma, sizeof(T) * batch) : nullptr;
+    if (batch && (!dx || !dy || (sigma && !dsig))) return io.finish(WX_EHIP);
+    if (batch == 0) return io.finish(WX_OK);
+    if constexpr (sizeof(T) == 8) {
+        static const bool off = wx_getenv("WX_DENOISE_ONEPASS") && atoi(wx_getenv("WX_DENOISE_ONEPASS")) == 0;
+        if (!off && !wx_force_generic() && !wx_skip_register_kernels() && th_kind != 3 && L >= 1 && wx_lattice_applicable_f64(filt)) {
+            int r = 0;
+            if (n == 4096) r = wx_lattice_denoise0_f64(dx, dy, n, L, batch, filt, th_kind, tscale, undersmooth, dsig, st);
+            else if (n == 2048) r = wx_lattice_denoise1_f64(dx, dy, n, L, batch, filt, th_kind, tscale, undersmooth, dsig, st);
+            else if (n == 1024) r = wx_lattice_denoise2_f64(dx, dy, n, L, batch, filt, th_kind, tscale, undersmooth, dsig, st);
+            if (r) return io.finish(r < 0 ? r : WX_OK);
+        }
+    }
+    // the separate steps: every one of them takes device pointers as they are
+    T *w = (T *)scr.alloc(sizeof(T) * n * batch);
+    if (!w) return io.finish(WX_EHIP);
+    if (!dsig) {
+        dsig = (T *)scr.alloc(sizeof(T) * batch);
+        if (!dsig) return io.finish(WX_EHIP);
+    }
+    std::vector<uint8_t> tree((size_t)(n > 1 ? n - 1 : 1), 0);
+    for (int d = 0; d < L; ++d) tree[((size_t)1 << d) - 1] = 1;
+    const int64_t ntree = n - 1;
+    rc = api_wpt1d<T, false>(dx, w, n, 0, tree.data(), ntree, batch, qmf, F, stream);
+    if (rc == WX_OK) {
+        if constexpr (sizeof(T) == 8) rc = wx_noisest_f64(w, n, 1, batch, n / 2, 0, dsig, stream);
+        else rc = wx_noisest_f32(w, n, 1, batch, n / 2, 0, dsig, stream);
+    }
+    if (rc == WX_OK)
+        rc = api_iwpt1d_thresh<T>(w, dy, n, 0, tree.data(), ntree, batch, qmf, F, th_kind, dsig, batch, undersmooth ? (n >> L) : 0, tscale, stream);
+    return io.finish(rc);
+}
+
 // ---- iwpd ---------------------------------------------------------------------------------
 template <typename T>
 static int api_iwpd1d(const T *xw, T *xh, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree, int64_t batch,
@@ -425,6 +483,13 @@ int wx_iwpt1d_thresh_f32(const float *xw, float *xhat, int64_t n, int L, const u
                          const double *qmf, int F, int th_kind, const float *t, int64_t nt, int64_t row_lo, double scale,
                          void *stream)
 { return api_iwpt1d_thresh<float>(xw, xhat, n, L, tree, ntree, batch, qmf, F, th_kind, t, nt, row_lo, scale, stream); }
+
+int wx_denoiseall_sig_f64(const double *x, double *xhat, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind, double t,
+                          int undersmooth, double *sigma, void *stream)
+{ return api_denoiseall_sig<double>(x, xhat, n, L, batch, qmf, F, th_kind, t, undersmooth, sigma, stream); }
+int wx_denoiseall_sig_f32(const float *x, float *xhat, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind, double t,
+                          int undersmooth, float *sigma, void *stream)
+{ return api_denoiseall_sig<float>(x, xhat, n, L, batch, qmf, F, th_kind, t, undersmooth, sigma, stream); }
 
 int wx_iwpd1d_f64(const double *xw, double *xhat, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree,
                   int64_t batch, const double *qmf, int F, void *stream)

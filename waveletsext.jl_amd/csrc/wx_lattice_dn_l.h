@@ -1,0 +1,68 @@
+// wx_lattice_dn_l.h -- launcher of the one-pass denoise kernels (wx_lattice_dn.h); included by wx_lattice_dn{0,1,2}.hip with WX_DN_SH = 0, 1, 2
+// (signals of 4096 >> SH samples) and WX_DN_FN = the launcher's name: one translation unit per length so that the kernels compile in parallel.
+// Reference: denoiseall(x, :sig, wt; L, dnt, estnoise = noisest, smooth) Denoising.jl:651-712.
+#include "wx_lattice_dn.h"
+#include <cstring>
+#include <vector>
+
+// 0 = not applicable (the caller runs the separate kernels), 1 = launched, < 0 = error
+int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, int th_kind, double scale, int undersmooth,
+             double *sigma, hipStream_t st)
+{
+    constexpr int SH = WX_DN_SH;
+    constexpr int64_t per = (int64_t)1 << SH;
+    if (n != (4096 >> SH) || L < 1 || L + SH > 12 || filt.F < 2 || batch < per || batch > 0x7fffffff) return 0;
+    if ((batch & (per - 1)) && x == y) return 0;             // the tail wavefront re-does signals: out of place only
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
+    const int ns = wx_lat_stages(filt.F);
+    if (ns != 1 && ns != 2 && ns != 4) return 0;
+    WxLatW cw2[2];
+    memset(cw2, 0, sizeof cw2);
+    WxLatW &cwf = cw2[0], &cwi = cw2[1];
+    if (!wx_lattice_factor(filt, L, false, &cwf.c) || !wx_lattice_factor(filt, L, true, &cwi.c)) return 0;
+    {
+        WxLat one;
+        if (!wx_lattice_factor(filt, 1, false, &one)) return 0;
+        const long double g = one.g0;                           // product of the cosines of one level
+        long double af = 1, ai = 1;
+        for (int l = 0; l <= 12; ++l) { cwf.gl[l] = (double)af; cwi.gl[l] = (double)ai; af *= g; ai *= 1 / g; }
+    }
+    cwf.tail_bsig = cwi.tail_bsig = 0;
+    WxScratch scr(st);
+    // the pyramid of depth L as node flags in heap order: node (d, 0) = index 2^d is split for d < L
+    std::vector<uint8_t> tree((size_t)n - 1, 0);
+    for (int d = 0; d < L; ++d) tree[((size_t)1 << d) - 1] = 1;
+    const uint8_t *dstatus = (const uint8_t *)scr.upload(tree.data(), tree.size());
+    WxLatTreeSc *tsc = (WxLatTreeSc *)scr.alloc(sizeof(WxLatTreeSc));
+    if (!dstatus || !tsc) return WX_EHIP;
+    if (hipMemsetAsync(tsc->dep, 0, sizeof(tsc->dep), st) != hipSuccess) return wx_set_error(WX_EHIP, "lattice tree tables");
+    hipLaunchKernelGGL((k_lat_treesc_prep<SH>), dim3(8), dim3(256), 0, st, dstatus, (int64_t)tree.size(), L, tsc);
+    hipLaunchKernelGGL(k_lat_treesc_prep2, dim3(1), dim3(64), 0, st, tsc, 0);
+    const WxLatTreeSc *ctsc = tsc;
+    const WxLatW *cws = (const WxLatW *)wx_const_upload(cw2, sizeof cw2, st, true);
+    if (!cws) return WX_EHIP;
+    const unsigned nw = (unsigned)((batch + per - 1) / per);
+    const int lsig = (int)(batch - per);
+    WxDnArg dn;
+    dn.kind = th_kind;
+    dn.zmask = undersmooth ? (((1u << L) - 1u) << SH) : 0u;
+    dn.zval = undersmooth ? 0u : 1u;
+    dn.scale = scale;
+    dn.sigma = sigma;
+    switch (ns) {
+#define WX_DN_GO(NSS)                                                                                                          \
+    case NSS:                                                                                                                  \
+        hipLaunchKernelGGL((k_lat_denoise_f64<NSS, 2, SH>), dim3(nw), dim3(64), 0, st, x, y, lsig, (unsigned)n, (unsigned)n, cws, ctsc, dn); \
+        break;
+#ifdef WX_DN_ONLY4
+        WX_DN_GO(4)
+#else
+        WX_DN_GO(1) WX_DN_GO(2) WX_DN_GO(4)
+#endif
+#undef WX_DN_GO
+    default: return 0;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wx_set_hip_error(e, "one-pass denoise launch", __FILE__, __LINE__);
+    return 1;
+}

@@ -190,6 +190,19 @@ def threshold(x, th, t):
     return out.arr
 
 
+def _denoise_sig(xa, wt, L, dnt, smooth, batched):
+    """denoise / denoiseall(x, :sig, wt; L, dnt, smooth) with estnoise = noisest (Denoising.jl:483-599, 651-712): wx_denoiseall_sig_*"""
+    from ._arrays import qmf_arg
+    n = xa.shape[0]
+    N = xa.shape[-1] if batched else 1
+    q, qp, F = qmf_arg(wt)
+    out = xa.new(xa.shape)
+    fn = getattr(_lib.lib(), "wx_denoiseall_sig" + xa.suffix)
+    _lib.check(fn(xa.ptr, out.ptr, n, int(L), N, qp, F, dnt.th.kind, float(dnt.t), 1 if smooth == "undersmooth" else 0,
+                  ctypes.c_void_p(0), xa.stream()))
+    return out.arr
+
+
 def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
     assert smooth in ("undersmooth", "regular")                       # Denoising.jl:493
     assert inputtype in INPUTTYPES                                     # Denoising.jl:494
@@ -202,6 +215,10 @@ def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
     if inputtype == "sig":
         if wt is None:
             raise ValueError("inputtype=:sig not supported with wt=nothing")    # Denoising.jl:498
+        if bestTH is None and (estnoise is None or estnoise is noisest) and xa.arr.ndim == (2 if batched else 1) and isdyadic(n):
+            # the whole pipeline behind one entry point: one pass over the signals where the lattice kernel applies (csrc/wx_lattice_dn.h),
+            # else dwtall -> noisest -> threshold on the loads of idwtall inside the library
+            return _denoise_sig(xa, wt, L, dnt, smooth, batched)
         xa = Arg(dwtall(xa.arr, wt, L) if batched else dwt(xa.arr, wt, L))
         inputtype = "dwt"
     if inputtype not in ("dwt", "wpt"):
