@@ -47,28 +47,28 @@ def _sigma_c(wx, x, wt, L, th_kind=0, t=1.0, undersmooth=0):
     return y, sig
 
 
-@pytest.mark.parametrize("n", [4096, 2048, 1024])
+@pytest.mark.parametrize("n", [4096, 2048, 1024, 512, 256, 128, 64])
 @pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db8"])
 def test_onepass_against_the_oracle(wx, oracle, n, wname):
     rng = np.random.default_rng(n + len(wname))
     wt = wx.wavelet(getattr(wx.WT, wname))
-    B = 37                                   # not a multiple of the signals per wavefront: the tail wavefront re-does signals
+    B = 37 if n >= 1024 else 3 * (4096 // n) + 5           # not a multiple of the signals per wavefront: the tail wavefront re-does signals
     x = _signals(rng, n, B, "noisy")
     Lmax = wx.maxtransformlevels(n)
-    for L in (Lmax, 5, 1):
+    for L in (Lmax, min(5, Lmax - 1), 1):
         for smooth in ("regular", "undersmooth"):
             for thname in ("hard", "soft", "semisoft", "stein"):
-                if (L, thname) not in ((Lmax, "hard"), (Lmax, "soft"), (5, "semisoft"), (5, "hard"), (1, "soft"), (Lmax, "stein")):
+                if (L, thname) not in ((Lmax, "hard"), (Lmax, "soft"), (min(5, Lmax - 1), "semisoft"), (min(5, Lmax - 1), "hard"), (1, "soft"), (Lmax, "stein")):
                     continue
                 dnt = wx.VisuShrink(n, getattr(wx, TH[thname])())
                 Y = wx.to_numpy(wx.denoiseall(x, "sig", wt, L=L, dnt=dnt, smooth=smooth))
                 assert Y.shape == (n, B)
-                for i in (0, 1, 2, 3, B - 2, B - 1):
+                for i in sorted(set(range(0, B, max(B // 9, 1))) | {1, 2, 3, B - 2, B - 1}):
                     exp = oracle.denoise(x[:, i], "sig", wt.qmf, L=L, th=thname, t=dnt.t, smooth=smooth)
                     assert relerr(Y[:, i], exp) <= 1e-10, (n, wname, L, smooth, thname, i)
 
 
-@pytest.mark.parametrize("n", [4096, 2048, 1024])
+@pytest.mark.parametrize("n", [4096, 2048, 1024, 512, 256, 128, 64])
 def test_onepass_noise_estimates(wx, oracle, n):
     """the sigma output of the entry point against oracle.noisest(dwt(x)) for ordinary, tied, heavy-tailed and wide-range data"""
     wt = wx.wavelet(wx.WT.db4)
@@ -77,7 +77,7 @@ def test_onepass_noise_estimates(wx, oracle, n):
     tree = np.asarray(wx.maketree(n, L, "dwt"), dtype=bool)
     for kind, w in (("noisy", wt), ("sparse", haar), ("quantised", haar), ("quantised", wt), ("range", wt), ("cauchy", wt)):
         rng = np.random.default_rng(hash((n, kind)) & 0xffff)
-        B = 21
+        B = 21 if n >= 1024 else 2 * (4096 // n) + 3
         x = _signals(rng, n, B, kind)
         y, sig = _sigma_c(wx, x, w, L)
         for i in range(B):
@@ -94,23 +94,23 @@ def test_onepass_noise_estimates(wx, oracle, n):
 
 def test_onepass_constant_nan_and_small_batches(wx, oracle):
     wt = wx.wavelet(wx.WT.db4)
-    for n in (4096, 2048, 1024):
+    for n in (4096, 2048, 1024, 512, 64):
         L = wx.maxtransformlevels(n)
         rng = np.random.default_rng(n)
-        x = _signals(rng, n, 9, "noisy")
+        x = _signals(rng, n, 9 if n >= 1024 else 4096 // n + 9, "noisy")
         x[:, 2] = 3.25                       # constant: every detail 0 up to rounding, sigma ~ 0, the signal comes back
         x[:, 5] = 0.0                        # exactly zero everywhere
         y, sig = _sigma_c(wx, x, wt, L)
         assert sig[5] == 0.0 and np.abs(y[:, 5]).max() == 0.0
         assert abs(sig[2]) <= 1e-12 and relerr(y[:, 2], x[:, 2]) <= 1e-10
-        for i in (0, 8):
+        for i in (0, x.shape[1] - 1):
             assert relerr(y[:, i], oracle.denoise(x[:, i], "sig", wt.qmf, L=L, th="hard", t=1.0)) <= 1e-10
         # a NaN sample: its signal's estimate is NaN (Statistics.median), the neighbours are untouched
         xn = x.copy(order="F")
         xn[n // 3, 4] = np.nan
         y2, sig2 = _sigma_c(wx, xn, wt, L)
         assert np.isnan(sig2[4])
-        for i in (3, 5, 8):
+        for i in (3, 5, x.shape[1] - 1):
             assert sig2[i] == sig[i] and (y2[:, i] == y[:, i]).all()
         # batches below the signals per wavefront (the separate kernels take them) and a single signal through denoise()
         for B in (1, 2, 3):
@@ -126,7 +126,7 @@ def test_entry_point_on_every_other_length_and_type(wx, oracle, dtype):
     """lengths and types the one-pass kernel does not take: the same entry point runs the separate steps"""
     wt = wx.wavelet(wx.WT.db4)
     tol = 1e-10 if dtype == np.float64 else 2e-4
-    for n in (8, 64, 256, 512, 8192, 16384) + ((1024, 4096) if dtype == np.float32 else ()):
+    for n in (8, 32, 8192, 16384) + ((64, 256, 1024, 4096) if dtype == np.float32 else ()):
         rng = np.random.default_rng(n)
         x = np.asfortranarray(_signals(rng, n, 5, "noisy").astype(dtype))
         for L in (wx.maxtransformlevels(n), 2, 0):

@@ -322,7 +322,7 @@ static int api_iwpt1d_thresh(const T *x, T *y, int64_t n, int L, const uint8_t *
 }
 
 // ---- denoiseall(x, :sig, wt; L, dnt, estnoise = noisest, smooth) Denoising.jl:651-712 ------------------------------------------
-// One pass over the signals where the lattice kernel applies (wx_lattice_dn.h: Float64, 1024 ... 4096 samples, up to 8 taps, Hard / Soft /
+// One pass over the signals where the lattice kernel applies (wx_lattice_dn.h: Float64, 64 ... 4096 samples, up to 8 taps, Hard / Soft /
 // SemiSoft), else the three steps the reference takes -- dwtall, noisest per signal, threshold on the loads of idwtall -- with the
 // coefficients and the estimates in stream-ordered scratch.  sigma (optional, device or host): the noise estimates.
 extern "C" int wx_noisest_f64(const double *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo, int64_t col, double *sigma, void *stream);
@@ -352,9 +352,12 @@ static int api_denoiseall_sig(const T *x, T *y, int64_t n, int L, int64_t batch,
         static const bool off = wx_getenv("WX_DENOISE_ONEPASS") && atoi(wx_getenv("WX_DENOISE_ONEPASS")) == 0;
         if (!off && !wx_force_generic() && !wx_skip_register_kernels() && th_kind != 3 && L >= 1 && wx_lattice_applicable_f64(filt)) {
             int r = 0;
-            if (n == 4096) r = wx_lattice_denoise0_f64(dx, dy, n, L, batch, filt, th_kind, tscale, undersmooth, dsig, st);
-            else if (n == 2048) r = wx_lattice_denoise1_f64(dx, dy, n, L, batch, filt, th_kind, tscale, undersmooth, dsig, st);
-            else if (n == 1024) r = wx_lattice_denoise2_f64(dx, dy, n, L, batch, filt, th_kind, tscale, undersmooth, dsig, st);
+            switch (n) {
+#define WX_DN_CASE(k) case 4096 >> k: r = wx_lattice_denoise##k##_f64(dx, dy, n, L, batch, filt, th_kind, tscale, undersmooth, dsig, st); break;
+                WX_DN_CASE(0) WX_DN_CASE(1) WX_DN_CASE(2) WX_DN_CASE(3) WX_DN_CASE(4) WX_DN_CASE(5) WX_DN_CASE(6)
+#undef WX_DN_CASE
+            default: break;
+            }
             if (r) return io.finish(r < 0 ? r : WX_OK);
         }
     }

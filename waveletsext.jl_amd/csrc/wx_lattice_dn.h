@@ -55,22 +55,31 @@ __device__ __forceinline__ double dn_next_up(double a)
     if (a == 0.0) return __longlong_as_double(1ll);
     return dn_unkey(dn_key(a) + 1ull);
 }
-template <int GW> __device__ __forceinline__ double dn_gmin(double v)
+// a signal's lanes: GW of them, ST apart (ST = 1: consecutive lanes)
+template <int GW, int ST = 1> __device__ __forceinline__ double dn_gmin(double v)
 {
 #pragma unroll
-    for (int o = GW / 2; o > 0; o >>= 1) { const double u = __shfl_xor(v, o, 64); v = u < v ? u : v; }
+    for (int o = ST * GW / 2; o >= ST; o >>= 1) { const double u = __shfl_xor(v, o, 64); v = u < v ? u : v; }
     return v;
 }
-template <int GW> __device__ __forceinline__ double dn_gmax(double v)
+template <int GW, int ST = 1> __device__ __forceinline__ double dn_gmax(double v)
 {
 #pragma unroll
-    for (int o = GW / 2; o > 0; o >>= 1) { const double u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
+    for (int o = ST * GW / 2; o >= ST; o >>= 1) { const double u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
     return v;
 }
-template <int GW> __device__ __forceinline__ int dn_gsum(int v)
+template <int GW, int ST = 1> __device__ __forceinline__ int dn_gsum(int v)
 {
+    if constexpr (GW == 16 && ST == 1) {
+        // every lane of a 16-lane row gets the row's sum: four DPP adds (quad_perm 1 0 3 2, quad_perm 2 3 0 1, row_half_mirror, row_mirror)
+        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
+    } else {
 #pragma unroll
-    for (int o = GW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        for (int o = ST * GW / 2; o >= ST; o >>= 1) v += __shfl_xor(v, o, 64);
+    }
     return v;
 }
 // c += #{lanes of the group with pred}: the whole wavefront -> ballot + population count (scalar), else a per-lane counter (dn_gsum later)
@@ -79,10 +88,10 @@ template <int GW> __device__ __forceinline__ void dn_acc(int &c, bool pred)
     if constexpr (GW == 64) c += (int)__popcll(__builtin_amdgcn_ballot_w64(pred));
     else c += pred ? 1 : 0;
 }
-template <int GW> __device__ __forceinline__ int dn_fin(int c)
+template <int GW, int ST = 1> __device__ __forceinline__ int dn_fin(int c)
 {
     if constexpr (GW == 64) return c;
-    else return dn_gsum<GW>(c);
+    else return dn_gsum<GW, ST>(c);
 }
 __device__ __forceinline__ bool dn_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0; }
 
@@ -92,27 +101,41 @@ template <int CB, typename F> __device__ __forceinline__ void dn_each(F &&f)
 {
     lat_for<64>([&](auto Rc) {
         constexpr int r = Rc;
-        if constexpr ((r >> CB) & 1) f(Rc, std::integral_constant<int, (r & ((1 << CB) - 1))>{});
+        if constexpr (CB < 0) f(Rc, std::integral_constant<int, 0>{});                    // every register, one class (dn_noisest in the last layout)
+        else if constexpr ((r >> CB) & 1) f(Rc, std::integral_constant<int, (r & ((1 << CB) - 1))>{});
     });
 }
+constexpr int dn_nc(int cb) { return cb < 0 ? 1 : 1 << cb; }
 
 // median (Statistics.median!: a/2 + b/2 of the order statistics k and k + 1, cnt even) of v = e (DEV = false) or |e - ctr| (DEV = true) per class
 // and lane group; [blo, bhi): #{v < blo} = 0, #{v < bhi} = cnt
-template <int CB, int GW, bool DEV>
-__device__ __forceinline__ void dn_median(const double (&e)[64], const double (&ctr)[1 << CB], const double (&blo)[1 << CB],
-                                          const double (&bhi)[1 << CB], int cnt, double (&med)[1 << CB])
+template <int CB, int GW, int ST, bool DEV>
+__device__ __forceinline__ void dn_median(const double (&e)[64], const double (&ctr)[dn_nc(CB)], const double (&blo)[dn_nc(CB)],
+                                          const double (&bhi)[dn_nc(CB)], int cnt, bool act, double (&med)[dn_nc(CB)])
 {
-    constexpr int NC = 1 << CB;
+    constexpr int NC = dn_nc(CB);
     const int k = cnt / 2 - 1;
+    // the deviations are formed again in every pass: hoisted out of the loops (they do not change) they are 32 / 64 more live doubles -- the
+    // centre goes through an opaque copy per pass
+    double cc[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) cc[q] = ctr[q];
+    auto opaque = [&]() {
+        if constexpr (DEV) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) asm volatile("" : "+v"(cc[q]));
+        }
+    };
     auto val = [&](auto Rc, auto Qc) -> double {
         constexpr int r = Rc, q = Qc;
-        if constexpr (DEV) return fabs(e[r] - ctr[q]);
+        if constexpr (DEV) return fabs(e[r] - cc[q]);
         else return e[r];
     };
     // smallest v >= lo of every group
     auto min_ge = [&](const double (&lo)[NC], double (&a)[NC]) {
 #pragma unroll
         for (int q = 0; q < NC; ++q) a[q] = __builtin_inf();
+        opaque();
         dn_each<CB>([&](auto Rc, auto Qc) {
             constexpr int q = Qc;
             const double v = val(Rc, Qc);
@@ -120,13 +143,13 @@ __device__ __forceinline__ void dn_median(const double (&e)[64], const double (&
             a[q] = w < a[q] ? w : a[q];
         });
 #pragma unroll
-        for (int q = 0; q < NC; ++q) a[q] = dn_gmin<GW>(a[q]);
+        for (int q = 0; q < NC; ++q) a[q] = dn_gmin<GW, ST>(a[q]);
     };
     double lo[NC], hi[NC];
     int clo[NC], chi[NC], stall[NC];
     bool done[NC];
 #pragma unroll
-    for (int q = 0; q < NC; ++q) { lo[q] = blo[q]; hi[q] = bhi[q]; clo[q] = 0; chi[q] = cnt; stall[q] = 0; done[q] = false; }
+    for (int q = 0; q < NC; ++q) { lo[q] = blo[q]; hi[q] = bhi[q]; clo[q] = 0; chi[q] = cnt; stall[q] = 0; done[q] = !act; }
     for (int it = 0; it < 192; ++it) {
         bool forced[NC], anyst = false;
 #pragma unroll
@@ -139,35 +162,44 @@ __device__ __forceinline__ void dn_median(const double (&e)[64], const double (&
                 if (forced[q]) { lo[q] = a[q]; stall[q] = 0; }
         }
         double p[NC];
-        bool live = false;
+        bool live = false, odd = false, vsp[NC];
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
             p[q] = hi[q];
+            vsp[q] = false;
             if (!done[q]) {
                 if (chi[q] - clo[q] <= 1) done[q] = true;
                 else {
-                    double m = forced[q] ? dn_next_up(lo[q]) : lo[q] * 0.5 + hi[q] * 0.5;
-                    const unsigned long long kl = dn_key(lo[q]), kh = dn_key(hi[q]);
-                    const double mk = dn_unkey(kl + ((kh - kl) >> 1));
-                    if (it >= 48 && !forced[q]) m = mk;
-                    if (!(m > lo[q] && m < hi[q])) m = mk;
-                    if (!(m > lo[q] && m < hi[q])) done[q] = true;      // no double between lo and hi: order statistic k is lo itself
-                    p[q] = m;
+                    p[q] = forced[q] ? dn_next_up(lo[q]) : lo[q] * 0.5 + hi[q] * 0.5;
+                    vsp[q] = !(p[q] > lo[q] && p[q] < hi[q]) || (it >= 48 && !forced[q]);      // the value's middle does not separate (any more)
+                    odd = odd || vsp[q];
                 }
             }
-            live = live || !done[q];
         }
+        if (dn_any(odd)) {
+            // rare: the middle of the order-preserving integer images; no double between lo and hi -> order statistic k is lo itself
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (vsp[q]) {
+                    const unsigned long long kl = dn_key(lo[q]), kh = dn_key(hi[q]);
+                    p[q] = dn_unkey(kl + ((kh - kl) >> 1));
+                    if (!(p[q] > lo[q] && p[q] < hi[q])) { done[q] = true; p[q] = hi[q]; }
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < NC; ++q) live = live || !done[q];
         if (!dn_any(live)) break;
         int c[NC];
 #pragma unroll
         for (int q = 0; q < NC; ++q) c[q] = 0;
+        opaque();
         dn_each<CB>([&](auto Rc, auto Qc) {
             constexpr int q = Qc;
             dn_acc<GW>(c[q], val(Rc, Qc) < p[q]);
         });
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
-            const int cq = dn_fin<GW>(c[q]);
+            const int cq = dn_fin<GW, ST>(c[q]);
             if (!done[q]) {
                 stall[q] = (cq == clo[q] || cq == chi[q]) ? stall[q] + 1 : 0;
                 if (cq <= k) { lo[q] = p[q]; clo[q] = cq; }
@@ -181,6 +213,7 @@ __device__ __forceinline__ void dn_median(const double (&e)[64], const double (&
     min_ge(lo, a);
 #pragma unroll
     for (int q = 0; q < NC; ++q) { nx[q] = __builtin_inf(); le[q] = 0; }
+    opaque();
     dn_each<CB>([&](auto Rc, auto Qc) {
         constexpr int q = Qc;
         const double v = val(Rc, Qc);
@@ -190,17 +223,18 @@ __device__ __forceinline__ void dn_median(const double (&e)[64], const double (&
     });
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
-        const double b = dn_fin<GW>(le[q]) >= k + 2 ? a[q] : dn_gmin<GW>(nx[q]);
+        const double b = dn_fin<GW, ST>(le[q]) >= k + 2 ? a[q] : dn_gmin<GW, ST>(nx[q]);
         med[q] = a[q] / 2 + b / 2;
     }
 }
 
-// noise estimates of the signals whose finest details sit in the registers with bit CB set: sig[q] for class q of this lane's group
-template <int CB, int GW>
-__device__ __forceinline__ void dn_noisest(const double (&e)[64], double (&sig)[1 << CB])
+// noise estimates of the signals whose finest details sit in the registers with bit CB set (CB < 0: in every register of the lanes with `act`):
+// sig[q] for class q of this lane's group (GW lanes, ST apart)
+template <int CB, int GW, int ST = 1>
+__device__ __forceinline__ void dn_noisest(const double (&e)[64], double (&sig)[dn_nc(CB)], bool act = true)
 {
-    constexpr int NC = 1 << CB;
-    constexpr int cnt = (32 >> CB) * GW;
+    constexpr int NC = dn_nc(CB);
+    constexpr int cnt = (CB < 0 ? 64 : (32 >> CB)) * GW;
     double vmin[NC], vmax[NC], zero[NC], med[NC], dhi[NC], mad[NC];
     int bad[NC];
 #pragma unroll
@@ -214,14 +248,17 @@ __device__ __forceinline__ void dn_noisest(const double (&e)[64], double (&sig)[
     });
     double hi0[NC];
 #pragma unroll
-    for (int q = 0; q < NC; ++q) { vmin[q] = dn_gmin<GW>(vmin[q]); vmax[q] = dn_gmax<GW>(vmax[q]); bad[q] = dn_fin<GW>(bad[q]); hi0[q] = dn_next_up(vmax[q]); }
-    dn_median<CB, GW, false>(e, zero, vmin, hi0, cnt, med);
+    for (int q = 0; q < NC; ++q) {
+        vmin[q] = dn_gmin<GW, ST>(vmin[q]); vmax[q] = dn_gmax<GW, ST>(vmax[q]); bad[q] = dn_fin<GW, ST>(bad[q]);
+        hi0[q] = dn_next_up(vmax[q]);
+    }
+    dn_median<CB, GW, ST, false>(e, zero, vmin, hi0, cnt, act, med);
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
         const double d0 = fabs(vmin[q] - med[q]), d1 = fabs(vmax[q] - med[q]);
         dhi[q] = dn_next_up(d0 > d1 ? d0 : d1);
     }
-    dn_median<CB, GW, true>(e, med, zero, dhi, cnt, mad);
+    dn_median<CB, GW, ST, true>(e, med, zero, dhi, cnt, act, mad);
 #pragma unroll
     for (int q = 0; q < NC; ++q) sig[q] = bad[q] ? __builtin_nan("") : mad[q] / 0.6745;
 }
@@ -254,8 +291,10 @@ __device__ __forceinline__ void dn_threshold(double (&c)[64], double t, int kind
     if constexpr (BIT == SH) {                                                                  \
         lat_level<KK, HH, NS, false>(REG, *cfp);                                                \
         _Pragma("unroll") for (int r = 0; r < 64; ++r) REG[r] = lat_mul(REG[r], ((r >> KK) & 1) ? ginv_ : g);    \
-        noise(REG);                                                                             \
-        fresh();                                                                                \
+        if constexpr (!SELC) {                                                                  \
+            noise(REG);                                                                         \
+            fresh();                                                                            \
+        }                                                                                       \
     } else if constexpr (BIT > SH) {                                                            \
         if (ANY) lat_level_hm<KK, HH, NS, false>(REG, *cfp, MK, g, ginv_);                      \
     }
@@ -267,15 +306,15 @@ __device__ __forceinline__ void dn_threshold(double (&c)[64], double t, int kind
         if (ANY) lat_level_hm<KK, HH, NS, true>(REG, ci, MK, ga, gd);                           \
     }
 
-// SH = 0, 1, 2: 2^SH signals of 4096 >> SH samples per wavefront; `tab` = the masks of the pyramid of depth L (k_lat_treesc_prep<SH>)
+// SH = 0 ... 6: 2^SH signals of 4096 >> SH samples per wavefront; `tab` = the masks of the pyramid of depth L (k_lat_treesc_prep<SH>)
 template <int NS, int WPE, int SH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_denoise_f64(
     const double *__restrict__ x, double *__restrict__ y, int last_sig, unsigned in_stride, unsigned out_stride, const WxLatW *__restrict__ cws,
     const WxLatTreeSc *__restrict__ tab, WxDnArg dn)
 {
-    static_assert(SH >= 0 && SH <= 2, "4096 .. 1024 samples");
-    __shared__ __attribute__((aligned(16))) double lds[2048];
-    __shared__ double tsm[64];
+    static_assert(SH >= 0 && SH <= 6, "4096 .. 64 samples");
+    __shared__ __attribute__((aligned(16))) double lds[WX_LAT_LDS];       // the window of the exchanges (absorb / emit / layout changes)
+    __shared__ double tsm[1 << SH];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
     const int sig0 = min((int)blockIdx.x << SH, last_sig);
@@ -299,26 +338,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         g = w.gl[1];
         ginv_ = w.c.g2 * w.gl[1];
     };
-    // class bits of the register index and lanes per signal in the layout of the root level (A for 4096 / 2048 samples, B for 1024)
-    constexpr int CB = SH == 1 ? 1 : 0, GW = SH == 2 ? 16 : 64;
+    // where the noise estimate runs: in the layout of the root level (A for 4096 / 2048 samples, B for 1024 / 512, C for 64; CB = signal bits held by
+    // the register index = the classes of dn_noisest, GW = lanes per signal), or -- 256 / 128 samples, where layout B would have 4 / 8 classes
+    // with a pivot each (1.23 / 1.64 ms per GiB) -- in the LAST layout just before the threshold: there the root's bit is lane bit SH, the finest
+    // details of a signal are every register of the 2 / 1 lanes with that bit set and the signal's low lane bits (they are final since the root level)
+    constexpr bool SELC = SH == 4 || SH == 5;
+    constexpr int CB = SELC ? -1 : (SH == 1 ? 1 : (SH == 3 ? 1 : 0)), GW = SELC ? (32 >> SH) : (SH <= 1 ? 64 : (SH <= 5 ? 16 : 1)), ST = SELC ? (2 << SH) : 1;
     auto noise = [&](double (&regs)[64]) {
-        double sg[1 << CB];
+        double sg[dn_nc(CB)];
+        const bool act = SELC ? ((lane >> SH) & 1) != 0 : true;
 #ifdef WX_DN_NOSEL
-        for (int q = 0; q < (1 << CB); ++q) sg[q] = regs[2 + q];
+        for (int q = 0; q < dn_nc(CB); ++q) sg[q] = regs[2 + q];
 #else
-        dn_noisest<CB, GW>(regs, sg);
+        dn_noisest<CB, GW, ST>(regs, sg, act);
 #endif
 #pragma unroll
-        for (int q = 0; q < (1 << CB); ++q) {
-            const int s = SH == 2 ? (lane >> 4) : q;                  // signal of the wavefront: index bits SH - 1 .. 0
-            if ((lane & (GW - 1)) == 0) {
+        for (int q = 0; q < dn_nc(CB); ++q) {
+            // signal of the wavefront: index bits SH - 1 .. 0; one lane of its group writes
+            const int s = SELC ? (lane & ((1 << SH) - 1)) : (SH <= 1 ? q : (SH <= 5 ? ((q << 2) | (lane >> 4)) : lane));
+            const bool first = SELC ? (lane >> SH) == 1 : (lane & (GW - 1)) == 0;
+            if (first) {
                 tsm[s] = sg[q] * dn.scale;
                 if (dn.sigma) dn.sigma[sig0 + s] = sg[q];
             }
         }
     };
     double c[64];
-    {
+    if constexpr (SH >= 6)
+        lat_absorb<6, 16 * SH>(c, lds0, xs, lane, cwf, in_stride, 0, 0, 0, 0xffffffffu);
+    else {
         double bb[64];
         if constexpr (SH < 2) {
             double a[64];
@@ -341,12 +389,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const unsigned long long *mk = tab->mC;
     if (!tab->deepB) {
         if (tab->anyC[0]) lat_level_cm<0, NS, false>(c, *cfp, mk + 0, g, ginv_);
+        if constexpr (SH >= 6) {                                 // 64 samples: this was the root level (its mask is every lane)
+            noise(c);
+            fresh();
+        }
         if (tab->anyC[1]) lat_level_cm<1, NS, false>(c, *cfp, mk + 32, g, ginv_);
     }
     if (tab->anyC[2]) lat_level_cm<2, NS, false>(c, *cfp, mk + 64, g, ginv_);
     if (tab->anyC[3]) lat_level_cm<3, NS, false>(c, *cfp, mk + 96, g, ginv_);
     if (tab->anyC[4]) lat_level_cm<4, NS, false>(c, *cfp, mk + 128, g, ginv_);
     if (tab->anyC[5]) lat_level_cm<5, NS, false>(c, *cfp, mk + 160, g, ginv_);
+    if constexpr (SELC) noise(c);
     // threshold: layout C, lane = index bits 5 .. 0 -> the lane's signal is its low SH bits
     lat_sync();
 #ifndef WX_DN_NOTHR
@@ -368,7 +421,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         if (tab->anyC[1]) lat_level_cm<1, NS, true>(c, ci, mk + 32, ga, gd);
         if (tab->anyC[0]) lat_level_cm<0, NS, true>(c, ci, mk + 0, ga, gd);
     }
-    {
+    if constexpr (SH >= 6)
+        lat_emit<6, 16 * SH>(c, lds0, ys, lane, cwi, out_stride, 0, 0, 0xffffffffu);
+    else {
         double bb[64];
         lat_t3i(c, bb, lds0, lane);
         if (tab->deepB) {

@@ -2,6 +2,11 @@
 // (signals of 4096 >> SH samples) and WX_DN_FN = the launcher's name: one translation unit per length so that the kernels compile in parallel.
 // Reference: denoiseall(x, :sig, wt; L, dnt, estnoise = noisest, smooth) Denoising.jl:651-712.
 #include "wx_lattice_dn.h"
+// waves per SIMD: 3 (0.85 / 0.95 / 0.87 ms per GiB of 1024 / 2048 / 4096-sample signals) against 2 (0.94 / 1.07 / 0.98): the kernel waits
+// on its exchanges and scalar loads 40 % of a wavefront's life, a third wavefront fills part of it although ~70 registers spill
+#ifndef WX_DN_WPE
+#define WX_DN_WPE (WX_DN_SH <= 2 ? 3 : 2)
+#endif
 #include <cstring>
 #include <vector>
 
@@ -37,7 +42,7 @@ int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const 
     if (!dstatus || !tsc) return WX_EHIP;
     if (hipMemsetAsync(tsc->dep, 0, sizeof(tsc->dep), st) != hipSuccess) return wx_set_error(WX_EHIP, "lattice tree tables");
     hipLaunchKernelGGL((k_lat_treesc_prep<SH>), dim3(8), dim3(256), 0, st, dstatus, (int64_t)tree.size(), L, tsc);
-    hipLaunchKernelGGL(k_lat_treesc_prep2, dim3(1), dim3(64), 0, st, tsc, 0);
+    hipLaunchKernelGGL(k_lat_treesc_prep2, dim3(1), dim3(64), 0, st, tsc, SH);
     const WxLatTreeSc *ctsc = tsc;
     const WxLatW *cws = (const WxLatW *)wx_const_upload(cw2, sizeof cw2, st, true);
     if (!cws) return WX_EHIP;
@@ -52,9 +57,9 @@ int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const 
     switch (ns) {
 #define WX_DN_GO(NSS)                                                                                                          \
     case NSS:                                                                                                                  \
-        hipLaunchKernelGGL((k_lat_denoise_f64<NSS, 2, SH>), dim3(nw), dim3(64), 0, st, x, y, lsig, (unsigned)n, (unsigned)n, cws, ctsc, dn); \
+        hipLaunchKernelGGL((k_lat_denoise_f64<NSS, WX_DN_WPE, SH>), dim3(nw), dim3(64), 0, st, x, y, lsig, (unsigned)n, (unsigned)n, cws, ctsc, dn); \
         break;
-#ifdef WX_DN_ONLY4
+#ifdef WX_DN_DEV
         WX_DN_GO(4)
 #else
         WX_DN_GO(1) WX_DN_GO(2) WX_DN_GO(4)
