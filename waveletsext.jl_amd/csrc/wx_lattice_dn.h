@@ -55,17 +55,37 @@ __device__ __forceinline__ double dn_next_up(double a)
     if (a == 0.0) return __longlong_as_double(1ll);
     return dn_unkey(dn_key(a) + 1ull);
 }
+// the value of lane ^ 32 beside the lane's own, as (value of the lower half's lane, value of the upper half's lane): v_permlane32_swap, no LDS
+// (with ds_bpermute in its loops the 256-sample kernel spilled 19 ... 168 registers)
+__device__ __forceinline__ void dn_x32(unsigned v, unsigned &lower, unsigned &upper)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    lower = r[0];
+    upper = r[1];
+}
+__device__ __forceinline__ void dn_x32(double v, double &lower, double &upper)
+{
+    unsigned l0, u0, l1, u1;
+    dn_x32((unsigned)__double2loint(v), l0, u0);
+    dn_x32((unsigned)__double2hiint(v), l1, u1);
+    lower = __hiloint2double((int)l1, (int)l0);
+    upper = __hiloint2double((int)u1, (int)u0);
+}
 // a signal's lanes: GW of them, ST apart (ST = 1: consecutive lanes)
+constexpr int dn_log2(int v) { return v <= 1 ? 0 : 1 + dn_log2(v >> 1); }
+template <int O> __device__ __forceinline__ double dn_xor(double v)
+{
+    if constexpr (O == 32) { double a, b; dn_x32(v, a, b); return ((unsigned)__lane_id() & 32u) ? a : b; }
+    else return __shfl_xor(v, O, 64);
+}
 template <int GW, int ST = 1> __device__ __forceinline__ double dn_gmin(double v)
 {
-#pragma unroll
-    for (int o = ST * GW / 2; o >= ST; o >>= 1) { const double u = __shfl_xor(v, o, 64); v = u < v ? u : v; }
+    lat_for<dn_log2(GW)>([&](auto Ic) { constexpr int o = (ST * GW / 2) >> Ic; const double u = dn_xor<o>(v); v = u < v ? u : v; });
     return v;
 }
 template <int GW, int ST = 1> __device__ __forceinline__ double dn_gmax(double v)
 {
-#pragma unroll
-    for (int o = ST * GW / 2; o >= ST; o >>= 1) { const double u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
+    lat_for<dn_log2(GW)>([&](auto Ic) { constexpr int o = (ST * GW / 2) >> Ic; const double u = dn_xor<o>(v); v = u > v ? u : v; });
     return v;
 }
 template <int GW, int ST = 1> __device__ __forceinline__ int dn_gsum(int v)
@@ -77,8 +97,11 @@ template <int GW, int ST = 1> __device__ __forceinline__ int dn_gsum(int v)
         v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
         v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
     } else {
-#pragma unroll
-        for (int o = ST * GW / 2; o >= ST; o >>= 1) v += __shfl_xor(v, o, 64);
+        lat_for<dn_log2(GW)>([&](auto Ic) {
+            constexpr int o = (ST * GW / 2) >> Ic;
+            if constexpr (o == 32) { unsigned a, b; dn_x32((unsigned)v, a, b); v = (int)(a + b); }
+            else v += __shfl_xor(v, o, 64);
+        });
     }
     return v;
 }
