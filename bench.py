@@ -132,6 +132,12 @@ WORKLOADS = {
                              ("k_ldb_class_partial<double>", 1), ("k_ldb_class_combine<double>", 1)],
                 desc="SURVEY 8(f) row 2: LDB time-frequency energy maps of 4 classes over wpdall(x) 16384x4096 f64 db8 "
                      "L=12; timed leg = energy_map over the resident 6.5 GiB table (wpdall is the other leg)"),
+    "denoise": dict(kind="denoise", n=4096, batch=65536, wavelet="db4", L=12, dtype="f64",
+                    kernel="k_lat_denoise_f64<4, 3, 0>", inv_kernel="k_mad<double>",
+                    fwd_kernels=[("k_lat_denoise_f64<4, 3, 0>", 1)],
+                    desc="SURVEY 8(f) row 1: denoiseall(x, :sig, wt) = dwtall -> noisest per signal -> threshold -> idwtall of 65536x4096 f64 db4 "
+                         "L=12 (VisuShrink, HardTH); first leg = the one-pass kernel behind wx_denoiseall_sig_* (signal in, denoised signal out), "
+                         "second leg = the same result from the separate steps dwtall, then denoiseall(:dwt) (noisest + threshold on the loads of idwtall)"),
     "siwt": dict(kind="siwt", n=1024, batch=4096, wavelet="db4", L=10, d=3, dtype="f64",
                  kernel="k_siwt_fwd_level<double, true, 8>",
                  fwd_kernels=[("k_siwt_fwd_level<double, false, 8>", 1), ("k_siwt_fwd_level<double, true, 8>", 9), ("k_siwt_norms<double>", 1),
@@ -253,6 +259,15 @@ def cpu_baseline(w, seconds):
             dt = time.perf_counter() - t0
             assert np.abs(xr - x[:, :, B - 1]).max() < 1e-3
             return dt, B * m * n
+        if kind == "denoise":
+            n = w["n"]
+            x = rng.standard_normal((n, B))
+            t0 = time.perf_counter()
+            for i in range(B):
+                y = wo.denoise(x[:, i], "sig", q, L=L, th="hard")
+            dt = time.perf_counter() - t0
+            assert y.shape == (n,)
+            return dt, B * n
         if kind == "wpd_bb":
             n = w["n"]
             x = rng.standard_normal((n, B))
@@ -323,7 +338,7 @@ def cpu_baseline(w, seconds):
     probe = 16 if kind in ("wpd", "wpt") else 2
     run(probe)                                   # first call: library load, page faults
     t_probe, _ = run(probe)
-    cap = {"wpd": 16384, "wpt": 16384, "wpt2d": 320, "wpd_bb": 4096, "wpd_ldb": 2048}.get(kind, 32)
+    cap = {"wpd": 16384, "wpt": 16384, "wpt2d": 320, "wpd_bb": 4096, "wpd_ldb": 2048, "denoise": 16384}.get(kind, 32)
     B = int(max(probe, min(cap, seconds / (t_probe / probe))))
     dt, samples = run(B)
     out = {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
@@ -641,6 +656,19 @@ def make_workload(w, wx, torch, dev, rank, world, a, dist):
         W.info = dict(fwd_bytes=es * (n * (L + 1) + ncost) * B + (n - 1) * B, inv_bytes=es * n * (L + 2) * B,
                       fwd_flops=4.0 * n * (L + 1) * B, samples=n * B, bound="hbm")
         W.keep = (x, xw)
+    elif kind == "denoise":
+        state = {}
+        dnt = wx.VisuShrink(n)
+
+        def fwd():      # one pass: wx_denoiseall_sig_*
+            state["y"] = wx.denoiseall(x, "sig", wt, L=L, dnt=dnt)
+
+        def inv():      # the separate steps (named inv only because the harness times two legs): dwtall, then noisest + threshold + idwtall
+            state["y2"] = wx.denoiseall(wx.dwtall(x, wt, L), "dwt", wt, L=L, dnt=dnt)
+
+        check = lambda: float((state["y"] - state["y2"]).abs().max() / x.abs().max())
+        W.info = dict(fwd_bytes=es * 2 * n * B, inv_bytes=es * 4.5 * n * B, fwd_flops=(2 * 8.0 * F + 100.0) * n * B, samples=n * B, bound="hbm")
+        W.keep = (x,)
     elif kind == "wpd_ldb":
         xw = wx.jl_empty((n, L + 1, B), td, dev)
         qq, qp, Fq = qmf_arg(wt)

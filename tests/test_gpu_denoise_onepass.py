@@ -48,7 +48,7 @@ def _sigma_c(wx, x, wt, L, th_kind=0, t=1.0, undersmooth=0):
 
 
 @pytest.mark.parametrize("n", [4096, 2048, 1024, 512, 256, 128, 64])
-@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db8"])
+@pytest.mark.parametrize("wname", ["haar", "db2", "db4", "db6", "db8", "db10"])
 def test_onepass_against_the_oracle(wx, oracle, n, wname):
     rng = np.random.default_rng(n + len(wname))
     wt = wx.wavelet(getattr(wx.WT, wname))

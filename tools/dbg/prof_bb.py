@@ -1,14 +1,18 @@
-import os, sys
+"""Kernel breakdown of bestbasistreeall(wpdall(x), BB()) at one length: rocprofv3 --kernel-trace --stats -- python3 tools/dbg/prof_bb.py <n>"""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import waveletsext_jl_amd as wx
+
+n = int(sys.argv[1])
 wt = wx.wavelet(wx.WT.db4)
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 L = wx.maxtransformlevels(n)
-Bq = max((1 << 28) // (n * (L + 1) * 8), 1)
-xq = wx.jl_empty((n, Bq), torch.float64, "cuda"); xq.normal_()
-tab = wx.wpdall(xq, wt, L)
-for _ in range(3):
+B = max((1 << 30) // (n * (L + 1) * 8), 1)
+x = wx.jl_empty((n, B), torch.float64, "cuda")
+x.normal_()
+tab = wx.wpdall(x, wt, L)
+for _ in range(6):
     t = wx.bestbasistreeall(tab, wx.BB())
 torch.cuda.synchronize()
-print(Bq)

@@ -13,5 +13,5 @@ cp gpurun_out/r06_floor.txt gpurun_out/r06_floor2d.txt $O/ 2>/dev/null
 { echo "# tools/floor_scan_wpd.py db8"; timeout 900 python tools/floor_scan_wpd.py db8 2>&1 | grep "^f"; } > $O/r06_floor_wpd_db8.txt
 { echo "# tools/floor_scan_swt.py, one MI355X"; timeout 1200 python tools/floor_scan_swt.py 2>&1 | grep "^f"; } > $O/r06_floor_swt.txt; tail -2 $O/r06_floor_swt.txt
 { echo "# tools/floor_scan_misc.py: the callers' side at several lengths, Float64, db4, 1 GiB of signals / 1 GiB tables, one MI355X (round-6 build)"; timeout 1200 python tools/floor_scan_misc.py 64 128 256 512 1024 2048 4096 16384 2>&1 | grep "^f"; } > $O/r06_floor_misc.txt; tail -3 $O/r06_floor_misc.txt
-WX_EVIDENCE_NOTEST=1 WX_EVIDENCE_WORKLOADS="cfg2 wpt_db8 target target_f32 target_n2048 target_n1024 target_haar tree_random tree_pyramid cfg3 cfg3_sdwt swpt_db4 cfg4 cfg4_256 cfg4_1024 cfg5 bb ldb siwt dwt_long" bash tools/refresh_evidence.sh r06d r06 2>&1 | tail -5
+WX_EVIDENCE_NOTEST=1 WX_EVIDENCE_WORKLOADS="cfg2 denoise wpt_db8 target target_f32 target_n2048 target_n1024 target_haar tree_random tree_pyramid cfg3 cfg3_sdwt swpt_db4 cfg4 cfg4_256 cfg4_1024 cfg5 bb ldb siwt dwt_long" bash tools/refresh_evidence.sh r06d r06 2>&1 | tail -5
 timeout 900 python bench.py > $O/r06_bench_default.json 2> $O/r06_bench_default.err; echo "bench rc $?"; tail -c 300 $O/r06_bench_default.json

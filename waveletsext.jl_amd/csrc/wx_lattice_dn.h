@@ -6,7 +6,7 @@
 // central order statistics), Wavelets.Threshold.threshold! (HardTH / SoftTH / SemiSoftTH / SteinTH), VisuShrink t = sqrt(2 log n).
 //
 // The separate kernels of this pipeline (k_lat_wpt_treesc_f64 -> k_mad* -> k_lat_iwpt_treesc_f64 with the threshold on its loads) move
-// 4.5 x the signals' bytes and take 1.8 ms per GiB of signals, 0.7 ... 0.85 ms of it the order statistics (profiles/r06_denoise.md).
+// 4.5 x the signals' bytes and take 1.8 ms per GiB of signals, 0.7 ... 0.85 ms of it the order statistics (profiles/r06_denoise_onepass.md).
 // Here a wavefront keeps its 4096 coefficients (2^SH signals of 4096 >> SH samples) in the in-place lattice layouts of wx_lattice_tree_sc.h:
 //   * the ROOT level leaves the finest details -- final values, every level normalises its own gains -- in the registers whose index has
 //     the root's bit set; the two medians of the noise estimate are EXACT ORDER STATISTICS found by counting: a pivot p per signal,

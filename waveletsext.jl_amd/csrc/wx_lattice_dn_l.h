@@ -20,7 +20,7 @@ int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const 
     if ((batch & (per - 1)) && x == y) return 0;             // the tail wavefront re-does signals: out of place only
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     const int ns = wx_lat_stages(filt.F);
-    if (ns != 1 && ns != 2 && ns != 4) return 0;
+    if (ns != 1 && ns != 2 && ns != 4 && ns != 6 && ns != 8) return 0;       // filters of up to 16 taps
     WxLatW cw2[2];
     memset(cw2, 0, sizeof cw2);
     WxLatW &cwf = cw2[0], &cwi = cw2[1];
@@ -60,9 +60,9 @@ int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const 
         hipLaunchKernelGGL((k_lat_denoise_f64<NSS, WX_DN_WPE, SH>), dim3(nw), dim3(64), 0, st, x, y, lsig, (unsigned)n, (unsigned)n, cws, ctsc, dn); \
         break;
 #ifdef WX_DN_DEV
-        WX_DN_GO(4)
+        WX_DN_GO(WX_DN_DEV)
 #else
-        WX_DN_GO(1) WX_DN_GO(2) WX_DN_GO(4)
+        WX_DN_GO(1) WX_DN_GO(2) WX_DN_GO(4) WX_DN_GO(6) WX_DN_GO(8)
 #endif
 #undef WX_DN_GO
     default: return 0;
