@@ -10,6 +10,7 @@
 #include "wx_common.h"
 #include "wx_host.h"
 #include "wx_kernels.h"
+#include "wx_select_count.h"
 #include <vector>
 
 #define WX_REQUIRE(cond, code, msg) \
@@ -382,6 +383,25 @@ __global__ __launch_bounds__(256) void k_mad_sort(const T *__restrict__ X, int64
     if (lane == 0 && live) sigma[sig] = any_nan ? (T)__builtin_nan("") : (T)(mad / (T)0.6745);
 }
 
+// 256 ... 4096 coefficients (signals of 512 ... 8192 samples at the finest level), round 6: ONE WAVEFRONT per signal keeps the values in NR = cnt / 64
+// registers per lane and finds the two medians by COUNTING against a pivot (wx_select_count.h: ballot + population count per register, the
+// bracket halved in value) -- no LDS, no sort.  Per GiB of signals in denoiseall(:dwt), Float64: 256 / 512 / 1024 / 2048 / 4096 coefficients
+// 0.63 / 0.43 / 0.33 / 0.30 / 0.46 ms (k_mad_sort: 0.69 / 0.71; the workgroup selection k_mad: 0.84 ms at 2048).
+template <typename T, int NR>
+__global__ __launch_bounds__(256) void k_mad_count(const T *__restrict__ X, int64_t sig_stride, int64_t off, int64_t batch, T *__restrict__ sigma)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t sig = (int64_t)blockIdx.x * 4 + wave;
+    if (sig >= batch) return;
+    const T *x = X + sig * sig_stride + off;
+    double e[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) e[u] = (double)x[lane + 64 * u];
+    double sg[1];
+    dn_noisest<-1, 64, 1, NR, T>(e, sg);
+    if (lane == 0) sigma[sig] = (T)sg[0];
+}
+
 // the same on detail ranges that do not fit a CU's LDS (signals of more than 32768 Float64 / 65536 Float32 samples' worth of details):
 // the copy that the second median overwrites lives in a global scratch row instead; the selection (wx_select_kth: counting passes
 // over the values) reads it through L2
@@ -466,7 +486,23 @@ int api_noisest(const T *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo,
     // 65 ... 2048 coefficients: one wavefront sorts the values in its registers (k_mad_sort); WX_MAD_SORT_MAX (knob) lowers the limit
     // (measured per GiB of signals, denoiseall: n = 256 / 512 / 1024 -- 128 / 256 / 512 coefficients -- 3.13 / 4.86 / 3.24 -> 1.83 / 1.88 / 1.83 ms;
     // 1024 / 2048 coefficients lose to the workgroup selection: 3.5 against 2.3, 4.3 against 1.8 ms -- the cross-lane stages grow with E)
-    static const int mad_sort_max = wx_getenv("WX_MAD_SORT_MAX") ? atoi(wx_getenv("WX_MAD_SORT_MAX")) : 512;
+    static const int mad_sort_max = wx_getenv("WX_MAD_SORT_MAX") ? atoi(wx_getenv("WX_MAD_SORT_MAX")) : 256;
+    // 256 ... 4096 coefficients (a power of two): one wavefront per signal counts against pivots (k_mad_count); WX_MAD_COUNT_MIN (knob) moves the lower limit
+    static const int mad_count_min = wx_getenv("WX_MAD_COUNT_MIN") ? atoi(wx_getenv("WX_MAD_COUNT_MIN")) : 256;
+    if (cnt >= 256 && cnt >= mad_count_min && cnt <= 4096 && (cnt & (cnt - 1)) == 0 && batch <= 0x7ffffff0) {
+        const dim3 g((unsigned)((batch + 3) / 4));
+#define WX_MC(NRR) hipLaunchKernelGGL((k_mad_count<T, NRR>), g, dim3(256), 0, st, dX, n * k, col * n + row_lo, batch, ds)
+        switch (cnt) {
+        case 256: WX_MC(4); break;
+        case 512: WX_MC(8); break;
+        case 1024: WX_MC(16); break;
+        case 2048: WX_MC(32); break;
+        default: WX_MC(64); break;
+        }
+#undef WX_MC
+        if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "noisest kernel failed to launch"));
+        return io.finish(WX_OK);
+    }
     if (cnt >= 3 && cnt <= 2048 && cnt <= mad_sort_max && batch <= 0x7ffffff0) {
         dim3 g((unsigned)((batch + 3) / 4));
 #define WX_MS(EE) hipLaunchKernelGGL((k_mad_sort<T, EE>), g, dim3(256), 0, st, dX, n * k, col * n + row_lo, (int)cnt, batch, ds)

@@ -29,6 +29,7 @@
 #include "wx_lattice_dev.h"
 #include "wx_host.h"
 #include "wx_lattice_tree_sc.h"
+#include "wx_select_count.h"
 
 struct WxDnArg {
     int kind;                 // Wavelets.Threshold rule, see wx_thresh
@@ -38,253 +39,6 @@ struct WxDnArg {
 };
 
 namespace {
-
-// order-preserving image of the doubles (NaN aside): a < b <=> key(a) < key(b), -0 just below +0
-__device__ __forceinline__ unsigned long long dn_key(double d)
-{
-    const unsigned long long u = (unsigned long long)__double_as_longlong(d);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double dn_unkey(unsigned long long k)
-{
-    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
-}
-// the smallest double above a (finite a)
-__device__ __forceinline__ double dn_next_up(double a)
-{
-    if (a == 0.0) return __longlong_as_double(1ll);
-    return dn_unkey(dn_key(a) + 1ull);
-}
-// the value of lane ^ 32 beside the lane's own, as (value of the lower half's lane, value of the upper half's lane): v_permlane32_swap, no LDS
-// (with ds_bpermute in its loops the 256-sample kernel spilled 19 ... 168 registers)
-__device__ __forceinline__ void dn_x32(unsigned v, unsigned &lower, unsigned &upper)
-{
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    lower = r[0];
-    upper = r[1];
-}
-__device__ __forceinline__ void dn_x32(double v, double &lower, double &upper)
-{
-    unsigned l0, u0, l1, u1;
-    dn_x32((unsigned)__double2loint(v), l0, u0);
-    dn_x32((unsigned)__double2hiint(v), l1, u1);
-    lower = __hiloint2double((int)l1, (int)l0);
-    upper = __hiloint2double((int)u1, (int)u0);
-}
-// a signal's lanes: GW of them, ST apart (ST = 1: consecutive lanes)
-constexpr int dn_log2(int v) { return v <= 1 ? 0 : 1 + dn_log2(v >> 1); }
-template <int O> __device__ __forceinline__ double dn_xor(double v)
-{
-    if constexpr (O == 32) { double a, b; dn_x32(v, a, b); return ((unsigned)__lane_id() & 32u) ? a : b; }
-    else return __shfl_xor(v, O, 64);
-}
-template <int GW, int ST = 1> __device__ __forceinline__ double dn_gmin(double v)
-{
-    lat_for<dn_log2(GW)>([&](auto Ic) { constexpr int o = (ST * GW / 2) >> Ic; const double u = dn_xor<o>(v); v = u < v ? u : v; });
-    return v;
-}
-template <int GW, int ST = 1> __device__ __forceinline__ double dn_gmax(double v)
-{
-    lat_for<dn_log2(GW)>([&](auto Ic) { constexpr int o = (ST * GW / 2) >> Ic; const double u = dn_xor<o>(v); v = u > v ? u : v; });
-    return v;
-}
-template <int GW, int ST = 1> __device__ __forceinline__ int dn_gsum(int v)
-{
-    if constexpr (GW == 16 && ST == 1) {
-        // every lane of a 16-lane row gets the row's sum: four DPP adds (quad_perm 1 0 3 2, quad_perm 2 3 0 1, row_half_mirror, row_mirror)
-        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
-        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
-    } else {
-        lat_for<dn_log2(GW)>([&](auto Ic) {
-            constexpr int o = (ST * GW / 2) >> Ic;
-            if constexpr (o == 32) { unsigned a, b; dn_x32((unsigned)v, a, b); v = (int)(a + b); }
-            else v += __shfl_xor(v, o, 64);
-        });
-    }
-    return v;
-}
-// c += #{lanes of the group with pred}: the whole wavefront -> ballot + population count (scalar), else a per-lane counter (dn_gsum later)
-template <int GW> __device__ __forceinline__ void dn_acc(int &c, bool pred)
-{
-    if constexpr (GW == 64) c += (int)__popcll(__builtin_amdgcn_ballot_w64(pred));
-    else c += pred ? 1 : 0;
-}
-template <int GW, int ST = 1> __device__ __forceinline__ int dn_fin(int c)
-{
-    if constexpr (GW == 64) return c;
-    else return dn_gsum<GW, ST>(c);
-}
-__device__ __forceinline__ bool dn_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0; }
-
-// the detail registers of the layout the root level ran in: index bit CB of the register set, class (= signal bits held by the register
-// index) q = r mod 2^CB
-template <int CB, typename F> __device__ __forceinline__ void dn_each(F &&f)
-{
-    lat_for<64>([&](auto Rc) {
-        constexpr int r = Rc;
-        if constexpr (CB < 0) f(Rc, std::integral_constant<int, 0>{});                    // every register, one class (dn_noisest in the last layout)
-        else if constexpr ((r >> CB) & 1) f(Rc, std::integral_constant<int, (r & ((1 << CB) - 1))>{});
-    });
-}
-constexpr int dn_nc(int cb) { return cb < 0 ? 1 : 1 << cb; }
-
-// median (Statistics.median!: a/2 + b/2 of the order statistics k and k + 1, cnt even) of v = e (DEV = false) or |e - ctr| (DEV = true) per class
-// and lane group; [blo, bhi): #{v < blo} = 0, #{v < bhi} = cnt
-template <int CB, int GW, int ST, bool DEV>
-__device__ __forceinline__ void dn_median(const double (&e)[64], const double (&ctr)[dn_nc(CB)], const double (&blo)[dn_nc(CB)],
-                                          const double (&bhi)[dn_nc(CB)], int cnt, bool act, double (&med)[dn_nc(CB)])
-{
-    constexpr int NC = dn_nc(CB);
-    const int k = cnt / 2 - 1;
-    // the deviations are formed again in every pass: hoisted out of the loops (they do not change) they are 32 / 64 more live doubles -- the
-    // centre goes through an opaque copy per pass
-    double cc[NC];
-#pragma unroll
-    for (int q = 0; q < NC; ++q) cc[q] = ctr[q];
-    auto opaque = [&]() {
-        if constexpr (DEV) {
-#pragma unroll
-            for (int q = 0; q < NC; ++q) asm volatile("" : "+v"(cc[q]));
-        }
-    };
-    auto val = [&](auto Rc, auto Qc) -> double {
-        constexpr int r = Rc, q = Qc;
-        if constexpr (DEV) return fabs(e[r] - cc[q]);
-        else return e[r];
-    };
-    // smallest v >= lo of every group
-    auto min_ge = [&](const double (&lo)[NC], double (&a)[NC]) {
-#pragma unroll
-        for (int q = 0; q < NC; ++q) a[q] = __builtin_inf();
-        opaque();
-        dn_each<CB>([&](auto Rc, auto Qc) {
-            constexpr int q = Qc;
-            const double v = val(Rc, Qc);
-            const double w = v >= lo[q] ? v : __builtin_inf();
-            a[q] = w < a[q] ? w : a[q];
-        });
-#pragma unroll
-        for (int q = 0; q < NC; ++q) a[q] = dn_gmin<GW, ST>(a[q]);
-    };
-    double lo[NC], hi[NC];
-    int clo[NC], chi[NC], stall[NC];
-    bool done[NC];
-#pragma unroll
-    for (int q = 0; q < NC; ++q) { lo[q] = blo[q]; hi[q] = bhi[q]; clo[q] = 0; chi[q] = cnt; stall[q] = 0; done[q] = !act; }
-    for (int it = 0; it < 192; ++it) {
-        bool forced[NC], anyst = false;
-#pragma unroll
-        for (int q = 0; q < NC; ++q) { forced[q] = !done[q] && stall[q] >= 2; anyst = anyst || forced[q]; }
-        if (dn_any(anyst)) {
-            double a[NC];
-            min_ge(lo, a);
-#pragma unroll
-            for (int q = 0; q < NC; ++q)
-                if (forced[q]) { lo[q] = a[q]; stall[q] = 0; }
-        }
-        double p[NC];
-        bool live = false, odd = false, vsp[NC];
-#pragma unroll
-        for (int q = 0; q < NC; ++q) {
-            p[q] = hi[q];
-            vsp[q] = false;
-            if (!done[q]) {
-                if (chi[q] - clo[q] <= 1) done[q] = true;
-                else {
-                    p[q] = forced[q] ? dn_next_up(lo[q]) : lo[q] * 0.5 + hi[q] * 0.5;
-                    vsp[q] = !(p[q] > lo[q] && p[q] < hi[q]) || (it >= 48 && !forced[q]);      // the value's middle does not separate (any more)
-                    odd = odd || vsp[q];
-                }
-            }
-        }
-        if (dn_any(odd)) {
-            // rare: the middle of the order-preserving integer images; no double between lo and hi -> order statistic k is lo itself
-#pragma unroll
-            for (int q = 0; q < NC; ++q)
-                if (vsp[q]) {
-                    const unsigned long long kl = dn_key(lo[q]), kh = dn_key(hi[q]);
-                    p[q] = dn_unkey(kl + ((kh - kl) >> 1));
-                    if (!(p[q] > lo[q] && p[q] < hi[q])) { done[q] = true; p[q] = hi[q]; }
-                }
-        }
-#pragma unroll
-        for (int q = 0; q < NC; ++q) live = live || !done[q];
-        if (!dn_any(live)) break;
-        int c[NC];
-#pragma unroll
-        for (int q = 0; q < NC; ++q) c[q] = 0;
-        opaque();
-        dn_each<CB>([&](auto Rc, auto Qc) {
-            constexpr int q = Qc;
-            dn_acc<GW>(c[q], val(Rc, Qc) < p[q]);
-        });
-#pragma unroll
-        for (int q = 0; q < NC; ++q) {
-            const int cq = dn_fin<GW, ST>(c[q]);
-            if (!done[q]) {
-                stall[q] = (cq == clo[q] || cq == chi[q]) ? stall[q] + 1 : 0;
-                if (cq <= k) { lo[q] = p[q]; clo[q] = cq; }
-                else { hi[q] = p[q]; chi[q] = cq; }
-            }
-        }
-    }
-    // order statistic k = the smallest v >= lo; k + 1 = the same value when at least k + 2 elements are <= it, else the next larger one
-    double a[NC], nx[NC];
-    int le[NC];
-    min_ge(lo, a);
-#pragma unroll
-    for (int q = 0; q < NC; ++q) { nx[q] = __builtin_inf(); le[q] = 0; }
-    opaque();
-    dn_each<CB>([&](auto Rc, auto Qc) {
-        constexpr int q = Qc;
-        const double v = val(Rc, Qc);
-        dn_acc<GW>(le[q], v <= a[q]);
-        const double w = v > a[q] ? v : __builtin_inf();
-        nx[q] = w < nx[q] ? w : nx[q];
-    });
-#pragma unroll
-    for (int q = 0; q < NC; ++q) {
-        const double b = dn_fin<GW, ST>(le[q]) >= k + 2 ? a[q] : dn_gmin<GW, ST>(nx[q]);
-        med[q] = a[q] / 2 + b / 2;
-    }
-}
-
-// noise estimates of the signals whose finest details sit in the registers with bit CB set (CB < 0: in every register of the lanes with `act`):
-// sig[q] for class q of this lane's group (GW lanes, ST apart)
-template <int CB, int GW, int ST = 1>
-__device__ __forceinline__ void dn_noisest(const double (&e)[64], double (&sig)[dn_nc(CB)], bool act = true)
-{
-    constexpr int NC = dn_nc(CB);
-    constexpr int cnt = (CB < 0 ? 64 : (32 >> CB)) * GW;
-    double vmin[NC], vmax[NC], zero[NC], med[NC], dhi[NC], mad[NC];
-    int bad[NC];
-#pragma unroll
-    for (int q = 0; q < NC; ++q) { vmin[q] = __builtin_inf(); vmax[q] = -__builtin_inf(); bad[q] = 0; zero[q] = 0.0; }
-    dn_each<CB>([&](auto Rc, auto Qc) {
-        constexpr int r = Rc, q = Qc;
-        const double v = e[r];
-        vmin[q] = v < vmin[q] ? v : vmin[q];
-        vmax[q] = v > vmax[q] ? v : vmax[q];
-        dn_acc<GW>(bad[q], v != v);
-    });
-    double hi0[NC];
-#pragma unroll
-    for (int q = 0; q < NC; ++q) {
-        vmin[q] = dn_gmin<GW, ST>(vmin[q]); vmax[q] = dn_gmax<GW, ST>(vmax[q]); bad[q] = dn_fin<GW, ST>(bad[q]);
-        hi0[q] = dn_next_up(vmax[q]);
-    }
-    dn_median<CB, GW, ST, false>(e, zero, vmin, hi0, cnt, act, med);
-#pragma unroll
-    for (int q = 0; q < NC; ++q) {
-        const double d0 = fabs(vmin[q] - med[q]), d1 = fabs(vmax[q] - med[q]);
-        dhi[q] = dn_next_up(d0 > d1 ? d0 : d1);
-    }
-    dn_median<CB, GW, ST, true>(e, med, zero, dhi, cnt, act, mad);
-#pragma unroll
-    for (int q = 0; q < NC; ++q) sig[q] = bad[q] ? __builtin_nan("") : mad[q] / 0.6745;
-}
 
 // HardTH, SoftTH and SemiSoftTH (wx_thresh, wx_common.h) as ONE branch-free rule with wave-uniform parameters: out = v where the rule keeps the
 // coefficient (Hard: not |v| <= t; SemiSoft: |v| > 2 t; Soft: never), else sign(v) max(A |v| - B, 0) with (A, B) = (0, 1) Hard, (1, t) Soft,
