@@ -19,8 +19,11 @@ int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const 
     if (n != (4096 >> SH) || L < 1 || L + SH > 12 || filt.F < 2 || batch < per || batch > 0x7fffffff) return 0;
     if ((batch & (per - 1)) && x == y) return 0;             // the tail wavefront re-does signals: out of place only
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
-    const int ns = wx_lat_stages(filt.F);
-    if (ns != 1 && ns != 2 && ns != 4 && ns != 6 && ns != 8) return 0;       // filters of up to 16 taps
+    // built for 2, 4 and 8 rotation stages: a shorter filter runs on the next of them bit-identically (wx_lattice_factor leaves the missing stages at
+    // p = kappa = 0: identities) -- Haar on 2, db3 on 4, db5 ... db7 on 8; filters of up to 16 taps
+    const int ns0 = wx_lat_stages(filt.F);
+    const int ns = ns0 <= 2 ? 2 : (ns0 <= 4 ? 4 : (ns0 <= 8 ? 8 : 0));
+    if (!ns) return 0;
     WxLatW cw2[2];
     memset(cw2, 0, sizeof cw2);
     WxLatW &cwf = cw2[0], &cwi = cw2[1];
@@ -62,7 +65,7 @@ int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const 
 #ifdef WX_DN_DEV
         WX_DN_GO(WX_DN_DEV)
 #else
-        WX_DN_GO(1) WX_DN_GO(2) WX_DN_GO(4) WX_DN_GO(6) WX_DN_GO(8)
+        WX_DN_GO(2) WX_DN_GO(4) WX_DN_GO(8)
 #endif
 #undef WX_DN_GO
     default: return 0;
