@@ -73,6 +73,93 @@ __global__ __launch_bounds__(256) void k_bb_costs1d_short(const T *__restrict__ 
     }
 }
 
+// short signals, round 6: ONE WAVEFRONT per signal (four per workgroup) reads the signal's table row by row -- norm of the root, then the costs of
+// every node: a level's row is NCH chunks of 64 coefficients, a node of cnt >= 64 coefficients is whole chunks (summed in the lane, then over the
+// wavefront), shorter nodes are groups of cnt lanes (butterfly over cnt lanes).  No norm kernel, no per-element index division, the next row's
+// loads fly under this row's logarithms.  (k_bb_norms + k_bb_costs1d_short: 0.94 ms per GiB table of 64-sample signals in five launches each;
+// this kernel: profiles/r06_floor_misc.txt.)
+template <typename T> __device__ __forceinline__ double bb_wave_sum(double v, int width)
+{
+    for (int w = width >> 1; w > 0; w >>= 1) v += __shfl_xor(v, w, 64);
+    return v;
+}
+// ALL (64 ... 256 samples): every row of the table is loaded before the first logarithm (7 ... 36 values per lane) -- with one row in flight per
+// wavefront the 64-sample kernel was bound by its seven dependent load latencies (0.69 ms per GiB table)
+template <typename T, int NCH, bool ALL>
+__global__ __launch_bounds__(256) void k_bb_costs1d_wave(const T *__restrict__ X, int k, int cost_kind, int64_t ncost, int64_t batch,
+                                                         T *__restrict__ costs)
+{
+    constexpr int n = 64 * NCH;
+    constexpr int KM = NCH == 1 ? 7 : (NCH == 2 ? 8 : (NCH == 4 ? 9 : 10));      // log2(n) + 1 rows at most
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t sig = (int64_t)blockIdx.x * 4 + wave;
+    if (sig >= batch) return;
+    const T *x = X + sig * (int64_t)k * n;
+    T *out = costs + sig * ncost;
+    T rows[ALL ? KM : 2][NCH];
+    if constexpr (ALL) {
+#pragma unroll
+        for (int d = 0; d < KM; ++d)
+            if (d < k) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) rows[d][c] = x[(int64_t)d * n + 64 * c + lane];
+            }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) rows[0][c] = x[64 * c + lane];
+    }
+    double a2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { const double d = (double)rows[0][c]; a2 = fma(d, d, a2); }
+    const T nr = (T)sqrt(bb_wave_sum<T>(a2, 64));
+    if (nr == (T)0) {
+        for (int64_t i = lane; i < ncost; i += 64) out[i] = (T)0.0;
+        return;
+    }
+    const WxNorm<T> nrw(nr);
+    auto level = [&](int depth, const T (&cur)[NCH]) {
+        const int cnt = n >> depth;
+        T *o = out + (((int64_t)1 << depth) - 1);
+        double t[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) t[c] = bb_term<T>(cur[c], nrw, cost_kind);
+        if (cnt >= 64) {
+            const int per = cnt >> 6;                              // chunks per node
+#pragma unroll
+            for (int c0 = 0; c0 < NCH; ++c0) {
+                if (c0 % per) continue;
+                double sacc = 0.0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (c >= c0 && c < c0 + per) sacc += t[c];
+                const double tot = bb_wave_sum<T>(sacc, 64);
+                if (lane == 0) o[c0 / per] = (T)tot;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const double tot = bb_wave_sum<T>(t[c], cnt);
+                if ((lane & (cnt - 1)) == 0) o[(64 * c + lane) / cnt] = (T)tot;
+            }
+        }
+    };
+    if constexpr (ALL) {
+#pragma unroll
+        for (int d = 0; d < KM; ++d)
+            if (d < k) level(d, rows[d]);
+    } else {
+        for (int depth = 0; depth < k; ++depth) {
+            if (depth + 1 < k) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) rows[1][c] = x[(int64_t)(depth + 1) * n + 64 * c + lane];
+            }
+            level(depth, rows[0]);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) rows[0][c] = rows[1][c];
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_bb_costs1d(const T *__restrict__ X, const T *__restrict__ nrm, int n, int k,
                                                     int redundant, int cost_kind, int64_t ncost,
@@ -286,6 +373,54 @@ __global__ __launch_bounds__(256) void k_bb_treeselect(T *__restrict__ costs, in
         for (int64_t i = threadIdx.x; i < ncost; i += blockDim.x) gc[i] = c[i];
 }
 
+// binary trees of at most 511 nodes (signals of up to 256 samples): ONE WAVEFRONT per signal, four per workgroup, the same two sweeps with
+// wave-level ordering instead of workgroup barriers (a 256-thread workgroup per 64-sample signal -- 127 costs, 12 barriers -- took 0.58 ms per
+// GiB table; this kernel: profiles/r06_floor_misc.txt)
+template <typename T>
+__global__ __launch_bounds__(256) void k_bb_treeselect_w(T *__restrict__ costs, int64_t ncost, int L, int64_t ntree, int type_max, int64_t batch,
+                                                         uint8_t *__restrict__ trees)
+{
+    extern __shared__ __attribute__((aligned(16))) char wx_smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t sig = (int64_t)blockIdx.x * 4 + wave;
+    if (sig >= batch) return;
+    const size_t per = ((size_t)ncost * (sizeof(T) + 1) + 15) & ~(size_t)15;
+    T *c = reinterpret_cast<T *>(wx_smem + wave * per);
+    uint8_t *flag = reinterpret_cast<uint8_t *>(c + ncost);                     // 1 = pruned, later the tree bit
+    T *gc = costs + sig * ncost;
+    auto wsync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int64_t i = lane; i < ncost; i += 64) c[i] = gc[i];
+    wsync();
+    for (int d = L - 1; d >= 0; --d) {
+        const int64_t lo = (int64_t)1 << d, hi = (int64_t)2 << d;
+        for (int64_t i = lo + lane; i < hi; i += 64) {
+            const T pc = c[i - 1];
+            const T cc = (T)(c[2 * i - 1] + c[2 * i]);
+            const bool better = type_max ? (cc > pc) : (cc < pc);
+            if (better) c[i - 1] = cc;
+            flag[i - 1] = better ? 0 : 1;
+        }
+        wsync();
+    }
+    for (int d = 0; d < L; ++d) {
+        const int64_t lo = (int64_t)1 << d, hi = (int64_t)2 << d;
+        for (int64_t i = lo + lane; i < hi; i += 64) {
+            bool keep = !flag[i - 1];
+            if (i > 1) keep = keep && flag[(i >> 1) - 1];
+            flag[i - 1] = keep ? 1 : 0;
+        }
+        wsync();
+    }
+    uint8_t *out = trees + sig * ntree;
+    const int64_t nfull = ((int64_t)1 << L) - 1;
+    for (int64_t i = lane; i < ntree; i += 64) out[i] = i < nfull ? flag[i] : 0;
+    for (int64_t i = lane; i < ncost; i += 64) gc[i] = c[i];
+}
+
 int need_device()
 {
     if (wx_device_count() < 1) return wx_set_error(WX_EHIP, "no HIP device visible: the MI355X kernels cannot run");
@@ -317,6 +452,18 @@ int api_bb_costs(const T *X, T *costs, int64_t m, int64_t n, int64_t k, int64_t 
     if (!dX || !dc) return io.finish(WX_EHIP);
     T *dn = (T *)scr.alloc(sizeof(T) * batch);
     if (!dn) return io.finish(WX_EHIP);
+    static const bool wave_off = wx_getenv("WX_BB_WAVE") && atoi(wx_getenv("WX_BB_WAVE")) == 0;
+    if (!two_d && !redundant && !wave_off && (m == 64 || m == 128 || m == 256 || m == 512) && batch <= 0x7ffffff0) {
+        const dim3 g((unsigned)((batch + 3) / 4));
+        switch (m) {
+        case 64: hipLaunchKernelGGL((k_bb_costs1d_wave<T, 1, true>), g, dim3(256), 0, st, dX, (int)k, cost_kind, ncost, batch, dc); break;
+        case 128: hipLaunchKernelGGL((k_bb_costs1d_wave<T, 2, true>), g, dim3(256), 0, st, dX, (int)k, cost_kind, ncost, batch, dc); break;
+        case 256: hipLaunchKernelGGL((k_bb_costs1d_wave<T, 4, true>), g, dim3(256), 0, st, dX, (int)k, cost_kind, ncost, batch, dc); break;
+        default: hipLaunchKernelGGL((k_bb_costs1d_wave<T, 8, false>), g, dim3(256), 0, st, dX, (int)k, cost_kind, ncost, batch, dc); break;
+        }
+        if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "BB cost kernels failed to launch"));
+        return io.finish(WX_OK);
+    }
     for (int64_t b0 = 0; b0 < batch; b0 += 65535) {                   // gridDim.y limit
         const int64_t bc = batch - b0 < 65535 ? batch - b0 : 65535;
         const T *xs = dX + b0 * sigsz * k;
@@ -387,6 +534,13 @@ int api_treeselect_batch(T *costs, int64_t ncost, int64_t m, int64_t n, int type
             const int64_t nb = batch - b0 < per ? batch - b0 : per;
             hipLaunchKernelGGL(kg, dim3((unsigned)nb), dim3(256), 0, st, dc + b0 * ncost, ncost, L, ntree, type_max, dt + b0 * ntree, gflags);
         }
+        if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "tree selection kernel failed to launch"));
+        return io.finish(WX_OK);
+    }
+    static const bool wave_off = wx_getenv("WX_BB_WAVE") && atoi(wx_getenv("WX_BB_WAVE")) == 0;
+    if (!two_d && !wave_off && ncost <= 511 && batch <= 0x7ffffff0) {      // up to 256 samples (512: 0.125 against 0.109 ms)
+        const size_t per = ((size_t)ncost * (sizeof(T) + 1) + 15) & ~(size_t)15;
+        hipLaunchKernelGGL(k_bb_treeselect_w<T>, dim3((unsigned)((batch + 3) / 4)), dim3(256), 4 * per, st, dc, ncost, L, ntree, type_max, batch, dt);
         if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "tree selection kernel failed to launch"));
         return io.finish(WX_OK);
     }
