@@ -5,7 +5,7 @@
 // waves per SIMD: 3 (0.85 / 0.95 / 0.87 ms per GiB of 1024 / 2048 / 4096-sample signals) against 2 (0.94 / 1.07 / 0.98): the kernel waits
 // on its exchanges and scalar loads 40 % of a wavefront's life, a third wavefront fills part of it although ~70 registers spill
 #ifndef WX_DN_WPE
-#define WX_DN_WPE (WX_DN_SH == 4 ? 2 : 3)
+#define WX_DN_WPE 3
 #endif
 #include <cstring>
 #include <vector>
