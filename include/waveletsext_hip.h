@@ -368,6 +368,14 @@ int wx_denoiseall_sig_f64(const double *x, double *xhat, int64_t n, int L, int64
 int wx_denoiseall_sig_f32(const float *x, float *xhat, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind,
                           double t, int undersmooth, float *sigma, void *stream);
 
+/* denoiseall(xw, :dwt, wt; L, dnt, estnoise = noisest, smooth) Denoising.jl:651-712: as wx_denoiseall_sig_* with the coefficients xw = dwtall(x, wt, L)
+ * as the input -- sigma_i = noisest(xw[:, i]), xhat[:, i] = idwt(threshold(xw[:, i], ...), wt, L).  One pass (coefficients in, signals out) under the
+ * conditions of wx_denoiseall_sig_*, else wx_noisest_* -> wx_iwpt1d_thresh_*.  xw is not modified. */
+int wx_denoiseall_dwt_f64(const double *xw, double *xhat, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind,
+                          double t, int undersmooth, double *sigma, void *stream);
+int wx_denoiseall_dwt_f32(const float *xw, float *xhat, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind,
+                          double t, int undersmooth, float *sigma, void *stream);
+
 /* iwpt / idwt with the thresholding step of denoise() applied while the coefficients are loaded (Denoising.jl:510-533:
  * threshold(x, dnt.th, sigma * dnt.t) followed by idwt / iwpt): one pass over the coefficient array instead of two.
  * Arguments as wx_iwpt1d_* plus those of wx_threshold_* (k = 1): rows [row_lo, n) of signal i are thresholded with

@@ -161,3 +161,36 @@ def test_device_arrays_and_errors(wx, oracle):
     out = np.empty_like(x, order="F")
     assert fn(ctypes.c_void_p(x.ctypes.data), ctypes.c_void_p(out.ctypes.data), 2048, 12, 130, ctypes.c_void_p(q.ctypes.data), len(q), 0, 1.0, 0, None, None) == _lib.WX_EASSERT
     assert fn(ctypes.c_void_p(x.ctypes.data), ctypes.c_void_p(out.ctypes.data), 2048, 3, 130, ctypes.c_void_p(q.ctypes.data), len(q), 7, 1.0, 0, None, None) == _lib.WX_EARG
+
+
+@pytest.mark.parametrize("n", [4096, 2048, 1024, 512, 256, 128, 64])
+@pytest.mark.parametrize("wname", ["haar", "db4", "db8"])
+def test_coefficients_in_signals_out(wx, oracle, n, wname):
+    """denoiseall(xw, :dwt, wt; L, dnt, smooth) behind wx_denoiseall_dwt_*: the coefficients of the pyramid in, the denoised signals out (one pass:
+    the front end of the tree-driven inverse, the noise estimate in the last register layout, threshold, synthesis), against oracle.denoise(:dwt)"""
+    rng = np.random.default_rng(7 * n + len(wname))
+    wt = wx.wavelet(getattr(wx.WT, wname))
+    B = 37 if n >= 1024 else 3 * (4096 // n) + 5
+    x = _signals(rng, n, B, "noisy")
+    Lmax = wx.maxtransformlevels(n)
+    for L in (Lmax, min(5, Lmax - 1), 1):
+        xw = wx.to_numpy(wx.dwtall(x, wt, L))
+        for smooth in ("regular", "undersmooth"):
+            for thname in ("hard", "soft", "semisoft", "stein"):
+                if (L, thname) not in ((Lmax, "hard"), (Lmax, "soft"), (min(5, Lmax - 1), "semisoft"), (1, "hard"), (Lmax, "stein")):
+                    continue
+                dnt = wx.VisuShrink(n, getattr(wx, TH[thname])())
+                Y = wx.to_numpy(wx.denoiseall(xw, "dwt", wt, L=L, dnt=dnt, smooth=smooth))
+                for i in sorted(set(range(0, B, max(B // 9, 1))) | {1, B - 1}):
+                    exp = oracle.denoise(np.asfortranarray(xw[:, i]), "dwt", wt.qmf, L=L, th=thname, t=dnt.t, smooth=smooth)
+                    assert relerr(Y[:, i], exp) <= 1e-10, (n, wname, L, smooth, thname, i)
+    # the noise estimates are those of noisest on the same coefficients, exactly (no transform in between)
+    from waveletsext_jl_amd import _lib
+    xw = np.asfortranarray(wx.to_numpy(wx.dwtall(x, wt, Lmax)))
+    q = np.ascontiguousarray(np.asarray(wt.qmf, dtype=np.float64))
+    y = np.empty_like(xw, order="F")
+    sig = np.empty(B)
+    _lib.check(_lib.lib().wx_denoiseall_dwt_f64(ctypes.c_void_p(xw.ctypes.data), ctypes.c_void_p(y.ctypes.data), n, Lmax, B, ctypes.c_void_p(q.ctypes.data),
+                                                  len(q), 0, 1.0, 0, ctypes.c_void_p(sig.ctypes.data), None))
+    for i in range(B):
+        assert sig[i] == oracle.noisest(xw[:, i], False), (n, wname, i)

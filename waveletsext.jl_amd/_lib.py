@@ -146,6 +146,8 @@ _PLAIN_SIGS = {
     "wx_dwt3d_f32": [_P, _P, _L, _L, _L, _I, _L, _P, _I, _P],
     "wx_idwt3d_f64": [_P, _P, _L, _L, _L, _I, _L, _P, _I, _P],
     "wx_idwt3d_f32": [_P, _P, _L, _L, _L, _I, _L, _P, _I, _P],
+    "wx_denoiseall_dwt_f64": [_P, _P, _L, _I, _L, _P, _I, _I, ctypes.c_double, _I, _P, _P],
+    "wx_denoiseall_dwt_f32": [_P, _P, _L, _I, _L, _P, _I, _I, ctypes.c_double, _I, _P, _P],
     "wx_denoiseall_sig_f64": [_P, _P, _L, _I, _L, _P, _I, _I, ctypes.c_double, _I, _P, _P],
     "wx_denoiseall_sig_f32": [_P, _P, _L, _I, _L, _P, _I, _I, ctypes.c_double, _I, _P, _P],
     "wx_iwpt1d_thresh_f64": [_P, _P, _L, _I, _P, _L, _L, _P, _I, _I, _P, _L, _L, ctypes.c_double, _P],

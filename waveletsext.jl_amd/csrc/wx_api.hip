@@ -327,7 +327,8 @@ static int api_iwpt1d_thresh(const T *x, T *y, int64_t n, int L, const uint8_t *
 // coefficients and the estimates in stream-ordered scratch.  sigma (optional, device or host): the noise estimates.
 extern "C" int wx_noisest_f64(const double *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo, int64_t col, double *sigma, void *stream);
 extern "C" int wx_noisest_f32(const float *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo, int64_t col, float *sigma, void *stream);
-template <typename T>
+// COEFS: x holds the coefficients dwtall(., wt, L) (inputtype :dwt) instead of the signals
+template <typename T, bool COEFS>
 static int api_denoiseall_sig(const T *x, T *y, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind, double tscale,
                               int undersmooth, T *sigma, void *stream)
 {
@@ -353,7 +354,7 @@ static int api_denoiseall_sig(const T *x, T *y, int64_t n, int L, int64_t batch,
         if (!off && !wx_force_generic() && !wx_skip_register_kernels() && th_kind != 3 && L >= 1 && wx_lattice_applicable_f64(filt)) {
             int r = 0;
             switch (n) {
-#define WX_DN_CASE(k) case 4096 >> k: r = wx_lattice_denoise##k##_f64(dx, dy, n, L, batch, filt, th_kind, tscale, undersmooth, dsig, st); break;
+#define WX_DN_CASE(k) case 4096 >> k: r = wx_lattice_denoise##k##_f64(dx, dy, n, L, batch, filt, th_kind, tscale, undersmooth, dsig, COEFS ? 1 : 0, st); break;
                 WX_DN_CASE(0) WX_DN_CASE(1) WX_DN_CASE(2) WX_DN_CASE(3) WX_DN_CASE(4) WX_DN_CASE(5) WX_DN_CASE(6)
 #undef WX_DN_CASE
             default: break;
@@ -362,7 +363,7 @@ static int api_denoiseall_sig(const T *x, T *y, int64_t n, int L, int64_t batch,
         }
     }
     // the separate steps: every one of them takes device pointers as they are
-    T *w = (T *)scr.alloc(sizeof(T) * n * batch);
+    T *w = COEFS ? const_cast<T *>(dx) : (T *)scr.alloc(sizeof(T) * n * batch);
     if (!w) return io.finish(WX_EHIP);
     if (!dsig) {
         dsig = (T *)scr.alloc(sizeof(T) * batch);
@@ -371,7 +372,7 @@ static int api_denoiseall_sig(const T *x, T *y, int64_t n, int L, int64_t batch,
     std::vector<uint8_t> tree((size_t)(n > 1 ? n - 1 : 1), 0);
     for (int d = 0; d < L; ++d) tree[((size_t)1 << d) - 1] = 1;
     const int64_t ntree = n - 1;
-    rc = api_wpt1d<T, false>(dx, w, n, 0, tree.data(), ntree, batch, qmf, F, stream);
+    rc = COEFS ? WX_OK : api_wpt1d<T, false>(dx, w, n, 0, tree.data(), ntree, batch, qmf, F, stream);
     if (rc == WX_OK) {
         if constexpr (sizeof(T) == 8) rc = wx_noisest_f64(w, n, 1, batch, n / 2, 0, dsig, stream);
         else rc = wx_noisest_f32(w, n, 1, batch, n / 2, 0, dsig, stream);
@@ -489,10 +490,16 @@ int wx_iwpt1d_thresh_f32(const float *xw, float *xhat, int64_t n, int L, const u
 
 int wx_denoiseall_sig_f64(const double *x, double *xhat, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind, double t,
                           int undersmooth, double *sigma, void *stream)
-{ return api_denoiseall_sig<double>(x, xhat, n, L, batch, qmf, F, th_kind, t, undersmooth, sigma, stream); }
+{ return api_denoiseall_sig<double, false>(x, xhat, n, L, batch, qmf, F, th_kind, t, undersmooth, sigma, stream); }
 int wx_denoiseall_sig_f32(const float *x, float *xhat, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind, double t,
                           int undersmooth, float *sigma, void *stream)
-{ return api_denoiseall_sig<float>(x, xhat, n, L, batch, qmf, F, th_kind, t, undersmooth, sigma, stream); }
+{ return api_denoiseall_sig<float, false>(x, xhat, n, L, batch, qmf, F, th_kind, t, undersmooth, sigma, stream); }
+int wx_denoiseall_dwt_f64(const double *xw, double *xhat, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind, double t,
+                          int undersmooth, double *sigma, void *stream)
+{ return api_denoiseall_sig<double, true>(xw, xhat, n, L, batch, qmf, F, th_kind, t, undersmooth, sigma, stream); }
+int wx_denoiseall_dwt_f32(const float *xw, float *xhat, int64_t n, int L, int64_t batch, const double *qmf, int F, int th_kind, double t,
+                          int undersmooth, float *sigma, void *stream)
+{ return api_denoiseall_sig<float, true>(xw, xhat, n, L, batch, qmf, F, th_kind, t, undersmooth, sigma, stream); }
 
 int wx_iwpd1d_f64(const double *xw, double *xhat, int64_t n, int k, int L, const uint8_t *tree, int64_t ntree,
                   int64_t batch, const double *qmf, int F, void *stream)

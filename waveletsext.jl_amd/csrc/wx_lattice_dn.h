@@ -225,4 +225,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #undef WX_DN_FWD
 #undef WX_DN_INV
 
+// denoiseall(xw, :dwt, wt; L, dnt, smooth): the coefficients of the pyramid come in (packet order), the denoised signals go out -- the front end
+// of k_lat_iwpt_treesc_f64 (KiB loads -> packet-order image in LDS -> table-addressed reads into the last layout), then the noise estimate in that
+// layout (the finest details of a signal are every register of the 32 >> SH lanes with lane bit SH set and the signal's low lane bits; 64 samples: the
+// odd registers of the signal's lane), the threshold, and the synthesis of k_lat_denoise_f64.  Replaces k_mad* + k_lat_iwpt_treesc_f64 with the
+// threshold on its loads + the tail kernel of the deep levels: 2 x the signals' bytes instead of 2.5 x and three launches.
+template <int NS, int WPE, int SH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lat_denoise_dwt_f64(
+    const double *__restrict__ xw, double *__restrict__ y, int last_sig, unsigned in_stride, unsigned out_stride, const WxLatW *__restrict__ cws,
+    const WxLatTreeSc *__restrict__ tab, WxDnArg dn)
+{
+    static_assert(SH >= 0 && SH <= 6, "4096 .. 64 samples");
+    __shared__ __attribute__((aligned(16))) double lds[2048];             // the packet-order image (two halves of 16 KiB in turn)
+    __shared__ double tsm[1 << SH];
+    const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
+    const int lane = threadIdx.x;
+    const int sig0 = min((int)blockIdx.x << SH, last_sig);
+    double *ys = y + (int64_t)sig0 * out_stride;
+    typedef const WxLatW __attribute__((address_space(4))) *dn_cst;
+    dn_cst cip = (dn_cst)(uintptr_t)(cws + 1);
+    asm volatile("" : "+s"(cip));
+    const WxLatW &cwi = *(const WxLatW *)cip;
+    const WxThreshArg none{nullptr, 0, 0, 0, 1.0};
+    constexpr int CB = SH == 6 ? 0 : -1, GW = SH == 6 ? 1 : (32 >> SH), ST = SH == 6 ? 1 : (2 << SH);
+    lat_treesc_inv_h<NS, SH, false, double, false>(
+        xw + (int64_t)sig0 * in_stride, sig0, lds0, lane, in_stride, 0u, (unsigned)(in_stride << SH), 1u << SH, cwi, tab, none,
+        [&](double (&regs)[64]) { lat_emit<(SH < 2 ? 0 : (SH < 6 ? 2 : 6)), 16 * SH>(regs, lds0, ys, lane, cwi, out_stride, 0, 0, 0xffffffffu); },
+        [&](double (&c)[64]) {
+            double sg[1];
+            const bool act = SH == 6 ? true : ((lane >> SH) & 1) != 0;
+            dn_noisest<CB, GW, ST>(c, sg, act);
+            const int s = lane & ((1 << SH) - 1);
+            if (SH == 6 || (lane >> SH) == 1) {
+                tsm[s] = sg[0] * dn.scale;
+                if (dn.sigma) dn.sigma[sig0 + s] = sg[0];
+            }
+            lat_sync();
+            dn_threshold(c, tsm[s], dn.kind, lane, dn.zmask, dn.zval);
+        });
+}
+
 }  // namespace

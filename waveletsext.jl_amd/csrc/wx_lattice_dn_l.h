@@ -11,13 +11,17 @@
 #include <vector>
 
 // 0 = not applicable (the caller runs the separate kernels), 1 = launched, < 0 = error
+// coefs != 0: x holds the coefficients of dwtall(., wt, L) (denoiseall(:dwt)), else the signals (denoiseall(:sig))
 int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const WxFilt &filt, int th_kind, double scale, int undersmooth,
-             double *sigma, hipStream_t st)
+             double *sigma, int coefs, hipStream_t st)
 {
     constexpr int SH = WX_DN_SH;
     constexpr int64_t per = (int64_t)1 << SH;
     if (n != (4096 >> SH) || L < 1 || L + SH > 12 || filt.F < 2 || batch < per || batch > 0x7fffffff) return 0;
     if ((batch & (per - 1)) && x == y) return 0;             // the tail wavefront re-does signals: out of place only
+    // coefficients in: 1.03 ms per GiB at 4096 samples against 0.83 for k_mad_count + the inverse with the threshold on its loads (the estimate in the
+    // last layout spans 32 lanes there); from 1024 samples down the one kernel wins (0.98 / 0.96 / 0.67 ms at 1024 / 256 / 64 against 1.13 / 1.46 / 1.39)
+    if (coefs && SH < 2) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31) return 0;
     // built for 2, 4 and 8 rotation stages: a shorter filter runs on the next of them bit-identically (wx_lattice_factor leaves the missing stages at
     // p = kappa = 0: identities) -- Haar on 2, db3 on 4, db5 ... db7 on 8; filters of up to 16 taps
@@ -60,7 +64,10 @@ int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const 
     switch (ns) {
 #define WX_DN_GO(NSS)                                                                                                          \
     case NSS:                                                                                                                  \
-        hipLaunchKernelGGL((k_lat_denoise_f64<NSS, WX_DN_WPE, SH>), dim3(nw), dim3(64), 0, st, x, y, lsig, (unsigned)n, (unsigned)n, cws, ctsc, dn); \
+        if (coefs)                                                                                                             \
+            hipLaunchKernelGGL((k_lat_denoise_dwt_f64<NSS, 2, SH>), dim3(nw), dim3(64), 0, st, x, y, lsig, (unsigned)n, (unsigned)n, cws, ctsc, dn); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((k_lat_denoise_f64<NSS, WX_DN_WPE, SH>), dim3(nw), dim3(64), 0, st, x, y, lsig, (unsigned)n, (unsigned)n, cws, ctsc, dn); \
         break;
 #ifdef WX_DN_DEV
         WX_DN_GO(WX_DN_DEV)

@@ -420,10 +420,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
 // the inverse transform up to the last register layout (A for 4096 / 2048 samples, B for 1024): `sink(regs)` takes it -- to memory
 // (lat_emit: k_lat_iwpt_treesc_f64) or on to the synthesis of an 8192-sample parent (wx_lattice_8k.h)
-template <int NS, int SH, bool THR, typename IO, bool FP32A, typename SINK>
-__device__ __forceinline__ void lat_treesc_inv(const IO *__restrict__ xs, int sig0, unsigned lds0, int lane, unsigned in_stride, unsigned col_stride,
-                                               unsigned boff_in, unsigned bsig, const WxLatW &cw, const WxLatTreeSc *__restrict__ tab,
-                                               const WxThreshArg &thr, SINK &&sink)
+// `hook(c)` sees the complete coefficient set in the last layout (lane = index bits 5 .. 0) before the first synthesis level: the noise estimate and
+// threshold of the one-pass denoise(:dwt) kernel (wx_lattice_dn.h); the plain inverse passes nothing
+template <int NS, int SH, bool THR, typename IO, bool FP32A, typename SINK, typename HOOK>
+__device__ __forceinline__ void lat_treesc_inv_h(const IO *__restrict__ xs, int sig0, unsigned lds0, int lane, unsigned in_stride, unsigned col_stride,
+                                                 unsigned boff_in, unsigned bsig, const WxLatW &cw, const WxLatTreeSc *__restrict__ tab,
+                                                 const WxThreshArg &thr, SINK &&sink, HOOK &&hook)
 {
     constexpr int NQ = 32 >> SH;                               // 128-element pieces of one signal
     typedef typename std::conditional<FP32A, lat_f2v, double>::type V;
@@ -527,6 +529,7 @@ __device__ __forceinline__ void lat_treesc_inv(const IO *__restrict__ xs, int si
     lat_wait16<32>(c);
     lat_wait16<48>(c);
     lat_sync();
+    hook(c);
     // synthesis: gl[1] = 1 / g, g2 = g^2 -- the a-slot of a split node enters as a / g, the d-slot as d g
     const double ga = cw.gl[1], gd = cw.c.g2 * cw.gl[1];
     const unsigned long long *mk = tab->mC;
@@ -561,6 +564,15 @@ __device__ __forceinline__ void lat_treesc_inv(const IO *__restrict__ xs, int si
             sink(a);
         }
     }
+}
+
+template <int NS, int SH, bool THR, typename IO, bool FP32A, typename SINK>
+__device__ __forceinline__ void lat_treesc_inv(const IO *__restrict__ xs, int sig0, unsigned lds0, int lane, unsigned in_stride, unsigned col_stride,
+                                               unsigned boff_in, unsigned bsig, const WxLatW &cw, const WxLatTreeSc *__restrict__ tab,
+                                               const WxThreshArg &thr, SINK &&sink)
+{
+    typedef typename std::conditional<FP32A, lat_f2v, double>::type V;
+    lat_treesc_inv_h<NS, SH, THR, IO, FP32A>(xs, sig0, lds0, lane, in_stride, col_stride, boff_in, bsig, cw, tab, thr, sink, [](V (&)[64]) {});
 }
 
 template <int NS, int WPE, int SH, bool THR, typename IO = double, bool FP32A = false>

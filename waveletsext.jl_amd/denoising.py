@@ -190,14 +190,15 @@ def threshold(x, th, t):
     return out.arr
 
 
-def _denoise_sig(xa, wt, L, dnt, smooth, batched):
-    """denoise / denoiseall(x, :sig, wt; L, dnt, smooth) with estnoise = noisest (Denoising.jl:483-599, 651-712): wx_denoiseall_sig_*"""
+def _denoise_sig(xa, wt, L, dnt, smooth, batched, entry="wx_denoiseall_sig"):
+    """denoise / denoiseall(x, :sig | :dwt, wt; L, dnt, smooth) with estnoise = noisest (Denoising.jl:483-599, 651-712): wx_denoiseall_sig_* /
+    wx_denoiseall_dwt_*"""
     from ._arrays import qmf_arg
     n = xa.shape[0]
     N = xa.shape[-1] if batched else 1
     q, qp, F = qmf_arg(wt)
     out = xa.new(xa.shape)
-    fn = getattr(_lib.lib(), "wx_denoiseall_sig" + xa.suffix)
+    fn = getattr(_lib.lib(), entry + xa.suffix)
     _lib.check(fn(xa.ptr, out.ptr, n, int(L), N, qp, F, dnt.th.kind, float(dnt.t), 1 if smooth == "undersmooth" else 0,
                   ctypes.c_void_p(0), xa.stream()))
     return out.arr
@@ -221,6 +222,9 @@ def _denoise(x, inputtype, wt, L, tree, dnt, estnoise, bestTH, smooth, batched):
             return _denoise_sig(xa, wt, L, dnt, smooth, batched)
         xa = Arg(dwtall(xa.arr, wt, L) if batched else dwt(xa.arr, wt, L))
         inputtype = "dwt"
+    elif (inputtype == "dwt" and wt is not None and bestTH is None and (estnoise is None or estnoise is noisest) and
+          xa.arr.ndim == (2 if batched else 1) and isdyadic(n)):
+        return _denoise_sig(xa, wt, L, dnt, smooth, batched, "wx_denoiseall_dwt")      # coefficients in, signals out: one pass where it applies
     if inputtype not in ("dwt", "wpt"):
         assert xa.arr.ndim > (2 if batched else 1)                     # @assert ndims(x) > 1
     N = xa.shape[-1] if batched else 1

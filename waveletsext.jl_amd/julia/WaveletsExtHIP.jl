@@ -664,10 +664,14 @@ function iwptall_thresholded(xw::HIP{T,2}, wt::OrthoFilter, tree::BitVector, th:
     return x̂
 end
 "idwtall(threshold(dwtall(x, wt, L), th, noisest.(columns) .* t), wt, L): denoiseall(x, :sig, wt; L, dnt, smooth) with estnoise = noisest"
-function denoiseall_sig(x::HIP{T,2}, wt::OrthoFilter, L::Integer, th::THType, t::Real, undersmooth::Bool) where T<:FT
+function denoiseall_sig(x::HIP{T,2}, wt::OrthoFilter, L::Integer, th::THType, t::Real, undersmooth::Bool; coefs::Bool = false) where T<:FT
     n, N = size(x)
     x̂ = newlike(x, T, (n, N)); q = qmfvec(wt)
-    check(wx_denoiseall_sig(T, raw(x), x̂, n, L, N, q, length(q), thkind(th), Float64(t), undersmooth ? 1 : 0, C_NULL, stream()))
+    if coefs       # x = dwtall(signals, wt, L): denoiseall(x, :dwt, wt; ...)
+        check(wx_denoiseall_dwt(T, raw(x), x̂, n, L, N, q, length(q), thkind(th), Float64(t), undersmooth ? 1 : 0, C_NULL, stream()))
+    else
+        check(wx_denoiseall_sig(T, raw(x), x̂, n, L, N, q, length(q), thkind(th), Float64(t), undersmooth ? 1 : 0, C_NULL, stream()))
+    end
     return x̂
 end
 # surethreshold / relerrorthreshold of one signal (Denoising.jl:146-166, 285-327) and of every signal of a batch (what
@@ -704,9 +708,9 @@ function WaveletsExt.Denoising.denoiseall(x::HIP{T,2}, inputtype::Symbol, wt::Or
     inputtype in (:sig, :dwt, :wpt) || throw(ArgumentError("device pipeline: inputtype :sig, :dwt or :wpt (compose the redundant types from noisestall / thresholdall!)"))
     estnoise isa Function && estnoise !== noisest && throw(ArgumentError("device pipeline: estnoise = noisest or precomputed values"))
     n = size(x, 1)
-    if inputtype === :sig && estnoise === noisest && bestTH === nothing
-        # the whole pipeline behind one entry point (one pass over the signals where the lattice kernel applies)
-        return denoiseall_sig(x, wt, L, dnt.th, dnt.t, smooth === :undersmooth)
+    if inputtype in (:sig, :dwt) && estnoise === noisest && bestTH === nothing
+        # the whole pipeline behind one entry point (one pass over the signals / coefficients where the lattice kernel applies)
+        return denoiseall_sig(x, wt, L, dnt.th, dnt.t, smooth === :undersmooth; coefs = inputtype === :dwt)
     end
     xw = inputtype === :sig ? HIP(dwtall(x, wt, L)) : x
     tr = inputtype === :wpt ? tree : maketree(n, L, :dwt)
