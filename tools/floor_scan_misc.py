@@ -1,4 +1,4 @@
-"""The callers' side of the path at several lengths: denoiseall (dwt -> per-signal MAD -> threshold -> idwt, Denoising.jl:651-712),
+"""The callers' side of the path at several lengths: denoiseall (dwt -> per-signal MAD -> threshold -> idwt, Denoising.jl:651-712; from the signals and from their coefficients),
 bestbasistreeall(wpdall(x), BB()) (BestBasis.jl:253-262) and getbasiscoefall along one tree (Utils.jl:199-225), Float64, db4, batches of about 1 GiB of
 signal (and packet tables of 1 GiB).  Times in ms and effective GB/s on signal-read-once + written-once bytes (denoise) or on the table's bytes."""
 import os
@@ -21,7 +21,10 @@ def scan(lengths=None):
         L = wx.maxtransformlevels(n)
         t = timed(torch, lambda: wx.denoiseall(x, "sig", wt))
         print("f64 n %6d denoiseall(sig, dwt)      %7.3f ms (%4.1f %% of peak on 2 x signal bytes)" % (n, t, 100 * 2.0 * n * B * 8 / (t * 1e-3) / HBM_PEAK), flush=True)
-        del x
+        xw = wx.dwtall(x, wt)
+        t = timed(torch, lambda: wx.denoiseall(xw, "dwt", wt))
+        print("f64 n %6d denoiseall(dwt)           %7.3f ms (%4.1f %% of peak on 2 x signal bytes)" % (n, t, 100 * 2.0 * n * B * 8 / (t * 1e-3) / HBM_PEAK), flush=True)
+        del x, xw
         torch.cuda.empty_cache()
         Bq = max((1 << 30) // (n * (L + 1) * 8), 1)          # tables of 1 GiB (0.25 GiB until round 6: launch-bound at every length)
         xq = wx.jl_empty((n, Bq), torch.float64, "cuda")

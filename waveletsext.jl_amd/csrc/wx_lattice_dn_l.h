@@ -62,6 +62,7 @@ int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const 
     dn.scale = scale;
     dn.sigma = sigma;
     switch (ns) {
+#if WX_DN_SH >= 2
 #define WX_DN_GO(NSS)                                                                                                          \
     case NSS:                                                                                                                  \
         if (coefs)                                                                                                             \
@@ -69,6 +70,12 @@ int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const 
         else                                                                                                                   \
             hipLaunchKernelGGL((k_lat_denoise_f64<NSS, WX_DN_WPE, SH>), dim3(nw), dim3(64), 0, st, x, y, lsig, (unsigned)n, (unsigned)n, cws, ctsc, dn); \
         break;
+#else               // 4096 / 2048 samples: the coefficients-in kernel is not built (declined above)
+#define WX_DN_GO(NSS)                                                                                                          \
+    case NSS:                                                                                                                  \
+        hipLaunchKernelGGL((k_lat_denoise_f64<NSS, WX_DN_WPE, SH>), dim3(nw), dim3(64), 0, st, x, y, lsig, (unsigned)n, (unsigned)n, cws, ctsc, dn); \
+        break;
+#endif
 #ifdef WX_DN_DEV
         WX_DN_GO(WX_DN_DEV)
 #else
