@@ -133,7 +133,7 @@ WORKLOADS = {
                 desc="SURVEY 8(f) row 2: LDB time-frequency energy maps of 4 classes over wpdall(x) 16384x4096 f64 db8 "
                      "L=12; timed leg = energy_map over the resident 6.5 GiB table (wpdall is the other leg)"),
     "denoise": dict(kind="denoise", n=4096, batch=65536, wavelet="db4", L=12, dtype="f64",
-                    kernel="k_lat_denoise_f64<4, 3, 0>", inv_kernel="k_mad<double>",
+                    kernel="k_lat_denoise_f64<4, 3, 0>", inv_kernel="k_lat_iwpt_treesc_f64<4, 2, 0, true",
                     fwd_kernels=[("k_lat_denoise_f64<4, 3, 0>", 1)],
                     desc="SURVEY 8(f) row 1: denoiseall(x, :sig, wt) = dwtall -> noisest per signal -> threshold -> idwtall of 65536x4096 f64 db4 "
                          "L=12 (VisuShrink, HardTH); first leg = the one-pass kernel behind wx_denoiseall_sig_* (signal in, denoised signal out), "

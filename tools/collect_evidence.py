@@ -26,7 +26,7 @@ def main(tag, prefix):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}      # workloads not in this run keep their entries
     for w in ("cfg2", "wpt_db8", "target", "target_n2048", "target_n1024", "target_haar", "tree_random", "tree_pyramid", "cfg3", "cfg3_sdwt", "swpt_db4",
-              "cfg4", "cfg4_256", "cfg4_1024", "cfg5", "bb", "ldb", "siwt", "dwt_long", "target_f32"):
+              "cfg4", "cfg4_256", "cfg4_1024", "cfg5", "bb", "ldb", "siwt", "dwt_long", "target_f32", "denoise"):
         src = os.path.join(ROOT, "gpurun_out", "prof_" + tag, w)
         if os.path.isdir(src):
             dst = os.path.join(ROOT, "profiles", "%s_%s" % (prefix, w))
