@@ -31,6 +31,10 @@
 #include "wx_lattice_tree_sc.h"
 #include "wx_select_count.h"
 
+#ifndef WX_DN_PARK2
+#define WX_DN_PARK2 5
+#endif
+
 struct WxDnArg {
     int kind;                 // Wavelets.Threshold rule, see wx_thresh
     unsigned zmask, zval;     // a coefficient with (index & zmask) == zval is left alone (undersmooth: the coarsest scaling coefficients)
@@ -92,6 +96,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     static_assert(SH >= 0 && SH <= 6, "4096 .. 64 samples");
     __shared__ __attribute__((aligned(16))) double lds[WX_LAT_LDS];       // the window of the exchanges (absorb / emit / layout changes)
     __shared__ double tsm[1 << SH];
+    __shared__ double lds2[64 * (WX_DN_PARK2 > 0 ? WX_DN_PARK2 : 1)];
     const unsigned lds0 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds;
     const int lane = threadIdx.x;
     const int sig0 = min((int)blockIdx.x << SH, last_sig);
@@ -127,7 +132,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #ifdef WX_DN_NOSEL
         for (int q = 0; q < dn_nc(CB); ++q) sg[q] = regs[2 + q];
 #else
+        // 4096 ... 512 samples at three wavefronts per SIMD: 17 of the 32 registers the estimate does not read (root bit clear) wait in the exchange
+        // window, which is idle here -- left to the register allocator they went to scratch and came back (21 doubles per lane: the kernel moved
+        // 1.33 x its algorithmic bytes through HBM, profiles/r06_denoise_onepass.md)
+        constexpr int NST = (!SELC && SH <= 3) ? 17 + WX_DN_PARK2 : 0;             // 17 fill the window, WX_DN_PARK2 more an array of their own
+        const unsigned park = lds0 + 8u * (unsigned)lane;
+        const unsigned park2 = (unsigned)(uintptr_t)(double __attribute__((address_space(3))) *)lds2 + 8u * (unsigned)lane;
+        lat_for<NST>([&](auto Jc) {
+            constexpr int j = Jc, r = ((j >> CB) << (CB + 1)) | (j & ((1 << CB) - 1));
+            if constexpr (j < 17) lds_wr<8 * 64 * j>(park, regs[r]);
+            else lds_wr<8 * 64 * (j - 17)>(park2, regs[r]);
+        });
+#pragma unroll
+        for (int j = 0; j < NST; ++j) asm volatile("" : "=v"(regs[((j >> CB) << (CB + 1)) | (j & ((1 << CB) - 1))]));      // dead until read back
         dn_noisest<CB, GW, ST>(regs, sg, act);
+        lat_for<NST>([&](auto Jc) {
+            constexpr int j = Jc, r = ((j >> CB) << (CB + 1)) | (j & ((1 << CB) - 1));
+            if constexpr (j < 17) regs[r] = lds_rd<8 * 64 * j, double>(park);
+            else regs[r] = lds_rd<8 * 64 * (j - 17), double>(park2);
+        });
+        if constexpr (NST > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < NST; ++j) asm volatile("" : "+v"(regs[((j >> CB) << (CB + 1)) | (j & ((1 << CB) - 1))]));  // no use above the wait
+        }
 #endif
 #pragma unroll
         for (int q = 0; q < dn_nc(CB); ++q) {
