@@ -250,3 +250,29 @@ def test_noisest_of_a_batch_of_short_signals(wx, oracle, n):
         assert wx.noisest(Xb, False) == oracle.noisest(Xb, False)
         exp = oracle.denoise(Xb, "dwt", wt.qmf, L=L, th="hard", t=dnt.t, smooth="regular")
         assert relerr(Y[:, b], exp) <= 1e-10, (n, b)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_noisest_counting_kernels_every_size(wx, oracle, dtype):
+    """the counting noise estimate (csrc/wx_select_count.h): one wavefront per signal for 256 ... 4096 details (k_mad_count), a workgroup of 4 / 8
+    wavefronts for 8192 ... 32768 (k_mad_count_wg) -- exact against the oracle's sort on ordinary, tied, sparse and wide-range values, NaN -> NaN"""
+    rng = np.random.default_rng(20260)
+    for n in (512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+        B = 5
+        for kind in ("normal", "ties", "sparse", "range"):
+            v = rng.standard_normal((n, B))
+            if kind == "ties":
+                v = np.round(v * 5) / 5
+            elif kind == "sparse":
+                v = np.where(rng.random((n, B)) < 0.03, v, 0.0)
+            elif kind == "range":
+                v = v * np.exp(rng.standard_normal((n, B)) * 12)
+            v = np.asfortranarray(v.astype(dtype))
+            from waveletsext_jl_amd import denoising as dn
+            sig = wx.to_numpy(dn._noisest(dn.Arg(v), True, "dwt", None))
+            for i in range(B):
+                assert sig[i] == oracle.noisest(v[:, i], False), (n, kind, i, dtype)
+        v = np.asfortranarray(rng.standard_normal((n, 3)).astype(dtype))
+        v[n - 5, 1] = np.nan
+        sig = wx.to_numpy(dn._noisest(dn.Arg(v), True, "dwt", None))
+        assert np.isnan(sig[1]) and sig[0] == oracle.noisest(v[:, 0], False) and sig[2] == oracle.noisest(v[:, 2], False)

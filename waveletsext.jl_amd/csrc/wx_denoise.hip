@@ -402,6 +402,23 @@ __global__ __launch_bounds__(256) void k_mad_count(const T *__restrict__ X, int6
     if (lane == 0) sigma[sig] = (T)sg[0];
 }
 
+// 8192 ... 32768 coefficients (signals of 16384 ... 65536 samples at the finest level): the same counting with a WORKGROUP of BW wavefronts per
+// signal -- every wavefront counts its NR registers per lane, the block sums go through a BW-entry LDS table (two barriers per pass); every
+// wavefront runs the same pivot arithmetic on the same sums.  Per GiB of signals in denoiseall(:dwt): 8192 / 16384 / 32768 coefficients took the
+// LDS histogram selection k_mad 0.73 / 1.23 ms and k_mad_g (values in global scratch) 1.69 ms; this kernel: profiles/r06_denoise_onepass.md section 5.
+template <typename T, int NR, int BW>
+__global__ __launch_bounds__(64 * BW) void k_mad_count_wg(const T *__restrict__ X, int64_t sig_stride, int64_t off, T *__restrict__ sigma)
+{
+    const int64_t sig = blockIdx.x;
+    const T *x = X + sig * sig_stride + off;
+    double e[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) e[u] = (double)x[threadIdx.x + 64 * BW * u];
+    double sg[1];
+    dn_noisest<-1, 64, 1, NR, T, BW>(e, sg);
+    if (threadIdx.x == 0) sigma[sig] = (T)sg[0];
+}
+
 // the same on detail ranges that do not fit a CU's LDS (signals of more than 32768 Float64 / 65536 Float32 samples' worth of details):
 // the copy that the second median overwrites lives in a global scratch row instead; the selection (wx_select_kth: counting passes
 // over the values) reads it through L2
@@ -466,6 +483,15 @@ int api_noisest(const T *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo,
     const T *dX = (const T *)io.in(X, sizeof(T) * n * k * batch);
     T *ds = (T *)io.out(sigma, sizeof(T) * batch);
     if (!dX || !ds) return io.finish(WX_EHIP);
+    static const int mad_count_wg = wx_getenv("WX_MAD_COUNT_WG") ? atoi(wx_getenv("WX_MAD_COUNT_WG")) : 1;
+    if (mad_count_wg && (cnt == 8192 || cnt == 16384 || cnt == 32768) && batch <= 0x7ffffff0) {
+        const dim3 g((unsigned)batch);
+        if (cnt == 8192) hipLaunchKernelGGL((k_mad_count_wg<T, 32, 4>), g, dim3(256), 0, st, dX, n * k, col * n + row_lo, ds);
+        else if (cnt == 16384) hipLaunchKernelGGL((k_mad_count_wg<T, 64, 4>), g, dim3(256), 0, st, dX, n * k, col * n + row_lo, ds);
+        else hipLaunchKernelGGL((k_mad_count_wg<T, 64, 8>), g, dim3(512), 0, st, dX, n * k, col * n + row_lo, ds);
+        if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "noisest kernel failed to launch"));
+        return io.finish(WX_OK);
+    }
     const size_t lds = (size_t)cnt * sizeof(T);
     if (lds > 128 * 1024) {
         // long signals (the reference has no limit: Denoising.jl:214-232): absolute deviations in a global scratch row per signal,

@@ -92,6 +92,38 @@ template <int GW, int ST = 1> __device__ __forceinline__ int dn_gsum(int v)
     }
     return v;
 }
+// BW > 1: the signal is BW wavefronts of one workgroup (every wavefront runs the same control flow on the same block-wide sums, so the pivots agree
+// and the barriers below are met by all): the per-wavefront result goes through a small LDS table
+template <int BW> __device__ __forceinline__ int dn_block_sum(int v)
+{
+    if constexpr (BW == 1) return v;
+    else {
+        __shared__ int tab[BW];
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) tab[w] = v;
+        __syncthreads();
+        int s = 0;
+#pragma unroll
+        for (int j = 0; j < BW; ++j) s += tab[j];
+        __syncthreads();
+        return s;
+    }
+}
+template <int BW, bool MAX> __device__ __forceinline__ double dn_block_ext(double v)
+{
+    if constexpr (BW == 1) return v;
+    else {
+        __shared__ double tab[BW];
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) tab[w] = v;
+        __syncthreads();
+        double s = tab[0];
+#pragma unroll
+        for (int j = 1; j < BW; ++j) s = MAX ? (tab[j] > s ? tab[j] : s) : (tab[j] < s ? tab[j] : s);
+        __syncthreads();
+        return s;
+    }
+}
 // c += #{lanes of the group with pred}: the whole wavefront -> ballot + population count (scalar), else a per-lane counter (dn_gsum later)
 template <int GW> __device__ __forceinline__ void dn_acc(int &c, bool pred)
 {
@@ -119,7 +151,7 @@ constexpr int dn_nc(int cb) { return cb < 0 ? 1 : 1 << cb; }
 
 // median (Statistics.median!: a/2 + b/2 of the order statistics k and k + 1, cnt even) of v = e (DEV = false) or |e - ctr| (DEV = true) per class
 // and lane group; [blo, bhi): #{v < blo} = 0, #{v < bhi} = cnt
-template <int CB, int GW, int ST, bool DEV, int NR = 64, typename T = double>
+template <int CB, int GW, int ST, bool DEV, int NR = 64, typename T = double, int BW = 1>
 __device__ __forceinline__ void dn_median(const double (&e)[NR], const double (&ctr)[dn_nc(CB)], const double (&blo)[dn_nc(CB)],
                                           const double (&bhi)[dn_nc(CB)], int cnt, bool act, double (&med)[dn_nc(CB)])
 {
@@ -153,7 +185,7 @@ __device__ __forceinline__ void dn_median(const double (&e)[NR], const double (&
             a[q] = w < a[q] ? w : a[q];
         });
 #pragma unroll
-        for (int q = 0; q < NC; ++q) a[q] = dn_gmin<GW, ST>(a[q]);
+        for (int q = 0; q < NC; ++q) a[q] = dn_block_ext<BW, false>(dn_gmin<GW, ST>(a[q]));
     };
     double lo[NC], hi[NC];
     int clo[NC], chi[NC], stall[NC];
@@ -212,7 +244,7 @@ __device__ __forceinline__ void dn_median(const double (&e)[NR], const double (&
         });
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
-            const int cq = dn_fin<GW, ST>(c[q]);
+            const int cq = dn_block_sum<BW>(dn_fin<GW, ST>(c[q]));
             if (!done[q]) {
                 stall[q] = (cq == clo[q] || cq == chi[q]) ? stall[q] + 1 : 0;
                 if (cq <= k) { lo[q] = p[q]; clo[q] = cq; }
@@ -229,8 +261,9 @@ __device__ __forceinline__ void dn_median(const double (&e)[NR], const double (&
     // two sweeps: in one, the compiler counts first and keeps the 64 deviations for the minimum (166 spilled registers in the 256-sample kernel)
     opaque();
     dn_each<CB, NR>([&](auto Rc, auto Qc) {
-        constexpr int q = Qc;
+        constexpr int r = Rc, q = Qc;
         dn_acc<GW>(le[q], val(Rc, Qc) <= a[q]);
+        if constexpr (GW == 64 && (r & 7) == 7) asm volatile("" : "+s"(le[q]));
     });
     opaque();
     dn_each<CB, NR>([&](auto Rc, auto Qc) {
@@ -241,7 +274,9 @@ __device__ __forceinline__ void dn_median(const double (&e)[NR], const double (&
     });
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
-        const double b = dn_fin<GW, ST>(le[q]) >= k + 2 ? a[q] : dn_gmin<GW, ST>(nx[q]);
+        const int leq = dn_block_sum<BW>(dn_fin<GW, ST>(le[q]));
+        const double nmin = dn_block_ext<BW, false>(dn_gmin<GW, ST>(nx[q]));
+        const double b = leq >= k + 2 ? a[q] : nmin;
         med[q] = (double)(T)((T)((T)a[q] / (T)2) + (T)((T)b / (T)2));
     }
 }
@@ -250,11 +285,11 @@ __device__ __forceinline__ void dn_median(const double (&e)[NR], const double (&
 // sig[q] for class q of this lane's group (GW lanes, ST apart)
 // NR registers per lane hold the values (64 in the lattice kernels); cnt_ = number of values per signal when it is not the full (registers x lanes)
 // block (k_mad_count: slots beyond it hold +Inf, which the counting never reaches below rank cnt_)
-template <int CB, int GW, int ST = 1, int NR = 64, typename T = double>
+template <int CB, int GW, int ST = 1, int NR = 64, typename T = double, int BW = 1>
 __device__ __forceinline__ void dn_noisest(const double (&e)[NR], double (&sig)[dn_nc(CB)], bool act = true, int cnt_ = 0)
 {
     constexpr int NC = dn_nc(CB);
-    const int cnt = cnt_ ? cnt_ : (CB < 0 ? NR : ((NR / 2) >> CB)) * GW;
+    const int cnt = cnt_ ? cnt_ : (CB < 0 ? NR : ((NR / 2) >> CB)) * GW * BW;
     double vmin[NC], vmax[NC], zero[NC], med[NC], dhi[NC], mad[NC];
     int bad[NC];
 #pragma unroll
@@ -265,20 +300,22 @@ __device__ __forceinline__ void dn_noisest(const double (&e)[NR], double (&sig)[
         vmin[q] = v < vmin[q] ? v : vmin[q];
         vmax[q] = v > vmax[q] ? v : vmax[q];
         dn_acc<GW>(bad[q], v != v);
+        if constexpr (GW == 64 && (r & 7) == 7) asm volatile("" : "+s"(bad[q]));
     });
     double hi0[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
-        vmin[q] = dn_gmin<GW, ST>(vmin[q]); vmax[q] = dn_gmax<GW, ST>(vmax[q]); bad[q] = dn_fin<GW, ST>(bad[q]);
+        vmin[q] = dn_block_ext<BW, false>(dn_gmin<GW, ST>(vmin[q])); vmax[q] = dn_block_ext<BW, true>(dn_gmax<GW, ST>(vmax[q]));
+        bad[q] = dn_block_sum<BW>(dn_fin<GW, ST>(bad[q]));
         hi0[q] = dn_next_up(vmax[q]);
     }
-    dn_median<CB, GW, ST, false, NR, T>(e, zero, vmin, hi0, cnt, act, med);
+    dn_median<CB, GW, ST, false, NR, T, BW>(e, zero, vmin, hi0, cnt, act, med);
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
         const double d0 = (double)(T)fabs((double)(T)((T)vmin[q] - (T)med[q])), d1 = (double)(T)fabs((double)(T)((T)vmax[q] - (T)med[q]));
         dhi[q] = dn_next_up(d0 > d1 ? d0 : d1);
     }
-    dn_median<CB, GW, ST, true, NR, T>(e, med, zero, dhi, cnt, act, mad);
+    dn_median<CB, GW, ST, true, NR, T, BW>(e, med, zero, dhi, cnt, act, mad);
 #pragma unroll
     for (int q = 0; q < NC; ++q) sig[q] = bad[q] ? __builtin_nan("") : (double)(T)((T)mad[q] / (T)0.6745);
 }
