@@ -276,3 +276,27 @@ def test_noisest_counting_kernels_every_size(wx, oracle, dtype):
         v[n - 5, 1] = np.nan
         sig = wx.to_numpy(dn._noisest(dn.Arg(v), True, "dwt", None))
         assert np.isnan(sig[1]) and sig[0] == oracle.noisest(v[:, 0], False) and sig[2] == oracle.noisest(v[:, 2], False)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_denoise_long_signals(wx, oracle, dtype):
+    """denoiseall(:sig / :dwt) of 8192 ... 65536-sample signals (the counting noise estimate with a workgroup per signal, the thresholded copy, the
+    tiled top passes of the long inverse over the lattice): every rule, both smoothings, shallow and full depth, against the oracle"""
+    rng = np.random.default_rng(424242)
+    wt = wx.wavelet(wx.WT.db4)
+    tol = 1e-10 if dtype == np.float64 else 3e-4
+    for n, B in ((8192, 5), (16384, 4), (32768, 3), (65536, 2)):
+        x = np.asfortranarray((rng.standard_normal((n, B)) + 3 * np.sin(np.arange(n) / 50.0)[:, None]).astype(dtype))
+        Lmax = wx.maxtransformlevels(n)
+        for L in (Lmax, 6, 3):
+            xw = np.asfortranarray(wx.to_numpy(wx.dwtall(x, wt, L)))
+            for smooth in ("regular", "undersmooth"):
+                for thname in (("hard", "soft", "semisoft", "stein") if L == Lmax else ("hard",)):
+                    dnt = wx.VisuShrink(n, getattr(wx, TH[thname])())
+                    Y = wx.to_numpy(wx.denoiseall(xw, "dwt", wt, L=L, dnt=dnt, smooth=smooth))
+                    for i in (0, B - 1):
+                        exp = oracle.denoise(np.asfortranarray(xw[:, i].astype(np.float64)), "dwt", wt.qmf, L=L, th=thname, t=dnt.t, smooth=smooth)
+                        assert relerr(Y[:, i], exp) <= tol, (n, L, smooth, thname, i, dtype)
+        Y = wx.to_numpy(wx.denoiseall(x, "sig", wt, dnt=wx.VisuShrink(n)))
+        exp = oracle.denoise(x[:, 0].astype(np.float64), "sig", wt.qmf, th="hard", t=wx.VisuShrink(n).t)
+        assert relerr(Y[:, 0], exp) <= tol
