@@ -1,4 +1,4 @@
-// wx_lattice_dn.h -- denoiseall(x, :sig, wt; L, dnt, estnoise = noisest, smooth) in ONE pass over the signals (Float64, 4096 ... 1024
+// wx_lattice_dn.h -- denoiseall(x, :sig, wt; L, dnt, estnoise = noisest, smooth) in ONE pass over the signals (Float64, 4096 ... 64
 // samples): pyramid analysis -> per-signal noise estimate -> threshold -> pyramid synthesis without the coefficients leaving the registers.
 //
 // Reference: Denoising.jl:651-712 (denoiseall: dwtall -> noisest per signal -> threshold! -> idwtall), Denoising.jl:483-599 (denoise),
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     auto noise = [&](double (&regs)[64]) {
         double sg[dn_nc(CB)];
         const bool act = SELC ? ((lane >> SH) & 1) != 0 : true;
-#ifdef WX_DN_NOSEL
+#ifdef WX_DN_NOSEL             // timing experiment of profiles/r06_denoise_onepass.md section 3: the estimate replaced by a register read (wrong results)
         for (int q = 0; q < dn_nc(CB); ++q) sg[q] = regs[2 + q];
 #else
         // 4096 ... 512 samples at three wavefronts per SIMD: 17 of the 32 registers the estimate does not read (root bit clear) wait in the exchange
@@ -207,12 +207,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if constexpr (SELC) noise(c);
     // threshold: layout C, lane = index bits 5 .. 0 -> the lane's signal is its low SH bits
     lat_sync();
-#ifndef WX_DN_NOTHR
     {
         const double t = tsm[lane & ((1 << SH) - 1)];
         dn_threshold(c, t, dn.kind, lane, dn.zmask, dn.zval);
     }
-#endif
     dn_cst cip = (dn_cst)(uintptr_t)(cws + 1);
     asm volatile("" : "+s"(cip));
     const WxLatW &cwi = *(const WxLatW *)cip;

@@ -1,9 +1,10 @@
-// wx_lattice_dn_l.h -- launcher of the one-pass denoise kernels (wx_lattice_dn.h); included by wx_lattice_dn{0,1,2}.hip with WX_DN_SH = 0, 1, 2
+// wx_lattice_dn_l.h -- launcher of the one-pass denoise kernels (wx_lattice_dn.h); included by wx_lattice_dn{0 .. 6}.hip with WX_DN_SH = 0 ... 6
 // (signals of 4096 >> SH samples) and WX_DN_FN = the launcher's name: one translation unit per length so that the kernels compile in parallel.
 // Reference: denoiseall(x, :sig, wt; L, dnt, estnoise = noisest, smooth) Denoising.jl:651-712.
 #include "wx_lattice_dn.h"
-// waves per SIMD: 3 (0.85 / 0.95 / 0.87 ms per GiB of 1024 / 2048 / 4096-sample signals) against 2 (0.94 / 1.07 / 0.98): the kernel waits
-// on its exchanges and scalar loads 40 % of a wavefront's life, a third wavefront fills part of it although ~70 registers spill
+// waves per SIMD: 3 (0.85 / 0.95 / 0.87 ms per GiB of 1024 / 2048 / 4096-sample signals when measured) against 2 (0.94 / 1.07 / 0.98): the kernel
+// waits on its exchanges and scalar loads 40 % of a wavefront's life and a third wavefront fills part of it; the registers the noise estimate
+// does not read wait in LDS meanwhile (wx_lattice_dn.h)
 #ifndef WX_DN_WPE
 #define WX_DN_WPE 3
 #endif
@@ -76,11 +77,7 @@ int WX_DN_FN(const double *x, double *y, int64_t n, int L, int64_t batch, const 
         hipLaunchKernelGGL((k_lat_denoise_f64<NSS, WX_DN_WPE, SH>), dim3(nw), dim3(64), 0, st, x, y, lsig, (unsigned)n, (unsigned)n, cws, ctsc, dn); \
         break;
 #endif
-#ifdef WX_DN_DEV
-        WX_DN_GO(WX_DN_DEV)
-#else
         WX_DN_GO(2) WX_DN_GO(4) WX_DN_GO(8)
-#endif
 #undef WX_DN_GO
     default: return 0;
     }
