@@ -222,6 +222,16 @@ def _node_costs(DM, sz, L, top_k):
     one_d = len(sz) == 1
     ncost = gettreelength(1 << L) if one_d else gettreelength(1 << L, 1 << L)
     cost = np.empty(ncost, dtype=DM.dtype)
+    if one_d:
+        # a depth at a time: its nodes are the rows of column d reshaped to (2^d, nodelength) -- the same top_k largest values in descending order and
+        # the same sequential sum per node as the loop below (which took 21 of the 24 ms of fit_transform on 4096-sample signals: one cumsum per node)
+        for d in range(L):                                        # gettreelength(2^L) = 2^L - 1 nodes: depths 0 .. L - 1
+            nth = nodelength(sz[0], d)
+            rows = np.ascontiguousarray(DM[:, d]).reshape(1 << d, nth)
+            if top_k < nth:
+                rows = np.sort(rows, axis=1)[:, ::-1][:, :top_k]
+            cost[(1 << d) - 1:(2 << d) - 1] = np.cumsum(rows, axis=1, dtype=DM.dtype)[:, -1] if rows.shape[1] else 0
+        return cost
     for i in range(1, ncost + 1):
         d = getdepth(i, "binary" if one_d else "quad")
         if one_d:
@@ -304,6 +314,7 @@ def fitdec_(f, Xw, y):
     """fitdec!(f, Xw, y) LDB.jl:186-251"""
     Xa = Arg(Xw)
     assert 3 <= Xa.arr.ndim <= 4
+    y = np.asarray(y)                    # once: a list of 300 k labels takes 7 ms to convert, and every step below looks at the labels
     classes, _ = _classes(y)
     nc = len(classes)
     f.sz = tuple(Xa.shape[:-2])
