@@ -254,11 +254,11 @@ def test_noisest_of_a_batch_of_short_signals(wx, oracle, n):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_noisest_counting_kernels_every_size(wx, oracle, dtype):
-    """the counting noise estimate (csrc/wx_select_count.h): one wavefront per signal for 256 ... 4096 details (k_mad_count), a workgroup of 4 / 8
-    wavefronts for 8192 ... 32768 (k_mad_count_wg) -- exact against the oracle's sort on ordinary, tied, sparse and wide-range values, NaN -> NaN"""
+    """the counting noise estimate (csrc/wx_select_count.h): four signals per wavefront for 128 ... 512 details (k_mad_count_rows), one wavefront per
+    signal for 1024 ... 4096 (k_mad_count), a workgroup of 4 / 8 wavefronts for 8192 ... 32768 (k_mad_count_wg) -- exact against the oracle's sort on ordinary, tied, sparse and wide-range values, NaN -> NaN"""
     rng = np.random.default_rng(20260)
-    for n in (512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
-        B = 5
+    for n in (256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+        B = 5 if n > 1024 else 23                   # four signals per wavefront up to 1024 samples: a ragged last wavefront
         for kind in ("normal", "ties", "sparse", "range"):
             v = rng.standard_normal((n, B))
             if kind == "ties":

@@ -402,6 +402,27 @@ __global__ __launch_bounds__(256) void k_mad_count(const T *__restrict__ X, int6
     if (lane == 0) sigma[sig] = (T)sg[0];
 }
 
+// 32 ... 1024 coefficients: FOUR signals per wavefront, each a row of 16 lanes with NR = cnt / 16 registers per lane (per-lane counters, four DPP
+// adds per pass) -- the pivot arithmetic of a pass, which outweighs the counting at these sizes, is shared by the four signals.  Per GiB of signals
+// in denoiseall(:dwt), Float64: 0.47 / 0.37 / 0.32 ms at 128 / 256 / 512 coefficients (one signal per wavefront: 0.63 / 0.43 at 256 / 512; sort: 0.67 at 128).
+template <typename T, int NR>
+__global__ __launch_bounds__(256) void k_mad_count_rows(const T *__restrict__ X, int64_t sig_stride, int64_t off, int64_t batch, T *__restrict__ sigma)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
+    const int64_t sig0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+    if (sig0 >= batch) return;
+    int64_t sig = sig0 + row;
+    const bool live = sig < batch;
+    if (!live) sig = batch - 1;                                      // the rows beyond the batch keep the wavefront's loops company
+    const T *x = X + sig * sig_stride + off;
+    double e[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) e[u] = (double)x[li + 16 * u];
+    double sg[1];
+    dn_noisest<-1, 16, 1, NR, T>(e, sg);
+    if (li == 0 && live) sigma[sig] = (T)sg[0];
+}
+
 // 8192 ... 32768 coefficients (signals of 16384 ... 65536 samples at the finest level): the same counting with a WORKGROUP of BW wavefronts per
 // signal -- every wavefront counts its NR registers per lane, the block sums go through a BW-entry LDS table (two barriers per pass); every
 // wavefront runs the same pivot arithmetic on the same sums.  Per GiB of signals in denoiseall(:dwt): 8192 / 16384 / 32768 coefficients took the
@@ -513,6 +534,26 @@ int api_noisest(const T *X, int64_t n, int64_t k, int64_t batch, int64_t row_lo,
     // (measured per GiB of signals, denoiseall: n = 256 / 512 / 1024 -- 128 / 256 / 512 coefficients -- 3.13 / 4.86 / 3.24 -> 1.83 / 1.88 / 1.83 ms;
     // 1024 / 2048 coefficients lose to the workgroup selection: 3.5 against 2.3, 4.3 against 1.8 ms -- the cross-lane stages grow with E)
     static const int mad_sort_max = wx_getenv("WX_MAD_SORT_MAX") ? atoi(wx_getenv("WX_MAD_SORT_MAX")) : 256;
+    // 128 ... 512 coefficients (knobs WX_MAD_ROWS_MIN / WX_MAD_ROWS_MAX; built for 32 ... 1024), a power of two: four signals per wavefront
+    // (k_mad_count_rows).  Per GiB of Float64 signals: 32 / 64 coefficients 1.03 / 0.67 ms against the sorting kernel's 0.55 / 0.69; 128 / 256 / 512
+    // 0.47 / 0.37 / 0.32 against 0.67 (sort) / 0.63 / 0.43 (one signal per wavefront); 1024 0.33 against 0.32
+    static const int mad_rows_max = wx_getenv("WX_MAD_ROWS_MAX") ? atoi(wx_getenv("WX_MAD_ROWS_MAX")) : 512;
+    static const int mad_rows_min = wx_getenv("WX_MAD_ROWS_MIN") ? atoi(wx_getenv("WX_MAD_ROWS_MIN")) : 128;
+    if (cnt >= 32 && cnt >= mad_rows_min && cnt <= 1024 && cnt <= mad_rows_max && (cnt & (cnt - 1)) == 0 && batch <= 0x7ffffff0) {
+        const dim3 g((unsigned)((batch + 15) / 16));
+#define WX_MR(NRR) hipLaunchKernelGGL((k_mad_count_rows<T, NRR>), g, dim3(256), 0, st, dX, n * k, col * n + row_lo, batch, ds)
+        switch (cnt) {
+        case 32: WX_MR(2); break;
+        case 64: WX_MR(4); break;
+        case 128: WX_MR(8); break;
+        case 256: WX_MR(16); break;
+        case 512: WX_MR(32); break;
+        default: WX_MR(64); break;
+        }
+#undef WX_MR
+        if (hipGetLastError() != hipSuccess) return io.finish(wx_set_error(WX_EHIP, "noisest kernel failed to launch"));
+        return io.finish(WX_OK);
+    }
     // 256 ... 4096 coefficients (a power of two): one wavefront per signal counts against pivots (k_mad_count); WX_MAD_COUNT_MIN (knob) moves the lower limit
     static const int mad_count_min = wx_getenv("WX_MAD_COUNT_MIN") ? atoi(wx_getenv("WX_MAD_COUNT_MIN")) : 256;
     if (cnt >= 256 && cnt >= mad_count_min && cnt <= 4096 && (cnt & (cnt - 1)) == 0 && batch <= 0x7ffffff0) {
