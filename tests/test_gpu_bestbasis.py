@@ -105,3 +105,28 @@ def test_bb_many_short_signals(wx, oracle):
         for b in range(0, B, 37):
             assert relerr(wx.tree_costs(Xw[:, :, b], m), oracle.tree_costs_bb(Xw[:, :, b], False, "shannon")) <= 1e-11
         assert (trees[:, ::37] == oracle.bestbasistreeall_bb(Xw[:, :, ::37], False, "shannon")).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("cost", ["shannon", "logenergy"])
+def test_bb_wave_per_signal_kernels(wx, oracle, dtype, cost):
+    """64 ... 512-sample signals: one wavefront per signal computes the norm and every node's cost (k_bb_costs1d_wave) and, up to 256 samples, selects
+    the tree (k_bb_treeselect_w) -- batches off the multiples of four, tables of fewer levels than the length admits, an all-zero signal, both costs,
+    both types; costs within tolerance of the oracle, trees equal"""
+    rng = np.random.default_rng(3100)
+    wt = _wt(wx, "db4")
+    for n in (64, 128, 256, 512):
+        Lmax = wx.maxtransformlevels(n)
+        for B, L in ((1, Lmax), (7, Lmax), (61, Lmax - 2), (130, 3)):
+            x = np.asfortranarray(np.cumsum(rng.standard_normal((n, B)), axis=0).astype(dtype))
+            if B > 3:
+                x[:, 3] = 0.0
+            Xw = wx.wpdall(x, wt, L)
+            m = wx.BB(cost=_cost(wx, cost))
+            trees = wx.bestbasistreeall(Xw, m)
+            exp = oracle.bestbasistreeall_bb(Xw, False, cost)
+            assert trees.shape == exp.shape == (n - 1, B)
+            assert (trees == exp).all(), (n, B, L, dtype, cost)
+            for i in sorted({0, B // 2, B - 1}):
+                c = wx.tree_costs(Xw[:, :, i], m)
+                assert relerr(c, oracle.tree_costs_bb(Xw[:, :, i], False, cost)) <= CTOL[np.dtype(dtype)], (n, B, L, i)
