@@ -66,7 +66,17 @@ def to_numpy(t):
     """device tensor (Julia shape) -> Fortran-ordered numpy array."""
     if not is_torch(t):
         return np.asfortranarray(t)
-    return np.asfortranarray(t.detach().cpu().numpy())
+    t = t.detach()
+    nbytes = t.numel() * t.element_size()
+    if t.is_cuda and (1 << 20) <= nbytes <= (256 << 20):
+        # through page-locked memory (torch's caching host allocator; empty_like keeps the strides, so column-major stays column-major): .cpu()
+        # copies into pageable memory at a fraction of the link's rate
+        import torch
+        host = torch.empty_like(t, device="cpu", pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return np.asfortranarray(host.numpy())
+    return np.asfortranarray(t.cpu().numpy())
 
 
 class Arg:
